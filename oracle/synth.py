@@ -1,0 +1,84 @@
+"""Deterministic synthetic weights / inputs shared by make_golden, the tests and the smoke check.
+TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+Weights are a pure function of (key, shape, seed) so that golden fixtures only need to store
+*outputs*: the generator script loads ``synth_state_dict`` into the reference model, the tests
+load the very same tensors into the oracle and into the HIP-backed modules.
+
+LayerScale gammas are drawn O(0.5) instead of the reference's 1e-5 initial value so that the
+attention / MLP branches actually contribute to the checked outputs.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+
+def _gen(key: str, seed: int) -> torch.Generator:
+    g = torch.Generator(device='cpu')
+    g.manual_seed((zlib.crc32(key.encode()) * 2654435761 + seed * 97 + 12345) % (2 ** 63 - 1))
+    return g
+
+
+def synth_tensor(key: str, shape, seed: int = 0) -> torch.Tensor:
+    shape = tuple(int(s) for s in shape)
+    g = _gen(key, seed)
+    if key.endswith('num_batches_tracked'):
+        return torch.zeros(shape, dtype=torch.int64)
+    if key.endswith('running_mean'):
+        return 0.2 * torch.randn(shape, generator=g)
+    if key.endswith('running_var'):
+        return 0.5 + torch.rand(shape, generator=g)
+    if key.endswith('.gamma'):                                   # LayerScale
+        return 0.25 + 0.5 * torch.rand(shape, generator=g)
+    last = key.rsplit('.', 2)
+    is_norm = any(t in key for t in ('.norm', '.bn.', 'norm1', 'norm2'))
+    if key.endswith('.weight') and len(shape) == 1:              # LN / BN scale
+        return 1.0 + 0.2 * torch.randn(shape, generator=g)
+    if key.endswith('.bias') and is_norm:
+        return 0.1 * torch.randn(shape, generator=g)
+    if key.endswith('.bias'):
+        if 'cls_preds' in key or 'obj_preds' in key:
+            # around the reference's prior-prob bias, raised so that detections exist
+            return -2.0 + 0.5 * torch.randn(shape, generator=g)
+        return 0.1 * torch.randn(shape, generator=g)
+    if key.endswith('.weight'):
+        fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+        return torch.randn(shape, generator=g) * (1.2 / max(fan_in, 1) ** 0.5)
+    if key.endswith('mask_token'):
+        return 0.02 * torch.randn(shape, generator=g)
+    del last
+    return torch.randn(shape, generator=g)
+
+
+def synth_state_dict(manifest, seed: int = 0):
+    """manifest: {key: shape}"""
+    return {k: synth_tensor(k, s, seed) for k, s in manifest.items()}
+
+
+def synth_events(T, B, C, H, W, seed=0, density=0.08, as_uint8=True):
+    """Stacked-histogram-like sparse small counts (SURVEY 8d synthetic input)."""
+    g = torch.Generator(device='cpu')
+    g.manual_seed(1000 + seed)
+    mask = torch.rand((T, B, C, H, W), generator=g) < density
+    vals = torch.randint(1, 10, (T, B, C, H, W), generator=g)
+    ev = (mask * vals)
+    return ev.to(torch.uint8) if as_uint8 else ev.to(torch.float32)
+
+
+def synth_labels(n_frames, hw, num_classes, seed=0, max_boxes=6, min_boxes=1):
+    """Per labelled frame 1..6 boxes, w~U(10,90), h~U(10,70), fully inside the frame.
+    Returns list of float32 [n,8] = (t,x,y,w,h,class_id,class_confidence,objectness), corner xy."""
+    H, W = hw
+    rng = np.random.RandomState(2000 + seed)
+    out = []
+    for _ in range(n_frames):
+        n = rng.randint(min_boxes, max_boxes + 1)
+        w = rng.uniform(10, min(90, W - 2), size=n)
+        h = rng.uniform(10, min(70, H - 2), size=n)
+        x = rng.uniform(0, W - 1 - w)
+        y = rng.uniform(0, H - 1 - h)
+        cls = rng.randint(0, num_classes, size=n)
+        lab = np.stack([np.full(n, 1.0), x, y, w, h, cls, np.ones(n), np.ones(n)], axis=1)
+        out.append(torch.from_numpy(lab.astype(np.float32)))
+    return out

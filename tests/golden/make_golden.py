@@ -1,0 +1,491 @@
+#!/usr/bin/env python
+"""Record golden vectors by importing and running the REFERENCE (/root/reference) on CPU.
+
+Runs only in the build container (the reference never travels to the GPU box); its outputs -- small
+.npz/.json fixtures next to this script -- are committed and are what pins ``oracle/`` to the
+reference (tests/test_oracle_golden.py).  Third-party packages the reference imports but that are
+absent here are served by the stand-ins in ``ref_stubs/`` (not reference source; see its README).
+
+Weights are ``oracle.synth.synth_state_dict(manifest, seed)`` -- a pure function of key/shape/seed --
+loaded into the reference model with ``load_state_dict``; inputs are seeded torch/numpy draws that
+the tests regenerate.  So fixtures store only the *expected outputs* (plus tiny inputs where that is
+simpler).
+
+Usage:  python tests/golden/make_golden.py            # rewrites tests/golden/*.npz, *.json
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, '..', '..'))
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(HERE, 'ref_stubs'))
+sys.path.insert(0, '/root/reference')
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+torch.cuda.get_device_name = lambda *a, **k: 'none'  # called at import time by the reference's coco_eval
+torch.set_num_threads(8)
+
+from omegaconf import DictConfig  # noqa: E402  (stand-in)
+from oracle.synth import synth_state_dict, synth_tensor, synth_events, synth_labels  # noqa: E402
+
+# ---- reference imports ---------------------------------------------------------------------------
+from models.layers.rnn import DWSConvLSTM2d  # noqa: E402
+from models.layers.maxvit import maxvit as ref_maxvit  # noqa: E402
+from models.detection.yolox_extension.models.detector import YoloXDetector  # noqa: E402
+from models.detection.yolox.utils.boxes import postprocess as ref_postprocess, bboxes_iou  # noqa: E402
+from modules.utils import ssod as ref_ssod  # noqa: E402
+from modules.utils.tta import tta_postprocess as ref_tta_postprocess  # noqa: E402
+from modules.utils.detection import RNNStates, BackboneFeatureSelector  # noqa: E402
+from data.genx_utils.labels import ObjectLabels  # noqa: E402
+from data.utils.representations import StackedHistogram  # noqa: E402
+from utils.padding import InputPadderFromShape  # noqa: E402
+
+
+def make_cfg(embed_dim, dim_head, fpn_depth, in_hw, part, num_classes=2, **head_kw):
+    head = dict(name='YoloX', compile=dict(enable=False, args=dict(mode='reduce-overhead')), depthwise=False,
+                act='silu', obj_focal_loss=False, bbox_loss_weighting='', ignore_bbox_thresh=None,
+                ignore_label=1024, ignore_bg_k=0, num_classes=num_classes)
+    head.update(head_kw)
+    return DictConfig(dict(
+        backbone=dict(name='MaxViTRNN', compile=dict(enable=False, args=dict(mode='reduce-overhead')),
+                      input_channels=20, enable_masking=False, partition_split_32=1, embed_dim=embed_dim,
+                      dim_multiplier=[1, 2, 4, 8], num_blocks=[1, 1, 1, 1], T_max_chrono_init=[4, 8, 16, 32],
+                      stem=dict(patch_size=4),
+                      stage=dict(downsample=dict(type='patch', overlap=True, norm_affine=True),
+                                 attention=dict(use_torch_mha=False, partition_size=part, dim_head=dim_head,
+                                                attention_bias=True, mlp_activation='gelu', mlp_gated=False,
+                                                mlp_bias=True, mlp_ratio=4, drop_mlp=0, drop_path=0,
+                                                ls_init_value=1e-5),
+                                 lstm=dict(dws_conv=False, dws_conv_only_hidden=True, dws_conv_kernel_size=3,
+                                           drop_cell_update=0)),
+                      in_res_hw=in_hw),
+        fpn=dict(name='PAFPN', compile=dict(enable=False, args=dict(mode='reduce-overhead')), depth=fpn_depth,
+                 in_stages=[2, 3, 4], depthwise=False, act='silu'),
+        head=head,
+        postprocess=dict(confidence_threshold=0.1, nms_threshold=0.45)))
+
+
+def manifest_of(module):
+    return {k: list(v.shape) for k, v in module.state_dict().items()}
+
+
+def load_synth(module, seed=0):
+    man = manifest_of(module)
+    sd = synth_state_dict(man, seed)
+    module.load_state_dict(sd, strict=True)
+    return man
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print('wrote', name, {k: v.shape for k, v in out.items()})
+
+
+# ====================================================================================================
+def g01_convlstm():
+    m = DWSConvLSTM2d(dim=32, dws_conv=False, dws_conv_only_hidden=True, dws_conv_kernel_size=3)
+    load_synth(m, 1)
+    x = rnd((2, 32, 8, 10), 11)
+    h0, c0 = rnd((2, 32, 8, 10), 12, 0.5), rnd((2, 32, 8, 10), 13, 0.5)
+    with torch.no_grad():
+        h_a, c_a = m(x, None)
+        h_b, c_b = m(x, (h0, c0))
+    save('g01_convlstm.npz', h_nostate=h_a, c_nostate=c_a, h_state=h_b, c_state=c_b)
+
+
+def g02_partition():
+    x = torch.arange(2 * 16 * 20, dtype=torch.float32).view(2, 16, 20, 1)
+    ws = (8, 10)
+    wp = ref_maxvit.window_partition(x, ws)
+    gp = ref_maxvit.grid_partition(x, ws)
+    wr = ref_maxvit.window_reverse(wp, ws, (16, 20))
+    gr = ref_maxvit.grid_reverse(gp, ws, (16, 20))
+    x2 = torch.arange(1 * 12 * 20, dtype=torch.float32).view(1, 12, 20, 1)   # gen4-like (6,10)
+    save('g02_partition.npz', window=wp.long(), grid=gp.long(), window_rev=wr.long(), grid_rev=gr.long(),
+         window_6x10=ref_maxvit.window_partition(x2, (6, 10)).long(),
+         grid_6x10=ref_maxvit.grid_partition(x2, (6, 10)).long())
+
+
+def g03_attention():
+    cfg = make_cfg(48, 24, 0.33, (256, 320), (8, 10)).backbone.stage.attention
+    x = rnd((2, 16, 20, 48), 31)
+    out = {}
+    for window, skip in [(True, False), (True, True), (False, False)]:
+        pt = ref_maxvit.PartitionType.WINDOW if window else ref_maxvit.PartitionType.GRID
+        m = ref_maxvit.PartitionAttentionCl(dim=48, partition_type=pt, attention_cfg=cfg, skip_first_norm=skip)
+        load_synth(m, 3)
+        with torch.no_grad():
+            out[f"blk_{'window' if window else 'grid'}_{'skip' if skip else 'norm'}"] = m(x)
+    sa = ref_maxvit.SelfAttentionCl(dim=48, dim_head=24, bias=True)
+    load_synth(sa, 4)
+    with torch.no_grad():
+        out['self_attn'] = sa(ref_maxvit.window_partition(x, (8, 10)))
+    save('g03_attention.npz', **out)
+
+
+MICRO = dict(embed_dim=16, dim_head=8, fpn_depth=0.33, in_hw=(64, 96), part=(2, 3))
+
+
+def g04_backbone():
+    det = YoloXDetector(make_cfg(**MICRO))
+    load_synth(det, 5)
+    det.eval()
+    ev = synth_events(3, 2, 20, 60, 90, seed=4, as_uint8=False)
+    padder = InputPadderFromShape(desired_hw=(64, 96))
+    ev = padder.pad_tensor_ev_repr(ev)
+    out, states = {}, None
+    with torch.no_grad():
+        for t in range(3):
+            feats, states = det.forward_backbone(ev[t], states)
+            for k, v in feats.items():
+                out[f't{t}_s{k}'] = v
+        for s, (h, c) in enumerate(states):
+            out[f'final_c{s + 1}'] = c
+    save('g04_backbone_micro.npz', **out)
+    # RVT-tiny at the real Gen1 geometry: one timestep, checksums + slices
+    det = YoloXDetector(make_cfg(32, 32, 0.33, (256, 320), (8, 10)))
+    load_synth(det, 6)
+    det.eval()
+    ev = InputPadderFromShape(desired_hw=(256, 320)).pad_tensor_ev_repr(
+        synth_events(2, 1, 20, 240, 304, seed=5, as_uint8=False))
+    out = {}
+    with torch.no_grad():
+        feats, states = det.forward_backbone(ev[0], None)
+        feats, states = det.forward_backbone(ev[1], states)
+    for k, v in feats.items():
+        out[f's{k}_mean'] = v.mean()
+        out[f's{k}_absmax'] = v.abs().max()
+        out[f's{k}_slice'] = v[0, :8, :4, :5]
+    save('g04_backbone_tiny256.npz', **out)
+
+
+def micro_labels(n_frames, seed, hw=(60, 90)):
+    labs = synth_labels(n_frames, hw, 2, seed=seed, max_boxes=4)
+    for l in labs:   # micro geometry: smaller boxes
+        l[:, 3] = l[:, 3].clamp(max=30)
+        l[:, 4] = l[:, 4].clamp(max=24)
+        l[:, 1] = torch.minimum(l[:, 1], hw[1] - 1 - l[:, 3])
+        l[:, 2] = torch.minimum(l[:, 2], hw[0] - 1 - l[:, 4])
+    return labs
+
+
+def g05_head():
+    det = YoloXDetector(make_cfg(**MICRO))
+    load_synth(det, 5)
+    feats = {2: rnd((3, 32, 8, 12), 51), 3: rnd((3, 64, 4, 6), 52), 4: rnd((3, 128, 2, 3), 53)}
+    det.eval()
+    with torch.no_grad():
+        pred_eval, _ = det.forward_detect(feats)
+    labs = micro_labels(3, seed=7)
+    labs[1] = labs[1][:1]                        # padded rows
+    labs[2][0, 1:5] = torch.tensor([0., 0., 12., 9.])   # border GT
+    targets = ObjectLabels.get_labels_as_batched_tensor([ObjectLabels(l, (60, 90)) for l in labs])
+    det.train()
+    for p in det.parameters():
+        p.grad = None
+    pred_tr, losses = det.forward_detect({k: v.clone().requires_grad_(True) for k, v in feats.items()},
+                                         targets=targets.clone())
+    losses['loss'].backward()
+    out = dict(pred_eval=pred_eval, pred_train=pred_tr, targets=targets,
+               **{f'loss_{k}': (v.detach() if torch.is_tensor(v) else v) for k, v in losses.items()})
+    sd = det.state_dict()
+    for k in ['fpn.lateral_conv0.bn.running_mean', 'fpn.lateral_conv0.bn.running_var',
+              'yolox_head.stems.0.bn.running_mean', 'yolox_head.cls_convs.2.1.bn.running_var']:
+        out['bn_' + k.replace('.', '_')] = sd[k]
+    gn = {n: p.grad.norm() for n, p in det.named_parameters() if p.grad is not None}
+    out['grad_keys'] = np.array(sorted(gn.keys()))
+    out['grad_norms'] = np.array([float(gn[k]) for k in sorted(gn.keys())], dtype=np.float64)
+    save('g05_head_micro.npz', **out)
+
+
+def g06_simota():
+    det = YoloXDetector(make_cfg(32, 32, 0.33, (256, 320), (8, 10)))
+    head = det.yolox_head
+    # anchors of the Gen1 geometry: 32x40, 16x20, 8x10
+    from oracle.head import make_grids
+    gx, gy, gs = make_grids([(32, 40), (16, 20), (8, 10)], (8, 16, 32))
+    A = gx.numel()
+    g = torch.Generator().manual_seed(61)
+    out = dict()
+    for case in range(3):
+        n = [5, 9, 3][case]
+        labs = synth_labels(1, (240, 304), 2, seed=60 + case, max_boxes=n, min_boxes=n)[0]
+        gt = torch.stack([labs[:, 1] + labs[:, 3] / 2, labs[:, 2] + labs[:, 4] / 2, labs[:, 3], labs[:, 4]], 1)
+        cls = labs[:, 5]
+        # predictions: anchors' own centres with noisy sizes, some pulled towards the GTs
+        bp = torch.stack([(gx + 0.5) * gs + torch.randn(A, generator=g) * 3,
+                          (gy + 0.5) * gs + torch.randn(A, generator=g) * 3,
+                          gs * (2 + 4 * torch.rand(A, generator=g)), gs * (2 + 3 * torch.rand(A, generator=g))], 1)
+        cls_l = torch.randn(A, 2, generator=g) * 2
+        obj_l = torch.randn(A, 1, generator=g) * 2
+        if case == 1:   # duplicate GT (ties) and identical predictions
+            gt[1] = gt[0]
+            cls[1] = cls[0]
+            bp[100:110] = bp[100]
+        fg, geom = head.get_geometry_constraint(gt, gs[None], gx[None], gy[None])
+        (mcls, fg_mask, pious, minds, nfg) = head.get_assignments(
+            n, gt, cls, bp, gs[None], gx[None], gy[None], cls_l, obj_l)
+        out.update({f'c{case}_gt': gt, f'c{case}_cls': cls, f'c{case}_bp': bp, f'c{case}_cls_l': cls_l,
+                    f'c{case}_obj_l': obj_l, f'c{case}_geom_fg': fg, f'c{case}_fg_mask': fg_mask,
+                    f'c{case}_matched': minds, f'c{case}_mcls': mcls, f'c{case}_pious': pious,
+                    f'c{case}_nfg': nfg})
+        # ignore variant: mark every third box as ignore
+        valid = torch.ones(n, dtype=torch.bool)
+        valid[::3] = False
+        (mcls, fg_mask, pious, minds, nfg, ign) = head.get_assignments_w_ignore(
+            int(valid.sum()), gt, cls, bp, gs[None], gx[None], gy[None], cls_l, obj_l, valid)
+        out.update({f'c{case}_valid': valid, f'c{case}_ig_fg_mask': fg_mask, f'c{case}_ig_matched': minds,
+                    f'c{case}_ig_mcls': mcls, f'c{case}_ig_pious': pious, f'c{case}_ig_nfg': nfg,
+                    f'c{case}_ig_ignore_mask': ign})
+    # full loss with ignore labels through get_losses (ignore_label 1024 rows + an all-ignore image)
+    labs = synth_labels(4, (240, 304), 2, seed=66, max_boxes=5, min_boxes=2)
+    tg = ObjectLabels.get_labels_as_batched_tensor([ObjectLabels(l, (240, 304)) for l in labs])
+    tg[0, 1, 0] = 1024
+    tg[2, :, 0] = torch.where(tg[2].sum(1) > 0, torch.full_like(tg[2, :, 0], 1024.), tg[2, :, 0])
+    tg[3] = 0
+    B = 4
+    outputs = torch.cat([
+        torch.stack([(gx + 0.5) * gs, (gy + 0.5) * gs, gs * 3, gs * 2.5], 1)[None].repeat(B, 1, 1)
+        + torch.randn(B, A, 4, generator=g), torch.randn(B, A, 3, generator=g)], -1)
+    xs = [gx[None, :1280], gx[None, 1280:1600], gx[None, 1600:]]
+    ys = [gy[None, :1280], gy[None, 1280:1600], gy[None, 1600:]]
+    ss = [gs[None, :1280], gs[None, 1280:1600], gs[None, 1600:]]
+    res = head.get_losses(xs, ys, ss, tg.clone(), outputs.clone(), [], torch.float32)
+    out.update(ign_targets=tg, ign_outputs=outputs,
+               ign_losses=np.array([float(r) for r in res], dtype=np.float64))
+    tg2 = tg.clone()
+    tg2[:, :, 0] = torch.where(tg2[:, :, 0] == 1024, torch.zeros_like(tg2[:, :, 0]), tg2[:, :, 0])
+    res2 = head.get_losses(xs, ys, ss, tg2.clone(), outputs.clone(), [], torch.float32)
+    out.update(noign_losses=np.array([float(r) for r in res2], dtype=np.float64))
+    # focal objectness
+    head2 = YoloXDetector(make_cfg(32, 32, 0.33, (256, 320), (8, 10), obj_focal_loss=True)).yolox_head
+    res3 = head2.get_losses(xs, ys, ss, tg2.clone(), outputs.clone(), [], torch.float32)
+    out.update(focal_losses=np.array([float(r) for r in res3], dtype=np.float64))
+    # ignore_bbox_thresh (soft-anchor config rnndet-soft.yaml:16)
+    head3 = YoloXDetector(make_cfg(32, 32, 0.33, (256, 320), (8, 10), ignore_bbox_thresh=[0.7, 0.35])).yolox_head
+    tg3 = tg2.clone()
+    tg3[:, :, 5] = torch.rand(tg3.shape[:2], generator=g) * (tg3.sum(2) > 0)
+    tg3[:, :, 6] = torch.rand(tg3.shape[:2], generator=g) * (tg3.sum(2) > 0)
+    res4 = head3.get_losses(xs, ys, ss, tg3.clone(), outputs.clone(), [], torch.float32)
+    out.update(thr_targets=tg3, thr_losses=np.array([float(r) for r in res4], dtype=np.float64))
+    save('g06_simota.npz', **out)
+
+
+def g07_postprocess():
+    g = torch.Generator().manual_seed(71)
+    out = {}
+
+    def run(name, pred, nc, conf, agnostic=False):
+        res = ref_postprocess(pred.clone(), nc, conf, 0.45, class_agnostic=agnostic, pad=torch.zeros((0, 7)))
+        out[name + '_pred'] = pred
+        out[name + '_n'] = np.array([len(r) for r in res])
+        out[name + '_det'] = torch.cat(res, 0)
+
+    A = 400
+    base = torch.rand(3, A, 2, generator=g) * torch.tensor([300., 230.])
+    pred = torch.cat([base, 10 + 60 * torch.rand(3, A, 2, generator=g), torch.rand(3, A, 1, generator=g),
+                      torch.rand(3, A, 2, generator=g)], -1)
+    for conf in (0.1, 0.01, 0.001):
+        run(f'rand_c{conf}', pred, 2, conf)
+    run('rand_agnostic', pred, 2, 0.1, agnostic=True)
+    # adversarial: clusters of identical / heavily overlapping boxes, tied scores, 3 classes
+    A = 240
+    centers = torch.tensor([[50., 50.], [52., 51.], [200., 120.]])
+    cid = torch.randint(0, 3, (2, A), generator=g)
+    cxy = centers[cid] + torch.round(torch.randn(2, A, 2, generator=g) * 2)
+    wh = torch.tensor([40., 30.]).expand(2, A, 2) + torch.round(torch.randn(2, A, 2, generator=g))
+    obj = torch.round(torch.rand(2, A, 1, generator=g) * 4) / 4       # many ties
+    cls = torch.round(torch.rand(2, A, 3, generator=g) * 4) / 4
+    pred = torch.cat([cxy, wh, obj, cls], -1)
+    pred[0, 10:20] = pred[0, 10]                                       # identical rows
+    run('adv_c0.1', pred, 3, 0.1)
+    run('adv_c0.001', pred, 3, 0.001)
+    # > 1000 surviving boxes -> torchvision's per-class branch on CPU
+    A = 1680
+    pred = torch.cat([torch.rand(1, A, 2, generator=g) * torch.tensor([300., 230.]),
+                      8 + 20 * torch.rand(1, A, 2, generator=g), 0.5 + 0.5 * torch.rand(1, A, 1, generator=g),
+                      0.5 + 0.5 * torch.rand(1, A, 2, generator=g)], -1)
+    run('many_c0.001', pred, 2, 0.001)
+    # nothing survives
+    run('none', pred * torch.tensor([1, 1, 1, 1, 0.01, 0.01, 0.01]), 2, 0.5)
+    save('g07_postprocess.npz', **out)
+
+
+def g08_pseudo():
+    g = torch.Generator().manual_seed(81)
+    out = {}
+    preds = []
+    for n in (12, 0, 30):
+        x1 = torch.rand(n, generator=g) * 330 - 20
+        y1 = torch.rand(n, generator=g) * 260 - 15
+        w = torch.rand(n, generator=g) * 120
+        h = torch.rand(n, generator=g) * 60
+        if n == 30:
+            w[:3] = torch.tensor([3., 280., 299.])
+        preds.append(torch.stack([x1, y1, x1 + w, y1 + h, torch.rand(n, generator=g), torch.rand(n, generator=g),
+                                  torch.randint(0, 2, (n,), generator=g).float()], 1))
+    fb = lambda b: ref_ssod.filter_pred_boxes(b, dataset_name='gen1', downsampled_by_2=False)  # noqa
+    labs = ref_ssod.pred2label([p.clone() for p in preds], obj_thresh=[0.6, 0.3], cls_thresh=[0.6, 0.3],
+                               filter_bbox_fn=fb, hw=(240, 304))
+    out['p2l_in'] = torch.cat(preds, 0)
+    out['p2l_lens_in'] = np.array([len(p) for p in preds])
+    out['p2l_lens'] = np.array([len(l) for l in labs])
+    out['p2l_out'] = torch.cat([l.object_labels for l in labs], 0)
+    fb4 = lambda b: ref_ssod.filter_pred_boxes(b, dataset_name='gen4', downsampled_by_2=True)  # noqa
+    preds4 = [p.clone() for p in preds]
+    for p in preds4:
+        p[:, :4] *= 2
+        p[:, 6] = torch.randint(0, 3, (len(p),), generator=g).float()
+    labs4 = ref_ssod.pred2label([p.clone() for p in preds4], obj_thresh=[0.3, 0.3, 0.6], cls_thresh=[0.3, 0.3, 0.6],
+                                filter_bbox_fn=fb4, hw=(360, 640))
+    out['p2l4_in'] = torch.cat(preds4, 0)
+    out['p2l4_lens'] = np.array([len(l) for l in labs4])
+    out['p2l4_out'] = torch.cat([l.object_labels for l in labs4], 0)
+    labs_f = ref_ssod.pred2label([p.clone() for p in preds], obj_thresh=0.5, cls_thresh=0.4, hw=(240, 304))
+    out['p2lf_lens'] = np.array([len(l) for l in labs_f])
+    out['p2lf_out'] = torch.cat([l.object_labels for l in labs_f], 0)
+    # TTA merge, tensor flavour: two views of a frame concatenated
+    views = [torch.cat([preds[0], preds[0] + torch.tensor([1., 1., 1., 1., 0, 0, 0])], 0), preds[2], preds[1]]
+    res = ref_tta_postprocess([v.clone() for v in views], conf_thre=0.01, nms_thre=0.45, pad=torch.zeros((0, 7)))
+    out['tta_in0'], out['tta_in1'] = views[0], views[1]
+    out['tta_n'] = np.array([len(r) for r in res])
+    out['tta_out'] = torch.cat(res, 0)
+    # label helpers
+    ol = ObjectLabels(out_lab := synth_labels(1, (240, 304), 2, seed=8)[0].clone(), (240, 304))
+    out['lab_in'] = out_lab.clone()
+    out['lab_yolox'] = ol.get_labels_as_tensors('yolox')
+    ol.flip_lr_()
+    out['lab_flip'] = ol.object_labels
+    out['subsample_21_1'] = np.array(ref_ssod.get_subsample_label_idx(21, use_every=1))
+    out['subsample_21_5'] = np.array(ref_ssod.get_subsample_label_idx(21, use_every=5))
+    out['subsample_10_r3'] = np.array(sorted(ref_ssod.get_subsample_label_idx(10, remove_every=3)))
+    save('g08_pseudo.npz', **out)
+
+
+def g10_voxel():
+    rng = np.random.RandomState(101)
+    out = {}
+    for name, n, fast, cutoff in [('a', 20000, True, None), ('b', 50000, False, 10), ('c', 3000, True, 3)]:
+        H, W, bins = 24, 30, 10
+        x = rng.randint(0, W, n)
+        y = rng.randint(0, H, n)
+        p = rng.randint(0, 2, n)
+        t = np.sort(rng.randint(1000, 51000, n))
+        if name == 'a':   # hot pixel overflowing uint8
+            x[:600], y[:600], p[:600] = 3, 4, 1
+            t[:600] = t[0]
+        rep = StackedHistogram(bins=bins, height=H, width=W, count_cutoff=cutoff, fastmode=fast).construct(
+            torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(p), torch.from_numpy(t))
+        out.update({f'{name}_x': x, f'{name}_y': y, f'{name}_p': p, f'{name}_t': t, f'{name}_rep': rep})
+    # t0 == t1
+    x, y, p, t = np.array([1, 2, 2]), np.array([0, 1, 1]), np.array([0, 1, 1]), np.array([5, 5, 5])
+    rep = StackedHistogram(bins=4, height=3, width=4).construct(*(torch.from_numpy(a) for a in (x, y, p, t)))
+    out.update(d_rep=rep)
+    save('g10_voxel.npz', **out)
+
+
+def g11_manifest():
+    man = {}
+    for name, ed, dh, fd in [('tiny', 32, 32, 0.33), ('small', 48, 24, 0.33), ('base', 64, 32, 0.67)]:
+        for ds, hw, part, nc in [('gen1', (256, 320), (8, 10), 2), ('gen4', (384, 640), (6, 10), 3)]:
+            det = YoloXDetector(make_cfg(ed, dh, fd, hw, part, nc))
+            man[f'{name}_{ds}'] = manifest_of(det)
+    man['micro'] = manifest_of(YoloXDetector(make_cfg(**MICRO)))
+    json.dump(man, open(os.path.join(HERE, 'g11_manifest.json'), 'w'))
+    print('wrote g11_manifest.json', {k: len(v) for k, v in man.items()})
+    # OneCycleLR values as configure_optimizers builds it (modules/detection.py:485-518)
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=2e-4, weight_decay=0)
+    sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=2e-4, div_factor=20, final_div_factor=10000 / 20,
+                                              total_steps=400000, pct_start=0.005, cycle_momentum=False,
+                                              anneal_strategy='linear')
+    want = {0, 1, 1000, 1999, 2000, 200000, 399998}
+    lrs = {}
+    for step in range(399999):
+        if step in want:
+            lrs[step] = opt.param_groups[0]['lr']
+        opt.step()
+        sch.step()
+    json.dump({str(k): v for k, v in lrs.items()}, open(os.path.join(HERE, 'g11_onecycle.json'), 'w'))
+    print('wrote g11_onecycle.json', lrs)
+
+
+def g12_trainstep():
+    """Two consecutive training steps of the micro detector driven exactly like
+    Module.training_step (modules/detection.py:150-298) with the reference's own RNNStates /
+    BackboneFeatureSelector / ObjectLabels, then clip-by-value + AdamW + OneCycleLR."""
+    torch.manual_seed(0)
+    det = YoloXDetector(make_cfg(**MICRO))
+    load_synth(det, 9)
+    det.train()
+    opt = torch.optim.AdamW(det.parameters(), lr=2e-4, weight_decay=0)
+    sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=2e-4, div_factor=20, final_div_factor=500,
+                                              total_steps=1000, pct_start=0.005, cycle_momentum=False,
+                                              anneal_strategy='linear')
+    padder = InputPadderFromShape(desired_hw=(64, 96))
+    rnn = RNNStates()
+    T, B = 5, 2
+    out = {}
+    for step in range(2):
+        ev = padder.pad_tensor_ev_repr(synth_events(T, B, 20, 60, 90, seed=20 + step, as_uint8=False))
+        lab_list = micro_labels(T * B, seed=30 + step)
+        labels = [[lab_list[t * B + b] if (t in (2, 4) or (t == 1 and b == 0)) else None for b in range(B)]
+                  for t in range(T)]
+        is_first = torch.tensor([True, True]) if step == 0 else torch.tensor([False, True])
+        rnn.reset(worker_id=0, indices_or_bool_tensor=is_first)
+        prev = rnn.get_states(worker_id=0)
+        sel = BackboneFeatureSelector()
+        obj_labels = []
+        for t in range(T):
+            feats, states = det.forward_backbone(x=ev[t], previous_states=prev)
+            prev = states
+            idx = [b for b in range(B) if labels[t][b] is not None]
+            if idx:
+                sel.add_backbone_features(backbone_features=feats, selected_indices=idx)
+                obj_labels.extend(ObjectLabels(labels[t][b], (60, 90)) for b in idx)
+        rnn.save_states_and_detach(worker_id=0, states=prev)
+        targets = ObjectLabels.get_labels_as_batched_tensor(obj_label_list=obj_labels, format_='yolox')
+        preds, losses = det.forward_detect(backbone_features=sel.get_batched_backbone_features(), targets=targets)
+        opt.zero_grad(set_to_none=True)
+        losses['loss'].backward()
+        torch.nn.utils.clip_grad_value_(det.parameters(), 1.0)
+        names = sorted(n for n, p in det.named_parameters() if p.grad is not None)
+        out[f's{step}_grad_keys'] = np.array(names)
+        gd = dict(det.named_parameters())
+        out[f's{step}_grad_norms'] = np.array([float(gd[n].grad.norm()) for n in names], dtype=np.float64)
+        out[f's{step}_grad_absmax'] = np.array([float(gd[n].grad.abs().max()) for n in names], dtype=np.float64)
+        out[f's{step}_losses'] = np.array([float(losses[k]) for k in
+                                          ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')],
+                                         dtype=np.float64)
+        out[f's{step}_pred_slice'] = preds[:, :40].detach()
+        opt.step()
+        sch.step()
+        out[f's{step}_lr_next'] = np.float64(opt.param_groups[0]['lr'])
+        out[f's{step}_param_norms'] = np.array([float(gd[n].detach().norm()) for n in names], dtype=np.float64)
+        out[f's{step}_state_c4'] = prev[3][1].detach().clone()  # clone: RNNStates.reset zeroes saved rows in place
+    save('g12_trainstep_micro.npz', **out)
+
+
+ALL = dict(g01=g01_convlstm, g02=g02_partition, g03=g03_attention, g04=g04_backbone, g05=g05_head,
+           g06=g06_simota, g07=g07_postprocess, g08=g08_pseudo, g10=g10_voxel, g11=g11_manifest,
+           g12=g12_trainstep)
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or list(ALL)
+    for w in which:
+        ALL[w]()

@@ -1,0 +1,278 @@
+"""Pin the oracle (oracle/) to the reference: every check here compares the CPU restatement with
+vectors recorded by running the reference itself (tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import backbone as ob
+from oracle import head as oh
+from oracle import postproc as op
+from oracle import train_step as ot
+from oracle.synth import synth_state_dict, synth_events, synth_labels
+
+RTOL, ATOL = 1e-5, 1e-6     # fp32 restatement vs reference
+
+
+def G(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    np.testing.assert_allclose(a, np.asarray(b), rtol=rtol, atol=atol)
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def sub_sd(man, seed):
+    return synth_state_dict(man, seed)
+
+
+def test_g01_convlstm(golden_dir):
+    g = G(golden_dir, 'g01_convlstm.npz')
+    sd = synth_state_dict({'conv1x1.weight': (128, 64, 1, 1), 'conv1x1.bias': (128,)}, 1)
+    sd = {'l.' + k: v for k, v in sd.items()}
+    x = rnd((2, 32, 8, 10), 11)
+    h0, c0 = rnd((2, 32, 8, 10), 12, 0.5), rnd((2, 32, 8, 10), 13, 0.5)
+    # synth keys are relative to the module in make_golden ('conv1x1.weight'): re-key
+    sd = {k.replace('l.', 'l.'): v for k, v in sd.items()}
+    sd2 = {'l.conv1x1.weight': synth_state_dict({'conv1x1.weight': (128, 64, 1, 1)}, 1)['conv1x1.weight'],
+           'l.conv1x1.bias': synth_state_dict({'conv1x1.bias': (128,)}, 1)['conv1x1.bias']}
+    h, c = ob.conv_lstm(x, None, sd2, 'l')
+    close(h, g['h_nostate']); close(c, g['c_nostate'])
+    h, c = ob.conv_lstm(x, (h0, c0), sd2, 'l')
+    close(h, g['h_state']); close(c, g['c_state'])
+
+
+def test_g02_partition(golden_dir):
+    g = G(golden_dir, 'g02_partition.npz')
+    x = torch.arange(2 * 16 * 20, dtype=torch.float32).view(2, 16, 20, 1)
+    wp, gp = ob.window_partition(x, (8, 10)), ob.grid_partition(x, (8, 10))
+    assert np.array_equal(wp.long().numpy(), g['window'])
+    assert np.array_equal(gp.long().numpy(), g['grid'])
+    assert np.array_equal(ob.window_reverse(wp, (8, 10), (16, 20)).long().numpy(), g['window_rev'])
+    assert np.array_equal(ob.grid_reverse(gp, (8, 10), (16, 20)).long().numpy(), g['grid_rev'])
+    x2 = torch.arange(12 * 20, dtype=torch.float32).view(1, 12, 20, 1)
+    assert np.array_equal(ob.window_partition(x2, (6, 10)).long().numpy(), g['window_6x10'])
+    assert np.array_equal(ob.grid_partition(x2, (6, 10)).long().numpy(), g['grid_6x10'])
+
+
+def _attn_manifest(C, with_norm1):
+    m = {}
+    if with_norm1:
+        m.update({'norm1.weight': (C,), 'norm1.bias': (C,)})
+    m.update({'self_attn.qkv.weight': (3 * C, C), 'self_attn.qkv.bias': (3 * C,),
+              'self_attn.proj.weight': (C, C), 'self_attn.proj.bias': (C,), 'ls1.gamma': (C,),
+              'norm2.weight': (C,), 'norm2.bias': (C,), 'mlp.net.0.0.weight': (4 * C, C),
+              'mlp.net.0.0.bias': (4 * C,), 'mlp.net.2.weight': (C, 4 * C), 'mlp.net.2.bias': (C,),
+              'ls2.gamma': (C,)})
+    return m
+
+
+def test_g03_attention(golden_dir):
+    g = G(golden_dir, 'g03_attention.npz')
+    x = rnd((2, 16, 20, 48), 31)
+    for window, skip, key in [(True, False, 'blk_window_norm'), (True, True, 'blk_window_skip'),
+                              (False, False, 'blk_grid_norm')]:
+        sd = {'b.' + k: v for k, v in synth_state_dict(_attn_manifest(48, not skip), 3).items()}
+        y = ob.partition_attention(x, sd, 'b', (8, 10), window, 24, skip_first_norm=skip)
+        close(y, g[key], rtol=2e-5, atol=2e-6)
+    sd = {'a.' + k: v for k, v in synth_state_dict(
+        {'qkv.weight': (144, 48), 'qkv.bias': (144,), 'proj.weight': (48, 48), 'proj.bias': (48,)}, 4).items()}
+    close(ob.self_attention(ob.window_partition(x, (8, 10)), sd, 'a', 24), g['self_attn'], rtol=2e-5, atol=2e-6)
+
+
+MICRO = ot.model_cfg(embed_dim=16, dim_head=8, fpn_depth=0.33, partition_size=(2, 3), in_res_hw=(64, 96))
+
+
+def test_g04_backbone(golden_dir, manifest):
+    g = G(golden_dir, 'g04_backbone_micro.npz')
+    sd = synth_state_dict(manifest['micro'], 5)
+    ev = ob.pad_ev_repr(synth_events(3, 2, 20, 60, 90, seed=4, as_uint8=False), (64, 96))
+    states = None
+    for t in range(3):
+        feats, states = ob.backbone_forward(ev[t], states, sd, MICRO)
+        for k, v in feats.items():
+            close(v, g[f't{t}_s{k}'], rtol=5e-5, atol=5e-6)
+    for s, (h, c) in enumerate(states):
+        close(c, g[f'final_c{s + 1}'], rtol=5e-5, atol=5e-6)
+    g = G(golden_dir, 'g04_backbone_tiny256.npz')
+    cfg = ot.model_cfg(32, 32, 0.33, (8, 10))
+    sd = synth_state_dict(manifest['tiny_gen1'], 6)
+    ev = ob.pad_ev_repr(synth_events(2, 1, 20, 240, 304, seed=5, as_uint8=False), (256, 320))
+    feats, states = ob.backbone_forward(ev[0], None, sd, cfg)
+    feats, states = ob.backbone_forward(ev[1], states, sd, cfg)
+    for k, v in feats.items():
+        close(v.mean(), g[f's{k}_mean'], rtol=1e-4, atol=1e-6)
+        close(v.abs().max(), g[f's{k}_absmax'], rtol=1e-4)
+        close(v[0, :8, :4, :5], g[f's{k}_slice'], rtol=1e-4, atol=1e-5)
+
+
+def micro_labels(n_frames, seed, hw=(60, 90)):
+    labs = synth_labels(n_frames, hw, 2, seed=seed, max_boxes=4)
+    for l in labs:
+        l[:, 3] = l[:, 3].clamp(max=30)
+        l[:, 4] = l[:, 4].clamp(max=24)
+        l[:, 1] = torch.minimum(l[:, 1], hw[1] - 1 - l[:, 3])
+        l[:, 2] = torch.minimum(l[:, 2], hw[0] - 1 - l[:, 4])
+    return labs
+
+
+def test_g05_head(golden_dir, manifest):
+    g = G(golden_dir, 'g05_head_micro.npz')
+    sd = synth_state_dict(manifest['micro'], 5)
+    feats = {2: rnd((3, 32, 8, 12), 51), 3: rnd((3, 64, 4, 6), 52), 4: rnd((3, 128, 2, 3), 53)}
+    pred, losses = oh.detect_forward(feats, sd, MICRO, training=False)
+    assert losses is None
+    close(pred, g['pred_eval'], rtol=5e-5, atol=5e-6)
+    labs = micro_labels(3, seed=7)
+    labs[1] = labs[1][:1]
+    labs[2][0, 1:5] = torch.tensor([0., 0., 12., 9.])
+    targets = op.batched_yolox_labels(labs)
+    close(targets, g['targets'])
+    sd = {k: v.clone() for k, v in sd.items()}
+    pkeys = [k for k, v in sd.items() if v.is_floating_point() and 'running_' not in k]
+    for k in pkeys:
+        sd[k].requires_grad_(True)
+    pred, losses = oh.detect_forward(feats, sd, MICRO, labels=targets.clone(), training=True)
+    close(pred, g['pred_train'], rtol=5e-5, atol=5e-6)
+    for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg'):
+        close(torch.as_tensor(losses[k]).float(), g['loss_' + k], rtol=2e-5)
+    for k in ['fpn.lateral_conv0.bn.running_mean', 'fpn.lateral_conv0.bn.running_var',
+              'yolox_head.stems.0.bn.running_mean', 'yolox_head.cls_convs.2.1.bn.running_var']:
+        close(sd[k], g['bn_' + k.replace('.', '_')], rtol=2e-5, atol=1e-6)
+    losses['loss'].backward()
+    gk = [str(k) for k in g['grad_keys']]
+    mine = np.array([float(sd[k].grad.norm()) for k in gk])
+    np.testing.assert_allclose(mine, g['grad_norms'], rtol=2e-4, atol=1e-7)
+
+
+def test_g06_simota(golden_dir):
+    g = G(golden_dir, 'g06_simota.npz')
+    gx, gy, gs = oh.make_grids([(32, 40), (16, 20), (8, 10)], (8, 16, 32))
+    for c in range(3):
+        T = lambda k: torch.from_numpy(g[f'c{c}_{k}'])  # noqa
+        gt, cls, bp, cl, ol = T('gt'), T('cls'), T('bp'), T('cls_l'), T('obj_l')
+        n = gt.shape[0]
+        inc = oh.is_in_centers(gt, gx, gy, gs)
+        assert np.array_equal((inc.sum(0) > 0).numpy(), g[f'c{c}_geom_fg'])
+        r = oh.get_assignments(gt, cls, torch.ones(n, dtype=torch.bool), bp, gx, gy, gs, cl, ol, 2)
+        assert np.array_equal(r['fg_mask'].numpy(), g[f'c{c}_fg_mask'])
+        assert np.array_equal(r['matched_gt_inds'].numpy(), g[f'c{c}_matched'])
+        assert np.array_equal(r['gt_matched_classes'].numpy(), g[f'c{c}_mcls'])
+        assert r['num_fg'] == int(g[f'c{c}_nfg'])
+        close(r['pred_ious'], g[f'c{c}_pious'], rtol=1e-6)
+        valid = T('valid')
+        r = oh.get_assignments(gt, cls, valid, bp, gx, gy, gs, cl, ol, 2)
+        assert np.array_equal(r['fg_mask'].numpy(), g[f'c{c}_ig_fg_mask'])
+        assert np.array_equal(r['ignore_mask'].numpy(), g[f'c{c}_ig_ignore_mask'])
+        assert np.array_equal(r['matched_gt_inds'].numpy(), g[f'c{c}_ig_matched'])
+        assert np.array_equal(r['gt_matched_classes'].numpy(), g[f'c{c}_ig_mcls'])
+        assert r['num_fg'] == int(g[f'c{c}_ig_nfg'])
+        # two-pass equivalence (reference's commented oracle, yolo_head.py:1112-1116)
+        af = oh.is_in_centers(gt, gx, gy, gs).sum(0) > 0
+        afv = oh.is_in_centers(gt[valid], gx, gy, gs).sum(0) > 0
+        assert torch.equal(r['ignore_mask'], af & ~afv)
+
+    def run(targets, outputs, **kw):
+        r = oh.get_losses(gx, gy, gs, targets.clone(), outputs.clone(), num_classes=2, **kw)
+        return np.array([float(r[k]) for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')])
+
+    tg, outp = torch.from_numpy(g['ign_targets']), torch.from_numpy(g['ign_outputs'])
+    np.testing.assert_allclose(run(tg, outp), g['ign_losses'], rtol=2e-6)
+    tg2 = tg.clone()
+    tg2[:, :, 0] = torch.where(tg2[:, :, 0] == 1024, torch.zeros_like(tg2[:, :, 0]), tg2[:, :, 0])
+    np.testing.assert_allclose(run(tg2, outp), g['noign_losses'], rtol=2e-6)
+    np.testing.assert_allclose(run(tg2, outp, obj_focal_loss=True), g['focal_losses'], rtol=2e-6)
+    np.testing.assert_allclose(run(torch.from_numpy(g['thr_targets']), outp, ignore_bbox_thresh=[0.7, 0.35]),
+                               g['thr_losses'], rtol=2e-6)
+
+
+@pytest.mark.parametrize('name,nc,conf,agn', [
+    ('rand_c0.1', 2, 0.1, False), ('rand_c0.01', 2, 0.01, False), ('rand_c0.001', 2, 0.001, False),
+    ('rand_agnostic', 2, 0.1, True), ('adv_c0.1', 3, 0.1, False), ('adv_c0.001', 3, 0.001, False),
+    ('many_c0.001', 2, 0.001, False), ('none', 2, 0.5, False)])
+def test_g07_postprocess(golden_dir, name, nc, conf, agn):
+    g = G(golden_dir, 'g07_postprocess.npz')
+    pred = torch.from_numpy(g[name + '_pred']).clone()
+    res = op.postprocess(pred, nc, conf, 0.45, class_agnostic=agn, pad=torch.zeros((0, 7)),
+                         device_semantics='cpu')
+    assert [len(r) for r in res] == list(g[name + '_n'])
+    det = torch.cat(res, 0).numpy()
+    assert np.array_equal(det, g[name + '_det'])          # bit-exact incl. order
+    # in-place xyxy side effect (boxes.py:41-46)
+    orig = torch.from_numpy(g[name + '_pred'])
+    assert torch.equal(pred[..., 0], orig[..., 0] - orig[..., 2] / 2)
+
+
+def test_g08_pseudo(golden_dir):
+    g = G(golden_dir, 'g08_pseudo.npz')
+    allp = torch.from_numpy(g['p2l_in'])
+    preds = list(torch.split(allp, list(g['p2l_lens_in'])))
+    labs = op.pred2label([p.clone() for p in preds], [0.6, 0.3], [0.6, 0.3], 'gen1', False)
+    assert [len(l) for l in labs] == list(g['p2l_lens'])
+    assert np.array_equal(torch.cat(labs).numpy(), g['p2l_out'])
+    preds4 = list(torch.split(torch.from_numpy(g['p2l4_in']), list(g['p2l_lens_in'])))
+    labs = op.pred2label(preds4, [0.3, 0.3, 0.6], [0.3, 0.3, 0.6], 'gen4', True)
+    assert [len(l) for l in labs] == list(g['p2l4_lens'])
+    assert np.array_equal(torch.cat(labs).numpy(), g['p2l4_out'])
+    labs = op.pred2label([p.clone() for p in preds], 0.5, 0.4, filter_boxes=False)
+    assert [len(l) for l in labs] == list(g['p2lf_lens'])
+    assert np.array_equal(torch.cat(labs).numpy(), g['p2lf_out'])
+    views = [torch.from_numpy(g['tta_in0']), torch.from_numpy(g['tta_in1']), torch.zeros((0, 7))]
+    res = op.tta_postprocess(views, 0.01, 0.45, pad=torch.zeros((0, 7)), device_semantics='cpu')
+    assert [len(r) for r in res] == list(g['tta_n'])
+    assert np.array_equal(torch.cat(res).numpy(), g['tta_out'])
+    lab = torch.from_numpy(g['lab_in'])
+    assert np.array_equal(op.labels_to_yolox(lab).numpy(), g['lab_yolox'])
+    assert np.array_equal(op.flip_lr_labels(lab, 304).numpy(), g['lab_flip'])
+    assert list(op.get_subsample_label_idx(21, use_every=1)) == list(g['subsample_21_1'])
+    assert list(op.get_subsample_label_idx(21, use_every=5)) == list(g['subsample_21_5'])
+    assert sorted(op.get_subsample_label_idx(10, remove_every=3)) == list(g['subsample_10_r3'])
+
+
+def test_g10_voxel(golden_dir):
+    g = G(golden_dir, 'g10_voxel.npz')
+    for name, fast, cutoff in [('a', True, None), ('b', False, 10), ('c', True, 3)]:
+        rep = op.stacked_histogram(g[f'{name}_x'], g[f'{name}_y'], g[f'{name}_p'], g[f'{name}_t'], 10, 24, 30,
+                                   count_cutoff=cutoff, fastmode=fast)
+        assert rep.dtype == np.uint8 and np.array_equal(rep, g[f'{name}_rep'])
+    rep = op.stacked_histogram(np.array([1, 2, 2]), np.array([0, 1, 1]), np.array([0, 1, 1]), np.array([5, 5, 5]), 4, 3, 4)
+    assert np.array_equal(rep, g['d_rep'])
+
+
+def test_g11_onecycle(golden_dir):
+    want = json.load(open(os.path.join(golden_dir, 'g11_onecycle.json')))
+    from oracle.schedule import one_cycle_lr
+    for k, v in want.items():
+        assert abs(one_cycle_lr(int(k), 2e-4, 400000, 0.005, 20, 10000) - v) <= 1e-12 + 1e-9 * v
+
+
+def test_g12_trainstep(golden_dir, manifest):
+    g = G(golden_dir, 'g12_trainstep_micro.npz')
+    sd = synth_state_dict(manifest['micro'], 9)
+    tr = ot.OracleTrainer(sd, MICRO, lr=2e-4, total_steps=1000, div_factor=20, final_div_factor=10000)
+    T, B = 5, 2
+    for step in range(2):
+        ev = synth_events(T, B, 20, 60, 90, seed=20 + step, as_uint8=True)
+        lab_list = micro_labels(T * B, seed=30 + step)
+        labels = [[lab_list[t * B + b] if (t in (2, 4) or (t == 1 and b == 0)) else None for b in range(B)]
+                  for t in range(T)]
+        is_first = torch.tensor([True, True]) if step == 0 else torch.tensor([False, True])
+        losses, grads = tr.step(ev, labels, is_first)
+        want = g[f's{step}_losses']
+        got = np.array([losses[k] for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')])
+        np.testing.assert_allclose(got, want, rtol=5e-5)
+        keys = [str(k) for k in g[f's{step}_grad_keys']]
+        np.testing.assert_allclose(np.array([float(grads[k].norm()) for k in keys]),
+                                   g[f's{step}_grad_norms'], rtol=2e-3, atol=1e-7)
+        np.testing.assert_allclose(np.array([float(tr.sd[k].detach().norm()) for k in keys]),
+                                   g[f's{step}_param_norms'], rtol=2e-4)  # Adam's first steps ~ lr*sign(g): noise-level grads flip
+        assert abs(tr.opt.param_groups[0]['lr'] - float(g[f's{step}_lr_next'])) < 1e-12
+        close(tr.states[3][1], g[f's{step}_state_c4'], rtol=1e-4, atol=1e-5)
