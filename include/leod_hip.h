@@ -1,0 +1,158 @@
+/* leod_hip.h -- C ABI of libleod_hip.so: the hand-written gfx950 (MI355X / CDNA4) kernels behind the
+ * LEOD hot path (RVT recurrent backbone fwd/bwd, YOLOX head + SimOTA + losses, pseudo-label NMS).
+ *
+ * The reference (Wuziyi616/LEOD) is 100 % Python and has no FFI; each entry point below replaces the
+ * ATen / torchvision call sequence of the cited reference lines (paths relative to the reference
+ * root).  The reference-side binding is the ctypes stub in leod_amd/_lib.py.
+ *
+ * Conventions
+ *   - plain C symbols, raw DEVICE pointers, explicit sizes; no torch types, no global state;
+ *   - every call only enqueues work on `stream` (hipStream_t passed as void*): it never allocates,
+ *     never synchronises and is re-entrant across streams; scratch is caller-provided;
+ *   - return 0 on success, <0 on error: -1 bad argument, -2 launch failure, -3 unsupported shape;
+ *   - activations are fp32 "rows": a row is one token/pixel of a channels-last (NHWC) map,
+ *     M = B*H*W rows, contiguous channels.  "+=" outputs accumulate (parameter gradients).
+ */
+#ifndef LEOD_HIP_H
+#define LEOD_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* leod_stream_t; /* hipStream_t */
+
+const char* leod_version(void);
+
+/* ---- backbone: MaxViT block pieces (models/layers/maxvit/maxvit.py) ------------------------------ */
+
+/* out[M,N] = LN(x)[M,K] W[N,K]^T + bias (LN skipped when ln_w == NULL); out_act (optional) = gelu_erf(out);
+ * stats_out (optional) [M,2] = (mean, rstd).  Replaces norm1->qkv (maxvit.py:267,347) and norm2->fc1->GELU (:110-118,269). */
+int leod_ln_linear_fwd(const float* x, long ldx, const float* ln_w, const float* ln_b, float eps, const float* W,
+                       const float* bias, float* out, float* out_act, float* stats_out, int M, int N, int K,
+                       leod_stream_t stream);
+
+/* t = a[M,K] W[N,K]^T + bias ; tout (optional) = t ; out = res + gamma * t.
+ * Replaces proj / fc2 followed by LayerScale and the residual add (maxvit.py:51-53,268-269,353). */
+int leod_linear_lsres_fwd(const float* a, const float* W, const float* bias, const float* gamma, const float* res,
+                          float* out, float* tout, int M, int N, int K, leod_stream_t stream);
+
+/* Partition attention core on the interleaved qkv rows [M,3C] of an NHWC map (head h owns columns
+ * [h*3d,(h+1)*3d) = q|k|v): out[M,C] = softmax(q k^T d^-1/2) v within each window (window=1) or grid
+ * (window=0) partition of ph x pw tokens; lse (optional) [M,heads].  Replaces window/grid_partition + SelfAttentionCl
+ * core + *_reverse (maxvit.py:252-265,273-304,347-352). */
+int leod_partition_attn_fwd(const float* qkv, float* out, float* lse, int B, int H, int W, int C, int heads, int ph,
+                            int pw, int window, leod_stream_t stream);
+/* dqkv[M,3C] from dout[M,C]; dsum [M,heads] scratch. */
+int leod_partition_attn_bwd(const float* qkv, const float* dout, const float* lse, float* dsum, float* dqkv, int B,
+                            int H, int W, int C, int heads, int ph, int pw, int window, leod_stream_t stream);
+
+/* Fused ConvLSTM cell, DWSConvLSTM2d.forward with dws_conv=False (models/layers/rnn.py:37-70):
+ * gates = [x|h_prev] W[4C,2C]^T + b, (f,i,o)=sigmoid, g=tanh, c=f*c_prev+i*g, h=o*tanh(c).
+ * h_prev/c_prev NULL = zero state; gates_out (optional) [M,4,C] post-activation gates. */
+int leod_convlstm_fwd(const float* x, const float* h_prev, const float* c_prev, const float* W, const float* bias,
+                      float* h_out, float* c_out, float* gates_out, int M, int C, leod_stream_t stream);
+/* dgates[M,4,C] (pre-activation), dc_prev (optional) from dh (optional), dc_next (optional). */
+int leod_convlstm_gates_bwd(const float* dh, const float* dc_next, const float* gates, const float* c_prev,
+                            const float* c_t, float* dgates, float* dc_prev, int M, int C, leod_stream_t stream);
+
+/* dx (=|+=) (dy[M,N]*kscale[N]) W[N,K] ; optional: multiply by gelu'(aux_u[M,K]); route columns >= nsplit to dx2;
+ * colsum[K] += column sums of the result.  Autograd of the Linear layers above. */
+int leod_linear_dgrad(const float* dy, long lddy, const float* kscale, const float* W, float* dx, long lddx, float* dx2,
+                      long lddx2, int nsplit, const float* aux_u, float* colsum, int accumulate, int M, int N, int K,
+                      leod_stream_t stream);
+/* dW[N,K] += dy^T X ; dbias[N] += colsum(dy) ; X = x, LN(x) (stats, ln_w, ln_b) or [x | x2] (K1 = cols of x). */
+int leod_linear_wgrad(const float* dy, long lddy, const float* x, long ldx, const float* stats, const float* ln_w,
+                      const float* ln_b, const float* x2, long ldx2, int K1, float* dW, float* dbias, int M, int N,
+                      int K, leod_stream_t stream);
+
+/* LayerNorm over channels (eps 1e-5), maxvit.py:172-178 and its autograd. */
+int leod_layernorm_fwd(const float* x, const float* w, const float* b, float* y, float* stats, int M, int C, float eps,
+                       leod_stream_t stream);
+int leod_layernorm_bwd(const float* dn, const float* x, const float* stats, const float* w, const float* dres, float* dx,
+                       float* dw, float* db, int M, int C, float eps, leod_stream_t stream);
+/* LayerScale autograd: dt = gamma*dz ; dgamma += sum_m dz*t (maxvit.py:45-53). */
+int leod_layerscale_bwd(const float* dz, const float* t, const float* gamma, float* dt, float* dgamma, int M, int C,
+                        leod_stream_t stream);
+
+/* ---- convolutions (implicit GEMM, NHWC) --------------------------------------------------------- */
+
+/* Stem conv of stage 1 straight from the raw NCHW event tensor (uint8 or fp32, H x W unpadded; reads outside are
+ * the zero padding of utils/padding.py:32-58 up to Hp x Wp): ConvDownsampling_Cf2Cl.conv, maxvit.py:160-176. */
+int leod_stem_conv_fwd(const void* x, int x_is_u8, const float* w, float* y, int B, int Cin, int H, int W, int Hp, int Wp,
+                       int N, int ks, int stride, int pad, leod_stream_t stream);
+int leod_stem_conv_wgrad(const float* dy, const void* x, int x_is_u8, float* dw, int B, int Cin, int H, int W, int Hp,
+                         int Wp, int N, int ks, int stride, int pad, leod_stream_t stream);
+/* y = conv(x NHWC, w[N,Cin,ks,ks]) (+bias); colstats (optional) [2,N] double += (sum, sumsq) for training BatchNorm;
+ * bn_w != NULL: eval BatchNorm folded + SiLU (network_blocks.py:29-54; yolo_pafpn.py:109-140; yolo_head.py:208-222). */
+int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, double* colstats, const float* bn_w,
+                       const float* bn_b, const float* bn_rm, const float* bn_rv, float bn_eps, int B, int H, int W,
+                       int Cin, int N, int ks, int stride, int pad, leod_stream_t stream);
+int leod_conv_nhwc_dgrad(const float* dy, const float* w, float* dx, int accumulate, int B, int H, int W, int Cin, int N,
+                         int ks, int stride, int pad, leod_stream_t stream);
+int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, float* dbias, int B, int H, int W, int Cin, int N,
+                         int ks, int stride, int pad, leod_stream_t stream);
+
+/* BatchNorm2d (batch statistics) + SiLU on rows and its autograd (network_blocks.py:47-51).  `count` = rows that
+ * entered colstats/sums (all ranks under SyncBN). */
+int leod_bn_silu_fwd(const float* z, const double* colstats, const float* w, const float* b, float* y, float* save_mean,
+                     float* save_rstd, float* run_mean, float* run_var, int M, int N, double count, float eps,
+                     float momentum, leod_stream_t stream);
+int leod_bn_silu_bwd_reduce(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
+                            const float* b, double* sums, int M, int N, leod_stream_t stream);
+int leod_bn_silu_bwd_apply(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
+                           const float* b, const double* sums, float* dz, float* dw, float* db, int M, int N, double count,
+                           leod_stream_t stream);
+
+/* ---- YOLOX head tail (models/detection/yolox/models/yolo_head.py) --------------------------------- */
+
+/* cls/reg/obj 1x1 prediction convs of one level + grid decode (:216-222,289-332): out_train = decoded boxes + logits,
+ * out_infer = decoded boxes + sigmoid, both [B, A, 5+nc] written at anchor offset a0. */
+int leod_head_pred_fwd(const float* cls_feat, const float* reg_feat, const float* cls_w, const float* cls_b,
+                       const float* reg_w, const float* reg_b, const float* obj_w, const float* obj_b, float* out_train,
+                       float* out_infer, int B, int h, int w, int Hd, int nc, int stride, int a0, int A, leod_stream_t stream);
+int leod_head_pred_bwd(const float* d_raw, const float* cls_feat, const float* reg_feat, const float* cls_w,
+                       const float* reg_w, const float* obj_w, float* d_cls_feat, float* d_reg_feat, float* d_cls_w,
+                       float* d_cls_b, float* d_reg_w, float* d_reg_b, float* d_obj_w, float* d_obj_b, int B, int h, int w,
+                       int Hd, int nc, int a0, int A, leod_stream_t stream);
+
+/* SimOTA (get_assignments / get_assignments_w_ignore / simota_matching, :606-774, :974-1148) for a whole batch:
+ * outputs [B,A,5+nc] decoded boxes + logits, labels [B,Nmax,7] = (cls,cx,cy,w,h,obj,cls_conf) zero padded.
+ * totals[3] int (caller-zeroed): sum num_fg, sum num_gt, status bit0 = some gt had no candidate anchor. */
+long leod_simota_workspace_floats(int B, int Nmax, int A);
+int leod_simota_assign(const float* outputs, const float* labels, float* workspace, unsigned char* fg_mask,
+                       unsigned char* ignore_mask, int* matched_row, int* matched_valid_idx, float* pred_iou,
+                       int* num_fg_img, int* totals, int B, int Nmax, int nc, int nlv, const int* hs, const int* ws,
+                       const int* strides, float ignore_label, leod_stream_t stream);
+/* Loss assembly (:547-597, losses.py:18-85) + gradient wrt the raw prediction-conv outputs (d_raw, optional).
+ * sums[3] double caller-zeroed; losses[6] = loss, iou_loss, conf_loss, cls_loss, l1_loss(0), num_fg/num_gt. */
+int leod_yolox_loss(const float* outputs, const float* labels, const unsigned char* fg_mask,
+                    const unsigned char* ignore_mask, const int* matched_row, const float* pred_iou, const int* totals,
+                    double* sums, float* losses, float* d_raw, int B, int Nmax, int nc, int nlv, const int* hs,
+                    const int* ws, const int* strides, int focal, float reg_weight, float obj_weight, float cls_weight,
+                    float grad_scale, leod_stream_t stream);
+
+/* ---- post-processing (models/detection/yolox/utils/boxes.py:32-86; modules/utils/ssod.py:40-188) -- */
+
+/* postprocess + torchvision-semantics batched NMS for B images at once.  nc>0: pred [B,A,5+nc] (cx,cy,w,h,obj,cls..),
+ * boxes rewritten IN PLACE to xyxy; nc==0: pred [B,A,7] already (xyxy,obj,cls_conf,cls_id) (TTA merge).
+ * det_out [B,max_det,7] in NMS order, det_cnt[B]. */
+int leod_postprocess_nms(float* pred, float* det_out, int* det_cnt, int B, int A, int nc, float conf_thre, float nms_thre,
+                         int class_agnostic, int max_det, int vanilla_limit, leod_stream_t stream);
+/* pred2label + filter_pred_boxes: det -> labels [B,max_det,8] = (0,x,y,w,h,cls,cls_conf,obj), lab_cnt[B]. */
+int leod_pseudo_filter(const float* det, const int* det_cnt, float* lab, int* lab_cnt, int B, int max_det,
+                       const float* obj_thr, const float* cls_thr, int nthr, int filter_boxes, float frame_w,
+                       float frame_h, leod_stream_t stream);
+
+/* ---- optimiser / input ----------------------------------------------------------------------------- */
+
+/* value-clip + AdamW over flat buffers (modules/detection.py:485-518; train.py:236-237). g is scaled/clipped in place. */
+int leod_adamw_clip_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int step, float clip_value, float grad_scale, leod_stream_t stream);
+/* StackedHistogram.construct (data/utils/representations.py:78-123): int64 events -> uint8 [2*bins,H,W]. */
+int leod_voxelize_u8(const long* x, const long* y, const long* pol, const long* t, long n_events, int* counts_ws,
+                     unsigned char* out, int bins, int H, int W, int count_cutoff, int fastmode, leod_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEOD_HIP_H */

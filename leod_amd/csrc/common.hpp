@@ -1,0 +1,73 @@
+// Common device helpers for the LEOD gfx950 kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LEOD_OK 0
+#define LEOD_ERR_ARG (-1)        // bad / unsupported argument combination
+#define LEOD_ERR_LAUNCH (-2)     // hipLaunch reported an error
+#define LEOD_ERR_UNSUPPORTED (-3)
+
+#define LEOD_API extern "C" __attribute__((visibility("default")))
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+static inline int leod_launch_status() {
+    return hipGetLastError() == hipSuccess ? LEOD_OK : LEOD_ERR_LAUNCH;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- wave64 helpers ------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// reduce over the 4 lanes that share (lane & 15): lanes l, l^16, l^32, l^48
+__device__ __forceinline__ float quad16_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float quad16_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+// reduce over the 16 lanes that share (lane >> 4)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float silu_grad(float x) {
+    const float s = sigmoidf_(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+
+__device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+__device__ __forceinline__ f4 zero4() { f4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+
+// v_mfma_f32_16x16x4_f32: exact fp32 (bitwise an fmaf chain over k).
+//   A: lane l holds A[i = l&15][k = l>>4];  B: lane l holds B[k = l>>4][j = l&15]
+//   C/D: lane l, reg r: row = 4*(l>>4) + r, col = l&15
+__device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}

@@ -1,0 +1,482 @@
+// fp32 MFMA (v_mfma_f32_16x16x4_f32) GEMM skeletons shared by every contraction on the LEOD path.
+//
+//   row GEMM   Out[m][n]  = sum_k A(m,k) * B(n,k)       gemm16_kernel   (forward / dgrad, implicit-GEMM conv)
+//   wgrad GEMM dW[n][k]  += sum_m dY(m,n) * X(m,k)       wgrad16_kernel  (weight / bias gradients)
+//
+// Design notes (MI355X): every GEMM on this path has K,N <= a few hundred and M = tokens, i.e. it is
+// HBM/latency bound, never MFMA bound (<= 36 FLOP/B).  So the skeleton favours simple,
+// fully coalesced 16-byte operand loads straight from L2/HBM into MFMA operand registers (no LDS
+// round trip: f32 MFMA issues once per 32 cycles, far below what the vector-memory path can feed),
+// one wave = 16 output rows x NT*16 columns, 4 waves per workgroup stacked along M, and fused
+// prologues/epilogues so each activation tensor crosses HBM once.
+//
+// K-permutation trick: one "chunk" = 16 consecutive k.  Lane (i = l&15, q = l>>4) loads the float4
+// A[row i][k0+4q .. k0+4q+3] and B[col i][k0+4q .. +3]; MFMA number j (0..3) of the chunk consumes
+// component j of both, i.e. k index (q) of that MFMA stands for k0+4q+j.  Summed over j this covers
+// each k of the chunk exactly once, and both operands are plain 16-byte row-contiguous loads.
+#pragma once
+#include "common.hpp"
+
+// =================================================================================================
+// A loaders (row operand).  init() is called by all 64 lanes (may shuffle); load() returns the float4
+// A(row, k..k+3) or zeros when out of range.
+// =================================================================================================
+struct ALRows {                 // plain rows, optional LayerNorm prologue, optional per-k scale
+    const float* x; long ld;
+    const float* ln_w; const float* ln_b; float eps;   // ln_w != nullptr -> normalise on the fly
+    const float* kscale;                                // optional per-k multiplier (LayerScale bwd)
+    float* stats_out;                                   // optional [M,2] (mean, rstd) written by n-block 0
+    int K;                                              // row length used for the LN statistics
+    struct St { const float* p; float mean, rstd; bool ok; };
+    __device__ __forceinline__ St init(int row, int M, int lane, bool write_stats) const {
+        St s; s.ok = row < M; s.p = x + (long)(s.ok ? row : M - 1) * ld; s.mean = 0.f; s.rstd = 1.f;
+        if (ln_w) {
+            const int q = lane >> 4;
+            float sum = 0.f;
+            for (int k = 4 * q; k < K; k += 16) { f4 v = ld4(s.p + k); sum += (v.x + v.y) + (v.z + v.w); }
+            sum = quad16_sum(sum);
+            const float mean = sum / (float)K;
+            float var = 0.f;
+            for (int k = 4 * q; k < K; k += 16) {
+                f4 v = ld4(s.p + k);
+                const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+                var += (a * a + b * b) + (c * c + d * d);
+            }
+            var = quad16_sum(var) / (float)K;
+            s.mean = mean; s.rstd = rsqrtf(var + eps);
+            if (write_stats && stats_out && s.ok && q == 0) { stats_out[2 * (long)row] = s.mean; stats_out[2 * (long)row + 1] = s.rstd; }
+        }
+        return s;
+    }
+    __device__ __forceinline__ f4 load(const St& s, int k, int Kt) const {
+        if (k >= Kt) return zero4();
+        f4 v = ld4(s.p + k);
+        if (ln_w) {
+            const f4 g = ld4(ln_w + k), b = ld4(ln_b + k);
+            v = (v - s.mean) * s.rstd * g + b;
+        }
+        if (kscale) v = v * ld4(kscale + k);
+        return s.ok ? v : zero4();
+    }
+};
+
+struct ALConcat2 {              // [x1 (K1 cols) | x2] along k  (ConvLSTM: cat(x, h_prev))
+    const float* x1; long ld1; int K1; const float* x2; long ld2;
+    struct St { const float* p1; const float* p2; bool ok; };
+    __device__ __forceinline__ St init(int row, int M, int, bool) const {
+        St s; s.ok = row < M; const long r = s.ok ? row : M - 1;
+        s.p1 = x1 + r * ld1; s.p2 = x2 ? x2 + r * ld2 : nullptr; return s;
+    }
+    __device__ __forceinline__ f4 load(const St& s, int k, int Kt) const {
+        if (k >= Kt || !s.ok) return zero4();
+        if (k < K1) return ld4(s.p1 + k);
+        return s.p2 ? ld4(s.p2 + (k - K1)) : zero4();      // x2 == nullptr: zero initial state
+    }
+};
+
+struct ALConvNHWC {             // implicit-GEMM im2col over an NHWC fp32 map; k' = tap*Cin + c
+    const float* x; int H, W, Cin, Ho, Wo, ks, stride, pad;
+    struct St { int b, iy0, ix0; bool ok; };
+    __device__ __forceinline__ St init(int row, int M, int, bool) const {
+        St s; s.ok = row < M; const int r = s.ok ? row : 0;
+        const int ox = r % Wo, t = r / Wo; const int oy = t % Ho; s.b = t / Ho;
+        s.iy0 = oy * stride - pad; s.ix0 = ox * stride - pad; return s;
+    }
+    __device__ __forceinline__ f4 load(const St& s, int k, int Kt) const {
+        if (k >= Kt || !s.ok) return zero4();
+        const int tap = k / Cin, c = k - tap * Cin;
+        const int kh = tap / ks, kw = tap - kh * ks;
+        const int iy = s.iy0 + kh, ix = s.ix0 + kw;
+        if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) return zero4();
+        return ld4(x + (((long)s.b * H + iy) * W + ix) * Cin + c);
+    }
+};
+
+template <typename T>
+struct ALStemNCHW {             // stem conv over the raw NCHW event tensor (uint8 or fp32), k = c*ks*ks + kh*ks + kw
+    const T* x; int Cin, H, W;  // H,W: stored (unpadded) size; anything outside reads as 0 (= bottom/right zero pad)
+    int Ho, Wo, ks, stride, pad;
+    struct St { const T* p; int iy0, ix0; bool ok; };
+    __device__ __forceinline__ St init(int row, int M, int, bool) const {
+        St s; s.ok = row < M; const int r = s.ok ? row : 0;
+        const int ox = r % Wo, t = r / Wo; const int oy = t % Ho; const int b = t / Ho;
+        s.p = x + (long)b * Cin * H * W; s.iy0 = oy * stride - pad; s.ix0 = ox * stride - pad; return s;
+    }
+    __device__ __forceinline__ float one(const St& s, int k) const {
+        const int kk = ks * ks; const int c = k / kk; const int r = k - c * kk; const int kh = r / ks, kw = r - kh * ks;
+        const int iy = s.iy0 + kh, ix = s.ix0 + kw;
+        if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) return 0.f;
+        return (float)s.p[((long)c * H + iy) * W + ix];
+    }
+    __device__ __forceinline__ f4 load(const St& s, int k, int Kt) const {
+        if (k >= Kt || !s.ok) return zero4();
+        f4 v; v.x = one(s, k); v.y = one(s, k + 1); v.z = one(s, k + 2); v.w = one(s, k + 3); return v;
+    }
+};
+
+struct ALConvT {                // dgrad of a conv: rows = input pixels, k' = tap*N + n over dY (NHWC [B,Ho,Wo,N])
+    const float* dy; int H, W, Ho, Wo, N, ks, stride, pad;
+    struct St { int b, iy, ix; bool ok; };
+    __device__ __forceinline__ St init(int row, int M, int, bool) const {
+        St s; s.ok = row < M; const int r = s.ok ? row : 0;
+        s.ix = r % W; const int t = r / W; s.iy = t % H; s.b = t / H; return s;
+    }
+    __device__ __forceinline__ f4 load(const St& s, int k, int Kt) const {
+        if (k >= Kt || !s.ok) return zero4();
+        const int tap = k / N, n = k - tap * N;
+        const int kh = tap / ks, kw = tap - kh * ks;
+        const int ty = s.iy + pad - kh, tx = s.ix + pad - kw;
+        if (ty < 0 || tx < 0 || (ty % stride) || (tx % stride)) return zero4();
+        const int oy = ty / stride, ox = tx / stride;
+        if (oy >= Ho || ox >= Wo) return zero4();
+        return ld4(dy + (((long)s.b * Ho + oy) * Wo + ox) * N + n);
+    }
+};
+
+// =================================================================================================
+// B loaders (column operand = weights).  load(nblk, t, i, k) -> float4 B(n, k..k+3)
+// =================================================================================================
+struct BLRows {                 // W[n][k], row stride ld (torch Linear / 1x1 conv weight)
+    const float* w; long ld; int N; int NT;
+    __device__ __forceinline__ int col(int nblk, int t, int i) const { return (nblk * NT + t) * 16 + i; }
+    __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt) const {
+        const int n = col(nblk, t, i);
+        if (n >= N || k >= Kt) return zero4();
+        return ld4(w + (long)n * ld + k);
+    }
+};
+struct BLGates {                // ConvLSTM: tile t = gate t (f,i,o,g), columns nblk*16.. of that gate; W[4C][K]
+    const float* w; long ld; int C;
+    __device__ __forceinline__ int col(int nblk, int t, int i) const { return t * C + nblk * 16 + i; }
+    __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt) const {
+        if (nblk * 16 + i >= C || k >= Kt) return zero4();
+        return ld4(w + (long)col(nblk, t, i) * ld + k);
+    }
+};
+struct BLTrans {                // B(n,k) = W[k][n]  (dgrad of a Linear: W is [Kred][N])
+    const float* w; long ld; int N; int NT;
+    __device__ __forceinline__ int col(int nblk, int t, int i) const { return (nblk * NT + t) * 16 + i; }
+    __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt) const {
+        const int n = col(nblk, t, i);
+        if (n >= N || k >= Kt) return zero4();
+        const float* p = w + (long)k * ld + n;
+        f4 v; v.x = p[0]; v.y = p[ld]; v.z = p[2 * ld]; v.w = p[3 * ld]; return v;
+    }
+};
+struct BLConvW {                // conv weight [N][Cin][ks][ks] read as B(n, k' = tap*Cin + c)
+    const float* w; int N, Cin, KK; int NT;
+    __device__ __forceinline__ int col(int nblk, int t, int i) const { return (nblk * NT + t) * 16 + i; }
+    __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt) const {
+        const int n = col(nblk, t, i);
+        if (n >= N || k >= Kt) return zero4();
+        const int tap = k / Cin, c = k - tap * Cin;
+        const float* p = w + ((long)n * Cin + c) * KK + tap;
+        f4 v; v.x = p[0]; v.y = p[KK]; v.z = p[2 * KK]; v.w = p[3 * KK]; return v;
+    }
+};
+struct BLConvWT {               // dgrad: B(col = c, k' = tap*N + n) = W[n][c][tap]
+    const float* w; int N, Cin, KK; int NT;
+    __device__ __forceinline__ int col(int nblk, int t, int i) const { return (nblk * NT + t) * 16 + i; }
+    __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt) const {
+        const int c = col(nblk, t, i);
+        if (c >= Cin || k >= Kt) return zero4();
+        const int tap = k / N, n = k - tap * N;
+        const long sn = (long)Cin * KK;
+        const float* p = w + ((long)n * Cin + c) * KK + tap;
+        f4 v; v.x = p[0]; v.y = p[sn]; v.z = p[2 * sn]; v.w = p[3 * sn]; return v;
+    }
+};
+
+// =================================================================================================
+// Epilogues.  acc[t][r] = Out[row0 + 4*(lane>>4) + r][col(nblk,t,lane&15)]
+// =================================================================================================
+enum { ACT_NONE = 0, ACT_GELU_DUAL = 1, ACT_AFFINE_SILU = 2, ACT_MUL_GELU_GRAD = 3 };
+
+struct EpStore {
+    float* out; long ld;            // primary output
+    float* out2; long ld2;          // ACT_GELU_DUAL: gelu(pre) goes to out2, pre to out;  split: cols >= nsplit
+    int nsplit;                     // columns >= nsplit are routed to out2 (col - nsplit); 0 = no split
+    const float* bias;              // optional per-column bias
+    const float* aux; long ldaux;   // ACT_MUL_GELU_GRAD: u (pre-activation) ; ACT_AFFINE_SILU: unused
+    const float* bn_w; const float* bn_b; const float* bn_rm; const float* bn_rv; float bn_eps;  // eval BN fold
+    double* colstats;               // optional [2][N] (sum, sumsq) accumulated atomically (train BN)
+    float* colsum;                  // optional [N]: += column sums of the stored value (bias gradient)
+    int act; int accumulate;
+    int N;
+    template <int NT, class BL>
+    __device__ __forceinline__ void run(f4 (&acc)[NT], const BL& bl, int row0, int nblk, int lane, int M) const {
+        const int i = lane & 15, rg = lane >> 4;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = bl.col(nblk, t, i);
+            const bool nok = n < N;
+            const float bv = (bias && nok) ? bias[n] : 0.f;
+            float sc = 1.f, sh = 0.f;
+            if (act == ACT_AFFINE_SILU && nok) {
+                sc = bn_w[n] * rsqrtf(bn_rv[n] + bn_eps); sh = bn_b[n] - bn_rm[n] * sc;
+            }
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 4 * rg + r;
+                float v = acc[t][r] + bv;
+                const bool ok = nok && row < M;
+                if (act == ACT_AFFINE_SILU) v = siluf_(v * sc + sh);
+                if (act == ACT_MUL_GELU_GRAD && ok) v *= gelu_erf_grad(aux[(long)row * ldaux + n]);
+                if (ok) {
+                    if (nsplit > 0 && n >= nsplit) {
+                        float* p = out2 + (long)row * ld2 + (n - nsplit);
+                        *p = accumulate ? *p + v : v;
+                    } else {
+                        float* p = out + (long)row * ld + n;
+                        *p = accumulate ? *p + v : v;
+                        if (act == ACT_GELU_DUAL) out2[(long)row * ld2 + n] = gelu_erf(v);
+                    }
+                    s1 += v; s2 += v * v;
+                }
+            }
+            if (colstats || colsum) {
+                s1 = quad16_sum(s1);
+                if (colstats) s2 = quad16_sum(s2);
+                if (rg == 0 && nok) {
+                    if (colstats) { atomicAdd(colstats + n, (double)s1); atomicAdd(colstats + N + n, (double)s2); }
+                    if (colsum) atomicAdd(colsum + n, s1);
+                }
+            }
+        }
+    }
+};
+
+struct EpLsRes {                    // t = acc + bias; tout = t; out = res + gamma * t   (LayerScale + residual)
+    float* out; float* tout; const float* res; const float* bias; const float* gamma; long ld; int N;
+    template <int NT, class BL>
+    __device__ __forceinline__ void run(f4 (&acc)[NT], const BL& bl, int row0, int nblk, int lane, int M) const {
+        const int i = lane & 15, rg = lane >> 4;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = bl.col(nblk, t, i);
+            if (n >= N) continue;
+            const float bv = bias ? bias[n] : 0.f, g = gamma ? gamma[n] : 1.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 4 * rg + r;
+                if (row >= M) continue;
+                const long o = (long)row * ld + n;
+                const float tv = acc[t][r] + bv;
+                if (tout) tout[o] = tv;
+                out[o] = res[o] + g * tv;
+            }
+        }
+    }
+};
+
+struct EpLstm {                     // NT must be 4: tiles = (f, i, o, g) of channels nblk*16 + lane&15
+    const float* bias; const float* c_prev; float* h_out; float* c_out; float* gates_out;  // gates_out [M][4][C] post-activation (optional)
+    int C;
+    template <int NT, class BL>
+    __device__ __forceinline__ void run(f4 (&acc)[NT], const BL&, int row0, int nblk, int lane, int M) const {
+        static_assert(NT == 4, "LSTM epilogue needs the four gate tiles");
+        const int i = lane & 15, rg = lane >> 4;
+        const int c = nblk * 16 + i;
+        if (c >= C) return;
+        const float bf = bias[c], bi = bias[C + c], bo = bias[2 * C + c], bg = bias[3 * C + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + 4 * rg + r;
+            if (row >= M) continue;
+            const float f = sigmoidf_(acc[0][r] + bf), ig = sigmoidf_(acc[1][r] + bi), o = sigmoidf_(acc[2][r] + bo);
+            const float g = tanhf(acc[3][r] + bg);
+            const long idx = (long)row * C + c;
+            const float cp = c_prev ? c_prev[idx] : 0.f;
+            const float cn = f * cp + ig * g;
+            c_out[idx] = cn;
+            h_out[idx] = o * tanhf(cn);
+            if (gates_out) {
+                float* gp = gates_out + (long)row * 4 * C + c;
+                gp[0] = f; gp[C] = ig; gp[2 * C] = o; gp[3 * C] = g;
+            }
+        }
+    }
+};
+
+// =================================================================================================
+// row GEMM kernel
+// =================================================================================================
+template <int NT, class AL, class BL, class EP>
+__global__ __launch_bounds__(256) void gemm16_kernel(AL al, BL bl, EP ep, int M, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int row0 = (blockIdx.x * 4 + wave) * 16;
+    const int nblk = blockIdx.y;
+    if (row0 >= M) return;                       // wave-uniform; no block-level sync is used below
+    typename AL::St st = al.init(row0 + i, M, lane, nblk == 0);
+    f4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = zero4();
+    const int KC = (K + 15) >> 4;
+    f4 a_cur = al.load(st, 4 * q, K), b_cur[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b_cur[t] = bl.load(nblk, t, i, 4 * q, K);
+    for (int kc = 0; kc < KC; ++kc) {
+        f4 a_nxt = zero4(), b_nxt[NT];
+        const int kn = (kc + 1) * 16 + 4 * q;
+        const bool more = kc + 1 < KC;
+        if (more) a_nxt = al.load(st, kn, K);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b_nxt[t] = more ? bl.load(nblk, t, i, kn, K) : zero4();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = mfma16(a_cur[j], b_cur[t][j], acc[t]);
+        a_cur = a_nxt;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b_cur[t] = b_nxt[t];
+    }
+    ep.template run<NT, BL>(acc, bl, row0, nblk, lane, M);
+}
+
+template <int NT, class AL, class BL, class EP>
+static inline int launch_gemm16(const AL& al, const BL& bl, const EP& ep, int M, int K, int nblocks_n, hipStream_t s) {
+    if (M <= 0) return LEOD_OK;
+    dim3 grid(cdiv(M, 64), nblocks_n);
+    hipLaunchKernelGGL((gemm16_kernel<NT, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+    return leod_launch_status();
+}
+
+// =================================================================================================
+// wgrad GEMM:  dW[n][k] += sum_m dY(m,n) * X(m,k)   (+ optional dbias[n] += sum_m dY(m,n))
+// Each workgroup owns `rows_per_block` rows of M and one (TN*16 x TK*16) tile of dW; its 4 waves
+// interleave 16-row chunks, reduce through LDS and issue one fp32 atomicAdd per dW element.
+// =================================================================================================
+struct XRows {                      // X(m,k) = x[m][k], optional LayerNorm with saved (mean, rstd)
+    const float* x; long ld; const float* stats; const float* ln_w; const float* ln_b;
+    const float* x2; long ld2; int K1;          // optional concat source for k >= K1
+    __device__ __forceinline__ float get(int m, int k) const {
+        if (x2 && k >= K1) return x2[(long)m * ld2 + (k - K1)];
+        float v = x[(long)m * ld + k];
+        if (stats) v = (v - stats[2 * (long)m]) * stats[2 * (long)m + 1] * ln_w[k] + ln_b[k];
+        return v;
+    }
+    __device__ __forceinline__ long waddr(int n, int k, long ldw) const { return (long)n * ldw + k; }
+};
+struct XConvNHWC {                  // im2col of an NHWC map; k' = tap*Cin + c ; dW laid out [N][Cin][ks][ks]
+    const float* x; int H, W, Cin, Ho, Wo, ks, stride, pad;
+    __device__ __forceinline__ float get(int m, int k) const {
+        const int ox = m % Wo, t = m / Wo; const int oy = t % Ho, b = t / Ho;
+        const int tap = k / Cin, c = k - tap * Cin; const int kh = tap / ks, kw = tap - kh * ks;
+        const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
+        if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) return 0.f;
+        return x[(((long)b * H + iy) * W + ix) * Cin + c];
+    }
+    __device__ __forceinline__ long waddr(int n, int k, long) const {
+        const int tap = k / Cin, c = k - tap * Cin;
+        return ((long)n * Cin + c) * (ks * ks) + tap;
+    }
+};
+template <typename T>
+struct XStemNCHW {
+    const T* x; int Cin, H, W, Ho, Wo, ks, stride, pad;
+    __device__ __forceinline__ float get(int m, int k) const {
+        const int ox = m % Wo, t = m / Wo; const int oy = t % Ho, b = t / Ho;
+        const int kk = ks * ks; const int c = k / kk; const int r = k - c * kk; const int kh = r / ks, kw = r - kh * ks;
+        const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
+        if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) return 0.f;
+        return (float)x[(((long)b * Cin + c) * H + iy) * W + ix];
+    }
+    __device__ __forceinline__ long waddr(int n, int k, long ldw) const { return (long)n * ldw + k; }
+};
+
+template <int TN, int TK, class XL>
+__global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ dy, long lddy, XL xl, float* dW, long ldw,
+                                                      float* dbias, int M, int N, int K, int rows_per_block) {
+    __shared__ float red[3][TN * TK * 256];
+    __shared__ float redb[3][TN * 16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.y * TN * 16, k0 = blockIdx.z * TK * 16;
+    const int mbeg = blockIdx.x * rows_per_block;
+    const int mend = min(M, mbeg + rows_per_block);
+    f4 acc[TN][TK];
+    float bsum[TN];
+#pragma unroll
+    for (int a = 0; a < TN; ++a) { bsum[a] = 0.f;
+#pragma unroll
+        for (int b = 0; b < TK; ++b) acc[a][b] = zero4(); }
+    const bool do_bias = dbias != nullptr && blockIdx.z == 0;
+    for (int m0 = mbeg + wave * 16; m0 < mend; m0 += 64) {
+        float av[TN][4], bv[TK][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + 4 * q + j;
+            const bool mok = m < mend;
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int n = n0 + 16 * a + i;
+                av[a][j] = (mok && n < N) ? dy[(long)m * lddy + n] : 0.f;
+            }
+#pragma unroll
+            for (int b = 0; b < TK; ++b) {
+                const int k = k0 + 16 * b + i;
+                bv[b][j] = (mok && k < K) ? xl.get(m, k) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                bsum[a] += av[a][j];
+#pragma unroll
+                for (int b = 0; b < TK; ++b) acc[a][b] = mfma16(av[a][j], bv[b][j], acc[a][b]);
+            }
+    }
+    // cross-wave reduction: waves 1..3 park their tiles in LDS, wave 0 adds and issues the atomics
+    if (wave > 0) {
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TK; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave - 1][((a * TK + b) * 4 + r) * 64 + lane] = acc[a][b][r];
+        if (do_bias) {
+#pragma unroll
+            for (int a = 0; a < TN; ++a) { const float s = quad16_sum(bsum[a]); if (q == 0) redb[wave - 1][a * 16 + i] = s; }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TK; ++b) {
+                const int k = k0 + 16 * b + i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + 16 * a + 4 * q + r;
+                    const int o = ((a * TK + b) * 4 + r) * 64 + lane;
+                    const float v = acc[a][b][r] + red[0][o] + red[1][o] + red[2][o];
+                    if (n < N && k < K) atomicAdd(dW + xl.waddr(n, k, ldw), v);
+                }
+            }
+        if (do_bias) {
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                float s = quad16_sum(bsum[a]);
+                const int n = n0 + 16 * a + i;
+                if (q == 0 && n < N) atomicAdd(dbias + n, s + redb[0][a * 16 + i] + redb[1][a * 16 + i] + redb[2][a * 16 + i]);
+            }
+        }
+    }
+}
+
+template <int TN, int TK, class XL>
+static inline int launch_wgrad16(const float* dy, long lddy, const XL& xl, float* dW, long ldw, float* dbias,
+                                 int M, int N, int K, hipStream_t s) {
+    if (M <= 0) return LEOD_OK;
+    const int tiles = cdiv(N, TN * 16) * cdiv(K, TK * 16);
+    // aim for ~1024 workgroups in total, at least 64 rows (one 16-row chunk per wave) each
+    int rpb = cdiv(M, max(1, 1024 / tiles));
+    rpb = max(64, ((rpb + 63) / 64) * 64);
+    dim3 grid(cdiv(M, rpb), cdiv(N, TN * 16), cdiv(K, TK * 16));
+    hipLaunchKernelGGL((wgrad16_kernel<TN, TK, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, rpb);
+    return leod_launch_status();
+}

@@ -1,0 +1,331 @@
+// MaxViT partition attention core (window = contiguous tiles, grid = dilated tiles) for the RVT
+// backbone: softmax(q k^T * d^-0.5) v per (partition, head), forward and backward.
+// Reference: models/layers/maxvit/maxvit.py:343-354 (SelfAttentionCl), :273-304 (partitions).
+//
+// Layout: qkv is the row-major [M, 3C] output of the qkv Linear in *image token order*
+// (M = B*H*W rows of an NHWC map); head h owns columns [h*3d, (h+1)*3d) = (q | k | v)
+// (maxvit.py:347 view(B,-1,heads,3d)).  Partitioning is pure index math on the row number, so no
+// partition/reverse copies exist.  Output O is [M, C] with channel = h*d + c.
+//
+// Mapping to CDNA4: one wave owns (partition, head, 16-token tile).  The score tile is computed
+// *transposed* (S^T = K Q^T, keys along MFMA rows) so that the softmax'ed accumulator registers are
+// already laid out as the A operand of the P.V MFMA (k index = lane>>4): no LDS, no shuffles apart
+// from the 2-step cross-row-group reductions.  P = 80 tokens -> 5 key tiles, 20 accumulator VGPRs.
+#include "common.hpp"
+
+struct AttnGeom {
+    int B, H, W, C, heads, d, ph, pw, window;   // window: 1 = window partition, 0 = grid partition
+};
+
+__device__ __forceinline__ long token_row(const AttnGeom& g, int p, int t) {
+    const int nH = g.H / g.ph, nW = g.W / g.pw;
+    const int per = nH * nW;
+    const int b = p / per, rem = p - b * per;
+    const int py = rem / nW, px = rem - py * nW;
+    const int ty = t / g.pw, tx = t - ty * g.pw;
+    const int y = g.window ? py * g.ph + ty : ty * nH + py;
+    const int x = g.window ? px * g.pw + tx : tx * nW + px;
+    return ((long)b * g.H + y) * g.W + x;
+}
+
+// float4 of a head slice (part: 0 q, 1 k, 2 v) at channel c..c+3, zero outside [0,d) or for row < 0
+__device__ __forceinline__ f4 ld_head4(const float* base, long row, long ld, int off, int c, int d) {
+    if (row < 0 || c >= d) return zero4();
+    return ld4(base + row * ld + off + c);
+}
+__device__ __forceinline__ float ld_head1(const float* base, long row, long ld, int off, int c, int d) {
+    if (row < 0 || c >= d) return 0.f;
+    return base[row * ld + off + c];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward: one wave = (partition p, head h, query tile qt)
+// ---------------------------------------------------------------------------------------------------
+template <int PT, int DCH>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                       float* __restrict__ lse, AttnGeom g, float scale, int ntasks) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int task = blockIdx.x * 4 + wave;
+    if (task >= ntasks) return;
+    const int i = lane & 15, rg = lane >> 4;
+    const int qt = task % PT, h = (task / PT) % g.heads, p = task / (PT * g.heads);
+    const int P = g.ph * g.pw, d = g.d;
+    const long ld = 3L * g.C;
+    const int hoff = h * 3 * d;
+
+    const int tq = 16 * qt + i;
+    const long rowq = tq < P ? token_row(g, p, tq) : -1;
+    f4 qf[DCH];
+#pragma unroll
+    for (int ch = 0; ch < DCH; ++ch) qf[ch] = ld_head4(qkv, rowq, ld, hoff, 16 * ch + 4 * rg, d);
+
+    f4 s[PT];
+#pragma unroll
+    for (int mt = 0; mt < PT; ++mt) {
+        s[mt] = zero4();
+        const int tk = 16 * mt + i;
+        const long rowk = tk < P ? token_row(g, p, tk) : -1;
+#pragma unroll
+        for (int ch = 0; ch < DCH; ++ch) {
+            const f4 kf = ld_head4(qkv, rowk, ld, hoff + d, 16 * ch + 4 * rg, d);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[mt] = mfma16(kf[j], qf[ch][j], s[mt]);
+        }
+    }
+    // softmax over keys (rows of S^T) for query column i
+    float mx = -INFINITY;
+#pragma unroll
+    for (int mt = 0; mt < PT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * mt + 4 * rg + r;
+            const float v = key < P ? s[mt][r] * scale : -INFINITY;
+            s[mt][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = quad16_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < PT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = expf(s[mt][r] - mx);      // exp(-inf) = 0 for padded keys
+            s[mt][r] = e;
+            sum += e;
+        }
+    sum = quad16_sum(sum);
+    const float inv = 1.0f / sum;
+    if (lse && rg == 0 && rowq >= 0) lse[rowq * g.heads + h] = mx + logf(sum);
+
+    // O = P V : A = P (s registers as they are), B = V rows gathered per (key = 16mt + 4rg + r)
+    f4 o[DCH];
+#pragma unroll
+    for (int ct = 0; ct < DCH; ++ct) o[ct] = zero4();
+#pragma unroll
+    for (int mt = 0; mt < PT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * mt + 4 * rg + r;
+            const long rowv = key < P ? token_row(g, p, key) : -1;
+#pragma unroll
+            for (int ct = 0; ct < DCH; ++ct) {
+                const float vv = ld_head1(qkv, rowv, ld, hoff + 2 * d, 16 * ct + i, d);
+                o[ct] = mfma16(s[mt][r] * inv, vv, o[ct]);
+            }
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = 16 * qt + 4 * rg + r;
+        if (t >= P) continue;
+        const long row = token_row(g, p, t);
+#pragma unroll
+        for (int ct = 0; ct < DCH; ++ct) {
+            const int c = 16 * ct + i;
+            if (c < d) out[row * g.C + h * d + c] = o[ct][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward, query-owned part: dQ and D[query] = sum_key P * dP
+// ---------------------------------------------------------------------------------------------------
+template <int PT, int DCH>
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                         const float* __restrict__ lse, float* __restrict__ dqkv,
+                                                         float* __restrict__ dsum, AttnGeom g, float scale, int ntasks) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int task = blockIdx.x * 4 + wave;
+    if (task >= ntasks) return;
+    const int i = lane & 15, rg = lane >> 4;
+    const int qt = task % PT, h = (task / PT) % g.heads, p = task / (PT * g.heads);
+    const int P = g.ph * g.pw, d = g.d;
+    const long ld = 3L * g.C;
+    const int hoff = h * 3 * d;
+
+    const int tq = 16 * qt + i;
+    const long rowq = tq < P ? token_row(g, p, tq) : -1;
+    f4 qf[DCH], dof[DCH];
+#pragma unroll
+    for (int ch = 0; ch < DCH; ++ch) {
+        qf[ch] = ld_head4(qkv, rowq, ld, hoff, 16 * ch + 4 * rg, d);
+        dof[ch] = ld_head4(dout, rowq, g.C, h * d, 16 * ch + 4 * rg, d);
+    }
+    const float l = rowq >= 0 ? lse[rowq * g.heads + h] : 0.f;
+    f4 s[PT], dp[PT];
+#pragma unroll
+    for (int mt = 0; mt < PT; ++mt) {
+        s[mt] = zero4(); dp[mt] = zero4();
+        const int tk = 16 * mt + i;
+        const long rowk = tk < P ? token_row(g, p, tk) : -1;
+#pragma unroll
+        for (int ch = 0; ch < DCH; ++ch) {
+            const f4 kf = ld_head4(qkv, rowk, ld, hoff + d, 16 * ch + 4 * rg, d);
+            const f4 vf = ld_head4(qkv, rowk, ld, hoff + 2 * d, 16 * ch + 4 * rg, d);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[mt] = mfma16(kf[j], qf[ch][j], s[mt]);
+                dp[mt] = mfma16(vf[j], dof[ch][j], dp[mt]);
+            }
+        }
+    }
+    float D = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < PT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * mt + 4 * rg + r;
+            const float pr = (key < P && rowq >= 0) ? expf(s[mt][r] * scale - l) : 0.f;
+            s[mt][r] = pr;
+            D += pr * dp[mt][r];
+        }
+    D = quad16_sum(D);
+    if (rg == 0 && rowq >= 0) dsum[rowq * g.heads + h] = D;
+    f4 dq[DCH];
+#pragma unroll
+    for (int ct = 0; ct < DCH; ++ct) dq[ct] = zero4();
+#pragma unroll
+    for (int mt = 0; mt < PT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * mt + 4 * rg + r;
+            const long rowk = key < P ? token_row(g, p, key) : -1;
+            const float ds = s[mt][r] * (dp[mt][r] - D) * scale;
+#pragma unroll
+            for (int ct = 0; ct < DCH; ++ct) {
+                const float kk = ld_head1(qkv, rowk, ld, hoff + d, 16 * ct + i, d);
+                dq[ct] = mfma16(ds, kk, dq[ct]);
+            }
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = 16 * qt + 4 * rg + r;
+        if (t >= P) continue;
+        const long row = token_row(g, p, t);
+#pragma unroll
+        for (int ct = 0; ct < DCH; ++ct) {
+            const int c = 16 * ct + i;
+            if (c < d) dqkv[row * ld + hoff + c] = dq[ct][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward, key-owned part: dK and dV for 16 keys, looping over all queries of the partition
+// ---------------------------------------------------------------------------------------------------
+template <int PT, int DCH>
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                          const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                          float* __restrict__ dqkv, AttnGeom g, float scale, int ntasks) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int task = blockIdx.x * 4 + wave;
+    if (task >= ntasks) return;
+    const int i = lane & 15, rg = lane >> 4;
+    const int kt = task % PT, h = (task / PT) % g.heads, p = task / (PT * g.heads);
+    const int P = g.ph * g.pw, d = g.d;
+    const long ld = 3L * g.C;
+    const int hoff = h * 3 * d;
+
+    const int tk = 16 * kt + i;
+    const long rowk = tk < P ? token_row(g, p, tk) : -1;
+    f4 kf[DCH], vf[DCH];
+#pragma unroll
+    for (int ch = 0; ch < DCH; ++ch) {
+        kf[ch] = ld_head4(qkv, rowk, ld, hoff + d, 16 * ch + 4 * rg, d);
+        vf[ch] = ld_head4(qkv, rowk, ld, hoff + 2 * d, 16 * ch + 4 * rg, d);
+    }
+    f4 dk[DCH], dv[DCH];
+#pragma unroll
+    for (int ct = 0; ct < DCH; ++ct) { dk[ct] = zero4(); dv[ct] = zero4(); }
+#pragma unroll
+    for (int qm = 0; qm < PT; ++qm) {
+        // S[query][key] (not transposed): A = Q rows, B = K^T
+        const int tq = 16 * qm + i;
+        const long rowq = tq < P ? token_row(g, p, tq) : -1;
+        f4 s = zero4(), dp = zero4();
+#pragma unroll
+        for (int ch = 0; ch < DCH; ++ch) {
+            const f4 qf = ld_head4(qkv, rowq, ld, hoff, 16 * ch + 4 * rg, d);
+            const f4 dof = ld_head4(dout, rowq, g.C, h * d, 16 * ch + 4 * rg, d);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s = mfma16(qf[j], kf[ch][j], s);
+                dp = mfma16(dof[j], vf[ch][j], dp);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tqr = 16 * qm + 4 * rg + r;          // query of accumulator row r; key = column i
+            const long rq = tqr < P ? token_row(g, p, tqr) : -1;
+            float pr = 0.f, ds = 0.f;
+            if (rq >= 0 && rowk >= 0) {
+                pr = expf(s[r] * scale - lse[rq * g.heads + h]);
+                ds = pr * (dp[r] - dsum[rq * g.heads + h]) * scale;
+            }
+#pragma unroll
+            for (int ct = 0; ct < DCH; ++ct) {
+                const float dov = ld_head1(dout, rq, g.C, h * d, 16 * ct + i, d);
+                const float qv = ld_head1(qkv, rq, ld, hoff, 16 * ct + i, d);
+                dv[ct] = mfma16(pr, dov, dv[ct]);
+                dk[ct] = mfma16(ds, qv, dk[ct]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = 16 * kt + 4 * rg + r;
+        if (t >= P) continue;
+        const long row = token_row(g, p, t);
+#pragma unroll
+        for (int ct = 0; ct < DCH; ++ct) {
+            const int c = 16 * ct + i;
+            if (c < d) {
+                dqkv[row * ld + hoff + d + c] = dk[ct][r];
+                dqkv[row * ld + hoff + 2 * d + c] = dv[ct][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <int PT, int DCH>
+static int run_attn(int which, const float* qkv, const float* dout, float* out, float* lse, float* dsum, float* dqkv,
+                    const AttnGeom& g, float scale, hipStream_t s) {
+    const int NP = g.B * (g.H / g.ph) * (g.W / g.pw);
+    const int ntasks = NP * g.heads * PT;
+    if (ntasks == 0) return LEOD_OK;
+    const dim3 grid(cdiv(ntasks, 4)), blk(256);
+    if (which == 0) hipLaunchKernelGGL((attn_fwd_kernel<PT, DCH>), grid, blk, 0, s, qkv, out, lse, g, scale, ntasks);
+    else if (which == 1) hipLaunchKernelGGL((attn_bwd_q_kernel<PT, DCH>), grid, blk, 0, s, qkv, dout, lse, dqkv, dsum, g, scale, ntasks);
+    else hipLaunchKernelGGL((attn_bwd_kv_kernel<PT, DCH>), grid, blk, 0, s, qkv, dout, lse, dsum, dqkv, g, scale, ntasks);
+    return leod_launch_status();
+}
+
+static int dispatch_attn(int which, const float* qkv, const float* dout, float* out, float* lse, float* dsum,
+                         float* dqkv, const AttnGeom& g, hipStream_t s) {
+    if (g.C != g.heads * g.d || (g.d & 3) || g.d > 32 || g.H % g.ph || g.W % g.pw) return LEOD_ERR_ARG;
+    const int P = g.ph * g.pw, PT = (P + 15) / 16, DCH = (g.d + 15) / 16;
+    const float scale = 1.0f / sqrtf((float)g.d);
+#define ATT(PTV, DV) if (PT == PTV && DCH == DV) return run_attn<PTV, DV>(which, qkv, dout, out, lse, dsum, dqkv, g, scale, s);
+    ATT(1, 1) ATT(1, 2) ATT(4, 1) ATT(4, 2) ATT(5, 1) ATT(5, 2) ATT(15, 2) ATT(2, 1) ATT(2, 2) ATT(3, 2) ATT(8, 2) ATT(10, 2)
+#undef ATT
+    return LEOD_ERR_UNSUPPORTED;
+}
+
+// out[M,C] = softmax(q k^T / sqrt(d)) v per partition/head ; lse[M,heads] (optional) = log-sum-exp of the scaled scores
+LEOD_API int leod_partition_attn_fwd(const float* qkv, float* out, float* lse, int B, int H, int W, int C, int heads,
+                                     int ph, int pw, int window, hipStream_t stream) {
+    if (!qkv || !out || heads <= 0) return LEOD_ERR_ARG;
+    AttnGeom g{B, H, W, C, heads, C / heads, ph, pw, window};
+    return dispatch_attn(0, qkv, nullptr, out, lse, nullptr, nullptr, g, stream);
+}
+
+// dqkv[M,3C] = gradient of the attention core wrt the qkv rows; dsum [M,heads] is scratch
+LEOD_API int leod_partition_attn_bwd(const float* qkv, const float* dout, const float* lse, float* dsum, float* dqkv,
+                                     int B, int H, int W, int C, int heads, int ph, int pw, int window,
+                                     hipStream_t stream) {
+    if (!qkv || !dout || !lse || !dsum || !dqkv || heads <= 0) return LEOD_ERR_ARG;
+    AttnGeom g{B, H, W, C, heads, C / heads, ph, pw, window};
+    int rc = dispatch_attn(1, qkv, dout, nullptr, const_cast<float*>(lse), dsum, dqkv, g, stream);
+    if (rc != LEOD_OK) return rc;
+    return dispatch_attn(2, qkv, dout, nullptr, const_cast<float*>(lse), dsum, dqkv, g, stream);
+}

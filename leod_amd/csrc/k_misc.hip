@@ -1,0 +1,82 @@
+// Optimiser and input-side kernels of the LEOD path: fused value-clip + AdamW over the flat
+// parameter buffer (modules/detection.py:485-518, train.py:236-237) and the stacked-histogram event
+// voxelisation (data/utils/representations.py:78-123).
+#include "common.hpp"
+#pragma clang fp contract(off)
+
+// torch.optim.AdamW single-tensor update order: p *= 1 - lr*wd ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ;
+// denom = sqrt(v)/sqrt(bc2) + eps ; p -= (lr/bc1) * m / denom.  Gradients are clipped BY VALUE first.
+__global__ __launch_bounds__(256) void adamw_clip_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, long n, float lr, float beta1, float beta2,
+                                                         float eps, float wd, float bc1, float bc2_sqrt, float clip,
+                                                         float grad_scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float gi = g[i] * grad_scale;
+        if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+        float pi = p[i] * (1.f - lr * wd);
+        // exp_avg.lerp_(grad, 1 - beta1) ; exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+        const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+        const float vi = v[i] * beta2 + (1.f - beta2) * (gi * gi);
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi = pi - (lr / bc1) * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi; g[i] = gi;
+    }
+}
+
+LEOD_API int leod_adamw_clip_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                                  float eps, float weight_decay, int step, float clip_value, float grad_scale,
+                                  hipStream_t stream) {
+    if (!p || !g || !m || !v || step < 1) return LEOD_ERR_ARG;
+    if (n == 0) return LEOD_OK;
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+    const int grid = (int)min((long)2048, (n + 255) / 256);
+    hipLaunchKernelGGL(adamw_clip_kernel, dim3(grid), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                       bc1, sqrtf(bc2), clip_value, grad_scale);
+    return leod_launch_status();
+}
+
+// ---- stacked histogram ---------------------------------------------------------------------------
+// counts[2*bins*H*W] (int32, zeroed by the caller) <- events ; then uint8 = clamp(wrap(counts), 0, cutoff)
+__global__ __launch_bounds__(256) void voxel_count_kernel(const long* __restrict__ x, const long* __restrict__ y,
+                                                          const long* __restrict__ pol, const long* __restrict__ t,
+                                                          int* __restrict__ counts, long n, int bins, int H, int W) {
+    const long t0 = t[0], t1 = t[n - 1];
+    const float denom = (float)max(t1 - t0, 1L);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        // reference: (time - t0) [int64] / max(t1-t0, 1) -> true division in fp32, * bins, floor, clamp
+        float tn = (float)(t[i] - t0) / denom;
+        tn = tn * (float)bins;
+        long ti = (long)floorf(tn);
+        if (ti > bins - 1) ti = bins - 1;
+        const long idx = x[i] + (long)W * y[i] + (long)H * W * ti + (long)bins * H * W * pol[i];
+        atomicAdd(counts + idx, 1);
+    }
+}
+__global__ __launch_bounds__(256) void voxel_finalize_kernel(const int* __restrict__ counts, unsigned char* __restrict__ out,
+                                                             long n, int cutoff, int fastmode) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int c = counts[i];
+        if (fastmode) c &= 255;                                  // uint8 accumulation wraps
+        else { c = (int)(short)(c & 0xffff); if (c < 0) c = 0; }  // int16 accumulation, clamp(min=0)
+        out[i] = (unsigned char)min(c, cutoff);
+    }
+}
+
+LEOD_API int leod_voxelize_u8(const long* x, const long* y, const long* pol, const long* t, long n_events, int* counts_ws,
+                              unsigned char* out, int bins, int H, int W, int count_cutoff, int fastmode, hipStream_t stream) {
+    if (!counts_ws || !out || bins < 1) return LEOD_ERR_ARG;
+    const long n = 2L * bins * H * W;
+    if (hipMemsetAsync(counts_ws, 0, n * sizeof(int), stream) != hipSuccess) return LEOD_ERR_LAUNCH;
+    if (n_events > 0) {
+        if (!x || !y || !pol || !t) return LEOD_ERR_ARG;
+        hipLaunchKernelGGL(voxel_count_kernel, dim3((int)min((long)2048, (n_events + 255) / 256)), dim3(256), 0, stream, x, y, pol,
+                           t, counts_ws, n_events, bins, H, W);
+    }
+    const int cutoff = count_cutoff <= 0 ? 255 : min(count_cutoff, 255);
+    hipLaunchKernelGGL(voxel_finalize_kernel, dim3((int)min((long)2048, (n + 255) / 256)), dim3(256), 0, stream, counts_ws, out, n,
+                       cutoff, fastmode);
+    return leod_launch_status();
+}
+
+LEOD_API const char* leod_version() { return "leod_hip 0.1 (gfx950)"; }

@@ -1,0 +1,371 @@
+// Row-wise normalisation / pointwise kernels of the LEOD path: LayerNorm fwd/bwd, LayerScale bwd,
+// ConvLSTM gate backward, BatchNorm(+SiLU) apply fwd/bwd.  fp32, channels-last rows.
+// These are pure HBM-streaming kernels: 16-byte accesses, 16 lanes per row (4 rows per wave) so that
+// C = 32..512 channel rows keep most lanes busy, per-column partial sums kept in registers and
+// flushed with one atomic per column per workgroup.
+#include "common.hpp"
+
+#define MAXCJ 8          // C <= 512
+
+// lane (i = l&15, rg = l>>4) of wave w handles row = base + rg and channels 4i + 64j .. +3
+template <int CJ>
+struct RowIter {
+    int lane, wave, i, rg;
+    __device__ RowIter() { lane = threadIdx.x & 63; wave = threadIdx.x >> 6; i = lane & 15; rg = lane >> 4; }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm forward (after the downsample conv): y = (x-mean)*rstd*w + b ; stats[M,2] = (mean, rstd)
+// Reference: models/layers/maxvit/maxvit.py:172-178 (timm LayerNorm, eps 1e-5)
+// ---------------------------------------------------------------------------------------------------
+template <int CJ>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ b, float* __restrict__ y,
+                                                     float* __restrict__ stats, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, rg = lane >> 4;
+    for (long base = ((long)blockIdx.x * 4 + wave) * 4; base < M; base += (long)gridDim.x * 16) {
+        const long row = base + rg;
+        const bool rok = row < M;
+        f4 v[CJ];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const int c = 4 * i + 64 * j;
+            v[j] = (rok && c < C) ? ld4(x + row * C + c) : zero4();
+            sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+        const float mean = row16_sum(sum) / (float)C;
+        float var = 0.f;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const int c = 4 * i + 64 * j;
+            if (c < C) { const f4 d = v[j] - mean; var += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
+        }
+        const float rstd = rsqrtf(row16_sum(var) / (float)C + eps);
+        if (!rok) continue;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const int c = 4 * i + 64 * j;
+            if (c < C) *reinterpret_cast<f4*>(y + row * C + c) = (v[j] - mean) * rstd * ld4(w + c) + ld4(b + c);
+        }
+        if (stats && i == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm backward: dx = rstd*(g - mean(g) - xhat*mean(g*xhat)) (+ dres), g = dn*w ;
+// dw += sum_m dn*xhat ; db += sum_m dn.   stats may be NULL (recomputed from x).
+// ---------------------------------------------------------------------------------------------------
+template <int CJ>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dn, const float* __restrict__ x,
+                                                     const float* __restrict__ stats, const float* __restrict__ w,
+                                                     const float* __restrict__ dres, float* __restrict__ dx,
+                                                     float* __restrict__ dw, float* __restrict__ db, int M, int C, float eps) {
+    __shared__ float red[2][4][CJ * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, rg = lane >> 4;
+    f4 aw[CJ], ab[CJ];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) { aw[j] = zero4(); ab[j] = zero4(); }
+    for (long base = ((long)blockIdx.x * 4 + wave) * 4; base < M; base += (long)gridDim.x * 16) {
+        const long row = base + rg;
+        const bool rok = row < M;
+        f4 xv[CJ], gv[CJ];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const int c = 4 * i + 64 * j;
+            xv[j] = (rok && c < C) ? ld4(x + row * C + c) : zero4();
+            sum += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
+        }
+        float mean, rstd;
+        if (stats) { mean = rok ? stats[2 * row] : 0.f; rstd = rok ? stats[2 * row + 1] : 0.f; }
+        else {
+            mean = row16_sum(sum) / (float)C;
+            float var = 0.f;
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) {
+                const int c = 4 * i + 64 * j;
+                if (c < C) { const f4 d = xv[j] - mean; var += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
+            }
+            rstd = rsqrtf(row16_sum(var) / (float)C + eps);
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const int c = 4 * i + 64 * j;
+            if (rok && c < C) {
+                const f4 d = ld4(dn + row * C + c);
+                const f4 xh = (xv[j] - mean) * rstd;
+                xv[j] = xh;
+                gv[j] = d * ld4(w + c);
+                aw[j] += d * xh; ab[j] += d;
+                s1 += (gv[j].x + gv[j].y) + (gv[j].z + gv[j].w);
+                const f4 gx = gv[j] * xh;
+                s2 += (gx.x + gx.y) + (gx.z + gx.w);
+            } else { gv[j] = zero4(); xv[j] = zero4(); }
+        }
+        s1 = row16_sum(s1) / (float)C;
+        s2 = row16_sum(s2) / (float)C;
+        if (!rok) continue;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const int c = 4 * i + 64 * j;
+            if (c < C) {
+                f4 r = (gv[j] - s1 - xv[j] * s2) * rstd;
+                if (dres) r += ld4(dres + row * C + c);
+                *reinterpret_cast<f4*>(dx + row * C + c) = r;
+            }
+        }
+    }
+    // column sums: over rg within the wave, then over the 4 waves through LDS, then one atomic per column
+#pragma unroll
+    for (int j = 0; j < CJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = quad16_sum(aw[j][e]), bsum = quad16_sum(ab[j][e]);
+            if (rg == 0) { red[0][wave][j * 64 + 4 * i + e] = a; red[1][wave][j * 64 + 4 * i + e] = bsum; }
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < CJ * 64; c += 256) {
+        if (c < C) {
+            atomicAdd(dw + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+            atomicAdd(db + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerScale backward: dt = gamma * dz ; dgamma += sum_m dz * t      (maxvit.py:51-53, :268-269)
+// ---------------------------------------------------------------------------------------------------
+template <int CJ>
+__global__ __launch_bounds__(256) void ls_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ t,
+                                                     const float* __restrict__ gamma, float* __restrict__ dt,
+                                                     float* __restrict__ dgamma, int M, int C) {
+    __shared__ float red[4][CJ * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, rg = lane >> 4;
+    f4 ag[CJ];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) ag[j] = zero4();
+    for (long base = ((long)blockIdx.x * 4 + wave) * 4; base < M; base += (long)gridDim.x * 16) {
+        const long row = base + rg;
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const int c = 4 * i + 64 * j;
+            if (c < C) {
+                const f4 d = ld4(dz + row * C + c);
+                ag[j] += d * ld4(t + row * C + c);
+                *reinterpret_cast<f4*>(dt + row * C + c) = d * ld4(gamma + c);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = quad16_sum(ag[j][e]);
+            if (rg == 0) red[wave][j * 64 + 4 * i + e] = a;
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < CJ * 64; c += 256)
+        if (c < C) atomicAdd(dgamma + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ConvLSTM gate backward (models/layers/rnn.py:58-68): from dh (total grad of h_t) and dc_next to
+// pre-activation gate grads [M,4,C] and dc_prev.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dc_next,
+                                                             const float* __restrict__ gates, const float* __restrict__ c_prev,
+                                                             const float* __restrict__ c_t, float* __restrict__ dgates,
+                                                             float* __restrict__ dc_prev, long M, int C) {
+    const long n4 = M * C / 4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
+        const long e = idx * 4;
+        const long row = e / C; const int c = (int)(e - row * C);
+        const float* gp = gates + row * 4 * C + c;
+        const f4 f = ld4(gp), ig = ld4(gp + C), o = ld4(gp + 2 * C), g = ld4(gp + 3 * C);
+        const f4 ct = ld4(c_t + e);
+        f4 th; th.x = tanhf(ct.x); th.y = tanhf(ct.y); th.z = tanhf(ct.z); th.w = tanhf(ct.w);
+        const f4 dhv = dh ? ld4(dh + e) : zero4();
+        f4 dc = dhv * o * (1.0f - th * th);
+        if (dc_next) dc += ld4(dc_next + e);
+        const f4 cp = c_prev ? ld4(c_prev + e) : zero4();
+        float* dg = dgates + row * 4 * C + c;
+        *reinterpret_cast<f4*>(dg) = dc * cp * f * (1.0f - f);
+        *reinterpret_cast<f4*>(dg + C) = dc * g * ig * (1.0f - ig);
+        *reinterpret_cast<f4*>(dg + 2 * C) = dhv * th * o * (1.0f - o);
+        *reinterpret_cast<f4*>(dg + 3 * C) = dc * ig * (1.0f - g * g);
+        if (dc_prev) *reinterpret_cast<f4*>(dc_prev + e) = dc * f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// BatchNorm2d (training statistics) + SiLU, channels-last rows  (network_blocks.py:29-51)
+//   fwd : colstats[2][N] (double sum, sumsq from the conv epilogue) -> mean / biased var ;
+//         y = silu((z-mean)*rstd*w + b) ; block 0 stores save_mean/save_rstd and updates the running buffers
+//   bwd1: sums[0][n] = sum du, sums[1][n] = sum du*xhat   with du = dy * silu'(u)
+//   bwd2: dz = w*rstd*(du - sums0/M - xhat*sums1/M) ; block 0: dw += sums1, db += sums0
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const float* __restrict__ z, const double* __restrict__ colstats,
+                                                          const float* __restrict__ w, const float* __restrict__ b,
+                                                          float* __restrict__ y, float* __restrict__ save_mean,
+                                                          float* __restrict__ save_rstd, float* __restrict__ run_mean,
+                                                          float* __restrict__ run_var, long M, int N, double count,
+                                                          float eps, float momentum) {
+    const long n4 = M * N / 4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
+        const long e = idx * 4; const int c = (int)(e % N);
+        f4 v = ld4(z + e), r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double mean = colstats[c + k] / count;
+            const double var = fmax(colstats[N + c + k] / count - mean * mean, 0.0);
+            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+            r[k] = siluf_((v[k] - (float)mean) * rstd * w[c + k] + b[c + k]);
+        }
+        *reinterpret_cast<f4*>(y + e) = r;
+    }
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < N; c += blockDim.x) {
+            const double mean = colstats[c] / count;
+            const double var = fmax(colstats[N + c] / count - mean * mean, 0.0);
+            save_mean[c] = (float)mean;
+            save_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+            if (run_mean) {
+                const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+                run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+                run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 const float* __restrict__ w, const float* __restrict__ b,
+                                                                 double* __restrict__ sums, long M, int N) {
+    // thread t owns 4 consecutive channels c0 = 4*(t % (N/4)) and strides over rows
+    const int ncg = N / 4;
+    const int cg = threadIdx.x % ncg;
+    const int rlane = threadIdx.x / ncg, rstep = blockDim.x / ncg;
+    if (rlane >= rstep) return;
+    const int c = 4 * cg;
+    const f4 mu = ld4(mean + c), rs = ld4(rstd + c), ww = ld4(w + c), bb = ld4(b + c);
+    f4 s0 = zero4(), s1 = zero4();
+    for (long row = (long)blockIdx.x * rstep + rlane; row < M; row += (long)gridDim.x * rstep) {
+        const f4 xh = (ld4(z + row * N + c) - mu) * rs;
+        const f4 u = xh * ww + bb;
+        f4 du = ld4(dy + row * N + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) du[k] *= silu_grad(u[k]);
+        s0 += du; s1 += du * xh;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { atomicAdd(sums + c + k, (double)s0[k]); atomicAdd(sums + N + c + k, (double)s1[k]); }
+}
+
+__global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ w, const float* __restrict__ b,
+                                                                const double* __restrict__ sums, float* __restrict__ dz,
+                                                                float* __restrict__ dw, float* __restrict__ db, long M, int N,
+                                                                double count) {
+    const long n4 = M * N / 4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
+        const long e = idx * 4; const int c = (int)(e % N);
+        const f4 mu = ld4(mean + c), rs = ld4(rstd + c), ww = ld4(w + c), bb = ld4(b + c);
+        const f4 xh = (ld4(z + e) - mu) * rs;
+        const f4 u = xh * ww + bb;
+        f4 du = ld4(dy + e), r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            du[k] *= silu_grad(u[k]);
+            const float m0 = (float)(sums[c + k] / count), m1 = (float)(sums[N + c + k] / count);
+            r[k] = ww[k] * rs[k] * (du[k] - m0 - xh[k] * m1);
+        }
+        *reinterpret_cast<f4*>(dz + e) = r;
+    }
+    if (blockIdx.x == 0 && dw)
+        for (int c = threadIdx.x; c < N; c += blockDim.x) { dw[c] += (float)sums[N + c]; db[c] += (float)sums[c]; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+#define DISPATCH_CJ(C, ...)                                              \
+    do {                                                                 \
+        const int cj_ = ((C) + 63) / 64;                                 \
+        if (cj_ <= 1) { constexpr int CJ = 1; __VA_ARGS__; }             \
+        else if (cj_ <= 2) { constexpr int CJ = 2; __VA_ARGS__; }        \
+        else if (cj_ <= 3) { constexpr int CJ = 3; __VA_ARGS__; }        \
+        else if (cj_ <= 4) { constexpr int CJ = 4; __VA_ARGS__; }        \
+        else if (cj_ <= 6) { constexpr int CJ = 6; __VA_ARGS__; }        \
+        else { constexpr int CJ = 8; __VA_ARGS__; }                      \
+    } while (0)
+
+static inline int row_grid(long M) { return (int)min((long)2048, max((long)1, (M + 15) / 16)); }
+static inline int flat_grid(long n) { return (int)min((long)4096, max((long)1, (n + 255) / 256)); }
+
+LEOD_API int leod_layernorm_fwd(const float* x, const float* w, const float* b, float* y, float* stats, int M, int C,
+                                float eps, hipStream_t stream) {
+    if (!x || !w || !b || !y || (C & 3) || C > 64 * MAXCJ) return LEOD_ERR_ARG;
+    if (M <= 0) return LEOD_OK;
+    DISPATCH_CJ(C, hipLaunchKernelGGL((ln_fwd_kernel<CJ>), dim3(row_grid(M)), dim3(256), 0, stream, x, w, b, y, stats, M, C, eps));
+    return leod_launch_status();
+}
+
+LEOD_API int leod_layernorm_bwd(const float* dn, const float* x, const float* stats, const float* w, const float* dres,
+                                float* dx, float* dw, float* db, int M, int C, float eps, hipStream_t stream) {
+    if (!dn || !x || !w || !dx || !dw || !db || (C & 3) || C > 64 * MAXCJ) return LEOD_ERR_ARG;
+    if (M <= 0) return LEOD_OK;
+    const int grid = min(row_grid(M), 512);
+    DISPATCH_CJ(C, hipLaunchKernelGGL((ln_bwd_kernel<CJ>), dim3(grid), dim3(256), 0, stream, dn, x, stats, w, dres, dx, dw, db, M, C, eps));
+    return leod_launch_status();
+}
+
+LEOD_API int leod_layerscale_bwd(const float* dz, const float* t, const float* gamma, float* dt, float* dgamma, int M,
+                                 int C, hipStream_t stream) {
+    if (!dz || !t || !gamma || !dt || !dgamma || (C & 3) || C > 64 * MAXCJ) return LEOD_ERR_ARG;
+    if (M <= 0) return LEOD_OK;
+    const int grid = min(row_grid(M), 512);
+    DISPATCH_CJ(C, hipLaunchKernelGGL((ls_bwd_kernel<CJ>), dim3(grid), dim3(256), 0, stream, dz, t, gamma, dt, dgamma, M, C));
+    return leod_launch_status();
+}
+
+LEOD_API int leod_convlstm_gates_bwd(const float* dh, const float* dc_next, const float* gates, const float* c_prev,
+                                     const float* c_t, float* dgates, float* dc_prev, int M, int C, hipStream_t stream) {
+    if (!gates || !c_t || !dgates || (C & 3)) return LEOD_ERR_ARG;
+    if (M <= 0) return LEOD_OK;
+    hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(flat_grid((long)M * C / 4)), dim3(256), 0, stream, dh, dc_next, gates,
+                       c_prev, c_t, dgates, dc_prev, (long)M, C);
+    return leod_launch_status();
+}
+
+LEOD_API int leod_bn_silu_fwd(const float* z, const double* colstats, const float* w, const float* b, float* y,
+                              float* save_mean, float* save_rstd, float* run_mean, float* run_var, int M, int N,
+                              double count, float eps, float momentum, hipStream_t stream) {
+    if (!z || !colstats || !w || !b || !y || !save_mean || !save_rstd || (N & 3)) return LEOD_ERR_ARG;
+    if (M <= 0) return LEOD_OK;
+    hipLaunchKernelGGL(bn_silu_fwd_kernel, dim3(flat_grid((long)M * N / 4)), dim3(256), 0, stream, z, colstats, w, b, y,
+                       save_mean, save_rstd, run_mean, run_var, (long)M, N, count, eps, momentum);
+    return leod_launch_status();
+}
+
+LEOD_API int leod_bn_silu_bwd_reduce(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
+                                     const float* b, double* sums, int M, int N, hipStream_t stream) {
+    if (!dy || !z || !mean || !rstd || !w || !b || !sums || (N & 3) || N / 4 > 256) return LEOD_ERR_ARG;
+    if (M <= 0) return LEOD_OK;
+    const int rstep = 256 / (N / 4);
+    const int grid = (int)min((long)256, max((long)1, ((long)M + rstep * 8 - 1) / (rstep * 8)));
+    hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3(grid), dim3(256), 0, stream, dy, z, mean, rstd, w, b, sums, (long)M, N);
+    return leod_launch_status();
+}
+
+LEOD_API int leod_bn_silu_bwd_apply(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
+                                    const float* b, const double* sums, float* dz, float* dw, float* db, int M, int N,
+                                    double count, hipStream_t stream) {
+    if (!dy || !z || !mean || !rstd || !w || !b || !sums || !dz || (N & 3)) return LEOD_ERR_ARG;
+    if (M <= 0) return LEOD_OK;
+    hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(flat_grid((long)M * N / 4)), dim3(256), 0, stream, dy, z, mean, rstd,
+                       w, b, sums, dz, dw, db, (long)M, N, count);
+    return leod_launch_status();
+}

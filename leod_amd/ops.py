@@ -1,0 +1,416 @@
+"""Thin tensor-level wrappers over the C ABI (include/leod_hip.h).
+
+PyTorch is used here only as plumbing: device memory (``torch.empty``), the current HIP stream and
+shape bookkeeping.  All arithmetic happens in libleod_hip.so; there is no fallback path -- every
+function raises if its input is not a contiguous fp32 CUDA(HIP) tensor or the library is missing.
+
+Convention: activations are channels-last.  2-D ``[M, C]`` "rows" and 4-D ``[B, H, W, C]`` maps are the
+same memory.
+"""
+from typing import Optional, Sequence, Tuple
+
+import ctypes
+
+import torch
+
+from ._lib import lib, check, LeodHipError
+
+F32 = torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _ck(t: Optional[torch.Tensor], dtype=F32, name='tensor'):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise LeodHipError(f'{name}: the LEOD HIP path needs device tensors (got {t.device}); there is no CPU fallback')
+    if t.dtype != dtype:
+        raise LeodHipError(f'{name}: expected {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise LeodHipError(f'{name}: expected a contiguous tensor, got strides {t.stride()}')
+
+
+def _empty(shape, like: torch.Tensor, dtype=F32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# ---------------------------------------------------------------------------------------------------
+# backbone pieces
+# ---------------------------------------------------------------------------------------------------
+def ln_linear_fwd(x, ln_w, ln_b, W, bias, want_act=False, want_stats=False, eps=1e-5):
+    """x [.., K] -> out [.., N] = LN(x) W^T + b ; optional gelu(out), LN stats [M,2]."""
+    for t, n in ((x, 'x'), (ln_w, 'ln_w'), (ln_b, 'ln_b'), (W, 'W'), (bias, 'bias')):
+        _ck(t, name=n)
+    K = x.shape[-1]
+    N = W.shape[0]
+    M = x.numel() // K
+    out = _empty(x.shape[:-1] + (N,), x)
+    act = _empty(out.shape, x) if want_act else None
+    stats = _empty((M, 2), x) if (want_stats and ln_w is not None) else None
+    check(lib().leod_ln_linear_fwd(_p(x), K, _p(ln_w), _p(ln_b), eps, _p(W), _p(bias), _p(out), _p(act), _p(stats),
+                                   M, N, K, _stream()), 'ln_linear_fwd')
+    return out, act, stats
+
+
+def linear_lsres_fwd(a, W, bias, gamma, res, want_t=True):
+    """out = res + gamma * (a W^T + b); also returns t = a W^T + b when want_t."""
+    for t, n in ((a, 'a'), (W, 'W'), (bias, 'bias'), (gamma, 'gamma'), (res, 'res')):
+        _ck(t, name=n)
+    K = a.shape[-1]
+    N = W.shape[0]
+    M = a.numel() // K
+    out = _empty(res.shape, a)
+    tout = _empty(res.shape, a) if want_t else None
+    check(lib().leod_linear_lsres_fwd(_p(a), _p(W), _p(bias), _p(gamma), _p(res), _p(out), _p(tout), M, N, K,
+                                      _stream()), 'linear_lsres_fwd')
+    return out, tout
+
+
+def partition_attn_fwd(qkv, heads, part, window, want_lse=False):
+    """qkv [B,H,W,3C] -> out [B,H,W,C] (+ lse [B,H,W,heads])."""
+    _ck(qkv, name='qkv')
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    out = _empty((B, H, W, C), qkv)
+    lse = _empty((B, H, W, heads), qkv) if want_lse else None
+    check(lib().leod_partition_attn_fwd(_p(qkv), _p(out), _p(lse), B, H, W, C, heads, part[0], part[1],
+                                        1 if window else 0, _stream()), 'partition_attn_fwd')
+    return out, lse
+
+
+def partition_attn_bwd(qkv, dout, lse, heads, part, window):
+    for t, n in ((qkv, 'qkv'), (dout, 'dout'), (lse, 'lse')):
+        _ck(t, name=n)
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    dqkv = _empty(qkv.shape, qkv)
+    dsum = _empty(lse.shape, qkv)
+    check(lib().leod_partition_attn_bwd(_p(qkv), _p(dout), _p(lse), _p(dsum), _p(dqkv), B, H, W, C, heads, part[0],
+                                        part[1], 1 if window else 0, _stream()), 'partition_attn_bwd')
+    return dqkv
+
+
+def convlstm_fwd(x, h_prev, c_prev, W, bias, want_gates=False):
+    """x/h_prev/c_prev [..,C] channels-last rows; W [4C,2C]; -> h, c, gates[M,4,C]."""
+    for t, n in ((x, 'x'), (h_prev, 'h_prev'), (c_prev, 'c_prev'), (W, 'W'), (bias, 'bias')):
+        _ck(t, name=n)
+    C = x.shape[-1]
+    M = x.numel() // C
+    h = _empty(x.shape, x)
+    c = _empty(x.shape, x)
+    gates = _empty((M, 4, C), x) if want_gates else None
+    check(lib().leod_convlstm_fwd(_p(x), _p(h_prev), _p(c_prev), _p(W), _p(bias), _p(h), _p(c), _p(gates), M, C,
+                                  _stream()), 'convlstm_fwd')
+    return h, c, gates
+
+
+def convlstm_gates_bwd(dh, dc_next, gates, c_prev, c_t, want_dc_prev=True):
+    for t, n in ((dh, 'dh'), (dc_next, 'dc_next'), (gates, 'gates'), (c_prev, 'c_prev'), (c_t, 'c_t')):
+        _ck(t, name=n)
+    M, _, C = gates.shape
+    dgates = _empty((M, 4 * C), gates)
+    dc_prev = _empty(c_t.shape, gates) if want_dc_prev else None
+    check(lib().leod_convlstm_gates_bwd(_p(dh), _p(dc_next), _p(gates), _p(c_prev), _p(c_t), _p(dgates), _p(dc_prev),
+                                        M, C, _stream()), 'convlstm_gates_bwd')
+    return dgates, dc_prev
+
+
+def linear_dgrad(dy, W, kscale=None, aux_u=None, colsum=None, out=None, accumulate=False, split=0, out2=None):
+    """dx = (dy * kscale) @ W  with W [N,K]; see leod_linear_dgrad."""
+    for t, n in ((dy, 'dy'), (W, 'W'), (kscale, 'kscale'), (aux_u, 'aux_u'), (colsum, 'colsum'), (out, 'out'), (out2, 'out2')):
+        _ck(t, name=n)
+    N, K = W.shape[0], W.shape[1] if W.dim() == 2 else W.numel() // W.shape[0]
+    M = dy.numel() // N
+    if split:
+        if out is None:
+            out = _empty(dy.shape[:-1] + (split,), dy)
+        if out2 is None:
+            out2 = _empty(dy.shape[:-1] + (K - split,), dy)
+        ld1, ld2 = split, K - split
+    else:
+        if out is None:
+            out = _empty(dy.shape[:-1] + (K,), dy)
+        ld1, ld2 = K, 0
+    check(lib().leod_linear_dgrad(_p(dy), N, _p(kscale), _p(W), _p(out), ld1, _p(out2), ld2, split, _p(aux_u),
+                                  _p(colsum), 1 if accumulate else 0, M, N, K, _stream()), 'linear_dgrad')
+    return (out, out2) if split else out
+
+
+def linear_wgrad(dy, x, dW, dbias=None, stats=None, ln_w=None, ln_b=None, x2=None):
+    """dW += dy^T X ; dbias += colsum(dy).  X = x | LN(x) | [x|x2]."""
+    for t, n in ((dy, 'dy'), (x, 'x'), (dW, 'dW'), (dbias, 'dbias'), (stats, 'stats'), (ln_w, 'ln_w'), (ln_b, 'ln_b'), (x2, 'x2')):
+        _ck(t, name=n)
+    N = dW.shape[0]
+    K = dW.numel() // N
+    M = dy.numel() // N
+    K1 = x.shape[-1]
+    check(lib().leod_linear_wgrad(_p(dy), N, _p(x), K1, _p(stats), _p(ln_w), _p(ln_b), _p(x2),
+                                  (x2.shape[-1] if x2 is not None else 0), K1, _p(dW), _p(dbias), M, N, K, _stream()),
+          'linear_wgrad')
+
+
+def layernorm_fwd(x, w, b, want_stats=False, eps=1e-5):
+    for t, n in ((x, 'x'), (w, 'w'), (b, 'b')):
+        _ck(t, name=n)
+    C = x.shape[-1]
+    M = x.numel() // C
+    y = _empty(x.shape, x)
+    stats = _empty((M, 2), x) if want_stats else None
+    check(lib().leod_layernorm_fwd(_p(x), _p(w), _p(b), _p(y), _p(stats), M, C, eps, _stream()), 'layernorm_fwd')
+    return y, stats
+
+
+def layernorm_bwd(dn, x, stats, w, dres, dw, db, eps=1e-5):
+    for t, n in ((dn, 'dn'), (x, 'x'), (stats, 'stats'), (w, 'w'), (dres, 'dres'), (dw, 'dw'), (db, 'db')):
+        _ck(t, name=n)
+    C = x.shape[-1]
+    M = x.numel() // C
+    dx = _empty(x.shape, x)
+    check(lib().leod_layernorm_bwd(_p(dn), _p(x), _p(stats), _p(w), _p(dres), _p(dx), _p(dw), _p(db), M, C, eps,
+                                   _stream()), 'layernorm_bwd')
+    return dx
+
+
+def layerscale_bwd(dz, t, gamma, dgamma):
+    for tt, n in ((dz, 'dz'), (t, 't'), (gamma, 'gamma'), (dgamma, 'dgamma')):
+        _ck(tt, name=n)
+    C = dz.shape[-1]
+    M = dz.numel() // C
+    dt = _empty(dz.shape, dz)
+    check(lib().leod_layerscale_bwd(_p(dz), _p(t), _p(gamma), _p(dt), _p(dgamma), M, C, _stream()), 'layerscale_bwd')
+    return dt
+
+
+# ---------------------------------------------------------------------------------------------------
+# convolutions
+# ---------------------------------------------------------------------------------------------------
+def _out_hw(H, W, ks, stride, pad):
+    return (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+
+
+def stem_conv_fwd(x_nchw, w, padded_hw, stride, pad):
+    """x [B,Cin,H,W] uint8|fp32 NCHW (unpadded) -> y [B,Ho,Wo,N] NHWC."""
+    if x_nchw.dtype not in (torch.uint8, F32):
+        raise LeodHipError(f'stem input must be uint8 or float32, got {x_nchw.dtype}')
+    _ck(x_nchw, x_nchw.dtype, 'x')
+    _ck(w, name='w')
+    B, Cin, H, W = x_nchw.shape
+    N, ks = w.shape[0], w.shape[-1]
+    Ho, Wo = _out_hw(padded_hw[0], padded_hw[1], ks, stride, pad)
+    y = torch.empty((B, Ho, Wo, N), dtype=F32, device=x_nchw.device)
+    check(lib().leod_stem_conv_fwd(_p(x_nchw), 1 if x_nchw.dtype == torch.uint8 else 0, _p(w), _p(y), B, Cin, H, W,
+                                   padded_hw[0], padded_hw[1], N, ks, stride, pad, _stream()), 'stem_conv_fwd')
+    return y
+
+
+def stem_conv_wgrad(dy, x_nchw, dw, padded_hw, stride, pad):
+    _ck(dy, name='dy')
+    _ck(x_nchw, x_nchw.dtype, 'x')
+    _ck(dw, name='dw')
+    B, Cin, H, W = x_nchw.shape
+    N, ks = dw.shape[0], dw.shape[-1]
+    check(lib().leod_stem_conv_wgrad(_p(dy), _p(x_nchw), 1 if x_nchw.dtype == torch.uint8 else 0, _p(dw), B, Cin, H, W,
+                                     padded_hw[0], padded_hw[1], N, ks, stride, pad, _stream()), 'stem_conv_wgrad')
+
+
+def conv_nhwc_fwd(x, w, bias=None, stride=1, colstats=None, bn=None, bn_eps=1e-5):
+    """x [B,H,W,Cin] -> y [B,Ho,Wo,N]; pad = (ks-1)//2.  bn = (weight, bias, running_mean, running_var) -> eval BN+SiLU fused."""
+    _ck(x, name='x')
+    _ck(w, name='w')
+    _ck(bias, name='bias')
+    _ck(colstats, torch.float64, 'colstats')
+    B, H, W, Cin = x.shape
+    N, ks = w.shape[0], w.shape[-1]
+    pad = (ks - 1) // 2
+    Ho, Wo = _out_hw(H, W, ks, stride, pad)
+    y = _empty((B, Ho, Wo, N), x)
+    bw = bb = brm = brv = None
+    if bn is not None:
+        bw, bb, brm, brv = bn
+        for t in bn:
+            _ck(t, name='bn')
+    check(lib().leod_conv_nhwc_fwd(_p(x), _p(w), _p(bias), _p(y), _p(colstats), _p(bw), _p(bb), _p(brm), _p(brv), bn_eps,
+                                   B, H, W, Cin, N, ks, stride, pad, _stream()), 'conv_nhwc_fwd')
+    return y
+
+
+def conv_nhwc_dgrad(dy, w, x_shape, stride=1, out=None, accumulate=False):
+    _ck(dy, name='dy')
+    _ck(w, name='w')
+    B, H, W, Cin = x_shape
+    N, ks = w.shape[0], w.shape[-1]
+    pad = (ks - 1) // 2
+    if out is None:
+        out = _empty(tuple(x_shape), dy)
+        accumulate = False
+    _ck(out, name='dx')
+    check(lib().leod_conv_nhwc_dgrad(_p(dy), _p(w), _p(out), 1 if accumulate else 0, B, H, W, Cin, N, ks, stride, pad,
+                                     _stream()), 'conv_nhwc_dgrad')
+    return out
+
+
+def conv_nhwc_wgrad(dy, x, dw, dbias=None, stride=1):
+    for t, n in ((dy, 'dy'), (x, 'x'), (dw, 'dw'), (dbias, 'dbias')):
+        _ck(t, name=n)
+    B, H, W, Cin = x.shape
+    N, ks = dw.shape[0], dw.shape[-1]
+    pad = (ks - 1) // 2
+    check(lib().leod_conv_nhwc_wgrad(_p(dy), _p(x), _p(dw), _p(dbias), B, H, W, Cin, N, ks, stride, pad, _stream()),
+          'conv_nhwc_wgrad')
+
+
+def bn_silu_fwd(z, colstats, w, b, run_mean, run_var, count, eps=1e-5, momentum=0.1):
+    _ck(z, name='z')
+    _ck(colstats, torch.float64, 'colstats')
+    N = z.shape[-1]
+    M = z.numel() // N
+    y = _empty(z.shape, z)
+    mean = _empty((N,), z)
+    rstd = _empty((N,), z)
+    check(lib().leod_bn_silu_fwd(_p(z), _p(colstats), _p(w), _p(b), _p(y), _p(mean), _p(rstd), _p(run_mean), _p(run_var),
+                                 M, N, float(count), eps, momentum, _stream()), 'bn_silu_fwd')
+    return y, mean, rstd
+
+
+def bn_silu_bwd_reduce(dy, z, mean, rstd, w, b):
+    _ck(dy, name='dy')
+    N = z.shape[-1]
+    M = z.numel() // N
+    sums = torch.zeros((2, N), dtype=torch.float64, device=z.device)
+    check(lib().leod_bn_silu_bwd_reduce(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(sums), M, N, _stream()),
+          'bn_silu_bwd_reduce')
+    return sums
+
+
+def bn_silu_bwd_apply(dy, z, mean, rstd, w, b, sums, dw, db, count):
+    N = z.shape[-1]
+    M = z.numel() // N
+    dz = _empty(z.shape, z)
+    check(lib().leod_bn_silu_bwd_apply(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(sums), _p(dz), _p(dw), _p(db),
+                                       M, N, float(count), _stream()), 'bn_silu_bwd_apply')
+    return dz
+
+
+# ---------------------------------------------------------------------------------------------------
+# head tail
+# ---------------------------------------------------------------------------------------------------
+def _iarr(v: Sequence[int]):
+    return (ctypes.c_int * len(v))(*[int(a) for a in v])
+
+
+def head_pred_fwd(cls_feat, reg_feat, cls_w, cls_b, reg_w, reg_b, obj_w, obj_b, out_train, out_infer, stride, a0):
+    for t in (cls_feat, reg_feat, cls_w, cls_b, reg_w, reg_b, obj_w, obj_b, out_train, out_infer):
+        _ck(t, name='head_pred')
+    B, h, w, Hd = cls_feat.shape
+    nc = cls_w.shape[0]
+    ref = out_train if out_train is not None else out_infer
+    A = ref.shape[1]
+    check(lib().leod_head_pred_fwd(_p(cls_feat), _p(reg_feat), _p(cls_w), _p(cls_b), _p(reg_w), _p(reg_b), _p(obj_w),
+                                   _p(obj_b), _p(out_train), _p(out_infer), B, h, w, Hd, nc, stride, a0, A, _stream()),
+          'head_pred_fwd')
+
+
+def head_pred_bwd(d_raw, cls_feat, reg_feat, cls_w, reg_w, obj_w, d_cls_w, d_cls_b, d_reg_w, d_reg_b, d_obj_w, d_obj_b, a0):
+    B, h, w, Hd = cls_feat.shape
+    nc = cls_w.shape[0]
+    A = d_raw.shape[1]
+    dcf = _empty(cls_feat.shape, cls_feat)
+    drf = _empty(reg_feat.shape, reg_feat)
+    check(lib().leod_head_pred_bwd(_p(d_raw), _p(cls_feat), _p(reg_feat), _p(cls_w), _p(reg_w), _p(obj_w), _p(dcf), _p(drf),
+                                   _p(d_cls_w), _p(d_cls_b), _p(d_reg_w), _p(d_reg_b), _p(d_obj_w), _p(d_obj_b), B, h, w,
+                                   Hd, nc, a0, A, _stream()), 'head_pred_bwd')
+    return dcf, drf
+
+
+def simota_assign(outputs, labels, hws, strides, ignore_label=1024.0):
+    """outputs [B,A,5+nc] decoded+logits, labels [B,Nmax,7] -> dict of device tensors (no host sync)."""
+    _ck(outputs, name='outputs')
+    _ck(labels, name='labels')
+    B, A, nch = outputs.shape
+    Nmax = labels.shape[1]
+    dev = outputs.device
+    ws = torch.empty(lib().leod_simota_workspace_floats(B, Nmax, A), dtype=F32, device=dev)
+    r = dict(fg_mask=torch.empty((B, A), dtype=torch.uint8, device=dev),
+             ignore_mask=torch.empty((B, A), dtype=torch.uint8, device=dev),
+             matched_row=torch.empty((B, A), dtype=torch.int32, device=dev),
+             matched_valid_idx=torch.empty((B, A), dtype=torch.int32, device=dev),
+             pred_iou=torch.empty((B, A), dtype=F32, device=dev),
+             num_fg_img=torch.empty((B,), dtype=torch.int32, device=dev),
+             totals=torch.zeros((3,), dtype=torch.int32, device=dev))
+    check(lib().leod_simota_assign(_p(outputs), _p(labels), _p(ws), _p(r['fg_mask']), _p(r['ignore_mask']),
+                                   _p(r['matched_row']), _p(r['matched_valid_idx']), _p(r['pred_iou']), _p(r['num_fg_img']),
+                                   _p(r['totals']), B, Nmax, nch - 5, len(hws), _iarr([h for h, _ in hws]),
+                                   _iarr([w for _, w in hws]), _iarr(strides), float(ignore_label), _stream()),
+          'simota_assign')
+    return r
+
+
+def yolox_loss(outputs, labels, assign, hws, strides, want_grad=True, focal=False, reg_weight=5.0, obj_weight=1.0,
+               cls_weight=1.0, grad_scale=1.0):
+    B, A, nch = outputs.shape
+    dev = outputs.device
+    sums = torch.zeros((3,), dtype=torch.float64, device=dev)
+    losses = torch.empty((6,), dtype=F32, device=dev)
+    d_raw = torch.empty_like(outputs) if want_grad else None
+    check(lib().leod_yolox_loss(_p(outputs), _p(labels), _p(assign['fg_mask']), _p(assign['ignore_mask']),
+                                _p(assign['matched_row']), _p(assign['pred_iou']), _p(assign['totals']), _p(sums), _p(losses),
+                                _p(d_raw), B, labels.shape[1], nch - 5, len(hws), _iarr([h for h, _ in hws]),
+                                _iarr([w for _, w in hws]), _iarr(strides), 1 if focal else 0, reg_weight, obj_weight,
+                                cls_weight, grad_scale, _stream()), 'yolox_loss')
+    return losses, d_raw
+
+
+def postprocess_nms(pred, num_classes, conf_thre, nms_thre, class_agnostic=False, max_det=None, vanilla_limit=20000):
+    """pred [B,A,5+nc] (mutated in place to xyxy) or, with num_classes=0, [B,A,7] xyxy rows.
+    -> det [B,max_det,7], cnt [B] (device tensors, no sync)."""
+    _ck(pred, name='pred')
+    B, A, _ = pred.shape
+    max_det = A if max_det is None else max_det
+    det = torch.empty((B, max_det, 7), dtype=F32, device=pred.device)
+    cnt = torch.empty((B,), dtype=torch.int32, device=pred.device)
+    check(lib().leod_postprocess_nms(_p(pred), _p(det), _p(cnt), B, A, num_classes, float(conf_thre), float(nms_thre),
+                                     1 if class_agnostic else 0, max_det, vanilla_limit, _stream()), 'postprocess_nms')
+    return det, cnt
+
+
+def pseudo_filter(det, cnt, obj_thr, cls_thr, filter_boxes, frame_hw):
+    _ck(det, name='det')
+    _ck(cnt, torch.int32, 'cnt')
+    B, max_det, _ = det.shape
+    ot = torch.as_tensor([obj_thr] if isinstance(obj_thr, float) else list(obj_thr), dtype=F32, device=det.device)
+    ct = torch.as_tensor([cls_thr] if isinstance(cls_thr, float) else list(cls_thr), dtype=F32, device=det.device)
+    if ot.numel() != ct.numel():
+        raise LeodHipError('obj_thresh and cls_thresh must both be floats or per-class lists of equal length')
+    lab = torch.empty((B, max_det, 8), dtype=F32, device=det.device)
+    lcnt = torch.empty((B,), dtype=torch.int32, device=det.device)
+    check(lib().leod_pseudo_filter(_p(det), _p(cnt), _p(lab), _p(lcnt), B, max_det, _p(ot), _p(ct), ot.numel(),
+                                   1 if filter_boxes else 0, float(frame_hw[1]), float(frame_hw[0]), _stream()),
+          'pseudo_filter')
+    return lab, lcnt
+
+
+# ---------------------------------------------------------------------------------------------------
+def adamw_clip_step(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_value=0.0, grad_scale=1.0):
+    for t in (p, g, m, v):
+        _ck(t, name='adamw buffer')
+    check(lib().leod_adamw_clip_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
+                                     int(step), float(clip_value), float(grad_scale), _stream()), 'adamw_clip_step')
+
+
+def voxelize_u8(x, y, pol, t, bins, height, width, count_cutoff=None, fastmode=True):
+    for a in (x, y, pol, t):
+        _ck(a, torch.int64, 'events')
+    dev = x.device
+    ws = torch.empty((2 * bins * height * width,), dtype=torch.int32, device=dev)
+    out = torch.empty((2 * bins, height, width), dtype=torch.uint8, device=dev)
+    check(lib().leod_voxelize_u8(_p(x), _p(y), _p(pol), _p(t), x.numel(), _p(ws), _p(out), bins, height, width,
+                                 0 if count_cutoff is None else int(count_cutoff), 1 if fastmode else 0, _stream()),
+          'voxelize_u8')
+    return out

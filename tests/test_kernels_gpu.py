@@ -1,0 +1,483 @@
+"""Parity of every hand-written HIP kernel (through the C ABI / leod_amd.ops) against the CPU oracle
+or a plain PyTorch fp32 CPU reference of the same op.  Needs a real MI355X: ``pytest -m gpu``.
+
+Tolerances: integer / index / byte outputs bit-exact; fp32 kernels 2e-5 relative (+ abs floor) for
+forward values, 2e-4 for gradients that are long reductions (weight grads accumulate over M rows
+with fp32 atomics in nondeterministic order)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import backbone as ob  # noqa: E402
+from oracle import head as oh  # noqa: E402
+from oracle import postproc as op  # noqa: E402
+from oracle.synth import synth_labels  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from leod_amd import ops as _ops
+    return _ops
+
+
+DEV = 'cuda'
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def close(a, b, rtol=2e-5, atol=2e-6, what=''):
+    a = a.detach().float().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().float().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K,ln,act', [(200, 144, 48, True, False), (333, 192, 48, True, True),
+                                          (64, 1152, 384, True, False), (130, 96, 32, False, False),
+                                          (77, 64, 16, True, True), (4096, 256, 64, True, True)])
+def test_ln_linear_fwd(ops, M, N, K, ln, act):
+    x, W, b = rnd((M, K), 1), rnd((N, K), 2, 0.2), rnd((N,), 3, 0.1)
+    lw, lb = 1 + 0.2 * rnd((K,), 4), 0.1 * rnd((K,), 5)
+    xn = F.layer_norm(x, (K,), lw, lb, 1e-5) if ln else x
+    ref = F.linear(xn, W, b)
+    out, a, st = ops.ln_linear_fwd(x.to(DEV), lw.to(DEV) if ln else None, lb.to(DEV) if ln else None, W.to(DEV),
+                                   b.to(DEV), want_act=act, want_stats=True)
+    close(out, ref, what='linear')
+    if act:
+        close(a, F.gelu(ref), what='gelu')
+    if ln:
+        close(st[:, 0], x.mean(1), atol=1e-6)
+        close(st[:, 1], 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-5), rtol=1e-5)
+
+
+@pytest.mark.parametrize('M,N,K', [(200, 48, 48), (129, 384, 1536), (64, 32, 128)])
+def test_linear_lsres_fwd(ops, M, N, K):
+    a, W, b, g, res = rnd((M, K), 1), rnd((N, K), 2, 0.2), rnd((N,), 3, 0.1), rnd((N,), 4), rnd((M, N), 5)
+    t = F.linear(a, W, b)
+    out, tt = ops.linear_lsres_fwd(a.to(DEV), W.to(DEV), b.to(DEV), g.to(DEV), res.to(DEV))
+    close(tt, t)
+    close(out, res + g * t)
+
+
+def _attn_ref(qkv, heads, part, window):
+    """attention core on [B,H,W,3C] via the oracle's partition helpers (maxvit.py:343-354)."""
+    B, H, W, C3 = qkv.shape
+    C = C3 // 3
+    d = C // heads
+    p = ob.window_partition(qkv, part) if window else ob.grid_partition(qkv, part)
+    Bp = p.shape[0]
+    q, k, v = p.reshape(Bp, -1, heads, 3 * d).transpose(1, 2).chunk(3, dim=3)
+    att = ((q @ k.transpose(-2, -1)) * d ** -0.5).softmax(-1)
+    o = (att @ v).transpose(1, 2).reshape(Bp, part[0], part[1], C)
+    return ob.window_reverse(o, part, (H, W)) if window else ob.grid_reverse(o, part, (H, W))
+
+
+@pytest.mark.parametrize('B,H,W,C,heads,part', [(2, 16, 20, 48, 2, (8, 10)), (1, 8, 10, 384, 16, (8, 10)),
+                                                (2, 4, 6, 16, 2, (2, 3)), (1, 12, 20, 64, 2, (6, 10)),
+                                                (3, 32, 40, 96, 4, (8, 10))])
+@pytest.mark.parametrize('window', [True, False])
+def test_partition_attn(ops, B, H, W, C, heads, part, window):
+    qkv = rnd((B, H, W, 3 * C), 7).requires_grad_(True)
+    ref = _attn_ref(qkv, heads, part, window)
+    dout = rnd(ref.shape, 8)
+    ref.backward(dout)
+    q = qkv.detach().to(DEV)
+    out, lse = ops.partition_attn_fwd(q, heads, part, window, want_lse=True)
+    close(out, ref, what='attn fwd')
+    dq = ops.partition_attn_bwd(q, dout.to(DEV), lse, heads, part, window)
+    close(dq, qkv.grad, rtol=5e-5, atol=5e-6, what='attn bwd')
+
+
+@pytest.mark.parametrize('M,C,state', [(160, 32, True), (160, 32, False), (70, 48, True), (640, 384, True)])
+def test_convlstm(ops, M, C, state):
+    x, h0, c0 = rnd((M, C), 1), rnd((M, C), 2, 0.5), rnd((M, C), 3, 0.5)
+    W, b = rnd((4 * C, 2 * C), 4, 0.15).requires_grad_(True), rnd((4 * C,), 5, 0.1).requires_grad_(True)
+    xr, hr, cr = x.clone().requires_grad_(True), h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+    sd = {'l.conv1x1.weight': W.view(4 * C, 2 * C, 1, 1), 'l.conv1x1.bias': b}
+    nchw = lambda t: t.t().reshape(1, C, M, 1)  # noqa
+    h, c = ob.conv_lstm(nchw(xr), (nchw(hr), nchw(cr)) if state else None, sd, 'l')
+    dh, dc = rnd((M, C), 6), rnd((M, C), 7)
+    (h.reshape(C, M).t() * dh).sum().add((c.reshape(C, M).t() * dc).sum()).backward()
+    xd, hd, cd = x.to(DEV), h0.to(DEV) if state else None, c0.to(DEV) if state else None
+    hh, cc, gates = ops.convlstm_fwd(xd, hd, cd, W.detach().to(DEV), b.detach().to(DEV), want_gates=True)
+    close(hh, h.reshape(C, M).t(), what='h')
+    close(cc, c.reshape(C, M).t(), what='c')
+    dg, dcp = ops.convlstm_gates_bwd(dh.to(DEV), dc.to(DEV), gates, cd, cc)
+    dW = torch.zeros((4 * C, 2 * C), device=DEV)
+    db = torch.zeros((4 * C,), device=DEV)
+    if state:
+        ops.linear_wgrad(dg, xd, dW, db, x2=hd)
+        dx, dhp = ops.linear_dgrad(dg, W.detach().to(DEV), split=C)
+        close(dhp, hr.grad, rtol=1e-4, atol=1e-5, what='dh_prev')
+        close(dcp, cr.grad, rtol=1e-4, atol=1e-5, what='dc_prev')
+        close(dW, W.grad, rtol=2e-4, atol=2e-5, what='dW')
+    else:
+        dWx = torch.zeros((4 * C, C), device=DEV)
+        ops.linear_wgrad(dg, xd, dWx, db)
+        dx = ops.linear_dgrad(dg, W.detach()[:, :C].contiguous().to(DEV))
+        close(dWx, W.grad[:, :C], rtol=2e-4, atol=2e-5, what='dW')
+    close(dx, xr.grad, rtol=1e-4, atol=1e-5, what='dx')
+    close(db, b.grad, rtol=2e-4, atol=2e-5, what='db')
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 144, 48), (1000, 48, 192), (257, 64, 32), (5000, 96, 96), (100, 1536, 384)])
+def test_linear_backward(ops, M, N, K):
+    x = rnd((M, K), 1).requires_grad_(True)
+    W, b = rnd((N, K), 2, 0.2).requires_grad_(True), rnd((N,), 3).requires_grad_(True)
+    lw, lb = (1 + 0.2 * rnd((K,), 4)), (0.1 * rnd((K,), 5))
+    u = F.linear(F.layer_norm(x, (K,), lw, lb, 1e-5), W, b)
+    dy = rnd((M, N), 6)
+    u.backward(dy)
+    _, _, st = ops.ln_linear_fwd(x.detach().to(DEV), lw.to(DEV), lb.to(DEV), W.detach().to(DEV), b.detach().to(DEV), want_stats=True)
+    dW, db = torch.zeros((N, K), device=DEV), torch.zeros((N,), device=DEV)
+    ops.linear_wgrad(dy.to(DEV), x.detach().to(DEV), dW, db, stats=st, ln_w=lw.to(DEV), ln_b=lb.to(DEV))
+    close(dW, W.grad, rtol=2e-4, atol=5e-5, what='dW (LN input)')
+    close(db, b.grad, rtol=2e-4, atol=5e-5, what='db')
+    # dgrad with per-column scale, GELU derivative and column sums
+    ks = rnd((N,), 7)
+    uu = rnd((M, K), 8)
+    dn = ops.linear_dgrad(dy.to(DEV), W.detach().to(DEV), kscale=ks.to(DEV))
+    close(dn, (dy * ks) @ W.detach(), rtol=5e-5, atol=5e-6, what='dgrad')
+    cs = torch.zeros((K,), device=DEV)
+    du = ops.linear_dgrad(dy.to(DEV), W.detach().to(DEV), aux_u=uu.to(DEV), colsum=cs)
+    uu2 = uu.clone().requires_grad_(True)
+    F.gelu(uu2).backward(dy @ W.detach())
+    close(du, uu2.grad, rtol=5e-5, atol=5e-6, what='dgrad*gelu')
+    close(cs, uu2.grad.sum(0), rtol=2e-4, atol=5e-5, what='colsum')
+
+
+@pytest.mark.parametrize('M,C', [(500, 48), (70, 384), (1000, 32), (33, 512)])
+def test_layernorm_layerscale(ops, M, C):
+    x = rnd((M, C), 1).requires_grad_(True)
+    w, b = (1 + 0.2 * rnd((C,), 2)).requires_grad_(True), (0.1 * rnd((C,), 3)).requires_grad_(True)
+    y = F.layer_norm(x, (C,), w, b, 1e-5)
+    dn, dres = rnd((M, C), 4), rnd((M, C), 5)
+    y.backward(dn)
+    yy, st = ops.layernorm_fwd(x.detach().to(DEV), w.detach().to(DEV), b.detach().to(DEV), want_stats=True)
+    close(yy, y)
+    for stats in (st, None):
+        dw, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        dx = ops.layernorm_bwd(dn.to(DEV), x.detach().to(DEV), stats, w.detach().to(DEV), dres.to(DEV), dw, db)
+        close(dx, x.grad + dres, rtol=5e-5, atol=5e-6, what='ln dx')
+        close(dw, w.grad, rtol=2e-4, atol=5e-5)
+        close(db, b.grad, rtol=2e-4, atol=5e-5)
+    g, t, dz = rnd((C,), 6), rnd((M, C), 7), rnd((M, C), 8)
+    dg = torch.zeros(C, device=DEV)
+    dt = ops.layerscale_bwd(dz.to(DEV), t.to(DEV), g.to(DEV), dg)
+    close(dt, dz * g)
+    close(dg, (dz * t).sum(0), rtol=2e-4, atol=5e-5)
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('u8', [True, False])
+def test_stem_conv(ops, u8):
+    B, Cin, H, W, N = 2, 20, 60, 90, 48
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand((B, Cin, H, W), generator=g) < 0.1) * torch.randint(1, 10, (B, Cin, H, W), generator=g)
+    x = x.to(torch.uint8) if u8 else x.float() + 0.25
+    w = rnd((N, Cin, 7, 7), 4, 0.05).requires_grad_(True)
+    xp = F.pad(x.float(), [0, 96 - W, 0, 64 - H])
+    ref = F.conv2d(xp, w, None, stride=4, padding=3)
+    dy = rnd(ref.shape, 5)
+    ref.backward(dy)
+    y = ops.stem_conv_fwd(x.to(DEV), w.detach().to(DEV), (64, 96), 4, 3)
+    close(y, ref.permute(0, 2, 3, 1), rtol=5e-5, atol=1e-5)
+    dw = torch.zeros_like(w.detach(), device=DEV)
+    ops.stem_conv_wgrad(dy.permute(0, 2, 3, 1).contiguous().to(DEV), x.to(DEV), dw, (64, 96), 4, 3)
+    close(dw, w.grad, rtol=2e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('B,H,W,Cin,N,ks,stride', [(2, 16, 24, 16, 32, 3, 2), (2, 32, 40, 48, 96, 3, 2),
+                                                   (3, 8, 12, 32, 32, 3, 1), (2, 8, 10, 96, 96, 3, 1),
+                                                   (2, 16, 20, 192, 96, 1, 1), (1, 7, 9, 64, 48, 3, 2)])
+def test_conv_nhwc(ops, B, H, W, Cin, N, ks, stride):
+    x = rnd((B, Cin, H, W), 1).requires_grad_(True)
+    w, bias = rnd((N, Cin, ks, ks), 2, 0.1).requires_grad_(True), rnd((N,), 3).requires_grad_(True)
+    ref = F.conv2d(x, w, bias, stride=stride, padding=(ks - 1) // 2)
+    dy = rnd(ref.shape, 4)
+    ref.backward(dy)
+    xn = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    dyn = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    cs = torch.zeros((2, N), dtype=torch.float64, device=DEV)
+    y = ops.conv_nhwc_fwd(xn, w.detach().to(DEV), bias.detach().to(DEV), stride=stride, colstats=cs)
+    refn = ref.detach().permute(0, 2, 3, 1)
+    close(y, refn, rtol=5e-5, atol=1e-5)
+    close(cs[0], refn.reshape(-1, N).double().sum(0), rtol=1e-5, atol=1e-4)
+    close(cs[1], (refn.reshape(-1, N).double() ** 2).sum(0), rtol=1e-5, atol=1e-4)
+    dx = ops.conv_nhwc_dgrad(dyn, w.detach().to(DEV), xn.shape, stride=stride)
+    close(dx, x.grad.permute(0, 2, 3, 1), rtol=1e-4, atol=1e-5, what='dgrad')
+    acc = rnd(tuple(xn.shape), 9).to(DEV)
+    dx2 = ops.conv_nhwc_dgrad(dyn, w.detach().to(DEV), xn.shape, stride=stride, out=acc.clone(), accumulate=True)
+    close(dx2, x.grad.permute(0, 2, 3, 1) + acc.cpu(), rtol=1e-4, atol=1e-5, what='dgrad acc')
+    dw, db = torch.zeros_like(w.detach(), device=DEV), torch.zeros(N, device=DEV)
+    ops.conv_nhwc_wgrad(dyn, xn, dw, db, stride=stride)
+    close(dw, w.grad, rtol=2e-4, atol=1e-4, what='wgrad')
+    close(db, bias.grad, rtol=2e-4, atol=1e-4)
+
+
+def test_conv_bn_eval_and_train(ops):
+    B, H, W, Cin, N = 3, 8, 12, 32, 64
+    x = rnd((B, Cin, H, W), 1).requires_grad_(True)
+    w = rnd((N, Cin, 3, 3), 2, 0.1).requires_grad_(True)
+    bw, bb = (1 + 0.2 * rnd((N,), 3)).requires_grad_(True), (0.1 * rnd((N,), 4)).requires_grad_(True)
+    rm, rv = 0.2 * rnd((N,), 5), 0.5 + torch.rand(N, generator=torch.Generator().manual_seed(6))
+    xn = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    # eval: folded BN + SiLU epilogue
+    ref = F.silu(F.batch_norm(F.conv2d(x, w, None, padding=1), rm, rv, bw, bb, False, 0.1, 1e-5)).detach()
+    y = ops.conv_nhwc_fwd(xn, w.detach().to(DEV), None, bn=(bw.detach().to(DEV), bb.detach().to(DEV), rm.to(DEV), rv.to(DEV)))
+    close(y, ref.permute(0, 2, 3, 1), rtol=5e-5, atol=1e-5)
+    # train: batch statistics
+    rm2, rv2 = rm.clone(), rv.clone()
+    z = F.conv2d(x, w, None, padding=1)
+    ref = F.silu(F.batch_norm(z, rm2, rv2, bw, bb, True, 0.1, 1e-5))
+    dy = rnd(ref.shape, 7)
+    ref.backward(dy)
+    cs = torch.zeros((2, N), dtype=torch.float64, device=DEV)
+    zz = ops.conv_nhwc_fwd(xn, w.detach().to(DEV), None, colstats=cs)
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    M = B * H * W
+    yy, mean, rstd = ops.bn_silu_fwd(zz, cs, bw.detach().to(DEV), bb.detach().to(DEV), rmd, rvd, M)
+    close(yy, ref.detach().permute(0, 2, 3, 1), rtol=5e-5, atol=1e-5)
+    close(rmd, rm2, rtol=1e-5, atol=1e-6)
+    close(rvd, rv2, rtol=1e-5, atol=1e-6)
+    dyn = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    sums = ops.bn_silu_bwd_reduce(dyn, zz, mean, rstd, bw.detach().to(DEV), bb.detach().to(DEV))
+    dbw, dbb = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+    dz = ops.bn_silu_bwd_apply(dyn, zz, mean, rstd, bw.detach().to(DEV), bb.detach().to(DEV), sums, dbw, dbb, M)
+    close(dbw, bw.grad, rtol=2e-4, atol=5e-5)
+    close(dbb, bb.grad, rtol=2e-4, atol=5e-5)
+    dx = ops.conv_nhwc_dgrad(dz, w.detach().to(DEV), xn.shape)
+    close(dx, x.grad.permute(0, 2, 3, 1), rtol=2e-4, atol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------------
+def _gen1_case(B, seed, nc=2, with_ignore=False):
+    hws, strides = [(32, 40), (16, 20), (8, 10)], (8, 16, 32)
+    gx, gy, gs = oh.make_grids(hws, strides)
+    A = gx.numel()
+    g = torch.Generator().manual_seed(seed)
+    outputs = torch.cat([torch.stack([(gx + 0.5) * gs, (gy + 0.5) * gs, gs * 3, gs * 2.5], 1)[None].repeat(B, 1, 1)
+                         + torch.randn(B, A, 4, generator=g) * 2, torch.randn(B, A, 1 + nc, generator=g) * 2], -1)
+    labs = synth_labels(B, (240, 304), nc, seed=seed, max_boxes=6)
+    tg = op.batched_yolox_labels(labs)
+    if B > 2:
+        tg[B - 1] = 0                                   # an image without labels
+    if with_ignore:
+        tg[0, 0, 0] = 1024
+        tg[1, :, 0] = torch.where(tg[1].sum(1) > 0, torch.full_like(tg[1, :, 0], 1024.), tg[1, :, 0])
+    return hws, strides, (gx, gy, gs), outputs, tg
+
+
+@pytest.mark.parametrize('with_ignore', [False, True])
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_simota_and_loss(ops, seed, with_ignore):
+    B = 5
+    hws, strides, (gx, gy, gs), outputs, tg = _gen1_case(B, seed, with_ignore=with_ignore)
+    outr = outputs.clone().requires_grad_(True)
+    ref = oh.get_losses(gx, gy, gs, tg.clone(), outr, num_classes=2, return_assign=True)
+    ref['loss'].backward()
+    od, td = outputs.to(DEV), tg.to(DEV)
+    asg = ops.simota_assign(od, td, hws, strides)
+    assert np.array_equal(asg['fg_mask'].cpu().numpy().astype(bool), ref['_fg_mask'].numpy())
+    assert np.array_equal(asg['ignore_mask'].cpu().numpy().astype(bool), ref['_ignore_mask'].numpy())
+    for b in range(B):
+        r = ref['_assign'][b]
+        fg = ref['_fg_mask'][b]
+        if r is None:
+            assert int(asg['num_fg_img'][b]) == 0
+            continue
+        assert int(asg['num_fg_img'][b]) == r['num_fg']
+        assert np.array_equal(asg['matched_valid_idx'][b].cpu()[fg].numpy(), r['matched_gt_inds'].numpy())
+        close(asg['pred_iou'][b].cpu()[fg], r['pred_ious'], rtol=1e-6, atol=0)
+    losses, d_raw = ops.yolox_loss(od, td, asg, hws, strides)
+    want = torch.tensor([float(ref[k]) for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')])
+    close(losses, want, rtol=2e-5, atol=1e-6)
+    # d_raw is the gradient wrt the raw conv outputs: chain the decode by hand on the reference side
+    gref = outr.grad.clone()
+    gref[..., 0:2] *= gs[None, :, None]
+    gref[..., 2:4] *= outputs[..., 2:4]
+    close(d_raw, gref, rtol=1e-4, atol=1e-7)
+
+
+def test_simota_golden(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g06_simota.npz'))
+    hws, strides = [(32, 40), (16, 20), (8, 10)], (8, 16, 32)
+    for c in range(3):
+        T = lambda k: torch.from_numpy(g[f'c{c}_{k}'])  # noqa
+        gt, cls, bp, cl, ol = T('gt'), T('cls'), T('bp'), T('cls_l'), T('obj_l')
+        out = torch.cat([bp, ol, cl], 1)[None].contiguous()
+        for ign in (False, True):
+            lab = torch.zeros((1, gt.shape[0] + 2, 7))
+            lab[0, :gt.shape[0], 0] = cls
+            lab[0, :gt.shape[0], 1:5] = gt
+            lab[0, :gt.shape[0], 5:7] = 1
+            pre = 'ig_' if ign else ''
+            if ign:
+                lab[0, :gt.shape[0], 0] = torch.where(T('valid'), cls, torch.full_like(cls, 1024.))
+            asg = ops.simota_assign(out.to(DEV), lab.to(DEV), hws, strides)
+            fg = g[f'c{c}_{pre}fg_mask']
+            assert np.array_equal(asg['fg_mask'][0].cpu().numpy().astype(bool), fg)
+            assert np.array_equal(asg['matched_valid_idx'][0].cpu().numpy()[fg], g[f'c{c}_{pre}matched'])
+            assert int(asg['num_fg_img'][0]) == int(g[f'c{c}_{pre}nfg'])
+            close(asg['pred_iou'][0].cpu()[torch.from_numpy(fg)], g[f'c{c}_{pre}pious'], rtol=1e-6, atol=0)
+            if ign:
+                assert np.array_equal(asg['ignore_mask'][0].cpu().numpy().astype(bool), g[f'c{c}_ig_ignore_mask'])
+    # full loss vectors of the reference (ignore rows, all-ignore image, empty image, focal)
+    tgt, outp = torch.from_numpy(g['ign_targets']), torch.from_numpy(g['ign_outputs'])
+    for targets, want, focal in [(tgt, g['ign_losses'], False)]:
+        asg = ops.simota_assign(outp.to(DEV), targets.to(DEV), hws, strides)
+        losses, _ = ops.yolox_loss(outp.to(DEV), targets.to(DEV), asg, hws, strides, want_grad=False, focal=focal)
+        close(losses, want, rtol=2e-5, atol=1e-6)
+    tg2 = tgt.clone()
+    tg2[:, :, 0] = torch.where(tg2[:, :, 0] == 1024, torch.zeros_like(tg2[:, :, 0]), tg2[:, :, 0])
+    asg = ops.simota_assign(outp.to(DEV), tg2.to(DEV), hws, strides)
+    close(ops.yolox_loss(outp.to(DEV), tg2.to(DEV), asg, hws, strides, want_grad=False)[0], g['noign_losses'], rtol=2e-5, atol=1e-6)
+    close(ops.yolox_loss(outp.to(DEV), tg2.to(DEV), asg, hws, strides, want_grad=False, focal=True)[0], g['focal_losses'], rtol=2e-5, atol=1e-6)
+
+
+def test_focal_grad(ops):
+    hws, strides, (gx, gy, gs), outputs, tg = _gen1_case(3, 11)
+    outr = outputs.clone().requires_grad_(True)
+    ref = oh.get_losses(gx, gy, gs, tg.clone(), outr, num_classes=2, obj_focal_loss=True)
+    ref['loss'].backward()
+    asg = ops.simota_assign(outputs.to(DEV), tg.to(DEV), hws, strides)
+    losses, d_raw = ops.yolox_loss(outputs.to(DEV), tg.to(DEV), asg, hws, strides, focal=True)
+    close(losses[0], float(ref['loss']), rtol=2e-5)
+    close(d_raw[..., 4], outr.grad[..., 4], rtol=1e-4, atol=1e-8)
+
+
+def test_head_pred(ops):
+    B, h, w, Hd, nc, stride = 3, 8, 10, 96, 2, 32
+    A, a0 = 200, 100
+    cf, rf = rnd((B, h, w, Hd), 1).requires_grad_(True), rnd((B, h, w, Hd), 2).requires_grad_(True)
+    cw, cb = rnd((nc, Hd), 3, 0.1).requires_grad_(True), rnd((nc,), 4).requires_grad_(True)
+    rw, rb = rnd((4, Hd), 5, 0.05).requires_grad_(True), rnd((4,), 6, 0.1).requires_grad_(True)
+    ow, obb = rnd((1, Hd), 7, 0.1).requires_grad_(True), rnd((1,), 8).requires_grad_(True)
+    raw = torch.cat([F.linear(rf, rw, rb), F.linear(rf, ow, obb), F.linear(cf, cw, cb)], -1).reshape(B, h * w, 5 + nc)
+    yv, xv = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing='ij')
+    grid = torch.stack([xv, yv], -1).reshape(1, -1, 2)
+    dec = torch.cat([(raw[..., :2] + grid) * stride, torch.exp(raw[..., 2:4]) * stride, raw[..., 4:]], -1)
+    d_raw = torch.zeros((B, A, 5 + nc))
+    d_raw[:, a0:a0 + h * w] = rnd((B, h * w, 5 + nc), 9)
+    raw.backward(d_raw[:, a0:a0 + h * w])
+    ot, oi = torch.zeros((B, A, 5 + nc), device=DEV), torch.zeros((B, A, 5 + nc), device=DEV)
+    D = lambda t: t.detach().to(DEV)  # noqa
+    ops.head_pred_fwd(D(cf), D(rf), D(cw), D(cb), D(rw), D(rb), D(ow), D(obb), ot, oi, stride, a0)
+    close(ot[:, a0:a0 + h * w], dec, rtol=5e-5, atol=1e-5)
+    close(oi[:, a0:a0 + h * w, :4], dec[..., :4], rtol=5e-5, atol=1e-5)
+    close(oi[:, a0:a0 + h * w, 4:], dec[..., 4:].sigmoid(), rtol=5e-5, atol=1e-6)
+    grads = [torch.zeros_like(D(t)) for t in (cw, cb, rw, rb, ow, obb)]
+    dcf, drf = ops.head_pred_bwd(d_raw.to(DEV), D(cf), D(rf), D(cw), D(rw), D(ow), *grads, a0)
+    close(dcf, cf.grad, rtol=1e-4, atol=1e-6)
+    close(drf, rf.grad, rtol=1e-4, atol=1e-6)
+    for gg, t in zip(grads, (cw, cb, rw, rb, ow, obb)):
+        close(gg, t.grad, rtol=2e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------
+def _check_dets(det, cnt, ref_list):
+    det, cnt = det.cpu(), cnt.cpu()
+    assert [int(c) for c in cnt] == [len(r) for r in ref_list]
+    for b, r in enumerate(ref_list):
+        assert np.array_equal(det[b, :len(r)].numpy(), r.numpy()), f'image {b}'
+
+
+@pytest.mark.parametrize('name,nc,conf,agn', [
+    ('rand_c0.1', 2, 0.1, False), ('rand_c0.01', 2, 0.01, False), ('rand_c0.001', 2, 0.001, False),
+    ('rand_agnostic', 2, 0.1, True), ('adv_c0.1', 3, 0.1, False), ('adv_c0.001', 3, 0.001, False),
+    ('many_c0.001', 2, 0.001, False), ('none', 2, 0.5, False)])
+def test_postprocess_golden(ops, golden_dir, name, nc, conf, agn):
+    g = np.load(os.path.join(golden_dir, 'g07_postprocess.npz'))
+    pred = torch.from_numpy(g[name + '_pred']).clone()
+    p = pred.to(DEV)
+    # the golden vectors were recorded with torchvision's CPU rule (per-class loop above 4000 box elements)
+    det, cnt = ops.postprocess_nms(p, nc, conf, 0.45, class_agnostic=agn, vanilla_limit=4000)
+    n = list(g[name + '_n'])
+    assert [int(c) for c in cnt.cpu()] == n
+    flat = torch.cat([det[b, :n[b]].cpu() for b in range(len(n))], 0).numpy()
+    assert np.array_equal(flat, g[name + '_det'])
+    close(p[..., 0].cpu(), pred[..., 0] - pred[..., 2] / 2, rtol=0, atol=0, what='in-place xyxy')
+
+
+@pytest.mark.parametrize('seed', [0, 1])
+@pytest.mark.parametrize('limit', [20000, 4000])
+def test_postprocess_full_size(ops, seed, limit):
+    """Gen1 size (1680 anchors) x 24 images and Gen4-ds2 size (5040 anchors), both NMS regimes."""
+    g = torch.Generator().manual_seed(seed)
+    for A, B, nc in [(1680, 24, 2), (5040, 4, 3)]:
+        pred = torch.cat([torch.rand(B, A, 2, generator=g) * torch.tensor([300., 230.]), 8 + 40 * torch.rand(B, A, 2, generator=g),
+                          torch.rand(B, A, 1, generator=g), torch.rand(B, A, nc, generator=g)], -1)
+        ref = op.postprocess(pred.clone(), nc, 0.1, 0.45, pad=torch.zeros((0, 7)),
+                             device_semantics='gpu' if limit == 20000 else 'cpu')
+        det, cnt = ops.postprocess_nms(pred.to(DEV), nc, 0.1, 0.45, vanilla_limit=limit)
+        _check_dets(det, cnt, ref)
+
+
+def test_tta_merge_and_pseudo_filter(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g08_pseudo.npz'))
+    views = [torch.from_numpy(g['tta_in0']), torch.from_numpy(g['tta_in1'])]
+    A = max(len(v) for v in views)
+    pred = torch.zeros((2, A, 7))
+    for i, v in enumerate(views):
+        pred[i, :len(v)] = v
+        pred[i, len(v):, 4] = -1.0          # padding rows can never pass the confidence test
+    det, cnt = ops.postprocess_nms(pred.to(DEV), 0, 0.01, 0.45, vanilla_limit=4000)
+    n = list(g['tta_n'])[:2]
+    assert [int(c) for c in cnt.cpu()] == n
+    assert np.array_equal(torch.cat([det[b, :n[b]].cpu() for b in range(2)]).numpy(), g['tta_out'])
+    # pred2label
+    lens = list(g['p2l_lens_in'])
+    allp = torch.from_numpy(g['p2l_in'])
+    det = torch.zeros((3, max(lens), 7))
+    s = 0
+    for i, n_ in enumerate(lens):
+        det[i, :n_] = allp[s:s + n_]
+        s += n_
+    cnt = torch.tensor(lens, dtype=torch.int32)
+    lab, lc = ops.pseudo_filter(det.to(DEV), cnt.to(DEV), [0.6, 0.3], [0.6, 0.3], True, (240, 304))
+    assert [int(c) for c in lc.cpu()] == list(g['p2l_lens'])
+    assert np.array_equal(torch.cat([lab[b, :int(lc[b])].cpu() for b in range(3)]).numpy(), g['p2l_out'])
+    lab, lc = ops.pseudo_filter(det.to(DEV), cnt.to(DEV), 0.5, 0.4, False, (240, 304))
+    assert [int(c) for c in lc.cpu()] == list(g['p2lf_lens'])
+    assert np.array_equal(torch.cat([lab[b, :int(lc[b])].cpu() for b in range(3)]).numpy(), g['p2lf_out'])
+    all4 = torch.from_numpy(g['p2l4_in'])
+    s = 0
+    for i, n_ in enumerate(lens):
+        det[i, :n_] = all4[s:s + n_]
+        s += n_
+    lab, lc = ops.pseudo_filter(det.to(DEV), cnt.to(DEV), [0.3, 0.3, 0.6], [0.3, 0.3, 0.6], True, (360, 640))
+    assert [int(c) for c in lc.cpu()] == list(g['p2l4_lens'])
+    assert np.array_equal(torch.cat([lab[b, :int(lc[b])].cpu() for b in range(3)]).numpy(), g['p2l4_out'])
+
+
+def test_voxelize_golden(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g10_voxel.npz'))
+    for name, fast, cutoff in [('a', True, None), ('b', False, 10), ('c', True, 3)]:
+        ev = [torch.from_numpy(g[f'{name}_{k}'].astype(np.int64)).to(DEV) for k in 'xypt']
+        rep = ops.voxelize_u8(*ev, 10, 24, 30, count_cutoff=cutoff, fastmode=fast)
+        assert np.array_equal(rep.cpu().numpy(), g[f'{name}_rep'])
+
+
+def test_adamw_clip(ops):
+    n = 10007
+    p0, g0 = rnd((n,), 1), rnd((n,), 2, 2.0)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p], lr=2e-4, weight_decay=0.01)
+    pd, m, v = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        gi = g0 * (1 + 0.1 * step)
+        p.grad = gi.clone()
+        torch.nn.utils.clip_grad_value_([p], 1.0)
+        opt.step()
+        ops.adamw_clip_step(pd, gi.to(DEV), m, v, 2e-4, step, weight_decay=0.01, clip_value=1.0)
+        close(pd, p.detach(), rtol=1e-6, atol=1e-7)
