@@ -110,10 +110,11 @@ int leod_bn_silu_bwd_apply(const float* dy, const float* z, const float* mean, c
 int leod_head_pred_fwd(const float* cls_feat, const float* reg_feat, const float* cls_w, const float* cls_b,
                        const float* reg_w, const float* reg_b, const float* obj_w, const float* obj_b, float* out_train,
                        float* out_infer, int B, int h, int w, int Hd, int nc, int stride, int a0, int A, leod_stream_t stream);
+/* gscale (optional): device scalar multiplied into d_raw (the seed gradient of the loss). */
 int leod_head_pred_bwd(const float* d_raw, const float* cls_feat, const float* reg_feat, const float* cls_w,
                        const float* reg_w, const float* obj_w, float* d_cls_feat, float* d_reg_feat, float* d_cls_w,
-                       float* d_cls_b, float* d_reg_w, float* d_reg_b, float* d_obj_w, float* d_obj_b, int B, int h, int w,
-                       int Hd, int nc, int a0, int A, leod_stream_t stream);
+                       float* d_cls_b, float* d_reg_w, float* d_reg_b, float* d_obj_w, float* d_obj_b, const float* gscale,
+                       int B, int h, int w, int Hd, int nc, int a0, int A, leod_stream_t stream);
 
 /* SimOTA (get_assignments / get_assignments_w_ignore / simota_matching, :606-774, :974-1148) for a whole batch:
  * outputs [B,A,5+nc] decoded boxes + logits, labels [B,Nmax,7] = (cls,cx,cy,w,h,obj,cls_conf) zero padded.

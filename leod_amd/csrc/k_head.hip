@@ -66,8 +66,10 @@ __global__ __launch_bounds__(256) void head_pred_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void head_pred_bwd_feat_kernel(const float* __restrict__ d_raw, const float* __restrict__ cls_w,
                                                                  const float* __restrict__ reg_w, const float* __restrict__ obj_w,
                                                                  float* __restrict__ d_cls_feat, float* __restrict__ d_reg_feat,
+                                                                 const float* __restrict__ gscale,
                                                                  int B, int hw, int Hd, int nc, int a0, int A) {
     const int nch = 5 + nc;
+    const float gsc = gscale ? gscale[0] : 1.f;
     const long total = (long)B * hw * Hd;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int k = (int)(idx % Hd);
@@ -79,8 +81,8 @@ __global__ __launch_bounds__(256) void head_pred_bwd_feat_kernel(const float* __
         for (int ch = 0; ch < 4; ++ch) r = fmaf(d[ch], reg_w[(long)ch * Hd + k], r);
         r = fmaf(d[4], obj_w[k], r);
         for (int ch = 0; ch < nc; ++ch) c = fmaf(d[5 + ch], cls_w[(long)ch * Hd + k], c);
-        d_reg_feat[idx] = r;
-        d_cls_feat[idx] = c;
+        d_reg_feat[idx] = r * gsc;
+        d_cls_feat[idx] = c * gsc;
     }
 }
 // one workgroup per (output channel ch, k-chunk): dW[ch][k] += sum_pos d_raw[pos][ch] * feat[pos][k]
@@ -88,8 +90,10 @@ __global__ __launch_bounds__(256) void head_pred_bwd_w_kernel(const float* __res
                                                               const float* __restrict__ reg_feat, float* __restrict__ d_cls_w,
                                                               float* __restrict__ d_cls_b, float* __restrict__ d_reg_w,
                                                               float* __restrict__ d_reg_b, float* __restrict__ d_obj_w,
-                                                              float* __restrict__ d_obj_b, int B, int hw, int Hd, int nc, int a0, int A) {
+                                                              float* __restrict__ d_obj_b, const float* __restrict__ gscale,
+                                                              int B, int hw, int Hd, int nc, int a0, int A) {
     __shared__ float red[256];
+    const float gsc = gscale ? gscale[0] : 1.f;
     const int nch = 5 + nc;
     const int ch = blockIdx.x;
     const int k = blockIdx.y * 64 + (threadIdx.x & 63);
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(256) void head_pred_bwd_w_kernel(const float* __res
     const long npos = (long)B * hw;
     for (long pos = (long)blockIdx.z * 4 + slice; pos < npos; pos += (long)gridDim.z * 4) {
         const int p = (int)(pos % hw), b = (int)(pos / hw);
-        const float d = d_raw[((long)b * A + a0 + p) * nch + ch];
+        const float d = d_raw[((long)b * A + a0 + p) * nch + ch] * gsc;
         if (k < Hd) acc = fmaf(d, feat[pos * Hd + k], acc);
         bacc += d;
     }
@@ -431,7 +435,9 @@ __global__ void yolox_loss_finalize_kernel(const double* __restrict__ sums, cons
 // ---------------------------------------------------------------------------------------------------
 // postprocess + batched NMS: one workgroup (1024 threads) per image.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool iou_gt(const float* a, float area_a, const float* b, float area_b, float thr) {
+__device__ __forceinline__ bool iou_gt(const float* a, const float* b, float thr) {
+    // areas are recomputed from the (offset) boxes exactly as torchvision precomputes them: (x2-x1)*(y2-y1)
+    const float area_a = (a[2] - a[0]) * (a[3] - a[1]), area_b = (b[2] - b[0]) * (b[3] - b[1]);
     const float xx1 = fmaxf(a[0], b[0]), yy1 = fmaxf(a[1], b[1]), xx2 = fminf(a[2], b[2]), yy2 = fminf(a[3], b[3]);
     const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
     const float inter = w * h;
@@ -451,8 +457,7 @@ __global__ __launch_bounds__(1024) void postprocess_nms_kernel(float* __restrict
     float* skey = reinterpret_cast<float*>(smem);            // [NP2] scores (sorted desc)
     int* sidx = reinterpret_cast<int*>(skey + NP2);          // [NP2] anchor index
     float* sbox = reinterpret_cast<float*>(sidx + NP2);      // [A][4] boxes in sorted order (with class offset)
-    float* sarea = sbox + 4 * (size_t)A;                     // [A]
-    unsigned char* removed = reinterpret_cast<unsigned char*>(sarea + A);   // [A]
+    unsigned char* removed = reinterpret_cast<unsigned char*>(sbox + 4 * (size_t)A);   // [A]
     __shared__ int s_scan[NW], s_n, s_keep;
     __shared__ float s_red[NW];
     __shared__ unsigned long long s_kept;
@@ -527,7 +532,6 @@ __global__ __launch_bounds__(1024) void postprocess_nms_kernel(float* __restrict
         if (!class_agnostic && !vanilla) off = (float)cid * offs_unit;
         const float x1 = p[0] + off, y1 = p[1] + off, x2 = p[2] + off, y2 = p[3] + off;
         sbox[4 * j] = x1; sbox[4 * j + 1] = y1; sbox[4 * j + 2] = x2; sbox[4 * j + 3] = y2;
-        sarea[j] = (x2 - x1) * (y2 - y1);
         removed[j] = 0;
     }
     __syncthreads();
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(1024) void postprocess_nms_kernel(float* __restrict
             unsigned long long m = 0;
             if (valid) {
                 for (int t = lane + 1; t < 64 && s0 + t < n; ++t) {
-                    bool sup = iou_gt(sbox + 4 * j, sarea[j], sbox + 4 * (s0 + t), sarea[s0 + t], nms_thre);
+                    bool sup = iou_gt(sbox + 4 * j, sbox + 4 * (s0 + t), nms_thre);
                     if (sup && vanilla) {
                         const float* p = pb + (long)sidx[s0 + t] * ncols; int oc = 0; float cc = p[5];
                         for (int c = 1; c < nc; ++c) if (p[5 + c] > cc) { cc = p[5 + c]; oc = c; }
@@ -568,7 +572,7 @@ __global__ __launch_bounds__(1024) void postprocess_nms_kernel(float* __restrict
                 unsigned long long kk = kept;
                 while (kk) {
                     const int t = __ffsll((long long)kk) - 1; kk &= kk - 1;
-                    bool sup = iou_gt(sbox + 4 * (s0 + t), sarea[s0 + t], sbox + 4 * j, sarea[j], nms_thre);
+                    bool sup = iou_gt(sbox + 4 * (s0 + t), sbox + 4 * j, nms_thre);
                     if (sup && vanilla) {
                         const float* p = pb + (long)sidx[s0 + t] * ncols; int oc = 0; float cc = p[5];
                         for (int c = 1; c < nc; ++c) if (p[5 + c] > cc) { cc = p[5 + c]; oc = c; }
@@ -669,16 +673,16 @@ LEOD_API int leod_head_pred_fwd(const float* cls_feat, const float* reg_feat, co
 
 LEOD_API int leod_head_pred_bwd(const float* d_raw, const float* cls_feat, const float* reg_feat, const float* cls_w,
                                 const float* reg_w, const float* obj_w, float* d_cls_feat, float* d_reg_feat, float* d_cls_w,
-                                float* d_cls_b, float* d_reg_w, float* d_reg_b, float* d_obj_w, float* d_obj_b, int B, int h,
-                                int w, int Hd, int nc, int a0, int A, hipStream_t stream) {
+                                float* d_cls_b, float* d_reg_w, float* d_reg_b, float* d_obj_w, float* d_obj_b,
+                                const float* gscale, int B, int h, int w, int Hd, int nc, int a0, int A, hipStream_t stream) {
     if (!d_raw || !cls_feat || !reg_feat || !d_cls_feat || !d_reg_feat) return LEOD_ERR_ARG;
     const long total = (long)B * h * w * Hd;
     if (total == 0) return LEOD_OK;
     hipLaunchKernelGGL(head_pred_bwd_feat_kernel, dim3(flat_grid(total)), dim3(256), 0, stream, d_raw, cls_w, reg_w, obj_w,
-                       d_cls_feat, d_reg_feat, B, h * w, Hd, nc, a0, A);
+                       d_cls_feat, d_reg_feat, gscale, B, h * w, Hd, nc, a0, A);
     const int zs = (int)min((long)64, max((long)1, ((long)B * h * w + 255) / 256));
     hipLaunchKernelGGL(head_pred_bwd_w_kernel, dim3(5 + nc, cdiv(Hd, 64), zs), dim3(256), 0, stream, d_raw, cls_feat, reg_feat,
-                       d_cls_w, d_cls_b, d_reg_w, d_reg_b, d_obj_w, d_obj_b, B, h * w, Hd, nc, a0, A);
+                       d_cls_w, d_cls_b, d_reg_w, d_reg_b, d_obj_w, d_obj_b, gscale, B, h * w, Hd, nc, a0, A);
     return leod_launch_status();
 }
 
@@ -727,8 +731,8 @@ LEOD_API int leod_postprocess_nms(float* pred, float* det_out, int* det_cnt, int
     if (!pred || !det_out || !det_cnt || A <= 0) return LEOD_ERR_ARG;
     if (B == 0) return LEOD_OK;
     int np2 = 1; while (np2 < A) np2 <<= 1;
-    const size_t shm = (size_t)np2 * 8 + (size_t)A * 4 * 4 + (size_t)A * 4 + (size_t)A + 16;
-    if (shm > 150 * 1024) return LEOD_ERR_UNSUPPORTED;
+    const size_t shm = (size_t)np2 * 8 + (size_t)A * 4 * 4 + (size_t)A + 16;
+    if (shm > 156 * 1024) return LEOD_ERR_UNSUPPORTED;
     (void)hipFuncSetAttribute((const void*)postprocess_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     const int ncols = nc > 0 ? 5 + nc : 7;
     hipLaunchKernelGGL(postprocess_nms_kernel, dim3(B), dim3(1024), shm, stream, pred, det_out, det_cnt, A, nc, ncols, conf_thre,

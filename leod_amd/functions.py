@@ -1,0 +1,263 @@
+"""autograd glue: each Function below is one fused block of the LEOD hot path whose forward AND
+backward are sequences of hand-written HIP kernels (leod_amd.ops -> libleod_hip.so).
+
+PyTorch's autograd engine is used purely as the tape between blocks (the graph of a training step is
+~350 nodes).  Parameter gradients are NOT returned to autograd: the wgrad kernels accumulate straight
+into ``param.grad`` (allocated once, or a view into the flat gradient buffer set up by
+``leod_amd.parallel.FlatParams``), so that the 21 timesteps of a sequence add into one buffer without
+21 extra elementwise adds per parameter.  The Functions therefore return ``None`` for parameter
+inputs; parameters are still passed to ``apply`` so that the outputs are attached to the graph.
+"""
+from typing import Optional, Tuple
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+_SYNC_BN = {'group': None, 'world_size': 1}
+
+
+def set_sync_batchnorm(process_group, world_size: int):
+    """Enable SyncBatchNorm semantics (reference: train.py:247 sync_batchnorm=True when >1 GPU): the
+    per-channel (sum, sumsq) and backward (sum du, sum du*xhat) vectors are all-reduced over RCCL."""
+    _SYNC_BN['group'] = process_group
+    _SYNC_BN['world_size'] = int(world_size)
+
+
+def _allreduce_stats(t: torch.Tensor):
+    if _SYNC_BN['world_size'] > 1:
+        import torch.distributed as dist
+        dist.all_reduce(t, group=_SYNC_BN['group'])
+
+
+def grad_buf(p: torch.nn.Parameter) -> torch.Tensor:
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+def to_nhwc(t: torch.Tensor) -> torch.Tensor:
+    """[B,C,H,W] (any strides) -> contiguous [B,H,W,C]; zero-copy for channels-last memory."""
+    v = t.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def as_nchw(t_nhwc: torch.Tensor) -> torch.Tensor:
+    return t_nhwc.permute(0, 3, 1, 2)
+
+
+def _cont(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    return None if t is None else (t if t.is_contiguous() else t.contiguous())
+
+
+# ---------------------------------------------------------------------------------------------------
+class ConvLNFn(Function):
+    """ConvDownsampling_Cf2Cl (maxvit.py:143-182): conv(no bias) -> NHWC -> LayerNorm.
+    ``x`` is the raw NCHW event tensor for the stem (uint8 / fp32, optionally unpadded) or an NHWC map."""
+
+    @staticmethod
+    def forward(ctx, mod, x, conv_w, ln_w, ln_b, is_stem: bool, stride: int, padded_hw):
+        need = torch.is_grad_enabled()
+        if is_stem:
+            z = ops.stem_conv_fwd(x, conv_w, padded_hw, stride, conv_w.shape[-1] // 2)
+        else:
+            z = ops.conv_nhwc_fwd(x, conv_w, None, stride=stride)
+        y, stats = ops.layernorm_fwd(z, ln_w, ln_b, want_stats=need)
+        ctx.mod, ctx.is_stem, ctx.stride, ctx.padded_hw = mod, is_stem, stride, padded_hw
+        ctx.save_for_backward(x, z, stats, conv_w, ln_w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z, stats, conv_w, ln_w = ctx.saved_tensors
+        mod = ctx.mod
+        dz = ops.layernorm_bwd(_cont(dy), z, stats, ln_w, None, grad_buf(mod.norm.weight), grad_buf(mod.norm.bias))
+        dx = None
+        if ctx.is_stem:
+            ops.stem_conv_wgrad(dz, x, grad_buf(mod.conv.weight), ctx.padded_hw, ctx.stride, conv_w.shape[-1] // 2)
+        else:
+            ops.conv_nhwc_wgrad(dz, x, grad_buf(mod.conv.weight), None, stride=ctx.stride)
+            if ctx.needs_input_grad[1]:
+                dx = ops.conv_nhwc_dgrad(dz, conv_w, x.shape, stride=ctx.stride)
+        return None, dx, None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------
+class AttnBlockFn(Function):
+    """PartitionAttentionCl.forward (maxvit.py:185-270): x + ls1(attn(norm1(x))) then + ls2(mlp(norm2(.)))."""
+
+    @staticmethod
+    def forward(ctx, mod, x, *params):
+        need = torch.is_grad_enabled()
+        (n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, g1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, g2) = params
+        heads, part, window = mod.self_attn.num_heads, mod.partition_size, mod.partition_window
+        qkv, _, st1 = ops.ln_linear_fwd(x, n1w, n1b, qkv_w, qkv_b, want_stats=need)
+        o, lse = ops.partition_attn_fwd(qkv, heads, part, window, want_lse=need)
+        y, t1 = ops.linear_lsres_fwd(o, proj_w, proj_b, g1, x, want_t=need)
+        u, h, st2 = ops.ln_linear_fwd(y, n2w, n2b, fc1_w, fc1_b, want_act=True, want_stats=need)
+        z, t2 = ops.linear_lsres_fwd(h, fc2_w, fc2_b, g2, y, want_t=need)
+        if need:
+            ctx.mod = mod
+            ctx.save_for_backward(x, qkv, st1, o, lse, y, t1, u, h, st2, t2, *params)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        (x, qkv, st1, o, lse, y, t1, u, h, st2, t2,
+         n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, g1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, g2) = ctx.saved_tensors
+        mod = ctx.mod
+        sa, mlp = mod.self_attn, mod.mlp
+        heads, part, window = sa.num_heads, mod.partition_size, mod.partition_window
+        dz = _cont(dz)
+        # ---- MLP branch ---------------------------------------------------------------------------
+        dt2 = ops.layerscale_bwd(dz, t2, g2, grad_buf(mod.ls2.gamma))
+        ops.linear_wgrad(dt2, h, grad_buf(mlp.net[2].weight), grad_buf(mlp.net[2].bias))
+        du = ops.linear_dgrad(dt2, fc2_w, aux_u=u)
+        ops.linear_wgrad(du, y, grad_buf(mlp.net[0][0].weight), grad_buf(mlp.net[0][0].bias), stats=st2, ln_w=n2w, ln_b=n2b)
+        dn2 = ops.linear_dgrad(du, fc1_w)
+        dy = ops.layernorm_bwd(dn2, y, st2, n2w, dz, grad_buf(mod.norm2.weight), grad_buf(mod.norm2.bias))
+        # ---- attention branch ---------------------------------------------------------------------
+        dt1 = ops.layerscale_bwd(dy, t1, g1, grad_buf(mod.ls1.gamma))
+        ops.linear_wgrad(dt1, o, grad_buf(sa.proj.weight), grad_buf(sa.proj.bias))
+        do = ops.linear_dgrad(dt1, proj_w)
+        dqkv = ops.partition_attn_bwd(qkv, do, lse, heads, part, window)
+        if n1w is not None:
+            ops.linear_wgrad(dqkv, x, grad_buf(sa.qkv.weight), grad_buf(sa.qkv.bias), stats=st1, ln_w=n1w, ln_b=n1b)
+            dn1 = ops.linear_dgrad(dqkv, qkv_w)
+            dx = ops.layernorm_bwd(dn1, x, st1, n1w, dy, grad_buf(mod.norm1.weight), grad_buf(mod.norm1.bias))
+        else:
+            ops.linear_wgrad(dqkv, x, grad_buf(sa.qkv.weight), grad_buf(sa.qkv.bias))
+            dx = ops.linear_dgrad(dqkv, qkv_w, out=dy, accumulate=True)     # dy is private to this backward
+        return (None, dx) + (None,) * 14
+
+
+# ---------------------------------------------------------------------------------------------------
+class ConvLSTMFn(Function):
+    """DWSConvLSTM2d.forward (models/layers/rnn.py:37-70) on channels-last rows."""
+
+    @staticmethod
+    def forward(ctx, mod, x, h_prev, c_prev, w, b):
+        need = torch.is_grad_enabled()
+        C = x.shape[-1]
+        h, c, gates = ops.convlstm_fwd(x, h_prev, c_prev, w.view(4 * C, 2 * C), b, want_gates=need)
+        if need:
+            ctx.mod = mod
+            ctx.set_materialize_grads(False)
+            ctx.save_for_backward(x, h_prev, c_prev, c, gates, w)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        x, h_prev, c_prev, c, gates, w = ctx.saved_tensors
+        mod = ctx.mod
+        C = x.shape[-1]
+        dgates, dc_prev = ops.convlstm_gates_bwd(_cont(dh), _cont(dc), gates, c_prev, c, want_dc_prev=ctx.needs_input_grad[3])
+        ops.linear_wgrad(dgates, x, grad_buf(mod.conv1x1.weight).view(4 * C, 2 * C), grad_buf(mod.conv1x1.bias), x2=h_prev)
+        dx, dh_prev = ops.linear_dgrad(dgates, w.view(4 * C, 2 * C), split=C)
+        dx = dx.view(x.shape)
+        dh_prev = dh_prev.view(x.shape) if ctx.needs_input_grad[2] else None
+        return None, dx, dh_prev, dc_prev, None, None
+
+
+# ---------------------------------------------------------------------------------------------------
+class BaseConvFn(Function):
+    """BaseConv (network_blocks.py:29-51): conv(no bias) -> BatchNorm2d -> SiLU on NHWC maps."""
+
+    @staticmethod
+    def forward(ctx, mod, x, conv_w, bn_w, bn_b, stride: int, training: bool):
+        if not training:
+            return ops.conv_nhwc_fwd(x, conv_w, None, stride=stride,
+                                     bn=(bn_w, bn_b, mod.bn.running_mean, mod.bn.running_var), bn_eps=mod.bn.eps)
+        N = conv_w.shape[0]
+        colstats = torch.zeros((2, N), dtype=torch.float64, device=x.device)
+        z = ops.conv_nhwc_fwd(x, conv_w, None, stride=stride, colstats=colstats)
+        count = z.numel() // N
+        if _SYNC_BN['world_size'] > 1:
+            cnt = torch.tensor([float(count)], dtype=torch.float64, device=x.device)
+            packed = torch.cat([colstats.view(-1), cnt])
+            _allreduce_stats(packed)
+            colstats = packed[:-1].view(2, N).contiguous()
+            count = packed[-1]          # stays on the device; the kernels take it as a host double below
+            count = float(count)        # one small sync per layer only under SyncBN (as in the reference)
+        mom = mod.bn.momentum if mod.bn.momentum is not None else 0.1
+        y, mean, rstd = ops.bn_silu_fwd(z, colstats, bn_w, bn_b, mod.bn.running_mean, mod.bn.running_var, count,
+                                        eps=mod.bn.eps, momentum=mom)
+        mod.bn.num_batches_tracked += 1
+        if torch.is_grad_enabled():
+            ctx.mod, ctx.stride, ctx.count = mod, stride, count
+            ctx.save_for_backward(x, z, mean, rstd, conv_w, bn_w, bn_b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z, mean, rstd, conv_w, bn_w, bn_b = ctx.saved_tensors
+        mod = ctx.mod
+        dy = _cont(dy)
+        sums = ops.bn_silu_bwd_reduce(dy, z, mean, rstd, bn_w, bn_b)
+        _allreduce_stats(sums)
+        dz = ops.bn_silu_bwd_apply(dy, z, mean, rstd, bn_w, bn_b, sums, grad_buf(mod.bn.weight), grad_buf(mod.bn.bias), ctx.count)
+        ops.conv_nhwc_wgrad(dz, x, grad_buf(mod.conv.weight), None, stride=ctx.stride)
+        dx = ops.conv_nhwc_dgrad(dz, conv_w, x.shape, stride=ctx.stride) if ctx.needs_input_grad[1] else None
+        return None, dx, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------
+class HeadTailFn(Function):
+    """Prediction convs + decode + SimOTA + losses of YOLOXHead (yolo_head.py:216-287,403-597).
+
+    inputs : labels [B,N,7], (cls_feat_k, reg_feat_k) per level (NHWC), then per level
+             (cls_w, cls_b, reg_w, reg_b, obj_w, obj_b)
+    outputs: losses[6] = (loss, iou_loss, conf_loss, cls_loss, l1_loss, num_fg ratio), decoded predictions.
+    Only ``losses[0]`` is differentiable (that is what the reference back-propagates)."""
+
+    @staticmethod
+    def forward(ctx, mod, labels, *tensors):
+        nl = len(mod.strides)
+        feats, params = tensors[:2 * nl], tensors[2 * nl:]
+        B = feats[0].shape[0]
+        hws = [tuple(feats[2 * k].shape[1:3]) for k in range(nl)]
+        A = sum(h * w for h, w in hws)
+        nc = mod.num_classes
+        dev = feats[0].device
+        out_train = torch.empty((B, A, 5 + nc), dtype=torch.float32, device=dev)
+        out_infer = torch.empty((B, A, 5 + nc), dtype=torch.float32, device=dev)
+        a0 = 0
+        offs = []
+        for k in range(nl):
+            cw, cb, rw, rb, ow, ob = params[6 * k:6 * k + 6]
+            ops.head_pred_fwd(feats[2 * k], feats[2 * k + 1], cw.view(nc, -1), cb, rw.view(4, -1), rb, ow.view(1, -1), ob,
+                              out_train, out_infer, mod.strides[k], a0)
+            offs.append(a0)
+            a0 += hws[k][0] * hws[k][1]
+        labels = mod._ignore_bbox(labels)
+        asg = ops.simota_assign(out_train, labels, hws, mod.strides, ignore_label=float(mod.ignore_label))
+        need = torch.is_grad_enabled()
+        losses, d_raw = ops.yolox_loss(out_train, labels, asg, hws, mod.strides, want_grad=need,
+                                       focal=mod.obj_focal_loss, reg_weight=mod.reg_weight, obj_weight=mod.obj_weight,
+                                       cls_weight=mod.cls_weight)
+        mod.last_assignment = asg
+        if need:
+            ctx.mod, ctx.offs = mod, offs
+            ctx.save_for_backward(d_raw, *feats, *params)
+        ctx.mark_non_differentiable(out_infer)
+        return losses, out_infer
+
+    @staticmethod
+    def backward(ctx, dlosses, _dout):
+        mod = ctx.mod
+        nl = len(mod.strides)
+        saved = ctx.saved_tensors
+        d_raw, feats, params = saved[0], saved[1:1 + 2 * nl], saved[1 + 2 * nl:]
+        nc = mod.num_classes
+        gscale = dlosses[0:1].contiguous()           # device scalar: d(loss) seed (1.0 for loss.backward())
+        grads = []
+        for k in range(nl):
+            cw, cb, rw, rb, ow, ob = params[6 * k:6 * k + 6]
+            dcf, drf = ops.head_pred_bwd(d_raw, feats[2 * k], feats[2 * k + 1], cw.view(nc, -1), rw.view(4, -1), ow.view(1, -1),
+                                         grad_buf(mod.cls_preds[k].weight), grad_buf(mod.cls_preds[k].bias),
+                                         grad_buf(mod.reg_preds[k].weight), grad_buf(mod.reg_preds[k].bias),
+                                         grad_buf(mod.obj_preds[k].weight), grad_buf(mod.obj_preds[k].bias),
+                                         ctx.offs[k], gscale=gscale)
+            grads += [dcf, drf]
+        return (None, None) + tuple(grads) + (None,) * len(params)

@@ -1,0 +1,108 @@
+"""4-stage recurrent MaxViT backbone (mirror of the reference's
+models/detection/recurrent_backbone/maxvit_rnn.py:23-201; same module tree => same state-dict keys
+``stages.{i}.{downsample_cf2cl,att_blocks.{j}.att_{window,grid},lstm}``).
+
+Per stage and timestep the HIP path launches 13 kernels: conv, LayerNorm, 2 x (LN+qkv, attention,
+proj+LayerScale+residual, LN+fc1+GELU, fc2+LayerScale+residual) and the fused ConvLSTM cell.
+Feature maps are returned as logical [B,C,h,w] tensors backed by channels-last memory."""
+from typing import Dict, Optional, Tuple
+
+import torch as th
+import torch.nn as nn
+
+from ...layers.rnn import DWSConvLSTM2d
+from ...layers.maxvit.maxvit import PartitionAttentionCl, nhwC_2_nChw, get_downsample_layer_Cf2Cl, PartitionType
+from .base import BaseDetector
+
+
+class MaxVitAttentionPairCl(nn.Module):
+    def __init__(self, dim: int, skip_first_norm: bool, attention_cfg):
+        super().__init__()
+        self.att_window = PartitionAttentionCl(dim=dim, partition_type=PartitionType.WINDOW,
+                                               attention_cfg=attention_cfg, skip_first_norm=skip_first_norm)
+        self.att_grid = PartitionAttentionCl(dim=dim, partition_type=PartitionType.GRID,
+                                             attention_cfg=attention_cfg, skip_first_norm=False)
+
+    def forward(self, x):
+        return self.att_grid(self.att_window(x))
+
+
+class RNNDetectorStage(nn.Module):
+    def __init__(self, dim_in: int, stage_dim: int, spatial_downsample_factor: int, num_blocks: int,
+                 enable_token_masking: bool, T_max_chrono_init: Optional[int], stage_cfg):
+        super().__init__()
+        assert isinstance(num_blocks, int) and num_blocks > 0
+        if enable_token_masking:
+            raise NotImplementedError('token masking (enable_masking) is off in every shipped config')
+        lstm_cfg = stage_cfg.lstm
+        self.downsample_cf2cl = get_downsample_layer_Cf2Cl(dim_in=dim_in, dim_out=stage_dim,
+                                                           downsample_factor=spatial_downsample_factor,
+                                                           downsample_cfg=stage_cfg.downsample)
+        self.att_blocks = nn.ModuleList([
+            MaxVitAttentionPairCl(dim=stage_dim, skip_first_norm=(i == 0 and self.downsample_cf2cl.output_is_normed()),
+                                  attention_cfg=stage_cfg.attention) for i in range(num_blocks)])
+        self.lstm = DWSConvLSTM2d(dim=stage_dim, dws_conv=lstm_cfg.dws_conv,
+                                  dws_conv_only_hidden=lstm_cfg.dws_conv_only_hidden,
+                                  dws_conv_kernel_size=lstm_cfg.dws_conv_kernel_size,
+                                  cell_update_dropout=lstm_cfg.get('drop_cell_update', 0))
+        self.mask_token = None
+
+    def forward(self, x: th.Tensor, h_and_c_previous=None, token_mask: Optional[th.Tensor] = None, padded_hw=None):
+        assert token_mask is None, 'token masking is not part of the shipped configs'
+        x = self.downsample_cf2cl(x, padded_hw=padded_hw)          # -> N H W C
+        for blk in self.att_blocks:
+            x = blk(x)
+        h_c = self.lstm(nhwC_2_nChw(x), h_and_c_previous)          # zero-copy view, no .contiguous()
+        return h_c[0], h_c
+
+
+class RNNDetector(BaseDetector):
+    def __init__(self, mdl_config):
+        super().__init__()
+        in_channels = mdl_config.input_channels
+        embed_dim = mdl_config.embed_dim
+        dim_multiplier = tuple(mdl_config.dim_multiplier)
+        num_blocks = tuple(mdl_config.num_blocks)
+        t_max = tuple(mdl_config.T_max_chrono_init)          # parsed, never used by the reference either
+        assert len(num_blocks) == 4 == len(dim_multiplier) == len(t_max)
+        assert isinstance(embed_dim, int)
+        self.in_res_hw = tuple(mdl_config.in_res_hw) if mdl_config.get('in_res_hw', None) is not None else None
+        patch_size = mdl_config.stem.patch_size
+        self.stage_dims = [embed_dim * m for m in dim_multiplier]
+        self.stages = nn.ModuleList()
+        self.strides = []
+        input_dim, stride = in_channels, 1
+        for i, (nb, tm) in enumerate(zip(num_blocks, t_max)):
+            factor = patch_size if i == 0 else 2
+            self.stages.append(RNNDetectorStage(dim_in=input_dim, stage_dim=self.stage_dims[i],
+                                                spatial_downsample_factor=factor, num_blocks=nb,
+                                                enable_token_masking=mdl_config.enable_masking and i == 0,
+                                                T_max_chrono_init=tm, stage_cfg=mdl_config.stage))
+            stride *= factor
+            self.strides.append(stride)
+            input_dim = self.stage_dims[i]
+        self.num_stages = 4
+
+    def get_stage_dims(self, stages: Tuple[int, ...]) -> Tuple[int, ...]:
+        idx = [s - 1 for s in stages]
+        assert min(idx) >= 0 and max(idx) < len(self.stages), idx
+        return tuple(self.stage_dims[i] for i in idx)
+
+    def get_strides(self, stages: Tuple[int, ...]) -> Tuple[int, ...]:
+        idx = [s - 1 for s in stages]
+        assert min(idx) >= 0 and max(idx) < len(self.stages), idx
+        return tuple(self.strides[i] for i in idx)
+
+    def forward(self, x: th.Tensor, prev_states=None, token_mask: Optional[th.Tensor] = None):
+        """x: [B,C,H,W] event voxels -- fp32 already padded to ``in_res_hw`` (reference convention) or the raw
+        uint8/fp32 unpadded tensor (the zero padding is then folded into the stem kernel)."""
+        if prev_states is None:
+            prev_states = [None] * self.num_stages
+        assert len(prev_states) == self.num_stages
+        padded_hw = self.in_res_hw if (self.in_res_hw is not None and tuple(x.shape[-2:]) != self.in_res_hw) else None
+        states, output = [], {}
+        for i, stage in enumerate(self.stages):
+            x, state = stage(x, prev_states[i], token_mask if i == 0 else None, padded_hw if i == 0 else None)
+            states.append(state)
+            output[i + 1] = x
+        return output, states

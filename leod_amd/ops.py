@@ -317,15 +317,16 @@ def head_pred_fwd(cls_feat, reg_feat, cls_w, cls_b, reg_w, reg_b, obj_w, obj_b, 
           'head_pred_fwd')
 
 
-def head_pred_bwd(d_raw, cls_feat, reg_feat, cls_w, reg_w, obj_w, d_cls_w, d_cls_b, d_reg_w, d_reg_b, d_obj_w, d_obj_b, a0):
+def head_pred_bwd(d_raw, cls_feat, reg_feat, cls_w, reg_w, obj_w, d_cls_w, d_cls_b, d_reg_w, d_reg_b, d_obj_w, d_obj_b, a0,
+                  gscale=None):
     B, h, w, Hd = cls_feat.shape
     nc = cls_w.shape[0]
     A = d_raw.shape[1]
     dcf = _empty(cls_feat.shape, cls_feat)
     drf = _empty(reg_feat.shape, reg_feat)
     check(lib().leod_head_pred_bwd(_p(d_raw), _p(cls_feat), _p(reg_feat), _p(cls_w), _p(reg_w), _p(obj_w), _p(dcf), _p(drf),
-                                   _p(d_cls_w), _p(d_cls_b), _p(d_reg_w), _p(d_reg_b), _p(d_obj_w), _p(d_obj_b), B, h, w,
-                                   Hd, nc, a0, A, _stream()), 'head_pred_bwd')
+                                   _p(d_cls_w), _p(d_cls_b), _p(d_reg_w), _p(d_reg_b), _p(d_obj_w), _p(d_obj_b), _p(gscale),
+                                   B, h, w, Hd, nc, a0, A, _stream()), 'head_pred_bwd')
     return dcf, drf
 
 

@@ -36,9 +36,12 @@ def rnd(shape, seed, scale=1.0):
 
 
 def close(a, b, rtol=2e-5, atol=2e-6, what=''):
-    a = a.detach().float().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
-    b = b.detach().float().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
-    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg=what)
+    """fp32 parity: |a-b| <= atol + rtol*|b| with the absolute floor scaled by the tensor's magnitude
+    (fp32 dot products of length K carry ~sqrt(K)*eps*max|term| of summation-order noise)."""
+    a = a.detach().float().cpu().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().float().cpu().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    scale = float(np.abs(b).max()) if b.size else 1.0
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol + 5e-6 * scale if atol > 0 else 0, err_msg=what)
 
 
 # ---------------------------------------------------------------------------------------------------

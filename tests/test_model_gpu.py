@@ -1,0 +1,202 @@
+"""Model-level parity on the GPU: the HIP-backed modules (reference API, reference state-dict keys)
+against the golden vectors recorded from the reference and against the CPU oracle's autograd.
+``pytest -m gpu``."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import backbone as ob  # noqa: E402
+from oracle import head as oh  # noqa: E402
+from oracle import postproc as op  # noqa: E402
+from oracle import train_step as ot  # noqa: E402
+from oracle.synth import synth_state_dict, synth_events, synth_labels  # noqa: E402
+
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    return True
+
+
+def build(manifest, key, seed, size, dataset='gen1', micro=False, train=False, **head_over):
+    from leod_amd.config import full_config, dynamically_modify_train_config, create
+    from leod_amd.models.detection.yolox_extension.models.detector import YoloXDetector
+    over = {}
+    if micro:
+        over = dict(model=dict(backbone=dict(embed_dim=16, stage=dict(attention=dict(dim_head=8))), fpn=dict(depth=0.33)))
+    cfg = dynamically_modify_train_config(full_config(dataset, size, overrides=over))
+    if micro:
+        cfg.model.backbone.in_res_hw = (64, 96)
+        cfg.model.backbone.stage.attention.partition_size = (2, 3)
+    for k, v in head_over.items():
+        cfg.model.head[k] = v
+    det = YoloXDetector(cfg.model)
+    sd = synth_state_dict(manifest[key], seed)
+    det.load_state_dict(sd, strict=True)
+    det.to(DEV)
+    det.train(train)
+    return det, sd, cfg
+
+
+def close(a, b, rtol=1e-4, atol=1e-5, what=''):
+    a = a.detach().float().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().float().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    scale = float(np.abs(b).max()) if b.size else 1.0
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol + 1e-5 * scale, err_msg=what)
+
+
+MICRO = ot.model_cfg(embed_dim=16, dim_head=8, fpn_depth=0.33, partition_size=(2, 3), in_res_hw=(64, 96))
+
+
+def micro_labels(n_frames, seed, hw=(60, 90)):
+    labs = synth_labels(n_frames, hw, 2, seed=seed, max_boxes=4)
+    for l in labs:
+        l[:, 3] = l[:, 3].clamp(max=30)
+        l[:, 4] = l[:, 4].clamp(max=24)
+        l[:, 1] = torch.minimum(l[:, 1], hw[1] - 1 - l[:, 3])
+        l[:, 2] = torch.minimum(l[:, 2], hw[0] - 1 - l[:, 4])
+    return labs
+
+
+def test_backbone_micro_golden(gpu, golden_dir, manifest):
+    g = np.load(os.path.join(golden_dir, 'g04_backbone_micro.npz'))
+    det, _, _ = build(manifest, 'micro', 5, 'small', micro=True)
+    ev_u8 = synth_events(3, 2, 20, 60, 90, seed=4, as_uint8=True).to(DEV)
+    ev_f32 = ob.pad_ev_repr(ev_u8.float(), (64, 96))
+    for ev in (ev_u8, ev_f32):          # raw unpadded uint8 (padding folded into the stem) and reference-style padded fp32
+        states = None
+        with torch.no_grad():
+            for t in range(3):
+                feats, states = det.forward_backbone(ev[t], states)
+                for k, v in feats.items():
+                    assert tuple(v.shape) == g[f't{t}_s{k}'].shape
+                    close(v, g[f't{t}_s{k}'], what=f't{t} stage{k}')
+        for s, (h, c) in enumerate(states):
+            close(c, g[f'final_c{s + 1}'])
+
+
+def test_backbone_tiny256_golden(gpu, golden_dir, manifest):
+    g = np.load(os.path.join(golden_dir, 'g04_backbone_tiny256.npz'))
+    det, _, _ = build(manifest, 'tiny_gen1', 6, 'tiny')
+    ev = synth_events(2, 1, 20, 240, 304, seed=5, as_uint8=True).to(DEV)
+    with torch.no_grad():
+        feats, states = det.forward_backbone(ev[0], None)
+        feats, states = det.forward_backbone(ev[1], states)
+    for k, v in feats.items():
+        close(v.mean(), g[f's{k}_mean'], rtol=2e-4, atol=1e-6)
+        close(v.abs().max(), g[f's{k}_absmax'], rtol=2e-4)
+        close(v[0, :8, :4, :5], g[f's{k}_slice'], rtol=2e-4, atol=2e-5)
+
+
+def test_detector_head_golden_and_grads(gpu, golden_dir, manifest):
+    g = np.load(os.path.join(golden_dir, 'g05_head_micro.npz'))
+    det, sd, _ = build(manifest, 'micro', 5, 'small', micro=True)
+
+    def rnd(shape, seed):
+        return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+    feats_cpu = {2: rnd((3, 32, 8, 12), 51), 3: rnd((3, 64, 4, 6), 52), 4: rnd((3, 128, 2, 3), 53)}
+    with torch.no_grad():
+        pred, losses = det.forward_detect({k: v.to(DEV) for k, v in feats_cpu.items()})
+    assert losses is None
+    close(pred, g['pred_eval'], what='eval predictions')
+    # training mode: losses, BN buffers and every gradient against the oracle's autograd
+    labs = micro_labels(3, seed=7)
+    labs[1] = labs[1][:1]
+    labs[2][0, 1:5] = torch.tensor([0., 0., 12., 9.])
+    targets = op.batched_yolox_labels(labs)
+    det.train()
+    fg = {k: v.to(DEV).requires_grad_(True) for k, v in feats_cpu.items()}
+    pred, losses = det.forward_detect(fg, targets=targets.to(DEV))
+    close(pred, g['pred_train'], what='train predictions')
+    for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg'):
+        close(losses[k], g['loss_' + k], rtol=5e-5, what=k)
+    dsd = det.state_dict()
+    for k in ['fpn.lateral_conv0.bn.running_mean', 'fpn.lateral_conv0.bn.running_var',
+              'yolox_head.stems.0.bn.running_mean', 'yolox_head.cls_convs.2.1.bn.running_var']:
+        close(dsd[k], g['bn_' + k.replace('.', '_')], rtol=5e-5, atol=1e-6)
+    losses['loss'].backward()
+    osd = {k: v.clone() for k, v in sd.items()}
+    pkeys = [k for k, v in osd.items() if v.is_floating_point() and 'running_' not in k]
+    for k in pkeys:
+        osd[k].requires_grad_(True)
+    fo = {k: v.clone().requires_grad_(True) for k, v in feats_cpu.items()}
+    _, olosses = oh.detect_forward(fo, osd, MICRO, labels=targets.clone(), training=True)
+    olosses['loss'].backward()
+    params = dict(det.named_parameters())
+    for k in pkeys:
+        if osd[k].grad is None:
+            continue
+        close(params[k].grad, osd[k].grad, rtol=2e-3, atol=2e-5, what='grad ' + k)
+    for k in fo:
+        close(fg[k].grad, fo[k].grad, rtol=2e-3, atol=2e-5, what=f'grad feature {k}')
+    gk = [str(k) for k in g['grad_keys']]
+    mine = np.array([float(params[k].grad.norm()) for k in gk])
+    np.testing.assert_allclose(mine, g['grad_norms'], rtol=2e-3, atol=1e-6)
+
+
+def test_backbone_backward_vs_oracle(gpu, manifest):
+    """Gradients of a 3-step unrolled micro backbone (states carried, features of every stage used)."""
+    det, sd, _ = build(manifest, 'micro', 5, 'small', micro=True, train=True)
+    ev = synth_events(3, 2, 20, 60, 90, seed=4, as_uint8=True)
+    ws = {s: torch.randn((2, 16 * 2 ** (s - 1), 64 // 2 ** (s + 1), 96 // 2 ** (s + 1)),
+                         generator=torch.Generator().manual_seed(90 + s)) for s in (1, 2, 3, 4)}
+    states, loss = None, 0.
+    for t in range(3):
+        feats, states = det.forward_backbone(ev[t].to(DEV), states)
+        for s, v in feats.items():
+            loss = loss + (v * ws[s].to(DEV)).sum() * (0.5 + 0.25 * t)
+    loss = loss + (states[2][1] ** 2).sum()
+    loss.backward()
+    osd = {k: v.clone() for k, v in sd.items()}
+    bkeys = [k for k in osd if k.startswith('backbone.')]
+    for k in bkeys:
+        osd[k].requires_grad_(True)
+    evp = ob.pad_ev_repr(ev.float(), (64, 96))
+    states, oloss = None, 0.
+    for t in range(3):
+        feats, states = ob.backbone_forward(evp[t], states, osd, MICRO)
+        for s, v in feats.items():
+            oloss = oloss + (v * ws[s]).sum() * (0.5 + 0.25 * t)
+    oloss = oloss + (states[2][1] ** 2).sum()
+    oloss.backward()
+    close(loss, oloss, rtol=1e-4)
+    params = dict(det.named_parameters())
+    for k in bkeys:
+        close(params[k].grad, osd[k].grad, rtol=2e-3, atol=1e-5, what='grad ' + k)
+
+
+def test_small_real_geometry_fwd_bwd(gpu, manifest):
+    """RVT-small at the real Gen1 geometry (256x320, partition 8x10, dim_head 24), 2 timesteps, bs 1:
+    forward features and a sample of gradients vs the oracle."""
+    det, sd, _ = build(manifest, 'small_gen1', 3, 'small', train=True)
+    cfg = ot.model_cfg(48, 24, 0.33, (8, 10))
+    ev = synth_events(2, 1, 20, 240, 304, seed=9, as_uint8=True)
+    states, loss = None, 0.
+    for t in range(2):
+        feats, states = det.forward_backbone(ev[t].to(DEV), states)
+    loss = sum((v ** 2).mean() for v in feats.values())
+    loss.backward()
+    osd = {k: v.clone() for k, v in sd.items()}
+    bkeys = [k for k in osd if k.startswith('backbone.')]
+    for k in bkeys:
+        osd[k].requires_grad_(True)
+    evp = ob.pad_ev_repr(ev.float(), (256, 320))
+    states = None
+    for t in range(2):
+        ofeats, states = ob.backbone_forward(evp[t], states, osd, cfg)
+    oloss = sum((v ** 2).mean() for v in ofeats.values())
+    oloss.backward()
+    for s in ofeats:
+        close(feats[s], ofeats[s], rtol=2e-4, atol=2e-5, what=f'stage {s}')
+    close(loss, oloss, rtol=1e-4)
+    params = dict(det.named_parameters())
+    for k in bkeys:
+        close(params[k].grad, osd[k].grad, rtol=3e-3, atol=1e-6, what='grad ' + k)
