@@ -93,15 +93,15 @@ int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, float* dbia
                          int ks, int stride, int pad, leod_stream_t stream);
 
 /* BatchNorm2d (batch statistics) + SiLU on rows and its autograd (network_blocks.py:47-51).  `count` = rows that
- * entered colstats/sums (all ranks under SyncBN). */
+ * entered colstats/sums; count_dev (optional, device scalar) overrides it (all-rank row count under SyncBN). */
 int leod_bn_silu_fwd(const float* z, const double* colstats, const float* w, const float* b, float* y, float* save_mean,
-                     float* save_rstd, float* run_mean, float* run_var, int M, int N, double count, float eps,
-                     float momentum, leod_stream_t stream);
+                     float* save_rstd, float* run_mean, float* run_var, int M, int N, double count,
+                     const double* count_dev, float eps, float momentum, leod_stream_t stream);
 int leod_bn_silu_bwd_reduce(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
                             const float* b, double* sums, int M, int N, leod_stream_t stream);
 int leod_bn_silu_bwd_apply(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
                            const float* b, const double* sums, float* dz, float* dw, float* db, int M, int N, double count,
-                           leod_stream_t stream);
+                           const double* count_dev, leod_stream_t stream);
 
 /* ---- YOLOX head tail (models/detection/yolox/models/yolo_head.py) --------------------------------- */
 

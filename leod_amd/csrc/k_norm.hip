@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const float* __restric
                                                           float* __restrict__ y, float* __restrict__ save_mean,
                                                           float* __restrict__ save_rstd, float* __restrict__ run_mean,
                                                           float* __restrict__ run_var, long M, int N, double count,
-                                                          float eps, float momentum) {
+                                                          const double* __restrict__ count_dev, float eps, float momentum) {
+    if (count_dev) count = count_dev[0];
     const long n4 = M * N / 4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
         const long e = idx * 4; const int c = (int)(e % N);
@@ -270,7 +271,8 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const float* __r
                                                                 const float* __restrict__ w, const float* __restrict__ b,
                                                                 const double* __restrict__ sums, float* __restrict__ dz,
                                                                 float* __restrict__ dw, float* __restrict__ db, long M, int N,
-                                                                double count) {
+                                                                double count, const double* __restrict__ count_dev) {
+    if (count_dev) count = count_dev[0];
     const long n4 = M * N / 4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
         const long e = idx * 4; const int c = (int)(e % N);
@@ -342,11 +344,11 @@ LEOD_API int leod_convlstm_gates_bwd(const float* dh, const float* dc_next, cons
 
 LEOD_API int leod_bn_silu_fwd(const float* z, const double* colstats, const float* w, const float* b, float* y,
                               float* save_mean, float* save_rstd, float* run_mean, float* run_var, int M, int N,
-                              double count, float eps, float momentum, hipStream_t stream) {
+                              double count, const double* count_dev, float eps, float momentum, hipStream_t stream) {
     if (!z || !colstats || !w || !b || !y || !save_mean || !save_rstd || (N & 3)) return LEOD_ERR_ARG;
     if (M <= 0) return LEOD_OK;
     hipLaunchKernelGGL(bn_silu_fwd_kernel, dim3(flat_grid((long)M * N / 4)), dim3(256), 0, stream, z, colstats, w, b, y,
-                       save_mean, save_rstd, run_mean, run_var, (long)M, N, count, eps, momentum);
+                       save_mean, save_rstd, run_mean, run_var, (long)M, N, count, count_dev, eps, momentum);
     return leod_launch_status();
 }
 
@@ -362,10 +364,10 @@ LEOD_API int leod_bn_silu_bwd_reduce(const float* dy, const float* z, const floa
 
 LEOD_API int leod_bn_silu_bwd_apply(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
                                     const float* b, const double* sums, float* dz, float* dw, float* db, int M, int N,
-                                    double count, hipStream_t stream) {
+                                    double count, const double* count_dev, hipStream_t stream) {
     if (!dy || !z || !mean || !rstd || !w || !b || !sums || !dz || (N & 3)) return LEOD_ERR_ARG;
     if (M <= 0) return LEOD_OK;
     hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(flat_grid((long)M * N / 4)), dim3(256), 0, stream, dy, z, mean, rstd,
-                       w, b, sums, dz, dw, db, (long)M, N, count);
+                       w, b, sums, dz, dw, db, (long)M, N, count, count_dev);
     return leod_launch_status();
 }

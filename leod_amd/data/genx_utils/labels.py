@@ -1,0 +1,222 @@
+"""Box-label containers on the boundary of the hot path (the subset of the reference's
+data/genx_utils/labels.py that the detection / pseudo-label modules touch).
+
+Layout contract kept from the reference: ``object_labels`` is float [N, 8] =
+(t, x, y, w, h, class_id, class_confidence, objectness) with (x, y) the TOP-LEFT corner; pseudo labels
+carry t == 0; the loss target layout is [B, Nmax, 7] = (cls, cx, cy, w, h, obj, cls_conf) zero padded
+(labels.py:543-603).  BBOX_DTYPE is the 40-byte on-disk record (labels.py:12-16)."""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch as th
+
+BBOX_DTYPE = np.dtype({
+    'names': ['t', 'x', 'y', 'w', 'h', 'class_id', 'class_confidence', 'objectness'],
+    'formats': ['<i8', '<f4', '<f4', '<f4', '<f4', '<u4', '<f4', '<f4'],
+    'offsets': [0, 8, 12, 16, 20, 24, 28, 32], 'itemsize': 40})
+
+FIELDS = ('t', 'x', 'y', 'w', 'h', 'class_id', 'class_confidence', 'objectness')
+_IDX = {k: i for i, k in enumerate(FIELDS)}
+
+
+class ObjectLabels:
+    _str2idx = dict(_IDX)
+
+    def __init__(self, object_labels: th.Tensor, input_size_hw: Tuple[int, int]):
+        if isinstance(object_labels, np.ndarray):
+            object_labels = th.from_numpy(object_labels)
+        assert object_labels.is_floating_point() and object_labels.dim() == 2 and object_labels.shape[1] == len(FIELDS)
+        assert isinstance(input_size_hw, tuple) and len(input_size_hw) == 2
+        self.object_labels = object_labels
+        self._input_size_hw = input_size_hw
+
+    # ---- field access -------------------------------------------------------------------------------
+    def __getattr__(self, name):
+        idx = _IDX.get(name)
+        if idx is None:
+            raise AttributeError(name)
+        return self.object_labels[:, idx]
+
+    def _set(self, name, value):
+        self.object_labels[:, _IDX[name]] = value
+
+    def get(self, request: str):
+        return self.object_labels[:, _IDX[request]]
+
+    @property
+    def input_size_hw(self):
+        return self._input_size_hw
+
+    @input_size_hw.setter
+    def input_size_hw(self, hw):
+        assert isinstance(hw, tuple) and len(hw) == 2 and hw[0] > 0 and hw[1] > 0
+        self._input_size_hw = hw
+
+    @classmethod
+    def keys(cls) -> List[str]:
+        return list(FIELDS)
+
+    @property
+    def dtype(self):
+        return self.object_labels.dtype
+
+    @property
+    def device(self):
+        return self.object_labels.device
+
+    def __len__(self):
+        return self.object_labels.shape[0]
+
+    def __add__(self, other: 'ObjectLabels') -> 'ObjectLabels':
+        assert isinstance(other, ObjectLabels) and self.input_size_hw == other.input_size_hw
+        return ObjectLabels(th.cat([self.object_labels, other.object_labels], dim=0), self.input_size_hw)
+
+    def to(self, *args, **kwargs):
+        self.object_labels = self.object_labels.to(*args, **kwargs)
+        return self
+
+    def new_zeros(self) -> 'ObjectLabels':
+        return ObjectLabels(self.object_labels.new_zeros((0, len(FIELDS))), self.input_size_hw)
+
+    # ---- predicates ---------------------------------------------------------------------------------
+    def is_pseudo_label(self):
+        return self.object_labels[:, 0] == 0          # pseudo labels are written with t == 0
+
+    def is_gt_label(self):
+        return ~self.is_pseudo_label()
+
+    def is_ignore(self, ignore_label):
+        return self.object_labels[:, 5] == ignore_label
+
+    # ---- transforms the hot path uses -----------------------------------------------------------------
+    def flip_lr_(self) -> None:
+        if len(self):
+            self._set('x', self.input_size_hw[1] - 1 - self.object_labels[:, 1] - self.object_labels[:, 3])
+
+    def reverse_flip_lr_(self) -> None:
+        self.flip_lr_()
+
+    def clamp_to_frame_(self):
+        ht, wd = self.input_size_hw
+        o = self.object_labels
+        x0, y0 = o[:, 1].clamp(0, wd - 1), o[:, 2].clamp(0, ht - 1)
+        x1, y1 = (o[:, 1] + o[:, 3]).clamp(0, wd - 1), (o[:, 2] + o[:, 4]).clamp(0, ht - 1)
+        o[:, 1], o[:, 2], o[:, 3], o[:, 4] = x0, y0, x1 - x0, y1 - y0
+
+    def get_xywh(self, format_='center', add_class_id=False):
+        o = self.object_labels
+        x, y = (o[:, 1] + 0.5 * o[:, 3], o[:, 2] + 0.5 * o[:, 4]) if format_ == 'center' else (o[:, 1], o[:, 2])
+        cols = [x, y, o[:, 3], o[:, 4]] + ([o[:, 5]] if add_class_id else [])
+        return th.stack(cols, dim=-1)
+
+    def get_xyxy(self, add_class_id=False):
+        o = self.object_labels
+        cols = [o[:, 1], o[:, 2], o[:, 1] + o[:, 3], o[:, 2] + o[:, 4]] + ([o[:, 5]] if add_class_id else [])
+        return th.stack(cols, dim=-1)
+
+    def get_labels_as_tensors(self, format_: str = 'yolox') -> th.Tensor:
+        o = self.object_labels
+        out = th.zeros((len(self), 7), dtype=th.float32, device=o.device)
+        if len(self) == 0:
+            return out
+        if format_ == 'yolox':          # (cls, cx, cy, w, h, obj, cls_conf)
+            out[:, 0], out[:, 1], out[:, 2] = o[:, 5], o[:, 1] + 0.5 * o[:, 3], o[:, 2] + 0.5 * o[:, 4]
+            out[:, 3], out[:, 4], out[:, 5], out[:, 6] = o[:, 3], o[:, 4], o[:, 7], o[:, 6]
+        elif format_ == 'prophesee':    # (x1, y1, x2, y2, obj, cls_conf, cls)
+            out[:, 0], out[:, 1], out[:, 2], out[:, 3] = o[:, 1], o[:, 2], o[:, 1] + o[:, 3], o[:, 2] + o[:, 4]
+            out[:, 4], out[:, 5], out[:, 6] = o[:, 7], o[:, 6], o[:, 5]
+        else:
+            raise NotImplementedError(format_)
+        return out
+
+    @staticmethod
+    def pad_labels(obj_label_list: Sequence[Union['ObjectLabels', th.Tensor]], N: int, format_: str = 'yolox') -> th.Tensor:
+        assert format_ == 'yolox'
+        first = obj_label_list[0]
+        dev = first.device
+        out = th.zeros((len(obj_label_list), N, 7), dtype=th.float32, device=dev)
+        for i, l in enumerate(obj_label_list):
+            t = l.get_labels_as_tensors('yolox') if isinstance(l, ObjectLabels) else l
+            out[i, :len(t)] = t
+        return out
+
+    @staticmethod
+    def get_labels_as_batched_tensor(obj_label_list: List['ObjectLabels'], format_: str = 'yolox') -> th.Tensor:
+        assert len(obj_label_list) > 0
+        N = max(len(x) for x in obj_label_list)
+        assert N > 0
+        return ObjectLabels.pad_labels(obj_label_list, N=N, format_=format_)
+
+    @staticmethod
+    def from_structured_array(labels: np.ndarray, input_size_hw: Tuple[int, int]) -> 'ObjectLabels':
+        cols = []
+        for k in FIELDS:
+            src = k if k in labels.dtype.names else 'class_confidence'     # objectness defaults to class_confidence
+            cols.append(labels[src].astype('float32'))
+        return ObjectLabels(th.from_numpy(np.stack(cols, axis=1)), input_size_hw)
+
+    def to_structured_array(self) -> np.ndarray:
+        o = self.object_labels.detach().cpu().numpy()
+        out = np.zeros((len(self),), dtype=BBOX_DTYPE)
+        for k in FIELDS:
+            out[k] = o[:, _IDX[k]]
+        return out
+
+
+class SparselyBatchedObjectLabels:
+    """One timestep of a batch: a list (len B) of ObjectLabels or None."""
+
+    def __init__(self, sparse_object_labels_batch: List[Optional[ObjectLabels]]):
+        self.sparse_object_labels_batch = [None if (l is not None and len(l) == 0) else l
+                                           for l in sparse_object_labels_batch]
+
+    def __len__(self):
+        return len(self.sparse_object_labels_batch)
+
+    def __iter__(self):
+        return iter(self.sparse_object_labels_batch)
+
+    def __getitem__(self, item: int):
+        if item < 0 or item >= len(self):
+            raise IndexError(item)
+        return self.sparse_object_labels_batch[item]
+
+    def __add__(self, other):
+        return SparselyBatchedObjectLabels(self.sparse_object_labels_batch + other.sparse_object_labels_batch)
+
+    def is_empty(self):
+        return all(x is None for x in self.sparse_object_labels_batch)
+
+    def set_non_gt_labels_to_none_(self):
+        """Drop frames that only carry pseudo labels (never GT) -- modules/detection.py:141-147."""
+        for i, l in enumerate(self.sparse_object_labels_batch):
+            if l is not None and bool(l.is_pseudo_label().all()):
+                self.sparse_object_labels_batch[i] = None
+
+    def flip_lr_(self):
+        for l in self.sparse_object_labels_batch:
+            if l is not None:
+                l.flip_lr_()
+
+    def to(self, *args, **kwargs):
+        for l in self.sparse_object_labels_batch:
+            if l is not None:
+                l.to(*args, **kwargs)
+        return self
+
+    def get_valid_labels_and_batch_indices(self, ignore: bool = False, ignore_label: int = None):
+        out, idx = [], []
+        for i, l in enumerate(self.sparse_object_labels_batch):
+            if l is None:
+                continue
+            if ignore and bool(l.is_ignore(ignore_label).all()):
+                continue
+            out.append(l)
+            idx.append(i)
+        return out, idx
+
+    @staticmethod
+    def transpose_list(lst: List['SparselyBatchedObjectLabels']) -> List['SparselyBatchedObjectLabels']:
+        return [SparselyBatchedObjectLabels(list(t)) for t in zip(*lst)]

@@ -58,7 +58,7 @@ class ConvLNFn(Function):
 
     @staticmethod
     def forward(ctx, mod, x, conv_w, ln_w, ln_b, is_stem: bool, stride: int, padded_hw):
-        need = torch.is_grad_enabled()
+        need = any(ctx.needs_input_grad)
         if is_stem:
             z = ops.stem_conv_fwd(x, conv_w, padded_hw, stride, conv_w.shape[-1] // 2)
         else:
@@ -89,7 +89,7 @@ class AttnBlockFn(Function):
 
     @staticmethod
     def forward(ctx, mod, x, *params):
-        need = torch.is_grad_enabled()
+        need = any(ctx.needs_input_grad)
         (n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, g1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, g2) = params
         heads, part, window = mod.self_attn.num_heads, mod.partition_size, mod.partition_window
         qkv, _, st1 = ops.ln_linear_fwd(x, n1w, n1b, qkv_w, qkv_b, want_stats=need)
@@ -138,7 +138,7 @@ class ConvLSTMFn(Function):
 
     @staticmethod
     def forward(ctx, mod, x, h_prev, c_prev, w, b):
-        need = torch.is_grad_enabled()
+        need = any(ctx.needs_input_grad)
         C = x.shape[-1]
         h, c, gates = ops.convlstm_fwd(x, h_prev, c_prev, w.view(4 * C, 2 * C), b, want_gates=need)
         if need:
@@ -173,19 +173,18 @@ class BaseConvFn(Function):
         colstats = torch.zeros((2, N), dtype=torch.float64, device=x.device)
         z = ops.conv_nhwc_fwd(x, conv_w, None, stride=stride, colstats=colstats)
         count = z.numel() // N
-        if _SYNC_BN['world_size'] > 1:
-            cnt = torch.tensor([float(count)], dtype=torch.float64, device=x.device)
-            packed = torch.cat([colstats.view(-1), cnt])
+        count_dev = None
+        if _SYNC_BN['world_size'] > 1:      # SyncBatchNorm: one small all-reduce of (sum, sumsq, rows) per layer
+            packed = torch.cat([colstats.view(-1), torch.full((1,), float(count), dtype=torch.float64, device=x.device)])
             _allreduce_stats(packed)
-            colstats = packed[:-1].view(2, N).contiguous()
-            count = packed[-1]          # stays on the device; the kernels take it as a host double below
-            count = float(count)        # one small sync per layer only under SyncBN (as in the reference)
+            colstats = packed
+            count_dev = packed[2 * N:]
         mom = mod.bn.momentum if mod.bn.momentum is not None else 0.1
         y, mean, rstd = ops.bn_silu_fwd(z, colstats, bn_w, bn_b, mod.bn.running_mean, mod.bn.running_var, count,
-                                        eps=mod.bn.eps, momentum=mom)
+                                        eps=mod.bn.eps, momentum=mom, count_dev=count_dev)
         mod.bn.num_batches_tracked += 1
-        if torch.is_grad_enabled():
-            ctx.mod, ctx.stride, ctx.count = mod, stride, count
+        if any(ctx.needs_input_grad):
+            ctx.mod, ctx.stride, ctx.count, ctx.count_dev = mod, stride, count, count_dev
             ctx.save_for_backward(x, z, mean, rstd, conv_w, bn_w, bn_b)
         return y
 
@@ -196,7 +195,8 @@ class BaseConvFn(Function):
         dy = _cont(dy)
         sums = ops.bn_silu_bwd_reduce(dy, z, mean, rstd, bn_w, bn_b)
         _allreduce_stats(sums)
-        dz = ops.bn_silu_bwd_apply(dy, z, mean, rstd, bn_w, bn_b, sums, grad_buf(mod.bn.weight), grad_buf(mod.bn.bias), ctx.count)
+        dz = ops.bn_silu_bwd_apply(dy, z, mean, rstd, bn_w, bn_b, sums, grad_buf(mod.bn.weight), grad_buf(mod.bn.bias), ctx.count,
+                                   count_dev=ctx.count_dev)
         ops.conv_nhwc_wgrad(dz, x, grad_buf(mod.conv.weight), None, stride=ctx.stride)
         dx = ops.conv_nhwc_dgrad(dz, conv_w, x.shape, stride=ctx.stride) if ctx.needs_input_grad[1] else None
         return None, dx, None, None, None, None, None
@@ -232,7 +232,7 @@ class HeadTailFn(Function):
             a0 += hws[k][0] * hws[k][1]
         labels = mod._ignore_bbox(labels)
         asg = ops.simota_assign(out_train, labels, hws, mod.strides, ignore_label=float(mod.ignore_label))
-        need = torch.is_grad_enabled()
+        need = any(ctx.needs_input_grad)
         losses, d_raw = ops.yolox_loss(out_train, labels, asg, hws, mod.strides, want_grad=need,
                                        focal=mod.obj_focal_loss, reg_weight=mod.reg_weight, obj_weight=mod.obj_weight,
                                        cls_weight=mod.cls_weight)

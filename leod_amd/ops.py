@@ -266,7 +266,7 @@ def conv_nhwc_wgrad(dy, x, dw, dbias=None, stride=1):
           'conv_nhwc_wgrad')
 
 
-def bn_silu_fwd(z, colstats, w, b, run_mean, run_var, count, eps=1e-5, momentum=0.1):
+def bn_silu_fwd(z, colstats, w, b, run_mean, run_var, count, eps=1e-5, momentum=0.1, count_dev=None):
     _ck(z, name='z')
     _ck(colstats, torch.float64, 'colstats')
     N = z.shape[-1]
@@ -275,7 +275,7 @@ def bn_silu_fwd(z, colstats, w, b, run_mean, run_var, count, eps=1e-5, momentum=
     mean = _empty((N,), z)
     rstd = _empty((N,), z)
     check(lib().leod_bn_silu_fwd(_p(z), _p(colstats), _p(w), _p(b), _p(y), _p(mean), _p(rstd), _p(run_mean), _p(run_var),
-                                 M, N, float(count), eps, momentum, _stream()), 'bn_silu_fwd')
+                                 M, N, float(count), _p(count_dev), eps, momentum, _stream()), 'bn_silu_fwd')
     return y, mean, rstd
 
 
@@ -289,12 +289,12 @@ def bn_silu_bwd_reduce(dy, z, mean, rstd, w, b):
     return sums
 
 
-def bn_silu_bwd_apply(dy, z, mean, rstd, w, b, sums, dw, db, count):
+def bn_silu_bwd_apply(dy, z, mean, rstd, w, b, sums, dw, db, count, count_dev=None):
     N = z.shape[-1]
     M = z.numel() // N
     dz = _empty(z.shape, z)
     check(lib().leod_bn_silu_bwd_apply(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(sums), _p(dz), _p(dw), _p(db),
-                                       M, N, float(count), _stream()), 'bn_silu_bwd_apply')
+                                       M, N, float(count), _p(count_dev), _stream()), 'bn_silu_bwd_apply')
     return dz
 
 

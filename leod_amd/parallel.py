@@ -1,0 +1,124 @@
+"""Data-parallel plumbing for the LEOD training step on MI355X: one process per GPU, RCCL over xGMI.
+
+* ``FlatParams``: every trainable parameter becomes a 16-byte-aligned view into ONE fp32 buffer and every
+  ``.grad`` a view into ONE gradient buffer.  The wgrad kernels accumulate straight into it, the
+  optimiser is one ``leod_adamw_clip_step`` launch, zeroing is one memset and the gradient exchange is
+  ONE all-reduce of the flat buffer (RVT-S: 39.5 MB; on the fully connected xGMI mesh this is latency-,
+  not bandwidth-bound, and gradients of the recurrent backbone only become final at the very end of the
+  backward pass, so bucketed overlap would buy nothing -- SURVEY 2.2 C1).
+* SyncBatchNorm statistics go through ``functions.set_sync_batchnorm`` (reference: train.py:247).
+* Pseudo-labelling shards whole recordings over ranks with no collective on the data path
+  (``shard_sequences``; reference: data/utils/stream_sharded_datapipe.py:40-57,88-105).
+"""
+import os
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from . import functions as Fn
+
+ALIGN = 4   # floats (16 bytes): weight rows are read with 16-byte loads
+
+
+class FlatParams:
+    def __init__(self, module: torch.nn.Module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        dev = self.params[0].device
+        offs, n = [], 0
+        for p in self.params:
+            offs.append(n)
+            n += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.numel = n
+        self.data = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, offs):
+            k = p.numel()
+            self.data[o:o + k].copy_(p.detach().reshape(-1))
+            p.data = self.data[o:o + k].view(p.shape)
+            p.grad = self.grad[o:o + k].view(p.shape)
+        self.offsets = offs
+        self.step_count = 0
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def adamw_step(self, lr, weight_decay=0.0, clip_value=1.0, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
+        """value-clip + AdamW (reference: train.py:236-237 gradient_clip_val=1.0 by value; detection.py:485-488)."""
+        self.step_count += 1
+        ops.adamw_clip_step(self.data, self.grad, self.exp_avg, self.exp_avg_sq, lr, self.step_count, betas=betas,
+                            eps=eps, weight_decay=weight_decay, clip_value=clip_value, grad_scale=grad_scale)
+
+
+def one_cycle_lr(step, max_lr, total_steps, pct_start=0.005, div_factor=20, final_div_factor=10000):
+    """OneCycleLR(linear, no momentum cycling) with the reference's convention final_lr = max_lr/final_div_factor
+    (modules/detection.py:498-511)."""
+    initial_lr = max_lr / div_factor
+    min_lr = max_lr / final_div_factor
+    end1 = float(pct_start * total_steps) - 1
+    end2 = total_steps - 1
+    if step <= end1:
+        return (max_lr - initial_lr) * (step / end1) + initial_lr
+    return (min_lr - max_lr) * ((step - end1) / (end2 - end1)) + max_lr
+
+
+class DataParallel:
+    """Gradient averaging across ranks for a FlatParams buffer (torch.distributed 'nccl' == RCCL on ROCm,
+    'gloo' in the CPU tests)."""
+
+    def __init__(self, flat: Optional[FlatParams], process_group=None, sync_bn: bool = True):
+        self.flat = flat
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        if sync_bn and self.world_size > 1:
+            Fn.set_sync_batchnorm(process_group, self.world_size)
+
+    def broadcast_parameters(self, src=0):
+        if self.world_size > 1:
+            dist.broadcast(self.flat.data, src=src, group=self.group)
+
+    def all_reduce_gradients(self) -> float:
+        """Sum-reduce the flat gradient; returns the scale (1/world) the optimiser kernel applies."""
+        if self.world_size > 1:
+            dist.all_reduce(self.flat.grad, group=self.group)
+        return 1.0 / self.world_size
+
+
+def init_distributed(backend: Optional[str] = None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torchrun contract)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_sequences(lengths: Sequence[int], world_size: int, rank: int, keys: Optional[Sequence] = None) -> List[int]:
+    """Deal whole recordings to ranks: sort by length (descending) and assign in 'pyramid' (boustrophedon) order so
+    every rank gets a similar number of frames -- the order the reference uses for dataloader workers
+    (stream_sharded_datapipe.py:40-57).  ``keys`` (e.g. the recording path) groups entries that must stay together:
+    a recording and its time-flipped copy share a key and land on the same rank."""
+    n = len(lengths)
+    if keys is None:
+        keys = list(range(n))
+    groups = {}
+    for i, k in enumerate(keys):
+        groups.setdefault(k, []).append(i)
+    items = sorted(groups.items(), key=lambda kv: (-sum(lengths[i] for i in kv[1]), str(kv[0])))
+    mine: List[int] = []
+    for pos, (_, idxs) in enumerate(items):
+        rnd, slot = divmod(pos, world_size)
+        owner = slot if rnd % 2 == 0 else world_size - 1 - slot
+        if owner == rank:
+            mine.extend(idxs)
+    return sorted(mine)
