@@ -151,9 +151,12 @@ def linear_wgrad(dy, x, dW, dbias=None, stats=None, ln_w=None, ln_b=None, x2=Non
     K = dW.numel() // N
     M = dy.numel() // N
     K1 = x.shape[-1]
+    ev = _probe('linear_wgrad', 4.0 * (M * N + M * K + N * K))      # reads dy, X ; read-modify-writes dW (counted once)
     check(lib().leod_linear_wgrad(_p(dy), N, _p(x), K1, _p(stats), _p(ln_w), _p(ln_b), _p(x2),
                                   (x2.shape[-1] if x2 is not None else 0), K1, _p(dW), _p(dbias), M, N, K, _stream()),
           'linear_wgrad')
+    if ev is not None:
+        ev.record()
 
 
 def layernorm_fwd(x, w, b, want_stats=False, eps=1e-5):
@@ -415,3 +418,48 @@ def voxelize_u8(x, y, pol, t, bins, height, width, count_cutoff=None, fastmode=T
                                  0 if count_cutoff is None else int(count_cutoff), 1 if fastmode else 0, _stream()),
           'voxelize_u8')
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# live kernel timing for bench.py's roofline object
+# ---------------------------------------------------------------------------------------------------
+_PROBE = None
+
+
+class KernelProbe:
+    """Brackets every launch of ONE kernel family with HIP events on the launch stream (torch's current stream is
+    the stream every leod_* call is enqueued on) and tallies its algorithmic bytes:
+    achieved GB/s = sum(bytes) / sum(event time).  Default target: the weight-gradient GEMM ``wgrad16_kernel`` behind
+    ``linear_wgrad`` (the dominant kernel of the training step, see profiles/)."""
+
+    def __init__(self, target: str = 'linear_wgrad', kernel_name: str = 'wgrad16_kernel<.., XRows>'):
+        global _PROBE
+        self.target, self.kernel_name = target, kernel_name
+        self.events, self.bytes = [], 0.0
+        _PROBE = self
+
+    def begin(self, nbytes):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.events.append((e0, e1))
+        self.bytes += nbytes
+        return e1
+
+    def finish(self, peak_gbs):
+        global _PROBE
+        _PROBE = None
+        torch.cuda.synchronize()
+        if not self.events:
+            return None
+        ms = sum(a.elapsed_time(b) for a, b in self.events)
+        n = len(self.events)
+        achieved = self.bytes / (ms * 1e-3) / 1e9
+        return {'bound': 'hbm', 'kernel': self.kernel_name, 'launches': n, 'avg_us': round(1e3 * ms / n, 3),
+                'algorithmic_bytes_per_launch': round(self.bytes / n, 1), 'achieved': round(achieved, 2),
+                'peak': peak_gbs, 'unit': 'GB/s', 'frac': round(achieved / peak_gbs, 5), 'traffic': None}
+
+
+def _probe(name, nbytes):
+    if _PROBE is not None and _PROBE.target == name:
+        return _PROBE.begin(nbytes)
+    return None
