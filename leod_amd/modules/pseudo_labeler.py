@@ -1,0 +1,256 @@
+"""Pseudo-label generation loop with the reference's surface (modules/pseudo_labeler.py:27-796):
+``BBOX_DTYPE``, ``tta_postprocess`` (ObjectLabels flavour), ``EventSeqData`` and ``PseudoLabeler``.
+
+The per-batch hot loop (hflip copy, frame masks, backbone over L, head + postprocess + pred2label on the
+selected frames) runs on the HIP kernels; the ragged per-sequence bookkeeping stays host Python as in the
+reference.  Tracker-based filtering / in-painting (modules/tracking, pseudo_labeler.py:201-333) is the next
+component after the hot path and is not part of this module yet: ``EventSeqData.save``
+writes the NMS-merged labels."""
+import copy
+import os
+import os.path as osp
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch as th
+
+from leod_amd.data.genx_utils.labels import ObjectLabels, SparselyBatchedObjectLabels, BBOX_DTYPE  # noqa: F401
+from leod_amd.data.utils.types import DataType
+from leod_amd.models.detection.yolox.utils.boxes import postprocess
+from .detection import Module
+from .utils.detection import BackboneFeatureSelector, SeqLens, Mode, DATA_KEY
+from .utils.ssod import pred2label, filter_pred_boxes
+from .utils.tta import tta_postprocess as _tta_rows
+
+
+def tta_postprocess(preds: List[ObjectLabels], conf_thre: float = 0.7, nms_thre: float = 0.45,
+                    class_agnostic: bool = False) -> List[ObjectLabels]:
+    """Merge the (already concatenated) TTA predictions of each frame; frames that hold GT are passed through."""
+    if len(preds) == 0:
+        return preds
+    out: List[ObjectLabels] = [preds[0].new_zeros()] * len(preds)
+    rows, keep_idx = [], []
+    for i, p in enumerate(preds):
+        if len(p) and bool(p.is_gt_label().any()):
+            out[i] = p
+            continue
+        if len(p) == 0:
+            continue
+        rows.append(p.get_labels_as_tensors(format_='prophesee'))
+        keep_idx.append(i)
+    merged = _tta_rows(rows, conf_thre, nms_thre, class_agnostic, pad=None)
+    for i, det in zip(keep_idx, merged):
+        if det is None:
+            continue
+        # pseudo labels carry t == 0, so the time column of the merged boxes is 0 as well
+        lab = th.cat([th.zeros_like(det[:, :1]), det[:, 0:2], det[:, 2:4] - det[:, 0:2], det[:, 6:7], det[:, 5:6], det[:, 4:5]], 1)
+        out[i] = ObjectLabels(lab, preds[i].input_size_hw)
+    return out
+
+
+class EventSeqData:
+    """Accumulates the labels of one recording across batches and TTA views."""
+
+    def __init__(self, path: str, scale_ratio: float, filter_config, postproc_cfg):
+        self.path, self.scale_ratio = path, scale_ratio
+        self.filter_config, self.postproc_cfg = filter_config, postproc_cfg
+        self._eoe, self._aug = False, False
+        self.frame_idx_2_labels: Dict[int, ObjectLabels] = {}
+
+    def update(self, labels: List[Optional[ObjectLabels]], ev_idx: List[int], is_last_sample: bool,
+               is_padded_mask: List[bool], is_hflip: bool, is_tflip: bool, tflip_offset: int) -> None:
+        self._eoe = is_last_sample
+        if is_hflip:                       # un-flip: x <- W - 1 - x - w
+            for l in labels:
+                if l is not None:
+                    l.flip_lr_()
+            self._aug = True
+        if is_tflip:
+            ev_idx = [i + tflip_offset for i in ev_idx]
+            self._aug = True
+        for tidx, (label, frame_idx) in enumerate(zip(labels, ev_idx)):
+            if frame_idx < 0 or label is None or len(label) == 0:
+                continue
+            assert not is_padded_mask[tidx]
+            if self.scale_ratio != 1:
+                label.object_labels[:, 1:5] *= self.scale_ratio
+                label.input_size_hw = tuple(int(s * self.scale_ratio) for s in label.input_size_hw)
+            if frame_idx in self.frame_idx_2_labels:
+                if bool(label.is_gt_label().any()):
+                    continue               # GT is stored once
+                self.frame_idx_2_labels[frame_idx] = self.frame_idx_2_labels[frame_idx] + label
+            else:
+                self.frame_idx_2_labels[frame_idx] = label
+
+    def eoe(self) -> bool:
+        return self._eoe
+
+    @property
+    def aug(self) -> bool:
+        return self._aug
+
+    def _aggregate_results(self, num_frames: int) -> None:
+        assert self._eoe, 'Cannot aggregate results before the sequence ends.'
+        self.frame_idx = sorted(i for i in self.frame_idx_2_labels if 0 <= i < num_frames)
+        self.labels = [self.frame_idx_2_labels[i] for i in self.frame_idx]
+        if self._aug and self.labels:
+            self.labels = tta_postprocess(self.labels, conf_thre=self.postproc_cfg.confidence_threshold,
+                                          nms_thre=self.postproc_cfg.nms_threshold)
+
+    def _summarize(self):
+        labels, cnt, f2l, f2r = [], 0, [], []
+        for label, fidx in zip(self.labels, self.frame_idx):
+            f2l.append(cnt)
+            cnt += len(label)
+            labels.append(label.to_structured_array())
+            f2r.append(fidx)
+        labels = np.concatenate(labels) if labels else np.zeros((0,), dtype=BBOX_DTYPE)
+        return labels, np.array(f2l, dtype=np.int64), np.array(f2r, dtype=np.int64)
+
+    def save(self, save_dir: str, dst_name: str, num_frames: int) -> str:
+        """Write labels_v2/labels.npz + objframe_idx_2_repr_idx.npy; refuses to overwrite (reference :366-367)."""
+        self._aggregate_results(num_frames)
+        labels, f2l, f2r = self._summarize()
+        seq_dir = osp.join(save_dir, osp.basename(osp.normpath(self.path)))
+        os.makedirs(osp.join(seq_dir, 'labels_v2'), exist_ok=False)
+        np.savez(osp.join(seq_dir, 'labels_v2', 'labels.npz'), labels=labels, objframe_idx_2_label_idx=f2l)
+        np.save(osp.join(seq_dir, 'objframe_idx_2_repr_idx.npy'), f2r)
+        return seq_dir
+
+
+class PseudoLabeler(Module):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.mode_2_seq_lens = SeqLens()
+        self.ev_path_2_ev_data: Dict[str, EventSeqData] = {}
+        self.ev_cnt = 0
+        self.dst_name = self.dst_config.name
+        self.ds_by2 = self.dst_config.downsample_by_factor_2
+        assert self.dst_name in ('gen1', 'gen4')
+        self.save_dir = self.full_config.get('save_dir', '')
+        if self.save_dir:
+            assert self.dst_name in self.save_dir and 'train' in self.save_dir
+            assert not osp.exists(self.save_dir), f'{self.save_dir} already exists'
+        self.use_gt = self.full_config.get('use_gt', True)
+        self.tta_cfg = self.full_config.tta
+        self.filter_bbox_fn = lambda b: filter_pred_boxes(b, dataset_name=self.dst_name, downsampled_by_2=self.ds_by2)
+
+    def get_data_from_batch(self, batch: Any):
+        """hflip TTA: the flipped copy is concatenated on the batch dim (B -> 2B) and labels are flipped; padding is
+        applied by the stem kernel afterwards, i.e. to the right/bottom of the FLIPPED tensor as in the reference
+        (pseudo_labeler.py:469-470,493)."""
+        data = batch[DATA_KEY]
+        assert DataType.AUGM_STATE not in data
+        ev = th.stack(data[DataType.EV_REPR])
+        B = ev.shape[1]
+        data['is_hflip'] = np.array([False] * B, dtype=bool)
+        if self.tta_cfg.enable and self.tta_cfg.hflip:
+            ev = th.cat([ev, th.flip(ev, dims=[-1])], dim=1)
+            new = {}
+            for k in (DataType.IS_FIRST_SAMPLE, DataType.IS_LAST_SAMPLE, DataType.IS_REVERSED):
+                new[k] = th.cat([data[k]] * 2, dim=-1)
+            for k in (DataType.EV_IDX, DataType.IS_PADDED_MASK):
+                new[k] = [th.cat([d] * 2, dim=-1) for d in data[k]]
+            new[DataType.PATH] = data[DataType.PATH] * 2
+            for k in (DataType.OBJLABELS_SEQ, DataType.SKIPPED_OBJLABELS_SEQ):
+                labels, flipped = data[k], copy.deepcopy(data[k])
+                for i, (l, lf) in enumerate(zip(labels, flipped)):
+                    lf.flip_lr_()
+                    labels[i] = l + lf
+                new[k] = labels
+            new['is_hflip'] = np.array([False] * B + [True] * B, dtype=bool)
+            data = new
+        data[DataType.EV_REPR] = list(ev.unbind(0))
+        return data
+
+    def _get_pred_mask(self, worker_id: int, data: Dict):
+        obj_labels, skipped = data[DataType.OBJLABELS_SEQ], data[DataType.SKIPPED_OBJLABELS_SEQ]
+        L, B = len(obj_labels), len(obj_labels[0])
+        skip = np.zeros((L, B), dtype=bool)
+        gt_mask = np.zeros((L, B), dtype=bool)
+        skipped_gt = np.zeros((L, B), dtype=bool)
+        skip_len = max(self.mdl_config.pseudo_label.skip_first_t, 1)
+        prev_lens = self.mode_2_seq_lens.get_lens(worker_id=worker_id)
+        for b in range(B):
+            if prev_lens[b] < skip_len:
+                skip[:skip_len - int(prev_lens[b]), b] = True
+        for t in range(L):
+            for b in range(B):
+                has_gt = (obj_labels[t][b] is not None) and self.use_gt
+                has_sk = skipped[t][b] is not None
+                assert not (has_gt and has_sk)
+                gt_mask[t, b] = has_gt
+                skip[t, b] = has_gt
+                skipped_gt[t, b] = has_sk
+        skip[th.stack(data[DataType.IS_PADDED_MASK]).cpu().numpy()] = True
+        return ~skip, gt_mask, skipped_gt
+
+    @torch.inference_mode()
+    def _predict_step_impl(self, batch: Any, mode: Mode = Mode.TEST):
+        data = self.get_data_from_batch(batch)
+        worker_id = self.get_worker_id_from_batch(batch)
+        ev_seq = data[DataType.EV_REPR]
+        obj_labels, skipped = data[DataType.OBJLABELS_SEQ], data[DataType.SKIPPED_OBJLABELS_SEQ]
+        is_first = data[DataType.IS_FIRST_SAMPLE]
+        L, B = len(obj_labels), len(obj_labels[0])
+        rnn = self.mode_2_rnn_states[mode]
+        rnn.reset(worker_id=worker_id, indices_or_bool_tensor=is_first)
+        prev = rnn.get_states(worker_id=worker_id)
+        self.mode_2_seq_lens.reset(worker_id=worker_id, indices_or_bool_tensor=is_first)
+        pse_mask, gt_mask, _ = self._get_pred_mask(worker_id, data)
+        selector = BackboneFeatureSelector()
+        gt_labels: List[ObjectLabels] = []
+        for t in range(L):
+            feats, prev = self.mdl.forward_backbone(x=ev_seq[t], previous_states=prev)
+            if self.use_gt:
+                cur, _ = obj_labels[t].get_valid_labels_and_batch_indices()
+                gt_labels.extend(cur)
+            idx = np.where(pse_mask[t])[0].tolist()
+            if idx:
+                selector.add_backbone_features(feats, idx)
+        rnn.save_states_and_detach(worker_id=worker_id, states=prev)
+        self.mode_2_seq_lens.update_lens(worker_id=worker_id, lens=torch.ones(B).long() * L)
+        feats = selector.get_batched_backbone_features()
+        pse_labels: List[ObjectLabels] = []
+        if feats is not None:
+            preds, _ = self.mdl.forward_detect(backbone_features=feats)
+            dets = postprocess(prediction=preds, num_classes=self.num_classes,
+                               conf_thre=self.mdl_config.postprocess.confidence_threshold,
+                               nms_thre=self.mdl_config.postprocess.nms_threshold,
+                               pad=th.zeros((0, 7), device=preds.device))
+            pse_labels = pred2label(dets, obj_thresh=self.mdl_config.pseudo_label.obj_thresh,
+                                    cls_thresh=self.mdl_config.pseudo_label.cls_thresh, filter_bbox_fn=self.filter_bbox_fn,
+                                    hw=tuple(self.dst_config.ev_repr_hw), dataset_name=self.dst_name,
+                                    downsampled_by_2=self.ds_by2)
+        all_labels = [[None] * L for _ in range(B)]
+        gi = pi = 0
+        for t in range(L):
+            for b in range(B):
+                if pse_mask[t, b]:
+                    all_labels[b][t] = pse_labels[pi]
+                    pi += 1
+                elif gt_mask[t, b]:
+                    all_labels[b][t] = gt_labels[gi]
+                    gi += 1
+        assert pi == int(pse_mask.sum()) and gi == int(gt_mask.sum())
+        ev_idx = th.stack(data[DataType.EV_IDX]).transpose(1, 0).cpu().numpy().tolist()
+        padding = th.stack(data[DataType.IS_PADDED_MASK]).transpose(1, 0).cpu().numpy().tolist()
+        return (all_labels, data[DataType.PATH], ev_idx, is_first.cpu().numpy().tolist(),
+                data[DataType.IS_LAST_SAMPLE].cpu().numpy().tolist(), padding, data['is_hflip'],
+                data[DataType.IS_REVERSED].cpu().numpy().tolist())
+
+    def predict_step(self, batch: Any, batch_idx: int = 0) -> None:
+        out = self._predict_step_impl(batch=batch, mode=Mode.TEST)
+        for labels, path, ev_idx, is_first, is_last, padded, hflip, tflip in zip(*out):
+            if not path:
+                continue
+            if path not in self.ev_path_2_ev_data:
+                assert is_first, 'should load the first sample first'
+                self.ev_path_2_ev_data[path] = EventSeqData(path=path, scale_ratio=2. if self.ds_by2 else 1,
+                                                            filter_config=self.mdl_config.pseudo_label,
+                                                            postproc_cfg=self.mdl_config.postprocess)
+                self.ev_cnt += 1
+            self.ev_path_2_ev_data[path].update(labels=labels, ev_idx=ev_idx, is_last_sample=is_last,
+                                                is_padded_mask=padded, is_hflip=bool(hflip), is_tflip=bool(tflip),
+                                                tflip_offset=self.dst_config.data_augmentation.tflip_offset)

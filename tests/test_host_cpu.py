@@ -1,0 +1,152 @@
+"""Host-side logic of the product (no GPU): derived config values, label packing, LSTM-state bookkeeping,
+OneCycle schedule, sequence sharding and the data-parallel gradient path over gloo (world_size 2)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import postproc as op
+from oracle.synth import synth_labels
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+
+
+def test_derived_config_matches_reference_modifier():
+    from leod_amd.config import full_config, dynamically_modify_train_config
+    c = dynamically_modify_train_config(full_config('gen1', 'small'))
+    assert tuple(c.model.backbone.in_res_hw) == (256, 320)
+    assert tuple(c.model.backbone.stage.attention.partition_size) == (8, 10)
+    assert c.model.head.num_classes == 2 and c.model.backbone.embed_dim == 48 and c.model.backbone.stage.attention.dim_head == 24
+    assert tuple(c.dataset.ev_repr_hw) == (240, 304)
+    c = dynamically_modify_train_config(full_config('gen4', 'base', 'pseudo_labeler'))
+    assert tuple(c.model.backbone.in_res_hw) == (384, 640)
+    assert tuple(c.model.backbone.stage.attention.partition_size) == (6, 10)
+    assert c.model.head.num_classes == 3
+    assert list(c.model.pseudo_label.obj_thresh) == [0.3, 0.3, 0.6]       # (car, ped) -> (ped, cyc, car)
+    assert tuple(c.dataset.ev_repr_hw) == (360, 640)
+    assert c.dataset.data_augmentation.tflip_offset == -2
+
+
+def test_state_dict_manifest(manifest):
+    from leod_amd.config import full_config, dynamically_modify_train_config
+    from leod_amd.models.detection.yolox_extension.models.detector import YoloXDetector
+    for size in ('tiny', 'small', 'base'):
+        for ds in ('gen1', 'gen4'):
+            det = YoloXDetector(dynamically_modify_train_config(full_config(ds, size)).model)
+            mine = {k: list(v.shape) for k, v in det.state_dict().items()}
+            assert mine == manifest[f'{size}_{ds}']
+    # reference head bias init (yolo_head.py:184-193)
+    assert abs(float(det.yolox_head.obj_preds[0].bias[0]) + np.log(99.0)) < 1e-6
+
+
+def test_labels_match_oracle_and_golden(golden_dir):
+    from leod_amd.data.genx_utils.labels import ObjectLabels, SparselyBatchedObjectLabels, BBOX_DTYPE
+    g = np.load(os.path.join(golden_dir, 'g08_pseudo.npz'))
+    lab = torch.from_numpy(g['lab_in']).clone()
+    ol = ObjectLabels(lab.clone(), (240, 304))
+    assert np.array_equal(ol.get_labels_as_tensors('yolox').numpy(), g['lab_yolox'])
+    ol.flip_lr_()
+    assert np.array_equal(ol.object_labels.numpy(), g['lab_flip'])
+    labs = synth_labels(3, (240, 304), 2, seed=3)
+    batched = ObjectLabels.get_labels_as_batched_tensor([ObjectLabels(l, (240, 304)) for l in labs])
+    assert torch.equal(batched, op.batched_yolox_labels(labs))
+    assert BBOX_DTYPE.itemsize == 40
+    arr = ObjectLabels(labs[0], (240, 304)).to_structured_array()
+    back = ObjectLabels.from_structured_array(arr, (240, 304))
+    assert torch.allclose(back.object_labels, labs[0])
+    pseudo = labs[1].clone()
+    pseudo[:, 0] = 0
+    sb = SparselyBatchedObjectLabels([ObjectLabels(labs[0], (240, 304)), ObjectLabels(pseudo, (240, 304)), None])
+    sb.set_non_gt_labels_to_none_()
+    assert sb[0] is not None and sb[1] is None
+    assert sb.get_valid_labels_and_batch_indices()[1] == [0]
+
+
+def test_subsample_idx(golden_dir):
+    from leod_amd.modules.utils.ssod import get_subsample_label_idx
+    g = np.load(os.path.join(golden_dir, 'g08_pseudo.npz'))
+    assert list(get_subsample_label_idx(21, use_every=1)) == list(g['subsample_21_1'])
+    assert list(get_subsample_label_idx(21, use_every=5)) == list(g['subsample_21_5'])
+    assert sorted(get_subsample_label_idx(10, remove_every=3)) == list(g['subsample_10_r3'])
+
+
+def test_rnn_states_partial_reset_is_in_place():
+    from leod_amd.modules.utils.detection import RNNStates
+    rs = RNNStates()
+    h, c = torch.ones(3, 4, 2, 2), torch.ones(3, 4, 2, 2)
+    rs.save_states_and_detach(0, [(h.requires_grad_(True) * 1, c)])
+    saved = rs.get_states(0)
+    assert saved[0][0].requires_grad is False
+    rs.reset(0, torch.tensor([False, True, False]))
+    assert float(rs.get_states(0)[0][0][1].abs().sum()) == 0 and float(rs.get_states(0)[0][0][0].sum()) == 16
+    assert rs.get_states(1) is None
+
+
+def test_one_cycle_matches_reference_values(golden_dir):
+    from leod_amd.parallel import one_cycle_lr
+    want = json.load(open(os.path.join(golden_dir, 'g11_onecycle.json')))
+    for k, v in want.items():
+        assert abs(one_cycle_lr(int(k), 2e-4, 400000, 0.005, 20, 10000) - v) <= 1e-12 + 1e-9 * v
+
+
+def test_shard_sequences_partition_and_tflip_grouping():
+    from leod_amd.parallel import shard_sequences
+    rng = np.random.RandomState(0)
+    lengths = list(rng.randint(100, 5000, size=37))
+    world = 8
+    parts = [shard_sequences(lengths, world, r) for r in range(world)]
+    flat = sorted(i for p in parts for i in p)
+    assert flat == list(range(37))                                   # a partition: no overlap, nothing lost
+    loads = [sum(lengths[i] for i in p) for p in parts]
+    assert max(loads) < 1.6 * (sum(lengths) / world)
+    # a recording and its time-flipped copy share a key and must land on the same rank
+    keys = [f'rec{i // 2}' for i in range(36)]
+    parts = [shard_sequences(lengths[:36], world, r, keys) for r in range(world)]
+    for p in parts:
+        assert all((i ^ 1) in p for i in p)
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from leod_amd.parallel import init_distributed, FlatParams, DataParallel
+    from leod_amd import functions as Fn
+    init_distributed('gloo')
+    torch.manual_seed(rank)                                          # different init per rank on purpose
+    m = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    flat = FlatParams(m)
+    dp = DataParallel(flat, sync_bn=True)
+    dp.broadcast_parameters()
+    w0 = flat.data.clone()
+    for p in m.parameters():                                         # grads are views into the flat buffer
+        p.grad.fill_(float(rank + 1))
+    scale = dp.all_reduce_gradients()
+    stats = torch.tensor([1.0 + rank, 2.0], dtype=torch.float64)
+    Fn._allreduce_stats(stats)                                       # SyncBN statistic exchange
+    ok_align = all(o % 4 == 0 for o in flat.offsets)
+    q.put((rank, w0.sum().item(), float(m[0].weight.grad[0, 0]), scale, stats.tolist(), ok_align,
+           m[0].weight.data_ptr() == flat.data.data_ptr()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gloo_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert abs(res[0][1] - res[1][1]) < 1e-6                         # parameters broadcast from rank 0
+    for r in res:
+        assert r[2] == 3.0 and r[3] == 0.5                           # grads summed (1+2), averaged by the optimiser scale
+        assert r[4] == [3.0, 4.0] and r[5] and r[6]
