@@ -95,6 +95,7 @@ def main():
     ap.add_argument('--size', default='small')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='launch every kernel from Python instead of replaying one hipGraph per step')
     args = ap.parse_args()
 
     from leod_amd.parallel import init_distributed
@@ -133,27 +134,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # hipGraph replay of the whole step on a single GPU; with several ranks the step contains RCCL calls
+    # (gradient all-reduce + SyncBatchNorm statistics) and is launched eagerly unless LEOD_GRAPH=1
+    use_graph = (not args.no_graph) and (world == 1 or os.environ.get('LEOD_GRAPH') == '1')
+    if use_graph:
+        eng.step(ev, labels, label_tb, first_mask(0))                  # one eager step builds the LSTM states
+        eng.capture(ev, labels, label_tb, first_mask(1))
+        run = lambda m: eng.step_graph(None, None, m)                  # noqa: E731  (inputs already in the static buffers)
+    else:
+        run = lambda m: eng.step(ev, labels, label_tb, m)              # noqa: E731
     for s in range(args.warmup):
-        eng.step(ev, labels, label_tb, first_mask(s))
-    masks = [first_mask(args.warmup + s) for s in range(args.steps)]
-    probe = None
-    if not args.no_roofline:
-        probe = ops.KernelProbe()
+        run(first_mask(1 + s))
+    masks = [first_mask(1 + args.warmup + s) for s in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        losses = eng.step(ev, labels, label_tb, masks[s])
+        losses = run(masks[s])
     barrier()
     dt = time.perf_counter() - t0
     t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     dt = float(t_max)
-    loss_val = float(losses['loss'])
-
+    # roofline of the dominant kernel: a few extra eager steps with HIP events around each of its launches
     roofline = None
-    if probe is not None:
+    if not args.no_roofline and rank == 0:
+        probe = ops.KernelProbe()
+        for s in range(2):
+            eng.step(ev, labels, label_tb, first_mask(1))
         roofline = probe.finish(PEAK_HBM_GBS)
+    barrier()
+    loss_val = float(losses['loss'])
 
     if rank == 0:
         frames = world * B * T * args.steps
@@ -165,7 +176,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'RVT-{args.size} Gen1 240x304 (pad 256x320) T={T} bs={B}/GPU fully-supervised train step, '
                                    f'{len(label_ts)} labelled frames/sequence, random-init weights',
-                       'global_batch': world * B, 'seq_len': T, 'parallelism': f'dp{world}',
+                       'global_batch': world * B, 'seq_len': T, 'parallelism': f'dp{world}', 'launch': 'hipgraph' if use_graph else 'eager',
                        'per_gpu_event_frames_per_s': round(fps / world, 2), 'final_loss': round(loss_val, 4),
                        'whole_step_hbm_frac_of_peak': round(ALGO_MB_PER_FRAME_FP32 * 1e6 * fps / world / (PEAK_HBM_GBS * 1e9), 5)},
             'roofline': roofline,

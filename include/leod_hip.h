@@ -146,9 +146,14 @@ int leod_pseudo_filter(const float* det, const int* det_cnt, float* lab, int* la
 
 /* ---- optimiser / input ----------------------------------------------------------------------------- */
 
-/* value-clip + AdamW over flat buffers (modules/detection.py:485-518; train.py:236-237). g is scaled/clipped in place. */
+/* value-clip + AdamW over flat buffers (modules/detection.py:485-518; train.py:236-237). g is scaled/clipped in place.
+ * hp_dev (optional) = device float[4] {lr, 1-beta1^step, sqrt(1-beta2^step), grad_scale} overriding the host scalars, so a
+ * captured hipGraph can be replayed with a new learning rate every step. */
 int leod_adamw_clip_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
-                         float weight_decay, int step, float clip_value, float grad_scale, leod_stream_t stream);
+                         float weight_decay, int step, float clip_value, float grad_scale, const float* hp_dev,
+                         leod_stream_t stream);
+/* dst[0..3] = (a,b,c,d) on the device (launch-time scalars for a replayed hipGraph). */
+int leod_set_scalars4(float* dst, float a, float b, float c, float d, leod_stream_t stream);
 /* StackedHistogram.construct (data/utils/representations.py:78-123): int64 events -> uint8 [2*bins,H,W]. */
 int leod_voxelize_u8(const long* x, const long* y, const long* pol, const long* t, long n_events, int* counts_ws,
                      unsigned char* out, int bins, int H, int W, int count_cutoff, int fastmode, leod_stream_t stream);

@@ -28,6 +28,8 @@ struct ALRows {                 // plain rows, optional LayerNorm prologue, opti
     float* stats_out;                                   // optional [M,2] (mean, rstd) written by n-block 0
     int K;                                              // row length used for the LN statistics
     struct St { const float* p; float mean, rstd; bool ok; };
+    __device__ __forceinline__ int klen(const St&, int K) const { return K; }
+    __device__ __forceinline__ int aux(const St&) const { return 0; }
     __device__ __forceinline__ St init(int row, int M, int lane, bool write_stats) const {
         St s; s.ok = row < M; s.p = x + (long)(s.ok ? row : M - 1) * ld; s.mean = 0.f; s.rstd = 1.f;
         if (ln_w) {
@@ -63,6 +65,8 @@ struct ALRows {                 // plain rows, optional LayerNorm prologue, opti
 struct ALConcat2 {              // [x1 (K1 cols) | x2] along k  (ConvLSTM: cat(x, h_prev))
     const float* x1; long ld1; int K1; const float* x2; long ld2;
     struct St { const float* p1; const float* p2; bool ok; };
+    __device__ __forceinline__ int klen(const St&, int K) const { return K; }
+    __device__ __forceinline__ int aux(const St&) const { return 0; }
     __device__ __forceinline__ St init(int row, int M, int, bool) const {
         St s; s.ok = row < M; const long r = s.ok ? row : M - 1;
         s.p1 = x1 + r * ld1; s.p2 = x2 ? x2 + r * ld2 : nullptr; return s;
@@ -77,6 +81,8 @@ struct ALConcat2 {              // [x1 (K1 cols) | x2] along k  (ConvLSTM: cat(x
 struct ALConvNHWC {             // implicit-GEMM im2col over an NHWC fp32 map; k' = tap*Cin + c
     const float* x; int H, W, Cin, Ho, Wo, ks, stride, pad;
     struct St { int b, iy0, ix0; bool ok; };
+    __device__ __forceinline__ int klen(const St&, int K) const { return K; }
+    __device__ __forceinline__ int aux(const St&) const { return 0; }
     __device__ __forceinline__ St init(int row, int M, int, bool) const {
         St s; s.ok = row < M; const int r = s.ok ? row : 0;
         const int ox = r % Wo, t = r / Wo; const int oy = t % Ho; s.b = t / Ho;
@@ -97,6 +103,8 @@ struct ALStemNCHW {             // stem conv over the raw NCHW event tensor (uin
     const T* x; int Cin, H, W;  // H,W: stored (unpadded) size; anything outside reads as 0 (= bottom/right zero pad)
     int Ho, Wo, ks, stride, pad;
     struct St { const T* p; int iy0, ix0; bool ok; };
+    __device__ __forceinline__ int klen(const St&, int K) const { return K; }
+    __device__ __forceinline__ int aux(const St&) const { return 0; }
     __device__ __forceinline__ St init(int row, int M, int, bool) const {
         St s; s.ok = row < M; const int r = s.ok ? row : 0;
         const int ox = r % Wo, t = r / Wo; const int oy = t % Ho; const int b = t / Ho;
@@ -117,6 +125,8 @@ struct ALStemNCHW {             // stem conv over the raw NCHW event tensor (uin
 struct ALConvT {                // dgrad of a conv: rows = input pixels, k' = tap*N + n over dY (NHWC [B,Ho,Wo,N])
     const float* dy; int H, W, Ho, Wo, N, ks, stride, pad;
     struct St { int b, iy, ix; bool ok; };
+    __device__ __forceinline__ int klen(const St&, int K) const { return K; }
+    __device__ __forceinline__ int aux(const St&) const { return 0; }
     __device__ __forceinline__ St init(int row, int M, int, bool) const {
         St s; s.ok = row < M; const int r = s.ok ? row : 0;
         s.ix = r % W; const int t = r / W; s.iy = t % H; s.b = t / H; return s;
@@ -133,13 +143,42 @@ struct ALConvT {                // dgrad of a conv: rows = input pixels, k' = ta
     }
 };
 
+// dgrad of a 3x3 stride-2 pad-1 conv with rows grouped by input-pixel parity class (py,px): a pixel of class
+// (py,px) only receives (1+py)*(1+px) of the 9 taps, so each class contracts over just its live taps (1,2,2,4
+// instead of 9).  Row r: class = r / Q, (b, y2, x2) = unravel(r % Q), pixel = (2*y2+py, 2*x2+px); Q = B*(H/2)*(W/2)
+// must be a multiple of 16 so that a 16-row wave tile never mixes classes.  k' = t*N + n, t = live-tap index.
+struct ALConvT2 {
+    const float* dy; int H, W, Ho, Wo, N, Q;
+    struct St { int b, iy, ix, cls; bool ok; };
+    __device__ __forceinline__ St init(int row, int M, int, bool) const {
+        St s; s.ok = row < M; const int r = s.ok ? row : 0;
+        s.cls = r / Q; const int rem = r - s.cls * Q;
+        const int W2 = W >> 1, H2 = H >> 1;
+        const int x2 = rem % W2, t = rem / W2; const int y2 = t % H2; s.b = t / H2;
+        s.iy = 2 * y2 + (s.cls >> 1); s.ix = 2 * x2 + (s.cls & 1); return s;
+    }
+    __device__ __forceinline__ int klen(const St& s, int) const { return (1 + (s.cls >> 1)) * (1 + (s.cls & 1)) * N; }
+    __device__ __forceinline__ int aux(const St& s) const { return s.cls; }
+    __device__ __forceinline__ f4 load(const St& s, int k, int) const {
+        const int py = s.cls >> 1, px = s.cls & 1;
+        if (!s.ok || k >= (1 + py) * (1 + px) * N) return zero4();
+        const int t = k / N, n = k - t * N;
+        const int khi = t / (1 + px), kwi = t - khi * (1 + px);
+        // even coordinate: centre tap (k=1, o = i/2); odd: k=0 -> o=(i+1)/2, k=2 -> o=(i-1)/2
+        const int oy = py ? (khi == 0 ? (s.iy + 1) >> 1 : (s.iy - 1) >> 1) : s.iy >> 1;
+        const int ox = px ? (kwi == 0 ? (s.ix + 1) >> 1 : (s.ix - 1) >> 1) : s.ix >> 1;
+        if (oy >= Ho || ox >= Wo) return zero4();
+        return ld4(dy + (((long)s.b * Ho + oy) * Wo + ox) * N + n);
+    }
+};
+
 // =================================================================================================
 // B loaders (column operand = weights).  load(nblk, t, i, k) -> float4 B(n, k..k+3)
 // =================================================================================================
 struct BLRows {                 // W[n][k], row stride ld (torch Linear / 1x1 conv weight)
     const float* w; long ld; int N; int NT;
     __device__ __forceinline__ int col(int nblk, int t, int i) const { return (nblk * NT + t) * 16 + i; }
-    __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt) const {
+    __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt, int = 0) const {
         const int n = col(nblk, t, i);
         if (n >= N || k >= Kt) return zero4();
         return ld4(w + (long)n * ld + k);
@@ -148,7 +187,7 @@ struct BLRows {                 // W[n][k], row stride ld (torch Linear / 1x1 co
 struct BLGates {                // ConvLSTM: tile t = gate t (f,i,o,g), columns nblk*16.. of that gate; W[4C][K]
     const float* w; long ld; int C;
     __device__ __forceinline__ int col(int nblk, int t, int i) const { return t * C + nblk * 16 + i; }
-    __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt) const {
+    __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt, int = 0) const {
         if (nblk * 16 + i >= C || k >= Kt) return zero4();
         return ld4(w + (long)col(nblk, t, i) * ld + k);
     }
@@ -156,7 +195,7 @@ struct BLGates {                // ConvLSTM: tile t = gate t (f,i,o,g), columns 
 struct BLTrans {                // B(n,k) = W[k][n]  (dgrad of a Linear: W is [Kred][N])
     const float* w; long ld; int N; int NT;
     __device__ __forceinline__ int col(int nblk, int t, int i) const { return (nblk * NT + t) * 16 + i; }
-    __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt) const {
+    __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt, int = 0) const {
         const int n = col(nblk, t, i);
         if (n >= N || k >= Kt) return zero4();
         const float* p = w + (long)k * ld + n;
@@ -166,7 +205,7 @@ struct BLTrans {                // B(n,k) = W[k][n]  (dgrad of a Linear: W is [K
 struct BLConvW {                // conv weight [N][Cin][ks][ks] read as B(n, k' = tap*Cin + c)
     const float* w; int N, Cin, KK; int NT;
     __device__ __forceinline__ int col(int nblk, int t, int i) const { return (nblk * NT + t) * 16 + i; }
-    __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt) const {
+    __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt, int = 0) const {
         const int n = col(nblk, t, i);
         if (n >= N || k >= Kt) return zero4();
         const int tap = k / Cin, c = k - tap * Cin;
@@ -177,12 +216,28 @@ struct BLConvW {                // conv weight [N][Cin][ks][ks] read as B(n, k' 
 struct BLConvWT {               // dgrad: B(col = c, k' = tap*N + n) = W[n][c][tap]
     const float* w; int N, Cin, KK; int NT;
     __device__ __forceinline__ int col(int nblk, int t, int i) const { return (nblk * NT + t) * 16 + i; }
-    __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt) const {
+    __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt, int = 0) const {
         const int c = col(nblk, t, i);
         if (c >= Cin || k >= Kt) return zero4();
         const int tap = k / N, n = k - tap * N;
         const long sn = (long)Cin * KK;
         const float* p = w + ((long)n * Cin + c) * KK + tap;
+        f4 v; v.x = p[0]; v.y = p[sn]; v.z = p[2 * sn]; v.w = p[3 * sn]; return v;
+    }
+};
+
+struct BLConvWT2 {              // parity-class dgrad of a 3x3/s2 conv: B(col = c, k' = t*N + n) = W[n][c][kh][kw], (kh,kw) from (class, t)
+    const float* w; int N, Cin; int NT;
+    __device__ __forceinline__ int col(int nblk, int t, int i) const { return (nblk * NT + t) * 16 + i; }
+    __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int, int cls) const {
+        const int c = col(nblk, t, i);
+        const int py = cls >> 1, px = cls & 1;
+        if (c >= Cin || k >= (1 + py) * (1 + px) * N) return zero4();
+        const int tt = k / N, n = k - tt * N;
+        const int khi = tt / (1 + px), kwi = tt - khi * (1 + px);
+        const int kh = py ? 2 * khi : 1, kw = px ? 2 * kwi : 1;
+        const long sn = (long)Cin * 9;
+        const float* p = w + ((long)n * Cin + c) * 9 + kh * 3 + kw;
         f4 v; v.x = p[0]; v.y = p[sn]; v.z = p[2 * sn]; v.w = p[3 * sn]; return v;
     }
 };
@@ -203,6 +258,14 @@ struct EpStore {
     float* colsum;                  // optional [N]: += column sums of the stored value (bias gradient)
     int act; int accumulate;
     int N;
+    int rm_Q, rm_H, rm_W;           // rm_Q > 0: GEMM rows are parity-class ordered (ALConvT2) -> remap to pixel rows of the [B,H,W] map
+    __device__ __forceinline__ long maprow(int row) const {
+        if (rm_Q <= 0) return row;
+        const int cls = row / rm_Q, rem = row - cls * rm_Q;
+        const int W2 = rm_W >> 1, H2 = rm_H >> 1;
+        const int x2 = rem % W2, t = rem / W2; const int y2 = t % H2, b = t / H2;
+        return ((long)b * rm_H + 2 * y2 + (cls >> 1)) * rm_W + 2 * x2 + (cls & 1);
+    }
     template <int NT, class BL>
     __device__ __forceinline__ void run(f4 (&acc)[NT], const BL& bl, int row0, int nblk, int lane, int M) const {
         const int i = lane & 15, rg = lane >> 4;
@@ -218,19 +281,20 @@ struct EpStore {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = row0 + 4 * rg + r;
+                const int grow = row0 + 4 * rg + r;
                 float v = acc[t][r] + bv;
-                const bool ok = nok && row < M;
+                const bool ok = nok && grow < M;
+                const long row = maprow(grow);
                 if (act == ACT_AFFINE_SILU) v = siluf_(v * sc + sh);
-                if (act == ACT_MUL_GELU_GRAD && ok) v *= gelu_erf_grad(aux[(long)row * ldaux + n]);
+                if (act == ACT_MUL_GELU_GRAD && ok) v *= gelu_erf_grad(aux[row * ldaux + n]);
                 if (ok) {
                     if (nsplit > 0 && n >= nsplit) {
-                        float* p = out2 + (long)row * ld2 + (n - nsplit);
+                        float* p = out2 + row * ld2 + (n - nsplit);
                         *p = accumulate ? *p + v : v;
                     } else {
-                        float* p = out + (long)row * ld + n;
+                        float* p = out + row * ld + n;
                         *p = accumulate ? *p + v : v;
-                        if (act == ACT_GELU_DUAL) out2[(long)row * ld2 + n] = gelu_erf(v);
+                        if (act == ACT_GELU_DUAL) out2[row * ld2 + n] = gelu_erf(v);
                     }
                     s1 += v; s2 += v * v;
                 }
@@ -301,36 +365,90 @@ struct EpLstm {                     // NT must be 4: tiles = (f, i, o, g) of cha
 
 // =================================================================================================
 // row GEMM kernel
+//   KS == 1: the 4 waves of a workgroup own 4 consecutive 16-row tiles (64 rows) and the whole K range.
+//   KS == 4: small-M regime (RVT stages 3/4: a few hundred tokens, K up to 1536): the 4 waves share ONE 16-row
+//            tile and split the K chunks round-robin, then reduce through LDS -- 4x more wavefronts in flight
+//            and 4x shorter dependent MFMA chains, no atomics.
+// Operand loads run two chunks ahead of the MFMAs (register ring of depth 2).
 // =================================================================================================
-template <int NT, class AL, class BL, class EP>
+template <int NT, int KS, class AL, class BL, class EP>
 __global__ __launch_bounds__(256) void gemm16_kernel(AL al, BL bl, EP ep, int M, int K) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int row0 = (blockIdx.x * 4 + wave) * 16;
+    const int row0 = KS == 1 ? (blockIdx.x * 4 + wave) * 16 : blockIdx.x * 16;
     const int nblk = blockIdx.y;
-    if (row0 >= M) return;                       // wave-uniform; no block-level sync is used below
-    typename AL::St st = al.init(row0 + i, M, lane, nblk == 0);
+    if (row0 >= M) return;                       // wave-uniform (block-uniform for KS > 1)
+    typename AL::St st = al.init(row0 + i, M, lane, nblk == 0 && (KS == 1 || wave == 0));
     f4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = zero4();
+    K = al.klen(st, K);                          // wave-uniform (parity-class conv dgrad shortens K per tile)
+    const int aux = al.aux(st);
     const int KC = (K + 15) >> 4;
-    f4 a_cur = al.load(st, 4 * q, K), b_cur[NT];
+    const int kstep = KS == 1 ? 1 : KS;
+    int kc = KS == 1 ? 0 : wave;
+    f4 a0 = zero4(), a1 = zero4(), b0[NT], b1[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) b_cur[t] = bl.load(nblk, t, i, 4 * q, K);
-    for (int kc = 0; kc < KC; ++kc) {
-        f4 a_nxt = zero4(), b_nxt[NT];
-        const int kn = (kc + 1) * 16 + 4 * q;
-        const bool more = kc + 1 < KC;
-        if (more) a_nxt = al.load(st, kn, K);
+    for (int t = 0; t < NT; ++t) { b0[t] = zero4(); b1[t] = zero4(); }
+    if (kc < KC) {
+        a0 = al.load(st, kc * 16 + 4 * q, K);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) b_nxt[t] = more ? bl.load(nblk, t, i, kn, K) : zero4();
+        for (int t = 0; t < NT; ++t) b0[t] = bl.load(nblk, t, i, kc * 16 + 4 * q, K, aux);
+    }
+    if (kc + kstep < KC) {
+        a1 = al.load(st, (kc + kstep) * 16 + 4 * q, K);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int t = 0; t < NT; ++t) b1[t] = bl.load(nblk, t, i, (kc + kstep) * 16 + 4 * q, K, aux);
+    }
+    for (; kc < KC; kc += 2 * kstep) {
+        {   // chunk kc from ring slot 0, refill slot 0 with chunk kc + 2*kstep
+            const f4 ta = a0; f4 tb[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = mfma16(a_cur[j], b_cur[t][j], acc[t]);
-        a_cur = a_nxt;
+            for (int t = 0; t < NT; ++t) tb[t] = b0[t];
+            const int kn = kc + 2 * kstep;
+            if (kn < KC) {
+                a0 = al.load(st, kn * 16 + 4 * q, K);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) b_cur[t] = b_nxt[t];
+                for (int t = 0; t < NT; ++t) b0[t] = bl.load(nblk, t, i, kn * 16 + 4 * q, K, aux);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma16(ta[j], tb[t][j], acc[t]);
+        }
+        if (kc + kstep < KC) {   // chunk kc + kstep from ring slot 1
+            const f4 ta = a1; f4 tb[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) tb[t] = b1[t];
+            const int kn = kc + 3 * kstep;
+            if (kn < KC) {
+                a1 = al.load(st, kn * 16 + 4 * q, K);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) b1[t] = bl.load(nblk, t, i, kn * 16 + 4 * q, K, aux);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma16(ta[j], tb[t][j], acc[t]);
+        }
+    }
+    if (KS > 1) {
+        __shared__ float red[KS > 1 ? 3 : 1][NT * 256];
+        if (wave > 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave - 1][(t * 4 + r) * 64 + lane] = acc[t][r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = (t * 4 + r) * 64 + lane;
+                acc[t][r] += red[0][o] + red[1][o] + red[2][o];
+            }
     }
     ep.template run<NT, BL>(acc, bl, row0, nblk, lane, M);
 }
@@ -338,8 +456,15 @@ __global__ __launch_bounds__(256) void gemm16_kernel(AL al, BL bl, EP ep, int M,
 template <int NT, class AL, class BL, class EP>
 static inline int launch_gemm16(const AL& al, const BL& bl, const EP& ep, int M, int K, int nblocks_n, hipStream_t s) {
     if (M <= 0) return LEOD_OK;
-    dim3 grid(cdiv(M, 64), nblocks_n);
-    hipLaunchKernelGGL((gemm16_kernel<NT, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+    // fewer than ~2 workgroups per CU and a long K loop: split K across the 4 waves of each workgroup
+    const bool ksplit = (long)cdiv(M, 64) * nblocks_n < 512 && K >= 128;
+    if (ksplit) {
+        dim3 grid(cdiv(M, 16), nblocks_n);
+        hipLaunchKernelGGL((gemm16_kernel<NT, 4, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+    } else {
+        dim3 grid(cdiv(M, 64), nblocks_n);
+        hipLaunchKernelGGL((gemm16_kernel<NT, 1, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+    }
     return leod_launch_status();
 }
 
@@ -403,8 +528,8 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
 #pragma unroll
         for (int b = 0; b < TK; ++b) acc[a][b] = zero4(); }
     const bool do_bias = dbias != nullptr && blockIdx.z == 0;
-    for (int m0 = mbeg + wave * 16; m0 < mend; m0 += 64) {
-        float av[TN][4], bv[TK][4];
+    float av[TN][4], bv[TK][4], an[TN][4], bn[TK][4];
+    auto fetch = [&](int m0, float (&fa)[TN][4], float (&fb)[TK][4]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = m0 + 4 * q + j;
@@ -412,14 +537,20 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
 #pragma unroll
             for (int a = 0; a < TN; ++a) {
                 const int n = n0 + 16 * a + i;
-                av[a][j] = (mok && n < N) ? dy[(long)m * lddy + n] : 0.f;
+                fa[a][j] = (mok && n < N) ? dy[(long)m * lddy + n] : 0.f;
             }
 #pragma unroll
             for (int b = 0; b < TK; ++b) {
                 const int k = k0 + 16 * b + i;
-                bv[b][j] = (mok && k < K) ? xl.get(m, k) : 0.f;
+                fb[b][j] = (mok && k < K) ? xl.get(m, k) : 0.f;
             }
         }
+    };
+    int m0 = mbeg + wave * 16;
+    if (m0 < mend) fetch(m0, av, bv);
+    for (; m0 < mend; m0 += 64) {
+        const bool more = m0 + 64 < mend;
+        if (more) fetch(m0 + 64, an, bn);            // next 16-row chunk in flight under this chunk's MFMAs
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -428,6 +559,15 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
 #pragma unroll
                 for (int b = 0; b < TK; ++b) acc[a][b] = mfma16(av[a][j], bv[b][j], acc[a][b]);
             }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int a = 0; a < TN; ++a) av[a][j] = an[a][j];
+#pragma unroll
+                for (int b = 0; b < TK; ++b) bv[b][j] = bn[b][j];
+            }
+        }
     }
     // cross-wave reduction: waves 1..3 park their tiles in LDS, wave 0 adds and issues the atomics
     if (wave > 0) {
@@ -473,9 +613,10 @@ static inline int launch_wgrad16(const float* dy, long lddy, const XL& xl, float
                                  int M, int N, int K, hipStream_t s) {
     if (M <= 0) return LEOD_OK;
     const int tiles = cdiv(N, TN * 16) * cdiv(K, TK * 16);
-    // aim for ~1024 workgroups in total, at least 64 rows (one 16-row chunk per wave) each
+    // ~1024 workgroups in total, but at least 256 rows each (4 chunks per wave): every workgroup ends with one
+    // LDS reduction + one fp32 atomic per dW element, so few fat workgroups beat many thin ones
     int rpb = cdiv(M, max(1, 1024 / tiles));
-    rpb = max(64, ((rpb + 63) / 64) * 64);
+    rpb = max(256, ((rpb + 63) / 64) * 64);
     dim3 grid(cdiv(M, rpb), cdiv(N, TN * 16), cdiv(K, TK * 16));
     hipLaunchKernelGGL((wgrad16_kernel<TN, TK, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, rpb);
     return leod_launch_status();

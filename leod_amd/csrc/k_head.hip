@@ -702,7 +702,8 @@ LEOD_API int leod_simota_assign(const float* outputs, const float* labels, float
     const size_t shm = (size_t)L.A * 3 * sizeof(int);
     if (shm > 120 * 1024) return LEOD_ERR_UNSUPPORTED;
     AssignOut o{fg_mask, ignore_mask, matched_row, matched_valid_idx, pred_iou, num_fg_img, totals};
-    (void)hipFuncSetAttribute((const void*)simota_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    static int shm_set = 0;     // raise the dynamic-LDS limit once (not a stream operation; keeps graph capture clean)
+    if (shm_set < (int)shm) { (void)hipFuncSetAttribute((const void*)simota_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); shm_set = (int)shm; }
     hipLaunchKernelGGL(simota_kernel, dim3(B), dim3(256), shm, stream, outputs, labels, workspace, o, L, Nmax, nc, ignore_label);
     return leod_launch_status();
 }
@@ -733,7 +734,8 @@ LEOD_API int leod_postprocess_nms(float* pred, float* det_out, int* det_cnt, int
     int np2 = 1; while (np2 < A) np2 <<= 1;
     const size_t shm = (size_t)np2 * 8 + (size_t)A * 4 * 4 + (size_t)A + 16;
     if (shm > 156 * 1024) return LEOD_ERR_UNSUPPORTED;
-    (void)hipFuncSetAttribute((const void*)postprocess_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    static int shm_set = 0;
+    if (shm_set < (int)shm) { (void)hipFuncSetAttribute((const void*)postprocess_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); shm_set = (int)shm; }
     const int ncols = nc > 0 ? 5 + nc : 7;
     hipLaunchKernelGGL(postprocess_nms_kernel, dim3(B), dim3(1024), shm, stream, pred, det_out, det_cnt, A, nc, ncols, conf_thre,
                        nms_thre, class_agnostic, max_det, vanilla_limit, nc > 0 ? 1 : 0);

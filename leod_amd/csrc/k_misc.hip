@@ -9,7 +9,8 @@
 __global__ __launch_bounds__(256) void adamw_clip_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, long n, float lr, float beta1, float beta2,
                                                          float eps, float wd, float bc1, float bc2_sqrt, float clip,
-                                                         float grad_scale) {
+                                                         float grad_scale, const float* __restrict__ hp) {
+    if (hp) { lr = hp[0]; bc1 = hp[1]; bc2_sqrt = hp[2]; grad_scale = hp[3]; }   // per-step scalars from device memory (hipGraph replay)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float gi = g[i] * grad_scale;
         if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
@@ -25,14 +26,14 @@ __global__ __launch_bounds__(256) void adamw_clip_kernel(float* __restrict__ p, 
 
 LEOD_API int leod_adamw_clip_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                                   float eps, float weight_decay, int step, float clip_value, float grad_scale,
-                                  hipStream_t stream) {
-    if (!p || !g || !m || !v || step < 1) return LEOD_ERR_ARG;
+                                  const float* hp_dev, hipStream_t stream) {
+    if (!p || !g || !m || !v || (step < 1 && !hp_dev)) return LEOD_ERR_ARG;
     if (n == 0) return LEOD_OK;
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
     const int grid = (int)min((long)2048, (n + 255) / 256);
     hipLaunchKernelGGL(adamw_clip_kernel, dim3(grid), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
-                       bc1, sqrtf(bc2), clip_value, grad_scale);
+                       bc1, sqrtf(bc2), clip_value, grad_scale, hp_dev);
     return leod_launch_status();
 }
 
@@ -76,6 +77,14 @@ LEOD_API int leod_voxelize_u8(const long* x, const long* y, const long* pol, con
     const int cutoff = count_cutoff <= 0 ? 255 : min(count_cutoff, 255);
     hipLaunchKernelGGL(voxel_finalize_kernel, dim3((int)min((long)2048, (n + 255) / 256)), dim3(256), 0, stream, counts_ws, out, n,
                        cutoff, fastmode);
+    return leod_launch_status();
+}
+
+__global__ void set_scalars4_kernel(float* dst, float a, float b, float c, float d) { dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d; }
+// dst[0..3] = (a,b,c,d): per-step scalars handed to a replayed hipGraph without touching host memory
+LEOD_API int leod_set_scalars4(float* dst, float a, float b, float c, float d, hipStream_t stream) {
+    if (!dst) return LEOD_ERR_ARG;
+    hipLaunchKernelGGL(set_scalars4_kernel, dim3(1), dim3(1), 0, stream, dst, a, b, c, d);
     return leod_launch_status();
 }
 

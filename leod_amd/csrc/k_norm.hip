@@ -246,24 +246,31 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const float* __
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ w, const float* __restrict__ b,
                                                                  double* __restrict__ sums, long M, int N) {
-    // thread t owns 4 consecutive channels c0 = 4*(t % (N/4)) and strides over rows
+    // thread t owns 4 consecutive channels c = 4*(t % (N/4)) and strides over rows; partial sums are combined in
+    // LDS so that each workgroup issues ONE double atomic per (channel, statistic)
+    extern __shared__ float sred[];                 // [2*N]
+    for (int c = threadIdx.x; c < 2 * N; c += blockDim.x) sred[c] = 0.f;
+    __syncthreads();
     const int ncg = N / 4;
     const int cg = threadIdx.x % ncg;
     const int rlane = threadIdx.x / ncg, rstep = blockDim.x / ncg;
-    if (rlane >= rstep) return;
-    const int c = 4 * cg;
-    const f4 mu = ld4(mean + c), rs = ld4(rstd + c), ww = ld4(w + c), bb = ld4(b + c);
-    f4 s0 = zero4(), s1 = zero4();
-    for (long row = (long)blockIdx.x * rstep + rlane; row < M; row += (long)gridDim.x * rstep) {
-        const f4 xh = (ld4(z + row * N + c) - mu) * rs;
-        const f4 u = xh * ww + bb;
-        f4 du = ld4(dy + row * N + c);
+    if (rlane < rstep) {
+        const int c = 4 * cg;
+        const f4 mu = ld4(mean + c), rs = ld4(rstd + c), ww = ld4(w + c), bb = ld4(b + c);
+        f4 s0 = zero4(), s1 = zero4();
+        for (long row = (long)blockIdx.x * rstep + rlane; row < M; row += (long)gridDim.x * rstep) {
+            const f4 xh = (ld4(z + row * N + c) - mu) * rs;
+            const f4 u = xh * ww + bb;
+            f4 du = ld4(dy + row * N + c);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) du[k] *= silu_grad(u[k]);
-        s0 += du; s1 += du * xh;
+            for (int k = 0; k < 4; ++k) du[k] *= silu_grad(u[k]);
+            s0 += du; s1 += du * xh;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { atomicAdd(&sred[c + k], s0[k]); atomicAdd(&sred[N + c + k], s1[k]); }
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { atomicAdd(sums + c + k, (double)s0[k]); atomicAdd(sums + N + c + k, (double)s1[k]); }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * N; c += blockDim.x) atomicAdd(sums + c, (double)sred[c]);
 }
 
 __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z,
@@ -357,8 +364,8 @@ LEOD_API int leod_bn_silu_bwd_reduce(const float* dy, const float* z, const floa
     if (!dy || !z || !mean || !rstd || !w || !b || !sums || (N & 3) || N / 4 > 256) return LEOD_ERR_ARG;
     if (M <= 0) return LEOD_OK;
     const int rstep = 256 / (N / 4);
-    const int grid = (int)min((long)256, max((long)1, ((long)M + rstep * 8 - 1) / (rstep * 8)));
-    hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3(grid), dim3(256), 0, stream, dy, z, mean, rstd, w, b, sums, (long)M, N);
+    const int grid = (int)min((long)1024, max((long)1, ((long)M + rstep * 4 - 1) / (rstep * 4)));
+    hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3(grid), dim3(256), 2 * N * sizeof(float), stream, dy, z, mean, rstd, w, b, sums, (long)M, N);
     return leod_launch_status();
 }
 

@@ -29,21 +29,29 @@ class TrainEngine:
         self.global_step = 0
         self.states = None
         self.last_losses = None
+        self._idx_cache = {}
+        self._graph = None
 
     def current_lr(self):
         h = self.hp
         return one_cycle_lr(self.global_step, h['lr'], h['total_steps'], h['pct_start'], h['div_factor'], h['final_div_factor'])
 
+    def _reset_rows(self, states, is_first):
+        """RNNStates.reset: zero the LSTM rows of samples that start a new sequence (in place, sync-free:
+        a masked multiply instead of boolean indexing so the step can be captured in a hipGraph)."""
+        if states is None or is_first is None:
+            return
+        keep = (~is_first).to(torch.float32).view(-1, 1, 1, 1)
+        for h, c in states:
+            h.mul_(keep)
+            c.mul_(keep)
+
     def forward_loss(self, ev_seq: torch.Tensor, labels: torch.Tensor, label_tb: Sequence[Sequence[int]],
-                     is_first: Optional[torch.Tensor] = None):
+                     is_first: Optional[torch.Tensor] = None, states=None):
         """ev_seq [T,B,C,H,W] uint8/fp32 on the device; ``label_tb[t]`` = batch indices with labels at timestep t (host
         lists, static); labels [B',N,7] yolox targets in (t, b) order, already on the device."""
         T = ev_seq.shape[0]
-        if self.states is not None and is_first is not None:
-            for h, c in self.states:                    # RNNStates.reset: zero rows that start a new sequence
-                h[is_first] = 0
-                c[is_first] = 0
-        states = self.states
+        self._reset_rows(states, is_first)
         sel: Dict[int, List[torch.Tensor]] = {}
         for t in range(T):
             feats, states = self.det.forward_backbone(ev_seq[t], states)
@@ -51,22 +59,100 @@ class TrainEngine:
             if len(idx):
                 for k in self.det.fpn.in_features:
                     v = feats[k].permute(0, 2, 3, 1)    # NHWC view of the channels-last map
-                    sel.setdefault(k, []).append(v if len(idx) == v.shape[0] else v[list(idx)])
+                    sel.setdefault(k, []).append(v if len(idx) == v.shape[0] else v[self._index(idx, v.device)])
         feats = {k: torch.cat(v, 0).permute(0, 3, 1, 2) for k, v in sel.items()}
         preds, losses = self.det.forward_detect(feats, targets=labels)
-        self._new_states = [(h.detach(), c.detach()) for h, c in states]
-        return preds, losses
+        return preds, losses, [(h.detach(), c.detach()) for h, c in states]
+
+    def _index(self, idx, device):
+        key = tuple(idx)
+        if key not in self._idx_cache:
+            self._idx_cache[key] = torch.tensor(list(idx), dtype=torch.long, device=device)
+        return self._idx_cache[key]
+
+    def _step_body(self, ev_seq, labels, label_tb, is_first, states, hp_dev=None, lr=None, scale=1.0):
+        self.flat.zero_grad()
+        _, losses, new_states = self.forward_loss(ev_seq, labels, label_tb, is_first, states)
+        losses['loss'].backward()
+        if hp_dev is None:
+            scale = self.dp.all_reduce_gradients()
+            self.flat.adamw_step(lr, self.hp['weight_decay'], self.hp['clip_value'], grad_scale=scale)
+        else:
+            self.dp.all_reduce_gradients()
+            self.flat.adamw_step(0.0, self.hp['weight_decay'], self.hp['clip_value'], hp_dev=hp_dev)
+        return losses, new_states
 
     def step(self, ev_seq, labels, label_tb, is_first=None):
-        self.flat.zero_grad()
-        _, losses = self.forward_loss(ev_seq, labels, label_tb, is_first)
-        losses['loss'].backward()
-        scale = self.dp.all_reduce_gradients()
-        self.flat.adamw_step(self.current_lr(), self.hp['weight_decay'], self.hp['clip_value'], grad_scale=scale)
+        """Eager step (one launch per kernel from Python)."""
+        losses, self.states = self._step_body(ev_seq, labels, label_tb, is_first, self.states, lr=self.current_lr())
         self.global_step += 1
-        self.states = self._new_states
         self.last_losses = losses
         return losses
+
+    # ---- hipGraph replay ---------------------------------------------------------------------------------
+    def capture(self, ev_seq, labels, label_tb, is_first):
+        """Capture the WHOLE training step (zero-grad, 21 timesteps, head/loss, backward, all-reduce, AdamW, state
+        hand-over) into one hipGraph.  Shapes are static (reference asserts constant B and HxW, detection.py:176-199);
+        per-step scalars (lr, bias corrections) live in device memory.  ~4400 kernel launches per step then cost one
+        graph launch on the host."""
+        dev = ev_seq.device
+        self._g_ev, self._g_labels = ev_seq.clone(), labels.clone()
+        self._g_first = torch.ones_like(is_first)
+        self._g_label_tb = [list(x) for x in label_tb]
+        self._g_hp = torch.zeros(4, dtype=torch.float32, device=dev)
+        # static LSTM state buffers (channels-last memory, NCHW logical), produced by one eager forward
+        with torch.no_grad():
+            _, st = self.det.forward_backbone(ev_seq[0], None)
+        self._g_states = [(torch.zeros_like(h), torch.zeros_like(c)) for h, c in st]
+        if self.states is not None:
+            for (gh, gc), (h, c) in zip(self._g_states, self.states):
+                gh.copy_(h)
+                gc.copy_(c)
+        ops.set_scalars4(self._g_hp, 1e-12, 1.0, 1.0, 1.0)           # capture-time scalars (lr ~ 0: weights barely move)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        saved = (self.flat.data.clone(), self.flat.exp_avg.clone(), self.flat.exp_avg_sq.clone(),
+                 [(h.clone(), c.clone()) for h, c in self._g_states],
+                 [m.bn.running_mean.clone() for m in self.det.modules() if hasattr(m, 'bn')],
+                 [m.bn.running_var.clone() for m in self.det.modules() if hasattr(m, 'bn')])
+        with torch.cuda.stream(side):                                   # warm-up on a side stream, as torch requires
+            self._graph_body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._g_losses = self._graph_body()
+        # undo the side effects of the warm-up + capture passes (capture itself does not execute)
+        self.flat.data.copy_(saved[0]); self.flat.exp_avg.copy_(saved[1]); self.flat.exp_avg_sq.copy_(saved[2])
+        for (gh, gc), (h, c) in zip(self._g_states, saved[3]):
+            gh.copy_(h); gc.copy_(c)
+        bns = [m.bn for m in self.det.modules() if hasattr(m, 'bn')]
+        for bn, rm, rv in zip(bns, saved[4], saved[5]):
+            bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+        torch.cuda.synchronize()
+
+    def _graph_body(self):
+        losses, new_states = self._step_body(self._g_ev, self._g_labels, self._g_label_tb, self._g_first, self._g_states,
+                                             hp_dev=self._g_hp)
+        for (gh, gc), (h, c) in zip(self._g_states, new_states):        # hand the states over to the next replay
+            gh.copy_(h)
+            gc.copy_(c)
+        return torch.stack([losses[k] for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')])
+
+    def step_graph(self, ev_seq=None, labels=None, is_first=None):
+        """Replay the captured step.  New inputs (same shapes) are copied into the static buffers first."""
+        if ev_seq is not None and ev_seq.data_ptr() != self._g_ev.data_ptr():
+            self._g_ev.copy_(ev_seq, non_blocking=True)
+        if labels is not None and labels.data_ptr() != self._g_labels.data_ptr():
+            self._g_labels.copy_(labels, non_blocking=True)
+        if is_first is not None:
+            self._g_first.copy_(is_first, non_blocking=True)
+        ops.set_scalars4(self._g_hp, *self.flat.step_scalars(self.current_lr(), 1.0 / self.dp.world_size))
+        self._graph.replay()
+        self.global_step += 1
+        self.states = self._g_states
+        self.last_losses = dict(zip(('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg'), self._g_losses))
+        return self.last_losses
 
 
 class PseudoLabelEngine:

@@ -401,11 +401,17 @@ def pseudo_filter(det, cnt, obj_thr, cls_thr, filter_boxes, frame_hw):
 
 
 # ---------------------------------------------------------------------------------------------------
-def adamw_clip_step(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_value=0.0, grad_scale=1.0):
+def adamw_clip_step(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_value=0.0, grad_scale=1.0,
+                    hp_dev=None):
     for t in (p, g, m, v):
         _ck(t, name='adamw buffer')
     check(lib().leod_adamw_clip_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
-                                     int(step), float(clip_value), float(grad_scale), _stream()), 'adamw_clip_step')
+                                     int(step), float(clip_value), float(grad_scale), _p(hp_dev), _stream()), 'adamw_clip_step')
+
+
+def set_scalars4(dst, a, b, c, d):
+    _ck(dst, name='dst')
+    check(lib().leod_set_scalars4(_p(dst), float(a), float(b), float(c), float(d), _stream()), 'set_scalars4')
 
 
 def voxelize_u8(x, y, pol, t, bins, height, width, count_cutoff=None, fastmode=True):

@@ -46,11 +46,19 @@ class FlatParams:
     def zero_grad(self):
         self.grad.zero_()
 
-    def adamw_step(self, lr, weight_decay=0.0, clip_value=1.0, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8):
-        """value-clip + AdamW (reference: train.py:236-237 gradient_clip_val=1.0 by value; detection.py:485-488)."""
+    def adamw_step(self, lr, weight_decay=0.0, clip_value=1.0, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8, hp_dev=None):
+        """value-clip + AdamW (reference: train.py:236-237 gradient_clip_val=1.0 by value; detection.py:485-488).
+        With ``hp_dev`` (device float[4], see ``step_scalars``) the per-step scalars come from device memory."""
+        if hp_dev is None:
+            self.step_count += 1
+        ops.adamw_clip_step(self.data, self.grad, self.exp_avg, self.exp_avg_sq, lr, max(self.step_count, 1), betas=betas,
+                            eps=eps, weight_decay=weight_decay, clip_value=clip_value, grad_scale=grad_scale, hp_dev=hp_dev)
+
+    def step_scalars(self, lr, grad_scale=1.0, betas=(0.9, 0.999)):
+        """Advance the step counter and return [lr, 1-b1^t, sqrt(1-b2^t), grad_scale] for the graph-replayed optimiser."""
         self.step_count += 1
-        ops.adamw_clip_step(self.data, self.grad, self.exp_avg, self.exp_avg_sq, lr, self.step_count, betas=betas,
-                            eps=eps, weight_decay=weight_decay, clip_value=clip_value, grad_scale=grad_scale)
+        t = self.step_count
+        return [float(lr), 1.0 - betas[0] ** t, (1.0 - betas[1] ** t) ** 0.5, float(grad_scale)]
 
 
 def one_cycle_lr(step, max_lr, total_steps, pct_start=0.005, div_factor=20, final_div_factor=10000):

@@ -1,0 +1,128 @@
+"""Whole-step parity on the GPU: two consecutive training steps of the HIP engine (eager and hipGraph replay)
+against the golden vectors recorded from the reference's own training loop (g12) and the pseudo-label
+inference pass against the oracle.  ``pytest -m gpu``."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import postproc as op  # noqa: E402
+from oracle import train_step as ot  # noqa: E402
+from oracle.synth import synth_state_dict, synth_events, synth_labels  # noqa: E402
+
+DEV = 'cuda'
+MICRO = ot.model_cfg(embed_dim=16, dim_head=8, fpn_depth=0.33, partition_size=(2, 3), in_res_hw=(64, 96))
+KEYS = ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    return True
+
+
+def micro_detector(manifest, seed):
+    from leod_amd.config import full_config, dynamically_modify_train_config
+    from leod_amd.models.detection.yolox_extension.models.detector import YoloXDetector
+    over = dict(model=dict(backbone=dict(embed_dim=16, stage=dict(attention=dict(dim_head=8)))))
+    cfg = dynamically_modify_train_config(full_config('gen1', 'small', overrides=over))
+    cfg.model.backbone.in_res_hw = (64, 96)
+    cfg.model.backbone.stage.attention.partition_size = (2, 3)
+    det = YoloXDetector(cfg.model)
+    sd = synth_state_dict(manifest['micro'], seed)
+    det.load_state_dict(sd)
+    return det.to(DEV), sd
+
+
+def micro_labels(n_frames, seed, hw=(60, 90)):
+    labs = synth_labels(n_frames, hw, 2, seed=seed, max_boxes=4)
+    for l in labs:
+        l[:, 3] = l[:, 3].clamp(max=30)
+        l[:, 4] = l[:, 4].clamp(max=24)
+        l[:, 1] = torch.minimum(l[:, 1], hw[1] - 1 - l[:, 3])
+        l[:, 2] = torch.minimum(l[:, 2], hw[0] - 1 - l[:, 4])
+    return labs
+
+
+def g12_inputs(step, T=5, B=2):
+    ev = synth_events(T, B, 20, 60, 90, seed=20 + step, as_uint8=True)
+    lab_list = micro_labels(T * B, seed=30 + step)
+    label_tb, labs = [], []
+    for t in range(T):
+        idx = [b for b in range(B) if (t in (2, 4) or (t == 1 and b == 0))]
+        label_tb.append(idx)
+        labs += [lab_list[t * B + b] for b in idx]
+    is_first = torch.tensor([True, True]) if step == 0 else torch.tensor([False, True])
+    return ev, op.batched_yolox_labels(labs), label_tb, is_first
+
+
+def test_two_training_steps_match_reference_golden(gpu, golden_dir, manifest):
+    from leod_amd.engine import TrainEngine
+    g = np.load(os.path.join(golden_dir, 'g12_trainstep_micro.npz'))
+    det, _ = micro_detector(manifest, 9)
+    eng = TrainEngine(det, lr=2e-4, total_steps=1000, div_factor=20, final_div_factor=10000)
+    params = dict(det.named_parameters())
+    for step in range(2):
+        ev, labels, label_tb, is_first = g12_inputs(step)
+        losses = eng.step(ev.to(DEV), labels.to(DEV), label_tb, is_first.to(DEV))
+        got = np.array([float(losses[k]) for k in KEYS])
+        np.testing.assert_allclose(got, g[f's{step}_losses'], rtol=1e-4, err_msg=f'losses step {step}')
+        keys = [str(k) for k in g[f's{step}_grad_keys']]
+        # after the optimiser kernel .grad holds the value-clipped gradient, exactly what the golden run recorded
+        np.testing.assert_allclose(np.array([float(params[k].grad.norm()) for k in keys]), g[f's{step}_grad_norms'],
+                                   rtol=3e-3, atol=1e-6, err_msg=f'grad norms step {step}')
+        np.testing.assert_allclose(np.array([float(params[k].detach().norm()) for k in keys]), g[f's{step}_param_norms'],
+                                   rtol=2e-4, err_msg=f'param norms step {step}')
+        assert abs(eng.current_lr() - float(g[f's{step}_lr_next'])) < 1e-12
+        np.testing.assert_allclose(eng.states[3][1].cpu().numpy(), g[f's{step}_state_c4'], rtol=2e-4, atol=2e-5)
+
+
+def test_graph_replay_equals_eager(gpu, manifest):
+    from leod_amd.engine import TrainEngine
+    # same label layout on every step (a captured graph has static shapes)
+    T, B = 4, 2
+    label_tb = [[], [0], [], [0, 1]]
+    res = {}
+    for mode in ('eager', 'graph'):
+        det, _ = micro_detector(manifest, 9)
+        eng = TrainEngine(det, lr=2e-4, total_steps=1000)
+        out = []
+        for step in range(3):
+            ev = synth_events(T, B, 20, 60, 90, seed=50 + step, as_uint8=True).to(DEV)
+            labels = torch.zeros((3, 4, 7))
+            ll = op.batched_yolox_labels(micro_labels(3, seed=60 + step))
+            labels[:, :ll.shape[1]] = ll
+            labels = labels.to(DEV)
+            is_first = torch.tensor([step == 0, True], device=DEV)
+            if mode == 'graph':
+                if step == 0:
+                    eng.capture(ev, labels, label_tb, is_first)
+                losses = eng.step_graph(ev, labels, is_first)
+            else:
+                losses = eng.step(ev, labels, label_tb, is_first)
+            out.append([float(losses[k]) for k in KEYS])
+        res[mode] = (np.array(out), eng.flat.data.clone().cpu(), [c.clone().cpu() for _, c in eng.states])
+    np.testing.assert_allclose(res['graph'][0], res['eager'][0], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(res['graph'][1].numpy(), res['eager'][1].numpy(), rtol=1e-4, atol=2e-6)
+    for a, b in zip(res['graph'][2], res['eager'][2]):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_pseudo_label_inference_vs_oracle(gpu, manifest):
+    from leod_amd.engine import PseudoLabelEngine
+    det, sd = micro_detector(manifest, 5)
+    ev = synth_events(4, 2, 20, 60, 90, seed=3, as_uint8=True)
+    pl = PseudoLabelEngine(det, 2, conf_thre=0.01, obj_thresh=[0.1, 0.05], cls_thresh=[0.1, 0.05], hflip=True, max_det=126)
+    lab, lcnt, dets, cnt = pl.step(ev.to(DEV))
+    rdets, _, _ = ot.infer_sequence(sd, MICRO, ev, conf_thre=0.01, hflip=True)
+    assert [int(c) for c in cnt.cpu()] == [len(r) for r in rdets]
+    for i, r in enumerate(rdets):
+        np.testing.assert_allclose(dets[i, :len(r)].cpu().numpy(), r.numpy(), rtol=2e-4, atol=2e-4)
+    rl = op.pred2label([r.clone() for r in rdets], [0.1, 0.05], [0.1, 0.05], 'gen1', False)
+    assert [int(c) for c in lcnt.cpu()] == [len(r) for r in rl]
+    for i, r in enumerate(rl):
+        np.testing.assert_allclose(lab[i, :len(r)].cpu().numpy(), r.numpy(), rtol=2e-4, atol=2e-4)
