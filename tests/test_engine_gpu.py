@@ -107,7 +107,12 @@ def test_graph_replay_equals_eager(gpu, manifest):
             out.append([float(losses[k]) for k in KEYS])
         res[mode] = (np.array(out), eng.flat.data.clone().cpu(), [c.clone().cpu() for _, c in eng.states])
     np.testing.assert_allclose(res['graph'][0], res['eager'][0], rtol=2e-5, atol=1e-6)
-    np.testing.assert_allclose(res['graph'][1].numpy(), res['eager'][1].numpy(), rtol=1e-4, atol=2e-6)
+    # parameters: Adam turns noise-level gradients (fp32 atomics accumulate in a different order on every run) into
+    # +-lr steps, so a handful of elements may differ by up to 2*sum(lr) = 3.4e-4; everything else must agree tightly
+    pg, pe = res['graph'][1].numpy(), res['eager'][1].numpy()
+    diff = np.abs(pg - pe)
+    assert diff.max() < 3.5e-4
+    assert (diff > 2e-6 + 1e-4 * np.abs(pe)).mean() < 2e-3
     for a, b in zip(res['graph'][2], res['eager'][2]):
         np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-4, atol=1e-5)
 
