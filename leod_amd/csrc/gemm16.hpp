@@ -482,6 +482,12 @@ struct XRows {                      // X(m,k) = x[m][k], optional LayerNorm with
         if (stats) v = (v - stats[2 * (long)m]) * stats[2 * (long)m + 1] * ln_w[k] + ln_b[k];
         return v;
     }
+    __device__ __forceinline__ f4 get4(int m, int k) const {      // k % 4 == 0; K1 % 4 == 0
+        if (x2 && k >= K1) return ld4(x2 + (long)m * ld2 + (k - K1));
+        f4 v = ld4(x + (long)m * ld + k);
+        if (stats) v = (v - stats[2 * (long)m]) * stats[2 * (long)m + 1] * ld4(ln_w + k) + ld4(ln_b + k);
+        return v;
+    }
     __device__ __forceinline__ long waddr(int n, int k, long ldw) const { return (long)n * ldw + k; }
 };
 struct XConvNHWC {                  // im2col of an NHWC map; k' = tap*Cin + c ; dW laid out [N][Cin][ks][ks]
@@ -492,6 +498,13 @@ struct XConvNHWC {                  // im2col of an NHWC map; k' = tap*Cin + c ;
         const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
         if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) return 0.f;
         return x[(((long)b * H + iy) * W + ix) * Cin + c];
+    }
+    __device__ __forceinline__ f4 get4(int m, int k) const {      // 4 consecutive channels of one tap (Cin % 4 == 0)
+        const int ox = m % Wo, t = m / Wo; const int oy = t % Ho, b = t / Ho;
+        const int tap = k / Cin, c = k - tap * Cin; const int kh = tap / ks, kw = tap - kh * ks;
+        const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
+        if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) return zero4();
+        return ld4(x + (((long)b * H + iy) * W + ix) * Cin + c);
     }
     __device__ __forceinline__ long waddr(int n, int k, long) const {
         const int tap = k / Cin, c = k - tap * Cin;
@@ -508,115 +521,125 @@ struct XStemNCHW {
         if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) return 0.f;
         return (float)x[(((long)b * Cin + c) * H + iy) * W + ix];
     }
+    __device__ __forceinline__ f4 get4(int m, int k) const { f4 v; v.x = get(m, k); v.y = get(m, k + 1); v.z = get(m, k + 2); v.w = get(m, k + 3); return v; }
     __device__ __forceinline__ long waddr(int n, int k, long ldw) const { return (long)n * ldw + k; }
 };
+
+// LDS-transposing wgrad: dY and X row chunks are fetched with coalesced 16-byte loads (each element once per
+// workgroup), staged in LDS and read back column-wise as MFMA operands (the contraction runs over ROWS, which are
+// strided in memory).  The 4 waves split the TN*TK output tiles, keep them in registers over the workgroup's whole
+// row range and finish with one fp32 atomic per dW element (dW accumulates over timesteps and row splits).
+template <int T> struct LdsLd { static constexpr int value = 16 * T + ((16 * T) % 32 == 16 ? 0 : 16); };  // == 16 mod 32: conflict-free ds_read_b32
 
 template <int TN, int TK, class XL>
 __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ dy, long lddy, XL xl, float* dW, long ldw,
                                                       float* dbias, int M, int N, int K, int rows_per_block) {
-    __shared__ float red[3][TN * TK * 256];
-    __shared__ float redb[3][TN * 16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RC = 32;                                  // rows per staged chunk
+    constexpr int LDN = LdsLd<TN>::value, LDK = LdsLd<TK>::value;
+    constexpr int NV = TN * 4 * RC, KV = TK * 4 * RC;       // float4 slots per chunk
+    constexpr int RN = (NV + 255) / 256, RK = (KV + 255) / 256;
+    constexpr int NTILE = TN * TK, TPW = (NTILE + 3) / 4;   // tiles per wave
+    __shared__ __attribute__((aligned(16))) float sdy[2][RC * LDN];
+    __shared__ __attribute__((aligned(16))) float sx[2][RC * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int n0 = blockIdx.y * TN * 16, k0 = blockIdx.z * TK * 16;
     const int mbeg = blockIdx.x * rows_per_block;
     const int mend = min(M, mbeg + rows_per_block);
-    f4 acc[TN][TK];
-    float bsum[TN];
+    f4 acc[TPW];
 #pragma unroll
-    for (int a = 0; a < TN; ++a) { bsum[a] = 0.f;
-#pragma unroll
-        for (int b = 0; b < TK; ++b) acc[a][b] = zero4(); }
+    for (int t = 0; t < TPW; ++t) acc[t] = zero4();
     const bool do_bias = dbias != nullptr && blockIdx.z == 0;
-    float av[TN][4], bv[TK][4], an[TN][4], bn[TK][4];
-    auto fetch = [&](int m0, float (&fa)[TN][4], float (&fb)[TK][4]) {
+    float bsum = 0.f;                                        // wave 0, lane c < 16*TN: column sum of dY
+    f4 rn[RN], rk[RK];
+    auto fetch = [&](int m0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + 4 * q + j;
-            const bool mok = m < mend;
-#pragma unroll
-            for (int a = 0; a < TN; ++a) {
-                const int n = n0 + 16 * a + i;
-                fa[a][j] = (mok && n < N) ? dy[(long)m * lddy + n] : 0.f;
+        for (int e = 0; e < RN; ++e) {
+            const int s = tid + 256 * e;
+            rn[e] = zero4();
+            if (s < NV) {
+                const int r = s / (TN * 4), c = (s - r * (TN * 4)) * 4;
+                const int m = m0 + r, n = n0 + c;
+                if (m < mend && n < N) rn[e] = ld4(dy + (long)m * lddy + n);     // N % 4 == 0
             }
+        }
 #pragma unroll
-            for (int b = 0; b < TK; ++b) {
-                const int k = k0 + 16 * b + i;
-                fb[b][j] = (mok && k < K) ? xl.get(m, k) : 0.f;
+        for (int e = 0; e < RK; ++e) {
+            const int s = tid + 256 * e;
+            rk[e] = zero4();
+            if (s < KV) {
+                const int r = s / (TK * 4), c = (s - r * (TK * 4)) * 4;
+                const int m = m0 + r, k = k0 + c;
+                if (m < mend && k < K) rk[e] = xl.get4(m, k);
             }
         }
     };
-    int m0 = mbeg + wave * 16;
-    if (m0 < mend) fetch(m0, av, bv);
-    for (; m0 < mend; m0 += 64) {
-        const bool more = m0 + 64 < mend;
-        if (more) fetch(m0 + 64, an, bn);            // next 16-row chunk in flight under this chunk's MFMAs
+    auto stash = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int a = 0; a < TN; ++a) {
-                bsum[a] += av[a][j];
-#pragma unroll
-                for (int b = 0; b < TK; ++b) acc[a][b] = mfma16(av[a][j], bv[b][j], acc[a][b]);
-            }
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int a = 0; a < TN; ++a) av[a][j] = an[a][j];
-#pragma unroll
-                for (int b = 0; b < TK; ++b) bv[b][j] = bn[b][j];
-            }
+        for (int e = 0; e < RN; ++e) {
+            const int s = tid + 256 * e;
+            if (s < NV) { const int r = s / (TN * 4), c = (s - r * (TN * 4)) * 4; *reinterpret_cast<f4*>(&sdy[buf][r * LDN + c]) = rn[e]; }
         }
-    }
-    // cross-wave reduction: waves 1..3 park their tiles in LDS, wave 0 adds and issues the atomics
-    if (wave > 0) {
 #pragma unroll
-        for (int a = 0; a < TN; ++a)
-#pragma unroll
-            for (int b = 0; b < TK; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) red[wave - 1][((a * TK + b) * 4 + r) * 64 + lane] = acc[a][b][r];
-        if (do_bias) {
-#pragma unroll
-            for (int a = 0; a < TN; ++a) { const float s = quad16_sum(bsum[a]); if (q == 0) redb[wave - 1][a * 16 + i] = s; }
+        for (int e = 0; e < RK; ++e) {
+            const int s = tid + 256 * e;
+            if (s < KV) { const int r = s / (TK * 4), c = (s - r * (TK * 4)) * 4; *reinterpret_cast<f4*>(&sx[buf][r * LDK + c]) = rk[e]; }
         }
-    }
+    };
+    int buf = 0;
+    if (mbeg < mend) { fetch(mbeg); stash(0); }
     __syncthreads();
-    if (wave == 0) {
+    for (int m0 = mbeg; m0 < mend; m0 += RC) {
+        const bool more = m0 + RC < mend;
+        if (more) fetch(m0 + RC);                           // next chunk's global loads fly under this chunk's MFMAs
+        const float* __restrict__ pdy = sdy[buf];
+        const float* __restrict__ px = sx[buf];
 #pragma unroll
-        for (int a = 0; a < TN; ++a)
+        for (int st = 0; st < RC / 4; ++st) {
+            const int r = 4 * st + q;
 #pragma unroll
-            for (int b = 0; b < TK; ++b) {
-                const int k = k0 + 16 * b + i;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = n0 + 16 * a + 4 * q + r;
-                    const int o = ((a * TK + b) * 4 + r) * 64 + lane;
-                    const float v = acc[a][b][r] + red[0][o] + red[1][o] + red[2][o];
-                    if (n < N && k < K) atomicAdd(dW + xl.waddr(n, k, ldw), v);
+            for (int t = 0; t < TPW; ++t) {
+                const int tile = wave + 4 * t;
+                if (tile < NTILE) {
+                    const int a = tile / TK, b = tile - a * TK;
+                    acc[t] = mfma16(pdy[r * LDN + 16 * a + i], px[r * LDK + 16 * b + i], acc[t]);
                 }
             }
-        if (do_bias) {
+        }
+        if (do_bias && wave == 0 && lane < 16 * TN) {
+#pragma unroll 8
+            for (int r = 0; r < RC; ++r) bsum += pdy[r * LDN + lane];
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
 #pragma unroll
-            for (int a = 0; a < TN; ++a) {
-                float s = quad16_sum(bsum[a]);
-                const int n = n0 + 16 * a + i;
-                if (q == 0 && n < N) atomicAdd(dbias + n, s + redb[0][a * 16 + i] + redb[1][a * 16 + i] + redb[2][a * 16 + i]);
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = wave + 4 * t;
+        if (tile < NTILE) {
+            const int a = tile / TK, b = tile - a * TK;
+            const int k = k0 + 16 * b + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 16 * a + 4 * q + r;
+                if (n < N && k < K) atomicAdd(dW + xl.waddr(n, k, ldw), acc[t][r]);
             }
         }
     }
+    if (do_bias && wave == 0 && lane < 16 * TN && n0 + lane < N) atomicAdd(dbias + n0 + lane, bsum);
 }
 
 template <int TN, int TK, class XL>
 static inline int launch_wgrad16(const float* dy, long lddy, const XL& xl, float* dW, long ldw, float* dbias,
                                  int M, int N, int K, hipStream_t s) {
     if (M <= 0) return LEOD_OK;
+    if ((N & 3) || (K & 3) || (lddy & 3)) return LEOD_ERR_ARG;      // 16-byte row loads
     const int tiles = cdiv(N, TN * 16) * cdiv(K, TK * 16);
-    // ~1024 workgroups in total, but at least 256 rows each (4 chunks per wave): every workgroup ends with one
-    // LDS reduction + one fp32 atomic per dW element, so few fat workgroups beat many thin ones
-    int rpb = cdiv(M, max(1, 1024 / tiles));
-    rpb = max(256, ((rpb + 63) / 64) * 64);
+    // ~768 workgroups in total, at least 4 staged chunks (128 rows) each: every workgroup ends with one fp32 atomic
+    // per dW element, so a few fat workgroups beat many thin ones
+    int rpb = cdiv(M, max(1, 768 / tiles));
+    rpb = max(128, ((rpb + 31) / 32) * 32);
     dim3 grid(cdiv(M, rpb), cdiv(N, TN * 16), cdiv(K, TK * 16));
     hipLaunchKernelGGL((wgrad16_kernel<TN, TK, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, rpb);
     return leod_launch_status();
