@@ -15,6 +15,7 @@
 // component j of both, i.e. k index (q) of that MFMA stands for k0+4q+j.  Summed over j this covers
 // each k of the chunk exactly once, and both operands are plain 16-byte row-contiguous loads.
 #pragma once
+#include <stdlib.h>
 #include "common.hpp"
 
 // =================================================================================================
@@ -111,7 +112,8 @@ struct ALStemNCHW {             // stem conv over the raw NCHW event tensor (uin
         s.p = x + (long)b * Cin * H * W; s.iy0 = oy * stride - pad; s.ix0 = ox * stride - pad; return s;
     }
     __device__ __forceinline__ float one(const St& s, int k) const {
-        const int kk = ks * ks; const int c = k / kk; const int r = k - c * kk; const int kh = r / ks, kw = r - kh * ks;
+        // the RVT stem is always 7x7 (patch 4 -> kernel 2*4-1): constant divisors compile to multiply-shift
+        const int c = k / 49; const int r = k - c * 49; const int kh = r / 7, kw = r - kh * 7;
         const int iy = s.iy0 + kh, ix = s.ix0 + kw;
         if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) return 0.f;
         return (float)s.p[((long)c * H + iy) * W + ix];
@@ -516,7 +518,7 @@ struct XStemNCHW {
     const T* x; int Cin, H, W, Ho, Wo, ks, stride, pad;
     __device__ __forceinline__ float get(int m, int k) const {
         const int ox = m % Wo, t = m / Wo; const int oy = t % Ho, b = t / Ho;
-        const int kk = ks * ks; const int c = k / kk; const int r = k - c * kk; const int kh = r / ks, kw = r - kh * ks;
+        const int c = k / 49; const int r = k - c * 49; const int kh = r / 7, kw = r - kh * 7;     // 7x7 stem only
         const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
         if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) return 0.f;
         return (float)x[(((long)b * Cin + c) * H + iy) * W + ix];
@@ -638,8 +640,10 @@ static inline int launch_wgrad16(const float* dy, long lddy, const XL& xl, float
     const int tiles = cdiv(N, TN * 16) * cdiv(K, TK * 16);
     // ~768 workgroups in total, at least 4 staged chunks (128 rows) each: every workgroup ends with one fp32 atomic
     // per dW element, so a few fat workgroups beat many thin ones
-    int rpb = cdiv(M, max(1, 768 / tiles));
-    rpb = max(128, ((rpb + 31) / 32) * 32);
+    static const int tune_blocks = getenv("LEOD_WGRAD_BLOCKS") ? atoi(getenv("LEOD_WGRAD_BLOCKS")) : 768;   // tuning knob
+    static const int tune_minrows = getenv("LEOD_WGRAD_MINROWS") ? atoi(getenv("LEOD_WGRAD_MINROWS")) : 128;
+    int rpb = cdiv(M, max(1, tune_blocks / tiles));
+    rpb = max(tune_minrows, ((rpb + 31) / 32) * 32);
     dim3 grid(cdiv(M, rpb), cdiv(N, TN * 16), cdiv(K, TK * 16));
     hipLaunchKernelGGL((wgrad16_kernel<TN, TK, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, rpb);
     return leod_launch_status();

@@ -60,6 +60,7 @@ LEOD_API int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bia
 LEOD_API int leod_stem_conv_fwd(const void* x, int x_is_u8, const float* w, float* y, int B, int Cin, int H, int W,
                                 int Hp, int Wp, int N, int ks, int stride, int pad, hipStream_t stream) {
     if (!x || !w || !y || ((Cin * ks * ks) & 3)) return LEOD_ERR_ARG;
+    if (ks != 7) return LEOD_ERR_UNSUPPORTED;       // stem loaders hard-code the 7x7 tap decode
     const int Ho = (Hp + 2 * pad - ks) / stride + 1, Wo = (Wp + 2 * pad - ks) / stride + 1;
     const int M = B * Ho * Wo, K = Cin * ks * ks;
     EpStore ep = conv_epilogue(y, N, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
@@ -127,6 +128,7 @@ LEOD_API int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, fl
 LEOD_API int leod_stem_conv_wgrad(const float* dy, const void* x, int x_is_u8, float* dw, int B, int Cin, int H, int W,
                                   int Hp, int Wp, int N, int ks, int stride, int pad, hipStream_t stream) {
     if (!dy || !x || !dw) return LEOD_ERR_ARG;
+    if (ks != 7) return LEOD_ERR_UNSUPPORTED;
     const int Ho = (Hp + 2 * pad - ks) / stride + 1, Wo = (Wp + 2 * pad - ks) / stride + 1;
     const int M = B * Ho * Wo, K = Cin * ks * ks;
     if (x_is_u8) {

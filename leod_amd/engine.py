@@ -6,6 +6,7 @@ reset LSTM rows -> T backbone timesteps -> head + SimOTA + loss on labelled fram
 kernels accumulate into the flat gradient buffer) -> RCCL all-reduce -> fused value-clip + AdamW ->
 OneCycle LR -> detach states.  No host synchronisation happens inside a step.
 """
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -31,6 +32,8 @@ class TrainEngine:
         self.last_losses = None
         self._idx_cache = {}
         self._graph = None
+        self._streams = None
+        self.n_streams = int(os.environ.get('LEOD_STREAMS', '4'))
 
     def current_lr(self):
         h = self.hp
@@ -53,8 +56,7 @@ class TrainEngine:
         T = ev_seq.shape[0]
         self._reset_rows(states, is_first)
         sel: Dict[int, List[torch.Tensor]] = {}
-        for t in range(T):
-            feats, states = self.det.forward_backbone(ev_seq[t], states)
+        for t, feats, states in self._backbone_wavefront(ev_seq, states):
             idx = label_tb[t]
             if len(idx):
                 for k in self.det.fpn.in_features:
@@ -63,6 +65,51 @@ class TrainEngine:
         feats = {k: torch.cat(v, 0).permute(0, 3, 1, 2) for k, v in sel.items()}
         preds, losses = self.det.forward_detect(feats, targets=labels)
         return preds, losses, [(h.detach(), c.detach()) for h, c in states]
+
+    def _backbone_wavefront(self, ev_seq, states):
+        """Run the T x 4 recurrence as a wavefront over HIP streams: stage s of timestep t only depends on stage s-1
+        of t and on its own state from t-1, so each stage gets its own stream (event-chained to the stage below) and up
+        to four stage evaluations are in flight at once.  The per-stage kernels are small and latency-bound (a
+        640-token stage-4 map cannot fill 256 CUs), so overlapping them is what raises device utilisation; autograd
+        replays every node on the stream of its forward, which gives the mirrored wavefront in the backward pass.
+        With a single stream (``self.n_streams == 1``) this degenerates to the plain nested loop."""
+        stages = self.det.backbone.stages
+        T = ev_seq.shape[0]
+        if states is None:
+            states = [None] * len(stages)
+        padded = self.det.backbone.in_res_hw
+        if padded is not None and tuple(ev_seq.shape[-2:]) == tuple(padded):
+            padded = None
+        main = torch.cuda.current_stream()
+        multi = self.n_streams > 1
+        if multi:
+            if self._streams is None:
+                self._streams = [torch.cuda.Stream(device=ev_seq.device) for _ in stages]
+            for st in self._streams:
+                st.wait_stream(main)
+        out = []
+        states = list(states)
+        for t in range(T):
+            x = ev_seq[t]
+            feats = {}
+            prev_done = None
+            for si, stage in enumerate(stages):
+                if multi:
+                    st = self._streams[si]
+                    if prev_done is not None:
+                        st.wait_event(prev_done)
+                    with torch.cuda.stream(st):
+                        x, states[si] = stage(x, states[si], None, padded if si == 0 else None)
+                        prev_done = torch.cuda.Event()
+                        prev_done.record(st)
+                else:
+                    x, states[si] = stage(x, states[si], None, padded if si == 0 else None)
+                feats[si + 1] = x
+            out.append((t, feats, list(states)))
+        if multi:
+            for st in self._streams:
+                main.wait_stream(st)
+        return out
 
     def _index(self, idx, device):
         key = tuple(idx)
@@ -74,6 +121,12 @@ class TrainEngine:
         self.flat.zero_grad()
         _, losses, new_states = self.forward_loss(ev_seq, labels, label_tb, is_first, states)
         losses['loss'].backward()
+        if self._streams is not None:
+            # the wgrad kernels write parameter gradients directly (autograd does not see those writes), so the
+            # launch stream must explicitly wait for every stage stream before the all-reduce / optimiser
+            main = torch.cuda.current_stream()
+            for st in self._streams:
+                main.wait_stream(st)
         if hp_dev is None:
             scale = self.dp.all_reduce_gradients()
             self.flat.adamw_step(lr, self.hp['weight_decay'], self.hp['clip_value'], grad_scale=scale)
