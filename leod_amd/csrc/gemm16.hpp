@@ -528,65 +528,82 @@ struct XStemNCHW {
 };
 
 // LDS-transposing wgrad: dY and X row chunks are fetched with coalesced 16-byte loads (each element once per
-// workgroup), staged in LDS and read back column-wise as MFMA operands (the contraction runs over ROWS, which are
-// strided in memory).  The 4 waves split the TN*TK output tiles, keep them in registers over the workgroup's whole
-// row range and finish with one fp32 atomic per dW element (dW accumulates over timesteps and row splits).
-template <int T> struct LdsLd { static constexpr int value = 16 * T + ((16 * T) % 32 == 16 ? 0 : 16); };  // == 16 mod 32: conflict-free ds_read_b32
-
+// workgroup) and stored TRANSPOSED in LDS ([column][row], rows contiguous).  The contraction runs over rows, and with
+// the k-permutation "MFMA j of a 16-row step uses rows 4q+j" one ds_read_b128 per operand feeds four MFMAs.  The 4 waves
+// split the TN*TK output tiles, keep them in registers over the workgroup's whole row range and finish with one fp32
+// atomic per dW element (dW accumulates over timesteps and row splits).
 template <int TN, int TK, class XL>
 __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ dy, long lddy, XL xl, float* dW, long ldw,
-                                                      float* dbias, int M, int N, int K, int rows_per_block) {
+                                                      float* dbias, int M, int N, int K, int rows_per_block, int dbg) {
     constexpr int RC = 32;                                  // rows per staged chunk
-    constexpr int LDN = LdsLd<TN>::value, LDK = LdsLd<TK>::value;
-    constexpr int NV = TN * 4 * RC, KV = TK * 4 * RC;       // float4 slots per chunk
+    constexpr int LDR = RC + 4;                             // LDS leading dimension (rows) of a column: 144 B, odd multiple of 16 B
+    constexpr int C4N = TN * 4, C4K = TK * 4;               // float4 slots per staged row
+    constexpr int NV = C4N * RC, KV = C4K * RC;
     constexpr int RN = (NV + 255) / 256, RK = (KV + 255) / 256;
     constexpr int NTILE = TN * TK, TPW = (NTILE + 3) / 4;   // tiles per wave
-    __shared__ __attribute__((aligned(16))) float sdy[2][RC * LDN];
-    __shared__ __attribute__((aligned(16))) float sx[2][RC * LDK];
+    __shared__ __attribute__((aligned(16))) float sdy[2][16 * TN * LDR];
+    __shared__ __attribute__((aligned(16))) float sx[2][16 * TK * LDR];
+    __shared__ float sbias[16 * TN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int n0 = blockIdx.y * TN * 16, k0 = blockIdx.z * TK * 16;
     const int mbeg = blockIdx.x * rows_per_block;
     const int mend = min(M, mbeg + rows_per_block);
-    f4 acc[TPW];
+    const bool do_bias = dbias != nullptr && blockIdx.z == 0;
+    // ---- chunk-invariant slot geometry / LDS offsets (hoisted: the kernel is VALU-issue sensitive) ----------------------
+    int nr[RN], kr[RK], nl[RN], kl[RK], kc[RK];
+    const float* np[RN];
+    bool nok[RN], kok[RK];
+#pragma unroll
+    for (int e = 0; e < RN; ++e) {
+        const int s = tid + 256 * e, r = s / C4N, c = (s - r * C4N) * 4;
+        nr[e] = r; nl[e] = c * LDR + r; nok[e] = s < NV && n0 + c < N;
+        np[e] = dy + (long)(mbeg + r) * lddy + n0 + c;
+    }
+#pragma unroll
+    for (int e = 0; e < RK; ++e) {
+        const int s = tid + 256 * e, r = s / C4K, c = (s - r * C4K) * 4;
+        kr[e] = r; kl[e] = c * LDR + r; kc[e] = k0 + c; kok[e] = s < KV && k0 + c < K;
+    }
+    int offA[TPW], offB[TPW]; bool tok[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = wave + 4 * t;
+        tok[t] = tile < NTILE;
+        const int a = tok[t] ? tile / TK : 0, b = tok[t] ? tile - a * TK : 0;
+        offA[t] = (16 * a + i) * LDR + 4 * q; offB[t] = (16 * b + i) * LDR + 4 * q;
+    }
+    f4 acc[TPW], bacc[RN];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) acc[t] = zero4();
-    const bool do_bias = dbias != nullptr && blockIdx.z == 0;
-    float bsum = 0.f;                                        // wave 0, lane c < 16*TN: column sum of dY
+#pragma unroll
+    for (int e = 0; e < RN; ++e) bacc[e] = zero4();
+    if (tid < 16 * TN) sbias[tid] = 0.f;
     f4 rn[RN], rk[RK];
     auto fetch = [&](int m0) {
 #pragma unroll
         for (int e = 0; e < RN; ++e) {
-            const int s = tid + 256 * e;
-            rn[e] = zero4();
-            if (s < NV) {
-                const int r = s / (TN * 4), c = (s - r * (TN * 4)) * 4;
-                const int m = m0 + r, n = n0 + c;
-                if (m < mend && n < N) rn[e] = ld4(dy + (long)m * lddy + n);     // N % 4 == 0
-            }
+            rn[e] = (nok[e] && m0 + nr[e] < mend && !(dbg & 4)) ? ld4(np[e]) : zero4();
+            np[e] += (long)RC * lddy;
         }
 #pragma unroll
-        for (int e = 0; e < RK; ++e) {
-            const int s = tid + 256 * e;
-            rk[e] = zero4();
-            if (s < KV) {
-                const int r = s / (TK * 4), c = (s - r * (TK * 4)) * 4;
-                const int m = m0 + r, k = k0 + c;
-                if (m < mend && k < K) rk[e] = xl.get4(m, k);
-            }
-        }
+        for (int e = 0; e < RK; ++e) rk[e] = (kok[e] && m0 + kr[e] < mend && !(dbg & 4)) ? xl.get4(m0 + kr[e], kc[e]) : zero4();
     };
     auto stash = [&](int buf) {
 #pragma unroll
         for (int e = 0; e < RN; ++e) {
-            const int s = tid + 256 * e;
-            if (s < NV) { const int r = s / (TN * 4), c = (s - r * (TN * 4)) * 4; *reinterpret_cast<f4*>(&sdy[buf][r * LDN + c]) = rn[e]; }
+            if (tid + 256 * e < NV) {
+                float* d = &sdy[buf][nl[e]];
+                d[0] = rn[e].x; d[LDR] = rn[e].y; d[2 * LDR] = rn[e].z; d[3 * LDR] = rn[e].w;
+            }
+            bacc[e] += rn[e];
         }
 #pragma unroll
-        for (int e = 0; e < RK; ++e) {
-            const int s = tid + 256 * e;
-            if (s < KV) { const int r = s / (TK * 4), c = (s - r * (TK * 4)) * 4; *reinterpret_cast<f4*>(&sx[buf][r * LDK + c]) = rk[e]; }
-        }
+        for (int e = 0; e < RK; ++e)
+            if (tid + 256 * e < KV) {
+                float* d = &sx[buf][kl[e]];
+                d[0] = rk[e].x; d[LDR] = rk[e].y; d[2 * LDR] = rk[e].z; d[3 * LDR] = rk[e].w;
+            }
     };
     int buf = 0;
     if (mbeg < mend) { fetch(mbeg); stash(0); }
@@ -597,39 +614,42 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
         const float* __restrict__ pdy = sdy[buf];
         const float* __restrict__ px = sx[buf];
 #pragma unroll
-        for (int st = 0; st < RC / 4; ++st) {
-            const int r = 4 * st + q;
+        for (int st = 0; st < RC / 16; ++st)
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const int tile = wave + 4 * t;
-                if (tile < NTILE) {
-                    const int a = tile / TK, b = tile - a * TK;
-                    acc[t] = mfma16(pdy[r * LDN + 16 * a + i], px[r * LDK + 16 * b + i], acc[t]);
+            for (int t = 0; t < TPW; ++t)
+                if (tok[t] && !(dbg & 2)) {
+                    const f4 av = *reinterpret_cast<const f4*>(pdy + offA[t] + 16 * st);   // rows 16st+4q .. +3 of column (a, i)
+                    const f4 bv = *reinterpret_cast<const f4*>(px + offB[t] + 16 * st);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[t] = mfma16(av[j], bv[j], acc[t]);
                 }
-            }
-        }
-        if (do_bias && wave == 0 && lane < 16 * TN) {
-#pragma unroll 8
-            for (int r = 0; r < RC; ++r) bsum += pdy[r * LDN + lane];
-        }
         if (more) stash(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
+        if (!tok[t]) continue;
         const int tile = wave + 4 * t;
-        if (tile < NTILE) {
-            const int a = tile / TK, b = tile - a * TK;
-            const int k = k0 + 16 * b + i;
+        const int a = tile / TK, b = tile - a * TK;
+        const int k = k0 + 16 * b + i;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + 16 * a + 4 * q + r;
-                if (n < N && k < K) atomicAdd(dW + xl.waddr(n, k, ldw), acc[t][r]);
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + 16 * a + 4 * q + r;
+            if (n < N && k < K && !(dbg & 1)) atomicAdd(dW + xl.waddr(n, k, ldw), acc[t][r]);
         }
     }
-    if (do_bias && wave == 0 && lane < 16 * TN && n0 + lane < N) atomicAdd(dbias + n0 + lane, bsum);
+    if (do_bias) {                                          // column sums of dY from the values this thread staged
+#pragma unroll
+        for (int e = 0; e < RN; ++e)
+            if (tid + 256 * e < NV) {
+                const int c = (nl[e] - nr[e]) / LDR;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(&sbias[c + j], bacc[e][j]);
+            }
+        __syncthreads();
+        if (tid < 16 * TN && n0 + tid < N) atomicAdd(dbias + n0 + tid, sbias[tid]);
+    }
 }
 
 template <int TN, int TK, class XL>
@@ -645,6 +665,7 @@ static inline int launch_wgrad16(const float* dy, long lddy, const XL& xl, float
     int rpb = cdiv(M, max(1, tune_blocks / tiles));
     rpb = max(tune_minrows, ((rpb + 31) / 32) * 32);
     dim3 grid(cdiv(M, rpb), cdiv(N, TN * 16), cdiv(K, TK * 16));
-    hipLaunchKernelGGL((wgrad16_kernel<TN, TK, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, rpb);
+    static const int dbg = getenv("LEOD_WGRAD_DBG") ? atoi(getenv("LEOD_WGRAD_DBG")) : 0;   // ablation switches (profiling only)
+    hipLaunchKernelGGL((wgrad16_kernel<TN, TK, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, rpb, dbg);
     return leod_launch_status();
 }

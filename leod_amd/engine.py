@@ -33,7 +33,7 @@ class TrainEngine:
         self._idx_cache = {}
         self._graph = None
         self._streams = None
-        self.n_streams = int(os.environ.get('LEOD_STREAMS', '4'))
+        self.n_streams = int(os.environ.get('LEOD_STREAMS', '1'))   # >1: stage wavefront over streams (eager only: capturing the multi-stream backward crashes ROCm 7.2's hipStreamEndCapture)
 
     def current_lr(self):
         h = self.hp
