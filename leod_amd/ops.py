@@ -18,7 +18,27 @@ from ._lib import lib, check, LeodHipError
 F32 = torch.float32
 
 
+_LIB = None
+
+
+def _l():
+    """cached CDLL handle (attribute lookups on a CDLL are cached by ctypes after the first use)"""
+    global _LIB
+    if _LIB is None:
+        _LIB = lib()
+    return _LIB
+
+
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:                                        # pragma: no cover
+    _raw_stream = None
+
+
 def _stream():
+    """raw hipStream_t of torch's current stream (the stream every kernel of this library is enqueued on)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -27,13 +47,14 @@ def _p(t: Optional[torch.Tensor]):
 
 
 def _ck(t: Optional[torch.Tensor], dtype=F32, name='tensor'):
+    """Loud input validation: device tensor, expected dtype, contiguous.  No fallback of any kind."""
     if t is None:
         return
-    if not t.is_cuda:
-        raise LeodHipError(f'{name}: the LEOD HIP path needs device tensors (got {t.device}); there is no CPU fallback')
-    if t.dtype != dtype:
-        raise LeodHipError(f'{name}: expected {dtype}, got {t.dtype}')
-    if not t.is_contiguous():
+    if t.dtype is not dtype or not t.is_cuda or not t.is_contiguous():
+        if not t.is_cuda:
+            raise LeodHipError(f'{name}: the LEOD HIP path needs device tensors (got {t.device}); there is no CPU fallback')
+        if t.dtype != dtype:
+            raise LeodHipError(f'{name}: expected {dtype}, got {t.dtype}')
         raise LeodHipError(f'{name}: expected a contiguous tensor, got strides {t.stride()}')
 
 
@@ -54,7 +75,7 @@ def ln_linear_fwd(x, ln_w, ln_b, W, bias, want_act=False, want_stats=False, eps=
     out = _empty(x.shape[:-1] + (N,), x)
     act = _empty(out.shape, x) if want_act else None
     stats = _empty((M, 2), x) if (want_stats and ln_w is not None) else None
-    check(lib().leod_ln_linear_fwd(_p(x), K, _p(ln_w), _p(ln_b), eps, _p(W), _p(bias), _p(out), _p(act), _p(stats),
+    check(_l().leod_ln_linear_fwd(_p(x), K, _p(ln_w), _p(ln_b), eps, _p(W), _p(bias), _p(out), _p(act), _p(stats),
                                    M, N, K, _stream()), 'ln_linear_fwd')
     return out, act, stats
 
@@ -68,7 +89,7 @@ def linear_lsres_fwd(a, W, bias, gamma, res, want_t=True):
     M = a.numel() // K
     out = _empty(res.shape, a)
     tout = _empty(res.shape, a) if want_t else None
-    check(lib().leod_linear_lsres_fwd(_p(a), _p(W), _p(bias), _p(gamma), _p(res), _p(out), _p(tout), M, N, K,
+    check(_l().leod_linear_lsres_fwd(_p(a), _p(W), _p(bias), _p(gamma), _p(res), _p(out), _p(tout), M, N, K,
                                       _stream()), 'linear_lsres_fwd')
     return out, tout
 
@@ -80,7 +101,7 @@ def partition_attn_fwd(qkv, heads, part, window, want_lse=False):
     C = C3 // 3
     out = _empty((B, H, W, C), qkv)
     lse = _empty((B, H, W, heads), qkv) if want_lse else None
-    check(lib().leod_partition_attn_fwd(_p(qkv), _p(out), _p(lse), B, H, W, C, heads, part[0], part[1],
+    check(_l().leod_partition_attn_fwd(_p(qkv), _p(out), _p(lse), B, H, W, C, heads, part[0], part[1],
                                         1 if window else 0, _stream()), 'partition_attn_fwd')
     return out, lse
 
@@ -92,7 +113,7 @@ def partition_attn_bwd(qkv, dout, lse, heads, part, window):
     C = C3 // 3
     dqkv = _empty(qkv.shape, qkv)
     dsum = _empty(lse.shape, qkv)
-    check(lib().leod_partition_attn_bwd(_p(qkv), _p(dout), _p(lse), _p(dsum), _p(dqkv), B, H, W, C, heads, part[0],
+    check(_l().leod_partition_attn_bwd(_p(qkv), _p(dout), _p(lse), _p(dsum), _p(dqkv), B, H, W, C, heads, part[0],
                                         part[1], 1 if window else 0, _stream()), 'partition_attn_bwd')
     return dqkv
 
@@ -106,7 +127,7 @@ def convlstm_fwd(x, h_prev, c_prev, W, bias, want_gates=False):
     h = _empty(x.shape, x)
     c = _empty(x.shape, x)
     gates = _empty((M, 4, C), x) if want_gates else None
-    check(lib().leod_convlstm_fwd(_p(x), _p(h_prev), _p(c_prev), _p(W), _p(bias), _p(h), _p(c), _p(gates), M, C,
+    check(_l().leod_convlstm_fwd(_p(x), _p(h_prev), _p(c_prev), _p(W), _p(bias), _p(h), _p(c), _p(gates), M, C,
                                   _stream()), 'convlstm_fwd')
     return h, c, gates
 
@@ -117,7 +138,7 @@ def convlstm_gates_bwd(dh, dc_next, gates, c_prev, c_t, want_dc_prev=True):
     M, _, C = gates.shape
     dgates = _empty((M, 4 * C), gates)
     dc_prev = _empty(c_t.shape, gates) if want_dc_prev else None
-    check(lib().leod_convlstm_gates_bwd(_p(dh), _p(dc_next), _p(gates), _p(c_prev), _p(c_t), _p(dgates), _p(dc_prev),
+    check(_l().leod_convlstm_gates_bwd(_p(dh), _p(dc_next), _p(gates), _p(c_prev), _p(c_t), _p(dgates), _p(dc_prev),
                                         M, C, _stream()), 'convlstm_gates_bwd')
     return dgates, dc_prev
 
@@ -138,7 +159,7 @@ def linear_dgrad(dy, W, kscale=None, aux_u=None, colsum=None, out=None, accumula
         if out is None:
             out = _empty(dy.shape[:-1] + (K,), dy)
         ld1, ld2 = K, 0
-    check(lib().leod_linear_dgrad(_p(dy), N, _p(kscale), _p(W), _p(out), ld1, _p(out2), ld2, split, _p(aux_u),
+    check(_l().leod_linear_dgrad(_p(dy), N, _p(kscale), _p(W), _p(out), ld1, _p(out2), ld2, split, _p(aux_u),
                                   _p(colsum), 1 if accumulate else 0, M, N, K, _stream()), 'linear_dgrad')
     return (out, out2) if split else out
 
@@ -152,7 +173,7 @@ def linear_wgrad(dy, x, dW, dbias=None, stats=None, ln_w=None, ln_b=None, x2=Non
     M = dy.numel() // N
     K1 = x.shape[-1]
     ev = _probe('linear_wgrad', 4.0 * (M * N + M * K + N * K))      # reads dy, X ; read-modify-writes dW (counted once)
-    check(lib().leod_linear_wgrad(_p(dy), N, _p(x), K1, _p(stats), _p(ln_w), _p(ln_b), _p(x2),
+    check(_l().leod_linear_wgrad(_p(dy), N, _p(x), K1, _p(stats), _p(ln_w), _p(ln_b), _p(x2),
                                   (x2.shape[-1] if x2 is not None else 0), K1, _p(dW), _p(dbias), M, N, K, _stream()),
           'linear_wgrad')
     if ev is not None:
@@ -166,7 +187,7 @@ def layernorm_fwd(x, w, b, want_stats=False, eps=1e-5):
     M = x.numel() // C
     y = _empty(x.shape, x)
     stats = _empty((M, 2), x) if want_stats else None
-    check(lib().leod_layernorm_fwd(_p(x), _p(w), _p(b), _p(y), _p(stats), M, C, eps, _stream()), 'layernorm_fwd')
+    check(_l().leod_layernorm_fwd(_p(x), _p(w), _p(b), _p(y), _p(stats), M, C, eps, _stream()), 'layernorm_fwd')
     return y, stats
 
 
@@ -176,7 +197,7 @@ def layernorm_bwd(dn, x, stats, w, dres, dw, db, eps=1e-5):
     C = x.shape[-1]
     M = x.numel() // C
     dx = _empty(x.shape, x)
-    check(lib().leod_layernorm_bwd(_p(dn), _p(x), _p(stats), _p(w), _p(dres), _p(dx), _p(dw), _p(db), M, C, eps,
+    check(_l().leod_layernorm_bwd(_p(dn), _p(x), _p(stats), _p(w), _p(dres), _p(dx), _p(dw), _p(db), M, C, eps,
                                    _stream()), 'layernorm_bwd')
     return dx
 
@@ -187,7 +208,7 @@ def layerscale_bwd(dz, t, gamma, dgamma):
     C = dz.shape[-1]
     M = dz.numel() // C
     dt = _empty(dz.shape, dz)
-    check(lib().leod_layerscale_bwd(_p(dz), _p(t), _p(gamma), _p(dt), _p(dgamma), M, C, _stream()), 'layerscale_bwd')
+    check(_l().leod_layerscale_bwd(_p(dz), _p(t), _p(gamma), _p(dt), _p(dgamma), M, C, _stream()), 'layerscale_bwd')
     return dt
 
 
@@ -208,7 +229,7 @@ def stem_conv_fwd(x_nchw, w, padded_hw, stride, pad):
     N, ks = w.shape[0], w.shape[-1]
     Ho, Wo = _out_hw(padded_hw[0], padded_hw[1], ks, stride, pad)
     y = torch.empty((B, Ho, Wo, N), dtype=F32, device=x_nchw.device)
-    check(lib().leod_stem_conv_fwd(_p(x_nchw), 1 if x_nchw.dtype == torch.uint8 else 0, _p(w), _p(y), B, Cin, H, W,
+    check(_l().leod_stem_conv_fwd(_p(x_nchw), 1 if x_nchw.dtype == torch.uint8 else 0, _p(w), _p(y), B, Cin, H, W,
                                    padded_hw[0], padded_hw[1], N, ks, stride, pad, _stream()), 'stem_conv_fwd')
     return y
 
@@ -219,7 +240,7 @@ def stem_conv_wgrad(dy, x_nchw, dw, padded_hw, stride, pad):
     _ck(dw, name='dw')
     B, Cin, H, W = x_nchw.shape
     N, ks = dw.shape[0], dw.shape[-1]
-    check(lib().leod_stem_conv_wgrad(_p(dy), _p(x_nchw), 1 if x_nchw.dtype == torch.uint8 else 0, _p(dw), B, Cin, H, W,
+    check(_l().leod_stem_conv_wgrad(_p(dy), _p(x_nchw), 1 if x_nchw.dtype == torch.uint8 else 0, _p(dw), B, Cin, H, W,
                                      padded_hw[0], padded_hw[1], N, ks, stride, pad, _stream()), 'stem_conv_wgrad')
 
 
@@ -239,7 +260,7 @@ def conv_nhwc_fwd(x, w, bias=None, stride=1, colstats=None, bn=None, bn_eps=1e-5
         bw, bb, brm, brv = bn
         for t in bn:
             _ck(t, name='bn')
-    check(lib().leod_conv_nhwc_fwd(_p(x), _p(w), _p(bias), _p(y), _p(colstats), _p(bw), _p(bb), _p(brm), _p(brv), bn_eps,
+    check(_l().leod_conv_nhwc_fwd(_p(x), _p(w), _p(bias), _p(y), _p(colstats), _p(bw), _p(bb), _p(brm), _p(brv), bn_eps,
                                    B, H, W, Cin, N, ks, stride, pad, _stream()), 'conv_nhwc_fwd')
     return y
 
@@ -254,7 +275,7 @@ def conv_nhwc_dgrad(dy, w, x_shape, stride=1, out=None, accumulate=False):
         out = _empty(tuple(x_shape), dy)
         accumulate = False
     _ck(out, name='dx')
-    check(lib().leod_conv_nhwc_dgrad(_p(dy), _p(w), _p(out), 1 if accumulate else 0, B, H, W, Cin, N, ks, stride, pad,
+    check(_l().leod_conv_nhwc_dgrad(_p(dy), _p(w), _p(out), 1 if accumulate else 0, B, H, W, Cin, N, ks, stride, pad,
                                      _stream()), 'conv_nhwc_dgrad')
     return out
 
@@ -265,7 +286,7 @@ def conv_nhwc_wgrad(dy, x, dw, dbias=None, stride=1):
     B, H, W, Cin = x.shape
     N, ks = dw.shape[0], dw.shape[-1]
     pad = (ks - 1) // 2
-    check(lib().leod_conv_nhwc_wgrad(_p(dy), _p(x), _p(dw), _p(dbias), B, H, W, Cin, N, ks, stride, pad, _stream()),
+    check(_l().leod_conv_nhwc_wgrad(_p(dy), _p(x), _p(dw), _p(dbias), B, H, W, Cin, N, ks, stride, pad, _stream()),
           'conv_nhwc_wgrad')
 
 
@@ -277,7 +298,7 @@ def bn_silu_fwd(z, colstats, w, b, run_mean, run_var, count, eps=1e-5, momentum=
     y = _empty(z.shape, z)
     mean = _empty((N,), z)
     rstd = _empty((N,), z)
-    check(lib().leod_bn_silu_fwd(_p(z), _p(colstats), _p(w), _p(b), _p(y), _p(mean), _p(rstd), _p(run_mean), _p(run_var),
+    check(_l().leod_bn_silu_fwd(_p(z), _p(colstats), _p(w), _p(b), _p(y), _p(mean), _p(rstd), _p(run_mean), _p(run_var),
                                  M, N, float(count), _p(count_dev), eps, momentum, _stream()), 'bn_silu_fwd')
     return y, mean, rstd
 
@@ -287,7 +308,7 @@ def bn_silu_bwd_reduce(dy, z, mean, rstd, w, b):
     N = z.shape[-1]
     M = z.numel() // N
     sums = torch.zeros((2, N), dtype=torch.float64, device=z.device)
-    check(lib().leod_bn_silu_bwd_reduce(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(sums), M, N, _stream()),
+    check(_l().leod_bn_silu_bwd_reduce(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(sums), M, N, _stream()),
           'bn_silu_bwd_reduce')
     return sums
 
@@ -296,7 +317,7 @@ def bn_silu_bwd_apply(dy, z, mean, rstd, w, b, sums, dw, db, count, count_dev=No
     N = z.shape[-1]
     M = z.numel() // N
     dz = _empty(z.shape, z)
-    check(lib().leod_bn_silu_bwd_apply(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(sums), _p(dz), _p(dw), _p(db),
+    check(_l().leod_bn_silu_bwd_apply(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(sums), _p(dz), _p(dw), _p(db),
                                        M, N, float(count), _p(count_dev), _stream()), 'bn_silu_bwd_apply')
     return dz
 
@@ -315,7 +336,7 @@ def head_pred_fwd(cls_feat, reg_feat, cls_w, cls_b, reg_w, reg_b, obj_w, obj_b, 
     nc = cls_w.shape[0]
     ref = out_train if out_train is not None else out_infer
     A = ref.shape[1]
-    check(lib().leod_head_pred_fwd(_p(cls_feat), _p(reg_feat), _p(cls_w), _p(cls_b), _p(reg_w), _p(reg_b), _p(obj_w),
+    check(_l().leod_head_pred_fwd(_p(cls_feat), _p(reg_feat), _p(cls_w), _p(cls_b), _p(reg_w), _p(reg_b), _p(obj_w),
                                    _p(obj_b), _p(out_train), _p(out_infer), B, h, w, Hd, nc, stride, a0, A, _stream()),
           'head_pred_fwd')
 
@@ -327,7 +348,7 @@ def head_pred_bwd(d_raw, cls_feat, reg_feat, cls_w, reg_w, obj_w, d_cls_w, d_cls
     A = d_raw.shape[1]
     dcf = _empty(cls_feat.shape, cls_feat)
     drf = _empty(reg_feat.shape, reg_feat)
-    check(lib().leod_head_pred_bwd(_p(d_raw), _p(cls_feat), _p(reg_feat), _p(cls_w), _p(reg_w), _p(obj_w), _p(dcf), _p(drf),
+    check(_l().leod_head_pred_bwd(_p(d_raw), _p(cls_feat), _p(reg_feat), _p(cls_w), _p(reg_w), _p(obj_w), _p(dcf), _p(drf),
                                    _p(d_cls_w), _p(d_cls_b), _p(d_reg_w), _p(d_reg_b), _p(d_obj_w), _p(d_obj_b), _p(gscale),
                                    B, h, w, Hd, nc, a0, A, _stream()), 'head_pred_bwd')
     return dcf, drf
@@ -340,7 +361,7 @@ def simota_assign(outputs, labels, hws, strides, ignore_label=1024.0):
     B, A, nch = outputs.shape
     Nmax = labels.shape[1]
     dev = outputs.device
-    ws = torch.empty(lib().leod_simota_workspace_floats(B, Nmax, A), dtype=F32, device=dev)
+    ws = torch.empty(_l().leod_simota_workspace_floats(B, Nmax, A), dtype=F32, device=dev)
     r = dict(fg_mask=torch.empty((B, A), dtype=torch.uint8, device=dev),
              ignore_mask=torch.empty((B, A), dtype=torch.uint8, device=dev),
              matched_row=torch.empty((B, A), dtype=torch.int32, device=dev),
@@ -348,7 +369,7 @@ def simota_assign(outputs, labels, hws, strides, ignore_label=1024.0):
              pred_iou=torch.empty((B, A), dtype=F32, device=dev),
              num_fg_img=torch.empty((B,), dtype=torch.int32, device=dev),
              totals=torch.zeros((3,), dtype=torch.int32, device=dev))
-    check(lib().leod_simota_assign(_p(outputs), _p(labels), _p(ws), _p(r['fg_mask']), _p(r['ignore_mask']),
+    check(_l().leod_simota_assign(_p(outputs), _p(labels), _p(ws), _p(r['fg_mask']), _p(r['ignore_mask']),
                                    _p(r['matched_row']), _p(r['matched_valid_idx']), _p(r['pred_iou']), _p(r['num_fg_img']),
                                    _p(r['totals']), B, Nmax, nch - 5, len(hws), _iarr([h for h, _ in hws]),
                                    _iarr([w for _, w in hws]), _iarr(strides), float(ignore_label), _stream()),
@@ -363,7 +384,7 @@ def yolox_loss(outputs, labels, assign, hws, strides, want_grad=True, focal=Fals
     sums = torch.zeros((3,), dtype=torch.float64, device=dev)
     losses = torch.empty((6,), dtype=F32, device=dev)
     d_raw = torch.empty_like(outputs) if want_grad else None
-    check(lib().leod_yolox_loss(_p(outputs), _p(labels), _p(assign['fg_mask']), _p(assign['ignore_mask']),
+    check(_l().leod_yolox_loss(_p(outputs), _p(labels), _p(assign['fg_mask']), _p(assign['ignore_mask']),
                                 _p(assign['matched_row']), _p(assign['pred_iou']), _p(assign['totals']), _p(sums), _p(losses),
                                 _p(d_raw), B, labels.shape[1], nch - 5, len(hws), _iarr([h for h, _ in hws]),
                                 _iarr([w for _, w in hws]), _iarr(strides), 1 if focal else 0, reg_weight, obj_weight,
@@ -379,7 +400,7 @@ def postprocess_nms(pred, num_classes, conf_thre, nms_thre, class_agnostic=False
     max_det = A if max_det is None else max_det
     det = torch.empty((B, max_det, 7), dtype=F32, device=pred.device)
     cnt = torch.empty((B,), dtype=torch.int32, device=pred.device)
-    check(lib().leod_postprocess_nms(_p(pred), _p(det), _p(cnt), B, A, num_classes, float(conf_thre), float(nms_thre),
+    check(_l().leod_postprocess_nms(_p(pred), _p(det), _p(cnt), B, A, num_classes, float(conf_thre), float(nms_thre),
                                      1 if class_agnostic else 0, max_det, vanilla_limit, _stream()), 'postprocess_nms')
     return det, cnt
 
@@ -394,7 +415,7 @@ def pseudo_filter(det, cnt, obj_thr, cls_thr, filter_boxes, frame_hw):
         raise LeodHipError('obj_thresh and cls_thresh must both be floats or per-class lists of equal length')
     lab = torch.empty((B, max_det, 8), dtype=F32, device=det.device)
     lcnt = torch.empty((B,), dtype=torch.int32, device=det.device)
-    check(lib().leod_pseudo_filter(_p(det), _p(cnt), _p(lab), _p(lcnt), B, max_det, _p(ot), _p(ct), ot.numel(),
+    check(_l().leod_pseudo_filter(_p(det), _p(cnt), _p(lab), _p(lcnt), B, max_det, _p(ot), _p(ct), ot.numel(),
                                    1 if filter_boxes else 0, float(frame_hw[1]), float(frame_hw[0]), _stream()),
           'pseudo_filter')
     return lab, lcnt
@@ -405,13 +426,13 @@ def adamw_clip_step(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, weight_d
                     hp_dev=None):
     for t in (p, g, m, v):
         _ck(t, name='adamw buffer')
-    check(lib().leod_adamw_clip_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
+    check(_l().leod_adamw_clip_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
                                      int(step), float(clip_value), float(grad_scale), _p(hp_dev), _stream()), 'adamw_clip_step')
 
 
 def set_scalars4(dst, a, b, c, d):
     _ck(dst, name='dst')
-    check(lib().leod_set_scalars4(_p(dst), float(a), float(b), float(c), float(d), _stream()), 'set_scalars4')
+    check(_l().leod_set_scalars4(_p(dst), float(a), float(b), float(c), float(d), _stream()), 'set_scalars4')
 
 
 def voxelize_u8(x, y, pol, t, bins, height, width, count_cutoff=None, fastmode=True):
@@ -420,7 +441,7 @@ def voxelize_u8(x, y, pol, t, bins, height, width, count_cutoff=None, fastmode=T
     dev = x.device
     ws = torch.empty((2 * bins * height * width,), dtype=torch.int32, device=dev)
     out = torch.empty((2 * bins, height, width), dtype=torch.uint8, device=dev)
-    check(lib().leod_voxelize_u8(_p(x), _p(y), _p(pol), _p(t), x.numel(), _p(ws), _p(out), bins, height, width,
+    check(_l().leod_voxelize_u8(_p(x), _p(y), _p(pol), _p(t), x.numel(), _p(ws), _p(out), bins, height, width,
                                  0 if count_cutoff is None else int(count_cutoff), 1 if fastmode else 0, _stream()),
           'voxelize_u8')
     return out
