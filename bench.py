@@ -163,6 +163,11 @@ def main():
         for s in range(2):
             eng.step(ev, labels, label_tb, first_mask(1))
         roofline = probe.finish(PEAK_HBM_GBS)
+        # HBM bytes per launch of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
+        # separate rocprofv3 --pmc runs; bench.py itself cannot sample hardware counters)
+        tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
+        if roofline is not None and os.path.exists(tpath):
+            roofline['traffic'] = json.load(open(tpath)).get('hbm_bytes_per_launch')
     barrier()
     loss_val = float(losses['loss'])
 
