@@ -58,12 +58,24 @@ def make_batch(T, B, hw, num_classes, seed, device, label_ts):
     return ev.to(device), torch.from_numpy(tg).to(device), label_tb, labs
 
 
-def cpu_baseline(sample_B=2, T=21, threads=None):
+def usable_cores():
+    """Host cores this process may actually use: min(affinity mask, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(sample_B=8, T=21, threads=None):
     """The oracle (CPU restatement of the reference, torch fp32 autograd) on a bounded sample of the same workload."""
     from oracle import train_step as ot
     from oracle.synth import synth_state_dict
     import json as _json
-    threads = threads or os.cpu_count() or 1
+    threads = threads or usable_cores()
     torch.set_num_threads(threads)
     man = _json.load(open(os.path.join(ROOT, 'tests', 'golden', 'g11_manifest.json')))['small_gen1']
     tr = ot.OracleTrainer(synth_state_dict(man, 0), ot.model_cfg(48, 24, 0.33, (8, 10)))
@@ -83,6 +95,23 @@ def cpu_baseline(sample_B=2, T=21, threads=None):
     return dict(value=round(sample_B * T / dt, 3), unit='event-frames/s', cores=threads, kind='port',
                 sample=f'oracle (PyTorch-CPU fp32 restatement of the reference) RVT-S Gen1 T={T} bs={sample_B}, '
                        f'1 full training step = {sample_B * T} event-frames in {dt:.1f} s')
+
+
+def cpu_baseline_bounded(timeout_s=240):
+    """Run the CPU leg in a child process with a hard time limit so that bench.py always finishes within minutes."""
+    import subprocess
+    code = ('import json, sys; sys.path.insert(0, %r); import bench; '
+            'print("CPUBASE " + json.dumps(bench.cpu_baseline()))' % ROOT)
+    try:
+        out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=timeout_s,
+                             env=dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')).stdout
+        for line in out.splitlines():
+            if line.startswith('CPUBASE '):
+                return json.loads(line[8:])
+    except subprocess.TimeoutExpired:
+        pass
+    return dict(value=None, unit='event-frames/s', cores=usable_cores(), kind='port',
+                sample=f'CPU leg did not finish within {timeout_s} s on this host')
 
 
 def main():
@@ -187,7 +216,7 @@ def main():
             'roofline': roofline,
         }
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline_bounded()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
