@@ -124,7 +124,9 @@ def main():
     ap.add_argument('--size', default='small')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--no-graph', action='store_true', help='launch every kernel from Python instead of replaying one hipGraph per step')
+    ap.add_argument('--graph', action='store_true', help='replay one single-stream hipGraph per step instead of the default eager '
+                    'launch with the 4-stream stage wavefront (LEOD_GRAPH=1 does the same)')
+    ap.add_argument('--no-graph', action='store_true', help=argparse.SUPPRESS)        # old flag, now the default
     args = ap.parse_args()
 
     from leod_amd.parallel import init_distributed
@@ -163,9 +165,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # hipGraph replay of the whole step on a single GPU; with several ranks the step contains RCCL calls
-    # (gradient all-reduce + SyncBatchNorm statistics) and is launched eagerly unless LEOD_GRAPH=1
-    use_graph = (not args.no_graph) and (world == 1 or os.environ.get('LEOD_GRAPH') == '1')
+    # Default: eager launches with the stage wavefront over 4 HIP streams (engine.py) -- measured 2080 vs 1679
+    # event-frames/s for the single-stream hipGraph replay, because the per-stage kernels are too small to fill 256 CUs
+    # one at a time and ROCm 7.2 cannot capture the multi-stream backward.  --graph / LEOD_GRAPH=1 selects the replay.
+    use_graph = (args.graph or os.environ.get('LEOD_GRAPH') == '1') and not args.no_graph
     if use_graph:
         eng.step(ev, labels, label_tb, first_mask(0))                  # one eager step builds the LSTM states
         eng.capture(ev, labels, label_tb, first_mask(1))
@@ -189,8 +192,10 @@ def main():
     roofline = None
     if not args.no_roofline and rank == 0:
         probe = ops.KernelProbe()
+        n_streams, eng.n_streams = eng.n_streams, 1      # isolated launches: no co-running kernels inside the event bracket
         for s in range(2):
             eng.step(ev, labels, label_tb, first_mask(1))
+        eng.n_streams = n_streams
         roofline = probe.finish(PEAK_HBM_GBS)
         # HBM bytes per launch of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
         # separate rocprofv3 --pmc runs; bench.py itself cannot sample hardware counters)
@@ -210,7 +215,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'RVT-{args.size} Gen1 240x304 (pad 256x320) T={T} bs={B}/GPU fully-supervised train step, '
                                    f'{len(label_ts)} labelled frames/sequence, random-init weights',
-                       'global_batch': world * B, 'seq_len': T, 'parallelism': f'dp{world}', 'launch': 'hipgraph' if use_graph else 'eager',
+                       'global_batch': world * B, 'seq_len': T, 'parallelism': f'dp{world}', 'launch': 'hipgraph' if use_graph else f'eager, {eng.n_streams}-stream stage wavefront',
                        'per_gpu_event_frames_per_s': round(fps / world, 2), 'final_loss': round(loss_val, 4),
                        'whole_step_hbm_frac_of_peak': round(ALGO_MB_PER_FRAME_FP32 * 1e6 * fps / world / (PEAK_HBM_GBS * 1e9), 5)},
             'roofline': roofline,

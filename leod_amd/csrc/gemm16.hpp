@@ -28,12 +28,14 @@ struct ALRows {                 // plain rows, optional LayerNorm prologue, opti
     const float* kscale;                                // optional per-k multiplier (LayerScale bwd)
     float* stats_out;                                   // optional [M,2] (mean, rstd) written by n-block 0
     int K;                                              // row length used for the LN statistics
+    const float* stats_in;                              // optional precomputed [M,2] (mean, rstd): skips the statistics passes
     struct St { const float* p; float mean, rstd; bool ok; };
     __device__ __forceinline__ int klen(const St&, int K) const { return K; }
     __device__ __forceinline__ int aux(const St&) const { return 0; }
     __device__ __forceinline__ St init(int row, int M, int lane, bool write_stats) const {
         St s; s.ok = row < M; s.p = x + (long)(s.ok ? row : M - 1) * ld; s.mean = 0.f; s.rstd = 1.f;
-        if (ln_w) {
+        if (ln_w && stats_in) { s.mean = stats_in[2 * (long)(s.ok ? row : M - 1)]; s.rstd = stats_in[2 * (long)(s.ok ? row : M - 1) + 1]; }
+        else if (ln_w) {
             const int q = lane >> 4;
             float sum = 0.f;
             for (int k = 4 * q; k < K; k += 16) { f4 v = ld4(s.p + k); sum += (v.x + v.y) + (v.z + v.w); }
@@ -177,7 +179,9 @@ struct ALConvT2 {
 // =================================================================================================
 // B loaders (column operand = weights).  load(nblk, t, i, k) -> float4 B(n, k..k+3)
 // =================================================================================================
-struct BLRows {                 // W[n][k], row stride ld (torch Linear / 1x1 conv weight)
+struct BLRows {
+    static constexpr bool kTrans = false;
+    __device__ __forceinline__ f4 load_n4(int, int, int, int) const { return zero4(); }                 // W[n][k], row stride ld (torch Linear / 1x1 conv weight)
     const float* w; long ld; int N; int NT;
     __device__ __forceinline__ int col(int nblk, int t, int i) const { return (nblk * NT + t) * 16 + i; }
     __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt, int = 0) const {
@@ -186,7 +190,9 @@ struct BLRows {                 // W[n][k], row stride ld (torch Linear / 1x1 co
         return ld4(w + (long)n * ld + k);
     }
 };
-struct BLGates {                // ConvLSTM: tile t = gate t (f,i,o,g), columns nblk*16.. of that gate; W[4C][K]
+struct BLGates {
+    static constexpr bool kTrans = false;
+    __device__ __forceinline__ f4 load_n4(int, int, int, int) const { return zero4(); }                // ConvLSTM: tile t = gate t (f,i,o,g), columns nblk*16.. of that gate; W[4C][K]
     const float* w; long ld; int C;
     __device__ __forceinline__ int col(int nblk, int t, int i) const { return t * C + nblk * 16 + i; }
     __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt, int = 0) const {
@@ -194,7 +200,8 @@ struct BLGates {                // ConvLSTM: tile t = gate t (f,i,o,g), columns 
         return ld4(w + (long)col(nblk, t, i) * ld + k);
     }
 };
-struct BLTrans {                // B(n,k) = W[k][n]  (dgrad of a Linear: W is [Kred][N])
+struct BLTrans {
+    static constexpr bool kTrans = true;          // memory is contiguous along n (W[k][n]): stage with float4 along n                // B(n,k) = W[k][n]  (dgrad of a Linear: W is [Kred][N])
     const float* w; long ld; int N; int NT;
     __device__ __forceinline__ int col(int nblk, int t, int i) const { return (nblk * NT + t) * 16 + i; }
     __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt, int = 0) const {
@@ -203,8 +210,16 @@ struct BLTrans {                // B(n,k) = W[k][n]  (dgrad of a Linear: W is [K
         const float* p = w + (long)k * ld + n;
         f4 v; v.x = p[0]; v.y = p[ld]; v.z = p[2 * ld]; v.w = p[3 * ld]; return v;
     }
+    // (B(n,k), B(n+1,k), B(n+2,k), B(n+3,k)) = W[k][n..n+3] for the local column nl of n-block nblk (N % 4 == 0)
+    __device__ __forceinline__ f4 load_n4(int nblk, int nl, int k, int Kt) const {
+        const int n = nblk * NT * 16 + nl;
+        if (n >= N || k >= Kt) return zero4();
+        return ld4(w + (long)k * ld + n);
+    }
 };
-struct BLConvW {                // conv weight [N][Cin][ks][ks] read as B(n, k' = tap*Cin + c)
+struct BLConvW {
+    static constexpr bool kTrans = false;
+    __device__ __forceinline__ f4 load_n4(int, int, int, int) const { return zero4(); }                // conv weight [N][Cin][ks][ks] read as B(n, k' = tap*Cin + c)
     const float* w; int N, Cin, KK; int NT;
     __device__ __forceinline__ int col(int nblk, int t, int i) const { return (nblk * NT + t) * 16 + i; }
     __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt, int = 0) const {
@@ -215,7 +230,9 @@ struct BLConvW {                // conv weight [N][Cin][ks][ks] read as B(n, k' 
         f4 v; v.x = p[0]; v.y = p[KK]; v.z = p[2 * KK]; v.w = p[3 * KK]; return v;
     }
 };
-struct BLConvWT {               // dgrad: B(col = c, k' = tap*N + n) = W[n][c][tap]
+struct BLConvWT {
+    static constexpr bool kTrans = false;
+    __device__ __forceinline__ f4 load_n4(int, int, int, int) const { return zero4(); }               // dgrad: B(col = c, k' = tap*N + n) = W[n][c][tap]
     const float* w; int N, Cin, KK; int NT;
     __device__ __forceinline__ int col(int nblk, int t, int i) const { return (nblk * NT + t) * 16 + i; }
     __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt, int = 0) const {
@@ -228,7 +245,9 @@ struct BLConvWT {               // dgrad: B(col = c, k' = tap*N + n) = W[n][c][t
     }
 };
 
-struct BLConvWT2 {              // parity-class dgrad of a 3x3/s2 conv: B(col = c, k' = t*N + n) = W[n][c][kh][kw], (kh,kw) from (class, t)
+struct BLConvWT2 {
+    static constexpr bool kTrans = false;
+    __device__ __forceinline__ f4 load_n4(int, int, int, int) const { return zero4(); }              // parity-class dgrad of a 3x3/s2 conv: B(col = c, k' = t*N + n) = W[n][c][kh][kw], (kh,kw) from (class, t)
     const float* w; int N, Cin; int NT;
     __device__ __forceinline__ int col(int nblk, int t, int i) const { return (nblk * NT + t) * 16 + i; }
     __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int, int cls) const {
@@ -260,6 +279,7 @@ struct EpStore {
     float* colsum;                  // optional [N]: += column sums of the stored value (bias gradient)
     int act; int accumulate;
     int N;
+    int dbg;                        // profiling ablations only (LEOD_GEMM_DBG): bit0 skip stores, bit1 skip MFMAs
     int rm_Q, rm_H, rm_W;           // rm_Q > 0: GEMM rows are parity-class ordered (ALConvT2) -> remap to pixel rows of the [B,H,W] map
     __device__ __forceinline__ long maprow(int row) const {
         if (rm_Q <= 0) return row;
@@ -289,7 +309,7 @@ struct EpStore {
                 const long row = maprow(grow);
                 if (act == ACT_AFFINE_SILU) v = siluf_(v * sc + sh);
                 if (act == ACT_MUL_GELU_GRAD && ok) v *= gelu_erf_grad(aux[row * ldaux + n]);
-                if (ok) {
+                if (ok && !(dbg & 1)) {
                     if (nsplit > 0 && n >= nsplit) {
                         float* p = out2 + row * ld2 + (n - nsplit);
                         *p = accumulate ? *p + v : v;
@@ -469,6 +489,233 @@ static inline int launch_gemm16(const AL& al, const BL& bl, const EP& ep, int M,
     }
     return leod_launch_status();
 }
+
+// =================================================================================================
+// LDS-staged row GEMM (large M):  64 rows x NT*16 columns per workgroup, K swept in chunks of KCH.
+// Why: the register-direct kernels above load MFMA operands in operand layout, i.e. one wave instruction gathers
+// 16 rows x 64 B.  Measured on MI355X that gather pattern (16 partial cache lines per instruction, 4x the line
+// requests of a contiguous stream) caps those kernels at ~1 TB/s, whereas row-contiguous 1 KiB wave loads stream at
+// 2.5-3 TB/s.  Here both operands are fetched with fully coalesced 16-byte loads (each thread owns fixed (row, k4)
+// slots), double-buffered through LDS, and read back in operand layout with conflict-free ds_read_b128.
+// =================================================================================================
+template <int NT, int KCH, int NBUF, class AL, class BL, class EP>
+__global__ __launch_bounds__(256, NBUF == 1 ? (NT == 4 ? 4 : 6) : 2) void gemm_lds_kernel(AL al, BL bl, EP ep, int M, int K, int dbg) {
+    constexpr int LD = KCH + 4;                      // 16-lane b128 reads of rows i=0..15 hit banks 4i..4i+3: conflict-free
+    constexpr int K4 = KCH / 4;                      // float4 slots per staged row
+    constexpr int BN = NT * 16;
+    constexpr int RA = (64 * K4 + 255) / 256, RB = (BN * K4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float sA[NBUF][64 * LD];     // NBUF == 1: K fits one chunk, no pipeline -> half the LDS, 6 workgroups/CU
+    __shared__ __attribute__((aligned(16))) float sB[NBUF][BN * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int brow0 = blockIdx.x * 64, nblk = blockIdx.y;
+    // ---- fixed staging slots of this thread ------------------------------------------------------------------------
+    typename AL::St ast[RA];
+    int ak[RA], al_off[RA]; bool aok[RA];
+#pragma unroll
+    for (int p = 0; p < RA; ++p) {
+        const int e = tid + 256 * p, r = e / K4, k4 = (e - r * K4) * 4;
+        aok[p] = e < 64 * K4;
+        ast[p] = al.init(brow0 + (aok[p] ? r : 0), M, 0, false);
+        ak[p] = k4; al_off[p] = r * LD + k4;
+    }
+    int bk[RB], bn[RB], bl_off[RB]; bool bok[RB];
+#pragma unroll
+    for (int p = 0; p < RB; ++p) {
+        const int e = tid + 256 * p;
+        bok[p] = e < BN * K4;
+        if (!BL::kTrans) { const int nl = e / K4, k4 = (e - nl * K4) * 4; bn[p] = nl; bk[p] = k4; bl_off[p] = nl * LD + k4; }
+        else { const int kl = e / (BN / 4), n4 = (e - kl * (BN / 4)) * 4; bn[p] = n4; bk[p] = kl; bl_off[p] = n4 * LD + kl; }
+    }
+    f4 ra[RA], rb[RB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < RA; ++p) ra[p] = (aok[p] && !(dbg & 4)) ? al.load(ast[p], k0 + ak[p], K) : zero4();
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+            rb[p] = zero4();
+            if (bok[p] && !(dbg & 8)) {
+                if (!BL::kTrans) rb[p] = bl.load(nblk, bn[p] >> 4, bn[p] & 15, k0 + bk[p], K);
+                else rb[p] = bl.load_n4(nblk, bn[p], k0 + bk[p], K);
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < RA; ++p) if (aok[p]) *reinterpret_cast<f4*>(&sA[buf][al_off[p]]) = ra[p];
+#pragma unroll
+        for (int p = 0; p < RB; ++p) if (bok[p]) {
+            if (!BL::kTrans) *reinterpret_cast<f4*>(&sB[buf][bl_off[p]]) = rb[p];
+            else { float* d = &sB[buf][bl_off[p]]; d[0] = rb[p].x; d[LD] = rb[p].y; d[2 * LD] = rb[p].z; d[3 * LD] = rb[p].w; }
+        }
+    };
+    f4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = zero4();
+    const int nch = (K + KCH - 1) / KCH;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const int aoff = (16 * wave + i) * LD + 4 * q, boff = i * LD + 4 * q;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int buf = NBUF == 1 ? 0 : (ch & 1);
+        if (NBUF > 1 && ch + 1 < nch) fetch((ch + 1) * KCH);              // next chunk's global loads fly under this chunk's MFMAs
+        const float* __restrict__ pa = sA[buf] + aoff;
+        const float* __restrict__ pb = sB[buf] + boff;
+#pragma unroll
+        for (int c = 0; c < KCH / 16; ++c) {
+            const f4 av = *reinterpret_cast<const f4*>(pa + 16 * c);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f4 bv = *reinterpret_cast<const f4*>(pb + 16 * t * LD + 16 * c);
+                if (dbg & 2) acc[t] = acc[t] + av + bv;
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[t] = mfma16(av[j], bv[j], acc[t]);
+                }
+            }
+        }
+        if (NBUF > 1 && ch + 1 < nch) stash(buf ^ 1);
+        if (NBUF > 1) __syncthreads();
+    }
+    const int row0 = brow0 + 16 * wave;
+    if (dbg & 1) { if (acc[0].x == 1.2345f) ep.template run<NT, BL>(acc, bl, row0, nblk, lane, M); return; }
+    if (row0 < M) ep.template run<NT, BL>(acc, bl, row0, nblk, lane, M);
+}
+
+// (mean, rstd) of every row of x[M,K] -> stats[M,2]; 16 lanes per row, fully coalesced (the LN prologue of the
+// LDS-staged GEMM reads them instead of re-deriving the statistics per n-block).
+static __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, long ld, float* __restrict__ stats,
+                                                        int M, int K, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, rg = lane >> 4;
+    const long row = ((long)blockIdx.x * 4 + wave) * 4 + rg;
+    const bool rok = row < M;
+    const float* p = x + (rok ? row : 0) * ld;
+    float sum = 0.f;
+    for (int k = 4 * i; k < K; k += 64) { const f4 v = ld4(p + k); sum += (v.x + v.y) + (v.z + v.w); }
+    const float mean = row16_sum(sum) / (float)K;
+    float var = 0.f;
+    for (int k = 4 * i; k < K; k += 64) {
+        const f4 v = ld4(p + k);
+        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+        var += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rstd = rsqrtf(row16_sum(var) / (float)K + eps);
+    if (rok && i == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+static inline int launch_row_stats(const float* x, long ld, float* stats, int M, int K, float eps, hipStream_t s) {
+    static const int dbg = getenv("LEOD_LDS_DBG") ? atoi(getenv("LEOD_LDS_DBG")) : 0;
+    if (dbg & 16) return LEOD_OK;
+    hipLaunchKernelGGL(row_stats_kernel, dim3(cdiv(M, 16)), dim3(256), 0, s, x, ld, stats, M, K, eps);
+    return leod_launch_status();
+}
+
+template <int NT, class AL, class BL, class EP>
+static inline int launch_gemm_lds(const AL& al, const BL& bl, const EP& ep, int M, int K, int nblocks_n, hipStream_t s) {
+    dim3 grid(cdiv(M, 64), nblocks_n);
+    static const int dbg = getenv("LEOD_LDS_DBG") ? atoi(getenv("LEOD_LDS_DBG")) : 0;
+    if (K == 48) hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 1, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, dbg);
+    else if (K <= 64) hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 1, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, dbg);
+    else if (K % 48 == 0) hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 2, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, dbg);
+    else hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 2, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, dbg);
+    return leod_launch_status();
+}
+// enough 64-row workgroups to fill the chip; smaller problems stay on the register-direct kernels (K-split)
+static inline bool use_gemm_lds(int M, int nblocks_n) { return (long)cdiv(M, 64) * nblocks_n >= 256 && M >= 2048; }
+
+// =================================================================================================
+// A-stationary row GEMM (K <= 384): one wave loads its 16-row A tile ONCE into registers (K/16 float4 per lane),
+// applies LayerNorm / per-k scaling in registers (statistics from the registers: no extra passes over memory), then
+// sweeps the n-blocks assigned to it, streaming only the weight fragments (L1/L2-resident).  Compared with gemm16_kernel
+// this removes the per-n-block re-read of A and the two dependent statistics passes of the LayerNorm prologue.
+// =================================================================================================
+struct ARowSrc {                // [x1 (K1 cols) | x2] rows, optional LayerNorm (over the full K) and per-k scale
+    const float* x1; long ld1; int K1; const float* x2; long ld2;
+    const float* ln_w; const float* ln_b; float eps; const float* kscale; float* stats_out;
+};
+
+template <int KCMAX, int NT, class BL, class EP>
+__global__ __launch_bounds__(256) void gemm16a_kernel(ARowSrc al, BL bl, EP ep, int M, int K, int nblocks_n, int dbgk) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int row0 = (blockIdx.x * 4 + wave) * 16;
+    if (row0 >= M) return;
+    const int KC = (K + 15) >> 4;
+    const bool rok = row0 + i < M;
+    const long r = rok ? row0 + i : M - 1;
+    const float* p1 = al.x1 + r * al.ld1;
+    const float* p2 = al.x2 ? al.x2 + r * al.ld2 : nullptr;
+    f4 a[KCMAX];
+#pragma unroll
+    for (int c = 0; c < KCMAX; ++c) {
+        const int k = 16 * c + 4 * q;
+        a[c] = zero4();
+        if (c < KC && k < K) a[c] = k < al.K1 ? ld4(p1 + k) : (p2 ? ld4(p2 + (k - al.K1)) : zero4());
+    }
+    if (al.ln_w) {
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < KCMAX; ++c) sum += (a[c].x + a[c].y) + (a[c].z + a[c].w);      // padded k are zero
+        const float mean = quad16_sum(sum) / (float)K;
+        float var = 0.f;
+#pragma unroll
+        for (int c = 0; c < KCMAX; ++c) {
+            if (c < KC && 16 * c + 4 * q < K) { const f4 d = a[c] - mean; var += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
+        }
+        const float rstd = rsqrtf(quad16_sum(var) / (float)K + al.eps);
+        if (al.stats_out && blockIdx.y == 0 && rok && q == 0) { al.stats_out[2 * r] = mean; al.stats_out[2 * r + 1] = rstd; }
+#pragma unroll
+        for (int c = 0; c < KCMAX; ++c) {
+            const int k = 16 * c + 4 * q;
+            if (c < KC && k < K) a[c] = (a[c] - mean) * rstd * ld4(al.ln_w + k) + ld4(al.ln_b + k);
+        }
+    }
+    if (al.kscale) {
+#pragma unroll
+        for (int c = 0; c < KCMAX; ++c) { const int k = 16 * c + 4 * q; if (c < KC && k < K) a[c] = a[c] * ld4(al.kscale + k); }
+    }
+    if (!rok) {
+#pragma unroll
+        for (int c = 0; c < KCMAX; ++c) a[c] = zero4();
+    }
+    for (int nb = blockIdx.y; nb < nblocks_n; nb += gridDim.y) {
+        f4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = zero4();
+#pragma unroll
+        for (int c = 0; c < KCMAX; ++c) {
+            if (c < KC) {
+                f4 b[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) b[t] = bl.load(nb, t, i, 16 * c + 4 * q, K);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        if (dbgk & 2) acc[t][j] += a[c][j] + b[t][j]; else acc[t] = mfma16(a[c][j], b[t][j], acc[t]);
+                    }
+            }
+        }
+        ep.template run<NT, BL>(acc, bl, row0, nb, lane, M);
+    }
+}
+
+template <int NT, class BL, class EP>
+static inline int launch_gemm16a(const ARowSrc& al, const BL& bl, const EP& ep, int M, int K, int nblocks_n, hipStream_t s) {
+    const int tiles = cdiv(M, 16);
+    int ny = 1;                                   // split the n-blocks over gridDim.y until ~2048 waves are in flight
+    while (ny < nblocks_n && (long)tiles * ny < 2048) ++ny;
+    dim3 grid(cdiv(M, 64), ny);
+    const int KC = (K + 15) >> 4;
+    static const int dbgk = getenv("LEOD_GEMM_DBG") ? atoi(getenv("LEOD_GEMM_DBG")) : 0;
+    if (KC <= 3) hipLaunchKernelGGL((gemm16a_kernel<3, NT, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n, dbgk);
+    else if (KC <= 6) hipLaunchKernelGGL((gemm16a_kernel<6, NT, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n, dbgk);
+    else if (KC <= 12) hipLaunchKernelGGL((gemm16a_kernel<12, NT, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n, dbgk);
+    else hipLaunchKernelGGL((gemm16a_kernel<24, NT, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n, dbgk);
+    return leod_launch_status();
+}
+// the A-stationary kernel needs the row tile in registers (K <= 384) and enough row tiles to fill the chip
+static inline bool use_gemm16a(int M, int K) { return K <= 384 && M >= 2048; }
 
 // =================================================================================================
 // wgrad GEMM:  dW[n][k] += sum_m dY(m,n) * X(m,k)   (+ optional dbias[n] += sum_m dY(m,n))

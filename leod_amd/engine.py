@@ -12,6 +12,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from . import ops
+from .functions import WgradSide
 from .parallel import FlatParams, DataParallel, one_cycle_lr
 from .models.detection.yolox.utils.boxes import postprocess_padded
 from .modules.utils.ssod import pred2label_padded
@@ -33,7 +34,12 @@ class TrainEngine:
         self._idx_cache = {}
         self._graph = None
         self._streams = None
-        self.n_streams = int(os.environ.get('LEOD_STREAMS', '1'))   # >1: stage wavefront over streams (eager only: capturing the multi-stream backward crashes ROCm 7.2's hipStreamEndCapture)
+        self._capturing = False
+        self._multi_last = False
+        self.wgrad_side = os.environ.get('LEOD_WGRAD_STREAM', '0') == '1'   # weight-gradient kernels on a side stream, overlapping the dgrad chain
+        # stage wavefront over HIP streams (eager launches only: ROCm 7.2's hipStreamEndCapture crashes on the captured
+        # multi-stream backward, so capture() always records the single-stream schedule)
+        self.n_streams = int(os.environ.get('LEOD_STREAMS', '4'))
 
     def current_lr(self):
         h = self.hp
@@ -81,7 +87,8 @@ class TrainEngine:
         if padded is not None and tuple(ev_seq.shape[-2:]) == tuple(padded):
             padded = None
         main = torch.cuda.current_stream()
-        multi = self.n_streams > 1
+        multi = self.n_streams > 1 and not torch.cuda.is_current_stream_capturing() and not self._capturing
+        self._multi_last = multi
         if multi:
             if self._streams is None:
                 self._streams = [torch.cuda.Stream(device=ev_seq.device) for _ in stages]
@@ -120,8 +127,13 @@ class TrainEngine:
     def _step_body(self, ev_seq, labels, label_tb, is_first, states, hp_dev=None, lr=None, scale=1.0):
         self.flat.zero_grad()
         _, losses, new_states = self.forward_loss(ev_seq, labels, label_tb, is_first, states)
-        losses['loss'].backward()
-        if self._streams is not None:
+        WgradSide.active = self.wgrad_side
+        try:
+            losses['loss'].backward()
+        finally:
+            WgradSide.active = False
+            WgradSide.join()            # parameter gradients are complete on the launch stream from here on
+        if self._multi_last:
             # the wgrad kernels write parameter gradients directly (autograd does not see those writes), so the
             # launch stream must explicitly wait for every stage stream before the all-reduce / optimiser
             main = torch.cuda.current_stream()
@@ -168,6 +180,7 @@ class TrainEngine:
                  [(h.clone(), c.clone()) for h, c in self._g_states],
                  [m.bn.running_mean.clone() for m in self.det.modules() if hasattr(m, 'bn')],
                  [m.bn.running_var.clone() for m in self.det.modules() if hasattr(m, 'bn')])
+        self._capturing = True                                          # single-stream schedule from here on
         with torch.cuda.stream(side):                                   # warm-up on a side stream, as torch requires
             self._graph_body()
         torch.cuda.current_stream().wait_stream(side)
@@ -175,6 +188,7 @@ class TrainEngine:
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._g_losses = self._graph_body()
+        self._capturing = False
         # undo the side effects of the warm-up + capture passes (capture itself does not execute)
         self.flat.data.copy_(saved[0]); self.flat.exp_avg.copy_(saved[1]); self.flat.exp_avg_sq.copy_(saved[2])
         for (gh, gc), (h, c) in zip(self._g_states, saved[3]):

@@ -18,6 +18,59 @@ from . import ops
 _SYNC_BN = {'group': None, 'world_size': 1}
 
 
+class WgradSide:
+    """Weight-gradient kernels feed nothing until the optimiser, so the engine lets them run on a side HIP stream
+    next to the dgrad chain (the per-kernel work of an RVT stage is too small to fill 256 CUs on its own).
+    ``active`` is switched on by ``TrainEngine`` for the duration of its backward pass; it then calls ``join()``
+    before the gradient all-reduce.  Tensors read on the side stream are kept alive until the join, so the caching
+    allocator cannot hand their memory to a later main-stream kernel while the side stream still reads it."""
+    active = False
+    streams = {}            # launch stream (raw handle) -> its side stream
+    used = set()
+    keep = []
+
+    @classmethod
+    def side_of(cls, main):
+        key = main.cuda_stream
+        st = cls.streams.get(key)
+        if st is None:
+            st = cls.streams[key] = torch.cuda.Stream()
+        cls.used.add(key)
+        return st
+
+    @classmethod
+    def join(cls):
+        if cls.used:
+            cur = torch.cuda.current_stream()
+            for key in cls.used:
+                cur.wait_stream(cls.streams[key])
+            cls.used.clear()
+        cls.keep.clear()
+
+
+class _wgrad_side:
+    """``with _wgrad_side(dy, x): ops.linear_wgrad(...)`` -- fork: the side stream waits for everything enqueued so far."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+        self.ctx = None
+
+    def __enter__(self):
+        if not WgradSide.active:
+            return
+        main = torch.cuda.current_stream()
+        side = WgradSide.side_of(main)
+        side.wait_stream(main)
+        WgradSide.keep.extend(t for t in self.tensors if t is not None)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 def set_sync_batchnorm(process_group, world_size: int):
     """Enable SyncBatchNorm semantics (reference: train.py:247 sync_batchnorm=True when >1 GPU): the
     per-channel (sum, sumsq) and backward (sum du, sum du*xhat) vectors are all-reduced over RCCL."""
@@ -75,9 +128,11 @@ class ConvLNFn(Function):
         dz = ops.layernorm_bwd(_cont(dy), z, stats, ln_w, None, grad_buf(mod.norm.weight), grad_buf(mod.norm.bias))
         dx = None
         if ctx.is_stem:
-            ops.stem_conv_wgrad(dz, x, grad_buf(mod.conv.weight), ctx.padded_hw, ctx.stride, conv_w.shape[-1] // 2)
+            with _wgrad_side(dz, x):
+                ops.stem_conv_wgrad(dz, x, grad_buf(mod.conv.weight), ctx.padded_hw, ctx.stride, conv_w.shape[-1] // 2)
         else:
-            ops.conv_nhwc_wgrad(dz, x, grad_buf(mod.conv.weight), None, stride=ctx.stride)
+            with _wgrad_side(dz, x):
+                ops.conv_nhwc_wgrad(dz, x, grad_buf(mod.conv.weight), None, stride=ctx.stride)
             if ctx.needs_input_grad[1]:
                 dx = ops.conv_nhwc_dgrad(dz, conv_w, x.shape, stride=ctx.stride)
         return None, dx, None, None, None, None, None, None
@@ -110,24 +165,27 @@ class AttnBlockFn(Function):
         sa, mlp = mod.self_attn, mod.mlp
         heads, part, window = sa.num_heads, mod.partition_size, mod.partition_window
         dz = _cont(dz)
-        # ---- MLP branch ---------------------------------------------------------------------------
+        # ---- dgrad chain (critical path) ------------------------------------------------------------
         dt2 = ops.layerscale_bwd(dz, t2, g2, grad_buf(mod.ls2.gamma))
-        ops.linear_wgrad(dt2, h, grad_buf(mlp.net[2].weight), grad_buf(mlp.net[2].bias))
         du = ops.linear_dgrad(dt2, fc2_w, aux_u=u)
-        ops.linear_wgrad(du, y, grad_buf(mlp.net[0][0].weight), grad_buf(mlp.net[0][0].bias), stats=st2, ln_w=n2w, ln_b=n2b)
         dn2 = ops.linear_dgrad(du, fc1_w)
         dy = ops.layernorm_bwd(dn2, y, st2, n2w, dz, grad_buf(mod.norm2.weight), grad_buf(mod.norm2.bias))
-        # ---- attention branch ---------------------------------------------------------------------
         dt1 = ops.layerscale_bwd(dy, t1, g1, grad_buf(mod.ls1.gamma))
-        ops.linear_wgrad(dt1, o, grad_buf(sa.proj.weight), grad_buf(sa.proj.bias))
         do = ops.linear_dgrad(dt1, proj_w)
         dqkv = ops.partition_attn_bwd(qkv, do, lse, heads, part, window)
+        # ---- weight gradients: off the critical path (side stream when the engine enables it) ------
+        with _wgrad_side(dt2, h, du, y, st2, dt1, o, dqkv, x, st1):
+            ops.linear_wgrad(dt2, h, grad_buf(mlp.net[2].weight), grad_buf(mlp.net[2].bias))
+            ops.linear_wgrad(du, y, grad_buf(mlp.net[0][0].weight), grad_buf(mlp.net[0][0].bias), stats=st2, ln_w=n2w, ln_b=n2b)
+            ops.linear_wgrad(dt1, o, grad_buf(sa.proj.weight), grad_buf(sa.proj.bias))
+            if n1w is not None:
+                ops.linear_wgrad(dqkv, x, grad_buf(sa.qkv.weight), grad_buf(sa.qkv.bias), stats=st1, ln_w=n1w, ln_b=n1b)
+            else:
+                ops.linear_wgrad(dqkv, x, grad_buf(sa.qkv.weight), grad_buf(sa.qkv.bias))
         if n1w is not None:
-            ops.linear_wgrad(dqkv, x, grad_buf(sa.qkv.weight), grad_buf(sa.qkv.bias), stats=st1, ln_w=n1w, ln_b=n1b)
             dn1 = ops.linear_dgrad(dqkv, qkv_w)
             dx = ops.layernorm_bwd(dn1, x, st1, n1w, dy, grad_buf(mod.norm1.weight), grad_buf(mod.norm1.bias))
         else:
-            ops.linear_wgrad(dqkv, x, grad_buf(sa.qkv.weight), grad_buf(sa.qkv.bias))
             dx = ops.linear_dgrad(dqkv, qkv_w, out=dy, accumulate=True)     # dy is private to this backward
         return (None, dx) + (None,) * 14
 
@@ -153,7 +211,8 @@ class ConvLSTMFn(Function):
         mod = ctx.mod
         C = x.shape[-1]
         dgates, dc_prev = ops.convlstm_gates_bwd(_cont(dh), _cont(dc), gates, c_prev, c, want_dc_prev=ctx.needs_input_grad[3])
-        ops.linear_wgrad(dgates, x, grad_buf(mod.conv1x1.weight).view(4 * C, 2 * C), grad_buf(mod.conv1x1.bias), x2=h_prev)
+        with _wgrad_side(dgates, x, h_prev):
+            ops.linear_wgrad(dgates, x, grad_buf(mod.conv1x1.weight).view(4 * C, 2 * C), grad_buf(mod.conv1x1.bias), x2=h_prev)
         dx, dh_prev = ops.linear_dgrad(dgates, w.view(4 * C, 2 * C), split=C)
         dx = dx.view(x.shape)
         dh_prev = dh_prev.view(x.shape) if ctx.needs_input_grad[2] else None
@@ -197,7 +256,8 @@ class BaseConvFn(Function):
         _allreduce_stats(sums)
         dz = ops.bn_silu_bwd_apply(dy, z, mean, rstd, bn_w, bn_b, sums, grad_buf(mod.bn.weight), grad_buf(mod.bn.bias), ctx.count,
                                    count_dev=ctx.count_dev)
-        ops.conv_nhwc_wgrad(dz, x, grad_buf(mod.conv.weight), None, stride=ctx.stride)
+        with _wgrad_side(dz, x):
+            ops.conv_nhwc_wgrad(dz, x, grad_buf(mod.conv.weight), None, stride=ctx.stride)
         dx = ops.conv_nhwc_dgrad(dz, conv_w, x.shape, stride=ctx.stride) if ctx.needs_input_grad[1] else None
         return None, dx, None, None, None, None, None
 

@@ -74,7 +74,8 @@ def ln_linear_fwd(x, ln_w, ln_b, W, bias, want_act=False, want_stats=False, eps=
     M = x.numel() // K
     out = _empty(x.shape[:-1] + (N,), x)
     act = _empty(out.shape, x) if want_act else None
-    stats = _empty((M, 2), x) if (want_stats and ln_w is not None) else None
+    # always hand the kernel a statistics buffer: the LDS-staged GEMM reads precomputed (mean, rstd) from it
+    stats = _empty((M, 2), x) if ln_w is not None else None
     check(_l().leod_ln_linear_fwd(_p(x), K, _p(ln_w), _p(ln_b), eps, _p(W), _p(bias), _p(out), _p(act), _p(stats),
                                    M, N, K, _stream()), 'ln_linear_fwd')
     return out, act, stats
