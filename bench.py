@@ -127,6 +127,9 @@ def main():
     ap.add_argument('--graph', action='store_true', help='replay one single-stream hipGraph per step instead of the default eager '
                     'launch with the 4-stream stage wavefront (LEOD_GRAPH=1 does the same)')
     ap.add_argument('--no-graph', action='store_true', help=argparse.SUPPRESS)        # old flag, now the default
+    ap.add_argument('--launch', choices=('cells', 'eager', 'graph'), default=os.environ.get('LEOD_LAUNCH', 'eager'),
+                    help='cells: per-(stage,timestep) hipGraphs replayed as a 4-stream wavefront (leod_amd/cellgraph.py); '
+                         'eager: one Python launch per kernel, same wavefront; graph: one single-stream hipGraph per step')
     args = ap.parse_args()
 
     from leod_amd.parallel import init_distributed
@@ -138,7 +141,7 @@ def main():
     import torch.distributed as dist
     from leod_amd.config import full_config, dynamically_modify_train_config
     from leod_amd.models.detection.yolox_extension.models.detector import YoloXDetector
-    from leod_amd.engine import TrainEngine
+    from leod_amd.cellgraph import CellGraphEngine as TrainEngine      # TrainEngine + the per-cell hipGraph scheduler
     from leod_amd import ops
 
     cfg = dynamically_modify_train_config(full_config('gen1', args.size))
@@ -165,14 +168,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Default: eager launches with the stage wavefront over 4 HIP streams (engine.py) -- measured 2080 vs 1679
-    # event-frames/s for the single-stream hipGraph replay, because the per-stage kernels are too small to fill 256 CUs
-    # one at a time and ROCm 7.2 cannot capture the multi-stream backward.  --graph / LEOD_GRAPH=1 selects the replay.
-    use_graph = (args.graph or os.environ.get('LEOD_GRAPH') == '1') and not args.no_graph
-    if use_graph:
+    # Schedule (engine.schedule, default 'batched'): stage-major, every stage processes all T timesteps per launch; only
+    # the ConvLSTM recurrence is unrolled over t.  Launch modes on top of it (identical kernels, parity between them is
+    # tested in tests/test_engine_gpu.py):
+    #   eager (default): one Python launch per kernel (~900 launches per step: GPU-bound).
+    #   graph          : the whole step as one hipGraph (same speed on one GPU; no RCCL inside).
+    #   cells          : per-(stage,timestep) hipGraphs replayed as a 4-stream wavefront (leod_amd/cellgraph.py) -- the
+    #                    best launch mode for the timestep-major schedule, kept for comparison.
+    launch = 'graph' if (args.graph or os.environ.get('LEOD_GRAPH') == '1') else ('eager' if args.no_graph else args.launch)
+    use_graph = launch == 'graph'
+    if launch == 'graph':
         eng.step(ev, labels, label_tb, first_mask(0))                  # one eager step builds the LSTM states
         eng.capture(ev, labels, label_tb, first_mask(1))
         run = lambda m: eng.step_graph(None, None, m)                  # noqa: E731  (inputs already in the static buffers)
+    elif launch == 'cells':
+        eng.step(ev, labels, label_tb, first_mask(0))
+        eng.build(ev, labels, label_tb, first_mask(1))
+        run = lambda m: eng.step_cells(None, None, m)                  # noqa: E731
     else:
         run = lambda m: eng.step(ev, labels, label_tb, m)              # noqa: E731
     for s in range(args.warmup):
@@ -215,7 +227,8 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'RVT-{args.size} Gen1 240x304 (pad 256x320) T={T} bs={B}/GPU fully-supervised train step, '
                                    f'{len(label_ts)} labelled frames/sequence, random-init weights',
-                       'global_batch': world * B, 'seq_len': T, 'parallelism': f'dp{world}', 'launch': 'hipgraph' if use_graph else f'eager, {eng.n_streams}-stream stage wavefront',
+                       'global_batch': world * B, 'seq_len': T, 'parallelism': f'dp{world}', 'launch': {'graph': 'one single-stream hipGraph per step', 'eager': f'eager, schedule={eng.schedule}',
+                                  'cells': f'per-cell hipGraphs, {eng.n_streams}-stream stage wavefront'}[launch],
                        'per_gpu_event_frames_per_s': round(fps / world, 2), 'final_loss': round(loss_val, 4),
                        'whole_step_hbm_frac_of_peak': round(ALGO_MB_PER_FRAME_FP32 * 1e6 * fps / world / (PEAK_HBM_GBS * 1e9), 5)},
             'roofline': roofline,

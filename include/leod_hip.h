@@ -51,8 +51,9 @@ int leod_partition_attn_bwd(const float* qkv, const float* dout, const float* ls
  * h_prev/c_prev NULL = zero state; gates_out (optional) [M,4,C] post-activation gates. */
 int leod_convlstm_fwd(const float* x, const float* h_prev, const float* c_prev, const float* W, const float* bias,
                       float* h_out, float* c_out, float* gates_out, int M, int C, leod_stream_t stream);
-/* dgates[M,4,C] (pre-activation), dc_prev (optional) from dh (optional), dc_next (optional). */
-int leod_convlstm_gates_bwd(const float* dh, const float* dc_next, const float* gates, const float* c_prev,
+/* dgates[M,4,C] (pre-activation), dc_prev (optional) from dh + dh2 (both optional: gradient of h_t from the layers
+ * above and from timestep t+1) and dc_next (optional). */
+int leod_convlstm_gates_bwd(const float* dh, const float* dh2, const float* dc_next, const float* gates, const float* c_prev,
                             const float* c_t, float* dgates, float* dc_prev, int M, int C, leod_stream_t stream);
 
 /* dx (=|+=) (dy[M,N]*kscale[N]) W[N,K] ; optional: multiply by gelu'(aux_u[M,K]); route columns >= nsplit to dx2;

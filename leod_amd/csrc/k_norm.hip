@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) void ls_bwd_kernel(const float* __restrict__ d
 // ConvLSTM gate backward (models/layers/rnn.py:58-68): from dh (total grad of h_t) and dc_next to
 // pre-activation gate grads [M,4,C] and dc_prev.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dc_next,
+__global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dh2,
+                                                             const float* __restrict__ dc_next,
                                                              const float* __restrict__ gates, const float* __restrict__ c_prev,
                                                              const float* __restrict__ c_t, float* __restrict__ dgates,
                                                              float* __restrict__ dc_prev, long M, int C) {
@@ -187,7 +188,8 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __rest
         const f4 f = ld4(gp), ig = ld4(gp + C), o = ld4(gp + 2 * C), g = ld4(gp + 3 * C);
         const f4 ct = ld4(c_t + e);
         f4 th; th.x = tanhf(ct.x); th.y = tanhf(ct.y); th.z = tanhf(ct.z); th.w = tanhf(ct.w);
-        const f4 dhv = dh ? ld4(dh + e) : zero4();
+        f4 dhv = dh ? ld4(dh + e) : zero4();
+        if (dh2) dhv += ld4(dh2 + e);          // BPTT: gradient from the next timestep on top of the one from above
         f4 dc = dhv * o * (1.0f - th * th);
         if (dc_next) dc += ld4(dc_next + e);
         const f4 cp = c_prev ? ld4(c_prev + e) : zero4();
@@ -340,11 +342,11 @@ LEOD_API int leod_layerscale_bwd(const float* dz, const float* t, const float* g
     return leod_launch_status();
 }
 
-LEOD_API int leod_convlstm_gates_bwd(const float* dh, const float* dc_next, const float* gates, const float* c_prev,
+LEOD_API int leod_convlstm_gates_bwd(const float* dh, const float* dh2, const float* dc_next, const float* gates, const float* c_prev,
                                      const float* c_t, float* dgates, float* dc_prev, int M, int C, hipStream_t stream) {
     if (!gates || !c_t || !dgates || (C & 3)) return LEOD_ERR_ARG;
     if (M <= 0) return LEOD_OK;
-    hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(flat_grid((long)M * C / 4)), dim3(256), 0, stream, dh, dc_next, gates,
+    hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(flat_grid((long)M * C / 4)), dim3(256), 0, stream, dh, dh2, dc_next, gates,
                        c_prev, c_t, dgates, dc_prev, (long)M, C);
     return leod_launch_status();
 }

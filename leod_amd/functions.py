@@ -220,6 +220,66 @@ class ConvLSTMFn(Function):
 
 
 # ---------------------------------------------------------------------------------------------------
+class ConvLSTMSeqFn(Function):
+    """DWSConvLSTM2d (models/layers/rnn.py:37-70) unrolled over a whole sequence: x_seq [T,B,H,W,C] (channels-last rows),
+    initial state (h0, c0) or None.  Only this recurrence is sequential in an RVT stage -- everything in front of it
+    (downsampling conv, attention blocks) is per-frame and is run time-batched on [T*B] by the caller.
+
+    h and c of all timesteps live in one [T+1, ...] buffer each (slot 0 = initial state), so that ``h_prev`` of all
+    timesteps is the contiguous view ``hbuf[:T]``: the weight gradient of the whole sequence is ONE wgrad launch over
+    T*B*H*W rows, and BPTT needs two launches per timestep (gate backward with the two h-gradient sources fused, dgrad
+    with the [dx | dh_prev] split epilogue)."""
+
+    @staticmethod
+    def forward(ctx, mod, x_seq, h0, c0, w, b):
+        need = any(ctx.needs_input_grad)
+        T, C = x_seq.shape[0], x_seq.shape[-1]
+        M = x_seq[0].numel() // C
+        hbuf = x_seq.new_empty((T + 1,) + tuple(x_seq.shape[1:]))
+        cbuf = x_seq.new_empty((T + 1,) + tuple(x_seq.shape[1:]))
+        if h0 is None:
+            hbuf[0].zero_()
+            cbuf[0].zero_()
+        else:
+            hbuf[0].copy_(h0)
+            cbuf[0].copy_(c0)
+        gates = x_seq.new_empty((T, M, 4, C)) if need else None
+        W2 = w.view(4 * C, 2 * C)
+        for t in range(T):
+            zero_state = h0 is None and t == 0
+            ops.convlstm_fwd(x_seq[t], None if zero_state else hbuf[t], None if zero_state else cbuf[t], W2, b,
+                             h_out=hbuf[t + 1], c_out=cbuf[t + 1], gates_out=gates[t] if need else None)
+        if need:
+            ctx.mod = mod
+            ctx.set_materialize_grads(False)
+            ctx.save_for_backward(x_seq, hbuf, cbuf, gates, w)
+        return hbuf[1:], cbuf[T]
+
+    @staticmethod
+    def backward(ctx, dh_seq, dc_last):
+        x_seq, hbuf, cbuf, gates, w = ctx.saved_tensors
+        mod = ctx.mod
+        T, C = x_seq.shape[0], x_seq.shape[-1]
+        M = x_seq[0].numel() // C
+        W2 = w.view(4 * C, 2 * C)
+        dh_seq = _cont(dh_seq)
+        dgates = x_seq.new_empty((T, M, 4 * C))
+        dx_seq = torch.empty_like(x_seq)
+        need_h0, need_c0 = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        dh_next, dc_next = None, _cont(dc_last)
+        for t in reversed(range(T)):
+            _, dc_next = ops.convlstm_gates_bwd(dh_seq[t] if dh_seq is not None else None, dc_next, gates[t], cbuf[t], cbuf[t + 1],
+                                                want_dc_prev=(t > 0 or need_c0), dh2=dh_next, dgates_out=dgates[t])
+            _, dh_next = ops.linear_dgrad(dgates[t], W2, split=C, out=dx_seq[t].view(M, C))
+        with _wgrad_side(dgates, x_seq, hbuf):
+            ops.linear_wgrad(dgates.view(T * M, 4 * C), x_seq.view(T * M, C), grad_buf(mod.conv1x1.weight).view(4 * C, 2 * C),
+                             grad_buf(mod.conv1x1.bias), x2=hbuf[:T].view(T * M, C))
+        dh0 = dh_next.view(x_seq.shape[1:]) if need_h0 else None
+        dc0 = dc_next if need_c0 else None
+        return None, dx_seq, dh0, dc0, None, None
+
+
+# ---------------------------------------------------------------------------------------------------
 class BaseConvFn(Function):
     """BaseConv (network_blocks.py:29-51): conv(no bias) -> BatchNorm2d -> SiLU on NHWC maps."""
 

@@ -55,6 +55,15 @@ class RNNDetectorStage(nn.Module):
         h_c = self.lstm(nhwC_2_nChw(x), h_and_c_previous)          # zero-copy view, no .contiguous()
         return h_c[0], h_c
 
+    def forward_sequence(self, x: th.Tensor, T: int, h_and_c_previous=None, padded_hw=None):
+        """All T timesteps of a sequence batch at once: x [T*B,...].  Downsampling and the attention blocks are per-frame
+        maps, so they run ONCE on the T*B batch (21x larger launches instead of 21x more of them); only the ConvLSTM
+        recurrence walks over t (``DWSConvLSTM2d.forward_sequence``).  Same values as T chained ``forward`` calls."""
+        x = self.downsample_cf2cl(x, padded_hw=padded_hw)
+        for blk in self.att_blocks:
+            x = blk(x)
+        return self.lstm.forward_sequence(nhwC_2_nChw(x), T, h_and_c_previous)
+
 
 class RNNDetector(BaseDetector):
     def __init__(self, mdl_config):
@@ -103,6 +112,22 @@ class RNNDetector(BaseDetector):
         states, output = [], {}
         for i, stage in enumerate(self.stages):
             x, state = stage(x, prev_states[i], token_mask if i == 0 else None, padded_hw if i == 0 else None)
+            states.append(state)
+            output[i + 1] = x
+        return output, states
+
+    def forward_sequence(self, x_seq: th.Tensor, prev_states=None):
+        """x_seq [T,B,C,H,W]: stage-major, time-batched evaluation of a whole sequence (see
+        ``RNNDetectorStage.forward_sequence``).  Returns {stage: features of all timesteps [T*B,C,h,w]} and the final
+        states -- the per-timestep loop of modules/detection.py:188-226 with the loops interchanged."""
+        T, B = x_seq.shape[:2]
+        if prev_states is None:
+            prev_states = [None] * self.num_stages
+        padded_hw = self.in_res_hw if (self.in_res_hw is not None and tuple(x_seq.shape[-2:]) != self.in_res_hw) else None
+        x = x_seq.reshape((T * B,) + tuple(x_seq.shape[2:]))
+        states, output = [], {}
+        for i, stage in enumerate(self.stages):
+            x, state = stage.forward_sequence(x, T, prev_states[i], padded_hw if i == 0 else None)
             states.append(state)
             output[i + 1] = x
         return output, states

@@ -34,3 +34,17 @@ class DWSConvLSTM2d(nn.Module):
             h0, c0 = (Fn.to_nhwc(t) for t in h_and_c_previous)
         h, c = Fn.ConvLSTMFn.apply(self, xr, h0, c0, self.conv1x1.weight, self.conv1x1.bias)
         return Fn.as_nchw(h), Fn.as_nchw(c)
+
+    def forward_sequence(self, x: th.Tensor, T: int, h_and_c_previous: Optional[Tuple[th.Tensor, th.Tensor]] = None):
+        """Time-batched entry point: x [T*B,C,H,W] (logical NCHW, channels-last memory) holds the inputs of all T
+        timesteps of a sequence batch.  Returns h of all timesteps [T*B,C,H,W] and the final (h, c) state --
+        the same values as T calls of ``forward`` chained through the state."""
+        xr = Fn.to_nhwc(x)
+        TB, H, W, C = xr.shape
+        assert TB % T == 0
+        if h_and_c_previous is None:
+            h0 = c0 = None
+        else:
+            h0, c0 = (Fn.to_nhwc(t) for t in h_and_c_previous)
+        h_seq, c_last = Fn.ConvLSTMSeqFn.apply(self, xr.view(T, TB // T, H, W, C), h0, c0, self.conv1x1.weight, self.conv1x1.bias)
+        return Fn.as_nchw(h_seq.reshape(TB, H, W, C)), (Fn.as_nchw(h_seq[T - 1]), Fn.as_nchw(c_last))

@@ -119,27 +119,29 @@ def partition_attn_bwd(qkv, dout, lse, heads, part, window):
     return dqkv
 
 
-def convlstm_fwd(x, h_prev, c_prev, W, bias, want_gates=False):
-    """x/h_prev/c_prev [..,C] channels-last rows; W [4C,2C]; -> h, c, gates[M,4,C]."""
-    for t, n in ((x, 'x'), (h_prev, 'h_prev'), (c_prev, 'c_prev'), (W, 'W'), (bias, 'bias')):
+def convlstm_fwd(x, h_prev, c_prev, W, bias, want_gates=False, h_out=None, c_out=None, gates_out=None):
+    """x/h_prev/c_prev [..,C] channels-last rows; W [4C,2C]; -> h, c, gates[M,4,C] (optionally into given buffers)."""
+    for t, n in ((x, 'x'), (h_prev, 'h_prev'), (c_prev, 'c_prev'), (W, 'W'), (bias, 'bias'), (h_out, 'h_out'),
+                 (c_out, 'c_out'), (gates_out, 'gates_out')):
         _ck(t, name=n)
     C = x.shape[-1]
     M = x.numel() // C
-    h = _empty(x.shape, x)
-    c = _empty(x.shape, x)
-    gates = _empty((M, 4, C), x) if want_gates else None
+    h = _empty(x.shape, x) if h_out is None else h_out
+    c = _empty(x.shape, x) if c_out is None else c_out
+    gates = gates_out if gates_out is not None else (_empty((M, 4, C), x) if want_gates else None)
     check(_l().leod_convlstm_fwd(_p(x), _p(h_prev), _p(c_prev), _p(W), _p(bias), _p(h), _p(c), _p(gates), M, C,
                                   _stream()), 'convlstm_fwd')
     return h, c, gates
 
 
-def convlstm_gates_bwd(dh, dc_next, gates, c_prev, c_t, want_dc_prev=True):
-    for t, n in ((dh, 'dh'), (dc_next, 'dc_next'), (gates, 'gates'), (c_prev, 'c_prev'), (c_t, 'c_t')):
+def convlstm_gates_bwd(dh, dc_next, gates, c_prev, c_t, want_dc_prev=True, dh2=None, dgates_out=None):
+    for t, n in ((dh, 'dh'), (dc_next, 'dc_next'), (gates, 'gates'), (c_prev, 'c_prev'), (c_t, 'c_t'), (dh2, 'dh2'),
+                 (dgates_out, 'dgates_out')):
         _ck(t, name=n)
     M, _, C = gates.shape
-    dgates = _empty((M, 4 * C), gates)
+    dgates = _empty((M, 4 * C), gates) if dgates_out is None else dgates_out
     dc_prev = _empty(c_t.shape, gates) if want_dc_prev else None
-    check(_l().leod_convlstm_gates_bwd(_p(dh), _p(dc_next), _p(gates), _p(c_prev), _p(c_t), _p(dgates), _p(dc_prev),
+    check(_l().leod_convlstm_gates_bwd(_p(dh), _p(dh2), _p(dc_next), _p(gates), _p(c_prev), _p(c_t), _p(dgates), _p(dc_prev),
                                         M, C, _stream()), 'convlstm_gates_bwd')
     return dgates, dc_prev
 

@@ -117,6 +117,43 @@ def test_graph_replay_equals_eager(gpu, manifest):
         np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('capture_head', [True, False])
+def test_cell_graphs_equal_eager(gpu, manifest, capture_head):
+    """Per-cell hipGraphs replayed as a 4-stream wavefront (leod_amd.cellgraph) == the eager single-stream step."""
+    from leod_amd.engine import TrainEngine
+    from leod_amd.cellgraph import CellGraphEngine
+    T, B = 4, 2
+    label_tb = [[], [0], [], [0, 1]]
+    res = {}
+    for mode in ('eager', 'cells'):
+        det, _ = micro_detector(manifest, 9)
+        eng = (CellGraphEngine if mode == 'cells' else TrainEngine)(det, lr=2e-4, total_steps=1000)
+        eng.n_streams = 1
+        out = []
+        for step in range(3):
+            ev = synth_events(T, B, 20, 60, 90, seed=50 + step, as_uint8=True).to(DEV)
+            labels = torch.zeros((3, 4, 7))
+            ll = op.batched_yolox_labels(micro_labels(3, seed=60 + step))
+            labels[:, :ll.shape[1]] = ll
+            labels = labels.to(DEV)
+            is_first = torch.tensor([step == 0, True], device=DEV)
+            if mode == 'cells':
+                if step == 0:
+                    eng.build(ev, labels, label_tb, is_first, capture_head=capture_head)
+                losses = eng.step_cells(ev, labels, is_first)
+            else:
+                losses = eng.step(ev, labels, label_tb, is_first)
+            out.append([float(losses[k]) for k in KEYS])
+        res[mode] = (np.array(out), eng.flat.data.clone().cpu(), [c.clone().cpu() for _, c in eng.states])
+    np.testing.assert_allclose(res['cells'][0], res['eager'][0], rtol=2e-5, atol=1e-6)
+    pg, pe = res['cells'][1].numpy(), res['eager'][1].numpy()
+    diff = np.abs(pg - pe)
+    assert diff.max() < 3.5e-4                      # see test_graph_replay_equals_eager for the tolerance model
+    assert (diff > 2e-6 + 1e-4 * np.abs(pe)).mean() < 2e-3
+    for a, b in zip(res['cells'][2], res['eager'][2]):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-4, atol=1e-5)
+
+
 def test_pseudo_label_inference_vs_oracle(gpu, manifest):
     from leod_amd.engine import PseudoLabelEngine
     det, sd = micro_detector(manifest, 5)
