@@ -499,7 +499,7 @@ static inline int launch_gemm16(const AL& al, const BL& bl, const EP& ep, int M,
 // slots), double-buffered through LDS, and read back in operand layout with conflict-free ds_read_b128.
 // =================================================================================================
 template <int NT, int KCH, int NBUF, class AL, class BL, class EP>
-__global__ __launch_bounds__(256, NBUF == 1 ? (NT == 4 ? 4 : 6) : 2) void gemm_lds_kernel(AL al, BL bl, EP ep, int M, int K, int dbg) {
+__global__ __launch_bounds__(256, NBUF == 1 ? (NT == 4 ? 4 : 6) : 2) void gemm_lds_kernel(AL al, BL bl, EP ep, int M, int K) {
     constexpr int LD = KCH + 4;                      // 16-lane b128 reads of rows i=0..15 hit banks 4i..4i+3: conflict-free
     constexpr int K4 = KCH / 4;                      // float4 slots per staged row
     constexpr int BN = NT * 16;
@@ -527,15 +527,19 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (NT == 4 ? 4 : 6) : 2) void gemm_l
         if (!BL::kTrans) { const int nl = e / K4, k4 = (e - nl * K4) * 4; bn[p] = nl; bk[p] = k4; bl_off[p] = nl * LD + k4; }
         else { const int kl = e / (BN / 4), n4 = (e - kl * (BN / 4)) * 4; bn[p] = n4; bk[p] = kl; bl_off[p] = n4 * LD + kl; }
     }
+    // parity-class conv dgrad: the live-tap count (hence K) depends on the class of the rows; the caller guarantees
+    // that a 64-row workgroup never mixes classes, so both are workgroup-uniform
+    K = al.klen(ast[0], K);
+    const int aux = al.aux(ast[0]);
     f4 ra[RA], rb[RB];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int p = 0; p < RA; ++p) ra[p] = (aok[p] && !(dbg & 4)) ? al.load(ast[p], k0 + ak[p], K) : zero4();
+        for (int p = 0; p < RA; ++p) ra[p] = aok[p] ? al.load(ast[p], k0 + ak[p], K) : zero4();
 #pragma unroll
         for (int p = 0; p < RB; ++p) {
             rb[p] = zero4();
-            if (bok[p] && !(dbg & 8)) {
-                if (!BL::kTrans) rb[p] = bl.load(nblk, bn[p] >> 4, bn[p] & 15, k0 + bk[p], K);
+            if (bok[p]) {
+                if (!BL::kTrans) rb[p] = bl.load(nblk, bn[p] >> 4, bn[p] & 15, k0 + bk[p], K, aux);
                 else rb[p] = bl.load_n4(nblk, bn[p], k0 + bk[p], K);
             }
         }
@@ -568,18 +572,14 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (NT == 4 ? 4 : 6) : 2) void gemm_l
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const f4 bv = *reinterpret_cast<const f4*>(pb + 16 * t * LD + 16 * c);
-                if (dbg & 2) acc[t] = acc[t] + av + bv;
-                else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[t] = mfma16(av[j], bv[j], acc[t]);
-                }
+                for (int j = 0; j < 4; ++j) acc[t] = mfma16(av[j], bv[j], acc[t]);
             }
         }
         if (NBUF > 1 && ch + 1 < nch) stash(buf ^ 1);
         if (NBUF > 1) __syncthreads();
     }
     const int row0 = brow0 + 16 * wave;
-    if (dbg & 1) { if (acc[0].x == 1.2345f) ep.template run<NT, BL>(acc, bl, row0, nblk, lane, M); return; }
     if (row0 < M) ep.template run<NT, BL>(acc, bl, row0, nblk, lane, M);
 }
 
@@ -604,8 +604,6 @@ static __global__ __launch_bounds__(256) void row_stats_kernel(const float* __re
     if (rok && i == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
 static inline int launch_row_stats(const float* x, long ld, float* stats, int M, int K, float eps, hipStream_t s) {
-    static const int dbg = getenv("LEOD_LDS_DBG") ? atoi(getenv("LEOD_LDS_DBG")) : 0;
-    if (dbg & 16) return LEOD_OK;
     hipLaunchKernelGGL(row_stats_kernel, dim3(cdiv(M, 16)), dim3(256), 0, s, x, ld, stats, M, K, eps);
     return leod_launch_status();
 }
@@ -613,11 +611,10 @@ static inline int launch_row_stats(const float* x, long ld, float* stats, int M,
 template <int NT, class AL, class BL, class EP>
 static inline int launch_gemm_lds(const AL& al, const BL& bl, const EP& ep, int M, int K, int nblocks_n, hipStream_t s) {
     dim3 grid(cdiv(M, 64), nblocks_n);
-    static const int dbg = getenv("LEOD_LDS_DBG") ? atoi(getenv("LEOD_LDS_DBG")) : 0;
-    if (K == 48) hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 1, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, dbg);
-    else if (K <= 64) hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 1, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, dbg);
-    else if (K % 48 == 0) hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 2, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, dbg);
-    else hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 2, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, dbg);
+    if (K == 48) hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 1, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+    else if (K <= 64) hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 1, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+    else if (K % 48 == 0) hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 2, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+    else hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 2, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
     return leod_launch_status();
 }
 // enough 64-row workgroups to fill the chip; smaller problems stay on the register-direct kernels (K-split)

@@ -45,12 +45,17 @@ LEOD_API int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bia
     EpStore ep = conv_epilogue(y, N, bias, colstats, bn_w, bn_b, bn_rm, bn_rv, bn_eps);
     const int nt = pick_nt(N);
     int rc = LEOD_OK;
+    const bool lds = use_gemm_lds(M, cdiv(N, 16 * nt));      // large M: coalesced LDS-staged operands
     if (ks == 1 && stride == 1 && pad == 0) {
         ALRows al{}; al.x = x; al.ld = Cin; al.K = Cin;
-        DISPATCH_NT(nt, { BLRows bl{w, (long)Cin, N, NT}; rc = launch_gemm16<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
+        DISPATCH_NT(nt, { BLRows bl{w, (long)Cin, N, NT};
+                          rc = lds ? launch_gemm_lds<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream)
+                                   : launch_gemm16<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
     } else {
         ALConvNHWC al{x, H, W, Cin, Ho, Wo, ks, stride, pad};
-        DISPATCH_NT(nt, { BLConvW bl{w, N, Cin, ks * ks, NT}; rc = launch_gemm16<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
+        DISPATCH_NT(nt, { BLConvW bl{w, N, Cin, ks * ks, NT};
+                          rc = lds ? launch_gemm_lds<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream)
+                                   : launch_gemm16<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
     }
     return rc;
 }
@@ -66,12 +71,17 @@ LEOD_API int leod_stem_conv_fwd(const void* x, int x_is_u8, const float* w, floa
     EpStore ep = conv_epilogue(y, N, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
     const int nt = pick_nt(N);
     int rc = LEOD_OK;
+    const bool lds = use_gemm_lds(M, cdiv(N, 16 * nt));
     if (x_is_u8) {
         ALStemNCHW<uint8_t> al{(const uint8_t*)x, Cin, H, W, Ho, Wo, ks, stride, pad};
-        DISPATCH_NT(nt, { BLRows bl{w, (long)K, N, NT}; rc = launch_gemm16<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
+        DISPATCH_NT(nt, { BLRows bl{w, (long)K, N, NT};
+                          rc = lds ? launch_gemm_lds<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream)
+                                   : launch_gemm16<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
     } else {
         ALStemNCHW<float> al{(const float*)x, Cin, H, W, Ho, Wo, ks, stride, pad};
-        DISPATCH_NT(nt, { BLRows bl{w, (long)K, N, NT}; rc = launch_gemm16<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
+        DISPATCH_NT(nt, { BLRows bl{w, (long)K, N, NT};
+                          rc = lds ? launch_gemm_lds<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream)
+                                   : launch_gemm16<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
     }
     return rc;
 }
@@ -90,15 +100,23 @@ LEOD_API int leod_conv_nhwc_dgrad(const float* dy, const float* w, float* dx, in
         // live-tap formulation: rows grouped by input parity class, 2.25 taps per pixel on average instead of 9
         ALConvT2 al{dy, H, W, Ho, Wo, N, Q};
         ep.rm_Q = Q; ep.rm_H = H; ep.rm_W = W;
-        DISPATCH_NT(nt, { BLConvWT2 bl{w, N, Cin, NT}; rc = launch_gemm16<NT>(al, bl, ep, M, 4 * N, cdiv(Cin, 16 * NT), stream); });
+        const bool lds2 = use_gemm_lds(M, cdiv(Cin, 16 * nt)) && Q % 64 == 0;     // a 64-row workgroup must not mix classes
+        DISPATCH_NT(nt, { BLConvWT2 bl{w, N, Cin, NT};
+                          rc = lds2 ? launch_gemm_lds<NT>(al, bl, ep, M, 4 * N, cdiv(Cin, 16 * NT), stream)
+                                    : launch_gemm16<NT>(al, bl, ep, M, 4 * N, cdiv(Cin, 16 * NT), stream); });
         return rc;
     }
+    const bool lds = use_gemm_lds(M, cdiv(Cin, 16 * nt));
     if (ks == 1 && stride == 1 && pad == 0) {
         ALRows al{}; al.x = dy; al.ld = N; al.K = N;
-        DISPATCH_NT(nt, { BLTrans bl{w, (long)Cin, Cin, NT}; rc = launch_gemm16<NT>(al, bl, ep, M, K, cdiv(Cin, 16 * NT), stream); });
+        DISPATCH_NT(nt, { BLTrans bl{w, (long)Cin, Cin, NT};
+                          rc = lds ? launch_gemm_lds<NT>(al, bl, ep, M, K, cdiv(Cin, 16 * NT), stream)
+                                   : launch_gemm16<NT>(al, bl, ep, M, K, cdiv(Cin, 16 * NT), stream); });
     } else {
         ALConvT al{dy, H, W, Ho, Wo, N, ks, stride, pad};
-        DISPATCH_NT(nt, { BLConvWT bl{w, N, Cin, ks * ks, NT}; rc = launch_gemm16<NT>(al, bl, ep, M, K, cdiv(Cin, 16 * NT), stream); });
+        DISPATCH_NT(nt, { BLConvWT bl{w, N, Cin, ks * ks, NT};
+                          rc = lds ? launch_gemm_lds<NT>(al, bl, ep, M, K, cdiv(Cin, 16 * NT), stream)
+                                   : launch_gemm16<NT>(al, bl, ep, M, K, cdiv(Cin, 16 * NT), stream); });
     }
     return rc;
 }
