@@ -499,7 +499,7 @@ static inline int launch_gemm16(const AL& al, const BL& bl, const EP& ep, int M,
 // slots), double-buffered through LDS, and read back in operand layout with conflict-free ds_read_b128.
 // =================================================================================================
 template <int NT, int KCH, int NBUF, class AL, class BL, class EP>
-__global__ __launch_bounds__(256, NBUF == 1 ? (NT == 4 ? 4 : 6) : 2) void gemm_lds_kernel(AL al, BL bl, EP ep, int M, int K) {
+__global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_lds_kernel(AL al, BL bl, EP ep, int M, int K) {
     constexpr int LD = KCH + 4;                      // 16-lane b128 reads of rows i=0..15 hit banks 4i..4i+3: conflict-free
     constexpr int K4 = KCH / 4;                      // float4 slots per staged row
     constexpr int BN = NT * 16;
@@ -563,7 +563,8 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (NT == 4 ? 4 : 6) : 2) void gemm_l
     const int aoff = (16 * wave + i) * LD + 4 * q, boff = i * LD + 4 * q;
     for (int ch = 0; ch < nch; ++ch) {
         const int buf = NBUF == 1 ? 0 : (ch & 1);
-        if (NBUF > 1 && ch + 1 < nch) fetch((ch + 1) * KCH);              // next chunk's global loads fly under this chunk's MFMAs
+        const bool more = ch + 1 < nch;
+        if (more) fetch((ch + 1) * KCH);                      // next chunk's global loads fly under this chunk's MFMAs
         const float* __restrict__ pa = sA[buf] + aoff;
         const float* __restrict__ pb = sB[buf] + boff;
 #pragma unroll
@@ -576,8 +577,14 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (NT == 4 ? 4 : 6) : 2) void gemm_l
                 for (int j = 0; j < 4; ++j) acc[t] = mfma16(av[j], bv[j], acc[t]);
             }
         }
-        if (NBUF > 1 && ch + 1 < nch) stash(buf ^ 1);
-        if (NBUF > 1) __syncthreads();
+        if (NBUF > 1) {
+            if (more) stash(buf ^ 1);
+            __syncthreads();
+        } else if (more) {                                    // single LDS buffer (half the LDS -> twice the resident
+            __syncthreads();                                  // workgroups): everyone done reading, then refill
+            stash(0);
+            __syncthreads();
+        }
     }
     const int row0 = brow0 + 16 * wave;
     if (row0 < M) ep.template run<NT, BL>(acc, bl, row0, nblk, lane, M);
@@ -611,10 +618,16 @@ static inline int launch_row_stats(const float* x, long ld, float* stats, int M,
 template <int NT, class AL, class BL, class EP>
 static inline int launch_gemm_lds(const AL& al, const BL& bl, const EP& ep, int M, int K, int nblocks_n, hipStream_t s) {
     dim3 grid(cdiv(M, 64), nblocks_n);
-    if (K == 48) hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 1, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
-    else if (K <= 64) hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 1, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
-    else if (K % 48 == 0) hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 2, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
-    else hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 2, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+    // single LDS buffer + register prefetch everywhere: residency (4-6 workgroups per CU) hides the two barriers per chunk
+    // better than a double buffer at 2-3 workgroups per CU does (measured; LEOD_LDS_NBUF=2 selects the double buffer)
+    static const int nbuf = getenv("LEOD_LDS_NBUF") ? atoi(getenv("LEOD_LDS_NBUF")) : 1;
+    if (K % 48 == 0) {
+        if (nbuf == 1 || K == 48) hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 1, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+        else hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 2, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+    } else {
+        if (nbuf == 1 || K <= 64) hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 1, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+        else hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 2, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+    }
     return leod_launch_status();
 }
 // enough 64-row workgroups to fill the chip; smaller problems stay on the register-direct kernels (K-split)
@@ -912,4 +925,165 @@ static inline int launch_wgrad16(const float* dy, long lddy, const XL& xl, float
     static const int dbg = getenv("LEOD_WGRAD_DBG") ? atoi(getenv("LEOD_WGRAD_DBG")) : 0;   // ablation switches (profiling only)
     hipLaunchKernelGGL((wgrad16_kernel<TN, TK, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, rpb, dbg);
     return leod_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-tiled wgrad for the time-batched schedule (M = T*B*H*W rows: hundreds of thousands).  Same staging as above
+// (coalesced 16-byte loads, transposed LDS, double buffer), but
+//   * the workgroup tile is (TN x TK) MFMA tiles chosen per layer shape so that dY / X are streamed (almost) once:
+//     192x48, 48x192, 96x96 or 48x48 outputs,
+//   * each wave owns a contiguous WA x WB block of tiles and keeps its operand fragments in registers across the block:
+//     WA + WB ds_read_b128 feed 4*WA*WB MFMAs (3x3: 6 reads per 36 MFMAs; the round-robin kernel above needs 18),
+//   * waves left over after tiling the output (48x48) split the 16-row steps of a chunk (MS-way) instead.
+// dW accumulates with one fp32 atomic per element and workgroup, dbias from the staged dY values as before.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TN, int TK, int WA, int WB, int RC, class XL>
+__global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict__ dy, long lddy, XL xl, float* dW, long ldw,
+                                                     float* dbias, int M, int N, int K, int chunks_per_block) {
+    constexpr int NWN = TN / WA, NWK = TK / WB, MS = 4 / (NWN * NWK);      // wave grid over the tile, row-step split
+    static_assert(TN % WA == 0 && TK % WB == 0 && NWN * NWK * MS == 4, "4 waves must tile the workgroup");
+    constexpr int STEPS = RC / 16;
+    static_assert(STEPS % MS == 0, "row steps must split evenly over the waves");
+    constexpr int LDR = RC + 4;
+    constexpr int C4N = TN * 4, C4K = TK * 4;
+    constexpr int NV = C4N * RC, KV = C4K * RC;
+    constexpr int RN = (NV + 255) / 256, RK = (KV + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float sdy[2][16 * TN * LDR];
+    __shared__ __attribute__((aligned(16))) float sx[2][16 * TK * LDR];
+    __shared__ float sbias[16 * TN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int wa = wave % NWN, wb = (wave / NWN) % NWK, ws = wave / (NWN * NWK);
+    const int n0 = blockIdx.y * TN * 16, k0 = blockIdx.z * TK * 16;
+    // chunk c of this workgroup covers rows (blockIdx.x + c * gridDim.x) * RC ..: at any moment the resident workgroups
+    // stream ONE contiguous window of dY / X (DRAM-page and TLB friendly) instead of gridDim.x far-apart row ranges
+    const int mbeg = blockIdx.x * RC;
+    const long mstride = (long)gridDim.x * RC;
+    const int mend = M;
+    const bool do_bias = dbias != nullptr && blockIdx.z == 0;
+    int nr[RN], kr[RK], nl[RN], kl[RK], kc[RK];
+    long noff[RN];
+    const float* __restrict__ dyb = dy;
+    bool nok[RN], kok[RK];
+#pragma unroll
+    for (int e = 0; e < RN; ++e) {
+        const int s = tid + 256 * e, r = s / C4N, c = (s - r * C4N) * 4;
+        nr[e] = r; nl[e] = c * LDR + r; nok[e] = s < NV && n0 + c < N;
+        noff[e] = (long)r * lddy + n0 + c;
+    }
+#pragma unroll
+    for (int e = 0; e < RK; ++e) {
+        const int s = tid + 256 * e, r = s / C4K, c = (s - r * C4K) * 4;
+        kr[e] = r; kl[e] = c * LDR + r; kc[e] = k0 + c; kok[e] = s < KV && k0 + c < K;
+    }
+    const int offA = (16 * wa * WA + i) * LDR + 4 * q, offB = (16 * wb * WB + i) * LDR + 4 * q;
+    f4 acc[WA][WB], bacc[RN];
+#pragma unroll
+    for (int a = 0; a < WA; ++a)
+#pragma unroll
+        for (int b = 0; b < WB; ++b) acc[a][b] = zero4();
+#pragma unroll
+    for (int e = 0; e < RN; ++e) bacc[e] = zero4();
+    if (tid < 16 * TN) sbias[tid] = 0.f;
+    f4 rn[RN], rk[RK];
+    auto fetch = [&](long m0) {
+#pragma unroll
+        for (int e = 0; e < RN; ++e) rn[e] = (nok[e] && m0 + nr[e] < mend) ? ld4(dyb + (m0 * lddy + noff[e])) : zero4();
+#pragma unroll
+        for (int e = 0; e < RK; ++e) rk[e] = (kok[e] && m0 + kr[e] < mend) ? xl.get4((int)m0 + kr[e], kc[e]) : zero4();
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < RN; ++e) {
+            if (tid + 256 * e < NV) {
+                float* d = &sdy[buf][nl[e]];
+                d[0] = rn[e].x; d[LDR] = rn[e].y; d[2 * LDR] = rn[e].z; d[3 * LDR] = rn[e].w;
+            }
+            bacc[e] += rn[e];
+        }
+#pragma unroll
+        for (int e = 0; e < RK; ++e)
+            if (tid + 256 * e < KV) {
+                float* d = &sx[buf][kl[e]];
+                d[0] = rk[e].x; d[LDR] = rk[e].y; d[2 * LDR] = rk[e].z; d[3 * LDR] = rk[e].w;
+            }
+    };
+    int buf = 0;
+    fetch(mbeg);
+    stash(0);
+    __syncthreads();
+    for (long m0 = mbeg; m0 < mend; m0 += mstride) {
+        const bool more = m0 + mstride < mend;
+        if (more) fetch(m0 + mstride);                      // next chunk's global loads fly under this chunk's MFMAs
+        const float* __restrict__ pdy = sdy[buf] + offA;
+        const float* __restrict__ px = sx[buf] + offB;
+#pragma unroll
+        for (int st = ws; st < STEPS; st += MS) {
+            f4 av[WA], bv[WB];
+#pragma unroll
+            for (int a = 0; a < WA; ++a) av[a] = *reinterpret_cast<const f4*>(pdy + 16 * a * LDR + 16 * st);
+#pragma unroll
+            for (int b = 0; b < WB; ++b) bv[b] = *reinterpret_cast<const f4*>(px + 16 * b * LDR + 16 * st);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < WA; ++a)
+#pragma unroll
+                    for (int b = 0; b < WB; ++b) acc[a][b] = mfma16(av[a][j], bv[b][j], acc[a][b]);
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int a = 0; a < WA; ++a)
+#pragma unroll
+        for (int b = 0; b < WB; ++b) {
+            const int k = k0 + 16 * (wb * WB + b) + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 16 * (wa * WA + a) + 4 * q + r;
+                if (n < N && k < K) atomicAdd(dW + xl.waddr(n, k, ldw), acc[a][b][r]);
+            }
+        }
+    if (do_bias) {
+#pragma unroll
+        for (int e = 0; e < RN; ++e)
+            if (tid + 256 * e < NV) {
+                const int c = (nl[e] - nr[e]) / LDR;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(&sbias[c + j], bacc[e][j]);
+            }
+        __syncthreads();
+        if (tid < 16 * TN && n0 + tid < N) atomicAdd(dbias + n0 + tid, sbias[tid]);
+    }
+}
+
+template <int TN, int TK, int WA, int WB, int RC, class XL>
+static inline int launch_wgradw_cfg(const float* dy, long lddy, const XL& xl, float* dW, long ldw, float* dbias,
+                                    int M, int N, int K, hipStream_t s) {
+    const int tiles = cdiv(N, TN * 16) * cdiv(K, TK * 16);
+    static const int tune_blocks = getenv("LEOD_WGRADW_BLOCKS") ? atoi(getenv("LEOD_WGRADW_BLOCKS")) : 1024;   // 4 workgroups per CU resident
+    const int chunks = cdiv(M, RC);
+    const int gx = max(1, min(chunks / 4, tune_blocks / tiles));      // >= 4 chunks per workgroup: one atomic per dW element each
+    dim3 grid(gx, cdiv(N, TN * 16), cdiv(K, TK * 16));
+    hipLaunchKernelGGL((wgradw_kernel<TN, TK, WA, WB, RC, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, cdiv(chunks, gx));
+    return leod_launch_status();
+}
+
+// shape-driven choice of the workgroup tile (see the kernel header)
+template <class XL>
+static inline int launch_wgradw(const float* dy, long lddy, const XL& xl, float* dW, long ldw, float* dbias,
+                                int M, int N, int K, hipStream_t s) {
+    if (M <= 0) return LEOD_OK;
+    if ((N & 3) || (K & 3) || (lddy & 3)) return LEOD_ERR_ARG;      // 16-byte row loads
+    if (K <= 48 && N <= 48) return launch_wgradw_cfg<3, 3, 3, 3, 64>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s);
+    if (K <= 48) return launch_wgradw_cfg<12, 3, 3, 3, 16>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s);
+    if (N <= 48) return launch_wgradw_cfg<3, 12, 3, 3, 16>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s);
+    return launch_wgradw_cfg<6, 6, 3, 3, 16>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s);
+}
+// large row counts only: small problems keep the round-robin kernel (more workgroups per output tile)
+static inline bool use_wgradw(int M) {
+    static const int mode = getenv("LEOD_WGRADW") ? atoi(getenv("LEOD_WGRADW")) : 1;
+    return mode != 0 && M >= 8192;
 }

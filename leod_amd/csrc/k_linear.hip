@@ -135,6 +135,7 @@ LEOD_API int leod_linear_wgrad(const float* dy, long lddy, const float* x, long 
                                float* dW, float* dbias, int M, int N, int K, hipStream_t stream) {
     if (!dy || !x || !dW) return LEOD_ERR_ARG;
     XRows xl{x, ldx, stats, ln_w, ln_b, x2, ldx2, K1};
+    if (use_wgradw(M)) return launch_wgradw(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);
     if (N % 48 == 0 && K % 48 == 0) return launch_wgrad16<3, 3>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);
     if (N % 32 == 0 && K % 32 == 0 && (N % 64 || K % 64)) return launch_wgrad16<2, 2>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);
     if (N >= 64 && K >= 64) return launch_wgrad16<4, 4>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);

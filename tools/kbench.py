@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Per-op micro-benchmark at the RVT-S / Gen1 / bs 8 shapes of one timestep (GPU box): prints us, GB/s (algorithmic
-bytes) and TFLOP/s per op and stage.  usage: python tools/kbench.py [filter]"""
+"""Per-op micro-benchmark at the RVT-S / Gen1 / bs 8 shapes (GPU box): prints us, GB/s (algorithmic bytes) and TFLOP/s
+per op and stage.  KBENCH_T=21 (default) = the time-batched shapes of the training step (T*B samples per launch),
+KBENCH_T=1 = one timestep.  usage: python tools/kbench.py [filter[,filter..]]"""
 import os
 import sys
 
@@ -10,10 +11,11 @@ sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..')
 from leod_amd import ops  # noqa: E402
 
 DEV = 'cuda'
-STAGES = [(40960, 48, 2, 64, 80), (10240, 96, 4, 32, 40), (2560, 192, 8, 16, 20), (640, 384, 16, 8, 10)]
+TB = int(os.environ.get('KBENCH_T', '21'))
+STAGES = [(40960 * TB, 48, 2, 64, 80), (10240 * TB, 96, 4, 32, 40), (2560 * TB, 192, 8, 16, 20), (640 * TB, 384, 16, 8, 10)]
 
 
-def timeit(fn, n=20):
+def timeit(fn, n=int(os.environ.get('KBENCH_N', '6'))):
     if os.environ.get("KBENCH_EAGER"):
         for _ in range(3):
             fn()
@@ -47,7 +49,7 @@ def main():
     r = lambda *s: torch.randn(*s, device=DEV)  # noqa
     rows = []
     for si, (M, C, heads, H, W) in enumerate(STAGES):
-        B = 8
+        B = 8 * TB
         x, lw, lb = r(M, C), r(C), r(C)
         Wqkv, bqkv, Wp, bp, g = r(3 * C, C) * .1, r(3 * C), r(C, C) * .1, r(C), r(C)
         W1, b1, W2, b2 = r(4 * C, C) * .1, r(4 * C), r(C, 4 * C) * .1, r(C)
