@@ -49,12 +49,28 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Transcendentals of the hot epilogues.  The exact-GELU layers evaluate erf on 4C channels of every token in both
+// passes, which made libm's erff/expf a first-order VALU cost of the memory-bound MLP kernels.  These use the hardware
+// v_exp_f32 / v_rcp_f32 (1 ulp) and the Abramowitz-Stegun 7.1.26 rational form of the normal CDF (|error| <= 1.5e-7
+// absolute, the size of one fp32 rounding of the reference's own 0.5*(1+erf(x/sqrt2)) evaluation).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
+// Phi(x) = 0.5*(1+erf(x/sqrt2)); e_out = exp(-x*x/2) (shared with the Gaussian pdf of the GELU derivative)
+__device__ __forceinline__ float normal_cdf(float x, float& e_out) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = fast_rcp(fmaf(0.3275911f, z, 1.0f));
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = fast_exp(-z * z);
+    e_out = e;
+    const float half_tail = 0.5f * poly * e;                 // = 0.5*erfc(|x|/sqrt2)
+    return x >= 0.f ? 1.0f - half_tail : half_tail;
+}
+__device__ __forceinline__ float gelu_erf(float x) { float e; return x * normal_cdf(x, e); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float e;
+    const float cdf = normal_cdf(x, e);
+    return fmaf(x * 0.39894228040143267794f, e, cdf);
 }
 __device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
 __device__ __forceinline__ float silu_grad(float x) {

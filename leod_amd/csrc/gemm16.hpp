@@ -331,6 +331,70 @@ struct EpStore {
             }
         }
     }
+    // Row-layout epilogue of the LDS-staged GEMM: the wave's 16 x (NT*16) accumulator tile has been transposed through
+    // LDS (so[row][col], leading dimension ldo), lane (c4 = lane & 15, q = lane >> 4) owns columns 4*c4..4*c4+3 of rows
+    // q, q+4, q+8, q+12 -> every global access is a 16-byte access and a wave instruction covers whole row segments
+    // (NT*64 contiguous bytes per row) instead of 64-byte column slivers of 4-byte stores.
+    static constexpr bool kRowEpilogue = true;
+    template <int NT, class BL>
+    __device__ __forceinline__ void run_rows(const float* so, int ldo, const BL& bl, int row0, int nblk, int lane, int M) const {
+        const int c4 = lane & 15, q = lane >> 4;
+        const int n = bl.col(nblk, 0, 0) + 4 * c4;
+        const bool nok = c4 < NT * 4 && n < N;
+        f4 bv = zero4(), sc = {1.f, 1.f, 1.f, 1.f}, sh = zero4();
+        if (nok) {
+            if (bias) bv = ld4(bias + n);
+            if (act == ACT_AFFINE_SILU) {
+                const f4 w = ld4(bn_w + n), b = ld4(bn_b + n), rm = ld4(bn_rm + n), rv = ld4(bn_rv + n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { sc[j] = w[j] * rsqrtf(rv[j] + bn_eps); sh[j] = b[j] - rm[j] * sc[j]; }
+            }
+        }
+        f4 s1 = zero4(), s2 = zero4();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int lr = q + 4 * p, grow = row0 + lr;
+            if (!nok || grow >= M) continue;
+            f4 v = *reinterpret_cast<const f4*>(so + lr * ldo + 4 * c4) + bv;
+            const long row = maprow(grow);
+            if (act == ACT_AFFINE_SILU) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = siluf_(v[j] * sc[j] + sh[j]);
+            }
+            if (act == ACT_MUL_GELU_GRAD) {
+                const f4 u = ld4(aux + row * ldaux + n);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(u[j]);
+            }
+            if (nsplit > 0 && n >= nsplit) {
+                float* pp = out2 + row * ld2 + (n - nsplit);
+                if (accumulate) v += ld4(pp);
+                *reinterpret_cast<f4*>(pp) = v;
+            } else {
+                float* pp = out + row * ld + n;
+                if (accumulate) v += ld4(pp);
+                *reinterpret_cast<f4*>(pp) = v;
+                if (act == ACT_GELU_DUAL) {
+                    f4 g;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j] = gelu_erf(v[j]);
+                    *reinterpret_cast<f4*>(out2 + row * ld2 + n) = g;
+                }
+            }
+            s1 += v; s2 += v * v;
+        }
+        if (colstats || colsum) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = quad16_sum(s1[j]);
+                const float b = colstats ? quad16_sum(s2[j]) : 0.f;
+                if (q == 0 && nok) {
+                    if (colstats) { atomicAdd(colstats + n + j, (double)a); atomicAdd(colstats + N + n + j, (double)b); }
+                    if (colsum) atomicAdd(colsum + n + j, a);
+                }
+            }
+        }
+    }
 };
 
 struct EpLsRes {                    // t = acc + bias; tout = t; out = res + gamma * t   (LayerScale + residual)
@@ -354,9 +418,28 @@ struct EpLsRes {                    // t = acc + bias; tout = t; out = res + gam
             }
         }
     }
+    static constexpr bool kRowEpilogue = true;
+    template <int NT, class BL>
+    __device__ __forceinline__ void run_rows(const float* so, int ldo, const BL& bl, int row0, int nblk, int lane, int M) const {
+        const int c4 = lane & 15, q = lane >> 4;
+        const int n = bl.col(nblk, 0, 0) + 4 * c4;
+        if (c4 >= NT * 4 || n >= N) return;
+        const f4 bv = bias ? ld4(bias + n) : zero4();
+        const f4 g = gamma ? ld4(gamma + n) : f4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int lr = q + 4 * p, row = row0 + lr;
+            if (row >= M) continue;
+            const long o = (long)row * ld + n;
+            const f4 tv = *reinterpret_cast<const f4*>(so + lr * ldo + 4 * c4) + bv;
+            if (tout) *reinterpret_cast<f4*>(tout + o) = tv;
+            *reinterpret_cast<f4*>(out + o) = ld4(res + o) + g * tv;
+        }
+    }
 };
 
 struct EpLstm {                     // NT must be 4: tiles = (f, i, o, g) of channels nblk*16 + lane&15
+    static constexpr bool kRowEpilogue = false;
     const float* bias; const float* c_prev; float* h_out; float* c_out; float* gates_out;  // gates_out [M][4][C] post-activation (optional)
     int C;
     template <int NT, class BL>
@@ -499,16 +582,26 @@ static inline int launch_gemm16(const AL& al, const BL& bl, const EP& ep, int M,
 // slots), double-buffered through LDS, and read back in operand layout with conflict-free ds_read_b128.
 // =================================================================================================
 template <int NT, int KCH, int NBUF, class AL, class BL, class EP>
-__global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_lds_kernel(AL al, BL bl, EP ep, int M, int K) {
+__global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_lds_kernel(AL al, BL bl, EP ep, int M, int K, int nblocks_n) {
     constexpr int LD = KCH + 4;                      // 16-lane b128 reads of rows i=0..15 hit banks 4i..4i+3: conflict-free
     constexpr int K4 = KCH / 4;                      // float4 slots per staged row
     constexpr int BN = NT * 16;
     constexpr int RA = (64 * K4 + 255) / 256, RB = (BN * K4 + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float sA[NBUF][64 * LD];     // NBUF == 1: K fits one chunk, no pipeline -> half the LDS, 6 workgroups/CU
-    __shared__ __attribute__((aligned(16))) float sB[NBUF][BN * LD];
+    constexpr int LDO = BN + 4;                      // accumulator transposition tile of the row-layout epilogue (aliases A/B)
+    static_assert((64 + BN) * LD >= 64 * LDO, "epilogue tile must fit in the operand buffers");
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * (64 + BN) * LD];
+    float (*sA)[64 * LD] = reinterpret_cast<float (*)[64 * LD]>(smem);
+    float (*sB)[BN * LD] = reinterpret_cast<float (*)[BN * LD]>(smem + NBUF * 64 * LD);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int brow0 = blockIdx.x * 64, nblk = blockIdx.y;
+    // XCD-aware 1-D grid: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2).  All n-blocks of
+    // one 64-row block get ids with the same (id % 8) and adjacent dispatch slots, so the A tile is re-read from that XCD's
+    // L2 and the pieces of an output row are written close together (merged into full lines in L2).
+    const int per = 8 * nblocks_n;
+    const int grp = blockIdx.x / per, rem = blockIdx.x - grp * per;
+    const int nblk = rem >> 3;
+    const int brow0 = (grp * 8 + (rem & 7)) * 64;
+    if (brow0 >= M) return;                          // workgroup-uniform (padding of the last group)
     // ---- fixed staging slots of this thread ------------------------------------------------------------------------
     typename AL::St ast[RA];
     int ak[RA], al_off[RA]; bool aok[RA];
@@ -587,7 +680,18 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_lds_kernel(AL al,
         }
     }
     const int row0 = brow0 + 16 * wave;
-    if (row0 < M) ep.template run<NT, BL>(acc, bl, row0, nblk, lane, M);
+    if constexpr (EP::kRowEpilogue) {
+        __syncthreads();                                      // every wave is done with the operand buffers
+        float* so = smem + wave * 16 * LDO;                   // wave-private 16 x BN tile
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) so[(4 * q + r) * LDO + 16 * t + i] = acc[t][r];
+        __syncthreads();
+        if (row0 < M) ep.template run_rows<NT, BL>(so, LDO, bl, row0, nblk, lane, M);
+    } else {
+        if (row0 < M) ep.template run<NT, BL>(acc, bl, row0, nblk, lane, M);
+    }
 }
 
 // (mean, rstd) of every row of x[M,K] -> stats[M,2]; 16 lanes per row, fully coalesced (the LN prologue of the
@@ -617,16 +721,16 @@ static inline int launch_row_stats(const float* x, long ld, float* stats, int M,
 
 template <int NT, class AL, class BL, class EP>
 static inline int launch_gemm_lds(const AL& al, const BL& bl, const EP& ep, int M, int K, int nblocks_n, hipStream_t s) {
-    dim3 grid(cdiv(M, 64), nblocks_n);
+    dim3 grid(cdiv(cdiv(M, 64), 8) * 8 * nblocks_n);
     // single LDS buffer + register prefetch everywhere: residency (4-6 workgroups per CU) hides the two barriers per chunk
     // better than a double buffer at 2-3 workgroups per CU does (measured; LEOD_LDS_NBUF=2 selects the double buffer)
     static const int nbuf = getenv("LEOD_LDS_NBUF") ? atoi(getenv("LEOD_LDS_NBUF")) : 1;
     if (K % 48 == 0) {
-        if (nbuf == 1 || K == 48) hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 1, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
-        else hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 2, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+        if (nbuf == 1 || K == 48) hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 1, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
+        else hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 2, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
     } else {
-        if (nbuf == 1 || K <= 64) hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 1, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
-        else hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 2, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+        if (nbuf == 1 || K <= 64) hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 1, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
+        else hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 2, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
     }
     return leod_launch_status();
 }
