@@ -459,10 +459,10 @@ _PROBE = None
 class KernelProbe:
     """Brackets every launch of ONE kernel family with HIP events on the launch stream (torch's current stream is
     the stream every leod_* call is enqueued on) and tallies its algorithmic bytes:
-    achieved GB/s = sum(bytes) / sum(event time).  Default target: the weight-gradient GEMM ``wgrad16_kernel`` behind
-    ``linear_wgrad`` (the dominant kernel of the training step, see profiles/)."""
+    achieved GB/s = sum(bytes) / sum(event time).  Default target: the weight-gradient GEMM ``wgradw_kernel`` behind
+    ``linear_wgrad`` (the largest single kernel family of the training step, see profiles/)."""
 
-    def __init__(self, target: str = 'linear_wgrad', kernel_name: str = 'wgrad16_kernel<.., XRows>'):
+    def __init__(self, target: str = 'linear_wgrad', kernel_name: str = 'wgradw_kernel<.., XRows>'):
         global _PROBE
         self.target, self.kernel_name = target, kernel_name
         self.events, self.bytes = [], 0.0
