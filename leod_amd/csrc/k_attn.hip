@@ -308,6 +308,300 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
     }
 }
 
+// =====================================================================================================================
+// LDS-staged variants (default).  One workgroup = (partition, group of HG heads), one wave = (head, 16-token tile).
+// The qkv rows of the partition (per token HG*3d contiguous floats: head h owns columns [3dh, 3d(h+1)) = q|k|v) are
+// fetched ONCE with coalesced 16-byte loads into LDS [token][HG*3d + 4]; every MFMA operand then comes from LDS:
+//   A/B fragments along the head dim : one ds_read_b128 per lane (row stride == 4 mod 16 floats: conflict-free),
+//   B fragments along the token dim  : ds_read_b32 (key rows 4q+r land in distinct 16-bank groups).
+// The register-direct kernels above re-read K/V of a partition from global memory in every one of its PT waves and in
+// operand layout (16 rows x 64 B per instruction, 4-byte V loads); they stay as the LEOD_ATTN_LDS=0 reference.
+// Outputs go back through LDS so that a wave instruction stores whole per-token segments (O: d floats per head,
+// dqkv: the full 3d*HG segment with dq, dk, dv of both passes of the fused backward).
+// =====================================================================================================================
+__device__ __forceinline__ long token_row(const AttnGeom& g, int p, int t) {
+    const int nH = g.H / g.ph, nW = g.W / g.pw, per = nH * nW;
+    if (t >= g.ph * g.pw) return -1;
+    const int b = p / per, rem = p - b * per;
+    const int py = rem / nW, px = rem - py * nW;
+    const int ty = t / g.pw, tx = t - ty * g.pw;
+    return g.window ? ((long)b * g.H + (long)py * g.ph + ty) * g.W + (long)px * g.pw + tx
+                    : ((long)b * g.H + py + (long)ty * nH) * g.W + px + (long)tx * nW;
+}
+__device__ __forceinline__ f4 lds4(const float* p, bool ok) { return ok ? *reinterpret_cast<const f4*>(p) : zero4(); }
+
+template <int PT, int DCH, int HG>
+__global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                      float* __restrict__ lse, AttnGeom g, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NTHR = 64 * PT * HG, TOK = 16 * PT;
+    __shared__ long srow[TOK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, rg = lane >> 4;
+    const int hl = wave / PT, qt = wave - hl * PT;
+    const int ngrp = g.heads / HG;
+    const int p = blockIdx.x / ngrp, h0 = (blockIdx.x - p * ngrp) * HG;
+    const int P = g.ph * g.pw, d = g.d;
+    const long ld = 3L * g.C;
+    const int S = HG * 3 * d + 4, F = HG * 3 * d / 4;
+    if (tid < TOK) srow[tid] = token_row(g, p, tid);
+    __syncthreads();
+    for (int e = tid; e < TOK * F; e += NTHR) {
+        const int tok = e / F, f = e - tok * F;
+        const long row = srow[tok];
+        *reinterpret_cast<f4*>(smem + tok * S + 4 * f) = row >= 0 ? ld4(qkv + row * ld + h0 * 3 * d + 4 * f) : zero4();
+    }
+    __syncthreads();
+    const float* hb = smem + hl * 3 * d;                     // this wave's head inside a staged token row
+    const bool qvalid = 16 * qt + i < P;
+    f4 qf[DCH];
+#pragma unroll
+    for (int ch = 0; ch < DCH; ++ch) qf[ch] = lds4(hb + (16 * qt + i) * S + 16 * ch + 4 * rg, 16 * ch + 4 * rg < d);
+    f4 s[PT];
+#pragma unroll
+    for (int mt = 0; mt < PT; ++mt) {
+        s[mt] = zero4();
+#pragma unroll
+        for (int ch = 0; ch < DCH; ++ch) {
+            const f4 kf = lds4(hb + (16 * mt + i) * S + d + 16 * ch + 4 * rg, 16 * ch + 4 * rg < d);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[mt] = mfma16(kf[j], qf[ch][j], s[mt]);
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int mt = 0; mt < PT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * mt + 4 * rg + r;
+            const float v = key < P ? s[mt][r] * scale : -INFINITY;
+            s[mt][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = quad16_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < PT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = fast_exp(s[mt][r] - mx);          // v_exp_f32; exp(-inf) = 0 for padded keys
+            s[mt][r] = e;
+            sum += e;
+        }
+    sum = quad16_sum(sum);
+    const float inv = 1.0f / sum;
+    if (lse && rg == 0 && qvalid) lse[srow[16 * qt + i] * g.heads + h0 + hl] = mx + logf(sum);
+    f4 o[DCH];
+#pragma unroll
+    for (int ct = 0; ct < DCH; ++ct) o[ct] = zero4();
+#pragma unroll
+    for (int mt = 0; mt < PT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* vrow = hb + (16 * mt + 4 * rg + r) * S + 2 * d;
+#pragma unroll
+            for (int ct = 0; ct < DCH; ++ct) {
+                const float vv = 16 * ct + i < d ? vrow[16 * ct + i] : 0.f;
+                o[ct] = mfma16(s[mt][r] * inv, vv, o[ct]);
+            }
+        }
+    // O tile -> this wave's own q slots (nobody else reads them) -> per-token d-float segments
+    float* ob = smem + hl * 3 * d + (16 * qt) * S;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ct = 0; ct < DCH; ++ct)
+            if (16 * ct + i < d) ob[(4 * rg + r) * S + 16 * ct + i] = o[ct][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int d4 = d / 4;
+    for (int e = lane; e < 16 * d4; e += 64) {
+        const int tok = e / d4, c4 = e - tok * d4;
+        const long row = srow[16 * qt + tok];
+        if (row >= 0) *reinterpret_cast<f4*>(out + row * g.C + (h0 + hl) * d + 4 * c4) = *reinterpret_cast<const f4*>(ob + tok * S + 4 * c4);
+    }
+}
+
+// fused backward: phase 1 = query-owned (dQ, D), phase 2 = key-owned (dK, dV), then one coalesced store of the whole
+// [dq | dk | dv] segment of every token.  Probabilities are recomputed from lse in both phases.
+template <int PT, int DCH, int HG>
+__global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                      const float* __restrict__ lse, float* __restrict__ dqkv,
+                                                                      AttnGeom g, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NTHR = 64 * PT * HG, TOK = 16 * PT;
+    __shared__ long srow[TOK];
+    __shared__ float sL[HG * TOK], sD[HG * TOK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, rg = lane >> 4;
+    const int hl = wave / PT, qt = wave - hl * PT;            // also the key tile of phase 2
+    const int ngrp = g.heads / HG;
+    const int p = blockIdx.x / ngrp, h0 = (blockIdx.x - p * ngrp) * HG;
+    const int P = g.ph * g.pw, d = g.d;
+    const long ld = 3L * g.C;
+    const int S = HG * 3 * d + 4, F = HG * 3 * d / 4;
+    const int Sd = HG * d + 4, Fd = HG * d / 4;
+    float* sdo = smem + TOK * S;
+    if (tid < TOK) srow[tid] = token_row(g, p, tid);
+    __syncthreads();
+    for (int e = tid; e < TOK * F; e += NTHR) {
+        const int tok = e / F, f = e - tok * F;
+        const long row = srow[tok];
+        *reinterpret_cast<f4*>(smem + tok * S + 4 * f) = row >= 0 ? ld4(qkv + row * ld + h0 * 3 * d + 4 * f) : zero4();
+    }
+    for (int e = tid; e < TOK * Fd; e += NTHR) {
+        const int tok = e / Fd, f = e - tok * Fd;
+        const long row = srow[tok];
+        *reinterpret_cast<f4*>(sdo + tok * Sd + 4 * f) = row >= 0 ? ld4(dout + row * g.C + h0 * d + 4 * f) : zero4();
+    }
+    for (int e = tid; e < HG * TOK; e += NTHR) {
+        const int hh = e / TOK, tok = e - hh * TOK;
+        const long row = srow[tok];
+        sL[e] = row >= 0 ? lse[row * g.heads + h0 + hh] : 0.f;
+    }
+    __syncthreads();
+    const float* hb = smem + hl * 3 * d;
+    const float* db = sdo + hl * d;
+    // ---- phase 1: dQ and D of query tile qt ------------------------------------------------------------------------------
+    f4 dq[DCH];
+    {
+        const bool qvalid = 16 * qt + i < P;
+        f4 qf[DCH], dof[DCH];
+#pragma unroll
+        for (int ch = 0; ch < DCH; ++ch) {
+            const bool ok = 16 * ch + 4 * rg < d;
+            qf[ch] = lds4(hb + (16 * qt + i) * S + 16 * ch + 4 * rg, ok);
+            dof[ch] = lds4(db + (16 * qt + i) * Sd + 16 * ch + 4 * rg, ok);
+        }
+        const float l = sL[hl * TOK + 16 * qt + i];
+        f4 s[PT], dp[PT];
+#pragma unroll
+        for (int mt = 0; mt < PT; ++mt) {
+            s[mt] = zero4(); dp[mt] = zero4();
+#pragma unroll
+            for (int ch = 0; ch < DCH; ++ch) {
+                const bool ok = 16 * ch + 4 * rg < d;
+                const f4 kf = lds4(hb + (16 * mt + i) * S + d + 16 * ch + 4 * rg, ok);
+                const f4 vf = lds4(hb + (16 * mt + i) * S + 2 * d + 16 * ch + 4 * rg, ok);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s[mt] = mfma16(kf[j], qf[ch][j], s[mt]);
+                    dp[mt] = mfma16(vf[j], dof[ch][j], dp[mt]);
+                }
+            }
+        }
+        float D = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < PT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * mt + 4 * rg + r;
+                const float pr = (key < P && qvalid) ? fast_exp(s[mt][r] * scale - l) : 0.f;
+                s[mt][r] = pr;
+                D += pr * dp[mt][r];
+            }
+        D = quad16_sum(D);
+        if (rg == 0) sD[hl * TOK + 16 * qt + i] = D;
+#pragma unroll
+        for (int ct = 0; ct < DCH; ++ct) dq[ct] = zero4();
+#pragma unroll
+        for (int mt = 0; mt < PT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* krow = hb + (16 * mt + 4 * rg + r) * S + d;
+                const float ds = s[mt][r] * (dp[mt][r] - D) * scale;
+#pragma unroll
+                for (int ct = 0; ct < DCH; ++ct) {
+                    const float kk = 16 * ct + i < d ? krow[16 * ct + i] : 0.f;
+                    dq[ct] = mfma16(ds, kk, dq[ct]);
+                }
+            }
+    }
+    __syncthreads();                                          // D of every query of the partition is in LDS
+    // ---- phase 2: dK, dV of key tile kt = qt --------------------------------------------------------------------------------
+    f4 dk[DCH], dv[DCH];
+    {
+        const bool kvalid = 16 * qt + i < P;
+        f4 kf[DCH], vf[DCH];
+#pragma unroll
+        for (int ch = 0; ch < DCH; ++ch) {
+            const bool ok = 16 * ch + 4 * rg < d;
+            kf[ch] = lds4(hb + (16 * qt + i) * S + d + 16 * ch + 4 * rg, ok);
+            vf[ch] = lds4(hb + (16 * qt + i) * S + 2 * d + 16 * ch + 4 * rg, ok);
+        }
+#pragma unroll
+        for (int ct = 0; ct < DCH; ++ct) { dk[ct] = zero4(); dv[ct] = zero4(); }
+#pragma unroll
+        for (int qm = 0; qm < PT; ++qm) {
+            f4 s = zero4(), dp = zero4();
+#pragma unroll
+            for (int ch = 0; ch < DCH; ++ch) {
+                const bool ok = 16 * ch + 4 * rg < d;
+                const f4 qf = lds4(hb + (16 * qm + i) * S + 16 * ch + 4 * rg, ok);
+                const f4 dof = lds4(db + (16 * qm + i) * Sd + 16 * ch + 4 * rg, ok);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s = mfma16(qf[j], kf[ch][j], s);
+                    dp = mfma16(dof[j], vf[ch][j], dp);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int query = 16 * qm + 4 * rg + r;       // accumulator row r; key = column i
+                float pr = 0.f, ds = 0.f;
+                if (query < P && kvalid) {
+                    pr = fast_exp(s[r] * scale - sL[hl * TOK + query]);
+                    ds = pr * (dp[r] - sD[hl * TOK + query]) * scale;
+                }
+                const float* qrow = hb + query * S;
+                const float* dorow = db + query * Sd;
+#pragma unroll
+                for (int ct = 0; ct < DCH; ++ct) {
+                    const bool ok = 16 * ct + i < d;
+                    const float dov = ok ? dorow[16 * ct + i] : 0.f;
+                    const float qv = ok ? qrow[16 * ct + i] : 0.f;
+                    dv[ct] = mfma16(pr, dov, dv[ct]);
+                    dk[ct] = mfma16(ds, qv, dk[ct]);
+                }
+            }
+        }
+    }
+    __syncthreads();                                          // every wave is done reading the staged q/k/v
+    float* gb = smem + hl * 3 * d + (16 * qt) * S;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ct = 0; ct < DCH; ++ct)
+            if (16 * ct + i < d) {
+                float* t = gb + (4 * rg + r) * S + 16 * ct + i;
+                t[0] = dq[ct][r]; t[d] = dk[ct][r]; t[2 * d] = dv[ct][r];
+            }
+    __syncthreads();
+    for (int e = tid; e < TOK * F; e += NTHR) {
+        const int tok = e / F, f = e - tok * F;
+        const long row = srow[tok];
+        if (row >= 0) *reinterpret_cast<f4*>(dqkv + row * ld + h0 * 3 * d + 4 * f) = *reinterpret_cast<const f4*>(smem + tok * S + 4 * f);
+    }
+}
+
+template <int PT, int DCH, int HG>
+static int run_attn_lds(int which, const float* qkv, const float* dout, float* out, float* lse, float* dqkv,
+                        const AttnGeom& g, float scale, hipStream_t s) {
+    const int NP = g.B * (g.H / g.ph) * (g.W / g.pw);
+    const int nblk = NP * (g.heads / HG);
+    if (nblk == 0) return LEOD_OK;
+    const int TOK = 16 * PT, S = HG * 3 * g.d + 4, Sd = HG * g.d + 4;
+    if (which == 0) {
+        const size_t lds = (size_t)TOK * S * sizeof(float);
+        hipLaunchKernelGGL((attn_fwd_lds_kernel<PT, DCH, HG>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, out, lse, g, scale);
+    } else {
+        const size_t lds = (size_t)TOK * (S + Sd) * sizeof(float);
+        hipLaunchKernelGGL((attn_bwd_lds_kernel<PT, DCH, HG>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, dout, lse, dqkv, g, scale);
+    }
+    return leod_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------------------
 template <int PT, int DCH>
 static int run_attn(int which, const float* qkv, const float* dout, float* out, float* lse, float* dsum, float* dqkv,
@@ -327,6 +621,20 @@ static int dispatch_attn(int which, const float* qkv, const float* dout, float* 
     if (g.C != g.heads * g.d || (g.d & 3) || g.d > 32 || g.H % g.ph || g.W % g.pw) return LEOD_ERR_ARG;
     const int P = g.ph * g.pw, PT = (P + 15) / 16, DCH = (g.d + 15) / 16;
     const float scale = 1.0f / sqrtf((float)g.d);
+    static const int use_lds = getenv("LEOD_ATTN_LDS") ? atoi(getenv("LEOD_ATTN_LDS")) : 1;
+    const int HG = (g.heads % 2 == 0 && 2 * PT <= 16) ? 2 : 1;
+    const bool lds_shape = DCH <= 2 && (PT <= 5 || PT == 8 || (HG == 1 && (PT == 10 || PT == 15))) && !(PT == 3 && DCH == 1);
+    if (use_lds && lds_shape) {
+        // which: 0 forward, 1 fused backward (the register-direct path runs 1 = q pass, then 2 = kv pass)
+        if (which == 2) return LEOD_OK;                       // the fused LDS backward already produced dK / dV
+#define ATTL(PTV, DV, HGV) if (PT == PTV && DCH == DV && HG == HGV) return run_attn_lds<PTV, DV, HGV>(which, qkv, dout, out, lse, dqkv, g, scale, s);
+        ATTL(1, 1, 1) ATTL(1, 1, 2) ATTL(1, 2, 1) ATTL(1, 2, 2) ATTL(2, 1, 1) ATTL(2, 1, 2) ATTL(2, 2, 1) ATTL(2, 2, 2)
+        ATTL(3, 2, 1) ATTL(3, 2, 2) ATTL(4, 1, 1) ATTL(4, 1, 2) ATTL(4, 2, 1) ATTL(4, 2, 2) ATTL(5, 1, 1) ATTL(5, 1, 2)
+        ATTL(5, 2, 1) ATTL(5, 2, 2) ATTL(8, 1, 1) ATTL(8, 1, 2) ATTL(8, 2, 1) ATTL(8, 2, 2) ATTL(10, 1, 1) ATTL(10, 2, 1)
+        ATTL(15, 1, 1) ATTL(15, 2, 1)
+#undef ATTL
+        return LEOD_ERR_UNSUPPORTED;
+    }
 #define ATT(PTV, DV) if (PT == PTV && DCH == DV) return run_attn<PTV, DV>(which, qkv, dout, out, lse, dsum, dqkv, g, scale, s);
     ATT(1, 1) ATT(1, 2) ATT(4, 1) ATT(4, 2) ATT(5, 1) ATT(5, 2) ATT(15, 2) ATT(2, 1) ATT(2, 2) ATT(3, 2) ATT(8, 2) ATT(10, 2)
 #undef ATT
