@@ -581,17 +581,21 @@ static inline int launch_gemm16(const AL& al, const BL& bl, const EP& ep, int M,
 // 2.5-3 TB/s.  Here both operands are fetched with fully coalesced 16-byte loads (each thread owns fixed (row, k4)
 // slots), double-buffered through LDS, and read back in operand layout with conflict-free ds_read_b128.
 // =================================================================================================
-template <int NT, int KCH, int NBUF, class AL, class BL, class EP>
-__global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_lds_kernel(AL al, BL bl, EP ep, int M, int K, int nblocks_n) {
+// RW = 16-row fragments per wave (workgroup = 64*RW rows): RW = 2 halves the B-fragment LDS reads and the B staging per
+// output row -- the MFMA-bound shapes (RVT stages 3/4, 3x3 convs) were LDS-bandwidth limited at RW = 1 (every wave
+// re-reads the whole B tile: 5 ds_read_b128 per 16 MFMAs, x 16 resident waves per CU > 128 B/clk).
+template <int NT, int KCH, int NBUF, int RW, class AL, class BL, class EP>
+__global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_lds_kernel(AL al, BL bl, EP ep, int M, int K, int nblocks_n) {
+    constexpr int BM = 64 * RW;
     constexpr int LD = KCH + 4;                      // 16-lane b128 reads of rows i=0..15 hit banks 4i..4i+3: conflict-free
     constexpr int K4 = KCH / 4;                      // float4 slots per staged row
     constexpr int BN = NT * 16;
-    constexpr int RA = (64 * K4 + 255) / 256, RB = (BN * K4 + 255) / 256;
+    constexpr int RA = (BM * K4 + 255) / 256, RB = (BN * K4 + 255) / 256;
     constexpr int LDO = BN + 4;                      // accumulator transposition tile of the row-layout epilogue (aliases A/B)
-    static_assert((64 + BN) * LD >= 64 * LDO, "epilogue tile must fit in the operand buffers");
-    __shared__ __attribute__((aligned(16))) float smem[NBUF * (64 + BN) * LD];
-    float (*sA)[64 * LD] = reinterpret_cast<float (*)[64 * LD]>(smem);
-    float (*sB)[BN * LD] = reinterpret_cast<float (*)[BN * LD]>(smem + NBUF * 64 * LD);
+    static_assert((BM + BN) * LD >= 64 * LDO, "epilogue tile must fit in the operand buffers");
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * (BM + BN) * LD];
+    float (*sA)[BM * LD] = reinterpret_cast<float (*)[BM * LD]>(smem);
+    float (*sB)[BN * LD] = reinterpret_cast<float (*)[BN * LD]>(smem + NBUF * BM * LD);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     // XCD-aware 1-D grid: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2).  All n-blocks of
@@ -600,7 +604,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_lds_kernel(AL al,
     const int per = 8 * nblocks_n;
     const int grp = blockIdx.x / per, rem = blockIdx.x - grp * per;
     const int nblk = rem >> 3;
-    const int brow0 = (grp * 8 + (rem & 7)) * 64;
+    const int brow0 = (grp * 8 + (rem & 7)) * BM;
     if (brow0 >= M) return;                          // workgroup-uniform (padding of the last group)
     // ---- fixed staging slots of this thread ------------------------------------------------------------------------
     typename AL::St ast[RA];
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_lds_kernel(AL al,
 #pragma unroll
     for (int p = 0; p < RA; ++p) {
         const int e = tid + 256 * p, r = e / K4, k4 = (e - r * K4) * 4;
-        aok[p] = e < 64 * K4;
+        aok[p] = e < BM * K4;
         ast[p] = al.init(brow0 + (aok[p] ? r : 0), M, 0, false);
         ak[p] = k4; al_off[p] = r * LD + k4;
     }
@@ -646,14 +650,16 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_lds_kernel(AL al,
             else { float* d = &sB[buf][bl_off[p]]; d[0] = rb[p].x; d[LD] = rb[p].y; d[2 * LD] = rb[p].z; d[3 * LD] = rb[p].w; }
         }
     };
-    f4 acc[NT];
+    f4 acc[RW][NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = zero4();
+    for (int w = 0; w < RW; ++w)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[w][t] = zero4();
     const int nch = (K + KCH - 1) / KCH;
     fetch(0);
     stash(0);
     __syncthreads();
-    const int aoff = (16 * wave + i) * LD + 4 * q, boff = i * LD + 4 * q;
+    const int aoff = (16 * RW * wave + i) * LD + 4 * q, boff = i * LD + 4 * q;      // wave owns rows 16*RW*wave ..
     for (int ch = 0; ch < nch; ++ch) {
         const int buf = NBUF == 1 ? 0 : (ch & 1);
         const bool more = ch + 1 < nch;
@@ -662,12 +668,16 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_lds_kernel(AL al,
         const float* __restrict__ pb = sB[buf] + boff;
 #pragma unroll
         for (int c = 0; c < KCH / 16; ++c) {
-            const f4 av = *reinterpret_cast<const f4*>(pa + 16 * c);
+            f4 av[RW];
+#pragma unroll
+            for (int w = 0; w < RW; ++w) av[w] = *reinterpret_cast<const f4*>(pa + 16 * w * LD + 16 * c);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const f4 bv = *reinterpret_cast<const f4*>(pb + 16 * t * LD + 16 * c);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[t] = mfma16(av[j], bv[j], acc[t]);
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int w = 0; w < RW; ++w) acc[w][t] = mfma16(av[w][j], bv[j], acc[w][t]);
             }
         }
         if (NBUF > 1) {
@@ -679,18 +689,25 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void gemm_lds_kernel(AL al,
             __syncthreads();
         }
     }
-    const int row0 = brow0 + 16 * wave;
     if constexpr (EP::kRowEpilogue) {
-        __syncthreads();                                      // every wave is done with the operand buffers
         float* so = smem + wave * 16 * LDO;                   // wave-private 16 x BN tile
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int w = 0; w < RW; ++w) {
+            const int row0 = brow0 + 16 * (RW * wave + w);
+            __syncthreads();                                  // operand buffers (w = 0) / previous tile (w > 0) are done with
 #pragma unroll
-            for (int r = 0; r < 4; ++r) so[(4 * q + r) * LDO + 16 * t + i] = acc[t][r];
-        __syncthreads();
-        if (row0 < M) ep.template run_rows<NT, BL>(so, LDO, bl, row0, nblk, lane, M);
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) so[(4 * q + r) * LDO + 16 * t + i] = acc[w][t][r];
+            __syncthreads();
+            if (row0 < M) ep.template run_rows<NT, BL>(so, LDO, bl, row0, nblk, lane, M);
+        }
     } else {
-        if (row0 < M) ep.template run<NT, BL>(acc, bl, row0, nblk, lane, M);
+#pragma unroll
+        for (int w = 0; w < RW; ++w) {
+            const int row0 = brow0 + 16 * (RW * wave + w);
+            if (row0 < M) ep.template run<NT, BL>(acc[w], bl, row0, nblk, lane, M);
+        }
     }
 }
 
@@ -719,20 +736,26 @@ static inline int launch_row_stats(const float* x, long ld, float* stats, int M,
     return leod_launch_status();
 }
 
-template <int NT, class AL, class BL, class EP>
-static inline int launch_gemm_lds(const AL& al, const BL& bl, const EP& ep, int M, int K, int nblocks_n, hipStream_t s) {
-    dim3 grid(cdiv(cdiv(M, 64), 8) * 8 * nblocks_n);
-    // single LDS buffer + register prefetch everywhere: residency (4-6 workgroups per CU) hides the two barriers per chunk
+template <int NT, int RW, class AL, class BL, class EP>
+static inline int launch_gemm_lds_rw(const AL& al, const BL& bl, const EP& ep, int M, int K, int nblocks_n, hipStream_t s) {
+    dim3 grid(cdiv(cdiv(M, 64 * RW), 8) * 8 * nblocks_n);
+    // single LDS buffer + register prefetch everywhere: residency (3-6 workgroups per CU) hides the two barriers per chunk
     // better than a double buffer at 2-3 workgroups per CU does (measured; LEOD_LDS_NBUF=2 selects the double buffer)
     static const int nbuf = getenv("LEOD_LDS_NBUF") ? atoi(getenv("LEOD_LDS_NBUF")) : 1;
     if (K % 48 == 0) {
-        if (nbuf == 1 || K == 48) hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 1, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
-        else hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 2, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
+        if (nbuf == 1 || K == 48) hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 1, RW, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
+        else hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 2, RW, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
     } else {
-        if (nbuf == 1 || K <= 64) hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 1, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
-        else hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 2, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
+        if (nbuf == 1 || K <= 64) hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 1, RW, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
+        else hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 2, RW, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
     }
     return leod_launch_status();
+}
+template <int NT, class AL, class BL, class EP>
+static inline int launch_gemm_lds(const AL& al, const BL& bl, const EP& ep, int M, int K, int nblocks_n, hipStream_t s) {
+    // RW = 2 (128-row workgroups, two row fragments per wave) measured 5-40 % SLOWER on every RVT shape (3 instead of 4
+    // resident workgroups, two epilogue rounds), so only RW = 1 is instantiated.
+    return launch_gemm_lds_rw<NT, 1>(al, bl, ep, M, K, nblocks_n, s);
 }
 // enough 64-row workgroups to fill the chip; smaller problems stay on the register-direct kernels (K-split)
 static inline bool use_gemm_lds(int M, int nblocks_n) { return (long)cdiv(M, 64) * nblocks_n >= 256 && M >= 2048; }

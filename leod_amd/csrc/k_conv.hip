@@ -100,7 +100,7 @@ LEOD_API int leod_conv_nhwc_dgrad(const float* dy, const float* w, float* dx, in
         // live-tap formulation: rows grouped by input parity class, 2.25 taps per pixel on average instead of 9
         ALConvT2 al{dy, H, W, Ho, Wo, N, Q};
         ep.rm_Q = Q; ep.rm_H = H; ep.rm_W = W;
-        const bool lds2 = use_gemm_lds(M, cdiv(Cin, 16 * nt)) && Q % 64 == 0;     // a 64-row workgroup must not mix classes
+        const bool lds2 = use_gemm_lds(M, cdiv(Cin, 16 * nt)) && Q % 128 == 0;    // a (64|128)-row workgroup must not mix classes
         DISPATCH_NT(nt, { BLConvWT2 bl{w, N, Cin, NT};
                           rc = lds2 ? launch_gemm_lds<NT>(al, bl, ep, M, 4 * N, cdiv(Cin, 16 * NT), stream)
                                     : launch_gemm16<NT>(al, bl, ep, M, 4 * N, cdiv(Cin, 16 * NT), stream); });
