@@ -159,6 +159,18 @@ int leod_set_scalars4(float* dst, float a, float b, float c, float d, leod_strea
 int leod_voxelize_u8(const long* x, const long* y, const long* pol, const long* t, long n_events, int* counts_ws,
                      unsigned char* out, int bins, int H, int W, int count_cutoff, int fastmode, leod_stream_t stream);
 
+/* ---- host-side C++ of the path (no GPU involved) ------------------------------------------------------------------
+ * Tracking post-filter of the pseudo-label loop: linear-velocity tracklets, confidence-ordered greedy IoU association,
+ * short-tracklet removal and in-painting of missed detections.  Replaces modules/tracking/linear.py:10-292,
+ * modules/tracking/utils.py:7-96 and EventSeqData._track (modules/pseudo_labeler.py:201-258).
+ * boxes [N,5] float32 (cx,cy,w,h,class) of the labelled frames concatenated in frame order; is_gt [N] (uint8);
+ * frame_idx [F] strictly increasing; counts [F] boxes per labelled frame.  remove [N] (uint8) out: 1 = box on a finished
+ * non-GT tracklet with fewer than min_track_len hits.  inpaint != 0: predicted boxes of the kept tracklets at their
+ * missed frames -> inp_frame [inp_cap], inp_box [inp_cap,5], *n_inp (needed count; rc -3 if inp_cap is too small). */
+int leod_track_filter(const float* boxes, const unsigned char* is_gt, const int* frame_idx, const int* counts, int F,
+                      int img_h, int img_w, int min_track_len, double min_conf, double iou_threshold, double q,
+                      unsigned char* remove, int inpaint, int* inp_frame, float* inp_box, int inp_cap, int* n_inp);
+
 #ifdef __cplusplus
 }
 #endif

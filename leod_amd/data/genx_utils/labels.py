@@ -80,6 +80,10 @@ class ObjectLabels:
     def new_zeros(self) -> 'ObjectLabels':
         return ObjectLabels(self.object_labels.new_zeros((0, len(FIELDS))), self.input_size_hw)
 
+    def get_reverse(self) -> 'ObjectLabels':
+        """Rows in reverse order (labels.py:515-519): the time-reversed view used by backward tracking."""
+        return ObjectLabels(self.object_labels.flip(0), self.input_size_hw)
+
     # ---- predicates ---------------------------------------------------------------------------------
     def is_pseudo_label(self):
         return self.object_labels[:, 0] == 0          # pseudo labels are written with t == 0

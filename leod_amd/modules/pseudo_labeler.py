@@ -3,9 +3,9 @@
 
 The per-batch hot loop (hflip copy, frame masks, backbone over L, head + postprocess + pred2label on the
 selected frames) runs on the HIP kernels; the ragged per-sequence bookkeeping stays host Python as in the
-reference.  Tracker-based filtering / in-painting (modules/tracking, pseudo_labeler.py:201-333) is the next
-component after the hot path and is not part of this module yet: ``EventSeqData.save``
-writes the NMS-merged labels."""
+reference.  Tracker-based filtering / in-painting (modules/tracking, pseudo_labeler.py:201-333) runs in the native
+library (``leod_amd.modules.tracking`` -> ``leod_track_filter``): ``EventSeqData.save`` aggregates the TTA views,
+applies the tracking post-filter configured in ``filter_config`` and writes the labels."""
 import copy
 import os
 import os.path as osp
@@ -22,6 +22,7 @@ from .detection import Module
 from .utils.detection import BackboneFeatureSelector, SeqLens, Mode, DATA_KEY
 from .utils.ssod import pred2label, filter_pred_boxes
 from .utils.tta import tta_postprocess as _tta_rows
+from .tracking import track as _native_track
 
 
 def tta_postprocess(preds: List[ObjectLabels], conf_thre: float = 0.7, nms_thre: float = 0.45,
@@ -98,6 +99,65 @@ class EventSeqData:
             self.labels = tta_postprocess(self.labels, conf_thre=self.postproc_cfg.confidence_threshold,
                                           nms_thre=self.postproc_cfg.nms_threshold)
 
+    @staticmethod
+    def _track(labels: List[ObjectLabels], frame_idx: List[int], min_track_len: int = 6, inpaint: bool = False):
+        """Track the boxes of one recording and report those on short tracklets (reference :201-258; same signature and
+        return values: ``remove_idx`` and, with ``inpaint``, ``{frame: [n,8] label rows}``).  One native call."""
+        assert len(labels) == len(frame_idx)
+        if len(labels) == 0:
+            return []
+        boxes = [l.get_xywh(format_='center', add_class_id=True).detach().cpu().numpy() for l in labels]
+        is_gt = [l.is_gt_label().detach().cpu().numpy() for l in labels]
+        return _native_track(boxes, is_gt, frame_idx, labels[0].input_size_hw, min_track_len, inpaint)
+
+    def _track_filter(self) -> None:
+        """Forward / forward-and-backward tracking; boxes on short tracklets get ``ignore_label`` as class id,
+        missed detections of surviving tracklets are in-painted with ``ignore_label`` (reference :260-333)."""
+        if len(self.labels) == 0:
+            return
+        fc = self.filter_config
+        min_track_len = fc.min_track_len
+        if min_track_len <= 0:
+            return
+        track_method = fc.track_method
+        assert track_method in ['forward', 'forward or backward'], f'Unknown tracking post-processing {track_method}'
+        remove_idx, inpainted = self._track(self.labels, self.frame_idx, min_track_len=min_track_len, inpaint=fc.inpaint)
+        if 'backward' in track_method:
+            rev_labels = [l.get_reverse() for l in self.labels[::-1]]
+            rev_frame_idx = [max(self.frame_idx) - i for i in self.frame_idx[::-1]]
+            bg_remove_idx, _ = self._track(rev_labels, rev_frame_idx, min_track_len=min_track_len, inpaint=False)
+            nlabels = sum(len(l) for l in self.labels)
+            remove_idx = list(set(remove_idx) & {nlabels - i - 1 for i in bg_remove_idx})
+        remove = set(remove_idx)
+        bbox_idx = 0
+        for label in self.labels:
+            n = len(label)
+            hit = [i for i in range(n) if bbox_idx + i in remove]
+            if hit:
+                assert bool(label.is_pseudo_label().all()), 'Ignoring GT!'
+                label.object_labels[hit, 5] = float(fc.ignore_label)
+            bbox_idx += n
+        if not inpainted:
+            return
+        hw = self.labels[0].input_size_hw
+        ref = self.labels[0].object_labels
+        for f_idx in range(max(self.frame_idx) + 1):
+            if f_idx not in inpainted:
+                continue
+            rows = torch.from_numpy(inpainted[f_idx]).to(device=ref.device, dtype=ref.dtype)
+            rows[:, 5] = float(fc.ignore_label)
+            extra = ObjectLabels(rows, hw)
+            if f_idx in self.frame_idx:
+                k = self.frame_idx.index(f_idx)
+                assert bool(self.labels[k].is_pseudo_label().all()), 'Inpaint ignored bbox at labeled frames!'
+                self.labels[k] = self.labels[k] + extra
+            else:
+                self.frame_idx.append(f_idx)
+                self.labels.append(extra)
+        order = sorted(range(len(self.frame_idx)), key=lambda k: self.frame_idx[k])
+        self.labels = [self.labels[k] for k in order]
+        self.frame_idx = [self.frame_idx[k] for k in order]
+
     def _summarize(self):
         labels, cnt, f2l, f2r = [], 0, [], []
         for label, fidx in zip(self.labels, self.frame_idx):
@@ -111,6 +171,7 @@ class EventSeqData:
     def save(self, save_dir: str, dst_name: str, num_frames: int) -> str:
         """Write labels_v2/labels.npz + objframe_idx_2_repr_idx.npy; refuses to overwrite (reference :366-367)."""
         self._aggregate_results(num_frames)
+        self._track_filter()
         labels, f2l, f2r = self._summarize()
         seq_dir = osp.join(save_dir, osp.basename(osp.normpath(self.path)))
         os.makedirs(osp.join(seq_dir, 'labels_v2'), exist_ok=False)

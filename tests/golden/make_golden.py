@@ -399,6 +399,77 @@ def g10_voxel():
     save('g10_voxel.npz', **out)
 
 
+def tracker_sequences():
+    """Deterministic synthetic label sequences for the tracking post-filter: a few persistent objects that drift
+    (some of them out of the frame, which exercises the clamp-aware velocity), short-lived false positives, missed
+    detections, unlabelled gaps, occasional GT frames and a degenerate zero-area box.  Returned as plain arrays so the
+    tests can rebuild the very same input: per sequence (frame_idx [F], list of [n,8] float32 label rows)."""
+    seqs = []
+    for seed in range(6):
+        rng = np.random.RandomState(7000 + seed)
+        H, W = (240, 304) if seed % 2 == 0 else (360, 640)
+        n_frames = 70 + 10 * seed
+        objs = []
+        for _ in range(4 + seed % 3):
+            t0, life = rng.randint(0, n_frames // 2), rng.randint(8, n_frames)
+            w, h = rng.uniform(12, 80), rng.uniform(12, 60)
+            objs.append(dict(t0=t0, t1=t0 + life, x=rng.uniform(-10, W - 20), y=rng.uniform(-10, H - 20), w=w, h=h,
+                             vx=rng.uniform(-6, 6), vy=rng.uniform(-3, 3), cls=float(rng.randint(0, 2))))
+        frame_idx, rows = [], []
+        for f in range(n_frames):
+            if rng.rand() < 0.25:                      # frame without any label
+                continue
+            is_gt_frame = rng.rand() < 0.08
+            cur = []
+            for o in objs:
+                if not (o['t0'] <= f < o['t1']) or rng.rand() < 0.15:     # not alive / missed detection
+                    continue
+                x = o['x'] + o['vx'] * (f - o['t0']) + rng.normal(0, 1.0)
+                y = o['y'] + o['vy'] * (f - o['t0']) + rng.normal(0, 1.0)
+                x0, y0 = np.clip(x, 0, W - 1), np.clip(y, 0, H - 1)
+                x1, y1 = np.clip(x + o['w'], 0, W - 1), np.clip(y + o['h'], 0, H - 1)
+                if x1 - x0 < 2 or y1 - y0 < 2:
+                    continue
+                cur.append([1000. * (f + 1) if is_gt_frame else 0., x0, y0, x1 - x0, y1 - y0, o['cls'], 0.9, 0.8])
+            if not is_gt_frame:
+                for _ in range(rng.poisson(0.6)):      # false positives
+                    cur.append([0., rng.uniform(0, W - 40), rng.uniform(0, H - 40), rng.uniform(8, 40), rng.uniform(8, 40),
+                                float(rng.randint(0, 2)), 0.5, 0.5])
+                if seed == 3 and f == 20:
+                    cur.append([0., 50., 60., 0., 25., 0., 0.5, 0.5])     # zero-area box
+            if cur:
+                frame_idx.append(f)
+                rows.append(np.array(cur, dtype=np.float32))
+        seqs.append((np.array(frame_idx, dtype=np.int64), rows, (H, W)))
+    return seqs
+
+
+def g13_tracker():
+    """EventSeqData._track_filter of the reference (modules/pseudo_labeler.py:201-333) on the sequences above, for both
+    track methods, with and without in-painting.  Stored: which boxes end up with the ignore label, and the in-painted
+    boxes per frame."""
+    from modules.pseudo_labeler import EventSeqData
+    out = {}
+    for si, (frame_idx, rows, hw) in enumerate(tracker_sequences()):
+        out[f's{si}_frame_idx'] = frame_idx
+        out[f's{si}_counts'] = np.array([len(r) for r in rows], dtype=np.int64)
+        out[f's{si}_rows'] = np.concatenate(rows, 0)
+        out[f's{si}_hw'] = np.array(hw, dtype=np.int64)
+        for method in ('forward', 'forward or backward'):
+            for inpaint in (False, True):
+                cfg = DictConfig(dict(min_track_len=6, track_method=method, inpaint=inpaint, ignore_label=1024))
+                seq = EventSeqData(path='none', scale_ratio=1, filter_config=cfg, postproc_cfg=DictConfig({}))
+                seq.labels = [ObjectLabels(torch.from_numpy(r.copy()), hw) for r in rows]
+                seq.frame_idx = [int(f) for f in frame_idx]
+                seq._track_filter()
+                tag = f's{si}_{"fb" if "backward" in method else "f"}_{"inp" if inpaint else "noinp"}'
+                out[tag + '_frame_idx'] = np.array(seq.frame_idx, dtype=np.int64)
+                out[tag + '_counts'] = np.array([len(l) for l in seq.labels], dtype=np.int64)
+                lab = [l.object_labels if isinstance(l.object_labels, np.ndarray) else l.object_labels.numpy() for l in seq.labels]
+                out[tag + '_rows'] = np.concatenate(lab, 0).astype(np.float32)
+    save('g13_tracker.npz', **out)
+
+
 def g11_manifest():
     man = {}
     for name, ed, dh, fd in [('tiny', 32, 32, 0.33), ('small', 48, 24, 0.33), ('base', 64, 32, 0.67)]:
@@ -483,7 +554,7 @@ def g12_trainstep():
 
 ALL = dict(g01=g01_convlstm, g02=g02_partition, g03=g03_attention, g04=g04_backbone, g05=g05_head,
            g06=g06_simota, g07=g07_postprocess, g08=g08_pseudo, g10=g10_voxel, g11=g11_manifest,
-           g12=g12_trainstep)
+           g12=g12_trainstep, g13=g13_tracker)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)

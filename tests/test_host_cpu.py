@@ -150,3 +150,64 @@ def test_data_parallel_gloo_world2():
     for r in res:
         assert r[2] == 3.0 and r[3] == 0.5                           # grads summed (1+2), averaged by the optimiser scale
         assert r[4] == [3.0, 4.0] and r[5] and r[6]
+
+
+# ---- native tracking post-filter (host C++ behind leod_track_filter; no GPU) ---------------------------------------------
+def _tracker_cases(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g13_tracker.npz'))
+    for si in range(6):
+        fi, cnt, rows_all = g[f's{si}_frame_idx'], g[f's{si}_counts'], g[f's{si}_rows']
+        hw = tuple(int(v) for v in g[f's{si}_hw'])
+        off = np.concatenate([[0], np.cumsum(cnt)])
+        rows = [rows_all[off[k]:off[k + 1]] for k in range(len(cnt))]
+        for method, mt in (('forward', 'f'), ('forward or backward', 'fb')):
+            for inpaint, it in ((False, 'noinp'), (True, 'inp')):
+                tag = f's{si}_{mt}_{it}'
+                yield rows, fi, hw, method, inpaint, g[tag + '_frame_idx'], g[tag + '_counts'], g[tag + '_rows']
+
+
+def test_native_tracker_matches_oracle(golden_dir):
+    """leod_track_filter (C++) == oracle.tracker on the decisions: removed box indices and in-painted boxes."""
+    from oracle import tracker as ot
+    from leod_amd.modules.tracking import track_filter
+    for rows, fi, hw, method, inpaint, *_ in _tracker_cases(golden_dir):
+        boxes = [np.stack([r[:, 1] + np.float32(0.5) * r[:, 3], r[:, 2] + np.float32(0.5) * r[:, 4], r[:, 3], r[:, 4], r[:, 5]], -1)
+                 .astype(np.float32) for r in rows]
+        gts = [r[:, 0] != 0 for r in rows]
+        frames = [int(f) for f in fi]
+        rem, inp = track_filter(boxes, gts, frames, hw, 6, method, inpaint)
+        rem_o, inp_o = ot.track_filter(boxes, gts, frames, hw, 6, method, inpaint)
+        assert rem == rem_o
+        assert sorted(inp) == sorted(inp_o)
+        for f in inp:
+            np.testing.assert_array_equal(inp[f], inp_o[f])
+
+
+def test_event_seq_data_track_filter_matches_reference(golden_dir):
+    """EventSeqData._track_filter of the mirror (native tracker underneath) reproduces the label rows the reference
+    writes -- ignore labels, in-painted rows, inserted frames -- bit for bit (tests/golden/g13_tracker.npz)."""
+    from leod_amd.config.dictconfig import DictConfig
+    from leod_amd.data.genx_utils.labels import ObjectLabels
+    from leod_amd.modules.pseudo_labeler import EventSeqData
+    n = 0
+    for rows, fi, hw, method, inpaint, exp_f, exp_c, exp_rows in _tracker_cases(golden_dir):
+        cfg = DictConfig(dict(min_track_len=6, track_method=method, inpaint=inpaint, ignore_label=1024))
+        seq = EventSeqData(path='none', scale_ratio=1, filter_config=cfg, postproc_cfg=DictConfig({}))
+        seq.labels = [ObjectLabels(torch.from_numpy(r.copy()), hw) for r in rows]
+        seq.frame_idx = [int(f) for f in fi]
+        seq._track_filter()
+        assert seq.frame_idx == [int(f) for f in exp_f]
+        assert [len(l) for l in seq.labels] == [int(c) for c in exp_c]
+        np.testing.assert_array_equal(torch.cat([l.object_labels for l in seq.labels], 0).numpy(), exp_rows)
+        n += 1
+    assert n == 24
+
+
+def test_native_tracker_argument_checks():
+    from leod_amd._lib import LeodHipError
+    from leod_amd.modules.tracking import track
+    assert track([], [], [], (240, 304)) == ([], {})
+    b = [np.array([[10., 10., 5., 5., 0.]], np.float32)] * 2
+    g = [np.array([False])] * 2
+    with pytest.raises(LeodHipError):
+        track(b, g, [3, 3], (240, 304))                       # frame indices must be strictly increasing

@@ -276,3 +276,30 @@ def test_g12_trainstep(golden_dir, manifest):
                                    g[f's{step}_param_norms'], rtol=2e-4)  # Adam's first steps ~ lr*sign(g): noise-level grads flip
         assert abs(tr.opt.param_groups[0]['lr'] - float(g[f's{step}_lr_next'])) < 1e-12
         close(tr.states[3][1], g[f's{step}_state_c4'], rtol=1e-4, atol=1e-5)
+
+
+def _tracker_cases(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g13_tracker.npz'))
+    for si in range(6):
+        fi, cnt, rows_all = g[f's{si}_frame_idx'], g[f's{si}_counts'], g[f's{si}_rows']
+        hw = tuple(int(v) for v in g[f's{si}_hw'])
+        off = np.concatenate([[0], np.cumsum(cnt)])
+        rows = [rows_all[off[k]:off[k + 1]] for k in range(len(cnt))]
+        for method, mt in (('forward', 'f'), ('forward or backward', 'fb')):
+            for inpaint, it in ((False, 'noinp'), (True, 'inp')):
+                tag = f's{si}_{mt}_{it}'
+                yield rows, fi, hw, method, inpaint, g[tag + '_frame_idx'], g[tag + '_counts'], g[tag + '_rows']
+
+
+def test_tracker_oracle_matches_reference(golden_dir):
+    """oracle.tracker == the reference's EventSeqData._track_filter (modules/pseudo_labeler.py:201-333), bit for bit:
+    ignore labels, in-painted boxes, inserted frames."""
+    from oracle import tracker as ot
+    n = 0
+    for rows, fi, hw, method, inpaint, exp_f, exp_c, exp_rows in _tracker_cases(golden_dir):
+        f2, r2 = ot.apply_track_filter(rows, fi, hw, 6, method, inpaint, ignore_label=1024)
+        assert list(f2) == list(exp_f)
+        assert [len(r) for r in r2] == list(exp_c)
+        np.testing.assert_array_equal(np.concatenate(r2, 0), exp_rows)
+        n += 1
+    assert n == 24
