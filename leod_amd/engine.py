@@ -255,6 +255,7 @@ class PseudoLabelEngine:
         self.obj_thresh, self.cls_thresh = list(obj_thresh), list(cls_thresh)
         self.dataset_name, self.ds2, self.hflip, self.max_det = dataset_name, downsampled_by_2, hflip, max_det
         self.states = None
+        self.time_batched = os.environ.get('LEOD_SCHEDULE', 'batched') == 'batched'
 
     @torch.no_grad()
     def step(self, ev_seq: torch.Tensor, is_first: Optional[torch.Tensor] = None):
@@ -268,14 +269,20 @@ class PseudoLabelEngine:
             for h, c in self.states:
                 h[is_first] = 0
                 c[is_first] = 0
-        states = self.states
-        per_t: Dict[int, List[torch.Tensor]] = {}
-        for t in range(T):
-            feats, states = self.det.forward_backbone(ev_seq[t], states)
-            for k in self.det.fpn.in_features:
-                per_t.setdefault(k, []).append(feats[k].permute(0, 2, 3, 1))
+        if self.time_batched:
+            # stage-major: every stage sees all T*B' frames per launch, only the ConvLSTM walks over t (same values as
+            # the per-timestep loop of pseudo_labeler.py:687-722, see RNNDetector.forward_sequence)
+            feats_all, states = self.det.backbone.forward_sequence(ev_seq, self.states)
+            feats = {k: feats_all[k] for k in self.det.fpn.in_features}
+        else:
+            states = self.states
+            per_t: Dict[int, List[torch.Tensor]] = {}
+            for t in range(T):
+                f_t, states = self.det.forward_backbone(ev_seq[t], states)
+                for k in self.det.fpn.in_features:
+                    per_t.setdefault(k, []).append(f_t[k].permute(0, 2, 3, 1))
+            feats = {k: torch.cat(v, 0).permute(0, 3, 1, 2) for k, v in per_t.items()}
         self.states = states
-        feats = {k: torch.cat(v, 0).permute(0, 3, 1, 2) for k, v in per_t.items()}
         preds, _ = self.det.forward_detect(feats)
         det, cnt = postprocess_padded(preds, self.nc, self.conf, self.nms, max_det=self.max_det)
         lab, lcnt = pred2label_padded(det, cnt, self.obj_thresh, self.cls_thresh, self.dataset_name, self.ds2)
