@@ -63,6 +63,7 @@ struct ALRows {                 // plain rows, optional LayerNorm prologue, opti
         if (kscale) v = v * ld4(kscale + k);
         return s.ok ? v : zero4();
     }
+    template <int KCH> __device__ __forceinline__ f4 load2(const St& st, int k0, int ak, int Kt) const { return load(st, k0 + ak, Kt); }
 };
 
 struct ALConcat2 {              // [x1 (K1 cols) | x2] along k  (ConvLSTM: cat(x, h_prev))
@@ -79,6 +80,7 @@ struct ALConcat2 {              // [x1 (K1 cols) | x2] along k  (ConvLSTM: cat(x
         if (k < K1) return ld4(s.p1 + k);
         return s.p2 ? ld4(s.p2 + (k - K1)) : zero4();      // x2 == nullptr: zero initial state
     }
+    template <int KCH> __device__ __forceinline__ f4 load2(const St& st, int k0, int ak, int Kt) const { return load(st, k0 + ak, Kt); }
 };
 
 struct ALConvNHWC {             // implicit-GEMM im2col over an NHWC fp32 map; k' = tap*Cin + c
@@ -94,6 +96,17 @@ struct ALConvNHWC {             // implicit-GEMM im2col over an NHWC fp32 map; k
     __device__ __forceinline__ f4 load(const St& s, int k, int Kt) const {
         if (k >= Kt || !s.ok) return zero4();
         const int tap = k / Cin, c = k - tap * Cin;
+        const int kh = tap / ks, kw = tap - kh * ks;
+        const int iy = s.iy0 + kh, ix = s.ix0 + kw;
+        if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) return zero4();
+        return ld4(x + (((long)s.b * H + iy) * W + ix) * Cin + c);
+    }
+    // chunk form used by the LDS GEMM: k = k0 + ak with k0 workgroup-uniform.  When Cin % KCH == 0 a chunk never
+    // straddles a tap, so (tap, kh, kw) come out of scalar (wave-uniform) divisions instead of ~40 VALU per slot.
+    template <int KCH> __device__ __forceinline__ f4 load2(const St& s, int k0, int ak, int Kt) const {
+        if (Cin % KCH != 0) return load(s, k0 + ak, Kt);
+        if (k0 + ak >= Kt || !s.ok) return zero4();
+        const int tap = k0 / Cin, c = k0 - tap * Cin + ak;
         const int kh = tap / ks, kw = tap - kh * ks;
         const int iy = s.iy0 + kh, ix = s.ix0 + kw;
         if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) return zero4();
@@ -124,6 +137,7 @@ struct ALStemNCHW {             // stem conv over the raw NCHW event tensor (uin
         if (k >= Kt || !s.ok) return zero4();
         f4 v; v.x = one(s, k); v.y = one(s, k + 1); v.z = one(s, k + 2); v.w = one(s, k + 3); return v;
     }
+    template <int KCH> __device__ __forceinline__ f4 load2(const St& st, int k0, int ak, int Kt) const { return load(st, k0 + ak, Kt); }
 };
 
 struct ALConvT {                // dgrad of a conv: rows = input pixels, k' = tap*N + n over dY (NHWC [B,Ho,Wo,N])
@@ -138,6 +152,17 @@ struct ALConvT {                // dgrad of a conv: rows = input pixels, k' = ta
     __device__ __forceinline__ f4 load(const St& s, int k, int Kt) const {
         if (k >= Kt || !s.ok) return zero4();
         const int tap = k / N, n = k - tap * N;
+        const int kh = tap / ks, kw = tap - kh * ks;
+        const int ty = s.iy + pad - kh, tx = s.ix + pad - kw;
+        if (ty < 0 || tx < 0 || (ty % stride) || (tx % stride)) return zero4();
+        const int oy = ty / stride, ox = tx / stride;
+        if (oy >= Ho || ox >= Wo) return zero4();
+        return ld4(dy + (((long)s.b * Ho + oy) * Wo + ox) * N + n);
+    }
+    template <int KCH> __device__ __forceinline__ f4 load2(const St& s, int k0, int ak, int Kt) const {
+        if (N % KCH != 0) return load(s, k0 + ak, Kt);
+        if (k0 + ak >= Kt || !s.ok) return zero4();
+        const int tap = k0 / N, n = k0 - tap * N + ak;               // wave-uniform tap
         const int kh = tap / ks, kw = tap - kh * ks;
         const int ty = s.iy + pad - kh, tx = s.ix + pad - kw;
         if (ty < 0 || tx < 0 || (ty % stride) || (tx % stride)) return zero4();
@@ -174,6 +199,17 @@ struct ALConvT2 {
         if (oy >= Ho || ox >= Wo) return zero4();
         return ld4(dy + (((long)s.b * Ho + oy) * Wo + ox) * N + n);
     }
+    template <int KCH> __device__ __forceinline__ f4 load2(const St& s, int k0, int ak, int Kt) const {
+        if (N % KCH != 0) return load(s, k0 + ak, Kt);
+        const int py = s.cls >> 1, px = s.cls & 1;
+        if (!s.ok || k0 + ak >= (1 + py) * (1 + px) * N) return zero4();
+        const int t = k0 / N, n = k0 - t * N + ak;                   // wave-uniform live-tap index
+        const int khi = t / (1 + px), kwi = t - khi * (1 + px);
+        const int oy = py ? (khi == 0 ? (s.iy + 1) >> 1 : (s.iy - 1) >> 1) : s.iy >> 1;
+        const int ox = px ? (kwi == 0 ? (s.ix + 1) >> 1 : (s.ix - 1) >> 1) : s.ix >> 1;
+        if (oy >= Ho || ox >= Wo) return zero4();
+        return ld4(dy + (((long)s.b * Ho + oy) * Wo + ox) * N + n);
+    }
 };
 
 // =================================================================================================
@@ -182,6 +218,7 @@ struct ALConvT2 {
 struct BLRows {
     static constexpr bool kTrans = false;
     __device__ __forceinline__ f4 load_n4(int, int, int, int) const { return zero4(); }                 // W[n][k], row stride ld (torch Linear / 1x1 conv weight)
+    template <int KCH> __device__ __forceinline__ f4 load2(int nblk, int t, int i, int k0, int bk, int Kt, int a = 0) const { return load(nblk, t, i, k0 + bk, Kt, a); }
     const float* w; long ld; int N; int NT;
     __device__ __forceinline__ int col(int nblk, int t, int i) const { return (nblk * NT + t) * 16 + i; }
     __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt, int = 0) const {
@@ -193,6 +230,7 @@ struct BLRows {
 struct BLGates {
     static constexpr bool kTrans = false;
     __device__ __forceinline__ f4 load_n4(int, int, int, int) const { return zero4(); }                // ConvLSTM: tile t = gate t (f,i,o,g), columns nblk*16.. of that gate; W[4C][K]
+    template <int KCH> __device__ __forceinline__ f4 load2(int nblk, int t, int i, int k0, int bk, int Kt, int a = 0) const { return load(nblk, t, i, k0 + bk, Kt, a); }
     const float* w; long ld; int C;
     __device__ __forceinline__ int col(int nblk, int t, int i) const { return t * C + nblk * 16 + i; }
     __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt, int = 0) const {
@@ -202,6 +240,7 @@ struct BLGates {
 };
 struct BLTrans {
     static constexpr bool kTrans = true;          // memory is contiguous along n (W[k][n]): stage with float4 along n                // B(n,k) = W[k][n]  (dgrad of a Linear: W is [Kred][N])
+    template <int KCH> __device__ __forceinline__ f4 load2(int nblk, int t, int i, int k0, int bk, int Kt, int a = 0) const { return load(nblk, t, i, k0 + bk, Kt, a); }
     const float* w; long ld; int N; int NT;
     __device__ __forceinline__ int col(int nblk, int t, int i) const { return (nblk * NT + t) * 16 + i; }
     __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt, int = 0) const {
@@ -229,6 +268,14 @@ struct BLConvW {
         const float* p = w + ((long)n * Cin + c) * KK + tap;
         f4 v; v.x = p[0]; v.y = p[KK]; v.z = p[2 * KK]; v.w = p[3 * KK]; return v;
     }
+    template <int KCH> __device__ __forceinline__ f4 load2(int nblk, int t, int i, int k0, int bk, int Kt, int = 0) const {
+        if (Cin % KCH != 0) return load(nblk, t, i, k0 + bk, Kt);
+        const int n = col(nblk, t, i);
+        if (n >= N || k0 + bk >= Kt) return zero4();
+        const int tap = k0 / Cin, c = k0 - tap * Cin + bk;           // wave-uniform tap
+        const float* p = w + ((long)n * Cin + c) * KK + tap;
+        f4 v; v.x = p[0]; v.y = p[KK]; v.z = p[2 * KK]; v.w = p[3 * KK]; return v;
+    }
 };
 struct BLConvWT {
     static constexpr bool kTrans = false;
@@ -239,6 +286,15 @@ struct BLConvWT {
         const int c = col(nblk, t, i);
         if (c >= Cin || k >= Kt) return zero4();
         const int tap = k / N, n = k - tap * N;
+        const long sn = (long)Cin * KK;
+        const float* p = w + ((long)n * Cin + c) * KK + tap;
+        f4 v; v.x = p[0]; v.y = p[sn]; v.z = p[2 * sn]; v.w = p[3 * sn]; return v;
+    }
+    template <int KCH> __device__ __forceinline__ f4 load2(int nblk, int t, int i, int k0, int bk, int Kt, int = 0) const {
+        if (N % KCH != 0) return load(nblk, t, i, k0 + bk, Kt);
+        const int c = col(nblk, t, i);
+        if (c >= Cin || k0 + bk >= Kt) return zero4();
+        const int tap = k0 / N, n = k0 - tap * N + bk;               // wave-uniform tap
         const long sn = (long)Cin * KK;
         const float* p = w + ((long)n * Cin + c) * KK + tap;
         f4 v; v.x = p[0]; v.y = p[sn]; v.z = p[2 * sn]; v.w = p[3 * sn]; return v;
@@ -255,6 +311,18 @@ struct BLConvWT2 {
         const int py = cls >> 1, px = cls & 1;
         if (c >= Cin || k >= (1 + py) * (1 + px) * N) return zero4();
         const int tt = k / N, n = k - tt * N;
+        const int khi = tt / (1 + px), kwi = tt - khi * (1 + px);
+        const int kh = py ? 2 * khi : 1, kw = px ? 2 * kwi : 1;
+        const long sn = (long)Cin * 9;
+        const float* p = w + ((long)n * Cin + c) * 9 + kh * 3 + kw;
+        f4 v; v.x = p[0]; v.y = p[sn]; v.z = p[2 * sn]; v.w = p[3 * sn]; return v;
+    }
+    template <int KCH> __device__ __forceinline__ f4 load2(int nblk, int t, int i, int k0, int bk, int Kt, int cls) const {
+        if (N % KCH != 0) return load(nblk, t, i, k0 + bk, Kt, cls);
+        const int c = col(nblk, t, i);
+        const int py = cls >> 1, px = cls & 1;
+        if (c >= Cin || k0 + bk >= (1 + py) * (1 + px) * N) return zero4();
+        const int tt = k0 / N, n = k0 - tt * N + bk;                 // wave-uniform live-tap index
         const int khi = tt / (1 + px), kwi = tt - khi * (1 + px);
         const int kh = py ? 2 * khi : 1, kw = px ? 2 * kwi : 1;
         const long sn = (long)Cin * 9;
@@ -587,15 +655,24 @@ static inline int launch_gemm16(const AL& al, const BL& bl, const EP& ep, int M,
 template <int NT, int KCH, int NBUF, int RW, class AL, class BL, class EP>
 __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_lds_kernel(AL al, BL bl, EP ep, int M, int K, int nblocks_n) {
     constexpr int BM = 64 * RW;
-    constexpr int LD = KCH + 4;                      // 16-lane b128 reads of rows i=0..15 hit banks 4i..4i+3: conflict-free
+    // ds_read_b128 is serviced in 4 groups of 16 lanes, {0-3,12-15,20-27}, ...: rows {0-3,12-15} at k-offset 4q and rows
+    // {4-11} at 4(q+1) share a group.  A row stride == 8 (mod 16) dwords puts the 16 starts on 16 distinct 4-bank slots
+    // (conflict-free, 4 LDS cycles); the KCH + 4 used first was 2-way conflicted (PMC: 39 % of LDS cycles were conflicts)
+    constexpr int LD = KCH + 8;
     constexpr int K4 = KCH / 4;                      // float4 slots per staged row
     constexpr int BN = NT * 16;
     constexpr int RA = (BM * K4 + 255) / 256, RB = (BN * K4 + 255) / 256;
-    constexpr int LDO = BN + 4;                      // accumulator transposition tile of the row-layout epilogue (aliases A/B)
-    static_assert((BM + BN) * LD >= 64 * LDO, "epilogue tile must fit in the operand buffers");
-    __shared__ __attribute__((aligned(16))) float smem[NBUF * (BM + BN) * LD];
+    // transposed weights (dgrad: W is [k][n], n contiguous) stay in their natural [k][n] layout in LDS: 16-byte stores,
+    // B fragments by 4 x ds_read_b32 (rows 4q+j land in distinct 16-bank halves when LDN == 4 mod 8).  Transposing on
+    // the way in cost 4 scalar stores per float4 with 8- to 16-way bank conflicts.
+    constexpr int LDN = BN + 4;
+    constexpr int BSZ = BL::kTrans ? KCH * LDN : BN * LD;
+    constexpr int LDO = 64;                          // accumulator transposition tile of the row-layout epilogue (aliases A/B);
+                                                     // 256-byte rows: the (row q, 16-byte column c4) reads are conflict-free
+    static_assert(BM * LD + BSZ >= 64 * LDO, "epilogue tile must fit in the operand buffers");
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * (BM * LD + BSZ)];
     float (*sA)[BM * LD] = reinterpret_cast<float (*)[BM * LD]>(smem);
-    float (*sB)[BN * LD] = reinterpret_cast<float (*)[BN * LD]>(smem + NBUF * BM * LD);
+    float (*sB)[BSZ] = reinterpret_cast<float (*)[BSZ]>(smem + NBUF * BM * LD);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     // XCD-aware 1-D grid: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2).  All n-blocks of
@@ -615,6 +692,9 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
         aok[p] = e < BM * K4;
         ast[p] = al.init(brow0 + (aok[p] ? r : 0), M, 0, false);
         ak[p] = k4; al_off[p] = r * LD + k4;
+        // 256 % K4 == 0: every slot of a thread has the same k offset -> say so, and the k -> (tap, channel) decode of the
+        // im2col / stem loaders is computed once per chunk instead of once per slot
+        if constexpr (256 % K4 == 0) ak[p] = ak[0];
     }
     int bk[RB], bn[RB], bl_off[RB]; bool bok[RB];
 #pragma unroll
@@ -622,7 +702,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
         const int e = tid + 256 * p;
         bok[p] = e < BN * K4;
         if (!BL::kTrans) { const int nl = e / K4, k4 = (e - nl * K4) * 4; bn[p] = nl; bk[p] = k4; bl_off[p] = nl * LD + k4; }
-        else { const int kl = e / (BN / 4), n4 = (e - kl * (BN / 4)) * 4; bn[p] = n4; bk[p] = kl; bl_off[p] = n4 * LD + kl; }
+        else { const int kl = e / (BN / 4), n4 = (e - kl * (BN / 4)) * 4; bn[p] = n4; bk[p] = kl; bl_off[p] = kl * LDN + n4; }
     }
     // parity-class conv dgrad: the live-tap count (hence K) depends on the class of the rows; the caller guarantees
     // that a 64-row workgroup never mixes classes, so both are workgroup-uniform
@@ -631,12 +711,12 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
     f4 ra[RA], rb[RB];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int p = 0; p < RA; ++p) ra[p] = aok[p] ? al.load(ast[p], k0 + ak[p], K) : zero4();
+        for (int p = 0; p < RA; ++p) ra[p] = aok[p] ? al.template load2<KCH>(ast[p], k0, ak[p], K) : zero4();
 #pragma unroll
         for (int p = 0; p < RB; ++p) {
             rb[p] = zero4();
             if (bok[p]) {
-                if (!BL::kTrans) rb[p] = bl.load(nblk, bn[p] >> 4, bn[p] & 15, k0 + bk[p], K, aux);
+                if (!BL::kTrans) rb[p] = bl.template load2<KCH>(nblk, bn[p] >> 4, bn[p] & 15, k0, bk[p], K, aux);
                 else rb[p] = bl.load_n4(nblk, bn[p], k0 + bk[p], K);
             }
         }
@@ -646,8 +726,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
         for (int p = 0; p < RA; ++p) if (aok[p]) *reinterpret_cast<f4*>(&sA[buf][al_off[p]]) = ra[p];
 #pragma unroll
         for (int p = 0; p < RB; ++p) if (bok[p]) {
-            if (!BL::kTrans) *reinterpret_cast<f4*>(&sB[buf][bl_off[p]]) = rb[p];
-            else { float* d = &sB[buf][bl_off[p]]; d[0] = rb[p].x; d[LD] = rb[p].y; d[2 * LD] = rb[p].z; d[3 * LD] = rb[p].w; }
+            *reinterpret_cast<f4*>(&sB[buf][bl_off[p]]) = rb[p];
         }
     };
     f4 acc[RW][NT];
@@ -659,7 +738,8 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
     fetch(0);
     stash(0);
     __syncthreads();
-    const int aoff = (16 * RW * wave + i) * LD + 4 * q, boff = i * LD + 4 * q;      // wave owns rows 16*RW*wave ..
+    const int aoff = (16 * RW * wave + i) * LD + 4 * q;                            // wave owns rows 16*RW*wave ..
+    const int boff = BL::kTrans ? (4 * q) * LDN + i : i * LD + 4 * q;
     for (int ch = 0; ch < nch; ++ch) {
         const int buf = NBUF == 1 ? 0 : (ch & 1);
         const bool more = ch + 1 < nch;
@@ -673,7 +753,13 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
             for (int w = 0; w < RW; ++w) av[w] = *reinterpret_cast<const f4*>(pa + 16 * w * LD + 16 * c);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const f4 bv = *reinterpret_cast<const f4*>(pb + 16 * t * LD + 16 * c);
+                f4 bv;
+                if constexpr (BL::kTrans) {
+                    const float* pt = pb + (16 * c) * LDN + 16 * t;
+                    bv.x = pt[0]; bv.y = pt[LDN]; bv.z = pt[2 * LDN]; bv.w = pt[3 * LDN];
+                } else {
+                    bv = *reinterpret_cast<const f4*>(pb + 16 * t * LD + 16 * c);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
