@@ -1157,12 +1157,15 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
     static_assert(TN % WA == 0 && TK % WB == 0 && NWN * NWK * MS == 4, "4 waves must tile the workgroup");
     constexpr int STEPS = RC / 16;
     static_assert(STEPS % MS == 0, "row steps must split evenly over the waves");
-    constexpr int LDR = RC + 4;
+    // dY / X chunks stay in their natural [row][col] layout in LDS: 16-byte stores (conflict-free), MFMA fragments by
+    // 4 x ds_read_b32 -- rows 4q+j of a 32-lane group land in distinct 16-bank halves because LDN, LDK == 4 (mod 8).
+    // (The first version transposed on the way in: 4 scalar stores per float4 with 6- to 12-way bank conflicts.)
+    constexpr int LDN = 16 * TN + 4, LDK = 16 * TK + 4;
     constexpr int C4N = TN * 4, C4K = TK * 4;
     constexpr int NV = C4N * RC, KV = C4K * RC;
     constexpr int RN = (NV + 255) / 256, RK = (KV + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float sdy[2][16 * TN * LDR];
-    __shared__ __attribute__((aligned(16))) float sx[2][16 * TK * LDR];
+    __shared__ __attribute__((aligned(16))) float sdy[2][RC * LDN];
+    __shared__ __attribute__((aligned(16))) float sx[2][RC * LDK];
     __shared__ float sbias[16 * TN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -1181,15 +1184,15 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < RN; ++e) {
         const int s = tid + 256 * e, r = s / C4N, c = (s - r * C4N) * 4;
-        nr[e] = r; nl[e] = c * LDR + r; nok[e] = s < NV && n0 + c < N;
+        nr[e] = r; nl[e] = r * LDN + c; nok[e] = s < NV && n0 + c < N;
         noff[e] = (long)r * lddy + n0 + c;
     }
 #pragma unroll
     for (int e = 0; e < RK; ++e) {
         const int s = tid + 256 * e, r = s / C4K, c = (s - r * C4K) * 4;
-        kr[e] = r; kl[e] = c * LDR + r; kc[e] = k0 + c; kok[e] = s < KV && k0 + c < K;
+        kr[e] = r; kl[e] = r * LDK + c; kc[e] = k0 + c; kok[e] = s < KV && k0 + c < K;
     }
-    const int offA = (16 * wa * WA + i) * LDR + 4 * q, offB = (16 * wb * WB + i) * LDR + 4 * q;
+    const int offA = (4 * q) * LDN + 16 * wa * WA + i, offB = (4 * q) * LDK + 16 * wb * WB + i;
     f4 acc[WA][WB], bacc[RN];
 #pragma unroll
     for (int a = 0; a < WA; ++a)
@@ -1208,18 +1211,12 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
     auto stash = [&](int buf) {
 #pragma unroll
         for (int e = 0; e < RN; ++e) {
-            if (tid + 256 * e < NV) {
-                float* d = &sdy[buf][nl[e]];
-                d[0] = rn[e].x; d[LDR] = rn[e].y; d[2 * LDR] = rn[e].z; d[3 * LDR] = rn[e].w;
-            }
+            if (tid + 256 * e < NV) *reinterpret_cast<f4*>(&sdy[buf][nl[e]]) = rn[e];
             bacc[e] += rn[e];
         }
 #pragma unroll
         for (int e = 0; e < RK; ++e)
-            if (tid + 256 * e < KV) {
-                float* d = &sx[buf][kl[e]];
-                d[0] = rk[e].x; d[LDR] = rk[e].y; d[2 * LDR] = rk[e].z; d[3 * LDR] = rk[e].w;
-            }
+            if (tid + 256 * e < KV) *reinterpret_cast<f4*>(&sx[buf][kl[e]]) = rk[e];
     };
     int buf = 0;
     fetch(mbeg);
@@ -1234,9 +1231,15 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
         for (int st = ws; st < STEPS; st += MS) {
             f4 av[WA], bv[WB];
 #pragma unroll
-            for (int a = 0; a < WA; ++a) av[a] = *reinterpret_cast<const f4*>(pdy + 16 * a * LDR + 16 * st);
+            for (int a = 0; a < WA; ++a) {
+                const float* t = pdy + (16 * st) * LDN + 16 * a;
+                av[a].x = t[0]; av[a].y = t[LDN]; av[a].z = t[2 * LDN]; av[a].w = t[3 * LDN];
+            }
 #pragma unroll
-            for (int b = 0; b < WB; ++b) bv[b] = *reinterpret_cast<const f4*>(px + 16 * b * LDR + 16 * st);
+            for (int b = 0; b < WB; ++b) {
+                const float* t = px + (16 * st) * LDK + 16 * b;
+                bv[b].x = t[0]; bv[b].y = t[LDK]; bv[b].z = t[2 * LDK]; bv[b].w = t[3 * LDK];
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1263,7 +1266,7 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < RN; ++e)
             if (tid + 256 * e < NV) {
-                const int c = (nl[e] - nr[e]) / LDR;
+                const int c = nl[e] - nr[e] * LDN;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) atomicAdd(&sbias[c + j], bacc[e][j]);
             }
