@@ -1006,13 +1006,13 @@ template <int TN, int TK, class XL>
 __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ dy, long lddy, XL xl, float* dW, long ldw,
                                                       float* dbias, int M, int N, int K, int rows_per_block, int dbg) {
     constexpr int RC = 32;                                  // rows per staged chunk
-    constexpr int LDR = RC + 4;                             // LDS leading dimension (rows) of a column: 144 B, odd multiple of 16 B
+    constexpr int LDN = 16 * TN + 4, LDK = 16 * TK + 4;    // natural [row][col] LDS tiles, see wgradw_kernel
     constexpr int C4N = TN * 4, C4K = TK * 4;               // float4 slots per staged row
     constexpr int NV = C4N * RC, KV = C4K * RC;
     constexpr int RN = (NV + 255) / 256, RK = (KV + 255) / 256;
     constexpr int NTILE = TN * TK, TPW = (NTILE + 3) / 4;   // tiles per wave
-    __shared__ __attribute__((aligned(16))) float sdy[2][16 * TN * LDR];
-    __shared__ __attribute__((aligned(16))) float sx[2][16 * TK * LDR];
+    __shared__ __attribute__((aligned(16))) float sdy[2][RC * LDN];
+    __shared__ __attribute__((aligned(16))) float sx[2][RC * LDK];
     __shared__ float sbias[16 * TN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -1027,13 +1027,13 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
 #pragma unroll
     for (int e = 0; e < RN; ++e) {
         const int s = tid + 256 * e, r = s / C4N, c = (s - r * C4N) * 4;
-        nr[e] = r; nl[e] = c * LDR + r; nok[e] = s < NV && n0 + c < N;
+        nr[e] = r; nl[e] = r * LDN + c; nok[e] = s < NV && n0 + c < N;
         np[e] = dy + (long)(mbeg + r) * lddy + n0 + c;
     }
 #pragma unroll
     for (int e = 0; e < RK; ++e) {
         const int s = tid + 256 * e, r = s / C4K, c = (s - r * C4K) * 4;
-        kr[e] = r; kl[e] = c * LDR + r; kc[e] = k0 + c; kok[e] = s < KV && k0 + c < K;
+        kr[e] = r; kl[e] = r * LDK + c; kc[e] = k0 + c; kok[e] = s < KV && k0 + c < K;
     }
     int offA[TPW], offB[TPW]; bool tok[TPW];
 #pragma unroll
@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
         const int tile = wave + 4 * t;
         tok[t] = tile < NTILE;
         const int a = tok[t] ? tile / TK : 0, b = tok[t] ? tile - a * TK : 0;
-        offA[t] = (16 * a + i) * LDR + 4 * q; offB[t] = (16 * b + i) * LDR + 4 * q;
+        offA[t] = (4 * q) * LDN + 16 * a + i; offB[t] = (4 * q) * LDK + 16 * b + i;
     }
     f4 acc[TPW], bacc[RN];
 #pragma unroll
@@ -1062,18 +1062,12 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
     auto stash = [&](int buf) {
 #pragma unroll
         for (int e = 0; e < RN; ++e) {
-            if (tid + 256 * e < NV) {
-                float* d = &sdy[buf][nl[e]];
-                d[0] = rn[e].x; d[LDR] = rn[e].y; d[2 * LDR] = rn[e].z; d[3 * LDR] = rn[e].w;
-            }
+            if (tid + 256 * e < NV) *reinterpret_cast<f4*>(&sdy[buf][nl[e]]) = rn[e];
             bacc[e] += rn[e];
         }
 #pragma unroll
         for (int e = 0; e < RK; ++e)
-            if (tid + 256 * e < KV) {
-                float* d = &sx[buf][kl[e]];
-                d[0] = rk[e].x; d[LDR] = rk[e].y; d[2 * LDR] = rk[e].z; d[3 * LDR] = rk[e].w;
-            }
+            if (tid + 256 * e < KV) *reinterpret_cast<f4*>(&sx[buf][kl[e]]) = rk[e];
     };
     int buf = 0;
     if (mbeg < mend) { fetch(mbeg); stash(0); }
@@ -1088,8 +1082,11 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
 #pragma unroll
             for (int t = 0; t < TPW; ++t)
                 if (tok[t] && !(dbg & 2)) {
-                    const f4 av = *reinterpret_cast<const f4*>(pdy + offA[t] + 16 * st);   // rows 16st+4q .. +3 of column (a, i)
-                    const f4 bv = *reinterpret_cast<const f4*>(px + offB[t] + 16 * st);
+                    const float* ta = pdy + offA[t] + (16 * st) * LDN;                    // rows 16st+4q .. +3 of column (a, i)
+                    const float* tb = px + offB[t] + (16 * st) * LDK;
+                    f4 av, bv;
+                    av.x = ta[0]; av.y = ta[LDN]; av.z = ta[2 * LDN]; av.w = ta[3 * LDN];
+                    bv.x = tb[0]; bv.y = tb[LDK]; bv.z = tb[2 * LDK]; bv.w = tb[3 * LDK];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[t] = mfma16(av[j], bv[j], acc[t]);
                 }
@@ -1113,7 +1110,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < RN; ++e)
             if (tid + 256 * e < NV) {
-                const int c = (nl[e] - nr[e]) / LDR;
+                const int c = nl[e] - nr[e] * LDN;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) atomicAdd(&sbias[c + j], bacc[e][j]);
             }
