@@ -202,17 +202,20 @@ def main():
     dt = float(t_max)
     # roofline of the dominant kernel: a few extra eager steps with HIP events around each of its launches
     roofline = None
-    if not args.no_roofline and rank == 0:
-        probe = ops.KernelProbe()
+    if not args.no_roofline:
+        # EVERY rank runs the two probe steps (a step contains collectives: a rank-0-only step would dead-lock N > 1);
+        # only rank 0 brackets the kernel with events and reports
+        probe = ops.KernelProbe() if rank == 0 else None
         n_streams, eng.n_streams = eng.n_streams, 1      # isolated launches: no co-running kernels inside the event bracket
         for s in range(2):
             eng.step(ev, labels, label_tb, first_mask(1))
         eng.n_streams = n_streams
-        roofline = probe.finish(PEAK_HBM_GBS)
+        if probe is not None:
+            roofline = probe.finish(PEAK_HBM_GBS)
         # HBM bytes per launch of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
         # separate rocprofv3 --pmc runs; bench.py itself cannot sample hardware counters)
         tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
-        if roofline is not None and os.path.exists(tpath):
+        if rank == 0 and roofline is not None and os.path.exists(tpath):
             roofline['traffic'] = json.load(open(tpath)).get('hbm_bytes_per_launch')
     barrier()
     loss_val = float(losses['loss'])

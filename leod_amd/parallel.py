@@ -100,9 +100,12 @@ def init_distributed(backend: Optional[str] = None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # functional testing of the N > 1 path on a single GPU: LEOD_DIST_BACKEND=gloo LEOD_FORCE_LOCAL_DEVICE=0
+    if 'LEOD_FORCE_LOCAL_DEVICE' in os.environ:
+        local = int(os.environ['LEOD_FORCE_LOCAL_DEVICE'])
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('LEOD_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend == 'nccl':

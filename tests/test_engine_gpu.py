@@ -168,3 +168,63 @@ def test_pseudo_label_inference_vs_oracle(gpu, manifest):
     assert [int(c) for c in lcnt.cpu()] == [len(r) for r in rl]
     for i, r in enumerate(rl):
         np.testing.assert_allclose(lab[i, :len(r)].cpu().numpy(), r.numpy(), rtol=2e-4, atol=2e-4)
+
+
+# ---- world-size 2 on ONE GPU (gloo carries the device tensors): SyncBatchNorm + gradient all-reduce end to end -------------
+def _world2_worker(rank, port, manifest, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=2)
+    from leod_amd.engine import TrainEngine
+    det, _ = micro_detector(manifest, 9)
+    eng = TrainEngine(det, lr=2e-4, total_steps=1000)
+    T, B = 4, 4
+    ev = synth_events(T, B, 20, 60, 90, seed=70, as_uint8=True)
+    labs_all = micro_labels(T * B, seed=71)
+    mine = [2 * rank, 2 * rank + 1]                                   # this rank's half of the global batch
+    label_tb = [[], [0, 1], [], [0, 1]]
+    labs = [labs_all[t * B + mine[b]] for t in range(T) for b in label_tb[t]]
+    labels = op.batched_yolox_labels(labs).to(DEV)
+    losses = eng.step(ev[:, mine].to(DEV), labels, label_tb, torch.ones(2, dtype=torch.bool, device=DEV))
+    bns = [m.bn for m in det.modules() if hasattr(m, 'bn')]
+    q.put((rank, float(losses['loss']), eng.flat.data.detach().cpu().numpy(),
+           np.concatenate([b.running_mean.detach().cpu().numpy() for b in bns]),
+           np.concatenate([b.running_var.detach().cpu().numpy() for b in bns])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_syncbn_and_replica_consistency(gpu, manifest):
+    """Two ranks (each half of a batch of 4 sequences) through the whole HIP training step with the data-parallel engine:
+    the replicas must end bit-identical (same all-reduced gradients, same optimiser step), and the SyncBatchNorm running
+    statistics must equal those of ONE process that sees the full batch (train.py:247 sync_batchnorm semantics)."""
+    import torch.multiprocessing as mp
+    from leod_amd.engine import TrainEngine
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31000 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_world2_worker, args=(r, port, manifest, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(res[0][2], res[1][2])               # replicas identical after the step
+    np.testing.assert_array_equal(res[0][3], res[1][3])
+    np.testing.assert_array_equal(res[0][4], res[1][4])
+    # single process, full batch: BatchNorm statistics of the forward pass are the global ones
+    det, _ = micro_detector(manifest, 9)
+    eng = TrainEngine(det, lr=2e-4, total_steps=1000)
+    T, B = 4, 4
+    ev = synth_events(T, B, 20, 60, 90, seed=70, as_uint8=True)
+    labs_all = micro_labels(T * B, seed=71)
+    label_tb = [[], [0, 1, 2, 3], [], [0, 1, 2, 3]]
+    labs = [labs_all[t * B + b] for t in range(T) for b in label_tb[t]]
+    eng.step(ev.to(DEV), op.batched_yolox_labels(labs).to(DEV), label_tb, torch.ones(B, dtype=torch.bool, device=DEV))
+    bns = [m.bn for m in det.modules() if hasattr(m, 'bn')]
+    rm = np.concatenate([b.running_mean.detach().cpu().numpy() for b in bns])
+    rv = np.concatenate([b.running_var.detach().cpu().numpy() for b in bns])
+    np.testing.assert_allclose(res[0][3], rm, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(res[0][4], rv, rtol=2e-5, atol=1e-6)
