@@ -25,6 +25,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0           # MI355X HBM3E peak (MI355X_MICROARCH.md)
+PEAK_F32_MFMA_TFLOPS = 157.3    # dense fp32 MFMA peak: 256 FLOP/clk/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md)
 # SURVEY 8d / DESIGN.md: algorithmic HBM traffic of one RVT-S training event-frame at fp32 activations
 # = 2 x the bf16 figure for activations (2 x (68.61 + 32/168*29.01)) + 395/168 MB optimiser traffic
 ALGO_MB_PER_FRAME_FP32 = 2 * (68.61 + 32.0 / 168.0 * 29.01) + 395.0 / 168.0
@@ -211,7 +212,7 @@ def main():
             eng.step(ev, labels, label_tb, first_mask(1))
         eng.n_streams = n_streams
         if probe is not None:
-            roofline = probe.finish(PEAK_HBM_GBS)
+            roofline = probe.finish(PEAK_HBM_GBS, PEAK_F32_MFMA_TFLOPS)
         # HBM bytes per launch of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
         # separate rocprofv3 --pmc runs; bench.py itself cannot sample hardware counters)
         tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')

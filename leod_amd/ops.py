@@ -175,7 +175,8 @@ def linear_wgrad(dy, x, dW, dbias=None, stats=None, ln_w=None, ln_b=None, x2=Non
     K = dW.numel() // N
     M = dy.numel() // N
     K1 = x.shape[-1]
-    ev = _probe('linear_wgrad', 4.0 * (M * N + M * K + N * K))      # reads dy, X ; read-modify-writes dW (counted once)
+    # algorithmic work of one launch: reads dy, X once, read-modify-writes dW once; 2*M*N*K flops
+    ev = _probe('linear_wgrad', 4.0 * (M * N + M * K + N * K), 2.0 * M * N * K)
     check(_l().leod_linear_wgrad(_p(dy), N, _p(x), K1, _p(stats), _p(ln_w), _p(ln_b), _p(x2),
                                   (x2.shape[-1] if x2 is not None else 0), K1, _p(dW), _p(dbias), M, N, K, _stream()),
           'linear_wgrad')
@@ -465,17 +466,21 @@ class KernelProbe:
     def __init__(self, target: str = 'linear_wgrad', kernel_name: str = 'wgradw_kernel<.., XRows>'):
         global _PROBE
         self.target, self.kernel_name = target, kernel_name
-        self.events, self.bytes = [], 0.0
+        self.events, self.bytes, self.flops = [], 0.0, 0.0
         _PROBE = self
 
-    def begin(self, nbytes):
+    def begin(self, nbytes, flops=0.0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         self.events.append((e0, e1))
         self.bytes += nbytes
+        self.flops += flops
         return e1
 
-    def finish(self, peak_gbs):
+    def finish(self, peak_gbs, peak_tflops=157.3):
+        """Roofline object of the probed kernel family.  The bound is chosen by the family's arithmetic intensity
+        (sum flops / sum algorithmic bytes) against the ridge peak_tflops / peak_gbs; ``achieved`` is in the unit of that
+        bound, the other roof is reported alongside."""
         global _PROBE
         _PROBE = None
         torch.cuda.synchronize()
@@ -483,13 +488,23 @@ class KernelProbe:
             return None
         ms = sum(a.elapsed_time(b) for a, b in self.events)
         n = len(self.events)
-        achieved = self.bytes / (ms * 1e-3) / 1e9
-        return {'bound': 'hbm', 'kernel': self.kernel_name, 'launches': n, 'avg_us': round(1e3 * ms / n, 3),
-                'algorithmic_bytes_per_launch': round(self.bytes / n, 1), 'achieved': round(achieved, 2),
-                'peak': peak_gbs, 'unit': 'GB/s', 'frac': round(achieved / peak_gbs, 5), 'traffic': None}
+        gbs = self.bytes / (ms * 1e-3) / 1e9
+        tfl = self.flops / (ms * 1e-3) / 1e12
+        ridge = peak_tflops * 1e12 / (peak_gbs * 1e9)
+        intensity = self.flops / max(self.bytes, 1.0)
+        out = {'kernel': self.kernel_name, 'launches': n, 'avg_us': round(1e3 * ms / n, 3),
+               'algorithmic_bytes_per_launch': round(self.bytes / n, 1), 'algorithmic_flops_per_launch': round(self.flops / n, 1),
+               'flop_per_byte': round(intensity, 2), 'ridge_flop_per_byte': round(ridge, 2),
+               'hbm_achieved_GBs': round(gbs, 2), 'hbm_frac': round(gbs / peak_gbs, 5),
+               'mfma_achieved_TFLOPs': round(tfl, 2), 'mfma_frac': round(tfl / peak_tflops, 5), 'traffic': None}
+        if intensity >= ridge:
+            out.update(bound='mfma', achieved=round(tfl, 2), peak=peak_tflops, unit='TFLOP/s', frac=round(tfl / peak_tflops, 5))
+        else:
+            out.update(bound='hbm', achieved=round(gbs, 2), peak=peak_gbs, unit='GB/s', frac=round(gbs / peak_gbs, 5))
+        return out
 
 
-def _probe(name, nbytes):
+def _probe(name, nbytes, flops=0.0):
     if _PROBE is not None and _PROBE.target == name:
-        return _PROBE.begin(nbytes)
+        return _PROBE.begin(nbytes, flops)
     return None
