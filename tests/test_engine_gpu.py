@@ -228,3 +228,100 @@ def test_world2_syncbn_and_replica_consistency(gpu, manifest):
     rv = np.concatenate([b.running_var.detach().cpu().numpy() for b in bns])
     np.testing.assert_allclose(res[0][3], rm, rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(res[0][4], rv, rtol=2e-5, atol=1e-6)
+
+
+# ---- BASELINE.json configs[1] size (RVT-S, Gen1 240x304, T=21, bs=8): size-independent properties -----------------------
+def _full_size_engine(seed=0):
+    from leod_amd.config import full_config, dynamically_modify_train_config
+    from leod_amd.models.detection.yolox_extension.models.detector import YoloXDetector
+    from leod_amd.engine import TrainEngine
+    cfg = dynamically_modify_train_config(full_config('gen1', 'small'))
+    torch.manual_seed(seed)
+    det = YoloXDetector(cfg.model).to(DEV)
+    return TrainEngine(det, lr=cfg.training.learning_rate), det
+
+
+def _full_size_batch(T=21, B=8, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    mask = torch.rand((T, B, 20, 240, 304), generator=g) < 0.08
+    ev = (mask * torch.randint(1, 10, (T, B, 20, 240, 304), generator=g)).to(torch.uint8)
+    rng = np.random.RandomState(seed)
+    label_tb, rows = [], []
+    for t in range(T):
+        idx = list(range(B)) if t in (4, 9, 14, 19) else []
+        label_tb.append(idx)
+        for _ in idx:
+            n = rng.randint(1, 6)
+            w, h = rng.uniform(10, 90, n), rng.uniform(10, 70, n)
+            x, y = rng.uniform(0, 303 - w), rng.uniform(0, 239 - h)
+            rows.append(np.stack([rng.randint(0, 2, n), x + w / 2, y + h / 2, w, h, np.ones(n), np.ones(n)], 1).astype(np.float32))
+    nmax = max(len(r) for r in rows)
+    lab = np.zeros((len(rows), nmax, 7), np.float32)
+    for i, r in enumerate(rows):
+        lab[i, :len(r)] = r
+    return ev.to(DEV), torch.from_numpy(lab).to(DEV), label_tb
+
+
+def test_full_size_schedule_invariance(gpu):
+    """At the benchmark size the stage-major time-batched schedule and the reference's timestep-major loop are the same
+    function: losses, final LSTM states and the updated parameters of one training step agree."""
+    ev, labels, label_tb = _full_size_batch()
+    first = torch.ones(8, dtype=torch.bool, device=DEV)
+    out = {}
+    for sched in ('batched', 'wavefront'):
+        eng, det = _full_size_engine(0)
+        eng.schedule, eng.n_streams = sched, 1
+        losses = eng.step(ev, labels, label_tb, first)
+        out[sched] = (np.array([float(losses[k]) for k in KEYS]), eng.flat.data.detach().cpu().numpy(),
+                      [c.detach().cpu().numpy() for _, c in eng.states])
+    np.testing.assert_allclose(out['batched'][0], out['wavefront'][0], rtol=2e-5, atol=1e-6)
+    for a, b in zip(out['batched'][2], out['wavefront'][2]):
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-5)
+    d = np.abs(out['batched'][1] - out['wavefront'][1])
+    assert d.max() < 4.5e-4                                   # <= 2 * lr: Adam sign flips on noise-level gradients only
+    assert (d > 2e-6 + 1e-4 * np.abs(out['wavefront'][1])).mean() < 5e-3
+
+
+def test_full_size_pseudo_label_pass_properties(gpu):
+    """Pseudo-label pass at the benchmark resolution (hflip TTA on): (1) permuting the sequences of the batch permutes the
+    outputs and changes nothing else (no kernel mixes batch entries: partition index math, time-batched row order, NMS
+    per image); (2) a recording processed as two chunks with the LSTM state carried over gives the same detections as one
+    long chunk (RNN state hand-over of pseudo_labeler.py:687-722 under the time-batched schedule)."""
+    from leod_amd.engine import PseudoLabelEngine
+    _, det = _full_size_engine(1)
+    T, B = 10, 4
+    ev, _, _ = _full_size_batch(T=T, B=B, seed=5)
+
+    def run(chunks, perm=None):
+        # random-init heads score every anchor ~1e-4 (bias -log 99): a threshold below that keeps a few hundred boxes/frame
+        eng = PseudoLabelEngine(det, 2, conf_thre=9.5e-5, hflip=True, max_det=512)
+        outs = []
+        for lo, hi in chunks:
+            x = ev[lo:hi] if perm is None else ev[lo:hi][:, perm]
+            lab, lcnt, dets, cnt = eng.step(x)
+            n = hi - lo
+            outs.append((dets.view(n, 2 * B, *dets.shape[1:]).cpu().numpy(), cnt.view(n, 2 * B).cpu().numpy()))
+        return np.concatenate([o[0] for o in outs], 0), np.concatenate([o[1] for o in outs], 0)
+
+    d0, c0 = run([(0, T)])
+    assert int(c0.sum()) > 0
+    # (1) batch permutation (applied to the sequences; the hflip copies follow their sources)
+    perm = torch.tensor([2, 0, 3, 1], device=DEV)
+    d1, c1 = run([(0, T)], perm)
+    p = perm.cpu().numpy()
+    idx = np.concatenate([p, B + p])
+    np.testing.assert_array_equal(c1, c0[:, idx])
+    for t in range(T):
+        for j, src in enumerate(idx):
+            n = c0[t, src]
+            np.testing.assert_allclose(d1[t, j, :n], d0[t, src, :n], rtol=1e-5, atol=1e-5)
+    # (2) chunked == one pass
+    d2, c2 = run([(0, 4), (4, T)])
+    np.testing.assert_array_equal(c2, c0)
+
+    def canon(a):                                             # random-init scores tie to ~1e-7: compare as a set of boxes
+        return a[np.lexsort((np.round(a[:, 1], 2), np.round(a[:, 0], 2)))]
+
+    for t in range(T):
+        for b in range(2 * B):
+            np.testing.assert_allclose(canon(d2[t, b, :c0[t, b]]), canon(d0[t, b, :c0[t, b]]), rtol=2e-4, atol=2e-4)
