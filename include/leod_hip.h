@@ -74,6 +74,11 @@ int leod_layernorm_bwd(const float* dn, const float* x, const float* stats, cons
 /* LayerScale autograd: dt = gamma*dz ; dgamma += sum_m dz*t (maxvit.py:45-53). */
 int leod_layerscale_bwd(const float* dz, const float* t, const float* gamma, float* dt, float* dgamma, int M, int C,
                         leod_stream_t stream);
+/* LayerScale autograd without the stored pre-scale tensor t = h W^T + b (maxvit.py:45-53, :268-269): from the UN-scaled
+ * weight gradient G[N,K] = dz^T h and s[N] = colsum(dz) of the Linear in front of the LayerScale:
+ * dW += diag(gamma) G ; db += gamma*s ; dgamma[n] += sum_k W[n,k] G[n,k] + b[n] s[n]. */
+int leod_layerscale_finalize(const float* W, const float* b, const float* gamma, const float* G, const float* s, float* dW,
+                             float* db, float* dgamma, int N, int K, leod_stream_t stream);
 
 /* ---- convolutions (implicit GEMM, NHWC) --------------------------------------------------------- */
 

@@ -172,6 +172,37 @@ __global__ __launch_bounds__(256) void ls_bwd_kernel(const float* __restrict__ d
 }
 
 // ---------------------------------------------------------------------------------------------------
+// LayerScale gradient without the stored pre-scale tensor.  For z = res + gamma * (h W^T + b) and upstream dz:
+//   G = dz^T h (the UN-scaled weight gradient, from the wgrad kernel), s = colsum(dz)
+//   dW = diag(gamma) G ; db = gamma * s ; dgamma[n] = sum_m dz[m,n] t[m,n] = sum_k W[n,k] G[n,k] + b[n] s[n]
+// so neither t = h W^T + b (forward store) nor dt = gamma * dz (backward store) ever exist in HBM.  One wave per row n.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ls_finalize_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                          const float* __restrict__ gamma, const float* __restrict__ G,
+                                                          const float* __restrict__ s, float* __restrict__ dW,
+                                                          float* __restrict__ db, float* __restrict__ dgamma, int N, int K) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;                                       // wave-uniform
+    const float g = gamma[n];
+    const float* wr = W + (long)n * K;
+    const float* gr = G + (long)n * K;
+    float* dr = dW + (long)n * K;
+    float dot = 0.f;
+    for (int k = 4 * lane; k < K; k += 256) {
+        const f4 gv = ld4(gr + k), wv = ld4(wr + k);
+        dot += (gv.x * wv.x + gv.y * wv.y) + (gv.z * wv.z + gv.w * wv.w);
+        *reinterpret_cast<f4*>(dr + k) = ld4(dr + k) + g * gv;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    if (lane == 0) {
+        const float sn = s[n];
+        dgamma[n] += dot + (b ? b[n] * sn : 0.f);
+        if (db) db[n] += g * sn;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // ConvLSTM gate backward (models/layers/rnn.py:58-68): from dh (total grad of h_t) and dc_next to
 // pre-activation gate grads [M,4,C] and dc_prev.
 // ---------------------------------------------------------------------------------------------------
@@ -339,6 +370,14 @@ LEOD_API int leod_layerscale_bwd(const float* dz, const float* t, const float* g
     if (M <= 0) return LEOD_OK;
     const int grid = min(row_grid(M), 512);
     DISPATCH_CJ(C, hipLaunchKernelGGL((ls_bwd_kernel<CJ>), dim3(grid), dim3(256), 0, stream, dz, t, gamma, dt, dgamma, M, C));
+    return leod_launch_status();
+}
+
+LEOD_API int leod_layerscale_finalize(const float* W, const float* b, const float* gamma, const float* G, const float* s,
+                                      float* dW, float* db, float* dgamma, int N, int K, hipStream_t stream) {
+    if (!W || !gamma || !G || !s || !dW || !dgamma || (K & 3)) return LEOD_ERR_ARG;
+    if (N <= 0) return LEOD_OK;
+    hipLaunchKernelGGL(ls_finalize_kernel, dim3(cdiv(N, 4)), dim3(256), 0, stream, W, b, gamma, G, s, dW, db, dgamma, N, K);
     return leod_launch_status();
 }
 

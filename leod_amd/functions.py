@@ -149,35 +149,36 @@ class AttnBlockFn(Function):
         heads, part, window = mod.self_attn.num_heads, mod.partition_size, mod.partition_window
         qkv, _, st1 = ops.ln_linear_fwd(x, n1w, n1b, qkv_w, qkv_b, want_stats=need)
         o, lse = ops.partition_attn_fwd(qkv, heads, part, window, want_lse=need)
-        y, t1 = ops.linear_lsres_fwd(o, proj_w, proj_b, g1, x, want_t=need)
+        # the pre-LayerScale outputs are NOT stored: dgamma is recovered from the un-scaled weight gradient in backward
+        y, _ = ops.linear_lsres_fwd(o, proj_w, proj_b, g1, x, want_t=False)
         u, h, st2 = ops.ln_linear_fwd(y, n2w, n2b, fc1_w, fc1_b, want_act=True, want_stats=need)
-        z, t2 = ops.linear_lsres_fwd(h, fc2_w, fc2_b, g2, y, want_t=need)
+        z, _ = ops.linear_lsres_fwd(h, fc2_w, fc2_b, g2, y, want_t=False)
         if need:
             ctx.mod = mod
-            ctx.save_for_backward(x, qkv, st1, o, lse, y, t1, u, h, st2, t2, *params)
+            ctx.save_for_backward(x, qkv, st1, o, lse, y, u, h, st2, *params)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        (x, qkv, st1, o, lse, y, t1, u, h, st2, t2,
+        (x, qkv, st1, o, lse, y, u, h, st2,
          n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, g1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, g2) = ctx.saved_tensors
         mod = ctx.mod
         sa, mlp = mod.self_attn, mod.mlp
         heads, part, window = sa.num_heads, mod.partition_size, mod.partition_window
         dz = _cont(dz)
-        # ---- dgrad chain (critical path) ------------------------------------------------------------
-        dt2 = ops.layerscale_bwd(dz, t2, g2, grad_buf(mod.ls2.gamma))
-        du = ops.linear_dgrad(dt2, fc2_w, aux_u=u)
+        # ---- dgrad chain (critical path); LayerScale is folded into the dgrad loader (dz * gamma) -------------------------
+        du = ops.linear_dgrad(dz, fc2_w, kscale=g2, aux_u=u)
         dn2 = ops.linear_dgrad(du, fc1_w)
         dy = ops.layernorm_bwd(dn2, y, st2, n2w, dz, grad_buf(mod.norm2.weight), grad_buf(mod.norm2.bias))
-        dt1 = ops.layerscale_bwd(dy, t1, g1, grad_buf(mod.ls1.gamma))
-        do = ops.linear_dgrad(dt1, proj_w)
+        do = ops.linear_dgrad(dy, proj_w, kscale=g1)
         dqkv = ops.partition_attn_bwd(qkv, do, lse, heads, part, window)
         # ---- weight gradients: off the critical path (side stream when the engine enables it) ------
-        with _wgrad_side(dt2, h, du, y, st2, dt1, o, dqkv, x, st1):
-            ops.linear_wgrad(dt2, h, grad_buf(mlp.net[2].weight), grad_buf(mlp.net[2].bias))
+        with _wgrad_side(dz, h, du, y, st2, dy, o, dqkv, x, st1):
+            ops.layerscale_linear_wgrad(dz, h, fc2_w, fc2_b, g2, grad_buf(mlp.net[2].weight), grad_buf(mlp.net[2].bias),
+                                        grad_buf(mod.ls2.gamma))
             ops.linear_wgrad(du, y, grad_buf(mlp.net[0][0].weight), grad_buf(mlp.net[0][0].bias), stats=st2, ln_w=n2w, ln_b=n2b)
-            ops.linear_wgrad(dt1, o, grad_buf(sa.proj.weight), grad_buf(sa.proj.bias))
+            ops.layerscale_linear_wgrad(dy, o, proj_w, proj_b, g1, grad_buf(sa.proj.weight), grad_buf(sa.proj.bias),
+                                        grad_buf(mod.ls1.gamma))
             if n1w is not None:
                 ops.linear_wgrad(dqkv, x, grad_buf(sa.qkv.weight), grad_buf(sa.qkv.bias), stats=st1, ln_w=n1w, ln_b=n1b)
             else:
@@ -186,7 +187,10 @@ class AttnBlockFn(Function):
             dn1 = ops.linear_dgrad(dqkv, qkv_w)
             dx = ops.layernorm_bwd(dn1, x, st1, n1w, dy, grad_buf(mod.norm1.weight), grad_buf(mod.norm1.bias))
         else:
-            dx = ops.linear_dgrad(dqkv, qkv_w, out=dy, accumulate=True)     # dy is private to this backward
+            if WgradSide.active:                                            # dy is still being read on the side stream
+                dx = dy + ops.linear_dgrad(dqkv, qkv_w)
+            else:
+                dx = ops.linear_dgrad(dqkv, qkv_w, out=dy, accumulate=True) # dy is private to this backward
         return (None, dx) + (None,) * 14
 
 

@@ -216,6 +216,18 @@ def layerscale_bwd(dz, t, gamma, dgamma):
     return dt
 
 
+def layerscale_linear_wgrad(dz, h, W, b, gamma, dW, db, dgamma):
+    """Weight, bias and LayerScale gradients of z = res + gamma * (h W^T + b) from dz alone: the un-scaled G = dz^T h goes
+    into a scratch buffer (one wgrad launch), ``leod_layerscale_finalize`` turns it into dW, db and dgamma -- the stored
+    pre-scale tensor of the forward pass and the scaled copy of dz are not needed."""
+    N, K = W.shape
+    scratch = torch.zeros(N * K + N, dtype=torch.float32, device=dz.device)
+    G, s = scratch[:N * K].view(N, K), scratch[N * K:]
+    linear_wgrad(dz, h, G, s)
+    check(_l().leod_layerscale_finalize(_p(W), _p(b), _p(gamma), _p(G), _p(s), _p(dW), _p(db), _p(dgamma), N, K, _stream()),
+          'layerscale_finalize')
+
+
 # ---------------------------------------------------------------------------------------------------
 # convolutions
 # ---------------------------------------------------------------------------------------------------
