@@ -330,20 +330,21 @@ __device__ __forceinline__ long token_row(const AttnGeom& g, int p, int t) {
 }
 __device__ __forceinline__ f4 lds4(const float* p, bool ok) { return ok ? *reinterpret_cast<const f4*>(p) : zero4(); }
 
-template <int PT, int DCH, int HG>
+template <int PT, int D, int HG>
 __global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                       float* __restrict__ lse, AttnGeom g, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NTHR = 64 * PT * HG, TOK = 16 * PT;
+    // head dim D is a template parameter: every LDS offset below is a compile-time immediate off one base register
+    constexpr int NTHR = 64 * PT * HG, TOK = 16 * PT, DCH = (D + 15) / 16, d = D;
+    constexpr int S = HG * 3 * D + 4, F = HG * 3 * D / 4;
     __shared__ long srow[TOK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, rg = lane >> 4;
     const int hl = wave / PT, qt = wave - hl * PT;
     const int ngrp = g.heads / HG;
     const int p = blockIdx.x / ngrp, h0 = (blockIdx.x - p * ngrp) * HG;
-    const int P = g.ph * g.pw, d = g.d;
+    const int P = g.ph * g.pw;
     const long ld = 3L * g.C;
-    const int S = HG * 3 * d + 4, F = HG * 3 * d / 4;
     if (tid < TOK) srow[tid] = token_row(g, p, tid);
     __syncthreads();
     for (int e = tid; e < TOK * F; e += NTHR) {
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds_kernel(const float*
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int d4 = d / 4;
+    constexpr int d4 = D / 4;
     for (int e = lane; e < 16 * d4; e += 64) {
         const int tok = e / d4, c4 = e - tok * d4;
         const long row = srow[16 * qt + tok];
@@ -425,12 +426,14 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds_kernel(const float*
 
 // fused backward: phase 1 = query-owned (dQ, D), phase 2 = key-owned (dK, dV), then one coalesced store of the whole
 // [dq | dk | dv] segment of every token.  Probabilities are recomputed from lse in both phases.
-template <int PT, int DCH, int HG>
+template <int PT, int D, int HG>
 __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                       const float* __restrict__ lse, float* __restrict__ dqkv,
                                                                       AttnGeom g, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int NTHR = 64 * PT * HG, TOK = 16 * PT;
+    constexpr int NTHR = 64 * PT * HG, TOK = 16 * PT, DCH = (D + 15) / 16, d = D;
+    constexpr int S = HG * 3 * D + 4, F = HG * 3 * D / 4;
+    constexpr int Sd = HG * D + 4, Fd = HG * D / 4;
     __shared__ long srow[TOK];
     __shared__ float sL[HG * TOK], sD[HG * TOK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -438,10 +441,8 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float*
     const int hl = wave / PT, qt = wave - hl * PT;            // also the key tile of phase 2
     const int ngrp = g.heads / HG;
     const int p = blockIdx.x / ngrp, h0 = (blockIdx.x - p * ngrp) * HG;
-    const int P = g.ph * g.pw, d = g.d;
+    const int P = g.ph * g.pw;
     const long ld = 3L * g.C;
-    const int S = HG * 3 * d + 4, F = HG * 3 * d / 4;
-    const int Sd = HG * d + 4, Fd = HG * d / 4;
     float* sdo = smem + TOK * S;
     if (tid < TOK) srow[tid] = token_row(g, p, tid);
     __syncthreads();
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float*
                 }
             }
         }
-        float D = 0.f;
+        float Dq = 0.f;
 #pragma unroll
         for (int mt = 0; mt < PT; ++mt)
 #pragma unroll
@@ -499,10 +500,10 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float*
                 const int key = 16 * mt + 4 * rg + r;
                 const float pr = (key < P && qvalid) ? fast_exp(s[mt][r] * scale - l) : 0.f;
                 s[mt][r] = pr;
-                D += pr * dp[mt][r];
+                Dq += pr * dp[mt][r];
             }
-        D = quad16_sum(D);
-        if (rg == 0) sD[hl * TOK + 16 * qt + i] = D;
+        Dq = quad16_sum(Dq);
+        if (rg == 0) sD[hl * TOK + 16 * qt + i] = Dq;
 #pragma unroll
         for (int ct = 0; ct < DCH; ++ct) dq[ct] = zero4();
 #pragma unroll
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float*
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float* krow = hb + (16 * mt + 4 * rg + r) * S + d;
-                const float ds = s[mt][r] * (dp[mt][r] - D) * scale;
+                const float ds = s[mt][r] * (dp[mt][r] - Dq) * scale;
 #pragma unroll
                 for (int ct = 0; ct < DCH; ++ct) {
                     const float kk = 16 * ct + i < d ? krow[16 * ct + i] : 0.f;
@@ -585,19 +586,19 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float*
     }
 }
 
-template <int PT, int DCH, int HG>
+template <int PT, int D, int HG>
 static int run_attn_lds(int which, const float* qkv, const float* dout, float* out, float* lse, float* dqkv,
                         const AttnGeom& g, float scale, hipStream_t s) {
     const int NP = g.B * (g.H / g.ph) * (g.W / g.pw);
     const int nblk = NP * (g.heads / HG);
     if (nblk == 0) return LEOD_OK;
-    const int TOK = 16 * PT, S = HG * 3 * g.d + 4, Sd = HG * g.d + 4;
+    const int TOK = 16 * PT, S = HG * 3 * D + 4, Sd = HG * D + 4;
     if (which == 0) {
         const size_t lds = (size_t)TOK * S * sizeof(float);
-        hipLaunchKernelGGL((attn_fwd_lds_kernel<PT, DCH, HG>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, out, lse, g, scale);
+        hipLaunchKernelGGL((attn_fwd_lds_kernel<PT, D, HG>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, out, lse, g, scale);
     } else {
         const size_t lds = (size_t)TOK * (S + Sd) * sizeof(float);
-        hipLaunchKernelGGL((attn_bwd_lds_kernel<PT, DCH, HG>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, dout, lse, dqkv, g, scale);
+        hipLaunchKernelGGL((attn_bwd_lds_kernel<PT, D, HG>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, dout, lse, dqkv, g, scale);
     }
     return leod_launch_status();
 }
@@ -623,15 +624,15 @@ static int dispatch_attn(int which, const float* qkv, const float* dout, float* 
     const float scale = 1.0f / sqrtf((float)g.d);
     static const int use_lds = getenv("LEOD_ATTN_LDS") ? atoi(getenv("LEOD_ATTN_LDS")) : 1;
     const int HG = (g.heads % 2 == 0 && 2 * PT <= 16) ? 2 : 1;
-    const bool lds_shape = DCH <= 2 && (PT <= 5 || PT == 8 || (HG == 1 && (PT == 10 || PT == 15))) && !(PT == 3 && DCH == 1);
+    const bool lds_shape = (g.d == 24 || g.d == 32) && (PT <= 5 || PT == 8 || (HG == 1 && (PT == 10 || PT == 15)));
     if (use_lds && lds_shape) {
         // which: 0 forward, 1 fused backward (the register-direct path runs 1 = q pass, then 2 = kv pass)
         if (which == 2) return LEOD_OK;                       // the fused LDS backward already produced dK / dV
-#define ATTL(PTV, DV, HGV) if (PT == PTV && DCH == DV && HG == HGV) return run_attn_lds<PTV, DV, HGV>(which, qkv, dout, out, lse, dqkv, g, scale, s);
-        ATTL(1, 1, 1) ATTL(1, 1, 2) ATTL(1, 2, 1) ATTL(1, 2, 2) ATTL(2, 1, 1) ATTL(2, 1, 2) ATTL(2, 2, 1) ATTL(2, 2, 2)
-        ATTL(3, 2, 1) ATTL(3, 2, 2) ATTL(4, 1, 1) ATTL(4, 1, 2) ATTL(4, 2, 1) ATTL(4, 2, 2) ATTL(5, 1, 1) ATTL(5, 1, 2)
-        ATTL(5, 2, 1) ATTL(5, 2, 2) ATTL(8, 1, 1) ATTL(8, 1, 2) ATTL(8, 2, 1) ATTL(8, 2, 2) ATTL(10, 1, 1) ATTL(10, 2, 1)
-        ATTL(15, 1, 1) ATTL(15, 2, 1)
+#define ATTL(PTV, DV, HGV) if (PT == PTV && g.d == DV && HG == HGV) return run_attn_lds<PTV, DV, HGV>(which, qkv, dout, out, lse, dqkv, g, scale, s);
+#define ATTD(PTV, HGV) ATTL(PTV, 24, HGV) ATTL(PTV, 32, HGV)
+        ATTD(1, 1) ATTD(1, 2) ATTD(2, 1) ATTD(2, 2) ATTD(3, 1) ATTD(3, 2) ATTD(4, 1) ATTD(4, 2) ATTD(5, 1) ATTD(5, 2)
+        ATTD(8, 1) ATTD(8, 2) ATTD(10, 1) ATTD(15, 1)
+#undef ATTD
 #undef ATTL
         return LEOD_ERR_UNSUPPORTED;
     }

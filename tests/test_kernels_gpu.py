@@ -87,7 +87,10 @@ def _attn_ref(qkv, heads, part, window):
 
 @pytest.mark.parametrize('B,H,W,C,heads,part', [(2, 16, 20, 48, 2, (8, 10)), (1, 8, 10, 384, 16, (8, 10)),
                                                 (2, 4, 6, 16, 2, (2, 3)), (1, 12, 20, 64, 2, (6, 10)),
-                                                (3, 32, 40, 96, 4, (8, 10))])
+                                                (3, 32, 40, 96, 4, (8, 10)),
+                                                (1, 8, 10, 24, 1, (8, 10)),        # one head: single-head LDS workgroups
+                                                (1, 12, 20, 64, 2, (12, 20)),      # 240-token partition (Gen4 720p stress)
+                                                (2, 16, 20, 96, 3, (8, 10))])      # d = 32, odd head count
 @pytest.mark.parametrize('window', [True, False])
 def test_partition_attn(ops, B, H, W, C, heads, part, window):
     qkv = rnd((B, H, W, 3 * C), 7).requires_grad_(True)
