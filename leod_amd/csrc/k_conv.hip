@@ -60,6 +60,139 @@ LEOD_API int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bia
     return rc;
 }
 
+// =====================================================================================================================
+// Dedicated stem forward for the raw uint8 voxels (7x7, stride 4, pad 3 -- the only stem RVT has).
+// The generic implicit GEMM gathers every A element with its own byte load (the 7x7/s4 windows overlap 3x, so each input
+// byte is fetched ~3 times in 1-byte pieces: TA-bound, 42 TFLOP/s).  Here one workgroup owns a 4 x 16 block of output
+// pixels; the 19 x 72-byte x Cin input patch it needs is copied ONCE into LDS with aligned dword loads (zero-filled
+// outside the stored H x W frame = the bottom/right padding of utils/padding.py), and the im2col operand fragments are
+// assembled from LDS bytes through a per-workgroup k -> byte-offset table.  Weights stream through LDS in 64-wide K chunks
+// exactly as in gemm_lds_kernel; outputs leave through the row-layout float4 epilogue.
+// =====================================================================================================================
+template <int NT>
+__global__ __launch_bounds__(256, 3) void stem_u8_fwd_kernel(const uint8_t* __restrict__ x, const float* __restrict__ w,
+                                                             float* __restrict__ y, int Cin, int H, int W, int Ho, int Wo,
+                                                             int N, int tiles_x, int tiles_y) {
+    constexpr int PR = 19, PC = 72, PD = PC / 4;              // patch rows, bytes per row, dwords per row
+    constexpr int KCH = 64, LD = KCH + 8, BN = NT * 16, K4 = KCH / 4;
+    constexpr int RB = (BN * K4 + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int K = Cin * 49, KP = (K + 15) & ~15;
+    const int patch_bytes = Cin * PR * PC;                    // + one zero dword for the k >= K tail
+    unsigned char* patch = smem_raw;
+    int* toff = reinterpret_cast<int*>(smem_raw + ((patch_bytes + 4 + 15) & ~15));
+    float* sB = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(toff) + ((KP * 4 + 15) & ~15));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y; const int b = bid / tiles_y;
+    const int oy0 = 4 * ty, ox0 = 16 * tx;
+    // ---- k -> byte offset inside the patch (relative to the pixel's window origin) ------------------------------------------
+    for (int k = tid; k < KP; k += 256) {
+        const int c = k / 49, r = k - c * 49, kh = r / 7, kw = r - kh * 7;
+        toff[k] = k < K ? c * (PR * PC) + kh * PC + kw + 1 : 0;                // tail: any valid byte (its weights are 0)
+    }
+    // ---- input patch: rows 4*oy0-3 .. +18, byte columns 4*ox0-4 .. +71, all channels ------------------------------------------
+    {
+        const int iy0 = 4 * oy0 - 3, ix0 = 4 * ox0 - 4;
+        const uint32_t* xb = reinterpret_cast<const uint32_t*>(x + (long)b * Cin * H * W);
+        uint32_t* pd = reinterpret_cast<uint32_t*>(patch);
+        const int total = Cin * PR * PD;
+        for (int e = tid; e < total; e += 256) {
+            const int c = e / (PR * PD), rem = e - c * (PR * PD), r = rem / PD, dw = rem - r * PD;
+            const int iy = iy0 + r, ix = ix0 + 4 * dw;
+            uint32_t v = 0;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xb[(((long)c * H + iy) * W + ix) >> 2];
+            pd[e] = v;
+        }
+        if (tid == 0) pd[total] = 0;
+    }
+    // ---- weight chunk staging (as gemm_lds_kernel, non-transposed B) ------------------------------------------------------------
+    int bn[RB], bk[RB], boffs[RB]; bool bok[RB];
+#pragma unroll
+    for (int p = 0; p < RB; ++p) {
+        const int e = tid + 256 * p, nl = e / K4, k4 = (e - nl * K4) * 4;
+        bok[p] = e < BN * K4 && nl < N; bn[p] = nl; bk[p] = k4; boffs[p] = nl * LD + k4;
+    }
+    f4 rb[RB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+            const int k = k0 + bk[p];
+            rb[p] = (bok[p] && k < K) ? ld4(w + (long)bn[p] * K + k) : zero4();      // K % 4 == 0
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int p = 0; p < RB; ++p) if (tid + 256 * p < BN * K4) *reinterpret_cast<f4*>(sB + boffs[p]) = rb[p];
+    };
+    f4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = zero4();
+    fetch(0);
+    stash();
+    __syncthreads();
+    const unsigned char* pix = patch + (4 * wave) * PC + 4 * i;        // window origin of pixel (oy0 + wave, ox0 + i)
+    const float* pb = sB + i * LD + 4 * q;
+    const int nch = (K + KCH - 1) / KCH;
+    for (int ch = 0; ch < nch; ++ch) {
+        const bool more = ch + 1 < nch;
+        if (more) fetch((ch + 1) * KCH);
+#pragma unroll
+        for (int c = 0; c < KCH / 16; ++c) {
+            const int k = ch * KCH + 16 * c + 4 * q;
+            f4 av = zero4();
+            if (k < KP) {
+                const int4 o = *reinterpret_cast<const int4*>(toff + k);
+                av.x = (float)pix[o.x]; av.y = (float)pix[o.y]; av.z = (float)pix[o.z]; av.w = (float)pix[o.w];
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f4 bv = *reinterpret_cast<const f4*>(pb + 16 * t * LD + 16 * c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t] = mfma16(av[j], bv[j], acc[t]);
+            }
+        }
+        if (more) {
+            __syncthreads();
+            stash();
+            __syncthreads();
+        }
+    }
+    // ---- epilogue: 16 pixels x BN channels per wave through a 256-byte-row LDS tile, float4 row stores --------------------
+    __syncthreads();
+    float* so = reinterpret_cast<float*>(smem_raw) + wave * 16 * 64;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) so[(4 * q + r) * 64 + 16 * t + i] = acc[t][r];
+    __syncthreads();
+    const int oy = oy0 + wave;
+    if (oy < Ho) {
+        const int c4 = lane & 15, qq = lane >> 4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int px = qq + 4 * p, ox = ox0 + px;
+            if (ox < Wo && 4 * c4 < N)
+                *reinterpret_cast<f4*>(y + (((long)b * Ho + oy) * Wo + ox) * N + 4 * c4) = *reinterpret_cast<const f4*>(so + px * 64 + 4 * c4);
+        }
+    }
+}
+
+template <int NT>
+static int launch_stem_u8(const uint8_t* x, const float* w, float* y, int B, int Cin, int H, int W, int Ho, int Wo, int N,
+                          hipStream_t s) {
+    const int tiles_x = cdiv(Wo, 16), tiles_y = cdiv(Ho, 4);
+    const int K = Cin * 49, KP = (K + 15) & ~15;
+    const size_t patch = ((size_t)Cin * 19 * 72 + 4 + 15) & ~(size_t)15;
+    size_t lds = patch + (((size_t)KP * 4 + 15) & ~(size_t)15) + (size_t)NT * 16 * 72 * 4;
+    lds = lds < 4 * 16 * 64 * 4 ? 4 * 16 * 64 * 4 : lds;                 // the epilogue tile aliases the front of the buffer
+    hipLaunchKernelGGL((stem_u8_fwd_kernel<NT>), dim3(B * tiles_x * tiles_y), dim3(256), lds, s, x, w, y, Cin, H, W, Ho, Wo, N,
+                       tiles_x, tiles_y);
+    return leod_launch_status();
+}
+
 // Stem: y[B,Ho,Wo,N] = conv(pad(x[B,Cin,H,W] NCHW) , w[N,Cin,ks,ks]) with Hp,Wp the padded size
 // (Ho = (Hp + 2*pad - ks)/stride + 1).  x_is_u8: raw uint8 stacked-histogram voxels.
 LEOD_API int leod_stem_conv_fwd(const void* x, int x_is_u8, const float* w, float* y, int B, int Cin, int H, int W,
@@ -72,6 +205,17 @@ LEOD_API int leod_stem_conv_fwd(const void* x, int x_is_u8, const float* w, floa
     const int nt = pick_nt(N);
     int rc = LEOD_OK;
     const bool lds = use_gemm_lds(M, cdiv(N, 16 * nt));
+    static const int stem_patch = getenv("LEOD_STEM_PATCH") ? atoi(getenv("LEOD_STEM_PATCH")) : 1;
+    if (stem_patch && x_is_u8 && stride == 4 && pad == 3 && N <= 64 && !(N & 15) && !(W & 3) && Cin * 19 * 72 <= 60000 &&
+        ((uintptr_t)x & 3) == 0 && ((long)Cin * H * W) % 4 == 0) {
+        // LDS-resident uint8 patch kernel (dedicated to the RVT stem geometry); anything else takes the generic path
+        switch (N / 16) {
+            case 1: return launch_stem_u8<1>((const uint8_t*)x, w, y, B, Cin, H, W, Ho, Wo, N, stream);
+            case 2: return launch_stem_u8<2>((const uint8_t*)x, w, y, B, Cin, H, W, Ho, Wo, N, stream);
+            case 3: return launch_stem_u8<3>((const uint8_t*)x, w, y, B, Cin, H, W, Ho, Wo, N, stream);
+            default: return launch_stem_u8<4>((const uint8_t*)x, w, y, B, Cin, H, W, Ho, Wo, N, stream);
+        }
+    }
     if (x_is_u8) {
         ALStemNCHW<uint8_t> al{(const uint8_t*)x, Cin, H, W, Ho, Wo, ks, stride, pad};
         DISPATCH_NT(nt, { BLRows bl{w, (long)K, N, NT};

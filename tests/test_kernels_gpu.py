@@ -185,21 +185,24 @@ def test_layernorm_layerscale(ops, M, C):
 
 
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('u8', [True, False])
-def test_stem_conv(ops, u8):
-    B, Cin, H, W, N = 2, 20, 60, 90, 48
+@pytest.mark.parametrize('u8,B,H,W,Hp,Wp,N', [
+    (True, 2, 60, 90, 64, 96, 48), (False, 2, 60, 90, 64, 96, 48),     # W % 4 != 0 / fp32 input: generic implicit-GEMM path
+    (True, 2, 60, 88, 64, 96, 48), (True, 1, 240, 304, 256, 320, 48),   # uint8, W % 4 == 0: LDS-patch stem kernel (Gen1 size)
+    (True, 2, 36, 52, 40, 64, 32), (True, 1, 50, 100, 64, 128, 64)])    # tiny / base widths, ragged tiles
+def test_stem_conv(ops, u8, B, H, W, Hp, Wp, N):
+    Cin = 20
     g = torch.Generator().manual_seed(3)
     x = (torch.rand((B, Cin, H, W), generator=g) < 0.1) * torch.randint(1, 10, (B, Cin, H, W), generator=g)
     x = x.to(torch.uint8) if u8 else x.float() + 0.25
     w = rnd((N, Cin, 7, 7), 4, 0.05).requires_grad_(True)
-    xp = F.pad(x.float(), [0, 96 - W, 0, 64 - H])
+    xp = F.pad(x.float(), [0, Wp - W, 0, Hp - H])
     ref = F.conv2d(xp, w, None, stride=4, padding=3)
     dy = rnd(ref.shape, 5)
     ref.backward(dy)
-    y = ops.stem_conv_fwd(x.to(DEV), w.detach().to(DEV), (64, 96), 4, 3)
+    y = ops.stem_conv_fwd(x.to(DEV), w.detach().to(DEV), (Hp, Wp), 4, 3)
     close(y, ref.permute(0, 2, 3, 1), rtol=5e-5, atol=1e-5)
     dw = torch.zeros_like(w.detach(), device=DEV)
-    ops.stem_conv_wgrad(dy.permute(0, 2, 3, 1).contiguous().to(DEV), x.to(DEV), dw, (64, 96), 4, 3)
+    ops.stem_conv_wgrad(dy.permute(0, 2, 3, 1).contiguous().to(DEV), x.to(DEV), dw, (Hp, Wp), 4, 3)
     close(dw, w.grad, rtol=2e-4, atol=1e-4)
 
 
