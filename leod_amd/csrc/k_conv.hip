@@ -289,12 +289,153 @@ LEOD_API int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, fl
     return wgrad_any(dy, xl, dw, (long)K, dbias, M, N, K, stream);
 }
 
+// =====================================================================================================================
+// Dedicated stem weight gradient for uint8 voxels: dW[n][k] += sum_pixels dY[pixel][n] * im2col(x)[pixel][k].
+// Same LDS-resident patch as stem_u8_fwd_kernel.  A workgroup walks over 4 x 16-pixel tiles (grid-stride), owns one
+// quarter of the 62 k-tiles (blockIdx.y) and keeps its 3 x 4 MFMA tiles per wave in registers over all of its tiles; the
+// next tile's patch and dY rows are prefetched into registers while the current one is multiplied.  One fp32 atomic per
+// dW element and workgroup at the end.
+// =====================================================================================================================
+template <int NT>
+__global__ __launch_bounds__(256, 2) void stem_u8_wgrad_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ x,
+                                                               float* __restrict__ dW, int B, int Cin, int H, int W, int Ho,
+                                                               int Wo, int N, int tiles_x, int tiles_y) {
+    constexpr int PR = 19, PC = 72, PD = PC / 4;
+    constexpr int BN = NT * 16, LDN = BN + 4, KT = 4;         // k-tiles per wave
+    constexpr int RX = 27, RY = (64 * BN / 4 + 255) / 256;    // staging registers: patch dwords, dY float4s per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int K = Cin * 49;
+    const int patch_dw = Cin * PR * PD;
+    uint32_t* pd = reinterpret_cast<uint32_t*>(smem_raw);
+    float* sdy = reinterpret_cast<float*>(smem_raw + (((size_t)patch_dw * 4 + 15) & ~(size_t)15));
+    const unsigned char* patch = smem_raw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int ntiles = B * tiles_x * tiles_y;
+    // this wave's k columns: k-tiles (blockIdx.y * 4 + wave) * KT + b, column i of each
+    int toffk[KT]; int kcol[KT];
+#pragma unroll
+    for (int b = 0; b < KT; ++b) {
+        const int k = ((blockIdx.y * 4 + wave) * KT + b) * 16 + i;
+        kcol[b] = k;
+        const int kk = k < K ? k : 0;
+        const int c = kk / 49, r = kk - c * 49, kh = r / 7, kw = r - kh * 7;
+        toffk[b] = c * (PR * PC) + kh * PC + kw + 1;
+    }
+    f4 acc[NT][KT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < KT; ++b) acc[a][b] = zero4();
+    uint32_t rx[RX]; f4 ry[RY];
+    auto fetch = [&](int tile) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y; const int bb = t / tiles_y;
+        const int iy0 = 16 * ty - 3, ix0 = 64 * tx - 4;
+        const uint32_t* xb = reinterpret_cast<const uint32_t*>(x + (long)bb * Cin * H * W);
+#pragma unroll
+        for (int p = 0; p < RX; ++p) {
+            const int e = tid + 256 * p;
+            uint32_t v = 0;
+            if (e < patch_dw) {
+                const int c = e / (PR * PD), rem = e - c * (PR * PD), r = rem / PD, dw = rem - r * PD;
+                const int iy = iy0 + r, ix = ix0 + 4 * dw;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xb[(((long)c * H + iy) * W + ix) >> 2];
+            }
+            rx[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < RY; ++p) {
+            const int e = tid + 256 * p, px = e / (BN / 4), c4 = e - px * (BN / 4);       // pixel 0..63 = 16*row + col
+            const int oy = 4 * ty + (px >> 4), ox = 16 * tx + (px & 15);
+            ry[p] = (e < 64 * BN / 4 && oy < Ho && ox < Wo && 4 * c4 < N)
+                        ? ld4(dy + (((long)bb * Ho + oy) * Wo + ox) * N + 4 * c4) : zero4();
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int p = 0; p < RX; ++p) { const int e = tid + 256 * p; if (e < patch_dw) pd[e] = rx[p]; }
+#pragma unroll
+        for (int p = 0; p < RY; ++p) {
+            const int e = tid + 256 * p, px = e / (BN / 4), c4 = e - px * (BN / 4);
+            if (e < 64 * BN / 4) *reinterpret_cast<f4*>(sdy + px * LDN + 4 * c4) = ry[p];
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) { fetch(tile); stash(); }
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) fetch(next);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {                      // 16 pixels per step: output row st of the tile, ox = 4q + j
+            f4 av[NT], bv[KT];
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+                const float* t = sdy + (16 * st + 4 * q) * LDN + 16 * a + i;
+                av[a].x = t[0]; av[a].y = t[LDN]; av[a].z = t[2 * LDN]; av[a].w = t[3 * LDN];
+            }
+            const unsigned char* pb = patch + (4 * st) * PC + 16 * q;
+#pragma unroll
+            for (int b = 0; b < KT; ++b) {
+                const unsigned char* t = pb + toffk[b];
+                bv[b].x = (float)t[0]; bv[b].y = (float)t[4]; bv[b].z = (float)t[8]; bv[b].w = (float)t[12];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+#pragma unroll
+                    for (int b = 0; b < KT; ++b) acc[a][b] = mfma16(av[a][j], bv[b][j], acc[a][b]);
+        }
+        __syncthreads();
+        if (next < ntiles) stash();
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < KT; ++b) {
+            if (kcol[b] >= K) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = 16 * a + 4 * q + r;
+                if (n < N) atomicAdd(dW + (long)n * K + kcol[b], acc[a][b][r]);
+            }
+        }
+}
+
+template <int NT>
+static int launch_stem_u8_wgrad(const float* dy, const uint8_t* x, float* dW, int B, int Cin, int H, int W, int Ho, int Wo,
+                                int N, hipStream_t s) {
+    const int tiles_x = cdiv(Wo, 16), tiles_y = cdiv(Ho, 4);
+    const int K = Cin * 49, ktiles = cdiv(K, 16);
+    const int zs = cdiv(ktiles, 16);                                       // 16 k-tiles per workgroup (4 per wave)
+    const size_t lds = (((size_t)Cin * 19 * 72 + 15) & ~(size_t)15) + (size_t)64 * (NT * 16 + 4) * 4;
+    const int ntiles = B * tiles_x * tiles_y;
+    const int gx = ntiles < 192 ? ntiles : 192;
+    hipLaunchKernelGGL((stem_u8_wgrad_kernel<NT>), dim3(gx, zs), dim3(256), lds, s, dy, x, dW, B, Cin, H, W, Ho, Wo, N, tiles_x,
+                       tiles_y);
+    return leod_launch_status();
+}
+
 LEOD_API int leod_stem_conv_wgrad(const float* dy, const void* x, int x_is_u8, float* dw, int B, int Cin, int H, int W,
                                   int Hp, int Wp, int N, int ks, int stride, int pad, hipStream_t stream) {
     if (!dy || !x || !dw) return LEOD_ERR_ARG;
     if (ks != 7) return LEOD_ERR_UNSUPPORTED;
     const int Ho = (Hp + 2 * pad - ks) / stride + 1, Wo = (Wp + 2 * pad - ks) / stride + 1;
     const int M = B * Ho * Wo, K = Cin * ks * ks;
+    static const int stem_patch = getenv("LEOD_STEM_PATCH") ? atoi(getenv("LEOD_STEM_PATCH")) : 1;
+    if (stem_patch && x_is_u8 && stride == 4 && pad == 3 && N <= 64 && !(N & 15) && !(W & 3) && Cin * 19 * 18 <= 27 * 256 &&
+        ((uintptr_t)x & 3) == 0 && ((long)Cin * H * W) % 4 == 0) {
+        switch (N / 16) {
+            case 1: return launch_stem_u8_wgrad<1>(dy, (const uint8_t*)x, dw, B, Cin, H, W, Ho, Wo, N, stream);
+            case 2: return launch_stem_u8_wgrad<2>(dy, (const uint8_t*)x, dw, B, Cin, H, W, Ho, Wo, N, stream);
+            case 3: return launch_stem_u8_wgrad<3>(dy, (const uint8_t*)x, dw, B, Cin, H, W, Ho, Wo, N, stream);
+            default: return launch_stem_u8_wgrad<4>(dy, (const uint8_t*)x, dw, B, Cin, H, W, Ho, Wo, N, stream);
+        }
+    }
     if (x_is_u8) {
         XStemNCHW<uint8_t> xl{(const uint8_t*)x, Cin, H, W, Ho, Wo, ks, stride, pad};
         return wgrad_any(dy, xl, dw, (long)K, nullptr, M, N, K, stream);
