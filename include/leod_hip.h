@@ -89,12 +89,14 @@ int leod_stem_conv_fwd(const void* x, int x_is_u8, const float* w, float* y, int
 int leod_stem_conv_wgrad(const float* dy, const void* x, int x_is_u8, float* dw, int B, int Cin, int H, int W, int Hp,
                          int Wp, int N, int ks, int stride, int pad, leod_stream_t stream);
 /* y = conv(x NHWC, w[N,Cin,ks,ks]) (+bias); colstats (optional) [2,N] double += (sum, sumsq) for training BatchNorm;
- * bn_w != NULL: eval BatchNorm folded + SiLU (network_blocks.py:29-54; yolo_pafpn.py:109-140; yolo_head.py:208-222). */
+ * bn_w != NULL: eval BatchNorm folded + SiLU (network_blocks.py:29-54; yolo_pafpn.py:109-140; yolo_head.py:208-222).
+ * wpack (optional scratch, N*Cin*ks*ks floats): the call first writes a K-contiguous copy of w there and contracts
+ * against that (the native [N][Cin][ks][ks] layout strides every weight float4 over 36 bytes). */
 int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, double* colstats, const float* bn_w,
                        const float* bn_b, const float* bn_rm, const float* bn_rv, float bn_eps, int B, int H, int W,
-                       int Cin, int N, int ks, int stride, int pad, leod_stream_t stream);
+                       int Cin, int N, int ks, int stride, int pad, float* wpack, leod_stream_t stream);
 int leod_conv_nhwc_dgrad(const float* dy, const float* w, float* dx, int accumulate, int B, int H, int W, int Cin, int N,
-                         int ks, int stride, int pad, leod_stream_t stream);
+                         int ks, int stride, int pad, float* wpack, leod_stream_t stream);
 int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, float* dbias, int B, int H, int W, int Cin, int N,
                          int ks, int stride, int pad, leod_stream_t stream);
 

@@ -331,6 +331,25 @@ struct BLConvWT2 {
     }
 };
 
+struct BLPackT2 {                 // parity-class dgrad on PACKED weights wd[c][tap*N + n] (see conv_pack_kernel)
+    static constexpr bool kTrans = false;
+    __device__ __forceinline__ f4 load_n4(int, int, int, int) const { return zero4(); }
+    const float* w; int N, Cin; int NT;
+    __device__ __forceinline__ int col(int nblk, int t, int i) const { return (nblk * NT + t) * 16 + i; }
+    __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int, int cls) const {
+        const int c = col(nblk, t, i);
+        const int py = cls >> 1, px = cls & 1;
+        if (c >= Cin || k >= (1 + py) * (1 + px) * N) return zero4();
+        const int tt = k / N, n = k - tt * N;
+        const int khi = tt / (1 + px), kwi = tt - khi * (1 + px);
+        const int kh = py ? 2 * khi : 1, kw = px ? 2 * kwi : 1;
+        return ld4(w + ((long)c * 9 + kh * 3 + kw) * N + n);
+    }
+    template <int KCH> __device__ __forceinline__ f4 load2(int nblk, int t, int i, int k0, int bk, int Kt, int cls) const {
+        return load(nblk, t, i, k0 + bk, Kt, cls);
+    }
+};
+
 // =================================================================================================
 // Epilogues.  acc[t][r] = Out[row0 + 4*(lane>>4) + r][col(nblk,t,lane&15)]
 // =================================================================================================

@@ -33,12 +33,30 @@ static EpStore conv_epilogue(float* out, int N, const float* bias, double* colst
     return ep;
 }
 
+// K-contiguous copies of a conv weight w[N][Cin][KK] for the implicit GEMMs (the native layout makes every weight
+// float4 four 36-byte-strided scalar loads):  mode 0: wf[n][tap*Cin + c]  (forward, B rows = output channels)
+//                                              mode 1: wd[c][tap*N + n]    (dgrad,   B rows = input channels)
+__global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int N, int Cin,
+                                                        int KK, int mode) {
+    const long total = (long)N * Cin * KK;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int tap = (int)(e % KK); const long r = e / KK; const int c = (int)(r % Cin), n = (int)(r / Cin);
+        const long o = mode == 0 ? ((long)n * KK + tap) * Cin + c : ((long)c * KK + tap) * N + n;
+        out[o] = w[e];
+    }
+}
+static inline void launch_conv_pack(const float* w, float* out, int N, int Cin, int KK, int mode, hipStream_t s) {
+    const long total = (long)N * Cin * KK;
+    hipLaunchKernelGGL(conv_pack_kernel, dim3((int)min((long)1024, (total + 255) / 256)), dim3(256), 0, s, w, out, N, Cin, KK, mode);
+}
+
 // y[B,Ho,Wo,N] = conv(x[B,H,W,Cin] NHWC, w[N,Cin,ks,ks]) (+bias) ; Ho = (H + 2*pad - ks)/stride + 1
 //   colstats != NULL : also accumulate per-channel (sum, sumsq) in double for training BatchNorm
 //   bn_w != NULL     : eval mode, y = silu(bn(conv)) with running statistics folded in
 LEOD_API int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, double* colstats,
                                 const float* bn_w, const float* bn_b, const float* bn_rm, const float* bn_rv, float bn_eps,
-                                int B, int H, int W, int Cin, int N, int ks, int stride, int pad, hipStream_t stream) {
+                                int B, int H, int W, int Cin, int N, int ks, int stride, int pad, float* wpack,
+                                hipStream_t stream) {
     if (!x || !w || !y || (Cin & 3)) return LEOD_ERR_ARG;
     const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
     const int M = B * Ho * Wo, K = ks * ks * Cin;
@@ -53,6 +71,13 @@ LEOD_API int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bia
                                    : launch_gemm16<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
     } else {
         ALConvNHWC al{x, H, W, Cin, Ho, Wo, ks, stride, pad};
+        if (wpack && lds) {
+            // scratch given: repack the weights K-contiguous first (N*Cin*ks*ks floats, a few microseconds), then the B
+            // operand is a plain row-major matrix like a Linear weight
+            launch_conv_pack(w, wpack, N, Cin, ks * ks, 0, stream);
+            DISPATCH_NT(nt, { BLRows bl{wpack, (long)K, N, NT}; rc = launch_gemm_lds<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
+            return rc;
+        }
         DISPATCH_NT(nt, { BLConvW bl{w, N, Cin, ks * ks, NT};
                           rc = lds ? launch_gemm_lds<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream)
                                    : launch_gemm16<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
@@ -232,7 +257,7 @@ LEOD_API int leod_stem_conv_fwd(const void* x, int x_is_u8, const float* w, floa
 
 // dx[B,H,W,Cin] (=|+=) conv_transpose(dy[B,Ho,Wo,N], w)
 LEOD_API int leod_conv_nhwc_dgrad(const float* dy, const float* w, float* dx, int accumulate, int B, int H, int W, int Cin,
-                                  int N, int ks, int stride, int pad, hipStream_t stream) {
+                                  int N, int ks, int stride, int pad, float* wpack, hipStream_t stream) {
     if (!dy || !w || !dx || (N & 3)) return LEOD_ERR_ARG;
     const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
     const int M = B * H * W, K = ks * ks * N;
@@ -245,6 +270,11 @@ LEOD_API int leod_conv_nhwc_dgrad(const float* dy, const float* w, float* dx, in
         ALConvT2 al{dy, H, W, Ho, Wo, N, Q};
         ep.rm_Q = Q; ep.rm_H = H; ep.rm_W = W;
         const bool lds2 = use_gemm_lds(M, cdiv(Cin, 16 * nt)) && Q % 128 == 0;    // a (64|128)-row workgroup must not mix classes
+        if (wpack && lds2) {
+            launch_conv_pack(w, wpack, N, Cin, 9, 1, stream);
+            DISPATCH_NT(nt, { BLPackT2 bl{wpack, N, Cin, NT}; rc = launch_gemm_lds<NT>(al, bl, ep, M, 4 * N, cdiv(Cin, 16 * NT), stream); });
+            return rc;
+        }
         DISPATCH_NT(nt, { BLConvWT2 bl{w, N, Cin, NT};
                           rc = lds2 ? launch_gemm_lds<NT>(al, bl, ep, M, 4 * N, cdiv(Cin, 16 * NT), stream)
                                     : launch_gemm16<NT>(al, bl, ep, M, 4 * N, cdiv(Cin, 16 * NT), stream); });
@@ -258,6 +288,11 @@ LEOD_API int leod_conv_nhwc_dgrad(const float* dy, const float* w, float* dx, in
                                    : launch_gemm16<NT>(al, bl, ep, M, K, cdiv(Cin, 16 * NT), stream); });
     } else {
         ALConvT al{dy, H, W, Ho, Wo, N, ks, stride, pad};
+        if (wpack && lds) {
+            launch_conv_pack(w, wpack, N, Cin, ks * ks, 1, stream);         // wd[c][tap*N + n]: B(col = c, k' = tap*N + n)
+            DISPATCH_NT(nt, { BLRows bl{wpack, (long)K, Cin, NT}; rc = launch_gemm_lds<NT>(al, bl, ep, M, K, cdiv(Cin, 16 * NT), stream); });
+            return rc;
+        }
         DISPATCH_NT(nt, { BLConvWT bl{w, N, Cin, ks * ks, NT};
                           rc = lds ? launch_gemm_lds<NT>(al, bl, ep, M, K, cdiv(Cin, 16 * NT), stream)
                                    : launch_gemm16<NT>(al, bl, ep, M, K, cdiv(Cin, 16 * NT), stream); });

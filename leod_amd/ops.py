@@ -276,8 +276,9 @@ def conv_nhwc_fwd(x, w, bias=None, stride=1, colstats=None, bn=None, bn_eps=1e-5
         bw, bb, brm, brv = bn
         for t in bn:
             _ck(t, name='bn')
+    wpack = _empty((N * Cin * ks * ks,), x) if ks > 1 else None     # scratch for the K-contiguous weight copy
     check(_l().leod_conv_nhwc_fwd(_p(x), _p(w), _p(bias), _p(y), _p(colstats), _p(bw), _p(bb), _p(brm), _p(brv), bn_eps,
-                                   B, H, W, Cin, N, ks, stride, pad, _stream()), 'conv_nhwc_fwd')
+                                   B, H, W, Cin, N, ks, stride, pad, _p(wpack), _stream()), 'conv_nhwc_fwd')
     return y
 
 
@@ -291,8 +292,9 @@ def conv_nhwc_dgrad(dy, w, x_shape, stride=1, out=None, accumulate=False):
         out = _empty(tuple(x_shape), dy)
         accumulate = False
     _ck(out, name='dx')
+    wpack = _empty((N * Cin * ks * ks,), dy) if ks > 1 else None
     check(_l().leod_conv_nhwc_dgrad(_p(dy), _p(w), _p(out), 1 if accumulate else 0, B, H, W, Cin, N, ks, stride, pad,
-                                     _stream()), 'conv_nhwc_dgrad')
+                                     _p(wpack), _stream()), 'conv_nhwc_dgrad')
     return out
 
 
