@@ -1,19 +1,26 @@
 // fp32 MFMA (v_mfma_f32_16x16x4_f32) GEMM skeletons shared by every contraction on the LEOD path.
 //
-//   row GEMM   Out[m][n]  = sum_k A(m,k) * B(n,k)       gemm16_kernel   (forward / dgrad, implicit-GEMM conv)
-//   wgrad GEMM dW[n][k]  += sum_m dY(m,n) * X(m,k)       wgrad16_kernel  (weight / bias gradients)
+//   gemm_lds_kernel   Out[m][n]  = sum_k A(m,k) * B(n,k)   forward / dgrad / implicit-GEMM conv at M >= 2048: operands
+//                     fetched with coalesced 16-byte loads, staged in ONE LDS buffer (register prefetch of the next K
+//                     chunk), conflict-free fragment reads, row-layout float4 epilogue, XCD-aware 1-D grid
+//   gemm16_kernel     same contraction for small M (per-timestep LSTM cells of stages 3/4, micro shapes): operands
+//                     straight from global memory in MFMA layout, optional 4-way K split over the waves
+//   wgradw_kernel     dW[n][k] += sum_m dY(m,n) * X(m,k) for M >= 8192 (Linear layers of the time-batched step):
+//                     workgroup tile chosen per layer shape, 3x3 MFMA tiles per wave, natural-layout LDS tiles
+//   wgrad16_kernel    the same for small M and for the im2col / stem X loaders
 //
-// Design notes (MI355X): every GEMM on this path has K,N <= a few hundred and M = tokens, i.e. it is
-// HBM/latency bound, never MFMA bound (<= 36 FLOP/B).  So the skeleton favours simple,
-// fully coalesced 16-byte operand loads straight from L2/HBM into MFMA operand registers (no LDS
-// round trip: f32 MFMA issues once per 32 cycles, far below what the vector-memory path can feed),
-// one wave = 16 output rows x NT*16 columns, 4 waves per workgroup stacked along M, and fused
-// prologues/epilogues so each activation tensor crosses HBM once.
+// Common conventions:
+//   * K-permutation: a chunk is 16 consecutive k; lane (i = lane & 15, q = lane >> 4) holds k0+4q..+3 as one float4 and
+//     MFMA j of the chunk consumes component j -- every fragment is a single 16-byte access, for both operands.
+//   * A loaders (AL*): rows of an activation / gradient matrix (plain rows, [x | h] concatenation, im2col of an NHWC map,
+//     the raw NCHW uint8 stem input, transposed-conv gathers), optional LayerNorm / per-k scale applied on load.
+//   * B loaders (BL*): weights in their stored layout (row-major, transposed, ConvLSTM gate-major, conv [N][Cin][ks][ks]).
+//   * Epilogues (Ep*): bias / GELU (dual store) / gelu' / folded BatchNorm+SiLU / LayerScale+residual / LSTM gates,
+//     column statistics for BatchNorm and bias gradients.
+//   * LDS bank rules that fix the layouts (MI355X_MICROARCH.md, LDS): ds_read_b128 is served in the lane groups
+//     {0-3,12-15,20-27},...: row-major tiles read as fragments need a row stride == 8 (mod 16) dwords; operands that arrive
+//     transposed stay in natural layout (16-byte stores) and are read with 4 x ds_read_b32 at a stride == 4 (mod 8).
 //
-// K-permutation trick: one "chunk" = 16 consecutive k.  Lane (i = l&15, q = l>>4) loads the float4
-// A[row i][k0+4q .. k0+4q+3] and B[col i][k0+4q .. +3]; MFMA number j (0..3) of the chunk consumes
-// component j of both, i.e. k index (q) of that MFMA stands for k0+4q+j.  Summed over j this covers
-// each k of the chunk exactly once, and both operands are plain 16-byte row-contiguous loads.
 #pragma once
 #include <stdlib.h>
 #include "common.hpp"
@@ -366,7 +373,6 @@ struct EpStore {
     float* colsum;                  // optional [N]: += column sums of the stored value (bias gradient)
     int act; int accumulate;
     int N;
-    int dbg;                        // profiling ablations only (LEOD_GEMM_DBG): bit0 skip stores, bit1 skip MFMAs
     int rm_Q, rm_H, rm_W;           // rm_Q > 0: GEMM rows are parity-class ordered (ALConvT2) -> remap to pixel rows of the [B,H,W] map
     __device__ __forceinline__ long maprow(int row) const {
         if (rm_Q <= 0) return row;
@@ -396,7 +402,7 @@ struct EpStore {
                 const long row = maprow(grow);
                 if (act == ACT_AFFINE_SILU) v = siluf_(v * sc + sh);
                 if (act == ACT_MUL_GELU_GRAD && ok) v *= gelu_erf_grad(aux[row * ldaux + n]);
-                if (ok && !(dbg & 1)) {
+                if (ok) {
                     if (nsplit > 0 && n >= nsplit) {
                         float* p = out2 + row * ld2 + (n - nsplit);
                         *p = accumulate ? *p + v : v;
@@ -866,100 +872,6 @@ static inline int launch_gemm_lds(const AL& al, const BL& bl, const EP& ep, int 
 static inline bool use_gemm_lds(int M, int nblocks_n) { return (long)cdiv(M, 64) * nblocks_n >= 256 && M >= 2048; }
 
 // =================================================================================================
-// A-stationary row GEMM (K <= 384): one wave loads its 16-row A tile ONCE into registers (K/16 float4 per lane),
-// applies LayerNorm / per-k scaling in registers (statistics from the registers: no extra passes over memory), then
-// sweeps the n-blocks assigned to it, streaming only the weight fragments (L1/L2-resident).  Compared with gemm16_kernel
-// this removes the per-n-block re-read of A and the two dependent statistics passes of the LayerNorm prologue.
-// =================================================================================================
-struct ARowSrc {                // [x1 (K1 cols) | x2] rows, optional LayerNorm (over the full K) and per-k scale
-    const float* x1; long ld1; int K1; const float* x2; long ld2;
-    const float* ln_w; const float* ln_b; float eps; const float* kscale; float* stats_out;
-};
-
-template <int KCMAX, int NT, class BL, class EP>
-__global__ __launch_bounds__(256) void gemm16a_kernel(ARowSrc al, BL bl, EP ep, int M, int K, int nblocks_n, int dbgk) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 15, q = lane >> 4;
-    const int row0 = (blockIdx.x * 4 + wave) * 16;
-    if (row0 >= M) return;
-    const int KC = (K + 15) >> 4;
-    const bool rok = row0 + i < M;
-    const long r = rok ? row0 + i : M - 1;
-    const float* p1 = al.x1 + r * al.ld1;
-    const float* p2 = al.x2 ? al.x2 + r * al.ld2 : nullptr;
-    f4 a[KCMAX];
-#pragma unroll
-    for (int c = 0; c < KCMAX; ++c) {
-        const int k = 16 * c + 4 * q;
-        a[c] = zero4();
-        if (c < KC && k < K) a[c] = k < al.K1 ? ld4(p1 + k) : (p2 ? ld4(p2 + (k - al.K1)) : zero4());
-    }
-    if (al.ln_w) {
-        float sum = 0.f;
-#pragma unroll
-        for (int c = 0; c < KCMAX; ++c) sum += (a[c].x + a[c].y) + (a[c].z + a[c].w);      // padded k are zero
-        const float mean = quad16_sum(sum) / (float)K;
-        float var = 0.f;
-#pragma unroll
-        for (int c = 0; c < KCMAX; ++c) {
-            if (c < KC && 16 * c + 4 * q < K) { const f4 d = a[c] - mean; var += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
-        }
-        const float rstd = rsqrtf(quad16_sum(var) / (float)K + al.eps);
-        if (al.stats_out && blockIdx.y == 0 && rok && q == 0) { al.stats_out[2 * r] = mean; al.stats_out[2 * r + 1] = rstd; }
-#pragma unroll
-        for (int c = 0; c < KCMAX; ++c) {
-            const int k = 16 * c + 4 * q;
-            if (c < KC && k < K) a[c] = (a[c] - mean) * rstd * ld4(al.ln_w + k) + ld4(al.ln_b + k);
-        }
-    }
-    if (al.kscale) {
-#pragma unroll
-        for (int c = 0; c < KCMAX; ++c) { const int k = 16 * c + 4 * q; if (c < KC && k < K) a[c] = a[c] * ld4(al.kscale + k); }
-    }
-    if (!rok) {
-#pragma unroll
-        for (int c = 0; c < KCMAX; ++c) a[c] = zero4();
-    }
-    for (int nb = blockIdx.y; nb < nblocks_n; nb += gridDim.y) {
-        f4 acc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = zero4();
-#pragma unroll
-        for (int c = 0; c < KCMAX; ++c) {
-            if (c < KC) {
-                f4 b[NT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) b[t] = bl.load(nb, t, i, 16 * c + 4 * q, K);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        if (dbgk & 2) acc[t][j] += a[c][j] + b[t][j]; else acc[t] = mfma16(a[c][j], b[t][j], acc[t]);
-                    }
-            }
-        }
-        ep.template run<NT, BL>(acc, bl, row0, nb, lane, M);
-    }
-}
-
-template <int NT, class BL, class EP>
-static inline int launch_gemm16a(const ARowSrc& al, const BL& bl, const EP& ep, int M, int K, int nblocks_n, hipStream_t s) {
-    const int tiles = cdiv(M, 16);
-    int ny = 1;                                   // split the n-blocks over gridDim.y until ~2048 waves are in flight
-    while (ny < nblocks_n && (long)tiles * ny < 2048) ++ny;
-    dim3 grid(cdiv(M, 64), ny);
-    const int KC = (K + 15) >> 4;
-    static const int dbgk = getenv("LEOD_GEMM_DBG") ? atoi(getenv("LEOD_GEMM_DBG")) : 0;
-    if (KC <= 3) hipLaunchKernelGGL((gemm16a_kernel<3, NT, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n, dbgk);
-    else if (KC <= 6) hipLaunchKernelGGL((gemm16a_kernel<6, NT, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n, dbgk);
-    else if (KC <= 12) hipLaunchKernelGGL((gemm16a_kernel<12, NT, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n, dbgk);
-    else hipLaunchKernelGGL((gemm16a_kernel<24, NT, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n, dbgk);
-    return leod_launch_status();
-}
-// the A-stationary kernel needs the row tile in registers (K <= 384) and enough row tiles to fill the chip
-static inline bool use_gemm16a(int M, int K) { return K <= 384 && M >= 2048; }
-
-// =================================================================================================
 // wgrad GEMM:  dW[n][k] += sum_m dY(m,n) * X(m,k)   (+ optional dbias[n] += sum_m dY(m,n))
 // Each workgroup owns `rows_per_block` rows of M and one (TN*16 x TK*16) tile of dW; its 4 waves
 // interleave 16-row chunks, reduce through LDS and issue one fp32 atomicAdd per dW element.
@@ -1023,7 +935,7 @@ struct XStemNCHW {
 // atomic per dW element (dW accumulates over timesteps and row splits).
 template <int TN, int TK, class XL>
 __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ dy, long lddy, XL xl, float* dW, long ldw,
-                                                      float* dbias, int M, int N, int K, int rows_per_block, int dbg) {
+                                                      float* dbias, int M, int N, int K, int rows_per_block) {
     constexpr int RC = 32;                                  // rows per staged chunk
     constexpr int LDN = 16 * TN + 4, LDK = 16 * TK + 4;    // natural [row][col] LDS tiles, see wgradw_kernel
     constexpr int C4N = TN * 4, C4K = TK * 4;               // float4 slots per staged row
@@ -1072,11 +984,11 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
     auto fetch = [&](int m0) {
 #pragma unroll
         for (int e = 0; e < RN; ++e) {
-            rn[e] = (nok[e] && m0 + nr[e] < mend && !(dbg & 4)) ? ld4(np[e]) : zero4();
+            rn[e] = (nok[e] && m0 + nr[e] < mend) ? ld4(np[e]) : zero4();
             np[e] += (long)RC * lddy;
         }
 #pragma unroll
-        for (int e = 0; e < RK; ++e) rk[e] = (kok[e] && m0 + kr[e] < mend && !(dbg & 4)) ? xl.get4(m0 + kr[e], kc[e]) : zero4();
+        for (int e = 0; e < RK; ++e) rk[e] = (kok[e] && m0 + kr[e] < mend) ? xl.get4(m0 + kr[e], kc[e]) : zero4();
     };
     auto stash = [&](int buf) {
 #pragma unroll
@@ -1100,7 +1012,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
         for (int st = 0; st < RC / 16; ++st)
 #pragma unroll
             for (int t = 0; t < TPW; ++t)
-                if (tok[t] && !(dbg & 2)) {
+                if (tok[t]) {
                     const float* ta = pdy + offA[t] + (16 * st) * LDN;                    // rows 16st+4q .. +3 of column (a, i)
                     const float* tb = px + offB[t] + (16 * st) * LDK;
                     f4 av, bv;
@@ -1122,7 +1034,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = n0 + 16 * a + 4 * q + r;
-            if (n < N && k < K && !(dbg & 1)) atomicAdd(dW + xl.waddr(n, k, ldw), acc[t][r]);
+            if (n < N && k < K) atomicAdd(dW + xl.waddr(n, k, ldw), acc[t][r]);
         }
     }
     if (do_bias) {                                          // column sums of dY from the values this thread staged
@@ -1151,8 +1063,7 @@ static inline int launch_wgrad16(const float* dy, long lddy, const XL& xl, float
     int rpb = cdiv(M, max(1, tune_blocks / tiles));
     rpb = max(tune_minrows, ((rpb + 31) / 32) * 32);
     dim3 grid(cdiv(M, rpb), cdiv(N, TN * 16), cdiv(K, TK * 16));
-    static const int dbg = getenv("LEOD_WGRAD_DBG") ? atoi(getenv("LEOD_WGRAD_DBG")) : 0;   // ablation switches (profiling only)
-    hipLaunchKernelGGL((wgrad16_kernel<TN, TK, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, rpb, dbg);
+    hipLaunchKernelGGL((wgrad16_kernel<TN, TK, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, rpb);
     return leod_launch_status();
 }
 

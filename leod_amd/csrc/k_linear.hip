@@ -20,17 +20,9 @@ static inline int pick_nt(int N) {
         default: { constexpr int NT = 4; __VA_ARGS__; } break;         \
     }
 
-// LEOD_GEMM_MODE: 2 (default) LDS-staged coalesced GEMM for large M, 1 A-stationary register kernel, 0 register-direct only
-static inline int gemm_mode() {
-    static const int m = getenv("LEOD_GEMM_MODE") ? atoi(getenv("LEOD_GEMM_MODE")) : 2;
-    return m;
-}
-
 static inline EpStore ep_store(float* out, long ld, int N) {
     EpStore e{};
     e.out = out; e.ld = ld; e.N = N; e.act = ACT_NONE;
-    static const int dbg = getenv("LEOD_GEMM_DBG") ? atoi(getenv("LEOD_GEMM_DBG")) : 0;
-    e.dbg = dbg;
     return e;
 }
 
@@ -47,14 +39,9 @@ LEOD_API int leod_ln_linear_fwd(const float* x, long ldx, const float* ln_w, con
     if (out_act) { ep.act = ACT_GELU_DUAL; ep.out2 = out_act; ep.ld2 = N; }
     const int nt = pick_nt(N);
     int rc = LEOD_OK;
-    if (gemm_mode() == 2 && use_gemm_lds(M, cdiv(N, 16 * nt)) && (!ln_w || stats_out)) {
+    if (use_gemm_lds(M, cdiv(N, 16 * nt)) && (!ln_w || stats_out)) {
         if (ln_w) { rc = launch_row_stats(x, ldx, stats_out, M, K, eps, stream); if (rc) return rc; al.stats_in = stats_out; }
         DISPATCH_NT(nt, { BLRows bl{W, (long)K, N, NT}; rc = launch_gemm_lds<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
-        return rc;
-    }
-    if (gemm_mode() == 1 && use_gemm16a(M, K)) {
-        ARowSrc as{x, ldx, K, nullptr, 0, ln_w, ln_b, eps, nullptr, stats_out};
-        DISPATCH_NT(nt, { BLRows bl{W, (long)K, N, NT}; rc = launch_gemm16a<NT>(as, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
         return rc;
     }
     DISPATCH_NT(nt, { BLRows bl{W, (long)K, N, NT}; rc = launch_gemm16<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
@@ -69,13 +56,8 @@ LEOD_API int leod_linear_lsres_fwd(const float* a, const float* W, const float* 
     EpLsRes ep{out, tout, res, bias, gamma, (long)N, N};
     const int nt = pick_nt(N);
     int rc = LEOD_OK;
-    if (gemm_mode() == 2 && use_gemm_lds(M, cdiv(N, 16 * nt))) {
+    if (use_gemm_lds(M, cdiv(N, 16 * nt))) {
         DISPATCH_NT(nt, { BLRows bl{W, (long)K, N, NT}; rc = launch_gemm_lds<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
-        return rc;
-    }
-    if (gemm_mode() == 1 && use_gemm16a(M, K)) {
-        ARowSrc as{a, (long)K, K, nullptr, 0, nullptr, nullptr, 0.f, nullptr, nullptr};
-        DISPATCH_NT(nt, { BLRows bl{W, (long)K, N, NT}; rc = launch_gemm16a<NT>(as, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
         return rc;
     }
     DISPATCH_NT(nt, { BLRows bl{W, (long)K, N, NT}; rc = launch_gemm16<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
@@ -94,11 +76,7 @@ LEOD_API int leod_convlstm_fwd(const float* x, const float* h_prev, const float*
     EpLstm ep{bias, c_prev, h_out, c_out, gates_out, C};
     // a zero initial state contributes nothing: stop the contraction at K = C
     const int K = h_prev ? 2 * C : C;
-    if (gemm_mode() == 2 && use_gemm_lds(M, C / 16)) return launch_gemm_lds<4>(al, bl, ep, M, K, C / 16, stream);
-    if (gemm_mode() == 1 && use_gemm16a(M, K)) {
-        ARowSrc as{x, (long)C, C, h_prev, (long)C, nullptr, nullptr, 0.f, nullptr, nullptr};
-        return launch_gemm16a<4>(as, bl, ep, M, K, C / 16, stream);
-    }
+    if (use_gemm_lds(M, C / 16)) return launch_gemm_lds<4>(al, bl, ep, M, K, C / 16, stream);
     return launch_gemm16<4>(al, bl, ep, M, K, C / 16, stream);
 }
 
@@ -116,13 +94,8 @@ LEOD_API int leod_linear_dgrad(const float* dy, long lddy, const float* kscale, 
     if (aux_u) { ep.act = ACT_MUL_GELU_GRAD; ep.aux = aux_u; ep.ldaux = K; }
     const int nt = pick_nt(K);
     int rc = LEOD_OK;
-    if (gemm_mode() == 2 && use_gemm_lds(M, cdiv(K, 16 * nt))) {
+    if (use_gemm_lds(M, cdiv(K, 16 * nt))) {
         DISPATCH_NT(nt, { BLTrans bl{W, (long)K, K, NT}; rc = launch_gemm_lds<NT>(al, bl, ep, M, N, cdiv(K, 16 * NT), stream); });
-        return rc;
-    }
-    if (gemm_mode() == 1 && use_gemm16a(M, N)) {
-        ARowSrc as{dy, lddy, N, nullptr, 0, nullptr, nullptr, 0.f, kscale, nullptr};
-        DISPATCH_NT(nt, { BLTrans bl{W, (long)K, K, NT}; rc = launch_gemm16a<NT>(as, bl, ep, M, N, cdiv(K, 16 * NT), stream); });
         return rc;
     }
     DISPATCH_NT(nt, { BLTrans bl{W, (long)K, K, NT}; rc = launch_gemm16<NT>(al, bl, ep, M, N, cdiv(K, 16 * NT), stream); });
