@@ -30,7 +30,9 @@ from typing import List, Optional, Sequence
 
 import torch
 
+from . import ops
 from .engine import TrainEngine
+from .functions import flush_bn_counters
 
 
 class CellGraphEngine(TrainEngine):
@@ -191,6 +193,7 @@ class CellGraphEngine(TrainEngine):
 
     def _head_pass(self, labels, label_tb):
         """PAFPN + head + loss on the labelled frames and its backward into ``d feat``; returns the stacked losses."""
+        ops.StatArena.begin_step(labels.device)
         sel, leaf_of = {}, []
         for t, idx in enumerate(label_tb):
             if not len(idx):
@@ -205,6 +208,8 @@ class CellGraphEngine(TrainEngine):
         losses['loss'].backward()
         for s, t, leaf in leaf_of:
             self._dfeat[s][t].copy_(leaf.grad)
+        ops.StatArena.end_step()
+        flush_bn_counters(self.det)
         return torch.stack([losses[k].detach() for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')])
 
     # ------------------------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from . import ops
-from .functions import WgradSide
+from .functions import WgradSide, flush_bn_counters
 from .parallel import FlatParams, DataParallel, one_cycle_lr
 from .models.detection.yolox.utils.boxes import postprocess_padded
 from .modules.utils.ssod import pred2label_padded
@@ -147,6 +147,7 @@ class TrainEngine:
 
     def _step_body(self, ev_seq, labels, label_tb, is_first, states, hp_dev=None, lr=None, scale=1.0):
         self.flat.zero_grad()
+        ops.StatArena.begin_step(ev_seq.device)          # one memset for all BatchNorm statistic accumulators of the step
         _, losses, new_states = self.forward_loss(ev_seq, labels, label_tb, is_first, states)
         WgradSide.active = self.wgrad_side
         try:
@@ -166,6 +167,8 @@ class TrainEngine:
         else:
             self.dp.all_reduce_gradients()
             self.flat.adamw_step(0.0, self.hp['weight_decay'], self.hp['clip_value'], hp_dev=hp_dev)
+        ops.StatArena.end_step()
+        flush_bn_counters(self.det)
         return losses, new_states
 
     def step(self, ev_seq, labels, label_tb, is_first=None):

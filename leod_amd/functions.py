@@ -84,6 +84,25 @@ def _allreduce_stats(t: torch.Tensor):
         dist.all_reduce(t, group=_SYNC_BN['group'])
 
 
+def flush_bn_counters(module: torch.nn.Module) -> None:
+    """``BatchNorm2d.num_batches_tracked`` of every BaseConv is advanced lazily: the forward pass only counts calls on the
+    host, this adds the pending counts to the device buffers in ONE fused launch (39 one-element add kernels per step
+    otherwise).  Called by the engines at the end of a step and by ``BaseConv`` before its state dict is read."""
+    bufs, incs = [], []
+    for m in module.modules():
+        n = getattr(m, 'bn_calls_pending', 0)
+        if n and hasattr(m, 'bn'):
+            bufs.append(m.bn.num_batches_tracked)
+            incs.append(n)
+            m.bn_calls_pending = 0
+    if bufs:
+        if len(set(incs)) == 1:
+            torch._foreach_add_(bufs, incs[0])
+        else:
+            for b, n in zip(bufs, incs):
+                b += n
+
+
 def grad_buf(p: torch.nn.Parameter) -> torch.Tensor:
     if p.grad is None:
         p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
@@ -293,7 +312,7 @@ class BaseConvFn(Function):
             return ops.conv_nhwc_fwd(x, conv_w, None, stride=stride,
                                      bn=(bn_w, bn_b, mod.bn.running_mean, mod.bn.running_var), bn_eps=mod.bn.eps)
         N = conv_w.shape[0]
-        colstats = torch.zeros((2, N), dtype=torch.float64, device=x.device)
+        colstats = ops.StatArena.zeros((2, N), x.device)
         z = ops.conv_nhwc_fwd(x, conv_w, None, stride=stride, colstats=colstats)
         count = z.numel() // N
         count_dev = None
@@ -305,7 +324,7 @@ class BaseConvFn(Function):
         mom = mod.bn.momentum if mod.bn.momentum is not None else 0.1
         y, mean, rstd = ops.bn_silu_fwd(z, colstats, bn_w, bn_b, mod.bn.running_mean, mod.bn.running_var, count,
                                         eps=mod.bn.eps, momentum=mom, count_dev=count_dev)
-        mod.bn.num_batches_tracked += 1
+        mod.bn_calls_pending = getattr(mod, 'bn_calls_pending', 0) + 1     # flushed into num_batches_tracked lazily (flush_bn_counters)
         if any(ctx.needs_input_grad):
             ctx.mod, ctx.stride, ctx.count, ctx.count_dev = mod, stride, count, count_dev
             ctx.save_for_backward(x, z, mean, rstd, conv_w, bn_w, bn_b)

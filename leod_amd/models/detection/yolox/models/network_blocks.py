@@ -25,6 +25,8 @@ class BaseConv(nn.Module):
         self.bn = nn.BatchNorm2d(out_channels)
         self.act = get_activation(act, inplace=True)
         self.stride = stride
+        self.bn_calls_pending = 0            # training forwards not yet added to bn.num_batches_tracked (Fn.flush_bn_counters)
+        self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: Fn.flush_bn_counters(module))
 
     def forward_nhwc(self, x):
         return Fn.BaseConvFn.apply(self, x, self.conv.weight, self.bn.weight, self.bn.bias, self.stride, self.training)

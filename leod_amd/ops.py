@@ -321,11 +321,46 @@ def bn_silu_fwd(z, colstats, w, b, run_mean, run_var, count, eps=1e-5, momentum=
     return y, mean, rstd
 
 
+class StatArena:
+    """Zero-initialised float64 scratch for the BatchNorm statistic accumulators of ONE training step ((sum, sumsq) per
+    conv in the forward pass, (sum du, sum du*xhat) in the backward pass: 78 tiny buffers per step).  The engine zeroes
+    the whole arena with one memset at the start of a step and the ops take slices; outside an engine step (or when the
+    arena is exhausted) the ops fall back to ``torch.zeros``."""
+    buf: Optional[torch.Tensor] = None
+    off = 0
+    active = False
+    SIZE = 1 << 17                                    # doubles (1 MiB)
+
+    @classmethod
+    def begin_step(cls, device):
+        if cls.buf is None or cls.buf.device != torch.device(device):
+            cls.buf = torch.zeros(cls.SIZE, dtype=torch.float64, device=device)
+        else:
+            cls.buf.zero_()
+        cls.off, cls.active = 0, True
+
+    @classmethod
+    def end_step(cls):
+        cls.active = False
+
+    @classmethod
+    def zeros(cls, shape, device):
+        n = 1
+        for d in shape:
+            n *= d
+        n_al = (n + 1) & ~1                           # keep 16-byte alignment
+        if cls.active and cls.buf is not None and cls.buf.device == torch.device(device) and cls.off + n_al <= cls.SIZE:
+            t = cls.buf[cls.off:cls.off + n].view(shape)
+            cls.off += n_al
+            return t
+        return torch.zeros(shape, dtype=torch.float64, device=device)
+
+
 def bn_silu_bwd_reduce(dy, z, mean, rstd, w, b):
     _ck(dy, name='dy')
     N = z.shape[-1]
     M = z.numel() // N
-    sums = torch.zeros((2, N), dtype=torch.float64, device=z.device)
+    sums = StatArena.zeros((2, N), z.device)
     check(_l().leod_bn_silu_bwd_reduce(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(sums), M, N, _stream()),
           'bn_silu_bwd_reduce')
     return sums
