@@ -207,10 +207,12 @@ def main():
         # EVERY rank runs the two probe steps (a step contains collectives: a rank-0-only step would dead-lock N > 1);
         # only rank 0 brackets the kernel with events and reports
         probe = ops.KernelProbe() if rank == 0 else None
-        n_streams, eng.n_streams = eng.n_streams, 1      # isolated launches: no co-running kernels inside the event bracket
+        # isolated launches: no co-running kernels inside the event bracket (single stream, wgrad on the launch stream)
+        n_streams, eng.n_streams = eng.n_streams, 1
+        side, eng.wgrad_side = eng.wgrad_side, False
         for s in range(2):
             eng.step(ev, labels, label_tb, first_mask(1))
-        eng.n_streams = n_streams
+        eng.n_streams, eng.wgrad_side = n_streams, side
         if probe is not None:
             roofline = probe.finish(PEAK_HBM_GBS, PEAK_F32_MFMA_TFLOPS)
         # HBM bytes per launch of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
@@ -231,7 +233,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'RVT-{args.size} Gen1 240x304 (pad 256x320) T={T} bs={B}/GPU fully-supervised train step, '
                                    f'{len(label_ts)} labelled frames/sequence, random-init weights',
-                       'global_batch': world * B, 'seq_len': T, 'parallelism': f'dp{world}', 'launch': {'graph': 'one single-stream hipGraph per step', 'eager': f'eager, schedule={eng.schedule}',
+                       'global_batch': world * B, 'seq_len': T, 'parallelism': f'dp{world}', 'launch': {'graph': 'one single-stream hipGraph per step', 'eager': f'eager, schedule={eng.schedule}, wgrad side stream {"on" if eng.wgrad_side else "off"}',
                                   'cells': f'per-cell hipGraphs, {eng.n_streams}-stream stage wavefront'}[launch],
                        'per_gpu_event_frames_per_s': round(fps / world, 2), 'final_loss': round(loss_val, 4),
                        'whole_step_hbm_frac_of_peak': round(ALGO_MB_PER_FRAME_FP32 * 1e6 * fps / world / (PEAK_HBM_GBS * 1e9), 5)},
