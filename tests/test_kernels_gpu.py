@@ -47,7 +47,11 @@ def close(a, b, rtol=2e-5, atol=2e-6, what=''):
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('M,N,K,ln,act', [(200, 144, 48, True, False), (333, 192, 48, True, True),
                                           (64, 1152, 384, True, False), (130, 96, 32, False, False),
-                                          (77, 64, 16, True, True), (4096, 256, 64, True, True)])
+                                          (77, 64, 16, True, True), (4096, 256, 64, True, True),
+                                          # large M: LDS-staged GEMM, row-layout epilogue, row_stats prologue
+                                          (20000, 144, 48, True, False), (33333, 192, 48, True, True),
+                                          (17000, 1152, 384, True, False), (24000, 96, 96, False, True),
+                                          (9000, 128, 64, True, True)])
 def test_ln_linear_fwd(ops, M, N, K, ln, act):
     x, W, b = rnd((M, K), 1), rnd((N, K), 2, 0.2), rnd((N,), 3, 0.1)
     lw, lb = 1 + 0.2 * rnd((K,), 4), 0.1 * rnd((K,), 5)
@@ -63,7 +67,8 @@ def test_ln_linear_fwd(ops, M, N, K, ln, act):
         close(st[:, 1], 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-5), rtol=1e-5)
 
 
-@pytest.mark.parametrize('M,N,K', [(200, 48, 48), (129, 384, 1536), (64, 32, 128)])
+@pytest.mark.parametrize('M,N,K', [(200, 48, 48), (129, 384, 1536), (64, 32, 128),
+                                   (30000, 48, 192), (17000, 384, 1536), (65000, 48, 48), (9001, 64, 256)])
 def test_linear_lsres_fwd(ops, M, N, K):
     a, W, b, g, res = rnd((M, K), 1), rnd((N, K), 2, 0.2), rnd((N,), 3, 0.1), rnd((N,), 4), rnd((M, N), 5)
     t = F.linear(a, W, b)
@@ -104,7 +109,8 @@ def test_partition_attn(ops, B, H, W, C, heads, part, window):
     close(dq, qkv.grad, rtol=5e-5, atol=5e-6, what='attn bwd')
 
 
-@pytest.mark.parametrize('M,C,state', [(160, 32, True), (160, 32, False), (70, 48, True), (640, 384, True)])
+@pytest.mark.parametrize('M,C,state', [(160, 32, True), (160, 32, False), (70, 48, True), (640, 384, True),
+                                       (40960, 48, True), (10240, 96, False), (9000, 192, True)])
 def test_convlstm(ops, M, C, state):
     x, h0, c0 = rnd((M, C), 1), rnd((M, C), 2, 0.5), rnd((M, C), 3, 0.5)
     W, b = rnd((4 * C, 2 * C), 4, 0.15).requires_grad_(True), rnd((4 * C,), 5, 0.1).requires_grad_(True)
@@ -136,7 +142,10 @@ def test_convlstm(ops, M, C, state):
     close(db, b.grad, rtol=2e-4, atol=2e-5, what='db')
 
 
-@pytest.mark.parametrize('M,N,K', [(300, 144, 48), (1000, 48, 192), (257, 64, 32), (5000, 96, 96), (100, 1536, 384)])
+@pytest.mark.parametrize('M,N,K', [(300, 144, 48), (1000, 48, 192), (257, 64, 32), (5000, 96, 96), (100, 1536, 384),
+                                   # large M: wave-tiled wgrad (192x48, 48x192, 96x96, 48x48 tiles) and LDS dgrad
+                                   (30000, 192, 48), (30000, 48, 192), (20000, 288, 96), (65000, 48, 48),
+                                   (9000, 1536, 384), (12345, 144, 48), (16000, 128, 64)])
 def test_linear_backward(ops, M, N, K):
     x = rnd((M, K), 1).requires_grad_(True)
     W, b = rnd((N, K), 2, 0.2).requires_grad_(True), rnd((N,), 3).requires_grad_(True)
@@ -208,7 +217,10 @@ def test_stem_conv(ops, u8, B, H, W, Hp, Wp, N):
 
 @pytest.mark.parametrize('B,H,W,Cin,N,ks,stride', [(2, 16, 24, 16, 32, 3, 2), (2, 32, 40, 48, 96, 3, 2),
                                                    (3, 8, 12, 32, 32, 3, 1), (2, 8, 10, 96, 96, 3, 1),
-                                                   (2, 16, 20, 192, 96, 1, 1), (1, 7, 9, 64, 48, 3, 2)])
+                                                   (2, 16, 20, 192, 96, 1, 1), (1, 7, 9, 64, 48, 3, 2),
+                                                   # large M: LDS GEMM with repacked weights, parity-class dgrad (Q % 128 == 0)
+                                                   (8, 64, 80, 48, 96, 3, 2), (16, 32, 40, 96, 96, 3, 1),
+                                                   (24, 32, 40, 96, 192, 3, 2), (32, 16, 20, 192, 192, 1, 1)])
 def test_conv_nhwc(ops, B, H, W, Cin, N, ks, stride):
     x = rnd((B, Cin, H, W), 1).requires_grad_(True)
     w, bias = rnd((N, Cin, ks, ks), 2, 0.1).requires_grad_(True), rnd((N,), 3).requires_grad_(True)
