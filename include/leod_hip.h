@@ -166,6 +166,12 @@ int leod_set_scalars4(float* dst, float a, float b, float c, float d, leod_strea
 int leod_voxelize_u8(const long* x, const long* y, const long* pol, const long* t, long n_events, int* counts_ws,
                      unsigned char* out, int bins, int H, int W, int count_cutoff, int fastmode, leod_stream_t stream);
 
+/* On-device spatial augmentation of uint8 event representations src/dst [T,B,C,H,W] (data/utils/augmentor.py:216-331,
+ * 390-401): per batch sample b, params[b] = {hflip, mode (0 none, 1 zoom-in, 2 zoom-out), x0, y0, win_h, win_w}; flip
+ * first, then the zoom with ATen's nearest-exact index rule; zoom-out leaves zeros outside the pasted window. */
+int leod_augment_u8(const unsigned char* src, unsigned char* dst, const int* params, int T, int B, int C, int H, int W,
+                    leod_stream_t stream);
+
 /* ---- host-side C++ of the path (no GPU involved) ------------------------------------------------------------------
  * Tracking post-filter of the pseudo-label loop: linear-velocity tracklets, confidence-ordered greedy IoU association,
  * short-tracklet removal and in-painting of missed detections.  Replaces modules/tracking/linear.py:10-292,

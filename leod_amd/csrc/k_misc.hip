@@ -89,3 +89,64 @@ LEOD_API int leod_set_scalars4(float* dst, float a, float b, float c, float d, h
 }
 
 LEOD_API const char* leod_version() { return "leod_hip 0.1 (gfx950)"; }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// On-device spatial augmentation of uint8 event representations (data/utils/augmentor.py:216-331,390-401):
+// horizontal flip, then EITHER zoom-in (crop a window, nearest-exact resize to the full frame) OR zoom-out
+// (nearest-exact resize of the full frame to a window pasted at (x0, y0) on a zero canvas), per batch sample and
+// identically for all timesteps / channels of that sample.  One gather pass: every output byte is computed from the
+// source byte it maps to (the reference materialises the flipped tensor, the window and the resized tensor).
+// Index rule = ATen's nearest-exact: src = min(int(floorf((dst + 0.5f) * (float(in) / out))), in - 1).
+// params[b] = {hflip, mode (0 none, 1 zoom-in, 2 zoom-out), x0, y0, win_h, win_w}.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int nearest_exact(int dst, int in_size, int out_size) {
+    const float scale = (float)in_size / (float)out_size;
+    return min((int)floorf(((float)dst + 0.5f) * scale), in_size - 1);
+}
+
+__global__ __launch_bounds__(256) void augment_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                         const int* __restrict__ params, int B, int C, int H, int W) {
+    // grid: x = pixel quads of one plane, y = (t*B + b)*C + c
+    const int plane = blockIdx.y;
+    const int b = (plane / C) % B;
+    const int* pp = params + 6 * b;
+    const int hflip = pp[0], mode = pp[1], x0 = pp[2], y0 = pp[3], wh = pp[4], ww = pp[5];
+    const uint8_t* sp = src + (long)plane * H * W;
+    uint8_t* dp = dst + (long)plane * H * W;
+    const int quads = H * (W / 4);
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < quads; e += gridDim.x * 256) {
+        const int y = e / (W / 4), xq = (e - y * (W / 4)) * 4;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = xq + k;
+            int sy = y, sx = x;
+            bool live = true;
+            if (mode == 1) {                                  // zoom-in: window (wh x ww) at (y0, x0) -> full frame
+                sy = y0 + nearest_exact(y, wh, H);
+                sx = x0 + nearest_exact(x, ww, W);
+            } else if (mode == 2) {                           // zoom-out: full frame -> window at (y0, x0), zeros elsewhere
+                const int j = y - y0, i = x - x0;
+                live = (unsigned)j < (unsigned)wh && (unsigned)i < (unsigned)ww;
+                sy = live ? nearest_exact(j, H, wh) : 0;
+                sx = live ? nearest_exact(i, W, ww) : 0;
+            }
+            if (hflip) sx = W - 1 - sx;                       // the zooms act on the already flipped frame
+            const uint32_t v = live ? sp[(long)sy * W + sx] : 0u;
+            packed |= v << (8 * k);
+        }
+        *reinterpret_cast<uint32_t*>(dp + (long)y * W + xq) = packed;
+    }
+}
+
+LEOD_API int leod_augment_u8(const unsigned char* src, unsigned char* dst, const int* params, int T, int B, int C, int H, int W,
+                             hipStream_t stream) {
+    if (!src || !dst || !params || src == dst || (W & 3) || T <= 0 || B <= 0 || C <= 0) return LEOD_ERR_ARG;
+    const long planes = (long)T * B * C;
+    if (planes > 65535) return LEOD_ERR_UNSUPPORTED;            // grid.y limit; 21 x 8 x 20 = 3360 at the bench shape
+    const int quads = H * (W / 4);
+    dim3 grid(min(cdiv(quads, 256), 64), (unsigned)planes);
+    hipLaunchKernelGGL(augment_u8_kernel, grid, dim3(256), 0, stream, src, dst, params, B, C, H, W);
+    return leod_launch_status();
+}

@@ -102,6 +102,71 @@ class ObjectLabels:
     def reverse_flip_lr_(self) -> None:
         self.flip_lr_()
 
+    # ---- spatial augmentation of the labels (labels.py:67-69, 372-408, 436-457, 486-504) ---------------------------------
+    def remove_flat_labels_(self) -> None:
+        keep = (self.object_labels[:, 3] > 0) & (self.object_labels[:, 4] > 0)
+        self.object_labels = self.object_labels[keep]
+
+    def scale_(self, scaling_multiplier: float) -> None:
+        if len(self) == 0:
+            return
+        assert scaling_multiplier > 0
+        if scaling_multiplier == 1:
+            return
+        img_ht, img_wd = self.input_size_hw
+        new_ht, new_wd = scaling_multiplier * img_ht, scaling_multiplier * img_wd
+        self.input_size_hw = (new_ht, new_wd)
+        o = self.object_labels
+        x1 = th.clamp((o[:, 1] + o[:, 3]) * scaling_multiplier, max=new_wd - 1)
+        y1 = th.clamp((o[:, 2] + o[:, 4]) * scaling_multiplier, max=new_ht - 1)
+        self._set('x', o[:, 1] * scaling_multiplier)
+        self._set('y', o[:, 2] * scaling_multiplier)
+        self._set('w', x1 - self.object_labels[:, 1])
+        self._set('h', y1 - self.object_labels[:, 2])
+        self.remove_flat_labels_()
+
+    def zoom_in_and_rescale_(self, zoom_coordinates_x0y0, zoom_in_factor: float) -> None:
+        """Crop to the zoom window at ``zoom_coordinates_x0y0`` (size = frame / factor), drop boxes that fall outside,
+        rescale back to the frame resolution."""
+        if len(self) == 0:
+            return
+        assert len(zoom_coordinates_x0y0) == 2 and zoom_in_factor >= 1
+        if zoom_in_factor == 1:
+            return
+        z_x0, z_y0 = zoom_coordinates_x0y0
+        h_orig, w_orig = self.input_size_hw
+        assert 0 <= z_x0 <= w_orig - 1 and 0 <= z_y0 <= h_orig - 1
+        win_h, win_w = tuple(v / zoom_in_factor for v in self.input_size_hw)
+        z_x1 = min(z_x0 + win_w, w_orig - 1)
+        z_y1 = min(z_y0 + win_h, h_orig - 1)
+        o = self.object_labels
+        x0 = th.clamp(o[:, 1], min=z_x0, max=z_x1 - 1)
+        y0 = th.clamp(o[:, 2], min=z_y0, max=z_y1 - 1)
+        x1 = th.clamp(o[:, 1] + o[:, 3], min=z_x0, max=z_x1 - 1)
+        y1 = th.clamp(o[:, 2] + o[:, 4], min=z_y0, max=z_y1 - 1)
+        self._set('x', x0 - z_x0)
+        self._set('y', y0 - z_y0)
+        self._set('w', x1 - x0)
+        self._set('h', y1 - y0)
+        self.input_size_hw = (win_h, win_w)
+        self.remove_flat_labels_()
+        self.scale_(scaling_multiplier=zoom_in_factor)
+
+    def zoom_out_and_rescale_(self, zoom_coordinates_x0y0, zoom_out_factor: float) -> None:
+        """Shrink by 1 / factor and shift to the paste position of the shrunk frame."""
+        if len(self) == 0:
+            return
+        assert len(zoom_coordinates_x0y0) == 2 and zoom_out_factor >= 1
+        if zoom_out_factor == 1:
+            return
+        h_orig, w_orig = self.input_size_hw
+        self.scale_(scaling_multiplier=1 / zoom_out_factor)
+        self.input_size_hw = (h_orig, w_orig)
+        z_x0, z_y0 = zoom_coordinates_x0y0
+        assert 0 <= z_x0 <= w_orig - 1 and 0 <= z_y0 <= h_orig - 1
+        self._set('x', self.object_labels[:, 1] + z_x0)
+        self._set('y', self.object_labels[:, 2] + z_y0)
+
     def clamp_to_frame_(self):
         ht, wd = self.input_size_hw
         o = self.object_labels

@@ -82,3 +82,31 @@ def synth_labels(n_frames, hw, num_classes, seed=0, max_boxes=6, min_boxes=1):
         lab = np.stack([np.full(n, 1.0), x, y, w, h, cls, np.ones(n), np.ones(n)], axis=1)
         out.append(torch.from_numpy(lab.astype(np.float32)))
     return out
+
+
+def synth_augment_sample(seed: int, H: int, W: int, T: int = 4):
+    """One synthetic loader sample for the augmentation fixtures (tests/golden/g14_augment.npz): T uint8 voxel frames
+    [20,H,W] and per-frame label rows [n,8] (t,x,y,w,h,class,cls_conf,obj) or None on unlabelled frames."""
+    import torch
+    g = torch.Generator().manual_seed(4000 + seed)
+    ev = [((torch.rand((20, H, W), generator=g) < 0.15) * torch.randint(1, 12, (20, H, W), generator=g)).to(torch.uint8)
+          for _ in range(T)]
+    labels = []
+    for t in range(T):
+        if t % 2 == 0 and not (seed == 3 and t == 0):
+            labels.append(None)
+            continue
+        n = int(torch.randint(1, 4, (1,), generator=g))
+        w = torch.rand(n, generator=g) * 0.4 * W + 6
+        h = torch.rand(n, generator=g) * 0.4 * H + 6
+        x = torch.rand(n, generator=g) * (W - 1 - w)
+        y = torch.rand(n, generator=g) * (H - 1 - h)
+        labels.append(torch.stack([torch.full((n,), 1000. * (t + 1)), x, y, w, h,
+                                   torch.randint(0, 2, (n,), generator=g).float(), torch.ones(n), torch.ones(n)], 1))
+    return ev, labels
+
+
+AUGMENT_CASES = [(s, 60, 76) for s in range(8)] + [(100, 48, 64), (101, 48, 64)]
+AUGMENT_CFG = dict(prob_hflip=0.5, prob_tflip=0, rotate=dict(prob=0, min_angle_deg=2, max_angle_deg=6),
+                   zoom=dict(prob=0.8, zoom_in=dict(weight=8, factor=dict(min=1, max=1.5)),
+                             zoom_out=dict(weight=2, factor=dict(min=1, max=1.2))))

@@ -552,9 +552,37 @@ def g12_trainstep():
     save('g12_trainstep_micro.npz', **out)
 
 
+def g14_augment():
+    """RandomSpatialAugmentorGenX.__call__ of the reference (data/utils/augmentor.py:455-476) on seeded loader samples with
+    the shipped augmentation config (hflip 0.5, zoom 0.8: in 8 / out 2): resulting augmentation state, augmented uint8
+    tensors and transformed labels."""
+    from data.utils.augmentor import RandomSpatialAugmentorGenX
+    from data.genx_utils.labels import SparselyBatchedObjectLabels
+    from data.utils.types import DataType
+    from oracle.synth import synth_augment_sample, AUGMENT_CASES, AUGMENT_CFG
+    cfg = DictConfig(AUGMENT_CFG)
+    out = {}
+    for seed, H, W in AUGMENT_CASES:
+        ev, labels = synth_augment_sample(seed, H, W)
+        aug = RandomSpatialAugmentorGenX(dataset_hw=(H, W), automatic_randomization=True, augm_config=cfg)
+        objs = [None if l is None else ObjectLabels(l.clone(), (H, W)) for l in labels]
+        torch.manual_seed(900 + seed)
+        res = aug({DataType.EV_REPR: [e.clone() for e in ev], DataType.OBJLABELS_SEQ: SparselyBatchedObjectLabels(objs)})
+        st = res[DataType.AUGM_STATE]
+        out[f's{seed}_state'] = np.array([float(st.apply_h_flip), float(st.zoom_in.active), st.zoom_in.x0, st.zoom_in.y0,
+                                          st.zoom_in.zoom_in_factor, float(st.zoom_out.active), st.zoom_out.x0,
+                                          st.zoom_out.y0, st.zoom_out.zoom_out_factor], dtype=np.float64)
+        out[f's{seed}_ev'] = torch.stack(res[DataType.EV_REPR]).numpy()
+        for t, l in enumerate(res[DataType.OBJLABELS_SEQ]):
+            if l is not None:
+                out[f's{seed}_lab{t}'] = l.object_labels.numpy().astype(np.float32)
+                out[f's{seed}_hw{t}'] = np.array(l.input_size_hw, dtype=np.float64)
+    save('g14_augment.npz', **out)
+
+
 ALL = dict(g01=g01_convlstm, g02=g02_partition, g03=g03_attention, g04=g04_backbone, g05=g05_head,
            g06=g06_simota, g07=g07_postprocess, g08=g08_pseudo, g10=g10_voxel, g11=g11_manifest,
-           g12=g12_trainstep, g13=g13_tracker)
+           g12=g12_trainstep, g13=g13_tracker, g14=g14_augment)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)

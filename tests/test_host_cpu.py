@@ -211,3 +211,29 @@ def test_native_tracker_argument_checks():
     g = [np.array([False])] * 2
     with pytest.raises(LeodHipError):
         track(b, g, [3, 3], (240, 304))                       # frame indices must be strictly increasing
+
+
+def test_augmentor_state_and_labels_match_reference(golden_dir):
+    """Host side of the on-device augmentation: with the reference's seed the mirror draws the same AugmentationState
+    (same torch RNG call sequence, data/utils/augmentor.py:173-207,284-309,495-558) and transforms the labels to the same
+    rows and canvas sizes (data/genx_utils/labels.py:372-408,436-457,486-509)."""
+    from oracle.synth import synth_augment_sample, AUGMENT_CASES, AUGMENT_CFG
+    from leod_amd.config.dictconfig import DictConfig
+    from leod_amd.data.genx_utils.labels import ObjectLabels
+    from leod_amd.data.utils.augmentor import RandomSpatialAugmentorGenX
+    g = np.load(os.path.join(golden_dir, 'g14_augment.npz'))
+    for seed, H, W in AUGMENT_CASES:
+        _, labels = synth_augment_sample(seed, H, W)
+        aug = RandomSpatialAugmentorGenX((H, W), True, DictConfig(AUGMENT_CFG))
+        objs = [None if l is None else ObjectLabels(l.clone(), (H, W)) for l in labels]
+        torch.manual_seed(900 + seed)
+        st = aug.augment_sample_labels(objs)
+        got = np.array([float(st.apply_h_flip), float(st.zoom_in.active), st.zoom_in.x0, st.zoom_in.y0, st.zoom_in.zoom_in_factor,
+                        float(st.zoom_out.active), st.zoom_out.x0, st.zoom_out.y0, st.zoom_out.zoom_out_factor])
+        np.testing.assert_array_equal(got, g[f's{seed}_state'])
+        for t, l in enumerate(objs):
+            if l is None:
+                assert f's{seed}_lab{t}' not in g.files
+                continue
+            np.testing.assert_array_equal(l.object_labels.numpy(), g[f's{seed}_lab{t}'])
+            assert tuple(float(v) for v in l.input_size_hw) == tuple(g[f's{seed}_hw{t}'])

@@ -502,3 +502,52 @@ def test_adamw_clip(ops):
         opt.step()
         ops.adamw_clip_step(pd, gi.to(DEV), m, v, 2e-4, step, weight_decay=0.01, clip_value=1.0)
         close(pd, p.detach(), rtol=1e-6, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_augment_u8_golden(golden_dir):
+    """leod_augment_u8 (one gather kernel per batch) == the reference's per-sample flip / interpolate / paste pipeline on the
+    recorded augmentation states, batched as [T, B] with a different state per sample."""
+    from oracle.synth import synth_augment_sample, AUGMENT_CASES
+    from leod_amd.data.utils.augmentor import AugmentationState, ZoomInState, ZoomOutState, augment_events
+    g = np.load(os.path.join(golden_dir, 'g14_augment.npz'))
+    for hw in ((60, 76), (48, 64)):
+        cases = [c for c in AUGMENT_CASES if (c[1], c[2]) == hw]
+        evs, states = [], []
+        for seed, H, W in cases:
+            ev, _ = synth_augment_sample(seed, H, W)
+            evs.append(torch.stack(ev))
+            s = g[f's{seed}_state']
+            states.append(AugmentationState(apply_h_flip=bool(s[0]),
+                                            zoom_in=ZoomInState(bool(s[1]), int(s[2]), int(s[3]), float(s[4])),
+                                            zoom_out=ZoomOutState(bool(s[5]), int(s[6]), int(s[7]), float(s[8]))))
+        batch = torch.stack(evs, 1).contiguous().to(DEV)                   # [T, B, 20, H, W]
+        out = augment_events(batch, states).cpu().numpy()
+        for b, (seed, _, _) in enumerate(cases):
+            np.testing.assert_array_equal(out[:, b], g[f's{seed}_ev'])
+
+
+@pytest.mark.parametrize('hflip', [False, True])
+@pytest.mark.parametrize('mode,x0,y0,factor', [(0, 0, 0, 1.0), (1, 37, 21, 1.37), (1, 0, 0, 1.5), (2, 11, 9, 1.13), (2, 0, 0, 1.2)])
+def test_augment_u8_full_size_vs_torch(hflip, mode, x0, y0, factor):
+    """Gen1 frame size: the kernel against plain PyTorch (flip + interpolate(nearest-exact) + paste) on the device."""
+    from leod_amd.data.utils.augmentor import AugmentationState, ZoomInState, ZoomOutState, augment_events
+    T, B, H, W = 3, 2, 240, 304
+    g = torch.Generator().manual_seed(11)
+    ev = ((torch.rand((T, B, 20, H, W), generator=g) < 0.1) * torch.randint(1, 200, (T, B, 20, H, W), generator=g)).to(torch.uint8).to(DEV)
+    st = AugmentationState(apply_h_flip=hflip, zoom_in=ZoomInState(mode == 1, x0, y0, factor if mode == 1 else 1.0),
+                           zoom_out=ZoomOutState(mode == 2, x0, y0, factor if mode == 2 else 1.0))
+    ident = AugmentationState()
+    out = augment_events(ev, [st, ident])
+    ref = ev[:, 0].reshape(T * 20, H, W)
+    if hflip:
+        ref = torch.flip(ref, dims=[-1])
+    wh, ww = int(H / factor), int(W / factor)
+    if mode == 1:
+        ref = F.interpolate(ref[None, :, y0:y0 + wh, x0:x0 + ww].float(), size=(H, W), mode='nearest-exact')[0].to(torch.uint8)
+    elif mode == 2:
+        win = F.interpolate(ref[None].float(), size=(wh, ww), mode='nearest-exact')[0].to(torch.uint8)
+        ref = torch.zeros_like(ref)
+        ref[:, y0:y0 + wh, x0:x0 + ww] = win
+    assert torch.equal(out[:, 0].reshape(T * 20, H, W), ref)
+    assert torch.equal(out[:, 1], ev[:, 1])

@@ -303,3 +303,21 @@ def test_tracker_oracle_matches_reference(golden_dir):
         np.testing.assert_array_equal(np.concatenate(r2, 0), exp_rows)
         n += 1
     assert n == 24
+
+
+def test_augment_oracle_matches_reference(golden_dir):
+    """oracle.augment (flip / zoom-in / zoom-out with ATen's nearest-exact index rule) == the tensors the reference's
+    RandomSpatialAugmentorGenX produced for the recorded augmentation states (data/utils/augmentor.py:229-331,396-401)."""
+    from oracle import augment as oa
+    from oracle.synth import synth_augment_sample, AUGMENT_CASES
+    g = np.load(os.path.join(golden_dir, 'g14_augment.npz'))
+    modes = set()
+    for seed, H, W in AUGMENT_CASES:
+        ev, _ = synth_augment_sample(seed, H, W)
+        st = g[f's{seed}_state']
+        mode = 1 if st[1] else (2 if st[5] else 0)
+        x0, y0, f = (int(st[2]), int(st[3]), float(st[4])) if mode == 1 else (int(st[6]), int(st[7]), float(st[8]))
+        out = oa.apply(torch.stack(ev).numpy(), bool(st[0]), mode, x0, y0, f)
+        np.testing.assert_array_equal(out, g[f's{seed}_ev'])
+        modes.add((bool(st[0]), mode))
+    assert {m for _, m in modes} == {0, 1, 2} and {f for f, _ in modes} == {False, True}
