@@ -123,6 +123,9 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--seq-len', type=int, default=21)
     ap.add_argument('--size', default='small')
+    ap.add_argument('--dataset', choices=('gen1', 'gen4'), default='gen1', help='gen4: 3 classes, 360x640 frames (downsampled by 2)')
+    ap.add_argument('--full-res', action='store_true', help='gen4 at 720x1280 -> 768x1280, 240-token partitions '
+                    '(BASELINE configs[3]: --dataset gen4 --full-res --size base --seq-len 11 --batch 2)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay one single-stream hipGraph per step instead of the default eager '
@@ -145,7 +148,11 @@ def main():
     from leod_amd.cellgraph import CellGraphEngine as TrainEngine      # TrainEngine + the per-cell hipGraph scheduler
     from leod_amd import ops
 
-    cfg = dynamically_modify_train_config(full_config('gen1', args.size))
+    over = dict(dataset=dict(downsample_by_factor_2=not args.full_res)) if args.dataset == 'gen4' else {}
+    cfg = dynamically_modify_train_config(full_config(args.dataset, args.size, overrides=over))
+    hw = (240, 304) if args.dataset == 'gen1' else ((720, 1280) if args.full_res else (360, 640))
+    in_hw = tuple(cfg.model.backbone.in_res_hw)
+    headline = args.dataset == 'gen1' and args.size == 'small'       # the configuration BASELINE.json's metric is quoted on
     torch.manual_seed(0)                                  # identical random-init weights on every rank
     det = YoloXDetector(cfg.model).to(dev)
     eng = TrainEngine(det, lr=cfg.training.learning_rate, weight_decay=cfg.training.weight_decay,
@@ -155,7 +162,7 @@ def main():
                       clip_value=cfg.training.gradient_clip_val)
     T, B = args.seq_len, args.batch
     label_ts = tuple(t for t in (4, 9, 14, 19) if t < T) or (T - 1,)
-    ev, labels, label_tb, _ = make_batch(T, B, (240, 304), cfg.model.head.num_classes, rank, dev, label_ts)
+    ev, labels, label_tb, _ = make_batch(T, B, hw, cfg.model.head.num_classes, rank, dev, label_ts)
     g = torch.Generator(device='cpu').manual_seed(77 + rank)
 
     def first_mask(step):
@@ -231,15 +238,16 @@ def main():
             'value': round(fps, 2), 'unit': 'event-frames/s (whole job)', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1000 * dt / args.steps, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'RVT-{args.size} Gen1 240x304 (pad 256x320) T={T} bs={B}/GPU fully-supervised train step, '
+            'config': {'workload': f'RVT-{args.size} {args.dataset} {hw[0]}x{hw[1]} (pad {in_hw[0]}x{in_hw[1]}) T={T} bs={B}/GPU fully-supervised train step, '
                                    f'{len(label_ts)} labelled frames/sequence, random-init weights',
                        'global_batch': world * B, 'seq_len': T, 'parallelism': f'dp{world}', 'launch': {'graph': 'one single-stream hipGraph per step', 'eager': f'eager, schedule={eng.schedule}, wgrad side stream {"on" if eng.wgrad_side else "off"}',
                                   'cells': f'per-cell hipGraphs, {eng.n_streams}-stream stage wavefront'}[launch],
                        'per_gpu_event_frames_per_s': round(fps / world, 2), 'final_loss': round(loss_val, 4),
-                       'whole_step_hbm_frac_of_peak': round(ALGO_MB_PER_FRAME_FP32 * 1e6 * fps / world / (PEAK_HBM_GBS * 1e9), 5)},
+                       'whole_step_hbm_frac_of_peak': round(ALGO_MB_PER_FRAME_FP32 * 1e6 * fps / world / (PEAK_HBM_GBS * 1e9), 5)
+                       if headline else None},
             'roofline': roofline,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and headline:
             out['cpu_baseline'] = cpu_baseline_bounded()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -144,7 +144,9 @@ int leod_yolox_loss(const float* outputs, const float* labels, const unsigned ch
 
 /* postprocess + torchvision-semantics batched NMS for B images at once.  nc>0: pred [B,A,5+nc] (cx,cy,w,h,obj,cls..),
  * boxes rewritten IN PLACE to xyxy; nc==0: pred [B,A,7] already (xyxy,obj,cls_conf,cls_id) (TTA merge).
- * det_out [B,max_det,7] in NMS order, det_cnt[B]. */
+ * det_out [B,max_det,7] in NMS order, det_cnt[B].  One workgroup per image keeps the candidates in LDS: all A anchors when
+ * they fit (A <= 5040: Gen1, Gen4), else 4096 candidates -- an image with more boxes above conf_thre gets det_cnt = -1
+ * (leod_pseudo_filter passes the -1 on). */
 int leod_postprocess_nms(float* pred, float* det_out, int* det_cnt, int B, int A, int nc, float conf_thre, float nms_thre,
                          int class_agnostic, int max_det, int vanilla_limit, leod_stream_t stream);
 /* pred2label + filter_pred_boxes: det -> labels [B,max_det,8] = (0,x,y,w,h,cls,cls_conf,obj), lab_cnt[B]. */
@@ -167,8 +169,10 @@ int leod_voxelize_u8(const long* x, const long* y, const long* pol, const long* 
                      unsigned char* out, int bins, int H, int W, int count_cutoff, int fastmode, leod_stream_t stream);
 
 /* On-device spatial augmentation of uint8 event representations src/dst [T,B,C,H,W] (data/utils/augmentor.py:216-331,
- * 390-401): per batch sample b, params[b] = {hflip, mode (0 none, 1 zoom-in, 2 zoom-out), x0, y0, win_h, win_w}; flip
- * first, then the zoom with ATen's nearest-exact index rule; zoom-out leaves zeros outside the pasted window. */
+ * 390-401): per batch sample b, params[b] = {hflip, mode (0 none, 1 zoom-in, 2 zoom-out), x0, y0, win_h, win_w, tflip}
+ * (7 ints); flip first, then the zoom with ATen's nearest-exact index rule; zoom-out leaves zeros outside the pasted
+ * window.  tflip != 0 additionally applies time_flip_data (data/genx_utils/sequence_base.py:207-227): frames in reverse
+ * order and the 2*bins channel planes of each frame reversed. */
 int leod_augment_u8(const unsigned char* src, unsigned char* dst, const int* params, int T, int B, int C, int H, int W,
                     leod_stream_t stream);
 

@@ -164,15 +164,17 @@ struct AssignOut {
 #define MAXGT 128
 __global__ __launch_bounds__(256) void simota_kernel(const float* __restrict__ outputs, const float* __restrict__ labels,
                                                      float* __restrict__ ws, AssignOut o, Levels L, int Nmax, int nc,
-                                                     float ignore_label) {
+                                                     float ignore_label, int cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int A = L.A;
     const int b = blockIdx.x;
     const int nch = 5 + nc;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int* cand = reinterpret_cast<int*>(smem);               // [A] compacted candidate anchors
-    int* cnt = cand + A;                                    // [A] per-candidate match count
-    int* selg = cnt + A;                                    // [A] the gt that selected the candidate
+    // candidates lie within 1.5 strides of a gt centre: at most 3 x 3 anchors per gt and level, so `cap` (host: 16 per gt and
+    // level, bounded by A) never binds; an overflow would be reported through status bit 2 instead of corrupting LDS
+    int* cand = reinterpret_cast<int*>(smem);               // [cap] compacted candidate anchors
+    int* cnt = cand + cap;                                  // [cap] per-candidate match count
+    int* selg = cnt + cap;                                  // [cap] the gt that selected the candidate
     __shared__ float gtb[MAXGT][4];
     __shared__ int gtrow[MAXGT], gtcls[MAXGT], kg[MAXGT];
     __shared__ int s_nw, s_n, s_nvalid, s_npos, s_any_invalid, s_scan[5], s_nfg;
@@ -236,11 +238,12 @@ __global__ __launch_bounds__(256) void simota_kernel(const float* __restrict__ o
         __syncthreads();
         int off = s_npos;
         for (int w2 = 0; w2 < wave; ++w2) off += s_scan[w2];
-        if (isc) { const int j = off + __popcll(bal & ((1ull << lane) - 1)); cand[j] = a; cnt[j] = 0; selg[j] = -1; }
+        if (isc) { const int j = off + __popcll(bal & ((1ull << lane) - 1)); if (j < cap) { cand[j] = a; cnt[j] = 0; selg[j] = -1; } }
         __syncthreads();
         if (tid == 0) s_npos += s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
         __syncthreads();
     }
+    if (s_npos > cap) { if (tid == 0) { o.num_fg_img[b] = 0; atomicOr(o.totals + 2, 2); } return; }
     const int npos = s_npos;
     if (n == 0) { if (tid == 0) { o.num_fg_img[b] = 0; } return; }
     if (tid == 0) atomicAdd(o.totals + 1, n);
@@ -449,15 +452,17 @@ __device__ __forceinline__ bool iou_gt(const float* a, const float* b, float thr
 __global__ __launch_bounds__(1024) void postprocess_nms_kernel(float* __restrict__ pred, float* __restrict__ det_out,
                                                                int* __restrict__ det_cnt, int A, int nc, int ncols,
                                                                float conf_thre, float nms_thre, int class_agnostic,
-                                                               int max_det, int vanilla_limit, int convert_boxes) {
+                                                               int max_det, int vanilla_limit, int convert_boxes, int cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NW = 16;
-    int NP2 = 1; while (NP2 < A) NP2 <<= 1;
+    // cap = most candidates (score >= conf_thre) the LDS arrays hold: A when everything fits (Gen1 1680, Gen4 5040 anchors),
+    // 4096 for larger heads (1 Mpx: 20160 anchors); an image with more candidates reports det_cnt = -1
+    int NP2 = 1; while (NP2 < cap) NP2 <<= 1;
     float* skey = reinterpret_cast<float*>(smem);            // [NP2] scores (sorted desc)
     int* sidx = reinterpret_cast<int*>(skey + NP2);          // [NP2] anchor index
-    float* sbox = reinterpret_cast<float*>(sidx + NP2);      // [A][4] boxes in sorted order (with class offset)
-    unsigned char* removed = reinterpret_cast<unsigned char*>(sbox + 4 * (size_t)A);   // [A]
+    float* sbox = reinterpret_cast<float*>(sidx + NP2);      // [cap][4] boxes in sorted order (with class offset)
+    unsigned char* removed = reinterpret_cast<unsigned char*>(sbox + 4 * (size_t)cap);   // [cap]
     __shared__ int s_scan[NW], s_n, s_keep;
     __shared__ float s_red[NW];
     __shared__ unsigned long long s_kept;
@@ -484,12 +489,13 @@ __global__ __launch_bounds__(1024) void postprocess_nms_kernel(float* __restrict
         __syncthreads();
         int off = s_n;
         for (int w2 = 0; w2 < wave; ++w2) off += s_scan[w2];
-        if (ok) { const int j = off + __popcll(bal & ((1ull << lane) - 1)); skey[j] = score; sidx[j] = a; }
+        if (ok) { const int j = off + __popcll(bal & ((1ull << lane) - 1)); if (j < cap) { skey[j] = score; sidx[j] = a; } }
         __syncthreads();
         if (tid == 0) { int t = 0; for (int w2 = 0; w2 < NW; ++w2) t += s_scan[w2]; s_n += t; }
         __syncthreads();
     }
     const int n = s_n;
+    if (n > cap) { if (tid == 0) det_cnt[b] = -1; return; }      // boxes were converted in place like the reference does
     if (n == 0) { if (tid == 0) det_cnt[b] = 0; return; }
     int np2 = 1; while (np2 < n) np2 <<= 1;
     for (int j = n + tid; j < np2; j += 1024) { skey[j] = -INFINITY; sidx[j] = 0x7fffffff; }
@@ -621,6 +627,7 @@ __global__ __launch_bounds__(64) void pseudo_filter_kernel(const float* __restri
                                                            int nthr, int filter_boxes, float frame_w, float frame_h) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int n = det_cnt[b];
+    if (n < 0) { if (lane == 0) lab_cnt[b] = -1; return; }          // NMS overflow report travels with the counts
     int outn = 0;
     for (int base = 0; base < n; base += 64) {
         const int j = base + lane;
@@ -699,12 +706,13 @@ LEOD_API int leod_simota_assign(const float* outputs, const float* labels, float
         return LEOD_ERR_ARG;
     if (B == 0) return LEOD_OK;
     const Levels L = make_levels(nlv, hs, wsz, strides);
-    const size_t shm = (size_t)L.A * 3 * sizeof(int);
+    const int cap = (int)min((long)L.A, 16L * nlv * min(Nmax, MAXGT));
+    const size_t shm = (size_t)max(cap, 1) * 3 * sizeof(int);
     if (shm > 120 * 1024) return LEOD_ERR_UNSUPPORTED;
     AssignOut o{fg_mask, ignore_mask, matched_row, matched_valid_idx, pred_iou, num_fg_img, totals};
     static int shm_set = 0;     // raise the dynamic-LDS limit once (not a stream operation; keeps graph capture clean)
     if (shm_set < (int)shm) { (void)hipFuncSetAttribute((const void*)simota_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); shm_set = (int)shm; }
-    hipLaunchKernelGGL(simota_kernel, dim3(B), dim3(256), shm, stream, outputs, labels, workspace, o, L, Nmax, nc, ignore_label);
+    hipLaunchKernelGGL(simota_kernel, dim3(B), dim3(256), shm, stream, outputs, labels, workspace, o, L, Nmax, nc, ignore_label, cap);
     return leod_launch_status();
 }
 
@@ -731,14 +739,14 @@ LEOD_API int leod_postprocess_nms(float* pred, float* det_out, int* det_cnt, int
                                   float nms_thre, int class_agnostic, int max_det, int vanilla_limit, hipStream_t stream) {
     if (!pred || !det_out || !det_cnt || A <= 0) return LEOD_ERR_ARG;
     if (B == 0) return LEOD_OK;
-    int np2 = 1; while (np2 < A) np2 <<= 1;
-    const size_t shm = (size_t)np2 * 8 + (size_t)A * 4 * 4 + (size_t)A + 16;
-    if (shm > 156 * 1024) return LEOD_ERR_UNSUPPORTED;
+    auto lds_bytes = [](int cap_) { int np2 = 1; while (np2 < cap_) np2 <<= 1; return (size_t)np2 * 8 + (size_t)cap_ * 17 + 16; };
+    const int cap = lds_bytes(A) <= 156 * 1024 ? A : 4096;
+    const size_t shm = lds_bytes(cap);
     static int shm_set = 0;
     if (shm_set < (int)shm) { (void)hipFuncSetAttribute((const void*)postprocess_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); shm_set = (int)shm; }
     const int ncols = nc > 0 ? 5 + nc : 7;
     hipLaunchKernelGGL(postprocess_nms_kernel, dim3(B), dim3(1024), shm, stream, pred, det_out, det_cnt, A, nc, ncols, conf_thre,
-                       nms_thre, class_agnostic, max_det, vanilla_limit, nc > 0 ? 1 : 0);
+                       nms_thre, class_agnostic, max_det, vanilla_limit, nc > 0 ? 1 : 0, cap);
     return leod_launch_status();
 }
 

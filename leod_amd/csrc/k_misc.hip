@@ -98,7 +98,9 @@ LEOD_API const char* leod_version() { return "leod_hip 0.1 (gfx950)"; }
 // identically for all timesteps / channels of that sample.  One gather pass: every output byte is computed from the
 // source byte it maps to (the reference materialises the flipped tensor, the window and the resized tensor).
 // Index rule = ATen's nearest-exact: src = min(int(floorf((dst + 0.5f) * (float(in) / out))), in - 1).
-// params[b] = {hflip, mode (0 none, 1 zoom-in, 2 zoom-out), x0, y0, win_h, win_w}.
+// params[b] = {hflip, mode (0 none, 1 zoom-in, 2 zoom-out), x0, y0, win_h, win_w, tflip}.
+// tflip (data/genx_utils/sequence_base.py:207-227, time_flip_data): the sample's frames in reverse order and each frame's
+// 2*bins channel planes reversed (`x.flip(0)`), i.e. out[t, b, c] = aug(in[T-1-t, b, C-1-c]).
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int nearest_exact(int dst, int in_size, int out_size) {
     const float scale = (float)in_size / (float)out_size;
@@ -106,13 +108,18 @@ __device__ __forceinline__ int nearest_exact(int dst, int in_size, int out_size)
 }
 
 __global__ __launch_bounds__(256) void augment_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                                         const int* __restrict__ params, int B, int C, int H, int W) {
+                                                         const int* __restrict__ params, int T, int B, int C, int H, int W) {
     // grid: x = pixel quads of one plane, y = (t*B + b)*C + c
     const int plane = blockIdx.y;
     const int b = (plane / C) % B;
-    const int* pp = params + 6 * b;
+    const int* pp = params + 7 * b;
     const int hflip = pp[0], mode = pp[1], x0 = pp[2], y0 = pp[3], wh = pp[4], ww = pp[5];
-    const uint8_t* sp = src + (long)plane * H * W;
+    int src_plane = plane;
+    if (pp[6]) {
+        const int c = plane % C, t = plane / (C * B);
+        src_plane = ((T - 1 - t) * B + b) * C + (C - 1 - c);
+    }
+    const uint8_t* sp = src + (long)src_plane * H * W;
     uint8_t* dp = dst + (long)plane * H * W;
     const int quads = H * (W / 4);
     for (int e = blockIdx.x * 256 + threadIdx.x; e < quads; e += gridDim.x * 256) {
@@ -147,6 +154,6 @@ LEOD_API int leod_augment_u8(const unsigned char* src, unsigned char* dst, const
     if (planes > 65535) return LEOD_ERR_UNSUPPORTED;            // grid.y limit; 21 x 8 x 20 = 3360 at the bench shape
     const int quads = H * (W / 4);
     dim3 grid(min(cdiv(quads, 256), 64), (unsigned)planes);
-    hipLaunchKernelGGL(augment_u8_kernel, grid, dim3(256), 0, stream, src, dst, params, B, C, H, W);
+    hipLaunchKernelGGL(augment_u8_kernel, grid, dim3(256), 0, stream, src, dst, params, T, B, C, H, W);
     return leod_launch_status();
 }

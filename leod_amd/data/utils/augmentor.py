@@ -196,11 +196,16 @@ class RandomSpatialAugmentorGenX:
 
 
 def state_to_params(state: AugmentationState, hw: Tuple[int, int]) -> List[int]:
-    """{hflip, mode, x0, y0, win_h, win_w} of ``leod_augment_u8``; window sizes as the reference computes them
-    (``int(size / factor)``, cropped at the frame border like the slice ``[y0:y0+h, x0:x0+w]``)."""
+    """{hflip, mode, x0, y0, win_h, win_w, tflip} of ``leod_augment_u8``; window sizes as the reference computes them
+    (``int(size / factor)``, cropped at the frame border like the slice ``[y0:y0+h, x0:x0+w]``).  ``apply_t_flip`` is
+    the loader's ``time_flip_data`` (sequence_base.py:207-227: frames reversed, channel planes reversed) -- the reference's
+    augmentor leaves it to the dataset (augmentor.py:464-465), here it rides in the same gather pass."""
     if state.rotation.active:
         raise NotImplementedError('rotation augmentation (probability 0 in every shipped config)')
-    assert not state.apply_t_flip, 'time flip is applied by the loader, not here (augmentor.py:464-465)'
+    return _spatial_params(state, hw) + [int(bool(state.apply_t_flip))]
+
+
+def _spatial_params(state: AugmentationState, hw: Tuple[int, int]) -> List[int]:
     H, W = hw
     if state.zoom_in.active and state.zoom_in.zoom_in_factor != 1:
         assert not state.zoom_out.active

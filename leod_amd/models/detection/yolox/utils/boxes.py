@@ -31,7 +31,7 @@ def postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45, class_agn
     if len(prediction) == 0:
         return []
     det, cnt = postprocess_padded(prediction, num_classes, conf_thre, nms_thre, class_agnostic)
-    counts = cnt.tolist()                      # the only host sync of the call (the API returns ragged lists)
+    counts = ops.host_counts(cnt)              # the only host sync of the call (the API returns ragged lists)
     return [det[i, :n] if n > 0 else pad for i, n in enumerate(counts)]
 
 

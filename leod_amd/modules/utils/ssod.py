@@ -55,7 +55,7 @@ def pred2label(pred: List[th.Tensor], obj_thresh: Union[float, List[float]] = 0.
     cnt = torch.tensor([len(p) for p in pred], dtype=torch.int32, device=dev)
     lab, lcnt = ops.pseudo_filter(det, cnt, obj_thresh, cls_thresh, filter_bbox_fn is not None,
                                   frame_hw(dataset_name, downsampled_by_2))
-    return [ObjectLabels(lab[i, :n], hw) for i, n in enumerate(lcnt.tolist())]
+    return [ObjectLabels(lab[i, :n], hw) for i, n in enumerate(ops.host_counts(lcnt, 'pred2label'))]
 
 
 def filter_pred_boxes(boxes: th.Tensor, dataset_name: str = 'gen1', downsampled_by_2: bool = False):

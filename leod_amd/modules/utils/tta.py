@@ -27,7 +27,7 @@ def tta_postprocess(preds: List[th.Tensor], conf_thre: float = 0.7, nms_thre: fl
     for j, i in enumerate(live):
         rows[j, :preds[i].shape[0]] = preds[i]
     det, cnt = tta_postprocess_padded(rows, conf_thre, nms_thre, class_agnostic)
-    for j, (i, n) in enumerate(zip(live, cnt.tolist())):
+    for j, (i, n) in enumerate(zip(live, ops.host_counts(cnt, 'tta_postprocess'))):
         if n > 0:
             out[i] = det[j, :n]
     return out

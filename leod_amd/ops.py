@@ -458,6 +458,16 @@ def postprocess_nms(pred, num_classes, conf_thre, nms_thre, class_agnostic=False
     return det, cnt
 
 
+def host_counts(cnt, what='postprocess_nms'):
+    """Per-image counts on the host (one sync).  A negative count is the kernels' overflow report: more candidates above the
+    confidence threshold than the workgroup's LDS arrays hold (only possible for heads with more than 5040 anchors)."""
+    counts = cnt.tolist()
+    if counts and min(counts) < 0:
+        raise LeodHipError(f'{what}: image {counts.index(min(counts))} has more than 4096 candidates above conf_thre '
+                           f'(anchor count too large for the single-workgroup NMS); raise conf_thre')
+    return counts
+
+
 def pseudo_filter(det, cnt, obj_thr, cls_thr, filter_boxes, frame_hw):
     _ck(det, name='det')
     _ck(cnt, torch.int32, 'cnt')

@@ -282,14 +282,18 @@ def test_conv_bn_eval_and_train(ops):
 
 
 # ---------------------------------------------------------------------------------------------------
-def _gen1_case(B, seed, nc=2, with_ignore=False):
-    hws, strides = [(32, 40), (16, 20), (8, 10)], (8, 16, 32)
+HEAD_GEOMS = {'gen1': ((256, 320), (240, 304), 2), 'gen4': ((384, 640), (360, 640), 3), '1mpx': ((768, 1280), (720, 1280), 3)}
+
+
+def _gen1_case(B, seed, nc=2, with_ignore=False, geom='gen1'):
+    (Hp, Wp), frame_hw, nc = HEAD_GEOMS[geom][0], HEAD_GEOMS[geom][1], (nc if geom == 'gen1' else HEAD_GEOMS[geom][2])
+    hws, strides = [(Hp // s_, Wp // s_) for s_ in (8, 16, 32)], (8, 16, 32)
     gx, gy, gs = oh.make_grids(hws, strides)
     A = gx.numel()
     g = torch.Generator().manual_seed(seed)
     outputs = torch.cat([torch.stack([(gx + 0.5) * gs, (gy + 0.5) * gs, gs * 3, gs * 2.5], 1)[None].repeat(B, 1, 1)
                          + torch.randn(B, A, 4, generator=g) * 2, torch.randn(B, A, 1 + nc, generator=g) * 2], -1)
-    labs = synth_labels(B, (240, 304), nc, seed=seed, max_boxes=6)
+    labs = synth_labels(B, frame_hw, nc, seed=seed, max_boxes=6)
     tg = op.batched_yolox_labels(labs)
     if B > 2:
         tg[B - 1] = 0                                   # an image without labels
@@ -300,12 +304,13 @@ def _gen1_case(B, seed, nc=2, with_ignore=False):
 
 
 @pytest.mark.parametrize('with_ignore', [False, True])
-@pytest.mark.parametrize('seed', [1, 2, 3])
-def test_simota_and_loss(ops, seed, with_ignore):
+@pytest.mark.parametrize('seed,geom', [(1, 'gen1'), (2, 'gen1'), (3, 'gen1'), (4, 'gen4'), (5, '1mpx')])
+def test_simota_and_loss(ops, seed, with_ignore, geom):
+    """Gen1 (1680 anchors), Gen4-ds2 (5040) and 1 Mpx (20160 anchors, BASELINE configs[3]) heads."""
     B = 5
-    hws, strides, (gx, gy, gs), outputs, tg = _gen1_case(B, seed, with_ignore=with_ignore)
+    hws, strides, (gx, gy, gs), outputs, tg = _gen1_case(B, seed, with_ignore=with_ignore, geom=geom)
     outr = outputs.clone().requires_grad_(True)
-    ref = oh.get_losses(gx, gy, gs, tg.clone(), outr, num_classes=2, return_assign=True)
+    ref = oh.get_losses(gx, gy, gs, tg.clone(), outr, num_classes=HEAD_GEOMS[geom][2], return_assign=True)
     ref['loss'].backward()
     od, td = outputs.to(DEV), tg.to(DEV)
     asg = ops.simota_assign(od, td, hws, strides)
@@ -444,6 +449,29 @@ def test_postprocess_full_size(ops, seed, limit):
         _check_dets(det, cnt, ref)
 
 
+def test_postprocess_1mpx_head(ops):
+    """20160 anchors (768x1280): the workgroup keeps up to 4096 candidates in LDS -- exact against the oracle below that,
+    a loud error (negative count -> LeodHipError, also through the pseudo-label filter) above it."""
+    from leod_amd._lib import LeodHipError
+    from leod_amd.ops import host_counts
+    g = torch.Generator().manual_seed(3)
+    A, B, nc = 20160, 3, 3
+    pred = torch.cat([torch.rand(B, A, 2, generator=g) * torch.tensor([1270., 710.]), 8 + 60 * torch.rand(B, A, 2, generator=g),
+                      torch.rand(B, A, 1, generator=g), torch.rand(B, A, nc, generator=g)], -1)
+    conf = 0.75                                            # ~ 8 % of the anchors: 1500-1800 candidates per image
+    ref = op.postprocess(pred.clone(), nc, conf, 0.45, pad=torch.zeros((0, 7)), device_semantics='gpu')
+    det, cnt = ops.postprocess_nms(pred.to(DEV), nc, conf, 0.45, max_det=4096)
+    assert 0 < int(cnt.min())
+    _check_dets(det, cnt, ref)
+    det, cnt = ops.postprocess_nms(pred.to(DEV), nc, 0.1, 0.45, max_det=4096)       # > 4096 candidates
+    assert [int(c) for c in cnt.cpu()] == [-1] * B
+    with pytest.raises(LeodHipError):
+        host_counts(cnt)
+    lab, lcnt = ops.pseudo_filter(det, cnt, 0.5, 0.5, True, (720, 1280))
+    with pytest.raises(LeodHipError):
+        host_counts(lcnt, 'pred2label')
+
+
 def test_tta_merge_and_pseudo_filter(ops, golden_dir):
     g = np.load(os.path.join(golden_dir, 'g08_pseudo.npz'))
     views = [torch.from_numpy(g['tta_in0']), torch.from_numpy(g['tta_in1'])]
@@ -551,3 +579,21 @@ def test_augment_u8_full_size_vs_torch(hflip, mode, x0, y0, factor):
         ref[:, y0:y0 + wh, x0:x0 + ww] = win
     assert torch.equal(out[:, 0].reshape(T * 20, H, W), ref)
     assert torch.equal(out[:, 1], ev[:, 1])
+
+
+def test_augment_u8_time_flip():
+    """tflip rides in the same pass: out[t,b,c] = aug(in[T-1-t,b,C-1-c]) (time_flip_data, sequence_base.py:207-227:
+    `[x.flip(0) for x in ev_repr[::-1]]`), combined with the per-sample spatial state."""
+    from leod_amd.data.utils.augmentor import AugmentationState, ZoomInState, augment_events
+    T, B, H, W = 5, 3, 48, 64
+    g = torch.Generator().manual_seed(5)
+    ev = torch.randint(0, 255, (T, B, 20, H, W), generator=g).to(torch.uint8).to(DEV)
+    sts = [AugmentationState(apply_t_flip=True), AugmentationState(apply_h_flip=True),
+           AugmentationState(apply_h_flip=True, apply_t_flip=True, zoom_in=ZoomInState(True, 5, 3, 1.25))]
+    out = augment_events(ev, sts)
+    plain = [AugmentationState(), sts[1], AugmentationState(apply_h_flip=True, zoom_in=ZoomInState(True, 5, 3, 1.25))]
+    spatial = augment_events(ev, plain)
+    for b in (0, 2):
+        assert torch.equal(out[:, b], torch.flip(spatial[:, b], dims=[0, 1]))
+    assert torch.equal(out[:, 1], spatial[:, 1])
+    assert torch.equal(spatial[:, 0], ev[:, 0])

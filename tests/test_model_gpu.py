@@ -200,3 +200,59 @@ def test_small_real_geometry_fwd_bwd(gpu, manifest):
     params = dict(det.named_parameters())
     for k in bkeys:
         close(params[k].grad, osd[k].grad, rtol=3e-3, atol=1e-6, what='grad ' + k)
+
+
+def _build_gen4(size, full_res, seed, train=True):
+    """Gen4 / 1 Mpx detector: ds2 (360x640 -> 384x640, partition 6x10) or full resolution (720x1280 -> 768x1280,
+    partition 12x20 = 240-token partitions, BASELINE configs[3]); weights synthesised from the module's own key -> shape map
+    (the relative-position tables depend on the partition size)."""
+    from leod_amd.config import full_config, dynamically_modify_train_config
+    from leod_amd.models.detection.yolox_extension.models.detector import YoloXDetector
+    over = dict(dataset=dict(downsample_by_factor_2=not full_res))
+    cfg = dynamically_modify_train_config(full_config('gen4', size, overrides=over))
+    det = YoloXDetector(cfg.model)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in det.state_dict().items()}, seed)
+    det.load_state_dict(sd, strict=True)
+    det.to(DEV)
+    det.train(train)
+    return det, sd, cfg
+
+
+@pytest.mark.parametrize('size,full_res,T', [('base', False, 2), ('base', True, 2), ('small', True, 1)])
+def test_gen4_geometries_fwd_bwd(gpu, size, full_res, T):
+    """BASELINE configs[3] geometry as a parity case: RVT-base / RVT-small on Gen4 frames, downsampled (384x640, 60-token
+    partitions) and at the full 1 Mpx resolution (768x1280, 240-token partitions, stage-1 map 192x320), bs 1, carried LSTM
+    states: features of every stage and every backbone parameter gradient vs the oracle."""
+    det, sd, cfg = _build_gen4(size, full_res, 21)
+    in_hw = tuple(cfg.model.backbone.in_res_hw)
+    part = tuple(cfg.model.backbone.stage.attention.partition_size)
+    hw = (720, 1280) if full_res else (360, 640)
+    assert in_hw == ((768, 1280) if full_res else (384, 640)) and part == ((12, 20) if full_res else (6, 10))
+    E, dh = {'base': (64, 32), 'small': (48, 24)}[size]
+    ocfg = ot.model_cfg(E, dh, 0.67 if size == 'base' else 0.33, part, num_classes=3, in_res_hw=in_hw)
+    ev = synth_events(T, 1, 20, hw[0], hw[1], seed=31, as_uint8=True)
+    states = None
+    for t in range(T):
+        feats, states = det.forward_backbone(ev[t].to(DEV), states)
+    loss = sum((v ** 2).mean() for v in feats.values())
+    loss.backward()
+    osd = {k: v.clone() for k, v in sd.items()}
+    bkeys = [k for k in osd if k.startswith('backbone.') and osd[k].is_floating_point()]
+    for k in bkeys:
+        osd[k].requires_grad_(True)
+    evp = ob.pad_ev_repr(ev.float(), in_hw)
+    ostates = None
+    for t in range(T):
+        ofeats, ostates = ob.backbone_forward(evp[t], ostates, osd, ocfg)
+    oloss = sum((v ** 2).mean() for v in ofeats.values())
+    oloss.backward()
+    for s in ofeats:
+        assert feats[s].shape == ofeats[s].shape
+        close(feats[s], ofeats[s], rtol=2e-4, atol=2e-5, what=f'stage {s}')
+    for (h, c), (oh_, oc) in zip(states, ostates):
+        close(h, oh_, rtol=2e-4, atol=2e-5, what='h')
+        close(c, oc, rtol=2e-4, atol=2e-5, what='c')
+    close(loss, oloss, rtol=1e-4)
+    params = dict(det.named_parameters())
+    for k in bkeys:
+        close(params[k].grad, osd[k].grad, rtol=3e-3, atol=1e-6, what='grad ' + k)
