@@ -172,7 +172,7 @@ def main():
         return m.to(dev)
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -205,7 +205,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     dt = float(t_max)
     # roofline of the dominant kernel: a few extra eager steps with HIP events around each of its launches
@@ -250,7 +250,7 @@ def main():
         if not args.no_cpu_baseline and world == 1 and headline:
             out['cpu_baseline'] = cpu_baseline_bounded()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

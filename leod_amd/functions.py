@@ -15,7 +15,7 @@ from torch.autograd import Function
 
 from . import ops
 
-_SYNC_BN = {'group': None, 'world_size': 1}
+_SYNC_BN = {'group': None, 'world_size': 1, 'force': False}
 
 
 class WgradSide:
@@ -78,8 +78,12 @@ def set_sync_batchnorm(process_group, world_size: int):
     _SYNC_BN['world_size'] = int(world_size)
 
 
+def _sync_bn_on() -> bool:
+    return _SYNC_BN['world_size'] > 1 or _SYNC_BN['force']
+
+
 def _allreduce_stats(t: torch.Tensor):
-    if _SYNC_BN['world_size'] > 1:
+    if _sync_bn_on():
         import torch.distributed as dist
         dist.all_reduce(t, group=_SYNC_BN['group'])
 
@@ -316,7 +320,7 @@ class BaseConvFn(Function):
         z = ops.conv_nhwc_fwd(x, conv_w, None, stride=stride, colstats=colstats)
         count = z.numel() // N
         count_dev = None
-        if _SYNC_BN['world_size'] > 1:      # SyncBatchNorm: one small all-reduce of (sum, sumsq, rows) per layer
+        if _sync_bn_on():                   # SyncBatchNorm: one small all-reduce of (sum, sumsq, rows) per layer
             packed = torch.cat([colstats.view(-1), torch.full((1,), float(count), dtype=torch.float64, device=x.device)])
             _allreduce_stats(packed)
             colstats = packed

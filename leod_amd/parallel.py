@@ -81,16 +81,20 @@ class DataParallel:
         self.flat = flat
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
-        if sync_bn and self.world_size > 1:
+        # LEOD_FORCE_COLLECTIVES=1: issue every collective of the N > 1 path even with one rank (exercises RCCL --
+        # communicator, all-reduce of the flat gradient, SyncBN exchanges, stream ordering -- on a single-GPU box)
+        self.force = os.environ.get('LEOD_FORCE_COLLECTIVES') == '1' and dist.is_available() and dist.is_initialized()
+        if sync_bn and (self.world_size > 1 or self.force):
             Fn.set_sync_batchnorm(process_group, self.world_size)
+            Fn._SYNC_BN['force'] = self.force
 
     def broadcast_parameters(self, src=0):
-        if self.world_size > 1:
+        if self.world_size > 1 or self.force:
             dist.broadcast(self.flat.data, src=src, group=self.group)
 
     def all_reduce_gradients(self) -> float:
         """Sum-reduce the flat gradient; returns the scale (1/world) the optimiser kernel applies."""
-        if self.world_size > 1:
+        if self.world_size > 1 or self.force:
             dist.all_reduce(self.flat.grad, group=self.group)
         return 1.0 / self.world_size
 
@@ -103,7 +107,7 @@ def init_distributed(backend: Optional[str] = None):
     # functional testing of the N > 1 path on a single GPU: LEOD_DIST_BACKEND=gloo LEOD_FORCE_LOCAL_DEVICE=0
     if 'LEOD_FORCE_LOCAL_DEVICE' in os.environ:
         local = int(os.environ['LEOD_FORCE_LOCAL_DEVICE'])
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get('LEOD_FORCE_COLLECTIVES') == '1') and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get('LEOD_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
