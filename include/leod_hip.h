@@ -188,6 +188,16 @@ int leod_track_filter(const float* boxes, const unsigned char* is_gt, const int*
                       int img_h, int img_w, int min_track_len, double min_conf, double iou_threshold, double q,
                       unsigned char* remove, int inpaint, int* inp_frame, float* inp_box, int inp_cap, int* n_inp);
 
+/* Detection evaluation of the validation / test loop: the COCO bbox protocol the reference delegates to pycocotools'
+ * COCOeval / detectron2's COCOeval_opt (utils/evaluation/prophesee/metrics/coco_eval.py:121-139) over the image windows
+ * built by the +-50 ms time matching (coco_eval.py:49-97).  gt_box [G,4] / dt_box [D,4] = (x,y,w,h) float32 rows of all
+ * images concatenated, gt_off / dt_off [n_img+1] first row of every image, *_cls class ids in [0,n_cat), dt_score the
+ * class confidences.  iou_thrs [T], rec_thrs [R] as np.linspace gives them.  Out: precision [T,R,n_cat,4,3] and recall
+ * [T,n_cat,4,3] (area ranges all/small/medium/large, maxDets 1/10/100), -1 where COCOeval leaves them undefined. */
+int leod_coco_eval(const float* gt_box, const int* gt_cls, const int* gt_off, const float* dt_box, const int* dt_cls,
+                   const float* dt_score, const int* dt_off, int n_img, int n_cat, const double* iou_thrs, int T,
+                   const double* rec_thrs, int R, double* precision, double* recall);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,15 @@ class ObjectLabels:
     def get(self, request: str):
         return self.object_labels[:, _IDX[request]]
 
+    def numpy_(self) -> None:
+        """In-place conversion to numpy (labels.py:82-87); used by the evaluation records."""
+        if th.is_tensor(self.object_labels):
+            self.object_labels = self.object_labels.detach().cpu().numpy()
+
+    def torch_(self) -> None:
+        if not th.is_tensor(self.object_labels):
+            self.object_labels = th.from_numpy(self.object_labels)
+
     @property
     def input_size_hw(self):
         return self._input_size_hw

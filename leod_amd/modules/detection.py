@@ -22,6 +22,8 @@ from leod_amd.data.genx_utils.labels import ObjectLabels
 from leod_amd.data.utils.types import DataType, DatasetSamplingMode, ObjDetOutput
 from leod_amd.models.detection.yolox.utils.boxes import postprocess
 from leod_amd.models.detection.yolox_extension.models.detector import YoloXDetector
+from leod_amd.utils.evaluation.prophesee.evaluator import PropheseeEvaluator
+from leod_amd.utils.evaluation.prophesee.io.box_loading import to_prophesee
 from leod_amd.utils.padding import InputPadderFromShape
 from .utils.detection import (BackboneFeatureSelector, EventReprSelector, Mode, RNNStates, mode_2_string,
                               merge_mixed_batches, WORKER_ID_KEY, DATA_KEY)
@@ -44,20 +46,30 @@ class Module(_Base):
         self.mode_2_hw: Dict[Mode, Optional[Tuple[int, int]]] = {m: None for m in Mode}
         self.mode_2_batch_size: Dict[Mode, Optional[int]] = {m: None for m in Mode}
         self.mode_2_sampling_mode: Dict[Mode, Any] = {}
+        self.mode_2_psee_evaluator: Dict[Mode, PropheseeEvaluator] = {}
         self.started_training = True
         self.train_vis_every = int(1e9)
+        self.train_eval_every = None
 
     # ---- Lightning-compatible plumbing -----------------------------------------------------------------
     def setup(self, stage: Optional[str] = None) -> None:
         dst = self.full_config.dataset
+        new_evaluator = lambda: PropheseeEvaluator(dataset=dst.name, downsample_by_2=dst.downsample_by_factor_2)  # noqa: E731
         if stage == 'fit':
             self.train_config = self.full_config.training
+            metrics_cfg = self.full_config.get('logging', {}).get('train', {}).get('metrics', None)
+            if metrics_cfg is not None and metrics_cfg.get('compute', False):      # detection KPIs on the training stream
+                self.train_eval_every = metrics_cfg.get('detection_metrics_every_n_steps', None)
+                self.mode_2_psee_evaluator[Mode.TRAIN] = new_evaluator()
+            self.mode_2_psee_evaluator[Mode.VAL] = new_evaluator()
             self.mode_2_sampling_mode[Mode.TRAIN] = dst.train.sampling
             self.mode_2_sampling_mode[Mode.VAL] = dst.eval.sampling
             self.started_training = False
         elif stage == 'validate':
+            self.mode_2_psee_evaluator[Mode.VAL] = new_evaluator()
             self.mode_2_sampling_mode[Mode.VAL] = dst.eval.sampling
         elif stage in ('test', 'predict'):
+            self.mode_2_psee_evaluator[Mode.TEST] = new_evaluator()
             self.mode_2_sampling_mode[Mode.TEST] = dst.eval.sampling
         else:
             raise NotImplementedError(f'Stage {stage} not implemented.')
@@ -144,8 +156,56 @@ class Module(_Base):
         pred_processed = postprocess(prediction=predictions, num_classes=self.num_classes,
                                      conf_thre=self.mdl_config.postprocess.confidence_threshold,
                                      nms_thre=self.mdl_config.postprocess.nms_threshold)
-        return {ObjDetOutput.LABELS_PROPH: obj_labels, ObjDetOutput.PRED_PROPH: pred_processed,
+        # Prophesee records [t, x, y, w, h, class_id, class_confidence], (x, y) = top-left corner (reference :384-399)
+        labels_proph, preds_proph = to_prophesee(obj_labels, pred_processed)
+        if self.started_training and mode in self.mode_2_psee_evaluator:
+            self.mode_2_psee_evaluator[mode].add_labels(labels_proph)
+            self.mode_2_psee_evaluator[mode].add_predictions(preds_proph)
+        return {ObjDetOutput.LABELS_PROPH: labels_proph[-1], ObjDetOutput.PRED_PROPH: preds_proph[-1],
                 ObjDetOutput.EV_REPR: ev_selector.get_ev_repr_as_list(start_idx=-1)[0], ObjDetOutput.SKIP_VIZ: False}
+
+    def run_psee_evaluator(self, mode: Mode, log: bool = True, reset_buffer: bool = True, ret_pr_curve: bool = False):
+        """Prophesee / COCO KPIs over everything buffered for ``mode`` (reference :409-463); ``{'val/AP': tensor, ...}``.
+        With Lightning the dictionary is also logged; without it (or with ``log=False``) it is returned."""
+        from warnings import warn
+        evaluator = self.mode_2_psee_evaluator.get(mode)
+        if evaluator is None:
+            warn(f'{mode=} psee_evaluator is None', UserWarning, stacklevel=2)
+            return None
+        if mode == Mode.VAL:
+            assert reset_buffer, 'Not reseting evaluator in validation'
+        hw, batch_size = self.mode_2_hw[mode], self.mode_2_batch_size[mode]
+        assert hw is not None and batch_size is not None
+        if not evaluator.has_data():
+            warn(f'{mode=} psee_evaluator no data', UserWarning, stacklevel=2)
+            return None
+        metrics = evaluator.evaluate_buffer(img_height=hw[0], img_width=hw[1], ret_pr_curve=ret_pr_curve)
+        assert metrics is not None
+        if reset_buffer:
+            evaluator.reset_buffer()
+        pr_curves = {k: metrics.pop(k) for k in [k for k in metrics if 'PR' in k]} if ret_pr_curve else None
+        device = next(self.parameters()).device
+        log_dict = {f'{mode_2_string[mode]}/{k}': torch.as_tensor(v).to(device) for k, v in metrics.items()}
+        if log and hasattr(self, 'log_dict') and _Base is not th.nn.Module:  # pragma: no cover
+            self.log_dict(log_dict, on_step=False, on_epoch=True, batch_size=batch_size, sync_dist=True)
+            return pr_curves
+        if ret_pr_curve:
+            return pr_curves
+        log_dict['batch_size'] = batch_size
+        return log_dict
+
+    def on_train_epoch_end(self):
+        if Mode.TRAIN in self.mode_2_psee_evaluator and self.train_eval_every is None and self.mode_2_hw[Mode.TRAIN] is not None:
+            return self.run_psee_evaluator(mode=Mode.TRAIN)
+
+    def on_validation_epoch_end(self):
+        if self.started_training:
+            assert self.mode_2_psee_evaluator[Mode.VAL].has_data()
+            return self.run_psee_evaluator(mode=Mode.VAL)
+
+    def on_test_epoch_end(self):
+        assert self.mode_2_psee_evaluator[Mode.TEST].has_data()
+        return self.run_psee_evaluator(mode=Mode.TEST, reset_buffer=False)
 
     def validation_step(self, batch: Any, batch_idx: int = 0):
         return self._val_test_step_impl(batch=batch, mode=Mode.VAL)

@@ -247,7 +247,9 @@ class PseudoLabeler(Module):
         skip[th.stack(data[DataType.IS_PADDED_MASK]).cpu().numpy()] = True
         return ~skip, gt_mask, skipped_gt
 
-    @torch.inference_mode()
+    # no_grad rather than the reference's inference_mode (:622): the labels are edited in place afterwards (un-flip,
+    # tracking filter), which inference tensors only allow inside Lightning's own inference-mode predict loop
+    @torch.no_grad()
     def _predict_step_impl(self, batch: Any, mode: Mode = Mode.TEST):
         data = self.get_data_from_batch(batch)
         worker_id = self.get_worker_id_from_batch(batch)

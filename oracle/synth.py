@@ -110,3 +110,54 @@ AUGMENT_CASES = [(s, 60, 76) for s in range(8)] + [(100, 48, 64), (101, 48, 64)]
 AUGMENT_CFG = dict(prob_hflip=0.5, prob_tflip=0, rotate=dict(prob=0, min_angle_deg=2, max_angle_deg=6),
                    zoom=dict(prob=0.8, zoom_in=dict(weight=8, factor=dict(min=1, max=1.5)),
                              zoom_out=dict(weight=2, factor=dict(min=1, max=1.2))))
+
+
+EVAL_BBOX_DTYPE = np.dtype({'names': ['t', 'x', 'y', 'w', 'h', 'class_id', 'track_id', 'class_confidence'],
+                            'formats': ['<i8', '<f4', '<f4', '<f4', '<f4', '<u4', '<u4', '<f4'],
+                            'offsets': [0, 8, 12, 16, 20, 24, 28, 32], 'itemsize': 40})
+
+
+def synth_eval_sequences(seed: int, hw=(240, 304), n_cls: int = 2, n_seq: int = 3, n_frames: int = 12, dt_per_gt=(0, 4),
+                         jitter_us: int = 0, quantize_scores: bool = False):
+    """Label / detection records for the evaluator fixtures: ``n_seq`` recordings, labelled frames every 100 ms from 0.3 s
+    (so the first ones fall under the 0.5 s filter), boxes from tiny to large, detections = jittered copies of the labels
+    (hits of varying IoU), duplicates and clutter; ``jitter_us`` moves detection timestamps around the label time (some beyond
+    the +-50 ms tolerance); ``quantize_scores`` produces score ties.  Returns (labels, detections): lists of structured arrays
+    sorted by time."""
+    rng = np.random.RandomState(7000 + seed)
+    H, W = hw
+    labels, dets = [], []
+    for _ in range(n_seq):
+        g_rows, d_rows = [], []
+        for f in range(n_frames):
+            t = 300000 + 100000 * f
+            for _ in range(rng.randint(0, 5)):
+                w, h = rng.uniform(4, 0.6 * W), rng.uniform(4, 0.6 * H)
+                if rng.rand() < 0.3:
+                    w, h = rng.uniform(4, 40), rng.uniform(4, 30)
+                x, y = rng.uniform(0, W - w), rng.uniform(0, H - h)
+                c = rng.randint(0, n_cls)
+                g_rows.append((t, x, y, w, h, c, 0, 1.0))
+                for _ in range(rng.randint(dt_per_gt[0], dt_per_gt[1] + 1)):
+                    s = rng.uniform(0.02, 0.25)
+                    dw, dh = w * (1 + rng.uniform(-s, s)), h * (1 + rng.uniform(-s, s))
+                    dx, dy = x + rng.uniform(-s, s) * w, y + rng.uniform(-s, s) * h
+                    dc = c if rng.rand() < 0.9 else rng.randint(0, n_cls)
+                    td = t + (int(rng.randint(-jitter_us, jitter_us + 1)) if jitter_us else 0)
+                    d_rows.append((td, dx, dy, dw, dh, dc, 0, rng.uniform(0.05, 1.0)))
+            for _ in range(rng.randint(0, 3)):                       # clutter, also on frames without labels
+                w, h = rng.uniform(8, 80), rng.uniform(8, 60)
+                td = t + (int(rng.randint(-jitter_us, jitter_us + 1)) if jitter_us else 0)
+                d_rows.append((td, rng.uniform(0, W - w), rng.uniform(0, H - h), w, h, rng.randint(0, n_cls), 0,
+                               rng.uniform(0.05, 0.6)))
+        g = np.array(g_rows, dtype=EVAL_BBOX_DTYPE) if g_rows else np.zeros((0,), dtype=EVAL_BBOX_DTYPE)
+        d = np.array(d_rows, dtype=EVAL_BBOX_DTYPE) if d_rows else np.zeros((0,), dtype=EVAL_BBOX_DTYPE)
+        if quantize_scores and len(d):
+            d['class_confidence'] = np.round(d['class_confidence'] * 8) / 8 + 0.0625
+        labels.append(g[np.argsort(g['t'], kind='stable')])
+        dets.append(d[np.argsort(d['t'], kind='stable')])
+    return labels, dets
+
+
+EVAL_CASES = [dict(seed=0), dict(seed=1, jitter_us=70000), dict(seed=2, hw=(360, 640), n_cls=3, jitter_us=30000),
+              dict(seed=3, quantize_scores=True, dt_per_gt=(1, 6)), dict(seed=4, n_seq=1, n_frames=4, dt_per_gt=(0, 0))]

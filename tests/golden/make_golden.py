@@ -552,6 +552,67 @@ def g12_trainstep():
     save('g12_trainstep_micro.npz', **out)
 
 
+def g15_evaluator():
+    """Prophesee evaluation up to the COCO records: the reference's box filters, +-50 ms time matching and
+    `_to_coco_format` on synthetic label / detection records (pycocotools itself is absent: the AP numbers are not in
+    this fixture, see oracle/coco_eval.py)."""
+    from oracle.synth import synth_eval_sequences, EVAL_CASES
+    from utils.evaluation.prophesee.io.box_filtering import filter_boxes
+    from utils.evaluation.prophesee.metrics import coco_eval as ref_ce
+    from utils.evaluation.prophesee.io.box_loading import to_prophesee, BBOX_DTYPE as REF_EVAL_DTYPE
+    out = {}
+    for ci, case in enumerate(EVAL_CASES):
+        labels, dets = synth_eval_sequences(**case)
+        gen4 = case.get('n_cls', 2) == 3
+        diag, side = (30, 10) if gen4 else (30, 10)          # gen4 case is the downsampled one: 60/2, 20/2
+        gts, dts = [], []
+        for k, (g, d) in enumerate(zip(labels, dets)):
+            gf, df = filter_boxes(g, int(5e5), diag, side), filter_boxes(d, int(5e5), diag, side)
+            # which rows survived (the records are distinct, so membership identifies them)
+            out[f'c{ci}_s{k}_gt_kept'] = np.array([r.item() in {x.item() for x in gf} for r in g], dtype=bool)
+            out[f'c{ci}_s{k}_dt_kept'] = np.array([r.item() in {x.item() for x in df} for r in d], dtype=bool)
+            out[f'c{ci}_s{k}_n_gt'], out[f'c{ci}_s{k}_n_dt'] = np.int64(len(gf)), np.int64(len(df))
+            gw, dw = ref_ce._match_times(np.unique(gf['t']), gf, df, 50000)
+            gts += gw
+            dts += dw
+        out[f'c{ci}_gt_cnt'] = np.array([len(x) for x in gts], dtype=np.int64)
+        out[f'c{ci}_dt_cnt'] = np.array([len(x) for x in dts], dtype=np.int64)
+        cats = [dict(id=i + 1, name=str(i), supercategory='none') for i in range(case.get('n_cls', 2))]
+        dataset, results = ref_ce._to_coco_format(gts, dts, cats, height=case.get('hw', (240, 304))[0],
+                                                 width=case.get('hw', (240, 304))[1])
+        ann = dataset['annotations']
+        out[f'c{ci}_ann_area'] = np.array([a['area'] for a in ann], dtype=np.float64)
+        out[f'c{ci}_ann_bbox'] = np.array([[float(v) for v in a['bbox']] for a in ann], dtype=np.float64).reshape(-1, 4)
+        out[f'c{ci}_ann_cat'] = np.array([a['category_id'] for a in ann], dtype=np.int64)
+        out[f'c{ci}_ann_img'] = np.array([a['image_id'] for a in ann], dtype=np.int64)
+        out[f'c{ci}_res_score'] = np.array([r['score'] for r in results], dtype=np.float64)
+        out[f'c{ci}_res_bbox'] = np.array([[float(v) for v in r['bbox']] for r in results], dtype=np.float64).reshape(-1, 4)
+        out[f'c{ci}_res_cat'] = np.array([r['category_id'] for r in results], dtype=np.int64)
+        out[f'c{ci}_res_img'] = np.array([r['image_id'] for r in results], dtype=np.int64)
+        out[f'c{ci}_n_img'] = np.int64(len(dataset['images']))
+    # to_prophesee: labels + post-processed detections of single frames -> records
+    g = torch.Generator().manual_seed(15)
+    labs, preds = [], []
+    for f in range(4):
+        n = 1 + f
+        l = torch.rand((n, 8), generator=g) * 50
+        l[:, 0] = 1000000 + 50000 * f
+        l[:, 5] = torch.randint(0, 2, (n,), generator=g).float()
+        labs.append(ObjectLabels(l, (240, 304)))
+        m = [3, 0, 2, 1][f]
+        p = torch.rand((m, 7), generator=g) * 100
+        p[:, 2:4] += p[:, 0:2]
+        p[:, 6] = torch.randint(0, 2, (m,), generator=g).float()
+        preds.append(p if m else None)
+    assert REF_EVAL_DTYPE.itemsize == 40
+    lp, pp = to_prophesee(labs, preds)
+    for f in range(4):
+        for name in REF_EVAL_DTYPE.names:                       # field by field (the 4 padding bytes of a record are not data)
+            out[f'proph_lab{f}_{name}'] = lp[f][name]
+            out[f'proph_pred{f}_{name}'] = pp[f][name]
+    save('g15_evaluator.npz', **out)
+
+
 def g14_augment():
     """RandomSpatialAugmentorGenX.__call__ of the reference (data/utils/augmentor.py:455-476) on seeded loader samples with
     the shipped augmentation config (hflip 0.5, zoom 0.8: in 8 / out 2): resulting augmentation state, augmented uint8
@@ -582,7 +643,7 @@ def g14_augment():
 
 ALL = dict(g01=g01_convlstm, g02=g02_partition, g03=g03_attention, g04=g04_backbone, g05=g05_head,
            g06=g06_simota, g07=g07_postprocess, g08=g08_pseudo, g10=g10_voxel, g11=g11_manifest,
-           g12=g12_trainstep, g13=g13_tracker, g14=g14_augment)
+           g12=g12_trainstep, g13=g13_tracker, g14=g14_augment, g15=g15_evaluator)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)

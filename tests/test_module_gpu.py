@@ -1,0 +1,205 @@
+"""The reference's LightningModule surface on the HIP path (modules/detection.py): ``training_step``, ``validation_step`` with
+the Prophesee evaluator, ``on_validation_epoch_end`` -- driven with loader-shaped batches and checked against the oracle.
+``pytest -m gpu``."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import coco_eval as oc  # noqa: E402
+from oracle import postproc as op  # noqa: E402
+from oracle import train_step as ot  # noqa: E402
+from oracle.synth import synth_state_dict, synth_events, synth_labels  # noqa: E402
+
+DEV = 'cuda'
+MICRO = ot.model_cfg(embed_dim=16, dim_head=8, fpn_depth=0.33, partition_size=(2, 3), in_res_hw=(64, 96))
+HW = (60, 90)
+
+
+@pytest.fixture(scope='module')
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    return True
+
+
+def micro_module(manifest, seed, stage):
+    from leod_amd.config import full_config, dynamically_modify_train_config
+    from leod_amd.modules.detection import Module
+    over = dict(model=dict(backbone=dict(embed_dim=16, stage=dict(attention=dict(dim_head=8)))),
+                dataset=dict(sequence_length=4))
+    cfg = dynamically_modify_train_config(full_config('gen1', 'small', overrides=over))
+    cfg.model.backbone.in_res_hw = (64, 96)
+    cfg.model.backbone.stage.attention.partition_size = (2, 3)
+    mod = Module(cfg)
+    sd = synth_state_dict(manifest['micro'], seed)
+    mod.mdl.load_state_dict(sd)
+    mod.to(DEV)
+    mod.setup(stage)
+    return mod, sd, cfg
+
+
+def micro_labels(n_frames, seed, t_us):
+    labs = synth_labels(n_frames, HW, 2, seed=seed, max_boxes=4)
+    for l, t in zip(labs, t_us):
+        l[:, 3] = l[:, 3].clamp(min=12, max=30)
+        l[:, 4] = l[:, 4].clamp(min=12, max=24)
+        l[:, 1] = torch.minimum(l[:, 1], HW[1] - 1 - l[:, 3])
+        l[:, 2] = torch.minimum(l[:, 2], HW[0] - 1 - l[:, 4])
+        l[:, 0] = t
+    return labs
+
+
+def loader_batch(ev, labels_tb, is_first):
+    """ev [L,B,20,H,W] uint8, labels_tb[t][b] = None | [n,8] tensor -> the dictionary the reference's loaders emit."""
+    from leod_amd.data.genx_utils.labels import ObjectLabels, SparselyBatchedObjectLabels
+    from leod_amd.data.utils.types import DataType
+    from leod_amd.modules.utils.detection import WORKER_ID_KEY, DATA_KEY
+    L, B = ev.shape[:2]
+    seq = [SparselyBatchedObjectLabels([None if labels_tb[t][b] is None else ObjectLabels(labels_tb[t][b].clone(), HW)
+                                        for b in range(B)]) for t in range(L)]
+    data = {DataType.EV_REPR: [ev[t].to(DEV) for t in range(L)], DataType.OBJLABELS_SEQ: seq,
+            DataType.IS_FIRST_SAMPLE: is_first.to(DEV), DataType.IS_PADDED_MASK: [[False] * B for _ in range(L)]}
+    return {DATA_KEY: data, WORKER_ID_KEY: 0}
+
+
+def test_training_step_losses_vs_oracle(gpu, manifest):
+    mod, sd, _ = micro_module(manifest, 5, 'fit')
+    mod.train()
+    L, B = 4, 2
+    ev = synth_events(L, B, 20, HW[0], HW[1], seed=41, as_uint8=True)
+    flat = micro_labels(4, 42, [1e6, 1e6, 2e6, 2e6])
+    labels_tb = [[None, None], [flat[0], flat[1]], [None, None], [flat[2], flat[3]]]
+    out = mod.training_step(loader_batch(ev, labels_tb, torch.ones(B, dtype=torch.bool)), 0, log=False)
+    ref, _, _, sel = ot.forward_sequence({k: v.clone() for k, v in sd.items()}, MICRO, ev, labels_tb, None, training=True)
+    assert sel == [(1, 0), (1, 1), (3, 0), (3, 1)]
+    for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss'):
+        np.testing.assert_allclose(float(out['log_dict'][f'train/{k}'].detach()), float(ref[k]), rtol=2e-4, atol=1e-6, err_msg=k)
+    out['loss'].backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in mod.mdl.parameters() if p.requires_grad)
+
+
+def test_validation_steps_and_evaluator_vs_oracle(gpu, manifest):
+    """Two consecutive streaming batches (LSTM state carried by worker id, second batch restarts sample 1), detections
+    buffered as Prophesee records, KPIs at epoch end: records vs the oracle's inference, KPIs vs the oracle's evaluator."""
+    from leod_amd.modules.utils.detection import Mode
+    mod, sd, cfg = micro_module(manifest, 6, 'validate')
+    mod.eval()
+    cfg.model.postprocess.confidence_threshold = 0.001
+    L, B = 4, 2
+    states, want_labels, want_dets = None, [], []
+    osd = {k: v.clone() for k, v in sd.items()}
+    for step in range(2):
+        ev = synth_events(L, B, 20, HW[0], HW[1], seed=50 + step, as_uint8=True)
+        base = 600000 + 400000 * step
+        flat = micro_labels(3, 60 + step, [base + 100000, base + 300000, base + 300000])
+        labels_tb = [[None, None], [flat[0], None], [None, None], [flat[1], flat[2]]]
+        is_first = torch.tensor([True, True]) if step == 0 else torch.tensor([False, True])
+        out = mod.validation_step(loader_batch(ev, labels_tb, is_first), step)
+        assert not out[list(out)[-1]]                      # SKIP_VIZ False
+        with torch.no_grad():
+            _, preds, states, sel = ot.forward_sequence(osd, MICRO, ev, labels_tb, states, is_first_sample=is_first, training=False)
+        dets = op.postprocess(preds, 2, 0.001, 0.45, pad=torch.zeros((0, 7)), device_semantics='gpu')
+        want_labels += [labels_tb[t][b] for t, b in sel]
+        want_dets += dets
+    buf = mod.mode_2_psee_evaluator[Mode.VAL]._buffer
+    labels_rec, preds_rec = buf['lables'], buf['predictions']
+    assert len(labels_rec) == len(preds_rec) == len(want_labels) == 6
+    n_det = 0
+    for rec, prd, lab, det in zip(labels_rec, preds_rec, want_labels, want_dets):
+        assert np.array_equal(rec['t'], lab[:, 0].numpy().astype(np.int64)) and np.array_equal(rec['class_id'], lab[:, 5].numpy().astype(np.uint32))
+        np.testing.assert_array_equal(np.stack([rec[k] for k in 'xywh'], 1), lab[:, 1:5].numpy())
+        assert len(prd) == len(det) and (prd['t'] == rec['t'][0]).all()
+        d = det.numpy()
+        np.testing.assert_allclose(np.stack([prd['x'], prd['y'], prd['w'], prd['h']], 1),
+                                   np.stack([d[:, 0], d[:, 1], d[:, 2] - d[:, 0], d[:, 3] - d[:, 1]], 1), rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(prd['class_confidence'], d[:, 5], rtol=2e-4, atol=1e-6)
+        assert np.array_equal(prd['class_id'], d[:, 6].astype(np.uint32))
+        n_det += len(prd)
+    assert n_det > 20
+    want = oc.evaluate_buffer([r.copy() for r in labels_rec], [p.copy() for p in preds_rec], 'gen1', False)
+    got = mod.on_validation_epoch_end()
+    assert got.pop('batch_size') == B
+    assert {k: float(v) for k, v in got.items()} == {f'val/{k}': v for k, v in want.items()}
+    assert not mod.mode_2_psee_evaluator[Mode.VAL].has_data()
+
+
+def test_pseudo_labeler_predict_step_vs_oracle(gpu, manifest):
+    """PseudoLabeler.predict_step over two streaming batches with horizontal-flip TTA and one GT frame: what lands in
+    EventSeqData after aggregation (un-flipped, TTA-merged labels per frame; GT stored once, GT frames not predicted) vs the oracle's inference + pred2label + tta_postprocess (pseudo_labeler.py:107-177,458-495,622-770)."""
+    from leod_amd.config import full_config, dynamically_modify_train_config
+    from leod_amd.data.genx_utils.labels import ObjectLabels, SparselyBatchedObjectLabels
+    from leod_amd.data.utils.types import DataType
+    from leod_amd.modules.pseudo_labeler import PseudoLabeler
+    from leod_amd.modules.utils.detection import WORKER_ID_KEY, DATA_KEY
+    over = dict(model=dict(backbone=dict(embed_dim=16, stage=dict(attention=dict(dim_head=8)))),
+                dataset=dict(sequence_length=4), tta=dict(enable=True, hflip=True, tflip=False))
+    cfg = dynamically_modify_train_config(full_config('gen1', 'small', model='pseudo_labeler', overrides=over))
+    cfg.dataset.ev_repr_hw = HW
+    cfg.model.backbone.in_res_hw = (64, 96)
+    cfg.model.backbone.stage.attention.partition_size = (2, 3)
+    cfg.model.postprocess.confidence_threshold = 0.01
+    obj_thr, cls_thr = [0.1, 0.05], [0.1, 0.05]
+    cfg.model.pseudo_label.obj_thresh, cfg.model.pseudo_label.cls_thresh = obj_thr, cls_thr
+    mod = PseudoLabeler(cfg)
+    sd = synth_state_dict(manifest['micro'], 8)
+    mod.mdl.load_state_dict(sd)
+    mod.to(DEV).eval()
+    mod.setup('predict')
+    L, B, W = 4, 2, HW[1]
+    gt = micro_labels(1, 77, [1234567.0])[0]
+    states, want = None, {0: {}, 1: {}}
+    osd = {k: v.clone() for k, v in sd.items()}
+    for step in range(2):
+        ev = synth_events(L, B, 20, HW[0], HW[1], seed=80 + step, as_uint8=True)
+        labels_tb = [[None, None] for _ in range(L)]
+        if step == 0:
+            labels_tb[2][0] = gt
+        seq = [SparselyBatchedObjectLabels([None if l is None else ObjectLabels(l.clone(), HW) for l in labels_tb[t]]) for t in range(L)]
+        none_seq = [SparselyBatchedObjectLabels([None] * B) for _ in range(L)]
+        first = torch.full((B,), step == 0)
+        data = {DataType.EV_REPR: [ev[t].to(DEV) for t in range(L)], DataType.OBJLABELS_SEQ: seq,
+                DataType.SKIPPED_OBJLABELS_SEQ: none_seq, DataType.IS_FIRST_SAMPLE: first.to(DEV),
+                DataType.IS_LAST_SAMPLE: torch.full((B,), step == 1), DataType.IS_REVERSED: torch.zeros(B, dtype=torch.bool),
+                DataType.EV_IDX: [torch.full((B,), L * step + t, dtype=torch.long) for t in range(L)],
+                DataType.IS_PADDED_MASK: [torch.zeros(B, dtype=torch.bool) for _ in range(L)], DataType.PATH: ['rec/seqA', 'rec/seqB']}
+        mod.predict_step({DATA_KEY: data, WORKER_ID_KEY: 0}, step)
+        with torch.no_grad():
+            dets, states, _ = ot.infer_sequence(osd, MICRO, ev, states, conf_thre=0.01, hflip=True)
+        for t in range(L):
+            for b in range(B):
+                frame = L * step + t
+                # NB the reference's skip-first-frames flags are overwritten by `skip_mask[t, b] = has_gt`
+                # (pseudo_labeler.py:533-540), so the first frame of a new sequence IS predicted -- kept as is
+                if labels_tb[t][b] is not None:
+                    want[b][frame] = ('gt', labels_tb[t][b])
+                    continue
+                views = op.pred2label([dets[t * 2 * B + b].clone(), dets[t * 2 * B + B + b].clone()], obj_thr, cls_thr, 'gen1', False)
+                flipped = views[1].clone()
+                flipped[:, 1] = W - 1 - flipped[:, 1] - flipped[:, 3]
+                rows = torch.cat([views[0], flipped], 0)
+                if len(rows) == 0:
+                    continue
+                xyxy = torch.cat([rows[:, 1:3], rows[:, 1:3] + rows[:, 3:5], rows[:, 7:8], rows[:, 6:7], rows[:, 5:6]], 1)
+                merged = op.tta_postprocess([xyxy], 0.01, 0.45)[0]
+                if merged is not None:
+                    want[b][frame] = ('pse', merged)
+    assert set(mod.ev_path_2_ev_data) == {'rec/seqA', 'rec/seqB'}
+    total = 0
+    for b, path in enumerate(['rec/seqA', 'rec/seqB']):
+        esd = mod.ev_path_2_ev_data[path]
+        assert esd.eoe() and esd.aug
+        esd._aggregate_results(num_frames=2 * L)
+        got = {f: l for f, l in zip(esd.frame_idx, esd.labels) if len(l)}
+        assert set(got) == set(want[b]), (sorted(got), sorted(want[b]))
+        for f, (kind, ref) in want[b].items():
+            o = got[f].object_labels.cpu()
+            if kind == 'gt':
+                assert torch.equal(o, ref)
+                continue
+            assert len(o) == len(ref) and bool((o[:, 0] == 0).all())
+            np.testing.assert_allclose(o[:, 1:5].numpy(), torch.cat([ref[:, 0:2], ref[:, 2:4] - ref[:, 0:2]], 1).numpy(), rtol=3e-4, atol=3e-4)
+            np.testing.assert_allclose(o[:, 5:8].numpy(), ref[:, [6, 5, 4]].numpy(), rtol=3e-4, atol=1e-6)
+            total += len(o)
+    assert total > 10
