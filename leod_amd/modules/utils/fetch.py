@@ -5,7 +5,8 @@ def fetch_model_module(config):
     name = config.model.name
     if name == 'rnndet':
         if config.get('tta', {}).get('enable', False):
-            raise NotImplementedError('TTAModule (eval-time ensemble) is scheduled after the hot path (SURVEY 8f)')
+            from leod_amd.modules.utils.tta import TTAModule
+            return TTAModule(config)
         from leod_amd.modules.detection import Module
         return Module(config)
     if name == 'pseudo_labeler':

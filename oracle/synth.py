@@ -161,3 +161,58 @@ def synth_eval_sequences(seed: int, hw=(240, 304), n_cls: int = 2, n_seq: int = 
 
 EVAL_CASES = [dict(seed=0), dict(seed=1, jitter_us=70000), dict(seed=2, hw=(360, 640), n_cls=3, jitter_us=30000),
               dict(seed=3, quantize_scores=True, dt_per_gt=(1, 6)), dict(seed=4, n_seq=1, n_frames=4, dt_per_gt=(0, 0))]
+
+
+def synth_tta_views(case: int, hw=(240, 304)):
+    """Scripted input of the TTA result fixtures (tests/golden/g16_tta_result.npz): one recording of 8 frames, labels on 5 of
+    them, delivered in two chunks per view.  Returns (views, hw); a view = dict(hflip, tflip, ev_idx, gts, preds, last) with
+    gts[k] = [n,8] label tensor or the float placeholder 1.0 (frame without labels) and preds[k] = [m,7] tensor
+    (x1, y1, x2, y2, obj, cls_conf, cls_id) in the coordinates OF THAT VIEW.  case 0: plain + hflip; 1: all four views; 2: plain
+    only (no merge)."""
+    import torch
+    g = torch.Generator().manual_seed(8100 + case)
+    H, W = hw
+    labelled = {1, 2, 4, 6, 7}
+    gt_of = {}
+    for f in sorted(labelled):
+        n = int(torch.randint(1, 4, (1,), generator=g))
+        w, h = 20 + 60 * torch.rand(n, generator=g), 15 + 50 * torch.rand(n, generator=g)
+        x, y = torch.rand(n, generator=g) * (W - 1 - w), torch.rand(n, generator=g) * (H - 1 - h)
+        gt_of[f] = torch.stack([torch.full((n,), 100000. * (f + 1)), x, y, w, h, torch.randint(0, 2, (n,), generator=g).float(),
+                                torch.ones(n), torch.ones(n)], 1)
+
+    def dets_for(f, hflip):
+        gt = gt_of[f]
+        reps = int(torch.randint(1, 4, (1,), generator=g))
+        rows = gt.repeat(reps, 1)
+        n = len(rows)
+        x1 = rows[:, 1] + 4 * torch.randn(n, generator=g)
+        y1 = rows[:, 2] + 4 * torch.randn(n, generator=g)
+        wv, hv = rows[:, 3] * (1 + 0.1 * torch.randn(n, generator=g)), rows[:, 4] * (1 + 0.1 * torch.randn(n, generator=g))
+        if hflip:
+            x1 = W - 1 - x1 - wv
+        extra = int(torch.randint(0, 3, (1,), generator=g))
+        p = torch.stack([x1, y1, x1 + wv, y1 + hv, 0.2 + 0.8 * torch.rand(n, generator=g), 0.2 + 0.8 * torch.rand(n, generator=g), rows[:, 5]], 1)
+        if extra:
+            c = torch.rand(extra, 2, generator=g) * torch.tensor([W - 60., H - 50.])
+            p = torch.cat([p, torch.cat([c, c + 40, torch.rand(extra, 2, generator=g), torch.randint(0, 2, (extra, 1), generator=g).float()], 1)])
+        return p
+
+    combos = {0: [(False, False), (True, False)], 1: [(False, False), (True, False), (False, True), (True, True)],
+              2: [(False, False)]}[case]
+    views = []
+    for hflip, tflip in combos:
+        # the reversed recording shows plain frame f at reversed index f + 1 (offset -1), in descending plain order
+        order = list(range(8)) if not tflip else list(range(7, -1, -1))
+        for ci, chunk in enumerate((order[:4], order[4:])):
+            gts, preds, idx = [], [], []
+            for f in chunk:
+                idx.append(f if not tflip else f + 1)
+                if f in labelled:
+                    gts.append(gt_of[f])
+                    preds.append(dets_for(f, hflip))
+                else:
+                    gts.append(1.0)
+                    preds.append(1.0)
+            views.append(dict(hflip=hflip, tflip=tflip, ev_idx=idx, gts=gts, preds=preds, last=ci == 1))
+    return views, hw

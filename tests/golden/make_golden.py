@@ -613,6 +613,29 @@ def g15_evaluator():
     save('g15_evaluator.npz', **out)
 
 
+def g16_tta_result():
+    """EventSeqResult (modules/utils/tta.py:64-195) driven with scripted TTA views of one recording: plain, h-flipped,
+    time-reversed (offset -1) and both; 8 frames of which 5 carry labels; the merged detections and label records."""
+    from oracle.synth import synth_tta_views
+    from modules.utils.tta import EventSeqResult
+    out = {}
+    for case in range(3):
+        views, hw = synth_tta_views(case)
+        res = EventSeqResult(path='seq', img_hw=hw, postproc_cfg=DictConfig(dict(confidence_threshold=0.1, nms_threshold=0.45)))
+        for v in views:
+            gts = [ObjectLabels(g.clone(), hw) if torch.is_tensor(g) else g for g in v['gts']]
+            preds = [p.clone() if torch.is_tensor(p) else p for p in v['preds']]
+            res.update(is_hflip=v['hflip'], is_tflip=v['tflip'], preds=preds, gts=gts, ev_idx=list(v['ev_idx']),
+                       is_last_sample=v['last'], tflip_offset=-1)
+        labels, preds = res.aggregate_results()
+        out[f'c{case}_n'] = np.int64(len(labels))
+        for k, (l, p) in enumerate(zip(labels, preds)):
+            for name in l.dtype.names:
+                out[f'c{case}_lab{k}_{name}'] = l[name]
+                out[f'c{case}_pred{k}_{name}'] = p[name]
+    save('g16_tta_result.npz', **out)
+
+
 def g14_augment():
     """RandomSpatialAugmentorGenX.__call__ of the reference (data/utils/augmentor.py:455-476) on seeded loader samples with
     the shipped augmentation config (hflip 0.5, zoom 0.8: in 8 / out 2): resulting augmentation state, augmented uint8
@@ -643,7 +666,7 @@ def g14_augment():
 
 ALL = dict(g01=g01_convlstm, g02=g02_partition, g03=g03_attention, g04=g04_backbone, g05=g05_head,
            g06=g06_simota, g07=g07_postprocess, g08=g08_pseudo, g10=g10_voxel, g11=g11_manifest,
-           g12=g12_trainstep, g13=g13_tracker, g14=g14_augment, g15=g15_evaluator)
+           g12=g12_trainstep, g13=g13_tracker, g14=g14_augment, g15=g15_evaluator, g16=g16_tta_result)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)

@@ -203,3 +203,103 @@ def test_pseudo_labeler_predict_step_vs_oracle(gpu, manifest):
             np.testing.assert_allclose(o[:, 5:8].numpy(), ref[:, [6, 5, 4]].numpy(), rtol=3e-4, atol=1e-6)
             total += len(o)
     assert total > 10
+
+
+def test_event_seq_result_golden(gpu, golden_dir):
+    """EventSeqResult on device tensors (TTA merge = one batched HIP NMS launch) vs the records the reference produced."""
+    import os
+    from oracle.synth import synth_tta_views
+    from leod_amd.config.dictconfig import DictConfig
+    from leod_amd.data.genx_utils.labels import ObjectLabels
+    from leod_amd.modules.utils.tta import EventSeqResult
+    g = np.load(os.path.join(golden_dir, 'g16_tta_result.npz'))
+    for case in range(3):
+        views, hw = synth_tta_views(case)
+        res = EventSeqResult('seq', hw, DictConfig(dict(confidence_threshold=0.1, nms_threshold=0.45)))
+        for v in views:
+            gts = [ObjectLabels(x.clone().to(DEV), hw) if torch.is_tensor(x) else x for x in v['gts']]
+            preds = [x.clone().to(DEV) if torch.is_tensor(x) else x for x in v['preds']]
+            res.update(is_hflip=v['hflip'], is_tflip=v['tflip'], preds=preds, gts=gts, ev_idx=list(v['ev_idx']),
+                       is_last_sample=v['last'], tflip_offset=-1)
+        assert res.eoe and res.aug == (case != 2)
+        labels, preds = res.aggregate_results()
+        assert len(labels) == int(g[f'c{case}_n'])
+        for k, (l, p) in enumerate(zip(labels, preds)):
+            for name in l.dtype.names:
+                assert np.array_equal(l[name], g[f'c{case}_lab{k}_{name}']), (case, k, name)
+                assert np.array_equal(p[name], g[f'c{case}_pred{k}_{name}']), (case, k, name)
+
+
+def test_tta_module_test_step_vs_oracle(gpu, manifest):
+    """fetch_model_module(tta.enable) -> TTAModule: a recording streamed plain and time-reversed (the loader's job), each with
+    the horizontally flipped copy made by the module; merged detections per labelled frame and the final KPIs vs the oracle
+    (inference on every view, un-flip / re-index, tta_postprocess, evaluator)."""
+    from oracle import tta as otta
+    from leod_amd.config import full_config, dynamically_modify_train_config
+    from leod_amd.data.genx_utils.labels import ObjectLabels, SparselyBatchedObjectLabels
+    from leod_amd.data.utils.types import DataType
+    from leod_amd.modules.utils.detection import WORKER_ID_KEY, DATA_KEY, Mode
+    from leod_amd.modules.utils.fetch import fetch_model_module
+    from leod_amd.modules.utils.tta import TTAModule
+    over = dict(model=dict(backbone=dict(embed_dim=16, stage=dict(attention=dict(dim_head=8)))),
+                dataset=dict(sequence_length=4), tta=dict(enable=True, hflip=True, tflip=True))
+    cfg = dynamically_modify_train_config(full_config('gen1', 'small', overrides=over))
+    cfg.dataset.ev_repr_hw = HW
+    cfg.model.backbone.in_res_hw = (64, 96)
+    cfg.model.backbone.stage.attention.partition_size = (2, 3)
+    cfg.model.postprocess.confidence_threshold = 0.005
+    mod = fetch_model_module(cfg)
+    assert isinstance(mod, TTAModule)
+    sd = synth_state_dict(manifest['micro'], 12)
+    mod.mdl.load_state_dict(sd)
+    mod.to(DEV).eval()
+    mod.setup('test')
+    L, B, W, F = 4, 1, HW[1], 8
+    ev_all = synth_events(F, B, 20, HW[0], HW[1], seed=90, as_uint8=True)            # the recording: 8 frames
+    labelled = {2: 700000.0, 3: 800000.0, 5: 1000000.0, 7: 1200000.0}
+    gt_of = {f: l for f, l in zip(labelled, micro_labels(4, 91, list(labelled.values())))}
+    osd = {k: v.clone() for k, v in sd.items()}
+    views = []
+    for tflip in (False, True):
+        # the time-reversed recording: frames in reverse order, channels reversed (time_flip_data), and the labels of plain frame
+        # f sit on reversed index f + 1 (tflip_offset -1), i.e. position F - 1 - f + ... -> delivered below as ev_idx
+        order = list(range(F)) if not tflip else list(range(F - 1, -1, -1))
+        ev_view = ev_all[order] if not tflip else torch.flip(ev_all[order], dims=[2])
+        states = None
+        for step in range(F // L):
+            chunk = order[step * L:(step + 1) * L]
+            ev = ev_view[step * L:(step + 1) * L]
+            labels_tb = [[gt_of.get(f)] for f in chunk]
+            idx = [f if not tflip else f + 1 for f in chunk]
+            seq = [SparselyBatchedObjectLabels([None if l[0] is None else ObjectLabels(l[0].clone(), HW)]) for l in labels_tb]
+            data = {DataType.EV_REPR: [ev[t].to(DEV) for t in range(L)], DataType.OBJLABELS_SEQ: seq,
+                    DataType.IS_FIRST_SAMPLE: torch.tensor([step == 0], device=DEV), DataType.IS_LAST_SAMPLE: torch.tensor([step == 1]),
+                    DataType.IS_REVERSED: torch.tensor([tflip]), DataType.EV_IDX: [torch.tensor([i]) for i in idx],
+                    DataType.PATH: ['/data/gen1/test/seq_0']}
+            mod.test_step({DATA_KEY: data, WORKER_ID_KEY: 1 if tflip else 0}, step)
+            with torch.no_grad():
+                dets, states, _ = ot.infer_sequence(osd, MICRO, ev, states, conf_thre=0.005, hflip=True)
+            for hflip in (False, True):
+                views.append(dict(hflip=hflip, tflip=tflip, ev_idx=idx, last=step == 1,
+                                  gts=[l[0] if l[0] is not None else 1.0 for l in labels_tb],
+                                  preds=[dets[t * 2 + int(hflip)] if labels_tb[t][0] is not None else 1.0 for t in range(L)]))
+    want = otta.aggregate_views(views, HW, 0.005, 0.45)
+    res = mod.ev_path_2_ev_pred['seq_0']
+    assert res.eoe and res.aug and sorted(res.ev_idx_2_gt) == sorted(labelled)
+    lab_rec, prd_rec = res.aggregate_results()
+    assert len(lab_rec) == len(want) == 4
+    n = 0
+    for (wl, wp), l, p in zip(want, lab_rec, prd_rec):
+        for name in wl.dtype.names:
+            assert np.array_equal(l[name], wl[name]), name
+        assert len(p) == len(wp)
+        for name in ('x', 'y', 'w', 'h', 'class_confidence'):
+            np.testing.assert_allclose(p[name], wp[name], rtol=3e-4, atol=3e-4, err_msg=name)
+        assert np.array_equal(p['class_id'], wp['class_id']) and np.array_equal(p['t'], wp['t'])
+        n += len(p)
+    assert n > 8
+    got = mod.on_test_epoch_end()
+    assert got.pop('batch_size') == 2 * B
+    ref = oc.evaluate_buffer(lab_rec, prd_rec, 'gen1', False)
+    assert {k: float(v) for k, v in got.items()} == {f'test/{k}': v for k, v in ref.items()}
+    assert not mod.mode_2_psee_evaluator[Mode.TEST].has_data()          # TTAModule resets the buffer (tta.py:387)

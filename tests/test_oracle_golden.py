@@ -321,3 +321,18 @@ def test_augment_oracle_matches_reference(golden_dir):
         np.testing.assert_array_equal(out, g[f's{seed}_ev'])
         modes.add((bool(st[0]), mode))
     assert {m for _, m in modes} == {0, 1, 2} and {f for f, _ in modes} == {False, True}
+
+
+def test_tta_result_oracle_matches_reference(golden_dir):
+    """oracle.tta.aggregate_views == the reference's EventSeqResult (modules/utils/tta.py:64-195) on scripted views."""
+    from oracle import tta as otta
+    from oracle.synth import synth_tta_views
+    g = np.load(os.path.join(golden_dir, 'g16_tta_result.npz'))
+    for case in range(3):
+        views, hw = synth_tta_views(case)
+        got = otta.aggregate_views(views, hw, 0.1, 0.45)
+        assert len(got) == int(g[f'c{case}_n']) == 5
+        for k, (lab, prd) in enumerate(got):
+            for name in lab.dtype.names:
+                assert np.array_equal(lab[name], g[f'c{case}_lab{k}_{name}']), (case, k, name)
+                assert np.array_equal(prd[name], g[f'c{case}_pred{k}_{name}']), (case, k, name)
