@@ -40,8 +40,15 @@ def model_config(size: str = 'small', name: str = 'rnndet', partition_split_32: 
                   bbox_loss_weighting='', ignore_bbox_thresh=None, ignore_label=1024, ignore_bg_k=0),
         postprocess=dict(confidence_threshold=0.1, nms_threshold=0.45),
         use_label_every=1, ignore_image=False)
-    if name == 'pseudo_labeler':
-        cfg['pseudo_label'] = dict(skip_first_t=0, obj_thresh=[0.6, 0.3], cls_thresh=[0.6, 0.3], min_track_len=6,
+    # the shipped model groups (config/model/*.yaml): `model=rnndet-soft` (self-training rounds: pseudo boxes below the
+    # per-class obj/cls confidence are ignored, not suppressed), its 1 Mpx WSOD variant, and the two pseudo-labellers
+    if name in ('rnndet-soft', 'rnndet-soft-gen4-wsod'):
+        cfg['name'] = 'rnndet'
+        cfg['head']['ignore_bbox_thresh'] = [0.7, 0.35] if name == 'rnndet-soft' else [0.7, 0.55]
+    if name in ('pseudo_labeler', 'pseudo_labeler-gen4-wsod'):
+        cfg['name'] = 'pseudo_labeler'
+        thr = [0.6, 0.3] if name == 'pseudo_labeler' else [0.6, 0.5]
+        cfg['pseudo_label'] = dict(skip_first_t=0, obj_thresh=list(thr), cls_thresh=list(thr), min_track_len=6,
                                    track_method='forward or backward', inpaint=True, ignore_label=1024)
     for k, v in over.items():
         cfg[k] = v

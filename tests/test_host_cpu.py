@@ -29,6 +29,13 @@ def test_derived_config_matches_reference_modifier():
     assert list(c.model.pseudo_label.obj_thresh) == [0.3, 0.3, 0.6]       # (car, ped) -> (ped, cyc, car)
     assert tuple(c.dataset.ev_repr_hw) == (360, 640)
     assert c.dataset.data_augmentation.tflip_offset == -2
+    # the other shipped model groups (config/model/rnndet-soft*.yaml, pseudo_labeler-gen4-wsod.yaml; modifier.py:82-104)
+    c = dynamically_modify_train_config(full_config('gen1', 'small', 'rnndet-soft'))
+    assert c.model.name == 'rnndet' and list(c.model.head.ignore_bbox_thresh) == [0.7, 0.35]
+    c = dynamically_modify_train_config(full_config('gen4', 'small', 'rnndet-soft-gen4-wsod'))
+    assert c.model.name == 'rnndet' and list(c.model.head.ignore_bbox_thresh) == [0.55, 0.55, 0.7]
+    c = dynamically_modify_train_config(full_config('gen4', 'small', 'pseudo_labeler-gen4-wsod'))
+    assert c.model.name == 'pseudo_labeler' and list(c.model.pseudo_label.cls_thresh) == [0.5, 0.5, 0.6]
 
 
 def test_state_dict_manifest(manifest):

@@ -369,6 +369,17 @@ def test_simota_golden(ops, golden_dir):
     asg = ops.simota_assign(outp.to(DEV), tg2.to(DEV), hws, strides)
     close(ops.yolox_loss(outp.to(DEV), tg2.to(DEV), asg, hws, strides, want_grad=False)[0], g['noign_losses'], rtol=2e-5, atol=1e-6)
     close(ops.yolox_loss(outp.to(DEV), tg2.to(DEV), asg, hws, strides, want_grad=False, focal=True)[0], g['focal_losses'], rtol=2e-5, atol=1e-6)
+    # self-training head (model=rnndet-soft): pseudo boxes under the per-class confidence thresholds become ignore boxes
+    # (yolo_head.py:383-401) before the assignment
+    from leod_amd.config import full_config, dynamically_modify_train_config
+    from leod_amd.models.detection.yolox_extension.models.build import build_yolox_head
+    cfg = dynamically_modify_train_config(full_config('gen1', 'small', 'rnndet-soft')).model
+    head = build_yolox_head(cfg.head, in_channels=(96, 192, 384), strides=strides)
+    assert list(head.ignore_bbox_thresh) == [0.7, 0.35]
+    thr = head._ignore_bbox(torch.from_numpy(g['thr_targets']).clone().to(DEV))
+    assert int((thr[:, :, 0] == 1024).sum()) > 0
+    asg = ops.simota_assign(outp.to(DEV), thr, hws, strides)
+    close(ops.yolox_loss(outp.to(DEV), thr, asg, hws, strides, want_grad=False)[0], g['thr_losses'], rtol=2e-5, atol=1e-6)
 
 
 def test_focal_grad(ops):
