@@ -325,3 +325,28 @@ def test_full_size_pseudo_label_pass_properties(gpu):
     for t in range(T):
         for b in range(2 * B):
             np.testing.assert_allclose(canon(d2[t, b, :c0[t, b]]), canon(d0[t, b, :c0[t, b]]), rtol=2e-4, atol=2e-4)
+
+
+def test_host_feeder_double_buffer(gpu):
+    """HostFeeder: batches arrive intact and in order through the two device buffers, for pinned and pageable sources, with a
+    consumer kernel still reading buffer k when batch k + 2 is staged."""
+    from leod_amd.engine import HostFeeder
+    shape = (3, 2, 20, 60, 76)
+    g = torch.Generator().manual_seed(1)
+    batches = [torch.randint(0, 255, shape, generator=g, dtype=torch.uint8) for _ in range(6)]
+    batches = [b.pin_memory() if i % 2 else b for i, b in enumerate(batches)]
+    feeder = HostFeeder(shape, DEV)
+    feeder.put(batches[0])
+    sums = []
+    for i in range(6):
+        x = feeder.get()
+        if i + 1 < 6:
+            feeder.put(batches[i + 1])
+        y = x.to(torch.float64)
+        for _ in range(20):                       # keep the launch stream busy reading x
+            y = y * 1.0 + 0.0
+        sums.append((y.sum(), x.clone()))
+        feeder.done()
+    torch.cuda.synchronize()
+    for i, (s, x) in enumerate(sums):
+        assert torch.equal(x.cpu(), batches[i]) and float(s) == float(batches[i].to(torch.float64).sum())
