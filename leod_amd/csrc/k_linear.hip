@@ -1,6 +1,8 @@
 // Token-row contractions of the RVT backbone: LayerNorm->Linear(+GELU), Linear->LayerScale+residual,
 // the fused ConvLSTM cell, and the matching dgrad / wgrad GEMMs.  All tensors fp32, channels-last
 // ("rows" = tokens of an NHWC map).  C-ABI declared in include/leod_hip.h.
+#include <type_traits>
+
 #include "gemm16.hpp"
 
 static inline int pick_nt(int N) {
@@ -26,6 +28,168 @@ static inline EpStore ep_store(float* out, long ld, int N) {
     return e;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-autonomous row-streaming GEMM for the one-chunk contractions of stage 1 (K = 48, N = 144 / 192: LN -> qkv, LN -> fc1 +
+// GELU).  A 64 x 48 workgroup of the LDS-staged GEMM lives ~11 us for 36 MFMAs per wave (operand loads, barrier, MFMAs, barrier,
+// transposition, barrier, stores: two serialized memory latencies) and 4 of them per CU keep only ~2.5 TB/s in flight.  Here the
+// whole weight matrix stays in LDS for the life of a persistent workgroup, every WAVE streams its own 16-row tiles with the A
+// fragments loaded straight into the MFMA operand layout two tiles ahead, and the only LDS traffic besides the B fragments is a
+// wave-private 16 x 64 transposition tile for 16-byte row stores -- no workgroup barrier after the prologue.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NTT, bool LN, bool ACT>
+__global__ __launch_bounds__(256, NTT <= 9 ? 3 : 2) void rowstream48_kernel(const float* __restrict__ x, long ldx, float* __restrict__ stats_out,
+                                                             const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
+                                                             const float* __restrict__ W, const float* __restrict__ bias,
+                                                             float* __restrict__ out, float* __restrict__ out2, int M) {
+    constexpr int K = 48, LD = K + 8, N = NTT * 16, LDO = 68, NG = (NTT + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float sW[N * LD];
+    __shared__ __attribute__((aligned(16))) float sO[4][16 * LDO];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    for (int e = tid; e < N * (K / 4); e += 256) {
+        const int n = e / (K / 4), k4 = (e - n * (K / 4)) * 4;
+        *reinterpret_cast<f4*>(&sW[n * LD + k4]) = ld4(W + (long)n * K + k4);
+    }
+    // everything a tile needs besides its own rows is loaded ONCE: a global load inside the tile loop makes the compiler wait
+    // for vmcnt(0) at its first use, i.e. for every prefetched fragment and every store still in flight
+    f4 lw[3], lb[3], bv[NG];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        lw[c] = LN ? ld4(ln_w + 16 * c + 4 * q) : f4{1.f, 1.f, 1.f, 1.f};
+        lb[c] = LN ? ld4(ln_b + 16 * c + 4 * q) : zero4();
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int n = 64 * g + 4 * i;
+        bv[g] = (bias && n < N) ? ld4(bias + n) : zero4();
+    }
+    __syncthreads();
+    const int ntiles = (M + 15) / 16;
+    const int stride = gridDim.x * 4;
+    float* so = sO[wave];
+    struct Frag { f4 a[3]; };
+    // branch-free: out-of-range tiles / rows read the last row again (never stored), so the loads carry no select and the
+    // compiler has no reason to wait for them before their first real use two tiles later
+    auto load = [&](Frag& f, int tile) {
+        const long row = min((long)tile * 16 + i, (long)M - 1);
+        const float* p = x + row * ldx + 4 * q;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f.a[c] = ld4(p + 16 * c);
+    };
+    // FULL tiles store unconditionally: a store behind a branch is invisible to the compiler's vmcnt bookkeeping, which then
+    // waits for (nearly) everything in flight before the next tile's first MFMA
+    auto compute = [&](const Frag& f, int tile, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const long row0 = (long)tile * 16;
+        // LayerNorm statistics of row i from the fragments themselves (the row's 48 values sit in the 4 lanes i, i+16, i+32,
+        // i+48): two-pass mean / variance like the reference's LayerNorm, (mean, rstd) kept for the backward pass
+        float mean = 0.f, rstd = 1.f;
+        if (LN) {
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sum += (f.a[c][0] + f.a[c][1]) + (f.a[c][2] + f.a[c][3]);
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            mean = sum * (1.0f / K);
+            float var = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const f4 d = f.a[c] - mean;
+                var += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            }
+            var += __shfl_xor(var, 16, 64);
+            var += __shfl_xor(var, 32, 64);
+            rstd = rsqrtf(var * (1.0f / K) + eps);
+            if (FULL || row0 + i < M) {                       // the 4 lanes of a row write the same pair (no q == 0 branch)
+                float2 st; st.x = mean; st.y = rstd;
+                *reinterpret_cast<float2*>(stats_out + 2 * (row0 + i)) = st;
+            }
+        }
+        f4 acc[NTT];
+#pragma unroll
+        for (int t = 0; t < NTT; ++t) acc[t] = zero4();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            f4 av = f.a[c];
+            if (LN) av = (av - mean) * rstd * lw[c] + lb[c];
+#pragma unroll
+            for (int t = 0; t < NTT; ++t) {
+                const f4 b = *reinterpret_cast<const f4*>(&sW[(16 * t + i) * LD + 16 * c + 4 * q]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t] = mfma16(av[j], b[j], acc[t]);
+            }
+        }
+        auto emit = [&](long row, int n, f4 v) {
+            if (!FULL && row >= M) return;
+            *reinterpret_cast<f4*>(out + row * N + n) = v;
+            if (ACT) {
+                f4 ge;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ge[j] = gelu_erf(v[j]);
+                *reinterpret_cast<f4*>(out2 + row * N + n) = ge;
+            }
+        };
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int nt_g = NTT - 4 * g >= 4 ? 4 : NTT - 4 * g;              // column tiles of this group (compile time after unroll)
+            // wave-private tile: LDS operations of one wave execute in order, so only the COMPILER must keep write -> read ->
+            // write order (no fence: it would drain vmcnt, i.e. the prefetched fragments and the stores in flight)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 4 * g; t < NTT && t < 4 * g + 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) so[(4 * q + r) * LDO + 16 * (t - 4 * g) + i] = acc[t][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (nt_g == 4) {                                                 // 64 columns: lane = (4 rows q + 4p) x 16-byte column i
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int lr = q + 4 * p;
+                    emit(row0 + lr, 64 * g + 4 * i, *reinterpret_cast<const f4*>(&so[lr * LDO + 4 * i]) + bv[g]);
+                }
+            } else {                                                         // 16 columns: every lane stores one (row, 16-byte column)
+                const int lr = lane >> 2, c4 = lane & 3;
+                const f4 b4 = {__shfl(bv[g][0], c4, 64), __shfl(bv[g][1], c4, 64), __shfl(bv[g][2], c4, 64), __shfl(bv[g][3], c4, 64)};
+                emit(row0 + lr, 64 * g + 4 * c4, *reinterpret_cast<const f4*>(&so[lr * LDO + 4 * c4]) + b4);
+            }
+        }
+    };
+    static_assert(NTT % 4 == 0 || NTT % 4 == 1, "remainder groups of 2 or 3 column tiles are not laid out");
+    const int nfull = M / 16;
+    int tile = blockIdx.x * 4 + wave;
+    Frag f0, f1, f2;
+    load(f0, tile);
+    load(f1, tile + stride);
+    const std::true_type full{};
+    while (true) {
+        load(f2, tile + 2 * stride);
+        if (tile >= nfull) break;
+        compute(f0, tile, full); tile += stride;
+        load(f0, tile + 2 * stride);
+        if (tile >= nfull) { f0 = f1; break; }
+        compute(f1, tile, full); tile += stride;
+        load(f1, tile + 2 * stride);
+        if (tile >= nfull) { f0 = f2; break; }
+        compute(f2, tile, full); tile += stride;
+    }
+    if (tile == nfull && (M & 15)) compute(f0, tile, std::false_type{});       // the ragged last tile, on whichever wave owns it
+}
+
+static inline bool use_rowstream48(int M, int N, int K) {
+    static const int on = getenv("LEOD_ROWSTREAM") ? atoi(getenv("LEOD_ROWSTREAM")) : 1;
+    return on && K == 48 && (N == 144 || N == 192) && M >= 16384;
+}
+template <int NTT, bool ACT>
+static int launch_rowstream48(const float* x, long ldx, float* stats, const float* ln_w, const float* ln_b, float eps, const float* W,
+                              const float* bias, float* out, float* out2, int M, hipStream_t s) {
+    const int per_cu = NTT <= 9 ? 3 : 2;                    // resident workgroups per CU (registers / LDS): one wave of them
+    const int grid = min(cdiv(cdiv(M, 16), 4), 256 * per_cu);
+    if (stats) hipLaunchKernelGGL((rowstream48_kernel<NTT, true, ACT>), dim3(grid), dim3(256), 0, s, x, ldx, stats, ln_w, ln_b, eps, W, bias, out, out2, M);
+    else hipLaunchKernelGGL((rowstream48_kernel<NTT, false, ACT>), dim3(grid), dim3(256), 0, s, x, ldx, stats, ln_w, ln_b, eps, W, bias, out, out2, M);
+    return leod_launch_status();
+}
+
 // out[M,N] = LN(x)[M,K] @ W[N,K]^T + bias ; optionally also out_act = gelu(out)
 // ln_w == NULL -> no LayerNorm.  stats_out (optional) [M,2] = (mean, rstd) for the backward pass.
 // Reference: models/layers/maxvit/maxvit.py:267-269 (norm1 -> qkv, :347) and :110-118 (norm2 -> fc1 -> GELU)
@@ -39,6 +203,13 @@ LEOD_API int leod_ln_linear_fwd(const float* x, long ldx, const float* ln_w, con
     if (out_act) { ep.act = ACT_GELU_DUAL; ep.out2 = out_act; ep.ld2 = N; }
     const int nt = pick_nt(N);
     int rc = LEOD_OK;
+    if (use_rowstream48(M, N, K) && (!ln_w || stats_out) && ldx == K) {
+        float* st = ln_w ? stats_out : nullptr;                 // the kernel derives (mean, rstd) itself and leaves them here
+        if (N == 144) return out_act ? launch_rowstream48<9, true>(x, ldx, st, ln_w, ln_b, eps, W, bias, out, out_act, M, stream)
+                                     : launch_rowstream48<9, false>(x, ldx, st, ln_w, ln_b, eps, W, bias, out, nullptr, M, stream);
+        return out_act ? launch_rowstream48<12, true>(x, ldx, st, ln_w, ln_b, eps, W, bias, out, out_act, M, stream)
+                       : launch_rowstream48<12, false>(x, ldx, st, ln_w, ln_b, eps, W, bias, out, nullptr, M, stream);
+    }
     if (use_gemm_lds(M, cdiv(N, 16 * nt)) && (!ln_w || stats_out)) {
         if (ln_w) { rc = launch_row_stats(x, ldx, stats_out, M, K, eps, stream); if (rc) return rc; al.stats_in = stats_out; }
         DISPATCH_NT(nt, { BLRows bl{W, (long)K, N, NT}; rc = launch_gemm_lds<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });

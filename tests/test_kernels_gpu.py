@@ -51,7 +51,11 @@ def close(a, b, rtol=2e-5, atol=2e-6, what=''):
                                           # large M: LDS-staged GEMM, row-layout epilogue, row_stats prologue
                                           (20000, 144, 48, True, False), (33333, 192, 48, True, True),
                                           (17000, 1152, 384, True, False), (24000, 96, 96, False, True),
-                                          (9000, 128, 64, True, True)])
+                                          (9000, 128, 64, True, True),
+                                          # K = 48, N = 144 / 192: wave-autonomous row-streaming kernel (ragged last tile,
+                                          # fewer tiles than persistent waves, with / without LayerNorm and GELU)
+                                          (70001, 144, 48, True, False), (50000, 192, 48, True, True),
+                                          (16390, 144, 48, False, True), (300000, 192, 48, False, False)])
 def test_ln_linear_fwd(ops, M, N, K, ln, act):
     x, W, b = rnd((M, K), 1), rnd((N, K), 2, 0.2), rnd((N,), 3, 0.1)
     lw, lb = 1 + 0.2 * rnd((K,), 4), 0.1 * rnd((K,), 5)
