@@ -29,19 +29,26 @@ static inline EpStore ep_store(float* out, long ld, int N) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Wave-autonomous row-streaming GEMM for the one-chunk contractions of stage 1 (K = 48, N = 144 / 192: LN -> qkv, LN -> fc1 +
-// GELU).  A 64 x 48 workgroup of the LDS-staged GEMM lives ~11 us for 36 MFMAs per wave (operand loads, barrier, MFMAs, barrier,
+// Wave-autonomous row-streaming GEMM for the short contractions of stages 1 and 2 (K = 48: N = 144 / 192, K = 96: N = 288 / 384
+// in column slabs: LN -> qkv, LN -> fc1 + GELU).  A 64 x 48 workgroup of the LDS-staged GEMM lives ~11 us for 36 MFMAs per wave (operand loads, barrier, MFMAs, barrier,
 // transposition, barrier, stores: two serialized memory latencies) and 4 of them per CU keep only ~2.5 TB/s in flight.  Here the
 // whole weight matrix stays in LDS for the life of a persistent workgroup, every WAVE streams its own 16-row tiles with the A
 // fragments loaded straight into the MFMA operand layout two tiles ahead, and the only LDS traffic besides the B fragments is a
 // wave-private 16 x 64 transposition tile for 16-byte row stores -- no workgroup barrier after the prologue.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NTT, bool LN, bool ACT>
-__global__ __launch_bounds__(256, NTT <= 9 ? 3 : 2) void rowstream48_kernel(const float* __restrict__ x, long ldx, float* __restrict__ stats_out,
+// K = 16 * KC.  A workgroup owns the NTT column tiles of slab blockIdx.y (its weights: NTT*16 x K floats in LDS); the slabs of
+// one row range get workgroup ids that differ by a multiple of 8, i.e. run on the same XCD and re-read the rows from its L2.
+template <int KC, int NTT, bool LN, bool ACT>
+__global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream48_kernel(const float* __restrict__ x, long ldx, float* __restrict__ stats_out,
                                                              const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
                                                              const float* __restrict__ W, const float* __restrict__ bias,
-                                                             float* __restrict__ out, float* __restrict__ out2, int M) {
-    constexpr int K = 48, LD = K + 8, N = NTT * 16, LDO = 68, NG = (NTT + 3) / 4;
+                                                             float* __restrict__ out, float* __restrict__ out2, int M, int Ntot) {
+    constexpr int K = 16 * KC, LD = K + 8, N = NTT * 16, LDO = 68, NG = (NTT + 3) / 4;
+    const int n0 = blockIdx.y * N;                              // first column of this slab
+    W += (long)n0 * K;
+    if (bias) bias += n0;
+    out += n0;
+    if (ACT) out2 += n0;
     __shared__ __attribute__((aligned(16))) float sW[N * LD];
     __shared__ __attribute__((aligned(16))) float sO[4][16 * LDO];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -52,9 +59,9 @@ __global__ __launch_bounds__(256, NTT <= 9 ? 3 : 2) void rowstream48_kernel(cons
     }
     // everything a tile needs besides its own rows is loaded ONCE: a global load inside the tile loop makes the compiler wait
     // for vmcnt(0) at its first use, i.e. for every prefetched fragment and every store still in flight
-    f4 lw[3], lb[3], bv[NG];
+    f4 lw[KC], lb[KC], bv[NG];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < KC; ++c) {
         lw[c] = LN ? ld4(ln_w + 16 * c + 4 * q) : f4{1.f, 1.f, 1.f, 1.f};
         lb[c] = LN ? ld4(ln_b + 16 * c + 4 * q) : zero4();
     }
@@ -67,14 +74,14 @@ __global__ __launch_bounds__(256, NTT <= 9 ? 3 : 2) void rowstream48_kernel(cons
     const int ntiles = (M + 15) / 16;
     const int stride = gridDim.x * 4;
     float* so = sO[wave];
-    struct Frag { f4 a[3]; };
+    struct Frag { f4 a[KC]; };
     // branch-free: out-of-range tiles / rows read the last row again (never stored), so the loads carry no select and the
     // compiler has no reason to wait for them before their first real use two tiles later
     auto load = [&](Frag& f, int tile) {
         const long row = min((long)tile * 16 + i, (long)M - 1);
         const float* p = x + row * ldx + 4 * q;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) f.a[c] = ld4(p + 16 * c);
+        for (int c = 0; c < KC; ++c) f.a[c] = ld4(p + 16 * c);
     };
     // FULL tiles store unconditionally: a store behind a branch is invisible to the compiler's vmcnt bookkeeping, which then
     // waits for (nearly) everything in flight before the next tile's first MFMA
@@ -87,20 +94,20 @@ __global__ __launch_bounds__(256, NTT <= 9 ? 3 : 2) void rowstream48_kernel(cons
         if (LN) {
             float sum = 0.f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) sum += (f.a[c][0] + f.a[c][1]) + (f.a[c][2] + f.a[c][3]);
+            for (int c = 0; c < KC; ++c) sum += (f.a[c][0] + f.a[c][1]) + (f.a[c][2] + f.a[c][3]);
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
             mean = sum * (1.0f / K);
             float var = 0.f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
+            for (int c = 0; c < KC; ++c) {
                 const f4 d = f.a[c] - mean;
                 var += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
             }
             var += __shfl_xor(var, 16, 64);
             var += __shfl_xor(var, 32, 64);
             rstd = rsqrtf(var * (1.0f / K) + eps);
-            if (FULL || row0 + i < M) {                       // the 4 lanes of a row write the same pair (no q == 0 branch)
+            if (blockIdx.y == 0 && (FULL || row0 + i < M)) {  // the 4 lanes of a row write the same pair (no q == 0 branch)
                 float2 st; st.x = mean; st.y = rstd;
                 *reinterpret_cast<float2*>(stats_out + 2 * (row0 + i)) = st;
             }
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(256, NTT <= 9 ? 3 : 2) void rowstream48_kernel(cons
 #pragma unroll
         for (int t = 0; t < NTT; ++t) acc[t] = zero4();
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < KC; ++c) {
             f4 av = f.a[c];
             if (LN) av = (av - mean) * rstd * lw[c] + lb[c];
 #pragma unroll
@@ -121,12 +128,12 @@ __global__ __launch_bounds__(256, NTT <= 9 ? 3 : 2) void rowstream48_kernel(cons
         }
         auto emit = [&](long row, int n, f4 v) {
             if (!FULL && row >= M) return;
-            *reinterpret_cast<f4*>(out + row * N + n) = v;
+            *reinterpret_cast<f4*>(out + row * Ntot + n) = v;
             if (ACT) {
                 f4 ge;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ge[j] = gelu_erf(v[j]);
-                *reinterpret_cast<f4*>(out2 + row * N + n) = ge;
+                *reinterpret_cast<f4*>(out2 + row * Ntot + n) = ge;
             }
         };
 #pragma unroll
@@ -176,17 +183,24 @@ __global__ __launch_bounds__(256, NTT <= 9 ? 3 : 2) void rowstream48_kernel(cons
     if (tile == nfull && (M & 15)) compute(f0, tile, std::false_type{});       // the ragged last tile, on whichever wave owns it
 }
 
-static inline bool use_rowstream48(int M, int N, int K) {
-    static const int on = getenv("LEOD_ROWSTREAM") ? atoi(getenv("LEOD_ROWSTREAM")) : 1;
-    return on && K == 48 && (N == 144 || N == 192) && M >= 16384;
+// (K, N) -> column tiles per slab; 0 = shape not covered.  K = 48: the whole N (9 / 12 tiles); K = 96: slabs of 9 (N = 288) or
+// 8 (N = 384) tiles, so that weights + wave tiles of two workgroups fit the 160 KB of a CU
+static inline int rowstream_slab(int M, int N, int K) {
+    static const int on = getenv("LEOD_ROWSTREAM") ? atoi(getenv("LEOD_ROWSTREAM")) : 2;     // 0 off, 1 stage 1 only, 2 stages 1 + 2
+    if (!on || M < 16384) return 0;
+    if (K == 48 && (N == 144 || N == 192)) return N / 16;
+    if (K == 96 && on >= 2) return N == 288 ? 9 : (N == 384 ? 8 : 0);
+    return 0;
 }
-template <int NTT, bool ACT>
+template <int KC, int NTT, bool ACT>
 static int launch_rowstream48(const float* x, long ldx, float* stats, const float* ln_w, const float* ln_b, float eps, const float* W,
-                              const float* bias, float* out, float* out2, int M, hipStream_t s) {
-    const int per_cu = NTT <= 9 ? 3 : 2;                    // resident workgroups per CU (registers / LDS): one wave of them
-    const int grid = min(cdiv(cdiv(M, 16), 4), 256 * per_cu);
-    if (stats) hipLaunchKernelGGL((rowstream48_kernel<NTT, true, ACT>), dim3(grid), dim3(256), 0, s, x, ldx, stats, ln_w, ln_b, eps, W, bias, out, out2, M);
-    else hipLaunchKernelGGL((rowstream48_kernel<NTT, false, ACT>), dim3(grid), dim3(256), 0, s, x, ldx, stats, ln_w, ln_b, eps, W, bias, out, out2, M);
+                              const float* bias, float* out, float* out2, int M, int N, hipStream_t s) {
+    const int per_cu = (KC == 3 && NTT <= 9) ? 3 : 2;        // resident workgroups per CU (registers / LDS): one wave of them
+    const int slabs = N / (16 * NTT);
+    const int gx = min(cdiv(cdiv(M, 16), 4), max(8, (256 * per_cu / slabs) & ~7));   // multiple of 8: slabs of a row range share an XCD
+    const dim3 grid(gx, slabs);
+    if (stats) hipLaunchKernelGGL((rowstream48_kernel<KC, NTT, true, ACT>), grid, dim3(256), 0, s, x, ldx, stats, ln_w, ln_b, eps, W, bias, out, out2, M, N);
+    else hipLaunchKernelGGL((rowstream48_kernel<KC, NTT, false, ACT>), grid, dim3(256), 0, s, x, ldx, stats, ln_w, ln_b, eps, W, bias, out, out2, M, N);
     return leod_launch_status();
 }
 
@@ -203,12 +217,14 @@ LEOD_API int leod_ln_linear_fwd(const float* x, long ldx, const float* ln_w, con
     if (out_act) { ep.act = ACT_GELU_DUAL; ep.out2 = out_act; ep.ld2 = N; }
     const int nt = pick_nt(N);
     int rc = LEOD_OK;
-    if (use_rowstream48(M, N, K) && (!ln_w || stats_out) && ldx == K) {
+    if (const int slab = ((!ln_w || stats_out) && ldx == K) ? rowstream_slab(M, N, K) : 0) {
         float* st = ln_w ? stats_out : nullptr;                 // the kernel derives (mean, rstd) itself and leaves them here
-        if (N == 144) return out_act ? launch_rowstream48<9, true>(x, ldx, st, ln_w, ln_b, eps, W, bias, out, out_act, M, stream)
-                                     : launch_rowstream48<9, false>(x, ldx, st, ln_w, ln_b, eps, W, bias, out, nullptr, M, stream);
-        return out_act ? launch_rowstream48<12, true>(x, ldx, st, ln_w, ln_b, eps, W, bias, out, out_act, M, stream)
-                       : launch_rowstream48<12, false>(x, ldx, st, ln_w, ln_b, eps, W, bias, out, nullptr, M, stream);
+#define RS_CASE(KCV, NTTV)                                                                                                         \
+        if (K == 16 * KCV && slab == NTTV)                                                                                         \
+            return out_act ? launch_rowstream48<KCV, NTTV, true>(x, ldx, st, ln_w, ln_b, eps, W, bias, out, out_act, M, N, stream)   \
+                           : launch_rowstream48<KCV, NTTV, false>(x, ldx, st, ln_w, ln_b, eps, W, bias, out, nullptr, M, N, stream);
+        RS_CASE(3, 9) RS_CASE(3, 12) RS_CASE(6, 9) RS_CASE(6, 8)
+#undef RS_CASE
     }
     if (use_gemm_lds(M, cdiv(N, 16 * nt)) && (!ln_w || stats_out)) {
         if (ln_w) { rc = launch_row_stats(x, ldx, stats_out, M, K, eps, stream); if (rc) return rc; al.stats_in = stats_out; }

@@ -55,7 +55,9 @@ def close(a, b, rtol=2e-5, atol=2e-6, what=''):
                                           # K = 48, N = 144 / 192: wave-autonomous row-streaming kernel (ragged last tile,
                                           # fewer tiles than persistent waves, with / without LayerNorm and GELU)
                                           (70001, 144, 48, True, False), (50000, 192, 48, True, True),
-                                          (16390, 144, 48, False, True), (300000, 192, 48, False, False)])
+                                          (16390, 144, 48, False, True), (300000, 192, 48, False, False),
+                                          # K = 96 in column slabs (stage 2: N = 288 -> 2 x 144, N = 384 -> 3 x 128)
+                                          (40003, 288, 96, True, False), (30000, 384, 96, True, True), (20000, 384, 96, False, False)])
 def test_ln_linear_fwd(ops, M, N, K, ln, act):
     x, W, b = rnd((M, K), 1), rnd((N, K), 2, 0.2), rnd((N,), 3, 0.1)
     lw, lb = 1 + 0.2 * rnd((K,), 4), 0.1 * rnd((K,), 5)
