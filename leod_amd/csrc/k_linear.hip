@@ -38,31 +38,44 @@ static inline EpStore ep_store(float* out, long ld, int N) {
 // ---------------------------------------------------------------------------------------------------------------------
 // K = 16 * KC.  A workgroup owns the NTT column tiles of slab blockIdx.y (its weights: NTT*16 x K floats in LDS); the slabs of
 // one row range get workgroup ids that differ by a multiple of 8, i.e. run on the same XCD and re-read the rows from its L2.
-template <int KC, int NTT, bool LN, bool ACT>
+// DG = 0: forward (W [Ntot][K]; optional LayerNorm on load, optional exact-GELU second output).
+// DG = 1 / 2: dgrad of a Linear, dx = (dy * kscale) @ W with W [K][Ntot] (read transposed into LDS once per workgroup); ln_w
+// carries kscale (may be NULL), DG = 2 multiplies by gelu'(aux) with aux = out2 [M][Ntot] (the pre-activation), loaded at the
+// START of the tile so that its wait falls behind the tile's MFMAs.
+template <int KC, int NTT, bool LN, bool ACT, int DG = 0>
 __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream48_kernel(const float* __restrict__ x, long ldx, float* __restrict__ stats_out,
                                                              const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
                                                              const float* __restrict__ W, const float* __restrict__ bias,
                                                              float* __restrict__ out, float* __restrict__ out2, int M, int Ntot) {
     constexpr int K = 16 * KC, LD = K + 8, N = NTT * 16, LDO = 68, NG = (NTT + 3) / 4;
     const int n0 = blockIdx.y * N;                              // first column of this slab
-    W += (long)n0 * K;
+    W += DG ? (long)n0 : (long)n0 * K;
     if (bias) bias += n0;
     out += n0;
-    if (ACT) out2 += n0;
+    if (ACT || DG == 2) out2 += n0;
     __shared__ __attribute__((aligned(16))) float sW[N * LD];
     __shared__ __attribute__((aligned(16))) float sO[4][16 * LDO];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
-    for (int e = tid; e < N * (K / 4); e += 256) {
-        const int n = e / (K / 4), k4 = (e - n * (K / 4)) * 4;
-        *reinterpret_cast<f4*>(&sW[n * LD + k4]) = ld4(W + (long)n * K + k4);
+    if (DG == 0) {
+        for (int e = tid; e < N * (K / 4); e += 256) {
+            const int n = e / (K / 4), k4 = (e - n * (K / 4)) * 4;
+            *reinterpret_cast<f4*>(&sW[n * LD + k4]) = ld4(W + (long)n * K + k4);
+        }
+    } else {
+        for (int e = tid; e < K * (N / 4); e += 256) {
+            const int k = e / (N / 4), n4 = (e - k * (N / 4)) * 4;
+            const f4 w = ld4(W + (long)k * Ntot + n4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sW[(n4 + j) * LD + k] = w[j];
+        }
     }
     // everything a tile needs besides its own rows is loaded ONCE: a global load inside the tile loop makes the compiler wait
     // for vmcnt(0) at its first use, i.e. for every prefetched fragment and every store still in flight
     f4 lw[KC], lb[KC], bv[NG];
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
-        lw[c] = LN ? ld4(ln_w + 16 * c + 4 * q) : f4{1.f, 1.f, 1.f, 1.f};
+        lw[c] = (LN || (DG && ln_w)) ? ld4(ln_w + 16 * c + 4 * q) : f4{1.f, 1.f, 1.f, 1.f};
         lb[c] = LN ? ld4(ln_b + 16 * c + 4 * q) : zero4();
     }
 #pragma unroll
@@ -112,6 +125,23 @@ __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream4
                 *reinterpret_cast<float2*>(stats_out + 2 * (row0 + i)) = st;
             }
         }
+        // dgrad through GELU: this tile's slice of the pre-activation, in the lane layout of the row stores below
+        f4 ug[DG == 2 ? NTT : 1];
+        if (DG == 2) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (NTT - 4 * g >= 4) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const long row = FULL ? row0 + q + 4 * p : min(row0 + q + 4 * p, (long)M - 1);
+                        ug[4 * g + p] = ld4(out2 + row * Ntot + 64 * g + 4 * i);
+                    }
+                } else {
+                    const long row = FULL ? row0 + (lane >> 2) : min(row0 + (lane >> 2), (long)M - 1);
+                    ug[4 * g] = ld4(out2 + row * Ntot + 64 * g + 4 * (lane & 3));
+                }
+            }
+        }
         f4 acc[NTT];
 #pragma unroll
         for (int t = 0; t < NTT; ++t) acc[t] = zero4();
@@ -119,6 +149,7 @@ __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream4
         for (int c = 0; c < KC; ++c) {
             f4 av = f.a[c];
             if (LN) av = (av - mean) * rstd * lw[c] + lb[c];
+            if (DG) av = av * lw[c];
 #pragma unroll
             for (int t = 0; t < NTT; ++t) {
                 const f4 b = *reinterpret_cast<const f4*>(&sW[(16 * t + i) * LD + 16 * c + 4 * q]);
@@ -126,8 +157,12 @@ __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream4
                 for (int j = 0; j < 4; ++j) acc[t] = mfma16(av[j], b[j], acc[t]);
             }
         }
-        auto emit = [&](long row, int n, f4 v) {
+        auto emit = [&](long row, int n, f4 v, const f4& u) {
             if (!FULL && row >= M) return;
+            if (DG == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(u[j]);
+            }
             *reinterpret_cast<f4*>(out + row * Ntot + n) = v;
             if (ACT) {
                 f4 ge;
@@ -153,12 +188,12 @@ __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream4
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const int lr = q + 4 * p;
-                    emit(row0 + lr, 64 * g + 4 * i, *reinterpret_cast<const f4*>(&so[lr * LDO + 4 * i]) + bv[g]);
+                    emit(row0 + lr, 64 * g + 4 * i, *reinterpret_cast<const f4*>(&so[lr * LDO + 4 * i]) + bv[g], ug[DG == 2 ? 4 * g + p : 0]);
                 }
             } else {                                                         // 16 columns: every lane stores one (row, 16-byte column)
                 const int lr = lane >> 2, c4 = lane & 3;
                 const f4 b4 = {__shfl(bv[g][0], c4, 64), __shfl(bv[g][1], c4, 64), __shfl(bv[g][2], c4, 64), __shfl(bv[g][3], c4, 64)};
-                emit(row0 + lr, 64 * g + 4 * c4, *reinterpret_cast<const f4*>(&so[lr * LDO + 4 * c4]) + b4);
+                emit(row0 + lr, 64 * g + 4 * c4, *reinterpret_cast<const f4*>(&so[lr * LDO + 4 * c4]) + b4, ug[DG == 2 ? 4 * g : 0]);
             }
         }
     };
@@ -201,6 +236,18 @@ static int launch_rowstream48(const float* x, long ldx, float* stats, const floa
     const dim3 grid(gx, slabs);
     if (stats) hipLaunchKernelGGL((rowstream48_kernel<KC, NTT, true, ACT>), grid, dim3(256), 0, s, x, ldx, stats, ln_w, ln_b, eps, W, bias, out, out2, M, N);
     else hipLaunchKernelGGL((rowstream48_kernel<KC, NTT, false, ACT>), grid, dim3(256), 0, s, x, ldx, stats, ln_w, ln_b, eps, W, bias, out, out2, M, N);
+    return leod_launch_status();
+}
+
+template <int KC, int NTT>
+static int launch_rowstream_dgrad(const float* dy, long lddy, const float* kscale, const float* W, const float* aux_u, float* dx,
+                                  int M, int Nout, hipStream_t s) {
+    const int slabs = Nout / (16 * NTT);
+    const int gx = min(cdiv(cdiv(M, 16), 4), max(8, (256 * 2 / slabs) & ~7));
+    const dim3 grid(gx, slabs);
+    float* aux = const_cast<float*>(aux_u);
+    if (aux_u) hipLaunchKernelGGL((rowstream48_kernel<KC, NTT, false, false, 2>), grid, dim3(256), 0, s, dy, lddy, nullptr, kscale, nullptr, 0.f, W, nullptr, dx, aux, M, Nout);
+    else hipLaunchKernelGGL((rowstream48_kernel<KC, NTT, false, false, 1>), grid, dim3(256), 0, s, dy, lddy, nullptr, kscale, nullptr, 0.f, W, nullptr, dx, aux, M, Nout);
     return leod_launch_status();
 }
 
@@ -281,6 +328,13 @@ LEOD_API int leod_linear_dgrad(const float* dy, long lddy, const float* kscale, 
     if (aux_u) { ep.act = ACT_MUL_GELU_GRAD; ep.aux = aux_u; ep.ldaux = K; }
     const int nt = pick_nt(K);
     int rc = LEOD_OK;
+    // contraction over N in {48, 96}, K in {192, 384} output columns (dgrad of fc2, optionally through GELU): streaming kernel
+    if (!dx2 && !colsum && !accumulate && lddy == N && lddx == K && nsplit <= 0) {
+        if (const int slab = rowstream_slab(M, K, N)) {
+            if (N == 48 && slab == 12) return launch_rowstream_dgrad<3, 12>(dy, lddy, kscale, W, aux_u, dx, M, K, stream);
+            if (N == 96 && slab == 8) return launch_rowstream_dgrad<6, 8>(dy, lddy, kscale, W, aux_u, dx, M, K, stream);
+        }
+    }
     if (use_gemm_lds(M, cdiv(K, 16 * nt))) {
         DISPATCH_NT(nt, { BLTrans bl{W, (long)K, K, NT}; rc = launch_gemm_lds<NT>(al, bl, ep, M, N, cdiv(K, 16 * NT), stream); });
         return rc;

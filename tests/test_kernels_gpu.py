@@ -151,7 +151,9 @@ def test_convlstm(ops, M, C, state):
 @pytest.mark.parametrize('M,N,K', [(300, 144, 48), (1000, 48, 192), (257, 64, 32), (5000, 96, 96), (100, 1536, 384),
                                    # large M: wave-tiled wgrad (192x48, 48x192, 96x96, 48x48 tiles) and LDS dgrad
                                    (30000, 192, 48), (30000, 48, 192), (20000, 288, 96), (65000, 48, 48),
-                                   (9000, 1536, 384), (12345, 144, 48), (16000, 128, 64)])
+                                   (9000, 1536, 384), (12345, 144, 48), (16000, 128, 64),
+                                   # dgrad of fc2 on the row-streaming kernel (contraction 48 / 96, ragged last tile)
+                                   (40007, 48, 192), (20000, 96, 384)])
 def test_linear_backward(ops, M, N, K):
     x = rnd((M, K), 1).requires_grad_(True)
     W, b = rnd((N, K), 2, 0.2).requires_grad_(True), rnd((N,), 3).requires_grad_(True)
@@ -175,6 +177,10 @@ def test_linear_backward(ops, M, N, K):
     F.gelu(uu2).backward(dy @ W.detach())
     close(du, uu2.grad, rtol=5e-5, atol=5e-6, what='dgrad*gelu')
     close(cs, uu2.grad.sum(0), rtol=2e-4, atol=5e-5, what='colsum')
+    du2 = ops.linear_dgrad(dy.to(DEV), W.detach().to(DEV), kscale=ks.to(DEV), aux_u=uu.to(DEV))       # as AttnBlockFn calls it
+    uu3 = uu.clone().requires_grad_(True)
+    F.gelu(uu3).backward((dy * ks) @ W.detach())
+    close(du2, uu3.grad, rtol=5e-5, atol=5e-6, what='dgrad*kscale*gelu')
 
 
 @pytest.mark.parametrize('M,C', [(500, 48), (70, 384), (1000, 32), (33, 512)])
