@@ -330,6 +330,39 @@ __device__ __forceinline__ long token_row(const AttnGeom& g, int p, int t) {
 }
 __device__ __forceinline__ f4 lds4(const float* p, bool ok) { return ok ? *reinterpret_cast<const f4*>(p) : zero4(); }
 
+// Fragment of one token row along the head dimension for the contractions over d (Q K^T, dO V^T): full 16-wide chunks in the
+// K-permuted layout (lane (i, rg) holds k = 16c + 4rg .. +3, four MFMAs per chunk) and, for d = 24, an 8-wide tail with
+// k = 16 + 2rg .. +1 (TWO MFMAs, every lane valid) instead of a half-empty third chunk: 6 instead of 8 MFMAs per product
+// and no select per operand element.
+template <int D>
+struct KFrag {
+    static constexpr int NC = D / 16, TAIL = D % 16;
+    static_assert(TAIL == 0 || TAIL == 8, "head dimension must be 16c or 16c + 8");
+    f4 c[NC > 0 ? NC : 1];
+    float t0, t1;
+};
+template <int D>
+__device__ __forceinline__ KFrag<D> kfrag_load(const float* row, int rg) {
+    KFrag<D> f;
+#pragma unroll
+    for (int c = 0; c < KFrag<D>::NC; ++c) f.c[c] = *reinterpret_cast<const f4*>(row + 16 * c + 4 * rg);
+    f.t0 = f.t1 = 0.f;
+    if (KFrag<D>::TAIL) {
+        const float2 t = *reinterpret_cast<const float2*>(row + 16 * KFrag<D>::NC + 2 * rg);
+        f.t0 = t.x; f.t1 = t.y;
+    }
+    return f;
+}
+template <int D>
+__device__ __forceinline__ f4 kfrag_mfma(const KFrag<D>& a, const KFrag<D>& b, f4 acc) {
+#pragma unroll
+    for (int c = 0; c < KFrag<D>::NC; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = mfma16(a.c[c][j], b.c[c][j], acc);
+    if (KFrag<D>::TAIL) { acc = mfma16(a.t0, b.t0, acc); acc = mfma16(a.t1, b.t1, acc); }
+    return acc;
+}
+
 template <int PT, int D, int HG>
 __global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                       float* __restrict__ lse, AttnGeom g, float scale) {
@@ -347,28 +380,29 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds_kernel(const float*
     const long ld = 3L * g.C;
     if (tid < TOK) srow[tid] = token_row(g, p, tid);
     __syncthreads();
-    for (int e = tid; e < TOK * F; e += NTHR) {
-        const int tok = e / F, f = e - tok * F;
-        const long row = srow[tok];
-        *reinterpret_cast<f4*>(smem + tok * S + 4 * f) = row >= 0 ? ld4(qkv + row * ld + h0 * 3 * d + 4 * f) : zero4();
+    {   // all global loads of the thread are issued before the first LDS store: a load -> store loop waits for every load in
+        // turn (4-5 dependent HBM round trips per workgroup)
+        constexpr int NL = (TOK * F + NTHR - 1) / NTHR;
+        f4 stage[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int e = tid + j * NTHR, tok = min(e / F, TOK - 1), f = e - (e / F) * F;
+            const long row = srow[tok];
+            stage[j] = (e < TOK * F && row >= 0) ? ld4(qkv + row * ld + h0 * 3 * d + 4 * f) : zero4();
+        }
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int e = tid + j * NTHR, tok = e / F, f = e - tok * F;
+            if (e < TOK * F) *reinterpret_cast<f4*>(smem + tok * S + 4 * f) = stage[j];
+        }
     }
     __syncthreads();
     const float* hb = smem + hl * 3 * d;                     // this wave's head inside a staged token row
     const bool qvalid = 16 * qt + i < P;
-    f4 qf[DCH];
-#pragma unroll
-    for (int ch = 0; ch < DCH; ++ch) qf[ch] = lds4(hb + (16 * qt + i) * S + 16 * ch + 4 * rg, 16 * ch + 4 * rg < d);
+    const KFrag<D> qf = kfrag_load<D>(hb + (16 * qt + i) * S, rg);
     f4 s[PT];
 #pragma unroll
-    for (int mt = 0; mt < PT; ++mt) {
-        s[mt] = zero4();
-#pragma unroll
-        for (int ch = 0; ch < DCH; ++ch) {
-            const f4 kf = lds4(hb + (16 * mt + i) * S + d + 16 * ch + 4 * rg, 16 * ch + 4 * rg < d);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s[mt] = mfma16(kf[j], qf[ch][j], s[mt]);
-        }
-    }
+    for (int mt = 0; mt < PT; ++mt) s[mt] = kfrag_mfma<D>(kfrag_load<D>(hb + (16 * mt + i) * S + d, rg), qf, zero4());
     float mx = -INFINITY;
 #pragma unroll
     for (int mt = 0; mt < PT; ++mt)
@@ -446,20 +480,43 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float*
     float* sdo = smem + TOK * S;
     if (tid < TOK) srow[tid] = token_row(g, p, tid);
     __syncthreads();
-    for (int e = tid; e < TOK * F; e += NTHR) {
-        const int tok = e / F, f = e - tok * F;
-        const long row = srow[tok];
-        *reinterpret_cast<f4*>(smem + tok * S + 4 * f) = row >= 0 ? ld4(qkv + row * ld + h0 * 3 * d + 4 * f) : zero4();
-    }
-    for (int e = tid; e < TOK * Fd; e += NTHR) {
-        const int tok = e / Fd, f = e - tok * Fd;
-        const long row = srow[tok];
-        *reinterpret_cast<f4*>(sdo + tok * Sd + 4 * f) = row >= 0 ? ld4(dout + row * g.C + h0 * d + 4 * f) : zero4();
-    }
-    for (int e = tid; e < HG * TOK; e += NTHR) {
-        const int hh = e / TOK, tok = e - hh * TOK;
-        const long row = srow[tok];
-        sL[e] = row >= 0 ? lse[row * g.heads + h0 + hh] : 0.f;
+    {   // every global load of the thread first, then the LDS stores (see the forward kernel)
+        constexpr int NL = (TOK * F + NTHR - 1) / NTHR, NLd = (TOK * Fd + NTHR - 1) / NTHR, NLl = (HG * TOK + NTHR - 1) / NTHR;
+        f4 stage[NL], staged[NLd];
+        float stagel[NLl];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int e = tid + j * NTHR, tok = min(e / F, TOK - 1), f = e - (e / F) * F;
+            const long row = srow[tok];
+            stage[j] = (e < TOK * F && row >= 0) ? ld4(qkv + row * ld + h0 * 3 * d + 4 * f) : zero4();
+        }
+#pragma unroll
+        for (int j = 0; j < NLd; ++j) {
+            const int e = tid + j * NTHR, tok = min(e / Fd, TOK - 1), f = e - (e / Fd) * Fd;
+            const long row = srow[tok];
+            staged[j] = (e < TOK * Fd && row >= 0) ? ld4(dout + row * g.C + h0 * d + 4 * f) : zero4();
+        }
+#pragma unroll
+        for (int j = 0; j < NLl; ++j) {
+            const int e = tid + j * NTHR, hh = min(e / TOK, HG - 1), tok = e - (e / TOK) * TOK;
+            const long row = srow[tok];
+            stagel[j] = (e < HG * TOK && row >= 0) ? lse[row * g.heads + h0 + hh] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int e = tid + j * NTHR, tok = e / F, f = e - tok * F;
+            if (e < TOK * F) *reinterpret_cast<f4*>(smem + tok * S + 4 * f) = stage[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NLd; ++j) {
+            const int e = tid + j * NTHR, tok = e / Fd, f = e - tok * Fd;
+            if (e < TOK * Fd) *reinterpret_cast<f4*>(sdo + tok * Sd + 4 * f) = staged[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NLl; ++j) {
+            const int e = tid + j * NTHR;
+            if (e < HG * TOK) sL[e] = stagel[j];
+        }
     }
     __syncthreads();
     const float* hb = smem + hl * 3 * d;
@@ -468,29 +525,13 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float*
     f4 dq[DCH];
     {
         const bool qvalid = 16 * qt + i < P;
-        f4 qf[DCH], dof[DCH];
-#pragma unroll
-        for (int ch = 0; ch < DCH; ++ch) {
-            const bool ok = 16 * ch + 4 * rg < d;
-            qf[ch] = lds4(hb + (16 * qt + i) * S + 16 * ch + 4 * rg, ok);
-            dof[ch] = lds4(db + (16 * qt + i) * Sd + 16 * ch + 4 * rg, ok);
-        }
+        const KFrag<D> qf = kfrag_load<D>(hb + (16 * qt + i) * S, rg), dof = kfrag_load<D>(db + (16 * qt + i) * Sd, rg);
         const float l = sL[hl * TOK + 16 * qt + i];
         f4 s[PT], dp[PT];
 #pragma unroll
         for (int mt = 0; mt < PT; ++mt) {
-            s[mt] = zero4(); dp[mt] = zero4();
-#pragma unroll
-            for (int ch = 0; ch < DCH; ++ch) {
-                const bool ok = 16 * ch + 4 * rg < d;
-                const f4 kf = lds4(hb + (16 * mt + i) * S + d + 16 * ch + 4 * rg, ok);
-                const f4 vf = lds4(hb + (16 * mt + i) * S + 2 * d + 16 * ch + 4 * rg, ok);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    s[mt] = mfma16(kf[j], qf[ch][j], s[mt]);
-                    dp[mt] = mfma16(vf[j], dof[ch][j], dp[mt]);
-                }
-            }
+            s[mt] = kfrag_mfma<D>(kfrag_load<D>(hb + (16 * mt + i) * S + d, rg), qf, zero4());
+            dp[mt] = kfrag_mfma<D>(kfrag_load<D>(hb + (16 * mt + i) * S + 2 * d, rg), dof, zero4());
         }
         float Dq = 0.f;
 #pragma unroll
@@ -524,29 +565,13 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float*
     f4 dk[DCH], dv[DCH];
     {
         const bool kvalid = 16 * qt + i < P;
-        f4 kf[DCH], vf[DCH];
-#pragma unroll
-        for (int ch = 0; ch < DCH; ++ch) {
-            const bool ok = 16 * ch + 4 * rg < d;
-            kf[ch] = lds4(hb + (16 * qt + i) * S + d + 16 * ch + 4 * rg, ok);
-            vf[ch] = lds4(hb + (16 * qt + i) * S + 2 * d + 16 * ch + 4 * rg, ok);
-        }
+        const KFrag<D> kf = kfrag_load<D>(hb + (16 * qt + i) * S + d, rg), vf = kfrag_load<D>(hb + (16 * qt + i) * S + 2 * d, rg);
 #pragma unroll
         for (int ct = 0; ct < DCH; ++ct) { dk[ct] = zero4(); dv[ct] = zero4(); }
 #pragma unroll
         for (int qm = 0; qm < PT; ++qm) {
-            f4 s = zero4(), dp = zero4();
-#pragma unroll
-            for (int ch = 0; ch < DCH; ++ch) {
-                const bool ok = 16 * ch + 4 * rg < d;
-                const f4 qf = lds4(hb + (16 * qm + i) * S + 16 * ch + 4 * rg, ok);
-                const f4 dof = lds4(db + (16 * qm + i) * Sd + 16 * ch + 4 * rg, ok);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    s = mfma16(qf[j], kf[ch][j], s);
-                    dp = mfma16(dof[j], vf[ch][j], dp);
-                }
-            }
+            const f4 s = kfrag_mfma<D>(kfrag_load<D>(hb + (16 * qm + i) * S, rg), kf, zero4());
+            const f4 dp = kfrag_mfma<D>(kfrag_load<D>(db + (16 * qm + i) * Sd, rg), vf, zero4());
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int query = 16 * qm + 4 * rg + r;       // accumulator row r; key = column i
