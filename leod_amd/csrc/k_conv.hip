@@ -124,12 +124,23 @@ __global__ __launch_bounds__(256, 3) void stem_u8_fwd_kernel(const uint8_t* __re
         const uint32_t* xb = reinterpret_cast<const uint32_t*>(x + (long)b * Cin * H * W);
         uint32_t* pd = reinterpret_cast<uint32_t*>(patch);
         const int total = Cin * PR * PD;
-        for (int e = tid; e < total; e += 256) {
-            const int c = e / (PR * PD), rem = e - c * (PR * PD), r = rem / PD, dw = rem - r * PD;
-            const int iy = iy0 + r, ix = ix0 + 4 * dw;
-            uint32_t v = 0;
-            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xb[(((long)c * H + iy) * W + ix) >> 2];
-            pd[e] = v;
+        // nine loads in flight per thread before the first LDS store (a load -> store loop pays one HBM round trip per iteration:
+        // 27 of them for the 20 x 19 x 18 dwords of a patch)
+        constexpr int U = 9;
+        for (int e0 = tid; e0 < total; e0 += 256 * U) {
+            uint32_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = min(e0 + 256 * u, total - 1);
+                const int c = e / (PR * PD), rem = e - c * (PR * PD), r = rem / PD, dw = rem - r * PD;
+                const int iy = iy0 + r, ix = ix0 + 4 * dw;
+                const bool in = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const uint32_t w = xb[in ? (((long)c * H + iy) * W + ix) >> 2 : 0];
+                v[u] = in ? w : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (e0 + 256 * u < total) pd[e0 + 256 * u] = v[u];
         }
         if (tid == 0) pd[total] = 0;
     }
