@@ -218,6 +218,121 @@ __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream4
     if (tile == nfull && (M & 15)) compute(f0, tile, std::false_type{});       // the ragged last tile, on whichever wave owns it
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same streaming scheme for the wide-input, 48-column-output contractions of stage 1 (K = 144 / 192 -> 48):
+//   MODE 0: out = res + gamma * (A W^T + bias)      W [48][K]   (fc2 + LayerScale + residual, maxvit.py:268-269)
+//   MODE 1: out = A W                                W [K][48]   (dgrad of fc1 / qkv)
+// One wave = one 16-row tile; 48 output columns = 12 float4 per row = 3 per lane (idx = 64 p + lane -> row idx / 12,
+// column idx % 12); the residual slice of the tile is loaded before its MFMAs.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KC, int MODE>
+__global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                  const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ res, float* __restrict__ out, int M) {
+    constexpr int K = 16 * KC, LD = K + 8, N = 48, LDO = 52;
+    __shared__ __attribute__((aligned(16))) float sW[N * LD];
+    __shared__ __attribute__((aligned(16))) float sO[4][16 * LDO];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    if (MODE == 0) {
+        for (int e = tid; e < N * (K / 4); e += 256) {
+            const int n = e / (K / 4), k4 = (e - n * (K / 4)) * 4;
+            *reinterpret_cast<f4*>(&sW[n * LD + k4]) = ld4(W + (long)n * K + k4);
+        }
+    } else {
+        for (int e = tid; e < K * (N / 4); e += 256) {
+            const int k = e / (N / 4), n4 = (e - k * (N / 4)) * 4;
+            const f4 w = ld4(W + (long)k * N + n4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sW[(n4 + j) * LD + k] = w[j];
+        }
+    }
+    int lr[3], c4[3];
+    f4 b4[3], g4[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int idx = 64 * p + lane;
+        lr[p] = idx / 12; c4[p] = idx - lr[p] * 12;
+        b4[p] = (MODE == 0 && bias) ? ld4(bias + 4 * c4[p]) : zero4();
+        g4[p] = (MODE == 0 && gamma) ? ld4(gamma + 4 * c4[p]) : f4{1.f, 1.f, 1.f, 1.f};
+    }
+    __syncthreads();
+    const int stride = gridDim.x * 4;
+    float* so = sO[wave];
+    struct Frag { f4 a[KC]; };
+    auto load = [&](Frag& f, int tile) {
+        const long row = min((long)tile * 16 + i, (long)M - 1);
+        const float* p = x + row * K + 4 * q;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) f.a[c] = ld4(p + 16 * c);
+    };
+    auto compute = [&](const Frag& f, int tile, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const long row0 = (long)tile * 16;
+        f4 r4[3];
+        if (MODE == 0) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const long row = FULL ? row0 + lr[p] : min(row0 + lr[p], (long)M - 1);
+                r4[p] = ld4(res + row * N + 4 * c4[p]);
+            }
+        }
+        f4 acc[3] = {zero4(), zero4(), zero4()};
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const f4 b = *reinterpret_cast<const f4*>(&sW[(16 * t + i) * LD + 16 * c + 4 * q]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t] = mfma16(f.a[c][j], b[j], acc[t]);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private tile: compiler ordering only (see above)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) so[(4 * q + r) * LDO + 16 * t + i] = acc[t][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            f4 v = *reinterpret_cast<const f4*>(&so[lr[p] * LDO + 4 * c4[p]]);
+            if (MODE == 0) v = r4[p] + g4[p] * (v + b4[p]);
+            if (FULL || row0 + lr[p] < M) *reinterpret_cast<f4*>(out + (row0 + lr[p]) * N + 4 * c4[p]) = v;
+        }
+    };
+    const int nfull = M / 16;
+    int tile = blockIdx.x * 4 + wave;
+    Frag f0, f1, f2;
+    load(f0, tile);
+    load(f1, tile + stride);
+    const std::true_type full{};
+    while (true) {
+        load(f2, tile + 2 * stride);
+        if (tile >= nfull) break;
+        compute(f0, tile, full); tile += stride;
+        load(f0, tile + 2 * stride);
+        if (tile >= nfull) { f0 = f1; break; }
+        compute(f1, tile, full); tile += stride;
+        load(f1, tile + 2 * stride);
+        if (tile >= nfull) { f0 = f2; break; }
+        compute(f2, tile, full); tile += stride;
+    }
+    if (tile == nfull && (M & 15)) compute(f0, tile, std::false_type{});
+}
+static inline bool use_rowstream_narrow(int M, int Kc, int Nout) {
+    static const int on = getenv("LEOD_ROWSTREAM") ? atoi(getenv("LEOD_ROWSTREAM")) : 2;
+    return on >= 2 && M >= 16384 && Nout == 48 && (Kc == 144 || Kc == 192);
+}
+template <int MODE>
+static int launch_rowstream_narrow(const float* x, const float* W, const float* bias, const float* gamma, const float* res,
+                                   float* out, int M, int Kc, hipStream_t s) {
+    const int grid = min(cdiv(cdiv(M, 16), 4), 256 * 2);
+    if (Kc == 192) hipLaunchKernelGGL((rowstream_narrow_kernel<12, MODE>), dim3(grid), dim3(256), 0, s, x, W, bias, gamma, res, out, M);
+    else hipLaunchKernelGGL((rowstream_narrow_kernel<9, MODE>), dim3(grid), dim3(256), 0, s, x, W, bias, gamma, res, out, M);
+    return leod_launch_status();
+}
+
 // (K, N) -> column tiles per slab; 0 = shape not covered.  K = 48: the whole N (9 / 12 tiles); K = 96: slabs of 9 (N = 288) or
 // 8 (N = 384) tiles, so that weights + wave tiles of two workgroups fit the 160 KB of a CU
 static inline int rowstream_slab(int M, int N, int K) {
@@ -290,6 +405,7 @@ LEOD_API int leod_linear_lsres_fwd(const float* a, const float* W, const float* 
     EpLsRes ep{out, tout, res, bias, gamma, (long)N, N};
     const int nt = pick_nt(N);
     int rc = LEOD_OK;
+    if (!tout && use_rowstream_narrow(M, K, N)) return launch_rowstream_narrow<0>(a, W, bias, gamma, res, out, M, K, stream);
     if (use_gemm_lds(M, cdiv(N, 16 * nt))) {
         DISPATCH_NT(nt, { BLRows bl{W, (long)K, N, NT}; rc = launch_gemm_lds<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
         return rc;
@@ -330,6 +446,8 @@ LEOD_API int leod_linear_dgrad(const float* dy, long lddy, const float* kscale, 
     int rc = LEOD_OK;
     // contraction over N in {48, 96}, K in {192, 384} output columns (dgrad of fc2, optionally through GELU): streaming kernel
     if (!dx2 && !colsum && !accumulate && lddy == N && lddx == K && nsplit <= 0) {
+        if (!kscale && !aux_u && use_rowstream_narrow(M, N, K))
+            return launch_rowstream_narrow<1>(dy, W, nullptr, nullptr, nullptr, dx, M, N, stream);
         if (const int slab = rowstream_slab(M, K, N)) {
             if (N == 48 && slab == 12) return launch_rowstream_dgrad<3, 12>(dy, lddy, kscale, W, aux_u, dx, M, K, stream);
             if (N == 96 && slab == 8) return launch_rowstream_dgrad<6, 8>(dy, lddy, kscale, W, aux_u, dx, M, K, stream);

@@ -74,13 +74,19 @@ def test_ln_linear_fwd(ops, M, N, K, ln, act):
 
 
 @pytest.mark.parametrize('M,N,K', [(200, 48, 48), (129, 384, 1536), (64, 32, 128),
-                                   (30000, 48, 192), (17000, 384, 1536), (65000, 48, 48), (9001, 64, 256)])
+                                   (30000, 48, 192), (17000, 384, 1536), (65000, 48, 48), (9001, 64, 256),
+                                   (40005, 48, 144)])
 def test_linear_lsres_fwd(ops, M, N, K):
     a, W, b, g, res = rnd((M, K), 1), rnd((N, K), 2, 0.2), rnd((N,), 3, 0.1), rnd((N,), 4), rnd((M, N), 5)
     t = F.linear(a, W, b)
     out, tt = ops.linear_lsres_fwd(a.to(DEV), W.to(DEV), b.to(DEV), g.to(DEV), res.to(DEV))
     close(tt, t)
     close(out, res + g * t)
+    # the training step does not keep t (LayerScale gradient from the un-scaled wgrad): K = 144 / 192 -> 48 then runs on the
+    # row-streaming kernel
+    out2, none = ops.linear_lsres_fwd(a.to(DEV), W.to(DEV), b.to(DEV), g.to(DEV), res.to(DEV), want_t=False)
+    assert none is None
+    close(out2, res + g * t)
 
 
 def _attn_ref(qkv, heads, part, window):
@@ -153,7 +159,9 @@ def test_convlstm(ops, M, C, state):
                                    (30000, 192, 48), (30000, 48, 192), (20000, 288, 96), (65000, 48, 48),
                                    (9000, 1536, 384), (12345, 144, 48), (16000, 128, 64),
                                    # dgrad of fc2 on the row-streaming kernel (contraction 48 / 96, ragged last tile)
-                                   (40007, 48, 192), (20000, 96, 384)])
+                                   (40007, 48, 192), (20000, 96, 384),
+                                   # plain dgrad 192 / 144 -> 48 columns on the narrow row-streaming kernel
+                                   (40009, 192, 48), (20011, 144, 48)])
 def test_linear_backward(ops, M, N, K):
     x = rnd((M, K), 1).requires_grad_(True)
     W, b = rnd((N, K), 2, 0.2).requires_grad_(True), rnd((N,), 3).requires_grad_(True)
@@ -171,6 +179,7 @@ def test_linear_backward(ops, M, N, K):
     uu = rnd((M, K), 8)
     dn = ops.linear_dgrad(dy.to(DEV), W.detach().to(DEV), kscale=ks.to(DEV))
     close(dn, (dy * ks) @ W.detach(), rtol=5e-5, atol=5e-6, what='dgrad')
+    close(ops.linear_dgrad(dy.to(DEV), W.detach().to(DEV)), dy @ W.detach(), rtol=5e-5, atol=5e-6, what='plain dgrad')
     cs = torch.zeros((K,), device=DEV)
     du = ops.linear_dgrad(dy.to(DEV), W.detach().to(DEV), aux_u=uu.to(DEV), colsum=cs)
     uu2 = uu.clone().requires_grad_(True)

@@ -62,8 +62,8 @@ def main():
         cases = [
             ('ln_qkv_fwd', lambda: ops.ln_linear_fwd(x, lw, lb, Wqkv, bqkv, want_stats=True), 4 * M * 4 * C, 2 * M * C * 3 * C),
             ('ln_fc1_gelu_fwd', lambda: ops.ln_linear_fwd(x, lw, lb, W1, b1, want_act=True, want_stats=True), 4 * M * 9 * C, 2 * M * C * 4 * C),
-            ('proj_lsres_fwd', lambda: ops.linear_lsres_fwd(x, Wp, bp, g, x), 4 * M * 4 * C, 2 * M * C * C),
-            ('fc2_lsres_fwd', lambda: ops.linear_lsres_fwd(u, W2, b2, g, x), 4 * M * 7 * C, 2 * M * C * 4 * C),
+            ('proj_lsres_fwd', lambda: ops.linear_lsres_fwd(x, Wp, bp, g, x, want_t=False), 4 * M * 3 * C, 2 * M * C * C),
+            ('fc2_lsres_fwd', lambda: ops.linear_lsres_fwd(u, W2, b2, g, x, want_t=False), 4 * M * 6 * C, 2 * M * C * 4 * C),
             ('attn_fwd_window', lambda: ops.partition_attn_fwd(qkv4, heads, (8, 10), True, want_lse=True), 4 * M * 4 * C, 4 * M * 80 * C),
             ('attn_fwd_grid', lambda: ops.partition_attn_fwd(qkv4, heads, (8, 10), False, want_lse=True), 4 * M * 4 * C, 4 * M * 80 * C),
             ('attn_bwd_window', lambda: ops.partition_attn_bwd(qkv4, o, lse, heads, (8, 10), True), 4 * M * 8 * C, 10 * M * 80 * C),
