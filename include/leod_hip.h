@@ -176,6 +176,14 @@ int leod_voxelize_u8(const long* x, const long* y, const long* pol, const long* 
 int leod_augment_u8(const unsigned char* src, unsigned char* dst, const int* params, int T, int B, int C, int H, int W,
                     leod_stream_t stream);
 
+/* dgrad of a Linear fused with the LayerNorm backward of its producer (x -> norm -> Linear, maxvit.py:267-269,110-118):
+ * dx[M,K] = LN-backward(dy[M,N] @ W[N,K]) (+ dres), dgamma[K] += sum dn*xhat, dbeta[K] += sum dn, with x[M,K] the LayerNorm
+ * input and stats[M,2] its saved (mean, rstd).  Stage-1 shapes only (K = 48, N = 144 / 192, M >= 16384): returns -3
+ * (unsupported shape) otherwise and the caller runs leod_linear_dgrad + leod_layernorm_bwd. */
+int leod_linear_dgrad_lnbwd(const float* dy, const float* W, const float* x, const float* stats, const float* ln_w,
+                            const float* dres, float* dx, float* dgamma, float* dbeta, int M, int N, int K,
+                            leod_stream_t stream);
+
 /* ---- host-side C++ of the path (no GPU involved) ------------------------------------------------------------------
  * Tracking post-filter of the pseudo-label loop: linear-velocity tracklets, confidence-ordered greedy IoU association,
  * short-tracklet removal and in-painting of missed detections.  Replaces modules/tracking/linear.py:10-292,

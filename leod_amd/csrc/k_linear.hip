@@ -222,13 +222,21 @@ __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream4
 // The same streaming scheme for the wide-input, 48-column-output contractions of stage 1 (K = 144 / 192 -> 48):
 //   MODE 0: out = res + gamma * (A W^T + bias)      W [48][K]   (fc2 + LayerScale + residual, maxvit.py:268-269)
 //   MODE 1: out = A W                                W [K][48]   (dgrad of fc1 / qkv)
+//   MODE 2: MODE 1 followed by the LayerNorm backward of the producer in the same epilogue (maxvit.py:267-269: x -> norm ->
+//           Linear): dn = A W never leaves the registers; in accumulator layout a lane holds columns 16t + i of rows 4q + r, so
+//           the two row means are one 16-lane reduction each, dx = rstd (dn w - mean(dn w) - xhat mean(dn w xhat)) + dres goes
+//           through the transposition tile, and dgamma / dbeta accumulate per lane over all tiles (one atomic per column and
+//           wave at the end).  xin / stats / dres of the tile are loaded before its MFMAs.
 // One wave = one 16-row tile; 48 output columns = 12 float4 per row = 3 per lane (idx = 64 p + lane -> row idx / 12,
 // column idx % 12); the residual slice of the tile is loaded before its MFMAs.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int KC, int MODE>
 __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                                   const float* __restrict__ bias, const float* __restrict__ gamma,
-                                                                  const float* __restrict__ res, float* __restrict__ out, int M) {
+                                                                  const float* __restrict__ res, float* __restrict__ out, int M,
+                                                                  const float* __restrict__ xin = nullptr,
+                                                                  const float* __restrict__ stats = nullptr,
+                                                                  float* __restrict__ dgamma = nullptr, float* __restrict__ dbeta = nullptr) {
     constexpr int K = 16 * KC, LD = K + 8, N = 48, LDO = 52;
     __shared__ __attribute__((aligned(16))) float sW[N * LD];
     __shared__ __attribute__((aligned(16))) float sO[4][16 * LDO];
@@ -256,6 +264,11 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
         b4[p] = (MODE == 0 && bias) ? ld4(bias + 4 * c4[p]) : zero4();
         g4[p] = (MODE == 0 && gamma) ? ld4(gamma + 4 * c4[p]) : f4{1.f, 1.f, 1.f, 1.f};
     }
+    float lnw[3] = {1.f, 1.f, 1.f}, agam[3] = {0.f, 0.f, 0.f}, abet[3] = {0.f, 0.f, 0.f};
+    if (MODE == 2) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) lnw[t] = gamma[16 * t + i];                 // LayerNorm weight of column 16t + i
+    }
     __syncthreads();
     const int stride = gridDim.x * 4;
     float* so = sO[wave];
@@ -270,11 +283,22 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
         constexpr bool FULL = decltype(full_tag)::value;
         const long row0 = (long)tile * 16;
         f4 r4[3];
-        if (MODE == 0) {
+        if (MODE == 0 || (MODE == 2 && res)) {
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 const long row = FULL ? row0 + lr[p] : min(row0 + lr[p], (long)M - 1);
                 r4[p] = ld4(res + row * N + 4 * c4[p]);
+            }
+        }
+        float xi[3][4], mean[4], rstd[4];
+        if (MODE == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long row = FULL ? row0 + 4 * q + r : min(row0 + 4 * q + r, (long)M - 1);
+                const float2 st = *reinterpret_cast<const float2*>(stats + 2 * row);
+                mean[r] = st.x; rstd[r] = st.y;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) xi[t][r] = xin[row * N + 16 * t + i];
             }
         }
         f4 acc[3] = {zero4(), zero4(), zero4()};
@@ -286,6 +310,25 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[t] = mfma16(f.a[c][j], b[j], acc[t]);
             }
+        if (MODE == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool live = FULL || row0 + 4 * q + r < M;
+                float s1 = 0.f, s2 = 0.f, xh[3], gw[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const float dn = live ? acc[t][r] : 0.f;
+                    xh[t] = (xi[t][r] - mean[r]) * rstd[r];
+                    gw[t] = dn * lnw[t];
+                    agam[t] += dn * xh[t]; abet[t] += dn;
+                    s1 += gw[t]; s2 += gw[t] * xh[t];
+                }
+                s1 = row16_sum(s1) * (1.0f / N);
+                s2 = row16_sum(s2) * (1.0f / N);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc[t][r] = (gw[t] - s1 - xh[t] * s2) * rstd[r];
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private tile: compiler ordering only (see above)
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -298,6 +341,7 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
         for (int p = 0; p < 3; ++p) {
             f4 v = *reinterpret_cast<const f4*>(&so[lr[p] * LDO + 4 * c4[p]]);
             if (MODE == 0) v = r4[p] + g4[p] * (v + b4[p]);
+            if (MODE == 2 && res) v = v + r4[p];
             if (FULL || row0 + lr[p] < M) *reinterpret_cast<f4*>(out + (row0 + lr[p]) * N + 4 * c4[p]) = v;
         }
     };
@@ -319,6 +363,15 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
         compute(f2, tile, full); tile += stride;
     }
     if (tile == nfull && (M & 15)) compute(f0, tile, std::false_type{});
+    if (MODE == 2) {                                         // column sums of this wave: over the 4 row groups, then one atomic
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            float a = agam[t], b = abet[t];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+            if (q == 0) { atomicAdd(dgamma + 16 * t + i, a); atomicAdd(dbeta + 16 * t + i, b); }
+        }
+    }
 }
 static inline bool use_rowstream_narrow(int M, int Kc, int Nout) {
     static const int on = getenv("LEOD_ROWSTREAM") ? atoi(getenv("LEOD_ROWSTREAM")) : 2;
@@ -474,4 +527,19 @@ LEOD_API int leod_linear_wgrad(const float* dy, long lddy, const float* x, long 
     if (K >= 64) return launch_wgrad16<1, 4>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);
     if (N >= 64) return launch_wgrad16<4, 1>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);
     return launch_wgrad16<1, 1>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);
+}
+
+// dx[M,K] = LayerNorm backward of (dy[M,N] @ W[N,K]) in one pass: dn = dy W stays in registers, dx = rstd (dn w - mean(dn w) -
+// xhat mean(dn w xhat)) (+ dres), dgamma[K] += sum_m dn xhat, dbeta[K] += sum_m dn   (x[M,K] = the LayerNorm input, stats[M,2] =
+// its saved (mean, rstd)).  Covers K = 48 with N = 144 / 192 and M >= 16384 (stage 1); LEOD_ERR_UNSUPPORTED otherwise -- the
+// caller then runs leod_linear_dgrad + leod_layernorm_bwd.
+LEOD_API int leod_linear_dgrad_lnbwd(const float* dy, const float* W, const float* x, const float* stats, const float* ln_w,
+                                     const float* dres, float* dx, float* dgamma, float* dbeta, int M, int N, int K,
+                                     hipStream_t stream) {
+    if (!dy || !W || !x || !stats || !ln_w || !dx || !dgamma || !dbeta) return LEOD_ERR_ARG;
+    if (!use_rowstream_narrow(M, N, K)) return LEOD_ERR_UNSUPPORTED;
+    const int grid = min(cdiv(cdiv(M, 16), 4), 256 * 2);
+    if (N == 192) hipLaunchKernelGGL((rowstream_narrow_kernel<12, 2>), dim3(grid), dim3(256), 0, stream, dy, W, nullptr, ln_w, dres, dx, M, x, stats, dgamma, dbeta);
+    else hipLaunchKernelGGL((rowstream_narrow_kernel<9, 2>), dim3(grid), dim3(256), 0, stream, dy, W, nullptr, ln_w, dres, dx, M, x, stats, dgamma, dbeta);
+    return leod_launch_status();
 }

@@ -191,8 +191,7 @@ class AttnBlockFn(Function):
         dz = _cont(dz)
         # ---- dgrad chain (critical path); LayerScale is folded into the dgrad loader (dz * gamma) -------------------------
         du = ops.linear_dgrad(dz, fc2_w, kscale=g2, aux_u=u)
-        dn2 = ops.linear_dgrad(du, fc1_w)
-        dy = ops.layernorm_bwd(dn2, y, st2, n2w, dz, grad_buf(mod.norm2.weight), grad_buf(mod.norm2.bias))
+        dy = ops.linear_dgrad_ln_bwd(du, fc1_w, y, st2, n2w, dz, grad_buf(mod.norm2.weight), grad_buf(mod.norm2.bias))
         do = ops.linear_dgrad(dy, proj_w, kscale=g1)
         dqkv = ops.partition_attn_bwd(qkv, do, lse, heads, part, window)
         # ---- weight gradients: off the critical path (side stream when the engine enables it) ------
@@ -207,8 +206,7 @@ class AttnBlockFn(Function):
             else:
                 ops.linear_wgrad(dqkv, x, grad_buf(sa.qkv.weight), grad_buf(sa.qkv.bias))
         if n1w is not None:
-            dn1 = ops.linear_dgrad(dqkv, qkv_w)
-            dx = ops.layernorm_bwd(dn1, x, st1, n1w, dy, grad_buf(mod.norm1.weight), grad_buf(mod.norm1.bias))
+            dx = ops.linear_dgrad_ln_bwd(dqkv, qkv_w, x, st1, n1w, dy, grad_buf(mod.norm1.weight), grad_buf(mod.norm1.bias))
         else:
             if WgradSide.active:                                            # dy is still being read on the side stream
                 dx = dy + ops.linear_dgrad(dqkv, qkv_w)

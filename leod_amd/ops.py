@@ -206,6 +206,21 @@ def layernorm_bwd(dn, x, stats, w, dres, dw, db, eps=1e-5):
     return dx
 
 
+def linear_dgrad_ln_bwd(dy, W, x, stats, ln_w, dres, dw, db, eps=1e-5):
+    """dx of  x -> LayerNorm -> Linear(W)  from dy: LN-backward(dy @ W) + dres; dw / db accumulate the LayerNorm weight / bias
+    gradients.  One fused launch for the stage-1 shapes, leod_linear_dgrad + leod_layernorm_bwd otherwise."""
+    for t, n in ((dy, 'dy'), (W, 'W'), (x, 'x'), (stats, 'stats'), (ln_w, 'ln_w'), (dres, 'dres'), (dw, 'dw'), (db, 'db')):
+        _ck(t, name=n)
+    N, K = W.shape
+    M = dy.numel() // N
+    dx = _empty(x.shape, x)
+    rc = _l().leod_linear_dgrad_lnbwd(_p(dy), _p(W), _p(x), _p(stats), _p(ln_w), _p(dres), _p(dx), _p(dw), _p(db), M, N, K, _stream())
+    if rc == -3:                                            # shape outside the fused kernel's coverage
+        return layernorm_bwd(linear_dgrad(dy, W), x, stats, ln_w, dres, dw, db, eps)
+    check(rc, 'linear_dgrad_lnbwd')
+    return dx
+
+
 def layerscale_bwd(dz, t, gamma, dgamma):
     for tt, n in ((dz, 'dz'), (t, 't'), (gamma, 'gamma'), (dgamma, 'dgamma')):
         _ck(tt, name=n)

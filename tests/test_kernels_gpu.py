@@ -629,3 +629,23 @@ def test_augment_u8_time_flip():
         assert torch.equal(out[:, b], torch.flip(spatial[:, b], dims=[0, 1]))
     assert torch.equal(out[:, 1], spatial[:, 1])
     assert torch.equal(spatial[:, 0], ev[:, 0])
+
+
+@pytest.mark.parametrize('M,N,K,with_res', [(40009, 192, 48, True), (20011, 144, 48, True), (33000, 192, 48, False),
+                                            (5000, 192, 48, True), (20000, 288, 96, True)])
+def test_linear_dgrad_ln_bwd(ops, M, N, K, with_res):
+    """x -> LayerNorm -> Linear: gradient wrt x from dy in one launch (stage-1 shapes: dn = dy W stays in registers, the
+    LayerNorm backward runs in the epilogue of the row-streaming dgrad) or through the two-kernel fallback -- same result
+    as autograd either way, including the LayerNorm weight / bias gradients."""
+    x = rnd((M, K), 1).requires_grad_(True)
+    lw, lb = (1 + 0.2 * rnd((K,), 2)).requires_grad_(True), (0.1 * rnd((K,), 3)).requires_grad_(True)
+    W = rnd((N, K), 4, 0.2)
+    dy, dres = rnd((M, N), 5), rnd((M, K), 6)
+    F.linear(F.layer_norm(x, (K,), lw, lb, 1e-5), W).backward(dy)
+    _, st = ops.layernorm_fwd(x.detach().to(DEV), lw.detach().to(DEV), lb.detach().to(DEV), want_stats=True)
+    dw, db = torch.zeros(K, device=DEV), torch.zeros(K, device=DEV)
+    dx = ops.linear_dgrad_ln_bwd(dy.to(DEV), W.to(DEV), x.detach().to(DEV), st, lw.detach().to(DEV),
+                                 dres.to(DEV) if with_res else None, dw, db)
+    close(dx, x.grad + (dres if with_res else 0), rtol=1e-4, atol=1e-5, what='dx')
+    close(dw, lw.grad, rtol=3e-4, atol=1e-4, what='d ln weight')
+    close(db, lb.grad, rtol=3e-4, atol=1e-4, what='d ln bias')
