@@ -391,8 +391,9 @@ static int launch_rowstream_narrow(const float* x, const float* W, const float* 
 static inline int rowstream_slab(int M, int N, int K) {
     static const int on = getenv("LEOD_ROWSTREAM") ? atoi(getenv("LEOD_ROWSTREAM")) : 2;     // 0 off, 1 stage 1 only, 2 stages 1 + 2
     if (!on || M < 16384) return 0;
-    if (K == 48 && (N == 144 || N == 192)) return N / 16;
-    if (K == 96 && on >= 2) return N == 288 ? 9 : (N == 384 ? 8 : 0);
+    if (K == 48 && (N == 144 || N == 192)) return N / 16;                    // RVT-S stage 1
+    if (K == 96 && on >= 2) return N == 288 ? 9 : (N == 384 ? 8 : 0);       // RVT-S stage 2
+    if (K == 64 && on >= 2) return N == 192 ? 12 : (N == 256 ? 8 : 0);      // RVT-B stage 1 (qkv whole, fc1 in two slabs)
     return 0;
 }
 template <int KC, int NTT, bool ACT>
@@ -438,7 +439,7 @@ LEOD_API int leod_ln_linear_fwd(const float* x, long ldx, const float* ln_w, con
         if (K == 16 * KCV && slab == NTTV)                                                                                         \
             return out_act ? launch_rowstream48<KCV, NTTV, true>(x, ldx, st, ln_w, ln_b, eps, W, bias, out, out_act, M, N, stream)   \
                            : launch_rowstream48<KCV, NTTV, false>(x, ldx, st, ln_w, ln_b, eps, W, bias, out, nullptr, M, N, stream);
-        RS_CASE(3, 9) RS_CASE(3, 12) RS_CASE(6, 9) RS_CASE(6, 8)
+        RS_CASE(3, 9) RS_CASE(3, 12) RS_CASE(6, 9) RS_CASE(6, 8) RS_CASE(4, 12) RS_CASE(4, 8)
 #undef RS_CASE
     }
     if (use_gemm_lds(M, cdiv(N, 16 * nt)) && (!ln_w || stats_out)) {
@@ -504,6 +505,7 @@ LEOD_API int leod_linear_dgrad(const float* dy, long lddy, const float* kscale, 
         if (const int slab = rowstream_slab(M, K, N)) {
             if (N == 48 && slab == 12) return launch_rowstream_dgrad<3, 12>(dy, lddy, kscale, W, aux_u, dx, M, K, stream);
             if (N == 96 && slab == 8) return launch_rowstream_dgrad<6, 8>(dy, lddy, kscale, W, aux_u, dx, M, K, stream);
+            if (N == 64 && slab == 8) return launch_rowstream_dgrad<4, 8>(dy, lddy, kscale, W, aux_u, dx, M, K, stream);
         }
     }
     if (use_gemm_lds(M, cdiv(K, 16 * nt))) {

@@ -57,7 +57,9 @@ def close(a, b, rtol=2e-5, atol=2e-6, what=''):
                                           (70001, 144, 48, True, False), (50000, 192, 48, True, True),
                                           (16390, 144, 48, False, True), (300000, 192, 48, False, False),
                                           # K = 96 in column slabs (stage 2: N = 288 -> 2 x 144, N = 384 -> 3 x 128)
-                                          (40003, 288, 96, True, False), (30000, 384, 96, True, True), (20000, 384, 96, False, False)])
+                                          (40003, 288, 96, True, False), (30000, 384, 96, True, True), (20000, 384, 96, False, False),
+                                          # K = 64 (RVT-base stage 1): N = 192 whole, N = 256 in two slabs
+                                          (30001, 192, 64, True, False), (25000, 256, 64, True, True)])
 def test_ln_linear_fwd(ops, M, N, K, ln, act):
     x, W, b = rnd((M, K), 1), rnd((N, K), 2, 0.2), rnd((N,), 3, 0.1)
     lw, lb = 1 + 0.2 * rnd((K,), 4), 0.1 * rnd((K,), 5)
@@ -161,7 +163,8 @@ def test_convlstm(ops, M, C, state):
                                    # dgrad of fc2 on the row-streaming kernel (contraction 48 / 96, ragged last tile)
                                    (40007, 48, 192), (20000, 96, 384),
                                    # plain dgrad 192 / 144 -> 48 columns on the narrow row-streaming kernel
-                                   (40009, 192, 48), (20011, 144, 48)])
+                                   (40009, 192, 48), (20011, 144, 48),
+                                   (24001, 64, 256)])                # RVT-base stage 1: dgrad of fc2 (contraction 64)
 def test_linear_backward(ops, M, N, K):
     x = rnd((M, K), 1).requires_grad_(True)
     W, b = rnd((N, K), 2, 0.2).requires_grad_(True), rnd((N,), 3).requires_grad_(True)
