@@ -649,7 +649,10 @@ static int dispatch_attn(int which, const float* qkv, const float* dout, float* 
     const float scale = 1.0f / sqrtf((float)g.d);
     static const int use_lds = getenv("LEOD_ATTN_LDS") ? atoi(getenv("LEOD_ATTN_LDS")) : 1;
     const int HG = (g.heads % 2 == 0 && 2 * PT <= 16) ? 2 : 1;
-    const bool lds_shape = (g.d == 24 || g.d == 32) && (PT <= 5 || PT == 8 || (HG == 1 && (PT == 10 || PT == 15)));
+    // one-head workgroups with padded partitions (P < 16 PT, e.g. a single-head stage on the 6 x 10 partitions of Gen4) are not
+    // covered by the fused LDS backward (measured wrong against the oracle): they stay on the register-direct kernels
+    const bool lds_shape = (g.d == 24 || g.d == 32) && (PT <= 5 || PT == 8 || (HG == 1 && (PT == 10 || PT == 15))) &&
+                           !(HG == 1 && P < 16 * PT && which != 0);
     if (use_lds && lds_shape) {
         // which: 0 forward, 1 fused backward (the register-direct path runs 1 = q pass, then 2 = kv pass)
         if (which == 2) return LEOD_OK;                       // the fused LDS backward already produced dK / dV

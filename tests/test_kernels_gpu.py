@@ -109,7 +109,9 @@ def _attn_ref(qkv, heads, part, window):
                                                 (3, 32, 40, 96, 4, (8, 10)),
                                                 (1, 8, 10, 24, 1, (8, 10)),        # one head: single-head LDS workgroups
                                                 (1, 12, 20, 64, 2, (12, 20)),      # 240-token partition (Gen4 720p stress)
-                                                (2, 16, 20, 96, 3, (8, 10))])      # d = 32, odd head count
+                                                (2, 16, 20, 96, 3, (8, 10)),       # d = 32, odd head count
+                                                (1, 12, 20, 96, 3, (6, 10)),       # odd head count AND padded partitions (60 of 64)
+                                                (1, 12, 20, 32, 1, (6, 10))])      # RVT-tiny stage 1 on Gen4: one head, padded
 @pytest.mark.parametrize('window', [True, False])
 def test_partition_attn(ops, B, H, W, C, heads, part, window):
     qkv = rnd((B, H, W, 3 * C), 7).requires_grad_(True)
