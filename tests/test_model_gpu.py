@@ -218,7 +218,7 @@ def _build_gen4(size, full_res, seed, train=True):
     return det, sd, cfg
 
 
-@pytest.mark.parametrize('size,full_res,T', [('base', False, 2), ('base', True, 2), ('small', True, 1)])
+@pytest.mark.parametrize('size,full_res,T', [('base', False, 2), ('base', True, 2), ('small', True, 1), ('tiny', False, 2)])
 def test_gen4_geometries_fwd_bwd(gpu, size, full_res, T):
     """BASELINE configs[3] geometry as a parity case: RVT-base / RVT-small on Gen4 frames, downsampled (384x640, 60-token
     partitions) and at the full 1 Mpx resolution (768x1280, 240-token partitions, stage-1 map 192x320), bs 1, carried LSTM
@@ -228,7 +228,7 @@ def test_gen4_geometries_fwd_bwd(gpu, size, full_res, T):
     part = tuple(cfg.model.backbone.stage.attention.partition_size)
     hw = (720, 1280) if full_res else (360, 640)
     assert in_hw == ((768, 1280) if full_res else (384, 640)) and part == ((12, 20) if full_res else (6, 10))
-    E, dh = {'base': (64, 32), 'small': (48, 24)}[size]
+    E, dh = {'base': (64, 32), 'small': (48, 24), 'tiny': (32, 32)}[size]      # tiny: ONE head in stage 1 (padded 6 x 10 partitions)
     ocfg = ot.model_cfg(E, dh, 0.67 if size == 'base' else 0.33, part, num_classes=3, in_res_hw=in_hw)
     ev = synth_events(T, 1, 20, hw[0], hw[1], seed=31, as_uint8=True)
     states = None
