@@ -211,10 +211,21 @@ class ObjectLabels:
 
     @staticmethod
     def pad_labels(obj_label_list: Sequence[Union['ObjectLabels', th.Tensor]], N: int, format_: str = 'yolox') -> th.Tensor:
+        """[len(list), N, 7] zero-padded loss targets (labels.py:543-570).  All-``ObjectLabels`` input (the training step)
+        is converted with one concatenation + one scatter instead of ~12 tiny tensor ops per frame."""
         assert format_ == 'yolox'
         first = obj_label_list[0]
         dev = first.device
         out = th.zeros((len(obj_label_list), N, 7), dtype=th.float32, device=dev)
+        if all(isinstance(l, ObjectLabels) for l in obj_label_list):
+            lens = [len(l) for l in obj_label_list]
+            assert max(lens) <= N
+            o = th.cat([l.object_labels for l in obj_label_list], dim=0)
+            rows = th.stack([o[:, 5], o[:, 1] + 0.5 * o[:, 3], o[:, 2] + 0.5 * o[:, 4], o[:, 3], o[:, 4], o[:, 7], o[:, 6]], dim=1)
+            frame = th.repeat_interleave(th.arange(len(lens)), th.tensor(lens)).to(dev)
+            slot = th.cat([th.arange(n) for n in lens]).to(dev)
+            out[frame, slot] = rows.to(th.float32)
+            return out
         for i, l in enumerate(obj_label_list):
             t = l.get_labels_as_tensors('yolox') if isinstance(l, ObjectLabels) else l
             out[i, :len(t)] = t

@@ -1,10 +1,11 @@
-"""Native training / pseudo-labelling drivers for the LEOD hot path on MI355X (what Lightning's
-Trainer does for the reference, train.py:228-251, minus logging/checkpoint UI).
+"""Tensor-level drivers of the LEOD hot path on MI355X, below the reference-shaped API of ``leod_amd.modules``
+(``Module.training_step`` + ``leod_amd.optim.FlatAdamW`` is the product training path; it runs the same schedule and kernels).
 
-``TrainEngine.step(ev_seq, labels, is_first)`` = one full training step with inputs already on the device:
-reset LSTM rows -> T backbone timesteps -> head + SimOTA + loss on labelled frames -> backward (HIP wgrad
-kernels accumulate into the flat gradient buffer) -> RCCL all-reduce -> fused value-clip + AdamW ->
-OneCycle LR -> detach states.  No host synchronisation happens inside a step.
+``TrainEngine.step(ev_seq, labels, label_tb, is_first)`` = one full training step on device tensors (no label containers,
+no loader dictionaries): reset LSTM rows -> stage-major time-batched backbone over T frames -> head + SimOTA + loss on the
+labelled frames -> backward (HIP wgrad kernels accumulate into the flat gradient buffer) -> RCCL all-reduce -> fused
+value-clip + AdamW -> OneCycle LR -> detach states.  No host synchronisation inside a step, so the whole step can also be
+captured into ONE hipGraph (``capture`` / ``step_graph``).  Used by the kernel-level parity tests and the graph replay.
 """
 import os
 from typing import Dict, List, Optional, Sequence
@@ -33,18 +34,11 @@ class TrainEngine:
         self.last_losses = None
         self._idx_cache = {}
         self._graph = None
-        self._streams = None
         self._capturing = False
-        self._multi_last = False
         # weight-gradient kernels on a side HIP stream (eager launches): they feed nothing until the optimiser, so they
         # fill the device while the sequential parts of the backward pass (BPTT of the ConvLSTMs: 2 small launches per
         # timestep) run on the launch stream.  45.4 -> 43.6 ms per step; not used inside hipGraph capture.
         self.wgrad_side = os.environ.get('LEOD_WGRAD_STREAM', '1') == '1'
-        # stage wavefront over HIP streams (eager launches only: ROCm 7.2's hipStreamEndCapture crashes on the captured
-        # multi-stream backward, so capture() always records the single-stream schedule)
-        self.n_streams = int(os.environ.get('LEOD_STREAMS', '4'))
-        # 'batched': stage-major, all T timesteps of a stage per launch (default); 'wavefront': timestep-major loop
-        self.schedule = os.environ.get('LEOD_SCHEDULE', 'batched')
 
     def current_lr(self):
         h = self.hp
@@ -64,28 +58,12 @@ class TrainEngine:
                      is_first: Optional[torch.Tensor] = None, states=None):
         """ev_seq [T,B,C,H,W] uint8/fp32 on the device; ``label_tb[t]`` = batch indices with labels at timestep t (host
         lists, static); labels [B',N,7] yolox targets in (t, b) order, already on the device."""
-        T = ev_seq.shape[0]
         self._reset_rows(states, is_first)
-        if self.schedule == 'batched':
-            return self._forward_loss_batched(ev_seq, labels, label_tb, states)
-        sel: Dict[int, List[torch.Tensor]] = {}
-        for t, feats, states in self._backbone_wavefront(ev_seq, states):
-            idx = label_tb[t]
-            if len(idx):
-                for k in self.det.fpn.in_features:
-                    v = feats[k].permute(0, 2, 3, 1)    # NHWC view of the channels-last map
-                    sel.setdefault(k, []).append(v if len(idx) == v.shape[0] else v[self._index(idx, v.device)])
-        feats = {k: torch.cat(v, 0).permute(0, 3, 1, 2) for k, v in sel.items()}
-        preds, losses = self.det.forward_detect(feats, targets=labels)
-        return preds, losses, [(h.detach(), c.detach()) for h, c in states]
-
-    def _forward_loss_batched(self, ev_seq, labels, label_tb, states):
-        """Stage-major, time-batched schedule (default): every stage processes all T timesteps of the batch in one go
-        (``RNNDetector.forward_sequence``) -- the per-frame layers see T*B samples per launch, only the ConvLSTM
-        recurrence is unrolled over t.  Same arithmetic as the per-timestep loop of modules/detection.py:188-226 (no
-        layer in front of the LSTM mixes samples), ~6x fewer and ~21x larger kernel launches."""
+        # Stage-major, time-batched schedule: every stage processes all T timesteps of the batch in one go
+        # (``RNNDetector.forward_sequence``) -- the per-frame layers see T*B samples per launch, only the ConvLSTM
+        # recurrence is unrolled over t.  Same arithmetic as the per-timestep loop of modules/detection.py:188-226 (no
+        # layer in front of the LSTM mixes samples), ~6x fewer and ~21x larger kernel launches.
         T, B = ev_seq.shape[:2]
-        self._multi_last = False
         feats_all, states = self.det.backbone.forward_sequence(ev_seq, states)
         rows = tuple(t * B + b for t in range(T) for b in label_tb[t])
         idx = self._index(rows, ev_seq.device)
@@ -95,52 +73,6 @@ class TrainEngine:
             feats[k] = v.index_select(0, idx).permute(0, 3, 1, 2)
         preds, losses = self.det.forward_detect(feats, targets=labels)
         return preds, losses, [(h.detach(), c.detach()) for h, c in states]
-
-    def _backbone_wavefront(self, ev_seq, states):
-        """Run the T x 4 recurrence as a wavefront over HIP streams: stage s of timestep t only depends on stage s-1
-        of t and on its own state from t-1, so each stage gets its own stream (event-chained to the stage below) and up
-        to four stage evaluations are in flight at once.  The per-stage kernels are small and latency-bound (a
-        640-token stage-4 map cannot fill 256 CUs), so overlapping them is what raises device utilisation; autograd
-        replays every node on the stream of its forward, which gives the mirrored wavefront in the backward pass.
-        With a single stream (``self.n_streams == 1``) this degenerates to the plain nested loop."""
-        stages = self.det.backbone.stages
-        T = ev_seq.shape[0]
-        if states is None:
-            states = [None] * len(stages)
-        padded = self.det.backbone.in_res_hw
-        if padded is not None and tuple(ev_seq.shape[-2:]) == tuple(padded):
-            padded = None
-        main = torch.cuda.current_stream()
-        multi = self.n_streams > 1 and not torch.cuda.is_current_stream_capturing() and not self._capturing
-        self._multi_last = multi
-        if multi:
-            if self._streams is None:
-                self._streams = [torch.cuda.Stream(device=ev_seq.device) for _ in stages]
-            for st in self._streams:
-                st.wait_stream(main)
-        out = []
-        states = list(states)
-        for t in range(T):
-            x = ev_seq[t]
-            feats = {}
-            prev_done = None
-            for si, stage in enumerate(stages):
-                if multi:
-                    st = self._streams[si]
-                    if prev_done is not None:
-                        st.wait_event(prev_done)
-                    with torch.cuda.stream(st):
-                        x, states[si] = stage(x, states[si], None, padded if si == 0 else None)
-                        prev_done = torch.cuda.Event()
-                        prev_done.record(st)
-                else:
-                    x, states[si] = stage(x, states[si], None, padded if si == 0 else None)
-                feats[si + 1] = x
-            out.append((t, feats, list(states)))
-        if multi:
-            for st in self._streams:
-                main.wait_stream(st)
-        return out
 
     def _index(self, idx, device):
         key = tuple(idx)
@@ -158,12 +90,6 @@ class TrainEngine:
         finally:
             WgradSide.active = False
             WgradSide.join()            # parameter gradients are complete on the launch stream from here on
-        if self._multi_last:
-            # the wgrad kernels write parameter gradients directly (autograd does not see those writes), so the
-            # launch stream must explicitly wait for every stage stream before the all-reduce / optimiser
-            main = torch.cuda.current_stream()
-            for st in self._streams:
-                main.wait_stream(st)
         if hp_dev is None:
             scale = self.dp.all_reduce_gradients()
             self.flat.adamw_step(lr, self.hp['weight_decay'], self.hp['clip_value'], grad_scale=scale)
@@ -261,7 +187,6 @@ class PseudoLabelEngine:
         self.obj_thresh, self.cls_thresh = list(obj_thresh), list(cls_thresh)
         self.dataset_name, self.ds2, self.hflip, self.max_det = dataset_name, downsampled_by_2, hflip, max_det
         self.states = None
-        self.time_batched = os.environ.get('LEOD_SCHEDULE', 'batched') == 'batched'
 
     @torch.no_grad()
     def step(self, ev_seq: torch.Tensor, is_first: Optional[torch.Tensor] = None):
@@ -275,19 +200,10 @@ class PseudoLabelEngine:
             for h, c in self.states:
                 h[is_first] = 0
                 c[is_first] = 0
-        if self.time_batched:
-            # stage-major: every stage sees all T*B' frames per launch, only the ConvLSTM walks over t (same values as
-            # the per-timestep loop of pseudo_labeler.py:687-722, see RNNDetector.forward_sequence)
-            feats_all, states = self.det.backbone.forward_sequence(ev_seq, self.states)
-            feats = {k: feats_all[k] for k in self.det.fpn.in_features}
-        else:
-            states = self.states
-            per_t: Dict[int, List[torch.Tensor]] = {}
-            for t in range(T):
-                f_t, states = self.det.forward_backbone(ev_seq[t], states)
-                for k in self.det.fpn.in_features:
-                    per_t.setdefault(k, []).append(f_t[k].permute(0, 2, 3, 1))
-            feats = {k: torch.cat(v, 0).permute(0, 3, 1, 2) for k, v in per_t.items()}
+        # stage-major: every stage sees all T*B' frames per launch, only the ConvLSTM walks over t (same values as the
+        # per-timestep loop of pseudo_labeler.py:687-722, see RNNDetector.forward_sequence)
+        feats_all, states = self.det.backbone.forward_sequence(ev_seq, self.states)
+        feats = {k: feats_all[k] for k in self.det.fpn.in_features}
         self.states = states
         preds, _ = self.det.forward_detect(feats)
         det, cnt = postprocess_padded(preds, self.nc, self.conf, self.nms, max_det=self.max_det)

@@ -1,12 +1,18 @@
 """Detection module with the reference's LightningModule method surface (modules/detection.py:25-594):
 ``setup, forward, get_data_from_batch, training_step, validation_step, test_step, configure_optimizers,
 predict_one_seq, load_weight``.  pytorch_lightning is optional: without it the class is a plain
-``nn.Module`` with the same methods, and ``leod_amd.engine.TrainEngine`` drives it.
+``nn.Module`` with the same methods, driven by ``leod_amd.optim.fit_step`` (what Lightning's automatic
+optimisation does with one batch).
+
+This surface IS the fast path: ``training_step`` runs the stage-major time-batched schedule, and
+``configure_optimizers`` returns ``leod_amd.optim.FlatAdamW`` (one fused clip + AdamW launch on the flat parameter
+buffer, the data-parallel all-reduce and SyncBatchNorm switch included) plus torch's own ``OneCycleLR``.
 
 Hot-loop differences from the reference (same results): the event tensor stays uint8 and unpadded (the cast
 and the bottom/right zero padding are folded into the stem kernel instead of materialising a
-[L,B,20,256,320] fp32 tensor, detection.py:132-135), and the detection head/loss never synchronises with
-the host."""
+[L,B,20,256,320] fp32 tensor, detection.py:132-135), the L timesteps are evaluated stage by stage instead of
+frame by frame, and the detection head/loss never synchronises with the host."""
+import os
 from typing import Any, Dict, List, Optional, Tuple
 
 import torch
@@ -18,14 +24,16 @@ try:  # pragma: no cover
 except ImportError:
     _Base = th.nn.Module
 
-from leod_amd.data.genx_utils.labels import ObjectLabels
+from leod_amd import ops
+from leod_amd.functions import WgradSide
+from leod_amd.data.genx_utils.labels import ObjectLabels, SparselyBatchedObjectLabels
 from leod_amd.data.utils.types import DataType, DatasetSamplingMode, ObjDetOutput
 from leod_amd.models.detection.yolox.utils.boxes import postprocess
 from leod_amd.models.detection.yolox_extension.models.detector import YoloXDetector
 from leod_amd.utils.evaluation.prophesee.evaluator import PropheseeEvaluator
 from leod_amd.utils.evaluation.prophesee.io.box_loading import to_prophesee
 from leod_amd.utils.padding import InputPadderFromShape
-from .utils.detection import (BackboneFeatureSelector, EventReprSelector, Mode, RNNStates, mode_2_string,
+from .utils.detection import (BackboneFeatureSelector, Mode, RNNStates, mode_2_string,
                               merge_mixed_batches, WORKER_ID_KEY, DATA_KEY)
 from .utils.ssod import get_subsample_label_idx
 
@@ -50,6 +58,11 @@ class Module(_Base):
         self.started_training = True
         self.train_vis_every = int(1e9)
         self.train_eval_every = None
+        # 'batched' (default): stage-major, all L timesteps of a stage per launch; anything else: the reference's
+        # timestep-major loop over ``forward_backbone`` (same values, ~5x more and smaller launches)
+        self.time_batched = os.environ.get('LEOD_SCHEDULE', 'batched') == 'batched'
+        self.wgrad_side = os.environ.get('LEOD_WGRAD_STREAM', '1') == '1'
+        self._row_idx_cache: Dict[Any, th.Tensor] = {}
 
     # ---- Lightning-compatible plumbing -----------------------------------------------------------------
     def setup(self, stage: Optional[str] = None) -> None:
@@ -94,7 +107,28 @@ class Module(_Base):
         return data
 
     # ---- the hot loop -----------------------------------------------------------------------------------
-    def _run_sequence(self, mode: Mode, data, worker_id: int, training: bool, ignore_kwargs=None):
+    @staticmethod
+    def _stack_frames(ev_seq) -> th.Tensor:
+        """The loader hands over L frame tensors [B,C,H,W] (reference: a Python list, detection.py:132); when they are
+        consecutive slices of one [L,B,C,H,W] buffer (``leod_amd.data`` loaders, ``HostFeeder``) that buffer is used as is,
+        otherwise the frames are stacked (one device copy of the uint8 batch)."""
+        if th.is_tensor(ev_seq):
+            return ev_seq
+        f0 = ev_seq[0]
+        base = f0._base
+        step = f0.numel() * f0.element_size()
+        if (base is not None and tuple(base.shape) == (len(ev_seq),) + tuple(f0.shape) and base.is_contiguous()
+                and base.dtype == f0.dtype and base.data_ptr() == f0.data_ptr()
+                and all(e.shape == f0.shape and e.is_contiguous() and e.data_ptr() == f0.data_ptr() + t * step
+                        for t, e in enumerate(ev_seq))):
+            return base
+        return th.stack(list(ev_seq))
+
+    def _run_sequence(self, mode: Mode, data, worker_id: int, ignore_kwargs=None):
+        """reset states -> backbone over the L frames -> features of the labelled frames (reference: the ``for tidx in
+        range(L)`` loop of detection.py:188-226).  Default schedule: stage-major and time-batched
+        (``RNNDetector.forward_sequence``: every per-frame layer sees L*B frames per launch, only the ConvLSTM walks over
+        t) -- same values as the per-timestep loop, which stays available (``self.time_batched = False``)."""
         ev_seq = data[DataType.EV_REPR]
         labels_seq = data[DataType.OBJLABELS_SEQ]
         is_first = data[DataType.IS_FIRST_SAMPLE]
@@ -106,23 +140,47 @@ class Module(_Base):
             self.mode_2_batch_size[mode] = B
         else:
             assert self.mode_2_batch_size[mode] == B
+        hw = tuple(ev_seq[0].shape[-2:])
+        if self.mode_2_hw[mode] is None:
+            self.mode_2_hw[mode] = hw
+        else:
+            assert self.mode_2_hw[mode] == hw
         prev_states = rnn.get_states(worker_id=worker_id)
-        selector, ev_selector, obj_labels = BackboneFeatureSelector(), EventReprSelector(), []
+        obj_labels, where = [], []
         for tidx in range(L):
-            ev = ev_seq[tidx]
-            if self.mode_2_hw[mode] is None:
-                self.mode_2_hw[mode] = tuple(ev.shape[-2:])
-            else:
-                assert self.mode_2_hw[mode] == tuple(ev.shape[-2:])
-            feats, states = self.mdl.forward_backbone(x=ev, previous_states=prev_states)
-            prev_states = states
             cur, idx = labels_seq[tidx].get_valid_labels_and_batch_indices(**(ignore_kwargs or {}))
-            if len(cur) > 0:
-                selector.add_backbone_features(backbone_features=feats, selected_indices=idx)
-                obj_labels.extend(cur)
-                ev_selector.add_ev_repr(ev_repr=ev, selected_indices=idx)
-        rnn.save_states_and_detach(worker_id=worker_id, states=prev_states)
-        return selector, ev_selector, obj_labels, B
+            obj_labels.extend(cur)
+            where.extend((tidx, b) for b in idx)
+        in_features = self.mdl.fpn.in_features
+        if self.time_batched:
+            ev = self._stack_frames(ev_seq)
+            feats_all, states = self.mdl.backbone.forward_sequence(ev, prev_states)
+            feats = None
+            if where:
+                rows = self._row_index(tuple(t * B + b for t, b in where), ev.device)
+                feats = {k: feats_all[k].permute(0, 2, 3, 1).index_select(0, rows).permute(0, 3, 1, 2) for k in in_features}
+        else:
+            selector = BackboneFeatureSelector()
+            states = prev_states
+            by_t: Dict[int, List[int]] = {}
+            for t, b in where:
+                by_t.setdefault(t, []).append(b)
+            for tidx in range(L):
+                f_t, states = self.mdl.forward_backbone(x=ev_seq[tidx], previous_states=states)
+                if tidx in by_t:
+                    selector.add_backbone_features(backbone_features={k: f_t[k] for k in in_features},
+                                                   selected_indices=by_t[tidx])
+            feats = selector.get_batched_backbone_features()
+        rnn.save_states_and_detach(worker_id=worker_id, states=states)
+        return feats, obj_labels, where, B
+
+    def _row_index(self, rows, device):
+        key = (rows, str(device))
+        if key not in self._row_idx_cache:
+            if len(self._row_idx_cache) > 256:
+                self._row_idx_cache.clear()
+            self._row_idx_cache[key] = th.tensor(rows, dtype=th.long, device=device)
+        return self._row_idx_cache[key]
 
     def training_step(self, batch: Any, batch_idx: int = 0, log: bool = True):
         batch = merge_mixed_batches(batch)
@@ -131,28 +189,36 @@ class Module(_Base):
         self.started_training = True
         ign = dict(ignore=self.mdl_config.get('ignore_image', False),
                    ignore_label=self.mdl_config.head.get('ignore_label', 1024))
-        selector, _, obj_labels, B = self._run_sequence(Mode.TRAIN, data, worker_id, True, ign)
+        device = data[DataType.EV_REPR][0].device
+        ops.StatArena.begin_step(device)             # one memset for every BatchNorm statistic accumulator of the step
+        feats, obj_labels, _, B = self._run_sequence(Mode.TRAIN, data, worker_id, ign)
         assert len(obj_labels) > 0
-        feats = selector.get_batched_backbone_features()
         labels_yolox = ObjectLabels.get_labels_as_batched_tensor(obj_label_list=obj_labels, format_='yolox')
-        labels_yolox = labels_yolox.to(device=next(iter(feats.values())).device, dtype=torch.float32)
-        predictions, losses = self.mdl.forward_detect(backbone_features=feats, targets=labels_yolox)
+        if labels_yolox.device != device:            # host labels: pinned + asynchronous, the launch thread never waits for the GPU
+            labels_yolox = labels_yolox.pin_memory().to(device=device, non_blocking=True)
+        predictions, losses = self.mdl.forward_detect(backbone_features=feats, targets=labels_yolox.to(torch.float32))
         assert losses is not None and 'loss' in losses
+        # the weight-gradient kernels of the backward pass that follows run on a side HIP stream until the optimiser joins it
+        WgradSide.active = self.wgrad_side and torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()
         output = {'loss': losses['loss'],
                   'log_dict': {f'{mode_2_string[Mode.TRAIN]}/{k}': v for k, v in losses.items()}}
         if hasattr(self, 'log_dict') and log and _Base is not th.nn.Module:  # pragma: no cover
             self.log_dict(output['log_dict'], on_step=True, on_epoch=True, batch_size=B, sync_dist=False, rank_zero_only=True)
         return output
 
+    def backward(self, loss: th.Tensor, *args, **kwargs) -> None:
+        """Lightning's backward hook (and what ``leod_amd.optim.fit_step`` calls)."""
+        loss.backward(*args, **kwargs)
+
     @torch.no_grad()
     def _val_test_step_impl(self, batch: Any, mode: Mode):
         data = self.get_data_from_batch(batch)
         worker_id = self.get_worker_id_from_batch(batch)
         assert mode in (Mode.VAL, Mode.TEST)
-        selector, ev_selector, obj_labels, _ = self._run_sequence(mode, data, worker_id, False)
+        feats, obj_labels, where, _ = self._run_sequence(mode, data, worker_id)
         if len(obj_labels) == 0:
             return {ObjDetOutput.SKIP_VIZ: True}
-        predictions, _ = self.mdl.forward_detect(backbone_features=selector.get_batched_backbone_features())
+        predictions, _ = self.mdl.forward_detect(backbone_features=feats)
         pred_processed = postprocess(prediction=predictions, num_classes=self.num_classes,
                                      conf_thre=self.mdl_config.postprocess.confidence_threshold,
                                      nms_thre=self.mdl_config.postprocess.nms_threshold)
@@ -161,8 +227,9 @@ class Module(_Base):
         if self.started_training and mode in self.mode_2_psee_evaluator:
             self.mode_2_psee_evaluator[mode].add_labels(labels_proph)
             self.mode_2_psee_evaluator[mode].add_predictions(preds_proph)
+        t_last, b_last = where[-1]
         return {ObjDetOutput.LABELS_PROPH: labels_proph[-1], ObjDetOutput.PRED_PROPH: preds_proph[-1],
-                ObjDetOutput.EV_REPR: ev_selector.get_ev_repr_as_list(start_idx=-1)[0], ObjDetOutput.SKIP_VIZ: False}
+                ObjDetOutput.EV_REPR: data[DataType.EV_REPR][t_last][b_last], ObjDetOutput.SKIP_VIZ: False}
 
     def run_psee_evaluator(self, mode: Mode, log: bool = True, reset_buffer: bool = True, ret_pr_curve: bool = False):
         """Prophesee / COCO KPIs over everything buffered for ``mode`` (reference :409-463); ``{'val/AP': tensor, ...}``.
@@ -214,10 +281,13 @@ class Module(_Base):
         return self._val_test_step_impl(batch=batch, mode=Mode.TEST)
 
     def configure_optimizers(self) -> Any:
-        """With Lightning: torch AdamW + OneCycleLR exactly as the reference (:485-518).  The native path
-        (leod_amd.engine.TrainEngine) uses the fused HIP AdamW on the flat parameter buffer instead."""
+        """AdamW + OneCycleLR with the reference's hyper-parameters (:485-518).  The optimiser is ``FlatAdamW``: a
+        ``torch.optim.Optimizer`` whose ``step`` is the flat-gradient all-reduce (N > 1 ranks) + ONE fused
+        value-clip / AdamW launch; the scheduler is torch's ``OneCycleLR`` acting on its ``param_groups``."""
+        from leod_amd.optim import FlatAdamW
         tc = self.full_config.training
-        opt = th.optim.AdamW(self.mdl.parameters(), lr=tc.learning_rate, weight_decay=tc.weight_decay)
+        opt = FlatAdamW(self.mdl, lr=tc.learning_rate, weight_decay=tc.weight_decay,
+                        clip_value=tc.get('gradient_clip_val', None))
         sp = tc.lr_scheduler
         if not sp.use:
             return opt
@@ -228,24 +298,56 @@ class Module(_Base):
         return {'optimizer': opt, 'lr_scheduler': {'scheduler': sch, 'interval': 'step', 'frequency': 1, 'strict': True,
                                                    'name': 'learning_rate'}}
 
+    # ---- Lightning hooks that keep the Trainer's generic machinery off the flat buffers -----------------------------------
+    def configure_gradient_clipping(self, optimizer, gradient_clip_val=None, gradient_clip_algorithm=None) -> None:
+        """``Trainer(gradient_clip_val=1.0, gradient_clip_algorithm='value')`` (train.py:236-237): the clip is fused into
+        the optimiser kernel, AFTER the cross-rank gradient sum, so the Trainer's own clipping pass is replaced by this."""
+        if gradient_clip_val is None:
+            return
+        assert gradient_clip_algorithm in (None, 'value'), 'the reference clips by value (train.py:237)'
+        optimizer = getattr(optimizer, 'optimizer', optimizer)          # LightningOptimizer wrapper
+        optimizer.clip_value = float(gradient_clip_val)
+
+    def transfer_batch_to_device(self, batch: Any, device, dataloader_idx: int = 0) -> Any:
+        """Tensors go to the device asynchronously; box labels stay on the host (their per-frame bookkeeping is host work,
+        the padded target tensor is uploaded once per step in ``training_step``)."""
+        def move(o):
+            if th.is_tensor(o):
+                return o.to(device, non_blocking=True)
+            if isinstance(o, (ObjectLabels, SparselyBatchedObjectLabels)) or o is None or isinstance(o, (str, int, float, bool)):
+                return o
+            if isinstance(o, dict):
+                return {k: move(v) for k, v in o.items()}
+            if isinstance(o, (list, tuple)):
+                return type(o)(move(v) for v in o)
+            return o
+        return move(batch)
+
     @torch.no_grad()
     def predict_one_seq(self, batch: Any, head_every: int = 128):
-        """B=1 full sequence: backbone per timestep, head every ``head_every`` timesteps (reference :520-581)."""
+        """B=1 full sequence (reference :520-581): the backbone over chunks of ``head_every`` timesteps (time-batched, LSTM
+        state carried from chunk to chunk), the head + postprocess once per chunk."""
         data = self.get_data_from_batch(batch)
         ev_seq = data[DataType.EV_REPR]
         labels_seq = data[DataType.OBJLABELS_SEQ]
-        prev, feats_buf, preds = None, [], []
+        prev, preds = None, []
         L = len(ev_seq)
-        for tidx in range(L):
-            feats, prev = self.mdl.forward_backbone(x=ev_seq[tidx], previous_states=prev)
-            feats_buf.append(feats)
-            if (tidx + 1) % head_every == 0 or tidx == L - 1:
-                cat = {k: th.cat([f[k] for f in feats_buf]) for k in feats}
-                p, _ = self.mdl.forward_detect(backbone_features=cat)
-                preds.extend(postprocess(prediction=p, num_classes=self.num_classes,
-                                         conf_thre=self.mdl_config.postprocess.confidence_threshold,
-                                         nms_thre=self.mdl_config.postprocess.nms_threshold))
-                feats_buf = []
+        in_features = self.mdl.fpn.in_features
+        for lo in range(0, L, head_every):
+            chunk = ev_seq[lo:lo + head_every]
+            if self.time_batched:
+                feats_all, prev = self.mdl.backbone.forward_sequence(th.stack(list(chunk)), prev)
+                cat = {k: feats_all[k] for k in in_features}
+            else:
+                buf = []
+                for ev in chunk:
+                    f_t, prev = self.mdl.forward_backbone(x=ev, previous_states=prev)
+                    buf.append(f_t)
+                cat = {k: th.cat([f[k] for f in buf]) for k in in_features}
+            p, _ = self.mdl.forward_detect(backbone_features=cat)
+            preds.extend(postprocess(prediction=p, num_classes=self.num_classes,
+                                     conf_thre=self.mdl_config.postprocess.confidence_threshold,
+                                     nms_thre=self.mdl_config.postprocess.nms_threshold))
         return preds, th.stack([e[0] for e in ev_seq]), [l[0] for l in labels_seq]
 
     def load_weight(self, ckpt_path: str, strict: bool = True) -> None:

@@ -262,19 +262,32 @@ class PseudoLabeler(Module):
         prev = rnn.get_states(worker_id=worker_id)
         self.mode_2_seq_lens.reset(worker_id=worker_id, indices_or_bool_tensor=is_first)
         pse_mask, gt_mask, _ = self._get_pred_mask(worker_id, data)
-        selector = BackboneFeatureSelector()
         gt_labels: List[ObjectLabels] = []
-        for t in range(L):
-            feats, prev = self.mdl.forward_backbone(x=ev_seq[t], previous_states=prev)
-            if self.use_gt:
+        if self.use_gt:
+            for t in range(L):
                 cur, _ = obj_labels[t].get_valid_labels_and_batch_indices()
                 gt_labels.extend(cur)
-            idx = np.where(pse_mask[t])[0].tolist()
-            if idx:
-                selector.add_backbone_features(feats, idx)
+        in_features = self.mdl.fpn.in_features
+        rows = tuple(t * B + int(b) for t in range(L) for b in np.where(pse_mask[t])[0])
+        feats = None
+        if self.time_batched:
+            # stage-major: every stage sees all L*B frames per launch, only the ConvLSTM walks over t (same values as the
+            # per-timestep loop of pseudo_labeler.py:687-722, see RNNDetector.forward_sequence)
+            ev = self._stack_frames(ev_seq)
+            feats_all, prev = self.mdl.backbone.forward_sequence(ev, prev)
+            if rows:
+                ridx = self._row_index(rows, ev.device)
+                feats = {k: feats_all[k].permute(0, 2, 3, 1).index_select(0, ridx).permute(0, 3, 1, 2) for k in in_features}
+        else:
+            selector = BackboneFeatureSelector()
+            for t in range(L):
+                f_t, prev = self.mdl.forward_backbone(x=ev_seq[t], previous_states=prev)
+                idx = np.where(pse_mask[t])[0].tolist()
+                if idx:
+                    selector.add_backbone_features({k: f_t[k] for k in in_features}, idx)
+            feats = selector.get_batched_backbone_features()
         rnn.save_states_and_detach(worker_id=worker_id, states=prev)
         self.mode_2_seq_lens.update_lens(worker_id=worker_id, lens=torch.ones(B).long() * L)
-        feats = selector.get_batched_backbone_features()
         pse_labels: List[ObjectLabels] = []
         if feats is not None:
             preds, _ = self.mdl.forward_detect(backbone_features=feats)

@@ -95,6 +95,11 @@ class RNNStates:
             assert t.requires_grad is False
             if indices_or_bool_tensor is None:
                 t[:] = 0
+            elif th.is_tensor(indices_or_bool_tensor) and indices_or_bool_tensor.dtype == th.bool:
+                # same rows as ``t[mask] = 0``, written as a masked fill: no index list, no host synchronisation
+                assert len(indices_or_bool_tensor) > 0
+                mask = indices_or_bool_tensor.to(t.device, non_blocking=True)
+                t.masked_fill_(mask.view((-1,) + (1,) * (t.dim() - 1)), 0)
             else:
                 assert len(indices_or_bool_tensor) > 0
                 t[indices_or_bool_tensor] = 0

@@ -167,24 +167,39 @@ class TTAModule(Module):
         rnn = self.mode_2_rnn_states[mode]
         rnn.reset(worker_id=worker_id, indices_or_bool_tensor=is_first)
         states = rnn.get_states(worker_id=worker_id)
-        selector, gts, where = BackboneFeatureSelector(), [], []
+        hw = tuple(ev_seq[0].shape[-2:])
+        if self.mode_2_hw[mode] is None:
+            self.mode_2_hw[mode] = hw
+        else:
+            assert self.mode_2_hw[mode] == hw
+        gts, where = [], []
         for t in range(L):
-            ev = ev_seq[t]
-            if self.mode_2_hw[mode] is None:
-                self.mode_2_hw[mode] = tuple(ev.shape[-2:])
-            else:
-                assert self.mode_2_hw[mode] == tuple(ev.shape[-2:])
-            feats, states = self.mdl.forward_backbone(x=ev, previous_states=states)
             cur, idx = labels_seq[t].get_valid_labels_and_batch_indices()
-            if len(cur) > 0:
-                selector.add_backbone_features(backbone_features=feats, selected_indices=idx)
-                gts.extend(cur)
-                where.extend((t, b) for b in idx)
+            gts.extend(cur)
+            where.extend((t, b) for b in idx)
+        in_features = self.mdl.fpn.in_features
+        feats = None
+        if self.time_batched:                                  # stage-major, all L frames of a stage per launch
+            ev = self._stack_frames(ev_seq)
+            feats_all, states = self.mdl.backbone.forward_sequence(ev, states)
+            if where:
+                ridx = self._row_index(tuple(t * B + b for t, b in where), ev.device)
+                feats = {k: feats_all[k].permute(0, 2, 3, 1).index_select(0, ridx).permute(0, 3, 1, 2) for k in in_features}
+        else:
+            selector = BackboneFeatureSelector()
+            by_t: Dict[int, List[int]] = {}
+            for t, b in where:
+                by_t.setdefault(t, []).append(b)
+            for t in range(L):
+                f_t, states = self.mdl.forward_backbone(x=ev_seq[t], previous_states=states)
+                if t in by_t:
+                    selector.add_backbone_features(backbone_features={k: f_t[k] for k in in_features}, selected_indices=by_t[t])
+            feats = selector.get_batched_backbone_features()
         rnn.save_states_and_detach(worker_id=worker_id, states=states)
-        if selector.is_empty():
+        if feats is None:
             assert len(gts) == 0
             return tuple([[]] * 8)
-        predictions, _ = self.mdl.forward_detect(backbone_features=selector.get_batched_backbone_features())
+        predictions, _ = self.mdl.forward_detect(backbone_features=feats)
         dets = postprocess(prediction=predictions, num_classes=self.mdl_config.head.num_classes,
                            conf_thre=self.postproc_cfg.confidence_threshold, nms_thre=self.postproc_cfg.nms_threshold,
                            pad=th.zeros((0, 7), dtype=predictions.dtype, device=predictions.device))

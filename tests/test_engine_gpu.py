@@ -117,43 +117,6 @@ def test_graph_replay_equals_eager(gpu, manifest):
         np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=5e-4, atol=5e-5)
 
 
-@pytest.mark.parametrize('capture_head', [True, False])
-def test_cell_graphs_equal_eager(gpu, manifest, capture_head):
-    """Per-cell hipGraphs replayed as a 4-stream wavefront (leod_amd.cellgraph) == the eager single-stream step."""
-    from leod_amd.engine import TrainEngine
-    from leod_amd.cellgraph import CellGraphEngine
-    T, B = 4, 2
-    label_tb = [[], [0], [], [0, 1]]
-    res = {}
-    for mode in ('eager', 'cells'):
-        det, _ = micro_detector(manifest, 9)
-        eng = (CellGraphEngine if mode == 'cells' else TrainEngine)(det, lr=2e-4, total_steps=1000)
-        eng.n_streams = 1
-        out = []
-        for step in range(3):
-            ev = synth_events(T, B, 20, 60, 90, seed=50 + step, as_uint8=True).to(DEV)
-            labels = torch.zeros((3, 4, 7))
-            ll = op.batched_yolox_labels(micro_labels(3, seed=60 + step))
-            labels[:, :ll.shape[1]] = ll
-            labels = labels.to(DEV)
-            is_first = torch.tensor([step == 0, True], device=DEV)
-            if mode == 'cells':
-                if step == 0:
-                    eng.build(ev, labels, label_tb, is_first, capture_head=capture_head)
-                losses = eng.step_cells(ev, labels, is_first)
-            else:
-                losses = eng.step(ev, labels, label_tb, is_first)
-            out.append([float(losses[k]) for k in KEYS])
-        res[mode] = (np.array(out), eng.flat.data.clone().cpu(), [c.clone().cpu() for _, c in eng.states])
-    np.testing.assert_allclose(res['cells'][0], res['eager'][0], rtol=1e-4, atol=1e-5)
-    pg, pe = res['cells'][1].numpy(), res['eager'][1].numpy()
-    diff = np.abs(pg - pe)
-    assert diff.max() < 3.5e-4                      # see test_graph_replay_equals_eager for the tolerance model
-    assert (diff > 2e-6 + 1e-4 * np.abs(pe)).mean() < 5e-3
-    for a, b in zip(res['cells'][2], res['eager'][2]):
-        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=5e-4, atol=5e-5)
-
-
 def test_pseudo_label_inference_vs_oracle(gpu, manifest):
     from leod_amd.engine import PseudoLabelEngine
     det, sd = micro_detector(manifest, 5)
@@ -262,24 +225,127 @@ def _full_size_batch(T=21, B=8, seed=3):
     return ev.to(DEV), torch.from_numpy(lab).to(DEV), label_tb
 
 
+def _full_size_module(seed=0, schedule='batched'):
+    from leod_amd.config import full_config, dynamically_modify_train_config
+    from leod_amd.modules.utils.fetch import fetch_model_module
+    cfg = dynamically_modify_train_config(full_config('gen1', 'small'))
+    torch.manual_seed(seed)
+    mod = fetch_model_module(cfg).to(DEV)
+    mod.setup('fit')
+    mod.train()
+    mod.time_batched = schedule == 'batched'
+    oc = mod.configure_optimizers()
+    return mod, oc['optimizer'], oc['lr_scheduler']['scheduler']
+
+
+def _loader_batch(ev, rows, label_tb, is_first, hw=(240, 304)):
+    """Device frames + host box labels in the dictionary the reference's loaders emit; ``rows`` are yolox rows
+    (cls, cx, cy, w, h, obj, cls_conf) of the labelled frames in (t, b) order."""
+    from leod_amd.data.genx_utils.labels import ObjectLabels, SparselyBatchedObjectLabels
+    from leod_amd.data.utils.types import DataType
+    from leod_amd.modules.utils.detection import WORKER_ID_KEY, DATA_KEY
+    T, B = ev.shape[:2]
+    it = iter(rows)
+    seq = []
+    for t in range(T):
+        row = [None] * B
+        for b in label_tb[t]:
+            r = torch.as_tensor(next(it))
+            r = r[r.sum(1) > 0]
+            row[b] = ObjectLabels(torch.stack([torch.ones(len(r)), r[:, 1] - r[:, 3] / 2, r[:, 2] - r[:, 4] / 2, r[:, 3], r[:, 4],
+                                               r[:, 0], r[:, 6], r[:, 5]], 1), hw)
+        seq.append(SparselyBatchedObjectLabels(row))
+    return {WORKER_ID_KEY: 0, DATA_KEY: {DataType.EV_REPR: [ev[t] for t in range(T)], DataType.OBJLABELS_SEQ: seq,
+                                         DataType.IS_FIRST_SAMPLE: is_first}}
+
+
 def test_full_size_schedule_invariance(gpu):
-    """At the benchmark size the stage-major time-batched schedule and the reference's timestep-major loop are the same
-    function: losses, final LSTM states and the updated parameters of one training step agree."""
+    """At the benchmark size, through the Module surface: the stage-major time-batched schedule and the reference's
+    timestep-major loop over ``forward_backbone`` are the same function -- losses, final LSTM states and the updated
+    parameters of one training step (training_step + FlatAdamW.step) agree."""
+    from leod_amd.optim import fit_step
+    from leod_amd.modules.utils.detection import Mode
     ev, labels, label_tb = _full_size_batch()
     first = torch.ones(8, dtype=torch.bool, device=DEV)
     out = {}
-    for sched in ('batched', 'wavefront'):
-        eng, det = _full_size_engine(0)
-        eng.schedule, eng.n_streams = sched, 1
-        losses = eng.step(ev, labels, label_tb, first)
-        out[sched] = (np.array([float(losses[k]) for k in KEYS]), eng.flat.data.detach().cpu().numpy(),
-                      [c.detach().cpu().numpy() for _, c in eng.states])
-    np.testing.assert_allclose(out['batched'][0], out['wavefront'][0], rtol=2e-5, atol=1e-6)
-    for a, b in zip(out['batched'][2], out['wavefront'][2]):
+    for sched in ('batched', 'timestep'):
+        mod, opt, lrs = _full_size_module(0, sched)
+        res = fit_step(mod, opt, lrs, _loader_batch(ev, labels.cpu().numpy(), label_tb, first))
+        states = mod.mode_2_rnn_states[Mode.TRAIN].get_states(0)
+        out[sched] = (np.array([float(res['log_dict'][f'train/{k}'].detach()) for k in KEYS]), opt.flat.data.detach().cpu().numpy(),
+                      [c.detach().cpu().numpy() for _, c in states])
+    np.testing.assert_allclose(out['batched'][0], out['timestep'][0], rtol=2e-5, atol=1e-6)
+    for a, b in zip(out['batched'][2], out['timestep'][2]):
         np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-5)
-    d = np.abs(out['batched'][1] - out['wavefront'][1])
+    d = np.abs(out['batched'][1] - out['timestep'][1])
     assert d.max() < 4.5e-4                                   # <= 2 * lr: Adam sign flips on noise-level gradients only
-    assert (d > 2e-6 + 1e-4 * np.abs(out['wavefront'][1])).mean() < 5e-3
+    assert (d > 2e-6 + 1e-4 * np.abs(out['timestep'][1])).mean() < 5e-3
+
+
+def test_full_size_module_step_equals_engine_step(gpu):
+    """The reference-shaped surface IS the fast path: ``Module.training_step`` + ``FlatAdamW.step`` + ``OneCycleLR.step``
+    (fetch_model_module -> configure_optimizers, driven like Lightning's automatic optimisation) and the tensor-level
+    ``TrainEngine.step`` run the same kernels in the same order -- two steps at the benchmark size, second one with carried
+    LSTM state and a partial reset: losses, learning rate and parameters agree."""
+    from leod_amd.optim import fit_step
+    ev, labels, label_tb = _full_size_batch()
+    ev2, labels2, _ = _full_size_batch(seed=4)
+    firsts = [torch.ones(8, dtype=torch.bool, device=DEV),
+              torch.tensor([False, True, False, False, True, True, True, True], device=DEV)]
+    eng, _ = _full_size_engine(0)
+    mod, opt, lrs = _full_size_module(0)
+    np.testing.assert_array_equal(eng.flat.data.cpu().numpy(), opt.flat.data.cpu().numpy())
+    for step, (e, l, f) in enumerate(zip((ev, ev2), (labels, labels2), firsts)):
+        le = eng.step(e, l, label_tb, f.clone())
+        assert abs(opt.param_groups[0]['lr'] - one_cycle(step)) < 1e-12
+        res = fit_step(mod, opt, lrs, _loader_batch(e, l.cpu().numpy(), label_tb, f.clone()), step)
+        got = np.array([float(res['log_dict'][f'train/{k}'].detach()) for k in KEYS])
+        np.testing.assert_allclose(got, np.array([float(le[k]) for k in KEYS]), rtol=2e-5, atol=1e-6, err_msg=f'step {step}')
+        d = np.abs(opt.flat.data.cpu().numpy() - eng.flat.data.cpu().numpy())
+        assert d.max() < 4.5e-4 * (step + 1) and (d > 2e-6 + 1e-4 * np.abs(eng.flat.data.cpu().numpy())).mean() < 5e-3
+
+
+def one_cycle(step):
+    from leod_amd.parallel import one_cycle_lr
+    return one_cycle_lr(step, 2e-4, 400000, 0.005, 20, 10000)
+
+
+def test_full_size_training_step_vs_oracle(gpu, manifest):
+    """BASELINE configs[1] at full size against the CPU oracle directly: RVT-S, Gen1 240x304, T=21, bs=8, 32 labelled
+    frames, synthetic weights; ONE training step through Module.training_step + FlatAdamW (the benchmarked schedule) vs
+    ``OracleTrainer.step`` (modules/detection.py:188-298, yolo_head.py:403-597): the six losses to 2e-5 relative (num_fg is
+    the SimOTA foreground count / labelled boxes: equal only if the assignment is identical), a sample of post-step
+    parameters, the final LSTM cell states."""
+    from oracle.synth import synth_state_dict
+    from leod_amd.optim import fit_step
+    from leod_amd.modules.utils.detection import Mode
+    sd = synth_state_dict(manifest['small_gen1'], 3)
+    mod, opt, lrs = _full_size_module(0)
+    mod.mdl.load_state_dict(sd)
+    ev, labels, label_tb = _full_size_batch(seed=11)
+    rows = labels.cpu().numpy()
+    first = torch.ones(8, dtype=torch.bool)
+    batch = _loader_batch(ev, rows, label_tb, first.to(DEV))
+    from leod_amd.data.utils.types import DataType
+    seq = batch['data'][DataType.OBJLABELS_SEQ]
+    ref_labels = [[None if l is None else l.object_labels.clone() for l in seq[t]] for t in range(21)]
+    res = fit_step(mod, opt, lrs, batch)
+    otr = ot.OracleTrainer(sd, ot.model_cfg(48, 24, 0.33, (8, 10)))
+    ref, _ = otr.step(ev.cpu(), ref_labels, first)
+    got = {k: float(res['log_dict'][f'train/{k}'].detach()) for k in KEYS}
+    assert got['num_fg'] == pytest.approx(ref['num_fg'], rel=1e-6), 'SimOTA foreground count differs'
+    for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss'):
+        assert got[k] == pytest.approx(ref[k], rel=2e-5, abs=1e-6), k
+    params = dict(mod.mdl.named_parameters())
+    rng = np.random.RandomState(0)
+    for k in [otr.param_keys[i] for i in rng.choice(len(otr.param_keys), 40, replace=False)]:
+        a, b = params[k].detach().cpu().numpy().ravel(), otr.sd[k].detach().numpy().ravel()
+        d = np.abs(a - b)
+        # lr0 = 1e-5: an element whose noise-level gradient changes sign moves by up to 2 * lr0
+        assert d.max() < 2.5e-5 and (d > 1e-6 + 1e-4 * np.abs(b)).mean() < 2e-2, k
+    states = mod.mode_2_rnn_states[Mode.TRAIN].get_states(0)
+    for (h, c), (rh, rc) in zip(states, otr.states):
+        np.testing.assert_allclose(c.cpu().numpy(), rc.numpy(), rtol=2e-4, atol=2e-5)
 
 
 def test_full_size_pseudo_label_pass_properties(gpu):

@@ -303,3 +303,115 @@ def test_tta_module_test_step_vs_oracle(gpu, manifest):
     ref = oc.evaluate_buffer(lab_rec, prd_rec, 'gen1', False)
     assert {k: float(v) for k, v in got.items()} == {f'test/{k}': v for k, v in ref.items()}
     assert not mod.mode_2_psee_evaluator[Mode.TEST].has_data()          # TTAModule resets the buffer (tta.py:387)
+
+
+# ---- the training path through the reference's surface: Module.training_step + configure_optimizers ----------------------
+def _g12_batch(step, T=5, B=2):
+    """Inputs of the reference-recorded two-step golden (tests/golden/make_golden.py, g12) as a loader dictionary."""
+    ev = synth_events(T, B, 20, 60, 90, seed=20 + step, as_uint8=True)
+    lab_list = synth_labels(T * B, HW, 2, seed=30 + step, max_boxes=4)
+    for l in lab_list:                                  # the box clamps of make_golden.py's g12 recipe
+        l[:, 3] = l[:, 3].clamp(max=30)
+        l[:, 4] = l[:, 4].clamp(max=24)
+        l[:, 1] = torch.minimum(l[:, 1], HW[1] - 1 - l[:, 3])
+        l[:, 2] = torch.minimum(l[:, 2], HW[0] - 1 - l[:, 4])
+    labels_tb = [[lab_list[t * B + b] if (t in (2, 4) or (t == 1 and b == 0)) else None for b in range(B)] for t in range(T)]
+    is_first = torch.tensor([True, True]) if step == 0 else torch.tensor([False, True])
+    return loader_batch(ev, labels_tb, is_first)
+
+
+def test_module_two_training_steps_match_reference_golden(gpu, golden_dir, manifest):
+    """fetch_model_module -> setup('fit') -> configure_optimizers -> two Lightning-style optimisation steps vs the vectors the
+    REFERENCE's own training loop recorded (g12: losses, clipped-gradient norms, parameter norms, next learning rate, carried
+    LSTM state) -- the time-batched schedule, FlatAdamW and torch's OneCycleLR behind the reference's API."""
+    import os
+    from leod_amd.modules.utils.detection import Mode
+    from leod_amd.optim import FlatAdamW, fit_step
+    g = np.load(os.path.join(golden_dir, 'g12_trainstep_micro.npz'))
+    mod, _, cfg = micro_module(manifest, 9, 'fit')
+    cfg.training.lr_scheduler.total_steps = 1000
+    mod.train()
+    oc = mod.configure_optimizers()
+    opt, sched = oc['optimizer'], oc['lr_scheduler']['scheduler']
+    assert isinstance(opt, FlatAdamW) and opt.clip_value == 1.0
+    params = dict(mod.mdl.named_parameters())
+    keys6 = ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')
+    for step in range(2):
+        out = fit_step(mod, opt, sched, _g12_batch(step), step)
+        got = np.array([float(out['log_dict'][f'train/{k}'].detach()) for k in keys6])
+        np.testing.assert_allclose(got, g[f's{step}_losses'], rtol=1e-4, err_msg=f'losses step {step}')
+        keys = [str(k) for k in g[f's{step}_grad_keys']]
+        np.testing.assert_allclose(np.array([float(params[k].grad.norm()) for k in keys]), g[f's{step}_grad_norms'],
+                                   rtol=3e-3, atol=1e-6, err_msg=f'grad norms step {step}')
+        np.testing.assert_allclose(np.array([float(params[k].detach().norm()) for k in keys]), g[f's{step}_param_norms'],
+                                   rtol=2e-4, err_msg=f'param norms step {step}')
+        assert abs(opt.param_groups[0]['lr'] - float(g[f's{step}_lr_next'])) < 1e-12
+        c4 = mod.mode_2_rnn_states[Mode.TRAIN].get_states(0)[3][1]
+        np.testing.assert_allclose(c4.cpu().numpy(), g[f's{step}_state_c4'], rtol=2e-4, atol=2e-5)
+    # optimizer checkpoint round trip (Lightning stores optimizer.state_dict() in the .ckpt)
+    sd = opt.state_dict()
+    opt.flat.exp_avg.zero_()
+    opt.load_state_dict(sd)
+    assert opt.flat.step_count == 2 and float(opt.flat.exp_avg.abs().sum()) > 0
+
+
+def _module_world2_worker(rank, port, manifest, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=2)
+    from leod_amd.optim import fit_step
+    mod, _, _ = micro_module(manifest, 9, 'fit')
+    mod.train()
+    oc = mod.configure_optimizers()                # world size 2 -> flat gradient all-reduce + SyncBatchNorm switched on here
+    opt, sched = oc['optimizer'], oc['lr_scheduler']['scheduler']
+    assert opt.world_size == 2
+    T, B = 4, 4
+    ev = synth_events(T, B, 20, HW[0], HW[1], seed=70, as_uint8=True)
+    labs_all = micro_labels(T * B, 71, [1e6] * (T * B))
+    mine = [2 * rank, 2 * rank + 1]                # this rank's half of the global batch
+    labels_tb = [[labs_all[t * B + b] if t in (1, 3) else None for b in mine] for t in range(T)]
+    out = fit_step(mod, opt, sched, loader_batch(ev[:, mine], labels_tb, torch.ones(2, dtype=torch.bool)))
+    bns = [m.bn for m in mod.mdl.modules() if hasattr(m, 'bn')]
+    q.put((rank, float(out['loss'].detach()), opt.flat.data.detach().cpu().numpy(),
+           np.concatenate([b.running_mean.detach().cpu().numpy() for b in bns]),
+           np.concatenate([b.running_var.detach().cpu().numpy() for b in bns])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_module_world2_through_reference_surface(gpu, manifest):
+    """N > 1 through the surface train.py uses (fetch_model_module / configure_optimizers / training_step), two ranks on one GPU
+    over gloo: replicas bit-identical after the step (one flat all-reduce inside FlatAdamW.step), BatchNorm running statistics
+    equal to ONE process seeing the whole batch (train.py:247 sync_batchnorm)."""
+    import os
+    import torch.multiprocessing as mp
+    from leod_amd.optim import fit_step
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33000 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_module_world2_worker, args=(r, port, manifest, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for k in (2, 3, 4):
+        np.testing.assert_array_equal(res[0][k], res[1][k])
+    mod, _, _ = micro_module(manifest, 9, 'fit')
+    mod.train()
+    oc = mod.configure_optimizers()
+    opt = oc['optimizer']
+    assert opt.world_size == 1
+    T, B = 4, 4
+    ev = synth_events(T, B, 20, HW[0], HW[1], seed=70, as_uint8=True)
+    labs_all = micro_labels(T * B, 71, [1e6] * (T * B))
+    labels_tb = [[labs_all[t * B + b] if t in (1, 3) else None for b in range(B)] for t in range(T)]
+    fit_step(mod, opt, oc['lr_scheduler']['scheduler'], loader_batch(ev, labels_tb, torch.ones(B, dtype=torch.bool)))
+    bns = [m.bn for m in mod.mdl.modules() if hasattr(m, 'bn')]
+    rm = np.concatenate([b.running_mean.detach().cpu().numpy() for b in bns])
+    rv = np.concatenate([b.running_var.detach().cpu().numpy() for b in bns])
+    np.testing.assert_allclose(res[0][3], rm, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(res[0][4], rv, rtol=2e-5, atol=1e-6)
