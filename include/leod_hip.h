@@ -126,7 +126,9 @@ int leod_head_pred_bwd(const float* d_raw, const float* cls_feat, const float* r
 
 /* SimOTA (get_assignments / get_assignments_w_ignore / simota_matching, :606-774, :974-1148) for a whole batch:
  * outputs [B,A,5+nc] decoded boxes + logits, labels [B,Nmax,7] = (cls,cx,cy,w,h,obj,cls_conf) zero padded.
- * totals[3] int (caller-zeroed): sum num_fg, sum num_gt, status bit0 = some gt had no candidate anchor. */
+ * totals[3] int (caller-zeroed): sum num_fg, sum num_gt, status bit0 = some gt had no candidate anchor.
+ * No limit on Nmax (boxes per frame) or A: the per-gt and per-candidate arrays live in LDS when they fit (Nmax <= 128,
+ * candidates <= 10240) and in the workspace otherwise.  workspace = leod_simota_workspace_floats(B, Nmax, A) floats. */
 long leod_simota_workspace_floats(int B, int Nmax, int A);
 int leod_simota_assign(const float* outputs, const float* labels, float* workspace, unsigned char* fg_mask,
                        unsigned char* ignore_mask, int* matched_row, int* matched_valid_idx, float* pred_iou,
@@ -145,10 +147,12 @@ int leod_yolox_loss(const float* outputs, const float* labels, const unsigned ch
 /* postprocess + torchvision-semantics batched NMS for B images at once.  nc>0: pred [B,A,5+nc] (cx,cy,w,h,obj,cls..),
  * boxes rewritten IN PLACE to xyxy; nc==0: pred [B,A,7] already (xyxy,obj,cls_conf,cls_id) (TTA merge).
  * det_out [B,max_det,7] in NMS order, det_cnt[B].  One workgroup per image keeps the candidates in LDS: all A anchors when
- * they fit (A <= 5040: Gen1, Gen4), else 4096 candidates -- an image with more boxes above conf_thre gets det_cnt = -1
- * (leod_pseudo_filter passes the -1 on). */
-int leod_postprocess_nms(float* pred, float* det_out, int* det_cnt, int B, int A, int nc, float conf_thre, float nms_thre,
-                         int class_agnostic, int max_det, int vanilla_limit, leod_stream_t stream);
+ * they fit (A <= 5040: Gen1, Gen4), else 4096 candidates; an image with more boxes above conf_thre than that is sorted and
+ * suppressed in its slice of ``workspace`` (leod_postprocess_nms_workspace_bytes(B, A) bytes, 0 when never needed) -- the
+ * reference has no candidate limit (boxes.py:53-80).  workspace == NULL: such an image reports det_cnt = -1. */
+long leod_postprocess_nms_workspace_bytes(int B, int A);
+int leod_postprocess_nms(float* pred, float* det_out, int* det_cnt, void* workspace, int B, int A, int nc, float conf_thre,
+                         float nms_thre, int class_agnostic, int max_det, int vanilla_limit, leod_stream_t stream);
 /* pred2label + filter_pred_boxes: det -> labels [B,max_det,8] = (0,x,y,w,h,cls,cls_conf,obj), lab_cnt[B]. */
 int leod_pseudo_filter(const float* det, const int* det_cnt, float* lab, int* lab_cnt, int B, int max_det,
                        const float* obj_thr, const float* cls_thr, int nthr, int filter_boxes, float frame_w,

@@ -163,8 +163,8 @@ struct AssignOut {
 
 #define MAXGT 128
 __global__ __launch_bounds__(256) void simota_kernel(const float* __restrict__ outputs, const float* __restrict__ labels,
-                                                     float* __restrict__ ws, AssignOut o, Levels L, int Nmax, int nc,
-                                                     float ignore_label, int cap) {
+                                                     float* __restrict__ ws, int* __restrict__ gws, AssignOut o, Levels L,
+                                                     int Nmax, int nc, float ignore_label, int cap, int cand_in_lds) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int A = L.A;
     const int b = blockIdx.x;
@@ -172,11 +172,20 @@ __global__ __launch_bounds__(256) void simota_kernel(const float* __restrict__ o
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // candidates lie within 1.5 strides of a gt centre: at most 3 x 3 anchors per gt and level, so `cap` (host: 16 per gt and
     // level, bounded by A) never binds; an overflow would be reported through status bit 2 instead of corrupting LDS
-    int* cand = reinterpret_cast<int*>(smem);               // [cap] compacted candidate anchors
+    // The candidate arrays live in LDS when they fit (every shipped configuration) and in the per-image slice of the
+    // global workspace otherwise; likewise the per-gt arrays above MAXGT label rows per frame -- the reference has no limit
+    // on either (yolo_head.py:606-700), a crowded 1 Mpx frame must not abort a training run.
+    int* gimg = gws + (long)b * (3L * cap + 7L * Nmax);
+    int* cand = cand_in_lds ? reinterpret_cast<int*>(smem) : gimg;   // [cap] compacted candidate anchors
     int* cnt = cand + cap;                                  // [cap] per-candidate match count
     int* selg = cnt + cap;                                  // [cap] the gt that selected the candidate
-    __shared__ float gtb[MAXGT][4];
-    __shared__ int gtrow[MAXGT], gtcls[MAXGT], kg[MAXGT];
+    __shared__ float gtb_s[MAXGT][4];
+    __shared__ int gtrow_s[MAXGT], gtcls_s[MAXGT], kg_s[MAXGT];
+    const bool gt_in_lds = Nmax <= MAXGT;
+    float (*gtb)[4] = gt_in_lds ? gtb_s : reinterpret_cast<float (*)[4]>(gimg + 3L * cap);
+    int* gtrow = gt_in_lds ? gtrow_s : gimg + 3L * cap + 4L * Nmax;
+    int* gtcls = gt_in_lds ? gtcls_s : gtrow + Nmax;
+    int* kg = gt_in_lds ? kg_s : gtcls + Nmax;
     __shared__ int s_nw, s_n, s_nvalid, s_npos, s_any_invalid, s_scan[5], s_nfg;
     const float* lab = labels + (long)b * Nmax * 7;
     const float* outb = outputs + (long)b * A * nch;
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(256) void simota_kernel(const float* __restrict__ o
             nw += nz; n += (nz && valid);
         }
         int nv = 0, anyinv = 0;
-        for (int r = 0; r < nw && r < MAXGT; ++r) {
+        for (int r = 0; r < nw; ++r) {
             if (lab[r * 7] != ignore_label) {
                 gtrow[nv] = r; gtcls[nv] = (int)lab[r * 7];
                 gtb[nv][0] = lab[r * 7 + 1]; gtb[nv][1] = lab[r * 7 + 2]; gtb[nv][2] = lab[r * 7 + 3]; gtb[nv][3] = lab[r * 7 + 4];
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(256) void simota_kernel(const float* __restrict__ o
         s_nw = nw; s_n = n; s_nvalid = nv; s_any_invalid = anyinv; s_npos = 0; s_nfg = 0;
     }
     __syncthreads();
-    const int nw = min(s_nw, MAXGT), nvalid = s_nvalid, n = s_n;
+    const int nw = s_nw, nvalid = s_nvalid, n = s_n;
     // ---- geometry: candidate / ignore masks, ordered compaction of candidates -----------------------
     for (int base = 0; base < A; base += 256) {
         const int a = base + tid;
@@ -452,12 +461,15 @@ __device__ __forceinline__ bool iou_gt(const float* a, const float* b, float thr
 __global__ __launch_bounds__(1024) void postprocess_nms_kernel(float* __restrict__ pred, float* __restrict__ det_out,
                                                                int* __restrict__ det_cnt, int A, int nc, int ncols,
                                                                float conf_thre, float nms_thre, int class_agnostic,
-                                                               int max_det, int vanilla_limit, int convert_boxes, int cap) {
+                                                               int max_det, int vanilla_limit, int convert_boxes, int cap,
+                                                               char* __restrict__ gws, long gws_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NW = 16;
     // cap = most candidates (score >= conf_thre) the LDS arrays hold: A when everything fits (Gen1 1680, Gen4 5040 anchors),
-    // 4096 for larger heads (1 Mpx: 20160 anchors); an image with more candidates reports det_cnt = -1
+    // 4096 for larger heads (1 Mpx: 20160 anchors).  An image with more candidates than that re-runs the compaction into
+    // its slice of the global workspace (sized for all A anchors) and sorts / suppresses there: no limit, as in the
+    // reference (boxes.py:53-80); without a workspace it reports det_cnt = -1.
     int NP2 = 1; while (NP2 < cap) NP2 <<= 1;
     float* skey = reinterpret_cast<float*>(smem);            // [NP2] scores (sorted desc)
     int* sidx = reinterpret_cast<int*>(skey + NP2);          // [NP2] anchor index
@@ -470,32 +482,47 @@ __global__ __launch_bounds__(1024) void postprocess_nms_kernel(float* __restrict
     if (tid == 0) { s_n = 0; s_keep = 0; }
     __syncthreads();
     // 1. xywh -> xyxy in place, class max, confidence mask, ordered compaction
-    for (int base = 0; base < A; base += 1024) {
-        const int a = base + tid;
-        bool ok = false; float score = 0.f;
-        if (a < A) {
-            float* p = pb + (long)a * ncols;
-            if (convert_boxes) {
-                const float cx = p[0], cy = p[1], w = p[2], h = p[3];
-                p[0] = cx - w / 2; p[1] = cy - h / 2; p[2] = cx + w / 2; p[3] = cy + h / 2;
+    auto compact = [&](bool convert, int limit) {
+        for (int base = 0; base < A; base += 1024) {
+            const int a = base + tid;
+            bool ok = false; float score = 0.f;
+            if (a < A) {
+                float* p = pb + (long)a * ncols;
+                if (convert) {
+                    const float cx = p[0], cy = p[1], w = p[2], h = p[3];
+                    p[0] = cx - w / 2; p[1] = cy - h / 2; p[2] = cx + w / 2; p[3] = cy + h / 2;
+                }
+                float cc;
+                if (nc > 0) { cc = p[5]; for (int c = 1; c < nc; ++c) cc = fmaxf(cc, p[5 + c]); } else cc = p[5];
+                score = p[4] * cc;
+                ok = score >= conf_thre;
             }
-            float cc;
-            if (nc > 0) { cc = p[5]; for (int c = 1; c < nc; ++c) cc = fmaxf(cc, p[5 + c]); } else cc = p[5];
-            score = p[4] * cc;
-            ok = score >= conf_thre;
+            const unsigned long long bal = __ballot(ok);
+            if (lane == 0) s_scan[wave] = __popcll(bal);
+            __syncthreads();
+            int off = s_n;
+            for (int w2 = 0; w2 < wave; ++w2) off += s_scan[w2];
+            if (ok) { const int j = off + __popcll(bal & ((1ull << lane) - 1)); if (j < limit) { skey[j] = score; sidx[j] = a; } }
+            __syncthreads();
+            if (tid == 0) { int t = 0; for (int w2 = 0; w2 < NW; ++w2) t += s_scan[w2]; s_n += t; }
+            __syncthreads();
         }
-        const unsigned long long bal = __ballot(ok);
-        if (lane == 0) s_scan[wave] = __popcll(bal);
-        __syncthreads();
-        int off = s_n;
-        for (int w2 = 0; w2 < wave; ++w2) off += s_scan[w2];
-        if (ok) { const int j = off + __popcll(bal & ((1ull << lane) - 1)); if (j < cap) { skey[j] = score; sidx[j] = a; } }
-        __syncthreads();
-        if (tid == 0) { int t = 0; for (int w2 = 0; w2 < NW; ++w2) t += s_scan[w2]; s_n += t; }
-        __syncthreads();
-    }
+    };
+    compact(convert_boxes != 0, cap);
     const int n = s_n;
-    if (n > cap) { if (tid == 0) det_cnt[b] = -1; return; }      // boxes were converted in place like the reference does
+    if (n > cap) {                                       // boxes were converted in place like the reference does
+        if (!gws) { if (tid == 0) det_cnt[b] = -1; return; }
+        int AP2 = 1; while (AP2 < A) AP2 <<= 1;
+        char* g = gws + (long)b * gws_stride;
+        skey = reinterpret_cast<float*>(g);
+        sidx = reinterpret_cast<int*>(skey + AP2);
+        sbox = reinterpret_cast<float*>(sidx + AP2);
+        removed = reinterpret_cast<unsigned char*>(sbox + 4 * (size_t)A);
+        __syncthreads();
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        compact(false, A);
+    }
     if (n == 0) { if (tid == 0) det_cnt[b] = 0; return; }
     int np2 = 1; while (np2 < n) np2 <<= 1;
     for (int j = n + tid; j < np2; j += 1024) { skey[j] = -INFINITY; sidx[j] = 0x7fffffff; }
@@ -693,8 +720,12 @@ LEOD_API int leod_head_pred_bwd(const float* d_raw, const float* cls_feat, const
     return leod_launch_status();
 }
 
-// workspace floats needed by leod_simota_assign
-LEOD_API long leod_simota_workspace_floats(int B, int Nmax, int A) { return 2L * B * Nmax * A; }
+// candidates lie within 1.5 strides of a gt centre: at most 3 x 3 anchors per gt and level; 16 leaves slack
+static inline int simota_cap(int Nmax, int nlv, int A) { return (int)max(1L, min((long)A, 16L * nlv * Nmax)); }
+
+// workspace floats needed by leod_simota_assign: cost + IoU matrices [B][2][Nmax][A], then (as ints) the per-image candidate
+// and gt arrays used when they do not fit in LDS (3 * cap + 7 * Nmax per image; cap <= A)
+LEOD_API long leod_simota_workspace_floats(int B, int Nmax, int A) { return 2L * B * Nmax * A + (long)B * (3L * A + 7L * Nmax); }
 
 // totals[3] (int, zeroed by the caller): sum num_fg, sum num_gt, status bits (1 = a gt had no candidate anchor)
 LEOD_API int leod_simota_assign(const float* outputs, const float* labels, float* workspace, unsigned char* fg_mask,
@@ -702,17 +733,19 @@ LEOD_API int leod_simota_assign(const float* outputs, const float* labels, float
                                 int* num_fg_img, int* totals, int B, int Nmax, int nc, int nlv, const int* hs, const int* wsz,
                                 const int* strides, float ignore_label, hipStream_t stream) {
     if (!outputs || !labels || !workspace || !fg_mask || !ignore_mask || !matched_row || !matched_valid_idx || !pred_iou ||
-        !num_fg_img || !totals || nlv < 1 || nlv > MAXLVL || Nmax > MAXGT)
+        !num_fg_img || !totals || nlv < 1 || nlv > MAXLVL || Nmax < 1)
         return LEOD_ERR_ARG;
     if (B == 0) return LEOD_OK;
     const Levels L = make_levels(nlv, hs, wsz, strides);
-    const int cap = (int)min((long)L.A, 16L * nlv * min(Nmax, MAXGT));
-    const size_t shm = (size_t)max(cap, 1) * 3 * sizeof(int);
-    if (shm > 120 * 1024) return LEOD_ERR_UNSUPPORTED;
+    const int cap = simota_cap(Nmax, nlv, L.A);
+    const int cand_in_lds = (size_t)cap * 3 * sizeof(int) <= 120 * 1024;
+    const size_t shm = cand_in_lds ? (size_t)cap * 3 * sizeof(int) : 16;
+    int* gws = reinterpret_cast<int*>(workspace + 2L * B * Nmax * L.A);
     AssignOut o{fg_mask, ignore_mask, matched_row, matched_valid_idx, pred_iou, num_fg_img, totals};
     static int shm_set = 0;     // raise the dynamic-LDS limit once (not a stream operation; keeps graph capture clean)
     if (shm_set < (int)shm) { (void)hipFuncSetAttribute((const void*)simota_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); shm_set = (int)shm; }
-    hipLaunchKernelGGL(simota_kernel, dim3(B), dim3(256), shm, stream, outputs, labels, workspace, o, L, Nmax, nc, ignore_label, cap);
+    hipLaunchKernelGGL(simota_kernel, dim3(B), dim3(256), shm, stream, outputs, labels, workspace, gws, o, L, Nmax, nc, ignore_label,
+                       cap, cand_in_lds);
     return leod_launch_status();
 }
 
@@ -735,18 +768,28 @@ LEOD_API int leod_yolox_loss(const float* outputs, const float* labels, const un
 // postprocess (boxes.py:32-86): nc > 0: pred rows are (cx,cy,w,h,obj,cls_0..cls_nc-1), boxes converted in place.
 // nc == 0: rows are already (x1,y1,x2,y2,obj,cls_conf,cls_id) (TTA merge, tta.py:18-61 / pseudo_labeler.py:37-91).
 // vanilla_limit: box-element count above which torchvision loops per class (20000 on GPU, 4000 on CPU).
-LEOD_API int leod_postprocess_nms(float* pred, float* det_out, int* det_cnt, int B, int A, int nc, float conf_thre,
+static inline size_t nms_array_bytes(int cap_) { int np2 = 1; while (np2 < cap_) np2 <<= 1; return (size_t)np2 * 8 + (size_t)cap_ * 17 + 16; }
+
+// bytes of the optional global workspace of leod_postprocess_nms: 0 when the candidate arrays of all A anchors fit in LDS
+// (Gen1 / Gen4 heads), else one slice per image for the images that exceed the 4096-candidate LDS tier
+LEOD_API long leod_postprocess_nms_workspace_bytes(int B, int A) {
+    if (A <= 0 || nms_array_bytes(A) <= 156 * 1024) return 0;
+    return (long)B * (long)((nms_array_bytes(A) + 255) / 256 * 256);
+}
+
+LEOD_API int leod_postprocess_nms(float* pred, float* det_out, int* det_cnt, void* workspace, int B, int A, int nc, float conf_thre,
                                   float nms_thre, int class_agnostic, int max_det, int vanilla_limit, hipStream_t stream) {
     if (!pred || !det_out || !det_cnt || A <= 0) return LEOD_ERR_ARG;
     if (B == 0) return LEOD_OK;
-    auto lds_bytes = [](int cap_) { int np2 = 1; while (np2 < cap_) np2 <<= 1; return (size_t)np2 * 8 + (size_t)cap_ * 17 + 16; };
+    auto lds_bytes = nms_array_bytes;
     const int cap = lds_bytes(A) <= 156 * 1024 ? A : 4096;
+    const long gstride = (long)((nms_array_bytes(A) + 255) / 256 * 256);
     const size_t shm = lds_bytes(cap);
     static int shm_set = 0;
     if (shm_set < (int)shm) { (void)hipFuncSetAttribute((const void*)postprocess_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); shm_set = (int)shm; }
     const int ncols = nc > 0 ? 5 + nc : 7;
     hipLaunchKernelGGL(postprocess_nms_kernel, dim3(B), dim3(1024), shm, stream, pred, det_out, det_cnt, A, nc, ncols, conf_thre,
-                       nms_thre, class_agnostic, max_det, vanilla_limit, nc > 0 ? 1 : 0, cap);
+                       nms_thre, class_agnostic, max_det, vanilla_limit, nc > 0 ? 1 : 0, cap, static_cast<char*>(workspace), gstride);
     return leod_launch_status();
 }
 

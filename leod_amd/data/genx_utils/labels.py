@@ -254,6 +254,44 @@ class ObjectLabels:
         return out
 
 
+class ObjectLabelFactory:
+    """All boxes of one recording + the start offset of every labelled frame (reference: labels.py:188-246).
+    ``factory[i]`` = the boxes of the i-th labelled frame as a fresh ``ObjectLabels`` (rescaled by 1 / downsample_factor
+    when the recording is loaded at half resolution).  Boxes are clamped to the frame once, at construction."""
+
+    def __init__(self, object_labels: th.Tensor, objframe_idx_2_label_idx: th.Tensor, input_size_hw: Tuple[int, int],
+                 downsample_factor: Optional[float] = None):
+        assert objframe_idx_2_label_idx.dtype == th.int64 and objframe_idx_2_label_idx.dim() == 1
+        assert downsample_factor is None or downsample_factor > 1
+        self._all = ObjectLabels(object_labels, tuple(input_size_hw))
+        self._all.clamp_to_frame_()
+        self.object_labels = self._all.object_labels
+        self.input_size_hw = tuple(input_size_hw)
+        self.starts = objframe_idx_2_label_idx.tolist()
+        self.objframe_idx_2_label_idx = objframe_idx_2_label_idx
+        self.downsample_factor = downsample_factor
+
+    @staticmethod
+    def from_structured_array(object_labels: np.ndarray, objframe_idx_2_label_idx: np.ndarray, input_size_hw: Tuple[int, int],
+                              downsample_factor: Optional[float] = None) -> 'ObjectLabelFactory':
+        rows = ObjectLabels.from_structured_array(object_labels, tuple(input_size_hw)).object_labels
+        return ObjectLabelFactory(rows, th.from_numpy(objframe_idx_2_label_idx.astype('int64')), input_size_hw, downsample_factor)
+
+    def __len__(self):
+        return len(self.starts)
+
+    def __getitem__(self, item: int) -> ObjectLabels:
+        n = len(self)
+        assert 0 <= item < n
+        lo = self.starts[item]
+        hi = self.object_labels.shape[0] if item == n - 1 else self.starts[item + 1]
+        assert hi > lo
+        out = ObjectLabels(self.object_labels[lo:hi].clone(), self.input_size_hw)
+        if self.downsample_factor is not None:
+            out.scale_(scaling_multiplier=1 / self.downsample_factor)
+        return out
+
+
 class SparselyBatchedObjectLabels:
     """One timestep of a batch: a list (len B) of ObjectLabels or None."""
 
@@ -288,6 +326,9 @@ class SparselyBatchedObjectLabels:
         for l in self.sparse_object_labels_batch:
             if l is not None:
                 l.flip_lr_()
+
+    def time_flip_(self):
+        self.sparse_object_labels_batch.reverse()
 
     def to(self, *args, **kwargs):
         for l in self.sparse_object_labels_batch:

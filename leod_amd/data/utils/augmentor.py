@@ -163,11 +163,31 @@ class RandomSpatialAugmentorGenX:
         st.zoom_in_factor = f
 
 
-    def augment_sample_labels(self, labels: Sequence[Optional[ObjectLabels]]) -> AugmentationState:
+    def __call__(self, data_dict: Dict[Any, Any]) -> Dict[Any, Any]:
+        """One loader sample (reference ``__call__``, augmentor.py:455-476): the labels (visible and withheld) are transformed
+        here on the host; the event frames are NOT touched -- the drawn state rides along under ``DataType.AUGM_STATE`` and
+        the whole batch is flipped / zoomed by one ``leod_augment_u8`` launch on the device (``augment_events``)."""
+        from leod_amd.data.utils.types import DataType
+        primary = data_dict[DataType.OBJLABELS_SEQ]
+        others = [data_dict[k] for k in (DataType.SKIPPED_OBJLABELS_SEQ,) if k in data_dict]
+        # the two containers of the padding sample are one object: transform it once
+        others = [o for o in others if o is not primary]
+        state = self.augment_sample_labels(primary.sparse_object_labels_batch,
+                                           extra=[o.sparse_object_labels_batch for o in others])
+        if state.zoom_in.active:                     # boxes outside the zoom window are gone: empty frames become None
+            for c in [primary] + others:
+                c.sparse_object_labels_batch[:] = [None if (l is not None and len(l) == 0) else l for l in c.sparse_object_labels_batch]
+        data_dict[DataType.AUGM_STATE] = state
+        return data_dict
+
+    def augment_sample_labels(self, labels: Sequence[Optional[ObjectLabels]],
+                              extra: Sequence[Sequence[Optional[ObjectLabels]]] = ()) -> AugmentationState:
         """Everything ``__call__`` of the reference does for ONE loader sample except the pixel work (augmentor.py:455-476,
         in that order): draw the state, flip the labels, sample the zoom-in window from the (flipped) labels, transform
-        the labels.  Returns a copy of the resulting state; feed the states of a batch to ``augment_events``."""
+        the labels (``extra``: further label lists of the sample that follow the same transform, e.g. the withheld labels).
+        Returns a copy of the resulting state; feed the states of a batch to ``augment_events``."""
         import copy
+        every = [labels] + [list_ for list_ in extra]
         if self.automatic_randomization:
             self.randomize_augmentation()
         st = self.augm_state
@@ -175,13 +195,13 @@ class RandomSpatialAugmentorGenX:
         if st.rotation.active:
             raise NotImplementedError('rotation augmentation (probability 0 in every shipped config)')
         if st.apply_h_flip:
-            for lab in labels:
+            for lab in (l for list_ in every for l in list_):
                 if lab is not None:
                     lab.flip_lr_()
         if st.zoom_in.active:
             self.sample_zoom_in(labels)
             if st.zoom_in.active:
-                for lab in labels:
+                for lab in (l for list_ in every for l in list_):
                     if lab is not None:
                         lab.zoom_in_and_rescale_((st.zoom_in.x0, st.zoom_in.y0), st.zoom_in.zoom_in_factor)
         if st.zoom_out.active:
@@ -189,7 +209,7 @@ class RandomSpatialAugmentorGenX:
             if st.zoom_out.zoom_out_factor == 1:
                 st.zoom_out.active, st.zoom_out.x0, st.zoom_out.y0 = False, 0, 0
             else:
-                for lab in labels:
+                for lab in (l for list_ in every for l in list_):
                     if lab is not None:
                         lab.zoom_out_and_rescale_((st.zoom_out.x0, st.zoom_out.y0), st.zoom_out.zoom_out_factor)
         return copy.deepcopy(st)

@@ -1,0 +1,147 @@
+"""On-disk layout of a (pseudo-)labelled recording and the frame store behind it (the interface of the reference's
+data/utils/misc.py:11-99):
+
+    <split>/<recording>/
+        event_representations_v2/stacked_histogram_dt=50_nbins=10/
+            event_representations.h5 | event_representations_ds2_nearest.h5    'data' [N,20,H,W] uint8 (blosc-zstd HDF5)
+            event_representations.npy | event_representations_ds2_nearest.npy   the same array as a raw .npy (memory-mapped)
+            objframe_idx_2_repr_idx.npy                                         int64 [n_labelled_frames]
+        labels_v2/labels.npz                                                    labels (BBOX_DTYPE), objframe_idx_2_label_idx
+
+The reference reads the frames through h5py + hdf5plugin.  Neither is in the MI355X image, and a compressed HDF5 chunk
+store cannot feed >= 1.5 GB/s of uint8 voxels per GPU from Python anyway, so the frame store has two backends behind one
+interface: ``RawFrames`` (np.load(mmap_mode='r') of the .npy twin: page-cache reads straight into pinned batches) and
+``H5Frames`` (import-guarded h5py).  ``tools/h5_to_npy.py`` writes the twin once per recording."""
+import os
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+EV_REPR_NAME = 'stacked_histogram_dt=50_nbins=10'
+
+
+def get_labels_npz_fn(seq_dir: str) -> str:
+    return os.path.join(seq_dir, 'labels_v2', 'labels.npz')
+
+
+def read_npz_labels(label_fn: str) -> Tuple[np.ndarray, np.ndarray]:
+    if 'labels_v2' not in label_fn:
+        label_fn = get_labels_npz_fn(label_fn)
+    with np.load(label_fn) as z:
+        return z['labels'], z['objframe_idx_2_label_idx']
+
+
+def get_ev_dir(seq_dir: str) -> str:
+    return os.path.join(seq_dir, 'event_representations_v2', EV_REPR_NAME)
+
+
+def get_objframe_idx_2_repr_idx_fn(ev_dir: str) -> str:
+    if 'event_representations_v2' not in ev_dir:
+        ev_dir = get_ev_dir(ev_dir)
+    return os.path.join(ev_dir, 'objframe_idx_2_repr_idx.npy')
+
+
+def read_objframe_idx_2_repr_idx(npy_fn: str) -> np.ndarray:
+    if 'event_representations_v2' not in npy_fn:
+        npy_fn = get_objframe_idx_2_repr_idx_fn(npy_fn)
+    return np.load(npy_fn)
+
+
+def get_ev_h5_fn(ev_dir: str, dst_name: Optional[str] = None) -> str:
+    if 'event_representations_v2' not in ev_dir:
+        ev_dir = get_ev_dir(ev_dir)
+    if dst_name is None:
+        dst_name = 'gen1' if 'gen1' in ev_dir else 'gen4'
+    name = 'event_representations.h5' if dst_name == 'gen1' else 'event_representations_ds2_nearest.h5'
+    return os.path.join(ev_dir, name)
+
+
+def get_ev_raw_fn(ev_dir: str, dst_name: Optional[str] = None) -> str:
+    """The raw twin of the HDF5 frame file (same stem, ``.npy``)."""
+    return os.path.splitext(get_ev_h5_fn(ev_dir, dst_name))[0] + '.npy'
+
+
+def resolve_link(fn: str) -> str:
+    while os.path.islink(fn):
+        fn = os.readlink(fn)
+    return fn
+
+
+class RawFrames:
+    """[N,20,H,W] uint8 frames of one recording, memory-mapped from a .npy file."""
+
+    def __init__(self, fn: str):
+        self.fn = fn
+        self.data = np.load(fn, mmap_mode='r')
+        assert self.data.dtype == np.uint8 and self.data.ndim == 4, (fn, self.data.dtype, self.data.shape)
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    def __len__(self):
+        return self.data.shape[0]
+
+    def read(self, start: int, end: int, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Frames [start, end) -> ``out`` (e.g. a slice of a pinned batch) or a new array."""
+        if out is None:
+            return np.array(self.data[start:end])
+        np.copyto(out, self.data[start:end])
+        return out
+
+    def close(self):
+        self.data = None
+
+
+class H5Frames:
+    """Same interface over the reference's HDF5 files (dataset 'data'); needs h5py (+ hdf5plugin for blosc chunks)."""
+
+    def __init__(self, fn: str):
+        try:
+            import h5py
+        except ImportError as e:                                  # pragma: no cover
+            raise ImportError(f'{fn}: reading HDF5 event representations needs h5py; convert the recording once with '
+                              'tools/h5_to_npy.py and the raw twin is used instead') from e
+        try:                                                      # pragma: no cover
+            import hdf5plugin  # noqa: F401
+        except ImportError:
+            pass
+        self.fn = fn
+        self.h5f = h5py.File(fn, 'r')
+        self.data = self.h5f['data']
+
+    @property
+    def shape(self):
+        return tuple(self.data.shape)
+
+    def __len__(self):
+        return self.data.shape[0]
+
+    def read(self, start: int, end: int, out: Optional[np.ndarray] = None) -> np.ndarray:
+        if out is None:
+            return self.data[start:end]
+        self.data.read_direct(out, np.s_[start:end])
+        return out
+
+    def close(self):
+        self.h5f.close()
+
+
+def open_ev_repr(seq_or_ev_dir: str, dst_name: Optional[str] = None):
+    """Frame store of a recording: the raw .npy twin when it exists, else the HDF5 file."""
+    raw = resolve_link(get_ev_raw_fn(seq_or_ev_dir, dst_name))
+    if os.path.exists(raw):
+        return RawFrames(raw)
+    h5 = resolve_link(get_ev_h5_fn(seq_or_ev_dir, dst_name))
+    if os.path.exists(h5):
+        return H5Frames(h5)
+    raise FileNotFoundError(f'no event representation under {seq_or_ev_dir} (looked for {raw} and {h5})')
+
+
+def ev_repr_files(seq_or_ev_dir: str, dst_name: Optional[str] = None) -> List[str]:
+    """The frame files that exist for a recording (link targets resolved), raw twin first."""
+    out = []
+    for fn in (get_ev_raw_fn(seq_or_ev_dir, dst_name), get_ev_h5_fn(seq_or_ev_dir, dst_name)):
+        if os.path.lexists(fn):
+            out.append(fn)
+    return out

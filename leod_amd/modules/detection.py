@@ -63,6 +63,8 @@ class Module(_Base):
         self.time_batched = os.environ.get('LEOD_SCHEDULE', 'batched') == 'batched'
         self.wgrad_side = os.environ.get('LEOD_WGRAD_STREAM', '1') == '1'
         self._row_idx_cache: Dict[Any, th.Tensor] = {}
+        self._pin_ring: List[Any] = []
+        self._pin_next = 0
 
     # ---- Lightning-compatible plumbing -----------------------------------------------------------------
     def setup(self, stage: Optional[str] = None) -> None:
@@ -174,6 +176,23 @@ class Module(_Base):
         rnn.save_states_and_detach(worker_id=worker_id, states=states)
         return feats, obj_labels, where, B
 
+    def _upload_pinned(self, t: th.Tensor, device) -> th.Tensor:
+        """Host tensor -> device through a ring of 4 pinned staging buffers (asynchronous copy on the launch stream; a
+        buffer is reused only after the copy that read it has completed -- normally three steps earlier)."""
+        n = t.numel()
+        if not self._pin_ring or self._pin_ring[0][0].numel() < n or self._pin_ring[0][0].dtype != t.dtype:
+            self._pin_ring = [[th.empty(max(2 * n, 4096), dtype=t.dtype).pin_memory(), None] for _ in range(4)]
+            self._pin_next = 0
+        slot = self._pin_ring[self._pin_next]
+        self._pin_next = (self._pin_next + 1) % len(self._pin_ring)
+        if slot[1] is not None:
+            slot[1].synchronize()
+        slot[0][:n].copy_(t.reshape(-1))
+        out = slot[0][:n].to(device, non_blocking=True).view(t.shape)
+        slot[1] = th.cuda.Event()
+        slot[1].record()
+        return out
+
     def _row_index(self, rows, device):
         key = (rows, str(device))
         if key not in self._row_idx_cache:
@@ -195,7 +214,7 @@ class Module(_Base):
         assert len(obj_labels) > 0
         labels_yolox = ObjectLabels.get_labels_as_batched_tensor(obj_label_list=obj_labels, format_='yolox')
         if labels_yolox.device != device:            # host labels: pinned + asynchronous, the launch thread never waits for the GPU
-            labels_yolox = labels_yolox.pin_memory().to(device=device, non_blocking=True)
+            labels_yolox = self._upload_pinned(labels_yolox, device)
         predictions, losses = self.mdl.forward_detect(backbone_features=feats, targets=labels_yolox.to(torch.float32))
         assert losses is not None and 'loss' in losses
         # the weight-gradient kernels of the backward pass that follows run on a side HIP stream until the optimiser joins it

@@ -16,6 +16,7 @@ import torch
 import torch as th
 
 from leod_amd.data.genx_utils.labels import ObjectLabels, SparselyBatchedObjectLabels, BBOX_DTYPE  # noqa: F401
+from leod_amd.data.utils import misc
 from leod_amd.data.utils.types import DataType
 from leod_amd.models.detection.yolox.utils.boxes import postprocess
 from .detection import Module
@@ -74,16 +75,15 @@ class EventSeqData:
             if frame_idx < 0 or label is None or len(label) == 0:
                 continue
             assert not is_padded_mask[tidx]
-            if self.scale_ratio != 1:
-                label.object_labels[:, 1:5] *= self.scale_ratio
-                label.input_size_hw = tuple(int(s * self.scale_ratio) for s in label.input_size_hw)
+            label.scale_(self.scale_ratio)  # labels are stored at the recording's native resolution (reference :139)
             if frame_idx in self.frame_idx_2_labels:
                 if bool(label.is_gt_label().any()):
-                    continue               # GT is stored once
+                    continue               # GT is stored once (a differing copy only draws a warning in the reference, :144-152)
                 self.frame_idx_2_labels[frame_idx] = self.frame_idx_2_labels[frame_idx] + label
             else:
                 self.frame_idx_2_labels[frame_idx] = label
 
+    @property
     def eoe(self) -> bool:
         return self._eoe
 
@@ -168,16 +168,45 @@ class EventSeqData:
         labels = np.concatenate(labels) if labels else np.zeros((0,), dtype=BBOX_DTYPE)
         return labels, np.array(f2l, dtype=np.int64), np.array(f2r, dtype=np.int64)
 
-    def save(self, save_dir: str, dst_name: str, num_frames: int) -> str:
-        """Write labels_v2/labels.npz + objframe_idx_2_repr_idx.npy; refuses to overwrite (reference :366-367)."""
-        self._aggregate_results(num_frames)
+    def save(self, save_dir: str, dst_name: str, num_frames: Optional[int] = None) -> str:
+        """Write the recording into the new dataset tree exactly where the reference's loaders look for it (:335-397):
+
+            save_dir/<recording>/event_representations_v2/<ev_repr_name>/<frame file>   soft link to the source recording's
+            save_dir/<recording>/event_representations_v2/<ev_repr_name>/objframe_idx_2_repr_idx.npy
+            save_dir/<recording>/labels_v2/labels.npz                                   labels, objframe_idx_2_label_idx
+            dirname(save_dir)/{val,test}                                                soft links to the source splits
+
+        Refuses to overwrite (``os.makedirs(exist_ok=False)``).  ``num_frames`` defaults to the frame count of the source
+        recording's frame file (HDF5 or its raw .npy twin)."""
+        assert dst_name in ('gen1', 'gen4')
+        assert 'train' in save_dir and dst_name in save_dir
+        assert 'train' in self.path and dst_name in self.path
+        path = osp.normpath(self.path)
+        base_dir = osp.dirname(osp.dirname(path))
+        sources = [(fn, misc.resolve_link(fn)) for fn in misc.ev_repr_files(path, dst_name)]
+        if num_frames is None:
+            frames = misc.open_ev_repr(path, dst_name)
+            num_frames = len(frames)
+            frames.close()
+        new_base_dir = osp.dirname(osp.normpath(save_dir))
+        new_seq_dir = osp.join(save_dir, osp.basename(path))
+        new_ev_dir = misc.get_ev_dir(new_seq_dir)
+        new_labels_npz_fn = misc.get_labels_npz_fn(new_seq_dir)
+        os.makedirs(new_ev_dir, exist_ok=False)
+        os.makedirs(osp.dirname(new_labels_npz_fn), exist_ok=False)
+        for fn, target in sources:                      # the frames are linked, never copied
+            os.symlink(osp.abspath(target), osp.join(new_ev_dir, osp.basename(fn)))
+        self._aggregate_results(num_frames=num_frames)
         self._track_filter()
         labels, f2l, f2r = self._summarize()
-        seq_dir = osp.join(save_dir, osp.basename(osp.normpath(self.path)))
-        os.makedirs(osp.join(seq_dir, 'labels_v2'), exist_ok=False)
-        np.savez(osp.join(seq_dir, 'labels_v2', 'labels.npz'), labels=labels, objframe_idx_2_label_idx=f2l)
-        np.save(osp.join(seq_dir, 'objframe_idx_2_repr_idx.npy'), f2r)
-        return seq_dir
+        np.save(misc.get_objframe_idx_2_repr_idx_fn(new_ev_dir), f2r)
+        np.savez(new_labels_npz_fn, labels=labels, objframe_idx_2_label_idx=f2l)
+        if not osp.islink(osp.join(new_base_dir, 'val')):          # link the evaluation splits once, for completeness
+            for split in ('val', 'test'):
+                os.symlink(osp.abspath(misc.resolve_link(osp.join(base_dir, split))), osp.join(new_base_dir, split))
+        else:
+            assert osp.islink(osp.join(new_base_dir, 'test'))
+        return new_seq_dir
 
 
 class PseudoLabeler(Module):

@@ -468,18 +468,19 @@ def postprocess_nms(pred, num_classes, conf_thre, nms_thre, class_agnostic=False
     max_det = A if max_det is None else max_det
     det = torch.empty((B, max_det, 7), dtype=F32, device=pred.device)
     cnt = torch.empty((B,), dtype=torch.int32, device=pred.device)
-    check(_l().leod_postprocess_nms(_p(pred), _p(det), _p(cnt), B, A, num_classes, float(conf_thre), float(nms_thre),
+    nws = int(_l().leod_postprocess_nms_workspace_bytes(B, A))
+    ws = torch.empty(nws, dtype=torch.uint8, device=pred.device) if nws else None
+    check(_l().leod_postprocess_nms(_p(pred), _p(det), _p(cnt), _p(ws), B, A, num_classes, float(conf_thre), float(nms_thre),
                                      1 if class_agnostic else 0, max_det, vanilla_limit, _stream()), 'postprocess_nms')
     return det, cnt
 
 
 def host_counts(cnt, what='postprocess_nms'):
-    """Per-image counts on the host (one sync).  A negative count is the kernels' overflow report: more candidates above the
-    confidence threshold than the workgroup's LDS arrays hold (only possible for heads with more than 5040 anchors)."""
+    """Per-image counts on the host (one sync).  A negative count can only come from calling the C ABI without the NMS
+    workspace (``ops.postprocess_nms`` always passes it)."""
     counts = cnt.tolist()
     if counts and min(counts) < 0:
-        raise LeodHipError(f'{what}: image {counts.index(min(counts))} has more than 4096 candidates above conf_thre '
-                           f'(anchor count too large for the single-workgroup NMS); raise conf_thre')
+        raise LeodHipError(f'{what}: image {counts.index(min(counts))} overflowed the LDS candidate arrays and no workspace was given')
     return counts
 
 

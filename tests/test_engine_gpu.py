@@ -331,7 +331,7 @@ def test_full_size_training_step_vs_oracle(gpu, manifest):
     ref_labels = [[None if l is None else l.object_labels.clone() for l in seq[t]] for t in range(21)]
     res = fit_step(mod, opt, lrs, batch)
     otr = ot.OracleTrainer(sd, ot.model_cfg(48, 24, 0.33, (8, 10)))
-    ref, _ = otr.step(ev.cpu(), ref_labels, first)
+    ref, ref_grads = otr.step(ev.cpu(), ref_labels, first)
     got = {k: float(res['log_dict'][f'train/{k}'].detach()) for k in KEYS}
     assert got['num_fg'] == pytest.approx(ref['num_fg'], rel=1e-6), 'SimOTA foreground count differs'
     for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss'):
@@ -339,10 +339,13 @@ def test_full_size_training_step_vs_oracle(gpu, manifest):
     params = dict(mod.mdl.named_parameters())
     rng = np.random.RandomState(0)
     for k in [otr.param_keys[i] for i in rng.choice(len(otr.param_keys), 40, replace=False)]:
+        # after the optimiser kernel .grad holds the value-clipped gradient, which is what the oracle returns
+        g, gr = params[k].grad.detach().cpu().numpy().ravel(), ref_grads[k].numpy().ravel()
+        np.testing.assert_allclose(g, gr, rtol=3e-3, atol=3e-3 * float(np.abs(gr).max()) + 1e-8, err_msg=f'grad {k}')
+        # parameters: lr0 = 1e-5, Adam's first step moves every element by ~lr0 * sign(g); an element whose gradient is pure
+        # rounding noise (e.g. the key part of a qkv bias: softmax is shift-invariant) may go the other way: <= 2 * lr0 apart
         a, b = params[k].detach().cpu().numpy().ravel(), otr.sd[k].detach().numpy().ravel()
-        d = np.abs(a - b)
-        # lr0 = 1e-5: an element whose noise-level gradient changes sign moves by up to 2 * lr0
-        assert d.max() < 2.5e-5 and (d > 1e-6 + 1e-4 * np.abs(b)).mean() < 2e-2, k
+        assert np.abs(a - b).max() < 2.5e-5, k
     states = mod.mode_2_rnn_states[Mode.TRAIN].get_states(0)
     for (h, c), (rh, rc) in zip(states, otr.states):
         np.testing.assert_allclose(c.cpu().numpy(), rc.numpy(), rtol=2e-4, atol=2e-5)

@@ -487,26 +487,67 @@ def test_postprocess_full_size(ops, seed, limit):
 
 
 def test_postprocess_1mpx_head(ops):
-    """20160 anchors (768x1280): the workgroup keeps up to 4096 candidates in LDS -- exact against the oracle below that,
-    a loud error (negative count -> LeodHipError, also through the pseudo-label filter) above it."""
-    from leod_amd._lib import LeodHipError
+    """20160 anchors (768x1280): the workgroup keeps up to 4096 candidates in LDS; an image with more sorts and suppresses in
+    its slice of the global workspace -- exact against the oracle on both sides of that boundary and in both torchvision
+    regimes (coordinate trick up to 5000 boxes, per-class loop above).  No candidate limit, like the reference."""
+    from leod_amd._lib import LeodHipError, lib
     from leod_amd.ops import host_counts
     g = torch.Generator().manual_seed(3)
     A, B, nc = 20160, 3, 3
     pred = torch.cat([torch.rand(B, A, 2, generator=g) * torch.tensor([1270., 710.]), 8 + 60 * torch.rand(B, A, 2, generator=g),
                       torch.rand(B, A, 1, generator=g), torch.rand(B, A, nc, generator=g)], -1)
-    conf = 0.75                                            # ~ 8 % of the anchors: 1500-1800 candidates per image
-    ref = op.postprocess(pred.clone(), nc, conf, 0.45, pad=torch.zeros((0, 7)), device_semantics='gpu')
-    det, cnt = ops.postprocess_nms(pred.to(DEV), nc, conf, 0.45, max_det=4096)
-    assert 0 < int(cnt.min())
-    _check_dets(det, cnt, ref)
-    det, cnt = ops.postprocess_nms(pred.to(DEV), nc, 0.1, 0.45, max_det=4096)       # > 4096 candidates
-    assert [int(c) for c in cnt.cpu()] == [-1] * B
+    # candidates per image: ~1700 (LDS tier), ~4200 (workspace tier, coordinate trick), ~6300 and ~17200 (per-class regime)
+    for conf in (0.75, 0.6, 0.5, 0.1):
+        ref = op.postprocess(pred.clone(), nc, conf, 0.45, pad=torch.zeros((0, 7)), device_semantics='gpu')
+        det, cnt = ops.postprocess_nms(pred.to(DEV), nc, conf, 0.45)
+        assert 0 < int(cnt.min())
+        _check_dets(det, cnt, ref)
+    # the raw C ABI without a workspace reports the overflow instead of truncating
+    p = pred.to(DEV)
+    det = torch.empty((B, 4096, 7), device=DEV)
+    cnt = torch.empty((B,), dtype=torch.int32, device=DEV)
+    rc = lib().leod_postprocess_nms(p.data_ptr(), det.data_ptr(), cnt.data_ptr(), None, B, A, nc, 0.1, 0.45, 0, 4096, 20000,
+                                    torch.cuda.current_stream().cuda_stream)
+    assert rc == 0 and [int(c) for c in cnt.cpu()] == [-1] * B
     with pytest.raises(LeodHipError):
         host_counts(cnt)
     lab, lcnt = ops.pseudo_filter(det, cnt, 0.5, 0.5, True, (720, 1280))
     with pytest.raises(LeodHipError):
         host_counts(lcnt, 'pred2label')
+
+
+@pytest.mark.parametrize('geom,n_gt', [('gen1', 150), ('1mpx', 260)])
+def test_simota_crowded_frame_beyond_lds_tiers(ops, geom, n_gt):
+    """More boxes per frame than the per-gt LDS arrays hold (128) and, on the 1 Mpx head, more candidate anchors than the LDS
+    candidate arrays hold (10240): the assignment and the losses come out of the workspace tier, exact against the oracle --
+    the reference has no limit on boxes per frame (yolo_head.py:606-700)."""
+    (Hp, Wp), frame_hw, nc = HEAD_GEOMS[geom]
+    hws, strides = [(Hp // s_, Wp // s_) for s_ in (8, 16, 32)], (8, 16, 32)
+    gx, gy, gs = oh.make_grids(hws, strides)
+    A, B = gx.numel(), 2
+    g = torch.Generator().manual_seed(n_gt)
+    outputs = torch.cat([torch.stack([(gx + 0.5) * gs, (gy + 0.5) * gs, gs * 3, gs * 2.5], 1)[None].repeat(B, 1, 1)
+                         + torch.randn(B, A, 4, generator=g) * 2, torch.randn(B, A, 1 + nc, generator=g) * 2], -1)
+    tg = torch.zeros(B, n_gt, 7)
+    for b in range(B):
+        n = n_gt - 9 * b
+        wh = 12 + 50 * torch.rand(n, 2, generator=g)
+        c = wh / 2 + torch.rand(n, 2, generator=g) * (torch.tensor([frame_hw[1], frame_hw[0]]) - 1 - wh)
+        tg[b, :n] = torch.cat([torch.randint(0, nc, (n, 1), generator=g).float(), c, wh, torch.ones(n, 2)], 1)
+    tg[1, 5, 0] = 1024                                   # one ignore box: the _w_ignore path
+    ref = oh.get_losses(gx, gy, gs, tg.clone(), outputs.clone(), num_classes=nc, return_assign=True)
+    od, td = outputs.to(DEV), tg.to(DEV)
+    asg = ops.simota_assign(od, td, hws, strides)
+    assert int(asg['totals'][2]) & 2 == 0
+    assert np.array_equal(asg['fg_mask'].cpu().numpy().astype(bool), ref['_fg_mask'].numpy())
+    assert np.array_equal(asg['ignore_mask'].cpu().numpy().astype(bool), ref['_ignore_mask'].numpy())
+    for b in range(B):
+        r, fg = ref['_assign'][b], ref['_fg_mask'][b]
+        assert int(asg['num_fg_img'][b]) == r['num_fg'] > n_gt
+        assert np.array_equal(asg['matched_valid_idx'][b].cpu()[fg].numpy(), r['matched_gt_inds'].numpy())
+    losses, _ = ops.yolox_loss(od, td, asg, hws, strides)
+    want = torch.tensor([float(ref[k]) for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')])
+    close(losses, want, rtol=2e-5, atol=1e-6)
 
 
 def test_tta_merge_and_pseudo_filter(ops, golden_dir):

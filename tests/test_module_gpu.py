@@ -189,7 +189,7 @@ def test_pseudo_labeler_predict_step_vs_oracle(gpu, manifest):
     total = 0
     for b, path in enumerate(['rec/seqA', 'rec/seqB']):
         esd = mod.ev_path_2_ev_data[path]
-        assert esd.eoe() and esd.aug
+        assert esd.eoe and esd.aug
         esd._aggregate_results(num_frames=2 * L)
         got = {f: l for f, l in zip(esd.frame_idx, esd.labels) if len(l)}
         assert set(got) == set(want[b]), (sorted(got), sorted(want[b]))

@@ -25,4 +25,4 @@ for it in range(4):
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print(f'streams={eng.n_streams} enqueue {1e3 * (t1 - t0):.1f} ms, drain {1e3 * (t2 - t1):.1f} ms, total {1e3 * (t2 - t0):.1f} ms')
+    print(f'enqueue {1e3 * (t1 - t0):.1f} ms, drain {1e3 * (t2 - t1):.1f} ms, total {1e3 * (t2 - t0):.1f} ms')
