@@ -68,9 +68,18 @@ _DATASETS = {
 def dataset_config(name: str) -> dict:
     d = dict(_DATASETS[name])
     tfo = d.pop('tflip_offset')
-    d.update(ratio=-1, train_ratio=-1, val_ratio=-1, test_ratio=-1, only_load_labels=False, reverse_event_order=False,
+    rot = dict(prob=0, min_angle_deg=2, max_angle_deg=6)
+    d.update(ssod=False, ratio=-1, train_ratio=-1, val_ratio=-1, test_ratio=-1, only_load_labels=False, reverse_event_order=False,
              train=dict(sampling='mixed', random=dict(weighted_sampling=False), mixed=dict(w_stream=1, w_random=1)),
-             eval=dict(sampling='stream'), data_augmentation=dict(tflip_offset=tfo))
+             eval=dict(sampling='stream'),
+             # config/dataset/base.yaml:19-58
+             data_augmentation=dict(
+                 tflip_offset=tfo,
+                 random=dict(prob_hflip=0.5, prob_tflip=0, rotate=dict(rot),
+                             zoom=dict(prob=0.8, zoom_in=dict(weight=8, factor=dict(min=1, max=1.5)),
+                                       zoom_out=dict(weight=2, factor=dict(min=1, max=1.2)))),
+                 stream=dict(start_from_zero=False, prob_hflip=0.5, prob_tflip=0, rotate=dict(rot),
+                             zoom=dict(prob=0.5, zoom_out=dict(factor=dict(min=1, max=1.2))))))
     return d
 
 

@@ -125,10 +125,10 @@ class SequenceBase:
             return None, False
         return self.label_factory[idx], idx in self._kept
 
-    def _load_range_labels(self, start_idx: int, end_idx: int):
+    def _load_range_labels(self, start_idx: int, end_idx: int, time_flip: Optional[bool] = None):
         """Labels of frames [start_idx, end_idx): (visible labels | None, withheld labels | None) per frame.  In the
         time-reversed view frame i shows what precedes it, so it takes the label of frame i + tflip_offset (:149-176)."""
-        if self.time_flip:
+        if self.time_flip if time_flip is None else time_flip:
             start_idx, end_idx = start_idx + self.time_flip_label_offset, end_idx + self.time_flip_label_offset
         labels, skipped = [], []
         for repr_idx in range(start_idx, end_idx):
@@ -138,7 +138,8 @@ class SequenceBase:
         return labels, skipped
 
     # ---- sample assembly -----------------------------------------------------------------------------------------------------
-    def _ev_repr_list(self, start_idx: int, end_idx: int, pad_front: int, pad_back: int, out: Optional[np.ndarray]) -> List[torch.Tensor]:
+    def _ev_repr_list(self, start_idx: int, end_idx: int, pad_front: int, pad_back: int, out: Optional[np.ndarray],
+                      reverse: bool = False) -> List[torch.Tensor]:
         """L = pad_front + (end - start) + pad_back frame tensors [C,H,W]: views of ``out`` [L,C,H,W] when given."""
         n = end_idx - start_idx
         if out is None:
@@ -150,7 +151,7 @@ class SequenceBase:
                 buf[:pad_front] = 0
             if pad_back:
                 buf[pad_front + n:] = 0
-        self.read_frames(start_idx, end_idx, out=buf[pad_front:pad_front + n], reverse=self.time_flip)
+        self.read_frames(start_idx, end_idx, out=buf[pad_front:pad_front + n], reverse=reverse)
         return list(torch.from_numpy(buf).unbind(0)) if out is None else [torch.from_numpy(buf[t]) for t in range(buf.shape[0])]
 
     @staticmethod
@@ -173,8 +174,13 @@ class SequenceBase:
     def __len__(self) -> int:
         raise NotImplementedError
 
-    def __getitem__(self, index: int) -> Any:
+    def sample(self, index: int, out: Optional[np.ndarray] = None, time_flip: Optional[bool] = None) -> Any:
+        """Sample ``index``; ``time_flip`` overrides the instance flag for this call only (several batch slots may stream the
+        same recording object concurrently in different directions)."""
         raise NotImplementedError
+
+    def __getitem__(self, index: int) -> Any:
+        return self.sample(index)
 
     def is_only_loading_labels(self) -> bool:
         return self._only_load_labels

@@ -38,14 +38,15 @@ class SequenceForRandomAccess(SequenceBase):
     def __len__(self):
         return self.length
 
-    def __getitem__(self, index: int, out: Optional[np.ndarray] = None) -> Dict:
+    def sample(self, index: int, out: Optional[np.ndarray] = None, time_flip: Optional[bool] = None) -> Dict:
         L = self.seq_len
-        if self.time_flip:
+        time_flip = self.time_flip if time_flip is None else time_flip
+        if time_flip:
             # reversed view: the labelled frame should come as LATE as possible, i.e. the window starts at it (in forward
             # indexing) and runs L frames ahead; the very last labelled frame has nothing after it -> draw another sample
             objframe = index
             if objframe == self.real_all_objframe_idx[-1]:
-                return self._rand_another(idx=objframe, out=out)
+                return self._rand_another(idx=objframe, out=out, time_flip=time_flip)
             label_repr_idx = int(self.objframe_idx_2_repr_idx[objframe]) - self.time_flip_label_offset
             end_idx = min(self.num_ev_repr, label_repr_idx + L)
         else:
@@ -53,32 +54,33 @@ class SequenceForRandomAccess(SequenceBase):
             end_idx = int(self.objframe_idx_2_repr_idx[objframe]) + 1
         start_idx = end_idx - L
         assert start_idx >= 0, f'{self.ev_repr_file=}, {self.start_idx_offset=}, {start_idx=}, {end_idx=}'
-        labels, skipped = self._load_range_labels(start_idx, end_idx)
+        labels, skipped = self._load_range_labels(start_idx, end_idx, time_flip)
         if all(l is None for l in labels):                      # every label in the window is withheld
-            return self._rand_another(out=out)
+            return self._rand_another(out=out, time_flip=time_flip)
         ev_idx = list(range(start_idx, end_idx))
-        if self.time_flip:
+        if time_flip:
             ev_idx.reverse(); labels.reverse(); skipped.reverse()
         sample = {DataType.OBJLABELS_SEQ: SparselyBatchedObjectLabels(labels),
                   DataType.SKIPPED_OBJLABELS_SEQ: SparselyBatchedObjectLabels(skipped)}
         if self._only_load_labels:
             return sample
         sample.update({DataType.PATH: self.path, DataType.EV_IDX: ev_idx,
-                       DataType.EV_REPR: self._ev_repr_list(start_idx, end_idx, 0, 0, out),
-                       DataType.IS_FIRST_SAMPLE: True, DataType.IS_LAST_SAMPLE: False, DataType.IS_REVERSED: self.time_flip,
+                       DataType.EV_REPR: self._ev_repr_list(start_idx, end_idx, 0, 0, out, reverse=time_flip),
+                       DataType.IS_FIRST_SAMPLE: True, DataType.IS_LAST_SAMPLE: False, DataType.IS_REVERSED: time_flip,
                        DataType.IS_PADDED_MASK: [False] * L})
         return sample
 
-    def _rand_another(self, idx=None, out: Optional[np.ndarray] = None) -> Any:
+    def _rand_another(self, idx=None, out: Optional[np.ndarray] = None, time_flip: Optional[bool] = None) -> Any:
         """Replacement draw (:119-148; numpy's global RNG, like the reference).  Without withheld labels this only happens
         for the last labelled frame in the reversed view: any other frame will do.  With withheld labels: one of the kept
         frames (not the last one in the reversed view when it is the recording's last label)."""
+        time_flip = self.time_flip if time_flip is None else time_flip
         if not self.skip_label:
-            assert self.time_flip, 'only happens when `time_flip` is True'
+            assert time_flip, 'only happens when `time_flip` is True'
             assert idx == self.real_all_objframe_idx[-1], 'only happens when trying to load the last labeled frame'
-            return self.__getitem__(int(np.random.choice(len(self) - 1, 1)[0]), out=out)
-        pool = self.all_objframe_idx[:-1] if (self.time_flip and self.same_last_idx) else self.all_objframe_idx
+            return self.sample(int(np.random.choice(len(self) - 1, 1)[0]), out=out, time_flip=time_flip)
+        pool = self.all_objframe_idx[:-1] if (time_flip and self.same_last_idx) else self.all_objframe_idx
         idx = int(np.random.choice(pool, 1)[0])
-        if not self.time_flip:
+        if not time_flip:
             idx -= self.start_idx_offset
-        return self.__getitem__(idx, out=out)
+        return self.sample(idx, out=out, time_flip=time_flip)

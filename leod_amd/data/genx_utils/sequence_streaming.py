@@ -71,19 +71,20 @@ class SequenceForIter(SequenceBase):
     def __len__(self):
         return self.length
 
-    def __getitem__(self, index: int, out: Optional[np.ndarray] = None) -> Dict:
+    def sample(self, index: int, out: Optional[np.ndarray] = None, time_flip: Optional[bool] = None) -> Dict:
         """Sample ``index``: frames [start, stop) of the recording padded to L.  ``out`` [L,C,H,W] uint8 (e.g. a slot of a
         pinned batch buffer) receives the frames; EV_REPR are then views of it."""
-        if self.time_flip:
+        time_flip = self.time_flip if time_flip is None else time_flip
+        if time_flip:
             start_idx, end_idx = self.time_flip_start_indices[index], self.time_flip_stop_indices[index]
         else:
             start_idx, end_idx = self.start_indices[index], self.stop_indices[index]
         n, L = end_idx - start_idx, self.seq_len
         assert L >= n > 0, f'{L=}, {n=}, {start_idx=}, {end_idx=}'
         pad = L - n
-        labels, skipped = self._load_range_labels(start_idx, end_idx)
+        labels, skipped = self._load_range_labels(start_idx, end_idx, time_flip)
         ev_idx = list(range(start_idx, end_idx))
-        if self.time_flip:                      # reversed order; the padding still comes last
+        if time_flip:                           # reversed order; the padding still comes last
             ev_idx.reverse(); labels.reverse(); skipped.reverse()
         ev_idx += [-1] * pad
         labels += [None] * pad
@@ -93,9 +94,9 @@ class SequenceForIter(SequenceBase):
             DataType.OBJLABELS_SEQ: SparselyBatchedObjectLabels(labels),
             DataType.SKIPPED_OBJLABELS_SEQ: SparselyBatchedObjectLabels(skipped),
             DataType.IS_FIRST_SAMPLE: index == 0, DataType.IS_LAST_SAMPLE: index == self.length - 1,
-            DataType.IS_REVERSED: self.time_flip, DataType.IS_PADDED_MASK: [False] * n + [True] * pad}
+            DataType.IS_REVERSED: time_flip, DataType.IS_PADDED_MASK: [False] * n + [True] * pad}
         if self._only_load_labels:
             sample[DataType.EV_REPR] = [self.padding_representation] * L
         else:
-            sample[DataType.EV_REPR] = self._ev_repr_list(start_idx, end_idx, 0, pad, out)
+            sample[DataType.EV_REPR] = self._ev_repr_list(start_idx, end_idx, 0, pad, out, reverse=time_flip)
         return sample

@@ -68,12 +68,17 @@ def resolve_link(fn: str) -> str:
 
 
 class RawFrames:
-    """[N,20,H,W] uint8 frames of one recording, memory-mapped from a .npy file."""
+    """[N,20,H,W] uint8 frames of one recording in a .npy file.  Reads into a caller buffer go through ``pread`` (the kernel
+    copies from the page cache straight into the destination, e.g. a slot of a pinned batch: no per-page mapping faults on the
+    source side, GIL released); ``data`` is the memory-mapped array for everything else."""
 
     def __init__(self, fn: str):
         self.fn = fn
         self.data = np.load(fn, mmap_mode='r')
-        assert self.data.dtype == np.uint8 and self.data.ndim == 4, (fn, self.data.dtype, self.data.shape)
+        assert self.data.dtype == np.uint8 and self.data.ndim == 4 and self.data.flags['C_CONTIGUOUS'], (fn, self.data.dtype, self.data.shape)
+        self._offset = int(self.data.offset)
+        self._frame_bytes = int(np.prod(self.data.shape[1:]))
+        self._fd = os.open(fn, os.O_RDONLY)
 
     @property
     def shape(self):
@@ -83,14 +88,39 @@ class RawFrames:
         return self.data.shape[0]
 
     def read(self, start: int, end: int, out: Optional[np.ndarray] = None) -> np.ndarray:
-        """Frames [start, end) -> ``out`` (e.g. a slice of a pinned batch) or a new array."""
+        """Frames [start, end) -> ``out`` [n,C,H,W] (each frame contiguous, e.g. ``batch[:, b]``) or a new array."""
+        assert 0 <= start < end <= len(self)
         if out is None:
-            return np.array(self.data[start:end])
-        np.copyto(out, self.data[start:end])
+            out = np.empty((end - start,) + tuple(self.data.shape[1:]), dtype=np.uint8)
+        assert out.shape == (end - start,) + tuple(self.data.shape[1:]) and out.dtype == np.uint8
+        if out.flags['C_CONTIGUOUS']:
+            self._pread(memoryview(out.reshape(-1)), self._offset + start * self._frame_bytes)
+        elif out[0].flags['C_CONTIGUOUS']:
+            for k in range(end - start):
+                self._pread(memoryview(out[k].reshape(-1)), self._offset + (start + k) * self._frame_bytes)
+        else:
+            np.copyto(out, self.data[start:end])
         return out
+
+    def _pread(self, mv, offset: int) -> None:
+        done, total = 0, len(mv)
+        while done < total:
+            n = os.preadv(self._fd, [mv[done:]], offset + done)
+            if n <= 0:
+                raise IOError(f'{self.fn}: short read at byte {offset + done}')
+            done += n
 
     def close(self):
         self.data = None
+        if self._fd is not None:
+            os.close(self._fd)
+            self._fd = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class H5Frames:

@@ -1,0 +1,248 @@
+"""Data module of the GenX datasets (the interface of the reference's modules/data/genx.py:16-232: ``DataModule(dataset_config,
+num_workers_train, num_workers_eval, batch_size_train, batch_size_eval)`` with ``setup(stage)`` and the four
+``*_dataloader()`` methods), without torch DataLoader worker processes.
+
+What the reference delegates to DataLoader workers + pin-memory thread + default collate is one producer thread per loader here:
+it walks the logical workers round-robin (each logical worker keeps its own slot streams and ``worker_id``, which keys the LSTM
+state in the module exactly as a DataLoader worker id does), has a thread pool read the B x L frames of a batch straight into a
+pinned ``[L,B,20,H,W]`` uint8 buffer, and keeps ``prefetch`` finished batches queued ahead of the training loop.  At
+>= 4000 event-frames/s per GPU the loader has to deliver >= 6 GB/s of voxels: that is page-cache memcpy speed, not
+Python-object speed."""
+import math
+import queue
+import threading
+from typing import Any, Dict, Iterator, List, Optional
+
+import torch
+
+from leod_amd.data.genx_utils.collate import BatchAssembler
+from leod_amd.data.genx_utils.dataset_rnd import CustomConcatDataset, build_random_access_dataset, get_weighted_random_sampler
+from leod_amd.data.genx_utils.dataset_streaming import build_streaming_dataset
+from leod_amd.data.utils.types import DatasetMode, DatasetSamplingMode
+from leod_amd.modules.utils.detection import DATA_KEY, WORKER_ID_KEY
+
+_END = object()
+
+
+def get_dataloading_hw(dataset_config):
+    hw = {'gen1': (240, 304), 'gen4': (720, 1280)}[dataset_config.name]
+    return tuple(x // 2 for x in hw) if dataset_config.downsample_by_factor_2 else hw
+
+
+class _PrefetchLoader:
+    """Iterable of batch dictionaries produced ahead of time on a background thread."""
+
+    def __init__(self, prefetch: int = 3):
+        self.prefetch = prefetch
+
+    def batches(self) -> Iterator[Dict]:                         # pragma: no cover
+        raise NotImplementedError
+
+    def __iter__(self):
+        if self.prefetch <= 0:
+            yield from self.batches()
+            return
+        q: 'queue.Queue[Any]' = queue.Queue(maxsize=self.prefetch)
+        stop = threading.Event()
+
+        def produce():
+            try:
+                for b in self.batches():
+                    while not stop.is_set():
+                        try:
+                            q.put(b, timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+                    if stop.is_set():
+                        return
+                q.put(_END)
+            except BaseException as e:                          # surface loader errors in the consumer
+                q.put(e)
+
+        th = threading.Thread(target=produce, daemon=True, name='leod-loader')
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is _END:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:                                                # consumer left (epoch end, break, error): stop and wait for the producer
+            stop.set()
+            while th.is_alive():
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    pass
+                th.join(timeout=0.05)
+
+
+class StreamLoader(_PrefetchLoader):
+    """Batches of a streaming dataset (``ConcatStreamingDataPipe`` for training, ``ShardedStreamingDataPipe`` otherwise): the
+    logical workers are served round-robin like DataLoader serves its worker processes; a worker that has run dry drops out."""
+
+    def __init__(self, dataset, num_workers: int, pin_memory: bool = True, prefetch: int = 3, io_threads: int = 8):
+        super().__init__(prefetch)
+        self.dataset, self.num_workers = dataset, max(1, num_workers)
+        first = dataset.datapipe_list[0]
+        self.assembler = BatchAssembler(first.seq_len, first.frame_shape, pin_memory, io_threads)
+        self.fill_value = getattr(dataset, 'fill_value', None)
+
+    def batches(self):
+        live = {w: iter(self.dataset.worker_plans(w, self.num_workers)) for w in range(self.num_workers)}
+        while live:
+            for w in list(live):
+                plans = next(live[w], None)
+                if plans is None:
+                    del live[w]
+                    continue
+                yield {DATA_KEY: self.assembler.assemble(plans, self.fill_value), WORKER_ID_KEY: w}
+
+
+class RandomLoader(_PrefetchLoader):
+    """Shuffled (or class-weighted) batches of independent samples; ``drop_last`` as in the reference's training loader."""
+
+    def __init__(self, dataset: CustomConcatDataset, batch_size: int, sampler=None, pin_memory: bool = True, prefetch: int = 3,
+                 io_threads: int = 8, num_workers: int = 1):
+        super().__init__(prefetch)
+        self.dataset, self.batch_size, self.sampler = dataset, batch_size, sampler
+        seq = dataset.datasets[0].sequence
+        self.assembler = BatchAssembler(seq.seq_len, seq.frame_shape, pin_memory, io_threads)
+        self.num_workers = max(1, num_workers)
+
+    def __len__(self):
+        return len(self.dataset) // self.batch_size
+
+    def batches(self):
+        order = list(iter(self.sampler)) if self.sampler is not None else torch.randperm(len(self.dataset)).tolist()
+        B = self.batch_size
+        for k in range(len(order) // B):
+            idx = order[k * B:(k + 1) * B]
+            plans = [(_ConcatSlot(self.dataset, i), 0, None) for i in idx]
+            # worker ids only label batches here (every random sample restarts the LSTM state); cycle them like DataLoader does
+            yield {DATA_KEY: self.assembler.assemble(plans), WORKER_ID_KEY: k % self.num_workers}
+
+
+class _ConcatSlot:
+    """Adapter: sample ``idx`` of the concatenated dataset behind the ``sample(index, out, time_flip)`` call of the assembler
+    (augmentation and the time-flip draw happen inside ``SequenceDataset.sample``)."""
+
+    def __init__(self, dataset: CustomConcatDataset, idx: int):
+        self.dataset, self.idx = dataset, idx
+
+    def sample(self, index, out=None, time_flip=None):
+        return self.dataset.sample(self.idx, out=out)
+
+
+class MixedLoader:
+    """{RANDOM: batch, STREAM: batch} per step until the LONGER loader ends, the shorter one restarting as needed (Lightning's
+    ``max_size_cycle`` handling of a dict of loaders, which is what the reference's ``train_dataloader`` returns);
+    ``merge_mixed_batches`` in the module concatenates the halves."""
+
+    def __init__(self, loaders: Dict[Any, Any]):
+        self.loaders = loaders
+
+    def __iter__(self):
+        its = {k: iter(v) for k, v in self.loaders.items()}
+        done = {k: False for k in its}
+        while True:
+            out = {}
+            for k in its:
+                b = next(its[k], None)
+                if b is None:
+                    done[k] = True
+                    if all(done.values()):
+                        return
+                    its[k] = iter(self.loaders[k])
+                    b = next(its[k])
+                out[k] = b
+            yield out
+
+
+class DataModule:
+    def __init__(self, dataset_config, num_workers_train: int, num_workers_eval: int, batch_size_train: int,
+                 batch_size_eval: int, pin_memory: bool = True, prefetch: int = 3, io_threads: int = 8):
+        assert num_workers_train >= 0 and num_workers_eval >= 0 and batch_size_train >= 1 and batch_size_eval >= 1
+        self.dataset_config = dataset_config
+        self.train_sampling_mode = DatasetSamplingMode(dataset_config.train.sampling)
+        self.eval_sampling_mode = DatasetSamplingMode(dataset_config.eval.sampling)
+        assert self.eval_sampling_mode == DatasetSamplingMode.STREAM
+        self.overall_batch_size_train, self.overall_batch_size_eval = batch_size_train, batch_size_eval
+        self.overall_num_workers_train, self.overall_num_workers_eval = num_workers_train, num_workers_eval
+        self.loader_kw = dict(pin_memory=pin_memory, prefetch=prefetch, io_threads=io_threads)
+        self.sampling_mode_2_dataset: Dict[Any, Any] = {}
+        self.sampling_mode_2_train_workers: Dict[Any, int] = {}
+        self.sampling_mode_2_train_batch_size: Dict[Any, int] = {}
+        self.validation_dataset = self.test_dataset = self.predict_dataset = None
+
+    def get_dataloading_hw(self):
+        return get_dataloading_hw(self.dataset_config)
+
+    def set_mixed_sampling_mode_variables_for_train(self):
+        """Split batch and workers between the random and the streaming loader by ``train.mixed.w_*`` (:120-144)."""
+        B, W = self.overall_batch_size_train, self.overall_num_workers_train
+        assert B >= 2, 'Cannot use mixed mode with batch size smaller than 2'
+        assert W >= 2, 'Cannot use mixed mode with num workers smaller than 2'
+        w_rnd, w_str = self.dataset_config.train.mixed.w_random, self.dataset_config.train.mixed.w_stream
+        assert w_rnd > 0 and w_str > 0
+        bs_rnd = min(round(B * w_rnd / (w_str + w_rnd)), B - 1)
+        workers_rnd = min(math.ceil(W * bs_rnd / B), W - 1)
+        self.sampling_mode_2_train_batch_size = {DatasetSamplingMode.RANDOM: bs_rnd, DatasetSamplingMode.STREAM: B - bs_rnd}
+        self.sampling_mode_2_train_workers = {DatasetSamplingMode.RANDOM: workers_rnd, DatasetSamplingMode.STREAM: W - workers_rnd}
+
+    def _eval_dataset(self, mode: DatasetMode, pseudo_labeling: bool = False):
+        return build_streaming_dataset(dataset_mode=mode, dataset_config=self.dataset_config,
+                                       batch_size=self.overall_batch_size_eval, num_workers=self.overall_num_workers_eval,
+                                       pseudo_labeling=pseudo_labeling)
+
+    def setup(self, stage: Optional[str] = None) -> None:
+        if stage == 'fit':
+            mode = self.train_sampling_mode
+            if mode == DatasetSamplingMode.MIXED:
+                self.set_mixed_sampling_mode_variables_for_train()
+            else:
+                self.sampling_mode_2_train_workers[mode] = self.overall_num_workers_train
+                self.sampling_mode_2_train_batch_size[mode] = self.overall_batch_size_train
+            if mode in (DatasetSamplingMode.RANDOM, DatasetSamplingMode.MIXED):
+                self.sampling_mode_2_dataset[DatasetSamplingMode.RANDOM] = build_random_access_dataset(
+                    dataset_mode=DatasetMode.TRAIN, dataset_config=self.dataset_config)
+            if mode in (DatasetSamplingMode.STREAM, DatasetSamplingMode.MIXED):
+                self.sampling_mode_2_dataset[DatasetSamplingMode.STREAM] = build_streaming_dataset(
+                    dataset_mode=DatasetMode.TRAIN, dataset_config=self.dataset_config,
+                    batch_size=self.sampling_mode_2_train_batch_size[DatasetSamplingMode.STREAM],
+                    num_workers=self.sampling_mode_2_train_workers[DatasetSamplingMode.STREAM])
+            self.validation_dataset = self._eval_dataset(DatasetMode.TESTING)       # the reference validates on the test split (:166-170)
+        elif stage == 'validate':
+            self.validation_dataset = self._eval_dataset(DatasetMode.VALIDATION)
+        elif stage == 'test':
+            self.test_dataset = self._eval_dataset(DatasetMode.TESTING)
+        elif stage == 'predict':                                # pseudo labels for the training split
+            self.predict_dataset = self._eval_dataset(DatasetMode.TRAIN, pseudo_labeling=True)
+        else:
+            raise NotImplementedError(stage)
+
+    def train_dataloader(self):
+        loaders = {}
+        for mode, dataset in self.sampling_mode_2_dataset.items():
+            workers, bs = self.sampling_mode_2_train_workers[mode], self.sampling_mode_2_train_batch_size[mode]
+            if mode == DatasetSamplingMode.STREAM:
+                loaders[mode] = StreamLoader(dataset, num_workers=workers, **self.loader_kw)
+            else:
+                sampler = get_weighted_random_sampler(dataset) if self.dataset_config.train.random.weighted_sampling else None
+                loaders[mode] = RandomLoader(dataset, batch_size=bs, sampler=sampler, num_workers=workers, **self.loader_kw)
+        return next(iter(loaders.values())) if len(loaders) == 1 else MixedLoader(loaders)
+
+    def _eval_loader(self, dataset):
+        return StreamLoader(dataset, num_workers=self.overall_num_workers_eval, **self.loader_kw)
+
+    def val_dataloader(self):
+        return self._eval_loader(self.validation_dataset)
+
+    def test_dataloader(self):
+        return self._eval_loader(self.test_dataset)
+
+    def predict_dataloader(self):
+        return self._eval_loader(self.predict_dataset)

@@ -106,6 +106,14 @@ class Module(_Base):
         for tidx in range(len(seq)):
             if tidx not in self.label_subsample_idx:
                 seq[tidx].set_non_gt_labels_to_none_()
+        states = data.get(DataType.AUGM_STATE, None)
+        if states is not None and th.is_tensor(data[DataType.EV_REPR][0]) and data[DataType.EV_REPR][0].is_cuda:
+            # spatial augmentation of the whole batch in ONE gather launch (the loaders transformed the labels on the host
+            # and left the frames untouched; the reference flips / zooms every frame in the dataloader workers)
+            from leod_amd.data.utils.augmentor import augment_events
+            if any(s.apply_h_flip or s.zoom_in.active or s.zoom_out.active for s in states):
+                ev = augment_events(self._stack_frames(data[DataType.EV_REPR]).contiguous(), states)
+                data[DataType.EV_REPR] = [ev[t] for t in range(ev.shape[0])]
         return data
 
     # ---- the hot loop -----------------------------------------------------------------------------------
@@ -330,13 +338,17 @@ class Module(_Base):
     def transfer_batch_to_device(self, batch: Any, device, dataloader_idx: int = 0) -> Any:
         """Tensors go to the device asynchronously; box labels stay on the host (their per-frame bookkeeping is host work,
         the padded target tensor is uploaded once per step in ``training_step``)."""
-        def move(o):
+        def move(o, key=None):
             if th.is_tensor(o):
                 return o.to(device, non_blocking=True)
             if isinstance(o, (ObjectLabels, SparselyBatchedObjectLabels)) or o is None or isinstance(o, (str, int, float, bool)):
                 return o
+            if key == DataType.EV_REPR and isinstance(o, list) and len(o) and th.is_tensor(o[0]):
+                # the L frames of a batch are views of one (pinned) [L,B,C,H,W] buffer: ONE PCIe copy, then views again
+                ev = self._stack_frames(o).to(device, non_blocking=True)
+                return [ev[t] for t in range(ev.shape[0])]
             if isinstance(o, dict):
-                return {k: move(v) for k, v in o.items()}
+                return {k: move(v, k) for k, v in o.items()}
             if isinstance(o, (list, tuple)):
                 return type(o)(move(v) for v in o)
             return o

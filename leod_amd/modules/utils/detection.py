@@ -142,10 +142,12 @@ def mixed_collate_fn(x1, x2):
     if isinstance(x1, SparselyBatchedObjectLabels):
         return x1 + x2
     if isinstance(x1, list):
-        assert len(x1) == len(x2)
-        if len(x1) and isinstance(x1[0], str):
-            return x1 + x2
-        return [mixed_collate_fn(a, b) for a, b in zip(x1, x2)]
+        # per-timestep lists (frames, indices, masks, label containers) merge element-wise on the batch dim; per-sample
+        # lists (paths, augmentation states) concatenate
+        if len(x1) and isinstance(x1[0], (th.Tensor, SparselyBatchedObjectLabels, list)):
+            assert len(x1) == len(x2)
+            return [mixed_collate_fn(a, b) for a, b in zip(x1, x2)]
+        return x1 + x2
     if isinstance(x1, dict):
         return {k: (mixed_collate_fn(x1[k], x2[k]) if isinstance(x1[k], dict) else x1[k] + x2[k]) for k in x1}
     raise NotImplementedError(type(x1))

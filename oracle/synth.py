@@ -216,3 +216,88 @@ def synth_tta_views(case: int, hw=(240, 304)):
                     preds.append(1.0)
             views.append(dict(hflip=hflip, tflip=tflip, ev_idx=idx, gts=gts, preds=preds, last=ci == 1))
     return views, hw
+
+
+# ---- a tiny GenX dataset tree on disk (loader goldens / tests) ------------------------------------------------------------------
+BBOX_DTYPE = np.dtype({'names': ['t', 'x', 'y', 'w', 'h', 'class_id', 'class_confidence', 'objectness'],
+                       'formats': ['<i8', '<f4', '<f4', '<f4', '<f4', '<u4', '<f4', '<f4'],
+                       'offsets': [0, 8, 12, 16, 20, 24, 28, 32], 'itemsize': 40})
+
+
+def synth_recording(split_dir: str, name: str, seed: int, n_frames: int, labelled: list, dst_name: str = 'gen1', frame_hw=(6, 8),
+                    ds2: bool = False, with_h5_placeholder: bool = True, objectness: bool = True) -> str:
+    """Write ``split_dir/name`` in the dataset layout of the reference (sequence_base.py:32-48): uint8 frames [N,20,h,w] as the
+    raw ``.npy`` twin of the HDF5 file (plus an empty ``.h5`` placeholder so that path checks of the reference pass: its h5py
+    stand-in reads the twin), ``objframe_idx_2_repr_idx.npy`` and ``labels_v2/labels.npz`` (BBOX_DTYPE).  ``labelled`` = frame
+    indices that carry boxes.  Frame content encodes (recording, frame, channel) so that any mix-up shows."""
+    import os
+    rng = np.random.RandomState(seed)
+    seq = os.path.join(split_dir, name)
+    ev_dir = os.path.join(seq, 'event_representations_v2', 'stacked_histogram_dt=50_nbins=10')
+    os.makedirs(ev_dir, exist_ok=True)
+    os.makedirs(os.path.join(seq, 'labels_v2'), exist_ok=True)
+    h, w = frame_hw
+    frames = rng.randint(0, 4, size=(n_frames, 20, h, w)).astype(np.uint8)
+    frames[:, :, 0, 0] = (np.arange(n_frames)[:, None] + 1) % 251           # frame index
+    frames[:, :, 0, 1] = np.arange(20)[None, :] + 1                         # channel index
+    frames[:, :, 0, 2] = seed % 251
+    stem = 'event_representations' + ('_ds2_nearest' if ds2 else '')
+    np.save(os.path.join(ev_dir, stem + '.npy'), frames)
+    if with_h5_placeholder:
+        open(os.path.join(ev_dir, stem + '.h5'), 'wb').close()
+    np.save(os.path.join(ev_dir, 'objframe_idx_2_repr_idx.npy'), np.asarray(labelled, dtype=np.int64))
+    H, W = (240, 304) if dst_name == 'gen1' else (720, 1280)
+    rows, starts = [], []
+    names = list(BBOX_DTYPE.names) if objectness else [n for n in BBOX_DTYPE.names if n != 'objectness']
+    dt = BBOX_DTYPE if objectness else np.dtype([(n, BBOX_DTYPE.fields[n][0]) for n in names])
+    for k, f in enumerate(labelled):
+        starts.append(len(rows))
+        for _ in range(rng.randint(1, 4)):
+            bw, bh = rng.uniform(20, 90), rng.uniform(20, 70)
+            x, y = rng.uniform(-10, W - bw + 10), rng.uniform(-10, H - bh + 10)     # some boxes stick out of the frame
+            rec = dict(t=(f + 1) * 50000, x=x, y=y, w=bw, h=bh, class_id=rng.randint(0, 2 if dst_name == 'gen1' else 3),
+                       class_confidence=1.0, objectness=1.0)
+            rows.append(tuple(rec[n] for n in names))
+    labels = np.array(rows, dtype=dt) if rows else np.zeros((0,), dtype=dt)
+    np.savez(os.path.join(seq, 'labels_v2', 'labels.npz'), labels=labels, objframe_idx_2_label_idx=np.asarray(starts, dtype=np.int64))
+    return seq
+
+
+LOADER_RECORDINGS = [   # (name, seed, n_frames, labelled frames)
+    ('rec_a', 11, 23, [4, 9, 10, 15, 22]),
+    ('rec_b', 12, 12, [1, 2, 11]),
+    ('rec_c', 13, 40, [6, 7, 30, 31, 39]),
+    ('rec_d', 14, 9, [8]),
+    ('rec_e', 15, 17, [3, 5, 7, 9, 11, 13, 16]),
+]
+
+
+def synth_dataset_tree(root: str, dst_name: str = 'gen1', ds2: bool = False):
+    """root/<dst_name>/{train,val,test}/rec_* from LOADER_RECORDINGS -> the dataset path."""
+    import os
+    base = os.path.join(root, dst_name)
+    for split, off in (('train', 0), ('val', 100), ('test', 200)):
+        for name, seed, n, lab in LOADER_RECORDINGS:
+            synth_recording(os.path.join(base, split), name, seed + off, n, lab, dst_name=dst_name, ds2=ds2)
+    return base
+
+
+def loader_cases():
+    """(kind, recording, constructor kwargs, time_flip, sample indices | None = all) -- used by tests/golden/make_golden.py (g17) and tests/test_loader_cpu.py."""
+    L = 5
+    cases = []
+    for rec in ('rec_a', 'rec_b', 'rec_c', 'rec_d', 'rec_e'):
+        for tf in (False, True):
+            cases.append(('iter', rec, dict(sequence_length=L), tf, None))
+            cases.append(('rnd', rec, dict(sequence_length=L), tf, None))
+    cases.append(('iter', 'rec_c', dict(sequence_length=7, start_from_zero=True), False, None))
+    cases.append(('iter', 'rec_c', dict(sequence_length=7, start_from_zero=True), True, None))
+    cases.append(('iter', 'rec_a', dict(sequence_length=L, range_indices=(5, 16)), False, None))
+    cases.append(('iter', 'rec_a', dict(sequence_length=L, range_indices=(5, 16)), True, None))
+    cases.append(('iter', 'rec_e', dict(sequence_length=L, objframe_idx=[1, 4], data_ratio=0.3), False, None))     # withheld labels
+    cases.append(('iter', 'rec_e', dict(sequence_length=L, objframe_idx=[], data_ratio=-1.0), True, None))         # all withheld
+    cases.append(('rnd', 'rec_e', dict(sequence_length=L, data_ratio=0.5), False, None))
+    cases.append(('rnd', 'rec_e', dict(sequence_length=L, data_ratio=0.5), True, None))
+    cases.append(('rnd', 'rec_e', dict(sequence_length=L, objframe_idx=[2, 5], data_ratio=0.3), False, None))
+    cases.append(('rnd', 'rec_c', dict(sequence_length=8, data_ratio=0.25), True, None))
+    return cases

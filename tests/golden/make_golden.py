@@ -664,9 +664,84 @@ def g14_augment():
     save('g14_augment.npz', **out)
 
 
+def record_sample(out, key, sample, DataType):
+    """Flatten one loader sample into arrays under ``key``."""
+    if DataType.EV_REPR in sample:
+        out[f'{key}_ev'] = torch.stack(list(sample[DataType.EV_REPR])).numpy()
+        out[f'{key}_idx'] = np.asarray(sample[DataType.EV_IDX], dtype=np.int64)
+        out[f'{key}_pad'] = np.asarray(sample[DataType.IS_PADDED_MASK], dtype=bool)
+        out[f'{key}_flags'] = np.asarray([sample[DataType.IS_FIRST_SAMPLE], sample[DataType.IS_LAST_SAMPLE], sample[DataType.IS_REVERSED]], dtype=bool)
+        out[f'{key}_path'] = np.asarray(os.path.basename(sample[DataType.PATH]))
+    for name, k in (('lab', DataType.OBJLABELS_SEQ), ('skip', DataType.SKIPPED_OBJLABELS_SEQ)):
+        rows, where = [], []
+        for t, l in enumerate(sample[k]):
+            if l is not None:
+                rows.append(l.object_labels.numpy().astype(np.float32))
+                where += [t] * len(l)
+                out[f'{key}_{name}hw{t}'] = np.asarray(l.input_size_hw, dtype=np.float64)
+        out[f'{key}_{name}'] = np.concatenate(rows) if rows else np.zeros((0, 8), np.float32)
+        out[f'{key}_{name}_t'] = np.asarray(where, dtype=np.int64)
+
+
+def g17_loader():
+    """The reference's own sequence classes (data/genx_utils/sequence_streaming.py:54-277, sequence_rnd.py:11-148,
+    sequence_base.py:52-205) over a synthetic dataset tree (oracle.synth.synth_dataset_tree; frames come from the .npy twin
+    through the h5py stand-in): every sample of every case -- frames, frame indices, padding masks, first / last / reversed
+    flags, visible and withheld labels -- plus the sub-sequence ranges of get_sequences_with_guaranteed_labels and the
+    recording -> worker dealing of ShardedStreamingDataPipe.assign_datapipes_to_worker."""
+    import tempfile
+    from pathlib import Path
+    from oracle.synth import synth_dataset_tree, loader_cases
+    from data.genx_utils.sequence_streaming import SequenceForIter as RefIter
+    from data.genx_utils.sequence_rnd import SequenceForRandomAccess as RefRnd
+    from data.utils.stream_sharded_datapipe import ShardedStreamingDataPipe as RefSharded
+    from data.utils.types import DataType, DatasetType
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for dst, ds2, dtype in (('gen1', False, DatasetType.GEN1), ('gen4', True, DatasetType.GEN4)):
+            base = synth_dataset_tree(tmp, dst, ds2)
+            common = dict(ev_representation_name='stacked_histogram_dt=50_nbins=10', dataset_type=dtype, downsample_by_factor_2=ds2,
+                          tflip_offset=-1 if dst == 'gen1' else -2)
+            for ci, (kind, rec, kw, tf, _) in enumerate(loader_cases()):
+                if dst == 'gen4' and ci % 3:                  # a third of the cases at half resolution is plenty
+                    continue
+                path = Path(base) / 'train' / rec
+                seq = (RefIter(path=path, **common, **kw) if kind == 'iter'
+                       else RefRnd(path=path, only_load_end_labels=False, **common, **kw))
+                seq.time_flip = tf
+                out[f'{dst}_c{ci}_len'] = np.asarray(len(seq))
+                for i in range(len(seq)):
+                    np.random.seed(1000 * ci + i)             # _rand_another draws from numpy's global RNG
+                    try:
+                        sample = seq[i]
+                    except ValueError:                        # replacement draw from an empty pool (one sample, reversed view)
+                        out[f'{dst}_c{ci}_s{i}_err'] = np.asarray(1)
+                        continue
+                    record_sample(out, f'{dst}_c{ci}_s{i}', sample, DataType)
+            for rec in ('rec_a', 'rec_c', 'rec_e'):
+                for L in (3, 5, 9):
+                    subs = RefIter.get_sequences_with_guaranteed_labels(path=Path(base) / 'train' / rec, sequence_length=L, **common)
+                    out[f'{dst}_{rec}_L{L}_ranges'] = np.asarray([[s.start_indices[0], s.stop_indices[-1], len(s)] for s in subs], dtype=np.int64)
+    lens = [7, 3, 9, 9, 1, 4, 12, 2, 5, 5, 6]
+
+    class _DP:
+        def __init__(self, n, tag):
+            self.n, self.tag = n, tag
+
+        def __len__(self):
+            return self.n
+    pipes = sorted([_DP(n, i) for i, n in enumerate(lens)], key=lambda x: len(x), reverse=True)
+    out['shard_sorted'] = np.asarray([p.tag for p in pipes], dtype=np.int64)
+    for total in (1, 2, 3, 4, 8):
+        for w in range(total):
+            got = RefSharded.assign_datapipes_to_worker(pipes, total_num_workers=total, global_worker_id=w)
+            out[f'shard_w{total}_{w}'] = np.asarray([p.tag for p in got], dtype=np.int64)
+    save('g17_loader.npz', **out)
+
+
 ALL = dict(g01=g01_convlstm, g02=g02_partition, g03=g03_attention, g04=g04_backbone, g05=g05_head,
            g06=g06_simota, g07=g07_postprocess, g08=g08_pseudo, g10=g10_voxel, g11=g11_manifest,
-           g12=g12_trainstep, g13=g13_tracker, g14=g14_augment, g15=g15_evaluator, g16=g16_tta_result)
+           g12=g12_trainstep, g13=g13_tracker, g14=g14_augment, g15=g15_evaluator, g16=g16_tta_result, g17=g17_loader)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)

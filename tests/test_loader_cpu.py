@@ -1,0 +1,247 @@
+"""on-disk formats + streaming / random / mixed loaders.  The sequence classes are checked sample by sample against
+vectors recorded from the REFERENCE's own classes (tests/golden/g17_loader.npz, make_golden.py:g17_loader); the batch-level
+machinery (slot streams, worker dealing, padding, pinned batch assembly, mixed batches, rank sharding) by its invariants."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.synth import LOADER_RECORDINGS, loader_cases, synth_dataset_tree
+
+EV_NAME = 'stacked_histogram_dt=50_nbins=10'
+BBOX_NAMES = ('t', 'x', 'y', 'w', 'h', 'class_id', 'class_confidence', 'objectness')
+
+
+@pytest.fixture(scope='module')
+def trees(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp('genx'))
+    return {'gen1': synth_dataset_tree(root, 'gen1', False), 'gen4': synth_dataset_tree(root, 'gen4', True)}
+
+
+def _check_sample(g, key, sample):
+    from leod_amd.data.utils.types import DataType
+    if DataType.EV_REPR in sample:
+        assert np.array_equal(torch.stack(list(sample[DataType.EV_REPR])).numpy(), g[f'{key}_ev']), key
+        assert list(sample[DataType.EV_IDX]) == g[f'{key}_idx'].tolist(), key
+        assert list(sample[DataType.IS_PADDED_MASK]) == g[f'{key}_pad'].tolist(), key
+        flags = [sample[DataType.IS_FIRST_SAMPLE], sample[DataType.IS_LAST_SAMPLE], sample[DataType.IS_REVERSED]]
+        assert flags == g[f'{key}_flags'].tolist(), key
+        assert os.path.basename(sample[DataType.PATH]) == str(g[f'{key}_path']), key
+    else:
+        assert f'{key}_ev' not in g
+    for name, k in (('lab', DataType.OBJLABELS_SEQ), ('skip', DataType.SKIPPED_OBJLABELS_SEQ)):
+        rows, where = [], []
+        for t, l in enumerate(sample[k]):
+            if l is not None:
+                rows.append(l.object_labels.numpy().astype(np.float32))
+                where += [t] * len(l)
+                assert tuple(float(v) for v in l.input_size_hw) == tuple(g[f'{key}_{name}hw{t}'].tolist()), (key, t)
+        got = np.concatenate(rows) if rows else np.zeros((0, 8), np.float32)
+        assert where == g[f'{key}_{name}_t'].tolist(), (key, name)
+        assert np.array_equal(got, g[f'{key}_{name}']), (key, name)
+
+
+@pytest.mark.parametrize('dst', ['gen1', 'gen4'])
+def test_sequence_samples_match_reference_golden(trees, golden_dir, dst):
+    from pathlib import Path
+    from leod_amd.data.genx_utils.sequence_rnd import SequenceForRandomAccess
+    from leod_amd.data.genx_utils.sequence_streaming import SequenceForIter
+    from leod_amd.data.utils.types import DatasetType
+    g = np.load(os.path.join(golden_dir, 'g17_loader.npz'))
+    ds2 = dst == 'gen4'
+    common = dict(ev_representation_name=EV_NAME, dataset_type=DatasetType.GEN4 if ds2 else DatasetType.GEN1,
+                  downsample_by_factor_2=ds2, tflip_offset=-2 if ds2 else -1)
+    n_samples = n_err = 0
+    for ci, (kind, rec, kw, tf, _) in enumerate(loader_cases()):
+        if ds2 and ci % 3:
+            continue
+        path = Path(trees[dst]) / 'train' / rec
+        seq = (SequenceForIter(path=path, **common, **kw) if kind == 'iter'
+               else SequenceForRandomAccess(path=path, only_load_end_labels=False, **common, **kw))
+        seq.time_flip = tf
+        assert len(seq) == int(g[f'{dst}_c{ci}_len']), (ci, kind, rec)
+        for i in range(len(seq)):
+            key = f'{dst}_c{ci}_s{i}'
+            np.random.seed(1000 * ci + i)
+            if f'{key}_err' in g:
+                with pytest.raises(ValueError):
+                    seq[i]
+                n_err += 1
+                continue
+            _check_sample(g, key, seq[i])
+            # the same sample produced INTO a caller-owned buffer slot (the pinned-batch path) is identical
+            np.random.seed(1000 * ci + i)
+            buf = np.full((seq.seq_len,) + seq.frame_shape, 255, np.uint8)
+            _check_sample(g, key, seq.sample(i, out=buf))
+            assert np.array_equal(buf, g[f'{key}_ev'])
+            n_samples += 1
+    assert n_samples > (30 if ds2 else 100) and n_err <= 2
+    for rec in ('rec_a', 'rec_c', 'rec_e'):
+        for L in (3, 5, 9):
+            subs = SequenceForIter.get_sequences_with_guaranteed_labels(path=Path(trees[dst]) / 'train' / rec, sequence_length=L, **common)
+            got = np.asarray([[s.start_indices[0], s.stop_indices[-1], len(s)] for s in subs], dtype=np.int64)
+            assert np.array_equal(got, g[f'{dst}_{rec}_L{L}_ranges']), (rec, L)
+
+
+def test_worker_dealing_matches_reference_golden(golden_dir):
+    from leod_amd.data.utils.stream_sharded_datapipe import ShardedStreamingDataPipe
+    g = np.load(os.path.join(golden_dir, 'g17_loader.npz'))
+
+    class DP:
+        def __init__(self, n, tag):
+            self.n, self.tag = n, tag
+
+        def __len__(self):
+            return self.n
+    lens = [7, 3, 9, 9, 1, 4, 12, 2, 5, 5, 6]
+    pipe = ShardedStreamingDataPipe([DP(n, i) for i, n in enumerate(lens)], batch_size=2)
+    assert [p.tag for p in pipe.datapipe_list] == g['shard_sorted'].tolist()
+    for total in (1, 2, 3, 4, 8):
+        seen = []
+        for w in range(total):
+            got = [p.tag for p in ShardedStreamingDataPipe.assign_datapipes_to_worker(pipe.datapipe_list, total, w)]
+            assert got == g[f'shard_w{total}_{w}'].tolist()
+            seen += got
+        assert sorted(seen) == list(range(len(lens)))
+
+
+def _cfg(tree, **over):
+    from leod_amd.config import full_config
+    cfg = full_config('gen1', 'small', overrides=dict(dataset=dict(path=tree, sequence_length=5, **over)))
+    return cfg.dataset
+
+
+def test_eval_stream_covers_every_frame_once_and_shards_by_rank(trees, monkeypatch):
+    """ShardedStreamingDataPipe through the data module: every frame of every recording exactly once across (ranks x workers x
+    slots), first/last flags at the recording boundaries, dry slots filled with padding samples, frames of a batch in ONE
+    [L,B,C,H,W] buffer; with the time-flip TTA copies a recording and its reversed twin are separate streams."""
+    from leod_amd.data.utils.stream_sharded_datapipe import ShardedStreamingDataPipe
+    from leod_amd.data.utils.types import DataType
+    from leod_amd.modules.data.genx import DataModule
+    from leod_amd.modules.utils.detection import DATA_KEY, WORKER_ID_KEY
+    want = {name: n for name, _, n, _ in LOADER_RECORDINGS}
+    for world in (1, 2):
+        seen = {}
+        for rank in range(world):
+            monkeypatch.setattr(ShardedStreamingDataPipe, 'world', staticmethod(lambda r=rank, w=world: (r, w)))
+            dm = DataModule(_cfg(trees['gen1'], data_augmentation=dict(stream=dict(start_from_zero=True))), 2, 1, 4, 2, prefetch=2)
+            dm.setup('test')
+            last_of_slot = {}
+            for batch in dm.test_dataloader():
+                data, w = batch[DATA_KEY], batch[WORKER_ID_KEY]
+                ev = data[DataType.EV_REPR]
+                assert len(ev) == 5 and ev[0].shape == (2, 20, 6, 8) and ev[0].dtype == torch.uint8
+                assert ev[1].data_ptr() == ev[0].data_ptr() + ev[0].numel()            # views of one batch buffer
+                for b, path in enumerate(data[DataType.PATH]):
+                    idx = [int(data[DataType.EV_IDX][t][b]) for t in range(5)]
+                    pad = [bool(data[DataType.IS_PADDED_MASK][t][b]) for t in range(5)]
+                    if not path:
+                        assert idx == [-1] * 5 and all(pad) and not bool(data[DataType.IS_FIRST_SAMPLE][b])
+                        assert all(int(ev[t][b].sum()) == 0 for t in range(5))
+                        continue
+                    name = os.path.basename(path)
+                    first = bool(data[DataType.IS_FIRST_SAMPLE][b])
+                    assert first == (idx[0] == 0)
+                    if not first:
+                        assert last_of_slot[(rank, w, b)] == (name, idx[0] - 1)           # the slot continues its recording
+                    live = [i for i, p in zip(idx, pad) if not p]
+                    assert live == list(range(live[0], live[0] + len(live))) and all(i == -1 for i, p in zip(idx, pad) if p)
+                    for t, i in enumerate(idx):
+                        if i >= 0:
+                            assert int(ev[t][b, 0, 0, 0]) == (i + 1) % 251 and int(ev[t][b, 5, 0, 1]) == 6   # frame / channel tags
+                    seen.setdefault(name, []).extend(live)
+                    last_of_slot[(rank, w, b)] = (name, live[-1])
+                    assert bool(data[DataType.IS_LAST_SAMPLE][b]) == (live[-1] == want[name] - 1)
+        assert {k: sorted(v) for k, v in seen.items()} == {k: list(range(n)) for k, n in want.items()}, world
+
+
+def test_train_streams_mixed_batches_and_augmentation_states(trees):
+    """Mixed training batches: stream half + random half (modules/data/genx.py:120-144), merged by the module's
+    ``merge_mixed_batches``; the random half always restarts the LSTM state, the stream half only at sub-sequence starts; every
+    sample carries labels somewhere and its augmentation state (labels already transformed, frames untouched)."""
+    from leod_amd.data.utils.types import DataType, DatasetSamplingMode
+    from leod_amd.modules.data.genx import DataModule, MixedLoader
+    from leod_amd.modules.utils.detection import DATA_KEY, WORKER_ID_KEY, merge_mixed_batches
+    torch.manual_seed(3)
+    np.random.seed(3)
+    dm = DataModule(_cfg(trees['gen1']), num_workers_train=4, num_workers_eval=1, batch_size_train=4, batch_size_eval=2, prefetch=2)
+    dm.setup('fit')
+    assert dm.sampling_mode_2_train_batch_size == {DatasetSamplingMode.RANDOM: 2, DatasetSamplingMode.STREAM: 2}
+    assert dm.sampling_mode_2_train_workers == {DatasetSamplingMode.RANDOM: 2, DatasetSamplingMode.STREAM: 2}
+    loader = dm.train_dataloader()
+    assert isinstance(loader, MixedLoader)
+    n = 0
+    cursor = {}
+    for batch in loader:
+        assert set(batch) == {DatasetSamplingMode.RANDOM, DatasetSamplingMode.STREAM}
+        wid = batch[DatasetSamplingMode.STREAM][WORKER_ID_KEY]
+        merged = merge_mixed_batches(batch)
+        data = merged[DATA_KEY]
+        assert merged[WORKER_ID_KEY] == wid
+        first = data[DataType.IS_FIRST_SAMPLE]
+        assert first.shape == (4,) and bool(first[2]) and bool(first[3])               # random half: always a fresh state
+        assert len(data[DataType.AUGM_STATE]) == 4 and len(data[DataType.PATH]) == 4
+        assert data[DataType.EV_REPR][0].shape == (4, 20, 6, 8)
+        for b in range(4):
+            assert any(data[DataType.OBJLABELS_SEQ][t][b] is not None for t in range(5))   # guaranteed labels
+        for b in range(2):                                                             # stream half: consecutive chunks
+            idx = [int(data[DataType.EV_IDX][t][b]) for t in range(5)]
+            rev = bool(data[DataType.IS_REVERSED][b])
+            key = (wid, b)
+            if not bool(first[b]):
+                path, nxt, prev_rev = cursor[key]
+                assert path == data[DataType.PATH][b] and rev == prev_rev
+                assert [i for i in idx if i >= 0][0] == nxt
+            live = [i for i in idx if i >= 0]
+            cursor[key] = (data[DataType.PATH][b], (live[-1] - 1) if rev else (live[-1] + 1), rev)
+        n += 1
+    assert n >= 4
+
+
+def test_pseudo_label_dataset_round_trip(trees, tmp_path):
+    """EventSeqData.save writes the reference's dataset layout (pseudo_labeler.py:335-397); the loaders read it back: the next
+    self-training round trains on exactly what the pseudo-labelling round wrote."""
+    from pathlib import Path
+    from leod_amd.config.dictconfig import DictConfig
+    from leod_amd.data.genx_utils.labels import ObjectLabels
+    from leod_amd.data.genx_utils.sequence_streaming import SequenceForIter
+    from leod_amd.data.utils import misc
+    from leod_amd.data.utils.types import DatasetType, DataType
+    from leod_amd.modules.pseudo_labeler import EventSeqData
+    src = os.path.join(trees['gen1'], 'train', 'rec_a')
+    esd = EventSeqData(path=src, scale_ratio=1, filter_config=DictConfig(dict(min_track_len=0, track_method='forward', inpaint=False, ignore_label=1024)),
+                       postproc_cfg=DictConfig(dict(confidence_threshold=0.01, nms_threshold=0.45)))
+    assert esd.eoe is False
+    rows = {3: [[0., 10., 20., 30., 40., 1., 0.8, 0.9]], 7: [[0., 50., 60., 20., 25., 0., 0.7, 0.6], [0., 5., 6., 70., 25., 1., 0.5, 0.95]],
+            22: [[1150000., 100., 100., 40., 40., 0., 1., 1.]]}
+    frames = sorted(rows)
+    labels = [ObjectLabels(torch.tensor(rows[f]), (240, 304)) for f in frames]
+    esd.update(labels=labels, ev_idx=frames, is_last_sample=True, is_padded_mask=[False] * 3, is_hflip=False, is_tflip=False, tflip_offset=-1)
+    assert esd.eoe is True and esd.aug is False
+    save_dir = str(tmp_path / 'gen1_pse' / 'train')
+    os.makedirs(save_dir)
+    new_seq = esd.save(save_dir, 'gen1')
+    ev_dir = misc.get_ev_dir(new_seq)
+    assert os.path.islink(os.path.join(ev_dir, 'event_representations.npy')) and os.path.islink(os.path.join(ev_dir, 'event_representations.h5'))
+    assert os.path.islink(str(tmp_path / 'gen1_pse' / 'val')) and os.path.islink(str(tmp_path / 'gen1_pse' / 'test'))
+    assert os.path.samefile(os.readlink(str(tmp_path / 'gen1_pse' / 'val')), os.path.join(trees['gen1'], 'val'))
+    assert misc.read_objframe_idx_2_repr_idx(new_seq).tolist() == frames
+    lab, starts = misc.read_npz_labels(new_seq)
+    assert starts.tolist() == [0, 1, 3] and lab.dtype.names == BBOX_NAMES and lab['t'].tolist() == [0, 0, 0, 1150000]
+    with pytest.raises(FileExistsError):
+        esd.save(save_dir, 'gen1')
+    seq = SequenceForIter(path=Path(new_seq), ev_representation_name=EV_NAME, sequence_length=5, dataset_type=DatasetType.GEN1,
+                          downsample_by_factor_2=False, start_from_zero=True)
+    got = {}
+    for i in range(len(seq)):
+        s = seq[i]
+        for t, l in enumerate(s[DataType.OBJLABELS_SEQ]):
+            if l is not None:
+                got[s[DataType.EV_IDX][t]] = l.object_labels.numpy()
+    assert sorted(got) == frames
+    for f in frames:
+        np.testing.assert_array_equal(got[f], np.asarray(rows[f], np.float32))
+    src_seq = SequenceForIter(path=Path(src), ev_representation_name=EV_NAME, sequence_length=5, dataset_type=DatasetType.GEN1,
+                              downsample_by_factor_2=False, start_from_zero=True)
+    assert torch.equal(torch.stack(seq[1][DataType.EV_REPR]), torch.stack(src_seq[1][DataType.EV_REPR]))       # linked frames
