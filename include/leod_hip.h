@@ -101,7 +101,8 @@ int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, float* dbia
                          int ks, int stride, int pad, leod_stream_t stream);
 
 /* BatchNorm2d (batch statistics) + SiLU on rows and its autograd (network_blocks.py:47-51).  `count` = rows that
- * entered colstats/sums; count_dev (optional, device scalar) overrides it (all-rank row count under SyncBN). */
+ * entered colstats/sums.  SyncBatchNorm: with count_dev (device scalar) the row count is count * count_dev[0] -- pass count =
+ * rows per image and count_dev = images over all ranks (one all-reduced scalar per step), colstats/sums all-reduced. */
 int leod_bn_silu_fwd(const float* z, const double* colstats, const float* w, const float* b, float* y, float* save_mean,
                      float* save_rstd, float* run_mean, float* run_var, int M, int N, double count,
                      const double* count_dev, float eps, float momentum, leod_stream_t stream);

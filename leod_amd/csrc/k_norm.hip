@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const float* __restric
                                                           float* __restrict__ save_rstd, float* __restrict__ run_mean,
                                                           float* __restrict__ run_var, long M, int N, double count,
                                                           const double* __restrict__ count_dev, float eps, float momentum) {
-    if (count_dev) count = count_dev[0];
+    if (count_dev) count = count * count_dev[0];     // SyncBatchNorm: rows per image (host) x images over all ranks (device)
     const long n4 = M * N / 4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
         const long e = idx * 4; const int c = (int)(e % N);
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const float* __r
                                                                 const double* __restrict__ sums, float* __restrict__ dz,
                                                                 float* __restrict__ dw, float* __restrict__ db, long M, int N,
                                                                 double count, const double* __restrict__ count_dev) {
-    if (count_dev) count = count_dev[0];
+    if (count_dev) count = count * count_dev[0];     // SyncBatchNorm: rows per image (host) x images over all ranks (device)
     const long n4 = M * N / 4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
         const long e = idx * 4; const int c = (int)(e % N);

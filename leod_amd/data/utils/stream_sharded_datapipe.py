@@ -48,11 +48,25 @@ class ShardedStreamingDataPipe:
             return dist.get_rank(), dist.get_world_size()
         return 0, 1
 
+    def datapipes_of_worker(self, local_worker_id: int, local_num_workers: int) -> List[Any]:
+        """The reference deals recordings to the global worker id rank * workers + worker (:88-105).  It only ever ran the
+        time-flip TTA on one GPU (predict.py:167-169): with several ranks a recording and its time-reversed copy (two streams
+        with the same ``path``) would land on different ranks and their detections could never be merged
+        (``EventSeqData`` / ``EventSeqResult`` are per process).  When a path occurs more than once, ranks therefore own whole
+        path groups (``leod_amd.parallel.shard_sequences``: length-balanced, no data-path collective) and only the dealing to
+        the rank's own workers follows the reference."""
+        rank, world = self.world()
+        paths = [getattr(dp, 'path', id(dp)) for dp in self.datapipe_list]
+        if world > 1 and len(set(paths)) < len(paths):
+            from leod_amd.parallel import shard_sequences
+            own = shard_sequences([len(dp) for dp in self.datapipe_list], world, rank, keys=paths)
+            return self.assign_datapipes_to_worker([self.datapipe_list[i] for i in own], local_num_workers, local_worker_id)
+        return self.assign_datapipes_to_worker(self.datapipe_list, local_num_workers * world, rank * local_num_workers + local_worker_id)
+
     def worker_plans(self, local_worker_id: int, local_num_workers: int) -> Iterator[List[Optional[Tuple[Any, int, Optional[bool]]]]]:
         """Batches of worker ``local_worker_id`` on this rank: per slot ``(recording, sample index, None)`` or ``None`` once
         the slot has run dry (ZipperLongest with the padding sample as fill value); ends when every slot is dry."""
-        rank, world = self.world()
-        mine = self.assign_datapipes_to_worker(self.datapipe_list, local_num_workers * world, rank * local_num_workers + local_worker_id)
+        mine = self.datapipes_of_worker(local_worker_id, local_num_workers)
         slots = self.slot_streams(mine, self.batch_size)
         cursors = [((dp, i) for dp in stream for i in range(len(dp))) for stream in slots]
         while True:

@@ -15,7 +15,7 @@ from torch.autograd import Function
 
 from . import ops
 
-_SYNC_BN = {'group': None, 'world_size': 1, 'force': False}
+_SYNC_BN = {'group': None, 'world_size': 1, 'force': False, 'images': None, 'n_collectives': 0}
 
 
 class WgradSide:
@@ -86,6 +86,19 @@ def _allreduce_stats(t: torch.Tensor):
     if _sync_bn_on():
         import torch.distributed as dist
         dist.all_reduce(t, group=_SYNC_BN['group'])
+        _SYNC_BN['n_collectives'] += 1
+
+
+def sync_bn_begin(n_images: int, device) -> None:
+    """Start of a detection-head pass under SyncBatchNorm: the number of images of THIS rank (labelled frames, data
+    dependent) is summed over ranks ONCE; every BatchNorm layer of the pass then derives its global row count on the device as
+    rows-per-image x images (exact integers), so the per-layer exchanges carry only the statistics, in place, with no packing."""
+    if not _sync_bn_on():
+        _SYNC_BN['images'] = None
+        return
+    images = torch.full((1,), float(n_images), dtype=torch.float64, device=device)
+    _allreduce_stats(images)
+    _SYNC_BN['images'] = images
 
 
 def flush_bn_counters(module: torch.nn.Module) -> None:
@@ -313,38 +326,122 @@ class BaseConvFn(Function):
         if not training:
             return ops.conv_nhwc_fwd(x, conv_w, None, stride=stride,
                                      bn=(bn_w, bn_b, mod.bn.running_mean, mod.bn.running_var), bn_eps=mod.bn.eps)
-        N = conv_w.shape[0]
-        colstats = ops.StatArena.zeros((2, N), x.device)
-        z = ops.conv_nhwc_fwd(x, conv_w, None, stride=stride, colstats=colstats)
-        count = z.numel() // N
-        count_dev = None
-        if _sync_bn_on():                   # SyncBatchNorm: one small all-reduce of (sum, sumsq, rows) per layer
-            packed = torch.cat([colstats.view(-1), torch.full((1,), float(count), dtype=torch.float64, device=x.device)])
-            _allreduce_stats(packed)
-            colstats = packed
-            count_dev = packed[2 * N:]
-        mom = mod.bn.momentum if mod.bn.momentum is not None else 0.1
-        y, mean, rstd = ops.bn_silu_fwd(z, colstats, bn_w, bn_b, mod.bn.running_mean, mod.bn.running_var, count,
-                                        eps=mod.bn.eps, momentum=mom, count_dev=count_dev)
-        mod.bn_calls_pending = getattr(mod, 'bn_calls_pending', 0) + 1     # flushed into num_batches_tracked lazily (flush_bn_counters)
-        if any(ctx.needs_input_grad):
-            ctx.mod, ctx.stride, ctx.count, ctx.count_dev = mod, stride, count, count_dev
-            ctx.save_for_backward(x, z, mean, rstd, conv_w, bn_w, bn_b)
+        need = any(ctx.needs_input_grad)
+        y, saved = _conv_bn_fwd([(mod, x, conv_w, bn_w, bn_b, stride)], need)[0]
+        if need:
+            ctx.mod, ctx.stride = mod, stride
+            ctx.count, ctx.count_dev = saved[-2], saved[-1]
+            ctx.save_for_backward(x, *saved[:-2], conv_w, bn_w, bn_b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, z, mean, rstd, conv_w, bn_w, bn_b = ctx.saved_tensors
-        mod = ctx.mod
-        dy = _cont(dy)
-        sums = ops.bn_silu_bwd_reduce(dy, z, mean, rstd, bn_w, bn_b)
-        _allreduce_stats(sums)
-        dz = ops.bn_silu_bwd_apply(dy, z, mean, rstd, bn_w, bn_b, sums, grad_buf(mod.bn.weight), grad_buf(mod.bn.bias), ctx.count,
-                                   count_dev=ctx.count_dev)
-        with _wgrad_side(dz, x):
-            ops.conv_nhwc_wgrad(dz, x, grad_buf(mod.conv.weight), None, stride=ctx.stride)
-        dx = ops.conv_nhwc_dgrad(dz, conv_w, x.shape, stride=ctx.stride) if ctx.needs_input_grad[1] else None
+        dx = _conv_bn_bwd([(ctx.mod, x, z, mean, rstd, conv_w, bn_w, bn_b, ctx.stride, ctx.count, ctx.count_dev, _cont(dy),
+                            ctx.needs_input_grad[1])])[0]
         return None, dx, None, None, None, None, None
+
+
+def _conv_bn_fwd(members, need):
+    """Training forward of one or several INDEPENDENT BaseConv layers: all convs (their epilogues accumulate the column
+    statistics into one contiguous block), ONE SyncBatchNorm all-reduce for the whole block, then the BN + SiLU kernels.
+    members: (mod, x, conv_w, bn_w, bn_b, stride) -> [(y, (z, mean, rstd, count, count_dev))]."""
+    dev = members[0][1].device
+    sync = _sync_bn_on()
+    block = ops.StatArena.zeros((sum(2 * m[2].shape[0] for m in members),), dev)
+    zs, off = [], 0
+    for mod, x, conv_w, bn_w, bn_b, stride in members:
+        N = conv_w.shape[0]
+        zs.append(ops.conv_nhwc_fwd(x, conv_w, None, stride=stride, colstats=block[off:off + 2 * N].view(2, N)))
+        off += 2 * N
+    images = _SYNC_BN['images'] if sync else None
+    if sync:
+        assert images is not None, 'SyncBatchNorm: functions.sync_bn_begin(n_images) must open the pass (YoloXDetector.forward_detect does)'
+        _allreduce_stats(block)
+    out, off = [], 0
+    for (mod, x, conv_w, bn_w, bn_b, stride), z in zip(members, zs):
+        N = conv_w.shape[0]
+        rows = z.numel() // N
+        count = rows // z.shape[0] if sync else rows            # SyncBN: rows per image; the kernels multiply by ``images``
+        mom = mod.bn.momentum if mod.bn.momentum is not None else 0.1
+        y, mean, rstd = ops.bn_silu_fwd(z, block[off:off + 2 * N].view(2, N), bn_w, bn_b, mod.bn.running_mean, mod.bn.running_var,
+                                        count, eps=mod.bn.eps, momentum=mom, count_dev=images)
+        off += 2 * N
+        mod.bn_calls_pending = getattr(mod, 'bn_calls_pending', 0) + 1     # flushed into num_batches_tracked lazily (flush_bn_counters)
+        out.append((y, (z, mean, rstd, count, images) if need else None))
+    return out
+
+
+def _conv_bn_bwd(members):
+    """Backward of the same group: the (sum du, sum du*xhat) reductions of all members into one block, ONE all-reduce, then
+    per member the BN backward, the weight gradient (side stream) and the input gradient.
+    members: (mod, x, z, mean, rstd, conv_w, bn_w, bn_b, stride, count, count_dev, dy, need_dx) -> [dx | None]."""
+    live = [m for m in members if m[11] is not None]
+    dxs = {}
+    if live:
+        dev = live[0][1].device
+        block = ops.StatArena.zeros((sum(2 * m[5].shape[0] for m in live),), dev)
+        off = 0
+        slices = []
+        for mod, x, z, mean, rstd, conv_w, bn_w, bn_b, stride, count, count_dev, dy, need_dx in live:
+            N = conv_w.shape[0]
+            sl = block[off:off + 2 * N].view(2, N)
+            ops.bn_silu_bwd_reduce(dy, z, mean, rstd, bn_w, bn_b, out=sl)
+            slices.append(sl)
+            off += 2 * N
+        _allreduce_stats(block)
+        for (mod, x, z, mean, rstd, conv_w, bn_w, bn_b, stride, count, count_dev, dy, need_dx), sl in zip(live, slices):
+            dz = ops.bn_silu_bwd_apply(dy, z, mean, rstd, bn_w, bn_b, sl, grad_buf(mod.bn.weight), grad_buf(mod.bn.bias), count,
+                                       count_dev=count_dev)
+            with _wgrad_side(dz, x):
+                ops.conv_nhwc_wgrad(dz, x, grad_buf(mod.conv.weight), None, stride=stride)
+            dxs[id(mod)] = ops.conv_nhwc_dgrad(dz, conv_w, x.shape, stride=stride) if need_dx else None
+    return [dxs.get(id(m[0])) for m in members]
+
+
+class BaseConvGroupFn(Function):
+    """Several independent BaseConv layers evaluated as ONE autograd node so that their SyncBatchNorm statistics travel in one
+    all-reduce per direction (the three head levels' stems, the cls / reg tower layers of equal depth, conv1 / conv2 of a CSP
+    layer).  Only used when SyncBatchNorm is on; values are identical to separate ``BaseConvFn`` calls.
+    apply(mods, x_0..x_{n-1}, (conv_w, bn_w, bn_b) x n) -> y_0..y_{n-1}"""
+
+    @staticmethod
+    def forward(ctx, mods, *tensors):
+        n = len(mods)
+        xs, params = tensors[:n], tensors[n:]
+        need = any(ctx.needs_input_grad)
+        res = _conv_bn_fwd([(mods[i], xs[i], params[3 * i], params[3 * i + 1], params[3 * i + 2], mods[i].stride) for i in range(n)], need)
+        if need:
+            ctx.mods = mods
+            ctx.meta = [(r[1][3], r[1][4]) for r in res]
+            flat = []
+            for i, r in enumerate(res):
+                flat += [xs[i], r[1][0], r[1][1], r[1][2], params[3 * i], params[3 * i + 1], params[3 * i + 2]]
+            ctx.save_for_backward(*flat)
+        return tuple(r[0] for r in res)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        sv, mods = ctx.saved_tensors, ctx.mods
+        n = len(mods)
+        members = []
+        for i in range(n):
+            x, z, mean, rstd, conv_w, bn_w, bn_b = sv[7 * i:7 * i + 7]
+            members.append((mods[i], x, z, mean, rstd, conv_w, bn_w, bn_b, mods[i].stride, ctx.meta[i][0], ctx.meta[i][1],
+                            _cont(dys[i]), ctx.needs_input_grad[1 + i]))
+        dxs = _conv_bn_bwd(members)
+        return (None,) + tuple(dxs) + (None,) * (3 * n)
+
+
+def base_conv_group(mods, xs):
+    """[BaseConv], [NHWC maps] -> [outputs]; grouped into one node (one statistics exchange) in SyncBatchNorm training, plain
+    per-layer calls otherwise."""
+    if len(mods) > 1 and mods[0].training and _sync_bn_on():
+        params = []
+        for m in mods:
+            params += [m.conv.weight, m.bn.weight, m.bn.bias]
+        return list(BaseConvGroupFn.apply(tuple(mods), *xs, *params))
+    return [m.forward_nhwc(x) for m, x in zip(mods, xs)]
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -61,8 +61,7 @@ class CSPLayer(nn.Module):
         self.m = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut, 1.0, depthwise, act=act) for _ in range(n)])
 
     def forward_nhwc(self, x):
-        x1 = self.conv1.forward_nhwc(x)
-        x2 = self.conv2.forward_nhwc(x)
+        x1, x2 = Fn.base_conv_group([self.conv1, self.conv2], [x, x])     # same input, independent: one statistics exchange
         for b in self.m:
             x1 = b.forward_nhwc(x1)
         return self.conv3.forward_nhwc(torch.cat((x1, x2), dim=-1))

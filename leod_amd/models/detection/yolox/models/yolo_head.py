@@ -76,12 +76,15 @@ class YOLOXHead(nn.Module):
         return labels
 
     def _towers(self, xin):
+        # the three levels are independent: layers of equal depth form one group (one SyncBatchNorm exchange per group)
+        n = len(xin)
+        xs = Fn.base_conv_group(list(self.stems), list(xin))
+        for d in (0, 1):
+            ys = Fn.base_conv_group([self.cls_convs[k][d] for k in range(n)] + [self.reg_convs[k][d] for k in range(n)],
+                                    (xs + xs) if d == 0 else ys)
         feats = []
-        for k, x in enumerate(xin):
-            x = self.stems[k].forward_nhwc(x)
-            cf = self.cls_convs[k][1].forward_nhwc(self.cls_convs[k][0].forward_nhwc(x))
-            rf = self.reg_convs[k][1].forward_nhwc(self.reg_convs[k][0].forward_nhwc(x))
-            feats += [cf, rf]
+        for k in range(n):
+            feats += [ys[k], ys[n + k]]
         return feats
 
     def forward(self, xin, labels=None, pred_probs=None):

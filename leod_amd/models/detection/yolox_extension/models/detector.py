@@ -29,6 +29,8 @@ class YoloXDetector(th.nn.Module):
         """-> (outputs [B, N, 4+1+num_cls], losses dict | None)."""
         assert soft_targets is None
         x2, x1, x0 = (Fn.to_nhwc(backbone_features[f]) for f in self.fpn.in_features)
+        if self.training:
+            Fn.sync_bn_begin(x0.shape[0], x0.device)     # SyncBatchNorm: images over all ranks, once per pass (no-op on one rank)
         fpn_feats = self.fpn.forward_nhwc(x2, x1, x0)
         if self.training:
             assert targets is not None

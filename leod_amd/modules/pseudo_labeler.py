@@ -290,7 +290,8 @@ class PseudoLabeler(Module):
         rnn.reset(worker_id=worker_id, indices_or_bool_tensor=is_first)
         prev = rnn.get_states(worker_id=worker_id)
         self.mode_2_seq_lens.reset(worker_id=worker_id, indices_or_bool_tensor=is_first)
-        pse_mask, gt_mask, _ = self._get_pred_mask(worker_id, data)
+        pse_mask, gt_mask, skipped_gt_mask = self._get_pred_mask(worker_id, data)
+        skipped_gt_labels: List[ObjectLabels] = [skipped[t][b] for t in range(L) for b in range(B) if skipped_gt_mask[t, b]]
         gt_labels: List[ObjectLabels] = []
         if self.use_gt:
             for t in range(L):
@@ -329,16 +330,27 @@ class PseudoLabeler(Module):
                                     hw=tuple(self.dst_config.ev_repr_hw), dataset_name=self.dst_name,
                                     downsampled_by_2=self.ds_by2)
         all_labels = [[None] * L for _ in range(B)]
+        skipped_gt_pse_labels: List[ObjectLabels] = []
         gi = pi = 0
         for t in range(L):
             for b in range(B):
+                if skipped_gt_mask[t, b]:
+                    assert pse_mask[t, b], 'should predict on skipped GT frames'
+                    skipped_gt_pse_labels.append(pse_labels[pi])
                 if pse_mask[t, b]:
                     all_labels[b][t] = pse_labels[pi]
                     pi += 1
                 elif gt_mask[t, b]:
                     all_labels[b][t] = gt_labels[gi]
                     gi += 1
-        assert pi == int(pse_mask.sum()) and gi == int(gt_mask.sum())
+        assert pi == int(pse_mask.sum()) and gi == int(gt_mask.sum()) and len(skipped_gt_pse_labels) == len(skipped_gt_labels)
+        if skipped_gt_labels and mode in self.mode_2_psee_evaluator:
+            # quality of the pseudo labels on frames whose GT was withheld (reference :753-763): detection KPIs at the end of the
+            # run (``run_psee_evaluator``; gathered over ranks by ``leod_amd.predict.run_pseudo_labeling``)
+            from leod_amd.utils.evaluation.prophesee.io.box_loading import to_prophesee
+            labels_proph, preds_proph = to_prophesee(skipped_gt_labels, skipped_gt_pse_labels)
+            self.mode_2_psee_evaluator[mode].add_labels(labels_proph)
+            self.mode_2_psee_evaluator[mode].add_predictions(preds_proph)
         ev_idx = th.stack(data[DataType.EV_IDX]).transpose(1, 0).cpu().numpy().tolist()
         padding = th.stack(data[DataType.IS_PADDED_MASK]).transpose(1, 0).cpu().numpy().tolist()
         return (all_labels, data[DataType.PATH], ev_idx, is_first.cpu().numpy().tolist(),
@@ -348,7 +360,8 @@ class PseudoLabeler(Module):
     def predict_step(self, batch: Any, batch_idx: int = 0) -> None:
         out = self._predict_step_impl(batch=batch, mode=Mode.TEST)
         for labels, path, ev_idx, is_first, is_last, padded, hflip, tflip in zip(*out):
-            if not path:
+            if not path:                                      # padding slot of the streaming loader
+                assert not is_first and not is_last and all(padded) and all(i == -1 for i in ev_idx), 'invalid empty data'
                 continue
             if path not in self.ev_path_2_ev_data:
                 assert is_first, 'should load the first sample first'

@@ -371,11 +371,11 @@ class StatArena:
         return torch.zeros(shape, dtype=torch.float64, device=device)
 
 
-def bn_silu_bwd_reduce(dy, z, mean, rstd, w, b):
+def bn_silu_bwd_reduce(dy, z, mean, rstd, w, b, out=None):
     _ck(dy, name='dy')
     N = z.shape[-1]
     M = z.numel() // N
-    sums = StatArena.zeros((2, N), z.device)
+    sums = StatArena.zeros((2, N), z.device) if out is None else out
     check(_l().leod_bn_silu_bwd_reduce(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(sums), M, N, _stream()),
           'bn_silu_bwd_reduce')
     return sums

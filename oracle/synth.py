@@ -272,13 +272,13 @@ LOADER_RECORDINGS = [   # (name, seed, n_frames, labelled frames)
 ]
 
 
-def synth_dataset_tree(root: str, dst_name: str = 'gen1', ds2: bool = False):
+def synth_dataset_tree(root: str, dst_name: str = 'gen1', ds2: bool = False, frame_hw=(6, 8)):
     """root/<dst_name>/{train,val,test}/rec_* from LOADER_RECORDINGS -> the dataset path."""
     import os
     base = os.path.join(root, dst_name)
     for split, off in (('train', 0), ('val', 100), ('test', 200)):
         for name, seed, n, lab in LOADER_RECORDINGS:
-            synth_recording(os.path.join(base, split), name, seed + off, n, lab, dst_name=dst_name, ds2=ds2)
+            synth_recording(os.path.join(base, split), name, seed + off, n, lab, dst_name=dst_name, ds2=ds2, frame_hw=frame_hw)
     return base
 
 

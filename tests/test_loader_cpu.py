@@ -245,3 +245,99 @@ def test_pseudo_label_dataset_round_trip(trees, tmp_path):
     src_seq = SequenceForIter(path=Path(src), ev_representation_name=EV_NAME, sequence_length=5, dataset_type=DatasetType.GEN1,
                               downsample_by_factor_2=False, start_from_zero=True)
     assert torch.equal(torch.stack(seq[1][DataType.EV_REPR]), torch.stack(src_seq[1][DataType.EV_REPR]))       # linked frames
+
+
+# ---- the pseudo-label pass sharded over ranks (gloo, world size 2, CPU) ----------------------------------------
+class _RecordingModule(torch.nn.Module):
+    """Stands in for PseudoLabeler where no GPU is available: same driver-facing surface (setup, transfer_batch_to_device,
+    predict_step, ev_path_2_ev_data, ev_cnt, evaluator buffer), but ``predict_step`` only records what it was fed."""
+
+    def __init__(self):
+        super().__init__()
+        from leod_amd.modules.utils.detection import Mode
+        from leod_amd.utils.evaluation.prophesee.evaluator import PropheseeEvaluator
+        self.w = torch.nn.Parameter(torch.zeros(1))
+        self.ev_path_2_ev_data, self.ev_cnt, self.save_dir, self.dst_name = {}, 0, '', 'gen1'
+        self.mode_2_psee_evaluator = {Mode.TEST: PropheseeEvaluator(dataset='gen1', downsample_by_2=False)}
+        self.mode_2_hw, self.mode_2_batch_size = {Mode.TEST: (240, 304)}, {Mode.TEST: 2}
+        self.seen = {}
+
+    def setup(self, stage):
+        assert stage == 'predict'
+
+    def transfer_batch_to_device(self, batch, device, dataloader_idx=0):
+        return batch
+
+    def predict_step(self, batch, batch_idx=0):
+        from leod_amd.data.utils.types import DataType
+        from leod_amd.modules.utils.detection import DATA_KEY, Mode
+        from leod_amd.utils.evaluation.prophesee.io.box_loading import to_prophesee
+        data = batch[DATA_KEY]
+        for b, path in enumerate(data[DataType.PATH]):
+            if not path:
+                continue
+            key = (path, bool(data[DataType.IS_REVERSED][b]))
+            self.seen.setdefault(key, []).extend(int(data[DataType.EV_IDX][t][b]) for t in range(len(data[DataType.EV_IDX]))
+                                                 if int(data[DataType.EV_IDX][t][b]) >= 0)
+            if path not in self.ev_path_2_ev_data:
+                self.ev_path_2_ev_data[path] = type('E', (), {'eoe': True})()
+                self.ev_cnt += 1
+            for t in range(len(data[DataType.OBJLABELS_SEQ])):
+                lab = data[DataType.OBJLABELS_SEQ][t][b]
+                if lab is not None and not key[1]:                   # "predict" the GT itself on the plain view
+                    l, p = to_prophesee([lab], [lab])
+                    self.mode_2_psee_evaluator[Mode.TEST].add_labels(l)
+                    self.mode_2_psee_evaluator[Mode.TEST].add_predictions(p)
+
+
+def _predict_worker(rank, world, port, tree, q):
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    from leod_amd.config import full_config, dynamically_modify_train_config
+    from leod_amd.modules.data.genx import DataModule
+    from leod_amd.predict import run_pseudo_labeling
+    cfg = dynamically_modify_train_config(full_config('gen1', 'small', model='pseudo_labeler', is_train=False, overrides=dict(
+        tta=dict(enable=True, hflip=True, tflip=True),
+        dataset=dict(path=tree, sequence_length=5, data_augmentation=dict(stream=dict(start_from_zero=True))))))
+    dm = DataModule(cfg.dataset, 2, 1, 4, 2, prefetch=2)
+    mod = _RecordingModule()
+    out = run_pseudo_labeling(cfg, mod, dm, device=torch.device('cpu'), save=False)
+    q.put((rank, {k: sorted(v) for k, v in mod.seen.items()}, out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_pseudo_label_pass_sharded_over_two_ranks_gloo(trees):
+    """run_pseudo_labeling with world size 2 (gloo): the union of what the ranks processed is exactly what one rank processes
+    (every frame of every recording once per TTA view), a recording and its time-reversed copy meet on ONE rank, nothing is
+    processed twice, and the gathered quality KPIs equal the single-rank ones."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    res = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = 35000 + (os.getpid() % 2000)
+        procs = [ctx.Process(target=_predict_worker, args=(r, world, port, trees['gen1'], q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res[world] = sorted((q.get(timeout=240) for _ in range(world)), key=lambda r: r[0])
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+    single = res[1][0]
+    assert len(single[1]) == 2 * len(LOADER_RECORDINGS)                            # plain + reversed view of every recording
+    assert single[2]['num_sequences'] == len(LOADER_RECORDINGS) and single[2]['metrics'] is not None
+    union = {}
+    for rank, seen, out in res[2]:
+        assert out['num_sequences'] == len(LOADER_RECORDINGS) and sum(out['num_sequences_rank']) == len(LOADER_RECORDINGS)
+        assert out['metrics'] == single[2]['metrics']
+        paths = {p for p, _ in seen}
+        assert {(p, False) for p in paths} | {(p, True) for p in paths} == set(seen)       # both views on this rank
+        for k, v in seen.items():
+            assert k not in union
+            union[k] = v
+    assert union == single[1]
+    assert min(res[2][0][2]['num_sequences_rank']) >= 1

@@ -415,3 +415,91 @@ def test_module_world2_through_reference_surface(gpu, manifest):
     rv = np.concatenate([b.running_var.detach().cpu().numpy() for b in bns])
     np.testing.assert_allclose(res[0][3], rm, rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(res[0][4], rv, rtol=2e-5, atol=1e-6)
+
+
+# ---- the pseudo-label pass over a dataset on disk, one rank vs two ranks ---------------------------------------
+def _pseudo_label_worker(rank, world, port, tree, save_dir, manifest, q):
+    import os
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    from leod_amd.config import full_config, dynamically_modify_train_config
+    from leod_amd.modules.data.genx import DataModule
+    from leod_amd.modules.utils.fetch import fetch_model_module
+    from leod_amd.predict import run_pseudo_labeling
+    over = dict(model=dict(backbone=dict(embed_dim=16, stage=dict(attention=dict(dim_head=8)))), save_dir=save_dir,
+                tta=dict(enable=True, hflip=True, tflip=True),
+                dataset=dict(path=tree, sequence_length=4, ratio=0.5, data_augmentation=dict(stream=dict(start_from_zero=True))))
+    cfg = dynamically_modify_train_config(full_config('gen1', 'small', model='pseudo_labeler', is_train=False, overrides=over))
+    cfg.dataset.ev_repr_hw = HW
+    cfg.model.backbone.in_res_hw = (64, 96)
+    cfg.model.backbone.stage.attention.partition_size = (2, 3)
+    cfg.model.postprocess.confidence_threshold = 0.01
+    cfg.model.pseudo_label.obj_thresh, cfg.model.pseudo_label.cls_thresh = [0.1, 0.05], [0.1, 0.05]
+    cfg.model.pseudo_label.min_track_len = 2
+    mod = fetch_model_module(cfg)
+    mod.mdl.load_state_dict(synth_state_dict(manifest['micro'], 8))
+    mod.to(DEV)
+    dm = DataModule(cfg.dataset, 2, 1, 4, 2, prefetch=2)
+    out = run_pseudo_labeling(cfg, mod, dm)
+    q.put((rank, out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_pseudo_label_round_one_rank_equals_two_ranks(gpu, manifest, tmp_path):
+    """The whole pseudo-labelling round through the product surface -- dataset tree on disk -> DataModule('predict') ->
+    PseudoLabeler.predict_step (hflip + time-flip TTA, sparse labels: every second labelled frame withheld and used for the
+    quality KPIs) -> EventSeqData.save -- sharded over two ranks (gloo, one GPU) writes the same dataset as one rank, and the
+    gathered KPIs agree."""
+    import os
+    import pickle
+    import torch.multiprocessing as mp
+    from oracle.synth import LOADER_RECORDINGS, synth_dataset_tree
+    from leod_amd.data.genx_utils import dataset_streaming
+    from leod_amd.data.utils import misc
+    tree = synth_dataset_tree(str(tmp_path / 'src'), 'gen1', False, frame_hw=HW)
+    # the sparse-label lists of the WSOD regime (normally written by build_random_access_dataset of the training run)
+    fn = os.path.join(dataset_streaming.SPLITS_DIR, 'gen1', 'ssod_0.500-off0.pkl')
+    had = os.path.exists(fn)
+    os.makedirs(os.path.dirname(fn), exist_ok=True)
+    if not had:
+        with open(fn, 'wb') as f:
+            pickle.dump({name: list(range(0, len(lab), 2)) for name, _, _, lab in LOADER_RECORDINGS}, f)
+    try:
+        ctx = mp.get_context('spawn')
+        res = {}
+        for world in (1, 2):
+            save_dir = str(tmp_path / f'gen1_w{world}' / 'train')
+            q = ctx.Queue()
+            port = 36000 + (os.getpid() % 2000) + world
+            procs = [ctx.Process(target=_pseudo_label_worker, args=(r, world, port, tree, save_dir, manifest, q)) for r in range(world)]
+            for p in procs:
+                p.start()
+            res[world] = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
+            for p in procs:
+                p.join(120)
+                assert p.exitcode == 0
+    finally:
+        if not had:
+            os.remove(fn)
+    one = res[1][0][1]
+    assert one['num_sequences'] == len(LOADER_RECORDINGS) and len(one['saved']) == len(LOADER_RECORDINGS)
+    assert one['metrics'] is not None
+    assert sorted(sum((r[1]['saved'] for r in res[2]), [])) == sorted(s.replace('gen1_w1', 'gen1_w2') for s in one['saved'])
+    assert all(len(r[1]['saved']) >= 1 for r in res[2])
+    n_boxes = 0
+    for name, _, _, _ in LOADER_RECORDINGS:
+        a, b = (str(tmp_path / f'gen1_w{w}' / 'train' / name) for w in (1, 2))
+        assert misc.read_objframe_idx_2_repr_idx(a).tolist() == misc.read_objframe_idx_2_repr_idx(b).tolist()
+        (la, sa), (lb, sb) = misc.read_npz_labels(a), misc.read_npz_labels(b)
+        assert sa.tolist() == sb.tolist() and len(la) == len(lb)
+        for k in la.dtype.names:
+            np.testing.assert_allclose(la[k].astype(np.float64), lb[k].astype(np.float64), rtol=1e-5, atol=1e-5, err_msg=f'{name} {k}')
+        n_boxes += len(la)
+    assert n_boxes > 20
+    for k, v in one['metrics'].items():
+        assert res[2][0][1]['metrics'][k] == pytest.approx(v, rel=1e-6, abs=1e-9), k
