@@ -23,6 +23,13 @@ typedef void* leod_stream_t; /* hipStream_t */
 
 const char* leod_version(void);
 
+/* Precision of the contractions (process-wide; set before the first step).  0: fp32 end to end -- v_mfma_f32_16x16x4_f32, bitwise an
+ * fp32 fmaf chain, the mode the parity tests pin against the fp32 oracle.  1: the reference's mixed precision (Lightning precision=16,
+ * train.py:236-243): GEMM / conv / attention operands rounded to bf16 for v_mfma_f32_16x16x16_bf16, fp32 accumulation; LayerNorm /
+ * BatchNorm statistics, softmax, the residual stream, LSTM state, SimOTA cost, losses and the optimiser stay fp32. */
+int leod_set_precision(int mode);
+int leod_get_precision(void);
+
 /* ---- backbone: MaxViT block pieces (models/layers/maxvit/maxvit.py) ------------------------------ */
 
 /* out[M,N] = LN(x)[M,K] W[N,K]^T + bias (LN skipped when ln_w == NULL); out_act (optional) = gelu_erf(out);

@@ -87,3 +87,39 @@ __device__ __forceinline__ f4 zero4() { f4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+
+
+// ---- bf16 MFMA operands (precision mode "bf16", reference: Lightning precision=16, train.py:236-243) -----------------------------
+// v_mfma_f32_16x16x16_bf16: A: lane l holds A[i = l&15][k = 4*(l>>4) .. +3] as 4 bf16; B: B[k = 4*(l>>4) .. +3][j = l&15];
+// C/D as above.  One instruction contracts the same 16-k chunk the fp32 path feeds to FOUR v_mfma_f32_16x16x4_f32 (the
+// K-permutation "lane (i,q) holds k0+4q..+3" IS this operand layout), at 8x the fp32 MFMA rate; fp32 accumulation.
+typedef short s4 __attribute__((ext_vector_type(4)));
+typedef float f2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bf2_ __attribute__((ext_vector_type(2)));
+typedef unsigned u2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s4 pack_bf16(f4 v) {             // 2 x v_cvt_pk_bf16_f32 (round to nearest even)
+    const f2_ lo = {v.x, v.y}, hi = {v.z, v.w};
+    const u2_ r = {__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf2_)),
+                   __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf2_))};
+    return __builtin_bit_cast(s4, r);
+}
+__device__ __forceinline__ f4 mfma16_bf16(s4 a, s4 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+
+// Operand fragment of one 16-k chunk in either precision: BF = false keeps the f4 (four exact fp32 MFMAs consume it),
+// BF = true packs it to 4 bf16 once (one bf16 MFMA consumes it).
+template <bool BF> struct Frag16;
+template <> struct Frag16<false> { f4 v; __device__ __forceinline__ void set(f4 x) { v = x; } };
+template <> struct Frag16<true> { s4 v; __device__ __forceinline__ void set(f4 x) { v = pack_bf16(x); } };
+template <bool BF> __device__ __forceinline__ f4 mfma_frag(const Frag16<BF>& a, const Frag16<BF>& b, f4 c) {
+    if constexpr (BF) return mfma16_bf16(a.v, b.v, c);
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = mfma16(a.v[j], b.v[j], c);
+        return c;
+    }
+}
+
+// Precision mode of the library (host side): 0 = fp32 end to end (bit-tight against the fp32 oracle), 1 = bf16 MFMA operands
+// with fp32 accumulation / statistics / state.  Set through leod_set_precision; read by the launchers.
+int leod_precision();
+#define LEOD_BY_PREC(CALL_BF, CALL_F32) (leod_precision() == 1 ? (CALL_BF) : (CALL_F32))

@@ -569,7 +569,7 @@ struct EpLstm {                     // NT must be 4: tiles = (f, i, o, g) of cha
 //            and 4x shorter dependent MFMA chains, no atomics.
 // Operand loads run two chunks ahead of the MFMAs (register ring of depth 2).
 // =================================================================================================
-template <int NT, int KS, class AL, class BL, class EP>
+template <int NT, int KS, bool BF, class AL, class BL, class EP>
 __global__ __launch_bounds__(256) void gemm16_kernel(AL al, BL bl, EP ep, int M, int K) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -609,10 +609,16 @@ __global__ __launch_bounds__(256) void gemm16_kernel(AL al, BL bl, EP ep, int M,
 #pragma unroll
                 for (int t = 0; t < NT; ++t) b0[t] = bl.load(nblk, t, i, kn * 16 + 4 * q, K, aux);
             }
+            if constexpr (BF) {
+                Frag16<true> fa; fa.set(ta);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int t = 0; t < NT; ++t) { Frag16<true> fb; fb.set(tb[t]); acc[t] = mfma_frag<true>(fa, fb, acc[t]); }
+            } else {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = mfma16(ta[j], tb[t][j], acc[t]);
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = mfma16(ta[j], tb[t][j], acc[t]);
+            }
         }
         if (kc + kstep < KC) {   // chunk kc + kstep from ring slot 1
             const f4 ta = a1; f4 tb[NT];
@@ -624,10 +630,16 @@ __global__ __launch_bounds__(256) void gemm16_kernel(AL al, BL bl, EP ep, int M,
 #pragma unroll
                 for (int t = 0; t < NT; ++t) b1[t] = bl.load(nblk, t, i, kn * 16 + 4 * q, K, aux);
             }
+            if constexpr (BF) {
+                Frag16<true> fa; fa.set(ta);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int t = 0; t < NT; ++t) { Frag16<true> fb; fb.set(tb[t]); acc[t] = mfma_frag<true>(fa, fb, acc[t]); }
+            } else {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = mfma16(ta[j], tb[t][j], acc[t]);
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = mfma16(ta[j], tb[t][j], acc[t]);
+            }
         }
     }
     if (KS > 1) {
@@ -656,12 +668,15 @@ static inline int launch_gemm16(const AL& al, const BL& bl, const EP& ep, int M,
     if (M <= 0) return LEOD_OK;
     // fewer than ~2 workgroups per CU and a long K loop: split K across the 4 waves of each workgroup
     const bool ksplit = (long)cdiv(M, 64) * nblocks_n < 512 && K >= 128;
+    const bool bf = leod_precision() == 1;
     if (ksplit) {
         dim3 grid(cdiv(M, 16), nblocks_n);
-        hipLaunchKernelGGL((gemm16_kernel<NT, 4, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+        if (bf) hipLaunchKernelGGL((gemm16_kernel<NT, 4, true, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+        else hipLaunchKernelGGL((gemm16_kernel<NT, 4, false, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
     } else {
         dim3 grid(cdiv(M, 64), nblocks_n);
-        hipLaunchKernelGGL((gemm16_kernel<NT, 1, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+        if (bf) hipLaunchKernelGGL((gemm16_kernel<NT, 1, true, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+        else hipLaunchKernelGGL((gemm16_kernel<NT, 1, false, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
     }
     return leod_launch_status();
 }
@@ -677,7 +692,13 @@ static inline int launch_gemm16(const AL& al, const BL& bl, const EP& ep, int M,
 // RW = 16-row fragments per wave (workgroup = 64*RW rows): RW = 2 halves the B-fragment LDS reads and the B staging per
 // output row -- the MFMA-bound shapes (RVT stages 3/4, 3x3 convs) were LDS-bandwidth limited at RW = 1 (every wave
 // re-reads the whole B tile: 5 ds_read_b128 per 16 MFMAs, x 16 resident waves per CU > 128 B/clk).
-template <int NT, int KCH, int NBUF, int RW, class AL, class BL, class EP>
+// BF = true (precision mode bf16): both operands are rounded to bf16 when they are stashed, LDS holds bf16 (half the bytes, half
+// the fragment-read traffic) and one v_mfma_f32_16x16x16_bf16 replaces the four fp32 MFMAs of a 16-k chunk.  Row-major operand tiles
+// keep rows of KCH + 8 bf16: a row stride of 4 * odd dwords puts the 32 fragment starts of a ds_read_b64 lane group on 32
+// distinct bank pairs.  Transposed weights (dgrad: W[k][n], n contiguous) are stored as [16 k][16 n] blocks in their natural
+// orientation (8-byte stores of 4 n; block stride 512 + 32 bytes keeps the 16-lane store groups conflict-free) and read back with
+// ds_read_b64_tr_b16, whose 16-lane groups return the [4 k][16 n] block column-wise: lane (i, q) gets W[4q..4q+3][n = i].
+template <int NT, int KCH, int NBUF, int RW, bool BF, class AL, class BL, class EP>
 __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_lds_kernel(AL al, BL bl, EP ep, int M, int K, int nblocks_n) {
     constexpr int BM = 64 * RW;
     // ds_read_b128 is serviced in 4 groups of 16 lanes, {0-3,12-15,20-27}, ...: rows {0-3,12-15} at k-offset 4q and rows
@@ -691,13 +712,17 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
     // B fragments by 4 x ds_read_b32 (rows 4q+j land in distinct 16-bank halves when LDN == 4 mod 8).  Transposing on
     // the way in cost 4 scalar stores per float4 with 8- to 16-way bank conflicts.
     constexpr int LDN = BN + 4;
-    constexpr int BSZ = BL::kTrans ? KCH * LDN : BN * LD;
+    constexpr int BST = 16 * 16 + 16;                // bf16 elements per [16 k][16 n] block of transposed weights (+ 32 bytes)
+    // operand buffer sizes in FLOAT units (bf16 tiles are counted in pairs)
+    constexpr int ASZ = BF ? (BM * LD) / 2 : BM * LD;
+    constexpr int BSZ = BF ? (BL::kTrans ? ((KCH / 16) * NT * BST) / 2 : (BN * LD) / 2) : (BL::kTrans ? KCH * LDN : BN * LD);
     constexpr int LDO = 64;                          // accumulator transposition tile of the row-layout epilogue (aliases A/B);
                                                      // 256-byte rows: the (row q, 16-byte column c4) reads are conflict-free
-    static_assert(BM * LD + BSZ >= 64 * LDO, "epilogue tile must fit in the operand buffers");
-    __shared__ __attribute__((aligned(16))) float smem[NBUF * (BM * LD + BSZ)];
-    float (*sA)[BM * LD] = reinterpret_cast<float (*)[BM * LD]>(smem);
-    float (*sB)[BSZ] = reinterpret_cast<float (*)[BSZ]>(smem + NBUF * BM * LD);
+    constexpr int OPS = NBUF * (ASZ + BSZ);
+    constexpr int SMEM = OPS >= 64 * LDO ? OPS : 64 * LDO;      // the epilogue tile must fit in the operand buffers
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float (*sA)[ASZ] = reinterpret_cast<float (*)[ASZ]>(smem);
+    float (*sB)[BSZ] = reinterpret_cast<float (*)[BSZ]>(smem + NBUF * ASZ);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     // XCD-aware 1-D grid: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own L2).  All n-blocks of
@@ -716,7 +741,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
         const int e = tid + 256 * p, r = e / K4, k4 = (e - r * K4) * 4;
         aok[p] = e < BM * K4;
         ast[p] = al.init(brow0 + (aok[p] ? r : 0), M, 0, false);
-        ak[p] = k4; al_off[p] = r * LD + k4;
+        ak[p] = k4; al_off[p] = r * LD + k4;        // element offset (fp32 or bf16 elements alike)
         // 256 % K4 == 0: every slot of a thread has the same k offset -> say so, and the k -> (tap, channel) decode of the
         // im2col / stem loaders is computed once per chunk instead of once per slot
         if constexpr (256 % K4 == 0) ak[p] = ak[0];
@@ -727,7 +752,10 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
         const int e = tid + 256 * p;
         bok[p] = e < BN * K4;
         if (!BL::kTrans) { const int nl = e / K4, k4 = (e - nl * K4) * 4; bn[p] = nl; bk[p] = k4; bl_off[p] = nl * LD + k4; }
-        else { const int kl = e / (BN / 4), n4 = (e - kl * (BN / 4)) * 4; bn[p] = n4; bk[p] = kl; bl_off[p] = kl * LDN + n4; }
+        else {
+            const int kl = e / (BN / 4), n4 = (e - kl * (BN / 4)) * 4; bn[p] = n4; bk[p] = kl;
+            bl_off[p] = BF ? ((kl >> 4) * NT + (n4 >> 4)) * BST + (kl & 15) * 16 + (n4 & 15) : kl * LDN + n4;
+        }
     }
     // parity-class conv dgrad: the live-tap count (hence K) depends on the class of the rows; the caller guarantees
     // that a 64-row workgroup never mixes classes, so both are workgroup-uniform
@@ -747,11 +775,20 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
         }
     };
     auto stash = [&](int buf) {
+        if constexpr (BF) {
+            unsigned short* __restrict__ a16 = reinterpret_cast<unsigned short*>(sA[buf]);
+            unsigned short* __restrict__ b16 = reinterpret_cast<unsigned short*>(sB[buf]);
 #pragma unroll
-        for (int p = 0; p < RA; ++p) if (aok[p]) *reinterpret_cast<f4*>(&sA[buf][al_off[p]]) = ra[p];
+            for (int p = 0; p < RA; ++p) if (aok[p]) *reinterpret_cast<s4*>(a16 + al_off[p]) = pack_bf16(ra[p]);
 #pragma unroll
-        for (int p = 0; p < RB; ++p) if (bok[p]) {
-            *reinterpret_cast<f4*>(&sB[buf][bl_off[p]]) = rb[p];
+            for (int p = 0; p < RB; ++p) if (bok[p]) *reinterpret_cast<s4*>(b16 + bl_off[p]) = pack_bf16(rb[p]);
+        } else {
+#pragma unroll
+            for (int p = 0; p < RA; ++p) if (aok[p]) *reinterpret_cast<f4*>(&sA[buf][al_off[p]]) = ra[p];
+#pragma unroll
+            for (int p = 0; p < RB; ++p) if (bok[p]) {
+                *reinterpret_cast<f4*>(&sB[buf][bl_off[p]]) = rb[p];
+            }
         }
     };
     f4 acc[RW][NT];
@@ -769,6 +806,26 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
         const int buf = NBUF == 1 ? 0 : (ch & 1);
         const bool more = ch + 1 < nch;
         if (more) fetch((ch + 1) * KCH);                      // next chunk's global loads fly under this chunk's MFMAs
+        if constexpr (BF) {
+            typedef __attribute__((address_space(3))) s4 lds_s4;
+            const unsigned short* __restrict__ pa = reinterpret_cast<const unsigned short*>(sA[buf]) + aoff;
+            const unsigned short* __restrict__ pb = reinterpret_cast<const unsigned short*>(sB[buf]) +
+                                                    (BL::kTrans ? (4 * q + (i >> 2)) * 16 + 4 * (i & 3) : boff);
+#pragma unroll
+            for (int c = 0; c < KCH / 16; ++c) {
+                s4 av[RW];
+#pragma unroll
+                for (int w = 0; w < RW; ++w) av[w] = *reinterpret_cast<const s4*>(pa + 16 * w * LD + 16 * c);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    s4 bv;
+                    if constexpr (BL::kTrans) bv = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(pb + (c * NT + t) * BST));
+                    else bv = *reinterpret_cast<const s4*>(pb + 16 * t * LD + 16 * c);
+#pragma unroll
+                    for (int w = 0; w < RW; ++w) acc[w][t] = mfma16_bf16(av[w], bv, acc[w][t]);
+                }
+            }
+        } else {
         const float* __restrict__ pa = sA[buf] + aoff;
         const float* __restrict__ pb = sB[buf] + boff;
 #pragma unroll
@@ -790,6 +847,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
 #pragma unroll
                     for (int w = 0; w < RW; ++w) acc[w][t] = mfma16(av[w][j], bv[j], acc[w][t]);
             }
+        }
         }
         if (NBUF > 1) {
             if (more) stash(buf ^ 1);
@@ -853,12 +911,14 @@ static inline int launch_gemm_lds_rw(const AL& al, const BL& bl, const EP& ep, i
     // single LDS buffer + register prefetch everywhere: residency (3-6 workgroups per CU) hides the two barriers per chunk
     // better than a double buffer at 2-3 workgroups per CU does (measured; LEOD_LDS_NBUF=2 selects the double buffer)
     static const int nbuf = getenv("LEOD_LDS_NBUF") ? atoi(getenv("LEOD_LDS_NBUF")) : 1;
+    (void)nbuf;                                      // the double-buffered variant is no longer instantiated (never faster, see above)
+    const bool bf = leod_precision() == 1;
     if (K % 48 == 0) {
-        if (nbuf == 1 || K == 48) hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 1, RW, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
-        else hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 2, RW, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
+        if (bf) hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 1, RW, true, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
+        else hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 1, RW, false, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
     } else {
-        if (nbuf == 1 || K <= 64) hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 1, RW, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
-        else hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 2, RW, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
+        if (bf) hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 1, RW, true, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
+        else hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 1, RW, false, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
     }
     return leod_launch_status();
 }

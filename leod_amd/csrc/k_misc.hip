@@ -88,7 +88,17 @@ LEOD_API int leod_set_scalars4(float* dst, float a, float b, float c, float d, h
     return leod_launch_status();
 }
 
-LEOD_API const char* leod_version() { return "leod_hip 0.1 (gfx950)"; }
+LEOD_API const char* leod_version() { return "leod_hip 0.2 (gfx950)"; }
+
+// precision mode of the contractions (see common.hpp): process-wide, set once before the first step
+static int g_precision = 0;
+int leod_precision() { return g_precision; }
+LEOD_API int leod_set_precision(int mode) {
+    if (mode != 0 && mode != 1) return LEOD_ERR_ARG;
+    g_precision = mode;
+    return LEOD_OK;
+}
+LEOD_API int leod_get_precision() { return g_precision; }
 
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -286,6 +286,16 @@ class PseudoLabeler(Module):
         obj_labels, skipped = data[DataType.OBJLABELS_SEQ], data[DataType.SKIPPED_OBJLABELS_SEQ]
         is_first = data[DataType.IS_FIRST_SAMPLE]
         L, B = len(obj_labels), len(obj_labels[0])
+        assert L > 0 and B > 0
+        if self.mode_2_batch_size[mode] is None:
+            self.mode_2_batch_size[mode] = B
+        else:
+            assert self.mode_2_batch_size[mode] == B
+        hw = tuple(ev_seq[0].shape[-2:])
+        if self.mode_2_hw[mode] is None:
+            self.mode_2_hw[mode] = hw
+        else:
+            assert self.mode_2_hw[mode] == hw
         rnn = self.mode_2_rnn_states[mode]
         rnn.reset(worker_id=worker_id, indices_or_bool_tensor=is_first)
         prev = rnn.get_states(worker_id=worker_id)

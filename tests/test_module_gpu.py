@@ -479,7 +479,16 @@ def test_pseudo_label_round_one_rank_equals_two_ranks(gpu, manifest, tmp_path):
             procs = [ctx.Process(target=_pseudo_label_worker, args=(r, world, port, tree, save_dir, manifest, q)) for r in range(world)]
             for p in procs:
                 p.start()
-            res[world] = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
+            got = []
+            for _ in range(40 * world):                           # a crashed worker fails the test at once, not after a timeout
+                try:
+                    got.append(q.get(timeout=15))
+                except Exception:
+                    assert all(p.is_alive() or p.exitcode == 0 for p in procs), 'a pseudo-label worker died'
+                if len(got) == world:
+                    break
+            assert len(got) == world
+            res[world] = sorted(got, key=lambda r: r[0])
             for p in procs:
                 p.join(120)
                 assert p.exitcode == 0
