@@ -26,6 +26,7 @@ import torch  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0           # MI355X HBM3E peak (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFLOPS = 157.3    # dense fp32 MFMA peak: 256 FLOP/clk/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF figure includes 2:1 sparsity)
 # SURVEY 8d / DESIGN.md: algorithmic HBM traffic of one RVT-S training event-frame at fp32 activations
 # = 2 x the bf16 figure for activations (2 x (68.61 + 32/168*29.01)) + 395/168 MB optimiser traffic
 ALGO_MB_PER_FRAME_FP32 = 2 * (68.61 + 32.0 / 168.0 * 29.01) + 395.0 / 168.0
@@ -133,14 +134,18 @@ def cpu_baseline_bounded(timeout_s=300):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=8)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--seq-len', type=int, default=21)
     ap.add_argument('--size', default='small')
     ap.add_argument('--dataset', choices=('gen1', 'gen4'), default='gen1', help='gen4: 3 classes, 360x640 frames (downsampled by 2)')
     ap.add_argument('--full-res', action='store_true', help='gen4 at 720x1280 -> 768x1280, 240-token partitions '
                     '(BASELINE configs[3]: --dataset gen4 --full-res --size base --seq-len 11 --batch 2)')
+    ap.add_argument('--dtype', choices=('bf16', 'f32'), default='bf16',
+                    help='precision mode of the contractions (leod_set_precision): bf16 = the reference\'s precision=16 placement (bf16 MFMA '
+                         'operands, fp32 accumulation / statistics / state / optimiser), f32 = fp32 end to end (the bit-tight parity mode)')
+    ap.add_argument('--no-second-dtype', action='store_true', help='skip the secondary line measured in the other precision (N=1 only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -166,91 +171,111 @@ def main():
     hw = (240, 304) if args.dataset == 'gen1' else ((720, 1280) if args.full_res else (360, 640))
     in_hw = tuple(cfg.model.backbone.in_res_hw)
     headline = args.dataset == 'gen1' and args.size == 'small'       # the configuration BASELINE.json's metric is quoted on
-    # The product path, through the reference's own surface (train.py:131-133,228-250): fetch_model_module(config) ->
-    # Module.setup('fit') -> configure_optimizers() -> per batch what Lightning's automatic optimisation does
-    # (optimizer.step(closure: zero_grad, training_step, backward), scheduler.step()).
-    torch.manual_seed(0)                                  # identical random-init weights on every rank
-    module = fetch_model_module(cfg).to(dev)
-    module.setup('fit')
-    module.train()
-    oc = module.configure_optimizers()                    # FlatAdamW (+ flat all-reduce / SyncBN when world > 1) and OneCycleLR
-    opt, sched = (oc['optimizer'], oc['lr_scheduler']['scheduler']) if isinstance(oc, dict) else (oc, None)
     T, B = args.seq_len, args.batch
     label_ts = tuple(t for t in (4, 9, 14, 19) if t < T) or (T - 1,)
-    ev, _, label_tb, labs = make_batch(T, B, hw, cfg.model.head.num_classes, rank, dev, label_ts)
-    g = torch.Generator(device='cpu').manual_seed(77 + rank)
-    # host-side box labels as the loader delivers them: [n, 8] = (t, x, y, w, h, class_id, class_confidence, objectness)
-    lab8 = [np.concatenate([np.ones((len(l), 1), np.float32), l[:, 1:2] - l[:, 3:4] / 2, l[:, 2:3] - l[:, 4:5] / 2, l[:, 3:5],
-                            l[:, 0:1], l[:, 6:7], l[:, 5:6]], 1) for l in labs]
 
-    def first_mask(step):
-        m = torch.ones(B, dtype=torch.bool)
-        if step > 0:                                      # stream half carries state, random half always restarts
-            m[:B // 2] = torch.rand(B // 2, generator=g) < 0.05
-        return m.to(dev)
+    def measure(dtype, steps, warmup, want_roofline):
+        """One full measurement in precision mode ``dtype``: fresh module (same seed), warm-up, K timed steps between barriers,
+        optional roofline probe.  -> dict(dt, loss, roofline, module)."""
+        # The product path, through the reference's own surface (train.py:131-133,228-250): fetch_model_module(config) ->
+        # Module.setup('fit') -> configure_optimizers() -> per batch what Lightning's automatic optimisation does
+        # (optimizer.step(closure: zero_grad, training_step, backward), scheduler.step()).
+        cfg.training.precision = 16 if dtype == 'bf16' else 32
+        os.environ.pop('LEOD_PRECISION', None)                # the config decides (Module.setup -> leod_set_precision)
+        torch.manual_seed(0)                                  # identical random-init weights on every rank
+        module = fetch_model_module(cfg).to(dev)
+        module.setup('fit')
+        module.train()
+        oc = module.configure_optimizers()                    # FlatAdamW (+ flat all-reduce / SyncBN when world > 1) and OneCycleLR
+        opt, sched = (oc['optimizer'], oc['lr_scheduler']['scheduler']) if isinstance(oc, dict) else (oc, None)
+        ev, _, label_tb, labs = make_batch(T, B, hw, cfg.model.head.num_classes, rank, dev, label_ts)
+        g = torch.Generator(device='cpu').manual_seed(77 + rank)
+        # host-side box labels as the loader delivers them: [n, 8] = (t, x, y, w, h, class_id, class_confidence, objectness)
+        lab8 = [np.concatenate([np.ones((len(l), 1), np.float32), l[:, 1:2] - l[:, 3:4] / 2, l[:, 2:3] - l[:, 4:5] / 2, l[:, 3:5],
+                                l[:, 0:1], l[:, 6:7], l[:, 5:6]], 1) for l in labs]
 
-    def loader_batch(mask):
-        """The dictionary the reference's loaders emit (modules/data/genx.py:120-144): a list of L frame tensors [B,20,H,W]
-        (uint8, device-resident: consecutive views of one buffer), L SparselyBatchedObjectLabels built from host arrays on
-        every step, the is_first_sample flags, the worker id that keys the LSTM state."""
-        it = iter(lab8)
-        seq = []
-        for t in range(T):
-            row = [None] * B
-            for b in label_tb[t]:
-                row[b] = ObjectLabels(torch.from_numpy(next(it).copy()), hw)
-            seq.append(SparselyBatchedObjectLabels(row))
-        return {WORKER_ID_KEY: 0, DATA_KEY: {DataType.EV_REPR: [ev[t] for t in range(T)], DataType.OBJLABELS_SEQ: seq,
-                                             DataType.IS_FIRST_SAMPLE: mask}}
+        def first_mask(step):
+            m = torch.ones(B, dtype=torch.bool)
+            if step > 0:                                      # stream half carries state, random half always restarts
+                m[:B // 2] = torch.rand(B // 2, generator=g) < 0.05
+            return m.to(dev)
 
-    def barrier():
+        def loader_batch(mask):
+            """The dictionary the reference's loaders emit (modules/data/genx.py:120-144): a list of L frame tensors [B,20,H,W]
+            (uint8, device-resident: consecutive views of one buffer), L SparselyBatchedObjectLabels built from host arrays on
+            every step, the is_first_sample flags, the worker id that keys the LSTM state."""
+            it = iter(lab8)
+            seq = []
+            for t in range(T):
+                row = [None] * B
+                for b in label_tb[t]:
+                    row[b] = ObjectLabels(torch.from_numpy(next(it).copy()), hw)
+                seq.append(SparselyBatchedObjectLabels(row))
+            return {WORKER_ID_KEY: 0, DATA_KEY: {DataType.EV_REPR: [ev[t] for t in range(T)], DataType.OBJLABELS_SEQ: seq,
+                                                 DataType.IS_FIRST_SAMPLE: mask}}
+
+        def barrier():
+            if dist.is_initialized():
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        step_no = [0]
+
+        def run(mask):
+            out = fit_step(module, opt, sched, loader_batch(mask), step_no[0])
+            step_no[0] += 1
+            return out
+
+        for s in range(args.warmup):
+            run(first_mask(s))
+        masks = [first_mask(1 + args.warmup + s) for s in range(args.steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(args.steps):
+            out = run(masks[s])
+        barrier()
+        dt = time.perf_counter() - t0
+        t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
         if dist.is_initialized():
-            dist.barrier()
-        torch.cuda.synchronize()
+            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dt = float(t_max)
+        # roofline of the dominant kernel: two extra steps with HIP events around each of its launches
+        roofline = None
+        if not args.no_roofline:
+            # EVERY rank runs the two probe steps (a step contains collectives: a rank-0-only step would dead-lock N > 1);
+            # only rank 0 brackets the kernel with events and reports
+            probe = ops.KernelProbe() if rank == 0 else None
+            # isolated launches: no co-running kernels inside the event bracket (wgrad on the launch stream)
+            side, module.wgrad_side = module.wgrad_side, False
+            for s in range(2):
+                run(first_mask(1))
+            module.wgrad_side = side
+            if probe is not None:
+                roofline = probe.finish(PEAK_HBM_GBS, PEAK_BF16_MFMA_TFLOPS if dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS)
+            # HBM bytes per launch of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
+            # separate rocprofv3 --pmc runs; bench.py itself cannot sample hardware counters)
+            tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
+            if rank == 0 and roofline is not None and os.path.exists(tpath):
+                tj = json.load(open(tpath)).get(dtype, {})
+                roofline['traffic'] = tj.get('hbm_bytes_per_launch')
+                roofline['traffic_source'] = tj.get('source')
+        barrier()
+        loss_val = float(out['loss'].detach())
 
-    step_no = [0]
+        launch = (f'eager, schedule={"batched" if module.time_batched else "timestep"}, wgrad side stream {"on" if module.wgrad_side else "off"}, '
+                  f'precision mode {ops.get_precision()}')
+        return dict(dt=dt, loss=loss_val, roofline=roofline, launch=launch)
 
-    def run(mask):
-        out = fit_step(module, opt, sched, loader_batch(mask), step_no[0])
-        step_no[0] += 1
-        return out
-
-    for s in range(args.warmup):
-        run(first_mask(s))
-    masks = [first_mask(1 + args.warmup + s) for s in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        out = run(masks[s])
-    barrier()
-    dt = time.perf_counter() - t0
-    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if dist.is_initialized():
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    dt = float(t_max)
-    # roofline of the dominant kernel: two extra steps with HIP events around each of its launches
-    roofline = None
-    if not args.no_roofline:
-        # EVERY rank runs the two probe steps (a step contains collectives: a rank-0-only step would dead-lock N > 1);
-        # only rank 0 brackets the kernel with events and reports
-        probe = ops.KernelProbe() if rank == 0 else None
-        # isolated launches: no co-running kernels inside the event bracket (wgrad on the launch stream)
-        side, module.wgrad_side = module.wgrad_side, False
-        for s in range(2):
-            run(first_mask(1))
-        module.wgrad_side = side
-        if probe is not None:
-            roofline = probe.finish(PEAK_HBM_GBS, PEAK_F32_MFMA_TFLOPS)
-        # HBM bytes per launch of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
-        # separate rocprofv3 --pmc runs; bench.py itself cannot sample hardware counters)
-        tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
-        if rank == 0 and roofline is not None and os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            roofline['traffic'] = tj.get('hbm_bytes_per_launch')
-            roofline['traffic_source'] = tj.get('source')
-    barrier()
-    loss_val = float(out['loss'].detach())
-
+    main_run = measure(args.dtype, args.steps, args.warmup, not args.no_roofline)
+    dt, loss_val, roofline, launch = main_run['dt'], main_run['loss'], main_run['roofline'], main_run['launch']
+    other = None
+    if world == 1 and headline and not args.no_second_dtype:
+        torch.cuda.empty_cache()
+        od = 'f32' if args.dtype == 'bf16' else 'bf16'
+        r2 = measure(od, args.steps, args.warmup, not args.no_roofline)
+        other = {'dtype': od, 'value': round(B * T * args.steps / r2['dt'], 2), 'unit': 'event-frames/s (whole job)',
+                 'ms_per_step': round(1000 * r2['dt'] / args.steps, 3), 'final_loss': round(r2['loss'], 4), 'roofline': r2['roofline']}
+        del r2
     if rank == 0:
         frames = world * B * T * args.steps
         fps = frames / dt
@@ -258,12 +283,15 @@ def main():
             'metric': 'event-frames/sec/GPU (RVT-S train, Gen1 T=21) at 1/2/4/8 GPUs; mAP@0.5 parity',
             'value': round(fps, 2), 'unit': 'event-frames/s (whole job)', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1000 * dt / args.steps, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'RVT-{args.size} {args.dataset} {hw[0]}x{hw[1]} (pad {in_hw[0]}x{in_hw[1]}) T={T} bs={B}/GPU fully-supervised train step, '
                                    f'{len(label_ts)} labelled frames/sequence, random-init weights',
                        'global_batch': world * B, 'seq_len': T, 'parallelism': f'dp{world}',
                        'driver': 'fetch_model_module(cfg) -> Module.training_step + FlatAdamW.step + OneCycleLR.step (leod_amd.optim.fit_step)',
-                       'launch': f'eager, schedule={"batched" if module.time_batched else "timestep"}, wgrad side stream {"on" if module.wgrad_side else "off"}',
+                       'launch': launch,
+                       'precision': ('bf16 MFMA operands (GEMM / conv / stem), fp32 accumulation, fp32 LayerNorm / BatchNorm statistics, softmax, '
+                                     'residual stream, LSTM state, SimOTA cost, losses, master weights and AdamW (the placement of the reference\'s '
+                                     'precision=16 run, train.py:236-243)') if args.dtype == 'bf16' else 'fp32 end to end',
                        'collective_backend': dist.get_backend() if dist.is_initialized() else None,
                        'collective_world_size': dist.get_world_size() if dist.is_initialized() else 1,
                        'per_gpu_event_frames_per_s': round(fps / world, 2), 'final_loss': round(loss_val, 4),
@@ -271,6 +299,8 @@ def main():
                        if headline else None},
             'roofline': roofline,
         }
+        if other is not None:
+            out['other_precision'] = other          # the same workload and step in the other precision mode, measured in this run
         if not args.no_cpu_baseline and world == 1 and headline:
             out['cpu_baseline'] = cpu_baseline_bounded()
         print(json.dumps(out), flush=True)

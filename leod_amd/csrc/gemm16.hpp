@@ -993,7 +993,7 @@ struct XStemNCHW {
 // the k-permutation "MFMA j of a 16-row step uses rows 4q+j" one ds_read_b128 per operand feeds four MFMAs.  The 4 waves
 // split the TN*TK output tiles, keep them in registers over the workgroup's whole row range and finish with one fp32
 // atomic per dW element (dW accumulates over timesteps and row splits).
-template <int TN, int TK, class XL>
+template <int TN, int TK, bool BF, class XL>
 __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ dy, long lddy, XL xl, float* dW, long ldw,
                                                       float* dbias, int M, int N, int K, int rows_per_block) {
     constexpr int RC = 32;                                  // rows per staged chunk
@@ -1078,8 +1078,11 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
                     f4 av, bv;
                     av.x = ta[0]; av.y = ta[LDN]; av.z = ta[2 * LDN]; av.w = ta[3 * LDN];
                     bv.x = tb[0]; bv.y = tb[LDK]; bv.z = tb[2 * LDK]; bv.w = tb[3 * LDK];
+                    if constexpr (BF) acc[t] = mfma16_bf16(pack_bf16(av), pack_bf16(bv), acc[t]);
+                    else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[t] = mfma16(av[j], bv[j], acc[t]);
+                        for (int j = 0; j < 4; ++j) acc[t] = mfma16(av[j], bv[j], acc[t]);
+                    }
                 }
         if (more) stash(buf ^ 1);
         __syncthreads();
@@ -1123,7 +1126,8 @@ static inline int launch_wgrad16(const float* dy, long lddy, const XL& xl, float
     int rpb = cdiv(M, max(1, tune_blocks / tiles));
     rpb = max(tune_minrows, ((rpb + 31) / 32) * 32);
     dim3 grid(cdiv(M, rpb), cdiv(N, TN * 16), cdiv(K, TK * 16));
-    hipLaunchKernelGGL((wgrad16_kernel<TN, TK, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, rpb);
+    if (leod_precision() == 1) hipLaunchKernelGGL((wgrad16_kernel<TN, TK, true, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, rpb);
+    else hipLaunchKernelGGL((wgrad16_kernel<TN, TK, false, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, rpb);
     return leod_launch_status();
 }
 
@@ -1137,7 +1141,7 @@ static inline int launch_wgrad16(const float* dy, long lddy, const XL& xl, float
 //   * waves left over after tiling the output (48x48) split the 16-row steps of a chunk (MS-way) instead.
 // dW accumulates with one fp32 atomic per element and workgroup, dbias from the staged dY values as before.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TN, int TK, int WA, int WB, int RC, class XL>
+template <int TN, int TK, int WA, int WB, int RC, bool BF, class XL>
 __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict__ dy, long lddy, XL xl, float* dW, long ldw,
                                                      float* dbias, int M, int N, int K, int chunks_per_block) {
     constexpr int NWN = TN / WA, NWK = TK / WB, MS = 4 / (NWN * NWK);      // wave grid over the tile, row-step split
@@ -1227,12 +1231,24 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
                 const float* t = px + (16 * st) * LDK + 16 * b;
                 bv[b].x = t[0]; bv[b].y = t[LDK]; bv[b].z = t[2 * LDK]; bv[b].w = t[3 * LDK];
             }
+            if constexpr (BF) {
+                s4 pa[WA], pb[WB];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int a = 0; a < WA; ++a) pa[a] = pack_bf16(av[a]);
+#pragma unroll
+                for (int b = 0; b < WB; ++b) pb[b] = pack_bf16(bv[b]);
 #pragma unroll
                 for (int a = 0; a < WA; ++a)
 #pragma unroll
-                    for (int b = 0; b < WB; ++b) acc[a][b] = mfma16(av[a][j], bv[b][j], acc[a][b]);
+                    for (int b = 0; b < WB; ++b) acc[a][b] = mfma16_bf16(pa[a], pb[b], acc[a][b]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int a = 0; a < WA; ++a)
+#pragma unroll
+                        for (int b = 0; b < WB; ++b) acc[a][b] = mfma16(av[a][j], bv[b][j], acc[a][b]);
+            }
         }
         if (more) stash(buf ^ 1);
         __syncthreads();
@@ -1270,7 +1286,8 @@ static inline int launch_wgradw_cfg(const float* dy, long lddy, const XL& xl, fl
     const int chunks = cdiv(M, RC);
     const int gx = max(1, min(chunks / 4, tune_blocks / tiles));      // >= 4 chunks per workgroup: one atomic per dW element each
     dim3 grid(gx, cdiv(N, TN * 16), cdiv(K, TK * 16));
-    hipLaunchKernelGGL((wgradw_kernel<TN, TK, WA, WB, RC, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, cdiv(chunks, gx));
+    if (leod_precision() == 1) hipLaunchKernelGGL((wgradw_kernel<TN, TK, WA, WB, RC, true, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, cdiv(chunks, gx));
+    else hipLaunchKernelGGL((wgradw_kernel<TN, TK, WA, WB, RC, false, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, cdiv(chunks, gx));
     return leod_launch_status();
 }
 

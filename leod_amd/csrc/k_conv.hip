@@ -94,7 +94,7 @@ LEOD_API int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bia
 // assembled from LDS bytes through a per-workgroup k -> byte-offset table.  Weights stream through LDS in 64-wide K chunks
 // exactly as in gemm_lds_kernel; outputs leave through the row-layout float4 epilogue.
 // =====================================================================================================================
-template <int NT>
+template <int NT, bool BF = false>
 __global__ __launch_bounds__(256, 3) void stem_u8_fwd_kernel(const uint8_t* __restrict__ x, const float* __restrict__ w,
                                                              float* __restrict__ y, int Cin, int H, int W, int Ho, int Wo,
                                                              int N, int tiles_x, int tiles_y) {
@@ -183,11 +183,18 @@ __global__ __launch_bounds__(256, 3) void stem_u8_fwd_kernel(const uint8_t* __re
                 const int4 o = *reinterpret_cast<const int4*>(toff + k);
                 av.x = (float)pix[o.x]; av.y = (float)pix[o.y]; av.z = (float)pix[o.z]; av.w = (float)pix[o.w];
             }
+            if constexpr (BF) {                               // uint8 counts are exact in bf16; the weights are rounded
+                const s4 pa = pack_bf16(av);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = mfma16_bf16(pa, pack_bf16(*reinterpret_cast<const f4*>(pb + 16 * t * LD + 16 * c)), acc[t]);
+            } else {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const f4 bv = *reinterpret_cast<const f4*>(pb + 16 * t * LD + 16 * c);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[t] = mfma16(av[j], bv[j], acc[t]);
+            }
             }
         }
         if (more) {
@@ -224,8 +231,12 @@ static int launch_stem_u8(const uint8_t* x, const float* w, float* y, int B, int
     const size_t patch = ((size_t)Cin * 19 * 72 + 4 + 15) & ~(size_t)15;
     size_t lds = patch + (((size_t)KP * 4 + 15) & ~(size_t)15) + (size_t)NT * 16 * 72 * 4;
     lds = lds < 4 * 16 * 64 * 4 ? 4 * 16 * 64 * 4 : lds;                 // the epilogue tile aliases the front of the buffer
-    hipLaunchKernelGGL((stem_u8_fwd_kernel<NT>), dim3(B * tiles_x * tiles_y), dim3(256), lds, s, x, w, y, Cin, H, W, Ho, Wo, N,
-                       tiles_x, tiles_y);
+    if (leod_precision() == 1)
+        hipLaunchKernelGGL((stem_u8_fwd_kernel<NT, true>), dim3(B * tiles_x * tiles_y), dim3(256), lds, s, x, w, y, Cin, H, W, Ho, Wo, N,
+                           tiles_x, tiles_y);
+    else
+        hipLaunchKernelGGL((stem_u8_fwd_kernel<NT>), dim3(B * tiles_x * tiles_y), dim3(256), lds, s, x, w, y, Cin, H, W, Ho, Wo, N,
+                           tiles_x, tiles_y);
     return leod_launch_status();
 }
 
@@ -342,7 +353,7 @@ LEOD_API int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, fl
 // next tile's patch and dY rows are prefetched into registers while the current one is multiplied.  One fp32 atomic per
 // dW element and workgroup at the end.
 // =====================================================================================================================
-template <int NT>
+template <int NT, bool BF = false>
 __global__ __launch_bounds__(256, 2) void stem_u8_wgrad_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ x,
                                                                float* __restrict__ dW, int B, int Cin, int H, int W, int Ho,
                                                                int Wo, int N, int tiles_x, int tiles_y) {
@@ -428,12 +439,24 @@ __global__ __launch_bounds__(256, 2) void stem_u8_wgrad_kernel(const float* __re
                 const unsigned char* t = pb + toffk[b];
                 bv[b].x = (float)t[0]; bv[b].y = (float)t[4]; bv[b].z = (float)t[8]; bv[b].w = (float)t[12];
             }
+            if constexpr (BF) {
+                s4 pa[NT], pk[KT];
+#pragma unroll
+                for (int a = 0; a < NT; ++a) pa[a] = pack_bf16(av[a]);
+#pragma unroll
+                for (int b = 0; b < KT; ++b) pk[b] = pack_bf16(bv[b]);
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+#pragma unroll
+                    for (int b = 0; b < KT; ++b) acc[a][b] = mfma16_bf16(pa[a], pk[b], acc[a][b]);
+            } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int a = 0; a < NT; ++a)
 #pragma unroll
                     for (int b = 0; b < KT; ++b) acc[a][b] = mfma16(av[a][j], bv[b][j], acc[a][b]);
+            }
         }
         __syncthreads();
         if (next < ntiles) stash();
@@ -461,8 +484,12 @@ static int launch_stem_u8_wgrad(const float* dy, const uint8_t* x, float* dW, in
     const size_t lds = (((size_t)Cin * 19 * 72 + 15) & ~(size_t)15) + (size_t)64 * (NT * 16 + 4) * 4;
     const int ntiles = B * tiles_x * tiles_y;
     const int gx = ntiles < 192 ? ntiles : 192;
-    hipLaunchKernelGGL((stem_u8_wgrad_kernel<NT>), dim3(gx, zs), dim3(256), lds, s, dy, x, dW, B, Cin, H, W, Ho, Wo, N, tiles_x,
-                       tiles_y);
+    if (leod_precision() == 1)
+        hipLaunchKernelGGL((stem_u8_wgrad_kernel<NT, true>), dim3(gx, zs), dim3(256), lds, s, dy, x, dW, B, Cin, H, W, Ho, Wo, N, tiles_x,
+                           tiles_y);
+    else
+        hipLaunchKernelGGL((stem_u8_wgrad_kernel<NT>), dim3(gx, zs), dim3(256), lds, s, dy, x, dW, B, Cin, H, W, Ho, Wo, N, tiles_x,
+                           tiles_y);
     return leod_launch_status();
 }
 

@@ -42,7 +42,10 @@ static inline EpStore ep_store(float* out, long ld, int N) {
 // DG = 1 / 2: dgrad of a Linear, dx = (dy * kscale) @ W with W [K][Ntot] (read transposed into LDS once per workgroup); ln_w
 // carries kscale (may be NULL), DG = 2 multiplies by gelu'(aux) with aux = out2 [M][Ntot] (the pre-activation), loaded at the
 // START of the tile so that its wait falls behind the tile's MFMAs.
-template <int KC, int NTT, bool LN, bool ACT, int DG = 0>
+// BF (precision mode bf16): the resident weights are rounded to bf16 ONCE in the prologue (rows of K + 8 bf16: a 4 * odd dword
+// stride keeps the ds_read_b64 fragment reads conflict-free), the streamed A fragments are packed in registers, and one
+// v_mfma_f32_16x16x16_bf16 replaces the four fp32 MFMAs of a 16-k chunk.
+template <int KC, int NTT, bool LN, bool ACT, int DG = 0, bool BF = false>
 __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream48_kernel(const float* __restrict__ x, long ldx, float* __restrict__ stats_out,
                                                              const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
                                                              const float* __restrict__ W, const float* __restrict__ bias,
@@ -53,21 +56,29 @@ __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream4
     if (bias) bias += n0;
     out += n0;
     if (ACT || DG == 2) out2 += n0;
-    __shared__ __attribute__((aligned(16))) float sW[N * LD];
+    __shared__ __attribute__((aligned(16))) float sW[BF ? (N * LD) / 2 : N * LD];
     __shared__ __attribute__((aligned(16))) float sO[4][16 * LDO];
+    unsigned short* sWh = reinterpret_cast<unsigned short*>(sW);        // BF: [N][LD] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     if (DG == 0) {
         for (int e = tid; e < N * (K / 4); e += 256) {
             const int n = e / (K / 4), k4 = (e - n * (K / 4)) * 4;
-            *reinterpret_cast<f4*>(&sW[n * LD + k4]) = ld4(W + (long)n * K + k4);
+            if constexpr (BF) *reinterpret_cast<s4*>(&sWh[n * LD + k4]) = pack_bf16(ld4(W + (long)n * K + k4));
+            else *reinterpret_cast<f4*>(&sW[n * LD + k4]) = ld4(W + (long)n * K + k4);
         }
     } else {
         for (int e = tid; e < K * (N / 4); e += 256) {
             const int k = e / (N / 4), n4 = (e - k * (N / 4)) * 4;
             const f4 w = ld4(W + (long)k * Ntot + n4);
+            if constexpr (BF) {
+                const s4 wh = pack_bf16(w);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sW[(n4 + j) * LD + k] = w[j];
+                for (int j = 0; j < 4; ++j) sWh[(n4 + j) * LD + k] = (unsigned short)wh[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sW[(n4 + j) * LD + k] = w[j];
+            }
         }
     }
     // everything a tile needs besides its own rows is loaded ONCE: a global load inside the tile loop makes the compiler wait
@@ -150,11 +161,18 @@ __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream4
             f4 av = f.a[c];
             if (LN) av = (av - mean) * rstd * lw[c] + lb[c];
             if (DG) av = av * lw[c];
+            if constexpr (BF) {
+                const s4 pa = pack_bf16(av);
+#pragma unroll
+                for (int t = 0; t < NTT; ++t)
+                    acc[t] = mfma16_bf16(pa, *reinterpret_cast<const s4*>(&sWh[(16 * t + i) * LD + 16 * c + 4 * q]), acc[t]);
+            } else {
 #pragma unroll
             for (int t = 0; t < NTT; ++t) {
                 const f4 b = *reinterpret_cast<const f4*>(&sW[(16 * t + i) * LD + 16 * c + 4 * q]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[t] = mfma16(av[j], b[j], acc[t]);
+            }
             }
         }
         auto emit = [&](long row, int n, f4 v, const f4& u) {
@@ -230,7 +248,7 @@ __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream4
 // One wave = one 16-row tile; 48 output columns = 12 float4 per row = 3 per lane (idx = 64 p + lane -> row idx / 12,
 // column idx % 12); the residual slice of the tile is loaded before its MFMAs.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int KC, int MODE>
+template <int KC, int MODE, bool BF = false>
 __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                                   const float* __restrict__ bias, const float* __restrict__ gamma,
                                                                   const float* __restrict__ res, float* __restrict__ out, int M,
@@ -238,21 +256,29 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
                                                                   const float* __restrict__ stats = nullptr,
                                                                   float* __restrict__ dgamma = nullptr, float* __restrict__ dbeta = nullptr) {
     constexpr int K = 16 * KC, LD = K + 8, N = 48, LDO = 52;
-    __shared__ __attribute__((aligned(16))) float sW[N * LD];
+    __shared__ __attribute__((aligned(16))) float sW[BF ? (N * LD) / 2 : N * LD];
     __shared__ __attribute__((aligned(16))) float sO[4][16 * LDO];
+    unsigned short* sWh = reinterpret_cast<unsigned short*>(sW);        // BF: [N][LD] bf16 (see rowstream48_kernel)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     if (MODE == 0) {
         for (int e = tid; e < N * (K / 4); e += 256) {
             const int n = e / (K / 4), k4 = (e - n * (K / 4)) * 4;
-            *reinterpret_cast<f4*>(&sW[n * LD + k4]) = ld4(W + (long)n * K + k4);
+            if constexpr (BF) *reinterpret_cast<s4*>(&sWh[n * LD + k4]) = pack_bf16(ld4(W + (long)n * K + k4));
+            else *reinterpret_cast<f4*>(&sW[n * LD + k4]) = ld4(W + (long)n * K + k4);
         }
     } else {
         for (int e = tid; e < K * (N / 4); e += 256) {
             const int k = e / (N / 4), n4 = (e - k * (N / 4)) * 4;
             const f4 w = ld4(W + (long)k * N + n4);
+            if constexpr (BF) {
+                const s4 wh = pack_bf16(w);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sW[(n4 + j) * LD + k] = w[j];
+                for (int j = 0; j < 4; ++j) sWh[(n4 + j) * LD + k] = (unsigned short)wh[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sW[(n4 + j) * LD + k] = w[j];
+            }
         }
     }
     int lr[3], c4[3];
@@ -303,13 +329,21 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
         }
         f4 acc[3] = {zero4(), zero4(), zero4()};
 #pragma unroll
-        for (int c = 0; c < KC; ++c)
+        for (int c = 0; c < KC; ++c) {
+            if constexpr (BF) {
+                const s4 pa = pack_bf16(f.a[c]);
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    acc[t] = mfma16_bf16(pa, *reinterpret_cast<const s4*>(&sWh[(16 * t + i) * LD + 16 * c + 4 * q]), acc[t]);
+            } else {
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const f4 b = *reinterpret_cast<const f4*>(&sW[(16 * t + i) * LD + 16 * c + 4 * q]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[t] = mfma16(f.a[c][j], b[j], acc[t]);
             }
+            }
+        }
         if (MODE == 2) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -381,6 +415,11 @@ template <int MODE>
 static int launch_rowstream_narrow(const float* x, const float* W, const float* bias, const float* gamma, const float* res,
                                    float* out, int M, int Kc, hipStream_t s) {
     const int grid = min(cdiv(cdiv(M, 16), 4), 256 * 2);
+    if (leod_precision() == 1) {
+        if (Kc == 192) hipLaunchKernelGGL((rowstream_narrow_kernel<12, MODE, true>), dim3(grid), dim3(256), 0, s, x, W, bias, gamma, res, out, M);
+        else hipLaunchKernelGGL((rowstream_narrow_kernel<9, MODE, true>), dim3(grid), dim3(256), 0, s, x, W, bias, gamma, res, out, M);
+        return leod_launch_status();
+    }
     if (Kc == 192) hipLaunchKernelGGL((rowstream_narrow_kernel<12, MODE>), dim3(grid), dim3(256), 0, s, x, W, bias, gamma, res, out, M);
     else hipLaunchKernelGGL((rowstream_narrow_kernel<9, MODE>), dim3(grid), dim3(256), 0, s, x, W, bias, gamma, res, out, M);
     return leod_launch_status();
@@ -403,6 +442,11 @@ static int launch_rowstream48(const float* x, long ldx, float* stats, const floa
     const int slabs = N / (16 * NTT);
     const int gx = min(cdiv(cdiv(M, 16), 4), max(8, (256 * per_cu / slabs) & ~7));   // multiple of 8: slabs of a row range share an XCD
     const dim3 grid(gx, slabs);
+    if (leod_precision() == 1) {
+        if (stats) hipLaunchKernelGGL((rowstream48_kernel<KC, NTT, true, ACT, 0, true>), grid, dim3(256), 0, s, x, ldx, stats, ln_w, ln_b, eps, W, bias, out, out2, M, N);
+        else hipLaunchKernelGGL((rowstream48_kernel<KC, NTT, false, ACT, 0, true>), grid, dim3(256), 0, s, x, ldx, stats, ln_w, ln_b, eps, W, bias, out, out2, M, N);
+        return leod_launch_status();
+    }
     if (stats) hipLaunchKernelGGL((rowstream48_kernel<KC, NTT, true, ACT>), grid, dim3(256), 0, s, x, ldx, stats, ln_w, ln_b, eps, W, bias, out, out2, M, N);
     else hipLaunchKernelGGL((rowstream48_kernel<KC, NTT, false, ACT>), grid, dim3(256), 0, s, x, ldx, stats, ln_w, ln_b, eps, W, bias, out, out2, M, N);
     return leod_launch_status();
@@ -415,6 +459,11 @@ static int launch_rowstream_dgrad(const float* dy, long lddy, const float* kscal
     const int gx = min(cdiv(cdiv(M, 16), 4), max(8, (256 * 2 / slabs) & ~7));
     const dim3 grid(gx, slabs);
     float* aux = const_cast<float*>(aux_u);
+    if (leod_precision() == 1) {
+        if (aux_u) hipLaunchKernelGGL((rowstream48_kernel<KC, NTT, false, false, 2, true>), grid, dim3(256), 0, s, dy, lddy, nullptr, kscale, nullptr, 0.f, W, nullptr, dx, aux, M, Nout);
+        else hipLaunchKernelGGL((rowstream48_kernel<KC, NTT, false, false, 1, true>), grid, dim3(256), 0, s, dy, lddy, nullptr, kscale, nullptr, 0.f, W, nullptr, dx, aux, M, Nout);
+        return leod_launch_status();
+    }
     if (aux_u) hipLaunchKernelGGL((rowstream48_kernel<KC, NTT, false, false, 2>), grid, dim3(256), 0, s, dy, lddy, nullptr, kscale, nullptr, 0.f, W, nullptr, dx, aux, M, Nout);
     else hipLaunchKernelGGL((rowstream48_kernel<KC, NTT, false, false, 1>), grid, dim3(256), 0, s, dy, lddy, nullptr, kscale, nullptr, 0.f, W, nullptr, dx, aux, M, Nout);
     return leod_launch_status();
@@ -541,6 +590,11 @@ LEOD_API int leod_linear_dgrad_lnbwd(const float* dy, const float* W, const floa
     if (!dy || !W || !x || !stats || !ln_w || !dx || !dgamma || !dbeta) return LEOD_ERR_ARG;
     if (!use_rowstream_narrow(M, N, K)) return LEOD_ERR_UNSUPPORTED;
     const int grid = min(cdiv(cdiv(M, 16), 4), 256 * 2);
+    if (leod_precision() == 1) {
+        if (N == 192) hipLaunchKernelGGL((rowstream_narrow_kernel<12, 2, true>), dim3(grid), dim3(256), 0, stream, dy, W, nullptr, ln_w, dres, dx, M, x, stats, dgamma, dbeta);
+        else hipLaunchKernelGGL((rowstream_narrow_kernel<9, 2, true>), dim3(grid), dim3(256), 0, stream, dy, W, nullptr, ln_w, dres, dx, M, x, stats, dgamma, dbeta);
+        return leod_launch_status();
+    }
     if (N == 192) hipLaunchKernelGGL((rowstream_narrow_kernel<12, 2>), dim3(grid), dim3(256), 0, stream, dy, W, nullptr, ln_w, dres, dx, M, x, stats, dgamma, dbeta);
     else hipLaunchKernelGGL((rowstream_narrow_kernel<9, 2>), dim3(grid), dim3(256), 0, stream, dy, W, nullptr, ln_w, dres, dx, M, x, stats, dgamma, dbeta);
     return leod_launch_status();

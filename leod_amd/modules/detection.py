@@ -68,6 +68,9 @@ class Module(_Base):
 
     # ---- Lightning-compatible plumbing -----------------------------------------------------------------
     def setup(self, stage: Optional[str] = None) -> None:
+        # training.precision (reference: Trainer(precision=config.training.precision), train.py:240): 16 -> bf16 contraction
+        # operands with fp32 accumulation / statistics / state, 32 -> fp32 end to end
+        ops.set_precision(ops.precision_from_config(self.full_config.get('training', None)))
         dst = self.full_config.dataset
         new_evaluator = lambda: PropheseeEvaluator(dataset=dst.name, downsample_by_2=dst.downsample_by_factor_2)  # noqa: E731
         if stage == 'fit':

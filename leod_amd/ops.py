@@ -35,6 +35,33 @@ except AttributeError:                                        # pragma: no cover
     _raw_stream = None
 
 
+PRECISIONS = {'f32': 0, 'fp32': 0, 'float32': 0, 32: 0, 'bf16': 1, 'bfloat16': 1, 16: 1, '16': 1, '32': 0}
+
+
+def set_precision(mode) -> int:
+    """'f32' (default): fp32 end to end, bit-tight against the fp32 oracle.  'bf16' (the reference's ``precision=16`` placement,
+    train.py:236-243): contraction operands rounded to bf16 for the bf16 MFMA, fp32 accumulation; statistics, softmax, residual
+    stream, LSTM state, SimOTA cost, losses and optimiser in fp32.  Process-wide; returns the previous mode (0 / 1)."""
+    prev = int(_l().leod_get_precision())
+    check(_l().leod_set_precision(PRECISIONS[mode] if not isinstance(mode, bool) and mode in PRECISIONS else int(mode)), 'set_precision')
+    return prev
+
+
+def precision_from_config(training_cfg=None) -> str:
+    """The mode a run asks for: ``LEOD_PRECISION`` (f32 | bf16) if set, else the reference's ``training.precision`` key
+    (config/general.yaml: 16 -> the mixed-precision mode, here bf16; 32 -> fp32)."""
+    import os
+    env = os.environ.get('LEOD_PRECISION')
+    if env:
+        return 'bf16' if PRECISIONS[env] == 1 else 'f32'
+    prec = None if training_cfg is None else training_cfg.get('precision', 32)
+    return 'bf16' if str(prec).lower() in ('16', 'bf16', '16-mixed', 'bf16-mixed') else 'f32'
+
+
+def get_precision() -> str:
+    return 'bf16' if int(_l().leod_get_precision()) == 1 else 'f32'
+
+
 def _stream():
     """raw hipStream_t of torch's current stream (the stream every kernel of this library is enqueued on)"""
     if _raw_stream is not None:
