@@ -913,6 +913,13 @@ static inline int launch_gemm_lds_rw(const AL& al, const BL& bl, const EP& ep, i
     static const int nbuf = getenv("LEOD_LDS_NBUF") ? atoi(getenv("LEOD_LDS_NBUF")) : 1;
     (void)nbuf;                                      // the double-buffered variant is no longer instantiated (never faster, see above)
     const bool bf = leod_precision() == 1;
+    // bf16 mode: the MFMAs of a chunk are ~8x cheaper, what remains per chunk is the fetch -> barrier -> stash -> barrier skeleton:
+    // 96-wide chunks (26 KB of bf16 tiles per workgroup) halve the number of rounds of the long contractions (K = 192 .. 1536)
+    static const int kch96 = getenv("LEOD_KCH96") ? atoi(getenv("LEOD_KCH96")) : 0;      // measured: 38.2 vs 34.2 ms per step with 96-wide chunks on -> off
+    if (bf && kch96 && K % 96 == 0 && K >= 192) {
+        hipLaunchKernelGGL((gemm_lds_kernel<NT, 96, 1, RW, true, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
+        return leod_launch_status();
+    }
     if (K % 48 == 0) {
         if (bf) hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 1, RW, true, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
         else hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 1, RW, false, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
@@ -998,12 +1005,13 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
                                                       float* dbias, int M, int N, int K, int rows_per_block) {
     constexpr int RC = 32;                                  // rows per staged chunk
     constexpr int LDN = 16 * TN + 4, LDK = 16 * TK + 4;    // natural [row][col] LDS tiles, see wgradw_kernel
+    constexpr int BST = 16 * 16 + 16;                       // BF: bf16 [16 row][16 col] blocks + transpose reads, see wgradw_kernel
     constexpr int C4N = TN * 4, C4K = TK * 4;               // float4 slots per staged row
     constexpr int NV = C4N * RC, KV = C4K * RC;
     constexpr int RN = (NV + 255) / 256, RK = (KV + 255) / 256;
     constexpr int NTILE = TN * TK, TPW = (NTILE + 3) / 4;   // tiles per wave
-    __shared__ __attribute__((aligned(16))) float sdy[2][RC * LDN];
-    __shared__ __attribute__((aligned(16))) float sx[2][RC * LDK];
+    __shared__ __attribute__((aligned(16))) float sdy[2][BF ? ((RC / 16) * TN * BST) / 2 : RC * LDN];
+    __shared__ __attribute__((aligned(16))) float sx[2][BF ? ((RC / 16) * TK * BST) / 2 : RC * LDK];
     __shared__ float sbias[16 * TN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -1018,13 +1026,13 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
 #pragma unroll
     for (int e = 0; e < RN; ++e) {
         const int s = tid + 256 * e, r = s / C4N, c = (s - r * C4N) * 4;
-        nr[e] = r; nl[e] = r * LDN + c; nok[e] = s < NV && n0 + c < N;
+        nr[e] = r; nl[e] = BF ? ((r >> 4) * TN + (c >> 4)) * BST + (r & 15) * 16 + (c & 15) : r * LDN + c; nok[e] = s < NV && n0 + c < N;
         np[e] = dy + (long)(mbeg + r) * lddy + n0 + c;
     }
 #pragma unroll
     for (int e = 0; e < RK; ++e) {
         const int s = tid + 256 * e, r = s / C4K, c = (s - r * C4K) * 4;
-        kr[e] = r; kl[e] = r * LDK + c; kc[e] = k0 + c; kok[e] = s < KV && k0 + c < K;
+        kr[e] = r; kl[e] = BF ? ((r >> 4) * TK + (c >> 4)) * BST + (r & 15) * 16 + (c & 15) : r * LDK + c; kc[e] = k0 + c; kok[e] = s < KV && k0 + c < K;
     }
     int offA[TPW], offB[TPW]; bool tok[TPW];
 #pragma unroll
@@ -1032,7 +1040,8 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
         const int tile = wave + 4 * t;
         tok[t] = tile < NTILE;
         const int a = tok[t] ? tile / TK : 0, b = tok[t] ? tile - a * TK : 0;
-        offA[t] = (4 * q) * LDN + 16 * a + i; offB[t] = (4 * q) * LDK + 16 * b + i;
+        offA[t] = BF ? a * BST + (4 * q + (i >> 2)) * 16 + 4 * (i & 3) : (4 * q) * LDN + 16 * a + i;
+        offB[t] = BF ? b * BST + (4 * q + (i >> 2)) * 16 + 4 * (i & 3) : (4 * q) * LDK + 16 * b + i;
     }
     f4 acc[TPW], bacc[RN];
 #pragma unroll
@@ -1051,6 +1060,18 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
         for (int e = 0; e < RK; ++e) rk[e] = (kok[e] && m0 + kr[e] < mend) ? xl.get4(m0 + kr[e], kc[e]) : zero4();
     };
     auto stash = [&](int buf) {
+        if constexpr (BF) {
+            unsigned short* __restrict__ d16 = reinterpret_cast<unsigned short*>(sdy[buf]);
+            unsigned short* __restrict__ x16 = reinterpret_cast<unsigned short*>(sx[buf]);
+#pragma unroll
+            for (int e = 0; e < RN; ++e) {
+                if (tid + 256 * e < NV) *reinterpret_cast<s4*>(d16 + nl[e]) = pack_bf16(rn[e]);
+                bacc[e] += rn[e];
+            }
+#pragma unroll
+            for (int e = 0; e < RK; ++e)
+                if (tid + 256 * e < KV) *reinterpret_cast<s4*>(x16 + kl[e]) = pack_bf16(rk[e]);
+        } else {
 #pragma unroll
         for (int e = 0; e < RN; ++e) {
             if (tid + 256 * e < NV) *reinterpret_cast<f4*>(&sdy[buf][nl[e]]) = rn[e];
@@ -1059,6 +1080,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < RK; ++e)
             if (tid + 256 * e < KV) *reinterpret_cast<f4*>(&sx[buf][kl[e]]) = rk[e];
+        }
     };
     int buf = 0;
     if (mbeg < mend) { fetch(mbeg); stash(0); }
@@ -1073,15 +1095,20 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
 #pragma unroll
             for (int t = 0; t < TPW; ++t)
                 if (tok[t]) {
+                    if constexpr (BF) {
+                        typedef __attribute__((address_space(3))) s4 lds_s4;
+                        const unsigned short* ta = reinterpret_cast<const unsigned short*>(pdy) + offA[t] + (st * TN) * BST;
+                        const unsigned short* tb = reinterpret_cast<const unsigned short*>(px) + offB[t] + (st * TK) * BST;
+                        acc[t] = mfma16_bf16(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)ta),
+                                             __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)tb), acc[t]);
+                    } else {
                     const float* ta = pdy + offA[t] + (16 * st) * LDN;                    // rows 16st+4q .. +3 of column (a, i)
                     const float* tb = px + offB[t] + (16 * st) * LDK;
                     f4 av, bv;
                     av.x = ta[0]; av.y = ta[LDN]; av.z = ta[2 * LDN]; av.w = ta[3 * LDN];
                     bv.x = tb[0]; bv.y = tb[LDK]; bv.z = tb[2 * LDK]; bv.w = tb[3 * LDK];
-                    if constexpr (BF) acc[t] = mfma16_bf16(pack_bf16(av), pack_bf16(bv), acc[t]);
-                    else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[t] = mfma16(av[j], bv[j], acc[t]);
+                    for (int j = 0; j < 4; ++j) acc[t] = mfma16(av[j], bv[j], acc[t]);
                     }
                 }
         if (more) stash(buf ^ 1);
@@ -1104,7 +1131,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < RN; ++e)
             if (tid + 256 * e < NV) {
-                const int c = nl[e] - nr[e] * LDN;
+                const int c = ((tid + 256 * e) - nr[e] * C4N) * 4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) atomicAdd(&sbias[c + j], bacc[e][j]);
             }
@@ -1151,12 +1178,17 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
     // dY / X chunks stay in their natural [row][col] layout in LDS: 16-byte stores (conflict-free), MFMA fragments by
     // 4 x ds_read_b32 -- rows 4q+j of a 32-lane group land in distinct 16-bank halves because LDN, LDK == 4 (mod 8).
     // (The first version transposed on the way in: 4 scalar stores per float4 with 6- to 12-way bank conflicts.)
+    // BF (precision mode bf16): the chunks are rounded to bf16 when stashed and kept as [16 row][16 col] blocks (8-byte stores of 4
+    // columns; block stride 512 + 32 bytes); a fragment = 4 consecutive ROWS of one column per lane is ONE ds_read_b64_tr_b16
+    // (the hardware transposes the [4 row][16 col] sub-block of each 16-lane group) instead of four ds_read_b32, and one
+    // v_mfma_f32_16x16x16_bf16 contracts the 16 rows of a step.
     constexpr int LDN = 16 * TN + 4, LDK = 16 * TK + 4;
+    constexpr int BST = 16 * 16 + 16;
     constexpr int C4N = TN * 4, C4K = TK * 4;
     constexpr int NV = C4N * RC, KV = C4K * RC;
     constexpr int RN = (NV + 255) / 256, RK = (KV + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float sdy[2][RC * LDN];
-    __shared__ __attribute__((aligned(16))) float sx[2][RC * LDK];
+    __shared__ __attribute__((aligned(16))) float sdy[2][BF ? ((RC / 16) * TN * BST) / 2 : RC * LDN];
+    __shared__ __attribute__((aligned(16))) float sx[2][BF ? ((RC / 16) * TK * BST) / 2 : RC * LDK];
     __shared__ float sbias[16 * TN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -1175,15 +1207,16 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < RN; ++e) {
         const int s = tid + 256 * e, r = s / C4N, c = (s - r * C4N) * 4;
-        nr[e] = r; nl[e] = r * LDN + c; nok[e] = s < NV && n0 + c < N;
+        nr[e] = r; nl[e] = BF ? ((r >> 4) * TN + (c >> 4)) * BST + (r & 15) * 16 + (c & 15) : r * LDN + c; nok[e] = s < NV && n0 + c < N;
         noff[e] = (long)r * lddy + n0 + c;
     }
 #pragma unroll
     for (int e = 0; e < RK; ++e) {
         const int s = tid + 256 * e, r = s / C4K, c = (s - r * C4K) * 4;
-        kr[e] = r; kl[e] = r * LDK + c; kc[e] = k0 + c; kok[e] = s < KV && k0 + c < K;
+        kr[e] = r; kl[e] = BF ? ((r >> 4) * TK + (c >> 4)) * BST + (r & 15) * 16 + (c & 15) : r * LDK + c; kc[e] = k0 + c; kok[e] = s < KV && k0 + c < K;
     }
-    const int offA = (4 * q) * LDN + 16 * wa * WA + i, offB = (4 * q) * LDK + 16 * wb * WB + i;
+    const int offA = BF ? (wa * WA) * BST + (4 * q + (i >> 2)) * 16 + 4 * (i & 3) : (4 * q) * LDN + 16 * wa * WA + i;
+    const int offB = BF ? (wb * WB) * BST + (4 * q + (i >> 2)) * 16 + 4 * (i & 3) : (4 * q) * LDK + 16 * wb * WB + i;
     f4 acc[WA][WB], bacc[RN];
 #pragma unroll
     for (int a = 0; a < WA; ++a)
@@ -1200,6 +1233,18 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
         for (int e = 0; e < RK; ++e) rk[e] = (kok[e] && m0 + kr[e] < mend) ? xl.get4((int)m0 + kr[e], kc[e]) : zero4();
     };
     auto stash = [&](int buf) {
+        if constexpr (BF) {
+            unsigned short* __restrict__ d16 = reinterpret_cast<unsigned short*>(sdy[buf]);
+            unsigned short* __restrict__ x16 = reinterpret_cast<unsigned short*>(sx[buf]);
+#pragma unroll
+            for (int e = 0; e < RN; ++e) {
+                if (tid + 256 * e < NV) *reinterpret_cast<s4*>(d16 + nl[e]) = pack_bf16(rn[e]);
+                bacc[e] += rn[e];
+            }
+#pragma unroll
+            for (int e = 0; e < RK; ++e)
+                if (tid + 256 * e < KV) *reinterpret_cast<s4*>(x16 + kl[e]) = pack_bf16(rk[e]);
+        } else {
 #pragma unroll
         for (int e = 0; e < RN; ++e) {
             if (tid + 256 * e < NV) *reinterpret_cast<f4*>(&sdy[buf][nl[e]]) = rn[e];
@@ -1208,6 +1253,7 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < RK; ++e)
             if (tid + 256 * e < KV) *reinterpret_cast<f4*>(&sx[buf][kl[e]]) = rk[e];
+        }
     };
     int buf = 0;
     fetch(mbeg);
@@ -1216,6 +1262,23 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
     for (long m0 = mbeg; m0 < mend; m0 += mstride) {
         const bool more = m0 + mstride < mend;
         if (more) fetch(m0 + mstride);                      // next chunk's global loads fly under this chunk's MFMAs
+        if constexpr (BF) {
+            typedef __attribute__((address_space(3))) s4 lds_s4;
+            const unsigned short* __restrict__ pdy = reinterpret_cast<const unsigned short*>(sdy[buf]) + offA;
+            const unsigned short* __restrict__ px = reinterpret_cast<const unsigned short*>(sx[buf]) + offB;
+#pragma unroll
+            for (int st = ws; st < STEPS; st += MS) {
+                s4 pa[WA], pb[WB];
+#pragma unroll
+                for (int a = 0; a < WA; ++a) pa[a] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(pdy + (st * TN + a) * BST));
+#pragma unroll
+                for (int b = 0; b < WB; ++b) pb[b] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(px + (st * TK + b) * BST));
+#pragma unroll
+                for (int a = 0; a < WA; ++a)
+#pragma unroll
+                    for (int b = 0; b < WB; ++b) acc[a][b] = mfma16_bf16(pa[a], pb[b], acc[a][b]);
+            }
+        } else {
         const float* __restrict__ pdy = sdy[buf] + offA;
         const float* __restrict__ px = sx[buf] + offB;
 #pragma unroll
@@ -1231,24 +1294,13 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
                 const float* t = px + (16 * st) * LDK + 16 * b;
                 bv[b].x = t[0]; bv[b].y = t[LDK]; bv[b].z = t[2 * LDK]; bv[b].w = t[3 * LDK];
             }
-            if constexpr (BF) {
-                s4 pa[WA], pb[WB];
 #pragma unroll
-                for (int a = 0; a < WA; ++a) pa[a] = pack_bf16(av[a]);
-#pragma unroll
-                for (int b = 0; b < WB; ++b) pb[b] = pack_bf16(bv[b]);
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int a = 0; a < WA; ++a)
 #pragma unroll
-                    for (int b = 0; b < WB; ++b) acc[a][b] = mfma16_bf16(pa[a], pb[b], acc[a][b]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int a = 0; a < WA; ++a)
-#pragma unroll
-                        for (int b = 0; b < WB; ++b) acc[a][b] = mfma16(av[a][j], bv[b][j], acc[a][b]);
-            }
+                    for (int b = 0; b < WB; ++b) acc[a][b] = mfma16(av[a][j], bv[b][j], acc[a][b]);
+        }
         }
         if (more) stash(buf ^ 1);
         __syncthreads();
@@ -1269,7 +1321,7 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < RN; ++e)
             if (tid + 256 * e < NV) {
-                const int c = nl[e] - nr[e] * LDN;
+                const int c = ((tid + 256 * e) - nr[e] * C4N) * 4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) atomicAdd(&sbias[c + j], bacc[e][j]);
             }

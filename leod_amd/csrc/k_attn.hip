@@ -353,17 +353,27 @@ __device__ __forceinline__ KFrag<D> kfrag_load(const float* row, int rg) {
     }
     return f;
 }
-template <int D>
+// BF (precision mode bf16): operands rounded to bf16 in registers, one v_mfma_f32_16x16x16_bf16 per 16-wide chunk and one for the
+// 8-wide tail (both operands carry their two tail values in slots 0, 1 and zeros in 2, 3: a contraction only needs the two
+// operands to agree on which slot holds which k).
+template <int D, bool BF = false>
 __device__ __forceinline__ f4 kfrag_mfma(const KFrag<D>& a, const KFrag<D>& b, f4 acc) {
+    if constexpr (BF) {
+#pragma unroll
+        for (int c = 0; c < KFrag<D>::NC; ++c) acc = mfma16_bf16(pack_bf16(a.c[c]), pack_bf16(b.c[c]), acc);
+        if (KFrag<D>::TAIL) acc = mfma16_bf16(pack_bf16(f4{a.t0, a.t1, 0.f, 0.f}), pack_bf16(f4{b.t0, b.t1, 0.f, 0.f}), acc);
+        return acc;
+    } else {
 #pragma unroll
     for (int c = 0; c < KFrag<D>::NC; ++c)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = mfma16(a.c[c][j], b.c[c][j], acc);
     if (KFrag<D>::TAIL) { acc = mfma16(a.t0, b.t0, acc); acc = mfma16(a.t1, b.t1, acc); }
     return acc;
+    }
 }
 
-template <int PT, int D, int HG>
+template <int PT, int D, int HG, bool BF = false>
 __global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                       float* __restrict__ lse, AttnGeom g, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -402,7 +412,7 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds_kernel(const float*
     const KFrag<D> qf = kfrag_load<D>(hb + (16 * qt + i) * S, rg);
     f4 s[PT];
 #pragma unroll
-    for (int mt = 0; mt < PT; ++mt) s[mt] = kfrag_mfma<D>(kfrag_load<D>(hb + (16 * mt + i) * S + d, rg), qf, zero4());
+    for (int mt = 0; mt < PT; ++mt) s[mt] = kfrag_mfma<D, BF>(kfrag_load<D>(hb + (16 * mt + i) * S + d, rg), qf, zero4());
     float mx = -INFINITY;
 #pragma unroll
     for (int mt = 0; mt < PT; ++mt)
@@ -429,6 +439,21 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds_kernel(const float*
     f4 o[DCH];
 #pragma unroll
     for (int ct = 0; ct < DCH; ++ct) o[ct] = zero4();
+    if constexpr (BF) {
+        // P V: lane (i, rg) holds P[query i][keys 4rg .. +3] (its four accumulator rows) and gathers V[keys 4rg .. +3][col i]:
+        // ONE bf16 MFMA per (key tile, column tile) instead of four fp32 ones
+#pragma unroll
+        for (int mt = 0; mt < PT; ++mt) {
+            const s4 pa = pack_bf16(s[mt] * inv);
+            const float* vrow = hb + (16 * mt + 4 * rg) * S + 2 * d;
+#pragma unroll
+            for (int ct = 0; ct < DCH; ++ct) {
+                const bool ok = 16 * ct + i < d;
+                const f4 vv = ok ? f4{vrow[16 * ct + i], vrow[S + 16 * ct + i], vrow[2 * S + 16 * ct + i], vrow[3 * S + 16 * ct + i]} : zero4();
+                o[ct] = mfma16_bf16(pa, pack_bf16(vv), o[ct]);
+            }
+        }
+    } else {
 #pragma unroll
     for (int mt = 0; mt < PT; ++mt)
 #pragma unroll
@@ -440,6 +465,7 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds_kernel(const float*
                 o[ct] = mfma16(s[mt][r] * inv, vv, o[ct]);
             }
         }
+    }
     // O tile -> this wave's own q slots (nobody else reads them) -> per-token d-float segments
     float* ob = smem + hl * 3 * d + (16 * qt) * S;
 #pragma unroll
@@ -460,7 +486,7 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds_kernel(const float*
 
 // fused backward: phase 1 = query-owned (dQ, D), phase 2 = key-owned (dK, dV), then one coalesced store of the whole
 // [dq | dk | dv] segment of every token.  Probabilities are recomputed from lse in both phases.
-template <int PT, int D, int HG>
+template <int PT, int D, int HG, bool BF = false>
 __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                       const float* __restrict__ lse, float* __restrict__ dqkv,
                                                                       AttnGeom g, float scale) {
@@ -530,8 +556,8 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float*
         f4 s[PT], dp[PT];
 #pragma unroll
         for (int mt = 0; mt < PT; ++mt) {
-            s[mt] = kfrag_mfma<D>(kfrag_load<D>(hb + (16 * mt + i) * S + d, rg), qf, zero4());
-            dp[mt] = kfrag_mfma<D>(kfrag_load<D>(hb + (16 * mt + i) * S + 2 * d, rg), dof, zero4());
+            s[mt] = kfrag_mfma<D, BF>(kfrag_load<D>(hb + (16 * mt + i) * S + d, rg), qf, zero4());
+            dp[mt] = kfrag_mfma<D, BF>(kfrag_load<D>(hb + (16 * mt + i) * S + 2 * d, rg), dof, zero4());
         }
         float Dq = 0.f;
 #pragma unroll
@@ -547,6 +573,22 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float*
         if (rg == 0) sD[hl * TOK + 16 * qt + i] = Dq;
 #pragma unroll
         for (int ct = 0; ct < DCH; ++ct) dq[ct] = zero4();
+        if constexpr (BF) {
+#pragma unroll
+            for (int mt = 0; mt < PT; ++mt) {
+                f4 ds;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ds[r] = s[mt][r] * (dp[mt][r] - Dq) * scale;
+                const s4 pa = pack_bf16(ds);
+                const float* krow = hb + (16 * mt + 4 * rg) * S + d;
+#pragma unroll
+                for (int ct = 0; ct < DCH; ++ct) {
+                    const bool ok = 16 * ct + i < d;
+                    const f4 kk = ok ? f4{krow[16 * ct + i], krow[S + 16 * ct + i], krow[2 * S + 16 * ct + i], krow[3 * S + 16 * ct + i]} : zero4();
+                    dq[ct] = mfma16_bf16(pa, pack_bf16(kk), dq[ct]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int mt = 0; mt < PT; ++mt)
 #pragma unroll
@@ -559,6 +601,7 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float*
                     dq[ct] = mfma16(ds, kk, dq[ct]);
                 }
             }
+        }
     }
     __syncthreads();                                          // D of every query of the partition is in LDS
     // ---- phase 2: dK, dV of key tile kt = qt --------------------------------------------------------------------------------
@@ -570,8 +613,32 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float*
         for (int ct = 0; ct < DCH; ++ct) { dk[ct] = zero4(); dv[ct] = zero4(); }
 #pragma unroll
         for (int qm = 0; qm < PT; ++qm) {
-            const f4 s = kfrag_mfma<D>(kfrag_load<D>(hb + (16 * qm + i) * S, rg), kf, zero4());
-            const f4 dp = kfrag_mfma<D>(kfrag_load<D>(db + (16 * qm + i) * Sd, rg), vf, zero4());
+            const f4 s = kfrag_mfma<D, BF>(kfrag_load<D>(hb + (16 * qm + i) * S, rg), kf, zero4());
+            const f4 dp = kfrag_mfma<D, BF>(kfrag_load<D>(db + (16 * qm + i) * Sd, rg), vf, zero4());
+            if constexpr (BF) {
+                f4 pr4 = zero4(), ds4 = zero4();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int query = 16 * qm + 4 * rg + r;
+                    if (query < P && kvalid) {
+                        pr4[r] = fast_exp(s[r] * scale - sL[hl * TOK + query]);
+                        ds4[r] = pr4[r] * (dp[r] - sD[hl * TOK + query]) * scale;
+                    }
+                }
+                const s4 ppr = pack_bf16(pr4), pds = pack_bf16(ds4);
+                const float* qrow = hb + (16 * qm + 4 * rg) * S;
+                const float* dorow = db + (16 * qm + 4 * rg) * Sd;
+#pragma unroll
+                for (int ct = 0; ct < DCH; ++ct) {
+                    const bool ok = 16 * ct + i < d;
+                    const int cc = 16 * ct + i;
+                    const f4 dov = ok ? f4{dorow[cc], dorow[Sd + cc], dorow[2 * Sd + cc], dorow[3 * Sd + cc]} : zero4();
+                    const f4 qv = ok ? f4{qrow[cc], qrow[S + cc], qrow[2 * S + cc], qrow[3 * S + cc]} : zero4();
+                    dv[ct] = mfma16_bf16(ppr, pack_bf16(dov), dv[ct]);
+                    dk[ct] = mfma16_bf16(pds, pack_bf16(qv), dk[ct]);
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int query = 16 * qm + 4 * rg + r;       // accumulator row r; key = column i
@@ -620,10 +687,12 @@ static int run_attn_lds(int which, const float* qkv, const float* dout, float* o
     const int TOK = 16 * PT, S = HG * 3 * D + 4, Sd = HG * D + 4;
     if (which == 0) {
         const size_t lds = (size_t)TOK * S * sizeof(float);
-        hipLaunchKernelGGL((attn_fwd_lds_kernel<PT, D, HG>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, out, lse, g, scale);
+        if (leod_precision() == 1) hipLaunchKernelGGL((attn_fwd_lds_kernel<PT, D, HG, true>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, out, lse, g, scale);
+        else hipLaunchKernelGGL((attn_fwd_lds_kernel<PT, D, HG>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, out, lse, g, scale);
     } else {
         const size_t lds = (size_t)TOK * (S + Sd) * sizeof(float);
-        hipLaunchKernelGGL((attn_bwd_lds_kernel<PT, D, HG>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, dout, lse, dqkv, g, scale);
+        if (leod_precision() == 1) hipLaunchKernelGGL((attn_bwd_lds_kernel<PT, D, HG, true>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, dout, lse, dqkv, g, scale);
+        else hipLaunchKernelGGL((attn_bwd_lds_kernel<PT, D, HG>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, dout, lse, dqkv, g, scale);
     }
     return leod_launch_status();
 }

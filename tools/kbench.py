@@ -45,6 +45,8 @@ def timeit(fn, n=int(os.environ.get('KBENCH_N', '6'))):
 
 
 def main():
+    ops.set_precision(os.environ.get('LEOD_PRECISION', 'f32'))
+    print('precision mode', ops.get_precision())
     flt = sys.argv[1] if len(sys.argv) > 1 else ''
     r = lambda *s: torch.randn(*s, device=DEV)  # noqa
     rows = []
