@@ -60,16 +60,7 @@ def make_batch(T, B, hw, num_classes, seed, device, label_ts):
     return ev.to(device), torch.from_numpy(tg).to(device), label_tb, labs
 
 
-def usable_cores():
-    """Host cores this process may actually use: min(affinity mask, cgroup CPU quota)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    try:
-        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
-        if quota != 'max':
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return max(1, n)
+from leod_amd.utils.host import usable_cores  # noqa: E402  (min(affinity mask, cgroup CPU quota))
 
 
 def cpu_baseline(sample_B=8, T=21, threads=None, timed=3):

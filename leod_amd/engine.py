@@ -17,11 +17,13 @@ from .functions import WgradSide, flush_bn_counters
 from .parallel import FlatParams, DataParallel, one_cycle_lr
 from .models.detection.yolox.utils.boxes import postprocess_padded
 from .modules.utils.ssod import pred2label_padded
+from .utils.host import bound_host_threads
 
 
 class TrainEngine:
     def __init__(self, detector: torch.nn.Module, lr=2e-4, weight_decay=0.0, total_steps=400000, pct_start=0.005,
                  div_factor=20, final_div_factor=10000, clip_value=1.0, process_group=None, sync_bn=True):
+        bound_host_threads()
         self.det = detector
         self.det.train()
         self.flat = FlatParams(detector)
@@ -182,6 +184,7 @@ class PseudoLabelEngine:
 
     def __init__(self, detector: torch.nn.Module, num_classes: int, conf_thre=0.01, nms_thre=0.45, obj_thresh=(0.6, 0.3),
                  cls_thresh=(0.6, 0.3), dataset_name='gen1', downsampled_by_2=False, hflip=True, max_det=256):
+        bound_host_threads()
         self.det = detector.eval()
         self.nc, self.conf, self.nms = num_classes, conf_thre, nms_thre
         self.obj_thresh, self.cls_thresh = list(obj_thresh), list(cls_thresh)

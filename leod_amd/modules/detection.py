@@ -33,6 +33,7 @@ from leod_amd.models.detection.yolox_extension.models.detector import YoloXDetec
 from leod_amd.utils.evaluation.prophesee.evaluator import PropheseeEvaluator
 from leod_amd.utils.evaluation.prophesee.io.box_loading import to_prophesee
 from leod_amd.utils.padding import InputPadderFromShape
+from leod_amd.utils.host import bound_host_threads
 from .utils.detection import (BackboneFeatureSelector, Mode, RNNStates, mode_2_string,
                               merge_mixed_batches, WORKER_ID_KEY, DATA_KEY)
 from .utils.ssod import get_subsample_label_idx
@@ -71,6 +72,7 @@ class Module(_Base):
         # training.precision (reference: Trainer(precision=config.training.precision), train.py:240): 16 -> bf16 contraction
         # operands with fp32 accumulation / statistics / state, 32 -> fp32 end to end
         ops.set_precision(ops.precision_from_config(self.full_config.get('training', None)))
+        bound_host_threads()            # the launch thread must not be throttled by a spinning intra-op pool (utils/host.py)
         dst = self.full_config.dataset
         new_evaluator = lambda: PropheseeEvaluator(dataset=dst.name, downsample_by_2=dst.downsample_by_factor_2)  # noqa: E731
         if stage == 'fit':

@@ -244,3 +244,22 @@ def test_augmentor_state_and_labels_match_reference(golden_dir):
                 continue
             np.testing.assert_array_equal(l.object_labels.numpy(), g[f's{seed}_lab{t}'])
             assert tuple(float(v) for v in l.input_size_hw) == tuple(g[f's{seed}_hw{t}'])
+
+
+def test_bound_host_threads_respects_quota_and_env(monkeypatch):
+    """utils/host.py: the intra-op pool is capped by the cgroup quota (never raised), explicit env settings win."""
+    import torch
+    from leod_amd.utils import host
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.delenv('OMP_NUM_THREADS', raising=False)
+        monkeypatch.delenv('LEOD_HOST_THREADS', raising=False)
+        n = host.bound_host_threads(force=True)
+        assert 1 <= n <= min(4, max(1, host.usable_cores() // 2)) or n == before
+        assert n <= before
+        assert host.bound_host_threads(local_world_size=8, force=True) <= n       # more ranks per node -> fewer threads each
+        monkeypatch.setenv('LEOD_HOST_THREADS', '2')
+        assert host.bound_host_threads(force=True) == 2
+        assert host.bound_host_threads() == 2                                     # idempotent without force
+    finally:
+        torch.set_num_threads(before)
