@@ -95,11 +95,12 @@ int leod_stem_conv_fwd(const void* x, int x_is_u8, const float* w, float* y, int
                        int N, int ks, int stride, int pad, leod_stream_t stream);
 int leod_stem_conv_wgrad(const float* dy, const void* x, int x_is_u8, float* dw, int B, int Cin, int H, int W, int Hp,
                          int Wp, int N, int ks, int stride, int pad, leod_stream_t stream);
-/* y = conv(x NHWC, w[N,Cin,ks,ks]) (+bias); colstats (optional) [2,N] double += (sum, sumsq) for training BatchNorm;
+/* y = conv(x NHWC, w[N,Cin,ks,ks]) (+bias); colstats (optional) [stat_rep,2,N] double += (sum, sumsq) for training BatchNorm,
+ * spread over stat_rep replicas (power of two, 0/1 = one copy; the caller zero-fills, leod_bn_silu_fwd folds them);
  * bn_w != NULL: eval BatchNorm folded + SiLU (network_blocks.py:29-54; yolo_pafpn.py:109-140; yolo_head.py:208-222).
  * wpack (optional scratch, N*Cin*ks*ks floats): the call first writes a K-contiguous copy of w there and contracts
  * against that (the native [N][Cin][ks][ks] layout strides every weight float4 over 36 bytes). */
-int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, double* colstats, const float* bn_w,
+int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, double* colstats, int stat_rep, const float* bn_w,
                        const float* bn_b, const float* bn_rm, const float* bn_rv, float bn_eps, int B, int H, int W,
                        int Cin, int N, int ks, int stride, int pad, float* wpack, leod_stream_t stream);
 int leod_conv_nhwc_dgrad(const float* dy, const float* w, float* dx, int accumulate, int B, int H, int W, int Cin, int N,
@@ -110,7 +111,7 @@ int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, float* dbia
 /* BatchNorm2d (batch statistics) + SiLU on rows and its autograd (network_blocks.py:47-51).  `count` = rows that
  * entered colstats/sums.  SyncBatchNorm: with count_dev (device scalar) the row count is count * count_dev[0] -- pass count =
  * rows per image and count_dev = images over all ranks (one all-reduced scalar per step), colstats/sums all-reduced. */
-int leod_bn_silu_fwd(const float* z, const double* colstats, const float* w, const float* b, float* y, float* save_mean,
+int leod_bn_silu_fwd(const float* z, const double* colstats, int stat_rep, const float* w, const float* b, float* y, float* save_mean,
                      float* save_rstd, float* run_mean, float* run_var, int M, int N, double count,
                      const double* count_dev, float eps, float momentum, leod_stream_t stream);
 int leod_bn_silu_bwd_reduce(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,

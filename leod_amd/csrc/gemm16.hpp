@@ -369,7 +369,10 @@ struct EpStore {
     const float* bias;              // optional per-column bias
     const float* aux; long ldaux;   // ACT_MUL_GELU_GRAD: u (pre-activation) ; ACT_AFFINE_SILU: unused
     const float* bn_w; const float* bn_b; const float* bn_rm; const float* bn_rv; float bn_eps;  // eval BN fold
-    double* colstats;               // optional [2][N] (sum, sumsq) accumulated atomically (train BN)
+    double* colstats;               // optional [R][2][N] (sum, sumsq) accumulated atomically (train BN); R = stat_rep replicas
+    int stat_rep;                   // power of two (0 / 1 = one copy): wave-tile t adds into replica t & (R - 1).  All waves of a
+                                    // launch hammering the SAME 2N doubles (12 cache lines for N = 96) serialised in the L2 atomic
+                                    // units: +200 us on a 12 us 1x1 conv at M = 40960 (tools/kbench_conv.py); the consumer folds
     float* colsum;                  // optional [N]: += column sums of the stored value (bias gradient)
     int act; int accumulate;
     int N;
@@ -418,7 +421,10 @@ struct EpStore {
                 s1 = quad16_sum(s1);
                 if (colstats) s2 = quad16_sum(s2);
                 if (rg == 0 && nok) {
-                    if (colstats) { atomicAdd(colstats + n, (double)s1); atomicAdd(colstats + N + n, (double)s2); }
+                    if (colstats) {
+                        double* cs = colstats + (stat_rep > 1 ? (size_t)((row0 >> 4) & (stat_rep - 1)) * 2 * N : 0);
+                        atomicAdd(cs + n, (double)s1); atomicAdd(cs + N + n, (double)s2);
+                    }
                     if (colsum) atomicAdd(colsum + n, s1);
                 }
             }
@@ -482,7 +488,10 @@ struct EpStore {
                 const float a = quad16_sum(s1[j]);
                 const float b = colstats ? quad16_sum(s2[j]) : 0.f;
                 if (q == 0 && nok) {
-                    if (colstats) { atomicAdd(colstats + n + j, (double)a); atomicAdd(colstats + N + n + j, (double)b); }
+                    if (colstats) {
+                        double* cs = colstats + (stat_rep > 1 ? (size_t)((row0 >> 4) & (stat_rep - 1)) * 2 * N : 0);
+                        atomicAdd(cs + n + j, (double)a); atomicAdd(cs + N + n + j, (double)b);
+                    }
                     if (colsum) atomicAdd(colsum + n + j, a);
                 }
             }

@@ -25,10 +25,10 @@ static inline int pick_nt(int N) {
         default: { constexpr int NT = 4; __VA_ARGS__; } break;         \
     }
 
-static EpStore conv_epilogue(float* out, int N, const float* bias, double* colstats, const float* bn_w, const float* bn_b,
+static EpStore conv_epilogue(float* out, int N, const float* bias, double* colstats, int stat_rep, const float* bn_w, const float* bn_b,
                              const float* bn_rm, const float* bn_rv, float bn_eps) {
     EpStore ep{};
-    ep.out = out; ep.ld = N; ep.N = N; ep.bias = bias; ep.colstats = colstats; ep.act = ACT_NONE;
+    ep.out = out; ep.ld = N; ep.N = N; ep.bias = bias; ep.colstats = colstats; ep.stat_rep = stat_rep; ep.act = ACT_NONE;
     if (bn_w) { ep.act = ACT_AFFINE_SILU; ep.bn_w = bn_w; ep.bn_b = bn_b; ep.bn_rm = bn_rm; ep.bn_rv = bn_rv; ep.bn_eps = bn_eps; }
     return ep;
 }
@@ -51,16 +51,17 @@ static inline void launch_conv_pack(const float* w, float* out, int N, int Cin, 
 }
 
 // y[B,Ho,Wo,N] = conv(x[B,H,W,Cin] NHWC, w[N,Cin,ks,ks]) (+bias) ; Ho = (H + 2*pad - ks)/stride + 1
-//   colstats != NULL : also accumulate per-channel (sum, sumsq) in double for training BatchNorm
+//   colstats != NULL : also accumulate per-channel (sum, sumsq) in double for training BatchNorm, spread over stat_rep
+//                      replicas [stat_rep][2][N] (power of two, zero-initialised by the caller; leod_bn_silu_fwd folds them)
 //   bn_w != NULL     : eval mode, y = silu(bn(conv)) with running statistics folded in
-LEOD_API int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, double* colstats,
+LEOD_API int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, double* colstats, int stat_rep,
                                 const float* bn_w, const float* bn_b, const float* bn_rm, const float* bn_rv, float bn_eps,
                                 int B, int H, int W, int Cin, int N, int ks, int stride, int pad, float* wpack,
                                 hipStream_t stream) {
-    if (!x || !w || !y || (Cin & 3)) return LEOD_ERR_ARG;
+    if (!x || !w || !y || (Cin & 3) || (stat_rep > 1 && (stat_rep & (stat_rep - 1)))) return LEOD_ERR_ARG;
     const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
     const int M = B * Ho * Wo, K = ks * ks * Cin;
-    EpStore ep = conv_epilogue(y, N, bias, colstats, bn_w, bn_b, bn_rm, bn_rv, bn_eps);
+    EpStore ep = conv_epilogue(y, N, bias, colstats, stat_rep, bn_w, bn_b, bn_rm, bn_rv, bn_eps);
     const int nt = pick_nt(N);
     int rc = LEOD_OK;
     const bool lds = use_gemm_lds(M, cdiv(N, 16 * nt));      // large M: coalesced LDS-staged operands
@@ -248,7 +249,7 @@ LEOD_API int leod_stem_conv_fwd(const void* x, int x_is_u8, const float* w, floa
     if (ks != 7) return LEOD_ERR_UNSUPPORTED;       // stem loaders hard-code the 7x7 tap decode
     const int Ho = (Hp + 2 * pad - ks) / stride + 1, Wo = (Wp + 2 * pad - ks) / stride + 1;
     const int M = B * Ho * Wo, K = Cin * ks * ks;
-    EpStore ep = conv_epilogue(y, N, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f);
+    EpStore ep = conv_epilogue(y, N, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0.f);
     const int nt = pick_nt(N);
     int rc = LEOD_OK;
     const bool lds = use_gemm_lds(M, cdiv(N, 16 * nt));

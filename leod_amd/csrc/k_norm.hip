@@ -240,38 +240,43 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __rest
 //   bwd1: sums[0][n] = sum du, sums[1][n] = sum du*xhat   with du = dy * silu'(u)
 //   bwd2: dz = w*rstd*(du - sums0/M - xhat*sums1/M) ; block 0: dw += sums1, db += sums0
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const float* __restrict__ z, const double* __restrict__ colstats,
+__global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const float* __restrict__ z, const double* __restrict__ colstats, int rep,
                                                           const float* __restrict__ w, const float* __restrict__ b,
                                                           float* __restrict__ y, float* __restrict__ save_mean,
                                                           float* __restrict__ save_rstd, float* __restrict__ run_mean,
                                                           float* __restrict__ run_var, long M, int N, double count,
                                                           const double* __restrict__ count_dev, float eps, float momentum) {
+    // every workgroup folds the `rep` replicas of (sum, sumsq) once and keeps (mean, rstd) of all N channels in LDS: the
+    // double-precision divide / sqrt runs once per channel and workgroup instead of once per element
+    extern __shared__ float sstat[];                 // [2][N]: mean, rstd
     if (count_dev) count = count * count_dev[0];     // SyncBatchNorm: rows per image (host) x images over all ranks (device)
-    const long n4 = M * N / 4;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
-        const long e = idx * 4; const int c = (int)(e % N);
-        f4 v = ld4(z + e), r;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double mean = colstats[c + k] / count;
-            const double var = fmax(colstats[N + c + k] / count - mean * mean, 0.0);
-            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-            r[k] = siluf_((v[k] - (float)mean) * rstd * w[c + k] + b[c + k]);
-        }
-        *reinterpret_cast<f4*>(y + e) = r;
-    }
-    if (blockIdx.x == 0) {
-        for (int c = threadIdx.x; c < N; c += blockDim.x) {
-            const double mean = colstats[c] / count;
-            const double var = fmax(colstats[N + c] / count - mean * mean, 0.0);
+    for (int c = threadIdx.x; c < N; c += blockDim.x) {
+        double s = 0.0, ss = 0.0;
+        for (int r = 0; r < rep; ++r) { s += colstats[(size_t)r * 2 * N + c]; ss += colstats[(size_t)r * 2 * N + N + c]; }
+        const double mean = s / count;
+        const double var = fmax(ss / count - mean * mean, 0.0);
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        sstat[c] = (float)mean; sstat[N + c] = rstd;
+        if (blockIdx.x == 0) {
             save_mean[c] = (float)mean;
-            save_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+            save_rstd[c] = rstd;
             if (run_mean) {
                 const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
                 run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
                 run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
             }
         }
+    }
+    __syncthreads();
+    const long n4 = M * N / 4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
+        const long e = idx * 4; const int c = (int)(e % N);
+        const f4 v = ld4(z + e), mu = *reinterpret_cast<const f4*>(sstat + c), rs = *reinterpret_cast<const f4*>(sstat + N + c);
+        const f4 ww = ld4(w + c), bb = ld4(b + c);
+        f4 r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = siluf_((v[k] - mu[k]) * rs[k] * ww[k] + bb[k]);
+        *reinterpret_cast<f4*>(y + e) = r;
     }
 }
 
@@ -390,12 +395,13 @@ LEOD_API int leod_convlstm_gates_bwd(const float* dh, const float* dh2, const fl
     return leod_launch_status();
 }
 
-LEOD_API int leod_bn_silu_fwd(const float* z, const double* colstats, const float* w, const float* b, float* y,
+LEOD_API int leod_bn_silu_fwd(const float* z, const double* colstats, int stat_rep, const float* w, const float* b, float* y,
                               float* save_mean, float* save_rstd, float* run_mean, float* run_var, int M, int N,
                               double count, const double* count_dev, float eps, float momentum, hipStream_t stream) {
     if (!z || !colstats || !w || !b || !y || !save_mean || !save_rstd || (N & 3)) return LEOD_ERR_ARG;
     if (M <= 0) return LEOD_OK;
-    hipLaunchKernelGGL(bn_silu_fwd_kernel, dim3(flat_grid((long)M * N / 4)), dim3(256), 0, stream, z, colstats, w, b, y,
+    hipLaunchKernelGGL(bn_silu_fwd_kernel, dim3(flat_grid((long)M * N / 4)), dim3(256), 2 * N * sizeof(float), stream, z, colstats,
+                       stat_rep > 1 ? stat_rep : 1, w, b, y,
                        save_mean, save_rstd, run_mean, run_var, (long)M, N, count, count_dev, eps, momentum);
     return leod_launch_status();
 }

@@ -8,6 +8,7 @@ into ``param.grad`` (allocated once, or a view into the flat gradient buffer set
 21 extra elementwise adds per parameter.  The Functions therefore return ``None`` for parameter
 inputs; parameters are still passed to ``apply`` so that the outputs are attached to the graph.
 """
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -25,6 +26,7 @@ class WgradSide:
     before the gradient all-reduce.  Tensors read on the side stream are kept alive until the join, so the caching
     allocator cannot hand their memory to a later main-stream kernel while the side stream still reads it."""
     active = False
+    priority = int(os.environ.get('LEOD_WGRAD_PRIO', '0'))   # HIP stream priority of the side stream (-1 = high, 0 = default)
     streams = {}            # launch stream (raw handle) -> its side stream
     used = set()
     keep = []
@@ -34,7 +36,7 @@ class WgradSide:
         key = main.cuda_stream
         st = cls.streams.get(key)
         if st is None:
-            st = cls.streams[key] = torch.cuda.Stream()
+            st = cls.streams[key] = torch.cuda.Stream(priority=cls.priority)
         cls.used.add(key)
         return st
 
@@ -348,12 +350,13 @@ def _conv_bn_fwd(members, need):
     members: (mod, x, conv_w, bn_w, bn_b, stride) -> [(y, (z, mean, rstd, count, count_dev))]."""
     dev = members[0][1].device
     sync = _sync_bn_on()
-    block = ops.StatArena.zeros((sum(2 * m[2].shape[0] for m in members),), dev)
+    R = ops.STAT_REPLICAS                                       # the conv epilogues spread their atomics over R copies
+    block = ops.StatArena.zeros((sum(2 * R * m[2].shape[0] for m in members),), dev)
     zs, off = [], 0
     for mod, x, conv_w, bn_w, bn_b, stride in members:
         N = conv_w.shape[0]
-        zs.append(ops.conv_nhwc_fwd(x, conv_w, None, stride=stride, colstats=block[off:off + 2 * N].view(2, N)))
-        off += 2 * N
+        zs.append(ops.conv_nhwc_fwd(x, conv_w, None, stride=stride, colstats=block[off:off + 2 * R * N].view(R, 2, N)))
+        off += 2 * R * N
     images = _SYNC_BN['images'] if sync else None
     if sync:
         assert images is not None, 'SyncBatchNorm: functions.sync_bn_begin(n_images) must open the pass (YoloXDetector.forward_detect does)'
@@ -364,9 +367,9 @@ def _conv_bn_fwd(members, need):
         rows = z.numel() // N
         count = rows // z.shape[0] if sync else rows            # SyncBN: rows per image; the kernels multiply by ``images``
         mom = mod.bn.momentum if mod.bn.momentum is not None else 0.1
-        y, mean, rstd = ops.bn_silu_fwd(z, block[off:off + 2 * N].view(2, N), bn_w, bn_b, mod.bn.running_mean, mod.bn.running_var,
+        y, mean, rstd = ops.bn_silu_fwd(z, block[off:off + 2 * R * N].view(R, 2, N), bn_w, bn_b, mod.bn.running_mean, mod.bn.running_var,
                                         count, eps=mod.bn.eps, momentum=mom, count_dev=images)
-        off += 2 * N
+        off += 2 * R * N
         mod.bn_calls_pending = getattr(mod, 'bn_calls_pending', 0) + 1     # flushed into num_batches_tracked lazily (flush_bn_counters)
         out.append((y, (z, mean, rstd, count, images) if need else None))
     return out

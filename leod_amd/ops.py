@@ -302,8 +302,12 @@ def stem_conv_wgrad(dy, x_nchw, dw, padded_hw, stride, pad):
                                      padded_hw[0], padded_hw[1], N, ks, stride, pad, _stream()), 'stem_conv_wgrad')
 
 
+STAT_REPLICAS = 32          # copies of the BatchNorm (sum, sumsq) accumulators a conv epilogue spreads its atomics over
+
+
 def conv_nhwc_fwd(x, w, bias=None, stride=1, colstats=None, bn=None, bn_eps=1e-5):
-    """x [B,H,W,Cin] -> y [B,Ho,Wo,N]; pad = (ks-1)//2.  bn = (weight, bias, running_mean, running_var) -> eval BN+SiLU fused."""
+    """x [B,H,W,Cin] -> y [B,Ho,Wo,N]; pad = (ks-1)//2.  bn = (weight, bias, running_mean, running_var) -> eval BN+SiLU fused.
+    colstats: zero-filled float64 [2,N] or [R,2,N] (R a power of two: the epilogue's atomics are spread over the R copies)."""
     _ck(x, name='x')
     _ck(w, name='w')
     _ck(bias, name='bias')
@@ -319,7 +323,8 @@ def conv_nhwc_fwd(x, w, bias=None, stride=1, colstats=None, bn=None, bn_eps=1e-5
         for t in bn:
             _ck(t, name='bn')
     wpack = _empty((N * Cin * ks * ks,), x) if ks > 1 else None     # scratch for the K-contiguous weight copy
-    check(_l().leod_conv_nhwc_fwd(_p(x), _p(w), _p(bias), _p(y), _p(colstats), _p(bw), _p(bb), _p(brm), _p(brv), bn_eps,
+    rep = colstats.shape[0] if colstats is not None and colstats.dim() == 3 else 1
+    check(_l().leod_conv_nhwc_fwd(_p(x), _p(w), _p(bias), _p(y), _p(colstats), rep, _p(bw), _p(bb), _p(brm), _p(brv), bn_eps,
                                    B, H, W, Cin, N, ks, stride, pad, _p(wpack), _stream()), 'conv_nhwc_fwd')
     return y
 
@@ -358,7 +363,8 @@ def bn_silu_fwd(z, colstats, w, b, run_mean, run_var, count, eps=1e-5, momentum=
     y = _empty(z.shape, z)
     mean = _empty((N,), z)
     rstd = _empty((N,), z)
-    check(_l().leod_bn_silu_fwd(_p(z), _p(colstats), _p(w), _p(b), _p(y), _p(mean), _p(rstd), _p(run_mean), _p(run_var),
+    rep = colstats.shape[0] if colstats.dim() == 3 else 1
+    check(_l().leod_bn_silu_fwd(_p(z), _p(colstats), rep, _p(w), _p(b), _p(y), _p(mean), _p(rstd), _p(run_mean), _p(run_var),
                                  M, N, float(count), _p(count_dev), eps, momentum, _stream()), 'bn_silu_fwd')
     return y, mean, rstd
 
@@ -371,7 +377,7 @@ class StatArena:
     buf: Optional[torch.Tensor] = None
     off = 0
     active = False
-    SIZE = 1 << 17                                    # doubles (1 MiB)
+    SIZE = 1 << 19                                    # doubles (4 MiB: 39 BatchNorm layers x STAT_REPLICAS x (sum, sumsq))
 
     @classmethod
     def begin_step(cls, device):

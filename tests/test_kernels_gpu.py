@@ -284,7 +284,8 @@ def test_conv_nhwc(ops, B, H, W, Cin, N, ks, stride):
     close(db, bias.grad, rtol=2e-4, atol=1e-4)
 
 
-def test_conv_bn_eval_and_train(ops):
+@pytest.mark.parametrize('stat_rep', [1, 32])
+def test_conv_bn_eval_and_train(ops, stat_rep):
     B, H, W, Cin, N = 3, 8, 12, 32, 64
     x = rnd((B, Cin, H, W), 1).requires_grad_(True)
     w = rnd((N, Cin, 3, 3), 2, 0.1).requires_grad_(True)
@@ -301,7 +302,8 @@ def test_conv_bn_eval_and_train(ops):
     ref = F.silu(F.batch_norm(z, rm2, rv2, bw, bb, True, 0.1, 1e-5))
     dy = rnd(ref.shape, 7)
     ref.backward(dy)
-    cs = torch.zeros((2, N), dtype=torch.float64, device=DEV)
+    # stat_rep > 1: the conv epilogue spreads its (sum, sumsq) atomics over that many copies, bn_silu_fwd folds them
+    cs = torch.zeros((2, N) if stat_rep == 1 else (stat_rep, 2, N), dtype=torch.float64, device=DEV)
     zz = ops.conv_nhwc_fwd(xn, w.detach().to(DEV), None, colstats=cs)
     rmd, rvd = rm.to(DEV), rv.to(DEV)
     M = B * H * W
