@@ -63,6 +63,21 @@ int leod_convlstm_fwd(const float* x, const float* h_prev, const float* c_prev, 
 int leod_convlstm_gates_bwd(const float* dh, const float* dh2, const float* dc_next, const float* gates, const float* c_prev,
                             const float* c_t, float* dgates, float* dc_prev, int M, int C, leod_stream_t stream);
 
+/* The ConvLSTM recurrence of a whole sequence in ONE launch per direction (same cell as leod_convlstm_fwd, unrolled over the L
+ * timesteps of modules/detection.py:188-226): one workgroup carries 16 rows through all T timesteps with its slice of the weights
+ * resident in registers.  leod_convlstm_seq_mode(C): 1 = xin is x_seq [T,M,C] (fused [x|h] contraction), 2 = xin is the
+ * time-batched projection gx [T,M,4C] = x W_x^T + b computed by the caller, 0 = not available for this C / precision mode
+ * (callers then loop leod_convlstm_fwd).  hbuf, cbuf [T+1,M,C]: slot 0 = incoming state (zero_state: taken as zeros, not read),
+ * slots 1..T are written; gates_out [T,M,4,C] optional. */
+int leod_convlstm_seq_mode(int C);
+int leod_convlstm_seq_fwd(const float* xin, int x_is_projection, float* hbuf, float* cbuf, const float* W, const float* bias,
+                          float* gates_out, int M, int C, int T, int zero_state, leod_stream_t stream);
+/* Backward through time of the same: dh_seq [T,M,C] (optional) gradients of every h_t from above, dc_last [M,C] (optional);
+ * writes dgates_out [T,M,4C] (pre-activation; dx = dgates W_x and the weight gradient are one GEMM each over all T*M rows)
+ * and optionally dh0 / dc0 [M,C].  LEOD_ERR_UNSUPPORTED (-3) when the weight slice does not fit the registers. */
+int leod_convlstm_seq_bwd(const float* dh_seq, const float* dc_last, const float* gates, const float* cbuf, const float* W,
+                          float* dgates_out, float* dh0, float* dc0, int M, int C, int T, int zero_state, leod_stream_t stream);
+
 /* dx (=|+=) (dy[M,N]*kscale[N]) W[N,K] ; optional: multiply by gelu'(aux_u[M,K]); route columns >= nsplit to dx2;
  * colsum[K] += column sums of the result.  Autograd of the Linear layers above. */
 int leod_linear_dgrad(const float* dy, long lddy, const float* kscale, const float* W, float* dx, long lddx, float* dx2,

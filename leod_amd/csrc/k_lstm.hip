@@ -1,0 +1,324 @@
+// ConvLSTM recurrence of a whole sequence in ONE launch per direction (DWSConvLSTM2d with dws_conv = False,
+// models/layers/rnn.py:37-70, unrolled over the L timesteps of modules/detection.py:188-226).
+//
+// With a 1 x 1 cell convolution the recurrence of a pixel depends on no other pixel, so a workgroup can carry its 16 rows
+// (pixels) through all T timesteps: the per-timestep schedule paid 3 dependent launches per timestep and stage (cell forward; gate
+// backward + dgrad), each too small to fill 256 CUs -- 5 ms of a 28 ms RVT-S training step.  Here
+//   * one workgroup = one 16-row tile, one WAVE per 16 channels (C / 16 waves): the wave owns the four gate columns (f, i, o, g)
+//     of its channels, i.e. all of a channel's gate arithmetic is lane-local in the MFMA accumulator layout;
+//   * the wave's slice of the weights stays in REGISTERS as MFMA B fragments for the whole sequence (forward: W[4 gates x 16
+//     channels][K]; backward: W_h[4C][16 channels]) -- nothing but activations is read inside the time loop;
+//   * the A operand of timestep t ([x_t | h_{t-1}] forward, dgates_t backward) is exchanged between the waves through a
+//     double-buffered LDS tile: ONE workgroup barrier per timestep;
+//   * c_t lives in registers (fp32), h_t / c_t / gates_t are written for the backward pass as the per-timestep kernels did.
+// Forward variants: FX = true contracts [x_t | h_{t-1}] (K = 2C); FX = false takes the time-batched x projection gx =
+// x W_x^T + b (one large GEMM over all T * M rows, computed by the caller) as accumulator input and contracts h_{t-1} only.
+// BF = true: bf16 operands (A tile and B fragments rounded to bf16, v_mfma_f32_16x16x16_bf16), fp32 accumulation and state --
+// the same rounding points as the per-timestep bf16 kernels.  BF = false: v_mfma_f32_16x16x4_f32, with FX the same fmaf chain
+// as the per-timestep fp32 kernel.
+#include <stdlib.h>
+#include <type_traits>
+
+#include "common.hpp"
+
+template <bool FAST> __device__ __forceinline__ float tanh_(float x) {
+    if constexpr (FAST) return 2.0f * sigmoidf_(2.0f * x) - 1.0f;         // v_exp / v_rcp: |error| ~1e-7, bf16 mode only
+    else return tanhf(x);
+}
+
+template <bool BF> struct AElem;
+template <> struct AElem<true> { typedef unsigned short T; };
+template <> struct AElem<false> { typedef float T; };
+__device__ __forceinline__ unsigned short to_bf16(float v) {
+    const f2_ p = {v, 0.f};
+    return (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(p, bf2_)) & 0xffffu);
+}
+template <bool BF> __device__ __forceinline__ typename AElem<BF>::T a_elem(float v) {
+    if constexpr (BF) return to_bf16(v); else return v;
+}
+
+// One timestep's MFMAs of a wave: acc[g] += A[16 x 16*KC] . B_g   (A fragments from the LDS tile, B fragments in registers)
+template <int KC, int NG, bool BF, class BT>
+__device__ __forceinline__ void tile_mfma(f4 (&acc)[NG], const typename AElem<BF>::T* __restrict__ arow, const BT (&b)[NG][KC]) {
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+        // long contractions: keep the scheduler from hoisting all KC fragment reads (2 registers each) above the first MFMA
+        if (KC > 12 && kc % 8 == 0) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (BF) {
+            const s4 a = *reinterpret_cast<const s4*>(arow + 16 * kc);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = mfma16_bf16(a, b[g][kc], acc[g]);
+        } else {
+            const f4 a = *reinterpret_cast<const f4*>(arow + 16 * kc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = mfma16(a[j], b[g][kc][j], acc[g]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward
+//   xin   FX: x_seq [T][M][C]            !FX: gx [T][M][4C] = x_t W_x^T + b (pre-activation x part, bias included)
+//   hbuf, cbuf [T+1][M][C]: slot 0 = incoming state (zero_state != 0: treated as zeros and not read), slots 1..T written
+//   W [4C][2C] (gate-major rows f, i, o, g; columns [x | h]), bias [4C]; gates_out [T][M][4][C] post-activation or NULL
+// ---------------------------------------------------------------------------------------------------------------------
+template <int C, bool FX, bool BF>
+__global__ __launch_bounds__(C * 4) void lstm_seq_fwd_kernel(const float* __restrict__ xin, float* __restrict__ hbuf, float* __restrict__ cbuf,
+                                                              const float* __restrict__ W, const float* __restrict__ bias,
+                                                              float* __restrict__ gates_out, int M, int T, int zero_state) {
+    constexpr int NW = C / 16;                       // waves per workgroup
+    constexpr int KA = FX ? 2 * C : C;               // contraction length = columns of the A tile
+    constexpr int KC = KA / 16;
+    constexpr int LD = KA + 8;                       // bf16: rows of 4 * odd dwords; fp32: stride == 8 (mod 16) dwords
+    constexpr int HOFF = FX ? C : 0;                 // column of h inside the A tile
+    constexpr bool PF = C < 192;                     // prefetch the next timestep's projection (register room permitting)
+    typedef typename AElem<BF>::T AT;
+    typedef typename std::conditional<BF, s4, f4>::type BT;
+    __shared__ __attribute__((aligned(16))) AT sA[2][16 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const long row0 = (long)blockIdx.x * 16;
+    const int ch = 16 * wave + i;                    // this lane's channel (accumulator column)
+    const long MC = (long)M * C;
+    // ---- resident B fragments: B_g[k][j = i] = W[g*C + ch][koff + k] -----------------------------------------------------------
+    BT bw[4][KC];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float* wr = W + (long)(g * C + ch) * (2 * C) + (FX ? 0 : C) + 4 * q;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const f4 w = ld4(wr + 16 * kc);
+            if constexpr (BF) bw[g][kc] = pack_bf16(w); else bw[g][kc] = w;
+        }
+    }
+    float bg[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bg[g] = FX ? bias[g * C + ch] : 0.f;
+    // accumulator-layout rows of this lane: row0 + 4q + r; loads are clamped (never stored when out of range).  Element offsets
+    // inside one timestep's slab fit 32 bits (M * 4C < 2^31, checked by the launcher): per-timestep base pointers are scalar
+    int oc[4]; bool rok[4];                          // row * C + ch  (h, c);  the gate / projection offset is 4 * oc - 3 * ch
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { rok[r] = row0 + 4 * q + r < M; oc[r] = (int)(rok[r] ? row0 + 4 * q + r : (long)M - 1) * C + ch; }
+    // staging slot of this lane for the x part of the A tile: (row = lane >> 2, 4 channels 16*wave + 4*(lane & 3))
+    const int srow = lane >> 2, sc4 = 16 * wave + 4 * (lane & 3);
+    const int sxo = (int)min(row0 + srow, (long)M - 1) * C + sc4;
+    // ---- initial state --------------------------------------------------------------------------------------------------
+    float cst[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        cst[r] = zero_state ? 0.f : cbuf[oc[r]];
+        const float h0 = zero_state ? 0.f : hbuf[oc[r]];
+        sA[0][(4 * q + r) * LD + HOFF + ch] = a_elem<BF>(h0);
+    }
+    f4 xs = zero4();
+    float gx[4][4];
+    if (FX) {
+        xs = ld4(xin + sxo);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sA[0][srow * LD + sc4 + j] = a_elem<BF>(xs[j]);
+        if (T > 1) xs = ld4(xin + MC + sxo);
+    } else if (PF) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gx[g][r] = xin[4 * oc[r] - 3 * ch + g * C];
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        f4 acc[4];
+        if (FX) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = zero4();
+        } else if (!PF) {                             // C >= 192: no register room for a prefetched projection (3 waves per SIMD hide it)
+            const float* gp = xin + (long)t * M * 4 * C;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[g][r] = gp[4 * oc[r] - 3 * ch + g * C];
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[g][r] = gx[g][r];
+            if (t + 1 < T) {                          // next timestep's x projection flies under this timestep's MFMAs
+                const float* gp = xin + (long)(t + 1) * M * 4 * C;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gx[g][r] = gp[4 * oc[r] - 3 * ch + g * C];
+            }
+        }
+        tile_mfma<KC, 4, BF, BT>(acc, &sA[buf][i * LD + 4 * q], bw);
+        // ---- gates of channel ch, rows 4q + r (rnn.py:58-68) --------------------------------------------------------------------
+        float* hp = hbuf + (long)(t + 1) * MC;
+        float* cp = cbuf + (long)(t + 1) * MC;
+        float* gp = gates_out ? gates_out + (long)t * M * 4 * C : nullptr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float f = sigmoidf_(acc[0][r] + bg[0]), ig = sigmoidf_(acc[1][r] + bg[1]), o = sigmoidf_(acc[2][r] + bg[2]);
+            const float g = tanh_<BF>(acc[3][r] + bg[3]);
+            const float cn = f * cst[r] + ig * g;
+            const float hn = o * tanh_<BF>(cn);
+            cst[r] = cn;
+            sA[buf ^ 1][(4 * q + r) * LD + HOFF + ch] = a_elem<BF>(hn);
+            if (rok[r]) {
+                hp[oc[r]] = hn;
+                cp[oc[r]] = cn;
+                if (gp) {
+                    float* gr = gp + (4 * oc[r] - 3 * ch);
+                    gr[0] = f; gr[C] = ig; gr[2 * C] = o; gr[3 * C] = g;
+                }
+            }
+        }
+        if (FX && t + 1 < T) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sA[buf ^ 1][srow * LD + sc4 + j] = a_elem<BF>(xs[j]);
+            if (t + 2 < T) xs = ld4(xin + (long)(t + 2) * MC + sxo);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward through time
+//   dh_seq [T][M][C] gradient of every h_t from the layers above (or NULL), dc_last [M][C] gradient of c_T (or NULL)
+//   gates [T][M][4][C], cbuf [T+1][M][C] as written by the forward pass; zero_state: c_0 = 0 and not read
+//   dgates_out [T][M][4C] pre-activation gate gradients (for the weight gradient and dx = dgates W_x, one GEMM each over all T)
+//   dh0 / dc0 [M][C] (optional): gradients of the incoming state
+// Per timestep: gate backward (lane-local) -> dgates tile in LDS -> barrier -> dh_{t-1} += dgates_t W_h for the wave's 16 channels.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int C, bool BF>
+__global__ __launch_bounds__(C * 4) void lstm_seq_bwd_kernel(const float* __restrict__ dh_seq, const float* __restrict__ dc_last,
+                                                              const float* __restrict__ gates, const float* __restrict__ cbuf,
+                                                              const float* __restrict__ W, float* __restrict__ dgates_out,
+                                                              float* __restrict__ dh0, float* __restrict__ dc0, int M, int T, int zero_state) {
+    constexpr int NW = C / 16;
+    constexpr int KA = 4 * C, KC = KA / 16, LD = KA + 8;
+    typedef typename AElem<BF>::T AT;
+    typedef typename std::conditional<BF, s4, f4>::type BT;
+    __shared__ __attribute__((aligned(16))) AT sA[2][16 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const long row0 = (long)blockIdx.x * 16;
+    const int ch = 16 * wave + i;
+    const long MC = (long)M * C;
+    // resident B fragments: B[k][j = i] = W_h[k][ch] = W[k][C + ch], k = 16 kc + 4 q + jj
+    BT bw[1][KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+        const float* wr = W + (long)(16 * kc + 4 * q) * (2 * C) + C + ch;
+        f4 w; w.x = wr[0]; w.y = wr[2 * C]; w.z = wr[4 * C]; w.w = wr[6 * C];
+        if constexpr (BF) bw[0][kc] = pack_bf16(w); else bw[0][kc] = w;
+    }
+    int oc[4]; bool rok[4];                          // row * C + ch; gate offset = 4 * oc - 3 * ch (see the forward kernel)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { rok[r] = row0 + 4 * q + r < M; oc[r] = (int)(rok[r] ? row0 + 4 * q + r : (long)M - 1) * C + ch; }
+    float dcn[4], dhr[4];                            // dc flowing to t - 1, dh from timestep t + 1
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { dcn[r] = dc_last ? dc_last[oc[r]] : 0.f; dhr[r] = 0.f; }
+    struct In { float g[4][4], cp[4], ct[4], dh[4]; };
+    auto load = [&](In& in, int t) {
+        const float* gp = gates + (long)t * M * 4 * C;
+        const float* c0 = cbuf + (long)t * MC;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* gr = gp + (4 * oc[r] - 3 * ch);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) in.g[g][r] = gr[g * C];
+            in.cp[r] = (zero_state && t == 0) ? 0.f : c0[oc[r]];
+            in.ct[r] = c0[MC + oc[r]];
+            in.dh[r] = dh_seq ? dh_seq[(long)t * MC + oc[r]] : 0.f;
+        }
+    };
+    // C >= 192 (12+ waves per workgroup, 3+ per SIMD): no register room for a second input set -- the co-resident waves hide the loads
+    constexpr bool PF = C < 192;
+    In cur, nxt;
+    load(cur, T - 1);
+    for (int t = T - 1; t >= 0; --t) {
+        const int buf = t & 1;
+        if (PF && t > 0) load(nxt, t - 1);            // flies under this timestep's arithmetic
+        float* dgp = dgates_out + (long)t * M * 4 * C;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float f = cur.g[0][r], ig = cur.g[1][r], o = cur.g[2][r], g = cur.g[3][r];
+            const float th = tanh_<BF>(cur.ct[r]);
+            const float dhv = cur.dh[r] + dhr[r];
+            const float dc = dhv * o * (1.0f - th * th) + dcn[r];
+            const float d0 = dc * cur.cp[r] * f * (1.0f - f), d1 = dc * g * ig * (1.0f - ig);
+            const float d2 = dhv * th * o * (1.0f - o), d3 = dc * ig * (1.0f - g * g);
+            dcn[r] = dc * f;
+            AT* ar = &sA[buf][(4 * q + r) * LD + ch];
+            ar[0] = a_elem<BF>(d0); ar[C] = a_elem<BF>(d1); ar[2 * C] = a_elem<BF>(d2); ar[3 * C] = a_elem<BF>(d3);
+            if (rok[r]) {
+                float* dr = dgp + (4 * oc[r] - 3 * ch);
+                dr[0] = d0; dr[C] = d1; dr[2 * C] = d2; dr[3 * C] = d3;
+            }
+        }
+        __syncthreads();
+        f4 acc[1] = {zero4()};
+        tile_mfma<KC, 1, BF, BT>(acc, &sA[buf][i * LD + 4 * q], bw);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dhr[r] = acc[0][r];
+        if (PF) cur = nxt;
+        else if (t > 0) load(cur, t - 1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (rok[r]) {
+            if (dh0) dh0[oc[r]] = dhr[r];
+            if (dc0) dc0[oc[r]] = dcn[r];
+        }
+}
+
+// registers of the resident B fragments per lane: 4 gates x K/16 chunks x (2 | 4) dwords
+static inline int fwd_bregs(int K, bool bf) { return 4 * (K / 16) * (bf ? 2 : 4); }
+
+/* 1 = fused [x | h] contraction, 2 = hoisted x projection (xin = gx), 0 = sequence kernel not available for this C / precision */
+LEOD_API int leod_convlstm_seq_mode(int C) {
+    if (getenv("LEOD_LSTM_SEQ") && atoi(getenv("LEOD_LSTM_SEQ")) == 0) return 0;
+    const bool bf = leod_precision() == 1;
+    if (C != 32 && C != 48 && C != 64 && C != 96 && C != 128 && C != 192) return 0;
+    if (fwd_bregs(2 * C, bf) <= 96) return 1;                               // beyond ~100 resident registers the kernels spill
+    if (fwd_bregs(C, bf) <= (C >= 192 ? 96 : 128)) return 2;
+    return 0;
+}
+
+#define LSTM_FWD_CASE(CV, FXV)                                                                                                  \
+    if (C == CV && fx == FXV) {                                                                                                 \
+        if (bf) hipLaunchKernelGGL((lstm_seq_fwd_kernel<CV, FXV, true>), grid, dim3(CV * 4), 0, stream, xin, hbuf, cbuf, W, bias, gates_out, M, T, zero_state); \
+        else hipLaunchKernelGGL((lstm_seq_fwd_kernel<CV, FXV, false>), grid, dim3(CV * 4), 0, stream, xin, hbuf, cbuf, W, bias, gates_out, M, T, zero_state);  \
+        return leod_launch_status();                                                                                            \
+    }
+
+LEOD_API int leod_convlstm_seq_fwd(const float* xin, int x_is_projection, float* hbuf, float* cbuf, const float* W, const float* bias,
+                                   float* gates_out, int M, int C, int T, int zero_state, hipStream_t stream) {
+    if (!xin || !hbuf || !cbuf || !W || !bias || M <= 0 || T <= 0 || (long)M * 4 * C >= (1L << 31)) return LEOD_ERR_ARG;
+    const int mode = leod_convlstm_seq_mode(C);
+    if (mode == 0 || (mode == 1) != (x_is_projection == 0)) return LEOD_ERR_UNSUPPORTED;
+    const bool bf = leod_precision() == 1, fx = mode == 1;
+    const dim3 grid(cdiv(M, 16));
+    LSTM_FWD_CASE(32, true) LSTM_FWD_CASE(48, true) LSTM_FWD_CASE(64, true) LSTM_FWD_CASE(96, true)
+    LSTM_FWD_CASE(64, false) LSTM_FWD_CASE(96, false) LSTM_FWD_CASE(128, false) LSTM_FWD_CASE(192, false)
+    return LEOD_ERR_UNSUPPORTED;
+}
+
+#define LSTM_BWD_CASE(CV)                                                                                                       \
+    if (C == CV) {                                                                                                              \
+        if (bf) hipLaunchKernelGGL((lstm_seq_bwd_kernel<CV, true>), grid, dim3(CV * 4), 0, stream, dh_seq, dc_last, gates, cbuf, W, dgates_out, dh0, dc0, M, T, zero_state); \
+        else hipLaunchKernelGGL((lstm_seq_bwd_kernel<CV, false>), grid, dim3(CV * 4), 0, stream, dh_seq, dc_last, gates, cbuf, W, dgates_out, dh0, dc0, M, T, zero_state);  \
+        return leod_launch_status();                                                                                            \
+    }
+
+LEOD_API int leod_convlstm_seq_bwd(const float* dh_seq, const float* dc_last, const float* gates, const float* cbuf, const float* W,
+                                   float* dgates_out, float* dh0, float* dc0, int M, int C, int T, int zero_state, hipStream_t stream) {
+    if (!gates || !cbuf || !W || !dgates_out || M <= 0 || T <= 0 || (long)M * 4 * C >= (1L << 31)) return LEOD_ERR_ARG;
+    const bool bf = leod_precision() == 1;
+    // B fragments of the backward pass: 4C/16 chunks x (2 | 4) dwords
+    if ((4 * C / 16) * (bf ? 2 : 4) > (C >= 192 ? 96 : 128)) return LEOD_ERR_UNSUPPORTED;
+    const dim3 grid(cdiv(M, 16));
+    LSTM_BWD_CASE(32) LSTM_BWD_CASE(48) LSTM_BWD_CASE(64) LSTM_BWD_CASE(96) LSTM_BWD_CASE(128) LSTM_BWD_CASE(192)
+    return LEOD_ERR_UNSUPPORTED;
+}

@@ -285,10 +285,18 @@ class ConvLSTMSeqFn(Function):
             cbuf[0].copy_(c0)
         gates = x_seq.new_empty((T, M, 4, C)) if need else None
         W2 = w.view(4 * C, 2 * C)
-        for t in range(T):
-            zero_state = h0 is None and t == 0
-            ops.convlstm_fwd(x_seq[t], None if zero_state else hbuf[t], None if zero_state else cbuf[t], W2, b,
-                             h_out=hbuf[t + 1], c_out=cbuf[t + 1], gates_out=gates[t] if need else None)
+        mode = ops.convlstm_seq_mode(C)
+        if mode:
+            # ONE launch for the whole recurrence (csrc/k_lstm.hip); mode 2: the x projection of all timesteps is one large GEMM
+            xin = x_seq
+            if mode == 2:
+                xin, _, _ = ops.ln_linear_fwd(x_seq.view(T * M, C), None, None, W2[:, :C].contiguous(), b)
+            ops.convlstm_seq_fwd(xin, mode == 2, hbuf, cbuf, W2, b, gates, zero_state=h0 is None)
+        else:
+            for t in range(T):
+                zero_state = h0 is None and t == 0
+                ops.convlstm_fwd(x_seq[t], None if zero_state else hbuf[t], None if zero_state else cbuf[t], W2, b,
+                                 h_out=hbuf[t + 1], c_out=cbuf[t + 1], gates_out=gates[t] if need else None)
         if need:
             ctx.mod = mod
             ctx.set_materialize_grads(False)
@@ -304,13 +312,20 @@ class ConvLSTMSeqFn(Function):
         W2 = w.view(4 * C, 2 * C)
         dh_seq = _cont(dh_seq)
         dgates = x_seq.new_empty((T, M, 4 * C))
-        dx_seq = torch.empty_like(x_seq)
         need_h0, need_c0 = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
-        dh_next, dc_next = None, _cont(dc_last)
-        for t in reversed(range(T)):
-            _, dc_next = ops.convlstm_gates_bwd(dh_seq[t] if dh_seq is not None else None, dc_next, gates[t], cbuf[t], cbuf[t + 1],
-                                                want_dc_prev=(t > 0 or need_c0), dh2=dh_next, dgates_out=dgates[t])
-            _, dh_next = ops.linear_dgrad(dgates[t], W2, split=C, out=dx_seq[t].view(M, C))
+        dh0 = x_seq.new_empty(x_seq.shape[1:]) if need_h0 else None
+        dc0 = x_seq.new_empty(x_seq.shape[1:]) if need_c0 else None
+        if ops.convlstm_seq_mode(C) and ops.convlstm_seq_bwd(dh_seq, _cont(dc_last), gates, cbuf, W2, dgates, dh0, dc0):
+            # backward through time in one launch; dx of all timesteps is ONE GEMM dgates W_x over T*M rows
+            dx_seq = ops.linear_dgrad(dgates.view(T * M, 4 * C), W2[:, :C].contiguous()).view(x_seq.shape)
+            dh_next, dc_next = dh0, dc0
+        else:
+            dx_seq = torch.empty_like(x_seq)
+            dh_next, dc_next = None, _cont(dc_last)
+            for t in reversed(range(T)):
+                _, dc_next = ops.convlstm_gates_bwd(dh_seq[t] if dh_seq is not None else None, dc_next, gates[t], cbuf[t], cbuf[t + 1],
+                                                    want_dc_prev=(t > 0 or need_c0), dh2=dh_next, dgates_out=dgates[t])
+                _, dh_next = ops.linear_dgrad(dgates[t], W2, split=C, out=dx_seq[t].view(M, C))
         with _wgrad_side(dgates, x_seq, hbuf):
             ops.linear_wgrad(dgates.view(T * M, 4 * C), x_seq.view(T * M, C), grad_buf(mod.conv1x1.weight).view(4 * C, 2 * C),
                              grad_buf(mod.conv1x1.bias), x2=hbuf[:T].view(T * M, C))

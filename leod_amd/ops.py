@@ -173,6 +173,41 @@ def convlstm_gates_bwd(dh, dc_next, gates, c_prev, c_t, want_dc_prev=True, dh2=N
     return dgates, dc_prev
 
 
+def convlstm_seq_mode(C: int) -> int:
+    """0: no sequence kernel for this channel count / precision mode; 1: fused [x | h] contraction (xin = x_seq);
+    2: the caller supplies the time-batched projection gx = x W_x^T + b (leod_convlstm_seq_mode)."""
+    return int(_l().leod_convlstm_seq_mode(int(C)))
+
+
+def convlstm_seq_fwd(xin, is_projection, hbuf, cbuf, W, bias, gates_out, zero_state):
+    """The whole recurrence in one launch: xin [T,M,C] (or gx [T,M,4C]), hbuf / cbuf [T+1,M,C] (slot 0 = incoming state,
+    slots 1.. written), W [4C,2C], gates_out [T,M,4,C] | None."""
+    for t, n in ((xin, 'xin'), (hbuf, 'hbuf'), (cbuf, 'cbuf'), (W, 'W'), (bias, 'bias'), (gates_out, 'gates_out')):
+        _ck(t, name=n)
+    T = hbuf.shape[0] - 1
+    C = hbuf.shape[-1]
+    M = hbuf[0].numel() // C
+    check(_l().leod_convlstm_seq_fwd(_p(xin), 1 if is_projection else 0, _p(hbuf), _p(cbuf), _p(W), _p(bias), _p(gates_out), M, C, T,
+                                      1 if zero_state else 0, _stream()), 'convlstm_seq_fwd')
+
+
+def convlstm_seq_bwd(dh_seq, dc_last, gates, cbuf, W, dgates_out, dh0=None, dc0=None, zero_state=False) -> bool:
+    """Backward through time in one launch -> dgates_out [T,M,4C] (+ dh0, dc0).  False: the weight slice does not fit the registers
+    for this C / precision mode (the caller then runs the per-timestep kernels on the same saved tensors)."""
+    for t, n in ((dh_seq, 'dh_seq'), (dc_last, 'dc_last'), (gates, 'gates'), (cbuf, 'cbuf'), (W, 'W'), (dgates_out, 'dgates_out'),
+                 (dh0, 'dh0'), (dc0, 'dc0')):
+        _ck(t, name=n)
+    T = cbuf.shape[0] - 1
+    C = cbuf.shape[-1]
+    M = cbuf[0].numel() // C
+    rc = _l().leod_convlstm_seq_bwd(_p(dh_seq), _p(dc_last), _p(gates), _p(cbuf), _p(W), _p(dgates_out), _p(dh0), _p(dc0), M, C, T,
+                                    1 if zero_state else 0, _stream())
+    if rc == -3:
+        return False
+    check(rc, 'convlstm_seq_bwd')
+    return True
+
+
 def linear_dgrad(dy, W, kscale=None, aux_u=None, colsum=None, out=None, accumulate=False, split=0, out2=None):
     """dx = (dy * kscale) @ W  with W [N,K]; see leod_linear_dgrad."""
     for t, n in ((dy, 'dy'), (W, 'W'), (kscale, 'kscale'), (aux_u, 'aux_u'), (colsum, 'colsum'), (out, 'out'), (out2, 'out2')):

@@ -170,6 +170,50 @@ def test_convlstm(ops, M, C, state):
     close(db, b.grad, rtol=2e-4, atol=2e-5, what='db')
 
 
+@pytest.mark.parametrize('T,B,H,W,C,state', [(4, 1, 7, 10, 48, True),       # 70 rows: ragged last 16-row tile, fused [x|h] kernel
+                                             (3, 2, 8, 10, 32, False),      # zero incoming state
+                                             (5, 4, 16, 40, 96, True),      # RVT-S stage 2 (fp32 mode: hoisted x projection)
+                                             (3, 2, 16, 20, 192, True),     # stage 3 (bf16 mode: hoisted, 12 waves; fp32 mode: per-timestep fallback)
+                                             (2, 1, 5, 8, 384, True),       # stage 4: per-timestep kernels
+                                             (21, 2, 16, 20, 48, True)])    # the benchmark's sequence length
+def test_convlstm_sequence(ops, T, B, H, W, C, state):
+    """DWSConvLSTM2d.forward_sequence (ONE launch per direction, csrc/k_lstm.hip, + the time-batched dx / weight-gradient GEMMs) against
+    T chained steps of the oracle cell (models/layers/rnn.py:37-70), forward and backward through time."""
+    from leod_amd.models.layers.rnn import DWSConvLSTM2d
+    x = rnd((T * B, C, H, W), 1)
+    h0, c0 = rnd((B, C, H, W), 2, 0.5), rnd((B, C, H, W), 3, 0.5)
+    Wt, b = rnd((4 * C, 2 * C, 1, 1), 4, 0.15), rnd((4 * C,), 5, 0.1)
+    xr, hr, cr = x.clone().requires_grad_(True), h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+    Wr, br = Wt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    sd = {'l.conv1x1.weight': Wr, 'l.conv1x1.bias': br}
+    st = (hr, cr) if state else None
+    hs = []
+    for t in range(T):
+        st = ob.conv_lstm(xr[t * B:(t + 1) * B], st, sd, 'l')
+        hs.append(st[0])
+    href = torch.cat(hs, 0)
+    dh, dc = rnd(href.shape, 6), rnd(st[1].shape, 7)
+    (href * dh).sum().add((st[1] * dc).sum()).backward()
+    mod = DWSConvLSTM2d(C, dws_conv=False).to(DEV)
+    with torch.no_grad():
+        mod.conv1x1.weight.copy_(Wt.to(DEV)); mod.conv1x1.bias.copy_(b.to(DEV))
+    cl = lambda t: t.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)  # noqa
+    xd, hd, cd = cl(x), cl(h0), cl(c0)
+    hseq, (hl, clast) = mod.forward_sequence(xd, T, (hd, cd) if state else None)
+    close(hseq, href, what='h of all timesteps')
+    close(clast, st[1], what='final c')
+    close(hl, hs[-1], what='final h')
+    (hseq * dh.to(DEV)).sum().add((clast * dc.to(DEV)).sum()).backward()
+    close(xd.grad, xr.grad, rtol=1e-4, atol=1e-5, what='dx')
+    if state:
+        close(hd.grad, hr.grad, rtol=1e-4, atol=1e-5, what='dh0')
+        close(cd.grad, cr.grad, rtol=1e-4, atol=1e-5, what='dc0')
+        close(mod.conv1x1.weight.grad, Wr.grad, rtol=2e-4, atol=2e-5, what='dW')
+    else:
+        close(mod.conv1x1.weight.grad[:, :C], Wr.grad[:, :C], rtol=2e-4, atol=2e-5, what='dW_x')
+    close(mod.conv1x1.bias.grad, br.grad, rtol=2e-4, atol=2e-5, what='db')
+
+
 @pytest.mark.parametrize('M,N,K', [(300, 144, 48), (1000, 48, 192), (257, 64, 32), (5000, 96, 96), (100, 1536, 384),
                                    # large M: wave-tiled wgrad (192x48, 48x192, 96x96, 48x48 tiles) and LDS dgrad
                                    (30000, 192, 48), (30000, 48, 192), (20000, 288, 96), (65000, 48, 48),
