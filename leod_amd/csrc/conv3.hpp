@@ -1,0 +1,9 @@
+// Direct 3x3 / stride-1 convolution (k_conv3.hip), called from the conv entry points of k_conv.hip in precision mode bf16.
+#pragma once
+#include <stddef.h>
+#include <hip/hip_runtime.h>
+
+bool conv3s1_supported(int H, int W, int Cin, int Cout);
+size_t conv3s1_pack_bytes(int Cin, int Cout);
+int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, int stat_rep, int accumulate, int B, int H, int W,
+                   int Cin, int Cout, int transposed, void* wpack, hipStream_t stream);

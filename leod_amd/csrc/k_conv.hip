@@ -8,6 +8,7 @@
 // Epilogues: raw store (+bias), raw store + per-channel (sum, sumsq) for training BatchNorm,
 // or folded eval-BatchNorm + SiLU.
 #include "gemm16.hpp"
+#include "conv3.hpp"
 
 static inline int pick_nt(int N) {
     int best = 1; long bestpad = 1L << 60;
@@ -61,6 +62,9 @@ LEOD_API int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bia
     if (!x || !w || !y || (Cin & 3) || (stat_rep > 1 && (stat_rep & (stat_rep - 1)))) return LEOD_ERR_ARG;
     const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
     const int M = B * Ho * Wo, K = ks * ks * Cin;
+    // PAFPN / head 3x3 convs in precision mode bf16: direct convolution from an LDS-resident input halo (k_conv3.hip)
+    if (ks == 3 && stride == 1 && pad == 1 && !bias && !bn_w && wpack && conv3s1_supported(H, W, Cin, N))
+        return conv3s1_launch(x, w, y, colstats, stat_rep, 0, B, H, W, Cin, N, 0, wpack, stream);
     EpStore ep = conv_epilogue(y, N, bias, colstats, stat_rep, bn_w, bn_b, bn_rm, bn_rv, bn_eps);
     const int nt = pick_nt(N);
     int rc = LEOD_OK;
@@ -284,6 +288,8 @@ LEOD_API int leod_conv_nhwc_dgrad(const float* dy, const float* w, float* dx, in
     if (!dy || !w || !dx || (N & 3)) return LEOD_ERR_ARG;
     const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
     const int M = B * H * W, K = ks * ks * N;
+    if (ks == 3 && stride == 1 && pad == 1 && wpack && conv3s1_supported(H, W, N, Cin))
+        return conv3s1_launch(dy, w, dx, nullptr, 0, accumulate, B, H, W, N, Cin, 1, wpack, stream);
     EpStore ep{}; ep.out = dx; ep.ld = Cin; ep.N = Cin; ep.accumulate = accumulate;
     const int nt = pick_nt(Cin);
     int rc = LEOD_OK;

@@ -365,10 +365,14 @@ def _conv_bn_fwd(members, need):
     members: (mod, x, conv_w, bn_w, bn_b, stride) -> [(y, (z, mean, rstd, count, count_dev))]."""
     dev = members[0][1].device
     sync = _sync_bn_on()
-    R = ops.STAT_REPLICAS                                       # the conv epilogues spread their atomics over R copies
-    block = ops.StatArena.zeros((sum(2 * R * m[2].shape[0] for m in members),), dev)
+    # the conv epilogues spread their (sum, sumsq) atomics over R copies (R by output rows), bn_silu_fwd folds them
+    def rows_of(x, stride):
+        # SyncBatchNorm: the block is all-reduced, so its layout must not depend on this rank's (data-dependent) image count
+        return (32 if sync else x.shape[0]) * ((x.shape[1] - 1) // stride + 1) * ((x.shape[2] - 1) // stride + 1)
+    reps = [ops.stat_replicas(rows_of(m[1], m[5])) for m in members]
+    block = ops.StatArena.zeros((sum(2 * R * m[2].shape[0] for m, R in zip(members, reps)),), dev)
     zs, off = [], 0
-    for mod, x, conv_w, bn_w, bn_b, stride in members:
+    for (mod, x, conv_w, bn_w, bn_b, stride), R in zip(members, reps):
         N = conv_w.shape[0]
         zs.append(ops.conv_nhwc_fwd(x, conv_w, None, stride=stride, colstats=block[off:off + 2 * R * N].view(R, 2, N)))
         off += 2 * R * N
@@ -377,7 +381,7 @@ def _conv_bn_fwd(members, need):
         assert images is not None, 'SyncBatchNorm: functions.sync_bn_begin(n_images) must open the pass (YoloXDetector.forward_detect does)'
         _allreduce_stats(block)
     out, off = [], 0
-    for (mod, x, conv_w, bn_w, bn_b, stride), z in zip(members, zs):
+    for (mod, x, conv_w, bn_w, bn_b, stride), z, R in zip(members, zs, reps):
         N = conv_w.shape[0]
         rows = z.numel() // N
         count = rows // z.shape[0] if sync else rows            # SyncBN: rows per image; the kernels multiply by ``images``

@@ -337,7 +337,16 @@ def stem_conv_wgrad(dy, x_nchw, dw, padded_hw, stride, pad):
                                      padded_hw[0], padded_hw[1], N, ks, stride, pad, _stream()), 'stem_conv_wgrad')
 
 
-STAT_REPLICAS = 32          # copies of the BatchNorm (sum, sumsq) accumulators a conv epilogue spreads its atomics over
+STAT_REPLICAS = 32          # most copies of the BatchNorm (sum, sumsq) accumulators a conv epilogue spreads its atomics over
+
+
+def stat_replicas(rows: int) -> int:
+    """Replica count for a conv with ``rows`` output pixels: one per ~1280 rows (80 wave tiles), a power of two in [1, 32] -- the
+    consumer (bn_silu_fwd) folds the replicas in every workgroup, so small layers should not carry 32 of them."""
+    r = 1
+    while r < STAT_REPLICAS and r * 1280 < rows:
+        r *= 2
+    return r
 
 
 def conv_nhwc_fwd(x, w, bias=None, stride=1, colstats=None, bn=None, bn_eps=1e-5):

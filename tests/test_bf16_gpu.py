@@ -59,6 +59,38 @@ def test_convlstm_bf16(bf16_ops, M, C, state):
     tk.test_convlstm(bf16_ops, M, C, state)
 
 
+@pytest.mark.parametrize('B,H,W,Cin,N', [(8, 32, 40, 96, 96),      # head / PAFPN level 0: 4 rows x 40 pixels per workgroup
+                                         (4, 16, 20, 96, 96),      # level 1: 8 rows x 20
+                                         (3, 8, 10, 192, 192),     # level 2: one workgroup per image and 96-channel slab
+                                         (2, 16, 20, 192, 192),    # LDS-limited row count
+                                         (2, 32, 40, 48, 48), (2, 9, 12, 48, 96), (1, 5, 7, 96, 48), (2, 24, 80, 96, 96)])
+def test_conv3x3_direct_bf16(bf16_ops, B, H, W, Cin, N):
+    """The direct 3x3 / stride-1 convolution of csrc/k_conv3.hip (forward with BatchNorm statistics, and as dgrad) against
+    torch's fp32 conv2d on the CPU; ragged last row block (H = 9, 5), widths that are no multiple of 16."""
+    import torch.nn.functional as F
+    ops = bf16_ops
+    x = tk.rnd((B, Cin, H, W), 1).requires_grad_(True)
+    w = tk.rnd((N, Cin, 3, 3), 2, 0.05).requires_grad_(True)
+    ref = F.conv2d(x, w, None, padding=1)
+    dy = tk.rnd(ref.shape, 3)
+    ref.backward(dy)
+    xn = x.detach().permute(0, 2, 3, 1).contiguous().to(tk.DEV)
+    R = 8
+    cs = torch.zeros((R, 2, N), dtype=torch.float64, device=tk.DEV)
+    y = ops.conv_nhwc_fwd(xn, w.detach().to(tk.DEV), None, colstats=cs)
+    tk.close(y, ref.detach().permute(0, 2, 3, 1), what='conv3x3 fwd')
+    # the statistics are sums of the kernel's own outputs
+    yd = y.double().reshape(-1, N)
+    # (fp32 partial sums of <= 12 rows per lane, double beyond)
+    assert torch.allclose(cs.sum(0)[0], yd.sum(0), rtol=1e-4, atol=1e-4 * yd.abs().sum(0).max().item())
+    assert torch.allclose(cs.sum(0)[1], (yd * yd).sum(0), rtol=1e-4)
+    dyn = dy.permute(0, 2, 3, 1).contiguous().to(tk.DEV)
+    dx = ops.conv_nhwc_dgrad(dyn, w.detach().to(tk.DEV), xn.shape)
+    tk.close(dx, x.grad.permute(0, 2, 3, 1), what='conv3x3 dgrad')
+    dx2 = ops.conv_nhwc_dgrad(dyn, w.detach().to(tk.DEV), xn.shape, out=dx.clone(), accumulate=True)
+    tk.close(dx2, 2 * x.grad.permute(0, 2, 3, 1), what='conv3x3 dgrad accumulate')
+
+
 # (C = 384 runs the per-timestep kernels in either mode: covered by test_convlstm_bf16 above)
 @pytest.mark.parametrize('T,B,H,W,C,state', [(4, 1, 7, 10, 48, True), (3, 2, 8, 10, 32, False), (5, 4, 16, 40, 96, True), (3, 2, 16, 20, 192, True),
                                              (21, 2, 16, 20, 48, True), (21, 1, 8, 10, 192, True)])
@@ -158,4 +190,4 @@ def test_linear_dgrad_ln_bwd_bf16(bf16_ops, M, N, K, with_res):
 
 
 def test_conv_bn_bf16(bf16_ops):
-    tk.test_conv_bn_eval_and_train(bf16_ops)
+    tk.test_conv_bn_eval_and_train(bf16_ops, 8)
