@@ -120,7 +120,10 @@ int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bias, float*
                        int Cin, int N, int ks, int stride, int pad, float* wpack, leod_stream_t stream);
 int leod_conv_nhwc_dgrad(const float* dy, const float* w, float* dx, int accumulate, int B, int H, int W, int Cin, int N,
                          int ks, int stride, int pad, float* wpack, leod_stream_t stream);
-int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, float* dbias, int B, int H, int W, int Cin, int N,
+/* dw[N,Cin,ks,ks] += weight gradient (dbias optional).  ws: scratch of leod_conv_nhwc_wgrad_workspace_floats(...) floats (may be
+ * NULL when that is 0; with a workspace the 3x3 / stride-1 gradients of the bf16 mode are reduced without atomics). */
+long leod_conv_nhwc_wgrad_workspace_floats(int B, int H, int W, int Cin, int N, int ks, int stride, int pad, int has_bias);
+int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, float* dbias, float* ws, int B, int H, int W, int Cin, int N,
                          int ks, int stride, int pad, leod_stream_t stream);
 
 /* BatchNorm2d (batch statistics) + SiLU on rows and its autograd (network_blocks.py:47-51).  `count` = rows that

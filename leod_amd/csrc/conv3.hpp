@@ -7,3 +7,6 @@ bool conv3s1_supported(int H, int W, int Cin, int Cout);
 size_t conv3s1_pack_bytes(int Cin, int Cout);
 int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, int stat_rep, int accumulate, int B, int H, int W,
                    int Cin, int Cout, int transposed, void* wpack, hipStream_t stream);
+bool conv3s1_wgrad_supported(int H, int W, int Cin, int Cout);
+size_t conv3s1_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout);
+int conv3s1_wgrad_launch(const float* dy, const float* x, float* dW, float* ws, int B, int H, int W, int Cin, int Cout, hipStream_t stream);

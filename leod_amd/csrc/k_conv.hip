@@ -340,7 +340,14 @@ static int wgrad_any(const float* dy, const XL& xl, float* dW, long ldw, float* 
 }
 
 // dw[N,Cin,ks,ks] += dy^T im2col(x) ; dbias[N] += colsum(dy)
-LEOD_API int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, float* dbias, int B, int H, int W, int Cin,
+// floats of workspace leod_conv_nhwc_wgrad wants for this shape in the current precision mode (0: none)
+LEOD_API long leod_conv_nhwc_wgrad_workspace_floats(int B, int H, int W, int Cin, int N, int ks, int stride, int pad, int has_bias) {
+    if (ks == 3 && stride == 1 && pad == 1 && !has_bias && conv3s1_wgrad_supported(H, W, Cin, N))
+        return (long)conv3s1_wgrad_workspace_floats(B, H, W, Cin, N);
+    return 0;
+}
+
+LEOD_API int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, float* dbias, float* ws, int B, int H, int W, int Cin,
                                   int N, int ks, int stride, int pad, hipStream_t stream) {
     if (!dy || !x || !dw) return LEOD_ERR_ARG;
     const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
@@ -349,6 +356,8 @@ LEOD_API int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, fl
         XRows xl{x, (long)Cin, nullptr, nullptr, nullptr, nullptr, 0, 0};
         return wgrad_any(dy, xl, dw, (long)Cin, dbias, M, N, K, stream);
     }
+    if (ks == 3 && stride == 1 && pad == 1 && !dbias && ws && conv3s1_wgrad_supported(H, W, Cin, N))
+        return conv3s1_wgrad_launch(dy, x, dw, ws, B, H, W, Cin, N, stream);
     XConvNHWC xl{x, H, W, Cin, Ho, Wo, ks, stride, pad};
     return wgrad_any(dy, xl, dw, (long)K, dbias, M, N, K, stream);
 }

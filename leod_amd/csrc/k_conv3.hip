@@ -215,6 +215,142 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same convolution: dW[n][c][tap] += sum_p dy[p][n] x[p + off(tap)][c].
+// A workgroup stages the bf16 input halo and the bf16 dy rows of a region once and contracts over the region's pixels for the three
+// taps of one kernel row (blockIdx.y): both MFMA operands are COLUMNS of pixel-major LDS tiles, read with ds_read_b64_tr_b16 (the
+// lane supplies the address of "its" pixel row, the hardware transposes 4 pixels x 16 channels per 16-lane group); the dy
+// fragments are shared by the three taps.  Each wave keeps a 3 x 3 block of 16 x 16 tiles per tap (27 accumulator tiles), the
+// workgroup walks over regions r, r + gridDim.x, ... and writes its partial sums with plain stores to part[worker][tap][n][c]
+// (c contiguous); conv3_wgrad_reduce_kernel adds the workers' partials into dW[n][c][tap].  No atomics: scattered 4-byte atomics into
+// the [n][c][3][3] layout ran at ~28 per ns (the atomic version of this kernel took 200 us, 94 us of it for 2.6 M atomics), and the
+// result is bitwise reproducible.
+// NA = N / 16, NB = Cin / 16 (both even: the 4 waves split the (n, c) tile grid 2 x 2).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NA, int NB>
+__global__ __launch_bounds__(256) void conv3s1_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
+                                                             int B, int H, int W, int RH, int nregions) {
+    static_assert(NA % 2 == 0 && NB % 2 == 0, "the 4 waves split the tile grid 2 x 2");
+    constexpr int N = 16 * NA, CI = 16 * NB, LDX = CI + 16, LDY = N + 16, TA = NA / 2, TB = NB / 2, MAXS = 5;
+    typedef __attribute__((address_space(3))) s4 lds_s4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int wa = wave & 1, wb = wave >> 1;
+    const int g = blockIdx.y;                                     // kernel row: taps 3g .. 3g + 2
+    const int WH = W + 2;
+    bf16_t* halo = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* sdy = halo + (((RH + 2) * WH * LDX + 7) & ~7);
+    f4 acc[3][TA][TB];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int a = 0; a < TA; ++a)
+#pragma unroll
+            for (int b = 0; b < TB; ++b) acc[j][a][b] = zero4();
+    const int rblocks = (H + RH - 1) / RH;
+    for (int reg = blockIdx.x; reg < nregions; reg += gridDim.x) {
+        const int b = reg / rblocks, y0 = (reg - b * rblocks) * RH;
+        const int rows = min(RH, H - y0);
+        const int P = rows * W, P32 = (P + 31) & ~31, steps = P32 >> 5;
+        // ---- stage the input halo and the dy rows (bf16); all loads of a batch before the first LDS store -----------------------
+        const int hslots = (rows + 2) * WH * (CI / 4);
+        const float* xb = x + (long)b * H * W * CI;
+        constexpr int HB = 12;
+        for (int e0 = tid; e0 < hslots; e0 += 256 * HB) {
+            f4 hv[HB]; int ho[HB];
+#pragma unroll
+            for (int j = 0; j < HB; ++j) {
+                const int e = e0 + 256 * j;
+                const int hp = e / (CI / 4), c4 = (e - hp * (CI / 4)) * 4;
+                const int hy = hp / WH, hx = hp - hy * WH;
+                const int iy = y0 - 1 + hy, ix = hx - 1;
+                ho[j] = e < hslots ? hp * LDX + c4 : -1;
+                hv[j] = zero4();
+                if (e < hslots && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) hv[j] = ld4(xb + ((long)iy * W + ix) * CI + c4);
+            }
+#pragma unroll
+            for (int j = 0; j < HB; ++j)
+                if (ho[j] >= 0) *reinterpret_cast<s4*>(halo + ho[j]) = pack_bf16(hv[j]);
+        }
+        const int dslots = P32 * (N / 4);
+        const float* dyb = dy + ((long)(b * H + y0) * W) * N;
+        for (int e0 = tid; e0 < dslots; e0 += 256 * HB) {
+            f4 hv[HB];
+#pragma unroll
+            for (int j = 0; j < HB; ++j) {
+                const int e = e0 + 256 * j;
+                const int p = e / (N / 4);
+                hv[j] = (e < dslots && p < P) ? ld4(dyb + (long)e * 4) : zero4();       // rows P .. P32 - 1: zeros (contribute nothing)
+            }
+#pragma unroll
+            for (int j = 0; j < HB; ++j) {
+                const int e = e0 + 256 * j;
+                if (e < dslots) { const int p = e / (N / 4), c4 = (e - p * (N / 4)) * 4; *reinterpret_cast<s4*>(sdy + p * LDY + c4) = pack_bf16(hv[j]); }
+            }
+        }
+        __syncthreads();
+        // ---- contraction over the region's pixels, 32 per MFMA ----------------------------------------------------------------------
+        for (int s = 0; s < steps; ++s) {
+            // the two pixel rows this lane addresses in a transpose read: p = 32 s + 8 q + (i >> 2) (+ 4)
+            int hx0[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int p = 32 * s + 8 * q + 4 * h + (i >> 2);
+                if (p >= P) p = P - 1;                                               // dy is zero there: any valid pixel will do
+                const int py = p / W, px = p - py * W;
+                hx0[h] = ((py + g) * WH + px) * LDX + 4 * (i & 3);                   // tap (g, 0); taps (g, 1), (g, 2): + LDX, + 2 LDX
+            }
+            const bf16_t* pdy = sdy + (32 * s + 8 * q + (i >> 2)) * LDY + 4 * (i & 3);
+            s8v av[TA];
+#pragma unroll
+            for (int a = 0; a < TA; ++a) {
+                const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(pdy + 16 * (TA * wa + a)));
+                const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(pdy + 4 * LDY + 16 * (TA * wa + a)));
+                av[a] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+#pragma unroll
+                for (int bb = 0; bb < TB; ++bb) {
+                    const int co = j * LDX + 16 * (TB * wb + bb);
+                    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(halo + hx0[0] + co));
+                    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(halo + hx0[1] + co));
+                    const s8v bv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int a = 0; a < TA; ++a) acc[j][a][bb] = mfma32_bf16(av[a], bv, acc[j][a][bb]);
+                }
+            }
+        }
+        __syncthreads();                                                             // the tiles are restaged for the next region
+    }
+    // ---- part[worker][3g + j][n][c] = acc: row 4q + r of tile (a, b) is output channel n, column i is input channel c ----------------
+    float* pw = part + (long)blockIdx.x * 9 * N * CI;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int a = 0; a < TA; ++a)
+#pragma unroll
+            for (int bb = 0; bb < TB; ++bb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = 16 * (TA * wa + a) + 4 * q + r, c = 16 * (TB * wb + bb) + i;
+                    pw[((long)(3 * g + j) * N + n) * CI + c] = acc[j][a][bb][r];
+                }
+}
+
+// dW[n][c][tap] += sum over workers of part[worker][tap][n][c]
+__global__ __launch_bounds__(256) void conv3_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int workers, int N, int CI) {
+    const int total = 9 * N * CI;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int w = 0; w < workers; ++w) s += part[(long)w * total + e];             // 8 independent loads in flight per thread
+    const int c = e % CI, r = e / CI; const int n = r % N, tap = r / N;
+    dW[((long)n * CI + c) * 9 + tap] += s;
+}
+
 static inline size_t conv3_smem(int RH, int W, int Cin, int nto) {
     const int LDP = Cin + (Cin % 32 == 0 ? 16 : 8);
     const size_t halo = (((size_t)(RH + 2) * (W + 2) * LDP + 7) & ~(size_t)7) * 2;
@@ -268,4 +404,48 @@ int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, i
 #undef C3_CASE
 #undef C3_CASE2
     return LEOD_ERR_UNSUPPORTED;
+}
+
+bool conv3s1_wgrad_supported(int H, int W, int Cin, int Cout) {
+    static const int on = getenv("LEOD_CONV3_DIRECT") ? atoi(getenv("LEOD_CONV3_DIRECT")) : 1;
+    if (!on || leod_precision() != 1) return false;
+    return W <= 160 && W >= 4 && Cin == 96 && Cout == 96;
+}
+
+static inline int conv3_wgrad_workers(int B, int H, int W, int Cin, int Cout, int* rh_out) {
+    const int LDX = Cin + 16, LDY = Cout + 16;
+    int RH = max(1, min(H, 160 / W));
+    while (RH > 0) {
+        const size_t halo = (((size_t)(RH + 2) * (W + 2) * LDX + 7) & ~(size_t)7) * 2;
+        const size_t sdy = (size_t)((RH * W + 31) & ~31) * LDY * 2;
+        if (halo + sdy <= 160 * 1024) break;
+        --RH;
+    }
+    if (rh_out) *rh_out = RH;
+    if (RH <= 0) return 0;
+    static const int cap = getenv("LEOD_CONV3_WORKERS") ? atoi(getenv("LEOD_CONV3_WORKERS")) : 64;      // measured: 64 -> 42 us, 85 -> 47, 128 -> 51 (level-0 head conv)
+    return min(B * cdiv(H, RH), cap);      // region workers per kernel row: each walks over nregions / workers regions
+}
+
+// floats of scratch conv3s1_wgrad_launch needs (the workers' partial sums)
+size_t conv3s1_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout) {
+    return (size_t)conv3_wgrad_workers(B, H, W, Cin, Cout, nullptr) * 9 * Cin * Cout;
+}
+
+// dW[Cout][Cin][3][3] += wgrad of y = conv3x3(x) for dy [B,H,W,Cout], x [B,H,W,Cin]; ws: conv3s1_wgrad_workspace_floats floats
+int conv3s1_wgrad_launch(const float* dy, const float* x, float* dW, float* ws, int B, int H, int W, int Cin, int Cout, hipStream_t stream) {
+    int RH = 0;
+    const int workers = conv3_wgrad_workers(B, H, W, Cin, Cout, &RH);
+    if (workers <= 0 || !ws) return LEOD_ERR_UNSUPPORTED;
+    const int LDX = Cin + 16, LDY = Cout + 16;
+    const size_t smem = (((size_t)(RH + 2) * (W + 2) * LDX + 7) & ~(size_t)7) * 2 + (size_t)((RH * W + 31) & ~31) * LDY * 2;
+    const int nregions = B * cdiv(H, RH);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3s1_wgrad_kernel<6, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3s1_wgrad_kernel<6, 6>), dim3(workers, 3), dim3(256), smem, stream, dy, x, ws, B, H, W, RH, nregions);
+    hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(cdiv(9 * Cin * Cout, 256)), dim3(256), 0, stream, ws, dW, workers, Cout, Cin);
+    return leod_launch_status();
 }

@@ -395,7 +395,9 @@ def conv_nhwc_wgrad(dy, x, dw, dbias=None, stride=1):
     B, H, W, Cin = x.shape
     N, ks = dw.shape[0], dw.shape[-1]
     pad = (ks - 1) // 2
-    check(_l().leod_conv_nhwc_wgrad(_p(dy), _p(x), _p(dw), _p(dbias), B, H, W, Cin, N, ks, stride, pad, _stream()),
+    nws = int(_l().leod_conv_nhwc_wgrad_workspace_floats(B, H, W, Cin, N, ks, stride, pad, 0 if dbias is None else 1))
+    ws = _empty((nws,), dy) if nws else None
+    check(_l().leod_conv_nhwc_wgrad(_p(dy), _p(x), _p(dw), _p(dbias), _p(ws), B, H, W, Cin, N, ks, stride, pad, _stream()),
           'conv_nhwc_wgrad')
 
 

@@ -63,7 +63,7 @@ def test_convlstm_bf16(bf16_ops, M, C, state):
                                          (4, 16, 20, 96, 96),      # level 1: 8 rows x 20
                                          (3, 8, 10, 192, 192),     # level 2: one workgroup per image and 96-channel slab
                                          (2, 16, 20, 192, 192),    # LDS-limited row count
-                                         (2, 32, 40, 48, 48), (2, 9, 12, 48, 96), (1, 5, 7, 96, 48), (2, 24, 80, 96, 96)])
+                                         (2, 32, 40, 48, 48), (2, 9, 12, 48, 96), (1, 5, 7, 96, 48), (2, 24, 80, 96, 96), (70, 9, 12, 96, 96), (1, 5, 7, 96, 96)])
 def test_conv3x3_direct_bf16(bf16_ops, B, H, W, Cin, N):
     """The direct 3x3 / stride-1 convolution of csrc/k_conv3.hip (forward with BatchNorm statistics, and as dgrad) against
     torch's fp32 conv2d on the CPU; ragged last row block (H = 9, 5), widths that are no multiple of 16."""
@@ -89,6 +89,12 @@ def test_conv3x3_direct_bf16(bf16_ops, B, H, W, Cin, N):
     tk.close(dx, x.grad.permute(0, 2, 3, 1), what='conv3x3 dgrad')
     dx2 = ops.conv_nhwc_dgrad(dyn, w.detach().to(tk.DEV), xn.shape, out=dx.clone(), accumulate=True)
     tk.close(dx2, 2 * x.grad.permute(0, 2, 3, 1), what='conv3x3 dgrad accumulate')
+    # weight gradient (direct kernel for 96 -> 96, the im2col kernel otherwise); it accumulates: two calls = twice the gradient
+    dw = torch.zeros_like(w.detach(), device=tk.DEV)
+    ops.conv_nhwc_wgrad(dyn, xn, dw, None)
+    tk.close(dw, w.grad, what='conv3x3 wgrad')
+    ops.conv_nhwc_wgrad(dyn, xn, dw, None)
+    tk.close(dw, 2 * w.grad, what='conv3x3 wgrad accumulates')
 
 
 # (C = 384 runs the per-timestep kernels in either mode: covered by test_convlstm_bf16 above)
