@@ -53,6 +53,19 @@ int leod_partition_attn_fwd(const float* qkv, float* out, float* lse, int B, int
 int leod_partition_attn_bwd(const float* qkv, const float* dout, const float* lse, float* dsum, float* dqkv, int B,
                             int H, int W, int C, int heads, int ph, int pw, int window, leod_stream_t stream);
 
+/* Precision mode bf16, stages 1-2 of the MLP (maxvit.py:110-118): the hidden pre-activation u = LN(x) W1^T + b1 is stored ONCE,
+ * as fp16 [M,N] (as the reference does under autocast, train.py:236-243; clamped to the fp16 range); the three consumers below
+ * apply GELU / GELU' while loading it.  leod_ln_linear_gelu16_fwd returns -3 where the row-streaming kernel does not cover (M, N, K): callers then use
+ * leod_ln_linear_fwd and its fp32 (u, gelu(u)) pair.  u16: device pointer to fp16 elements. */
+int leod_ln_linear_gelu16_fwd(const float* x, const float* ln_w, const float* ln_b, float eps, const float* W, const float* bias,
+                              void* u16, float* stats_out, int M, int N, int K, leod_stream_t stream);
+int leod_linear_lsres_gelu16_fwd(const void* u16, const float* W, const float* bias, const float* gamma, const float* res, float* out,
+                                 int M, int N, int K, leod_stream_t stream);
+int leod_linear_dgrad_gelu16(const float* dy, const float* kscale, const float* W, const void* u16, float* dx, int M, int N, int K,
+                             leod_stream_t stream);
+int leod_linear_wgrad_gelu16(const float* dy, long lddy, const void* u16, float* dW, float* dbias, int M, int N, int K,
+                             leod_stream_t stream);
+
 /* Fused ConvLSTM cell, DWSConvLSTM2d.forward with dws_conv=False (models/layers/rnn.py:37-70):
  * gates = [x|h_prev] W[4C,2C]^T + b, (f,i,o)=sigmoid, g=tanh, c=f*c_prev+i*g, h=o*tanh(c).
  * h_prev/c_prev NULL = zero state; gates_out (optional) [M,4,C] post-activation gates. */

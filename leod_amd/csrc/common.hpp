@@ -103,6 +103,31 @@ __device__ __forceinline__ s4 pack_bf16(f4 v) {             // 2 x v_cvt_pk_bf16
                    __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf2_))};
     return __builtin_bit_cast(s4, r);
 }
+// fp16 storage of the MLP hidden pre-activation (precision mode bf16, stages 1-2): the reference holds that tensor in fp16 under
+// autocast (11-bit significand: 8x less rounding noise than bf16 for a tensor that is only stored, never an MFMA operand as is);
+// values are clamped to the fp16 range so that an outlier saturates instead of becoming inf.
+typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s4 pack_h16(f4 v) {              // 2 x v_cvt_pk (round to nearest even)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(v[j], -65504.f), 65504.f);
+    const f2_ lo = {v.x, v.y}, hi = {v.z, v.w};
+    const u2_ r = {__builtin_bit_cast(unsigned, __builtin_convertvector(lo, h2_)),
+                   __builtin_bit_cast(unsigned, __builtin_convertvector(hi, h2_))};
+    return __builtin_bit_cast(s4, r);
+}
+__device__ __forceinline__ f4 unpack_h16(s4 v) {            // 4 fp16 -> 4 fp32 (exact)
+    f4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (float)__builtin_bit_cast(_Float16, (unsigned short)v[j]);
+    return o;
+}
+__device__ __forceinline__ float unpack_h16_1(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ f4 unpack_bf16(s4 v) {           // 4 bf16 -> 4 fp32 (exact)
+    f4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = __builtin_bit_cast(float, (unsigned)(unsigned short)v[j] << 16);
+    return r;
+}
 __device__ __forceinline__ f4 mfma16_bf16(s4 a, s4 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
 
 // Operand fragment of one 16-k chunk in either precision: BF = false keeps the f4 (four exact fp32 MFMAs consume it),

@@ -36,11 +36,14 @@ struct ALRows {                 // plain rows, optional LayerNorm prologue, opti
     float* stats_out;                                   // optional [M,2] (mean, rstd) written by n-block 0
     int K;                                              // row length used for the LN statistics
     const float* stats_in;                              // optional precomputed [M,2] (mean, rstd): skips the statistics passes
+    int fmt;                                            // 0: x is fp32; 1: x is an fp16 PRE-activation, A = gelu(x) (the MLP hidden of stages 1-2 is stored
+                                                        // once, as fp16, in precision mode bf16: maxvit.py:110-118 under the reference's autocast)
     struct St { const float* p; float mean, rstd; bool ok; };
     __device__ __forceinline__ int klen(const St&, int K) const { return K; }
     __device__ __forceinline__ int aux(const St&) const { return 0; }
     __device__ __forceinline__ St init(int row, int M, int lane, bool write_stats) const {
         St s; s.ok = row < M; s.p = x + (long)(s.ok ? row : M - 1) * ld; s.mean = 0.f; s.rstd = 1.f;
+        if (fmt == 1) s.p = reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(x) + (long)(s.ok ? row : M - 1) * ld);
         if (ln_w && stats_in) { s.mean = stats_in[2 * (long)(s.ok ? row : M - 1)]; s.rstd = stats_in[2 * (long)(s.ok ? row : M - 1) + 1]; }
         else if (ln_w) {
             const int q = lane >> 4;
@@ -62,6 +65,12 @@ struct ALRows {                 // plain rows, optional LayerNorm prologue, opti
     }
     __device__ __forceinline__ f4 load(const St& s, int k, int Kt) const {
         if (k >= Kt) return zero4();
+        if (fmt == 1) {
+            f4 v = unpack_h16(*reinterpret_cast<const s4*>(reinterpret_cast<const unsigned short*>(s.p) + k));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+            return s.ok ? v : zero4();
+        }
         f4 v = ld4(s.p + k);
         if (ln_w) {
             const f4 g = ld4(ln_w + k), b = ld4(ln_b + k);
@@ -955,13 +964,21 @@ static inline bool use_gemm_lds(int M, int nblocks_n) { return (long)cdiv(M, 64)
 struct XRows {                      // X(m,k) = x[m][k], optional LayerNorm with saved (mean, rstd)
     const float* x; long ld; const float* stats; const float* ln_w; const float* ln_b;
     const float* x2; long ld2; int K1;          // optional concat source for k >= K1
+    int fmt;                                    // 1: x is an fp16 pre-activation, X = gelu(x) (see ALRows::fmt)
     __device__ __forceinline__ float get(int m, int k) const {
+        if (fmt == 1) return gelu_erf(unpack_h16_1(reinterpret_cast<const unsigned short*>(x)[(long)m * ld + k]));
         if (x2 && k >= K1) return x2[(long)m * ld2 + (k - K1)];
         float v = x[(long)m * ld + k];
         if (stats) v = (v - stats[2 * (long)m]) * stats[2 * (long)m + 1] * ln_w[k] + ln_b[k];
         return v;
     }
     __device__ __forceinline__ f4 get4(int m, int k) const {      // k % 4 == 0; K1 % 4 == 0
+        if (fmt == 1) {
+            f4 v = unpack_h16(*reinterpret_cast<const s4*>(reinterpret_cast<const unsigned short*>(x) + (long)m * ld + k));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+            return v;
+        }
         if (x2 && k >= K1) return ld4(x2 + (long)m * ld2 + (k - K1));
         f4 v = ld4(x + (long)m * ld + k);
         if (stats) v = (v - stats[2 * (long)m]) * stats[2 * (long)m + 1] * ld4(ln_w + k) + ld4(ln_b + k);

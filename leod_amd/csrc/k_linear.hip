@@ -45,7 +45,9 @@ static inline EpStore ep_store(float* out, long ld, int N) {
 // BF (precision mode bf16): the resident weights are rounded to bf16 ONCE in the prologue (rows of K + 8 bf16: a 4 * odd dword
 // stride keeps the ds_read_b64 fragment reads conflict-free), the streamed A fragments are packed in registers, and one
 // v_mfma_f32_16x16x16_bf16 replaces the four fp32 MFMAs of a 16-k chunk.
-template <int KC, int NTT, bool LN, bool ACT, int DG = 0, bool BF = false>
+// UF (precision mode bf16, stages 1-2 of the MLP): the pre-activation u is kept ONCE, as fp16 -- ACT stores only fp16(u) through out2
+// (no fp32 u, no gelu(u) copy: 2 instead of 8 bytes per hidden element; its consumers apply GELU / GELU' on load), DG = 2 reads it back.
+template <int KC, int NTT, bool LN, bool ACT, int DG = 0, bool BF = false, bool UF = false>
 __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream48_kernel(const float* __restrict__ x, long ldx, float* __restrict__ stats_out,
                                                              const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
                                                              const float* __restrict__ W, const float* __restrict__ bias,
@@ -54,8 +56,9 @@ __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream4
     const int n0 = blockIdx.y * N;                              // first column of this slab
     W += DG ? (long)n0 : (long)n0 * K;
     if (bias) bias += n0;
-    out += n0;
-    if (ACT || DG == 2) out2 += n0;
+    if (!(ACT && UF)) out += n0;
+    unsigned short* u16 = reinterpret_cast<unsigned short*>(out2) + n0;      // UF: the fp16 pre-activation [M][Ntot]
+    if ((ACT || DG == 2) && !UF) out2 += n0;
     __shared__ __attribute__((aligned(16))) float sW[BF ? (N * LD) / 2 : N * LD];
     __shared__ __attribute__((aligned(16))) float sO[4][16 * LDO];
     unsigned short* sWh = reinterpret_cast<unsigned short*>(sW);        // BF: [N][LD] bf16
@@ -145,11 +148,13 @@ __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream4
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
                         const long row = FULL ? row0 + q + 4 * p : min(row0 + q + 4 * p, (long)M - 1);
-                        ug[4 * g + p] = ld4(out2 + row * Ntot + 64 * g + 4 * i);
+                        if constexpr (UF) ug[4 * g + p] = unpack_h16(*reinterpret_cast<const s4*>(u16 + row * Ntot + 64 * g + 4 * i));
+                        else ug[4 * g + p] = ld4(out2 + row * Ntot + 64 * g + 4 * i);
                     }
                 } else {
                     const long row = FULL ? row0 + (lane >> 2) : min(row0 + (lane >> 2), (long)M - 1);
-                    ug[4 * g] = ld4(out2 + row * Ntot + 64 * g + 4 * (lane & 3));
+                    if constexpr (UF) ug[4 * g] = unpack_h16(*reinterpret_cast<const s4*>(u16 + row * Ntot + 64 * g + 4 * (lane & 3)));
+                    else ug[4 * g] = ld4(out2 + row * Ntot + 64 * g + 4 * (lane & 3));
                 }
             }
         }
@@ -181,6 +186,7 @@ __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream4
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(u[j]);
             }
+            if constexpr (ACT && UF) { *reinterpret_cast<s4*>(u16 + row * Ntot + n) = pack_h16(v); return; }
             *reinterpret_cast<f4*>(out + row * Ntot + n) = v;
             if (ACT) {
                 f4 ge;
@@ -248,7 +254,8 @@ __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream4
 // One wave = one 16-row tile; 48 output columns = 12 float4 per row = 3 per lane (idx = 64 p + lane -> row idx / 12,
 // column idx % 12); the residual slice of the tile is loaded before its MFMAs.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int KC, int MODE, bool BF = false>
+// AF (MODE 0, precision mode bf16): x is the fp16 pre-activation of the MLP hidden, A = gelu(x) evaluated on the fragments.
+template <int KC, int MODE, bool BF = false, bool AF = false>
 __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                                   const float* __restrict__ bias, const float* __restrict__ gamma,
                                                                   const float* __restrict__ res, float* __restrict__ out, int M,
@@ -298,12 +305,19 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
     __syncthreads();
     const int stride = gridDim.x * 4;
     float* so = sO[wave];
-    struct Frag { f4 a[KC]; };
+    typedef typename std::conditional<AF, s4, f4>::type AFrag;
+    struct Frag { AFrag a[KC]; };
     auto load = [&](Frag& f, int tile) {
         const long row = min((long)tile * 16 + i, (long)M - 1);
-        const float* p = x + row * K + 4 * q;
+        if constexpr (AF) {
+            const unsigned short* p = reinterpret_cast<const unsigned short*>(x) + row * K + 4 * q;
 #pragma unroll
-        for (int c = 0; c < KC; ++c) f.a[c] = ld4(p + 16 * c);
+            for (int c = 0; c < KC; ++c) f.a[c] = *reinterpret_cast<const s4*>(p + 16 * c);
+        } else {
+            const float* p = x + row * K + 4 * q;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) f.a[c] = ld4(p + 16 * c);
+        }
     };
     auto compute = [&](const Frag& f, int tile, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
@@ -331,11 +345,17 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
             if constexpr (BF) {
-                const s4 pa = pack_bf16(f.a[c]);
+                s4 pa;
+                if constexpr (AF) {
+                    f4 u = unpack_h16(f.a[c]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) u[j] = gelu_erf(u[j]);
+                    pa = pack_bf16(u);
+                } else pa = pack_bf16(f.a[c]);
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
                     acc[t] = mfma16_bf16(pa, *reinterpret_cast<const s4*>(&sWh[(16 * t + i) * LD + 16 * c + 4 * q]), acc[t]);
-            } else {
+            } else if constexpr (!AF) {
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const f4 b = *reinterpret_cast<const f4*>(&sW[(16 * t + i) * LD + 16 * c + 4 * q]);
@@ -598,4 +618,85 @@ LEOD_API int leod_linear_dgrad_lnbwd(const float* dy, const float* W, const floa
     if (N == 192) hipLaunchKernelGGL((rowstream_narrow_kernel<12, 2>), dim3(grid), dim3(256), 0, stream, dy, W, nullptr, ln_w, dres, dx, M, x, stats, dgamma, dbeta);
     else hipLaunchKernelGGL((rowstream_narrow_kernel<9, 2>), dim3(grid), dim3(256), 0, stream, dy, W, nullptr, ln_w, dres, dx, M, x, stats, dgamma, dbeta);
     return leod_launch_status();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Precision mode bf16, stages 1-2: the MLP hidden u = LN(x) W1^T + b1 is stored ONCE as fp16 (as the reference does under
+// autocast); fc2, the dgrad through GELU and the fc2 weight gradient evaluate GELU / GELU' on load.  8 -> 2 bytes per hidden
+// element in the forward pass, 4 -> 2 on each of its three reads.
+// ---------------------------------------------------------------------------------------------------------------------
+// u16[M,N] = fp16(LN(x) W^T + bias); stats_out [M,2].  LEOD_ERR_UNSUPPORTED unless the row-streaming kernel covers (M, N, K)
+// in precision mode bf16 -- the caller then uses leod_ln_linear_fwd with its fp32 (u, gelu(u)) pair.
+LEOD_API int leod_ln_linear_gelu16_fwd(const float* x, const float* ln_w, const float* ln_b, float eps, const float* W, const float* bias,
+                                       void* u16, float* stats_out, int M, int N, int K, hipStream_t stream) {
+    if (!x || !W || !u16 || !ln_w || !stats_out) return LEOD_ERR_ARG;
+    static const int on = getenv("LEOD_U16") ? atoi(getenv("LEOD_U16")) : 1;
+    const int slab = rowstream_slab(M, N, K);
+    if (!on || leod_precision() != 1 || !slab) return LEOD_ERR_UNSUPPORTED;
+    const int slabs = N / (16 * slab);
+#define U16_CASE(KCV, NTTV)                                                                                                          \
+    if (K == 16 * KCV && slab == NTTV) {                                                                                             \
+        const int per_cu = (KCV == 3 && NTTV <= 9) ? 3 : 2;                                                                          \
+        const int gx = min(cdiv(cdiv(M, 16), 4), max(8, (256 * per_cu / slabs) & ~7));                                               \
+        hipLaunchKernelGGL((rowstream48_kernel<KCV, NTTV, true, true, 0, true, true>), dim3(gx, slabs), dim3(256), 0, stream, x, (long)K,   \
+                           stats_out, ln_w, ln_b, eps, W, bias, nullptr, reinterpret_cast<float*>(u16), M, N);                       \
+        return leod_launch_status();                                                                                                 \
+    }
+    U16_CASE(3, 12) U16_CASE(6, 8) U16_CASE(4, 8)
+#undef U16_CASE
+    return LEOD_ERR_UNSUPPORTED;
+}
+
+// out = res + gamma * (gelu(u16) W^T + bias)     (fc2 + LayerScale + residual on the fp16 pre-activation)
+LEOD_API int leod_linear_lsres_gelu16_fwd(const void* u16, const float* W, const float* bias, const float* gamma, const float* res,
+                                          float* out, int M, int N, int K, hipStream_t stream) {
+    if (!u16 || !W || !res || !out || (K & 3) || leod_precision() != 1) return LEOD_ERR_ARG;
+    const float* a = reinterpret_cast<const float*>(u16);
+    if (use_rowstream_narrow(M, K, N)) {
+        const int grid = min(cdiv(cdiv(M, 16), 4), 256 * 2);
+        if (K == 192) hipLaunchKernelGGL((rowstream_narrow_kernel<12, 0, true, true>), dim3(grid), dim3(256), 0, stream, a, W, bias, gamma, res, out, M);
+        else hipLaunchKernelGGL((rowstream_narrow_kernel<9, 0, true, true>), dim3(grid), dim3(256), 0, stream, a, W, bias, gamma, res, out, M);
+        return leod_launch_status();
+    }
+    ALRows al{}; al.x = a; al.ld = K; al.K = K; al.fmt = 1;
+    EpLsRes ep{out, nullptr, res, bias, gamma, (long)N, N};
+    const int nt = pick_nt(N);
+    int rc = LEOD_OK;
+    if (use_gemm_lds(M, cdiv(N, 16 * nt))) {
+        DISPATCH_NT(nt, { BLRows bl{W, (long)K, N, NT}; rc = launch_gemm_lds<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
+        return rc;
+    }
+    DISPATCH_NT(nt, { BLRows bl{W, (long)K, N, NT}; rc = launch_gemm16<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
+    return rc;
+}
+
+// du[M,K] = ((dy[M,N] * kscale[N]) @ W[N,K]) * gelu'(u16[M,K])      (dgrad of fc2 through GELU, fp16 pre-activation)
+LEOD_API int leod_linear_dgrad_gelu16(const float* dy, const float* kscale, const float* W, const void* u16, float* dx,
+                                      int M, int N, int K, hipStream_t stream) {
+    if (!dy || !W || !u16 || !dx || leod_precision() != 1) return LEOD_ERR_ARG;
+    const int slab = rowstream_slab(M, K, N);
+    if (!slab) return LEOD_ERR_UNSUPPORTED;
+    const int slabs = K / (16 * slab);
+    const int gx = min(cdiv(cdiv(M, 16), 4), max(8, (256 * 2 / slabs) & ~7));
+    float* aux = reinterpret_cast<float*>(const_cast<void*>(u16));
+#define DG16_CASE(KCV, NTTV)                                                                                                         \
+    if (N == 16 * KCV && slab == NTTV) {                                                                                             \
+        hipLaunchKernelGGL((rowstream48_kernel<KCV, NTTV, false, false, 2, true, true>), dim3(gx, slabs), dim3(256), 0, stream, dy, (long)N, \
+                           nullptr, kscale, nullptr, 0.f, W, nullptr, dx, aux, M, K);                                                \
+        return leod_launch_status();                                                                                                 \
+    }
+    DG16_CASE(3, 12) DG16_CASE(6, 8) DG16_CASE(4, 8)
+#undef DG16_CASE
+    return LEOD_ERR_UNSUPPORTED;
+}
+
+// dW[N,K] += dy[M,N]^T @ gelu(u16[M,K]) ; dbias[N] += colsum(dy)
+LEOD_API int leod_linear_wgrad_gelu16(const float* dy, long lddy, const void* u16, float* dW, float* dbias, int M, int N, int K,
+                                      hipStream_t stream) {
+    if (!dy || !u16 || !dW) return LEOD_ERR_ARG;
+    XRows xl{reinterpret_cast<const float*>(u16), (long)K, nullptr, nullptr, nullptr, nullptr, 0, 0, 1};
+    if (use_wgradw(M)) return launch_wgradw(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);
+    if (N % 48 == 0 && K % 48 == 0) return launch_wgrad16<3, 3>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);
+    return launch_wgrad16<4, 4>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);
 }

@@ -189,11 +189,13 @@ class AttnBlockFn(Function):
         o, lse = ops.partition_attn_fwd(qkv, heads, part, window, want_lse=need)
         # the pre-LayerScale outputs are NOT stored: dgamma is recovered from the un-scaled weight gradient in backward
         y, _ = ops.linear_lsres_fwd(o, proj_w, proj_b, g1, x, want_t=False)
-        u, h, st2 = ops.ln_linear_fwd(y, n2w, n2b, fc1_w, fc1_b, want_act=True, want_stats=need)
-        z, _ = ops.linear_lsres_fwd(h, fc2_w, fc2_b, g2, y, want_t=False)
+        # precision mode bf16, stages 1-2: u comes back as ONE fp16 tensor (h is None) and fc2 applies GELU while loading it
+        u, h, st2 = ops.ln_linear_fwd(y, n2w, n2b, fc1_w, fc1_b, want_act=True, want_stats=True)
+        z, _ = ops.linear_lsres_fwd(h if h is not None else u, fc2_w, fc2_b, g2, y, want_t=False)
         if need:
             ctx.mod = mod
-            ctx.save_for_backward(x, qkv, st1, o, lse, y, u, h, st2, *params)
+            ctx.u16 = h is None
+            ctx.save_for_backward(x, qkv, st1, o, lse, y, u, u if h is None else h, st2, *params)
         return z
 
     @staticmethod

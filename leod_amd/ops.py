@@ -93,12 +93,22 @@ def _empty(shape, like: torch.Tensor, dtype=F32):
 # backbone pieces
 # ---------------------------------------------------------------------------------------------------
 def ln_linear_fwd(x, ln_w, ln_b, W, bias, want_act=False, want_stats=False, eps=1e-5):
-    """x [.., K] -> out [.., N] = LN(x) W^T + b ; optional gelu(out), LN stats [M,2]."""
+    """x [.., K] -> out [.., N] = LN(x) W^T + b ; optional gelu(out), LN stats [M,2].
+    With want_act in precision mode bf16 and a shape the row-streaming kernel covers (RVT stages 1-2) the result is
+    (u as torch.float16, None, stats): pass that u to linear_lsres_fwd / linear_dgrad(aux_u=) / linear_wgrad(x=), which apply GELU."""
     for t, n in ((x, 'x'), (ln_w, 'ln_w'), (ln_b, 'ln_b'), (W, 'W'), (bias, 'bias')):
         _ck(t, name=n)
     K = x.shape[-1]
     N = W.shape[0]
     M = x.numel() // K
+    if want_act and want_stats and ln_w is not None and get_precision() == 'bf16':
+        # precision mode bf16, stages 1-2: the hidden pre-activation is stored once, as fp16 (the reference's autocast dtype); consumers apply GELU on load
+        u16 = torch.empty(x.shape[:-1] + (N,), dtype=torch.float16, device=x.device)
+        stats = _empty((M, 2), x)
+        rc = _l().leod_ln_linear_gelu16_fwd(_p(x), _p(ln_w), _p(ln_b), eps, _p(W), _p(bias), _p(u16), _p(stats), M, N, K, _stream())
+        if rc != -3:
+            check(rc, 'ln_linear_gelu16_fwd')
+            return u16, None, stats
     out = _empty(x.shape[:-1] + (N,), x)
     act = _empty(out.shape, x) if want_act else None
     # always hand the kernel a statistics buffer: the LDS-staged GEMM reads precomputed (mean, rstd) from it
@@ -110,11 +120,20 @@ def ln_linear_fwd(x, ln_w, ln_b, W, bias, want_act=False, want_stats=False, eps=
 
 def linear_lsres_fwd(a, W, bias, gamma, res, want_t=True):
     """out = res + gamma * (a W^T + b); also returns t = a W^T + b when want_t."""
-    for t, n in ((a, 'a'), (W, 'W'), (bias, 'bias'), (gamma, 'gamma'), (res, 'res')):
+    for t, n in ((W, 'W'), (bias, 'bias'), (gamma, 'gamma'), (res, 'res')):
         _ck(t, name=n)
     K = a.shape[-1]
     N = W.shape[0]
     M = a.numel() // K
+    if a.dtype is torch.float16:                             # a = fp16 pre-activation: out = res + gamma * (gelu(a) W^T + b)
+        _ck(a, torch.float16, 'a')
+        if want_t:
+            raise LeodHipError('linear_lsres_fwd: the fp16 pre-activation path does not return t')
+        out = _empty(res.shape, res)
+        check(_l().leod_linear_lsres_gelu16_fwd(_p(a), _p(W), _p(bias), _p(gamma), _p(res), _p(out), M, N, K, _stream()),
+              'linear_lsres_gelu16_fwd')
+        return out, None
+    _ck(a, name='a')
     out = _empty(res.shape, a)
     tout = _empty(res.shape, a) if want_t else None
     check(_l().leod_linear_lsres_fwd(_p(a), _p(W), _p(bias), _p(gamma), _p(res), _p(out), _p(tout), M, N, K,
@@ -210,10 +229,18 @@ def convlstm_seq_bwd(dh_seq, dc_last, gates, cbuf, W, dgates_out, dh0=None, dc0=
 
 def linear_dgrad(dy, W, kscale=None, aux_u=None, colsum=None, out=None, accumulate=False, split=0, out2=None):
     """dx = (dy * kscale) @ W  with W [N,K]; see leod_linear_dgrad."""
-    for t, n in ((dy, 'dy'), (W, 'W'), (kscale, 'kscale'), (aux_u, 'aux_u'), (colsum, 'colsum'), (out, 'out'), (out2, 'out2')):
+    for t, n in ((dy, 'dy'), (W, 'W'), (kscale, 'kscale'), (colsum, 'colsum'), (out, 'out'), (out2, 'out2')):
         _ck(t, name=n)
     N, K = W.shape[0], W.shape[1] if W.dim() == 2 else W.numel() // W.shape[0]
     M = dy.numel() // N
+    if aux_u is not None and aux_u.dtype is torch.float16:    # through GELU on the fp16 pre-activation (stages 1-2, bf16 mode)
+        _ck(aux_u, torch.float16, 'aux_u')
+        if split or colsum is not None or accumulate or out is not None:
+            raise LeodHipError('linear_dgrad: unsupported option with an fp16 pre-activation')
+        out = _empty(dy.shape[:-1] + (K,), dy)
+        check(_l().leod_linear_dgrad_gelu16(_p(dy), _p(kscale), _p(W), _p(aux_u), _p(out), M, N, K, _stream()), 'linear_dgrad_gelu16')
+        return out
+    _ck(aux_u, name='aux_u')
     if split:
         if out is None:
             out = _empty(dy.shape[:-1] + (split,), dy)
@@ -231,12 +258,22 @@ def linear_dgrad(dy, W, kscale=None, aux_u=None, colsum=None, out=None, accumula
 
 def linear_wgrad(dy, x, dW, dbias=None, stats=None, ln_w=None, ln_b=None, x2=None):
     """dW += dy^T X ; dbias += colsum(dy).  X = x | LN(x) | [x|x2]."""
-    for t, n in ((dy, 'dy'), (x, 'x'), (dW, 'dW'), (dbias, 'dbias'), (stats, 'stats'), (ln_w, 'ln_w'), (ln_b, 'ln_b'), (x2, 'x2')):
+    for t, n in ((dy, 'dy'), (dW, 'dW'), (dbias, 'dbias'), (stats, 'stats'), (ln_w, 'ln_w'), (ln_b, 'ln_b'), (x2, 'x2')):
         _ck(t, name=n)
     N = dW.shape[0]
     K = dW.numel() // N
     M = dy.numel() // N
     K1 = x.shape[-1]
+    if x.dtype is torch.float16:                             # X = gelu(x): x is the fp16 pre-activation of the MLP hidden
+        _ck(x, torch.float16, 'x')
+        if stats is not None or x2 is not None:
+            raise LeodHipError('linear_wgrad: LayerNorm / concat options do not combine with an fp16 pre-activation')
+        ev = _probe('linear_wgrad', 4.0 * (M * N + N * K) + 2.0 * M * K, 2.0 * M * N * K)
+        check(_l().leod_linear_wgrad_gelu16(_p(dy), N, _p(x), _p(dW), _p(dbias), M, N, K, _stream()), 'linear_wgrad_gelu16')
+        if ev is not None:
+            ev.record()
+        return
+    _ck(x, name='x')
     # algorithmic work of one launch: reads dy, X once, read-modify-writes dW once; 2*M*N*K flops
     ev = _probe('linear_wgrad', 4.0 * (M * N + M * K + N * K), 2.0 * M * N * K)
     check(_l().leod_linear_wgrad(_p(dy), N, _p(x), K1, _p(stats), _p(ln_w), _p(ln_b), _p(x2),

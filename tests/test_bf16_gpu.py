@@ -97,6 +97,37 @@ def test_conv3x3_direct_bf16(bf16_ops, B, H, W, Cin, N):
     tk.close(dw, 2 * w.grad, what='conv3x3 wgrad accumulates')
 
 
+@pytest.mark.parametrize('M,C', [(40009, 48), (20011, 96), (16384, 64)])
+def test_mlp_hidden_stored_once_as_fp16(bf16_ops, M, C):
+    """Stages 1-2 in precision mode bf16: norm2 -> fc1 keeps the hidden pre-activation u once, as fp16 (no fp32 u, no gelu(u) copy);
+    fc2 + LayerScale + residual, the dgrad through GELU and the fc2 weight gradient evaluate GELU / GELU' while loading it
+    (maxvit.py:110-118, 268-269).  Against the fp32 CPU arithmetic of the same chain, ragged row counts."""
+    import torch.nn.functional as F
+    ops = bf16_ops
+    x, res = tk.rnd((M, C), 1), tk.rnd((M, C), 2)
+    lw, lb = 1 + 0.2 * tk.rnd((C,), 3), 0.1 * tk.rnd((C,), 4)
+    W1, b1 = tk.rnd((4 * C, C), 5, 0.2), tk.rnd((4 * C,), 6, 0.2)
+    W2, b2, g = tk.rnd((C, 4 * C), 7, 0.1), tk.rnd((C,), 8, 0.1), 0.5 + 0.1 * tk.rnd((C,), 9)
+    u = F.linear(F.layer_norm(x, (C,), lw, lb, 1e-5), W1, b1).requires_grad_(True)
+    h = F.gelu(u)
+    W2r = W2.clone().requires_grad_(True)
+    z = res + g * F.linear(h, W2r, b2)
+    dz = tk.rnd((M, C), 10)
+    z.backward(dz)
+    d = lambda t: t.detach().to(tk.DEV)  # noqa
+    u16, hh, st = ops.ln_linear_fwd(d(x), d(lw), d(lb), d(W1), d(b1), want_act=True, want_stats=True)
+    assert u16.dtype is torch.float16 and hh is None, 'the row-streaming shapes keep one fp16 tensor'
+    tk.close(u16.float(), u, what='u (fp16)')
+    zz, _ = ops.linear_lsres_fwd(u16, d(W2), d(b2), d(g), d(res), want_t=False)
+    tk.close(zz, z, what='fc2 + LayerScale + residual from the fp16 pre-activation')
+    du = ops.linear_dgrad(d(dz), d(W2), kscale=d(g), aux_u=u16)
+    tk.close(du, u.grad, what='dgrad through GELU')
+    dW, db = torch.zeros((C, 4 * C), device=tk.DEV), torch.zeros((C,), device=tk.DEV)
+    ops.linear_wgrad(d(dz) * d(g), u16, dW, db)
+    tk.close(dW, W2r.grad, what='fc2 weight gradient')
+    tk.close(db, (dz * g).sum(0), what='fc2 bias gradient')
+
+
 # (C = 384 runs the per-timestep kernels in either mode: covered by test_convlstm_bf16 above)
 @pytest.mark.parametrize('T,B,H,W,C,state', [(4, 1, 7, 10, 48, True), (3, 2, 8, 10, 32, False), (5, 4, 16, 40, 96, True), (3, 2, 16, 20, 192, True),
                                              (21, 2, 16, 20, 48, True), (21, 1, 8, 10, 192, True)])
