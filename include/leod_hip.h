@@ -61,8 +61,8 @@ int leod_ln_linear_gelu16_fwd(const float* x, const float* ln_w, const float* ln
                               void* u16, float* stats_out, int M, int N, int K, leod_stream_t stream);
 int leod_linear_lsres_gelu16_fwd(const void* u16, const float* W, const float* bias, const float* gamma, const float* res, float* out,
                                  int M, int N, int K, leod_stream_t stream);
-int leod_linear_dgrad_gelu16(const float* dy, const float* kscale, const float* W, const void* u16, float* dx, int M, int N, int K,
-                             leod_stream_t stream);
+int leod_linear_dgrad_gelu16(const float* dy, const float* kscale, const float* W, const void* u16, void* dx, int M, int N, int K,
+                             int out_bf16, leod_stream_t stream);
 int leod_linear_wgrad_gelu16(const float* dy, long lddy, const void* u16, float* dW, float* dbias, int M, int N, int K,
                              leod_stream_t stream);
 
@@ -91,15 +91,17 @@ int leod_convlstm_seq_fwd(const float* xin, int x_is_projection, float* hbuf, fl
 int leod_convlstm_seq_bwd(const float* dh_seq, const float* dc_last, const float* gates, const float* cbuf, const float* W,
                           float* dgates_out, float* dh0, float* dc0, int M, int C, int T, int zero_state, leod_stream_t stream);
 
-/* dx (=|+=) (dy[M,N]*kscale[N]) W[N,K] ; optional: multiply by gelu'(aux_u[M,K]); route columns >= nsplit to dx2;
+/* dy_bf16 (here and in leod_linear_wgrad / leod_linear_dgrad_lnbwd): dy points to bf16 elements -- in precision mode bf16 the wide
+ * gradients du (out_bf16 of leod_linear_dgrad_gelu16) and dqkv are stored as the bf16 their consumers feed to the MFMAs anyway.
+ * dx (=|+=) (dy[M,N]*kscale[N]) W[N,K] ; optional: multiply by gelu'(aux_u[M,K]); route columns >= nsplit to dx2;
  * colsum[K] += column sums of the result.  Autograd of the Linear layers above. */
 int leod_linear_dgrad(const float* dy, long lddy, const float* kscale, const float* W, float* dx, long lddx, float* dx2,
                       long lddx2, int nsplit, const float* aux_u, float* colsum, int accumulate, int M, int N, int K,
-                      leod_stream_t stream);
+                      int dy_bf16, leod_stream_t stream);
 /* dW[N,K] += dy^T X ; dbias[N] += colsum(dy) ; X = x, LN(x) (stats, ln_w, ln_b) or [x | x2] (K1 = cols of x). */
 int leod_linear_wgrad(const float* dy, long lddy, const float* x, long ldx, const float* stats, const float* ln_w,
                       const float* ln_b, const float* x2, long ldx2, int K1, float* dW, float* dbias, int M, int N,
-                      int K, leod_stream_t stream);
+                      int K, int dy_bf16, leod_stream_t stream);
 
 /* LayerNorm over channels (eps 1e-5), maxvit.py:172-178 and its autograd. */
 int leod_layernorm_fwd(const float* x, const float* w, const float* b, float* y, float* stats, int M, int C, float eps,
@@ -225,7 +227,7 @@ int leod_augment_u8(const unsigned char* src, unsigned char* dst, const int* par
  * input and stats[M,2] its saved (mean, rstd).  Stage-1 shapes only (K = 48, N = 144 / 192, M >= 16384): returns -3
  * (unsupported shape) otherwise and the caller runs leod_linear_dgrad + leod_layernorm_bwd. */
 int leod_linear_dgrad_lnbwd(const float* dy, const float* W, const float* x, const float* stats, const float* ln_w,
-                            const float* dres, float* dx, float* dgamma, float* dbeta, int M, int N, int K,
+                            const float* dres, float* dx, float* dgamma, float* dbeta, int M, int N, int K, int dy_bf16,
                             leod_stream_t stream);
 
 /* ---- host-side C++ of the path (no GPU involved) ------------------------------------------------------------------

@@ -43,7 +43,7 @@ struct ALRows {                 // plain rows, optional LayerNorm prologue, opti
     __device__ __forceinline__ int aux(const St&) const { return 0; }
     __device__ __forceinline__ St init(int row, int M, int lane, bool write_stats) const {
         St s; s.ok = row < M; s.p = x + (long)(s.ok ? row : M - 1) * ld; s.mean = 0.f; s.rstd = 1.f;
-        if (fmt == 1) s.p = reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(x) + (long)(s.ok ? row : M - 1) * ld);
+        if (fmt) s.p = reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(x) + (long)(s.ok ? row : M - 1) * ld);
         if (ln_w && stats_in) { s.mean = stats_in[2 * (long)(s.ok ? row : M - 1)]; s.rstd = stats_in[2 * (long)(s.ok ? row : M - 1) + 1]; }
         else if (ln_w) {
             const int q = lane >> 4;
@@ -69,6 +69,11 @@ struct ALRows {                 // plain rows, optional LayerNorm prologue, opti
             f4 v = unpack_h16(*reinterpret_cast<const s4*>(reinterpret_cast<const unsigned short*>(s.p) + k));
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+            return s.ok ? v : zero4();
+        }
+        if (fmt == 2) {                                  // bf16 gradient rows (precision mode bf16: du / dqkv are stored as the bf16 the MFMAs consume)
+            f4 v = unpack_bf16(*reinterpret_cast<const s4*>(reinterpret_cast<const unsigned short*>(s.p) + k));
+            if (kscale) v = v * ld4(kscale + k);
             return s.ok ? v : zero4();
         }
         f4 v = ld4(s.p + k);
@@ -1028,7 +1033,7 @@ struct XStemNCHW {
 // atomic per dW element (dW accumulates over timesteps and row splits).
 template <int TN, int TK, bool BF, class XL>
 __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ dy, long lddy, XL xl, float* dW, long ldw,
-                                                      float* dbias, int M, int N, int K, int rows_per_block) {
+                                                      float* dbias, int M, int N, int K, int rows_per_block, int dyfmt) {
     constexpr int RC = 32;                                  // rows per staged chunk
     constexpr int LDN = 16 * TN + 4, LDK = 16 * TK + 4;    // natural [row][col] LDS tiles, see wgradw_kernel
     constexpr int BST = 16 * 16 + 16;                       // BF: bf16 [16 row][16 col] blocks + transpose reads, see wgradw_kernel
@@ -1047,13 +1052,13 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
     const bool do_bias = dbias != nullptr && blockIdx.z == 0;
     // ---- chunk-invariant slot geometry / LDS offsets (hoisted: the kernel is VALU-issue sensitive) ----------------------
     int nr[RN], kr[RK], nl[RN], kl[RK], kc[RK];
-    const float* np[RN];
+    long np[RN];                                            // element offsets into dy (fp32, or bf16 when dyfmt)
     bool nok[RN], kok[RK];
 #pragma unroll
     for (int e = 0; e < RN; ++e) {
         const int s = tid + 256 * e, r = s / C4N, c = (s - r * C4N) * 4;
         nr[e] = r; nl[e] = BF ? ((r >> 4) * TN + (c >> 4)) * BST + (r & 15) * 16 + (c & 15) : r * LDN + c; nok[e] = s < NV && n0 + c < N;
-        np[e] = dy + (long)(mbeg + r) * lddy + n0 + c;
+        np[e] = (long)(mbeg + r) * lddy + n0 + c;
     }
 #pragma unroll
     for (int e = 0; e < RK; ++e) {
@@ -1079,7 +1084,8 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
     auto fetch = [&](int m0) {
 #pragma unroll
         for (int e = 0; e < RN; ++e) {
-            rn[e] = (nok[e] && m0 + nr[e] < mend) ? ld4(np[e]) : zero4();
+            if (dyfmt) rn[e] = (nok[e] && m0 + nr[e] < mend) ? unpack_bf16(*reinterpret_cast<const s4*>(reinterpret_cast<const unsigned short*>(dy) + np[e])) : zero4();
+            else rn[e] = (nok[e] && m0 + nr[e] < mend) ? ld4(dy + np[e]) : zero4();
             np[e] += (long)RC * lddy;
         }
 #pragma unroll
@@ -1168,7 +1174,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
 
 template <int TN, int TK, class XL>
 static inline int launch_wgrad16(const float* dy, long lddy, const XL& xl, float* dW, long ldw, float* dbias,
-                                 int M, int N, int K, hipStream_t s) {
+                                 int M, int N, int K, hipStream_t s, int dyfmt = 0) {
     if (M <= 0) return LEOD_OK;
     if ((N & 3) || (K & 3) || (lddy & 3)) return LEOD_ERR_ARG;      // 16-byte row loads
     const int tiles = cdiv(N, TN * 16) * cdiv(K, TK * 16);
@@ -1179,8 +1185,8 @@ static inline int launch_wgrad16(const float* dy, long lddy, const XL& xl, float
     int rpb = cdiv(M, max(1, tune_blocks / tiles));
     rpb = max(tune_minrows, ((rpb + 31) / 32) * 32);
     dim3 grid(cdiv(M, rpb), cdiv(N, TN * 16), cdiv(K, TK * 16));
-    if (leod_precision() == 1) hipLaunchKernelGGL((wgrad16_kernel<TN, TK, true, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, rpb);
-    else hipLaunchKernelGGL((wgrad16_kernel<TN, TK, false, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, rpb);
+    if (leod_precision() == 1) hipLaunchKernelGGL((wgrad16_kernel<TN, TK, true, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, rpb, dyfmt);
+    else hipLaunchKernelGGL((wgrad16_kernel<TN, TK, false, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, rpb, dyfmt);
     return leod_launch_status();
 }
 
@@ -1196,7 +1202,7 @@ static inline int launch_wgrad16(const float* dy, long lddy, const XL& xl, float
 // ---------------------------------------------------------------------------------------------------------------------
 template <int TN, int TK, int WA, int WB, int RC, bool BF, class XL>
 __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict__ dy, long lddy, XL xl, float* dW, long ldw,
-                                                     float* dbias, int M, int N, int K, int chunks_per_block) {
+                                                     float* dbias, int M, int N, int K, int dyfmt) {
     constexpr int NWN = TN / WA, NWK = TK / WB, MS = 4 / (NWN * NWK);      // wave grid over the tile, row-step split
     static_assert(TN % WA == 0 && TK % WB == 0 && NWN * NWK * MS == 4, "4 waves must tile the workgroup");
     constexpr int STEPS = RC / 16;
@@ -1254,7 +1260,10 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
     f4 rn[RN], rk[RK];
     auto fetch = [&](long m0) {
 #pragma unroll
-        for (int e = 0; e < RN; ++e) rn[e] = (nok[e] && m0 + nr[e] < mend) ? ld4(dyb + (m0 * lddy + noff[e])) : zero4();
+        for (int e = 0; e < RN; ++e) {
+            if (dyfmt) rn[e] = (nok[e] && m0 + nr[e] < mend) ? unpack_bf16(*reinterpret_cast<const s4*>(reinterpret_cast<const unsigned short*>(dyb) + (m0 * lddy + noff[e]))) : zero4();
+            else rn[e] = (nok[e] && m0 + nr[e] < mend) ? ld4(dyb + (m0 * lddy + noff[e])) : zero4();
+        }
 #pragma unroll
         for (int e = 0; e < RK; ++e) rk[e] = (kok[e] && m0 + kr[e] < mend) ? xl.get4((int)m0 + kr[e], kc[e]) : zero4();
     };
@@ -1358,27 +1367,27 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
 
 template <int TN, int TK, int WA, int WB, int RC, class XL>
 static inline int launch_wgradw_cfg(const float* dy, long lddy, const XL& xl, float* dW, long ldw, float* dbias,
-                                    int M, int N, int K, hipStream_t s) {
+                                    int M, int N, int K, hipStream_t s, int dyfmt = 0) {
     const int tiles = cdiv(N, TN * 16) * cdiv(K, TK * 16);
     static const int tune_blocks = getenv("LEOD_WGRADW_BLOCKS") ? atoi(getenv("LEOD_WGRADW_BLOCKS")) : 1024;   // 4 workgroups per CU resident
     const int chunks = cdiv(M, RC);
     const int gx = max(1, min(chunks / 4, tune_blocks / tiles));      // >= 4 chunks per workgroup: one atomic per dW element each
     dim3 grid(gx, cdiv(N, TN * 16), cdiv(K, TK * 16));
-    if (leod_precision() == 1) hipLaunchKernelGGL((wgradw_kernel<TN, TK, WA, WB, RC, true, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, cdiv(chunks, gx));
-    else hipLaunchKernelGGL((wgradw_kernel<TN, TK, WA, WB, RC, false, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, cdiv(chunks, gx));
+    if (leod_precision() == 1) hipLaunchKernelGGL((wgradw_kernel<TN, TK, WA, WB, RC, true, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, dyfmt);
+    else hipLaunchKernelGGL((wgradw_kernel<TN, TK, WA, WB, RC, false, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, dyfmt);
     return leod_launch_status();
 }
 
 // shape-driven choice of the workgroup tile (see the kernel header)
 template <class XL>
 static inline int launch_wgradw(const float* dy, long lddy, const XL& xl, float* dW, long ldw, float* dbias,
-                                int M, int N, int K, hipStream_t s) {
+                                int M, int N, int K, hipStream_t s, int dyfmt = 0) {
     if (M <= 0) return LEOD_OK;
     if ((N & 3) || (K & 3) || (lddy & 3)) return LEOD_ERR_ARG;      // 16-byte row loads
-    if (K <= 48 && N <= 48) return launch_wgradw_cfg<3, 3, 3, 3, 64>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s);
-    if (K <= 48) return launch_wgradw_cfg<12, 3, 3, 3, 16>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s);
-    if (N <= 48) return launch_wgradw_cfg<3, 12, 3, 3, 16>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s);
-    return launch_wgradw_cfg<6, 6, 3, 3, 16>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s);
+    if (K <= 48 && N <= 48) return launch_wgradw_cfg<3, 3, 3, 3, 64>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s, dyfmt);
+    if (K <= 48) return launch_wgradw_cfg<12, 3, 3, 3, 16>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s, dyfmt);
+    if (N <= 48) return launch_wgradw_cfg<3, 12, 3, 3, 16>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s, dyfmt);
+    return launch_wgradw_cfg<6, 6, 3, 3, 16>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s, dyfmt);
 }
 // large row counts only: small problems keep the round-robin kernel (more workgroups per output tile)
 static inline bool use_wgradw(int M) {

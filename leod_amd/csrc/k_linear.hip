@@ -47,7 +47,9 @@ static inline EpStore ep_store(float* out, long ld, int N) {
 // v_mfma_f32_16x16x16_bf16 replaces the four fp32 MFMAs of a 16-k chunk.
 // UF (precision mode bf16, stages 1-2 of the MLP): the pre-activation u is kept ONCE, as fp16 -- ACT stores only fp16(u) through out2
 // (no fp32 u, no gelu(u) copy: 2 instead of 8 bytes per hidden element; its consumers apply GELU / GELU' on load), DG = 2 reads it back.
-template <int KC, int NTT, bool LN, bool ACT, int DG = 0, bool BF = false, bool UF = false>
+// OB: the output (the gradient du of the dgrad through GELU) is stored as bf16 -- both of its consumers (dgrad of fc1, fc1 weight
+// gradient) feed it to bf16 MFMAs, so nothing changes numerically and 4 -> 2 bytes move on the write and on both reads.
+template <int KC, int NTT, bool LN, bool ACT, int DG = 0, bool BF = false, bool UF = false, bool OB = false>
 __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream48_kernel(const float* __restrict__ x, long ldx, float* __restrict__ stats_out,
                                                              const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
                                                              const float* __restrict__ W, const float* __restrict__ bias,
@@ -56,7 +58,8 @@ __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream4
     const int n0 = blockIdx.y * N;                              // first column of this slab
     W += DG ? (long)n0 : (long)n0 * K;
     if (bias) bias += n0;
-    if (!(ACT && UF)) out += n0;
+    if (OB) out = reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(out) + n0);
+    else if (!(ACT && UF)) out += n0;
     unsigned short* u16 = reinterpret_cast<unsigned short*>(out2) + n0;      // UF: the fp16 pre-activation [M][Ntot]
     if ((ACT || DG == 2) && !UF) out2 += n0;
     __shared__ __attribute__((aligned(16))) float sW[BF ? (N * LD) / 2 : N * LD];
@@ -187,6 +190,7 @@ __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream4
                 for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(u[j]);
             }
             if constexpr (ACT && UF) { *reinterpret_cast<s4*>(u16 + row * Ntot + n) = pack_h16(v); return; }
+            if constexpr (OB) { *reinterpret_cast<s4*>(reinterpret_cast<unsigned short*>(out) + row * Ntot + n) = pack_bf16(v); return; }
             *reinterpret_cast<f4*>(out + row * Ntot + n) = v;
             if (ACT) {
                 f4 ge;
@@ -254,8 +258,9 @@ __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream4
 // One wave = one 16-row tile; 48 output columns = 12 float4 per row = 3 per lane (idx = 64 p + lane -> row idx / 12,
 // column idx % 12); the residual slice of the tile is loaded before its MFMAs.
 // ---------------------------------------------------------------------------------------------------------------------
-// AF (MODE 0, precision mode bf16): x is the fp16 pre-activation of the MLP hidden, A = gelu(x) evaluated on the fragments.
-template <int KC, int MODE, bool BF = false, bool AF = false>
+// AF = 1 (MODE 0, precision mode bf16): x is the fp16 pre-activation of the MLP hidden, A = gelu(x) evaluated on the fragments.
+// AF = 2 (MODE 1 / 2): x is a bf16 gradient (du / dqkv): its fragments ARE the MFMA operands.
+template <int KC, int MODE, bool BF = false, int AF = 0>
 __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                                   const float* __restrict__ bias, const float* __restrict__ gamma,
                                                                   const float* __restrict__ res, float* __restrict__ out, int M,
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
     __syncthreads();
     const int stride = gridDim.x * 4;
     float* so = sO[wave];
-    typedef typename std::conditional<AF, s4, f4>::type AFrag;
+    typedef typename std::conditional<AF != 0, s4, f4>::type AFrag;
     struct Frag { AFrag a[KC]; };
     auto load = [&](Frag& f, int tile) {
         const long row = min((long)tile * 16 + i, (long)M - 1);
@@ -346,7 +351,8 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
         for (int c = 0; c < KC; ++c) {
             if constexpr (BF) {
                 s4 pa;
-                if constexpr (AF) {
+                if constexpr (AF == 2) pa = f.a[c];
+                else if constexpr (AF == 1) {
                     f4 u = unpack_h16(f.a[c]);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) u[j] = gelu_erf(u[j]);
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
                     acc[t] = mfma16_bf16(pa, *reinterpret_cast<const s4*>(&sWh[(16 * t + i) * LD + 16 * c + 4 * q]), acc[t]);
-            } else if constexpr (!AF) {
+            } else if constexpr (AF == 0) {
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const f4 b = *reinterpret_cast<const f4*>(&sW[(16 * t + i) * LD + 16 * c + 4 * q]);
@@ -559,16 +565,16 @@ LEOD_API int leod_convlstm_fwd(const float* x, const float* h_prev, const float*
 //   colsum != NULL: colsum[K] += column sums of the stored dx (bias gradient of the producer)
 LEOD_API int leod_linear_dgrad(const float* dy, long lddy, const float* kscale, const float* W, float* dx, long lddx,
                                float* dx2, long lddx2, int nsplit, const float* aux_u, float* colsum,
-                               int accumulate, int M, int N, int K, hipStream_t stream) {
+                               int accumulate, int M, int N, int K, int dy_bf16, hipStream_t stream) {
     if (!dy || !W || !dx || (N & 3) || (lddy & 3)) return LEOD_ERR_ARG;
-    ALRows al{}; al.x = dy; al.ld = lddy; al.kscale = kscale; al.K = N;
+    ALRows al{}; al.x = dy; al.ld = lddy; al.kscale = kscale; al.K = N; al.fmt = dy_bf16 ? 2 : 0;
     EpStore ep = ep_store(dx, lddx, K);
     ep.out2 = dx2; ep.ld2 = lddx2; ep.nsplit = nsplit; ep.accumulate = accumulate; ep.colsum = colsum;
     if (aux_u) { ep.act = ACT_MUL_GELU_GRAD; ep.aux = aux_u; ep.ldaux = K; }
     const int nt = pick_nt(K);
     int rc = LEOD_OK;
     // contraction over N in {48, 96}, K in {192, 384} output columns (dgrad of fc2, optionally through GELU): streaming kernel
-    if (!dx2 && !colsum && !accumulate && lddy == N && lddx == K && nsplit <= 0) {
+    if (!dy_bf16 && !dx2 && !colsum && !accumulate && lddy == N && lddx == K && nsplit <= 0) {
         if (!kscale && !aux_u && use_rowstream_narrow(M, N, K))
             return launch_rowstream_narrow<1>(dy, W, nullptr, nullptr, nullptr, dx, M, N, stream);
         if (const int slab = rowstream_slab(M, K, N)) {
@@ -588,16 +594,17 @@ LEOD_API int leod_linear_dgrad(const float* dy, long lddy, const float* kscale, 
 // dW[N,K] += dy[M,N]^T @ X[M,K] ; dbias[N] += colsum(dy)  with X = x, LN(x) (stats + ln_w/ln_b) or [x | x2]
 LEOD_API int leod_linear_wgrad(const float* dy, long lddy, const float* x, long ldx, const float* stats,
                                const float* ln_w, const float* ln_b, const float* x2, long ldx2, int K1,
-                               float* dW, float* dbias, int M, int N, int K, hipStream_t stream) {
+                               float* dW, float* dbias, int M, int N, int K, int dy_bf16, hipStream_t stream) {
     if (!dy || !x || !dW) return LEOD_ERR_ARG;
     XRows xl{x, ldx, stats, ln_w, ln_b, x2, ldx2, K1};
-    if (use_wgradw(M)) return launch_wgradw(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);
-    if (N % 48 == 0 && K % 48 == 0) return launch_wgrad16<3, 3>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);
-    if (N % 32 == 0 && K % 32 == 0 && (N % 64 || K % 64)) return launch_wgrad16<2, 2>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);
-    if (N >= 64 && K >= 64) return launch_wgrad16<4, 4>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);
-    if (K >= 64) return launch_wgrad16<1, 4>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);
-    if (N >= 64) return launch_wgrad16<4, 1>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);
-    return launch_wgrad16<1, 1>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);
+    const int df = dy_bf16 ? 1 : 0;
+    if (use_wgradw(M)) return launch_wgradw(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, df);
+    if (N % 48 == 0 && K % 48 == 0) return launch_wgrad16<3, 3>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, df);
+    if (N % 32 == 0 && K % 32 == 0 && (N % 64 || K % 64)) return launch_wgrad16<2, 2>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, df);
+    if (N >= 64 && K >= 64) return launch_wgrad16<4, 4>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, df);
+    if (K >= 64) return launch_wgrad16<1, 4>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, df);
+    if (N >= 64) return launch_wgrad16<4, 1>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, df);
+    return launch_wgrad16<1, 1>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, df);
 }
 
 // dx[M,K] = LayerNorm backward of (dy[M,N] @ W[N,K]) in one pass: dn = dy W stays in registers, dx = rstd (dn w - mean(dn w) -
@@ -605,11 +612,17 @@ LEOD_API int leod_linear_wgrad(const float* dy, long lddy, const float* x, long 
 // its saved (mean, rstd)).  Covers K = 48 with N = 144 / 192 and M >= 16384 (stage 1); LEOD_ERR_UNSUPPORTED otherwise -- the
 // caller then runs leod_linear_dgrad + leod_layernorm_bwd.
 LEOD_API int leod_linear_dgrad_lnbwd(const float* dy, const float* W, const float* x, const float* stats, const float* ln_w,
-                                     const float* dres, float* dx, float* dgamma, float* dbeta, int M, int N, int K,
+                                     const float* dres, float* dx, float* dgamma, float* dbeta, int M, int N, int K, int dy_bf16,
                                      hipStream_t stream) {
     if (!dy || !W || !x || !stats || !ln_w || !dx || !dgamma || !dbeta) return LEOD_ERR_ARG;
     if (!use_rowstream_narrow(M, N, K)) return LEOD_ERR_UNSUPPORTED;
     const int grid = min(cdiv(cdiv(M, 16), 4), 256 * 2);
+    if (dy_bf16) {
+        if (leod_precision() != 1) return LEOD_ERR_ARG;
+        if (N == 192) hipLaunchKernelGGL((rowstream_narrow_kernel<12, 2, true, 2>), dim3(grid), dim3(256), 0, stream, dy, W, nullptr, ln_w, dres, dx, M, x, stats, dgamma, dbeta);
+        else hipLaunchKernelGGL((rowstream_narrow_kernel<9, 2, true, 2>), dim3(grid), dim3(256), 0, stream, dy, W, nullptr, ln_w, dres, dx, M, x, stats, dgamma, dbeta);
+        return leod_launch_status();
+    }
     if (leod_precision() == 1) {
         if (N == 192) hipLaunchKernelGGL((rowstream_narrow_kernel<12, 2, true>), dim3(grid), dim3(256), 0, stream, dy, W, nullptr, ln_w, dres, dx, M, x, stats, dgamma, dbeta);
         else hipLaunchKernelGGL((rowstream_narrow_kernel<9, 2, true>), dim3(grid), dim3(256), 0, stream, dy, W, nullptr, ln_w, dres, dx, M, x, stats, dgamma, dbeta);
@@ -655,8 +668,8 @@ LEOD_API int leod_linear_lsres_gelu16_fwd(const void* u16, const float* W, const
     const float* a = reinterpret_cast<const float*>(u16);
     if (use_rowstream_narrow(M, K, N)) {
         const int grid = min(cdiv(cdiv(M, 16), 4), 256 * 2);
-        if (K == 192) hipLaunchKernelGGL((rowstream_narrow_kernel<12, 0, true, true>), dim3(grid), dim3(256), 0, stream, a, W, bias, gamma, res, out, M);
-        else hipLaunchKernelGGL((rowstream_narrow_kernel<9, 0, true, true>), dim3(grid), dim3(256), 0, stream, a, W, bias, gamma, res, out, M);
+        if (K == 192) hipLaunchKernelGGL((rowstream_narrow_kernel<12, 0, true, 1>), dim3(grid), dim3(256), 0, stream, a, W, bias, gamma, res, out, M);
+        else hipLaunchKernelGGL((rowstream_narrow_kernel<9, 0, true, 1>), dim3(grid), dim3(256), 0, stream, a, W, bias, gamma, res, out, M);
         return leod_launch_status();
     }
     ALRows al{}; al.x = a; al.ld = K; al.K = K; al.fmt = 1;
@@ -672,8 +685,8 @@ LEOD_API int leod_linear_lsres_gelu16_fwd(const void* u16, const float* W, const
 }
 
 // du[M,K] = ((dy[M,N] * kscale[N]) @ W[N,K]) * gelu'(u16[M,K])      (dgrad of fc2 through GELU, fp16 pre-activation)
-LEOD_API int leod_linear_dgrad_gelu16(const float* dy, const float* kscale, const float* W, const void* u16, float* dx,
-                                      int M, int N, int K, hipStream_t stream) {
+LEOD_API int leod_linear_dgrad_gelu16(const float* dy, const float* kscale, const float* W, const void* u16, void* dx,
+                                      int M, int N, int K, int out_bf16, hipStream_t stream) {
     if (!dy || !W || !u16 || !dx || leod_precision() != 1) return LEOD_ERR_ARG;
     const int slab = rowstream_slab(M, K, N);
     if (!slab) return LEOD_ERR_UNSUPPORTED;
@@ -682,8 +695,10 @@ LEOD_API int leod_linear_dgrad_gelu16(const float* dy, const float* kscale, cons
     float* aux = reinterpret_cast<float*>(const_cast<void*>(u16));
 #define DG16_CASE(KCV, NTTV)                                                                                                         \
     if (N == 16 * KCV && slab == NTTV) {                                                                                             \
-        hipLaunchKernelGGL((rowstream48_kernel<KCV, NTTV, false, false, 2, true, true>), dim3(gx, slabs), dim3(256), 0, stream, dy, (long)N, \
-                           nullptr, kscale, nullptr, 0.f, W, nullptr, dx, aux, M, K);                                                \
+        if (out_bf16) hipLaunchKernelGGL((rowstream48_kernel<KCV, NTTV, false, false, 2, true, true, true>), dim3(gx, slabs), dim3(256), 0, stream, \
+                                         dy, (long)N, nullptr, kscale, nullptr, 0.f, W, nullptr, reinterpret_cast<float*>(dx), aux, M, K);          \
+        else hipLaunchKernelGGL((rowstream48_kernel<KCV, NTTV, false, false, 2, true, true>), dim3(gx, slabs), dim3(256), 0, stream, dy, (long)N, \
+                                nullptr, kscale, nullptr, 0.f, W, nullptr, reinterpret_cast<float*>(dx), aux, M, K);                              \
         return leod_launch_status();                                                                                                 \
     }
     DG16_CASE(3, 12) DG16_CASE(6, 8) DG16_CASE(4, 8)

@@ -229,7 +229,9 @@ def convlstm_seq_bwd(dh_seq, dc_last, gates, cbuf, W, dgates_out, dh0=None, dc0=
 
 def linear_dgrad(dy, W, kscale=None, aux_u=None, colsum=None, out=None, accumulate=False, split=0, out2=None):
     """dx = (dy * kscale) @ W  with W [N,K]; see leod_linear_dgrad."""
-    for t, n in ((dy, 'dy'), (W, 'W'), (kscale, 'kscale'), (colsum, 'colsum'), (out, 'out'), (out2, 'out2')):
+    dy16 = dy.dtype is torch.bfloat16                         # bf16 gradient rows (du / dqkv of precision mode bf16)
+    _ck(dy, torch.bfloat16 if dy16 else F32, 'dy')
+    for t, n in ((W, 'W'), (kscale, 'kscale'), (colsum, 'colsum'), (out, 'out'), (out2, 'out2')):
         _ck(t, name=n)
     N, K = W.shape[0], W.shape[1] if W.dim() == 2 else W.numel() // W.shape[0]
     M = dy.numel() // N
@@ -237,28 +239,34 @@ def linear_dgrad(dy, W, kscale=None, aux_u=None, colsum=None, out=None, accumula
         _ck(aux_u, torch.float16, 'aux_u')
         if split or colsum is not None or accumulate or out is not None:
             raise LeodHipError('linear_dgrad: unsupported option with an fp16 pre-activation')
-        out = _empty(dy.shape[:-1] + (K,), dy)
-        check(_l().leod_linear_dgrad_gelu16(_p(dy), _p(kscale), _p(W), _p(aux_u), _p(out), M, N, K, _stream()), 'linear_dgrad_gelu16')
+        if dy16:
+            raise LeodHipError('linear_dgrad: bf16 dy does not combine with an fp16 pre-activation')
+        # the gradient of the hidden goes out as bf16: its two consumers (dgrad of fc1, fc1 weight gradient) feed bf16 MFMAs
+        out = torch.empty(dy.shape[:-1] + (K,), dtype=torch.bfloat16 if BF16_GRADS else F32, device=dy.device)
+        check(_l().leod_linear_dgrad_gelu16(_p(dy), _p(kscale), _p(W), _p(aux_u), _p(out), M, N, K, 1 if BF16_GRADS else 0, _stream()),
+              'linear_dgrad_gelu16')
         return out
     _ck(aux_u, name='aux_u')
     if split:
         if out is None:
-            out = _empty(dy.shape[:-1] + (split,), dy)
+            out = torch.empty(dy.shape[:-1] + (split,), dtype=F32, device=dy.device)
         if out2 is None:
-            out2 = _empty(dy.shape[:-1] + (K - split,), dy)
+            out2 = torch.empty(dy.shape[:-1] + (K - split,), dtype=F32, device=dy.device)
         ld1, ld2 = split, K - split
     else:
         if out is None:
-            out = _empty(dy.shape[:-1] + (K,), dy)
+            out = torch.empty(dy.shape[:-1] + (K,), dtype=F32, device=dy.device)
         ld1, ld2 = K, 0
     check(_l().leod_linear_dgrad(_p(dy), N, _p(kscale), _p(W), _p(out), ld1, _p(out2), ld2, split, _p(aux_u),
-                                  _p(colsum), 1 if accumulate else 0, M, N, K, _stream()), 'linear_dgrad')
+                                  _p(colsum), 1 if accumulate else 0, M, N, K, 1 if dy16 else 0, _stream()), 'linear_dgrad')
     return (out, out2) if split else out
 
 
 def linear_wgrad(dy, x, dW, dbias=None, stats=None, ln_w=None, ln_b=None, x2=None):
     """dW += dy^T X ; dbias += colsum(dy).  X = x | LN(x) | [x|x2]."""
-    for t, n in ((dy, 'dy'), (dW, 'dW'), (dbias, 'dbias'), (stats, 'stats'), (ln_w, 'ln_w'), (ln_b, 'ln_b'), (x2, 'x2')):
+    dy16 = dy.dtype is torch.bfloat16
+    _ck(dy, torch.bfloat16 if dy16 else F32, 'dy')
+    for t, n in ((dW, 'dW'), (dbias, 'dbias'), (stats, 'stats'), (ln_w, 'ln_w'), (ln_b, 'ln_b'), (x2, 'x2')):
         _ck(t, name=n)
     N = dW.shape[0]
     K = dW.numel() // N
@@ -266,8 +274,8 @@ def linear_wgrad(dy, x, dW, dbias=None, stats=None, ln_w=None, ln_b=None, x2=Non
     K1 = x.shape[-1]
     if x.dtype is torch.float16:                             # X = gelu(x): x is the fp16 pre-activation of the MLP hidden
         _ck(x, torch.float16, 'x')
-        if stats is not None or x2 is not None:
-            raise LeodHipError('linear_wgrad: LayerNorm / concat options do not combine with an fp16 pre-activation')
+        if stats is not None or x2 is not None or dy16:
+            raise LeodHipError('linear_wgrad: LayerNorm / concat / bf16-dy options do not combine with an fp16 pre-activation')
         ev = _probe('linear_wgrad', 4.0 * (M * N + N * K) + 2.0 * M * K, 2.0 * M * N * K)
         check(_l().leod_linear_wgrad_gelu16(_p(dy), N, _p(x), _p(dW), _p(dbias), M, N, K, _stream()), 'linear_wgrad_gelu16')
         if ev is not None:
@@ -275,9 +283,9 @@ def linear_wgrad(dy, x, dW, dbias=None, stats=None, ln_w=None, ln_b=None, x2=Non
         return
     _ck(x, name='x')
     # algorithmic work of one launch: reads dy, X once, read-modify-writes dW once; 2*M*N*K flops
-    ev = _probe('linear_wgrad', 4.0 * (M * N + M * K + N * K), 2.0 * M * N * K)
+    ev = _probe('linear_wgrad', (2.0 if dy16 else 4.0) * M * N + 4.0 * (M * K + N * K), 2.0 * M * N * K)
     check(_l().leod_linear_wgrad(_p(dy), N, _p(x), K1, _p(stats), _p(ln_w), _p(ln_b), _p(x2),
-                                  (x2.shape[-1] if x2 is not None else 0), K1, _p(dW), _p(dbias), M, N, K, _stream()),
+                                  (x2.shape[-1] if x2 is not None else 0), K1, _p(dW), _p(dbias), M, N, K, 1 if dy16 else 0, _stream()),
           'linear_wgrad')
     if ev is not None:
         ev.record()
@@ -308,12 +316,15 @@ def layernorm_bwd(dn, x, stats, w, dres, dw, db, eps=1e-5):
 def linear_dgrad_ln_bwd(dy, W, x, stats, ln_w, dres, dw, db, eps=1e-5):
     """dx of  x -> LayerNorm -> Linear(W)  from dy: LN-backward(dy @ W) + dres; dw / db accumulate the LayerNorm weight / bias
     gradients.  One fused launch for the stage-1 shapes, leod_linear_dgrad + leod_layernorm_bwd otherwise."""
-    for t, n in ((dy, 'dy'), (W, 'W'), (x, 'x'), (stats, 'stats'), (ln_w, 'ln_w'), (dres, 'dres'), (dw, 'dw'), (db, 'db')):
+    dy16 = dy.dtype is torch.bfloat16
+    _ck(dy, torch.bfloat16 if dy16 else F32, 'dy')
+    for t, n in ((W, 'W'), (x, 'x'), (stats, 'stats'), (ln_w, 'ln_w'), (dres, 'dres'), (dw, 'dw'), (db, 'db')):
         _ck(t, name=n)
     N, K = W.shape
     M = dy.numel() // N
     dx = _empty(x.shape, x)
-    rc = _l().leod_linear_dgrad_lnbwd(_p(dy), _p(W), _p(x), _p(stats), _p(ln_w), _p(dres), _p(dx), _p(dw), _p(db), M, N, K, _stream())
+    rc = _l().leod_linear_dgrad_lnbwd(_p(dy), _p(W), _p(x), _p(stats), _p(ln_w), _p(dres), _p(dx), _p(dw), _p(db), M, N, K,
+                                      1 if dy16 else 0, _stream())
     if rc == -3:                                            # shape outside the fused kernel's coverage
         return layernorm_bwd(linear_dgrad(dy, W), x, stats, ln_w, dres, dw, db, eps)
     check(rc, 'linear_dgrad_lnbwd')
@@ -374,6 +385,7 @@ def stem_conv_wgrad(dy, x_nchw, dw, padded_hw, stride, pad):
                                      padded_hw[0], padded_hw[1], N, ks, stride, pad, _stream()), 'stem_conv_wgrad')
 
 
+BF16_GRADS = __import__('os').environ.get('LEOD_BF16_GRADS', '1') == '1'   # precision mode bf16: du (and dqkv) stored as bf16
 STAT_REPLICAS = 32          # most copies of the BatchNorm (sum, sumsq) accumulators a conv epilogue spreads its atomics over
 
 

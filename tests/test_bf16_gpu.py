@@ -121,7 +121,23 @@ def test_mlp_hidden_stored_once_as_fp16(bf16_ops, M, C):
     zz, _ = ops.linear_lsres_fwd(u16, d(W2), d(b2), d(g), d(res), want_t=False)
     tk.close(zz, z, what='fc2 + LayerScale + residual from the fp16 pre-activation')
     du = ops.linear_dgrad(d(dz), d(W2), kscale=d(g), aux_u=u16)
-    tk.close(du, u.grad, what='dgrad through GELU')
+    assert du.dtype is (torch.bfloat16 if ops.BF16_GRADS else torch.float32)
+    tk.close(du.float(), u.grad, what='dgrad through GELU')
+    # the bf16 gradient of the hidden feeds the dgrad of fc1 (+ LayerNorm backward) and the fc1 weight gradient as is
+    xr = x.clone().requires_grad_(True)
+    W1r, b1r = W1.clone().requires_grad_(True), b1.clone().requires_grad_(True)
+    lwr, lbr = lw.clone().requires_grad_(True), lb.clone().requires_grad_(True)
+    dures = tk.rnd((M, C), 11)
+    (F.linear(F.layer_norm(xr, (C,), lwr, lbr, 1e-5), W1r, b1r) * du.float().cpu()).sum().add((xr * dures).sum()).backward()
+    dlw, dlb = torch.zeros((C,), device=tk.DEV), torch.zeros((C,), device=tk.DEV)
+    dxx = ops.linear_dgrad_ln_bwd(du, d(W1), d(x), st, d(lw), d(dures), dlw, dlb)
+    tk.close(dxx, xr.grad, what='dgrad of fc1 + LayerNorm backward from bf16 du')
+    tk.close(dlw, lwr.grad, what='LayerNorm weight gradient')
+    tk.close(dlb, lbr.grad, what='LayerNorm bias gradient')
+    dW1, db1 = torch.zeros((4 * C, C), device=tk.DEV), torch.zeros((4 * C,), device=tk.DEV)
+    ops.linear_wgrad(du, d(x), dW1, db1, stats=st, ln_w=d(lw), ln_b=d(lb))
+    tk.close(dW1, W1r.grad, what='fc1 weight gradient from bf16 du')
+    tk.close(db1, b1r.grad, what='fc1 bias gradient from bf16 du')
     dW, db = torch.zeros((C, 4 * C), device=tk.DEV), torch.zeros((C,), device=tk.DEV)
     ops.linear_wgrad(d(dz) * d(g), u16, dW, db)
     tk.close(dW, W2r.grad, what='fc2 weight gradient')
