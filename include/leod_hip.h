@@ -48,10 +48,18 @@ int leod_linear_lsres_fwd(const float* a, const float* W, const float* bias, con
  * (window=0) partition of ph x pw tokens; lse (optional) [M,heads].  Replaces window/grid_partition + SelfAttentionCl
  * core + *_reverse (maxvit.py:252-265,273-304,347-352). */
 int leod_partition_attn_fwd(const float* qkv, float* out, float* lse, int B, int H, int W, int C, int heads, int ph,
-                            int pw, int window, leod_stream_t stream);
+                            int pw, int window, int qkv_bf16, leod_stream_t stream);
 /* dqkv[M,3C] from dout[M,C]; dsum [M,heads] scratch. */
 int leod_partition_attn_bwd(const float* qkv, const float* dout, const float* lse, float* dsum, float* dqkv, int B,
-                            int H, int W, int C, int heads, int ph, int pw, int window, leod_stream_t stream);
+                            int H, int W, int C, int heads, int ph, int pw, int window, int qkv_bf16, int dqkv_bf16,
+                            leod_stream_t stream);
+/* Precision mode bf16: q, k, v only ever enter bf16 MFMAs and dqkv's consumers feed bf16 MFMAs, so both tensors may live in HBM as
+ * bf16 (qkv_bf16 / dqkv_bf16 above: the pointers then address bf16 elements) where the LDS attention kernels cover the geometry --
+ * 1 from this query; leod_ln_linear_bf16_fwd produces the bf16 qkv rows. */
+int leod_partition_attn_16bit_ok(int B, int H, int W, int C, int heads, int ph, int pw);
+/* out16[M,N] = bf16(LN(x) W^T + bias), stats_out [M,2]; -3 unless the row-streaming kernel covers (M, N, K) in precision mode bf16. */
+int leod_ln_linear_bf16_fwd(const float* x, const float* ln_w, const float* ln_b, float eps, const float* W, const float* bias,
+                            void* out16, float* stats_out, int M, int N, int K, leod_stream_t stream);
 
 /* Precision mode bf16, stages 1-2 of the MLP (maxvit.py:110-118): the hidden pre-activation u = LN(x) W1^T + b1 is stored ONCE,
  * as fp16 [M,N] (as the reference does under autocast, train.py:236-243; clamped to the fp16 range); the three consumers below

@@ -15,6 +15,8 @@
 
 struct AttnGeom {
     int B, H, W, C, heads, d, ph, pw, window;   // window: 1 = window partition, 0 = grid partition
+    int fmt;                                    // precision mode bf16, LDS kernels only: bit 0 = qkv holds bf16, bit 1 = dqkv is written as
+                                                // bf16 (q, k, v only ever enter bf16 MFMAs; dqkv's consumers feed bf16 MFMAs)
 };
 
 // Row (token) addressing without integer division in the inner loops: every lane computes, ONCE per wave, the row of
@@ -398,7 +400,8 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds_kernel(const float*
         for (int j = 0; j < NL; ++j) {
             const int e = tid + j * NTHR, tok = min(e / F, TOK - 1), f = e - (e / F) * F;
             const long row = srow[tok];
-            stage[j] = (e < TOK * F && row >= 0) ? ld4(qkv + row * ld + h0 * 3 * d + 4 * f) : zero4();
+            if (g.fmt & 1) stage[j] = (e < TOK * F && row >= 0) ? unpack_bf16(*reinterpret_cast<const s4*>(reinterpret_cast<const unsigned short*>(qkv) + row * ld + h0 * 3 * d + 4 * f)) : zero4();
+            else stage[j] = (e < TOK * F && row >= 0) ? ld4(qkv + row * ld + h0 * 3 * d + 4 * f) : zero4();
         }
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
@@ -514,7 +517,8 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float*
         for (int j = 0; j < NL; ++j) {
             const int e = tid + j * NTHR, tok = min(e / F, TOK - 1), f = e - (e / F) * F;
             const long row = srow[tok];
-            stage[j] = (e < TOK * F && row >= 0) ? ld4(qkv + row * ld + h0 * 3 * d + 4 * f) : zero4();
+            if (g.fmt & 1) stage[j] = (e < TOK * F && row >= 0) ? unpack_bf16(*reinterpret_cast<const s4*>(reinterpret_cast<const unsigned short*>(qkv) + row * ld + h0 * 3 * d + 4 * f)) : zero4();
+            else stage[j] = (e < TOK * F && row >= 0) ? ld4(qkv + row * ld + h0 * 3 * d + 4 * f) : zero4();
         }
 #pragma unroll
         for (int j = 0; j < NLd; ++j) {
@@ -674,7 +678,11 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float*
     for (int e = tid; e < TOK * F; e += NTHR) {
         const int tok = e / F, f = e - tok * F;
         const long row = srow[tok];
-        if (row >= 0) *reinterpret_cast<f4*>(dqkv + row * ld + h0 * 3 * d + 4 * f) = *reinterpret_cast<const f4*>(smem + tok * S + 4 * f);
+        if (row >= 0) {
+            const f4 v = *reinterpret_cast<const f4*>(smem + tok * S + 4 * f);
+            if (g.fmt & 2) *reinterpret_cast<s4*>(reinterpret_cast<unsigned short*>(dqkv) + row * ld + h0 * 3 * d + 4 * f) = pack_bf16(v);
+            else *reinterpret_cast<f4*>(dqkv + row * ld + h0 * 3 * d + 4 * f) = v;
+        }
     }
 }
 
@@ -733,6 +741,7 @@ static int dispatch_attn(int which, const float* qkv, const float* dout, float* 
 #undef ATTL
         return LEOD_ERR_UNSUPPORTED;
     }
+    if (g.fmt) return LEOD_ERR_UNSUPPORTED;                    // the register-direct kernels read / write fp32 only
 #define ATT(PTV, DV) if (PT == PTV && DCH == DV) return run_attn<PTV, DV>(which, qkv, dout, out, lse, dsum, dqkv, g, scale, s);
     ATT(1, 1) ATT(1, 2) ATT(4, 1) ATT(4, 2) ATT(5, 1) ATT(5, 2) ATT(15, 2) ATT(2, 1) ATT(2, 2) ATT(3, 2) ATT(8, 2) ATT(10, 2)
 #undef ATT
@@ -740,19 +749,31 @@ static int dispatch_attn(int which, const float* qkv, const float* dout, float* 
 }
 
 // out[M,C] = softmax(q k^T / sqrt(d)) v per partition/head ; lse[M,heads] (optional) = log-sum-exp of the scaled scores
+// 1: forward and fused backward of this geometry run on the LDS kernels in the current precision mode bf16, i.e. qkv may be handed
+// over as bf16 (qkv_bf16) and dqkv produced as bf16 (dqkv_bf16); 0: fp32 tensors only
+LEOD_API int leod_partition_attn_16bit_ok(int B, int H, int W, int C, int heads, int ph, int pw) {
+    if (leod_precision() != 1 || heads <= 0 || C % heads || H % ph || W % pw) return 0;
+    static const int use_lds = getenv("LEOD_ATTN_LDS") ? atoi(getenv("LEOD_ATTN_LDS")) : 1;
+    static const int on = getenv("LEOD_QKV16") ? atoi(getenv("LEOD_QKV16")) : 1;
+    const int d = C / heads, P = ph * pw, PT = (P + 15) / 16;
+    const int HG = (heads % 2 == 0 && 2 * PT <= 16) ? 2 : 1;
+    const bool inst = PT <= 5 || PT == 8 || (HG == 1 && (PT == 10 || PT == 15));
+    return on && use_lds && (d == 24 || d == 32) && inst && !(HG == 1 && P < 16 * PT);
+}
+
 LEOD_API int leod_partition_attn_fwd(const float* qkv, float* out, float* lse, int B, int H, int W, int C, int heads,
-                                     int ph, int pw, int window, hipStream_t stream) {
+                                     int ph, int pw, int window, int qkv_bf16, hipStream_t stream) {
     if (!qkv || !out || heads <= 0) return LEOD_ERR_ARG;
-    AttnGeom g{B, H, W, C, heads, C / heads, ph, pw, window};
+    AttnGeom g{B, H, W, C, heads, C / heads, ph, pw, window, qkv_bf16 ? 1 : 0};
     return dispatch_attn(0, qkv, nullptr, out, lse, nullptr, nullptr, g, stream);
 }
 
 // dqkv[M,3C] = gradient of the attention core wrt the qkv rows; dsum [M,heads] is scratch
 LEOD_API int leod_partition_attn_bwd(const float* qkv, const float* dout, const float* lse, float* dsum, float* dqkv,
                                      int B, int H, int W, int C, int heads, int ph, int pw, int window,
-                                     hipStream_t stream) {
+                                     int qkv_bf16, int dqkv_bf16, hipStream_t stream) {
     if (!qkv || !dout || !lse || !dsum || !dqkv || heads <= 0) return LEOD_ERR_ARG;
-    AttnGeom g{B, H, W, C, heads, C / heads, ph, pw, window};
+    AttnGeom g{B, H, W, C, heads, C / heads, ph, pw, window, (qkv_bf16 ? 1 : 0) | (dqkv_bf16 ? 2 : 0)};
     int rc = dispatch_attn(1, qkv, dout, nullptr, const_cast<float*>(lse), dsum, dqkv, g, stream);
     if (rc != LEOD_OK) return rc;
     return dispatch_attn(2, qkv, dout, nullptr, const_cast<float*>(lse), dsum, dqkv, g, stream);

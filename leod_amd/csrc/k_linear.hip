@@ -661,6 +661,26 @@ LEOD_API int leod_ln_linear_gelu16_fwd(const float* x, const float* ln_w, const 
     return LEOD_ERR_UNSUPPORTED;
 }
 
+// out16[M,N] = bf16(LN(x) W^T + bias) (the qkv rows of stages 1-2: q, k, v only ever enter bf16 MFMAs); stats_out [M,2]
+LEOD_API int leod_ln_linear_bf16_fwd(const float* x, const float* ln_w, const float* ln_b, float eps, const float* W, const float* bias,
+                                     void* out16, float* stats_out, int M, int N, int K, hipStream_t stream) {
+    if (!x || !W || !out16 || !ln_w || !stats_out) return LEOD_ERR_ARG;
+    const int slab = rowstream_slab(M, N, K);
+    if (leod_precision() != 1 || !slab) return LEOD_ERR_UNSUPPORTED;
+    const int slabs = N / (16 * slab);
+#define O16_CASE(KCV, NTTV)                                                                                                          \
+    if (K == 16 * KCV && slab == NTTV) {                                                                                             \
+        const int per_cu = (KCV == 3 && NTTV <= 9) ? 3 : 2;                                                                          \
+        const int gx = min(cdiv(cdiv(M, 16), 4), max(8, (256 * per_cu / slabs) & ~7));                                               \
+        hipLaunchKernelGGL((rowstream48_kernel<KCV, NTTV, true, false, 0, true, false, true>), dim3(gx, slabs), dim3(256), 0, stream, x, (long)K, \
+                           stats_out, ln_w, ln_b, eps, W, bias, reinterpret_cast<float*>(out16), nullptr, M, N);                     \
+        return leod_launch_status();                                                                                                 \
+    }
+    O16_CASE(3, 9) O16_CASE(6, 9) O16_CASE(4, 12)
+#undef O16_CASE
+    return LEOD_ERR_UNSUPPORTED;
+}
+
 // out = res + gamma * (gelu(u16) W^T + bias)     (fc2 + LayerScale + residual on the fp16 pre-activation)
 LEOD_API int leod_linear_lsres_gelu16_fwd(const void* u16, const float* W, const float* bias, const float* gamma, const float* res,
                                           float* out, int M, int N, int K, hipStream_t stream) {

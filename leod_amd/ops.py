@@ -92,7 +92,7 @@ def _empty(shape, like: torch.Tensor, dtype=F32):
 # ---------------------------------------------------------------------------------------------------
 # backbone pieces
 # ---------------------------------------------------------------------------------------------------
-def ln_linear_fwd(x, ln_w, ln_b, W, bias, want_act=False, want_stats=False, eps=1e-5):
+def ln_linear_fwd(x, ln_w, ln_b, W, bias, want_act=False, want_stats=False, eps=1e-5, out_bf16=False):
     """x [.., K] -> out [.., N] = LN(x) W^T + b ; optional gelu(out), LN stats [M,2].
     With want_act in precision mode bf16 and a shape the row-streaming kernel covers (RVT stages 1-2) the result is
     (u as torch.float16, None, stats): pass that u to linear_lsres_fwd / linear_dgrad(aux_u=) / linear_wgrad(x=), which apply GELU."""
@@ -101,6 +101,14 @@ def ln_linear_fwd(x, ln_w, ln_b, W, bias, want_act=False, want_stats=False, eps=
     K = x.shape[-1]
     N = W.shape[0]
     M = x.numel() // K
+    if out_bf16 and not want_act and ln_w is not None:
+        # the qkv rows of stages 1-2 in precision mode bf16 (consumed only by bf16 MFMAs): stored as bf16 where the kernels allow
+        o16 = torch.empty(x.shape[:-1] + (N,), dtype=torch.bfloat16, device=x.device)
+        stats = _empty((M, 2), x)
+        rc = _l().leod_ln_linear_bf16_fwd(_p(x), _p(ln_w), _p(ln_b), eps, _p(W), _p(bias), _p(o16), _p(stats), M, N, K, _stream())
+        if rc != -3:
+            check(rc, 'ln_linear_bf16_fwd')
+            return o16, None, stats
     if want_act and want_stats and ln_w is not None and get_precision() == 'bf16':
         # precision mode bf16, stages 1-2: the hidden pre-activation is stored once, as fp16 (the reference's autocast dtype); consumers apply GELU on load
         u16 = torch.empty(x.shape[:-1] + (N,), dtype=torch.float16, device=x.device)
@@ -143,25 +151,33 @@ def linear_lsres_fwd(a, W, bias, gamma, res, want_t=True):
 
 def partition_attn_fwd(qkv, heads, part, window, want_lse=False):
     """qkv [B,H,W,3C] -> out [B,H,W,C] (+ lse [B,H,W,heads])."""
-    _ck(qkv, name='qkv')
+    q16 = qkv.dtype is torch.bfloat16
+    _ck(qkv, torch.bfloat16 if q16 else F32, 'qkv')
     B, H, W, C3 = qkv.shape
     C = C3 // 3
-    out = _empty((B, H, W, C), qkv)
-    lse = _empty((B, H, W, heads), qkv) if want_lse else None
+    out = torch.empty((B, H, W, C), dtype=F32, device=qkv.device)
+    lse = torch.empty((B, H, W, heads), dtype=F32, device=qkv.device) if want_lse else None
     check(_l().leod_partition_attn_fwd(_p(qkv), _p(out), _p(lse), B, H, W, C, heads, part[0], part[1],
-                                        1 if window else 0, _stream()), 'partition_attn_fwd')
+                                        1 if window else 0, 1 if q16 else 0, _stream()), 'partition_attn_fwd')
     return out, lse
 
 
+def partition_attn_16bit_ok(B, H, W, C, heads, part) -> bool:
+    """qkv may be handed to partition_attn_fwd / _bwd as torch.bfloat16 (and dqkv comes back as bfloat16) for this geometry."""
+    return BF16_GRADS and bool(_l().leod_partition_attn_16bit_ok(B, H, W, C, heads, part[0], part[1]))
+
+
 def partition_attn_bwd(qkv, dout, lse, heads, part, window):
-    for t, n in ((qkv, 'qkv'), (dout, 'dout'), (lse, 'lse')):
+    q16 = qkv.dtype is torch.bfloat16
+    _ck(qkv, torch.bfloat16 if q16 else F32, 'qkv')
+    for t, n in ((dout, 'dout'), (lse, 'lse')):
         _ck(t, name=n)
     B, H, W, C3 = qkv.shape
     C = C3 // 3
-    dqkv = _empty(qkv.shape, qkv)
-    dsum = _empty(lse.shape, qkv)
+    dqkv = torch.empty(qkv.shape, dtype=qkv.dtype, device=qkv.device)     # bf16 qkv <=> bf16 dqkv (partition_attn_16bit_ok)
+    dsum = torch.empty(lse.shape, dtype=F32, device=qkv.device)
     check(_l().leod_partition_attn_bwd(_p(qkv), _p(dout), _p(lse), _p(dsum), _p(dqkv), B, H, W, C, heads, part[0],
-                                        part[1], 1 if window else 0, _stream()), 'partition_attn_bwd')
+                                        part[1], 1 if window else 0, 1 if q16 else 0, 1 if q16 else 0, _stream()), 'partition_attn_bwd')
     return dqkv
 
 

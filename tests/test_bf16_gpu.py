@@ -97,6 +97,42 @@ def test_conv3x3_direct_bf16(bf16_ops, B, H, W, Cin, N):
     tk.close(dw, 2 * w.grad, what='conv3x3 wgrad accumulates')
 
 
+@pytest.mark.parametrize('B,H,W,C,heads', [(3, 16, 20, 48, 2), (2, 32, 40, 96, 4), (1, 8, 10, 384, 16)])
+@pytest.mark.parametrize('window', [True, False])
+def test_partition_attn_bf16_tensors(bf16_ops, B, H, W, C, heads, window):
+    """qkv handed over as bf16 and dqkv produced as bf16 (precision mode bf16, LDS attention kernels): q, k, v only ever enter bf16
+    MFMAs, so the results are those of the fp32-tensor path on the same (rounded) values -- checked against the fp32 CPU attention."""
+    ops = bf16_ops
+    part = (8, 10)
+    assert ops.partition_attn_16bit_ok(B, H, W, C, heads, part)
+    qkv16 = tk.rnd((B, H, W, 3 * C), 7).to(torch.bfloat16)
+    qkv = qkv16.float().requires_grad_(True)
+    ref = tk._attn_ref(qkv, heads, part, window)
+    dout = tk.rnd(ref.shape, 8)
+    ref.backward(dout)
+    q = qkv16.to(tk.DEV)
+    out, lse = ops.partition_attn_fwd(q, heads, part, window, want_lse=True)
+    tk.close(out, ref, what='attn fwd from bf16 qkv')
+    dq = ops.partition_attn_bwd(q, dout.to(tk.DEV), lse, heads, part, window)
+    assert dq.dtype is torch.bfloat16
+    tk.close(dq.float(), qkv.grad, what='bf16 dqkv')
+
+
+@pytest.mark.parametrize('M,N,K', [(40009, 144, 48), (20011, 288, 96)])
+def test_ln_qkv_bf16_rows(bf16_ops, M, N, K):
+    import torch.nn.functional as F
+    ops = bf16_ops
+    x, lw, lb = tk.rnd((M, K), 1), 1 + 0.2 * tk.rnd((K,), 2), 0.1 * tk.rnd((K,), 3)
+    W, b = tk.rnd((N, K), 4, 0.2), tk.rnd((N,), 5, 0.2)
+    ref = F.linear(F.layer_norm(x, (K,), lw, lb, 1e-5), W, b)
+    d = lambda t: t.to(tk.DEV)  # noqa
+    o16, _, st = ops.ln_linear_fwd(d(x), d(lw), d(lb), d(W), d(b), want_stats=True, out_bf16=True)
+    assert o16.dtype is torch.bfloat16 and st is not None
+    tk.close(o16.float(), ref, what='bf16 qkv rows')
+    mean = x.mean(1)
+    tk.close(st[:, 0], mean, rtol=1e-4, atol=1e-5, what='LayerNorm mean')
+
+
 @pytest.mark.parametrize('M,C', [(40009, 48), (20011, 96), (16384, 64)])
 def test_mlp_hidden_stored_once_as_fp16(bf16_ops, M, C):
     """Stages 1-2 in precision mode bf16: norm2 -> fc1 keeps the hidden pre-activation u once, as fp16 (no fp32 u, no gelu(u) copy);
