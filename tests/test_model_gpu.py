@@ -256,3 +256,49 @@ def test_gen4_geometries_fwd_bwd(gpu, size, full_res, T):
     params = dict(det.named_parameters())
     for k in bkeys:
         close(params[k].grad, osd[k].grad, rtol=3e-3, atol=1e-6, what='grad ' + k)
+
+
+def test_1mpx_training_step_and_nms_vs_oracle(gpu):
+    """BASELINE configs[3] past the backbone: RVT-base on 720x1280 frames (768x1280 padded, 20160 anchors, 3 classes), T = 2, bs = 1,
+    both frames labelled -- ONE full training step (backbone, PAFPN, head, SimOTA, losses, backward, clip + AdamW) against
+    ``OracleTrainer.step`` (modules/detection.py:188-298, yolo_head.py:403-597): six losses to 2e-5, identical SimOTA foreground
+    count; then the pseudo-label pass (head eval + postprocess / batched NMS, boxes.py:32-86) on the same frames: keep counts equal,
+    kept boxes to 2e-4."""
+    from oracle import postproc as op
+    from oracle.synth import synth_labels
+    from leod_amd.engine import TrainEngine, PseudoLabelEngine
+    det, sd, cfg = _build_gen4('base', True, 23)
+    in_hw = tuple(cfg.model.backbone.in_res_hw)
+    part = tuple(cfg.model.backbone.stage.attention.partition_size)
+    ocfg = ot.model_cfg(64, 32, 0.67, part, num_classes=3, in_res_hw=in_hw)
+    T, B, hw = 2, 1, (720, 1280)
+    ev = synth_events(T, B, 20, hw[0], hw[1], seed=41, as_uint8=True)
+    labs = [synth_labels(B, hw, 3, seed=50 + t, max_boxes=6) for t in range(T)]
+    labels = [[labs[t][b] for b in range(B)] for t in range(T)]
+    first = torch.ones(B, dtype=torch.bool)
+    otr = ot.OracleTrainer(sd, ocfg, total_steps=1000)
+    ref, _ = otr.step(ev, labels, first)
+    eng = TrainEngine(det, total_steps=1000)
+    flat = [labs[t][b] for t in range(T) for b in range(B)]
+    got = eng.step(ev.to(DEV), op.batched_yolox_labels(flat).to(DEV), [list(range(B)) for _ in range(T)], first.to(DEV))
+    keys = ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')
+    g = {k: float(got[k]) for k in keys}
+    assert g['num_fg'] == pytest.approx(ref['num_fg'], rel=1e-6), 'SimOTA foreground count differs'
+    for k in keys[:5]:
+        assert g[k] == pytest.approx(ref[k], rel=2e-5, abs=1e-6), (k, g[k], ref[k])
+    # inference + NMS on the 20160-anchor head (weights reloaded: the step above moved them)
+    det.load_state_dict(sd)
+    pl = PseudoLabelEngine(det, 3, conf_thre=0.01, obj_thresh=[0.05] * 3, cls_thresh=[0.05] * 3, hflip=False, max_det=8192,
+                           dataset_name='gen4', downsampled_by_2=False)
+    _, _, dets, cnt = pl.step(ev.to(DEV))
+    rdets, _, _ = ot.infer_sequence(sd, ocfg, ev, conf_thre=0.01, hflip=False)
+    assert [int(c) for c in cnt.cpu()] == [len(r) for r in rdets], 'NMS keep counts differ from the oracle'
+    for i, r in enumerate(rdets):
+        # 4800 kept boxes from random weights carry many near-equal scores: kept SETS are compared (every oracle box has exactly one
+        # partner within 2e-3 in all 7 columns), the score order up to swaps of neighbours whose scores agree to 1e-6
+        a, b = dets[i, :len(r)].cpu().numpy().astype(np.float64), r.numpy().astype(np.float64)
+        d = np.abs(a[None, :, :] - b[:, None, :]).max(-1)                  # [ref, got]
+        j = d.argmin(1)
+        assert d[np.arange(len(b)), j].max() < 2e-3 and len(set(j.tolist())) == len(b)
+        sc_a, sc_b = a[:, 4] * a[:, 5], b[:, 4] * b[:, 5]
+        assert np.all(np.diff(sc_a) <= 1e-6) and np.abs(sc_a - sc_b).max() < 1e-5
