@@ -11,6 +11,9 @@ from leod_amd.config import full_config, dynamically_modify_train_config
 from leod_amd.models.detection.yolox_extension.models.detector import YoloXDetector
 from leod_amd.engine import PseudoLabelEngine
 
+from leod_amd import ops
+ops.set_precision(os.environ.get('LEOD_PRECISION', 'bf16'))      # the engine-level driver does not go through Module.setup
+print('precision mode', ops.get_precision())
 dev = torch.device('cuda', 0)
 cfg = dynamically_modify_train_config(full_config('gen1', 'small'))
 torch.manual_seed(0)

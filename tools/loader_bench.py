@@ -48,6 +48,8 @@ def main():
     ap.add_argument('--root', default='/dev/shm/leod_synth')
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=4)
+    ap.add_argument('--io-threads', type=int, default=8)
+    ap.add_argument('--loader-only', action='store_true')
     args = ap.parse_args()
     t0 = time.time()
     base = make_dataset(args.root)
@@ -59,7 +61,7 @@ def main():
     from leod_amd.optim import fit_step
     cfg = dynamically_modify_train_config(full_config('gen1', 'small', overrides=dict(dataset=dict(path=base))))
     dm = DataModule(cfg.dataset, num_workers_train=cfg.hardware.num_workers.train, num_workers_eval=2,
-                    batch_size_train=cfg.batch_size.train, batch_size_eval=cfg.batch_size.eval, prefetch=4, io_threads=8)
+                    batch_size_train=cfg.batch_size.train, batch_size_eval=cfg.batch_size.eval, prefetch=4, io_threads=args.io_threads)
     dm.setup('fit')
     T, B = cfg.dataset.sequence_length, cfg.batch_size.train
     # (a) loader alone
@@ -70,6 +72,8 @@ def main():
             break
     dt = time.perf_counter() - t0
     print(f'loader alone : {n * T * B / dt:9.1f} event-frames/s ({1e3 * dt / n:.1f} ms/batch, {n * T * B * 20 * 240 * 304 / dt / 1e9:.2f} GB/s of voxels)')
+    if args.loader_only:
+        return
     dev = torch.device('cuda', 0)
     torch.manual_seed(0)
     module = fetch_model_module(cfg).to(dev)
