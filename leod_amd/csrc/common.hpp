@@ -130,6 +130,14 @@ __device__ __forceinline__ f4 unpack_bf16(s4 v) {           // 4 bf16 -> 4 fp32 
 }
 __device__ __forceinline__ f4 mfma16_bf16(s4 a, s4 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
 
+// v_mfma_f32_16x16x32_bf16: 8 bf16 per lane and operand (k = 8*(l>>4) .. +7); on gfx950 the 16-k form above issues at the same 16
+// cycles per instruction, i.e. at half the bf16 MFMA rate -- MFMA-bound kernels use this one.
+typedef short s8v __attribute__((ext_vector_type(8)));
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f4 mfma32_bf16(s8v a, s8v b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
+}
+
 // Operand fragment of one 16-k chunk in either precision: BF = false keeps the f4 (four exact fp32 MFMAs consume it),
 // BF = true packs it to 4 bf16 once (one bf16 MFMA consumes it).
 template <bool BF> struct Frag16;

@@ -35,11 +35,6 @@ __global__ __launch_bounds__(256) void conv3_pack_kernel(const float* __restrict
 // KC = input channels / 16, NTO = output column tiles (16 channels each) per workgroup, TW = row tiles per wave (ceil(10 / 4))
 // K32 (Cin % 32 == 0): v_mfma_f32_16x16x32_bf16 (8 bf16 per lane and operand, 16-byte fragment reads) -- on gfx950 the 16x16x16 form
 // issues at the same 16 cycles per instruction, i.e. at half the bf16 MFMA rate
-typedef short s8v __attribute__((ext_vector_type(8)));
-typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f4 mfma32_bf16(s8v a, s8v b, f4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
-}
 
 template <int KC, int NTO, int TW>
 __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wp, float* __restrict__ y,
