@@ -260,27 +260,29 @@ __global__ __launch_bounds__(256, (KC == 3 && NTT <= 9) ? 3 : 2) void rowstream4
 // ---------------------------------------------------------------------------------------------------------------------
 // AF = 1 (MODE 0, precision mode bf16): x is the fp16 pre-activation of the MLP hidden, A = gelu(x) evaluated on the fragments.
 // AF = 2 (MODE 1 / 2): x is a bf16 gradient (du / dqkv): its fragments ARE the MFMA operands.
-template <int KC, int MODE, bool BF = false, int AF = 0>
-__global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* __restrict__ x, const float* __restrict__ W,
+// NTN = output column tiles: 3 (48 columns, stage 1: 4 waves, two workgroups per CU) or 6 (96 columns, stage 2, bf16 mode with
+// 16-bit A rows only: 8 waves, the 75 KB weight tile allows one workgroup per CU).
+template <int KC, int MODE, bool BF = false, int AF = 0, int NTN = 3>
+__global__ __launch_bounds__(NTN == 3 ? 256 : 512, NTN == 3 ? 2 : 1) void rowstream_narrow_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                                   const float* __restrict__ bias, const float* __restrict__ gamma,
                                                                   const float* __restrict__ res, float* __restrict__ out, int M,
                                                                   const float* __restrict__ xin = nullptr,
                                                                   const float* __restrict__ stats = nullptr,
                                                                   float* __restrict__ dgamma = nullptr, float* __restrict__ dbeta = nullptr) {
-    constexpr int K = 16 * KC, LD = K + 8, N = 48, LDO = 52;
+    constexpr int K = 16 * KC, LD = K + 8, N = 16 * NTN, LDO = N + 4, NWV = NTN == 3 ? 4 : 8, NTHR = 64 * NWV, F4R = N / 4;
     __shared__ __attribute__((aligned(16))) float sW[BF ? (N * LD) / 2 : N * LD];
-    __shared__ __attribute__((aligned(16))) float sO[4][16 * LDO];
+    __shared__ __attribute__((aligned(16))) float sO[NWV][16 * LDO];
     unsigned short* sWh = reinterpret_cast<unsigned short*>(sW);        // BF: [N][LD] bf16 (see rowstream48_kernel)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     if (MODE == 0) {
-        for (int e = tid; e < N * (K / 4); e += 256) {
+        for (int e = tid; e < N * (K / 4); e += NTHR) {
             const int n = e / (K / 4), k4 = (e - n * (K / 4)) * 4;
             if constexpr (BF) *reinterpret_cast<s4*>(&sWh[n * LD + k4]) = pack_bf16(ld4(W + (long)n * K + k4));
             else *reinterpret_cast<f4*>(&sW[n * LD + k4]) = ld4(W + (long)n * K + k4);
         }
     } else {
-        for (int e = tid; e < K * (N / 4); e += 256) {
+        for (int e = tid; e < K * (N / 4); e += NTHR) {
             const int k = e / (N / 4), n4 = (e - k * (N / 4)) * 4;
             const f4 w = ld4(W + (long)k * N + n4);
             if constexpr (BF) {
@@ -293,22 +295,24 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
             }
         }
     }
-    int lr[3], c4[3];
-    f4 b4[3], g4[3];
+    int lr[NTN], c4[NTN];
+    f4 b4[NTN], g4[NTN];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < NTN; ++p) {
         const int idx = 64 * p + lane;
-        lr[p] = idx / 12; c4[p] = idx - lr[p] * 12;
+        lr[p] = idx / F4R; c4[p] = idx - lr[p] * F4R;
         b4[p] = (MODE == 0 && bias) ? ld4(bias + 4 * c4[p]) : zero4();
         g4[p] = (MODE == 0 && gamma) ? ld4(gamma + 4 * c4[p]) : f4{1.f, 1.f, 1.f, 1.f};
     }
-    float lnw[3] = {1.f, 1.f, 1.f}, agam[3] = {0.f, 0.f, 0.f}, abet[3] = {0.f, 0.f, 0.f};
+    float lnw[NTN], agam[NTN], abet[NTN];
+#pragma unroll
+    for (int t = 0; t < NTN; ++t) { lnw[t] = 1.f; agam[t] = 0.f; abet[t] = 0.f; }
     if (MODE == 2) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t) lnw[t] = gamma[16 * t + i];                 // LayerNorm weight of column 16t + i
+        for (int t = 0; t < NTN; ++t) lnw[t] = gamma[16 * t + i];                 // LayerNorm weight of column 16t + i
     }
     __syncthreads();
-    const int stride = gridDim.x * 4;
+    const int stride = gridDim.x * NWV;
     float* so = sO[wave];
     typedef typename std::conditional<AF != 0, s4, f4>::type AFrag;
     struct Frag { AFrag a[KC]; };
@@ -327,15 +331,15 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
     auto compute = [&](const Frag& f, int tile, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         const long row0 = (long)tile * 16;
-        f4 r4[3];
+        f4 r4[NTN];
         if (MODE == 0 || (MODE == 2 && res)) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NTN; ++p) {
                 const long row = FULL ? row0 + lr[p] : min(row0 + lr[p], (long)M - 1);
                 r4[p] = ld4(res + row * N + 4 * c4[p]);
             }
         }
-        float xi[3][4], mean[4], rstd[4];
+        float xi[NTN][4], mean[4], rstd[4];
         if (MODE == 2) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -343,10 +347,12 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
                 const float2 st = *reinterpret_cast<const float2*>(stats + 2 * row);
                 mean[r] = st.x; rstd[r] = st.y;
 #pragma unroll
-                for (int t = 0; t < 3; ++t) xi[t][r] = xin[row * N + 16 * t + i];
+                for (int t = 0; t < NTN; ++t) xi[t][r] = xin[row * N + 16 * t + i];
             }
         }
-        f4 acc[3] = {zero4(), zero4(), zero4()};
+        f4 acc[NTN];
+#pragma unroll
+        for (int t = 0; t < NTN; ++t) acc[t] = zero4();
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
             if constexpr (BF) {
@@ -359,11 +365,11 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
                     pa = pack_bf16(u);
                 } else pa = pack_bf16(f.a[c]);
 #pragma unroll
-                for (int t = 0; t < 3; ++t)
+                for (int t = 0; t < NTN; ++t)
                     acc[t] = mfma16_bf16(pa, *reinterpret_cast<const s4*>(&sWh[(16 * t + i) * LD + 16 * c + 4 * q]), acc[t]);
             } else if constexpr (AF == 0) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
+            for (int t = 0; t < NTN; ++t) {
                 const f4 b = *reinterpret_cast<const f4*>(&sW[(16 * t + i) * LD + 16 * c + 4 * q]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[t] = mfma16(f.a[c][j], b[j], acc[t]);
@@ -374,9 +380,9 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool live = FULL || row0 + 4 * q + r < M;
-                float s1 = 0.f, s2 = 0.f, xh[3], gw[3];
+                float s1 = 0.f, s2 = 0.f, xh[NTN], gw[NTN];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
+                for (int t = 0; t < NTN; ++t) {
                     const float dn = live ? acc[t][r] : 0.f;
                     xh[t] = (xi[t][r] - mean[r]) * rstd[r];
                     gw[t] = dn * lnw[t];
@@ -386,19 +392,19 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
                 s1 = row16_sum(s1) * (1.0f / N);
                 s2 = row16_sum(s2) * (1.0f / N);
 #pragma unroll
-                for (int t = 0; t < 3; ++t) acc[t][r] = (gw[t] - s1 - xh[t] * s2) * rstd[r];
+                for (int t = 0; t < NTN; ++t) acc[t][r] = (gw[t] - s1 - xh[t] * s2) * rstd[r];
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private tile: compiler ordering only (see above)
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < NTN; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) so[(4 * q + r) * LDO + 16 * t + i] = acc[t][r];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NTN; ++p) {
             f4 v = *reinterpret_cast<const f4*>(&so[lr[p] * LDO + 4 * c4[p]]);
             if (MODE == 0) v = r4[p] + g4[p] * (v + b4[p]);
             if (MODE == 2 && res) v = v + r4[p];
@@ -406,26 +412,40 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
         }
     };
     const int nfull = M / 16;
-    int tile = blockIdx.x * 4 + wave;
-    Frag f0, f1, f2;
-    load(f0, tile);
-    load(f1, tile + stride);
+    int tile = blockIdx.x * NWV + wave;
     const std::true_type full{};
-    while (true) {
-        load(f2, tile + 2 * stride);
-        if (tile >= nfull) break;
-        compute(f0, tile, full); tile += stride;
-        load(f0, tile + 2 * stride);
-        if (tile >= nfull) { f0 = f1; break; }
-        compute(f1, tile, full); tile += stride;
-        load(f1, tile + 2 * stride);
-        if (tile >= nfull) { f0 = f2; break; }
-        compute(f2, tile, full); tile += stride;
+    if constexpr (NTN == 3) {                                 // fragments two tiles ahead (three register sets)
+        Frag f0, f1, f2;
+        load(f0, tile);
+        load(f1, tile + stride);
+        while (true) {
+            load(f2, tile + 2 * stride);
+            if (tile >= nfull) break;
+            compute(f0, tile, full); tile += stride;
+            load(f0, tile + 2 * stride);
+            if (tile >= nfull) { f0 = f1; break; }
+            compute(f1, tile, full); tile += stride;
+            load(f1, tile + 2 * stride);
+            if (tile >= nfull) { f0 = f2; break; }
+            compute(f2, tile, full); tile += stride;
+        }
+        if (tile == nfull && (M & 15)) compute(f0, tile, std::false_type{});
+    } else {                                                  // 96 columns: one tile ahead (two sets: a third would spill), 8 waves per CU
+        Frag f0, f1;
+        load(f0, tile);
+        while (true) {
+            load(f1, tile + stride);
+            if (tile >= nfull) break;
+            compute(f0, tile, full); tile += stride;
+            load(f0, tile + stride);
+            if (tile >= nfull) { f0 = f1; break; }
+            compute(f1, tile, full); tile += stride;
+        }
+        if (tile == nfull && (M & 15)) compute(f0, tile, std::false_type{});
     }
-    if (tile == nfull && (M & 15)) compute(f0, tile, std::false_type{});
     if (MODE == 2) {                                         // column sums of this wave: over the 4 row groups, then one atomic
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < NTN; ++t) {
             float a = agam[t], b = abet[t];
             a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
             b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
@@ -436,6 +456,11 @@ __global__ __launch_bounds__(256, 2) void rowstream_narrow_kernel(const float* _
 static inline bool use_rowstream_narrow(int M, int Kc, int Nout) {
     static const int on = getenv("LEOD_ROWSTREAM") ? atoi(getenv("LEOD_ROWSTREAM")) : 2;
     return on >= 2 && M >= 16384 && Nout == 48 && (Kc == 144 || Kc == 192);
+}
+// stage 2 of RVT-S in precision mode bf16: 16-bit A rows (fp16 hidden, bf16 du / dqkv), 288 / 384 -> 96 columns
+static inline bool use_rowstream_narrow96(int M, int Kc, int Nout) {
+    static const int on = getenv("LEOD_ROWSTREAM96") ? atoi(getenv("LEOD_ROWSTREAM96")) : 1;
+    return on && leod_precision() == 1 && M >= 16384 && Nout == 96 && (Kc == 288 || Kc == 384);
 }
 template <int MODE>
 static int launch_rowstream_narrow(const float* x, const float* W, const float* bias, const float* gamma, const float* res,
@@ -615,6 +640,12 @@ LEOD_API int leod_linear_dgrad_lnbwd(const float* dy, const float* W, const floa
                                      const float* dres, float* dx, float* dgamma, float* dbeta, int M, int N, int K, int dy_bf16,
                                      hipStream_t stream) {
     if (!dy || !W || !x || !stats || !ln_w || !dx || !dgamma || !dbeta) return LEOD_ERR_ARG;
+    if (dy_bf16 && use_rowstream_narrow96(M, N, K)) {
+        const dim3 g96(min(cdiv(cdiv(M, 16), 8), 256));
+        if (N == 384) hipLaunchKernelGGL((rowstream_narrow_kernel<24, 2, true, 2, 6>), g96, dim3(512), 0, stream, dy, W, nullptr, ln_w, dres, dx, M, x, stats, dgamma, dbeta);
+        else hipLaunchKernelGGL((rowstream_narrow_kernel<18, 2, true, 2, 6>), g96, dim3(512), 0, stream, dy, W, nullptr, ln_w, dres, dx, M, x, stats, dgamma, dbeta);
+        return leod_launch_status();
+    }
     if (!use_rowstream_narrow(M, N, K)) return LEOD_ERR_UNSUPPORTED;
     const int grid = min(cdiv(cdiv(M, 16), 4), 256 * 2);
     if (dy_bf16) {
@@ -686,6 +717,10 @@ LEOD_API int leod_linear_lsres_gelu16_fwd(const void* u16, const float* W, const
                                           float* out, int M, int N, int K, hipStream_t stream) {
     if (!u16 || !W || !res || !out || (K & 3) || leod_precision() != 1) return LEOD_ERR_ARG;
     const float* a = reinterpret_cast<const float*>(u16);
+    if (K == 384 && use_rowstream_narrow96(M, K, N)) {
+        hipLaunchKernelGGL((rowstream_narrow_kernel<24, 0, true, 1, 6>), dim3(min(cdiv(cdiv(M, 16), 8), 256)), dim3(512), 0, stream, a, W, bias, gamma, res, out, M);
+        return leod_launch_status();
+    }
     if (use_rowstream_narrow(M, K, N)) {
         const int grid = min(cdiv(cdiv(M, 16), 4), 256 * 2);
         if (K == 192) hipLaunchKernelGGL((rowstream_narrow_kernel<12, 0, true, 1>), dim3(grid), dim3(256), 0, stream, a, W, bias, gamma, res, out, M);

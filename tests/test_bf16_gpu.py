@@ -280,3 +280,26 @@ def test_linear_dgrad_ln_bwd_bf16(bf16_ops, M, N, K, with_res):
 
 def test_conv_bn_bf16(bf16_ops):
     tk.test_conv_bn_eval_and_train(bf16_ops, 8)
+
+
+@pytest.mark.parametrize('M,N,K,with_res', [(40009, 192, 48, True), (20011, 144, 48, False),       # stage 1: narrow row-streaming kernel
+                                            (20011, 288, 96, True), (16400, 384, 96, True),         # stage 2: its 96-column form
+                                            (5000, 288, 96, True)])                                 # two-kernel fallback
+def test_linear_dgrad_ln_bwd_from_bf16_rows(bf16_ops, M, N, K, with_res):
+    """dgrad of (LayerNorm -> Linear) with the LayerNorm backward in the epilogue, fed by bf16 gradient rows (du / dqkv of precision
+    mode bf16): against autograd on the same (rounded) rows."""
+    import torch.nn.functional as F
+    ops = bf16_ops
+    x = tk.rnd((M, K), 1).requires_grad_(True)
+    lw, lb = (1 + 0.2 * tk.rnd((K,), 2)).requires_grad_(True), (0.1 * tk.rnd((K,), 3)).requires_grad_(True)
+    W = tk.rnd((N, K), 4, 0.2)
+    dy16 = tk.rnd((M, N), 5).to(torch.bfloat16)
+    dres = tk.rnd((M, K), 6)
+    F.linear(F.layer_norm(x, (K,), lw, lb, 1e-5), W).backward(dy16.float())
+    d = lambda t: t.detach().to(tk.DEV)  # noqa
+    _, st = ops.layernorm_fwd(d(x), d(lw), d(lb), want_stats=True)
+    dw, db = torch.zeros(K, device=tk.DEV), torch.zeros(K, device=tk.DEV)
+    dx = ops.linear_dgrad_ln_bwd(dy16.to(tk.DEV), W.to(tk.DEV), d(x), st, d(lw), d(dres) if with_res else None, dw, db)
+    tk.close(dx, x.grad + (dres if with_res else 0), what='dx')
+    tk.close(dw, lw.grad, what='d ln weight')
+    tk.close(db, lb.grad, what='d ln bias')
