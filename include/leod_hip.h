@@ -86,18 +86,24 @@ int leod_convlstm_gates_bwd(const float* dh, const float* dh2, const float* dc_n
 
 /* The ConvLSTM recurrence of a whole sequence in ONE launch per direction (same cell as leod_convlstm_fwd, unrolled over the L
  * timesteps of modules/detection.py:188-226): one workgroup carries 16 rows through all T timesteps with its slice of the weights
- * resident in registers.  leod_convlstm_seq_mode(C): 1 = xin is x_seq [T,M,C] (fused [x|h] contraction), 2 = xin is the
+ * resident in registers.  leod_convlstm_seq_mode(C): 1 = xin is x_seq [T,M,C] (fused [x|h] contraction), 2 / 3 = xin is the
  * time-batched projection gx [T,M,4C] = x W_x^T + b computed by the caller, 0 = not available for this C / precision mode
  * (callers then loop leod_convlstm_fwd).  hbuf, cbuf [T+1,M,C]: slot 0 = incoming state (zero_state: taken as zeros, not read),
  * slots 1..T are written; gates_out [T,M,4,C] optional. */
 int leod_convlstm_seq_mode(int C);
+/* mode 3 (C = 256 / 384 in precision mode bf16: the weight slice of a wave does not fit its registers): like mode 2, and the waves
+ * stream their MFMA B fragments from a fragment-ordered bf16 copy of W_h -- leod_convlstm_seq_pack writes it (once per step, shared by
+ * forward and backward) into a buffer of leod_convlstm_seq_pack_bytes(C) bytes, passed as wpack (NULL in modes 1 / 2). */
+long leod_convlstm_seq_pack_bytes(int C);
+int leod_convlstm_seq_pack(const float* W, void* wpack, int C, leod_stream_t stream);
 int leod_convlstm_seq_fwd(const float* xin, int x_is_projection, float* hbuf, float* cbuf, const float* W, const float* bias,
-                          float* gates_out, int M, int C, int T, int zero_state, leod_stream_t stream);
+                          float* gates_out, const void* wpack, int M, int C, int T, int zero_state, leod_stream_t stream);
 /* Backward through time of the same: dh_seq [T,M,C] (optional) gradients of every h_t from above, dc_last [M,C] (optional);
  * writes dgates_out [T,M,4C] (pre-activation; dx = dgates W_x and the weight gradient are one GEMM each over all T*M rows)
  * and optionally dh0 / dc0 [M,C].  LEOD_ERR_UNSUPPORTED (-3) when the weight slice does not fit the registers. */
 int leod_convlstm_seq_bwd(const float* dh_seq, const float* dc_last, const float* gates, const float* cbuf, const float* W,
-                          float* dgates_out, float* dh0, float* dc0, int M, int C, int T, int zero_state, leod_stream_t stream);
+                          float* dgates_out, float* dh0, float* dc0, const void* wpack, int M, int C, int T, int zero_state,
+                          leod_stream_t stream);
 
 /* dy_bf16 (here and in leod_linear_wgrad / leod_linear_dgrad_lnbwd): dy points to bf16 elements -- in precision mode bf16 the wide
  * gradients du (out_bf16 of leod_linear_dgrad_gelu16) and dqkv are stored as the bf16 their consumers feed to the MFMAs anyway.

@@ -273,13 +273,243 @@ __global__ __launch_bounds__(C * 4) void lstm_seq_bwd_kernel(const float* __rest
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Stage 4 (C = 384; also 256): the weight slice of a wave no longer fits its registers (4 gates x 24 chunks per 16 channels, and a
+// workgroup can have at most 16 waves).  Same structure -- one workgroup per 16-row tile for all T timesteps, h exchanged through
+// LDS, one barrier per timestep -- but every wave owns 32 channels (two groups of 16) and STREAMS its B fragments from a bf16
+// copy of W_h packed in fragment order (512 contiguous bytes per wave load, L2-resident: 1.2 MB for C = 384), four chunks (forward) / eight (backward) ahead in
+// a second register set.  Only 40 workgroups exist for RVT-S (640 rows per timestep), so the per-timestep launches it replaces
+// (33 + 28 us per timestep for a few hundred kilobytes of state) were pure latency; here a timestep costs the L2 -> CU stream of
+// the slice.  bf16 mode, hoisted x projection (xin = gx) only.
+// ---------------------------------------------------------------------------------------------------------------------
+// wpf[((w*2 + grp)*KC + kc)*4 + g][lane] = bf16 W[g*C + 32w + 16grp + i][C + 16kc + 4q .. +3]          (forward, KC = C/16)
+// wpb[(w*2 + grp)*4KC + kc][lane]        = bf16 (W[16kc + 4q + j][C + 32w + 16grp + i]), j = 0..3        (backward)
+__global__ __launch_bounds__(256) void lstm_pack_kernel(const float* __restrict__ W, s4* __restrict__ wpf, s4* __restrict__ wpb, int C) {
+    const int KC = C / 16, NWV = C / 32;
+    const int nf = NWV * 2 * KC * 4 * 64, nb = NWV * 2 * 4 * KC * 64;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < nf + nb; e += gridDim.x * 256) {
+        if (e < nf) {
+            const int lane = e & 63, g = (e >> 6) & 3, r = e >> 8, kc = r % KC, wg = r / KC;      // wg = w*2 + grp
+            const int i = lane & 15, q = lane >> 4;
+            wpf[e] = pack_bf16(ld4(W + (long)(g * C + 16 * wg + i) * (2 * C) + C + 16 * kc + 4 * q));
+        } else {
+            const int o = e - nf, lane = o & 63, r = o >> 6, kc = r % (4 * KC), wg = r / (4 * KC);
+            const int i = lane & 15, q = lane >> 4;
+            const float* wr = W + (long)(16 * kc + 4 * q) * (2 * C) + C + 16 * wg + i;
+            const f4 w = {wr[0], wr[2 * C], wr[4 * C], wr[6 * C]};
+            wpb[o] = pack_bf16(w);
+        }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(C * 2) void lstm_seq_fwd_stream_kernel(const float* __restrict__ gxin, float* __restrict__ hbuf, float* __restrict__ cbuf,
+                                                                     const s4* __restrict__ wpf, float* __restrict__ gates_out, int M, int T,
+                                                                     int zero_state) {
+    constexpr int KC = C / 16, LD = C + 8, NB = 4, NBT = KC / NB;           // NB chunks per register batch
+    static_assert(KC % NB == 0, "chunk batches");
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][16 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const long row0 = (long)blockIdx.x * 16;
+    const long MC = (long)M * C;
+    unsigned oc[2][4]; bool rok[4];      // unsigned: zero-extended offsets address as scalar base + 32-bit lane offset (no 64-bit address pair per access)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        rok[r] = row0 + 4 * q + r < M;
+        const int row = (int)(rok[r] ? row0 + 4 * q + r : (long)M - 1);
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) oc[grp][r] = (unsigned)(row * C + 32 * wave + 16 * grp + i);
+    }
+    float cst[2][4];
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            cst[grp][r] = zero_state ? 0.f : cbuf[oc[grp][r]];
+            sA[0][(4 * q + r) * LD + 32 * wave + 16 * grp + i] = to_bf16(zero_state ? 0.f : hbuf[oc[grp][r]]);
+        }
+    __syncthreads();
+    // wave-uniform base (scalar registers) + lane: the 192 fragment loads of a timestep address as SGPR base + lane offset + immediate;
+    // a per-lane 64-bit pointer made the compiler keep one address pair per load (1.5 KB of spills per lane)
+    const s4* wb0 = wpf + (long)(__builtin_amdgcn_readfirstlane(wave) * 2) * KC * 4 * 64;        // [grp][kc][g][64 lanes]
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        // the fragment addresses are the same every timestep: without this the compiler hoists all 192 loads out of the time loop and
+        // parks the VALUES in scratch (1.5 KB per lane = a private 1.15 MB copy of the slice per workgroup)
+        const s4* wb = wb0;
+        asm volatile("" : "+s"(wb));
+        const float* gp = gxin + (long)t * M * 4 * C;
+        float* hp = hbuf + (long)(t + 1) * MC;
+        float* cp = cbuf + (long)(t + 1) * MC;
+        float* go = gates_out ? gates_out + (long)t * M * 4 * C : nullptr;
+        const unsigned short* arow = &sA[buf][i * LD + 4 * q];
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) {                    // one channel group at a time: 4 accumulator tiles live
+            const unsigned ch = 32 * wave + 16 * grp + i;
+            // derived offsets (4 oc - 3 ch + g C ...) are recomputed per timestep: hoisted out of the time loop they cost ~150 registers
+            unsigned ocg[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ocg[r] = oc[grp][r]; asm volatile("" : "+v"(ocg[r])); }
+            s4 bb[2][NB][4];
+            auto loadb = [&](s4 (&b)[NB][4], int bt) {
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) b[k][g] = wb[((grp * KC + bt * NB + k) * 4 + g) * 64 + lane];
+            };
+            loadb(bb[0], 0);
+            f4 acc[4];                                          // the x projection of the group's gate columns, in accumulator layout
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[g][r] = gp[4u * ocg[r] - 3u * ch + (unsigned)(g * C)];
+#pragma unroll
+            for (int bt = 0; bt < NBT; ++bt) {
+                __builtin_amdgcn_sched_barrier(0);             // keep the scheduler from hoisting every batch's loads to the top
+                if (bt + 1 < NBT) loadb(bb[(bt + 1) & 1], bt + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    const s4 a = *reinterpret_cast<const s4*>(arow + 16 * (bt * NB + k));
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = mfma16_bf16(a, bb[bt & 1][k][g], acc[g]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float f = sigmoidf_(acc[0][r]), ig = sigmoidf_(acc[1][r]), o = sigmoidf_(acc[2][r]);
+                const float g = tanh_<true>(acc[3][r]);
+                const float cn = f * cst[grp][r] + ig * g;
+                const float hn = o * tanh_<true>(cn);
+                cst[grp][r] = cn;
+                sA[buf ^ 1][(4 * q + r) * LD + ch] = to_bf16(hn);
+                if (rok[r]) {
+                    hp[ocg[r]] = hn;
+                    cp[ocg[r]] = cn;
+                    if (go) {
+                        float* gr = go + (4u * ocg[r] - 3u * ch);
+                        gr[0] = f; gr[C] = ig; gr[2 * C] = o; gr[3 * C] = g;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(C * 2) void lstm_seq_bwd_stream_kernel(const float* __restrict__ dh_seq, const float* __restrict__ dc_last,
+                                                                     const float* __restrict__ gates, const float* __restrict__ cbuf,
+                                                                     const s4* __restrict__ wpb, float* __restrict__ dgates_out,
+                                                                     float* __restrict__ dh0, float* __restrict__ dc0, int M, int T) {
+    constexpr int KA = 4 * C, KC = KA / 16, LD = KA + 8, NB = 8, NBT = KC / NB;
+    static_assert(KC % NB == 0, "chunk batches");
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][16 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const long row0 = (long)blockIdx.x * 16;
+    const long MC = (long)M * C;
+    unsigned oc[2][4]; bool rok[4];      // unsigned: zero-extended offsets address as scalar base + 32-bit lane offset (no 64-bit address pair per access)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        rok[r] = row0 + 4 * q + r < M;
+        const int row = (int)(rok[r] ? row0 + 4 * q + r : (long)M - 1);
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) oc[grp][r] = (unsigned)(row * C + 32 * wave + 16 * grp + i);
+    }
+    float dcn[2][4], dhr[2][4];
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dcn[grp][r] = dc_last ? dc_last[oc[grp][r]] : 0.f; dhr[grp][r] = 0.f; }
+    const s4* wb0 = wpb + (long)(__builtin_amdgcn_readfirstlane(wave) * 2) * KC * 64;              // [grp][kc][64 lanes], wave-uniform base
+    for (int t = T - 1; t >= 0; --t) {
+        const int buf = t & 1;
+        const s4* wb = wb0;
+        asm volatile("" : "+s"(wb));                          // see the forward kernel: keeps the fragment loads inside the time loop
+        const float* gp = gates + (long)t * M * 4 * C;
+        const float* c0 = cbuf + (long)t * MC;
+        float* dgp = dgates_out + (long)t * M * 4 * C;
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) {
+            const unsigned ch = 32 * wave + 16 * grp + i;
+            float gg[4][4], cpv[4], ctv[4], dhv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float* gr = gp + (4u * oc[grp][r] - 3u * ch);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gg[g][r] = gr[g * C];
+                cpv[r] = c0[oc[grp][r]];
+                ctv[r] = c0[MC + oc[grp][r]];
+                dhv[r] = dh_seq ? dh_seq[(long)t * MC + oc[grp][r]] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float f = gg[0][r], ig = gg[1][r], o = gg[2][r], g = gg[3][r];
+                const float th = tanh_<true>(ctv[r]);
+                const float dh = dhv[r] + dhr[grp][r];
+                const float dc = dh * o * (1.0f - th * th) + dcn[grp][r];
+                const float d0 = dc * cpv[r] * f * (1.0f - f), d1 = dc * g * ig * (1.0f - ig);
+                const float d2 = dh * th * o * (1.0f - o), d3 = dc * ig * (1.0f - g * g);
+                dcn[grp][r] = dc * f;
+                unsigned short* ar = &sA[buf][(4 * q + r) * LD + ch];
+                ar[0] = to_bf16(d0); ar[C] = to_bf16(d1); ar[2 * C] = to_bf16(d2); ar[3 * C] = to_bf16(d3);
+                if (rok[r]) {
+                    float* dr = dgp + (4u * oc[grp][r] - 3u * ch);
+                    dr[0] = d0; dr[C] = d1; dr[2 * C] = d2; dr[3 * C] = d3;
+                }
+            }
+        }
+        __syncthreads();
+        // dh_{t-1}[rows, own 32 channels] = dgates_t [16 x 4C] . W_h[4C x 32]: A fragments shared by the two channel groups
+        f4 acc[2] = {zero4(), zero4()};
+        s4 bb[2][NB][2];
+        auto loadb = [&](s4 (&b)[NB][2], int bt) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+#pragma unroll
+                for (int grp = 0; grp < 2; ++grp) b[k][grp] = wb[(grp * KC + bt * NB + k) * 64 + lane];
+        };
+        const unsigned short* arow = &sA[buf][i * LD + 4 * q];
+        loadb(bb[0], 0);
+#pragma unroll
+        for (int bt = 0; bt < NBT; ++bt) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (bt + 1 < NBT) loadb(bb[(bt + 1) & 1], bt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const s4 a = *reinterpret_cast<const s4*>(arow + 16 * (bt * NB + k));
+#pragma unroll
+                for (int grp = 0; grp < 2; ++grp) acc[grp] = mfma16_bf16(a, bb[bt & 1][k][grp], acc[grp]);
+            }
+        }
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dhr[grp][r] = acc[grp][r];
+    }
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (rok[r]) {
+                if (dh0) dh0[oc[grp][r]] = dhr[grp][r];
+                if (dc0) dc0[oc[grp][r]] = dcn[grp][r];
+            }
+}
+
 // registers of the resident B fragments per lane: 4 gates x K/16 chunks x (2 | 4) dwords
 static inline int fwd_bregs(int K, bool bf) { return 4 * (K / 16) * (bf ? 2 : 4); }
 
-/* 1 = fused [x | h] contraction, 2 = hoisted x projection (xin = gx), 0 = sequence kernel not available for this C / precision */
+/* 1 = fused [x | h] contraction, 2 = hoisted x projection (xin = gx), 3 = hoisted + streamed weights (wpack from leod_convlstm_seq_pack),
+ * 0 = sequence kernel not available for this C / precision */
 LEOD_API int leod_convlstm_seq_mode(int C) {
     if (getenv("LEOD_LSTM_SEQ") && atoi(getenv("LEOD_LSTM_SEQ")) == 0) return 0;
     const bool bf = leod_precision() == 1;
+    static const int stream_on = getenv("LEOD_LSTM_STREAM") ? atoi(getenv("LEOD_LSTM_STREAM")) : 1;
+    if (bf && stream_on && (C == 256 || C == 384)) return 3;               // hoisted x projection + weights streamed from a packed bf16 copy
     if (C != 32 && C != 48 && C != 64 && C != 96 && C != 128 && C != 192) return 0;
     if (fwd_bregs(2 * C, bf) <= 96) return 1;                               // beyond ~100 resident registers the kernels spill
     if (fwd_bregs(C, bf) <= (C >= 192 ? 96 : 128)) return 2;
@@ -293,11 +523,30 @@ LEOD_API int leod_convlstm_seq_mode(int C) {
         return leod_launch_status();                                                                                            \
     }
 
+// bytes of the packed bf16 weight copy mode 3 needs (0 otherwise)
+LEOD_API long leod_convlstm_seq_pack_bytes(int C) { return leod_convlstm_seq_mode(C) == 3 ? (long)2 * 4 * C * C * 2 : 0; }
+
+// wpack <- the two fragment-ordered bf16 copies of W_h (once per step: forward and backward of the same weights share it)
+LEOD_API int leod_convlstm_seq_pack(const float* W, void* wpack, int C, hipStream_t stream) {
+    if (!W || !wpack || leod_convlstm_seq_mode(C) != 3) return LEOD_ERR_ARG;
+    s4* wpf = reinterpret_cast<s4*>(wpack);
+    hipLaunchKernelGGL(lstm_pack_kernel, dim3(cdiv((long)2 * C * C, 256)), dim3(256), 0, stream, W, wpf, wpf + (long)C * C, C);
+    return leod_launch_status();
+}
+
 LEOD_API int leod_convlstm_seq_fwd(const float* xin, int x_is_projection, float* hbuf, float* cbuf, const float* W, const float* bias,
-                                   float* gates_out, int M, int C, int T, int zero_state, hipStream_t stream) {
+                                   float* gates_out, const void* wpack, int M, int C, int T, int zero_state, hipStream_t stream) {
     if (!xin || !hbuf || !cbuf || !W || !bias || M <= 0 || T <= 0 || (long)M * 4 * C >= (1L << 31)) return LEOD_ERR_ARG;
     const int mode = leod_convlstm_seq_mode(C);
     if (mode == 0 || (mode == 1) != (x_is_projection == 0)) return LEOD_ERR_UNSUPPORTED;
+    if (mode == 3) {
+        if (!wpack) return LEOD_ERR_ARG;
+        const s4* wpf = reinterpret_cast<const s4*>(wpack);
+        const dim3 g3(cdiv(M, 16));
+        if (C == 384) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<384>), g3, dim3(768), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
+        else hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<256>), g3, dim3(512), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
+        return leod_launch_status();
+    }
     const bool bf = leod_precision() == 1, fx = mode == 1;
     const dim3 grid(cdiv(M, 16));
     LSTM_FWD_CASE(32, true) LSTM_FWD_CASE(48, true) LSTM_FWD_CASE(64, true) LSTM_FWD_CASE(96, true)
@@ -313,9 +562,18 @@ LEOD_API int leod_convlstm_seq_fwd(const float* xin, int x_is_projection, float*
     }
 
 LEOD_API int leod_convlstm_seq_bwd(const float* dh_seq, const float* dc_last, const float* gates, const float* cbuf, const float* W,
-                                   float* dgates_out, float* dh0, float* dc0, int M, int C, int T, int zero_state, hipStream_t stream) {
+                                   float* dgates_out, float* dh0, float* dc0, const void* wpack, int M, int C, int T, int zero_state,
+                                   hipStream_t stream) {
     if (!gates || !cbuf || !W || !dgates_out || M <= 0 || T <= 0 || (long)M * 4 * C >= (1L << 31)) return LEOD_ERR_ARG;
     const bool bf = leod_precision() == 1;
+    if (leod_convlstm_seq_mode(C) == 3) {
+        if (!wpack) return LEOD_ERR_ARG;
+        const s4* wpb = reinterpret_cast<const s4*>(wpack) + (long)C * C;
+        const dim3 g3(cdiv(M, 16));
+        if (C == 384) hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<384>), g3, dim3(768), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
+        else hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<256>), g3, dim3(512), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
+        return leod_launch_status();
+    }
     // B fragments of the backward pass: 4C/16 chunks x (2 | 4) dwords
     if ((4 * C / 16) * (bf ? 2 : 4) > (C >= 192 ? 96 : 128)) return LEOD_ERR_UNSUPPORTED;
     const dim3 grid(cdiv(M, 16));

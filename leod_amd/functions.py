@@ -290,12 +290,16 @@ class ConvLSTMSeqFn(Function):
         gates = x_seq.new_empty((T, M, 4, C)) if need else None
         W2 = w.view(4 * C, 2 * C)
         mode = ops.convlstm_seq_mode(C)
+        wpack = None
         if mode:
-            # ONE launch for the whole recurrence (csrc/k_lstm.hip); mode 2: the x projection of all timesteps is one large GEMM
+            # ONE launch for the whole recurrence (csrc/k_lstm.hip); modes 2 / 3: the x projection of all timesteps is one large GEMM;
+            # mode 3 (stage 4): the waves stream their weight fragments from a packed bf16 copy (shared with the backward pass)
             xin = x_seq
-            if mode == 2:
+            if mode >= 2:
                 xin, _, _ = ops.ln_linear_fwd(x_seq.view(T * M, C), None, None, W2[:, :C].contiguous(), b)
-            ops.convlstm_seq_fwd(xin, mode == 2, hbuf, cbuf, W2, b, gates, zero_state=h0 is None)
+            if mode == 3:
+                wpack = ops.convlstm_seq_pack(W2, C)
+            ops.convlstm_seq_fwd(xin, mode >= 2, hbuf, cbuf, W2, b, gates, zero_state=h0 is None, wpack=wpack)
         else:
             for t in range(T):
                 zero_state = h0 is None and t == 0
@@ -303,6 +307,7 @@ class ConvLSTMSeqFn(Function):
                                  h_out=hbuf[t + 1], c_out=cbuf[t + 1], gates_out=gates[t] if need else None)
         if need:
             ctx.mod = mod
+            ctx.wpack = wpack
             ctx.set_materialize_grads(False)
             ctx.save_for_backward(x_seq, hbuf, cbuf, gates, w)
         return hbuf[1:], cbuf[T]
@@ -319,7 +324,9 @@ class ConvLSTMSeqFn(Function):
         need_h0, need_c0 = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
         dh0 = x_seq.new_empty(x_seq.shape[1:]) if need_h0 else None
         dc0 = x_seq.new_empty(x_seq.shape[1:]) if need_c0 else None
-        if ops.convlstm_seq_mode(C) and ops.convlstm_seq_bwd(dh_seq, _cont(dc_last), gates, cbuf, W2, dgates, dh0, dc0):
+        mode = ops.convlstm_seq_mode(C)
+        wpack = ctx.wpack if mode == 3 and ctx.wpack is not None else (ops.convlstm_seq_pack(W2, C) if mode == 3 else None)
+        if mode and ops.convlstm_seq_bwd(dh_seq, _cont(dc_last), gates, cbuf, W2, dgates, dh0, dc0, wpack=wpack):
             # backward through time in one launch; dx of all timesteps is ONE GEMM dgates W_x over T*M rows
             dx_seq = ops.linear_dgrad(dgates.view(T * M, 4 * C), W2[:, :C].contiguous()).view(x_seq.shape)
             dh_next, dc_next = dh0, dc0

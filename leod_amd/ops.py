@@ -214,7 +214,18 @@ def convlstm_seq_mode(C: int) -> int:
     return int(_l().leod_convlstm_seq_mode(int(C)))
 
 
-def convlstm_seq_fwd(xin, is_projection, hbuf, cbuf, W, bias, gates_out, zero_state):
+def convlstm_seq_pack(W, C: int):
+    """Mode 3 only: the fragment-ordered bf16 copy of W_h the sequence kernels stream (valid until the weights change) | None."""
+    n = int(_l().leod_convlstm_seq_pack_bytes(int(C)))
+    if n == 0:
+        return None
+    _ck(W, name='W')
+    wp = torch.empty(n, dtype=torch.uint8, device=W.device)
+    check(_l().leod_convlstm_seq_pack(_p(W), _p(wp), int(C), _stream()), 'convlstm_seq_pack')
+    return wp
+
+
+def convlstm_seq_fwd(xin, is_projection, hbuf, cbuf, W, bias, gates_out, zero_state, wpack=None):
     """The whole recurrence in one launch: xin [T,M,C] (or gx [T,M,4C]), hbuf / cbuf [T+1,M,C] (slot 0 = incoming state,
     slots 1.. written), W [4C,2C], gates_out [T,M,4,C] | None."""
     for t, n in ((xin, 'xin'), (hbuf, 'hbuf'), (cbuf, 'cbuf'), (W, 'W'), (bias, 'bias'), (gates_out, 'gates_out')):
@@ -222,11 +233,11 @@ def convlstm_seq_fwd(xin, is_projection, hbuf, cbuf, W, bias, gates_out, zero_st
     T = hbuf.shape[0] - 1
     C = hbuf.shape[-1]
     M = hbuf[0].numel() // C
-    check(_l().leod_convlstm_seq_fwd(_p(xin), 1 if is_projection else 0, _p(hbuf), _p(cbuf), _p(W), _p(bias), _p(gates_out), M, C, T,
-                                      1 if zero_state else 0, _stream()), 'convlstm_seq_fwd')
+    check(_l().leod_convlstm_seq_fwd(_p(xin), 1 if is_projection else 0, _p(hbuf), _p(cbuf), _p(W), _p(bias), _p(gates_out), _p(wpack),
+                                      M, C, T, 1 if zero_state else 0, _stream()), 'convlstm_seq_fwd')
 
 
-def convlstm_seq_bwd(dh_seq, dc_last, gates, cbuf, W, dgates_out, dh0=None, dc0=None, zero_state=False) -> bool:
+def convlstm_seq_bwd(dh_seq, dc_last, gates, cbuf, W, dgates_out, dh0=None, dc0=None, zero_state=False, wpack=None) -> bool:
     """Backward through time in one launch -> dgates_out [T,M,4C] (+ dh0, dc0).  False: the weight slice does not fit the registers
     for this C / precision mode (the caller then runs the per-timestep kernels on the same saved tensors)."""
     for t, n in ((dh_seq, 'dh_seq'), (dc_last, 'dc_last'), (gates, 'gates'), (cbuf, 'cbuf'), (W, 'W'), (dgates_out, 'dgates_out'),
@@ -235,8 +246,8 @@ def convlstm_seq_bwd(dh_seq, dc_last, gates, cbuf, W, dgates_out, dh0=None, dc0=
     T = cbuf.shape[0] - 1
     C = cbuf.shape[-1]
     M = cbuf[0].numel() // C
-    rc = _l().leod_convlstm_seq_bwd(_p(dh_seq), _p(dc_last), _p(gates), _p(cbuf), _p(W), _p(dgates_out), _p(dh0), _p(dc0), M, C, T,
-                                    1 if zero_state else 0, _stream())
+    rc = _l().leod_convlstm_seq_bwd(_p(dh_seq), _p(dc_last), _p(gates), _p(cbuf), _p(W), _p(dgates_out), _p(dh0), _p(dc0), _p(wpack),
+                                    M, C, T, 1 if zero_state else 0, _stream())
     if rc == -3:
         return False
     check(rc, 'convlstm_seq_bwd')
