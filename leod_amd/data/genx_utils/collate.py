@@ -50,7 +50,11 @@ class BatchAssembler:
         self.seq_len, self.frame_shape, self.pin = seq_len, tuple(frame_shape), pin_memory and torch.cuda.is_available()
         self.pool = ThreadPoolExecutor(max_workers=io_threads) if io_threads > 1 else None
 
+    buffer_source = None     # process-wide override: callable(shape) -> uint8 tensor (modules/data/process_loader.py: ring slots)
+
     def new_buffer(self, batch_size: int) -> torch.Tensor:
+        if BatchAssembler.buffer_source is not None:
+            return BatchAssembler.buffer_source((self.seq_len, batch_size) + self.frame_shape)
         # a fresh pinned tensor per batch: torch's caching host allocator recycles the blocks and never hands one out while
         # an asynchronous copy that reads it is still in flight
         return torch.empty((self.seq_len, batch_size) + self.frame_shape, dtype=torch.uint8, pin_memory=self.pin)

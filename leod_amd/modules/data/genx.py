@@ -164,7 +164,8 @@ class MixedLoader:
 
 class DataModule:
     def __init__(self, dataset_config, num_workers_train: int, num_workers_eval: int, batch_size_train: int,
-                 batch_size_eval: int, pin_memory: bool = True, prefetch: int = 3, io_threads: int = 8):
+                 batch_size_eval: int, pin_memory: bool = True, prefetch: int = 3, io_threads: int = 8,
+                 worker_process: bool = False, device=None, ring_slots: int = 8):
         assert num_workers_train >= 0 and num_workers_eval >= 0 and batch_size_train >= 1 and batch_size_eval >= 1
         self.dataset_config = dataset_config
         self.train_sampling_mode = DatasetSamplingMode(dataset_config.train.sampling)
@@ -173,6 +174,9 @@ class DataModule:
         self.overall_batch_size_train, self.overall_batch_size_eval = batch_size_train, batch_size_eval
         self.overall_num_workers_train, self.overall_num_workers_eval = num_workers_train, num_workers_eval
         self.loader_kw = dict(pin_memory=pin_memory, prefetch=prefetch, io_threads=io_threads)
+        # worker_process: batch assembly in a forked process, frames through a HIP-registered shared ring (process_loader.py);
+        # with `device` the loaders yield batches whose frames are already on that device (copied one batch ahead)
+        self.worker_process, self.device, self.ring_slots = worker_process, device, ring_slots
         self.sampling_mode_2_dataset: Dict[Any, Any] = {}
         self.sampling_mode_2_train_workers: Dict[Any, int] = {}
         self.sampling_mode_2_train_batch_size: Dict[Any, int] = {}
@@ -224,19 +228,36 @@ class DataModule:
         else:
             raise NotImplementedError(stage)
 
+    def _in_process(self, build, batch_size: int):
+        """``build(**loader_kw)`` as it is, or behind a ``ProcessLoader`` (the worker's loaders then keep one batch of
+        look-ahead of their own: the ring is the prefetch queue)."""
+        if not self.worker_process:
+            return build(**self.loader_kw)
+        from leod_amd.modules.data.process_loader import ProcessLoader
+        kw = dict(self.loader_kw, pin_memory=False, prefetch=1)
+        hw = self.get_dataloading_hw()
+        L = self.dataset_config.sequence_length
+        slot = L * batch_size * 20 * hw[0] * hw[1]
+        return ProcessLoader(lambda: build(**kw), slot_bytes=slot, n_slots=self.ring_slots, device=self.device)
+
     def train_dataloader(self):
+        B = max(self.sampling_mode_2_train_batch_size.values())
+        return self._in_process(self._train_loaders, B)
+
+    def _train_loaders(self, **loader_kw):
         loaders = {}
         for mode, dataset in self.sampling_mode_2_dataset.items():
             workers, bs = self.sampling_mode_2_train_workers[mode], self.sampling_mode_2_train_batch_size[mode]
             if mode == DatasetSamplingMode.STREAM:
-                loaders[mode] = StreamLoader(dataset, num_workers=workers, **self.loader_kw)
+                loaders[mode] = StreamLoader(dataset, num_workers=workers, **loader_kw)
             else:
                 sampler = get_weighted_random_sampler(dataset) if self.dataset_config.train.random.weighted_sampling else None
-                loaders[mode] = RandomLoader(dataset, batch_size=bs, sampler=sampler, num_workers=workers, **self.loader_kw)
+                loaders[mode] = RandomLoader(dataset, batch_size=bs, sampler=sampler, num_workers=workers, **loader_kw)
         return next(iter(loaders.values())) if len(loaders) == 1 else MixedLoader(loaders)
 
     def _eval_loader(self, dataset):
-        return StreamLoader(dataset, num_workers=self.overall_num_workers_eval, **self.loader_kw)
+        return self._in_process(lambda **kw: StreamLoader(dataset, num_workers=self.overall_num_workers_eval, **kw),
+                                self.overall_batch_size_eval)
 
     def val_dataloader(self):
         return self._eval_loader(self.validation_dataset)

@@ -341,3 +341,89 @@ def test_pseudo_label_pass_sharded_over_two_ranks_gloo(trees):
             union[k] = v
     assert union == single[1]
     assert min(res[2][0][2]['num_sequences_rank']) >= 1
+
+
+def _flatten(o, out, prefix=''):
+    from leod_amd.data.genx_utils.labels import ObjectLabels, SparselyBatchedObjectLabels
+    if torch.is_tensor(o):
+        out.append((prefix, o.clone().numpy()))
+    elif isinstance(o, ObjectLabels):
+        out.append((prefix + '/ol', o.object_labels.clone().numpy())); out.append((prefix + '/hw', np.asarray(o.input_size_hw)))
+    elif isinstance(o, SparselyBatchedObjectLabels):
+        for i, l in enumerate(o.sparse_object_labels_batch):
+            _flatten(l, out, f'{prefix}/sb{i}')
+    elif isinstance(o, dict):
+        for k, v in o.items():
+            _flatten(v, out, f'{prefix}/{k}')
+    elif isinstance(o, (list, tuple)):
+        for i, v in enumerate(o):
+            _flatten(v, out, f'{prefix}/{i}')
+    elif o is None or isinstance(o, (str, int, float, bool)):
+        out.append((prefix, o))
+    else:                                                       # augmentation states: compare by repr of their fields
+        out.append((prefix, repr(getattr(o, '__dict__', o))))
+
+
+@pytest.mark.parametrize('stage', ['fit-stream', 'fit-random', 'fit-mixed', 'test'])
+def test_worker_process_loader_yields_the_in_process_batches(trees, stage):
+    """modules/data/process_loader.py: batch assembly in a forked worker, frames through the shared ring, labels as numpy over a
+    pipe -- the batches must be the ones the in-process loader yields (same RNG state at the start of the epoch), frames of a
+    batch still views of ONE [L,B,C,H,W] buffer, and a slot must not be recycled while the consumer may still read it."""
+    from leod_amd.data.utils.types import DataType
+    from leod_amd.modules.data.genx import DataModule
+    from leod_amd.modules.data.process_loader import ProcessLoader
+
+    def run(worker_process):
+        torch.manual_seed(11); np.random.seed(11)
+        import random; random.seed(11)
+        over = dict(train=dict(sampling=stage[4:])) if stage.startswith('fit') else {}
+        dm = DataModule(_cfg(trees['gen1'], **over), num_workers_train=4, num_workers_eval=2, batch_size_train=4, batch_size_eval=2,
+                        prefetch=2, io_threads=1, worker_process=worker_process, ring_slots=8)
+        dm.setup(stage[:3] if stage.startswith('fit') else stage)
+        loader = dm.train_dataloader() if stage.startswith('fit') else dm.test_dataloader()
+        assert isinstance(loader, ProcessLoader) == worker_process
+        batches, live = [], []
+        for batch in loader:
+            flat = []
+            _flatten(batch, flat)
+            batches.append(flat)
+            sub = [batch] if 'data' in batch else list(batch.values())
+            for s in sub:
+                ev = s['data'][DataType.EV_REPR]
+                assert ev[1].data_ptr() == ev[0].data_ptr() + ev[0].numel() and ev[0]._base is not None
+                assert tuple(ev[0]._base.shape) == (len(ev),) + tuple(ev[0].shape)      # what Module._stack_frames recognises
+            live.append((batch, flat))
+            if len(live) > 2:
+                live.pop(0)
+            for b, f in live:                                   # the previous batches' frames have not been overwritten
+                g = []
+                _flatten(b, g)
+                assert all(np.array_equal(x[1], y[1]) if isinstance(x[1], np.ndarray) else x[1] == y[1] for x, y in zip(f, g))
+        return batches
+
+    ref, got = run(False), run(True)
+    assert len(ref) == len(got) and len(ref) >= 4
+    for fr, fg in zip(ref, got):
+        if stage == 'fit-mixed':            # two producer threads share the global RNG: the draws interleave differently from run to
+            assert [(k, getattr(a, 'shape', None)) for k, a in fr if 'EV_REPR' in k] == \
+                   [(k, getattr(a, 'shape', None)) for k, a in fg if 'EV_REPR' in k]       # run also in process; structure only
+            continue
+        assert [k for k, _ in fr] == [k for k, _ in fg]
+        for (k, a), (_, b) in zip(fr, fg):
+            if isinstance(a, np.ndarray):
+                assert a.dtype == b.dtype and np.array_equal(a, b), k
+            else:
+                assert a == b, k
+
+
+def test_worker_process_loader_surfaces_worker_errors():
+    from leod_amd.modules.data.process_loader import ProcessLoader
+
+    def broken():
+        yield {'data': {}, 'worker_id': 0}
+        raise ValueError('recording 7 is truncated')
+
+    it = iter(ProcessLoader(broken, slot_bytes=1024, n_slots=2))
+    assert next(it) == {'data': {}, 'worker_id': 0}
+    with pytest.raises(RuntimeError, match='recording 7 is truncated'):
+        next(it)

@@ -72,6 +72,19 @@ def main():
             break
     dt = time.perf_counter() - t0
     print(f'loader alone : {n * T * B / dt:9.1f} event-frames/s ({1e3 * dt / n:.1f} ms/batch, {n * T * B * 20 * 240 * 304 / dt / 1e9:.2f} GB/s of voxels)')
+    dmh = DataModule(cfg.dataset, num_workers_train=cfg.hardware.num_workers.train, num_workers_eval=2,
+                     batch_size_train=cfg.batch_size.train, batch_size_eval=cfg.batch_size.eval, prefetch=4, io_threads=args.io_threads,
+                     worker_process=True)
+    dmh.setup('fit')
+    n, t0 = 0, None
+    for batch in dmh.train_dataloader():
+        if n == 2:
+            t0 = time.perf_counter()
+        n += 1
+        if n == args.steps + 2:
+            break
+    dt = time.perf_counter() - t0
+    print(f'loader in a worker process, alone : {(n - 2) * T * B / dt:9.1f} event-frames/s ({1e3 * dt / (n - 2):.1f} ms/batch)')
     if args.loader_only:
         return
     dev = torch.device('cuda', 0)
@@ -99,6 +112,12 @@ def main():
 
     ms_loader = 1e3 * timed(DevicePrefetcher(epochs(dm.train_dataloader), module, dev))
     print(f'loader -> pinned -> side-stream copy -> training_step: {T * B / ms_loader * 1e3:9.1f} event-frames/s ({ms_loader:.2f} ms/step)')
+    dmp = DataModule(cfg.dataset, num_workers_train=cfg.hardware.num_workers.train, num_workers_eval=2,
+                     batch_size_train=cfg.batch_size.train, batch_size_eval=cfg.batch_size.eval, prefetch=4, io_threads=args.io_threads,
+                     worker_process=True, device=dev)
+    dmp.setup('fit')
+    ms_proc = 1e3 * timed(epochs(dmp.train_dataloader))
+    print(f'worker process -> registered shared ring -> side-stream copy -> training_step: {T * B / ms_proc * 1e3:9.1f} event-frames/s ({ms_proc:.2f} ms/step)')
     ms_inline = 1e3 * timed(module.transfer_batch_to_device(b, dev, 0) for b in epochs(dm.train_dataloader))
     print(f'loader -> pinned -> copy on the launch stream        : {T * B / ms_inline * 1e3:9.1f} event-frames/s ({ms_inline:.2f} ms/step)')
     it = iter(dm.train_dataloader())
@@ -124,7 +143,7 @@ def main():
             yield out
     ms_res = 1e3 * timed(resident_batches())
     print(f'HBM-resident batch (same module, same step)           : {T * B / ms_res * 1e3:9.1f} event-frames/s ({ms_res:.2f} ms/step)')
-    print(f'loader-fed / resident = {ms_res / ms_loader:.3f}')
+    print(f'loader-fed / resident = {ms_res / ms_loader:.3f} (loader thread in the training process), {ms_res / ms_proc:.3f} (loader in a worker process)')
 
 
 if __name__ == '__main__':
