@@ -9,6 +9,7 @@
 // or folded eval-BatchNorm + SiLU.
 #include "gemm16.hpp"
 #include "conv3.hpp"
+#include "stem.hpp"
 
 static inline int pick_nt(int N) {
     int best = 1; long bestpad = 1L << 60;
@@ -516,6 +517,8 @@ LEOD_API int leod_stem_conv_wgrad(const float* dy, const void* x, int x_is_u8, f
     const int Ho = (Hp + 2 * pad - ks) / stride + 1, Wo = (Wp + 2 * pad - ks) / stride + 1;
     const int M = B * Ho * Wo, K = Cin * ks * ks;
     static const int stem_patch = getenv("LEOD_STEM_PATCH") ? atoi(getenv("LEOD_STEM_PATCH")) : 1;
+    if (stem_patch && x_is_u8 && leod_precision() == 1 && stem_wgrad_bf16_supported(x, Cin, H, W, N, stride, pad))
+        return stem_wgrad_bf16_launch(dy, x, dw, B, Cin, H, W, Ho, Wo, N, stream);     // k_stem.hip
     if (stem_patch && x_is_u8 && stride == 4 && pad == 3 && N <= 64 && !(N & 15) && !(W & 3) && Cin * 19 * 18 <= 27 * 256 &&
         ((uintptr_t)x & 3) == 0 && ((long)Cin * H * W) % 4 == 0) {
         switch (N / 16) {

@@ -269,7 +269,8 @@ def test_partition_attn_bf16(bf16_ops, B, H, W, C, heads, part, window):
     tk.test_partition_attn(bf16_ops, B, H, W, C, heads, part, window)
 
 
-@pytest.mark.parametrize('u8,B,H,W,Hp,Wp,N', [(True, 2, 60, 90, 64, 96, 48), (True, 2, 60, 88, 64, 96, 48), (True, 1, 240, 304, 256, 320, 48)])
+@pytest.mark.parametrize('u8,B,H,W,Hp,Wp,N', [(True, 2, 60, 90, 64, 96, 48), (True, 2, 60, 88, 64, 96, 48), (True, 1, 240, 304, 256, 320, 48),
+                                              (True, 7, 240, 304, 256, 320, 48), (True, 2, 36, 52, 40, 64, 32)])   # 560 tiles: the persistent loop of k_stem.hip
 def test_stem_conv_bf16(bf16_ops, u8, B, H, W, Hp, Wp, N):
     tk.test_stem_conv(bf16_ops, u8, B, H, W, Hp, Wp, N)
 
