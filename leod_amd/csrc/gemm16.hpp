@@ -989,8 +989,34 @@ struct XRows {                      // X(m,k) = x[m][k], optional LayerNorm with
         if (stats) v = (v - stats[2 * (long)m]) * stats[2 * (long)m + 1] * ld4(ln_w + k) + ld4(ln_b + k);
         return v;
     }
+    // Two-phase access for the pipelined weight-gradient kernel: raw4 only ISSUES the loads (row data, and the row's (mean, rstd)
+    // in LayerNorm mode) -- nothing consumes a loaded value here, so all loads of a chunk are in flight together; fin4 applies
+    // get4's arithmetic later (same operations in the same order: bit-identical values).  The caller clamps (m, k) to valid
+    // coordinates and masks the result.
+    // XM: 0 plain rows (optionally [x | x2]), 1 LayerNorm(x) with saved statistics, 2 gelu(fp16 pre-activation) -- chosen once per
+    // launch (x_mode), so the loop has no mode branches
+    template <int XM> __device__ __forceinline__ void raw4(int m, int k, f4& v, u2_& h, f2_& st) const {
+        if constexpr (XM == 2) { h = *reinterpret_cast<const u2_*>(reinterpret_cast<const unsigned short*>(x) + (long)m * ld + k); return; }
+        if constexpr (XM == 1) st = *reinterpret_cast<const f2_*>(stats + 2 * (long)m);
+        const float* p = (x2 && k >= K1) ? x2 + (long)m * ld2 + (k - K1) : x + (long)m * ld + k;
+        v = ld4(p);
+    }
+    template <int XM> __device__ __forceinline__ f4 fin4(f4 v, u2_ h, f2_ st, int k, f4 g, f4 b) const {
+        if constexpr (XM == 2) {
+            f4 o = unpack_h16(__builtin_bit_cast(s4, h));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = gelu_erf(o[j]);
+            return o;
+        }
+        if constexpr (XM == 1) { const f4 n = (v - st.x) * st.y * g + b; return (x2 && k >= K1) ? v : n; }
+        return v;
+    }
+    int x_mode() const { return fmt == 1 ? 2 : (stats ? 1 : 0); }
     __device__ __forceinline__ long waddr(int n, int k, long ldw) const { return (long)n * ldw + k; }
 };
+// loaders with the raw4 / fin4 pair (see XRows) are staged in two phases by wgradw_kernel
+template <class XL, class = void> struct x_two_phase { static constexpr bool value = false; };
+template <class XL> struct x_two_phase<XL, decltype((void)&XL::x_mode)> { static constexpr bool value = true; };
 struct XConvNHWC {                  // im2col of an NHWC map; k' = tap*Cin + c ; dW laid out [N][Cin][ks][ks]
     const float* x; int H, W, Cin, Ho, Wo, ks, stride, pad;
     __device__ __forceinline__ float get(int m, int k) const {
@@ -1200,7 +1226,7 @@ static inline int launch_wgrad16(const float* dy, long lddy, const XL& xl, float
 //   * waves left over after tiling the output (48x48) split the 16-row steps of a chunk (MS-way) instead.
 // dW accumulates with one fp32 atomic per element and workgroup, dbias from the staged dY values as before.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TN, int TK, int WA, int WB, int RC, bool BF, class XL>
+template <int TN, int TK, int WA, int WB, int RC, bool BF, class XL, int DYF = -1, int XM = 0>   // DYF: dY fp32 (0) / bf16 (1); -1: runtime dyfmt
 __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict__ dy, long lddy, XL xl, float* dW, long ldw,
                                                      float* dbias, int M, int N, int K, int dyfmt) {
     constexpr int NWN = TN / WA, NWK = TK / WB, MS = 4 / (NWN * NWK);      // wave grid over the tile, row-step split
@@ -1257,15 +1283,60 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < RN; ++e) bacc[e] = zero4();
     if (tid < 16 * TN) sbias[tid] = 0.f;
-    f4 rn[RN], rk[RK];
+    // ---- two-phase staging: issue() only starts the loads of a chunk (unconditional, on clamped coordinates), finish() turns the
+    // raw registers into operand values (bf16 unpack, GELU, LayerNorm, edge masks) right before they are stashed.  With the
+    // arithmetic of the loaders sitting behind each load the compiler waited for every load in turn: 5-6 serialized memory
+    // round trips per 16-row chunk.
+    constexpr bool TP = x_two_phase<XL>::value;
+    f4 rn[RN], rk[RK]; f2_ rst[RK]; u2_ hn[RN], hk[RK];      // 16-byte and 8-byte raw registers are separate: no copies behind a load
+    __shared__ __attribute__((aligned(16))) float sln[2][TP ? 16 * TK : 4];   // LayerNorm weight / bias of this workgroup's columns
+    long noffc[RN]; int kcc[RK];
+#pragma unroll
+    for (int e = 0; e < RN; ++e) noffc[e] = nok[e] ? noff[e] : (long)nr[e] * lddy;
+#pragma unroll
+    for (int e = 0; e < RK; ++e) kcc[e] = kok[e] ? kc[e] : 0;      // (the raw registers stay uninitialised: each is written and read under the same
+                                                                    // workgroup-uniform mode test, and an initial value would become a copy behind every load)
+    if constexpr (TP && XM == 1) {
+        for (int c = tid; c < 16 * TK; c += 256) { sln[0][c] = k0 + c < K ? xl.ln_w[k0 + c] : 0.f; sln[1][c] = k0 + c < K ? xl.ln_b[k0 + c] : 0.f; }
+        __syncthreads();
+    }
     auto fetch = [&](long m0) {
+        if constexpr (!TP) {                                  // loaders without the raw / finish pair: values in one go
+#pragma unroll
+            for (int e = 0; e < RN; ++e) {
+                if (dyfmt) rn[e] = (nok[e] && m0 + nr[e] < mend) ? unpack_bf16(*reinterpret_cast<const s4*>(reinterpret_cast<const unsigned short*>(dyb) + (m0 * lddy + noff[e]))) : zero4();
+                else rn[e] = (nok[e] && m0 + nr[e] < mend) ? ld4(dyb + (m0 * lddy + noff[e])) : zero4();
+            }
+#pragma unroll
+            for (int e = 0; e < RK; ++e) rk[e] = (kok[e] && m0 + kr[e] < mend) ? xl.get4((int)m0 + kr[e], kc[e]) : zero4();
+            return;
+        } else {
 #pragma unroll
         for (int e = 0; e < RN; ++e) {
-            if (dyfmt) rn[e] = (nok[e] && m0 + nr[e] < mend) ? unpack_bf16(*reinterpret_cast<const s4*>(reinterpret_cast<const unsigned short*>(dyb) + (m0 * lddy + noff[e]))) : zero4();
-            else rn[e] = (nok[e] && m0 + nr[e] < mend) ? ld4(dyb + (m0 * lddy + noff[e])) : zero4();
+            const long mr = min(m0 + nr[e], (long)mend - 1) - nr[e];                 // clamped chunk origin of this slot
+            if constexpr (DYF == 1) hn[e] = *reinterpret_cast<const u2_*>(reinterpret_cast<const unsigned short*>(dyb) + (mr * lddy + noffc[e]));
+            else rn[e] = ld4(dyb + (mr * lddy + noffc[e]));
         }
 #pragma unroll
-        for (int e = 0; e < RK; ++e) rk[e] = (kok[e] && m0 + kr[e] < mend) ? xl.get4((int)m0 + kr[e], kc[e]) : zero4();
+        for (int e = 0; e < RK; ++e) xl.template raw4<XM>((int)min(m0 + kr[e], (long)mend - 1), kcc[e], rk[e], hk[e], rst[e]);
+        }
+    };
+    auto finish = [&](long m0) {
+        if constexpr (TP) {
+#pragma unroll
+        for (int e = 0; e < RN; ++e) {
+            f4 v;
+            if constexpr (DYF == 1) v = unpack_bf16(__builtin_bit_cast(s4, hn[e])); else v = rn[e];
+            rn[e] = (nok[e] && m0 + nr[e] < mend) ? v : zero4();
+        }
+#pragma unroll
+        for (int e = 0; e < RK; ++e) {
+            f4 g = zero4(), b = zero4();
+            if constexpr (XM == 1) { g = *reinterpret_cast<const f4*>(&sln[0][kcc[e] - k0]); b = *reinterpret_cast<const f4*>(&sln[1][kcc[e] - k0]); }
+            const f4 v = xl.template fin4<XM>(rk[e], hk[e], rst[e], kcc[e], g, b);
+            rk[e] = (kok[e] && m0 + kr[e] < mend) ? v : zero4();
+        }
+        }
     };
     auto stash = [&](int buf) {
         if constexpr (BF) {
@@ -1292,6 +1363,7 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
     };
     int buf = 0;
     fetch(mbeg);
+    finish(mbeg);
     stash(0);
     __syncthreads();
     for (long m0 = mbeg; m0 < mend; m0 += mstride) {
@@ -1337,7 +1409,7 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
                     for (int b = 0; b < WB; ++b) acc[a][b] = mfma16(av[a][j], bv[b][j], acc[a][b]);
         }
         }
-        if (more) stash(buf ^ 1);
+        if (more) { finish(m0 + mstride); stash(buf ^ 1); }
         __syncthreads();
         buf ^= 1;
     }
@@ -1373,8 +1445,20 @@ static inline int launch_wgradw_cfg(const float* dy, long lddy, const XL& xl, fl
     const int chunks = cdiv(M, RC);
     const int gx = max(1, min(chunks / 4, tune_blocks / tiles));      // >= 4 chunks per workgroup: one atomic per dW element each
     dim3 grid(gx, cdiv(N, TN * 16), cdiv(K, TK * 16));
-    if (leod_precision() == 1) hipLaunchKernelGGL((wgradw_kernel<TN, TK, WA, WB, RC, true, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, dyfmt);
-    else hipLaunchKernelGGL((wgradw_kernel<TN, TK, WA, WB, RC, false, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, dyfmt);
+#define LEOD_WGRADW_GO(BFV, DYFV, XMV) hipLaunchKernelGGL((wgradw_kernel<TN, TK, WA, WB, RC, BFV, XL, DYFV, XMV>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, dyfmt)
+    if constexpr (x_two_phase<XL>::value) {                  // one instantiation per (dY format, X mode): no mode branches in the loop
+        const int xm = xl.x_mode();
+        if (leod_precision() == 1) {
+            if (dyfmt) { if (xm == 2) LEOD_WGRADW_GO(true, 1, 2); else if (xm == 1) LEOD_WGRADW_GO(true, 1, 1); else LEOD_WGRADW_GO(true, 1, 0); }
+            else { if (xm == 2) LEOD_WGRADW_GO(true, 0, 2); else if (xm == 1) LEOD_WGRADW_GO(true, 0, 1); else LEOD_WGRADW_GO(true, 0, 0); }
+        } else {
+            if (dyfmt || xm == 2) return LEOD_ERR_ARG;       // 16-bit tensors exist in precision mode bf16 only
+            if (xm == 1) LEOD_WGRADW_GO(false, 0, 1); else LEOD_WGRADW_GO(false, 0, 0);
+        }
+    } else {
+        if (leod_precision() == 1) LEOD_WGRADW_GO(true, -1, 0); else LEOD_WGRADW_GO(false, -1, 0);
+    }
+#undef LEOD_WGRADW_GO
     return leod_launch_status();
 }
 
