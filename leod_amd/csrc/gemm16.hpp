@@ -87,6 +87,36 @@ struct ALRows {                 // plain rows, optional LayerNorm prologue, opti
     template <int KCH> __device__ __forceinline__ f4 load2(const St& st, int k0, int ak, int Kt) const { return load(st, k0 + ak, Kt); }
 };
 
+// ALRows with its modes fixed at compile time and the access split in two phases (gemm_lds_kernel): raw() only ISSUES the loads of a
+// slot -- row data, LayerNorm weight / bias, per-k scale -- and fin() applies ALRows::load's arithmetic later (same operations in the
+// same order: bit-identical values).  With the arithmetic sitting behind each load and the modes tested at run time, the compiler
+// waited for every load of a chunk in turn.  launch_gemm_lds dispatches the hot mode combinations here; the rest stays on ALRows.
+template <int FMT, bool LN, bool KS>
+struct ALRowsM : ALRows {
+    static constexpr bool kTwoPhase = true;
+    struct Raw { f4 v; u2_ h; f4 g, b, s; };
+    __device__ __forceinline__ void raw(const St& st, int k, Raw& r) const {
+        if constexpr (FMT == 0) r.v = ld4(st.p + k);
+        else r.h = *reinterpret_cast<const u2_*>(reinterpret_cast<const unsigned short*>(st.p) + k);
+        if constexpr (LN) { r.g = ld4(ln_w + k); r.b = ld4(ln_b + k); }
+        if constexpr (KS) r.s = ld4(kscale + k);
+    }
+    __device__ __forceinline__ f4 fin(const St& st, const Raw& r) const {
+        f4 v;
+        if constexpr (FMT == 1) {
+            v = unpack_h16(__builtin_bit_cast(s4, r.h));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+        } else if constexpr (FMT == 2) v = unpack_bf16(__builtin_bit_cast(s4, r.h));
+        else v = r.v;
+        if constexpr (LN) v = (v - st.mean) * st.rstd * r.g + r.b;
+        if constexpr (KS) v = v * r.s;
+        return v;
+    }
+};
+template <class AL, class = void> struct a_two_phase { static constexpr bool value = false; struct Raw {}; };
+template <class AL> struct a_two_phase<AL, decltype((void)AL::kTwoPhase)> { static constexpr bool value = true; typedef typename AL::Raw Raw; };
+
 struct ALConcat2 {              // [x1 (K1 cols) | x2] along k  (ConvLSTM: cat(x, h_prev))
     const float* x1; long ld1; int K1; const float* x2; long ld2;
     struct St { const float* p1; const float* p2; bool ok; };
@@ -785,15 +815,31 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
     K = al.klen(ast[0], K);
     const int aux = al.aux(ast[0]);
     f4 ra[RA], rb[RB];
+    constexpr bool ATP = a_two_phase<AL>::value;
+    typename a_two_phase<AL>::Raw raw_a[RA];                  // two-phase A loaders: raw registers of the next chunk
     auto fetch = [&](int k0) {
+        if constexpr (ATP) {
+#pragma unroll
+            for (int p = 0; p < RA; ++p) al.raw(ast[p], min(k0 + ak[p], K - 4), raw_a[p]);     // unconditional, clamped: all in flight together
+        } else {
 #pragma unroll
         for (int p = 0; p < RA; ++p) ra[p] = aok[p] ? al.template load2<KCH>(ast[p], k0, ak[p], K) : zero4();
+        }
 #pragma unroll
         for (int p = 0; p < RB; ++p) {
             rb[p] = zero4();
             if (bok[p]) {
                 if (!BL::kTrans) rb[p] = bl.template load2<KCH>(nblk, bn[p] >> 4, bn[p] & 15, k0, bk[p], K, aux);
                 else rb[p] = bl.load_n4(nblk, bn[p], k0 + bk[p], K);
+            }
+        }
+    };
+    auto finish = [&](int k0) {                               // raw registers -> operand values (two-phase A loaders)
+        if constexpr (ATP) {
+#pragma unroll
+            for (int p = 0; p < RA; ++p) {
+                const f4 v = al.fin(ast[p], raw_a[p]);
+                ra[p] = (aok[p] && ast[p].ok && k0 + ak[p] < K) ? v : zero4();
             }
         }
     };
@@ -821,6 +867,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
         for (int t = 0; t < NT; ++t) acc[w][t] = zero4();
     const int nch = (K + KCH - 1) / KCH;
     fetch(0);
+    finish(0);
     stash(0);
     __syncthreads();
     const int aoff = (16 * RW * wave + i) * LD + 4 * q;                            // wave owns rows 16*RW*wave ..
@@ -873,9 +920,10 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
         }
         }
         if (NBUF > 1) {
-            if (more) stash(buf ^ 1);
+            if (more) { finish((ch + 1) * KCH); stash(buf ^ 1); }
             __syncthreads();
         } else if (more) {                                    // single LDS buffer (half the LDS -> twice the resident
+            finish((ch + 1) * KCH);
             __syncthreads();                                  // workgroups): everyone done reading, then refill
             stash(0);
             __syncthreads();
@@ -956,6 +1004,25 @@ template <int NT, class AL, class BL, class EP>
 static inline int launch_gemm_lds(const AL& al, const BL& bl, const EP& ep, int M, int K, int nblocks_n, hipStream_t s) {
     // RW = 2 (128-row workgroups, two row fragments per wave) measured 5-40 % SLOWER on every RVT shape (3 instead of 4
     // resident workgroups, two epilogue rounds), so only RW = 1 is instantiated.
+    return launch_gemm_lds_rw<NT, 1>(al, bl, ep, M, K, nblocks_n, s);
+}
+// plain-row A operands: the hot mode combinations of the wide GEMMs (NT >= 3) run on the two-phase loader ALRowsM
+template <int NT, class BL, class EP>
+static inline int launch_gemm_lds(const ALRows& al, const BL& bl, const EP& ep, int M, int K, int nblocks_n, hipStream_t s) {
+    static const int two_phase = getenv("LEOD_GEMM_TWO_PHASE") ? atoi(getenv("LEOD_GEMM_TWO_PHASE")) : 1;
+    if constexpr (NT >= 3) {
+        const bool ln = al.ln_w != nullptr, ks = al.kscale != nullptr;
+        if (two_phase && !(K & 3) && K >= 4 && (!ln || al.stats_in)) {
+#define LEOD_ALM(F, L, S) { ALRowsM<F, L, S> am; static_cast<ALRows&>(am) = al; return launch_gemm_lds_rw<NT, 1>(am, bl, ep, M, K, nblocks_n, s); }
+            if (al.fmt == 0 && !ln && !ks) LEOD_ALM(0, false, false)
+            if (al.fmt == 0 && ln && !ks) LEOD_ALM(0, true, false)
+            if (al.fmt == 0 && !ln && ks) LEOD_ALM(0, false, true)
+            if (al.fmt == 2 && !ln && !ks) LEOD_ALM(2, false, false)
+            if (al.fmt == 2 && !ln && ks) LEOD_ALM(2, false, true)
+            if (al.fmt == 1 && !ln && !ks) LEOD_ALM(1, false, false)
+#undef LEOD_ALM
+        }
+    }
     return launch_gemm_lds_rw<NT, 1>(al, bl, ep, M, K, nblocks_n, s);
 }
 // enough 64-row workgroups to fill the chip; smaller problems stay on the register-direct kernels (K-split)
