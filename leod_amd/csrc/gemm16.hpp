@@ -1124,7 +1124,8 @@ struct XStemNCHW {
 // the k-permutation "MFMA j of a 16-row step uses rows 4q+j" one ds_read_b128 per operand feeds four MFMAs.  The 4 waves
 // split the TN*TK output tiles, keep them in registers over the workgroup's whole row range and finish with one fp32
 // atomic per dW element (dW accumulates over timesteps and row splits).
-template <int TN, int TK, bool BF, class XL>
+// DYF: dY rows are fp32 (0) / bf16 (1) -- fixed per instantiation, a run-time test put a wait behind every dY load
+template <int TN, int TK, bool BF, class XL, int DYF = 0>
 __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ dy, long lddy, XL xl, float* dW, long ldw,
                                                       float* dbias, int M, int N, int K, int rows_per_block, int dyfmt) {
     constexpr int RC = 32;                                  // rows per staged chunk
@@ -1177,7 +1178,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const float* __restrict__ 
     auto fetch = [&](int m0) {
 #pragma unroll
         for (int e = 0; e < RN; ++e) {
-            if (dyfmt) rn[e] = (nok[e] && m0 + nr[e] < mend) ? unpack_bf16(*reinterpret_cast<const s4*>(reinterpret_cast<const unsigned short*>(dy) + np[e])) : zero4();
+            if constexpr (DYF == 1) rn[e] = (nok[e] && m0 + nr[e] < mend) ? unpack_bf16(*reinterpret_cast<const s4*>(reinterpret_cast<const unsigned short*>(dy) + np[e])) : zero4();
             else rn[e] = (nok[e] && m0 + nr[e] < mend) ? ld4(dy + np[e]) : zero4();
             np[e] += (long)RC * lddy;
         }
@@ -1278,6 +1279,13 @@ static inline int launch_wgrad16(const float* dy, long lddy, const XL& xl, float
     int rpb = cdiv(M, max(1, tune_blocks / tiles));
     rpb = max(tune_minrows, ((rpb + 31) / 32) * 32);
     dim3 grid(cdiv(M, rpb), cdiv(N, TN * 16), cdiv(K, TK * 16));
+    if (dyfmt) {                                             // bf16 dY rows: Linear layers in precision mode bf16 only
+        if constexpr (x_two_phase<XL>::value) {
+            if (leod_precision() != 1) return LEOD_ERR_ARG;
+            hipLaunchKernelGGL((wgrad16_kernel<TN, TK, true, XL, 1>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, rpb, dyfmt);
+            return leod_launch_status();
+        } else return LEOD_ERR_ARG;
+    }
     if (leod_precision() == 1) hipLaunchKernelGGL((wgrad16_kernel<TN, TK, true, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, rpb, dyfmt);
     else hipLaunchKernelGGL((wgrad16_kernel<TN, TK, false, XL>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, rpb, dyfmt);
     return leod_launch_status();

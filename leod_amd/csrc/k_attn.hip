@@ -12,6 +12,7 @@
 // already laid out as the A operand of the P.V MFMA (k index = lane>>4): no LDS, no shuffles apart
 // from the 2-step cross-row-group reductions.  P = 80 tokens -> 5 key tiles, 20 accumulator VGPRs.
 #include "common.hpp"
+#include <type_traits>
 
 struct AttnGeom {
     int B, H, W, C, heads, d, ph, pw, window;   // window: 1 = window partition, 0 = grid partition
@@ -394,20 +395,31 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds_kernel(const float*
     __syncthreads();
     {   // all global loads of the thread are issued before the first LDS store: a load -> store loop waits for every load in
         // turn (4-5 dependent HBM round trips per workgroup)
+        // (the qkv format is tested ONCE, around the whole staging block, and the loads are unconditional on clamped rows: with
+        // the test and the bf16 unpack behind each load the compiler waited for every load in turn)
         constexpr int NL = (TOK * F + NTHR - 1) / NTHR;
-        f4 stage[NL];
+        auto stage_qkv = [&](auto q16) {
+            constexpr bool Q16 = decltype(q16)::value;
+            f4 stage[Q16 ? 1 : NL]; u2_ stageh[Q16 ? NL : 1];
+            unsigned ok = 0;
 #pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            const int e = tid + j * NTHR, tok = min(e / F, TOK - 1), f = e - (e / F) * F;
-            const long row = srow[tok];
-            if (g.fmt & 1) stage[j] = (e < TOK * F && row >= 0) ? unpack_bf16(*reinterpret_cast<const s4*>(reinterpret_cast<const unsigned short*>(qkv) + row * ld + h0 * 3 * d + 4 * f)) : zero4();
-            else stage[j] = (e < TOK * F && row >= 0) ? ld4(qkv + row * ld + h0 * 3 * d + 4 * f) : zero4();
-        }
+            for (int j = 0; j < NL; ++j) {
+                const int e = tid + j * NTHR, tok = min(e / F, TOK - 1), f = e - (e / F) * F;
+                const long row = srow[tok];
+                ok |= (unsigned)(e < TOK * F && row >= 0) << j;
+                const long off = max(row, 0L) * ld + h0 * 3 * d + 4 * f;
+                if constexpr (Q16) stageh[j] = *reinterpret_cast<const u2_*>(reinterpret_cast<const unsigned short*>(qkv) + off);
+                else stage[j] = ld4(qkv + off);
+            }
 #pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            const int e = tid + j * NTHR, tok = e / F, f = e - tok * F;
-            if (e < TOK * F) *reinterpret_cast<f4*>(smem + tok * S + 4 * f) = stage[j];
-        }
+            for (int j = 0; j < NL; ++j) {
+                const int e = tid + j * NTHR, tok = e / F, f = e - tok * F;
+                f4 v;
+                if constexpr (Q16) v = unpack_bf16(__builtin_bit_cast(s4, stageh[j])); else v = stage[j];
+                if (e < TOK * F) *reinterpret_cast<f4*>(smem + tok * S + 4 * f) = (ok >> j) & 1u ? v : zero4();
+            }
+        };
+        if (g.fmt & 1) stage_qkv(std::true_type{}); else stage_qkv(std::false_type{});
     }
     __syncthreads();
     const float* hb = smem + hl * 3 * d;                     // this wave's head inside a staged token row
@@ -511,42 +523,53 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float*
     __syncthreads();
     {   // every global load of the thread first, then the LDS stores (see the forward kernel)
         constexpr int NL = (TOK * F + NTHR - 1) / NTHR, NLd = (TOK * Fd + NTHR - 1) / NTHR, NLl = (HG * TOK + NTHR - 1) / NTHR;
-        f4 stage[NL], staged[NLd];
-        float stagel[NLl];
+        auto stage_all = [&](auto q16) {                      // format test hoisted around the block, unconditional clamped loads (see fwd)
+            constexpr bool Q16 = decltype(q16)::value;
+            f4 stage[Q16 ? 1 : NL], staged[NLd]; u2_ stageh[Q16 ? NL : 1];
+            float stagel[NLl];
+            unsigned ok = 0, okd = 0, okl = 0;
 #pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            const int e = tid + j * NTHR, tok = min(e / F, TOK - 1), f = e - (e / F) * F;
-            const long row = srow[tok];
-            if (g.fmt & 1) stage[j] = (e < TOK * F && row >= 0) ? unpack_bf16(*reinterpret_cast<const s4*>(reinterpret_cast<const unsigned short*>(qkv) + row * ld + h0 * 3 * d + 4 * f)) : zero4();
-            else stage[j] = (e < TOK * F && row >= 0) ? ld4(qkv + row * ld + h0 * 3 * d + 4 * f) : zero4();
-        }
+            for (int j = 0; j < NL; ++j) {
+                const int e = tid + j * NTHR, tok = min(e / F, TOK - 1), f = e - (e / F) * F;
+                const long row = srow[tok];
+                ok |= (unsigned)(e < TOK * F && row >= 0) << j;
+                const long off = max(row, 0L) * ld + h0 * 3 * d + 4 * f;
+                if constexpr (Q16) stageh[j] = *reinterpret_cast<const u2_*>(reinterpret_cast<const unsigned short*>(qkv) + off);
+                else stage[j] = ld4(qkv + off);
+            }
 #pragma unroll
-        for (int j = 0; j < NLd; ++j) {
-            const int e = tid + j * NTHR, tok = min(e / Fd, TOK - 1), f = e - (e / Fd) * Fd;
-            const long row = srow[tok];
-            staged[j] = (e < TOK * Fd && row >= 0) ? ld4(dout + row * g.C + h0 * d + 4 * f) : zero4();
-        }
+            for (int j = 0; j < NLd; ++j) {
+                const int e = tid + j * NTHR, tok = min(e / Fd, TOK - 1), f = e - (e / Fd) * Fd;
+                const long row = srow[tok];
+                okd |= (unsigned)(e < TOK * Fd && row >= 0) << j;
+                staged[j] = ld4(dout + max(row, 0L) * g.C + h0 * d + 4 * f);
+            }
 #pragma unroll
-        for (int j = 0; j < NLl; ++j) {
-            const int e = tid + j * NTHR, hh = min(e / TOK, HG - 1), tok = e - (e / TOK) * TOK;
-            const long row = srow[tok];
-            stagel[j] = (e < HG * TOK && row >= 0) ? lse[row * g.heads + h0 + hh] : 0.f;
-        }
+            for (int j = 0; j < NLl; ++j) {
+                const int e = tid + j * NTHR, hh = min(e / TOK, HG - 1), tok = e - (e / TOK) * TOK;
+                const long row = srow[tok];
+                okl |= (unsigned)(e < HG * TOK && row >= 0) << j;
+                stagel[j] = lse[max(row, 0L) * g.heads + h0 + hh];
+            }
 #pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            const int e = tid + j * NTHR, tok = e / F, f = e - tok * F;
-            if (e < TOK * F) *reinterpret_cast<f4*>(smem + tok * S + 4 * f) = stage[j];
-        }
+            for (int j = 0; j < NL; ++j) {
+                const int e = tid + j * NTHR, tok = e / F, f = e - tok * F;
+                f4 v;
+                if constexpr (Q16) v = unpack_bf16(__builtin_bit_cast(s4, stageh[j])); else v = stage[j];
+                if (e < TOK * F) *reinterpret_cast<f4*>(smem + tok * S + 4 * f) = (ok >> j) & 1u ? v : zero4();
+            }
 #pragma unroll
-        for (int j = 0; j < NLd; ++j) {
-            const int e = tid + j * NTHR, tok = e / Fd, f = e - tok * Fd;
-            if (e < TOK * Fd) *reinterpret_cast<f4*>(sdo + tok * Sd + 4 * f) = staged[j];
-        }
+            for (int j = 0; j < NLd; ++j) {
+                const int e = tid + j * NTHR, tok = e / Fd, f = e - tok * Fd;
+                if (e < TOK * Fd) *reinterpret_cast<f4*>(sdo + tok * Sd + 4 * f) = (okd >> j) & 1u ? staged[j] : zero4();
+            }
 #pragma unroll
-        for (int j = 0; j < NLl; ++j) {
-            const int e = tid + j * NTHR;
-            if (e < HG * TOK) sL[e] = stagel[j];
-        }
+            for (int j = 0; j < NLl; ++j) {
+                const int e = tid + j * NTHR;
+                if (e < HG * TOK) sL[e] = (okl >> j) & 1u ? stagel[j] : 0.f;
+            }
+        };
+        if (g.fmt & 1) stage_all(std::true_type{}); else stage_all(std::false_type{});
     }
     __syncthreads();
     const float* hb = smem + hl * 3 * d;
