@@ -1544,8 +1544,15 @@ static inline int launch_wgradw(const float* dy, long lddy, const XL& xl, float*
     if (M <= 0) return LEOD_OK;
     if ((N & 3) || (K & 3) || (lddy & 3)) return LEOD_ERR_ARG;      // 16-byte row loads
     if (K <= 48 && N <= 48) return launch_wgradw_cfg<3, 3, 3, 3, 64>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s, dyfmt);
+    // 32-row chunks (half the barriers, twice the bytes in flight per round) pay for the short row ranges of stages 3-4 with plain or
+    // fp16 X rows: 72 -> 63 us (fc2, stage 4), 118 -> 94 us (LSTM); the LayerNorm variant spills at 128 VGPRs and the long ranges of
+    // stage 2 are indifferent or slower
+    static const int rc32_on = getenv("LEOD_WGRADW_RC32") ? atoi(getenv("LEOD_WGRADW_RC32")) : 1;
+    bool rc32 = false;
+    if constexpr (x_two_phase<XL>::value) rc32 = rc32_on && M <= 65536 && xl.x_mode() != 1 && leod_precision() == 1;
     if (K <= 48) return launch_wgradw_cfg<12, 3, 3, 3, 16>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s, dyfmt);
     if (N <= 48) return launch_wgradw_cfg<3, 12, 3, 3, 16>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s, dyfmt);
+    if (rc32) return launch_wgradw_cfg<6, 6, 3, 3, 32>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s, dyfmt);
     return launch_wgradw_cfg<6, 6, 3, 3, 16>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s, dyfmt);
 }
 // large row counts only: small problems keep the round-robin kernel (more workgroups per output tile)
