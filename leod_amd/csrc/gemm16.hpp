@@ -22,6 +22,7 @@
 //     transposed stay in natural layout (16-byte stores) and are read with 4 x ds_read_b32 at a stride == 4 (mod 8).
 //
 #pragma once
+#include <type_traits>
 #include <stdlib.h>
 #include "common.hpp"
 
@@ -1301,8 +1302,21 @@ static inline int launch_wgrad16(const float* dy, long lddy, const XL& xl, float
 //   * waves left over after tiling the output (48x48) split the 16-row steps of a chunk (MS-way) instead.
 // dW accumulates with one fp32 atomic per element and workgroup, dbias from the staged dY values as before.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TN, int TK, int WA, int WB, int RC, bool BF, class XL, int DYF = -1, int XM = 0>   // DYF: dY fp32 (0) / bf16 (1); -1: runtime dyfmt
-__global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict__ dy, long lddy, XL xl, float* dW, long ldw,
+// LDS floats of one row group's double-buffered staging / of the whole workgroup (NG row groups: the staging of all groups, or the
+// accumulator exchange of the epilogue that reuses the same bytes)
+template <int TN, int TK, int RC, bool BF>
+constexpr int wgradw_stage_floats() {
+    return BF ? 2 * (((RC / 16) * TN * (16 * 16 + 16)) / 2 + ((RC / 16) * TK * (16 * 16 + 16)) / 2) : 2 * (RC * (16 * TN + 4) + RC * (16 * TK + 4));
+}
+template <int TN, int TK, int WA, int WB, int RC, bool BF, int NG>
+constexpr int wgradw_lds_floats() {
+    return NG * wgradw_stage_floats<TN, TK, RC, BF>() > (NG - 1) * WA * WB * 1024 ? NG * wgradw_stage_floats<TN, TK, RC, BF>() : (NG - 1) * WA * WB * 1024;
+}
+// NG > 1: the workgroup is NG independent 4-wave ROW GROUPS (own staging buffers, alternate row chunks, common barriers) that add
+// their accumulators through LDS before the epilogue: the same waves per CU in flight with 1 / NG of the dW atomics (each a fabric
+// write of 4 bytes: 9.4 M of them per launch were 20-30 us of a ~100 us launch).
+template <int TN, int TK, int WA, int WB, int RC, bool BF, class XL, int DYF = -1, int XM = 0, int NG = 1>   // DYF: dY fp32 (0) / bf16 (1); -1: runtime dyfmt
+__global__ __launch_bounds__(256 * NG, 4) void wgradw_kernel(const float* __restrict__ dy, long lddy, XL xl, float* dW, long ldw,
                                                      float* dbias, int M, int N, int K, int dyfmt) {
     constexpr int NWN = TN / WA, NWK = TK / WB, MS = 4 / (NWN * NWK);      // wave grid over the tile, row-step split
     static_assert(TN % WA == 0 && TK % WB == 0 && NWN * NWK * MS == 4, "4 waves must tile the workgroup");
@@ -1320,17 +1334,21 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
     constexpr int C4N = TN * 4, C4K = TK * 4;
     constexpr int NV = C4N * RC, KV = C4K * RC;
     constexpr int RN = (NV + 255) / 256, RK = (KV + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float sdy[2][BF ? ((RC / 16) * TN * BST) / 2 : RC * LDN];
-    __shared__ __attribute__((aligned(16))) float sx[2][BF ? ((RC / 16) * TK * BST) / 2 : RC * LDK];
+    constexpr int SDY = BF ? ((RC / 16) * TN * BST) / 2 : RC * LDN, SX = BF ? ((RC / 16) * TK * BST) / 2 : RC * LDK;
+    static_assert(2 * (SDY + SX) == wgradw_stage_floats<TN, TK, RC, BF>(), "staging size");
+    __shared__ __attribute__((aligned(16))) float slds[wgradw_lds_floats<TN, TK, WA, WB, RC, BF, NG>()];
     __shared__ float sbias[16 * TN];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = NG > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;      // row group of this wave
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    float* const sdy0 = slds + grp * (2 * (SDY + SX));       // [2][SDY] then [2][SX] of this group
+    float* const sx0 = sdy0 + 2 * SDY;
     const int i = lane & 15, q = lane >> 4;
     const int wa = wave % NWN, wb = (wave / NWN) % NWK, ws = wave / (NWN * NWK);
     const int n0 = blockIdx.y * TN * 16, k0 = blockIdx.z * TK * 16;
     // chunk c of this workgroup covers rows (blockIdx.x + c * gridDim.x) * RC ..: at any moment the resident workgroups
     // stream ONE contiguous window of dY / X (DRAM-page and TLB friendly) instead of gridDim.x far-apart row ranges
-    const int mbeg = blockIdx.x * RC;
-    const long mstride = (long)gridDim.x * RC;
+    const int mbeg = (blockIdx.x * NG + grp) * RC;
+    const long mstride = (long)gridDim.x * NG * RC;
     const int mend = M;
     const bool do_bias = dbias != nullptr && blockIdx.z == 0;
     int nr[RN], kr[RK], nl[RN], kl[RK], kc[RK];
@@ -1357,7 +1375,7 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
         for (int b = 0; b < WB; ++b) acc[a][b] = zero4();
 #pragma unroll
     for (int e = 0; e < RN; ++e) bacc[e] = zero4();
-    if (tid < 16 * TN) sbias[tid] = 0.f;
+    if ((int)threadIdx.x < 16 * TN) sbias[threadIdx.x] = 0.f;
     // ---- two-phase staging: issue() only starts the loads of a chunk (unconditional, on clamped coordinates), finish() turns the
     // raw registers into operand values (bf16 unpack, GELU, LayerNorm, edge masks) right before they are stashed.  With the
     // arithmetic of the loaders sitting behind each load the compiler waited for every load in turn: 5-6 serialized memory
@@ -1372,7 +1390,7 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
     for (int e = 0; e < RK; ++e) kcc[e] = kok[e] ? kc[e] : 0;      // (the raw registers stay uninitialised: each is written and read under the same
                                                                     // workgroup-uniform mode test, and an initial value would become a copy behind every load)
     if constexpr (TP && XM == 1) {
-        for (int c = tid; c < 16 * TK; c += 256) { sln[0][c] = k0 + c < K ? xl.ln_w[k0 + c] : 0.f; sln[1][c] = k0 + c < K ? xl.ln_b[k0 + c] : 0.f; }
+        for (int c = threadIdx.x; c < 16 * TK; c += 256 * NG) { sln[0][c] = k0 + c < K ? xl.ln_w[k0 + c] : 0.f; sln[1][c] = k0 + c < K ? xl.ln_b[k0 + c] : 0.f; }
         __syncthreads();
     }
     auto fetch = [&](long m0) {
@@ -1415,8 +1433,8 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
     };
     auto stash = [&](int buf) {
         if constexpr (BF) {
-            unsigned short* __restrict__ d16 = reinterpret_cast<unsigned short*>(sdy[buf]);
-            unsigned short* __restrict__ x16 = reinterpret_cast<unsigned short*>(sx[buf]);
+            unsigned short* __restrict__ d16 = reinterpret_cast<unsigned short*>(sdy0 + buf * SDY);
+            unsigned short* __restrict__ x16 = reinterpret_cast<unsigned short*>(sx0 + buf * SX);
 #pragma unroll
             for (int e = 0; e < RN; ++e) {
                 if (tid + 256 * e < NV) *reinterpret_cast<s4*>(d16 + nl[e]) = pack_bf16(rn[e]);
@@ -1428,12 +1446,12 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
         } else {
 #pragma unroll
         for (int e = 0; e < RN; ++e) {
-            if (tid + 256 * e < NV) *reinterpret_cast<f4*>(&sdy[buf][nl[e]]) = rn[e];
+            if (tid + 256 * e < NV) *reinterpret_cast<f4*>(sdy0 + buf * SDY + nl[e]) = rn[e];
             bacc[e] += rn[e];
         }
 #pragma unroll
         for (int e = 0; e < RK; ++e)
-            if (tid + 256 * e < KV) *reinterpret_cast<f4*>(&sx[buf][kl[e]]) = rk[e];
+            if (tid + 256 * e < KV) *reinterpret_cast<f4*>(sx0 + buf * SX + kl[e]) = rk[e];
         }
     };
     int buf = 0;
@@ -1441,13 +1459,16 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
     finish(mbeg);
     stash(0);
     __syncthreads();
-    for (long m0 = mbeg; m0 < mend; m0 += mstride) {
-        const bool more = m0 + mstride < mend;
+    // the trip count is that of the workgroup's first row group, so that every group meets every barrier (a group whose chunk lies
+    // past the last row stages zeros: clamped loads, masked in finish)
+    for (long mb = (long)blockIdx.x * NG * RC; mb < mend; mb += mstride) {
+        const long m0 = mb + grp * RC;
+        const bool more = mb + mstride < mend;
         if (more) fetch(m0 + mstride);                      // next chunk's global loads fly under this chunk's MFMAs
         if constexpr (BF) {
             typedef __attribute__((address_space(3))) s4 lds_s4;
-            const unsigned short* __restrict__ pdy = reinterpret_cast<const unsigned short*>(sdy[buf]) + offA;
-            const unsigned short* __restrict__ px = reinterpret_cast<const unsigned short*>(sx[buf]) + offB;
+            const unsigned short* __restrict__ pdy = reinterpret_cast<const unsigned short*>(sdy0 + buf * SDY) + offA;
+            const unsigned short* __restrict__ px = reinterpret_cast<const unsigned short*>(sx0 + buf * SX) + offB;
 #pragma unroll
             for (int st = ws; st < STEPS; st += MS) {
                 s4 pa[WA], pb[WB];
@@ -1461,8 +1482,8 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
                     for (int b = 0; b < WB; ++b) acc[a][b] = mfma16_bf16(pa[a], pb[b], acc[a][b]);
             }
         } else {
-        const float* __restrict__ pdy = sdy[buf] + offA;
-        const float* __restrict__ px = sx[buf] + offB;
+        const float* __restrict__ pdy = sdy0 + buf * SDY + offA;
+        const float* __restrict__ px = sx0 + buf * SX + offB;
 #pragma unroll
         for (int st = ws; st < STEPS; st += MS) {
             f4 av[WA], bv[WB];
@@ -1488,10 +1509,34 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
         __syncthreads();
         buf ^= 1;
     }
+    if constexpr (NG > 1) {
+        // accumulator exchange (the staging bytes are dead after the loop's last barrier): tile ab belongs to group ab % NG, every
+        // other group parks its copy in LDS, the owner adds them up and issues the tile's atomics
+        f4* sred = reinterpret_cast<f4*>(slds);
+#pragma unroll
+        for (int a = 0; a < WA; ++a)
+#pragma unroll
+            for (int b = 0; b < WB; ++b) {
+                const int ab = a * WB + b, owner = ab % NG;
+                if (grp != owner) sred[(ab * (NG - 1) + (grp - (grp > owner ? 1 : 0))) * 256 + tid] = acc[a][b];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < WA; ++a)
+#pragma unroll
+            for (int b = 0; b < WB; ++b) {
+                const int ab = a * WB + b, owner = ab % NG;
+                if (grp == owner) {
+#pragma unroll
+                    for (int o = 0; o < NG - 1; ++o) acc[a][b] += sred[(ab * (NG - 1) + o) * 256 + tid];
+                }
+            }
+    }
 #pragma unroll
     for (int a = 0; a < WA; ++a)
 #pragma unroll
         for (int b = 0; b < WB; ++b) {
+            if (NG > 1 && grp != (a * WB + b) % NG) continue;
             const int k = k0 + 16 * (wb * WB + b) + i;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1508,7 +1553,7 @@ __global__ __launch_bounds__(256, 4) void wgradw_kernel(const float* __restrict_
                 for (int j = 0; j < 4; ++j) atomicAdd(&sbias[c + j], bacc[e][j]);
             }
         __syncthreads();
-        if (tid < 16 * TN && n0 + tid < N) atomicAdd(dbias + n0 + tid, sbias[tid]);
+        if (grp == 0 && tid < 16 * TN && n0 + tid < N) atomicAdd(dbias + n0 + tid, sbias[tid]);
     }
 }
 
@@ -1517,10 +1562,28 @@ static inline int launch_wgradw_cfg(const float* dy, long lddy, const XL& xl, fl
                                     int M, int N, int K, hipStream_t s, int dyfmt = 0) {
     const int tiles = cdiv(N, TN * 16) * cdiv(K, TK * 16);
     static const int tune_blocks = getenv("LEOD_WGRADW_BLOCKS") ? atoi(getenv("LEOD_WGRADW_BLOCKS")) : 1024;   // 4 workgroups per CU resident
+    static const int tune_ng = getenv("LEOD_WGRADW_NG") ? atoi(getenv("LEOD_WGRADW_NG")) : 2;               // row groups per workgroup
+    static const int tune_align = getenv("LEOD_WGRADW_ALIGN8") ? atoi(getenv("LEOD_WGRADW_ALIGN8")) : 1;
     const int chunks = cdiv(M, RC);
-    const int gx = max(1, min(chunks / 4, tune_blocks / tiles));      // >= 4 chunks per workgroup: one atomic per dW element each
-    dim3 grid(gx, cdiv(N, TN * 16), cdiv(K, TK * 16));
-#define LEOD_WGRADW_GO(BFV, DYFV, XMV) hipLaunchKernelGGL((wgradw_kernel<TN, TK, WA, WB, RC, BFV, XL, DYFV, XMV>), grid, dim3(256), 0, s, dy, lddy, xl, dW, ldw, dbias, M, N, K, dyfmt)
+    auto go = [&](auto bfc, auto dyfc, auto xmc, auto ngc) {
+        constexpr bool BFV = decltype(bfc)::value;
+        constexpr int DYFV = decltype(dyfc)::value, XMV = decltype(xmc)::value, NGR = decltype(ngc)::value;
+        // the row groups' staging (or their accumulator exchange) must fit the 64 KB of static LDS next to sbias / sln
+        constexpr int NGE = (wgradw_lds_floats<TN, TK, WA, WB, RC, BFV, NGR>() + 16 * TN + 32 * TK + 64) * 4 <= 64 * 1024 ? NGR : 1;
+        // >= 4 chunks per row group (one atomic per dW element and workgroup); a multiple of 8 workgroups per output tile puts the
+        // workgroups that stream the same rows for different tiles on one XCD (dispatch slot = x + gx * tile): its L2 serves the re-reads
+        int gx = max(1, min(chunks / (4 * NGE), tune_blocks / (tiles * NGE)));
+        if (tune_align && gx >= 16) gx &= ~7;
+        dim3 grid(gx, cdiv(N, TN * 16), cdiv(K, TK * 16));
+        hipLaunchKernelGGL((wgradw_kernel<TN, TK, WA, WB, RC, BFV, XL, DYFV, XMV, NGE>), grid, dim3(256 * NGE), 0, s, dy, lddy, xl, dW, ldw,
+                           dbias, M, N, K, dyfmt);
+    };
+    using std::integral_constant;
+#define LEOD_WGRADW_GO(BFV, DYFV, XMV)                                                                                                  \
+    do {                                                                                                                                \
+        if (tune_ng == 2) go(integral_constant<bool, BFV>{}, integral_constant<int, DYFV>{}, integral_constant<int, XMV>{}, integral_constant<int, 2>{}); \
+        else go(integral_constant<bool, BFV>{}, integral_constant<int, DYFV>{}, integral_constant<int, XMV>{}, integral_constant<int, 1>{});             \
+    } while (0)
     if constexpr (x_two_phase<XL>::value) {                  // one instantiation per (dY format, X mode): no mode branches in the loop
         const int xm = xl.x_mode();
         if (leod_precision() == 1) {
@@ -1530,8 +1593,9 @@ static inline int launch_wgradw_cfg(const float* dy, long lddy, const XL& xl, fl
             if (dyfmt || xm == 2) return LEOD_ERR_ARG;       // 16-bit tensors exist in precision mode bf16 only
             if (xm == 1) LEOD_WGRADW_GO(false, 0, 1); else LEOD_WGRADW_GO(false, 0, 0);
         }
-    } else {
-        if (leod_precision() == 1) LEOD_WGRADW_GO(true, -1, 0); else LEOD_WGRADW_GO(false, -1, 0);
+    } else {                                                 // gather loaders (conv / stem): one row group
+        if (leod_precision() == 1) go(integral_constant<bool, true>{}, integral_constant<int, -1>{}, integral_constant<int, 0>{}, integral_constant<int, 1>{});
+        else go(integral_constant<bool, false>{}, integral_constant<int, -1>{}, integral_constant<int, 0>{}, integral_constant<int, 1>{});
     }
 #undef LEOD_WGRADW_GO
     return leod_launch_status();
