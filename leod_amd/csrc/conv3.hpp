@@ -1,4 +1,4 @@
-// Direct 3x3 / stride-1 convolution (k_conv3.hip), called from the conv entry points of k_conv.hip in precision mode bf16.
+// Direct 3x3 convolution (stride 1; weight gradient also stride 2) (k_conv3.hip), called from the conv entry points of k_conv.hip in precision mode bf16.
 #pragma once
 #include <stddef.h>
 #include <hip/hip_runtime.h>
@@ -7,6 +7,7 @@ bool conv3s1_supported(int H, int W, int Cin, int Cout);
 size_t conv3s1_pack_bytes(int Cin, int Cout);
 int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, int stat_rep, int accumulate, int B, int H, int W,
                    int Cin, int Cout, int transposed, void* wpack, hipStream_t stream);
-bool conv3s1_wgrad_supported(int H, int W, int Cin, int Cout);
-size_t conv3s1_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout);
-int conv3s1_wgrad_launch(const float* dy, const float* x, float* dW, float* ws, int B, int H, int W, int Cin, int Cout, hipStream_t stream);
+// weight gradient of a 3x3 / pad-1 conv of stride 1 or 2 (x [B,H,W,Cin], dy [B,H/stride,W/stride,Cout])
+bool conv3_wgrad_supported(int H, int W, int Cin, int Cout, int stride);
+size_t conv3_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride);
+int conv3_wgrad_launch(const float* dy, const float* x, float* dW, float* ws, int B, int H, int W, int Cin, int Cout, int stride, hipStream_t stream);

@@ -343,8 +343,8 @@ static int wgrad_any(const float* dy, const XL& xl, float* dW, long ldw, float* 
 // dw[N,Cin,ks,ks] += dy^T im2col(x) ; dbias[N] += colsum(dy)
 // floats of workspace leod_conv_nhwc_wgrad wants for this shape in the current precision mode (0: none)
 LEOD_API long leod_conv_nhwc_wgrad_workspace_floats(int B, int H, int W, int Cin, int N, int ks, int stride, int pad, int has_bias) {
-    if (ks == 3 && stride == 1 && pad == 1 && !has_bias && conv3s1_wgrad_supported(H, W, Cin, N))
-        return (long)conv3s1_wgrad_workspace_floats(B, H, W, Cin, N);
+    if (ks == 3 && pad == 1 && !has_bias && conv3_wgrad_supported(H, W, Cin, N, stride))
+        return (long)conv3_wgrad_workspace_floats(B, H, W, Cin, N, stride);
     return 0;
 }
 
@@ -357,8 +357,8 @@ LEOD_API int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, fl
         XRows xl{x, (long)Cin, nullptr, nullptr, nullptr, nullptr, 0, 0};
         return wgrad_any(dy, xl, dw, (long)Cin, dbias, M, N, K, stream);
     }
-    if (ks == 3 && stride == 1 && pad == 1 && !dbias && ws && conv3s1_wgrad_supported(H, W, Cin, N))
-        return conv3s1_wgrad_launch(dy, x, dw, ws, B, H, W, Cin, N, stream);
+    if (ks == 3 && pad == 1 && !dbias && ws && conv3_wgrad_supported(H, W, Cin, N, stride))
+        return conv3_wgrad_launch(dy, x, dw, ws, B, H, W, Cin, N, stride, stream);
     XConvNHWC xl{x, H, W, Cin, Ho, Wo, ks, stride, pad};
     return wgrad_any(dy, xl, dw, (long)K, dbias, M, N, K, stream);
 }

@@ -211,31 +211,38 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Weight gradient of the same convolution: dW[n][c][tap] += sum_p dy[p][n] x[p + off(tap)][c].
-// A workgroup stages the bf16 input halo and the bf16 dy rows of a region once and contracts over the region's pixels for the three
-// taps of one kernel row (blockIdx.y): both MFMA operands are COLUMNS of pixel-major LDS tiles, read with ds_read_b64_tr_b16 (the
-// lane supplies the address of "its" pixel row, the hardware transposes 4 pixels x 16 channels per 16-lane group); the dy
-// fragments are shared by the three taps.  Each wave keeps a 3 x 3 block of 16 x 16 tiles per tap (27 accumulator tiles), the
-// workgroup walks over regions r, r + gridDim.x, ... and writes its partial sums with plain stores to part[worker][tap][n][c]
-// (c contiguous); conv3_wgrad_reduce_kernel adds the workers' partials into dW[n][c][tap].  No atomics: scattered 4-byte atomics into
-// the [n][c][3][3] layout ran at ~28 per ns (the atomic version of this kernel took 200 us, 94 us of it for 2.6 M atomics), and the
-// result is bitwise reproducible.
-// NA = N / 16, NB = Cin / 16 (both even: the 4 waves split the (n, c) tile grid 2 x 2).
+// Weight gradient of a 3 x 3 / pad-1 convolution of stride S (1: PAFPN / head, 2: the backbone's downsampling convs and the PAFPN
+// bottom-up convs): dW[n][c][tap] += sum_p dy[p][n] x[S p + off(tap)][c].
+// A workgroup stages the bf16 input halo and the bf16 dy rows of a region (whole output rows of one image, <= 160 pixels) once and
+// contracts over the region's pixels for the three taps of one kernel row (blockIdx.y): both MFMA operands are COLUMNS of pixel-major
+// LDS tiles, read with ds_read_b64_tr_b16 (the lane supplies the address of "its" pixel row -- for stride 2 simply every other halo
+// pixel -- and the hardware transposes 4 pixels x 16 channels per 16-lane group); the dy fragments are shared by the three taps.
+// blockIdx.z picks a 16 NA x 16 NB slice of the (n, c) plane (wide layers: 192 -> 384 is 4 x 2 slices of 96 x 96).  Each wave keeps
+// a 3 x 3 block of 16 x 16 tiles per tap (27 accumulator tiles): the 4 waves split the slice 2 x 2, or -- 48 input channels -- 2 x 1
+// with the pixel steps dealt to the two halves.  The workgroup walks over regions r, r + gridDim.x, ... and writes its partial sums
+// with plain stores to part[worker][tap][n][c] (c contiguous); conv3_wgrad_reduce_kernel adds the workers' partials into
+// dW[n][c][tap].  No atomics: scattered 4-byte atomics into the [n][c][3][3] layout ran at ~28 per ns (the atomic version of this
+// kernel took 200 us, 94 us of it for 2.6 M atomics), and the result is bitwise reproducible.
+// The pixel-row stride of the halo tile is chosen so that the 4 pixel rows of a transpose read fall into different 32-byte bank
+// groups: S * LDX * 2 bytes is an odd multiple of 32 modulo 256 (LDX = CI + 16 for stride 1, CI + 8 for stride 2).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NA, int NB>
-__global__ __launch_bounds__(256) void conv3s1_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
-                                                             int B, int H, int W, int RH, int nregions) {
-    static_assert(NA % 2 == 0 && NB % 2 == 0, "the 4 waves split the tile grid 2 x 2");
-    constexpr int N = 16 * NA, CI = 16 * NB, LDX = CI + 16, LDY = N + 16, TA = NA / 2, TB = NB / 2, MAXS = 5;
+template <int NA, int NB, int S, int HB = 12>                      // HB: 16-byte staging loads in flight per thread
+__global__ __launch_bounds__(256) void conv3_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
+                                                           int B, int H, int W, int Ho, int Wo, int Ntot, int Ctot, int RH, int nregions) {
+    static_assert(NA % 2 == 0, "two wave rows over the output channels");
+    constexpr int WVB = NB % 2 == 0 ? 2 : 1, WVS = 2 / WVB;               // waves: 2 (n) x WVB (c) x WVS (pixel steps)
+    constexpr int N = 16 * NA, CI = 16 * NB, LDX = CI + (S == 1 ? 16 : 8), LDY = N + 16, TA = NA / 2, TB = NB / WVB;
     typedef __attribute__((address_space(3))) s4 lds_s4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int wa = wave & 1, wb = wave >> 1;
+    const int wa = wave & 1, wb = WVB == 2 ? wave >> 1 : 0, ws = WVB == 2 ? 0 : wave >> 1;
     const int g = blockIdx.y;                                     // kernel row: taps 3g .. 3g + 2
+    const int nsl = Ntot / N;
+    const int n0 = ((int)blockIdx.z % nsl) * N, c0 = ((int)blockIdx.z / nsl) * CI;
     const int WH = W + 2;
     bf16_t* halo = reinterpret_cast<bf16_t*>(smem_raw);
-    bf16_t* sdy = halo + (((RH + 2) * WH * LDX + 7) & ~7);
+    bf16_t* sdy = halo + (((S * (RH - 1) + 3) * WH * LDX + 7) & ~7);
     f4 acc[3][TA][TB];
 #pragma unroll
     for (int j = 0; j < 3; ++j)
@@ -243,15 +250,16 @@ __global__ __launch_bounds__(256) void conv3s1_wgrad_kernel(const float* __restr
         for (int a = 0; a < TA; ++a)
 #pragma unroll
             for (int b = 0; b < TB; ++b) acc[j][a][b] = zero4();
-    const int rblocks = (H + RH - 1) / RH;
+    const int rblocks = (Ho + RH - 1) / RH;
     for (int reg = blockIdx.x; reg < nregions; reg += gridDim.x) {
         const int b = reg / rblocks, y0 = (reg - b * rblocks) * RH;
-        const int rows = min(RH, H - y0);
-        const int P = rows * W, P32 = (P + 31) & ~31, steps = P32 >> 5;
+        const int rows = min(RH, Ho - y0);
+        const int P = rows * Wo, P32 = (P + 31) & ~31, steps = P32 >> 5;
         // ---- stage the input halo and the dy rows (bf16); all loads of a batch before the first LDS store -----------------------
-        const int hslots = (rows + 2) * WH * (CI / 4);
-        const float* xb = x + (long)b * H * W * CI;
-        constexpr int HB = 12;
+        // (issuing a region's loads before the previous region's MFMAs -- 28 + 12 staging registers per lane carried across the
+        // contraction -- was slower on every shape: 175 -> 189 us stage 2, 169 -> 265 us stage 4)
+        const int hslots = (S * (rows - 1) + 3) * WH * (CI / 4);
+        const float* xb = x + (long)b * H * W * Ctot + c0;
         for (int e0 = tid; e0 < hslots; e0 += 256 * HB) {
             f4 hv[HB]; int ho[HB];
 #pragma unroll
@@ -259,24 +267,24 @@ __global__ __launch_bounds__(256) void conv3s1_wgrad_kernel(const float* __restr
                 const int e = e0 + 256 * j;
                 const int hp = e / (CI / 4), c4 = (e - hp * (CI / 4)) * 4;
                 const int hy = hp / WH, hx = hp - hy * WH;
-                const int iy = y0 - 1 + hy, ix = hx - 1;
+                const int iy = S * y0 - 1 + hy, ix = hx - 1;
                 ho[j] = e < hslots ? hp * LDX + c4 : -1;
                 hv[j] = zero4();
-                if (e < hslots && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) hv[j] = ld4(xb + ((long)iy * W + ix) * CI + c4);
+                if (e < hslots && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) hv[j] = ld4(xb + ((long)iy * W + ix) * Ctot + c4);
             }
 #pragma unroll
             for (int j = 0; j < HB; ++j)
                 if (ho[j] >= 0) *reinterpret_cast<s4*>(halo + ho[j]) = pack_bf16(hv[j]);
         }
         const int dslots = P32 * (N / 4);
-        const float* dyb = dy + ((long)(b * H + y0) * W) * N;
+        const float* dyb = dy + ((long)(b * Ho + y0) * Wo) * Ntot + n0;
         for (int e0 = tid; e0 < dslots; e0 += 256 * HB) {
             f4 hv[HB];
 #pragma unroll
             for (int j = 0; j < HB; ++j) {
                 const int e = e0 + 256 * j;
-                const int p = e / (N / 4);
-                hv[j] = (e < dslots && p < P) ? ld4(dyb + (long)e * 4) : zero4();       // rows P .. P32 - 1: zeros (contribute nothing)
+                const int p = e / (N / 4), c4 = (e - p * (N / 4)) * 4;
+                hv[j] = (e < dslots && p < P) ? ld4(dyb + (long)p * Ntot + c4) : zero4();     // rows P .. P32 - 1: zeros (contribute nothing)
             }
 #pragma unroll
             for (int j = 0; j < HB; ++j) {
@@ -286,15 +294,15 @@ __global__ __launch_bounds__(256) void conv3s1_wgrad_kernel(const float* __restr
         }
         __syncthreads();
         // ---- contraction over the region's pixels, 32 per MFMA ----------------------------------------------------------------------
-        for (int s = 0; s < steps; ++s) {
+        for (int s = ws; s < steps; s += WVS) {
             // the two pixel rows this lane addresses in a transpose read: p = 32 s + 8 q + (i >> 2) (+ 4)
             int hx0[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 int p = 32 * s + 8 * q + 4 * h + (i >> 2);
                 if (p >= P) p = P - 1;                                               // dy is zero there: any valid pixel will do
-                const int py = p / W, px = p - py * W;
-                hx0[h] = ((py + g) * WH + px) * LDX + 4 * (i & 3);                   // tap (g, 0); taps (g, 1), (g, 2): + LDX, + 2 LDX
+                const int py = p / Wo, px = p - py * Wo;
+                hx0[h] = ((S * py + g) * WH + S * px) * LDX + 4 * (i & 3);           // tap (g, 0); taps (g, 1), (g, 2): + LDX, + 2 LDX
             }
             const bf16_t* pdy = sdy + (32 * s + 8 * q + (i >> 2)) * LDY + 4 * (i & 3);
             s8v av[TA];
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(256) void conv3s1_wgrad_kernel(const float* __restr
         __syncthreads();                                                             // the tiles are restaged for the next region
     }
     // ---- part[worker][3g + j][n][c] = acc: row 4q + r of tile (a, b) is output channel n, column i is input channel c ----------------
-    float* pw = part + (long)blockIdx.x * 9 * N * CI;
+    float* pw = part + (long)(blockIdx.x * WVS + ws) * 9 * Ntot * Ctot;
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -329,9 +337,128 @@ __global__ __launch_bounds__(256) void conv3s1_wgrad_kernel(const float* __restr
             for (int bb = 0; bb < TB; ++bb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int n = 16 * (TA * wa + a) + 4 * q + r, c = 16 * (TB * wb + bb) + i;
-                    pw[((long)(3 * g + j) * N + n) * CI + c] = acc[j][a][bb][r];
+                    const int n = n0 + 16 * (TA * wa + a) + 4 * q + r, c = c0 + 16 * (TB * wb + bb) + i;
+                    pw[((long)(3 * g + j) * Ntot + n) * Ctot + c] = acc[j][a][bb][r];
                 }
+}
+
+// Same contraction with all NINE taps in one 8-wave workgroup (conv3_wgrad_kernel is bound by its staging loads: the three kernel-row
+// workgroups of a region each fetch the same fp32 halo and dy rows).  Waves 0-3 own taps 0-4, waves 4-7 taps 5-8, each wave the same
+// 3 x 3 tile block as above per tap (45 / 36 accumulator tiles); a region's halo and dy rows are fetched and converted ONCE.
+template <int NA, int NB, int S, int HB = 8>
+__global__ __launch_bounds__(512) void conv3_wgrad9_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
+                                                            int B, int H, int W, int Ho, int Wo, int Ntot, int Ctot, int RH, int nregions) {
+    static_assert(NA % 2 == 0, "two wave rows over the output channels");
+    constexpr int WVB = NB % 2 == 0 ? 2 : 1, WVS = 2 / WVB;               // waves of a tap group: 2 (n) x WVB (c) x WVS (pixel steps)
+    constexpr int N = 16 * NA, CI = 16 * NB, LDX = CI + (S == 1 ? 16 : 8), LDY = N + 16, TA = NA / 2, TB = NB / WVB, NTH = 512, NJ = 5;
+    typedef __attribute__((address_space(3))) s4 lds_s4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2), w4 = wave & 3;
+    const int wa = w4 & 1, wb = WVB == 2 ? w4 >> 1 : 0, ws = WVB == 2 ? 0 : w4 >> 1;
+    const int nsl = Ntot / N;
+    const int n0 = ((int)blockIdx.y % nsl) * N, c0 = ((int)blockIdx.y / nsl) * CI;
+    const int WH = W + 2;
+    bf16_t* halo = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* sdy = halo + (((S * (RH - 1) + 3) * WH * LDX + 7) & ~7);
+    int toff[NJ];                                                 // halo offset of this wave's taps (the group of taps 5-8 repeats tap 8: not stored)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { const int t = min(5 * grp + j, 8); toff[j] = ((t / 3) * WH + (t % 3)) * LDX; }
+    f4 acc[NJ][TA][TB];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int a = 0; a < TA; ++a)
+#pragma unroll
+            for (int b = 0; b < TB; ++b) acc[j][a][b] = zero4();
+    const int rblocks = (Ho + RH - 1) / RH;
+    for (int reg = blockIdx.x; reg < nregions; reg += gridDim.x) {
+        const int b = reg / rblocks, y0 = (reg - b * rblocks) * RH;
+        const int rows = min(RH, Ho - y0);
+        const int P = rows * Wo, P32 = (P + 31) & ~31, steps = P32 >> 5;
+        const int hslots = (S * (rows - 1) + 3) * WH * (CI / 4);
+        const float* xb = x + (long)b * H * W * Ctot + c0;
+        for (int e0 = tid; e0 < hslots; e0 += NTH * HB) {
+            f4 hv[HB]; int ho[HB];
+#pragma unroll
+            for (int j = 0; j < HB; ++j) {
+                const int e = e0 + NTH * j;
+                const int hp = e / (CI / 4), c4 = (e - hp * (CI / 4)) * 4;
+                const int hy = hp / WH, hx = hp - hy * WH;
+                const int iy = S * y0 - 1 + hy, ix = hx - 1;
+                ho[j] = e < hslots ? hp * LDX + c4 : -1;
+                hv[j] = zero4();
+                if (e < hslots && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) hv[j] = ld4(xb + ((long)iy * W + ix) * Ctot + c4);
+            }
+#pragma unroll
+            for (int j = 0; j < HB; ++j)
+                if (ho[j] >= 0) *reinterpret_cast<s4*>(halo + ho[j]) = pack_bf16(hv[j]);
+        }
+        const int dslots = P32 * (N / 4);
+        const float* dyb = dy + ((long)(b * Ho + y0) * Wo) * Ntot + n0;
+        for (int e0 = tid; e0 < dslots; e0 += NTH * HB) {
+            f4 hv[HB];
+#pragma unroll
+            for (int j = 0; j < HB; ++j) {
+                const int e = e0 + NTH * j;
+                const int p = e / (N / 4), c4 = (e - p * (N / 4)) * 4;
+                hv[j] = (e < dslots && p < P) ? ld4(dyb + (long)p * Ntot + c4) : zero4();     // rows P .. P32 - 1: zeros (contribute nothing)
+            }
+#pragma unroll
+            for (int j = 0; j < HB; ++j) {
+                const int e = e0 + NTH * j;
+                if (e < dslots) { const int p = e / (N / 4), c4 = (e - p * (N / 4)) * 4; *reinterpret_cast<s4*>(sdy + p * LDY + c4) = pack_bf16(hv[j]); }
+            }
+        }
+        __syncthreads();
+        for (int s = ws; s < steps; s += WVS) {
+            int hx0[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int p = 32 * s + 8 * q + 4 * h + (i >> 2);
+                if (p >= P) p = P - 1;                                               // dy is zero there: any valid pixel will do
+                const int py = p / Wo, px = p - py * Wo;
+                hx0[h] = (S * py * WH + S * px) * LDX + 4 * (i & 3);                 // tap (0, 0); the others: + toff
+            }
+            const bf16_t* pdy = sdy + (32 * s + 8 * q + (i >> 2)) * LDY + 4 * (i & 3);
+            s8v av[TA];
+#pragma unroll
+            for (int a = 0; a < TA; ++a) {
+                const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(pdy + 16 * (TA * wa + a)));
+                const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(pdy + 4 * LDY + 16 * (TA * wa + a)));
+                av[a] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                for (int bb = 0; bb < TB; ++bb) {
+                    const int co = toff[j] + 16 * (TB * wb + bb);
+                    const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(halo + hx0[0] + co));
+                    const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(halo + hx0[1] + co));
+                    const s8v bv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int a = 0; a < TA; ++a) acc[j][a][bb] = mfma32_bf16(av[a], bv, acc[j][a][bb]);
+                }
+            }
+        }
+        __syncthreads();                                                             // the tiles are restaged for the next region
+    }
+    float* pw = part + (long)(blockIdx.x * WVS + ws) * 9 * Ntot * Ctot;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int t = 5 * grp + j;
+        if (t > 8) continue;
+#pragma unroll
+        for (int a = 0; a < TA; ++a)
+#pragma unroll
+            for (int bb = 0; bb < TB; ++bb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + 16 * (TA * wa + a) + 4 * q + r, c = c0 + 16 * (TB * wb + bb) + i;
+                    pw[((long)t * Ntot + n) * Ctot + c] = acc[j][a][bb][r];
+                }
+    }
 }
 
 // dW[n][c][tap] += sum over workers of part[worker][tap][n][c]
@@ -401,46 +528,112 @@ int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, i
     return LEOD_ERR_UNSUPPORTED;
 }
 
-bool conv3s1_wgrad_supported(int H, int W, int Cin, int Cout) {
+// shapes of the direct weight-gradient kernel: stride 1 or 2 (even H, W), output channels in slices of 96, input channels 48 or in
+// slices of 96
+bool conv3_wgrad_supported(int H, int W, int Cin, int Cout, int stride) {
     static const int on = getenv("LEOD_CONV3_DIRECT") ? atoi(getenv("LEOD_CONV3_DIRECT")) : 1;
+    static const int on2 = getenv("LEOD_CONV3_WGRAD_WIDE") ? atoi(getenv("LEOD_CONV3_WGRAD_WIDE")) : 1;      // everything but the 96 -> 96 / stride 1 case
     if (!on || leod_precision() != 1) return false;
-    return W <= 160 && W >= 4 && Cin == 96 && Cout == 96;
+    if (stride != 1 && stride != 2) return false;
+    if (stride == 2 && ((H & 1) || (W & 1))) return false;
+    const int Wo = W / stride;
+    if (Wo > 160 || Wo < 4 || Cout % 96 != 0) return false;
+    if (stride == 1 && Cin == 96 && Cout == 96) return true;
+    if (!on2) return false;
+    return Cin % 96 == 0 || (Cin == 48 && stride == 2);
 }
 
-static inline int conv3_wgrad_workers(int B, int H, int W, int Cin, int Cout, int* rh_out) {
-    const int LDX = Cin + 16, LDY = Cout + 16;
-    int RH = max(1, min(H, 160 / W));
+// the 8-wave / nine-tap kernel takes everything but the smallest problems (a few regions: the three kernel-row workgroups of
+// conv3_wgrad_kernel fill more CUs; 96 -> 96 on the 8 x 10 level: 17 vs 21 us)
+static inline bool conv3_wgrad_nine(int nregions, int nslices) {
+    static const int on = getenv("LEOD_CONV3_WGRAD9") ? atoi(getenv("LEOD_CONV3_WGRAD9")) : 1;
+    return on && nregions * nslices > 32;
+}
+struct Conv3WgradPlan { int RH, workers, wvs, nslices, ci; bool nine; size_t smem; };
+static inline Conv3WgradPlan conv3_wgrad_plan(int B, int H, int W, int Cin, int Cout, int S) {
+    Conv3WgradPlan pl{};
+    const int Ho = H / S, Wo = W / S;
+    pl.ci = Cin == 48 ? 48 : 96;
+    pl.wvs = pl.ci == 48 ? 2 : 1;
+    pl.nslices = (Cout / 96) * (Cin / pl.ci);
+    const int LDX = pl.ci + (S == 1 ? 16 : 8), LDY = 96 + 16;
+    static const int ldskb = getenv("LEOD_CONV3_WGRAD_LDSKB") ? atoi(getenv("LEOD_CONV3_WGRAD_LDSKB")) : 160;
+    int RH = max(1, min(Ho, 160 / Wo));
     while (RH > 0) {
-        const size_t halo = (((size_t)(RH + 2) * (W + 2) * LDX + 7) & ~(size_t)7) * 2;
-        const size_t sdy = (size_t)((RH * W + 31) & ~31) * LDY * 2;
-        if (halo + sdy <= 160 * 1024) break;
+        const size_t halo = (((size_t)(S * (RH - 1) + 3) * (W + 2) * LDX + 7) & ~(size_t)7) * 2;
+        const size_t sdy = (size_t)((RH * Wo + 31) & ~31) * LDY * 2;
+        pl.smem = halo + sdy;
+        if (pl.smem <= (size_t)ldskb * 1024) break;
         --RH;
     }
-    if (rh_out) *rh_out = RH;
-    if (RH <= 0) return 0;
-    static const int cap = getenv("LEOD_CONV3_WORKERS") ? atoi(getenv("LEOD_CONV3_WORKERS")) : 64;      // measured: 64 -> 42 us, 85 -> 47, 128 -> 51 (level-0 head conv)
-    return min(B * cdiv(H, RH), cap);      // region workers per kernel row: each walks over nregions / workers regions
-}
-
-// floats of scratch conv3s1_wgrad_launch needs (the workers' partial sums)
-size_t conv3s1_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout) {
-    return (size_t)conv3_wgrad_workers(B, H, W, Cin, Cout, nullptr) * 9 * Cin * Cout;
-}
-
-// dW[Cout][Cin][3][3] += wgrad of y = conv3x3(x) for dy [B,H,W,Cout], x [B,H,W,Cin]; ws: conv3s1_wgrad_workspace_floats floats
-int conv3s1_wgrad_launch(const float* dy, const float* x, float* dW, float* ws, int B, int H, int W, int Cin, int Cout, hipStream_t stream) {
-    int RH = 0;
-    const int workers = conv3_wgrad_workers(B, H, W, Cin, Cout, &RH);
-    if (workers <= 0 || !ws) return LEOD_ERR_UNSUPPORTED;
-    const int LDX = Cin + 16, LDY = Cout + 16;
-    const size_t smem = (((size_t)(RH + 2) * (W + 2) * LDX + 7) & ~(size_t)7) * 2 + (size_t)((RH * W + 31) & ~31) * LDY * 2;
-    const int nregions = B * cdiv(H, RH);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3s1_wgrad_kernel<6, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    if (RH <= 0) { pl.RH = 0; pl.workers = 0; return pl; }
+    RH = cdiv(Ho, cdiv(Ho, RH));                                  // equal row blocks
+    pl.smem = (((size_t)(S * (RH - 1) + 3) * (W + 2) * LDX + 7) & ~(size_t)7) * 2 + (size_t)((RH * Wo + 31) & ~31) * LDY * 2;
+    pl.RH = RH;
+    const int nregions = B * cdiv(Ho, RH);
+    // region workers per (kernel row, slice): each walks over nregions / workers regions.  96 -> 96 / stride 1 (level-0 head conv)
+    // measured: 64 -> 42 us, 85 -> 47, 128 -> 51; the sliced / strided shapes fill the chip once (3 * slices * workers ~ 256) with a
+    // multiple of 8 workers, so that the three kernel rows of a region (dispatch slots workers apart) share an XCD's L2
+    static const int cap = getenv("LEOD_CONV3_WORKERS") ? atoi(getenv("LEOD_CONV3_WORKERS")) : 64;
+    static const int fill = getenv("LEOD_CONV3_FILL") ? atoi(getenv("LEOD_CONV3_FILL")) : 256;
+    int workers = cap;
+    if (!(S == 1 && Cin == 96 && Cout == 96)) {
+        workers = max(1, fill / (3 * pl.nslices));
+        if (workers >= 8) workers &= ~7;
     }
-    hipLaunchKernelGGL((conv3s1_wgrad_kernel<6, 6>), dim3(workers, 3), dim3(256), smem, stream, dy, x, ws, B, H, W, RH, nregions);
-    hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(cdiv(9 * Cin * Cout, 256)), dim3(256), 0, stream, ws, dW, workers, Cout, Cin);
+    pl.nine = conv3_wgrad_nine(nregions, pl.nslices);
+    if (pl.nine) {
+        // 9-tap workgroups, one per CU (LDS): slices * workers of them, and each writes a whole 9 x 96 x CI slice of partial sums that
+        // the reduce kernel reads back -- 256 workgroups when each gets >= 2 regions (the backbone convs on 168 frames: stage 2
+        // 174 -> 103 us, stage 3 141 -> 69, stage 4 169 -> 74), 128 for the PAFPN / head convs on the 32 labelled frames (38 vs 43 us)
+        static const int fill9 = getenv("LEOD_CONV3_FILL9") ? atoi(getenv("LEOD_CONV3_FILL9")) : 0;
+        const int target = fill9 ? fill9 : (nregions * pl.nslices >= 512 ? 256 : 128);
+        workers = max(1, target / pl.nslices);
+    }
+    pl.workers = min(nregions, workers);
+    return pl;
+}
+
+// floats of scratch conv3_wgrad_launch needs (the workers' partial sums)
+size_t conv3_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride) {
+    const Conv3WgradPlan pl = conv3_wgrad_plan(B, H, W, Cin, Cout, stride);
+    return (size_t)pl.workers * pl.wvs * 9 * Cin * Cout;
+}
+
+// dW[Cout][Cin][3][3] += wgrad of y = conv3x3(x, stride) for dy [B,Ho,Wo,Cout], x [B,H,W,Cin]; ws: conv3_wgrad_workspace_floats floats
+int conv3_wgrad_launch(const float* dy, const float* x, float* dW, float* ws, int B, int H, int W, int Cin, int Cout, int stride, hipStream_t stream) {
+    const Conv3WgradPlan pl = conv3_wgrad_plan(B, H, W, Cin, Cout, stride);
+    if (pl.workers <= 0 || !ws) return LEOD_ERR_UNSUPPORTED;
+    const int Ho = H / stride, Wo = W / stride;
+    const int nregions = B * cdiv(Ho, pl.RH);
+    if (pl.nine) {
+        const dim3 grid9(pl.workers, pl.nslices);
+#define C3W9_CASE(NBV, SV)                                                                                                               \
+        if (pl.ci == 16 * NBV && stride == SV) {                                                                                         \
+            static bool attr_set = false;                                                                                                \
+            if (!attr_set) {                                                                                                             \
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgrad9_kernel<6, NBV, SV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                attr_set = true;                                                                                                         \
+            }                                                                                                                            \
+            hipLaunchKernelGGL((conv3_wgrad9_kernel<6, NBV, SV>), grid9, dim3(512), pl.smem, stream, dy, x, ws, B, H, W, Ho, Wo, Cout, Cin, pl.RH, nregions); \
+        } else
+        C3W9_CASE(6, 1) C3W9_CASE(6, 2) C3W9_CASE(3, 2) return LEOD_ERR_UNSUPPORTED;
+#undef C3W9_CASE
+        hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(cdiv(9 * Cin * Cout, 256)), dim3(256), 0, stream, ws, dW, pl.workers * pl.wvs, Cout, Cin);
+        return leod_launch_status();
+    }
+    const dim3 grid(pl.workers, 3, pl.nslices);
+#define C3W_CASE(NBV, SV, HBV)                                                                                                           \
+    if (pl.ci == 16 * NBV && stride == SV) {                                                                                             \
+        static bool attr_set = false;                                                                                                    \
+        if (!attr_set) {                                                                                                                 \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgrad_kernel<6, NBV, SV, HBV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                                                             \
+        }                                                                                                                                \
+        hipLaunchKernelGGL((conv3_wgrad_kernel<6, NBV, SV, HBV>), grid, dim3(256), pl.smem, stream, dy, x, ws, B, H, W, Ho, Wo, Cout, Cin, pl.RH, nregions); \
+    } else
+    C3W_CASE(6, 1, 12) C3W_CASE(6, 2, 12) C3W_CASE(3, 2, 12) return LEOD_ERR_UNSUPPORTED;      // (18 loads in flight: no faster)
+#undef C3W_CASE
+    hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(cdiv(9 * Cin * Cout, 256)), dim3(256), 0, stream, ws, dW, pl.workers * pl.wvs, Cout, Cin);
     return leod_launch_status();
 }

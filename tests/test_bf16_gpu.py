@@ -97,6 +97,34 @@ def test_conv3x3_direct_bf16(bf16_ops, B, H, W, Cin, N):
     tk.close(dw, 2 * w.grad, what='conv3x3 wgrad accumulates')
 
 
+@pytest.mark.parametrize('B,H,W,Cin,N,stride', [(5, 64, 80, 48, 96, 2),      # backbone downsampling, stage 2: 48-channel slice, pixel steps dealt to wave pairs
+                                                (3, 32, 40, 96, 192, 2),     # stage 3: two output-channel slices
+                                                (9, 16, 20, 192, 384, 2),    # stage 4: 4 x 2 slices, one region per image
+                                                (4, 32, 40, 96, 96, 2),      # PAFPN bottom-up conv
+                                                (2, 16, 20, 192, 192, 2), (3, 16, 20, 192, 192, 1),       # 192 -> 192, both strides
+                                                (2, 10, 12, 48, 96, 2), (1, 6, 8, 96, 96, 2), (70, 8, 12, 96, 96, 2),   # ragged regions, many regions per worker
+                                                (2, 18, 28, 96, 192, 1)])
+def test_conv3x3_wgrad_direct_bf16(bf16_ops, B, H, W, Cin, N, stride):
+    """The direct weight gradient of csrc/k_conv3.hip for stride 1 / 2 and sliced channel planes (conv3_wgrad_kernel) against torch's
+    fp32 conv2d on the CPU; it accumulates into dW."""
+    import torch.nn.functional as F
+    ops = bf16_ops
+    from leod_amd import _lib
+    assert _lib.lib().leod_conv_nhwc_wgrad_workspace_floats(B, H, W, Cin, N, 3, stride, 1, 0) > 0, 'shape must take the direct kernel'
+    x = tk.rnd((B, Cin, H, W), 1).requires_grad_(True)
+    w = tk.rnd((N, Cin, 3, 3), 2, 0.05).requires_grad_(True)
+    ref = F.conv2d(x, w, None, stride=stride, padding=1)
+    dy = tk.rnd(ref.shape, 3)
+    ref.backward(dy)
+    xn = x.detach().permute(0, 2, 3, 1).contiguous().to(tk.DEV)
+    dyn = dy.permute(0, 2, 3, 1).contiguous().to(tk.DEV)
+    dw = torch.zeros_like(w.detach(), device=tk.DEV)
+    ops.conv_nhwc_wgrad(dyn, xn, dw, None, stride=stride)
+    tk.close(dw, w.grad, what='conv3x3 wgrad (direct)')
+    ops.conv_nhwc_wgrad(dyn, xn, dw, None, stride=stride)
+    tk.close(dw, 2 * w.grad, what='conv3x3 wgrad (direct) accumulates')
+
+
 @pytest.mark.parametrize('B,H,W,C,heads', [(3, 16, 20, 48, 2), (2, 32, 40, 96, 4), (1, 8, 10, 384, 16)])
 @pytest.mark.parametrize('window', [True, False])
 def test_partition_attn_bf16_tensors(bf16_ops, B, H, W, C, heads, window):
