@@ -1314,7 +1314,9 @@ constexpr int wgradw_lds_floats() {
 }
 // NG > 1: the workgroup is NG independent 4-wave ROW GROUPS (own staging buffers, alternate row chunks, common barriers) that add
 // their accumulators through LDS before the epilogue: the same waves per CU in flight with 1 / NG of the dW atomics (each a fabric
-// write of 4 bytes: 9.4 M of them per launch were 20-30 us of a ~100 us launch).
+// write of 4 bytes: 9.4 M of them per launch were 20-30 us of a ~100 us launch).  Measured: NG = 2 -13.6 % over the 16 Linear shapes
+// of RVT-S in bf16 mode; NG = 4 (16-wave workgroups, exchange in two halves) is SLOWER than NG = 2 on every stage-2 shape
+// (91 -> 104, 104 -> 125, 146 -> 180 us): one barrier couples 16 waves per chunk.
 template <int TN, int TK, int WA, int WB, int RC, bool BF, class XL, int DYF = -1, int XM = 0, int NG = 1>   // DYF: dY fp32 (0) / bf16 (1); -1: runtime dyfmt
 __global__ __launch_bounds__(256 * NG, 4) void wgradw_kernel(const float* __restrict__ dy, long lddy, XL xl, float* dW, long ldw,
                                                      float* dbias, int M, int N, int K, int dyfmt) {
