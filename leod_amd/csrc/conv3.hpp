@@ -11,3 +11,6 @@ int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, i
 bool conv3_wgrad_supported(int H, int W, int Cin, int Cout, int stride);
 size_t conv3_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride);
 int conv3_wgrad_launch(const float* dy, const float* x, float* dW, float* ws, int B, int H, int W, int Cin, int Cout, int stride, hipStream_t stream);
+// input gradient of a 3x3 / stride-2 / pad-1 conv: dx [B,H,W,Cin] from dy [B,H/2,W/2,N], w [N][Cin][3][3]; wpack: conv3s1_pack_bytes(Cin, N)
+bool conv3s2_dgrad_supported(int H, int W, int Cin, int N);
+int conv3s2_dgrad_launch(const float* dy, const float* w, float* dx, int accumulate, int B, int H, int W, int Cin, int N, void* wpack, hipStream_t stream);

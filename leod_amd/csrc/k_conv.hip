@@ -291,6 +291,8 @@ LEOD_API int leod_conv_nhwc_dgrad(const float* dy, const float* w, float* dx, in
     const int M = B * H * W, K = ks * ks * N;
     if (ks == 3 && stride == 1 && pad == 1 && wpack && conv3s1_supported(H, W, N, Cin))
         return conv3s1_launch(dy, w, dx, nullptr, 0, accumulate, B, H, W, N, Cin, 1, wpack, stream);
+    if (ks == 3 && stride == 2 && pad == 1 && wpack && conv3s2_dgrad_supported(H, W, Cin, N))
+        return conv3s2_dgrad_launch(dy, w, dx, accumulate, B, H, W, Cin, N, wpack, stream);
     EpStore ep{}; ep.out = dx; ep.ld = Cin; ep.N = Cin; ep.accumulate = accumulate;
     const int nt = pick_nt(Cin);
     int rc = LEOD_OK;

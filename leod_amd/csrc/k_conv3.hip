@@ -211,6 +211,162 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Input gradient of a 3 x 3 / STRIDE-2 / pad-1 convolution (the backbone's downsampling convs, maxvit.py ConvDownsampling_Cf2Cl, and
+// the PAFPN bottom-up convs): dx[2a + py][2b + px][c] = sum over the live taps of dy[a + oy][b + ox][:] . w[:][c][ky][kx].
+// An input pixel of parity class (py, px) sees 1, 2, 2 or 4 of the nine taps (ky = 1 for even rows, ky in {0, 2} for odd rows, the
+// same in x), 2.25 on average; tap (ky, kx) feeds exactly one class, from the dy pixel shifted by (oy, ox) = (ky == 0, kx == 0).
+// So this is the forward kernel's loop with FOUR accumulator sets: a workgroup owns RH rows of "anchors" (a, b) = dy pixels, the bf16
+// dy halo ((RH + 1) x (Wo + 1) pixels, zero past the image) sits in LDS once, the nine per-tap weight tiles [48 input channels][N]
+// stream through a double-buffered LDS tile with three taps of register look-ahead, every MFMA is live work (the implicit GEMM over
+// parity classes on gemm_lds_kernel reached 80-107 TFLOP/s: its im2col chunks are rebuilt from global memory for every class).
+// KC = N / 16 (contraction: dy channels), 48 input channels (3 column tiles) per workgroup (blockIdx.y), TW anchor row tiles per wave.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KC, int TW>
+__global__ __launch_bounds__(256) void conv3s2_dgrad_kernel(const float* __restrict__ dy, const bf16_t* __restrict__ wp, float* __restrict__ dx,
+                                                             int accumulate, int B, int Ho, int Wo, int Cin, int RH) {
+    static_assert(KC % 2 == 0, "32-k MFMAs");
+    constexpr int NTO = 3, N = 16 * KC, LDP = N + 16, LDB = LDP, BN = NTO * 16, LDO = BN + 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int rblocks = (Ho + RH - 1) / RH;
+    const int b = blockIdx.x / rblocks, a0 = (blockIdx.x - b * rblocks) * RH;
+    const int rows = min(RH, Ho - a0);
+    const int P = rows * Wo, ntiles = (P + 15) >> 4;
+    const int c0 = blockIdx.y * BN;
+    const int WH = Wo + 1;
+    const int halo_elems = (RH + 1) * WH * LDP;
+    bf16_t* halo = reinterpret_cast<bf16_t*>(smem_raw);
+    bf16_t* sB = halo + ((halo_elems + 7) & ~7);                 // [2][BN * LDB]
+    constexpr int BSLOT = BN * (N / 8);                           // 16-byte slots of one tap's weight tile
+    constexpr int RB = (BSLOT + 255) / 256;
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    constexpr int PD = 3;
+    i4 rb[PD][RB];
+    // packed weights (conv3_pack_kernel mode 1): wp[8 - tap][c][n]
+    auto fetch_b = [&](int tap, i4 (&r)[RB]) {
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+            const int e = tid + 256 * p;
+            if (e < BSLOT) {
+                const int c = e / (N / 8), n8 = (e - c * (N / 8)) * 8;
+                r[p] = *reinterpret_cast<const i4*>(wp + ((long)(8 - tap) * Cin + c0 + c) * N + n8);
+            }
+        }
+    };
+    auto stash_b = [&](int buf, const i4 (&r)[RB]) {
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+            const int e = tid + 256 * p;
+            if (e < BSLOT) {
+                const int c = e / (N / 8), n8 = (e - c * (N / 8)) * 8;
+                *reinterpret_cast<i4*>(sB + buf * (BN * LDB) + c * LDB + n8) = r[p];
+            }
+        }
+    };
+    fetch_b(0, rb[0]);
+    fetch_b(1, rb[1]);
+    fetch_b(2, rb[2]);
+    // ---- dy halo: rows a0 .. a0 + rows, columns 0 .. Wo, zero past the image ------------------------------------------------------
+    const int hslots = (rows + 1) * WH * (N / 4);
+    const float* dyb = dy + (long)b * Ho * Wo * N;
+    constexpr int HB = 12;
+    for (int e0 = tid; e0 < hslots; e0 += 256 * HB) {
+        f4 hv[HB]; int ho[HB];
+#pragma unroll
+        for (int j = 0; j < HB; ++j) {
+            const int e = e0 + 256 * j;
+            const int hp = e / (N / 4), c4 = (e - hp * (N / 4)) * 4;
+            const int hy = hp / WH, hx = hp - hy * WH;
+            const int oy = a0 + hy;
+            ho[j] = e < hslots ? hp * LDP + c4 : -1;
+            hv[j] = zero4();
+            if (e < hslots && oy < Ho && hx < Wo) hv[j] = ld4(dyb + ((long)oy * Wo + hx) * N + c4);
+        }
+#pragma unroll
+        for (int j = 0; j < HB; ++j)
+            if (ho[j] >= 0) *reinterpret_cast<s4*>(halo + ho[j]) = pack_bf16(hv[j]);
+    }
+    stash_b(0, rb[0]);
+    fetch_b(3, rb[0]);
+    // ---- this wave's anchor tiles: lane i of tile t is anchor p = 16 t + i of the region -------------------------------------------
+    int hbase[TW]; bool tok[TW];
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        const int tile = wave + 4 * t;
+        tok[t] = tile < ntiles;
+        int p = tile * 16 + i;
+        if (p >= P) p = 0;
+        const int py = p / Wo, px = p - py * Wo;
+        hbase[t] = (py * WH + px) * LDP + 8 * q;
+    }
+    f4 acc[4][TW][NTO];
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int n = 0; n < NTO; ++n) acc[cl][t][n] = zero4();
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int buf = tap & 1;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int cl = (ky == 1 ? 0 : 2) + (kx == 1 ? 0 : 1);                          // parity class (py, px) this tap feeds
+        const int toff = ((ky == 0 ? 1 : 0) * WH + (kx == 0 ? 1 : 0)) * LDP;         // dy pixel (a + oy, b + ox)
+        const bf16_t* pb = sB + buf * (BN * LDB) + i * LDB + 8 * q;
+#pragma unroll
+        for (int kc = 0; kc < KC / 2; ++kc) {
+            s8v av[TW];
+#pragma unroll
+            for (int t = 0; t < TW; ++t) av[t] = *reinterpret_cast<const s8v*>(halo + hbase[t] + toff + 32 * kc);
+#pragma unroll
+            for (int n = 0; n < NTO; ++n) {
+                const s8v bv = *reinterpret_cast<const s8v*>(pb + 16 * n * LDB + 32 * kc);
+#pragma unroll
+                for (int t = 0; t < TW; ++t) acc[cl][t][n] = mfma32_bf16(av[t], bv, acc[cl][t][n]);   // absent tiles compute on anchor 0 (discarded)
+            }
+        }
+        if (tap + 1 < 9) stash_b(buf ^ 1, rb[(tap + 1) % PD]);
+        if (tap + 4 < 9) fetch_b(tap + 4, rb[(tap + 1) % PD]);
+        __syncthreads();
+    }
+    // ---- epilogue: class (py, px) of anchor (a, b) is input pixel (2a + py, 2b + px); rows through a wave-private LDS tile -------------
+    float* so = reinterpret_cast<float*>(smem_raw) + wave * 16 * LDO;
+    const int H = 2 * Ho, W = 2 * Wo;
+    float* xb = dx + (long)b * H * W * Cin + c0;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        if (!tok[t]) continue;                                             // wave-uniform
+        const int tile = wave + 4 * t;
+#pragma unroll
+        for (int cl = 0; cl < 4; ++cl) {
+#pragma unroll
+            for (int n = 0; n < NTO; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) so[(4 * q + r) * LDO + 16 * n + i] = acc[cl][t][n][r];
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < (16 * NTO * 4 + 63) / 64; ++k) {
+                const int idx = k * 64 + lane;
+                const int row = idx / (NTO * 4), c4 = (idx - row * (NTO * 4)) * 4;
+                const int p = tile * 16 + row;
+                if (idx < 16 * NTO * 4 && p < P) {
+                    const int py = p / Wo, px = p - py * Wo;
+                    f4 v = *reinterpret_cast<const f4*>(so + row * LDO + c4);
+                    float* dst = xb + ((long)(2 * (a0 + py) + (cl >> 1)) * W + 2 * px + (cl & 1)) * Cin + c4;
+                    if (accumulate) v += ld4(dst);
+                    *reinterpret_cast<f4*>(dst) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Weight gradient of a 3 x 3 / pad-1 convolution of stride S (1: PAFPN / head, 2: the backbone's downsampling convs and the PAFPN
 // bottom-up convs): dW[n][c][tap] += sum_p dy[p][n] x[S p + off(tap)][c].
 // A workgroup stages the bf16 input halo and the bf16 dy rows of a region (whole output rows of one image, <= 160 pixels) once and
@@ -636,4 +792,53 @@ int conv3_wgrad_launch(const float* dy, const float* x, float* dW, float* ws, in
 #undef C3W_CASE
     hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(cdiv(9 * Cin * Cout, 256)), dim3(256), 0, stream, ws, dW, pl.workers * pl.wvs, Cout, Cin);
     return leod_launch_status();
+}
+
+// ---- stride-2 dgrad ----------------------------------------------------------------------------------------------------------------
+static inline size_t conv3s2_dgrad_smem(int RH, int Wo, int N) {
+    const int LDP = N + 16;
+    const size_t halo = (((size_t)(RH + 1) * (Wo + 1) * LDP + 7) & ~(size_t)7) * 2;
+    const size_t sb = (size_t)2 * 48 * LDP * 2;
+    const size_t so = (size_t)4 * 16 * (48 + 4) * 4;
+    return max(halo + sb, so);
+}
+static inline int conv3s2_dgrad_rows(int Ho, int Wo, int N) {
+    int rh = max(1, min(Ho, 160 / Wo));
+    while (rh > 0 && conv3s2_dgrad_smem(rh, Wo, N) > 160 * 1024) --rh;
+    if (rh > 0) rh = cdiv(Ho, cdiv(Ho, rh));
+    return rh;
+}
+// x [B,H,W,Cin] <- dy [B,H/2,W/2,N]
+bool conv3s2_dgrad_supported(int H, int W, int Cin, int N) {
+    static const int on = getenv("LEOD_CONV3_DIRECT") ? atoi(getenv("LEOD_CONV3_DIRECT")) : 1;
+    static const int on2 = getenv("LEOD_CONV3_DGRAD2") ? atoi(getenv("LEOD_CONV3_DGRAD2")) : 1;
+    if (!on || !on2 || leod_precision() != 1) return false;
+    if ((H & 1) || (W & 1) || W / 2 > 160 || W / 2 < 4) return false;
+    if (Cin % 48 != 0 || (N != 96 && N != 192 && N != 384)) return false;
+    return conv3s2_dgrad_rows(H / 2, W / 2, N) > 0;
+}
+// w [N][Cin][3][3]; wpack: conv3s1_pack_bytes(Cin, N) bytes of scratch
+int conv3s2_dgrad_launch(const float* dy, const float* w, float* dx, int accumulate, int B, int H, int W, int Cin, int N, void* wpack, hipStream_t stream) {
+    bf16_t* wp = reinterpret_cast<bf16_t*>(wpack);
+    const long total = (long)9 * Cin * N;
+    hipLaunchKernelGGL(conv3_pack_kernel, dim3((int)min((long)1024, (total + 255) / 256)), dim3(256), 0, stream, w, wp, N, Cin, 1);
+    const int Ho = H / 2, Wo = W / 2;
+    const int RH = conv3s2_dgrad_rows(Ho, Wo, N);
+    if (RH <= 0) return LEOD_ERR_UNSUPPORTED;
+    const dim3 grid(B * cdiv(Ho, RH), Cin / 48);
+    const size_t smem = conv3s2_dgrad_smem(RH, Wo, N);
+    const int tw = cdiv(cdiv(RH * Wo, 16), 4);
+#define C3D_CASE(KCV, TWV)                                                                                                               \
+    if (N == 16 * KCV && tw == TWV) {                                                                                                    \
+        static bool attr_set = false;                                                                                                    \
+        if (!attr_set) {                                                                                                                 \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3s2_dgrad_kernel<KCV, TWV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                                                             \
+        }                                                                                                                                \
+        hipLaunchKernelGGL((conv3s2_dgrad_kernel<KCV, TWV>), grid, dim3(256), smem, stream, dy, wp, dx, accumulate, B, Ho, Wo, Cin, RH); \
+        return leod_launch_status();                                                                                                     \
+    }
+    C3D_CASE(6, 1) C3D_CASE(6, 2) C3D_CASE(6, 3) C3D_CASE(12, 1) C3D_CASE(12, 2) C3D_CASE(12, 3) C3D_CASE(24, 1) C3D_CASE(24, 2) C3D_CASE(24, 3)
+#undef C3D_CASE
+    return LEOD_ERR_UNSUPPORTED;
 }
