@@ -36,25 +36,29 @@ __global__ __launch_bounds__(256) void conv3_pack_kernel(const float* __restrict
 // K32 (Cin % 32 == 0): v_mfma_f32_16x16x32_bf16 (8 bf16 per lane and operand, 16-byte fragment reads) -- on gfx950 the 16x16x16 form
 // issues at the same 16 cycles per instruction, i.e. at half the bf16 MFMA rate
 
-template <int KC, int NTO, int TW>
+// S = 2 (forward only): the stride-2 convs of the backbone / PAFPN -- output pixel (oy, ox) reads halo pixel (2 oy + ky, 2 ox + kx);
+// H, W are the INPUT size, the pixel-row stride of the halo keeps the 16 lanes of a fragment read in different banks at DOUBLE the
+// pixel distance (dword stride of 2 pixels == 8 (mod 16) for the 16-byte reads, 4 * odd for the 8-byte reads)
+template <int KC, int NTO, int TW, int S = 1>
 __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wp, float* __restrict__ y,
                                                        double* __restrict__ colstats, int stat_rep, int accumulate,
                                                        int B, int H, int W, int Cout, int RH) {
     constexpr bool K32 = KC % 2 == 0;
     // operand rows (halo pixels, weight rows): bf16 rows whose dword stride is 4 * odd for the 8-byte fragment reads of the 16-k MFMA
     // and == 8 (mod 16) for the 16-byte reads of the 32-k MFMA (conflict-free ds_read_b64 / ds_read_b128, MI355X_MICROARCH.md LDS)
-    constexpr int CI = 16 * KC, LDP = CI + (K32 ? 16 : 8), LDB = LDP, BN = NTO * 16, LDO = BN + 4;
+    constexpr int CI = 16 * KC, LDB = CI + (K32 ? 16 : 8), LDP = S == 1 ? LDB : CI + (K32 ? 8 : 4), BN = NTO * 16, LDO = BN + 4;
     constexpr int QK = K32 ? 8 : 4;                               // k elements per lane and fragment
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int rblocks = (H + RH - 1) / RH;
+    const int Ho = H / S, Wo = W / S;
+    const int rblocks = (Ho + RH - 1) / RH;
     const int b = blockIdx.x / rblocks, y0 = (blockIdx.x - b * rblocks) * RH;
-    const int rows = min(RH, H - y0);
-    const int P = rows * W, ntiles = (P + 15) >> 4;
+    const int rows = min(RH, Ho - y0);
+    const int P = rows * Wo, ntiles = (P + 15) >> 4;
     const int co0 = blockIdx.y * BN;
     const int WH = W + 2;
-    const int halo_elems = (RH + 2) * WH * LDP;
+    const int halo_elems = (S * (RH - 1) + 3) * WH * LDP;
     bf16_t* halo = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* sB = halo + ((halo_elems + 7) & ~7);                 // [2][BN * LDB]
     // ---- weights of tap 0 start flying first ------------------------------------------------------------------------------
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
     fetch_b(2, rb[2]);
     // ---- input halo: rows y0 - 1 .. y0 + RH, columns -1 .. W, zero outside the image -------------------------------------------
     // (loads of a batch are all issued before the first LDS store: a load -> store loop pays one memory round trip per iteration)
-    const int hslots = (rows + 2) * WH * (CI / 4);
+    const int hslots = (S * (rows - 1) + 3) * WH * (CI / 4);
     const float* xb = x + (long)b * H * W * CI;
     constexpr int HB = 12;
     for (int e0 = tid; e0 < hslots; e0 += 256 * HB) {
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
             const int e = e0 + 256 * j;
             const int hp = e / (CI / 4), c4 = (e - hp * (CI / 4)) * 4;
             const int hy = hp / WH, hx = hp - hy * WH;
-            const int iy = y0 - 1 + hy, ix = hx - 1;
+            const int iy = S * y0 - 1 + hy, ix = hx - 1;
             ho[j] = e < hslots ? hp * LDP + c4 : -1;
             hv[j] = zero4();
             if (e < hslots && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) hv[j] = ld4(xb + ((long)iy * W + ix) * CI + c4);
@@ -119,8 +123,8 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
         tok[t] = tile < ntiles;
         int p = tile * 16 + i;
         if (p >= P) p = 0;
-        const int py = p / W, px = p - py * W;
-        hbase[t] = ((py + 1) * WH + px + 1) * LDP + QK * q;
+        const int py = p / Wo, px = p - py * Wo;
+        hbase[t] = ((S * py + 1) * WH + S * px + 1) * LDP + QK * q;
     }
     f4 acc[TW][NTO];
 #pragma unroll
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
     float cs[NTO], cq[NTO];
 #pragma unroll
     for (int n = 0; n < NTO; ++n) { cs[n] = 0.f; cq[n] = 0.f; }
-    float* yb = y + ((long)(b * H + y0) * W) * Cout + co0;
+    float* yb = y + ((long)(b * Ho + y0) * Wo) * Cout + co0;
 #pragma unroll
     for (int t = 0; t < TW; ++t) {
         if (!tok[t]) continue;                                             // wave-uniform
@@ -629,18 +633,31 @@ __global__ __launch_bounds__(256) void conv3_wgrad_reduce_kernel(const float* __
     dW[((long)n * CI + c) * 9 + tap] += s;
 }
 
-static inline size_t conv3_smem(int RH, int W, int Cin, int nto) {
-    const int LDP = Cin + (Cin % 32 == 0 ? 16 : 8);
-    const size_t halo = (((size_t)(RH + 2) * (W + 2) * LDP + 7) & ~(size_t)7) * 2;
-    const size_t sb = (size_t)2 * nto * 16 * LDP * 2;
+static inline size_t conv3_smem(int RH, int W, int Cin, int nto, int S = 1) {       // W: input width
+    const int LDB = Cin + (Cin % 32 == 0 ? 16 : 8), LDP = S == 1 ? LDB : Cin + (Cin % 32 == 0 ? 8 : 4);
+    const size_t halo = (((size_t)(S * (RH - 1) + 3) * (W + 2) * LDP + 7) & ~(size_t)7) * 2;
+    const size_t sb = (size_t)2 * nto * 16 * LDB * 2;
     const size_t so = (size_t)4 * 16 * (nto * 16 + 4) * 4;
     return max(halo + sb, so);
 }
 // output rows per workgroup: as many as give <= 160 pixels (10 row tiles) and fit the 160 KB of LDS; 0 = does not fit at all
-static inline int conv3_rows_per_block(int H, int W, int Cin, int nto) {
-    int rh = max(1, min(H, 160 / W));
-    while (rh > 0 && conv3_smem(rh, W, Cin, nto) > 160 * 1024) --rh;
+static inline int conv3_rows_per_block(int H, int W, int Cin, int nto, int S = 1) {       // H, W: input size; rows of the OUTPUT
+    const int Ho = H / S, Wo = W / S;
+    int rh = max(1, min(Ho, 160 / Wo));
+    while (rh > 0 && conv3_smem(rh, W, Cin, nto, S) > 160 * 1024) --rh;
+    if (S > 1 && rh > 0) rh = cdiv(Ho, cdiv(Ho, rh));             // equal row blocks
     return rh;
+}
+
+// forward of the stride-2 convs on the same kernel (S = 2)
+bool conv3s2_fwd_supported(int H, int W, int Cin, int Cout) {
+    static const int on = getenv("LEOD_CONV3_DIRECT") ? atoi(getenv("LEOD_CONV3_DIRECT")) : 1;
+    static const int on2 = getenv("LEOD_CONV3_FWD2") ? atoi(getenv("LEOD_CONV3_FWD2")) : 1;
+    if (!on || !on2 || leod_precision() != 1) return false;
+    if ((H & 1) || (W & 1) || W / 2 > 160 || W / 2 < 4) return false;
+    // (192 input channels: the weight tile takes half the LDS, 4 output rows per workgroup -- stage 4 of RVT-S 141 us vs 125 on the GEMM)
+    if ((Cin != 48 && Cin != 96) || Cout % 96 != 0) return false;
+    return conv3_rows_per_block(H, W, Cin, 6, 2) > 0;
 }
 
 bool conv3s1_supported(int H, int W, int Cin, int Cout) {
@@ -655,30 +672,32 @@ size_t conv3s1_pack_bytes(int Cin, int Cout) { return (size_t)9 * Cin * Cout * s
 // x [B,H,W,Cin] -> y [B,H,W,Cout].  transposed = 0: y = conv3x3(x, w[Cout][Cin][3][3]); 1: the dgrad of a conv whose weight is
 // w[Cin][Cout][3][3] (x = dy).  wpack: scratch of conv3s1_pack_bytes.
 int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, int stat_rep, int accumulate, int B, int H, int W,
-                   int Cin, int Cout, int transposed, void* wpack, hipStream_t stream) {
+                   int Cin, int Cout, int transposed, void* wpack, hipStream_t stream, int stride) {
     bf16_t* wp = reinterpret_cast<bf16_t*>(wpack);
     const long total = (long)9 * Cin * Cout;
     // the packed layout is [tap][out rows][k]; for the dgrad the stored weight is [N = Cin of this call][C = Cout of this call]
     hipLaunchKernelGGL(conv3_pack_kernel, dim3((int)min((long)1024, (total + 255) / 256)), dim3(256), 0, stream, w, wp,
                        transposed ? Cin : Cout, transposed ? Cout : Cin, transposed ? 1 : 0);
     const int nto = Cout == 48 ? 3 : 6;
-    const int RH = conv3_rows_per_block(H, W, Cin, nto);
+    const int RH = conv3_rows_per_block(H, W, Cin, nto, stride);
     if (RH <= 0) return LEOD_ERR_UNSUPPORTED;
-    const dim3 grid(B * cdiv(H, RH), Cout / (16 * nto));
-    const size_t smem = conv3_smem(RH, W, Cin, nto);
-    const int tw = cdiv(cdiv(min(RH, H) * W, 16), 4) <= 2 ? 2 : 3;          // row tiles per wave
-#define C3_CASE(KCV, NTOV) C3_CASE2(KCV, NTOV, 2) C3_CASE2(KCV, NTOV, 3)
-#define C3_CASE2(KCV, NTOV, TWV)                                                                                                     \
-    if (Cin == 16 * KCV && nto == NTOV && tw == TWV) {                                                                                            \
+    const int Ho = H / stride, Wo = W / stride;
+    const dim3 grid(B * cdiv(Ho, RH), Cout / (16 * nto));
+    const size_t smem = conv3_smem(RH, W, Cin, nto, stride);
+    const int tw = cdiv(cdiv(min(RH, Ho) * Wo, 16), 4) <= 2 ? 2 : 3;          // row tiles per wave
+#define C3_CASE(KCV, NTOV, SV) C3_CASE2(KCV, NTOV, 2, SV) C3_CASE2(KCV, NTOV, 3, SV)
+#define C3_CASE2(KCV, NTOV, TWV, SV)                                                                                                 \
+    if (Cin == 16 * KCV && nto == NTOV && tw == TWV && stride == SV) {                                                                \
         static bool attr_set = false;                                                                                                \
         if (!attr_set) {                                                                                                             \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3s1_kernel<KCV, NTOV, TWV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3s1_kernel<KCV, NTOV, TWV, SV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_set = true;                                                                                                         \
         }                                                                                                                            \
-        hipLaunchKernelGGL((conv3s1_kernel<KCV, NTOV, TWV>), grid, dim3(256), smem, stream, x, wp, y, colstats, stat_rep, accumulate, B, H, W, Cout, RH); \
+        hipLaunchKernelGGL((conv3s1_kernel<KCV, NTOV, TWV, SV>), grid, dim3(256), smem, stream, x, wp, y, colstats, stat_rep, accumulate, B, H, W, Cout, RH); \
         return leod_launch_status();                                                                                                 \
     }
-    C3_CASE(3, 3) C3_CASE(3, 6) C3_CASE(6, 3) C3_CASE(6, 6) C3_CASE(12, 3) C3_CASE(12, 6)
+    C3_CASE(3, 3, 1) C3_CASE(3, 6, 1) C3_CASE(6, 3, 1) C3_CASE(6, 6, 1) C3_CASE(12, 3, 1) C3_CASE(12, 6, 1)
+    C3_CASE(3, 6, 2) C3_CASE(6, 6, 2)
 #undef C3_CASE
 #undef C3_CASE2
     return LEOD_ERR_UNSUPPORTED;

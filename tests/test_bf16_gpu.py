@@ -104,9 +104,10 @@ def test_conv3x3_direct_bf16(bf16_ops, B, H, W, Cin, N):
                                                 (2, 16, 20, 192, 192, 2), (3, 16, 20, 192, 192, 1),       # 192 -> 192, both strides
                                                 (2, 10, 12, 48, 96, 2), (1, 6, 8, 96, 96, 2), (70, 8, 12, 96, 96, 2),   # ragged regions, many regions per worker
                                                 (2, 18, 28, 96, 192, 1)])
-def test_conv3x3_wgrad_direct_bf16(bf16_ops, B, H, W, Cin, N, stride):
-    """The direct weight gradient of csrc/k_conv3.hip for stride 1 / 2 and sliced channel planes (conv3_wgrad_kernel) against torch's
-    fp32 conv2d on the CPU; it accumulates into dW."""
+def test_conv3x3_strided_sliced_direct_bf16(bf16_ops, B, H, W, Cin, N, stride):
+    """The direct kernels of csrc/k_conv3.hip for stride 2 and sliced channel planes -- forward (conv3s1_kernel<.., S = 2>), input
+    gradient (conv3s2_dgrad_kernel: four parity classes), weight gradient (conv3_wgrad9_kernel / conv3_wgrad_kernel) -- against torch's
+    fp32 conv2d on the CPU."""
     import torch.nn.functional as F
     ops = bf16_ops
     from leod_amd import _lib
@@ -118,6 +119,19 @@ def test_conv3x3_wgrad_direct_bf16(bf16_ops, B, H, W, Cin, N, stride):
     ref.backward(dy)
     xn = x.detach().permute(0, 2, 3, 1).contiguous().to(tk.DEV)
     dyn = dy.permute(0, 2, 3, 1).contiguous().to(tk.DEV)
+    # forward (stride 2, <= 96 input channels: conv3s1_kernel<.., S = 2>) with BatchNorm statistics, dgrad (stride 2:
+    # conv3s2_dgrad_kernel), plain and accumulating
+    R = 8
+    cs = torch.zeros((R, 2, N), dtype=torch.float64, device=tk.DEV)
+    y = ops.conv_nhwc_fwd(xn, w.detach().to(tk.DEV), None, stride=stride, colstats=cs)
+    tk.close(y, ref.detach().permute(0, 2, 3, 1), what='conv3x3 fwd (strided)')
+    yd = y.double().reshape(-1, N)
+    assert torch.allclose(cs.sum(0)[0], yd.sum(0), rtol=1e-4, atol=1e-4 * yd.abs().sum(0).max().item())
+    assert torch.allclose(cs.sum(0)[1], (yd * yd).sum(0), rtol=1e-4)
+    dx = ops.conv_nhwc_dgrad(dyn, w.detach().to(tk.DEV), xn.shape, stride=stride)
+    tk.close(dx, x.grad.permute(0, 2, 3, 1), what='conv3x3 dgrad (strided)')
+    dx2 = ops.conv_nhwc_dgrad(dyn, w.detach().to(tk.DEV), xn.shape, stride=stride, out=dx.clone(), accumulate=True)
+    tk.close(dx2, 2 * x.grad.permute(0, 2, 3, 1), what='conv3x3 dgrad (strided) accumulate')
     dw = torch.zeros_like(w.detach(), device=tk.DEV)
     ops.conv_nhwc_wgrad(dyn, xn, dw, None, stride=stride)
     tk.close(dw, w.grad, what='conv3x3 wgrad (direct)')
