@@ -85,42 +85,72 @@ __global__ __launch_bounds__(256) void head_pred_bwd_feat_kernel(const float* __
         d_cls_feat[idx] = c * gsc;
     }
 }
-// one workgroup per (output channel ch, k-chunk): dW[ch][k] += sum_pos d_raw[pos][ch] * feat[pos][k]
+// dW[ch][k] += sum_pos d_raw[pos][ch] * feat[pos][k], db[ch] += sum_pos d_raw[pos][ch].
+// One workgroup per (tower, 64-column chunk of the features, position slice): blockIdx.x = 0 is the regression tower (channels 0-4:
+// box + objectness, reg_feat), 1.. the classification tower (channels 5 + 8 j .., cls_feat) -- a feature value is loaded ONCE for all
+// channels of its tower, eight positions per thread in flight (the first version ran one workgroup per channel with one dependent
+// load per loop iteration: 110 us for the 40960 positions of level 0).
 __global__ __launch_bounds__(256) void head_pred_bwd_w_kernel(const float* __restrict__ d_raw, const float* __restrict__ cls_feat,
                                                               const float* __restrict__ reg_feat, float* __restrict__ d_cls_w,
                                                               float* __restrict__ d_cls_b, float* __restrict__ d_reg_w,
                                                               float* __restrict__ d_reg_b, float* __restrict__ d_obj_w,
                                                               float* __restrict__ d_obj_b, const float* __restrict__ gscale,
                                                               int B, int hw, int Hd, int nc, int a0, int A) {
+    constexpr int CH = 8, U = 8;
     __shared__ float red[256];
     const float gsc = gscale ? gscale[0] : 1.f;
     const int nch = 5 + nc;
-    const int ch = blockIdx.x;
+    const int ch0 = blockIdx.x == 0 ? 0 : 5 + 8 * ((int)blockIdx.x - 1);
+    const int nme = blockIdx.x == 0 ? 5 : min(CH, nch - ch0);            // channels of this workgroup
     const int k = blockIdx.y * 64 + (threadIdx.x & 63);
+    const int kk = min(k, Hd - 1);
     const int slice = threadIdx.x >> 6;                 // 4 position slices
-    const float* feat = ch < 5 ? reg_feat : cls_feat;
-    float acc = 0.f, bacc = 0.f;
-    const long npos = (long)B * hw;
-    for (long pos = (long)blockIdx.z * 4 + slice; pos < npos; pos += (long)gridDim.z * 4) {
-        const int p = (int)(pos % hw), b = (int)(pos / hw);
-        const float d = d_raw[((long)b * A + a0 + p) * nch + ch] * gsc;
-        if (k < Hd) acc = fmaf(d, feat[pos * Hd + k], acc);
-        bacc += d;
+    const float* feat = blockIdx.x == 0 ? reg_feat : cls_feat;
+    float acc[CH], bacc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) { acc[c] = 0.f; bacc[c] = 0.f; }
+    const long npos = (long)B * hw, pstride = (long)gridDim.z * 4;
+    for (long pos0 = (long)blockIdx.z * 4 + slice; pos0 < npos; pos0 += pstride * U) {
+        float f[U]; const float* dp[U]; bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long pos = pos0 + pstride * u;
+            ok[u] = pos < npos;
+            const long pc = ok[u] ? pos : npos - 1;
+            const int p = (int)(pc % hw), b = (int)(pc / hw);
+            f[u] = feat[pc * Hd + kk];
+            dp[u] = d_raw + ((long)b * A + a0 + p) * nch + ch0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if (c < nme) {
+                    const float d = ok[u] ? dp[u][c] * gsc : 0.f;
+                    acc[c] = fmaf(d, f[u], acc[c]);
+                    bacc[c] += d;
+                }
     }
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    if (slice == 0 && k < Hd) {
-        const float v = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
-        float* dw = ch < 4 ? d_reg_w + (long)ch * Hd : (ch == 4 ? d_obj_w : d_cls_w + (long)(ch - 5) * Hd);
-        atomicAdd(dw + k, v);
-    }
-    __syncthreads();
-    if (blockIdx.y == 0) {
-        red[threadIdx.x] = (threadIdx.x & 63) == 0 ? bacc : 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        if (c >= nme) break;                                             // workgroup-uniform
+        const int ch = ch0 + c;
+        red[threadIdx.x] = acc[c];
         __syncthreads();
-        if (threadIdx.x == 0) {
-            float* db = ch < 4 ? d_reg_b + ch : (ch == 4 ? d_obj_b : d_cls_b + (ch - 5));
-            atomicAdd(db, red[0] + red[64] + red[128] + red[192]);
+        if (slice == 0 && k < Hd) {
+            const float v = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+            float* dw = ch < 4 ? d_reg_w + (long)ch * Hd : (ch == 4 ? d_obj_w : d_cls_w + (long)(ch - 5) * Hd);
+            atomicAdd(dw + k, v);
+        }
+        __syncthreads();
+        if (blockIdx.y == 0) {
+            red[threadIdx.x] = (threadIdx.x & 63) == 0 ? bacc[c] : 0.f;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float* db = ch < 4 ? d_reg_b + ch : (ch == 4 ? d_obj_b : d_cls_b + (ch - 5));
+                atomicAdd(db, red[0] + red[64] + red[128] + red[192]);
+            }
+            __syncthreads();
         }
     }
 }
@@ -714,8 +744,8 @@ LEOD_API int leod_head_pred_bwd(const float* d_raw, const float* cls_feat, const
     if (total == 0) return LEOD_OK;
     hipLaunchKernelGGL(head_pred_bwd_feat_kernel, dim3(flat_grid(total)), dim3(256), 0, stream, d_raw, cls_w, reg_w, obj_w,
                        d_cls_feat, d_reg_feat, gscale, B, h * w, Hd, nc, a0, A);
-    const int zs = (int)min((long)64, max((long)1, ((long)B * h * w + 255) / 256));
-    hipLaunchKernelGGL(head_pred_bwd_w_kernel, dim3(5 + nc, cdiv(Hd, 64), zs), dim3(256), 0, stream, d_raw, cls_feat, reg_feat,
+    const int zs = (int)min((long)128, max((long)1, ((long)B * h * w + 127) / 128));      // >= 32 positions per thread
+    hipLaunchKernelGGL(head_pred_bwd_w_kernel, dim3(1 + cdiv(nc, 8), cdiv(Hd, 64), zs), dim3(256), 0, stream, d_raw, cls_feat, reg_feat,
                        d_cls_w, d_cls_b, d_reg_w, d_reg_b, d_obj_w, d_obj_b, gscale, B, h * w, Hd, nc, a0, A);
     return leod_launch_status();
 }

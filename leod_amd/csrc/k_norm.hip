@@ -296,6 +296,7 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const float* __
         const int c = 4 * cg;
         const f4 mu = ld4(mean + c), rs = ld4(rstd + c), ww = ld4(w + c), bb = ld4(b + c);
         f4 s0 = zero4(), s1 = zero4();
+#pragma unroll 4
         for (long row = (long)blockIdx.x * rstep + rlane; row < M; row += (long)gridDim.x * rstep) {
             const f4 xh = (ld4(z + row * N + c) - mu) * rs;
             const f4 u = xh * ww + bb;
@@ -411,7 +412,10 @@ LEOD_API int leod_bn_silu_bwd_reduce(const float* dy, const float* z, const floa
     if (!dy || !z || !mean || !rstd || !w || !b || !sums || (N & 3) || N / 4 > 256) return LEOD_ERR_ARG;
     if (M <= 0) return LEOD_OK;
     const int rstep = 256 / (N / 4);
-    const int grid = (int)min((long)1024, max((long)1, ((long)M + rstep * 4 - 1) / (rstep * 4)));
+    // every workgroup ends with 2 N double atomics on the same few cache lines (1024 workgroups x 192 atomics: 31 us for the
+    // 40960 x 96 level-0 maps, 16 us with 256 workgroups): >= 16 rows per thread, <= 256 workgroups (tools/kbench_bn.py)
+    static const int cap = getenv("LEOD_BN_BWD_BLOCKS") ? atoi(getenv("LEOD_BN_BWD_BLOCKS")) : 256;
+    const int grid = (int)min((long)cap, max((long)1, ((long)M + rstep * 16 - 1) / (rstep * 16)));
     hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3(grid), dim3(256), 2 * N * sizeof(float), stream, dy, z, mean, rstd, w, b, sums, (long)M, N);
     return leod_launch_status();
 }
