@@ -282,31 +282,36 @@ __global__ __launch_bounds__(C * 4) void lstm_seq_bwd_kernel(const float* __rest
 // (33 + 28 us per timestep for a few hundred kilobytes of state) were pure latency; here a timestep costs the L2 -> CU stream of
 // the slice.  bf16 mode, hoisted x projection (xin = gx) only.
 // ---------------------------------------------------------------------------------------------------------------------
-// wpf[((w*2 + grp)*KC + kc)*4 + g][lane] = bf16 W[g*C + 32w + 16grp + i][C + 16kc + 4q .. +3]          (forward, KC = C/16)
-// wpb[(w*2 + grp)*4KC + kc][lane]        = bf16 (W[16kc + 4q + j][C + 32w + 16grp + i]), j = 0..3        (backward)
-__global__ __launch_bounds__(256) void lstm_pack_kernel(const float* __restrict__ W, s4* __restrict__ wpf, s4* __restrict__ wpb, int C) {
-    const int KC = C / 16, NWV = C / 32;
+// Fragments of v_mfma_f32_16x16x32_bf16 (8 bf16 = 16 bytes per lane: one global_load_dwordx4 is a whole B fragment; the 16-k form
+// issues at the same cost per instruction, i.e. half the rate, and needed twice the load instructions):
+// wpf[((w*2 + grp)*KC + kc)*4 + g][lane] = bf16 W[g*C + 32w + 16grp + i][C + 32kc + 8q .. +7]          (forward, KC = C/32)
+// wpb[(w*2 + grp)*4KC + kc][lane]        = bf16 (W[32kc + 8q + j][C + 32w + 16grp + i]), j = 0..7        (backward)
+__global__ __launch_bounds__(256) void lstm_pack_kernel(const float* __restrict__ W, s8v* __restrict__ wpf, s8v* __restrict__ wpb, int C) {
+    const int KC = C / 32, NWV = C / 32;
     const int nf = NWV * 2 * KC * 4 * 64, nb = NWV * 2 * 4 * KC * 64;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < nf + nb; e += gridDim.x * 256) {
         if (e < nf) {
             const int lane = e & 63, g = (e >> 6) & 3, r = e >> 8, kc = r % KC, wg = r / KC;      // wg = w*2 + grp
             const int i = lane & 15, q = lane >> 4;
-            wpf[e] = pack_bf16(ld4(W + (long)(g * C + 16 * wg + i) * (2 * C) + C + 16 * kc + 4 * q));
+            const float* wr = W + (long)(g * C + 16 * wg + i) * (2 * C) + C + 32 * kc + 8 * q;
+            const s4 lo = pack_bf16(ld4(wr)), hi = pack_bf16(ld4(wr + 4));
+            wpf[e] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         } else {
             const int o = e - nf, lane = o & 63, r = o >> 6, kc = r % (4 * KC), wg = r / (4 * KC);
             const int i = lane & 15, q = lane >> 4;
-            const float* wr = W + (long)(16 * kc + 4 * q) * (2 * C) + C + 16 * wg + i;
-            const f4 w = {wr[0], wr[2 * C], wr[4 * C], wr[6 * C]};
-            wpb[o] = pack_bf16(w);
+            const float* wr = W + (long)(32 * kc + 8 * q) * (2 * C) + C + 16 * wg + i;
+            const f4 w0 = {wr[0], wr[2 * C], wr[4 * C], wr[6 * C]}, w1 = {wr[8 * C], wr[10 * C], wr[12 * C], wr[14 * C]};
+            const s4 lo = pack_bf16(w0), hi = pack_bf16(w1);
+            wpb[o] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
     }
 }
 
 template <int C>
 __global__ __launch_bounds__(C * 2) void lstm_seq_fwd_stream_kernel(const float* __restrict__ gxin, float* __restrict__ hbuf, float* __restrict__ cbuf,
-                                                                     const s4* __restrict__ wpf, float* __restrict__ gates_out, int M, int T,
+                                                                     const s8v* __restrict__ wpf, float* __restrict__ gates_out, int M, int T,
                                                                      int zero_state) {
-    constexpr int KC = C / 16, LD = C + 8, NB = 4, NBT = KC / NB;           // NB chunks per register batch
+    constexpr int KC = C / 32, LD = C + 16, NB = 2, NBT = KC / NB;          // 32-k chunks, NB per register batch; LD / 2 == 8 (mod 16) dwords: conflict-free 16-byte A reads
     static_assert(KC % NB == 0, "chunk batches");
     __shared__ __attribute__((aligned(16))) unsigned short sA[2][16 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -332,18 +337,18 @@ __global__ __launch_bounds__(C * 2) void lstm_seq_fwd_stream_kernel(const float*
     __syncthreads();
     // wave-uniform base (scalar registers) + lane: the 192 fragment loads of a timestep address as SGPR base + lane offset + immediate;
     // a per-lane 64-bit pointer made the compiler keep one address pair per load (1.5 KB of spills per lane)
-    const s4* wb0 = wpf + (long)(__builtin_amdgcn_readfirstlane(wave) * 2) * KC * 4 * 64;        // [grp][kc][g][64 lanes]
+    const s8v* wb0 = wpf + (long)(__builtin_amdgcn_readfirstlane(wave) * 2) * KC * 4 * 64;       // [grp][kc][g][64 lanes]
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
         // the fragment addresses are the same every timestep: without this the compiler hoists all 192 loads out of the time loop and
         // parks the VALUES in scratch (1.5 KB per lane = a private 1.15 MB copy of the slice per workgroup)
-        const s4* wb = wb0;
+        const s8v* wb = wb0;
         asm volatile("" : "+s"(wb));
         const float* gp = gxin + (long)t * M * 4 * C;
         float* hp = hbuf + (long)(t + 1) * MC;
         float* cp = cbuf + (long)(t + 1) * MC;
         float* go = gates_out ? gates_out + (long)t * M * 4 * C : nullptr;
-        const unsigned short* arow = &sA[buf][i * LD + 4 * q];
+        const unsigned short* arow = &sA[buf][i * LD + 8 * q];
 #pragma unroll
         for (int grp = 0; grp < 2; ++grp) {                    // one channel group at a time: 4 accumulator tiles live
             const unsigned ch = 32 * wave + 16 * grp + i;
@@ -351,8 +356,8 @@ __global__ __launch_bounds__(C * 2) void lstm_seq_fwd_stream_kernel(const float*
             unsigned ocg[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { ocg[r] = oc[grp][r]; asm volatile("" : "+v"(ocg[r])); }
-            s4 bb[2][NB][4];
-            auto loadb = [&](s4 (&b)[NB][4], int bt) {
+            s8v bb[2][NB][4];
+            auto loadb = [&](s8v (&b)[NB][4], int bt) {
 #pragma unroll
                 for (int k = 0; k < NB; ++k)
 #pragma unroll
@@ -371,9 +376,9 @@ __global__ __launch_bounds__(C * 2) void lstm_seq_fwd_stream_kernel(const float*
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < NB; ++k) {
-                    const s4 a = *reinterpret_cast<const s4*>(arow + 16 * (bt * NB + k));
+                    const s8v a = *reinterpret_cast<const s8v*>(arow + 32 * (bt * NB + k));
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[g] = mfma16_bf16(a, bb[bt & 1][k][g], acc[g]);
+                    for (int g = 0; g < 4; ++g) acc[g] = mfma32_bf16(a, bb[bt & 1][k][g], acc[g]);
                 }
             }
 #pragma unroll
@@ -401,9 +406,9 @@ __global__ __launch_bounds__(C * 2) void lstm_seq_fwd_stream_kernel(const float*
 template <int C>
 __global__ __launch_bounds__(C * 2) void lstm_seq_bwd_stream_kernel(const float* __restrict__ dh_seq, const float* __restrict__ dc_last,
                                                                      const float* __restrict__ gates, const float* __restrict__ cbuf,
-                                                                     const s4* __restrict__ wpb, float* __restrict__ dgates_out,
+                                                                     const s8v* __restrict__ wpb, float* __restrict__ dgates_out,
                                                                      float* __restrict__ dh0, float* __restrict__ dc0, int M, int T) {
-    constexpr int KA = 4 * C, KC = KA / 16, LD = KA + 8, NB = 8, NBT = KC / NB;
+    constexpr int KA = 4 * C, KC = KA / 32, LD = KA + 16, NB = 4, NBT = KC / NB;
     static_assert(KC % NB == 0, "chunk batches");
     __shared__ __attribute__((aligned(16))) unsigned short sA[2][16 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -423,10 +428,10 @@ __global__ __launch_bounds__(C * 2) void lstm_seq_bwd_stream_kernel(const float*
     for (int grp = 0; grp < 2; ++grp)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { dcn[grp][r] = dc_last ? dc_last[oc[grp][r]] : 0.f; dhr[grp][r] = 0.f; }
-    const s4* wb0 = wpb + (long)(__builtin_amdgcn_readfirstlane(wave) * 2) * KC * 64;              // [grp][kc][64 lanes], wave-uniform base
+    const s8v* wb0 = wpb + (long)(__builtin_amdgcn_readfirstlane(wave) * 2) * KC * 64;             // [grp][kc][64 lanes], wave-uniform base
     for (int t = T - 1; t >= 0; --t) {
         const int buf = t & 1;
-        const s4* wb = wb0;
+        const s8v* wb = wb0;
         asm volatile("" : "+s"(wb));                          // see the forward kernel: keeps the fragment loads inside the time loop
         const float* gp = gates + (long)t * M * 4 * C;
         const float* c0 = cbuf + (long)t * MC;
@@ -464,14 +469,14 @@ __global__ __launch_bounds__(C * 2) void lstm_seq_bwd_stream_kernel(const float*
         __syncthreads();
         // dh_{t-1}[rows, own 32 channels] = dgates_t [16 x 4C] . W_h[4C x 32]: A fragments shared by the two channel groups
         f4 acc[2] = {zero4(), zero4()};
-        s4 bb[2][NB][2];
-        auto loadb = [&](s4 (&b)[NB][2], int bt) {
+        s8v bb[2][NB][2];
+        auto loadb = [&](s8v (&b)[NB][2], int bt) {
 #pragma unroll
             for (int k = 0; k < NB; ++k)
 #pragma unroll
                 for (int grp = 0; grp < 2; ++grp) b[k][grp] = wb[(grp * KC + bt * NB + k) * 64 + lane];
         };
-        const unsigned short* arow = &sA[buf][i * LD + 4 * q];
+        const unsigned short* arow = &sA[buf][i * LD + 8 * q];
         loadb(bb[0], 0);
 #pragma unroll
         for (int bt = 0; bt < NBT; ++bt) {
@@ -480,9 +485,9 @@ __global__ __launch_bounds__(C * 2) void lstm_seq_bwd_stream_kernel(const float*
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
-                const s4 a = *reinterpret_cast<const s4*>(arow + 16 * (bt * NB + k));
+                const s8v a = *reinterpret_cast<const s8v*>(arow + 32 * (bt * NB + k));
 #pragma unroll
-                for (int grp = 0; grp < 2; ++grp) acc[grp] = mfma16_bf16(a, bb[bt & 1][k][grp], acc[grp]);
+                for (int grp = 0; grp < 2; ++grp) acc[grp] = mfma32_bf16(a, bb[bt & 1][k][grp], acc[grp]);
             }
         }
 #pragma unroll
@@ -529,8 +534,8 @@ LEOD_API long leod_convlstm_seq_pack_bytes(int C) { return leod_convlstm_seq_mod
 // wpack <- the two fragment-ordered bf16 copies of W_h (once per step: forward and backward of the same weights share it)
 LEOD_API int leod_convlstm_seq_pack(const float* W, void* wpack, int C, hipStream_t stream) {
     if (!W || !wpack || leod_convlstm_seq_mode(C) != 3) return LEOD_ERR_ARG;
-    s4* wpf = reinterpret_cast<s4*>(wpack);
-    hipLaunchKernelGGL(lstm_pack_kernel, dim3(cdiv((long)2 * C * C, 256)), dim3(256), 0, stream, W, wpf, wpf + (long)C * C, C);
+    s8v* wpf = reinterpret_cast<s8v*>(wpack);                    // C * C / 2 sixteen-byte fragments each for the forward and the backward copy
+    hipLaunchKernelGGL(lstm_pack_kernel, dim3(cdiv((long)C * C, 256)), dim3(256), 0, stream, W, wpf, wpf + (long)C * C / 2, C);
     return leod_launch_status();
 }
 
@@ -541,7 +546,7 @@ LEOD_API int leod_convlstm_seq_fwd(const float* xin, int x_is_projection, float*
     if (mode == 0 || (mode == 1) != (x_is_projection == 0)) return LEOD_ERR_UNSUPPORTED;
     if (mode == 3) {
         if (!wpack) return LEOD_ERR_ARG;
-        const s4* wpf = reinterpret_cast<const s4*>(wpack);
+        const s8v* wpf = reinterpret_cast<const s8v*>(wpack);
         const dim3 g3(cdiv(M, 16));
         if (C == 384) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<384>), g3, dim3(768), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
         else hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<256>), g3, dim3(512), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
@@ -568,7 +573,7 @@ LEOD_API int leod_convlstm_seq_bwd(const float* dh_seq, const float* dc_last, co
     const bool bf = leod_precision() == 1;
     if (leod_convlstm_seq_mode(C) == 3) {
         if (!wpack) return LEOD_ERR_ARG;
-        const s4* wpb = reinterpret_cast<const s4*>(wpack) + (long)C * C;
+        const s8v* wpb = reinterpret_cast<const s8v*>(wpack) + (long)C * C / 2;
         const dim3 g3(cdiv(M, 16));
         if (C == 384) hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<384>), g3, dim3(768), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
         else hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<256>), g3, dim3(512), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
