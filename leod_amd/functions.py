@@ -19,6 +19,9 @@ from . import ops
 _SYNC_BN = {'group': None, 'world_size': 1, 'force': False, 'images': None, 'n_collectives': 0}
 
 
+_STEM_WGRAD_SIDE = int(os.environ.get('LEOD_STEM_WGRAD_SIDE', '0'))
+
+
 class WgradSide:
     """Weight-gradient kernels feed nothing until the optimiser, so the engine lets them run on a side HIP stream
     next to the dgrad chain (the per-kernel work of an RVT stage is too small to fill 256 CUs on its own).
@@ -166,7 +169,12 @@ class ConvLNFn(Function):
         dz = ops.layernorm_bwd(_cont(dy), z, stats, ln_w, None, grad_buf(mod.norm.weight), grad_buf(mod.norm.bias))
         dx = None
         if ctx.is_stem:
-            with _wgrad_side(dz, x):
+            # the stem is the LAST node of the backward pass: on the launch stream its weight gradient (310 us) runs next to the tail of the
+            # side stream's queue instead of behind it (the join before the optimiser waited for both in sequence)
+            if _STEM_WGRAD_SIDE:
+                with _wgrad_side(dz, x):
+                    ops.stem_conv_wgrad(dz, x, grad_buf(mod.conv.weight), ctx.padded_hw, ctx.stride, conv_w.shape[-1] // 2)
+            else:
                 ops.stem_conv_wgrad(dz, x, grad_buf(mod.conv.weight), ctx.padded_hw, ctx.stride, conv_w.shape[-1] // 2)
         else:
             with _wgrad_side(dz, x):
