@@ -696,6 +696,11 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float*
             if (16 * ct + i < d) {
                 float* t = gb + (4 * rg + r) * S + 16 * ct + i;
                 t[0] = dq[ct][r]; t[d] = dk[ct][r]; t[2 * d] = dv[ct][r];
+                // keeps the dq stores of the two column tiles apart: hipcc (ROCm 7.2) merged them into ds_write2_b32 and, for the
+                // one-head d = 32 instantiation (row stride 100 dwords), emitted offset0:25 / :50 instead of :100 / :200 for accumulator
+                // rows 2 and 3 (tools/attn_pad_diag.py: dq of tokens 2, 3 (mod 4) landed a quarter row into the previous rows) --
+                // the "padded one-head partitions" defect of round 1 was this instantiation, not the padding
+                asm volatile("" ::: "memory");
             }
     __syncthreads();
     for (int e = tid; e < TOK * F; e += NTHR) {
@@ -749,10 +754,11 @@ static int dispatch_attn(int which, const float* qkv, const float* dout, float* 
     const float scale = 1.0f / sqrtf((float)g.d);
     static const int use_lds = getenv("LEOD_ATTN_LDS") ? atoi(getenv("LEOD_ATTN_LDS")) : 1;
     const int HG = (g.heads % 2 == 0 && 2 * PT <= 16) ? 2 : 1;
-    // one-head workgroups with padded partitions (P < 16 PT, e.g. a single-head stage on the 6 x 10 partitions of Gen4) are not
-    // covered by the fused LDS backward (measured wrong against the oracle): they stay on the register-direct kernels
+    static const int force_pad1 = getenv("LEOD_ATTN_LDS_PAD1") ? atoi(getenv("LEOD_ATTN_LDS_PAD1")) : 1;
+    // (LEOD_ATTN_LDS_PAD1=0 restores the round-1 routing of one-head workgroups with padded partitions to the register-direct
+    // backward; the defect behind it was a mis-merged ds_write2_b32 in the <4, 32, 1> instantiation, see the kernel's epilogue)
     const bool lds_shape = (g.d == 24 || g.d == 32) && (PT <= 5 || PT == 8 || (HG == 1 && (PT == 10 || PT == 15))) &&
-                           !(HG == 1 && P < 16 * PT && which != 0);
+                           !(HG == 1 && P < 16 * PT && which != 0 && !force_pad1);
     if (use_lds && lds_shape) {
         // which: 0 forward, 1 fused backward (the register-direct path runs 1 = q pass, then 2 = kv pass)
         if (which == 2) return LEOD_OK;                       // the fused LDS backward already produced dK / dV
@@ -781,7 +787,8 @@ LEOD_API int leod_partition_attn_16bit_ok(int B, int H, int W, int C, int heads,
     const int d = C / heads, P = ph * pw, PT = (P + 15) / 16;
     const int HG = (heads % 2 == 0 && 2 * PT <= 16) ? 2 : 1;
     const bool inst = PT <= 5 || PT == 8 || (HG == 1 && (PT == 10 || PT == 15));
-    return on && use_lds && (d == 24 || d == 32) && inst && !(HG == 1 && P < 16 * PT);
+    static const int force_pad1 = getenv("LEOD_ATTN_LDS_PAD1") ? atoi(getenv("LEOD_ATTN_LDS_PAD1")) : 1;
+    return on && use_lds && (d == 24 || d == 32) && inst && !(HG == 1 && P < 16 * PT && !force_pad1);
 }
 
 LEOD_API int leod_partition_attn_fwd(const float* qkv, float* out, float* lse, int B, int H, int W, int C, int heads,

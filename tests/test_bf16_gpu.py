@@ -305,7 +305,8 @@ def test_full_size_training_step_bf16_vs_f32():
 
 
 @pytest.mark.parametrize('B,H,W,C,heads,part', [(2, 16, 20, 48, 2, (8, 10)), (1, 8, 10, 384, 16, (8, 10)), (3, 32, 40, 96, 4, (8, 10)),
-                                                (1, 8, 10, 24, 1, (8, 10)), (2, 16, 20, 96, 3, (8, 10)), (1, 12, 20, 64, 2, (6, 10))])
+                                                (1, 8, 10, 24, 1, (8, 10)), (2, 16, 20, 96, 3, (8, 10)), (1, 12, 20, 64, 2, (6, 10)),
+                                                (1, 16, 16, 32, 1, (8, 8)), (1, 12, 20, 32, 1, (6, 10)), (1, 14, 16, 24, 1, (7, 8))])
 @pytest.mark.parametrize('window', [True, False])
 def test_partition_attn_bf16(bf16_ops, B, H, W, C, heads, part, window):
     tk.test_partition_attn(bf16_ops, B, H, W, C, heads, part, window)

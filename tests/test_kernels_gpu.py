@@ -123,7 +123,11 @@ def _attn_ref(qkv, heads, part, window):
                                                 (1, 12, 20, 64, 2, (12, 20)),      # 240-token partition (Gen4 720p stress)
                                                 (2, 16, 20, 96, 3, (8, 10)),       # d = 32, odd head count
                                                 (1, 12, 20, 96, 3, (6, 10)),       # odd head count AND padded partitions (60 of 64)
-                                                (1, 12, 20, 32, 1, (6, 10))])      # RVT-tiny stage 1 on Gen4: one head, padded
+                                                (1, 12, 20, 32, 1, (6, 10)),       # RVT-tiny stage 1 on Gen4: one head, padded
+                                                # the <PT = 4, d = 32, one head> instantiation of the fused LDS backward, padded or not
+                                                # (hipcc mis-merged two of its epilogue stores: dq of accumulator rows 2, 3 misplaced)
+                                                (1, 16, 16, 32, 1, (8, 8)), (1, 14, 16, 32, 1, (7, 8)), (2, 16, 16, 96, 3, (8, 8)),
+                                                (1, 14, 16, 24, 1, (7, 8)), (1, 12, 12, 32, 1, (6, 6)), (1, 10, 14, 32, 1, (5, 7))])
 @pytest.mark.parametrize('window', [True, False])
 def test_partition_attn(ops, B, H, W, C, heads, part, window):
     qkv = rnd((B, H, W, 3 * C), 7).requires_grad_(True)
