@@ -359,6 +359,10 @@ LEOD_API int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, fl
     const int M = B * Ho * Wo, K = ks * ks * Cin;
     if (ks == 1 && stride == 1 && pad == 0) {
         XRows xl{x, (long)Cin, nullptr, nullptr, nullptr, nullptr, 0, 0};
+        // 1 x 1 convs are Linear layers over the pixel rows: the wave-tiled weight gradient of the Linear layers for the large maps in
+        // bf16 mode (22 -> 15, 28 -> 23, 18 -> 12 us on the PAFPN shapes; fp32 mode: 24 -> 28, 22 -> 26 us, not used)
+        static const int w11 = getenv("LEOD_WGRADW_CONV1X1") ? atoi(getenv("LEOD_WGRADW_CONV1X1")) : 1;
+        if (w11 && leod_precision() == 1 && use_wgradw(M)) return launch_wgradw(dy, (long)N, xl, dw, (long)Cin, dbias, M, N, K, stream);
         return wgrad_any(dy, xl, dw, (long)Cin, dbias, M, N, K, stream);
     }
     if (ks == 3 && pad == 1 && !dbias && ws && conv3_wgrad_supported(H, W, Cin, N, stride))
