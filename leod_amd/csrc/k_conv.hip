@@ -66,7 +66,7 @@ LEOD_API int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bia
     // PAFPN / head 3x3 convs in precision mode bf16: direct convolution from an LDS-resident input halo (k_conv3.hip)
     if (ks == 3 && stride == 1 && pad == 1 && !bias && !bn_w && wpack && conv3s1_supported(H, W, Cin, N))
         return conv3s1_launch(x, w, y, colstats, stat_rep, 0, B, H, W, Cin, N, 0, wpack, stream);
-    if (ks == 3 && stride == 2 && pad == 1 && !bias && !bn_w && wpack && conv3s2_fwd_supported(H, W, Cin, N))
+    if (ks == 3 && stride == 2 && pad == 1 && !bias && !bn_w && wpack && conv3s2_fwd_supported(B, H, W, Cin, N))
         return conv3s1_launch(x, w, y, colstats, stat_rep, 0, B, H, W, Cin, N, 0, wpack, stream, 2);
     EpStore ep = conv_epilogue(y, N, bias, colstats, stat_rep, bn_w, bn_b, bn_rm, bn_rv, bn_eps);
     const int nt = pick_nt(N);

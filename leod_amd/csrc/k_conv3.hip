@@ -650,13 +650,14 @@ static inline int conv3_rows_per_block(int H, int W, int Cin, int nto, int S = 1
 }
 
 // forward of the stride-2 convs on the same kernel (S = 2)
-bool conv3s2_fwd_supported(int H, int W, int Cin, int Cout) {
+bool conv3s2_fwd_supported(int B, int H, int W, int Cin, int Cout) {
     static const int on = getenv("LEOD_CONV3_DIRECT") ? atoi(getenv("LEOD_CONV3_DIRECT")) : 1;
     static const int on2 = getenv("LEOD_CONV3_FWD2") ? atoi(getenv("LEOD_CONV3_FWD2")) : 1;
     if (!on || !on2 || leod_precision() != 1) return false;
     if ((H & 1) || (W & 1) || W / 2 > 160 || W / 2 < 4) return false;
-    // (192 input channels: the weight tile takes half the LDS, 4 output rows per workgroup -- stage 4 of RVT-S 141 us vs 125 on the GEMM)
-    if ((Cin != 48 && Cin != 96) || Cout % 96 != 0) return false;
+    // (192 input channels: the weight tile takes half the LDS, 4 output rows per workgroup -- stage 4 of RVT-S, 13440 output pixels,
+    // 141 us vs 125 on the LDS GEMM; but the PAFPN bottom-up conv on 32 frames (2560 pixels) would fall to the register-direct GEMM: 114 us)
+    if ((Cin != 48 && Cin != 96 && !(Cin == 192 && (long)B * (H / 2) * (W / 2) < 8192)) || Cout % 96 != 0) return false;
     return conv3_rows_per_block(H, W, Cin, 6, 2) > 0;
 }
 
@@ -697,7 +698,7 @@ int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, i
         return leod_launch_status();                                                                                                 \
     }
     C3_CASE(3, 3, 1) C3_CASE(3, 6, 1) C3_CASE(6, 3, 1) C3_CASE(6, 6, 1) C3_CASE(12, 3, 1) C3_CASE(12, 6, 1)
-    C3_CASE(3, 6, 2) C3_CASE(6, 6, 2)
+    C3_CASE(3, 6, 2) C3_CASE(6, 6, 2) C3_CASE(12, 6, 2)
 #undef C3_CASE
 #undef C3_CASE2
     return LEOD_ERR_UNSUPPORTED;

@@ -10,7 +10,7 @@ from kbench import timeit  # noqa: E402
 DEV = 'cuda'
 CASES = [  # name, B, H, W, Cin, N, ks, stride
     ('down2 3x3/s2', 168, 64, 80, 48, 96, 3, 2), ('down3 3x3/s2', 168, 32, 40, 96, 192, 3, 2), ('down4 3x3/s2', 168, 16, 20, 192, 384, 3, 2),
-    ('fpn 1x1 s32', 32, 8, 10, 384, 192, 1, 1), ('fpn 3x3 s16', 32, 16, 20, 192, 192, 3, 1), ('fpn 3x3/s2 s8', 32, 32, 40, 96, 96, 3, 2),
+    ('fpn 1x1 s32', 32, 8, 10, 384, 192, 1, 1), ('fpn 3x3 s16', 32, 16, 20, 192, 192, 3, 1), ('fpn 3x3/s2 s8', 32, 32, 40, 96, 96, 3, 2), ('fpn 3x3/s2 s16', 32, 16, 20, 192, 192, 3, 2),
     ('fpn 3x3 s8', 32, 32, 40, 96, 96, 3, 1), ('1x1 s8 96', 32, 32, 40, 96, 96, 1, 1), ('1x1 s8 192->48', 32, 32, 40, 192, 48, 1, 1), ('1x1 s16 384->96', 32, 16, 20, 384, 96, 1, 1), ('head 3x3 s8', 32, 32, 40, 96, 96, 3, 1), ('head 3x3 s32', 32, 8, 10, 96, 96, 3, 1),
 ]
 if os.environ.get('LEOD_PRECISION'):
