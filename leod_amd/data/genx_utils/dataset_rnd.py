@@ -45,13 +45,19 @@ class SequenceDataset:
     def __len__(self):
         return len(self.sequence)
 
-    def sample(self, index: int, out: Optional[np.ndarray] = None):
-        """One sample with a fresh augmentation draw (:113-143): the time flip decides how the frames are read; the spatial part
-        transforms the labels now and the pixels later on the device (``DataType.AUGM_STATE``).  Raises ``ValueError`` when a
-        forced time flip is impossible (single visible label at the very end): the caller draws another sample."""
+    def draw_augmentation(self):
+        """The RNG part of one sample (:113-143), to be called SEQUENTIALLY: -> (time_flip, private copy of the drawn state | None).
+        The time flip decides how the frames are read and leaves the state.  Raises ``ValueError`` when a forced time flip is
+        impossible (single visible label at the very end): the caller draws another sample.
+
+        Several batch slots often come from the same recording (train_ratio 0.01-0.1) and share this dataset's augmentor; the
+        batch assembler reads samples on a thread pool, so the drawn state must not live in the shared ``augm_state`` across the
+        file read -- one thread's labels were transformed with the state another had re-randomised mid-flight."""
+        import copy
         seq, aug = self.sequence, self.spatial_augmentor
         apply_aug = aug is not None and not seq.is_only_loading_labels()
         time_flip = seq.time_flip
+        state = None
         if apply_aug:
             aug.randomize_augmentation()
             time_flip = False
@@ -62,10 +68,27 @@ class SequenceDataset:
                 else:
                     time_flip = True
                 aug.augm_state.apply_t_flip = False
+            state = copy.deepcopy(aug.augm_state)
         if self.always_tflip:
             assert time_flip, 'Not applying time flip'
-        item = seq.sample(index, out=out, time_flip=time_flip)
-        return aug(item) if apply_aug else item
+        return time_flip, state
+
+    def read(self, index: int, out: Optional[np.ndarray], time_flip: bool):
+        """The I/O part: frames (into ``out``) and untransformed labels.  Thread-safe (touches no augmentor state)."""
+        return self.sequence.sample(index, out=out, time_flip=time_flip)
+
+    def apply_augmentation(self, item, state):
+        """Label-side transform of ``item`` with the state drawn for it (draws the zoom-in window: call sequentially); the
+        pixels follow on the device (``DataType.AUGM_STATE``)."""
+        if state is None:
+            return item
+        self.spatial_augmentor.augm_state = state
+        return self.spatial_augmentor(item)
+
+    def sample(self, index: int, out: Optional[np.ndarray] = None, drawn=None):
+        """One sample with a fresh augmentation draw (or the given ``draw_augmentation()`` result)."""
+        time_flip, state = self.draw_augmentation() if drawn is None else drawn
+        return self.apply_augmentation(self.read(index, out, time_flip), state)
 
     def __getitem__(self, index: int):
         return self.sample(index)
@@ -86,12 +109,19 @@ class CustomConcatDataset:
         k = bisect.bisect_right(self.cumulative_sizes, idx)
         return self.datasets[k], idx - (self.cumulative_sizes[k - 1] if k else 0)
 
+    def plan(self, idx: int):
+        """Sequential half of ``sample``: -> (dataset, local index, (time_flip, state)); a sample whose forced time flip is
+        impossible is replaced by a random other one (:172-176)."""
+        while True:
+            ds, local = self.locate(idx)
+            try:
+                return ds, local, ds.draw_augmentation()
+            except ValueError:
+                idx = int(np.random.randint(len(self)))
+
     def sample(self, idx: int, out: Optional[np.ndarray] = None):
-        ds, local = self.locate(idx)
-        try:
-            return ds.sample(local, out=out)
-        except ValueError:
-            return self.sample(int(np.random.randint(len(self))), out=out)
+        ds, local, drawn = self.plan(idx)
+        return ds.sample(local, out=out, drawn=drawn)
 
     def __getitem__(self, idx: int):
         return self.sample(idx)

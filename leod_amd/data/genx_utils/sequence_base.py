@@ -50,10 +50,8 @@ class SequenceBase:
         raw, h5 = misc.resolve_link(str(ev_dir / (stem + '.npy'))), misc.resolve_link(str(ev_dir / (stem + '.h5')))
         self.ev_repr_file = Path(raw if os.path.exists(raw) else h5)
         assert self.ev_repr_file.exists(), f'{self.ev_repr_file=}'
-        self._frames = None
-        frames = self.frames
-        self.num_ev_repr = len(frames)
-        self.frame_shape = tuple(frames.shape[1:])
+        # only the header is read here; the store is opened on the first frame read and shared / bounded per process
+        self.num_ev_repr, self.frame_shape = misc.read_frame_header(str(self.ev_repr_file))
         # ---- labels --------------------------------------------------------------------------------------------------------
         labels, objframe_idx_2_label_idx = misc.read_npz_labels(str(path))
         self.label_factory = ObjectLabelFactory.from_structured_array(
@@ -70,15 +68,8 @@ class SequenceBase:
     # ---- frame store ----------------------------------------------------------------------------------------------------------
     @property
     def frames(self):
-        if self._frames is None:
-            fn = str(self.ev_repr_file)
-            self._frames = misc.RawFrames(fn) if fn.endswith('.npy') else misc.H5Frames(fn)
-        return self._frames
-
-    def __getstate__(self):                      # open file handles / memory maps do not travel to worker processes
-        d = dict(self.__dict__)
-        d['_frames'] = None
-        return d
+        """The recording's frame store from the per-process LRU (``misc.FRAME_STORES``): no sequence object owns an fd."""
+        return misc.FRAME_STORES.get(str(self.ev_repr_file))
 
     def read_frames(self, start_idx: int, end_idx: int, out: Optional[np.ndarray] = None, reverse: bool = False) -> np.ndarray:
         """Frames [start_idx, end_idx) as [n,C,H,W] uint8 (into ``out`` if given).  ``reverse``: the time-reversed view --

@@ -13,7 +13,7 @@ store cannot feed >= 1.5 GB/s of uint8 voxels per GPU from Python anyway, so the
 interface: ``RawFrames`` (np.load(mmap_mode='r') of the .npy twin: page-cache reads straight into pinned batches) and
 ``H5Frames`` (import-guarded h5py).  ``tools/h5_to_npy.py`` writes the twin once per recording."""
 import os
-from typing import List, Optional, Tuple
+from typing import Any,  List, Optional, Tuple
 
 import numpy as np
 
@@ -155,6 +155,59 @@ class H5Frames:
 
     def close(self):
         self.h5f.close()
+
+
+class FrameStoreCache:
+    """At most ``capacity`` open frame stores per process, shared by every sequence object over the same file.
+
+    A recording is wrapped by one ``SequenceForIter`` per labelled run plus one random-access sequence, and full Gen1 mixed-mode
+    training builds several thousand of them; each used to keep its own fd + mmap for life, past the usual 1024 RLIMIT_NOFILE
+    (the reference opens the HDF5 file per read, sequence_base.py:184-193).  Eviction only drops the cache's reference: a
+    reader that is still inside ``read`` holds its own, and the store closes itself when the last one goes."""
+
+    def __init__(self, capacity: int = 128):
+        import collections
+        import threading
+        self.capacity = capacity
+        self._stores: 'collections.OrderedDict[str, Any]' = collections.OrderedDict()
+        self._lock = threading.Lock()
+
+    def get(self, fn: str):
+        with self._lock:
+            st = self._stores.get(fn)
+            if st is not None:
+                self._stores.move_to_end(fn)
+                return st
+            st = RawFrames(fn) if fn.endswith('.npy') else H5Frames(fn)
+            self._stores[fn] = st
+            while len(self._stores) > self.capacity:
+                self._stores.popitem(last=False)
+            return st
+
+    def __len__(self):
+        return len(self._stores)
+
+    def clear(self):
+        with self._lock:
+            self._stores.clear()
+
+
+FRAME_STORES = FrameStoreCache()
+
+
+def read_frame_header(fn: str):
+    """(number of frames, (C, H, W)) of a frame file without keeping it open."""
+    if fn.endswith('.npy'):
+        with open(fn, 'rb') as f:
+            major, _ = np.lib.format.read_magic(f)
+            shape, fortran, dtype = (np.lib.format.read_array_header_1_0 if major == 1 else np.lib.format.read_array_header_2_0)(f)
+        assert dtype == np.uint8 and len(shape) == 4 and not fortran, (fn, dtype, shape)
+        return int(shape[0]), tuple(int(x) for x in shape[1:])
+    st = H5Frames(fn)
+    try:
+        return len(st), tuple(st.shape[1:])
+    finally:
+        st.close()
 
 
 def open_ev_repr(seq_or_ev_dir: str, dst_name: Optional[str] = None):

@@ -24,6 +24,28 @@ from leod_amd.modules.utils.detection import DATA_KEY, WORKER_ID_KEY
 _END = object()
 
 
+def dist_rank_world(rank=None, world_size=None):
+    """(rank, world_size) of this process in the data-parallel job: the arguments, else torch.distributed, else (0, 1)."""
+    if rank is None or world_size is None:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+    return int(rank), int(world_size)
+
+
+def shared_seed(world_size: int) -> int:
+    """A seed every rank agrees on: drawn on rank 0, broadcast (0 without a process group) -- the role of
+    ``DistributedSampler(seed=...)``, which Lightning puts in front of the reference's random-access loader."""
+    if world_size <= 1:
+        return 0
+    import torch.distributed as dist
+    box = [int(torch.empty((), dtype=torch.int64).random_().item()) % (1 << 62)]
+    if dist.is_available() and dist.is_initialized():
+        dist.broadcast_object_list(box, src=0)
+    return int(box[0])
+
+
 def get_dataloading_hw(dataset_config):
     hw = {'gen1': (240, 304), 'gen4': (720, 1280)}[dataset_config.name]
     return tuple(x // 2 for x in hw) if dataset_config.downsample_by_factor_2 else hw
@@ -106,35 +128,66 @@ class RandomLoader(_PrefetchLoader):
     """Shuffled (or class-weighted) batches of independent samples; ``drop_last`` as in the reference's training loader."""
 
     def __init__(self, dataset: CustomConcatDataset, batch_size: int, sampler=None, pin_memory: bool = True, prefetch: int = 3,
-                 io_threads: int = 8, num_workers: int = 1):
+                 io_threads: int = 8, num_workers: int = 1, rank: int = 0, world_size: int = 1, seed: int = 0):
         super().__init__(prefetch)
         self.dataset, self.batch_size, self.sampler = dataset, batch_size, sampler
         seq = dataset.datasets[0].sequence
         self.assembler = BatchAssembler(seq.seq_len, seq.frame_shape, pin_memory, io_threads)
         self.num_workers = max(1, num_workers)
+        # N > 1 ranks: ONE order per epoch shared by all ranks (generator seeded seed + epoch, the same on every rank), rank r
+        # takes order[r::world] -- what DistributedSampler / DistributedSamplerWrapper do for the reference under Lightning DDP
+        self.rank, self.world_size, self.seed, self.epoch = rank, max(1, world_size), seed, 0
+
+    def _per_rank(self) -> int:
+        return -(-len(self.dataset) // self.world_size)
 
     def __len__(self):
-        return len(self.dataset) // self.batch_size
+        return self._per_rank() // self.batch_size
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = int(epoch)
+
+    def _order(self):
+        if self.world_size == 1:                                # the global RNG, as the reference's single-GPU loader
+            return list(iter(self.sampler)) if self.sampler is not None else torch.randperm(len(self.dataset)).tolist()
+        g = torch.Generator().manual_seed(self.seed + self.epoch)
+        self.epoch += 1
+        if self.sampler is not None:
+            self.sampler.generator = g
+            order = list(iter(self.sampler))
+        else:
+            order = torch.randperm(len(self.dataset), generator=g).tolist()
+        total = self._per_rank() * self.world_size              # pad by wrapping so that every rank sees the same count
+        order += order[:total - len(order)]
+        return order[self.rank:total:self.world_size]
 
     def batches(self):
-        order = list(iter(self.sampler)) if self.sampler is not None else torch.randperm(len(self.dataset)).tolist()
+        order = self._order()
         B = self.batch_size
         for k in range(len(order) // B):
             idx = order[k * B:(k + 1) * B]
-            plans = [(_ConcatSlot(self.dataset, i), 0, None) for i in idx]
+            # RNG draws here, one sample after the other; the pool only reads frames; the label transforms follow sequentially
+            plans = [_ConcatSlot(*self.dataset.plan(i)).as_plan() for i in idx]
             # worker ids only label batches here (every random sample restarts the LSTM state); cycle them like DataLoader does
             yield {DATA_KEY: self.assembler.assemble(plans), WORKER_ID_KEY: k % self.num_workers}
 
 
 class _ConcatSlot:
-    """Adapter: sample ``idx`` of the concatenated dataset behind the ``sample(index, out, time_flip)`` call of the assembler
-    (augmentation and the time-flip draw happen inside ``SequenceDataset.sample``)."""
+    """Adapter: one planned sample of the concatenated dataset behind the ``(source, index, time_flip, finisher)`` plans of
+    the assembler: ``sample`` is the thread-pool part (frame reads), the finisher the sequential label-side augmentation with the
+    state drawn for THIS sample."""
 
-    def __init__(self, dataset: CustomConcatDataset, idx: int):
-        self.dataset, self.idx = dataset, idx
+    def __init__(self, dataset, local: int, drawn):
+        self.dataset, self.local, (self.time_flip, self.state) = dataset, local, drawn
 
     def sample(self, index, out=None, time_flip=None):
-        return self.dataset.sample(self.idx, out=out)
+        return self.dataset.read(self.local, out, self.time_flip)
+
+    def finish(self, item):
+        return self.dataset.apply_augmentation(item, self.state)
+
+    def as_plan(self):
+        return (self, 0, self.time_flip, self.finish if self.state is not None else None)
 
 
 class MixedLoader:
@@ -165,7 +218,8 @@ class MixedLoader:
 class DataModule:
     def __init__(self, dataset_config, num_workers_train: int, num_workers_eval: int, batch_size_train: int,
                  batch_size_eval: int, pin_memory: bool = True, prefetch: int = 3, io_threads: int = 8,
-                 worker_process: bool = False, device=None, ring_slots: int = 8):
+                 worker_process: bool = False, device=None, ring_slots: int = 8, rank: Optional[int] = None,
+                 world_size: Optional[int] = None):
         assert num_workers_train >= 0 and num_workers_eval >= 0 and batch_size_train >= 1 and batch_size_eval >= 1
         self.dataset_config = dataset_config
         self.train_sampling_mode = DatasetSamplingMode(dataset_config.train.sampling)
@@ -177,6 +231,15 @@ class DataModule:
         # worker_process: batch assembly in a forked process, frames through a HIP-registered shared ring (process_loader.py);
         # with `device` the loaders yield batches whose frames are already on that device (copied one batch ahead)
         self.worker_process, self.device, self.ring_slots = worker_process, device, ring_slots
+        # Seeding contract under N > 1 ranks (batch sizes / worker counts here are PER RANK, as in the reference under Lightning DDP):
+        #  * random-access loader: one shuffled order per epoch shared by all ranks, rank r takes order[r::world] (RandomLoader);
+        #  * everything drawn from the process-global RNGs (stream shuffles, augmentation draws, replacement samples) must differ
+        #    between ranks even if the user seeded all ranks identically: the loader's process is seeded base + rank -- the forked
+        #    worker of ProcessLoader per epoch, the training process itself once (first train_dataloader()) for the in-process
+        #    loaders.  Parameters are unaffected: FlatAdamW broadcasts rank 0's at construction.
+        self.rank, self.world_size = dist_rank_world(rank, world_size)
+        self._seed_shared: Optional[int] = None
+        self._rank_seeded = False
         self.sampling_mode_2_dataset: Dict[Any, Any] = {}
         self.sampling_mode_2_train_workers: Dict[Any, int] = {}
         self.sampling_mode_2_train_batch_size: Dict[Any, int] = {}
@@ -238,10 +301,17 @@ class DataModule:
         hw = self.get_dataloading_hw()
         L = self.dataset_config.sequence_length
         slot = L * batch_size * 20 * hw[0] * hw[1]
-        return ProcessLoader(lambda: build(**kw), slot_bytes=slot, n_slots=self.ring_slots, device=self.device)
+        return ProcessLoader(lambda: build(**kw), slot_bytes=slot, n_slots=self.ring_slots, device=self.device, rank=self.rank)
 
     def train_dataloader(self):
         B = max(self.sampling_mode_2_train_batch_size.values())
+        if self.world_size > 1:
+            if self._seed_shared is None:
+                self._seed_shared = shared_seed(self.world_size)
+            if not self.worker_process and not self._rank_seeded:
+                from leod_amd.modules.data.process_loader import draw_base_seed, seed_worker
+                seed_worker(draw_base_seed(), self.rank)
+                self._rank_seeded = True
         return self._in_process(self._train_loaders, B)
 
     def _train_loaders(self, **loader_kw):
@@ -252,7 +322,8 @@ class DataModule:
                 loaders[mode] = StreamLoader(dataset, num_workers=workers, **loader_kw)
             else:
                 sampler = get_weighted_random_sampler(dataset) if self.dataset_config.train.random.weighted_sampling else None
-                loaders[mode] = RandomLoader(dataset, batch_size=bs, sampler=sampler, num_workers=workers, **loader_kw)
+                loaders[mode] = RandomLoader(dataset, batch_size=bs, sampler=sampler, num_workers=workers, rank=self.rank,
+                                             world_size=self.world_size, seed=self._seed_shared or 0, **loader_kw)
         return next(iter(loaders.values())) if len(loaders) == 1 else MixedLoader(loaders)
 
     def _eval_loader(self, dataset):

@@ -147,9 +147,28 @@ class _Unpacker:
 
 
 # ---- worker ---------------------------------------------------------------------------------------------------------------------------
-def _worker(loader_fn: Callable[[], Iterable], ring: _Ring, results, free_slots):
+def draw_base_seed() -> int:
+    """One draw from the parent's torch generator (what torch's DataLoader does per epoch): advances the parent state."""
+    return int(torch.empty((), dtype=torch.int64).random_().item())
+
+
+def seed_worker(base_seed: int, rank: int = 0) -> int:
+    """Seed torch / numpy / random of the calling process with base_seed + rank (DataLoader: base_seed + worker_id)."""
+    import random as _random
+    seed = (int(base_seed) + int(rank)) % (1 << 63)
+    torch.manual_seed(seed)
+    np.random.seed(seed % (1 << 32))
+    _random.seed(seed)
+    return seed
+
+
+def _worker(loader_fn: Callable[[], Iterable], ring: _Ring, results, free_slots, base_seed: int = 0, rank: int = 0):
     try:
         torch.set_num_threads(1)                                  # a forked child must not enter the parent's OpenMP pool
+        # a forked child inherits the parent's RNG state unchanged: without a fresh seed every epoch replays the same shuffles and
+        # augmentation draws.  torch's DataLoader hands its workers base_seed + worker_id (reference: DataLoader workers under
+        # Lightning, modules/data/genx.py:172-232); here the worker of rank r in epoch e gets base_seed(e) + r.
+        seed_worker(base_seed, rank)
         free: List[int] = list(range(ring.n_slots))
         lock = threading.Lock()
 
@@ -171,8 +190,12 @@ class ProcessLoader:
     dictionaries built on ``BatchAssembler``), produced in a forked worker process.  One worker per iteration (epoch)."""
 
     def __init__(self, loader_fn: Callable[[], Iterable], slot_bytes: int, n_slots: int = 8, device=None, depth: int = 1,
-                 hold: int = 2, timeout: float = 300.):
+                 hold: int = 2, timeout: float = 300., rank: Optional[int] = None):
         self.timeout = timeout
+        if rank is None:                                          # data-parallel rank: folded into the worker's seed
+            import torch.distributed as dist
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self.rank = int(rank)
         self.loader_fn, self.slot_bytes, self.n_slots = loader_fn, int(slot_bytes), int(n_slots)
         self.device = torch.device(device) if device is not None else None
         self.depth, self.hold = max(1, depth), max(1, hold)
@@ -205,7 +228,10 @@ class ProcessLoader:
         self._ensure_ring()
         ctx = mp.get_context('fork')
         results, free_slots = ctx.Queue(maxsize=self.n_slots), ctx.Queue()
-        proc = ctx.Process(target=_worker, args=(self.loader_fn, self.ring, results, free_slots), daemon=True,
+        # one draw from the parent's generator per epoch (as torch's DataLoader does): it advances the parent state, so consecutive
+        # epochs get different worker seeds, and a seeded parent gives a reproducible sequence of epochs
+        base_seed = draw_base_seed()
+        proc = ctx.Process(target=_worker, args=(self.loader_fn, self.ring, results, free_slots, base_seed, self.rank), daemon=True,
                            name='leod-loader-proc')
         proc.start()
         pending: 'collections.deque' = collections.deque()       # (event | None, slots) waiting to go back to the worker

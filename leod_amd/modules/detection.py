@@ -112,13 +112,18 @@ class Module(_Base):
             if tidx not in self.label_subsample_idx:
                 seq[tidx].set_non_gt_labels_to_none_()
         states = data.get(DataType.AUGM_STATE, None)
-        if states is not None and th.is_tensor(data[DataType.EV_REPR][0]) and data[DataType.EV_REPR][0].is_cuda:
+        if states is not None and any(s.apply_h_flip or s.zoom_in.active or s.zoom_out.active for s in states):
             # spatial augmentation of the whole batch in ONE gather launch (the loaders transformed the labels on the host
             # and left the frames untouched; the reference flips / zooms every frame in the dataloader workers)
             from leod_amd.data.utils.augmentor import augment_events
-            if any(s.apply_h_flip or s.zoom_in.active or s.zoom_out.active for s in states):
-                ev = augment_events(self._stack_frames(data[DataType.EV_REPR]).contiguous(), states)
-                data[DataType.EV_REPR] = [ev[t] for t in range(ev.shape[0])]
+            f0 = data[DataType.EV_REPR][0]
+            if not (th.is_tensor(f0) and f0.is_cuda):
+                # the labels of this batch ARE transformed already: training on them over un-warped frames would be silently wrong
+                from leod_amd._lib import LeodHipError
+                raise LeodHipError('batch carries an active AUGM_STATE but its frames are not on the device: move the batch first '
+                                   '(Module.transfer_batch_to_device / DevicePrefetcher); there is no host fallback for the frame warp')
+            ev = augment_events(self._stack_frames(data[DataType.EV_REPR]).contiguous(), states)
+            data[DataType.EV_REPR] = [ev[t] for t in range(ev.shape[0])]
         return data
 
     # ---- the hot loop -----------------------------------------------------------------------------------

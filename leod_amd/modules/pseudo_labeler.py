@@ -201,11 +201,13 @@ class EventSeqData:
         labels, f2l, f2r = self._summarize()
         np.save(misc.get_objframe_idx_2_repr_idx_fn(new_ev_dir), f2r)
         np.savez(new_labels_npz_fn, labels=labels, objframe_idx_2_label_idx=f2l)
-        if not osp.islink(osp.join(new_base_dir, 'val')):          # link the evaluation splits once, for completeness
-            for split in ('val', 'test'):
+        # link the evaluation splits once, for completeness (:386-397).  Idempotent per split: with N ranks saving after the same
+        # barrier (leod_amd/predict.py) a check-then-create races (two ranks both see 'val' missing, or one sees 'val' before 'test').
+        for split in ('val', 'test'):
+            try:
                 os.symlink(osp.abspath(misc.resolve_link(osp.join(base_dir, split))), osp.join(new_base_dir, split))
-        else:
-            assert osp.islink(osp.join(new_base_dir, 'test'))
+            except FileExistsError:
+                pass
         return new_seq_dir
 
 

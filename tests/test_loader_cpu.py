@@ -382,6 +382,9 @@ def test_worker_process_loader_yields_the_in_process_batches(trees, stage):
         dm.setup(stage[:3] if stage.startswith('fit') else stage)
         loader = dm.train_dataloader() if stage.startswith('fit') else dm.test_dataloader()
         assert isinstance(loader, ProcessLoader) == worker_process
+        if not worker_process:                  # what ProcessLoader.__iter__ / _worker do: one parent draw, worker seeded with it
+            from leod_amd.modules.data.process_loader import draw_base_seed, seed_worker
+            seed_worker(draw_base_seed(), 0)
         batches, live = [], []
         for batch in loader:
             flat = []
@@ -427,3 +430,113 @@ def test_worker_process_loader_surfaces_worker_errors():
     assert next(it) == {'data': {}, 'worker_id': 0}
     with pytest.raises(RuntimeError, match='recording 7 is truncated'):
         next(it)
+
+
+def test_worker_process_loader_reseeds_every_epoch():
+    """a forked worker inherits the parent's RNG state; without a per-epoch base seed every epoch replayed the same
+    shuffles / augmentation draws.  Epochs must differ, a re-seeded parent must reproduce them, and ranks must differ."""
+    from leod_amd.modules.data.process_loader import ProcessLoader
+
+    def gen():
+        yield {'perm': torch.randperm(10), 'np': np.random.randint(0, 1 << 30, 4), 'worker_id': 0}
+
+    def epochs(rank):
+        torch.manual_seed(5)
+        loader = ProcessLoader(gen, slot_bytes=1024, n_slots=2, rank=rank)
+        return [next(iter(loader)) for _ in range(3)]
+
+    a, b, c = epochs(0), epochs(0), epochs(1)
+    perms = [tuple(e['perm'].tolist()) for e in a]
+    assert len(set(perms)) == 3, 'every epoch replayed the same draws'
+    assert len({tuple(e['np'].tolist()) for e in a}) == 3
+    assert perms == [tuple(e['perm'].tolist()) for e in b], 'a seeded parent must reproduce its epochs'
+    assert perms[0] != tuple(c[0]['perm'].tolist()), 'ranks must not draw the same stream'
+
+
+def test_training_loaders_are_rank_aware(trees):
+    """under N > 1 ranks the random-access loader must partition ONE shared order (DistributedSampler semantics: no
+    sample twice per epoch across ranks, every rank the same count) and the streaming loader must not replay the same shuffle on
+    every rank when all ranks were seeded identically (bench.py does torch.manual_seed(0) everywhere)."""
+    from leod_amd.data.utils.types import DataType
+    from leod_amd.modules.data.genx import DataModule, RandomLoader
+
+    def build(rank, world, sampling):
+        torch.manual_seed(0); np.random.seed(0)                 # identical user seed on every rank
+        dm = DataModule(_cfg(trees['gen1'], train=dict(sampling=sampling)), num_workers_train=2, num_workers_eval=1,
+                        batch_size_train=2, batch_size_eval=1, prefetch=0, io_threads=1, rank=rank, world_size=world)
+        dm._seed_shared = 1234                                  # what shared_seed() broadcasts from rank 0
+        dm.setup('fit')
+        return dm.train_dataloader()
+
+    # random access: the two ranks' index orders are disjoint halves of one permutation
+    loaders = [build(r, 2, 'random') for r in range(2)]
+    assert all(isinstance(l, RandomLoader) for l in loaders)
+    orders = [l._order() for l in loaders]
+    n = len(loaders[0].dataset)
+    assert len(orders[0]) == len(orders[1]) == -(-n // 2)
+    both = orders[0] + orders[1]
+    assert set(both) == set(range(n)) and len(both) - n in (0, 1)            # padded by at most one wrapped sample
+    assert len(loaders[0]) == len(orders[0]) // 2
+    nxt = [l._order() for l in loaders]                          # next epoch: another shared permutation
+    assert nxt[0] != orders[0] and set(nxt[0] + nxt[1]) == set(range(n))
+    one = build(0, 1, 'random')
+    assert len(one._order()) == n                                # single rank: everything, global RNG
+
+    # streaming: identically seeded ranks draw different shuffles (the process RNG is re-seeded base + rank)
+    def first_paths(rank):
+        loader = build(rank, 2, 'stream')
+        out = []
+        for i, batch in enumerate(loader):
+            out.append((tuple(batch['data'][DataType.PATH]), tuple(int(e) for e in batch['data'][DataType.EV_IDX][0])))
+            if i == 5:
+                break
+        return out
+    a, b, a2 = first_paths(0), first_paths(1), first_paths(0)
+    assert a == a2, 'a seeded rank must reproduce its stream'
+    assert a != b, 'two identically seeded ranks replayed the same stream order'
+
+
+def test_random_loader_is_deterministic_with_a_thread_pool_and_frame_stores_are_bounded(trees):
+    """(1) samples of one recording share an augmentor; with the reads on a thread pool the drawn state must be
+    private to its sample -- the batches of a seeded run with 8 I/O threads equal those with one thread; (2) sequence objects do
+    not own file descriptors: many of them over the same files keep at most ``FRAME_STORES.capacity`` stores open."""
+    from leod_amd.data.utils import misc
+    from leod_amd.data.utils.types import DataType
+    from leod_amd.modules.data.genx import DataModule
+
+    def run(io_threads):
+        torch.manual_seed(3); np.random.seed(3)
+        dm = DataModule(_cfg(trees['gen1'], train=dict(sampling='random')), num_workers_train=2, num_workers_eval=1,
+                        batch_size_train=4, batch_size_eval=1, prefetch=0, io_threads=io_threads)
+        dm.setup('fit')
+        out = []
+        for i, batch in enumerate(dm.train_dataloader()):
+            flat = []
+            _flatten(batch, flat)
+            out.append(flat)
+            if i == 3:
+                break
+        return out
+
+    a, b = run(1), run(8)
+    assert len(a) == len(b) == 4
+    for fa, fb in zip(a, b):
+        assert [k for k, _ in fa] == [k for k, _ in fb]
+        for (k, x), (_, y) in zip(fa, fb):
+            assert (np.array_equal(x, y) if isinstance(x, np.ndarray) else x == y), k
+    assert any('AUGM_STATE' in k for k, _ in a[0])
+
+    old = misc.FRAME_STORES
+    try:
+        misc.FRAME_STORES = misc.FrameStoreCache(capacity=2)
+        dm = DataModule(_cfg(trees['gen1'], train=dict(sampling='stream')), num_workers_train=2, num_workers_eval=1,
+                        batch_size_train=4, batch_size_eval=1, prefetch=0, io_threads=1)
+        dm.setup('fit')
+        n_seq = len(dm.sampling_mode_2_dataset[next(iter(dm.sampling_mode_2_dataset))].datapipe_list)
+        assert n_seq > 2 and len(misc.FRAME_STORES) == 0         # building the sequences opened nothing for keeps
+        for i, batch in enumerate(dm.train_dataloader()):
+            if i == 6:
+                break
+        assert 1 <= len(misc.FRAME_STORES) <= 2
+    finally:
+        misc.FRAME_STORES = old
