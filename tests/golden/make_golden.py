@@ -739,9 +739,177 @@ def g17_loader():
     save('g17_loader.npz', **out)
 
 
+# ====================================================================================================
+class _CudaLikeFp32Ops(torch.overrides.TorchFunctionMode):
+    """CUDA autocast keeps layer_norm / softmax / BCE-with-logits in its fp32 list (they upcast their inputs and return fp32);
+    CPU autocast lets them run in the input dtype (bf16).  Inside this mode the CPU autocast run gets the CUDA placement the
+    reference trains with (Lightning precision=16, train.py:236-243)."""
+    FP32 = None
+
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        import torch.nn.functional as F
+        kwargs = kwargs or {}
+        if _CudaLikeFp32Ops.FP32 is None:
+            _CudaLikeFp32Ops.FP32 = {F.layer_norm, torch.layer_norm, torch.Tensor.softmax, torch.softmax, F.softmax,
+                                     F.binary_cross_entropy_with_logits, torch.Tensor.exp, torch.exp, torch.Tensor.log, torch.log}
+        if func in _CudaLikeFp32Ops.FP32:
+            up = lambda a: a.float() if torch.is_tensor(a) and a.is_floating_point() and a.dtype != torch.float32 else a
+            args = tuple(up(a) for a in args)
+            kwargs = {k: up(v) for k, v in kwargs.items()}
+        return func(*args, **kwargs)
+
+
+def _ref_train_step(det, ev_padded, labels, hw, T, B, mode):
+    """One forward + backward of the reference detector driven like Module.training_step (as g12), in ``mode``:
+    'fp32' | 'ac' (torch.autocast('cpu', bfloat16) as it is) | 'acf' (the same with CUDA autocast's fp32-op placement).
+    -> dict(losses[6], grads {name: tensor}, feats of the last timestep {stage: tensor}, final LSTM (h, c) per stage)"""
+    import contextlib
+    det.train()
+    for p_ in det.parameters():
+        p_.grad = None
+    ctx = contextlib.ExitStack()
+    if mode in ('ac', 'acf'):
+        ctx.enter_context(torch.autocast('cpu', dtype=torch.bfloat16))
+    if mode == 'acf':
+        ctx.enter_context(_CudaLikeFp32Ops())
+    with ctx:
+        rnn = RNNStates()
+        rnn.reset(worker_id=0, indices_or_bool_tensor=torch.ones(B, dtype=torch.bool))
+        prev = rnn.get_states(worker_id=0)
+        sel = BackboneFeatureSelector()
+        obj_labels = []
+        feats = None
+        for t in range(T):
+            feats, prev = det.forward_backbone(x=ev_padded[t], previous_states=prev)
+            idx = [b for b in range(B) if labels[t][b] is not None]
+            if idx:
+                sel.add_backbone_features(backbone_features=feats, selected_indices=idx)
+                obj_labels.extend(ObjectLabels(labels[t][b], hw) for b in idx)
+        targets = ObjectLabels.get_labels_as_batched_tensor(obj_label_list=obj_labels, format_='yolox')
+        preds, losses = det.forward_detect(backbone_features=sel.get_batched_backbone_features(), targets=targets)
+        losses['loss'].float().backward()
+    return dict(losses=np.array([float(losses[k]) for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')], dtype=np.float64),
+                grads={n: p_.grad.detach().float().clone() for n, p_ in det.named_parameters() if p_.grad is not None},
+                feats={k: v.detach().float().clone() for k, v in feats.items()},
+                states=[(h.detach().float().clone(), c.detach().float().clone()) for h, c in prev])
+
+
+def _rel(a, b):
+    """||a - b|| / ||b|| (0 when both vanish)"""
+    d, n = float((a.double() - b.double()).norm()), float(b.double().norm())
+    return d / n if n > 0 else (0.0 if d == 0 else float('inf'))
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    n = float(a.norm() * b.norm())
+    return float(a @ b) / n if n > 0 else 1.0
+
+
+def _class_record(out, tag, ref, run):
+    """Deviation of one 16-bit run of the reference from its fp32 run: what the HIP bf16 mode is allowed to differ by."""
+    names = sorted(ref['grads'])
+    out[f'{tag}_losses'] = run['losses']
+    out[f'{tag}_grad_rel'] = np.array([_rel(run['grads'][n], ref['grads'][n]) for n in names], dtype=np.float64)
+    out[f'{tag}_grad_cos'] = np.array([_cos(run['grads'][n], ref['grads'][n]) for n in names], dtype=np.float64)
+    flat = lambda g: torch.cat([g[n].flatten() for n in names])
+    out[f'{tag}_grad_cos_global'] = np.float64(_cos(flat(run['grads']), flat(ref['grads'])))
+    out[f'{tag}_grad_rel_global'] = np.float64(_rel(flat(run['grads']), flat(ref['grads'])))
+    out[f'{tag}_feat_rel'] = np.array([_rel(run['feats'][k], ref['feats'][k]) for k in sorted(ref['feats'])], dtype=np.float64)
+    out[f'{tag}_feat_maxrel'] = np.array([float((run['feats'][k] - ref['feats'][k]).abs().max() / ref['feats'][k].abs().max())
+                                          for k in sorted(ref['feats'])], dtype=np.float64)
+    out[f'{tag}_state_h_rel'] = np.array([_rel(h, rh) for (h, _), (rh, _) in zip(run['states'], ref['states'])], dtype=np.float64)
+    out[f'{tag}_state_c_rel'] = np.array([_rel(c, rc) for (_, c), (_, rc) in zip(run['states'], ref['states'])], dtype=np.float64)
+    out[f'{tag}_state_c_maxrel'] = np.array([float((c - rc).abs().max() / rc.abs().max())
+                                             for (_, c), (_, rc) in zip(run['states'], ref['states'])], dtype=np.float64)
+
+
+def g18_autocast(full_size=True):
+    """The reference's own 16-bit class: the reference run in fp32 and under torch.autocast (bf16 on CPU -- the
+    only 16-bit autocast this container has; the reference trains with fp16 autocast on CUDA, train.py:236-243), once as CPU
+    autocast places ops ('ac') and once with CUDA autocast's fp32-op list emulated ('acf').  Stored: the fp32 run's losses /
+    gradient norms (so that the tests can pin their own fp32 side to it) and, per tensor, how far each 16-bit run is from fp32.
+    The -m gpu tests bound the HIP bf16 mode's deviation from fp32 by 1.5 x these.
+      micro_*   micro detector, T=5 B=2 (the g12 set-up, step 0)
+      tiny_*    RVT-tiny at 256x320, T=2 B=1 forward features (the g04 set-up)
+      small_*   RVT-small Gen1 240x304 T=21 bs=8, the benchmark workload (bench.make_batch seed 7): scalars only"""
+    out = {}
+    # ---- micro train step -------------------------------------------------------------------------------------------------
+    torch.manual_seed(0)
+    det = YoloXDetector(make_cfg(**MICRO))
+    load_synth(det, 9)
+    T, B = 5, 2
+    ev = InputPadderFromShape(desired_hw=(64, 96)).pad_tensor_ev_repr(synth_events(T, B, 20, 60, 90, seed=20, as_uint8=False))
+    lab_list = micro_labels(T * B, seed=30)
+    labels = [[lab_list[t * B + b] if (t in (2, 4) or (t == 1 and b == 0)) else None for b in range(B)] for t in range(T)]
+    runs = {m: _ref_train_step(det, ev, labels, (60, 90), T, B, m) for m in ('fp32', 'ac', 'acf')}
+    names = sorted(runs['fp32']['grads'])
+    out['micro_grad_keys'] = np.array(names)
+    out['micro_fp32_losses'] = runs['fp32']['losses']
+    out['micro_fp32_grad_norms'] = np.array([float(runs['fp32']['grads'][n].double().norm()) for n in names], dtype=np.float64)
+    out['micro_fp32_feat_norms'] = np.array([float(runs['fp32']['feats'][k].double().norm()) for k in sorted(runs['fp32']['feats'])])
+    for m in ('ac', 'acf'):
+        _class_record(out, f'micro_{m}', runs['fp32'], runs[m])
+    # ---- RVT-tiny forward at the real geometry ----------------------------------------------------------------------------
+    det = YoloXDetector(make_cfg(32, 32, 0.33, (256, 320), (8, 10)))
+    load_synth(det, 6)
+    det.eval()
+    ev = InputPadderFromShape(desired_hw=(256, 320)).pad_tensor_ev_repr(synth_events(2, 1, 20, 240, 304, seed=5, as_uint8=False))
+    import contextlib
+    fe = {}
+    for m in ('fp32', 'ac', 'acf'):
+        with contextlib.ExitStack() as ctx, torch.no_grad():
+            if m != 'fp32':
+                ctx.enter_context(torch.autocast('cpu', dtype=torch.bfloat16))
+            if m == 'acf':
+                ctx.enter_context(_CudaLikeFp32Ops())
+            f_, st = det.forward_backbone(ev[0], None)
+            f_, st = det.forward_backbone(ev[1], st)
+            fe[m] = {k: v.float() for k, v in f_.items()}
+    out['tiny_fp32_feat_norms'] = np.array([float(fe['fp32'][k].double().norm()) for k in sorted(fe['fp32'])])
+    for m in ('ac', 'acf'):
+        out[f'tiny_{m}_feat_rel'] = np.array([_rel(fe[m][k], fe['fp32'][k]) for k in sorted(fe['fp32'])], dtype=np.float64)
+        out[f'tiny_{m}_feat_maxrel'] = np.array([float((fe[m][k] - fe['fp32'][k]).abs().max() / fe['fp32'][k].abs().max())
+                                                 for k in sorted(fe['fp32'])], dtype=np.float64)
+    # ---- the benchmark workload -------------------------------------------------------------------------------------------
+    if full_size:
+        import bench
+        import time
+        T, B, hw = 21, 8, (240, 304)
+        evu, _, label_tb, labs = bench.make_batch(T, B, hw, 2, 7, 'cpu', (4, 9, 14, 19))
+        it = iter(labs)
+        labels = []
+        for t in range(T):
+            row = [None] * B
+            for b in label_tb[t]:
+                l = next(it)
+                row[b] = torch.from_numpy(np.concatenate([np.ones((len(l), 1), np.float32), l[:, 1:2] - l[:, 3:4] / 2,
+                                                          l[:, 2:3] - l[:, 4:5] / 2, l[:, 3:5], l[:, 0:1], l[:, 6:7], l[:, 5:6]], 1))
+            labels.append(row)
+        man = json.load(open(os.path.join(HERE, 'g11_manifest.json')))['small_gen1']
+        det = YoloXDetector(make_cfg(embed_dim=48, dim_head=24, fpn_depth=0.33, in_hw=(256, 320), part=(8, 10)))
+        det.load_state_dict(synth_state_dict(man, 0), strict=True)
+        x = InputPadderFromShape(desired_hw=(256, 320)).pad_tensor_ev_repr(evu.to(torch.float32))
+        runs = {}
+        for m in ('fp32', 'ac', 'acf'):
+            t0 = time.time()
+            runs[m] = _ref_train_step(det, x, labels, hw, T, B, m)
+            print(f'small {m}: {time.time() - t0:.1f} s, losses {runs[m]["losses"]}')
+        names = sorted(runs['fp32']['grads'])
+        out['small_grad_keys'] = np.array(names)
+        out['small_fp32_losses'] = runs['fp32']['losses']
+        out['small_fp32_grad_norms'] = np.array([float(runs['fp32']['grads'][n].double().norm()) for n in names], dtype=np.float64)
+        for m in ('ac', 'acf'):
+            _class_record(out, f'small_{m}', runs['fp32'], runs[m])
+    save('g18_autocast.npz', **out)
+    for k in sorted(out):
+        if 'global' in k or k.endswith('losses') or 'feat_rel' in k or 'state_c_rel' in k:
+            print(k, out[k])
+
+
 ALL = dict(g01=g01_convlstm, g02=g02_partition, g03=g03_attention, g04=g04_backbone, g05=g05_head,
            g06=g06_simota, g07=g07_postprocess, g08=g08_pseudo, g10=g10_voxel, g11=g11_manifest,
-           g12=g12_trainstep, g13=g13_tracker, g14=g14_augment, g15=g15_evaluator, g16=g16_tta_result, g17=g17_loader)
+           g12=g12_trainstep, g13=g13_tracker, g14=g14_augment, g15=g15_evaluator, g16=g16_tta_result, g17=g17_loader, g18=g18_autocast)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)

@@ -30,6 +30,9 @@ def test_worker_process_loader_delivers_device_frames(tmp_path):
         dm.setup('fit')
         out = []
         loader = dm.train_dataloader()
+        if not isinstance(loader, ProcessLoader):              # what ProcessLoader does per epoch: one parent draw seeds the worker
+            from leod_amd.modules.data.process_loader import draw_base_seed, seed_worker
+            seed_worker(draw_base_seed(), 0)
         for batch in loader:
             ev = batch['data'][DataType.EV_REPR]
             out.append((torch.stack([e.cpu() for e in ev]), [bool(x) for x in batch['data'][DataType.IS_FIRST_SAMPLE].cpu()], ev[0].device.type))

@@ -278,6 +278,45 @@ def test_g12_trainstep(golden_dir, manifest):
         close(tr.states[3][1], g[f's{step}_state_c4'], rtol=1e-4, atol=1e-5)
 
 
+def test_g18_fp32_side_of_the_autocast_fixture(golden_dir, manifest):
+    """g18_autocast.npz records how far the REFERENCE's autocast runs land from its fp32 run; the -m gpu tests measure this
+    build's bf16 mode against this build's fp32 mode on the same workloads.  The two fp32 sides must be the same function:
+    the oracle reproduces the fixture's fp32 losses and per-parameter gradient norms -- micro step and the benchmark workload
+    (RVT-S Gen1 240x304 T=21 bs=8, bench.make_batch seed 7; one full-size oracle step, ~10 s)."""
+    import bench
+    g = G(golden_dir, 'g18_autocast.npz')
+    keys = ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')
+    # micro (the g12 set-up, step 0, un-clipped gradients)
+    tr = ot.OracleTrainer(synth_state_dict(manifest['micro'], 9), MICRO, lr=2e-4, total_steps=1000, clip_value=0.0)
+    T, B = 5, 2
+    ev = synth_events(T, B, 20, 60, 90, seed=20, as_uint8=True)
+    lab_list = micro_labels(T * B, seed=30)
+    labels = [[lab_list[t * B + b] if (t in (2, 4) or (t == 1 and b == 0)) else None for b in range(B)] for t in range(T)]
+    losses, grads = tr.step(ev, labels, torch.ones(B, dtype=torch.bool))
+    np.testing.assert_allclose([losses[k] for k in keys], g['micro_fp32_losses'], rtol=5e-5)
+    names = [str(k) for k in g['micro_grad_keys']]
+    np.testing.assert_allclose([float(grads[k].double().norm()) for k in names], g['micro_fp32_grad_norms'], rtol=2e-3, atol=1e-7)
+    # the benchmark workload
+    T, B, hw = 21, 8, (240, 304)
+    ev, _, label_tb, labs = bench.make_batch(T, B, hw, 2, 7, 'cpu', (4, 9, 14, 19))
+    it = iter(labs)
+    labels = []
+    for t in range(T):
+        row = [None] * B
+        for b in label_tb[t]:
+            l = next(it)
+            row[b] = torch.from_numpy(np.concatenate([np.ones((len(l), 1), np.float32), l[:, 1:2] - l[:, 3:4] / 2, l[:, 2:3] - l[:, 4:5] / 2,
+                                                      l[:, 3:5], l[:, 0:1], l[:, 6:7], l[:, 5:6]], 1))
+        labels.append(row)
+    tr = ot.OracleTrainer(synth_state_dict(manifest['small_gen1'], 0), ot.model_cfg(48, 24, 0.33, (8, 10)), clip_value=0.0)
+    losses, grads = tr.step(ev, labels, torch.ones(B, dtype=torch.bool))
+    np.testing.assert_allclose([losses[k] for k in keys], g['small_fp32_losses'], rtol=2e-5, atol=1e-6)
+    names = [str(k) for k in g['small_grad_keys']]
+    np.testing.assert_allclose([float(grads[k].double().norm()) for k in names], g['small_fp32_grad_norms'], rtol=2e-3, atol=1e-7)
+    # sanity of the class itself: the looser autocast run of the reference sits at a gradient cosine of ~0.92 from its fp32 run
+    assert 0.85 < float(g['small_ac_grad_cos_global']) < float(g['small_acf_grad_cos_global']) < 0.99
+
+
 def _tracker_cases(golden_dir):
     g = np.load(os.path.join(golden_dir, 'g13_tracker.npz'))
     for si in range(6):
