@@ -102,6 +102,28 @@ struct ALRowsM : ALRows {
         if constexpr (LN) { r.g = ld4(ln_w + k); r.b = ld4(ln_b + k); }
         if constexpr (KS) r.s = ld4(kscale + k);
     }
+    // split form for kernels whose staging slots of a thread share ONE k offset (gemm_wide_bf16_kernel): the row data per slot, the
+    // per-k vectors (LayerNorm weight / bias, scale) once per chunk into the Raw of slot 0
+    __device__ __forceinline__ void raw_x(const St& st, int k, Raw& r) const {
+        if constexpr (FMT == 0) r.v = ld4(st.p + k);
+        else r.h = *reinterpret_cast<const u2_*>(reinterpret_cast<const unsigned short*>(st.p) + k);
+    }
+    __device__ __forceinline__ void raw_k(int k, Raw& r) const {
+        if constexpr (LN) { r.g = ld4(ln_w + k); r.b = ld4(ln_b + k); }
+        if constexpr (KS) r.s = ld4(kscale + k);
+    }
+    __device__ __forceinline__ f4 fin_k(const St& st, const Raw& r, const Raw& rk) const {
+        f4 v;
+        if constexpr (FMT == 1) {
+            v = unpack_h16(__builtin_bit_cast(s4, r.h));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+        } else if constexpr (FMT == 2) v = unpack_bf16(__builtin_bit_cast(s4, r.h));
+        else v = r.v;
+        if constexpr (LN) v = (v - st.mean) * st.rstd * rk.g + rk.b;
+        if constexpr (KS) v = v * rk.s;
+        return v;
+    }
     __device__ __forceinline__ f4 fin(const St& st, const Raw& r) const {
         f4 v;
         if constexpr (FMT == 1) {
@@ -421,6 +443,8 @@ struct EpStore {
     float* colsum;                  // optional [N]: += column sums of the stored value (bias gradient)
     int act; int accumulate;
     int N;
+    int out_fmt;                    // row epilogue only (run_rows): 0 = fp32 out; 1 = out holds fp16 (clamped), 2 = bf16 -- the 16-bit tensors of
+    int aux_fmt;                    // precision mode bf16 (MLP hidden pre-activation, qkv, du); aux_fmt 1: aux is an fp16 pre-activation
     int rm_Q, rm_H, rm_W;           // rm_Q > 0: GEMM rows are parity-class ordered (ALConvT2) -> remap to pixel rows of the [B,H,W] map
     __device__ __forceinline__ long maprow(int row) const {
         if (rm_Q <= 0) return row;
@@ -506,11 +530,15 @@ struct EpStore {
                 for (int j = 0; j < 4; ++j) v[j] = siluf_(v[j] * sc[j] + sh[j]);
             }
             if (act == ACT_MUL_GELU_GRAD) {
-                const f4 u = ld4(aux + row * ldaux + n);
+                const f4 u = aux_fmt ? unpack_h16(*reinterpret_cast<const s4*>(reinterpret_cast<const unsigned short*>(aux) + row * ldaux + n))
+                                     : ld4(aux + row * ldaux + n);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(u[j]);
             }
-            if (nsplit > 0 && n >= nsplit) {
+            if (out_fmt) {                                      // 16-bit primary output (no split / accumulate / dual store in this mode)
+                unsigned short* pp = reinterpret_cast<unsigned short*>(out) + row * ld + n;
+                *reinterpret_cast<s4*>(pp) = out_fmt == 1 ? pack_h16(v) : pack_bf16(v);
+            } else if (nsplit > 0 && n >= nsplit) {
                 float* pp = out2 + row * ld2 + (n - nsplit);
                 if (accumulate) v += ld4(pp);
                 *reinterpret_cast<f4*>(pp) = v;
@@ -1007,10 +1035,38 @@ static inline int launch_gemm_lds(const AL& al, const BL& bl, const EP& ep, int 
     // resident workgroups, two epilogue rounds), so only RW = 1 is instantiated.
     return launch_gemm_lds_rw<NT, 1>(al, bl, ep, M, K, nblocks_n, s);
 }
+#include "gemm_bf16.hpp"
 // plain-row A operands: the hot mode combinations of the wide GEMMs (NT >= 3) run on the two-phase loader ALRowsM
 template <int NT, class BL, class EP>
 static inline int launch_gemm_lds(const ALRows& al, const BL& bl, const EP& ep, int M, int K, int nblocks_n, hipStream_t s) {
     static const int two_phase = getenv("LEOD_GEMM_TWO_PHASE") ? atoi(getenv("LEOD_GEMM_TWO_PHASE")) : 1;
+    // precision mode bf16, Linear forward / dgrad with >= 144 output columns: the 128 x 192 / 256 wide-tile kernel (gemm_bf16.hpp)
+    if constexpr ((std::is_same<BL, BLRows>::value || std::is_same<BL, BLTrans>::value) &&
+                  (std::is_same<EP, EpStore>::value || std::is_same<EP, EpLsRes>::value)) {
+        const bool ln = al.ln_w != nullptr, ks = al.kscale != nullptr;
+        // the persistent wide tiles win where the main loop dominates (LayerNorm on load, contractions of >= 2 N); short contractions
+        // into wide outputs are bound by their epilogue traffic, which the many small workgroups of gemm_lds_kernel overlap better
+        // (tools/kbench_gemm.py; LEOD_GEMM_WIDE=2 routes every covered shape here)
+        static const int wide_mode = getenv("LEOD_GEMM_WIDE") ? atoi(getenv("LEOD_GEMM_WIDE")) : 1;
+        const int ntw = ((!ln || al.stats_in) && (wide_mode >= 2 || ln || K >= 2 * bl.N)) ? gemm_wide_ntw(M, bl.N, K) : 0;
+        if (ntw) {
+#define LEOD_WIDE(F, L, S) { ALRowsM<F, L, S> am; static_cast<ALRows&>(am) = al;                                                     \
+                             return ntw == 3 ? launch_gemm_wide<3>(am, bl, ep, M, K, bl.N, s) : launch_gemm_wide<4>(am, bl, ep, M, K, bl.N, s); }
+            constexpr bool rows = std::is_same<BL, BLRows>::value, store = std::is_same<EP, EpStore>::value;
+            if constexpr (rows && store) {                  // LN -> qkv / fc1, plain x projection of the ConvLSTM
+                if (al.fmt == 0 && !ln && !ks) LEOD_WIDE(0, false, false)
+                if (al.fmt == 0 && ln && !ks) LEOD_WIDE(0, true, false)
+            } else if constexpr (rows && !store) {          // proj / fc2 + LayerScale + residual (fc2: gelu of the fp16 pre-activation)
+                if (al.fmt == 0 && !ln && !ks) LEOD_WIDE(0, false, false)
+                if (al.fmt == 1 && !ln && !ks) LEOD_WIDE(1, false, false)
+            } else if constexpr (!rows && store) {          // dgrads: fp32 / bf16 gradient rows, optional LayerScale factor
+                if (al.fmt == 0 && !ln && !ks) LEOD_WIDE(0, false, false)
+                if (al.fmt == 0 && !ln && ks) LEOD_WIDE(0, false, true)
+                if (al.fmt == 2 && !ln && !ks) LEOD_WIDE(2, false, false)
+            }
+#undef LEOD_WIDE
+        }
+    }
     if constexpr (NT >= 3) {
         const bool ln = al.ln_w != nullptr, ks = al.kscale != nullptr;
         if (two_phase && !(K & 3) && K >= 4 && (!ln || al.stats_in)) {

@@ -22,6 +22,9 @@ static inline int pick_nt(int N) {
         default: { constexpr int NT = 4; __VA_ARGS__; } break;         \
     }
 
+static int ln_linear_16_generic(const float* x, const float* ln_w, const float* ln_b, float eps, const float* W, const float* bias,
+                                void* out16, float* stats_out, int M, int N, int K, int out_fmt, hipStream_t stream);
+
 static inline EpStore ep_store(float* out, long ld, int N) {
     EpStore e{};
     e.out = out; e.ld = ld; e.N = N; e.act = ACT_NONE;
@@ -677,7 +680,9 @@ LEOD_API int leod_ln_linear_gelu16_fwd(const float* x, const float* ln_w, const 
     if (!x || !W || !u16 || !ln_w || !stats_out) return LEOD_ERR_ARG;
     static const int on = getenv("LEOD_U16") ? atoi(getenv("LEOD_U16")) : 1;
     const int slab = rowstream_slab(M, N, K);
-    if (!on || leod_precision() != 1 || !slab) return LEOD_ERR_UNSUPPORTED;
+    static const int gen16 = getenv("LEOD_GENERIC16") ? atoi(getenv("LEOD_GENERIC16")) : 1;
+    if (!on || leod_precision() != 1) return LEOD_ERR_UNSUPPORTED;
+    if (!slab) return gen16 ? ln_linear_16_generic(x, ln_w, ln_b, eps, W, bias, u16, stats_out, M, N, K, 1, stream) : LEOD_ERR_UNSUPPORTED;
     const int slabs = N / (16 * slab);
 #define U16_CASE(KCV, NTTV)                                                                                                          \
     if (K == 16 * KCV && slab == NTTV) {                                                                                             \
@@ -692,12 +697,30 @@ LEOD_API int leod_ln_linear_gelu16_fwd(const float* x, const float* ln_w, const 
     return LEOD_ERR_UNSUPPORTED;
 }
 
+// Generic 16-bit producers (round 3: stages 3-4 and every geometry the row-streaming kernels do not cover): the LDS-staged / wide-tile
+// GEMMs with a 16-bit row epilogue.  out_fmt 1 = fp16 (the MLP hidden pre-activation), 2 = bf16 (qkv).  ln_w may be NULL (plain rows).
+static int ln_linear_16_generic(const float* x, const float* ln_w, const float* ln_b, float eps, const float* W, const float* bias,
+                                void* out16, float* stats_out, int M, int N, int K, int out_fmt, hipStream_t stream) {
+    if (leod_precision() != 1 || (K & 3) || (N & 3) || (ln_w && !stats_out)) return LEOD_ERR_UNSUPPORTED;
+    const int nt = pick_nt(N);
+    if (!use_gemm_lds(M, cdiv(N, 16 * nt))) return LEOD_ERR_UNSUPPORTED;
+    ALRows al{}; al.x = x; al.ld = K; al.ln_w = ln_w; al.ln_b = ln_b; al.eps = eps; al.K = K;
+    EpStore ep = ep_store(reinterpret_cast<float*>(out16), N, N);
+    ep.bias = bias; ep.out_fmt = out_fmt;
+    int rc = LEOD_OK;
+    if (ln_w) { rc = launch_row_stats(x, K, stats_out, M, K, eps, stream); if (rc) return rc; al.stats_in = stats_out; }
+    DISPATCH_NT(nt, { BLRows bl{W, (long)K, N, NT}; rc = launch_gemm_lds<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
+    return rc;
+}
+
 // out16[M,N] = bf16(LN(x) W^T + bias) (the qkv rows of stages 1-2: q, k, v only ever enter bf16 MFMAs); stats_out [M,2]
 LEOD_API int leod_ln_linear_bf16_fwd(const float* x, const float* ln_w, const float* ln_b, float eps, const float* W, const float* bias,
                                      void* out16, float* stats_out, int M, int N, int K, hipStream_t stream) {
-    if (!x || !W || !out16 || !ln_w || !stats_out) return LEOD_ERR_ARG;
-    const int slab = rowstream_slab(M, N, K);
-    if (leod_precision() != 1 || !slab) return LEOD_ERR_UNSUPPORTED;
+    if (!x || !W || !out16 || (ln_w && !stats_out)) return LEOD_ERR_ARG;
+    const int slab = ln_w ? rowstream_slab(M, N, K) : 0;
+    static const int gen16 = getenv("LEOD_GENERIC16") ? atoi(getenv("LEOD_GENERIC16")) : 1;
+    if (leod_precision() != 1) return LEOD_ERR_UNSUPPORTED;
+    if (!slab) return gen16 ? ln_linear_16_generic(x, ln_w, ln_b, eps, W, bias, out16, stats_out, M, N, K, 2, stream) : LEOD_ERR_UNSUPPORTED;
     const int slabs = N / (16 * slab);
 #define O16_CASE(KCV, NTTV)                                                                                                          \
     if (K == 16 * KCV && slab == NTTV) {                                                                                             \
@@ -744,7 +767,18 @@ LEOD_API int leod_linear_dgrad_gelu16(const float* dy, const float* kscale, cons
                                       int M, int N, int K, int out_bf16, hipStream_t stream) {
     if (!dy || !W || !u16 || !dx || leod_precision() != 1) return LEOD_ERR_ARG;
     const int slab = rowstream_slab(M, K, N);
-    if (!slab) return LEOD_ERR_UNSUPPORTED;
+    if (!slab) {
+        // generic shapes (stages 3-4): LDS-staged / wide-tile dgrad, gelu'(fp16 u) and the 16-bit store in the row epilogue
+        static const int gen16 = getenv("LEOD_GENERIC16") ? atoi(getenv("LEOD_GENERIC16")) : 1;
+        const int nt = pick_nt(K);
+        if (!gen16 || (N & 3) || (K & 3) || !use_gemm_lds(M, cdiv(K, 16 * nt))) return LEOD_ERR_UNSUPPORTED;
+        ALRows al{}; al.x = dy; al.ld = N; al.kscale = kscale; al.K = N;
+        EpStore ep = ep_store(reinterpret_cast<float*>(dx), K, K);
+        ep.act = ACT_MUL_GELU_GRAD; ep.aux = reinterpret_cast<const float*>(u16); ep.ldaux = K; ep.aux_fmt = 1; ep.out_fmt = out_bf16 ? 2 : 0;
+        int rc = LEOD_OK;
+        DISPATCH_NT(nt, { BLTrans bl{W, (long)K, K, NT}; rc = launch_gemm_lds<NT>(al, bl, ep, M, N, cdiv(K, 16 * NT), stream); });
+        return rc;
+    }
     const int slabs = K / (16 * slab);
     const int gx = min(cdiv(cdiv(M, 16), 4), max(8, (256 * 2 / slabs) & ~7));
     float* aux = reinterpret_cast<float*>(const_cast<void*>(u16));

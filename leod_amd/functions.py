@@ -194,7 +194,7 @@ class AttnBlockFn(Function):
         (n1w, n1b, qkv_w, qkv_b, proj_w, proj_b, g1, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, g2) = params
         heads, part, window = mod.self_attn.num_heads, mod.partition_size, mod.partition_window
         # precision mode bf16: where the LDS attention kernels cover the geometry, qkv (and dqkv in backward) live in HBM as bf16
-        q16 = n1w is not None and ops.partition_attn_16bit_ok(x.shape[0], x.shape[1], x.shape[2], x.shape[3], heads, part)
+        q16 = ops.partition_attn_16bit_ok(x.shape[0], x.shape[1], x.shape[2], x.shape[3], heads, part)
         qkv, _, st1 = ops.ln_linear_fwd(x, n1w, n1b, qkv_w, qkv_b, want_stats=need or q16, out_bf16=q16)
         o, lse = ops.partition_attn_fwd(qkv, heads, part, window, want_lse=need)
         # the pre-LayerScale outputs are NOT stored: dgamma is recovered from the un-scaled weight gradient in backward

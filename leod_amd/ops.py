@@ -101,16 +101,16 @@ def ln_linear_fwd(x, ln_w, ln_b, W, bias, want_act=False, want_stats=False, eps=
     K = x.shape[-1]
     N = W.shape[0]
     M = x.numel() // K
-    if out_bf16 and not want_act and ln_w is not None:
-        # the qkv rows of stages 1-2 in precision mode bf16 (consumed only by bf16 MFMAs): stored as bf16 where the kernels allow
+    if out_bf16 and not want_act:
+        # the qkv rows in precision mode bf16 (consumed only by bf16 MFMAs): stored as bf16 where the kernels allow (rc -3: they do not)
         o16 = torch.empty(x.shape[:-1] + (N,), dtype=torch.bfloat16, device=x.device)
-        stats = _empty((M, 2), x)
+        stats = _empty((M, 2), x) if ln_w is not None else None
         rc = _l().leod_ln_linear_bf16_fwd(_p(x), _p(ln_w), _p(ln_b), eps, _p(W), _p(bias), _p(o16), _p(stats), M, N, K, _stream())
         if rc != -3:
             check(rc, 'ln_linear_bf16_fwd')
             return o16, None, stats
     if want_act and want_stats and ln_w is not None and get_precision() == 'bf16':
-        # precision mode bf16, stages 1-2: the hidden pre-activation is stored once, as fp16 (the reference's autocast dtype); consumers apply GELU on load
+        # precision mode bf16: the hidden pre-activation is stored once, as fp16 (the reference's autocast dtype); consumers apply GELU on load
         u16 = torch.empty(x.shape[:-1] + (N,), dtype=torch.float16, device=x.device)
         stats = _empty((M, 2), x)
         rc = _l().leod_ln_linear_gelu16_fwd(_p(x), _p(ln_w), _p(ln_b), eps, _p(W), _p(bias), _p(u16), _p(stats), M, N, K, _stream())

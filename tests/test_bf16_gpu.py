@@ -160,7 +160,8 @@ def test_partition_attn_bf16_tensors(bf16_ops, B, H, W, C, heads, window):
     tk.close(dq.float(), qkv.grad, what='bf16 dqkv')
 
 
-@pytest.mark.parametrize('M,N,K', [(40009, 144, 48), (20011, 288, 96)])
+@pytest.mark.parametrize('M,N,K', [(40009, 144, 48), (20011, 288, 96),
+                                   (9001, 576, 192), (5003, 1152, 384), (8200, 192, 64), (12000, 96, 32)])   # generic 16-bit epilogue (stages 3-4, RVT-B / T)
 def test_ln_qkv_bf16_rows(bf16_ops, M, N, K):
     import torch.nn.functional as F
     ops = bf16_ops
@@ -175,9 +176,21 @@ def test_ln_qkv_bf16_rows(bf16_ops, M, N, K):
     tk.close(st[:, 0], mean, rtol=1e-4, atol=1e-5, what='LayerNorm mean')
 
 
-@pytest.mark.parametrize('M,C', [(40009, 48), (20011, 96), (16384, 64)])
+def test_qkv_bf16_rows_without_layernorm(bf16_ops):
+    """First attention block of a stage (norm1 = Identity, maxvit_rnn.py:164-166): the qkv rows still go out as bf16."""
+    import torch.nn.functional as F
+    ops = bf16_ops
+    for M, N, K in ((9001, 576, 192), (20011, 288, 96), (40009, 144, 48)):
+        x, W, b = tk.rnd((M, K), 1), tk.rnd((N, K), 4, 0.2), tk.rnd((N,), 5, 0.2)
+        o16, _, st = ops.ln_linear_fwd(x.to(tk.DEV), None, None, W.to(tk.DEV), b.to(tk.DEV), out_bf16=True)
+        assert o16.dtype is torch.bfloat16 and st is None
+        tk.close(o16.float(), F.linear(x, W, b), what=f'bf16 qkv rows without LayerNorm {M}x{N}x{K}')
+
+
+@pytest.mark.parametrize('M,C', [(40009, 48), (20011, 96), (16384, 64), (9001, 192), (5003, 384), (4100, 128)])
 def test_mlp_hidden_stored_once_as_fp16(bf16_ops, M, C):
-    """Stages 1-2 in precision mode bf16: norm2 -> fc1 keeps the hidden pre-activation u once, as fp16 (no fp32 u, no gelu(u) copy);
+    """Precision mode bf16 (stages 1-2 on the row-streaming kernels, everything else on the LDS-staged / wide-tile GEMMs with a 16-bit row
+    epilogue): norm2 -> fc1 keeps the hidden pre-activation u once, as fp16 (no fp32 u, no gelu(u) copy);
     fc2 + LayerScale + residual, the dgrad through GELU and the fc2 weight gradient evaluate GELU / GELU' while loading it
     (maxvit.py:110-118, 268-269).  Against the fp32 CPU arithmetic of the same chain, ragged row counts."""
     import torch.nn.functional as F

@@ -79,9 +79,14 @@ def test_ln_linear_fwd(ops, M, N, K, ln, act):
     ref = F.linear(xn, W, b)
     out, a, st = ops.ln_linear_fwd(x.to(DEV), lw.to(DEV) if ln else None, lb.to(DEV) if ln else None, W.to(DEV),
                                    b.to(DEV), want_act=act, want_stats=True)
-    close(out, ref, what='linear')
-    if act:
-        close(a, F.gelu(ref), what='gelu')
+    if out.dtype is torch.float16:
+        # precision mode bf16, LayerNorm -> fc1 -> GELU: the pre-activation comes back ONCE, as fp16 (consumers apply GELU on load)
+        assert act and ln and a is None and MODE['bf16']
+        close(out.float(), ref, what='linear (fp16 pre-activation)')
+    else:
+        close(out, ref, what='linear')
+        if act:
+            close(a, F.gelu(ref), what='gelu')
     if ln:
         close(st[:, 0], x.mean(1), atol=1e-6)
         close(st[:, 1], 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-5), rtol=1e-5)
