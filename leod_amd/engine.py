@@ -29,6 +29,7 @@ class TrainEngine:
         self.flat = FlatParams(detector)
         self.dp = DataParallel(self.flat, process_group, sync_bn=sync_bn)
         self.dp.broadcast_parameters()
+        self.dp.make_buckets(detector)
         self.hp = dict(lr=lr, weight_decay=weight_decay, total_steps=total_steps, pct_start=pct_start,
                        div_factor=div_factor, final_div_factor=final_div_factor, clip_value=clip_value)
         self.global_step = 0
@@ -84,6 +85,8 @@ class TrainEngine:
 
     def _step_body(self, ev_seq, labels, label_tb, is_first, states, hp_dev=None, lr=None, scale=1.0):
         self.flat.zero_grad()
+        if not self._capturing and not torch.cuda.is_current_stream_capturing():
+            self.dp.begin_step()                         # per-stage gradient buckets are exchanged under the backward pass
         ops.StatArena.begin_step(ev_seq.device)          # one memset for all BatchNorm statistic accumulators of the step
         _, losses, new_states = self.forward_loss(ev_seq, labels, label_tb, is_first, states)
         WgradSide.active = self.wgrad_side and not self._capturing and not torch.cuda.is_current_stream_capturing()

@@ -76,6 +76,35 @@ class _wgrad_side:
         return False
 
 
+class BucketBoundaryFn(Function):
+    """Identity in the forward pass; its backward runs when the gradients of ALL its inputs are complete, i.e. when every node
+    between them and the loss has run -- it then tells the data-parallel engine that gradient bucket ``k`` is final
+    (``leod_amd.parallel.GradBuckets.ready``): the all-reduce of that bucket starts under the rest of the backward pass."""
+
+    @staticmethod
+    def forward(ctx, k, *xs):
+        ctx.k = k
+        return tuple(x.view_as(x) for x in xs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        from .parallel import GradBuckets
+        if GradBuckets.current is not None:
+            GradBuckets.current.ready(ctx.k)
+        return (None,) + tuple(gs)
+
+
+def bucket_boundary(k: int, *xs):
+    """``xs`` unchanged unless a bucketed gradient exchange is active for this step (``GradBuckets.current``) and gradients flow."""
+    from .parallel import GradBuckets
+    if GradBuckets.current is None or not torch.is_grad_enabled() or not any(x.requires_grad for x in xs):
+        return xs if len(xs) > 1 else xs[0]
+    if k < 0:
+        k = GradBuckets.current.head                          # the PAFPN + head bucket
+    out = BucketBoundaryFn.apply(k, *xs)
+    return out if len(xs) > 1 else out[0]
+
+
 def set_sync_batchnorm(process_group, world_size: int):
     """Enable SyncBatchNorm semantics (reference: train.py:247 sync_batchnorm=True when >1 GPU): the
     per-channel (sum, sumsq) and backward (sum du, sum du*xhat) vectors are all-reduced over RCCL."""

@@ -126,7 +126,11 @@ class RNNDetector(BaseDetector):
         padded_hw = self.in_res_hw if (self.in_res_hw is not None and tuple(x_seq.shape[-2:]) != self.in_res_hw) else None
         x = x_seq.reshape((T * B,) + tuple(x_seq.shape[2:]))
         states, output = [], {}
+        from leod_amd.functions import bucket_boundary
         for i, stage in enumerate(self.stages):
+            if i > 0:
+                # data-parallel training: when the backward pass arrives here, stage i is done -> its gradient bucket is exchanged
+                x = bucket_boundary(i, x)
             x, state = stage.forward_sequence(x, T, prev_states[i], padded_hw if i == 0 else None)
             states.append(state)
             output[i + 1] = x

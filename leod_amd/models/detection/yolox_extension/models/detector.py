@@ -30,6 +30,8 @@ class YoloXDetector(th.nn.Module):
         assert soft_targets is None
         x2, x1, x0 = (Fn.to_nhwc(backbone_features[f]) for f in self.fpn.in_features)
         if self.training:
+            # data-parallel training: the backward pass leaves the PAFPN + head here -> their gradient bucket is exchanged
+            x2, x1, x0 = Fn.bucket_boundary(-1, x2, x1, x0)
             Fn.sync_bn_begin(x0.shape[0], x0.device)     # SyncBatchNorm: images over all ranks, once per pass (no-op on one rank)
         fpn_feats = self.fpn.forward_nhwc(x2, x1, x0)
         if self.training:

@@ -7,8 +7,9 @@ buffers of ``leod_amd.parallel.FlatParams``:
 
 * ``zero_grad``  one memset of the flat gradient buffer (the wgrad kernels accumulate into views of it; the views are
   never replaced by ``None``),
-* ``step``       join the weight-gradient side stream -> ONE all-reduce of the flat gradient over RCCL when the job has
-  more than one rank -> ONE ``leod_adamw_clip_step`` launch (value-clip + 1/world scaling + AdamW fused).
+* ``step``       join the weight-gradient side stream -> complete the gradient sum over RCCL when the job has more than one rank
+  (five per-stage buckets whose all-reduces were started DURING the backward pass, ``leod_amd.parallel.GradBuckets``) -> ONE
+  ``leod_adamw_clip_step`` launch (value-clip + 1/world scaling + AdamW fused).
 
 The data-parallel exchange lives here, not in a DistributedDataParallel wrapper: the autograd Functions of this package
 write parameter gradients straight into the flat buffer (21 timesteps accumulate in place) and return ``None`` to
@@ -31,6 +32,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self.flat = flat if flat is not None else FlatParams(module)
         self.dp = DataParallel(self.flat, process_group, sync_bn=sync_bn)
         self.dp.broadcast_parameters()
+        self.dp.make_buckets(module)                             # per-stage gradient buckets when the job has more than one rank
         self.clip_value = clip_value
         super().__init__(self.flat.params, dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps))
 
@@ -40,6 +42,7 @@ class FlatAdamW(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none: bool = False) -> None:      # noqa: ARG002 -- the .grad views must survive
         self.flat.zero_grad()
+        self.dp.begin_step()                                     # the backward pass that follows releases the gradient buckets
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -2,10 +2,15 @@
 
 * ``FlatParams``: every trainable parameter becomes a 16-byte-aligned view into ONE fp32 buffer and every
   ``.grad`` a view into ONE gradient buffer.  The wgrad kernels accumulate straight into it, the
-  optimiser is one ``leod_adamw_clip_step`` launch, zeroing is one memset and the gradient exchange is
-  ONE all-reduce of the flat buffer (RVT-S: 39.5 MB; on the fully connected xGMI mesh this is latency-,
-  not bandwidth-bound, and gradients of the recurrent backbone only become final at the very end of the
-  backward pass, so bucketed overlap would buy nothing -- SURVEY 2.2 C1).
+  optimiser is one ``leod_adamw_clip_step`` launch, zeroing is one memset.
+* ``GradBuckets``: the gradient exchange.  The training step runs STAGE-major (``RNNDetector.forward_sequence``), so
+  the backward pass finishes head / PAFPN -> stage 4 -> 3 -> 2 -> 1 and the parameters of a stage are final as soon
+  as that stage's backward (and its side-stream weight-gradient kernels) are done -- parameter counts scale with C^2,
+  so ~98 % of the 39.5 MB (RVT-S) are final before the backward pass of stage 1, the longest, even starts.  The flat
+  buffer is laid out in that module order, so each of the five buckets is ONE contiguous slice: it is all-reduced on a
+  communication stream the moment its boundary node fires in the backward pass (``functions.BucketBoundaryFn``), under
+  the rest of the backward pass; the optimiser waits for the five handles.  ``LEOD_DP_BUCKETS=0`` falls back to one
+  flat all-reduce after the backward pass; ``LEOD_DP_WIRE=bf16`` sends bf16 (half the bytes; fp32 sum on arrival).
 * SyncBatchNorm statistics go through ``functions.set_sync_batchnorm`` (reference: train.py:247).
 * Pseudo-labelling shards whole recordings over ranks with no collective on the data path
   (``shard_sequences``; reference: data/utils/stream_sharded_datapipe.py:40-57,88-105).
@@ -92,11 +97,103 @@ class DataParallel:
         if self.world_size > 1 or self.force:
             dist.broadcast(self.flat.data, src=src, group=self.group)
 
+    def make_buckets(self, module: torch.nn.Module) -> Optional['GradBuckets']:
+        """Per-stage buckets for ``module`` (None: one rank, or LEOD_DP_BUCKETS=0 -> flat all-reduce after the backward pass)."""
+        self.buckets = None
+        if (self.world_size > 1 or self.force) and os.environ.get('LEOD_DP_BUCKETS', '1') != '0':
+            self.buckets = GradBuckets(self.flat, module, self)
+        return self.buckets
+
+    def begin_step(self):
+        b = getattr(self, 'buckets', None)
+        if b is not None:
+            b.begin_step()
+
     def all_reduce_gradients(self) -> float:
-        """Sum-reduce the flat gradient; returns the scale (1/world) the optimiser kernel applies."""
-        if self.world_size > 1 or self.force:
+        """Complete the gradient sum over ranks (bucketed exchanges already in flight, or one flat all-reduce); returns the scale
+        (1/world) the optimiser kernel applies."""
+        b = getattr(self, 'buckets', None)
+        if b is not None and GradBuckets.current is b:
+            b.finish()
+        elif self.world_size > 1 or self.force:
             dist.all_reduce(self.flat.grad, group=self.group)
         return 1.0 / self.world_size
+
+
+class GradBuckets:
+    """Contiguous per-stage slices of a ``FlatParams`` gradient buffer, all-reduced as the backward pass releases them.
+
+    Bucket k < n_stages = parameters of ``backbone.stages.k``; the last bucket = everything else (PAFPN + head).  A bucket is
+    released by ``ready(k)`` -- called from the backward of the boundary node in front of stage k (``functions.bucket_boundary``) or
+    of the features that enter the PAFPN -- and by ``finish()`` for whatever is left (stage 1 has no differentiable input, hence
+    no boundary).  All ranks build the same autograd graph, so they release the buckets in the same order."""
+    current: Optional['GradBuckets'] = None       # the instance the boundary nodes of the running step report to
+
+    def __init__(self, flat: FlatParams, module: torch.nn.Module, dp: 'DataParallel'):
+        import re
+        self.flat, self.dp = flat, dp
+        names = [n for n, p in module.named_parameters() if p.requires_grad]
+        assert len(names) == len(flat.params)
+        ids = []
+        for n in names:
+            m = re.search(r'backbone\.stages\.(\d+)\.', n)
+            ids.append(int(m.group(1)) if m else -1)
+        self.n_stages = max(ids) + 1 if ids and max(ids) >= 0 else 0
+        ids = [i if i >= 0 else self.n_stages for i in ids]
+        assert all(a <= b for a, b in zip(ids, ids[1:])), 'parameters are not ordered stage by stage: buckets would not be contiguous'
+        ends = flat.offsets[1:] + [flat.numel]
+        self.ranges = []
+        for k in range(self.n_stages + 1):
+            idx = [j for j, b in enumerate(ids) if b == k]
+            self.ranges.append((flat.offsets[idx[0]], ends[idx[-1]]) if idx else None)
+        self.head = self.n_stages
+        self.wire_bf16 = os.environ.get('LEOD_DP_WIRE', 'f32').lower() in ('bf16', 'bfloat16')
+        self.comm = torch.cuda.Stream(device=flat.grad.device) if flat.grad.is_cuda else None
+        self.works, self.done, self.order = [], set(), []
+
+    def begin_step(self):
+        self.works, self.done, self.order = [], set(), []
+        GradBuckets.current = self
+
+    def ready(self, k: int):
+        """Bucket k is final on the launch stream and on the weight-gradient side stream(s): all-reduce it on the comm stream."""
+        if k in self.done or self.ranges[k] is None:
+            self.done.add(k)
+            return
+        self.done.add(k)
+        self.order.append(k)
+        lo, hi = self.ranges[k]
+        g = self.flat.grad[lo:hi]
+        if self.comm is None:                                  # CPU tensors (gloo tests)
+            self.works.append((dist.all_reduce(g, group=self.dp.group, async_op=True), None, None))
+            return
+        main = torch.cuda.current_stream()
+        self.comm.wait_stream(main)
+        for key in Fn.WgradSide.used:                          # this stage's weight gradients were enqueued there
+            self.comm.wait_stream(Fn.WgradSide.streams[key])
+        with torch.cuda.stream(self.comm):
+            if self.wire_bf16:
+                wire = g.to(torch.bfloat16)
+                self.works.append((dist.all_reduce(wire, group=self.dp.group, async_op=True), wire, g))
+            else:
+                self.works.append((dist.all_reduce(g, group=self.dp.group, async_op=True), None, None))
+
+    def finish(self):
+        """Release what no boundary released (stage 1), then make the launch stream wait for every exchange."""
+        for k in reversed(range(len(self.ranges))):
+            self.ready(k)
+        for work, wire, g in self.works:
+            if self.comm is not None:
+                with torch.cuda.stream(self.comm):
+                    work.wait()
+                    if wire is not None:
+                        g.copy_(wire)
+            else:
+                work.wait()
+        if self.comm is not None:
+            torch.cuda.current_stream().wait_stream(self.comm)
+        self.works = []
+        GradBuckets.current = None
 
 
 def init_distributed(backend: Optional[str] = None):

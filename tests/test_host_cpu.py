@@ -159,6 +159,101 @@ def test_data_parallel_gloo_world2():
         assert r[4] == [3.0, 4.0] and r[5] and r[6]
 
 
+class _ToyStage(torch.nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.lin = torch.nn.Linear(d, d)
+
+    def forward(self, x):
+        return torch.tanh(self.lin(x))
+
+
+class _ToyDetector(torch.nn.Module):
+    """Four 'backbone.stages.i' + a head, wired like RNNDetector.forward_sequence / YoloXDetector.forward_detect wire the bucket
+    boundaries (maxvit_rnn.py, detector.py): one boundary in front of every stage but the first, one on the features entering the head."""
+
+    def __init__(self):
+        super().__init__()
+        self.backbone = torch.nn.Module()
+        self.backbone.stages = torch.nn.ModuleList([_ToyStage(6) for _ in range(4)])
+        self.head = torch.nn.Linear(18, 1)
+
+    def forward(self, x):
+        from leod_amd.functions import bucket_boundary
+        feats = []
+        for i, st in enumerate(self.backbone.stages):
+            if i > 0:
+                x = bucket_boundary(i, x)
+            x = st(x)
+            feats.append(x)
+        f2, f3, f4 = bucket_boundary(-1, *feats[1:])
+        return self.head(torch.cat([f2, f3, f4], -1)).sum()
+
+
+def _bucket_worker(rank, world, port, q, bucketed, wire):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      LEOD_DP_BUCKETS='1' if bucketed else '0', LEOD_DP_WIRE=wire)
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from leod_amd.parallel import init_distributed, FlatParams, DataParallel, GradBuckets
+    init_distributed('gloo')
+    torch.manual_seed(0)
+    m = _ToyDetector()
+    flat = FlatParams(m)
+    dp = DataParallel(flat, sync_bn=False)
+    buckets = dp.make_buckets(m)
+    assert (buckets is not None) == bucketed
+    flat.zero_grad()
+    dp.begin_step()
+    x = torch.randn(5, 6, generator=torch.Generator().manual_seed(10 + rank))
+    loss = m(x)
+    # autograd would REPLACE p.grad views by new tensors: accumulate into the flat buffer like the wgrad kernels do
+    grads = torch.autograd.grad(loss, flat.params)
+    order_at_backward_end = list(buckets.order) if bucketed else []
+    # (a real step's kernels write the flat buffer BEFORE the boundary fires; here the buckets released during autograd.grad were
+    # still zero: complete that exchange, fill the buffer, then release everything again for the value check)
+    if bucketed:
+        dp.all_reduce_gradients()
+        assert GradBuckets.current is None and float(flat.grad.abs().max()) == 0.0
+    for p, g in zip(flat.params, grads):
+        p.grad.add_(g)
+    if bucketed:
+        buckets.begin_step()
+    scale = dp.all_reduce_gradients()
+    q.put((rank, flat.grad.clone().numpy(), scale, order_at_backward_end, [r for r in buckets.ranges] if bucketed else None,
+           flat.numel))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('wire', ['f32', 'bf16'])
+def test_gradient_buckets_equal_flat_allreduce_gloo_world2(wire):
+    """leod_amd.parallel.GradBuckets: five contiguous per-stage buckets, released head -> stage 4 -> 3 -> 2 by the boundary nodes of
+    the backward pass (stage 1 by finish()), summed over two gloo ranks == ONE flat all-reduce (1e-6; bf16 wire: 2^-8 relative)."""
+    ctx = mp.get_context('spawn')
+    res = {}
+    for bucketed in (True, False):
+        q = ctx.Queue()
+        port = 29500 + ((os.getpid() + 7 + bucketed) % 2000)
+        procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q, bucketed, wire if bucketed else 'f32')) for r in range(2)]
+        for p in procs:
+            p.start()
+        res[bucketed] = sorted((q.get(timeout=120) for _ in range(2)), key=lambda r: r[0])
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+    b, f = res[True], res[False]
+    assert b[0][3] == [4, 3, 2, 1] == b[1][3], 'release order during the backward pass: head, then stages 4, 3, 2'
+    ranges = b[0][4]
+    assert len(ranges) == 5 and ranges[0][0] == 0 and ranges[-1][1] == b[0][5]
+    assert all(ranges[k][1] == ranges[k + 1][0] for k in range(4)), 'buckets tile the flat buffer'
+    tol = 2.0 ** -7 if wire == 'bf16' else 1e-6
+    for r in range(2):
+        np.testing.assert_allclose(b[r][1], f[r][1], rtol=tol, atol=tol * 1e-2)
+        assert b[r][2] == f[r][2] == 0.5
+    np.testing.assert_array_equal(b[0][1], b[1][1])                 # replicas hold the same reduced gradient
+
+
 # ---- native tracking post-filter (host C++ behind leod_track_filter; no GPU) ---------------------------------------------
 def _tracker_cases(golden_dir):
     g = np.load(os.path.join(golden_dir, 'g13_tracker.npz'))

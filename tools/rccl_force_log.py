@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """The N > 1 code path on a single-GPU box: LEOD_FORCE_COLLECTIVES=1 makes a one-rank job create the RCCL communicator and issue
-every collective of a data-parallel training step (parameter broadcast, the SyncBatchNorm statistic exchanges, the flat gradient
-all-reduce) through torch.distributed's 'nccl' backend (= RCCL on ROCm).  Each collective is bracketed with HIP events on the launch
+every collective of a data-parallel training step (parameter broadcast, the SyncBatchNorm statistic exchanges, the five per-stage
+gradient buckets released under the backward pass -- LEOD_DP_BUCKETS=0: one flat all-reduce after it) through torch.distributed's 'nccl' backend (= RCCL on ROCm).  Each collective is bracketed with HIP events on the launch
 stream; the table goes to stdout (kept under profiles/).  With one rank the collectives move no data between GPUs: what this run
 shows is that the RCCL calls are issued, ordered correctly against the HIP kernels (losses equal the plain run) and how many of
 them a step contains -- not xGMI timings.
@@ -70,9 +70,14 @@ for s in range(steps + 2):
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
 us = np.array([a.elapsed_time(b) * 1e3 for _, a, b in log]); size = np.array([n for n, _, _ in log])
 print(f'{steps} steps, {1e3 * dt:.2f} ms/step with every collective issued; losses: ' + ' '.join(f'{float(l):.4f}' for l in losses))
-print(f'collectives per step: {len(log) / steps:.1f} all-reduce ({Fn._SYNC_BN["n_collectives"] / steps:.1f} SyncBatchNorm + 1 gradient)')
-for name, m in (('SyncBatchNorm statistics (<= 16 KiB)', size <= 16384), ('flat gradient', size > 16384)):
+print(f'collectives per step: {len(log) / steps:.1f} all-reduce ({Fn._SYNC_BN["n_collectives"] / steps:.1f} SyncBatchNorm + {(len(log) / steps - Fn._SYNC_BN["n_collectives"] / steps):.0f} gradient)')
+bsizes = set(4 * (r[1] - r[0]) for r in opt.dp.buckets.ranges) if opt.dp.buckets is not None else {4 * opt.flat.numel}
+isg = np.array([n in bsizes for n in size])
+for name, m in (('SyncBatchNorm statistics', ~isg), ('gradient buckets (head+PAFPN, stage 4..1)' if opt.dp.buckets is not None else 'flat gradient', isg)):
     if m.any():
         print(f'  {name:38s} n/step {m.sum() / steps:5.1f}  bytes {size[m].min()}..{size[m].max()}  event-bracketed us: mean {us[m].mean():.1f} '
               f'min {us[m].min():.1f} max {us[m].max():.1f}  total/step {us[m].sum() / steps / 1e3:.3f} ms')
+b = opt.dp.buckets
+if b is not None:
+    print('bucket release order of the last step:', b.order, ' bytes per bucket:', [4 * (r[1] - r[0]) for r in b.ranges])
 dist.barrier(); dist.destroy_process_group()
