@@ -108,10 +108,11 @@ int leod_convlstm_seq_bwd(const float* dh_seq, const float* dc_last, const float
 /* dy_bf16 (here and in leod_linear_wgrad / leod_linear_dgrad_lnbwd): dy points to bf16 elements -- in precision mode bf16 the wide
  * gradients du (out_bf16 of leod_linear_dgrad_gelu16) and dqkv are stored as the bf16 their consumers feed to the MFMAs anyway.
  * dx (=|+=) (dy[M,N]*kscale[N]) W[N,K] ; optional: multiply by gelu'(aux_u[M,K]); route columns >= nsplit to dx2;
- * colsum[K] += column sums of the result.  Autograd of the Linear layers above. */
+ * colsum[K] += column sums of the result; dres [M,K] (optional, leading dimension lddx): dx = dres + result (the second gradient source of a
+ * residual branch, so that no separate add kernel runs).  Autograd of the Linear layers above. */
 int leod_linear_dgrad(const float* dy, long lddy, const float* kscale, const float* W, float* dx, long lddx, float* dx2,
-                      long lddx2, int nsplit, const float* aux_u, float* colsum, int accumulate, int M, int N, int K,
-                      int dy_bf16, leod_stream_t stream);
+                      long lddx2, int nsplit, const float* aux_u, float* colsum, int accumulate, const float* dres, int M, int N,
+                      int K, int dy_bf16, leod_stream_t stream);
 /* dW[N,K] += dy^T X ; dbias[N] += colsum(dy) ; X = x, LN(x) (stats, ln_w, ln_b) or [x | x2] (K1 = cols of x). */
 int leod_linear_wgrad(const float* dy, long lddy, const float* x, long ldx, const float* stats, const float* ln_w,
                       const float* ln_b, const float* x2, long ldx2, int K1, float* dW, float* dbias, int M, int N,
@@ -143,12 +144,14 @@ int leod_stem_conv_wgrad(const float* dy, const void* x, int x_is_u8, float* dw,
  * spread over stat_rep replicas (power of two, 0/1 = one copy; the caller zero-fills, leod_bn_silu_fwd folds them);
  * bn_w != NULL: eval BatchNorm folded + SiLU (network_blocks.py:29-54; yolo_pafpn.py:109-140; yolo_head.py:208-222).
  * wpack (optional scratch, N*Cin*ks*ks floats): the call first writes a K-contiguous copy of w there and contracts
- * against that (the native [N][Cin][ks][ks] layout strides every weight float4 over 36 bytes). */
+ * against that (the native [N][Cin][ks][ks] layout strides every weight float4 over 36 bytes).  wpack_valid != 0: wpack already
+ * holds the packed copy this very call (same weights, geometry, direction, precision mode) wrote earlier and w has not changed since --
+ * the pack launch is skipped (the weights change once per optimiser step, the PAFPN / head convs run 40 packs per step otherwise). */
 int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, double* colstats, int stat_rep, const float* bn_w,
                        const float* bn_b, const float* bn_rm, const float* bn_rv, float bn_eps, int B, int H, int W,
-                       int Cin, int N, int ks, int stride, int pad, float* wpack, leod_stream_t stream);
+                       int Cin, int N, int ks, int stride, int pad, float* wpack, int wpack_valid, leod_stream_t stream);
 int leod_conv_nhwc_dgrad(const float* dy, const float* w, float* dx, int accumulate, int B, int H, int W, int Cin, int N,
-                         int ks, int stride, int pad, float* wpack, leod_stream_t stream);
+                         int ks, int stride, int pad, float* wpack, int wpack_valid, leod_stream_t stream);
 /* dw[N,Cin,ks,ks] += weight gradient (dbias optional).  ws: scratch of leod_conv_nhwc_wgrad_workspace_floats(...) floats (may be
  * NULL when that is 0; with a workspace the 3x3 / stride-1 gradients of the bf16 mode are reduced without atomics). */
 long leod_conv_nhwc_wgrad_workspace_floats(int B, int H, int W, int Cin, int N, int ks, int stride, int pad, int has_bias);

@@ -6,7 +6,7 @@
 bool conv3s1_supported(int H, int W, int Cin, int Cout);
 size_t conv3s1_pack_bytes(int Cin, int Cout);
 int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, int stat_rep, int accumulate, int B, int H, int W,
-                   int Cin, int Cout, int transposed, void* wpack, hipStream_t stream, int stride = 1);
+                   int Cin, int Cout, int transposed, void* wpack, hipStream_t stream, int stride = 1, int packed = 0);
 bool conv3s2_fwd_supported(int B, int H, int W, int Cin, int Cout);      // forward of a stride-2 conv on the same kernel (stride = 2, H, W: input size)
 // weight gradient of a 3x3 / pad-1 conv of stride 1 or 2 (x [B,H,W,Cin], dy [B,H/stride,W/stride,Cout])
 bool conv3_wgrad_supported(int H, int W, int Cin, int Cout, int stride);
@@ -14,4 +14,4 @@ size_t conv3_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int 
 int conv3_wgrad_launch(const float* dy, const float* x, float* dW, float* ws, int B, int H, int W, int Cin, int Cout, int stride, hipStream_t stream);
 // input gradient of a 3x3 / stride-2 / pad-1 conv: dx [B,H,W,Cin] from dy [B,H/2,W/2,N], w [N][Cin][3][3]; wpack: conv3s1_pack_bytes(Cin, N)
 bool conv3s2_dgrad_supported(int H, int W, int Cin, int N);
-int conv3s2_dgrad_launch(const float* dy, const float* w, float* dx, int accumulate, int B, int H, int W, int Cin, int N, void* wpack, hipStream_t stream);
+int conv3s2_dgrad_launch(const float* dy, const float* w, float* dx, int accumulate, int B, int H, int W, int Cin, int N, void* wpack, hipStream_t stream, int packed = 0);

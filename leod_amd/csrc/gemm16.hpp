@@ -443,6 +443,7 @@ struct EpStore {
     float* colsum;                  // optional [N]: += column sums of the stored value (bias gradient)
     int act; int accumulate;
     int N;
+    const float* addsrc;            // optional [M][ld]: out = addsrc + value (second gradient source of a residual branch; not with nsplit / accumulate)
     int out_fmt;                    // row epilogue only (run_rows): 0 = fp32 out; 1 = out holds fp16 (clamped), 2 = bf16 -- the 16-bit tensors of
     int aux_fmt;                    // precision mode bf16 (MLP hidden pre-activation, qkv, du); aux_fmt 1: aux is an fp16 pre-activation
     int rm_Q, rm_H, rm_W;           // rm_Q > 0: GEMM rows are parity-class ordered (ALConvT2) -> remap to pixel rows of the [B,H,W] map
@@ -480,6 +481,7 @@ struct EpStore {
                         *p = accumulate ? *p + v : v;
                     } else {
                         float* p = out + row * ld + n;
+                        if (addsrc) v += addsrc[row * ld + n];
                         *p = accumulate ? *p + v : v;
                         if (act == ACT_GELU_DUAL) out2[row * ld2 + n] = gelu_erf(v);
                     }
@@ -544,6 +546,7 @@ struct EpStore {
                 *reinterpret_cast<f4*>(pp) = v;
             } else {
                 float* pp = out + row * ld + n;
+                if (addsrc) v += ld4(addsrc + row * ld + n);
                 if (accumulate) v += ld4(pp);
                 *reinterpret_cast<f4*>(pp) = v;
                 if (act == ACT_GELU_DUAL) {

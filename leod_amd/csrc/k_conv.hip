@@ -58,16 +58,16 @@ static inline void launch_conv_pack(const float* w, float* out, int N, int Cin, 
 //   bn_w != NULL     : eval mode, y = silu(bn(conv)) with running statistics folded in
 LEOD_API int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, double* colstats, int stat_rep,
                                 const float* bn_w, const float* bn_b, const float* bn_rm, const float* bn_rv, float bn_eps,
-                                int B, int H, int W, int Cin, int N, int ks, int stride, int pad, float* wpack,
+                                int B, int H, int W, int Cin, int N, int ks, int stride, int pad, float* wpack, int wpack_valid,
                                 hipStream_t stream) {
     if (!x || !w || !y || (Cin & 3) || (stat_rep > 1 && (stat_rep & (stat_rep - 1)))) return LEOD_ERR_ARG;
     const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
     const int M = B * Ho * Wo, K = ks * ks * Cin;
     // PAFPN / head 3x3 convs in precision mode bf16: direct convolution from an LDS-resident input halo (k_conv3.hip)
     if (ks == 3 && stride == 1 && pad == 1 && !bias && !bn_w && wpack && conv3s1_supported(H, W, Cin, N))
-        return conv3s1_launch(x, w, y, colstats, stat_rep, 0, B, H, W, Cin, N, 0, wpack, stream);
+        return conv3s1_launch(x, w, y, colstats, stat_rep, 0, B, H, W, Cin, N, 0, wpack, stream, 1, wpack_valid);
     if (ks == 3 && stride == 2 && pad == 1 && !bias && !bn_w && wpack && conv3s2_fwd_supported(B, H, W, Cin, N))
-        return conv3s1_launch(x, w, y, colstats, stat_rep, 0, B, H, W, Cin, N, 0, wpack, stream, 2);
+        return conv3s1_launch(x, w, y, colstats, stat_rep, 0, B, H, W, Cin, N, 0, wpack, stream, 2, wpack_valid);
     EpStore ep = conv_epilogue(y, N, bias, colstats, stat_rep, bn_w, bn_b, bn_rm, bn_rv, bn_eps);
     const int nt = pick_nt(N);
     int rc = LEOD_OK;
@@ -82,7 +82,7 @@ LEOD_API int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bia
         if (wpack && lds) {
             // scratch given: repack the weights K-contiguous first (N*Cin*ks*ks floats, a few microseconds), then the B
             // operand is a plain row-major matrix like a Linear weight
-            launch_conv_pack(w, wpack, N, Cin, ks * ks, 0, stream);
+            if (!wpack_valid) launch_conv_pack(w, wpack, N, Cin, ks * ks, 0, stream);
             DISPATCH_NT(nt, { BLRows bl{wpack, (long)K, N, NT}; rc = launch_gemm_lds<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
             return rc;
         }
@@ -287,14 +287,14 @@ LEOD_API int leod_stem_conv_fwd(const void* x, int x_is_u8, const float* w, floa
 
 // dx[B,H,W,Cin] (=|+=) conv_transpose(dy[B,Ho,Wo,N], w)
 LEOD_API int leod_conv_nhwc_dgrad(const float* dy, const float* w, float* dx, int accumulate, int B, int H, int W, int Cin,
-                                  int N, int ks, int stride, int pad, float* wpack, hipStream_t stream) {
+                                  int N, int ks, int stride, int pad, float* wpack, int wpack_valid, hipStream_t stream) {
     if (!dy || !w || !dx || (N & 3)) return LEOD_ERR_ARG;
     const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
     const int M = B * H * W, K = ks * ks * N;
     if (ks == 3 && stride == 1 && pad == 1 && wpack && conv3s1_supported(H, W, N, Cin))
-        return conv3s1_launch(dy, w, dx, nullptr, 0, accumulate, B, H, W, N, Cin, 1, wpack, stream);
+        return conv3s1_launch(dy, w, dx, nullptr, 0, accumulate, B, H, W, N, Cin, 1, wpack, stream, 1, wpack_valid);
     if (ks == 3 && stride == 2 && pad == 1 && wpack && conv3s2_dgrad_supported(H, W, Cin, N))
-        return conv3s2_dgrad_launch(dy, w, dx, accumulate, B, H, W, Cin, N, wpack, stream);
+        return conv3s2_dgrad_launch(dy, w, dx, accumulate, B, H, W, Cin, N, wpack, stream, wpack_valid);
     EpStore ep{}; ep.out = dx; ep.ld = Cin; ep.N = Cin; ep.accumulate = accumulate;
     const int nt = pick_nt(Cin);
     int rc = LEOD_OK;
@@ -305,7 +305,7 @@ LEOD_API int leod_conv_nhwc_dgrad(const float* dy, const float* w, float* dx, in
         ep.rm_Q = Q; ep.rm_H = H; ep.rm_W = W;
         const bool lds2 = use_gemm_lds(M, cdiv(Cin, 16 * nt)) && Q % 128 == 0;    // a (64|128)-row workgroup must not mix classes
         if (wpack && lds2) {
-            launch_conv_pack(w, wpack, N, Cin, 9, 1, stream);
+            if (!wpack_valid) launch_conv_pack(w, wpack, N, Cin, 9, 1, stream);
             DISPATCH_NT(nt, { BLPackT2 bl{wpack, N, Cin, NT}; rc = launch_gemm_lds<NT>(al, bl, ep, M, 4 * N, cdiv(Cin, 16 * NT), stream); });
             return rc;
         }
@@ -323,7 +323,7 @@ LEOD_API int leod_conv_nhwc_dgrad(const float* dy, const float* w, float* dx, in
     } else {
         ALConvT al{dy, H, W, Ho, Wo, N, ks, stride, pad};
         if (wpack && lds) {
-            launch_conv_pack(w, wpack, N, Cin, ks * ks, 1, stream);         // wd[c][tap*N + n]: B(col = c, k' = tap*N + n)
+            if (!wpack_valid) launch_conv_pack(w, wpack, N, Cin, ks * ks, 1, stream);         // wd[c][tap*N + n]: B(col = c, k' = tap*N + n)
             DISPATCH_NT(nt, { BLRows bl{wpack, (long)K, Cin, NT}; rc = launch_gemm_lds<NT>(al, bl, ep, M, K, cdiv(Cin, 16 * NT), stream); });
             return rc;
         }

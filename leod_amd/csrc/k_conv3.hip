@@ -673,12 +673,13 @@ size_t conv3s1_pack_bytes(int Cin, int Cout) { return (size_t)9 * Cin * Cout * s
 // x [B,H,W,Cin] -> y [B,H,W,Cout].  transposed = 0: y = conv3x3(x, w[Cout][Cin][3][3]); 1: the dgrad of a conv whose weight is
 // w[Cin][Cout][3][3] (x = dy).  wpack: scratch of conv3s1_pack_bytes.
 int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, int stat_rep, int accumulate, int B, int H, int W,
-                   int Cin, int Cout, int transposed, void* wpack, hipStream_t stream, int stride) {
+                   int Cin, int Cout, int transposed, void* wpack, hipStream_t stream, int stride, int packed) {
     bf16_t* wp = reinterpret_cast<bf16_t*>(wpack);
     const long total = (long)9 * Cin * Cout;
     // the packed layout is [tap][out rows][k]; for the dgrad the stored weight is [N = Cin of this call][C = Cout of this call]
-    hipLaunchKernelGGL(conv3_pack_kernel, dim3((int)min((long)1024, (total + 255) / 256)), dim3(256), 0, stream, w, wp,
-                       transposed ? Cin : Cout, transposed ? Cout : Cin, transposed ? 1 : 0);
+    if (!packed)
+        hipLaunchKernelGGL(conv3_pack_kernel, dim3((int)min((long)1024, (total + 255) / 256)), dim3(256), 0, stream, w, wp,
+                           transposed ? Cin : Cout, transposed ? Cout : Cin, transposed ? 1 : 0);
     const int nto = Cout == 48 ? 3 : 6;
     const int RH = conv3_rows_per_block(H, W, Cin, nto, stride);
     if (RH <= 0) return LEOD_ERR_UNSUPPORTED;
@@ -838,10 +839,10 @@ bool conv3s2_dgrad_supported(int H, int W, int Cin, int N) {
     return conv3s2_dgrad_rows(H / 2, W / 2, N) > 0;
 }
 // w [N][Cin][3][3]; wpack: conv3s1_pack_bytes(Cin, N) bytes of scratch
-int conv3s2_dgrad_launch(const float* dy, const float* w, float* dx, int accumulate, int B, int H, int W, int Cin, int N, void* wpack, hipStream_t stream) {
+int conv3s2_dgrad_launch(const float* dy, const float* w, float* dx, int accumulate, int B, int H, int W, int Cin, int N, void* wpack, hipStream_t stream, int packed) {
     bf16_t* wp = reinterpret_cast<bf16_t*>(wpack);
     const long total = (long)9 * Cin * N;
-    hipLaunchKernelGGL(conv3_pack_kernel, dim3((int)min((long)1024, (total + 255) / 256)), dim3(256), 0, stream, w, wp, N, Cin, 1);
+    if (!packed) hipLaunchKernelGGL(conv3_pack_kernel, dim3((int)min((long)1024, (total + 255) / 256)), dim3(256), 0, stream, w, wp, N, Cin, 1);
     const int Ho = H / 2, Wo = W / 2;
     const int RH = conv3s2_dgrad_rows(Ho, Wo, N);
     if (RH <= 0) return LEOD_ERR_UNSUPPORTED;

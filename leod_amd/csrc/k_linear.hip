@@ -593,16 +593,17 @@ LEOD_API int leod_convlstm_fwd(const float* x, const float* h_prev, const float*
 //   colsum != NULL: colsum[K] += column sums of the stored dx (bias gradient of the producer)
 LEOD_API int leod_linear_dgrad(const float* dy, long lddy, const float* kscale, const float* W, float* dx, long lddx,
                                float* dx2, long lddx2, int nsplit, const float* aux_u, float* colsum,
-                               int accumulate, int M, int N, int K, int dy_bf16, hipStream_t stream) {
+                               int accumulate, const float* dres, int M, int N, int K, int dy_bf16, hipStream_t stream) {
     if (!dy || !W || !dx || (N & 3) || (lddy & 3)) return LEOD_ERR_ARG;
     ALRows al{}; al.x = dy; al.ld = lddy; al.kscale = kscale; al.K = N; al.fmt = dy_bf16 ? 2 : 0;
     EpStore ep = ep_store(dx, lddx, K);
-    ep.out2 = dx2; ep.ld2 = lddx2; ep.nsplit = nsplit; ep.accumulate = accumulate; ep.colsum = colsum;
+    ep.out2 = dx2; ep.ld2 = lddx2; ep.nsplit = nsplit; ep.accumulate = accumulate; ep.colsum = colsum; ep.addsrc = dres;
+    if (dres && (nsplit > 0 || accumulate)) return LEOD_ERR_ARG;
     if (aux_u) { ep.act = ACT_MUL_GELU_GRAD; ep.aux = aux_u; ep.ldaux = K; }
     const int nt = pick_nt(K);
     int rc = LEOD_OK;
     // contraction over N in {48, 96}, K in {192, 384} output columns (dgrad of fc2, optionally through GELU): streaming kernel
-    if (!dy_bf16 && !dx2 && !colsum && !accumulate && lddy == N && lddx == K && nsplit <= 0) {
+    if (!dy_bf16 && !dx2 && !colsum && !accumulate && !dres && lddy == N && lddx == K && nsplit <= 0) {
         if (!kscale && !aux_u && use_rowstream_narrow(M, N, K))
             return launch_rowstream_narrow<1>(dy, W, nullptr, nullptr, nullptr, dx, M, N, stream);
         if (const int slab = rowstream_slab(M, K, N)) {

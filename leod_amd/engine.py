@@ -67,13 +67,9 @@ class TrainEngine:
         # recurrence is unrolled over t.  Same arithmetic as the per-timestep loop of modules/detection.py:188-226 (no
         # layer in front of the LSTM mixes samples), ~6x fewer and ~21x larger kernel launches.
         T, B = ev_seq.shape[:2]
-        feats_all, states = self.det.backbone.forward_sequence(ev_seq, states)
         rows = tuple(t * B + b for t in range(T) for b in label_tb[t])
         idx = self._index(rows, ev_seq.device)
-        feats = {}
-        for k in self.det.fpn.in_features:
-            v = feats_all[k].permute(0, 2, 3, 1)                 # NHWC view of the channels-last map, [T*B,h,w,C]
-            feats[k] = v.index_select(0, idx).permute(0, 3, 1, 2)
+        _, states, feats = self.det.backbone.forward_sequence(ev_seq, states, select_rows=idx, select_stages=tuple(self.det.fpn.in_features))
         preds, losses = self.det.forward_detect(feats, targets=labels)
         return preds, losses, [(h.detach(), c.detach()) for h, c in states]
 
@@ -149,6 +145,7 @@ class TrainEngine:
         self._capturing = False
         # undo the side effects of the warm-up + capture passes (capture itself does not execute)
         self.flat.data.copy_(saved[0]); self.flat.exp_avg.copy_(saved[1]); self.flat.exp_avg_sq.copy_(saved[2])
+        self.flat.touch()
         for (gh, gc), (h, c) in zip(self._g_states, saved[3]):
             gh.copy_(h); gc.copy_(c)
         bns = [m.bn for m in self.det.modules() if hasattr(m, 'bn')]
@@ -174,6 +171,7 @@ class TrainEngine:
             self._g_first.copy_(is_first, non_blocking=True)
         ops.set_scalars4(self._g_hp, *self.flat.step_scalars(self.current_lr(), 1.0 / self.dp.world_size))
         self._graph.replay()
+        ops.PackCache.invalidate()                          # the replayed AdamW kernel rewrote the parameters
         self.global_step += 1
         self.states = self._g_states
         self.last_losses = dict(zip(('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg'), self._g_losses))

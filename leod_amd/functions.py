@@ -105,6 +105,39 @@ def bucket_boundary(k: int, *xs):
     return out if len(xs) > 1 else out[0]
 
 
+class ForkSelectFn(Function):
+    """A stage's output map x [N,H,W,C] (all T*B frames) has two consumers in the training step: the next stage (all frames) and the
+    PAFPN (the labelled frames ``idx`` only, modules/detection.py:209-224).  As two autograd edges the backward pass costs a zero
+    fill of an [N,H,W,C] tensor, an index_add into it and a full-size add of the two gradients; as ONE node the labelled frames'
+    gradient is added in place into the gradient that arrives from the next stage (a fresh tensor private to this backward pass)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(idx)
+        ctx.shape = tuple(x.shape)
+        return x.view_as(x), x.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g_pass, g_sel):
+        (idx,) = ctx.saved_tensors
+        if g_pass is None:
+            if g_sel is None:
+                return None, None
+            dx = torch.zeros(ctx.shape, dtype=g_sel.dtype, device=g_sel.device)
+        else:
+            dx = _cont(g_pass)
+        if g_sel is not None:
+            dx.index_add_(0, idx, _cont(g_sel))
+        return dx, None
+
+
+def fork_select(x_nchw: torch.Tensor, idx: torch.Tensor):
+    """x [N,C,H,W] (channels-last memory) -> (x for the next consumer, x[idx]), both logical NCHW views of NHWC memory."""
+    xp, xs = ForkSelectFn.apply(to_nhwc(x_nchw), idx)
+    return as_nchw(xp), as_nchw(xs)
+
+
 def set_sync_batchnorm(process_group, world_size: int):
     """Enable SyncBatchNorm semantics (reference: train.py:247 sync_batchnorm=True when >1 GPU): the
     per-channel (sum, sumsq) and backward (sum du, sum du*xhat) vectors are all-reduced over RCCL."""
@@ -264,10 +297,9 @@ class AttnBlockFn(Function):
         if n1w is not None:
             dx = ops.linear_dgrad_ln_bwd(dqkv, qkv_w, x, st1, n1w, dy, grad_buf(mod.norm1.weight), grad_buf(mod.norm1.bias))
         else:
-            if WgradSide.active:                                            # dy is still being read on the side stream
-                dx = dy + ops.linear_dgrad(dqkv, qkv_w)
-            else:
-                dx = ops.linear_dgrad(dqkv, qkv_w, out=dy, accumulate=True) # dy is private to this backward
+            # dy (the residual branch's gradient) is still being read on the weight-gradient side stream: it is the dgrad's second
+            # source, the sum goes to a new tensor in the same launch (no separate add kernel)
+            dx = ops.linear_dgrad(dqkv, qkv_w, dres=dy)
         return (None, dx) + (None,) * 14
 
 

@@ -116,22 +116,28 @@ class RNNDetector(BaseDetector):
             output[i + 1] = x
         return output, states
 
-    def forward_sequence(self, x_seq: th.Tensor, prev_states=None):
+    def forward_sequence(self, x_seq: th.Tensor, prev_states=None, select_rows: Optional[th.Tensor] = None, select_stages=()):
         """x_seq [T,B,C,H,W]: stage-major, time-batched evaluation of a whole sequence (see
         ``RNNDetectorStage.forward_sequence``).  Returns {stage: features of all timesteps [T*B,C,h,w]} and the final
-        states -- the per-timestep loop of modules/detection.py:188-226 with the loops interchanged."""
+        states -- the per-timestep loop of modules/detection.py:188-226 with the loops interchanged.
+        ``select_rows`` (frame indices t*B + b of the labelled frames) + ``select_stages``: additionally returns {stage: features of
+        those frames} (what ``BackboneFeatureSelector`` gathers, modules/utils/detection.py:27-58), selected inside the stage loop so
+        that the two consumers of a stage output share one autograd node (``functions.ForkSelectFn``)."""
         T, B = x_seq.shape[:2]
         if prev_states is None:
             prev_states = [None] * self.num_stages
         padded_hw = self.in_res_hw if (self.in_res_hw is not None and tuple(x_seq.shape[-2:]) != self.in_res_hw) else None
         x = x_seq.reshape((T * B,) + tuple(x_seq.shape[2:]))
         states, output = [], {}
-        from leod_amd.functions import bucket_boundary
+        from leod_amd.functions import bucket_boundary, fork_select
+        selected = {}
         for i, stage in enumerate(self.stages):
             if i > 0:
                 # data-parallel training: when the backward pass arrives here, stage i is done -> its gradient bucket is exchanged
                 x = bucket_boundary(i, x)
             x, state = stage.forward_sequence(x, T, prev_states[i], padded_hw if i == 0 else None)
             states.append(state)
+            if select_rows is not None and (i + 1) in select_stages:
+                x, selected[i + 1] = fork_select(x, select_rows)
             output[i + 1] = x
-        return output, states
+        return (output, states) if select_rows is None else (output, states, selected)

@@ -174,11 +174,12 @@ class Module(_Base):
         in_features = self.mdl.fpn.in_features
         if self.time_batched:
             ev = self._stack_frames(ev_seq)
-            feats_all, states = self.mdl.backbone.forward_sequence(ev, prev_states)
             feats = None
             if where:
                 rows = self._row_index(tuple(t * B + b for t, b in where), ev.device)
-                feats = {k: feats_all[k].permute(0, 2, 3, 1).index_select(0, rows).permute(0, 3, 1, 2) for k in in_features}
+                _, states, feats = self.mdl.backbone.forward_sequence(ev, prev_states, select_rows=rows, select_stages=tuple(in_features))
+            else:
+                _, states = self.mdl.backbone.forward_sequence(ev, prev_states)
         else:
             selector = BackboneFeatureSelector()
             states = prev_states

@@ -254,17 +254,17 @@ def convlstm_seq_bwd(dh_seq, dc_last, gates, cbuf, W, dgates_out, dh0=None, dc0=
     return True
 
 
-def linear_dgrad(dy, W, kscale=None, aux_u=None, colsum=None, out=None, accumulate=False, split=0, out2=None):
-    """dx = (dy * kscale) @ W  with W [N,K]; see leod_linear_dgrad."""
+def linear_dgrad(dy, W, kscale=None, aux_u=None, colsum=None, out=None, accumulate=False, split=0, out2=None, dres=None):
+    """dx = (dy * kscale) @ W  with W [N,K] (+ dres: the other gradient source of a residual branch); see leod_linear_dgrad."""
     dy16 = dy.dtype is torch.bfloat16                         # bf16 gradient rows (du / dqkv of precision mode bf16)
     _ck(dy, torch.bfloat16 if dy16 else F32, 'dy')
-    for t, n in ((W, 'W'), (kscale, 'kscale'), (colsum, 'colsum'), (out, 'out'), (out2, 'out2')):
+    for t, n in ((W, 'W'), (kscale, 'kscale'), (colsum, 'colsum'), (out, 'out'), (out2, 'out2'), (dres, 'dres')):
         _ck(t, name=n)
     N, K = W.shape[0], W.shape[1] if W.dim() == 2 else W.numel() // W.shape[0]
     M = dy.numel() // N
     if aux_u is not None and aux_u.dtype is torch.float16:    # through GELU on the fp16 pre-activation (stages 1-2, bf16 mode)
         _ck(aux_u, torch.float16, 'aux_u')
-        if split or colsum is not None or accumulate or out is not None:
+        if split or colsum is not None or accumulate or out is not None or dres is not None:
             raise LeodHipError('linear_dgrad: unsupported option with an fp16 pre-activation')
         if dy16:
             raise LeodHipError('linear_dgrad: bf16 dy does not combine with an fp16 pre-activation')
@@ -285,7 +285,7 @@ def linear_dgrad(dy, W, kscale=None, aux_u=None, colsum=None, out=None, accumula
             out = torch.empty(dy.shape[:-1] + (K,), dtype=F32, device=dy.device)
         ld1, ld2 = K, 0
     check(_l().leod_linear_dgrad(_p(dy), N, _p(kscale), _p(W), _p(out), ld1, _p(out2), ld2, split, _p(aux_u),
-                                  _p(colsum), 1 if accumulate else 0, M, N, K, 1 if dy16 else 0, _stream()), 'linear_dgrad')
+                                  _p(colsum), 1 if accumulate else 0, _p(dres), M, N, K, 1 if dy16 else 0, _stream()), 'linear_dgrad')
     return (out, out2) if split else out
 
 
@@ -373,7 +373,7 @@ def layerscale_linear_wgrad(dz, h, W, b, gamma, dW, db, dgamma):
     into a scratch buffer (one wgrad launch), ``leod_layerscale_finalize`` turns it into dW, db and dgamma -- the stored
     pre-scale tensor of the forward pass and the scaled copy of dz are not needed."""
     N, K = W.shape
-    scratch = torch.zeros(N * K + N, dtype=torch.float32, device=dz.device)
+    scratch = StatArena.zeros((N * K + N,), dz.device, torch.float32)         # one memset per step instead of 16 fill kernels
     G, s = scratch[:N * K].view(N, K), scratch[N * K:]
     linear_wgrad(dz, h, G, s)
     check(_l().leod_layerscale_finalize(_p(W), _p(b), _p(gamma), _p(G), _p(s), _p(dW), _p(db), _p(dgamma), N, K, _stream()),
@@ -425,6 +425,36 @@ def stat_replicas(rows: int) -> int:
     return r
 
 
+class PackCache:
+    """Packed copies of the conv weights (K-contiguous / per-tap bf16, written by the conv calls themselves into ``wpack``), kept for
+    as long as the weights they were made from are unchanged: the 20 3x3 convs of PAFPN + head each re-packed their weights on every
+    forward AND dgrad call (40 pack launches per training step) although weights change once per optimiser step.
+
+    An entry is valid for (weight storage, direction, geometry) while the parameter's torch version counter, the library's precision
+    mode and ``epoch`` are unchanged.  ``epoch`` is advanced by whatever rewrites parameters behind torch's back -- the fused AdamW
+    kernel (``FlatParams.adamw_step``) -- and must be advanced (``PackCache.invalidate()``) by any other code that edits parameter
+    memory through another alias (e.g. in-place ops on ``FlatParams.data``; ``FlatParams`` wraps that in ``FlatParams.touch()``)."""
+    epoch = 0
+    entries = {}
+
+    @classmethod
+    def get(cls, w, key, nfloats):
+        k = (w.data_ptr(),) + key
+        ver = (w._version, cls.epoch, w.numel(), get_precision())
+        e = cls.entries.get(k)
+        if e is not None and e[1] == ver and e[0].numel() >= nfloats:
+            return e[0], 1
+        buf = e[0] if (e is not None and e[0].numel() >= nfloats and e[0].device == w.device) else torch.empty(nfloats, dtype=F32, device=w.device)
+        if len(cls.entries) > 4096:
+            cls.entries.clear()
+        cls.entries[k] = (buf, ver)
+        return buf, 0
+
+    @classmethod
+    def invalidate(cls):
+        cls.epoch += 1
+
+
 def conv_nhwc_fwd(x, w, bias=None, stride=1, colstats=None, bn=None, bn_eps=1e-5):
     """x [B,H,W,Cin] -> y [B,Ho,Wo,N]; pad = (ks-1)//2.  bn = (weight, bias, running_mean, running_var) -> eval BN+SiLU fused.
     colstats: zero-filled float64 [2,N] or [R,2,N] (R a power of two: the epilogue's atomics are spread over the R copies)."""
@@ -442,10 +472,10 @@ def conv_nhwc_fwd(x, w, bias=None, stride=1, colstats=None, bn=None, bn_eps=1e-5
         bw, bb, brm, brv = bn
         for t in bn:
             _ck(t, name='bn')
-    wpack = _empty((N * Cin * ks * ks,), x) if ks > 1 else None     # scratch for the K-contiguous weight copy
+    wpack, valid = PackCache.get(w, ('fwd', B, H, W, stride, bn is not None, bias is not None), N * Cin * ks * ks) if ks > 1 else (None, 0)
     rep = colstats.shape[0] if colstats is not None and colstats.dim() == 3 else 1
     check(_l().leod_conv_nhwc_fwd(_p(x), _p(w), _p(bias), _p(y), _p(colstats), rep, _p(bw), _p(bb), _p(brm), _p(brv), bn_eps,
-                                   B, H, W, Cin, N, ks, stride, pad, _p(wpack), _stream()), 'conv_nhwc_fwd')
+                                   B, H, W, Cin, N, ks, stride, pad, _p(wpack), valid, _stream()), 'conv_nhwc_fwd')
     return y
 
 
@@ -459,9 +489,9 @@ def conv_nhwc_dgrad(dy, w, x_shape, stride=1, out=None, accumulate=False):
         out = _empty(tuple(x_shape), dy)
         accumulate = False
     _ck(out, name='dx')
-    wpack = _empty((N * Cin * ks * ks,), dy) if ks > 1 else None
+    wpack, valid = PackCache.get(w, ('dgrad', B, H, W, stride), N * Cin * ks * ks) if ks > 1 else (None, 0)
     check(_l().leod_conv_nhwc_dgrad(_p(dy), _p(w), _p(out), 1 if accumulate else 0, B, H, W, Cin, N, ks, stride, pad,
-                                     _p(wpack), _stream()), 'conv_nhwc_dgrad')
+                                     _p(wpack), valid, _stream()), 'conv_nhwc_dgrad')
     return out
 
 
@@ -492,38 +522,41 @@ def bn_silu_fwd(z, colstats, w, b, run_mean, run_var, count, eps=1e-5, momentum=
 
 
 class StatArena:
-    """Zero-initialised float64 scratch for the BatchNorm statistic accumulators of ONE training step ((sum, sumsq) per
-    conv in the forward pass, (sum du, sum du*xhat) in the backward pass: 78 tiny buffers per step).  The engine zeroes
-    the whole arena with one memset at the start of a step and the ops take slices; outside an engine step (or when the
-    arena is exhausted) the ops fall back to ``torch.zeros``."""
-    buf: Optional[torch.Tensor] = None
+    """Zero-initialised scratch of ONE training step: the BatchNorm statistic accumulators ((sum, sumsq) per conv in the forward pass,
+    (sum du, sum du*xhat) in the backward pass: 78 tiny float64 buffers per step) and the fp32 un-scaled weight-gradient scratch of
+    the 16 LayerScale layers (``layerscale_linear_wgrad``).  The engine zeroes the used part of the arena with ONE memset at the start
+    of a step and the ops take slices; outside an engine step (or when the arena is exhausted) the ops fall back to ``torch.zeros``."""
+    buf: Optional[torch.Tensor] = None                # uint8
     off = 0
+    high = 0                                          # bytes handed out since the arena was last zeroed in full
     active = False
-    SIZE = 1 << 19                                    # doubles (4 MiB: 39 BatchNorm layers x STAT_REPLICAS x (sum, sumsq))
+    SIZE = 48 << 20                                   # bytes
 
     @classmethod
     def begin_step(cls, device):
         if cls.buf is None or cls.buf.device != torch.device(device):
-            cls.buf = torch.zeros(cls.SIZE, dtype=torch.float64, device=device)
-        else:
-            cls.buf.zero_()
-        cls.off, cls.active = 0, True
+            cls.buf = torch.zeros(cls.SIZE, dtype=torch.uint8, device=device)
+        elif cls.high:
+            cls.buf[:cls.high].zero_()                # everything beyond the high-water mark was never handed out: still zero
+        cls.off, cls.high, cls.active = 0, 0, True
 
     @classmethod
     def end_step(cls):
         cls.active = False
 
     @classmethod
-    def zeros(cls, shape, device):
+    def zeros(cls, shape, device, dtype=torch.float64):
         n = 1
         for d in shape:
             n *= d
-        n_al = (n + 1) & ~1                           # keep 16-byte alignment
+        nbytes = n * (8 if dtype is torch.float64 else 4)
+        n_al = (nbytes + 15) & ~15                    # keep 16-byte alignment
         if cls.active and cls.buf is not None and cls.buf.device == torch.device(device) and cls.off + n_al <= cls.SIZE:
-            t = cls.buf[cls.off:cls.off + n].view(shape)
+            t = cls.buf[cls.off:cls.off + nbytes].view(dtype).view(shape)
             cls.off += n_al
+            cls.high = max(cls.high, cls.off)
             return t
-        return torch.zeros(shape, dtype=torch.float64, device=device)
+        return torch.zeros(shape, dtype=dtype, device=device)
 
 
 def bn_silu_bwd_reduce(dy, z, mean, rstd, w, b, out=None):
@@ -591,7 +624,7 @@ def simota_assign(outputs, labels, hws, strides, ignore_label=1024.0):
              matched_valid_idx=torch.empty((B, A), dtype=torch.int32, device=dev),
              pred_iou=torch.empty((B, A), dtype=F32, device=dev),
              num_fg_img=torch.empty((B,), dtype=torch.int32, device=dev),
-             totals=torch.zeros((3,), dtype=torch.int32, device=dev))
+             totals=StatArena.zeros((3,), dev, torch.int32))
     check(_l().leod_simota_assign(_p(outputs), _p(labels), _p(ws), _p(r['fg_mask']), _p(r['ignore_mask']),
                                    _p(r['matched_row']), _p(r['matched_valid_idx']), _p(r['pred_iou']), _p(r['num_fg_img']),
                                    _p(r['totals']), B, Nmax, nch - 5, len(hws), _iarr([h for h, _ in hws]),
@@ -604,7 +637,7 @@ def yolox_loss(outputs, labels, assign, hws, strides, want_grad=True, focal=Fals
                cls_weight=1.0, grad_scale=1.0):
     B, A, nch = outputs.shape
     dev = outputs.device
-    sums = torch.zeros((3,), dtype=torch.float64, device=dev)
+    sums = StatArena.zeros((3,), dev, torch.float64)
     losses = torch.empty((6,), dtype=F32, device=dev)
     d_raw = torch.empty_like(outputs) if want_grad else None
     check(_l().leod_yolox_loss(_p(outputs), _p(labels), _p(assign['fg_mask']), _p(assign['ignore_mask']),

@@ -58,6 +58,12 @@ class FlatParams:
             self.step_count += 1
         ops.adamw_clip_step(self.data, self.grad, self.exp_avg, self.exp_avg_sq, lr, max(self.step_count, 1), betas=betas,
                             eps=eps, weight_decay=weight_decay, clip_value=clip_value, grad_scale=grad_scale, hp_dev=hp_dev)
+        ops.PackCache.invalidate()                     # the kernel rewrote every parameter: packed weight copies are stale
+
+    def touch(self):
+        """Call after editing ``self.data`` (or any parameter through another alias than the parameter itself) outside the optimiser:
+        cached derived copies of the weights (``ops.PackCache``) are dropped."""
+        ops.PackCache.invalidate()
 
     def step_scalars(self, lr, grad_scale=1.0, betas=(0.9, 0.999)):
         """Advance the step counter and return [lr, 1-b1^t, sqrt(1-b2^t), grad_scale] for the graph-replayed optimiser."""

@@ -274,6 +274,7 @@ def test_full_size_training_step_bf16_vs_f32():
                 g = torch.Generator(device='cuda').manual_seed(1)
                 with torch.no_grad():
                     opt.flat.data.mul_(1 + 2.0 ** -9 * (2 * torch.rand(opt.flat.data.shape, generator=g, device='cuda') - 1))
+                    opt.flat.touch()                            # edited through the flat alias: drop cached packed weights
             ops.set_precision('bf16' if mode == 'bf16' else 'f32')
             opt.clip_value = 0.0                                # compare the raw gradients (value clipping saturates many entries at +-1)
             out = fit_step(mod, opt, lrs, te._loader_batch(ev, labels.cpu().numpy(), label_tb, first.clone()))
