@@ -27,9 +27,10 @@ import torch  # noqa: E402
 PEAK_HBM_GBS = 8000.0           # MI355X HBM3E peak (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFLOPS = 157.3    # dense fp32 MFMA peak: 256 FLOP/clk/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF figure includes 2:1 sparsity)
-# SURVEY 8d / DESIGN.md: algorithmic HBM traffic of one RVT-S training event-frame at fp32 activations
-# = 2 x the bf16 figure for activations (2 x (68.61 + 32/168*29.01)) + 395/168 MB optimiser traffic
-ALGO_MB_PER_FRAME_FP32 = 2 * (68.61 + 32.0 / 168.0 * 29.01) + 395.0 / 168.0
+# SURVEY 8d / DESIGN.md: algorithmic HBM traffic of one RVT-S training event-frame: 16-bit activations (68.61 MB backbone + 32/168 of the
+# 29.01 MB of PAFPN + head per labelled frame) + 395/168 MB of optimiser traffic = 76.5 MB; with fp32 activations twice the activation part
+ALGO_MB_PER_FRAME = {'bf16': 68.61 + 32.0 / 168.0 * 29.01 + 395.0 / 168.0,
+                     'f32': 2 * (68.61 + 32.0 / 168.0 * 29.01) + 395.0 / 168.0}
 
 
 def make_batch(T, B, hw, num_classes, seed, device, label_ts):
@@ -125,8 +126,8 @@ def cpu_baseline_bounded(timeout_s=300):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--seq-len', type=int, default=21)
     ap.add_argument('--size', default='small')
@@ -231,7 +232,7 @@ def main():
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dt = float(t_max)
         # roofline of the dominant kernel: two extra steps with HIP events around each of its launches
-        roofline = None
+        roofline = roofline_gemm = family_ms = None
         if not args.no_roofline:
             # EVERY rank runs the two probe steps (a step contains collectives: a rank-0-only step would dead-lock N > 1);
             # only rank 0 brackets the kernel with events and reports
@@ -242,7 +243,11 @@ def main():
                 run(first_mask(1))
             module.wgrad_side = side
             if probe is not None:
-                roofline = probe.finish(PEAK_HBM_GBS, PEAK_BF16_MFMA_TFLOPS if dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS)
+                peak_t = PEAK_BF16_MFMA_TFLOPS if dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS
+                roofline = probe.finish(PEAK_HBM_GBS, peak_t, target='linear_wgrad')
+                roofline_gemm = probe.finish(PEAK_HBM_GBS, peak_t, target='linear_gemm')
+                # every C entry point bracketed with events during the same two single-stream steps: the line audits itself
+                family_ms = probe.family_ms(2)
             # HBM bytes per launch of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
             # separate rocprofv3 --pmc runs; bench.py itself cannot sample hardware counters)
             tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
@@ -255,7 +260,7 @@ def main():
 
         launch = (f'eager, schedule={"batched" if module.time_batched else "timestep"}, wgrad side stream {"on" if module.wgrad_side else "off"}, '
                   f'precision mode {ops.get_precision()}')
-        return dict(dt=dt, loss=loss_val, roofline=roofline, launch=launch)
+        return dict(dt=dt, loss=loss_val, roofline=roofline, roofline_gemm=roofline_gemm, family_ms=family_ms, launch=launch)
 
     main_run = measure(args.dtype, args.steps, args.warmup, not args.no_roofline)
     dt, loss_val, roofline, launch = main_run['dt'], main_run['loss'], main_run['roofline'], main_run['launch']
@@ -265,7 +270,8 @@ def main():
         od = 'f32' if args.dtype == 'bf16' else 'bf16'
         r2 = measure(od, args.steps, args.warmup, not args.no_roofline)
         other = {'dtype': od, 'value': round(B * T * args.steps / r2['dt'], 2), 'unit': 'event-frames/s (whole job)',
-                 'ms_per_step': round(1000 * r2['dt'] / args.steps, 3), 'final_loss': round(r2['loss'], 4), 'roofline': r2['roofline']}
+                 'ms_per_step': round(1000 * r2['dt'] / args.steps, 3), 'final_loss': round(r2['loss'], 4), 'roofline': r2['roofline'],
+                 'roofline_linear_gemm': r2['roofline_gemm']}
         del r2
     if rank == 0:
         frames = world * B * T * args.steps
@@ -286,9 +292,14 @@ def main():
                        'collective_backend': dist.get_backend() if dist.is_initialized() else None,
                        'collective_world_size': dist.get_world_size() if dist.is_initialized() else 1,
                        'per_gpu_event_frames_per_s': round(fps / world, 2), 'final_loss': round(loss_val, 4),
-                       'whole_step_hbm_frac_of_peak': round(ALGO_MB_PER_FRAME_FP32 * 1e6 * fps / world / (PEAK_HBM_GBS * 1e9), 5)
-                       if headline else None},
+                       # algorithmic bytes of the MEASURED precision mode: 76.5 MB per event-frame with 16-bit activations
+                       'whole_step_hbm_frac_of_peak': round(ALGO_MB_PER_FRAME[args.dtype] * 1e6 * fps / world / (PEAK_HBM_GBS * 1e9), 5)
+                       if headline else None,
+                       'algorithmic_MB_per_event_frame': round(ALGO_MB_PER_FRAME[args.dtype], 2) if headline else None,
+                       # GPU time per C entry point (= kernel family) and step, HIP events around every launch of two single-stream steps
+                       'family_ms_per_step': main_run['family_ms']},
             'roofline': roofline,
+            'roofline_linear_gemm': main_run['roofline_gemm'],
         }
         if other is not None:
             out['other_precision'] = other          # the same workload and step in the other precision mode, measured in this run

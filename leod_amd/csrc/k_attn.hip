@@ -714,6 +714,277 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds_kernel(const float*
     }
 }
 
+// =====================================================================================================================
+// bf16-tile variants (round 3, precision mode bf16 with bf16 qkv rows in HBM): q / k / v (and dO) are staged ONCE as bf16 -- the fp32
+// tiles above were re-packed to bf16 for every MFMA operand (2 v_cvt_pk per fragment, 4 ds_read_b32 + 2 v_cvt_pk per transposed
+// operand) and kept 15-19 % of the LDS cycles in bank conflicts.
+//   * rows of SD dwords with SD % 16 == 8 (72 for two heads of d = 24, no padding): the 16-byte head-dimension fragments of 16 rows
+//     (ds_read_b128, 8 bf16 = k 8rg .. 8rg+7 of ONE v_mfma_f32_16x16x32_bf16: d = 24 / 32 is a single MFMA instead of chunk + tail)
+//     fall on 16 distinct 4-bank slots of their service group, and the 8 rows x 32 bytes of a half-wave of ds_read_b64_tr_b16 (the
+//     operands that contract over TOKENS: V in P V, K in dS K, dO and Q in the key-owned pass) on 8 distinct 8-bank bins: both read
+//     patterns are conflict-free in the same un-swizzled layout;
+//   * d = 24: lanes rg = 3 of a head-dimension fragment hold k = 24 .. 31, i.e. the first 8 values of the NEXT part of the row --
+//     zeroed on ONE operand of every product (the wave's own q / dO / k / v fragment, loaded once), the streamed operand stays raw;
+//   * 32 KB of LDS per (partition, two heads) instead of 64: three 10-wave workgroups per CU.
+// =====================================================================================================================
+template <int D, int HG>
+struct A16L {
+    static constexpr int RW = HG * 3 * D, RWD = HG * D;                     // bf16 elements of a staged qkv / dO row
+    static constexpr int SD = (RW / 2 + 7) / 16 * 16 + 8;                   // row strides in dwords, == 8 (mod 16)
+    static constexpr int SDD = (RWD / 2 + 7) / 16 * 16 + 8;
+    static_assert(RW % 8 == 0 && RWD % 8 == 0 && SD >= RW / 2 && SDD >= RWD / 2, "rows are staged in units of 8 elements");
+};
+typedef unsigned u4v_ __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s4 lds_s4_;
+// head-dimension fragment: 8 bf16 of row `row` starting at dword `dw` (+ 4 rg)
+__device__ __forceinline__ s8v a16_frag(const unsigned* base, int row, int sd, int dw, int rg) {
+    return __builtin_bit_cast(s8v, *reinterpret_cast<const u4v_*>(base + row * sd + dw + 4 * rg));
+}
+template <int D> __device__ __forceinline__ s8v a16_mask(s8v v, int rg) {   // d = 24: k = 24 .. 31 belongs to the next part of the row
+    if (D == 24 && rg == 3) v = s8v{0, 0, 0, 0, 0, 0, 0, 0};
+    return v;
+}
+// token-dimension fragment: element [4 rg + j][16-column tile at dword dw] of the 16-row tile starting at row0, for j = 0 .. 3
+__device__ __forceinline__ s4 a16_tfrag(const unsigned* base, int row0, int sd, int dw, int i, int rg) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_*)(base + (row0 + 4 * rg + (i >> 2)) * sd + dw + 2 * (i & 3)));
+}
+
+// stage rows of 8-element units: src rows are bf16 (SRC16) or fp32; all global loads first, then the LDS stores.  The padding units of a
+// row (SDW / 4 > UNITS) and the 8 slack dwords behind the last row are ZEROED: the fragments of the last part of a row read 8 elements
+// past it, and although those values only ever meet a zeroed operand or feed discarded output columns, 0 * NaN is NaN.
+template <int NTHR, int TOK, int UNITS, int SDW, bool SRC16>
+__device__ __forceinline__ void a16_stage(unsigned* dst, const void* src, const long* srow, long ld, long col0, int tid) {
+    constexpr int UR = SDW / 4;                                // units per staged row, padding included
+    constexpr int NL = (TOK * UR + NTHR - 1) / NTHR;
+    u4v_ raw16[SRC16 ? NL : 1]; f4 raw32[SRC16 ? 1 : 2 * NL];
+    unsigned ok = 0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int e = tid + j * NTHR, tok = min(e / UR, TOK - 1), f = e - (e / UR) * UR;
+        const long row = srow[tok];
+        ok |= (unsigned)(e < TOK * UR && f < UNITS && row >= 0) << j;
+        const long off = max(row, 0L) * ld + col0 + 8 * min(f, UNITS - 1);
+        if constexpr (SRC16) raw16[j] = *reinterpret_cast<const u4v_*>(reinterpret_cast<const unsigned short*>(src) + off);
+        else { raw32[2 * j] = ld4(reinterpret_cast<const float*>(src) + off); raw32[2 * j + 1] = ld4(reinterpret_cast<const float*>(src) + off + 4); }
+    }
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int e = tid + j * NTHR, tok = e / UR, f = e - tok * UR;
+        u4v_ v;
+        if constexpr (SRC16) v = raw16[j];
+        else {
+            const s4 lo = pack_bf16(raw32[2 * j]), hi = pack_bf16(raw32[2 * j + 1]);
+            const u2_ a = __builtin_bit_cast(u2_, lo), b = __builtin_bit_cast(u2_, hi);
+            v = u4v_{a.x, a.y, b.x, b.y};
+        }
+        if (e < TOK * UR) *reinterpret_cast<u4v_*>(dst + tok * SDW + 4 * f) = (ok >> j) & 1u ? v : u4v_{0u, 0u, 0u, 0u};
+    }
+    if (tid < 8) dst[TOK * SDW + tid] = 0u;
+}
+
+template <int PT, int D, int HG>
+__global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds16_kernel(const void* __restrict__ qkv, float* __restrict__ out,
+                                                                        float* __restrict__ lse, AttnGeom g, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned smem16[];
+    constexpr int NTHR = 64 * PT * HG, TOK = 16 * PT, DCH = (D + 15) / 16, d = D;
+    constexpr int SD = A16L<D, HG>::SD, SO = D + 4;
+    __shared__ long srow[TOK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, rg = lane >> 4;
+    const int hl = wave / PT, qt = wave - hl * PT;
+    const int ngrp = g.heads / HG;
+    const int p = blockIdx.x / ngrp, h0 = (blockIdx.x - p * ngrp) * HG;
+    const int P = g.ph * g.pw;
+    unsigned* sq = smem16;
+    float* sout = reinterpret_cast<float*>(smem16 + TOK * SD + 8) + wave * 16 * SO;      // wave-private O tile
+    if (tid < TOK) srow[tid] = token_row(g, p, tid);
+    __syncthreads();
+    a16_stage<NTHR, TOK, A16L<D, HG>::RW / 8, SD, true>(sq, qkv, srow, 3L * g.C, (long)h0 * 3 * d, tid);
+    __syncthreads();
+    const int hq = hl * 3 * d / 2, hk = hq + d / 2, hv = hq + d;                          // dword offsets of this head's q | k | v
+    const bool qvalid = 16 * qt + i < P;
+    const s8v qf = a16_mask<D>(a16_frag(sq, 16 * qt + i, SD, hq, rg), rg);
+    f4 s[PT];
+#pragma unroll
+    for (int mt = 0; mt < PT; ++mt) s[mt] = mfma32_bf16(a16_frag(sq, 16 * mt + i, SD, hk, rg), qf, zero4());
+    float mx = -INFINITY;
+#pragma unroll
+    for (int mt = 0; mt < PT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * mt + 4 * rg + r;
+            const float v = key < P ? s[mt][r] * scale : -INFINITY;
+            s[mt][r] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = quad16_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < PT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = fast_exp(s[mt][r] - mx);
+            s[mt][r] = e;
+            sum += e;
+        }
+    sum = quad16_sum(sum);
+    const float inv = 1.0f / sum;
+    if (lse && rg == 0 && qvalid) lse[srow[16 * qt + i] * g.heads + h0 + hl] = mx + logf(sum);
+    f4 o[DCH];
+#pragma unroll
+    for (int ct = 0; ct < DCH; ++ct) o[ct] = zero4();
+#pragma unroll
+    for (int mt = 0; mt < PT; ++mt) {
+        const s4 pa = pack_bf16(s[mt] * inv);
+#pragma unroll
+        for (int ct = 0; ct < DCH; ++ct) o[ct] = mfma16_bf16(pa, a16_tfrag(sq, 16 * mt, SD, hv + 8 * ct, i, rg), o[ct]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ct = 0; ct < DCH; ++ct)
+            if (16 * ct + i < d) sout[(4 * rg + r) * SO + 16 * ct + i] = o[ct][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int d4 = D / 4;
+    for (int e = lane; e < 16 * d4; e += 64) {
+        const int tok = e / d4, c4 = e - tok * d4;
+        const long row = srow[16 * qt + tok];
+        if (row >= 0) *reinterpret_cast<f4*>(out + row * g.C + (h0 + hl) * d + 4 * c4) = *reinterpret_cast<const f4*>(sout + tok * SO + 4 * c4);
+    }
+}
+
+template <int PT, int D, int HG>
+__global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds16_kernel(const void* __restrict__ qkv, const float* __restrict__ dout,
+                                                                        const float* __restrict__ lse, void* __restrict__ dqkv,
+                                                                        AttnGeom g, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned smem16[];
+    constexpr int NTHR = 64 * PT * HG, TOK = 16 * PT, DCH = (D + 15) / 16, d = D;
+    constexpr int SD = A16L<D, HG>::SD, SDD = A16L<D, HG>::SDD, F8 = A16L<D, HG>::RW / 8;
+    __shared__ long srow[TOK];
+    __shared__ float sL[HG * TOK], sD[HG * TOK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, rg = lane >> 4;
+    const int hl = wave / PT, qt = wave - hl * PT;            // also the key tile of phase 2
+    const int ngrp = g.heads / HG;
+    const int p = blockIdx.x / ngrp, h0 = (blockIdx.x - p * ngrp) * HG;
+    const int P = g.ph * g.pw;
+    const long ld = 3L * g.C;
+    unsigned* sq = smem16;
+    unsigned* sdo = smem16 + TOK * SD + 8;
+    if (tid < TOK) srow[tid] = token_row(g, p, tid);
+    __syncthreads();
+    {   // lse first (its loads then fly with the rest), then qkv and dO rows
+        constexpr int NLl = (HG * TOK + NTHR - 1) / NTHR;
+        float stagel[NLl]; unsigned okl = 0;
+#pragma unroll
+        for (int j = 0; j < NLl; ++j) {
+            const int e = tid + j * NTHR, hh = min(e / TOK, HG - 1), tok = e - (e / TOK) * TOK;
+            const long row = srow[tok];
+            okl |= (unsigned)(e < HG * TOK && row >= 0) << j;
+            stagel[j] = lse[max(row, 0L) * g.heads + h0 + hh];
+        }
+        a16_stage<NTHR, TOK, F8, SD, true>(sq, qkv, srow, ld, (long)h0 * 3 * d, tid);
+        a16_stage<NTHR, TOK, A16L<D, HG>::RWD / 8, SDD, false>(sdo, dout, srow, (long)g.C, (long)h0 * d, tid);
+#pragma unroll
+        for (int j = 0; j < NLl; ++j) {
+            const int e = tid + j * NTHR;
+            if (e < HG * TOK) sL[e] = (okl >> j) & 1u ? stagel[j] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int hq = hl * 3 * d / 2, hk = hq + d / 2, hv = hq + d, hd = hl * d / 2;       // dword offsets: q | k | v of this head, its dO slice
+    // ---- phase 1: dQ and D of query tile qt ------------------------------------------------------------------------------
+    f4 dq[DCH];
+    {
+        const bool qvalid = 16 * qt + i < P;
+        const s8v qf = a16_mask<D>(a16_frag(sq, 16 * qt + i, SD, hq, rg), rg);
+        const s8v dof = a16_mask<D>(a16_frag(sdo, 16 * qt + i, SDD, hd, rg), rg);
+        const float l = sL[hl * TOK + 16 * qt + i];
+        f4 s[PT], dp[PT];
+#pragma unroll
+        for (int mt = 0; mt < PT; ++mt) {
+            s[mt] = mfma32_bf16(a16_frag(sq, 16 * mt + i, SD, hk, rg), qf, zero4());
+            dp[mt] = mfma32_bf16(a16_frag(sq, 16 * mt + i, SD, hv, rg), dof, zero4());
+        }
+        float Dq = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < PT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 16 * mt + 4 * rg + r;
+                const float pr = (key < P && qvalid) ? fast_exp(s[mt][r] * scale - l) : 0.f;
+                s[mt][r] = pr;
+                Dq += pr * dp[mt][r];
+            }
+        Dq = quad16_sum(Dq);
+        if (rg == 0) sD[hl * TOK + 16 * qt + i] = Dq;
+#pragma unroll
+        for (int ct = 0; ct < DCH; ++ct) dq[ct] = zero4();
+#pragma unroll
+        for (int mt = 0; mt < PT; ++mt) {
+            f4 ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[r] = s[mt][r] * (dp[mt][r] - Dq) * scale;
+            const s4 pa = pack_bf16(ds);
+#pragma unroll
+            for (int ct = 0; ct < DCH; ++ct) dq[ct] = mfma16_bf16(pa, a16_tfrag(sq, 16 * mt, SD, hk + 8 * ct, i, rg), dq[ct]);
+        }
+    }
+    __syncthreads();                                          // D of every query of the partition is in LDS
+    // ---- phase 2: dK, dV of key tile kt = qt --------------------------------------------------------------------------------
+    f4 dk[DCH], dv[DCH];
+    {
+        const bool kvalid = 16 * qt + i < P;
+        const s8v kf = a16_mask<D>(a16_frag(sq, 16 * qt + i, SD, hk, rg), rg);
+        const s8v vf = a16_mask<D>(a16_frag(sq, 16 * qt + i, SD, hv, rg), rg);
+#pragma unroll
+        for (int ct = 0; ct < DCH; ++ct) { dk[ct] = zero4(); dv[ct] = zero4(); }
+#pragma unroll
+        for (int qm = 0; qm < PT; ++qm) {
+            const f4 s = mfma32_bf16(a16_frag(sq, 16 * qm + i, SD, hq, rg), kf, zero4());
+            const f4 dp = mfma32_bf16(a16_frag(sdo, 16 * qm + i, SDD, hd, rg), vf, zero4());
+            f4 pr4 = zero4(), ds4 = zero4();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int query = 16 * qm + 4 * rg + r;       // accumulator row r; key = column i
+                if (query < P && kvalid) {
+                    pr4[r] = fast_exp(s[r] * scale - sL[hl * TOK + query]);
+                    ds4[r] = pr4[r] * (dp[r] - sD[hl * TOK + query]) * scale;
+                }
+            }
+            const s4 ppr = pack_bf16(pr4), pds = pack_bf16(ds4);
+#pragma unroll
+            for (int ct = 0; ct < DCH; ++ct) {
+                dv[ct] = mfma16_bf16(ppr, a16_tfrag(sdo, 16 * qm, SDD, hd + 8 * ct, i, rg), dv[ct]);
+                dk[ct] = mfma16_bf16(pds, a16_tfrag(sq, 16 * qm, SD, hq + 8 * ct, i, rg), dk[ct]);
+            }
+        }
+    }
+    __syncthreads();                                          // every wave is done reading the staged q / k / v
+    // [dq | dk | dv] of this wave's 16 tokens as bf16 into its own slots of the qkv tile, then one coalesced copy-out of whole rows
+    unsigned short* gb = reinterpret_cast<unsigned short*>(sq) + (16 * qt) * (2 * SD) + hl * 3 * d;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ct = 0; ct < DCH; ++ct)
+            if (16 * ct + i < d) {
+                unsigned short* t = gb + (4 * rg + r) * (2 * SD) + 16 * ct + i;
+                const s4 pk = pack_bf16(f4{dq[ct][r], dk[ct][r], dv[ct][r], 0.f});
+                t[0] = (unsigned short)pk[0]; t[d] = (unsigned short)pk[1]; t[2 * d] = (unsigned short)pk[2];
+                asm volatile("" ::: "memory");                // keep the 16-bit stores apart (see the ds_write2 defect above)
+            }
+    __syncthreads();
+    for (int e = tid; e < TOK * F8; e += NTHR) {
+        const int tok = e / F8, f = e - tok * F8;
+        const long row = srow[tok];
+        if (row >= 0)
+            *reinterpret_cast<u4v_*>(reinterpret_cast<unsigned short*>(dqkv) + row * ld + h0 * 3 * d + 8 * f) =
+                *reinterpret_cast<const u4v_*>(sq + tok * SD + 4 * f);
+    }
+}
+
 template <int PT, int D, int HG>
 static int run_attn_lds(int which, const float* qkv, const float* dout, float* out, float* lse, float* dqkv,
                         const AttnGeom& g, float scale, hipStream_t s) {
@@ -721,6 +992,18 @@ static int run_attn_lds(int which, const float* qkv, const float* dout, float* o
     const int nblk = NP * (g.heads / HG);
     if (nblk == 0) return LEOD_OK;
     const int TOK = 16 * PT, S = HG * 3 * D + 4, Sd = HG * D + 4;
+    // precision mode bf16 with bf16 qkv rows (and bf16 dqkv): the bf16-tile kernels
+    static const int t16 = getenv("LEOD_ATTN_TILE16") ? atoi(getenv("LEOD_ATTN_TILE16")) : 1;
+    if (t16 && leod_precision() == 1 && which == 0 && (g.fmt & 1)) {
+        const size_t lds = ((size_t)TOK * A16L<D, HG>::SD + 8) * 4 + (size_t)PT * HG * 16 * (D + 4) * 4;
+        hipLaunchKernelGGL((attn_fwd_lds16_kernel<PT, D, HG>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, out, lse, g, scale);
+        return leod_launch_status();
+    }
+    if (t16 && leod_precision() == 1 && which == 1 && (g.fmt & 3) == 3) {
+        const size_t lds = ((size_t)TOK * (A16L<D, HG>::SD + A16L<D, HG>::SDD) + 16) * 4;
+        hipLaunchKernelGGL((attn_bwd_lds16_kernel<PT, D, HG>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, dout, lse, dqkv, g, scale);
+        return leod_launch_status();
+    }
     if (which == 0) {
         const size_t lds = (size_t)TOK * S * sizeof(float);
         if (leod_precision() == 1) hipLaunchKernelGGL((attn_fwd_lds_kernel<PT, D, HG, true>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, out, lse, g, scale);

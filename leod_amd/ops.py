@@ -101,6 +101,20 @@ def ln_linear_fwd(x, ln_w, ln_b, W, bias, want_act=False, want_stats=False, eps=
     K = x.shape[-1]
     N = W.shape[0]
     M = x.numel() // K
+    ev = _probe('linear_gemm', 0, 0) if _PROBE is not None else None
+    try:
+        return _ln_linear_fwd(x, ln_w, ln_b, W, bias, want_act, want_stats, eps, out_bf16, K, N, M, ev)
+    finally:
+        if ev is not None:
+            ev.record()
+
+
+def _ln_linear_fwd(x, ln_w, ln_b, W, bias, want_act, want_stats, eps, out_bf16, K, N, M, ev):
+    def tally(out_bytes_per_el, n_out=1):
+        # algorithmic bytes: x once, W once, the output(s) at their stored width; 2 M N K flops
+        if ev is not None:
+            _PROBE.bytes['linear_gemm'] += 4.0 * M * K + 4.0 * N * K + out_bytes_per_el * n_out * M * N
+            _PROBE.flops['linear_gemm'] += 2.0 * M * N * K
     if out_bf16 and not want_act:
         # the qkv rows in precision mode bf16 (consumed only by bf16 MFMAs): stored as bf16 where the kernels allow (rc -3: they do not)
         o16 = torch.empty(x.shape[:-1] + (N,), dtype=torch.bfloat16, device=x.device)
@@ -108,6 +122,7 @@ def ln_linear_fwd(x, ln_w, ln_b, W, bias, want_act=False, want_stats=False, eps=
         rc = _l().leod_ln_linear_bf16_fwd(_p(x), _p(ln_w), _p(ln_b), eps, _p(W), _p(bias), _p(o16), _p(stats), M, N, K, _stream())
         if rc != -3:
             check(rc, 'ln_linear_bf16_fwd')
+            tally(2.0)
             return o16, None, stats
     if want_act and want_stats and ln_w is not None and get_precision() == 'bf16':
         # precision mode bf16: the hidden pre-activation is stored once, as fp16 (the reference's autocast dtype); consumers apply GELU on load
@@ -116,6 +131,7 @@ def ln_linear_fwd(x, ln_w, ln_b, W, bias, want_act=False, want_stats=False, eps=
         rc = _l().leod_ln_linear_gelu16_fwd(_p(x), _p(ln_w), _p(ln_b), eps, _p(W), _p(bias), _p(u16), _p(stats), M, N, K, _stream())
         if rc != -3:
             check(rc, 'ln_linear_gelu16_fwd')
+            tally(2.0)
             return u16, None, stats
     out = _empty(x.shape[:-1] + (N,), x)
     act = _empty(out.shape, x) if want_act else None
@@ -123,6 +139,7 @@ def ln_linear_fwd(x, ln_w, ln_b, W, bias, want_act=False, want_stats=False, eps=
     stats = _empty((M, 2), x) if ln_w is not None else None
     check(_l().leod_ln_linear_fwd(_p(x), K, _p(ln_w), _p(ln_b), eps, _p(W), _p(bias), _p(out), _p(act), _p(stats),
                                    M, N, K, _stream()), 'ln_linear_fwd')
+    tally(4.0, 2 if want_act else 1)
     return out, act, stats
 
 
@@ -133,6 +150,16 @@ def linear_lsres_fwd(a, W, bias, gamma, res, want_t=True):
     K = a.shape[-1]
     N = W.shape[0]
     M = a.numel() // K
+    # algorithmic bytes: a once (stored width), W, residual in, output out
+    ev = _probe('linear_gemm', a.element_size() * M * K + 4.0 * N * K + (12.0 if want_t else 8.0) * M * N, 2.0 * M * N * K)
+    try:
+        return _linear_lsres_fwd(a, W, bias, gamma, res, want_t, K, N, M)
+    finally:
+        if ev is not None:
+            ev.record()
+
+
+def _linear_lsres_fwd(a, W, bias, gamma, res, want_t, K, N, M):
     if a.dtype is torch.float16:                             # a = fp16 pre-activation: out = res + gamma * (gelu(a) W^T + b)
         _ck(a, torch.float16, 'a')
         if want_t:
@@ -262,6 +289,18 @@ def linear_dgrad(dy, W, kscale=None, aux_u=None, colsum=None, out=None, accumula
         _ck(t, name=n)
     N, K = W.shape[0], W.shape[1] if W.dim() == 2 else W.numel() // W.shape[0]
     M = dy.numel() // N
+    aux_b = 0.0 if aux_u is None else aux_u.element_size() * M * K
+    out_b = (2.0 if (aux_u is not None and aux_u.dtype is torch.float16 and BF16_GRADS) else 4.0) * M * K
+    ev = _probe('linear_gemm', dy.element_size() * M * N + 4.0 * N * K + aux_b + out_b + (4.0 * M * K if (accumulate or dres is not None) else 0.0),
+                2.0 * M * N * K)
+    try:
+        return _linear_dgrad(dy, W, kscale, aux_u, colsum, out, accumulate, split, out2, dres, dy16, N, K, M)
+    finally:
+        if ev is not None:
+            ev.record()
+
+
+def _linear_dgrad(dy, W, kscale, aux_u, colsum, out, accumulate, split, out2, dres, dy16, N, K, M):
     if aux_u is not None and aux_u.dtype is torch.float16:    # through GELU on the fp16 pre-activation (stages 1-2, bf16 mode)
         _ck(aux_u, torch.float16, 'aux_u')
         if split or colsum is not None or accumulate or out is not None or dres is not None:
@@ -721,42 +760,65 @@ _PROBE = None
 
 
 class KernelProbe:
-    """Brackets every launch of ONE kernel family with HIP events on the launch stream (torch's current stream is
-    the stream every leod_* call is enqueued on) and tallies its algorithmic bytes:
-    achieved GB/s = sum(bytes) / sum(event time).  Default target: the weight-gradient GEMM ``wgradw_kernel`` behind
-    ``linear_wgrad`` (the largest single kernel family of the training step, see profiles/)."""
+    """Brackets every launch of the probed kernel FAMILIES with HIP events on the launch stream (torch's current stream is
+    the stream every leod_* call is enqueued on) and tallies their algorithmic bytes / flops:
+    achieved GB/s = sum(bytes) / sum(event time).  Families: ``linear_wgrad`` (the weight-gradient GEMM ``wgradw_kernel``, the largest
+    single kernel family of the training step) and ``linear_gemm`` (forward / dgrad GEMMs of the Linear layers: row-streaming,
+    LDS-staged and wide-tile kernels).  With ``families=True`` every C entry point is bracketed as well (``family_ms``): the
+    benchmark line then carries its own per-family time table."""
 
-    def __init__(self, target: str = 'linear_wgrad', kernel_name: str = 'wgradw_kernel<.., XRows>'):
-        global _PROBE
-        self.target, self.kernel_name = target, kernel_name
-        self.events, self.bytes, self.flops = [], 0.0, 0.0
+    def __init__(self, targets=('linear_wgrad', 'linear_gemm'), kernel_names=None, families=True):
+        global _PROBE, _LIB
+        self.targets = tuple(targets)
+        self.kernel_names = kernel_names or {'linear_wgrad': 'wgradw_kernel<.., XRows>',
+                                             'linear_gemm': 'rowstream* / gemm_lds_kernel / gemm_wide_bf16_kernel (Linear forward + dgrad)'}
+        self.events = {t: [] for t in self.targets}
+        self.bytes = {t: 0.0 for t in self.targets}
+        self.flops = {t: 0.0 for t in self.targets}
+        self.fam_events = {}
+        self.real_lib = _l()
+        if families:
+            _LIB = _ProbedLib(self.real_lib, self)
         _PROBE = self
 
-    def begin(self, nbytes, flops=0.0):
+    def begin(self, target, nbytes, flops=0.0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        self.events.append((e0, e1))
-        self.bytes += nbytes
-        self.flops += flops
+        self.events[target].append((e0, e1))
+        self.bytes[target] += nbytes
+        self.flops[target] += flops
         return e1
 
-    def finish(self, peak_gbs, peak_tflops=157.3):
-        """Roofline object of the probed kernel family.  The bound is chosen by the family's arithmetic intensity
+    def close(self):
+        global _PROBE, _LIB
+        _PROBE = None
+        _LIB = self.real_lib
+        torch.cuda.synchronize()
+
+    def family_ms(self, steps, top=8):
+        """{C entry point: ms per step}, largest first, from the per-call event brackets (single-stream probe steps)."""
+        tot = {k: sum(a.elapsed_time(b) for a, b in v) / max(steps, 1) for k, v in self.fam_events.items()}
+        return {k: round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:top]}
+
+    def finish(self, peak_gbs, peak_tflops=157.3, target=None):
+        """Roofline object of one probed family.  The bound is chosen by the family's arithmetic intensity
         (sum flops / sum algorithmic bytes) against the ridge peak_tflops / peak_gbs; ``achieved`` is in the unit of that
         bound, the other roof is reported alongside."""
-        global _PROBE
-        _PROBE = None
-        torch.cuda.synchronize()
-        if not self.events:
+        if _PROBE is self:
+            self.close()
+        target = target or self.targets[0]
+        ev = self.events[target]
+        if not ev:
             return None
-        ms = sum(a.elapsed_time(b) for a, b in self.events)
-        n = len(self.events)
-        gbs = self.bytes / (ms * 1e-3) / 1e9
-        tfl = self.flops / (ms * 1e-3) / 1e12
+        ms = sum(a.elapsed_time(b) for a, b in ev)
+        n = len(ev)
+        nbytes, flops = self.bytes[target], self.flops[target]
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        tfl = flops / (ms * 1e-3) / 1e12
         ridge = peak_tflops * 1e12 / (peak_gbs * 1e9)
-        intensity = self.flops / max(self.bytes, 1.0)
-        out = {'kernel': self.kernel_name, 'launches': n, 'avg_us': round(1e3 * ms / n, 3),
-               'algorithmic_bytes_per_launch': round(self.bytes / n, 1), 'algorithmic_flops_per_launch': round(self.flops / n, 1),
+        intensity = flops / max(nbytes, 1.0)
+        out = {'kernel': self.kernel_names.get(target, target), 'launches': n, 'avg_us': round(1e3 * ms / n, 3),
+               'algorithmic_bytes_per_launch': round(nbytes / n, 1), 'algorithmic_flops_per_launch': round(flops / n, 1),
                'flop_per_byte': round(intensity, 2), 'ridge_flop_per_byte': round(ridge, 2),
                'hbm_achieved_GBs': round(gbs, 2), 'hbm_frac': round(gbs / peak_gbs, 5),
                'mfma_achieved_TFLOPs': round(tfl, 2), 'mfma_frac': round(tfl / peak_tflops, 5), 'traffic': None}
@@ -767,7 +829,33 @@ class KernelProbe:
         return out
 
 
+class _ProbedLib:
+    """Stand-in for the CDLL while a KernelProbe with ``families=True`` is active: every leod_* launch is bracketed with events."""
+
+    def __init__(self, lib, probe):
+        self._lib, self._probe, self._cache = lib, probe, {}
+
+    def __getattr__(self, name):
+        fn = self._cache.get(name)
+        if fn is None:
+            real = getattr(self._lib, name)
+            if not name.startswith('leod_') or name.endswith(('_ok', '_mode', '_bytes', '_floats', 'get_precision', 'set_precision')):
+                fn = real
+            else:
+                probe = self._probe
+
+                def fn(*a, _real=real, _name=name):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    rc = _real(*a)
+                    e1.record()
+                    probe.fam_events.setdefault(_name, []).append((e0, e1))
+                    return rc
+            self._cache[name] = fn
+        return fn
+
+
 def _probe(name, nbytes, flops=0.0):
-    if _PROBE is not None and _PROBE.target == name:
-        return _PROBE.begin(nbytes, flops)
+    if _PROBE is not None and name in _PROBE.targets:
+        return _PROBE.begin(name, nbytes, flops)
     return None

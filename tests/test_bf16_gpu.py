@@ -139,13 +139,17 @@ def test_conv3x3_strided_sliced_direct_bf16(bf16_ops, B, H, W, Cin, N, stride):
     tk.close(dw, 2 * w.grad, what='conv3x3 wgrad (direct) accumulates')
 
 
-@pytest.mark.parametrize('B,H,W,C,heads', [(3, 16, 20, 48, 2), (2, 32, 40, 96, 4), (1, 8, 10, 384, 16)])
+@pytest.mark.parametrize('B,H,W,C,heads,part', [(3, 16, 20, 48, 2, (8, 10)), (2, 32, 40, 96, 4, (8, 10)), (1, 8, 10, 384, 16, (8, 10)),
+                                                # the other instantiations of the bf16-tile kernels: d = 32, one-head workgroups, padded
+                                                # partitions (60 of 64, 56 of 64 tokens), 240-token partitions of the 1 Mpx geometry
+                                                (2, 16, 20, 64, 2, (8, 10)), (1, 12, 20, 32, 1, (6, 10)), (2, 12, 20, 96, 4, (6, 10)),
+                                                (1, 16, 16, 24, 1, (8, 8)), (1, 14, 16, 48, 2, (7, 8)), (1, 24, 40, 64, 2, (12, 20)),
+                                                (1, 24, 40, 72, 3, (12, 20))])
 @pytest.mark.parametrize('window', [True, False])
-def test_partition_attn_bf16_tensors(bf16_ops, B, H, W, C, heads, window):
+def test_partition_attn_bf16_tensors(bf16_ops, B, H, W, C, heads, part, window):
     """qkv handed over as bf16 and dqkv produced as bf16 (precision mode bf16, LDS attention kernels): q, k, v only ever enter bf16
     MFMAs, so the results are those of the fp32-tensor path on the same (rounded) values -- checked against the fp32 CPU attention."""
     ops = bf16_ops
-    part = (8, 10)
     assert ops.partition_attn_16bit_ok(B, H, W, C, heads, part)
     qkv16 = tk.rnd((B, H, W, 3 * C), 7).to(torch.bfloat16)
     qkv = qkv16.float().requires_grad_(True)

@@ -56,6 +56,7 @@ def main():
         Wqkv, bqkv, Wp, bp, g = r(3 * C, C) * .1, r(3 * C), r(C, C) * .1, r(C), r(C)
         W1, b1, W2, b2 = r(4 * C, C) * .1, r(4 * C), r(C, 4 * C) * .1, r(C)
         qkv4 = r(B, H, W, 3 * C)
+        qkv16 = qkv4.to(torch.bfloat16)
         u, dyC, dy3, dy4 = r(M, 4 * C), r(M, C), r(M, 3 * C), r(M, 4 * C)
         _, _, st = ops.ln_linear_fwd(x, lw, lb, Wqkv, bqkv, want_stats=True)
         o, lse = ops.partition_attn_fwd(qkv4, heads, (8, 10), True, want_lse=True)
@@ -69,6 +70,9 @@ def main():
             ('attn_fwd_window', lambda: ops.partition_attn_fwd(qkv4, heads, (8, 10), True, want_lse=True), 4 * M * 4 * C, 4 * M * 80 * C),
             ('attn_fwd_grid', lambda: ops.partition_attn_fwd(qkv4, heads, (8, 10), False, want_lse=True), 4 * M * 4 * C, 4 * M * 80 * C),
             ('attn_bwd_window', lambda: ops.partition_attn_bwd(qkv4, o, lse, heads, (8, 10), True), 4 * M * 8 * C, 10 * M * 80 * C),
+            ('attn_fwd_window16', lambda: ops.partition_attn_fwd(qkv16, heads, (8, 10), True, want_lse=True), M * (2 * 3 * C + 4 * C), 4 * M * 80 * C),
+            ('attn_bwd_window16', lambda: ops.partition_attn_bwd(qkv16, o, lse, heads, (8, 10), True), M * (2 * 6 * C + 4 * C), 10 * M * 80 * C),
+            ('attn_bwd_grid16', lambda: ops.partition_attn_bwd(qkv16, o, lse, heads, (8, 10), False), M * (2 * 6 * C + 4 * C), 10 * M * 80 * C),
             ('convlstm_fwd', lambda: ops.convlstm_fwd(x, h0, c0, Wl, bl_, want_gates=True), 4 * M * 9 * C, 2 * M * 2 * C * 4 * C),
             ('dgrad_fc2(gelu)', lambda: ops.linear_dgrad(dyC, W2, aux_u=u), 4 * M * 9 * C, 2 * M * C * 4 * C),
             ('dgrad_fc1', lambda: ops.linear_dgrad(dy4, W1), 4 * M * 5 * C, 2 * M * C * 4 * C),
