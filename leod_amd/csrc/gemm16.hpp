@@ -1376,7 +1376,7 @@ constexpr int wgradw_lds_floats() {
 // write of 4 bytes: 9.4 M of them per launch were 20-30 us of a ~100 us launch).  Measured: NG = 2 -13.6 % over the 16 Linear shapes
 // of RVT-S in bf16 mode; NG = 4 (16-wave workgroups, exchange in two halves) is SLOWER than NG = 2 on every stage-2 shape
 // (91 -> 104, 104 -> 125, 146 -> 180 us): one barrier couples 16 waves per chunk.
-template <int TN, int TK, int WA, int WB, int RC, bool BF, class XL, int DYF = -1, int XM = 0, int NG = 1>   // DYF: dY fp32 (0) / bf16 (1); -1: runtime dyfmt
+template <int TN, int TK, int WA, int WB, int RC, bool BF, class XL, int DYF = -1, int XM = 0, int NG = 1, int PDT = 1>   // DYF: dY fp32 (0) / bf16 (1); -1: runtime dyfmt
 __global__ __launch_bounds__(256 * NG, 4) void wgradw_kernel(const float* __restrict__ dy, long lddy, XL xl, float* dW, long ldw,
                                                      float* dbias, int M, int N, int K, int dyfmt) {
     constexpr int NWN = TN / WA, NWK = TK / WB, MS = 4 / (NWN * NWK);      // wave grid over the tile, row-step split
@@ -1442,7 +1442,12 @@ __global__ __launch_bounds__(256 * NG, 4) void wgradw_kernel(const float* __rest
     // arithmetic of the loaders sitting behind each load the compiler waited for every load in turn: 5-6 serialized memory
     // round trips per 16-row chunk.
     constexpr bool TP = x_two_phase<XL>::value;
-    f4 rn[RN], rk[RK]; f2_ rst[RK]; u2_ hn[RN], hk[RK];      // 16-byte and 8-byte raw registers are separate: no copies behind a load
+    constexpr bool TP_ = x_two_phase<XL>::value;
+    // PDT = 2: TWO raw register sets -- the loads of chunk c + 2 are issued before the MFMAs of chunk c, while the set of chunk c + 1 waits
+    // to be stashed, so every load has a whole iteration more to land (69 % of the wave cycles of the single-set version sit in
+    // s_waitcnt / barriers, profiles/r03_d_wgradw_pmc.txt).  Kept as an option, not instantiated (see launch_wgradw_cfg): no gain.
+    constexpr int PD = (TP_ && RC == 16) ? PDT : 1;
+    f4 rn_[PD][RN], rk_[PD][RK]; f2_ rst_[PD][RK]; u2_ hn_[PD][RN], hk_[PD][RK];      // 16-byte and 8-byte raw registers are separate: no copies behind a load
     __shared__ __attribute__((aligned(16))) float sln[2][TP ? 16 * TK : 4];   // LayerNorm weight / bias of this workgroup's columns
     long noffc[RN]; int kcc[RK];
 #pragma unroll
@@ -1454,7 +1459,9 @@ __global__ __launch_bounds__(256 * NG, 4) void wgradw_kernel(const float* __rest
         for (int c = threadIdx.x; c < 16 * TK; c += 256 * NG) { sln[0][c] = k0 + c < K ? xl.ln_w[k0 + c] : 0.f; sln[1][c] = k0 + c < K ? xl.ln_b[k0 + c] : 0.f; }
         __syncthreads();
     }
-    auto fetch = [&](long m0) {
+    auto fetch = [&](long m0, auto setc) {
+        constexpr int SI = decltype(setc)::value;
+        f4 (&rn)[RN] = rn_[SI]; f4 (&rk)[RK] = rk_[SI]; f2_ (&rst)[RK] = rst_[SI]; u2_ (&hn)[RN] = hn_[SI]; u2_ (&hk)[RK] = hk_[SI];
         if constexpr (!TP) {                                  // loaders without the raw / finish pair: values in one go
 #pragma unroll
             for (int e = 0; e < RN; ++e) {
@@ -1475,7 +1482,9 @@ __global__ __launch_bounds__(256 * NG, 4) void wgradw_kernel(const float* __rest
         for (int e = 0; e < RK; ++e) xl.template raw4<XM>((int)min(m0 + kr[e], (long)mend - 1), kcc[e], rk[e], hk[e], rst[e]);
         }
     };
-    auto finish = [&](long m0) {
+    auto finish = [&](long m0, auto setc) {
+        constexpr int SI = decltype(setc)::value;
+        f4 (&rn)[RN] = rn_[SI]; f4 (&rk)[RK] = rk_[SI]; f2_ (&rst)[RK] = rst_[SI]; u2_ (&hn)[RN] = hn_[SI]; u2_ (&hk)[RK] = hk_[SI];
         if constexpr (TP) {
 #pragma unroll
         for (int e = 0; e < RN; ++e) {
@@ -1492,7 +1501,9 @@ __global__ __launch_bounds__(256 * NG, 4) void wgradw_kernel(const float* __rest
         }
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, auto setc) {
+        constexpr int SI = decltype(setc)::value;
+        f4 (&rn)[RN] = rn_[SI]; f4 (&rk)[RK] = rk_[SI];
         if constexpr (BF) {
             unsigned short* __restrict__ d16 = reinterpret_cast<unsigned short*>(sdy0 + buf * SDY);
             unsigned short* __restrict__ x16 = reinterpret_cast<unsigned short*>(sx0 + buf * SX);
@@ -1516,16 +1527,9 @@ __global__ __launch_bounds__(256 * NG, 4) void wgradw_kernel(const float* __rest
         }
     };
     int buf = 0;
-    fetch(mbeg);
-    finish(mbeg);
-    stash(0);
-    __syncthreads();
-    // the trip count is that of the workgroup's first row group, so that every group meets every barrier (a group whose chunk lies
-    // past the last row stages zeros: clamped loads, masked in finish)
-    for (long mb = (long)blockIdx.x * NG * RC; mb < mend; mb += mstride) {
-        const long m0 = mb + grp * RC;
-        const bool more = mb + mstride < mend;
-        if (more) fetch(m0 + mstride);                      // next chunk's global loads fly under this chunk's MFMAs
+    const std::integral_constant<int, 0> S0{};
+    const std::integral_constant<int, PD - 1> S1{};
+    auto mfma_chunk = [&](int buf) {
         if constexpr (BF) {
             typedef __attribute__((address_space(3))) s4 lds_s4;
             const unsigned short* __restrict__ pdy = reinterpret_cast<const unsigned short*>(sdy0 + buf * SDY) + offA;
@@ -1566,9 +1570,47 @@ __global__ __launch_bounds__(256 * NG, 4) void wgradw_kernel(const float* __rest
                     for (int b = 0; b < WB; ++b) acc[a][b] = mfma16(av[a][j], bv[b][j], acc[a][b]);
         }
         }
-        if (more) { finish(m0 + mstride); stash(buf ^ 1); }
+    };
+    fetch(mbeg, S0);
+    finish(mbeg, S0);
+    stash(0, S0);
+    // the trip count is that of the workgroup's first row group, so that every group meets every barrier (a group whose chunk lies
+    // past the last row stages zeros: clamped loads, masked in finish)
+    const long mb0 = (long)blockIdx.x * NG * RC;
+    if constexpr (PD == 1) {
         __syncthreads();
-        buf ^= 1;
+        for (long mb = mb0; mb < mend; mb += mstride) {
+            const long m0 = mb + grp * RC;
+            const bool more = mb + mstride < mend;
+            if (more) fetch(m0 + mstride, S0);              // next chunk's global loads fly under this chunk's MFMAs
+            mfma_chunk(buf);
+            if (more) { finish(m0 + mstride, S0); stash(buf ^ 1, S0); }
+            __syncthreads();
+            buf ^= 1;
+        }
+    } else {
+        // chunk c sits in LDS buffer c & 1, chunk c + 1 in register set (c + 1) & 1 (issued one iteration ago), and the loads of
+        // chunk c + 2 go to set c & 1 (stashed one iteration ago) before the MFMAs of chunk c: unrolled by two so that the set is static
+        if (mb0 + mstride < mend) fetch(mbeg + mstride, S1);
+        __syncthreads();
+        for (long mb = mb0; mb < mend; mb += 2 * mstride) {
+            const long m0 = mb + grp * RC;
+            {   // even chunk c: LDS buffer 0, next chunk in set 1, chunk after that into set 0
+                const bool more1 = mb + mstride < mend, more2 = mb + 2 * mstride < mend;
+                if (more2) fetch(m0 + 2 * mstride, S0);
+                mfma_chunk(0);
+                if (more1) { finish(m0 + mstride, S1); stash(1, S1); }
+                __syncthreads();
+                if (!more1) break;
+            }
+            {   // odd chunk c + 1: LDS buffer 1, next chunk in set 0, chunk after that into set 1
+                const bool more2 = mb + 2 * mstride < mend, more3 = mb + 3 * mstride < mend;
+                if (more3) fetch(m0 + 3 * mstride, S1);
+                mfma_chunk(1);
+                if (more2) { finish(m0 + 2 * mstride, S0); stash(0, S0); }
+                __syncthreads();
+            }
+        }
     }
     if constexpr (NG > 1) {
         // accumulator exchange (the staging bytes are dead after the loop's last barrier): tile ab belongs to group ab % NG, every
@@ -1636,7 +1678,9 @@ static inline int launch_wgradw_cfg(const float* dy, long lddy, const XL& xl, fl
         int gx = max(1, min(chunks / (4 * NGE), tune_blocks / (tiles * NGE)));
         if (tune_align && gx >= 16) gx &= ~7;
         dim3 grid(gx, cdiv(N, TN * 16), cdiv(K, TK * 16));
-        hipLaunchKernelGGL((wgradw_kernel<TN, TK, WA, WB, RC, BFV, XL, DYFV, XMV, NGE>), grid, dim3(256 * NGE), 0, s, dy, lddy, xl, dW, ldw,
+        // PDT = 2 (loads two chunks ahead, a second raw register set) was measured and is NOT instantiated: the plain / fp16 variants are
+        // unchanged (stage 1 fc2 147 vs 149 us: they are not latency-bound) and the LayerNorm variants spill at 128 VGPRs (130 -> 213 us)
+        hipLaunchKernelGGL((wgradw_kernel<TN, TK, WA, WB, RC, BFV, XL, DYFV, XMV, NGE, 1>), grid, dim3(256 * NGE), 0, s, dy, lddy, xl, dW, ldw,
                            dbias, M, N, K, dyfmt);
     };
     using std::integral_constant;
