@@ -97,13 +97,17 @@ int leod_convlstm_seq_mode(int C);
 long leod_convlstm_seq_pack_bytes(int C);
 int leod_convlstm_seq_pack(const float* W, void* wpack, int C, leod_stream_t stream);
 int leod_convlstm_seq_fwd(const float* xin, int x_is_projection, float* hbuf, float* cbuf, const float* W, const float* bias,
-                          float* gates_out, const void* wpack, int M, int C, int T, int zero_state, leod_stream_t stream);
+                          float* gates_out, const void* wpack, int M, int C, int T, int zero_state, int gates16, leod_stream_t stream);
 /* Backward through time of the same: dh_seq [T,M,C] (optional) gradients of every h_t from above, dc_last [M,C] (optional);
  * writes dgates_out [T,M,4C] (pre-activation; dx = dgates W_x and the weight gradient are one GEMM each over all T*M rows)
  * and optionally dh0 / dc0 [M,C].  LEOD_ERR_UNSUPPORTED (-3) when the weight slice does not fit the registers. */
 int leod_convlstm_seq_bwd(const float* dh_seq, const float* dc_last, const float* gates, const float* cbuf, const float* W,
                           float* dgates_out, float* dh0, float* dc0, const void* wpack, int M, int C, int T, int zero_state,
-                          leod_stream_t stream);
+                          int gates16, leod_stream_t stream);
+/* gates16 (both calls above; precision mode bf16 only, leod_convlstm_seq_gates16_ok(C) != 0): gates_out / gates point to fp16 storage in
+ * the sequence kernels' own lane-linear layout (T x ceil(M / 16) * 16 x 4C halfs, written and read by these two calls only), dgates_out to
+ * bf16 rows [T][M][4C] -- the reference's autocast holds the gates in 16 bits as well (rnn.py:58-62 under train.py:236-243). */
+int leod_convlstm_seq_gates16_ok(int C);
 
 /* dy_bf16 (here and in leod_linear_wgrad / leod_linear_dgrad_lnbwd): dy points to bf16 elements -- in precision mode bf16 the wide
  * gradients du (out_bf16 of leod_linear_dgrad_gelu16) and dqkv are stored as the bf16 their consumers feed to the MFMAs anyway.

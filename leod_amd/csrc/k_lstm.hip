@@ -26,6 +26,41 @@ template <bool FAST> __device__ __forceinline__ float tanh_(float x) {
     else return tanhf(x);
 }
 
+typedef unsigned u4_ __attribute__((ext_vector_type(4)));
+// G16 (precision mode bf16): the post-activation gates -- read back only by the backward kernel of the SAME lane mapping -- are kept
+// as fp16 in an opaque lane-linear layout, 16 halfs (gate-major: f, i, o, g x the lane's four rows) = two 16-byte accesses per lane
+// and channel group, fully coalesced (the [M][4][C] fp32 layout cost sixteen scattered 4-byte stores per lane and timestep); the gate
+// gradients go out as the bf16 [M][4C] rows the LDS exchange tile already holds (their consumers, dx = dgates W_x and the weight
+// gradient, feed them to bf16 MFMAs as they are), copied out with 16-byte stores.  Stage 1 of RVT-S: 1.16 -> 0.83 GB forward,
+// 1.65 -> 0.99 GB backward, and half the bytes in the two GEMMs behind them.
+__device__ __forceinline__ void gates16_store(u4_* dst, const float (&gv)[4][4]) {
+    u2_ h[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) h[g] = __builtin_bit_cast(u2_, pack_h16(f4{gv[g][0], gv[g][1], gv[g][2], gv[g][3]}));
+    dst[0] = u4_{h[0].x, h[0].y, h[1].x, h[1].y};
+    dst[1] = u4_{h[2].x, h[2].y, h[3].x, h[3].y};
+}
+__device__ __forceinline__ void gates16_load(const u4_* src, float (&gv)[4][4]) {
+    const u4_ a = src[0], b = src[1];
+    const u2_ h[4] = {u2_{a.x, a.y}, u2_{a.z, a.w}, u2_{b.x, b.y}, u2_{b.z, b.w}};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f4 v = unpack_h16(__builtin_bit_cast(s4, h[g]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gv[g][r] = v[r];
+    }
+}
+// dgates tile [16][KA] bf16 of the LDS exchange buffer (row stride LD) -> dg16 rows row0 .. of timestep t, 16-byte stores
+template <int KA, int LD, int NTHR>
+__device__ __forceinline__ void dgates16_copy(unsigned short* __restrict__ dg16, const unsigned short* tile, long t, long row0, int M, int tid) {
+    constexpr int U = KA / 8;
+    for (int e = tid; e < 16 * U; e += NTHR) {
+        const int row = e / U, u = e - row * U;
+        if (row0 + row < M)
+            *reinterpret_cast<u4_*>(dg16 + ((t * M + row0 + row) * KA + 8 * u)) = *reinterpret_cast<const u4_*>(tile + row * LD + 8 * u);
+    }
+}
+
 template <bool BF> struct AElem;
 template <> struct AElem<true> { typedef unsigned short T; };
 template <> struct AElem<false> { typedef float T; };
@@ -64,7 +99,7 @@ __device__ __forceinline__ void tile_mfma(f4 (&acc)[NG], const typename AElem<BF
 //   hbuf, cbuf [T+1][M][C]: slot 0 = incoming state (zero_state != 0: treated as zeros and not read), slots 1..T written
 //   W [4C][2C] (gate-major rows f, i, o, g; columns [x | h]), bias [4C]; gates_out [T][M][4][C] post-activation or NULL
 // ---------------------------------------------------------------------------------------------------------------------
-template <int C, bool FX, bool BF>
+template <int C, bool FX, bool BF, bool G16 = false>
 __global__ __launch_bounds__(C * 4) void lstm_seq_fwd_kernel(const float* __restrict__ xin, float* __restrict__ hbuf, float* __restrict__ cbuf,
                                                               const float* __restrict__ W, const float* __restrict__ bias,
                                                               float* __restrict__ gates_out, int M, int T, int zero_state) {
@@ -156,6 +191,7 @@ __global__ __launch_bounds__(C * 4) void lstm_seq_fwd_kernel(const float* __rest
         float* hp = hbuf + (long)(t + 1) * MC;
         float* cp = cbuf + (long)(t + 1) * MC;
         float* gp = gates_out ? gates_out + (long)t * M * 4 * C : nullptr;
+        float gv[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float f = sigmoidf_(acc[0][r] + bg[0]), ig = sigmoidf_(acc[1][r] + bg[1]), o = sigmoidf_(acc[2][r] + bg[2]);
@@ -163,16 +199,19 @@ __global__ __launch_bounds__(C * 4) void lstm_seq_fwd_kernel(const float* __rest
             const float cn = f * cst[r] + ig * g;
             const float hn = o * tanh_<BF>(cn);
             cst[r] = cn;
+            gv[0][r] = f; gv[1][r] = ig; gv[2][r] = o; gv[3][r] = g;
             sA[buf ^ 1][(4 * q + r) * LD + HOFF + ch] = a_elem<BF>(hn);
             if (rok[r]) {
                 hp[oc[r]] = hn;
                 cp[oc[r]] = cn;
-                if (gp) {
+                if (!G16 && gp) {
                     float* gr = gp + (4 * oc[r] - 3 * ch);
                     gr[0] = f; gr[C] = ig; gr[2 * C] = o; gr[3 * C] = g;
                 }
             }
         }
+        if (G16 && gates_out)
+            gates16_store(reinterpret_cast<u4_*>(gates_out) + ((((long)t * gridDim.x + blockIdx.x) * NW + wave) * 64 + lane) * 2, gv);
         if (FX && t + 1 < T) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) sA[buf ^ 1][srow * LD + sc4 + j] = a_elem<BF>(xs[j]);
@@ -190,7 +229,7 @@ __global__ __launch_bounds__(C * 4) void lstm_seq_fwd_kernel(const float* __rest
 //   dh0 / dc0 [M][C] (optional): gradients of the incoming state
 // Per timestep: gate backward (lane-local) -> dgates tile in LDS -> barrier -> dh_{t-1} += dgates_t W_h for the wave's 16 channels.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int C, bool BF>
+template <int C, bool BF, bool G16 = false>
 __global__ __launch_bounds__(C * 4) void lstm_seq_bwd_kernel(const float* __restrict__ dh_seq, const float* __restrict__ dc_last,
                                                               const float* __restrict__ gates, const float* __restrict__ cbuf,
                                                               const float* __restrict__ W, float* __restrict__ dgates_out,
@@ -223,11 +262,14 @@ __global__ __launch_bounds__(C * 4) void lstm_seq_bwd_kernel(const float* __rest
     auto load = [&](In& in, int t) {
         const float* gp = gates + (long)t * M * 4 * C;
         const float* c0 = cbuf + (long)t * MC;
+        if constexpr (G16) gates16_load(reinterpret_cast<const u4_*>(gates) + ((((long)t * gridDim.x + blockIdx.x) * NW + wave) * 64 + lane) * 2, in.g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float* gr = gp + (4 * oc[r] - 3 * ch);
+            if constexpr (!G16) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) in.g[g][r] = gr[g * C];
+                for (int g = 0; g < 4; ++g) in.g[g][r] = gr[g * C];
+            }
             in.cp[r] = (zero_state && t == 0) ? 0.f : c0[oc[r]];
             in.ct[r] = c0[MC + oc[r]];
             in.dh[r] = dh_seq ? dh_seq[(long)t * MC + oc[r]] : 0.f;
@@ -252,12 +294,13 @@ __global__ __launch_bounds__(C * 4) void lstm_seq_bwd_kernel(const float* __rest
             dcn[r] = dc * f;
             AT* ar = &sA[buf][(4 * q + r) * LD + ch];
             ar[0] = a_elem<BF>(d0); ar[C] = a_elem<BF>(d1); ar[2 * C] = a_elem<BF>(d2); ar[3 * C] = a_elem<BF>(d3);
-            if (rok[r]) {
+            if (!G16 && rok[r]) {
                 float* dr = dgp + (4 * oc[r] - 3 * ch);
                 dr[0] = d0; dr[C] = d1; dr[2 * C] = d2; dr[3 * C] = d3;
             }
         }
         __syncthreads();
+        if constexpr (G16 && BF) dgates16_copy<KA, LD, C * 4>(reinterpret_cast<unsigned short*>(dgates_out), reinterpret_cast<const unsigned short*>(sA[buf]), t, row0, M, tid);
         f4 acc[1] = {zero4()};
         tile_mfma<KC, 1, BF, BT>(acc, &sA[buf][i * LD + 4 * q], bw);
 #pragma unroll
@@ -307,7 +350,7 @@ __global__ __launch_bounds__(256) void lstm_pack_kernel(const float* __restrict_
     }
 }
 
-template <int C>
+template <int C, bool G16 = false>
 __global__ __launch_bounds__(C * 2) void lstm_seq_fwd_stream_kernel(const float* __restrict__ gxin, float* __restrict__ hbuf, float* __restrict__ cbuf,
                                                                      const s8v* __restrict__ wpf, float* __restrict__ gates_out, int M, int T,
                                                                      int zero_state) {
@@ -381,6 +424,7 @@ __global__ __launch_bounds__(C * 2) void lstm_seq_fwd_stream_kernel(const float*
                     for (int g = 0; g < 4; ++g) acc[g] = mfma32_bf16(a, bb[bt & 1][k][g], acc[g]);
                 }
             }
+            float gv[4][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float f = sigmoidf_(acc[0][r]), ig = sigmoidf_(acc[1][r]), o = sigmoidf_(acc[2][r]);
@@ -388,22 +432,25 @@ __global__ __launch_bounds__(C * 2) void lstm_seq_fwd_stream_kernel(const float*
                 const float cn = f * cst[grp][r] + ig * g;
                 const float hn = o * tanh_<true>(cn);
                 cst[grp][r] = cn;
+                gv[0][r] = f; gv[1][r] = ig; gv[2][r] = o; gv[3][r] = g;
                 sA[buf ^ 1][(4 * q + r) * LD + ch] = to_bf16(hn);
                 if (rok[r]) {
                     hp[ocg[r]] = hn;
                     cp[ocg[r]] = cn;
-                    if (go) {
+                    if (!G16 && go) {
                         float* gr = go + (4u * ocg[r] - 3u * ch);
                         gr[0] = f; gr[C] = ig; gr[2 * C] = o; gr[3 * C] = g;
                     }
                 }
             }
+            if (G16 && gates_out)
+                gates16_store(reinterpret_cast<u4_*>(gates_out) + (((((long)t * gridDim.x + blockIdx.x) * (C / 32) + wave) * 2 + grp) * 64 + lane) * 2, gv);
         }
         __syncthreads();
     }
 }
 
-template <int C>
+template <int C, bool G16 = false>
 __global__ __launch_bounds__(C * 2) void lstm_seq_bwd_stream_kernel(const float* __restrict__ dh_seq, const float* __restrict__ dc_last,
                                                                      const float* __restrict__ gates, const float* __restrict__ cbuf,
                                                                      const s8v* __restrict__ wpb, float* __restrict__ dgates_out,
@@ -440,11 +487,14 @@ __global__ __launch_bounds__(C * 2) void lstm_seq_bwd_stream_kernel(const float*
         for (int grp = 0; grp < 2; ++grp) {
             const unsigned ch = 32 * wave + 16 * grp + i;
             float gg[4][4], cpv[4], ctv[4], dhv[4];
+            if constexpr (G16) gates16_load(reinterpret_cast<const u4_*>(gates) + (((((long)t * gridDim.x + blockIdx.x) * (C / 32) + wave) * 2 + grp) * 64 + lane) * 2, gg);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float* gr = gp + (4u * oc[grp][r] - 3u * ch);
+                if constexpr (!G16) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) gg[g][r] = gr[g * C];
+                    for (int g = 0; g < 4; ++g) gg[g][r] = gr[g * C];
+                }
                 cpv[r] = c0[oc[grp][r]];
                 ctv[r] = c0[MC + oc[grp][r]];
                 dhv[r] = dh_seq ? dh_seq[(long)t * MC + oc[grp][r]] : 0.f;
@@ -460,13 +510,14 @@ __global__ __launch_bounds__(C * 2) void lstm_seq_bwd_stream_kernel(const float*
                 dcn[grp][r] = dc * f;
                 unsigned short* ar = &sA[buf][(4 * q + r) * LD + ch];
                 ar[0] = to_bf16(d0); ar[C] = to_bf16(d1); ar[2 * C] = to_bf16(d2); ar[3 * C] = to_bf16(d3);
-                if (rok[r]) {
+                if (!G16 && rok[r]) {
                     float* dr = dgp + (4u * oc[grp][r] - 3u * ch);
                     dr[0] = d0; dr[C] = d1; dr[2 * C] = d2; dr[3 * C] = d3;
                 }
             }
         }
         __syncthreads();
+        if constexpr (G16) dgates16_copy<KA, LD, C * 2>(reinterpret_cast<unsigned short*>(dgates_out), sA[buf], t, row0, M, tid);
         // dh_{t-1}[rows, own 32 channels] = dgates_t [16 x 4C] . W_h[4C x 32]: A fragments shared by the two channel groups
         f4 acc[2] = {zero4(), zero4()};
         s8v bb[2][NB][2];
@@ -523,10 +574,21 @@ LEOD_API int leod_convlstm_seq_mode(int C) {
 
 #define LSTM_FWD_CASE(CV, FXV)                                                                                                  \
     if (C == CV && fx == FXV) {                                                                                                 \
-        if (bf) hipLaunchKernelGGL((lstm_seq_fwd_kernel<CV, FXV, true>), grid, dim3(CV * 4), 0, stream, xin, hbuf, cbuf, W, bias, gates_out, M, T, zero_state); \
+        if (bf && gates16) hipLaunchKernelGGL((lstm_seq_fwd_kernel<CV, FXV, true, true>), grid, dim3(CV * 4), 0, stream, xin, hbuf, cbuf, W, bias, gates_out, M, T, zero_state); \
+        else if (bf) hipLaunchKernelGGL((lstm_seq_fwd_kernel<CV, FXV, true>), grid, dim3(CV * 4), 0, stream, xin, hbuf, cbuf, W, bias, gates_out, M, T, zero_state); \
         else hipLaunchKernelGGL((lstm_seq_fwd_kernel<CV, FXV, false>), grid, dim3(CV * 4), 0, stream, xin, hbuf, cbuf, W, bias, gates_out, M, T, zero_state);  \
         return leod_launch_status();                                                                                            \
     }
+
+// 1: the sequence kernels of this channel count keep the gates as fp16 (opaque layout, T x ceil(M / 16) * 16 x 4C halfs) and write the
+// gate gradients as bf16 rows [T][M][4C] when asked to (gates16 of leod_convlstm_seq_fwd / _bwd); 0: fp32 tensors only
+LEOD_API int leod_convlstm_seq_gates16_ok(int C) {
+    static const int on = getenv("LEOD_LSTM_G16") ? atoi(getenv("LEOD_LSTM_G16")) : 1;
+    if (!on || leod_precision() != 1) return 0;
+    const int mode = leod_convlstm_seq_mode(C);
+    if (mode == 3) return 1;
+    return mode != 0 && (4 * C / 16) * 2 <= (C >= 192 ? 96 : 128);         // the backward sequence kernel must exist as well
+}
 
 // bytes of the packed bf16 weight copy mode 3 needs (0 otherwise)
 LEOD_API long leod_convlstm_seq_pack_bytes(int C) { return leod_convlstm_seq_mode(C) == 3 ? (long)2 * 4 * C * C * 2 : 0; }
@@ -540,7 +602,8 @@ LEOD_API int leod_convlstm_seq_pack(const float* W, void* wpack, int C, hipStrea
 }
 
 LEOD_API int leod_convlstm_seq_fwd(const float* xin, int x_is_projection, float* hbuf, float* cbuf, const float* W, const float* bias,
-                                   float* gates_out, const void* wpack, int M, int C, int T, int zero_state, hipStream_t stream) {
+                                   float* gates_out, const void* wpack, int M, int C, int T, int zero_state, int gates16, hipStream_t stream) {
+    if (gates16 && !leod_convlstm_seq_gates16_ok(C)) return LEOD_ERR_ARG;
     if (!xin || !hbuf || !cbuf || !W || !bias || M <= 0 || T <= 0 || (long)M * 4 * C >= (1L << 31)) return LEOD_ERR_ARG;
     const int mode = leod_convlstm_seq_mode(C);
     if (mode == 0 || (mode == 1) != (x_is_projection == 0)) return LEOD_ERR_UNSUPPORTED;
@@ -548,7 +611,9 @@ LEOD_API int leod_convlstm_seq_fwd(const float* xin, int x_is_projection, float*
         if (!wpack) return LEOD_ERR_ARG;
         const s8v* wpf = reinterpret_cast<const s8v*>(wpack);
         const dim3 g3(cdiv(M, 16));
-        if (C == 384) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<384>), g3, dim3(768), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
+        if (C == 384 && gates16) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<384, true>), g3, dim3(768), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
+        else if (C == 384) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<384>), g3, dim3(768), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
+        else if (gates16) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<256, true>), g3, dim3(512), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
         else hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<256>), g3, dim3(512), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
         return leod_launch_status();
     }
@@ -561,21 +626,25 @@ LEOD_API int leod_convlstm_seq_fwd(const float* xin, int x_is_projection, float*
 
 #define LSTM_BWD_CASE(CV)                                                                                                       \
     if (C == CV) {                                                                                                              \
-        if (bf) hipLaunchKernelGGL((lstm_seq_bwd_kernel<CV, true>), grid, dim3(CV * 4), 0, stream, dh_seq, dc_last, gates, cbuf, W, dgates_out, dh0, dc0, M, T, zero_state); \
+        if (bf && gates16) hipLaunchKernelGGL((lstm_seq_bwd_kernel<CV, true, true>), grid, dim3(CV * 4), 0, stream, dh_seq, dc_last, gates, cbuf, W, dgates_out, dh0, dc0, M, T, zero_state); \
+        else if (bf) hipLaunchKernelGGL((lstm_seq_bwd_kernel<CV, true>), grid, dim3(CV * 4), 0, stream, dh_seq, dc_last, gates, cbuf, W, dgates_out, dh0, dc0, M, T, zero_state); \
         else hipLaunchKernelGGL((lstm_seq_bwd_kernel<CV, false>), grid, dim3(CV * 4), 0, stream, dh_seq, dc_last, gates, cbuf, W, dgates_out, dh0, dc0, M, T, zero_state);  \
         return leod_launch_status();                                                                                            \
     }
 
 LEOD_API int leod_convlstm_seq_bwd(const float* dh_seq, const float* dc_last, const float* gates, const float* cbuf, const float* W,
                                    float* dgates_out, float* dh0, float* dc0, const void* wpack, int M, int C, int T, int zero_state,
-                                   hipStream_t stream) {
+                                   int gates16, hipStream_t stream) {
+    if (gates16 && !leod_convlstm_seq_gates16_ok(C)) return LEOD_ERR_ARG;
     if (!gates || !cbuf || !W || !dgates_out || M <= 0 || T <= 0 || (long)M * 4 * C >= (1L << 31)) return LEOD_ERR_ARG;
     const bool bf = leod_precision() == 1;
     if (leod_convlstm_seq_mode(C) == 3) {
         if (!wpack) return LEOD_ERR_ARG;
         const s8v* wpb = reinterpret_cast<const s8v*>(wpack) + (long)C * C / 2;
         const dim3 g3(cdiv(M, 16));
-        if (C == 384) hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<384>), g3, dim3(768), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
+        if (C == 384 && gates16) hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<384, true>), g3, dim3(768), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
+        else if (C == 384) hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<384>), g3, dim3(768), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
+        else if (gates16) hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<256, true>), g3, dim3(512), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
         else hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<256>), g3, dim3(512), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
         return leod_launch_status();
     }

@@ -356,9 +356,11 @@ class ConvLSTMSeqFn(Function):
         else:
             hbuf[0].copy_(h0)
             cbuf[0].copy_(c0)
-        gates = x_seq.new_empty((T, M, 4, C)) if need else None
         W2 = w.view(4 * C, 2 * C)
         mode = ops.convlstm_seq_mode(C)
+        # precision mode bf16 + sequence kernels: gates as fp16 in the kernels' own layout, gate gradients as bf16 rows
+        g16 = bool(mode) and ops.convlstm_gates16_ok(C)
+        gates = (ops.convlstm_gates16_buffer(T, M, C, x_seq.device) if g16 else x_seq.new_empty((T, M, 4, C))) if need else None
         wpack = None
         if mode:
             # ONE launch for the whole recurrence (csrc/k_lstm.hip); modes 2 / 3: the x projection of all timesteps is one large GEMM;
@@ -389,13 +391,16 @@ class ConvLSTMSeqFn(Function):
         M = x_seq[0].numel() // C
         W2 = w.view(4 * C, 2 * C)
         dh_seq = _cont(dh_seq)
-        dgates = x_seq.new_empty((T, M, 4 * C))
+        g16 = gates.dtype is torch.float16
+        dgates = torch.empty((T, M, 4 * C), dtype=torch.bfloat16 if g16 else torch.float32, device=x_seq.device)
         need_h0, need_c0 = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
         dh0 = x_seq.new_empty(x_seq.shape[1:]) if need_h0 else None
         dc0 = x_seq.new_empty(x_seq.shape[1:]) if need_c0 else None
         mode = ops.convlstm_seq_mode(C)
         wpack = ctx.wpack if mode == 3 and ctx.wpack is not None else (ops.convlstm_seq_pack(W2, C) if mode == 3 else None)
-        if mode and ops.convlstm_seq_bwd(dh_seq, _cont(dc_last), gates, cbuf, W2, dgates, dh0, dc0, wpack=wpack):
+        seq_ok = bool(mode) and ops.convlstm_seq_bwd(dh_seq, _cont(dc_last), gates, cbuf, W2, dgates, dh0, dc0, wpack=wpack)
+        assert seq_ok or not g16, 'fp16 gates are only written when the backward sequence kernel exists'
+        if seq_ok:
             # backward through time in one launch; dx of all timesteps is ONE GEMM dgates W_x over T*M rows
             dx_seq = ops.linear_dgrad(dgates.view(T * M, 4 * C), W2[:, :C].contiguous()).view(x_seq.shape)
             dh_next, dc_next = dh0, dc0

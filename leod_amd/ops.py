@@ -252,29 +252,43 @@ def convlstm_seq_pack(W, C: int):
     return wp
 
 
+def convlstm_gates16_ok(C: int) -> bool:
+    """Precision mode bf16: the sequence kernels keep the gates as fp16 (their own layout) and emit bf16 gate-gradient rows."""
+    return bool(_l().leod_convlstm_seq_gates16_ok(int(C)))
+
+
+def convlstm_gates16_buffer(T: int, M: int, C: int, device):
+    """fp16 gate storage for convlstm_seq_fwd / _bwd (opaque layout: only those two calls read it)."""
+    return torch.empty((T, (M + 15) // 16 * 16, 4, C), dtype=torch.float16, device=device)
+
+
 def convlstm_seq_fwd(xin, is_projection, hbuf, cbuf, W, bias, gates_out, zero_state, wpack=None):
     """The whole recurrence in one launch: xin [T,M,C] (or gx [T,M,4C]), hbuf / cbuf [T+1,M,C] (slot 0 = incoming state,
-    slots 1.. written), W [4C,2C], gates_out [T,M,4,C] | None."""
-    for t, n in ((xin, 'xin'), (hbuf, 'hbuf'), (cbuf, 'cbuf'), (W, 'W'), (bias, 'bias'), (gates_out, 'gates_out')):
+    slots 1.. written), W [4C,2C], gates_out [T,M,4,C] fp32 | convlstm_gates16_buffer(...) | None."""
+    g16 = gates_out is not None and gates_out.dtype is torch.float16
+    for t, n in ((xin, 'xin'), (hbuf, 'hbuf'), (cbuf, 'cbuf'), (W, 'W'), (bias, 'bias')):
         _ck(t, name=n)
+    _ck(gates_out, torch.float16 if g16 else F32, 'gates_out')
     T = hbuf.shape[0] - 1
     C = hbuf.shape[-1]
     M = hbuf[0].numel() // C
     check(_l().leod_convlstm_seq_fwd(_p(xin), 1 if is_projection else 0, _p(hbuf), _p(cbuf), _p(W), _p(bias), _p(gates_out), _p(wpack),
-                                      M, C, T, 1 if zero_state else 0, _stream()), 'convlstm_seq_fwd')
+                                      M, C, T, 1 if zero_state else 0, 1 if g16 else 0, _stream()), 'convlstm_seq_fwd')
 
 
 def convlstm_seq_bwd(dh_seq, dc_last, gates, cbuf, W, dgates_out, dh0=None, dc0=None, zero_state=False, wpack=None) -> bool:
     """Backward through time in one launch -> dgates_out [T,M,4C] (+ dh0, dc0).  False: the weight slice does not fit the registers
     for this C / precision mode (the caller then runs the per-timestep kernels on the same saved tensors)."""
-    for t, n in ((dh_seq, 'dh_seq'), (dc_last, 'dc_last'), (gates, 'gates'), (cbuf, 'cbuf'), (W, 'W'), (dgates_out, 'dgates_out'),
-                 (dh0, 'dh0'), (dc0, 'dc0')):
+    g16 = gates.dtype is torch.float16
+    for t, n in ((dh_seq, 'dh_seq'), (dc_last, 'dc_last'), (cbuf, 'cbuf'), (W, 'W'), (dh0, 'dh0'), (dc0, 'dc0')):
         _ck(t, name=n)
+    _ck(gates, torch.float16 if g16 else F32, 'gates')
+    _ck(dgates_out, torch.bfloat16 if g16 else F32, 'dgates_out')
     T = cbuf.shape[0] - 1
     C = cbuf.shape[-1]
     M = cbuf[0].numel() // C
     rc = _l().leod_convlstm_seq_bwd(_p(dh_seq), _p(dc_last), _p(gates), _p(cbuf), _p(W), _p(dgates_out), _p(dh0), _p(dc0), _p(wpack),
-                                    M, C, T, 1 if zero_state else 0, _stream())
+                                    M, C, T, 1 if zero_state else 0, 1 if g16 else 0, _stream())
     if rc == -3:
         return False
     check(rc, 'convlstm_seq_bwd')
