@@ -142,6 +142,39 @@ def test_detector_head_golden_and_grads(gpu, golden_dir, manifest):
     np.testing.assert_allclose(mine, g['grad_norms'], rtol=2e-3, atol=1e-6)
 
 
+def test_head_level_streams_equal_single_stream(gpu, manifest, monkeypatch):
+    """The per-level HIP streams of the head towers (yolo_head._towers_streams) only reorder independent launches: predictions,
+    losses, BatchNorm buffers and every gradient are bit-identical to the grouped single-stream path, repeated to catch a race."""
+    from leod_amd.models.detection.yolox.models import yolo_head as yh
+
+    def rnd(shape, seed):
+        return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+    feats_cpu = {2: rnd((3, 32, 8, 12), 51), 3: rnd((3, 64, 4, 6), 52), 4: rnd((3, 128, 2, 3), 53)}
+    targets = op.batched_yolox_labels(micro_labels(3, seed=7))
+
+    def run(streams):
+        monkeypatch.setattr(yh, '_LEVEL_STREAMS', streams)
+        det, _, _ = build(manifest, 'micro', 5, 'small', micro=True)
+        det.train()
+        fg = {k: v.to(DEV).requires_grad_(True) for k, v in feats_cpu.items()}
+        pred, losses = det.forward_detect(fg, targets=targets.to(DEV))
+        losses['loss'].backward()
+        torch.cuda.synchronize()
+        out = {'pred': pred.detach().clone(), 'loss': losses['loss'].detach().clone()}
+        out.update({'g.' + k: v.grad.clone() for k, v in det.named_parameters() if v.grad is not None})
+        out.update({f'gf.{k}': v.grad.clone() for k, v in fg.items()})
+        out.update({'b.' + k: v.clone() for k, v in det.state_dict().items() if 'running_' in k})
+        return out
+
+    ref = run(False)
+    for _ in range(3):
+        got = run(True)
+        assert got.keys() == ref.keys()
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), k
+
+
 def test_backbone_backward_vs_oracle(gpu, manifest):
     """Gradients of a 3-step unrolled micro backbone (states carried, features of every stage used)."""
     det, sd, _ = build(manifest, 'micro', 5, 'small', micro=True, train=True)
