@@ -117,6 +117,13 @@ int leod_convlstm_seq_gates16_ok(int C);
 int leod_linear_dgrad(const float* dy, long lddy, const float* kscale, const float* W, float* dx, long lddx, float* dx2,
                       long lddx2, int nsplit, const float* aux_u, float* colsum, int accumulate, const float* dres, int M, int N,
                       int K, int dy_bf16, leod_stream_t stream);
+/* Workspace of the weight-gradient calls below for launches on `stream` (precision mode bf16: the per-workgroup partial tiles that a second
+ * kernel adds up -- 1024 workgroups adding to the same dW addresses with atomics were 130 us of a 200 us launch): leod_workspace_bytes()
+ * bytes, 16-byte aligned, owned by the caller and kept alive until replaced (ws == NULL withdraws it).  Without a registered workspace
+ * the library allocates one per stream on first use, or falls back to the atomic epilogue while the stream is being captured.
+ * (No counterpart in the reference: torch's autograd owns the cuBLAS workspaces there.) */
+long leod_workspace_bytes(void);
+int leod_set_workspace(void* ws, long bytes, leod_stream_t stream);
 /* dW[N,K] += dy^T X ; dbias[N] += colsum(dy) ; X = x, LN(x) (stats, ln_w, ln_b) or [x | x2] (K1 = cols of x). */
 int leod_linear_wgrad(const float* dy, long lddy, const float* x, long ldx, const float* stats, const float* ln_w,
                       const float* ln_b, const float* x2, long ldx2, int K1, float* dW, float* dbias, int M, int N,

@@ -4,6 +4,7 @@
 #include <type_traits>
 
 #include "gemm16.hpp"
+#include "wgrad_bf16.hpp"
 
 static inline int pick_nt(int N) {
     int best = 1; long bestpad = 1L << 60;
@@ -620,6 +621,15 @@ LEOD_API int leod_linear_dgrad(const float* dy, long lddy, const float* kscale, 
     return rc;
 }
 
+// Workspace of the weight-gradient kernels for launches on `stream` (wgrad_bf16.hpp: partial tiles, leod_workspace_bytes() bytes, 16-byte
+// aligned, caller-owned and alive until replaced; ws == NULL withdraws it).
+LEOD_API long leod_workspace_bytes() { return (long)kWgwScratchBytes; }
+LEOD_API int leod_set_workspace(void* ws, long bytes, hipStream_t stream) {
+    if (ws && (bytes <= 0 || (reinterpret_cast<uintptr_t>(ws) & 15))) return LEOD_ERR_ARG;
+    wgrad_wide_register_scratch(stream, ws, (size_t)(bytes > 0 ? bytes : 0));
+    return LEOD_OK;
+}
+
 // dW[N,K] += dy[M,N]^T @ X[M,K] ; dbias[N] += colsum(dy)  with X = x, LN(x) (stats + ln_w/ln_b) or [x | x2]
 LEOD_API int leod_linear_wgrad(const float* dy, long lddy, const float* x, long ldx, const float* stats,
                                const float* ln_w, const float* ln_b, const float* x2, long ldx2, int K1,
@@ -627,6 +637,7 @@ LEOD_API int leod_linear_wgrad(const float* dy, long lddy, const float* x, long 
     if (!dy || !x || !dW) return LEOD_ERR_ARG;
     XRows xl{x, ldx, stats, ln_w, ln_b, x2, ldx2, K1};
     const int df = dy_bf16 ? 1 : 0;
+    if (use_wgrad_wide(xl, lddy, M, N, K, df)) return launch_wgrad_wide(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, df);
     if (use_wgradw(M)) return launch_wgradw(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, df);
     if (N % 48 == 0 && K % 48 == 0) return launch_wgrad16<3, 3>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, df);
     if (N % 32 == 0 && K % 32 == 0 && (N % 64 || K % 64)) return launch_wgrad16<2, 2>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, df);
@@ -801,6 +812,7 @@ LEOD_API int leod_linear_wgrad_gelu16(const float* dy, long lddy, const void* u1
                                       hipStream_t stream) {
     if (!dy || !u16 || !dW) return LEOD_ERR_ARG;
     XRows xl{reinterpret_cast<const float*>(u16), (long)K, nullptr, nullptr, nullptr, nullptr, 0, 0, 1};
+    if (use_wgrad_wide(xl, lddy, M, N, K, 0)) return launch_wgrad_wide(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, 0);
     if (use_wgradw(M)) return launch_wgradw(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);
     if (N % 48 == 0 && K % 48 == 0) return launch_wgrad16<3, 3>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);
     return launch_wgrad16<4, 4>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);

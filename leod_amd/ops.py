@@ -342,6 +342,19 @@ def _linear_dgrad(dy, W, kscale, aux_u, colsum, out, accumulate, split, out2, dr
     return (out, out2) if split else out
 
 
+_WORKSPACES = {}     # raw stream -> uint8 tensor registered as that stream's weight-gradient workspace (kept alive here)
+
+
+def _wgrad_workspace(device):
+    """The partial-tile scratch of the wide weight-gradient kernel (wgrad_bf16.hpp), one per stream, from torch's allocator -- which also
+    serves a stream under graph capture, where the library could not allocate for itself."""
+    s = _stream()
+    if s not in _WORKSPACES:
+        ws = torch.empty(int(_l().leod_workspace_bytes()), dtype=torch.uint8, device=device)
+        check(_l().leod_set_workspace(ws.data_ptr(), ws.numel(), s), 'set_workspace')
+        _WORKSPACES[s] = ws
+
+
 def linear_wgrad(dy, x, dW, dbias=None, stats=None, ln_w=None, ln_b=None, x2=None):
     """dW += dy^T X ; dbias += colsum(dy).  X = x | LN(x) | [x|x2]."""
     dy16 = dy.dtype is torch.bfloat16
@@ -352,18 +365,20 @@ def linear_wgrad(dy, x, dW, dbias=None, stats=None, ln_w=None, ln_b=None, x2=Non
     K = dW.numel() // N
     M = dy.numel() // N
     K1 = x.shape[-1]
+    if M >= 8192 and _stream() not in _WORKSPACES and get_precision() == 'bf16':
+        _wgrad_workspace(dW.device)
     if x.dtype is torch.float16:                             # X = gelu(x): x is the fp16 pre-activation of the MLP hidden
         _ck(x, torch.float16, 'x')
         if stats is not None or x2 is not None or dy16:
             raise LeodHipError('linear_wgrad: LayerNorm / concat / bf16-dy options do not combine with an fp16 pre-activation')
-        ev = _probe('linear_wgrad', 4.0 * (M * N + N * K) + 2.0 * M * K, 2.0 * M * N * K)
+        ev = _probe('linear_wgrad', 4.0 * (M * N + N * K) + 2.0 * M * K, 2.0 * M * N * K, rows=M)
         check(_l().leod_linear_wgrad_gelu16(_p(dy), N, _p(x), _p(dW), _p(dbias), M, N, K, _stream()), 'linear_wgrad_gelu16')
         if ev is not None:
             ev.record()
         return
     _ck(x, name='x')
     # algorithmic work of one launch: reads dy, X once, read-modify-writes dW once; 2*M*N*K flops
-    ev = _probe('linear_wgrad', (2.0 if dy16 else 4.0) * M * N + 4.0 * (M * K + N * K), 2.0 * M * N * K)
+    ev = _probe('linear_wgrad', (2.0 if dy16 else 4.0) * M * N + 4.0 * (M * K + N * K), 2.0 * M * N * K, rows=M)
     check(_l().leod_linear_wgrad(_p(dy), N, _p(x), K1, _p(stats), _p(ln_w), _p(ln_b), _p(x2),
                                   (x2.shape[-1] if x2 is not None else 0), K1, _p(dW), _p(dbias), M, N, K, 1 if dy16 else 0, _stream()),
           'linear_wgrad')
@@ -776,7 +791,8 @@ _PROBE = None
 class KernelProbe:
     """Brackets every launch of the probed kernel FAMILIES with HIP events on the launch stream (torch's current stream is
     the stream every leod_* call is enqueued on) and tallies their algorithmic bytes / flops:
-    achieved GB/s = sum(bytes) / sum(event time).  Families: ``linear_wgrad`` (the weight-gradient GEMM ``wgradw_kernel``, the largest
+    achieved GB/s = sum(bytes) / sum(event time).  Families: ``linear_wgrad`` (the weight-gradient GEMM of the Linear layers -- ``wgrad_wide_bf16_kernel`` and its reduce kernel in precision mode
+    bf16, ``wgradw_kernel`` in f32 mode -- the largest
     single kernel family of the training step) and ``linear_gemm`` (forward / dgrad GEMMs of the Linear layers: row-streaming,
     LDS-staged and wide-tile kernels).  With ``families=True`` every C entry point is bracketed as well (``family_ms``): the
     benchmark line then carries its own per-family time table."""
@@ -784,21 +800,24 @@ class KernelProbe:
     def __init__(self, targets=('linear_wgrad', 'linear_gemm'), kernel_names=None, families=True):
         global _PROBE, _LIB
         self.targets = tuple(targets)
-        self.kernel_names = kernel_names or {'linear_wgrad': 'wgradw_kernel<.., XRows>',
+        self.kernel_names = kernel_names or {'linear_wgrad': 'wgrad_wide_bf16_kernel + wgrad_wide_reduce_kernel (bf16 mode) / wgradw_kernel<.., XRows> (f32 mode)',
                                              'linear_gemm': 'rowstream* / gemm_lds_kernel / gemm_wide_bf16_kernel (Linear forward + dgrad)'}
         self.events = {t: [] for t in self.targets}
         self.bytes = {t: 0.0 for t in self.targets}
         self.flops = {t: 0.0 for t in self.targets}
         self.fam_events = {}
+        self.by_rows = {}
         self.real_lib = _l()
         if families:
             _LIB = _ProbedLib(self.real_lib, self)
         _PROBE = self
 
-    def begin(self, target, nbytes, flops=0.0):
+    def begin(self, target, nbytes, flops=0.0, rows=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         self.events[target].append((e0, e1))
+        if rows is not None:
+            self.by_rows.setdefault(target, {}).setdefault(int(rows), []).append((e0, e1, nbytes, flops))
         self.bytes[target] += nbytes
         self.flops[target] += flops
         return e1
@@ -836,6 +855,16 @@ class KernelProbe:
                'flop_per_byte': round(intensity, 2), 'ridge_flop_per_byte': round(ridge, 2),
                'hbm_achieved_GBs': round(gbs, 2), 'hbm_frac': round(gbs / peak_gbs, 5),
                'mfma_achieved_TFLOPs': round(tfl, 2), 'mfma_frac': round(tfl / peak_tflops, 5), 'traffic': None}
+        # the same family split by the row count of the launch (= the stage of the backbone): the long row ranges of stages 1-2 are
+        # the HBM-bound launches, the short ones of stages 3-4 carry the same flops on 1/4 - 1/16 of the bytes
+        if target in self.by_rows:
+            split = []
+            for rows, evs in sorted(self.by_rows[target].items(), reverse=True):
+                t = sum(a.elapsed_time(b) for a, b, _, _ in evs) * 1e-3
+                by, fl = sum(e[2] for e in evs), sum(e[3] for e in evs)
+                split.append({'rows': rows, 'launches': len(evs), 'avg_us': round(1e6 * t / len(evs), 1), 'hbm_GBs': round(by / t / 1e9, 1),
+                              'hbm_frac': round(by / t / 1e9 / peak_gbs, 4), 'mfma_TFLOPs': round(fl / t / 1e12, 1)})
+            out['by_rows'] = split
         if intensity >= ridge:
             out.update(bound='mfma', achieved=round(tfl, 2), peak=peak_tflops, unit='TFLOP/s', frac=round(tfl / peak_tflops, 5))
         else:
@@ -869,7 +898,7 @@ class _ProbedLib:
         return fn
 
 
-def _probe(name, nbytes, flops=0.0):
+def _probe(name, nbytes, flops=0.0, rows=None):
     if _PROBE is not None and name in _PROBE.targets:
-        return _PROBE.begin(name, nbytes, flops)
+        return _PROBE.begin(name, nbytes, flops, rows)
     return None

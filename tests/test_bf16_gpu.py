@@ -239,6 +239,56 @@ def test_mlp_hidden_stored_once_as_fp16(bf16_ops, M, C):
     tk.close(db, (dz * g).sum(0), what='fc2 bias gradient')
 
 
+# (tile of wgrad_bf16.hpp, dY format, X mode): every instantiation of the wide weight-gradient kernel, ragged row counts, a second launch
+# accumulating on the first, and column counts below the tile width
+@pytest.mark.parametrize('M,N,K,dy16,xmode', [
+    (8200, 48, 48, False, 'rows'), (40009, 48, 48, False, 'rows'),            # 48 x 48: proj, stage 1
+    (8193, 144, 48, True, 'ln'), (40009, 192, 48, True, 'ln'),                # 192 x 48: qkv / fc1, stage 1
+    (8200, 48, 192, False, 'gelu16'), (33001, 32, 160, False, 'gelu16'),      # 48 x 192: fc2, stage 1
+    (20011, 96, 96, False, 'rows'), (9001, 192, 192, False, 'rows'),          # 96 x 96 tiles: proj
+    (20011, 288, 96, True, 'ln'), (8705, 768, 192, True, 'ln'),               # qkv / fc1
+    (12000, 96, 384, False, 'gelu16'), (8300, 192, 768, False, 'gelu16'),     # fc2
+    (20011, 384, 192, True, 'concat'), (8705, 768, 384, True, 'concat'),      # ConvLSTM 1x1 on [x | h] with bf16 gate gradients
+    (20011, 384, 192, False, 'concat'),
+])
+def test_wgrad_wide_bf16(bf16_ops, M, N, K, dy16, xmode):
+    import torch.nn.functional as F
+    ops = bf16_ops
+    dy = tk.rnd((M, N), 21)
+    if dy16:
+        dy = dy.to(torch.bfloat16).float()
+    d = lambda t: t.detach().to(tk.DEV)  # noqa
+    dW, db = torch.zeros((N, K), device=tk.DEV), torch.zeros((N,), device=tk.DEV)
+    dyd = d(dy).to(torch.bfloat16) if dy16 else d(dy)
+    if xmode == 'rows':
+        x = tk.rnd((M, K), 22)
+        X = x
+        call = lambda: ops.linear_wgrad(dyd, d(x), dW, db)  # noqa
+    elif xmode == 'ln':
+        x = 0.3 + 1.5 * tk.rnd((M, K), 22)
+        lw, lb = 1 + 0.2 * tk.rnd((K,), 23), 0.1 * tk.rnd((K,), 24)
+        X = F.layer_norm(x, (K,), lw, lb, 1e-5)
+        _, st = ops.layernorm_fwd(d(x), d(lw), d(lb), want_stats=True)
+        call = lambda: ops.linear_wgrad(dyd, d(x), dW, db, stats=st, ln_w=d(lw), ln_b=d(lb))  # noqa
+    elif xmode == 'gelu16':
+        u16 = tk.rnd((M, K), 22).to(torch.float16)
+        X = F.gelu(u16.float())
+        ud = d(u16)
+        call = lambda: ops.linear_wgrad(dyd, ud, dW, db)  # noqa
+    else:
+        K1 = K // 2
+        x, h = tk.rnd((M, K1), 22), tk.rnd((M, K - K1), 25)
+        X = torch.cat([x, h], 1)
+        call = lambda: ops.linear_wgrad(dyd, d(x), dW, db, x2=d(h))  # noqa
+    ref_w, ref_b = dy.double().t() @ X.double(), dy.double().sum(0)
+    call()
+    tk.close(dW, ref_w.float(), what=f'dW {M}x{N}x{K} {xmode}')
+    tk.close(db, ref_b.float(), what='dbias')
+    call()
+    tk.close(dW, 2 * ref_w.float(), what='dW accumulates')
+    tk.close(db, 2 * ref_b.float(), what='dbias accumulates')
+
+
 # (C = 384 runs the per-timestep kernels in either mode: covered by test_convlstm_bf16 above)
 @pytest.mark.parametrize('T,B,H,W,C,state', [(4, 1, 7, 10, 48, True), (3, 2, 8, 10, 32, False), (5, 4, 16, 40, 96, True), (3, 2, 16, 20, 192, True),
                                              (21, 2, 16, 20, 48, True), (21, 1, 8, 10, 192, True),

@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM traffic of the roofline kernel (wgradw_kernel<.., XRows>) from rocprofv3 PMC passes over bench.py, both precision modes:
+# HBM traffic of the roofline kernel family (Linear weight gradients: wgrad_wide_bf16_kernel + wgrad_wide_reduce_kernel / wgradw_kernel<.., XRows>) from rocprofv3 PMC passes over bench.py, both precision modes:
 # FETCH_SIZE and WRITE_SIZE in SEPARATE runs with --kernel-trace only (pool rule), summarised by tools/roofline_traffic.py into
 # gpurun_out/traffic/{bf16,f32}.{json,csv}.  usage (GPU box): bash tools/pmc_bench_traffic.sh
 set -u
@@ -13,6 +13,6 @@ for DT in bf16 f32; do
     timeout 600 rocprofv3 --kernel-trace --pmc $C -d $D -o p -- python $ROOT/bench.py --steps 1 --warmup 1 --dtype $DT \
         --no-cpu-baseline --no-second-dtype --no-roofline > $D.log 2>&1
   done
-  python $ROOT/tools/roofline_traffic.py $OUT/${DT}_FETCH_SIZE $OUT/${DT}_WRITE_SIZE wgradw_kernel $OUT/$DT.json $OUT/$DT.csv
+  python $ROOT/tools/roofline_traffic.py $OUT/${DT}_FETCH_SIZE $OUT/${DT}_WRITE_SIZE 'wgrad_wide|wgradw_kernel<.*XRows' $OUT/$DT.json $OUT/$DT.csv 'wgrad_wide_bf16_kernel|wgradw_kernel<.*XRows'
   rm -rf $OUT/${DT}_FETCH_SIZE $OUT/${DT}_WRITE_SIZE
 done
