@@ -57,6 +57,15 @@ int leod_partition_attn_bwd(const float* qkv, const float* dout, const float* ls
  * bf16 (qkv_bf16 / dqkv_bf16 above: the pointers then address bf16 elements) where the LDS attention kernels cover the geometry --
  * 1 from this query; leod_ln_linear_bf16_fwd produces the bf16 qkv rows. */
 int leod_partition_attn_16bit_ok(int B, int H, int W, int C, int heads, int ph, int pw);
+/* Bit 1 of qkv_bf16 in the two attention calls above: the attention output `out` (forward) is written / its gradient `dout` (backward)
+ * is read as bf16 rows [M,C] -- valid where leod_partition_attn_o16_ok returns 1 (bf16-tile kernels).  leod_attn_block_o16_ok adds the
+ * conditions of the block's other consumers (leod_linear_lsres_bf16_fwd, bit 1 of dy_bf16 in leod_linear_dgrad = dx written as bf16 rows,
+ * bit 1 of dy_bf16 in leod_linear_wgrad = x holds bf16 rows): the reference's autocast holds both tensors in 16 bits as well
+ * (maxvit.py:185-270 under train.py:236-243). */
+int leod_partition_attn_o16_ok(int B, int H, int W, int C, int heads, int ph, int pw);
+int leod_attn_block_o16_ok(int B, int H, int W, int C, int heads, int ph, int pw);
+int leod_linear_lsres_bf16_fwd(const void* a16, const float* W, const float* bias, const float* gamma, const float* res, float* out,
+                               int M, int N, int K, leod_stream_t stream);
 /* out16[M,N] = bf16(LN(x) W^T + bias), stats_out [M,2]; -3 unless the row-streaming kernel covers (M, N, K) in precision mode bf16. */
 int leod_ln_linear_bf16_fwd(const float* x, const float* ln_w, const float* ln_b, float eps, const float* W, const float* bias,
                             void* out16, float* stats_out, int M, int N, int K, leod_stream_t stream);

@@ -1096,7 +1096,7 @@ static inline bool use_gemm_lds(int M, int nblocks_n) { return (long)cdiv(M, 64)
 struct XRows {                      // X(m,k) = x[m][k], optional LayerNorm with saved (mean, rstd)
     const float* x; long ld; const float* stats; const float* ln_w; const float* ln_b;
     const float* x2; long ld2; int K1;          // optional concat source for k >= K1
-    int fmt;                                    // 1: x is an fp16 pre-activation, X = gelu(x) (see ALRows::fmt)
+    int fmt;                                    // 1: x is an fp16 pre-activation, X = gelu(x) (see ALRows::fmt); 2: x holds bf16 rows
     __device__ __forceinline__ float get(int m, int k) const {
         if (fmt == 1) return gelu_erf(unpack_h16_1(reinterpret_cast<const unsigned short*>(x)[(long)m * ld + k]));
         if (x2 && k >= K1) return x2[(long)m * ld2 + (k - K1)];
@@ -1138,7 +1138,7 @@ struct XRows {                      // X(m,k) = x[m][k], optional LayerNorm with
         if constexpr (XM == 1) { const f4 n = (v - st.x) * st.y * g + b; return (x2 && k >= K1) ? v : n; }
         return v;
     }
-    int x_mode() const { return fmt == 1 ? 2 : (stats ? 1 : 0); }
+    int x_mode() const { return fmt == 2 ? 3 : fmt == 1 ? 2 : (stats ? 1 : 0); }    // 3: bf16 rows (wgrad_wide_bf16_kernel only)
     __device__ __forceinline__ long waddr(int n, int k, long ldw) const { return (long)n * ldw + k; }
 };
 // loaders with the raw4 / fin4 pair (see XRows) are staged in two phases by wgradw_kernel

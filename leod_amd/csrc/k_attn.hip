@@ -851,7 +851,10 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds16_kernel(const void
     for (int e = lane; e < 16 * d4; e += 64) {
         const int tok = e / d4, c4 = e - tok * d4;
         const long row = srow[16 * qt + tok];
-        if (row >= 0) *reinterpret_cast<f4*>(out + row * g.C + (h0 + hl) * d + 4 * c4) = *reinterpret_cast<const f4*>(sout + tok * SO + 4 * c4);
+        if (row < 0) continue;
+        const f4 v = *reinterpret_cast<const f4*>(sout + tok * SO + 4 * c4);
+        if (g.fmt & 4) *reinterpret_cast<s4*>(reinterpret_cast<unsigned short*>(out) + row * g.C + (h0 + hl) * d + 4 * c4) = pack_bf16(v);
+        else *reinterpret_cast<f4*>(out + row * g.C + (h0 + hl) * d + 4 * c4) = v;
     }
 }
 
@@ -886,7 +889,8 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds16_kernel(const void
             stagel[j] = lse[max(row, 0L) * g.heads + h0 + hh];
         }
         a16_stage<NTHR, TOK, F8, SD, true>(sq, qkv, srow, ld, (long)h0 * 3 * d, tid);
-        a16_stage<NTHR, TOK, A16L<D, HG>::RWD / 8, SDD, false>(sdo, dout, srow, (long)g.C, (long)h0 * d, tid);
+        if (g.fmt & 8) a16_stage<NTHR, TOK, A16L<D, HG>::RWD / 8, SDD, true>(sdo, dout, srow, (long)g.C, (long)h0 * d, tid);
+        else a16_stage<NTHR, TOK, A16L<D, HG>::RWD / 8, SDD, false>(sdo, dout, srow, (long)g.C, (long)h0 * d, tid);
 #pragma unroll
         for (int j = 0; j < NLl; ++j) {
             const int e = tid + j * NTHR;
@@ -1004,6 +1008,7 @@ static int run_attn_lds(int which, const float* qkv, const float* dout, float* o
         hipLaunchKernelGGL((attn_bwd_lds16_kernel<PT, D, HG>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, dout, lse, dqkv, g, scale);
         return leod_launch_status();
     }
+    if (g.fmt & 12) return LEOD_ERR_UNSUPPORTED;               // bf16 O / dO rows: the bf16-tile kernels only
     if (which == 0) {
         const size_t lds = (size_t)TOK * S * sizeof(float);
         if (leod_precision() == 1) hipLaunchKernelGGL((attn_fwd_lds_kernel<PT, D, HG, true>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, out, lse, g, scale);
@@ -1073,11 +1078,18 @@ LEOD_API int leod_partition_attn_16bit_ok(int B, int H, int W, int C, int heads,
     static const int force_pad1 = getenv("LEOD_ATTN_LDS_PAD1") ? atoi(getenv("LEOD_ATTN_LDS_PAD1")) : 1;
     return on && use_lds && (d == 24 || d == 32) && inst && !(HG == 1 && P < 16 * PT && !force_pad1);
 }
+// 1: on top of leod_partition_attn_16bit_ok, the attention output O may be written as bf16 (forward, bit 1 of qkv_bf16) and its gradient
+// dO read as bf16 (backward, bit 1 of qkv_bf16): the bf16-tile kernels stage both as the bf16 MFMA operands they are anyway
+LEOD_API int leod_partition_attn_o16_ok(int B, int H, int W, int C, int heads, int ph, int pw) {
+    static const int t16 = getenv("LEOD_ATTN_TILE16") ? atoi(getenv("LEOD_ATTN_TILE16")) : 1;
+    static const int on = getenv("LEOD_O16") ? atoi(getenv("LEOD_O16")) : 1;
+    return on && t16 && leod_partition_attn_16bit_ok(B, H, W, C, heads, ph, pw);
+}
 
 LEOD_API int leod_partition_attn_fwd(const float* qkv, float* out, float* lse, int B, int H, int W, int C, int heads,
                                      int ph, int pw, int window, int qkv_bf16, hipStream_t stream) {
     if (!qkv || !out || heads <= 0) return LEOD_ERR_ARG;
-    AttnGeom g{B, H, W, C, heads, C / heads, ph, pw, window, qkv_bf16 ? 1 : 0};
+    AttnGeom g{B, H, W, C, heads, C / heads, ph, pw, window, ((qkv_bf16 & 1) ? 1 : 0) | ((qkv_bf16 & 2) ? 4 : 0)};
     return dispatch_attn(0, qkv, nullptr, out, lse, nullptr, nullptr, g, stream);
 }
 
@@ -1086,7 +1098,7 @@ LEOD_API int leod_partition_attn_bwd(const float* qkv, const float* dout, const 
                                      int B, int H, int W, int C, int heads, int ph, int pw, int window,
                                      int qkv_bf16, int dqkv_bf16, hipStream_t stream) {
     if (!qkv || !dout || !lse || !dsum || !dqkv || heads <= 0) return LEOD_ERR_ARG;
-    AttnGeom g{B, H, W, C, heads, C / heads, ph, pw, window, (qkv_bf16 ? 1 : 0) | (dqkv_bf16 ? 2 : 0)};
+    AttnGeom g{B, H, W, C, heads, C / heads, ph, pw, window, ((qkv_bf16 & 1) ? 1 : 0) | (dqkv_bf16 ? 2 : 0) | ((qkv_bf16 & 2) ? 8 : 0)};
     int rc = dispatch_attn(1, qkv, dout, nullptr, const_cast<float*>(lse), dsum, dqkv, g, stream);
     if (rc != LEOD_OK) return rc;
     return dispatch_attn(2, qkv, dout, nullptr, const_cast<float*>(lse), dsum, dqkv, g, stream);

@@ -596,15 +596,22 @@ LEOD_API int leod_linear_dgrad(const float* dy, long lddy, const float* kscale, 
                                float* dx2, long lddx2, int nsplit, const float* aux_u, float* colsum,
                                int accumulate, const float* dres, int M, int N, int K, int dy_bf16, hipStream_t stream) {
     if (!dy || !W || !dx || (N & 3) || (lddy & 3)) return LEOD_ERR_ARG;
+    const bool out16 = (dy_bf16 & 2) != 0;          // bit 1: dx is written as bf16 rows (row-epilogue kernels only)
+    dy_bf16 &= 1;
     ALRows al{}; al.x = dy; al.ld = lddy; al.kscale = kscale; al.K = N; al.fmt = dy_bf16 ? 2 : 0;
     EpStore ep = ep_store(dx, lddx, K);
+    if (out16) {
+        if (leod_precision() != 1 || dx2 || colsum || accumulate || dres || aux_u || nsplit > 0 || (K & 3) || !use_gemm_lds(M, cdiv(K, 16 * pick_nt(K))))
+            return LEOD_ERR_UNSUPPORTED;
+        ep.out_fmt = 2;
+    }
     ep.out2 = dx2; ep.ld2 = lddx2; ep.nsplit = nsplit; ep.accumulate = accumulate; ep.colsum = colsum; ep.addsrc = dres;
     if (dres && (nsplit > 0 || accumulate)) return LEOD_ERR_ARG;
     if (aux_u) { ep.act = ACT_MUL_GELU_GRAD; ep.aux = aux_u; ep.ldaux = K; }
     const int nt = pick_nt(K);
     int rc = LEOD_OK;
     // contraction over N in {48, 96}, K in {192, 384} output columns (dgrad of fc2, optionally through GELU): streaming kernel
-    if (!dy_bf16 && !dx2 && !colsum && !accumulate && !dres && lddy == N && lddx == K && nsplit <= 0) {
+    if (!dy_bf16 && !out16 && !dx2 && !colsum && !accumulate && !dres && lddy == N && lddx == K && nsplit <= 0) {
         if (!kscale && !aux_u && use_rowstream_narrow(M, N, K))
             return launch_rowstream_narrow<1>(dy, W, nullptr, nullptr, nullptr, dx, M, N, stream);
         if (const int slab = rowstream_slab(M, K, N)) {
@@ -636,7 +643,12 @@ LEOD_API int leod_linear_wgrad(const float* dy, long lddy, const float* x, long 
                                float* dW, float* dbias, int M, int N, int K, int dy_bf16, hipStream_t stream) {
     if (!dy || !x || !dW) return LEOD_ERR_ARG;
     XRows xl{x, ldx, stats, ln_w, ln_b, x2, ldx2, K1};
-    const int df = dy_bf16 ? 1 : 0;
+    const int df = (dy_bf16 & 1) ? 1 : 0;
+    if (dy_bf16 & 2) {                              // bit 1: x holds bf16 rows -- the wide kernel only
+        if (stats || x2) return LEOD_ERR_ARG;
+        xl.fmt = 2;
+        if (!use_wgrad_wide(xl, lddy, M, N, K, df)) return LEOD_ERR_UNSUPPORTED;
+    }
     if (use_wgrad_wide(xl, lddy, M, N, K, df)) return launch_wgrad_wide(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, df);
     if (use_wgradw(M)) return launch_wgradw(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, df);
     if (N % 48 == 0 && K % 48 == 0) return launch_wgrad16<3, 3>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, df);
@@ -745,6 +757,30 @@ LEOD_API int leod_ln_linear_bf16_fwd(const float* x, const float* ln_w, const fl
     O16_CASE(3, 9) O16_CASE(6, 9) O16_CASE(4, 12)
 #undef O16_CASE
     return LEOD_ERR_UNSUPPORTED;
+}
+
+// out = res + gamma * (a16 W^T + bias) with bf16 rows a16 (proj + LayerScale + residual on the bf16 attention output)
+LEOD_API int leod_linear_lsres_bf16_fwd(const void* a16, const float* W, const float* bias, const float* gamma, const float* res,
+                                        float* out, int M, int N, int K, hipStream_t stream) {
+    if (!a16 || !W || !res || !out || (K & 7) || leod_precision() != 1) return LEOD_ERR_ARG;
+    ALRows al{}; al.x = reinterpret_cast<const float*>(a16); al.ld = K; al.K = K; al.fmt = 2;
+    EpLsRes ep{out, nullptr, res, bias, gamma, (long)N, N};
+    const int nt = pick_nt(N);
+    if (!use_gemm_lds(M, cdiv(N, 16 * nt))) return LEOD_ERR_UNSUPPORTED;
+    int rc = LEOD_OK;
+    DISPATCH_NT(nt, { BLRows bl{W, (long)K, N, NT}; rc = launch_gemm_lds<NT>(al, bl, ep, M, K, cdiv(N, 16 * NT), stream); });
+    return rc;
+}
+
+// 1: an attention block of this geometry may keep its attention output O and the gradient dO as bf16 rows in precision mode bf16 --
+// every kernel that touches them has a 16-bit path: the bf16-tile attention kernels, proj forward (LDS-staged GEMM), the dgrad of proj
+// (row epilogue) and the proj weight gradient (wide kernel)
+extern "C" int leod_partition_attn_o16_ok(int B, int H, int W, int C, int heads, int ph, int pw);
+LEOD_API int leod_attn_block_o16_ok(int B, int H, int W, int C, int heads, int ph, int pw) {
+    const long M = (long)B * H * W;
+    if (M > 0x7fffffffL || !leod_partition_attn_o16_ok(B, H, W, C, heads, ph, pw)) return 0;
+    XRows xl{}; xl.ld = C; xl.fmt = 2;
+    return (C % 8 == 0) && use_gemm_lds((int)M, cdiv(C, 16 * pick_nt(C))) && use_wgrad_wide(xl, (long)C, (int)M, C, C, 0);
 }
 
 // out = res + gamma * (gelu(u16) W^T + bias)     (fc2 + LayerScale + residual on the fp16 pre-activation)

@@ -56,7 +56,7 @@ constexpr int wgw_lds_bytes() {
 }
 
 // TN x TK: 16 x 16 tiles of the workgroup's dW tile; NWN x NWK: wave grid over it (each wave 3 x 3 tiles; waves left over split the
-// 32-row steps of a chunk); RC rows per chunk; DYF: dY fp32 (0) / bf16 (1); XM: see XRows (0 rows, 1 LayerNorm, 2 gelu(fp16))
+// 32-row steps of a chunk); RC rows per chunk; DYF: dY fp32 (0) / bf16 (1); XM: see XRows (0 rows, 1 LayerNorm, 2 gelu(fp16), 3 bf16 rows)
 template <int TN, int TK, int NWN, int NWK, int RC, int DYF, int XM, int OCC>
 __global__ __launch_bounds__(256, OCC) void wgrad_wide_bf16_kernel(const void* __restrict__ dyv, long lddy, XRows xl, float* dW, long ldw,
                                                                     float* dbias, f4* __restrict__ part, int M, int N, int K, int dbg) {
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_wide_bf16_kernel(const void* _
     constexpr bool K16 = KS % MS != 0;              // the waves split 16-row steps instead (16-k MFMA): the 48 x 48 tile
     static_assert(WA == 3 && WB == 3 && NWN * NWK * MS == 4 && (RC / 16) % MS == 0, "4 waves of 3 x 3 tiles");
     constexpr int BST = 16 * 16 + 16;
-    constexpr int DCW = DYF ? 8 : 4, XCW = XM == 2 ? 8 : 4;                 // columns per 16-byte load
+    constexpr int DCW = DYF ? 8 : 4, XCW = XM >= 2 ? 8 : 4;                 // columns per 16-byte load
     constexpr int DSPR = 16 * TN / DCW, XSPR = 16 * TK / XCW;
     constexpr int DRG = wgw_row_groups(DSPR) < RC ? wgw_row_groups(DSPR) : RC, XRG = wgw_row_groups(XSPR) < RC ? wgw_row_groups(XSPR) : RC;
     // XG (gelu operands): the evaluation is VALU-bound, so ALL four waves stage X -- slot s = tid + 256 e of the chunk's RC x XSPR slots
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_wide_bf16_kernel(const void* _
     }
     const char* xbase; long xstride;
     {
-        constexpr int ES = XM == 2 ? 2 : 4;
+        constexpr int ES = XM >= 2 ? 2 : 4;
         const int c = xok ? xcol : 0;
         if (XM == 0 && xl.x2 && c >= xl.K1) { xbase = reinterpret_cast<const char*>(xl.x2) + (long)(c - xl.K1) * ES; xstride = xl.ld2 * ES; }
         else { xbase = reinterpret_cast<const char*>(xl.x) + (long)c * ES; xstride = xl.ld * ES; }
@@ -179,6 +179,11 @@ __global__ __launch_bounds__(256, OCC) void wgrad_wide_bf16_kernel(const void* _
                     };
                     const u4_ o = {cv(rx[e].x), cv(rx[e].y), cv(rx[e].z), cv(rx[e].w)};
                     *reinterpret_cast<u4_*>(d + gxo[e]) = o;
+                } else if constexpr (XM == 3) {                     // bf16 rows: staged as loaded
+                    u4_ v = rx[e];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
+                    *reinterpret_cast<u4_*>(d + wgw_slot_off<XRG, TK, BST>(e)) = v;
                 } else {
                     f4 v = __builtin_bit_cast(f4, rx[e]);
                     if constexpr (XM == 1) v = (v - rst[e].x) * rst[e].y;
@@ -451,23 +456,23 @@ static inline int launch_wgrad_wide_cfg(const void* dy, long lddy, const XRows& 
 }
 
 // The (tile, dY format, X mode) combinations of the RVT step in precision mode bf16 -- anything else stays on wgradw_kernel:
-//   48 x 48   proj (stage 1): fp32 dY, fp32 rows
+//   48 x 48   proj (stage 1): fp32 dY, fp32 or bf16 rows (the attention output O)
 //   192 x 48  qkv / fc1 (stage 1): bf16 dY, LayerNorm(fp32 rows)
 //   48 x 192  fc2 (stage 1): fp32 dY, gelu(fp16 rows)
 //   96 x 96   stages 2-4 and the ConvLSTM 1x1: the four pairs above and bf16 dY with fp32 [x | h] rows
 // chunk rows: ~18-25 KB of loads per chunk (fp32 rows carry twice the bytes of 16-bit rows, and twice the staging registers)
 static inline int wgrad_wide_combo(const XRows& xl, int N, int K, int dyfmt) {
-    const int xm = xl.x_mode(), c = (dyfmt ? 1 : 0) * 4 + xm;        // 0: f32/rows 1: f32/LN 2: f32/gelu16 4: bf16/rows 5: bf16/LN
-    if (N <= 48 && K <= 48) return c == 0 ? 1 : 0;
+    const int xm = xl.x_mode(), c = (dyfmt ? 1 : 0) * 4 + xm;        // 0: f32/rows 1: f32/LN 2: f32/gelu16 3: f32/bf16 rows 4: bf16/rows 5: bf16/LN
+    if (N <= 48 && K <= 48) return c == 0 ? 1 : c == 3 ? 8 : 0;
     if (K <= 48) return c == 5 ? 2 : 0;
     if (N <= 48) return c == 2 ? 3 : 0;
-    return c == 0 ? 4 : c == 5 ? 5 : c == 2 ? 6 : c == 4 ? 7 : 0;
+    return c == 0 ? 4 : c == 5 ? 5 : c == 2 ? 6 : c == 4 ? 7 : c == 3 ? 9 : 0;
 }
 static inline bool use_wgrad_wide(const XRows& xl, long lddy, int M, int N, int K, int dyfmt) {
     static const int mode = getenv("LEOD_WGRAD_WIDE") ? atoi(getenv("LEOD_WGRAD_WIDE")) : 1;
     if (!mode || leod_precision() != 1 || M < 8192) return false;
     const int xm = xl.x_mode();
-    const int dcw = dyfmt ? 8 : 4, xcw = xm == 2 ? 8 : 4;
+    const int dcw = dyfmt ? 8 : 4, xcw = xm >= 2 ? 8 : 4;
     if ((N % dcw) || (lddy % dcw) || (K % xcw) || (xl.ld % xcw)) return false;
     if (xl.x2 && (xm != 0 || (xl.K1 % 4) || (xl.ld2 % 4))) return false;
     return wgrad_wide_combo(xl, N, K, dyfmt) != 0;
@@ -484,6 +489,8 @@ static inline int launch_wgrad_wide(const void* dy, long lddy, const XRows& xl, 
         case 5: LEOD_WGW(6, 6, 2, 2, 32, 1, 1, 3);
         case 6: LEOD_WGW(6, 6, 2, 2, 64, 0, 2, 3);
         case 7: LEOD_WGW(6, 6, 2, 2, 32, 1, 0, 3);
+        case 8: LEOD_WGW(3, 3, 1, 1, 64, 0, 3, 2);
+        case 9: LEOD_WGW(6, 6, 2, 2, 32, 0, 3, 3);
     }
 #undef LEOD_WGW
     return LEOD_ERR_UNSUPPORTED;

@@ -258,7 +258,9 @@ class AttnBlockFn(Function):
         # precision mode bf16: where the LDS attention kernels cover the geometry, qkv (and dqkv in backward) live in HBM as bf16
         q16 = ops.partition_attn_16bit_ok(x.shape[0], x.shape[1], x.shape[2], x.shape[3], heads, part)
         qkv, _, st1 = ops.ln_linear_fwd(x, n1w, n1b, qkv_w, qkv_b, want_stats=need or q16, out_bf16=q16)
-        o, lse = ops.partition_attn_fwd(qkv, heads, part, window, want_lse=need)
+        # ... and the attention output O (dO in backward) as bf16 rows where every consumer has the 16-bit path
+        o16 = q16 and ops.attn_block_o16_ok(x.shape[0], x.shape[1], x.shape[2], x.shape[3], heads, part)
+        o, lse = ops.partition_attn_fwd(qkv, heads, part, window, want_lse=need, out_bf16=o16)
         # the pre-LayerScale outputs are NOT stored: dgamma is recovered from the un-scaled weight gradient in backward
         y, _ = ops.linear_lsres_fwd(o, proj_w, proj_b, g1, x, want_t=False)
         # precision mode bf16, stages 1-2: u comes back as ONE fp16 tensor (h is None) and fc2 applies GELU while loading it
@@ -281,7 +283,7 @@ class AttnBlockFn(Function):
         # ---- dgrad chain (critical path); LayerScale is folded into the dgrad loader (dz * gamma) -------------------------
         du = ops.linear_dgrad(dz, fc2_w, kscale=g2, aux_u=u)
         dy = ops.linear_dgrad_ln_bwd(du, fc1_w, y, st2, n2w, dz, grad_buf(mod.norm2.weight), grad_buf(mod.norm2.bias))
-        do = ops.linear_dgrad(dy, proj_w, kscale=g1)
+        do = ops.linear_dgrad(dy, proj_w, kscale=g1, out_bf16=o.dtype is torch.bfloat16)
         dqkv = ops.partition_attn_bwd(qkv, do, lse, heads, part, window)
         # ---- weight gradients: off the critical path (side stream when the engine enables it) ------
         with _wgrad_side(dz, h, du, y, st2, dy, o, dqkv, x, st1):

@@ -168,6 +168,14 @@ def _linear_lsres_fwd(a, W, bias, gamma, res, want_t, K, N, M):
         check(_l().leod_linear_lsres_gelu16_fwd(_p(a), _p(W), _p(bias), _p(gamma), _p(res), _p(out), M, N, K, _stream()),
               'linear_lsres_gelu16_fwd')
         return out, None
+    if a.dtype is torch.bfloat16:                            # a = bf16 rows (the attention output of precision mode bf16)
+        _ck(a, torch.bfloat16, 'a')
+        if want_t:
+            raise LeodHipError('linear_lsres_fwd: the bf16-row path does not return t')
+        out = _empty(res.shape, res)
+        check(_l().leod_linear_lsres_bf16_fwd(_p(a), _p(W), _p(bias), _p(gamma), _p(res), _p(out), M, N, K, _stream()),
+              'linear_lsres_bf16_fwd')
+        return out, None
     _ck(a, name='a')
     out = _empty(res.shape, a)
     tout = _empty(res.shape, a) if want_t else None
@@ -176,17 +184,22 @@ def _linear_lsres_fwd(a, W, bias, gamma, res, want_t, K, N, M):
     return out, tout
 
 
-def partition_attn_fwd(qkv, heads, part, window, want_lse=False):
-    """qkv [B,H,W,3C] -> out [B,H,W,C] (+ lse [B,H,W,heads])."""
+def partition_attn_fwd(qkv, heads, part, window, want_lse=False, out_bf16=False):
+    """qkv [B,H,W,3C] -> out [B,H,W,C] (+ lse [B,H,W,heads]); out_bf16 (attn_block_o16_ok): out as bf16 rows."""
     q16 = qkv.dtype is torch.bfloat16
     _ck(qkv, torch.bfloat16 if q16 else F32, 'qkv')
     B, H, W, C3 = qkv.shape
     C = C3 // 3
-    out = torch.empty((B, H, W, C), dtype=F32, device=qkv.device)
+    out = torch.empty((B, H, W, C), dtype=torch.bfloat16 if out_bf16 else F32, device=qkv.device)
     lse = torch.empty((B, H, W, heads), dtype=F32, device=qkv.device) if want_lse else None
     check(_l().leod_partition_attn_fwd(_p(qkv), _p(out), _p(lse), B, H, W, C, heads, part[0], part[1],
-                                        1 if window else 0, 1 if q16 else 0, _stream()), 'partition_attn_fwd')
+                                        1 if window else 0, (1 if q16 else 0) | (2 if out_bf16 else 0), _stream()), 'partition_attn_fwd')
     return out, lse
+
+
+def attn_block_o16_ok(B, H, W, C, heads, part) -> bool:
+    """The attention output O and its gradient dO of this block geometry may live in HBM as bf16 rows (every consumer has a 16-bit path)."""
+    return BF16_GRADS and bool(_l().leod_attn_block_o16_ok(B, H, W, C, heads, part[0], part[1]))
 
 
 def partition_attn_16bit_ok(B, H, W, C, heads, part) -> bool:
@@ -197,14 +210,15 @@ def partition_attn_16bit_ok(B, H, W, C, heads, part) -> bool:
 def partition_attn_bwd(qkv, dout, lse, heads, part, window):
     q16 = qkv.dtype is torch.bfloat16
     _ck(qkv, torch.bfloat16 if q16 else F32, 'qkv')
-    for t, n in ((dout, 'dout'), (lse, 'lse')):
-        _ck(t, name=n)
+    do16 = dout.dtype is torch.bfloat16                       # bf16 dO rows (attn_block_o16_ok)
+    _ck(dout, torch.bfloat16 if do16 else F32, 'dout')
+    _ck(lse, name='lse')
     B, H, W, C3 = qkv.shape
     C = C3 // 3
     dqkv = torch.empty(qkv.shape, dtype=qkv.dtype, device=qkv.device)     # bf16 qkv <=> bf16 dqkv (partition_attn_16bit_ok)
     dsum = torch.empty(lse.shape, dtype=F32, device=qkv.device)
     check(_l().leod_partition_attn_bwd(_p(qkv), _p(dout), _p(lse), _p(dsum), _p(dqkv), B, H, W, C, heads, part[0],
-                                        part[1], 1 if window else 0, 1 if q16 else 0, 1 if q16 else 0, _stream()), 'partition_attn_bwd')
+                                        part[1], 1 if window else 0, (1 if q16 else 0) | (2 if do16 else 0), 1 if q16 else 0, _stream()), 'partition_attn_bwd')
     return dqkv
 
 
@@ -295,7 +309,7 @@ def convlstm_seq_bwd(dh_seq, dc_last, gates, cbuf, W, dgates_out, dh0=None, dc0=
     return True
 
 
-def linear_dgrad(dy, W, kscale=None, aux_u=None, colsum=None, out=None, accumulate=False, split=0, out2=None, dres=None):
+def linear_dgrad(dy, W, kscale=None, aux_u=None, colsum=None, out=None, accumulate=False, split=0, out2=None, dres=None, out_bf16=False):
     """dx = (dy * kscale) @ W  with W [N,K] (+ dres: the other gradient source of a residual branch); see leod_linear_dgrad."""
     dy16 = dy.dtype is torch.bfloat16                         # bf16 gradient rows (du / dqkv of precision mode bf16)
     _ck(dy, torch.bfloat16 if dy16 else F32, 'dy')
@@ -304,17 +318,17 @@ def linear_dgrad(dy, W, kscale=None, aux_u=None, colsum=None, out=None, accumula
     N, K = W.shape[0], W.shape[1] if W.dim() == 2 else W.numel() // W.shape[0]
     M = dy.numel() // N
     aux_b = 0.0 if aux_u is None else aux_u.element_size() * M * K
-    out_b = (2.0 if (aux_u is not None and aux_u.dtype is torch.float16 and BF16_GRADS) else 4.0) * M * K
+    out_b = (2.0 if (out_bf16 or (aux_u is not None and aux_u.dtype is torch.float16 and BF16_GRADS)) else 4.0) * M * K
     ev = _probe('linear_gemm', dy.element_size() * M * N + 4.0 * N * K + aux_b + out_b + (4.0 * M * K if (accumulate or dres is not None) else 0.0),
                 2.0 * M * N * K)
     try:
-        return _linear_dgrad(dy, W, kscale, aux_u, colsum, out, accumulate, split, out2, dres, dy16, N, K, M)
+        return _linear_dgrad(dy, W, kscale, aux_u, colsum, out, accumulate, split, out2, dres, dy16, N, K, M, out_bf16)
     finally:
         if ev is not None:
             ev.record()
 
 
-def _linear_dgrad(dy, W, kscale, aux_u, colsum, out, accumulate, split, out2, dres, dy16, N, K, M):
+def _linear_dgrad(dy, W, kscale, aux_u, colsum, out, accumulate, split, out2, dres, dy16, N, K, M, out_bf16=False):
     if aux_u is not None and aux_u.dtype is torch.float16:    # through GELU on the fp16 pre-activation (stages 1-2, bf16 mode)
         _ck(aux_u, torch.float16, 'aux_u')
         if split or colsum is not None or accumulate or out is not None or dres is not None:
@@ -335,10 +349,11 @@ def _linear_dgrad(dy, W, kscale, aux_u, colsum, out, accumulate, split, out2, dr
         ld1, ld2 = split, K - split
     else:
         if out is None:
-            out = torch.empty(dy.shape[:-1] + (K,), dtype=F32, device=dy.device)
+            out = torch.empty(dy.shape[:-1] + (K,), dtype=torch.bfloat16 if out_bf16 else F32, device=dy.device)
         ld1, ld2 = K, 0
     check(_l().leod_linear_dgrad(_p(dy), N, _p(kscale), _p(W), _p(out), ld1, _p(out2), ld2, split, _p(aux_u),
-                                  _p(colsum), 1 if accumulate else 0, _p(dres), M, N, K, 1 if dy16 else 0, _stream()), 'linear_dgrad')
+                                  _p(colsum), 1 if accumulate else 0, _p(dres), M, N, K, (1 if dy16 else 0) | (2 if out_bf16 else 0), _stream()),
+          'linear_dgrad')
     return (out, out2) if split else out
 
 
@@ -376,12 +391,13 @@ def linear_wgrad(dy, x, dW, dbias=None, stats=None, ln_w=None, ln_b=None, x2=Non
         if ev is not None:
             ev.record()
         return
-    _ck(x, name='x')
+    x16 = x.dtype is torch.bfloat16                           # bf16 rows (the attention output of precision mode bf16)
+    _ck(x, torch.bfloat16 if x16 else F32, 'x')
     # algorithmic work of one launch: reads dy, X once, read-modify-writes dW once; 2*M*N*K flops
-    ev = _probe('linear_wgrad', (2.0 if dy16 else 4.0) * M * N + 4.0 * (M * K + N * K), 2.0 * M * N * K, rows=M)
+    ev = _probe('linear_wgrad', (2.0 if dy16 else 4.0) * M * N + (2.0 if x16 else 4.0) * M * K + 4.0 * N * K, 2.0 * M * N * K, rows=M)
     check(_l().leod_linear_wgrad(_p(dy), N, _p(x), K1, _p(stats), _p(ln_w), _p(ln_b), _p(x2),
-                                  (x2.shape[-1] if x2 is not None else 0), K1, _p(dW), _p(dbias), M, N, K, 1 if dy16 else 0, _stream()),
-          'linear_wgrad')
+                                  (x2.shape[-1] if x2 is not None else 0), K1, _p(dW), _p(dbias), M, N, K,
+                                  (1 if dy16 else 0) | (2 if x16 else 0), _stream()), 'linear_wgrad')
     if ev is not None:
         ev.record()
 

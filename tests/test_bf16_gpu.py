@@ -162,6 +162,39 @@ def test_partition_attn_bf16_tensors(bf16_ops, B, H, W, C, heads, part, window):
     dq = ops.partition_attn_bwd(q, dout.to(tk.DEV), lse, heads, part, window)
     assert dq.dtype is torch.bfloat16
     tk.close(dq.float(), qkv.grad, what='bf16 dqkv')
+    # the attention output written as bf16 rows / its gradient read as bf16 rows (bit 1 of qkv_bf16): the same values, rounded once
+    o16, lse2 = ops.partition_attn_fwd(q, heads, part, window, want_lse=True, out_bf16=True)
+    assert o16.dtype is torch.bfloat16 and torch.equal(lse2, lse)
+    assert torch.equal(o16, out.to(torch.bfloat16)), 'bf16 O = the fp32 O of the same kernel, rounded to nearest even'
+    do16 = dout.to(torch.bfloat16)
+    qkv2 = qkv16.float().requires_grad_(True)
+    tk._attn_ref(qkv2, heads, part, window).backward(do16.float())
+    dq2 = ops.partition_attn_bwd(q, do16.to(tk.DEV), lse, heads, part, window)
+    tk.close(dq2.float(), qkv2.grad, what='bf16 dqkv from bf16 dO')
+
+
+@pytest.mark.parametrize('B,H,W,C,heads', [(21, 32, 40, 48, 2), (8, 32, 40, 96, 4), (28, 16, 20, 192, 8)])
+def test_attention_block_keeps_o_and_do_as_bf16(bf16_ops, B, H, W, C, heads):
+    """Where leod_attn_block_o16_ok holds, the other consumers of O / dO take bf16 rows: proj + LayerScale + residual from bf16 O, the
+    dgrad of proj writing bf16 dO, and the proj weight gradient from bf16 O (maxvit.py:185-270) -- against fp32 CPU arithmetic on the
+    same rounded values."""
+    import torch.nn.functional as F
+    ops = bf16_ops
+    assert ops.attn_block_o16_ok(B, H, W, C, heads, (8, 10))
+    M = B * H * W
+    o16 = tk.rnd((M, C), 1).to(torch.bfloat16)
+    res, dy = tk.rnd((M, C), 2), tk.rnd((M, C), 3)
+    Wp, bp, g = tk.rnd((C, C), 4, 0.2), tk.rnd((C,), 5, 0.2), 0.5 + 0.1 * tk.rnd((C,), 6)
+    d = lambda t: t.detach().to(tk.DEV)  # noqa
+    y, _ = ops.linear_lsres_fwd(d(o16), d(Wp), d(bp), d(g), d(res), want_t=False)
+    tk.close(y, res + g * F.linear(o16.float(), Wp, bp), what='proj + LayerScale + residual from bf16 O')
+    do = ops.linear_dgrad(d(dy), d(Wp), kscale=d(g), out_bf16=True)
+    assert do.dtype is torch.bfloat16
+    tk.close(do.float(), (dy * g) @ Wp, what='bf16 dO')
+    dW, db = torch.zeros((C, C), device=tk.DEV), torch.zeros((C,), device=tk.DEV)
+    ops.linear_wgrad(d(dy), d(o16), dW, db)
+    tk.close(dW, (dy.double().t() @ o16.double()).float(), what='proj weight gradient from bf16 O')
+    tk.close(db, dy.double().sum(0).float(), what='proj bias gradient')
 
 
 @pytest.mark.parametrize('M,N,K', [(40009, 144, 48), (20011, 288, 96),
@@ -250,6 +283,7 @@ def test_mlp_hidden_stored_once_as_fp16(bf16_ops, M, C):
     (12000, 96, 384, False, 'gelu16'), (8300, 192, 768, False, 'gelu16'),     # fc2
     (20011, 384, 192, True, 'concat'), (8705, 768, 384, True, 'concat'),      # ConvLSTM 1x1 on [x | h] with bf16 gate gradients
     (20011, 384, 192, False, 'concat'),
+    (40009, 48, 48, False, 'rows16'), (20011, 96, 96, False, 'rows16'), (9001, 192, 192, False, 'rows16'),    # proj from the bf16 attention output
 ])
 def test_wgrad_wide_bf16(bf16_ops, M, N, K, dy16, xmode):
     import torch.nn.functional as F
@@ -260,10 +294,13 @@ def test_wgrad_wide_bf16(bf16_ops, M, N, K, dy16, xmode):
     d = lambda t: t.detach().to(tk.DEV)  # noqa
     dW, db = torch.zeros((N, K), device=tk.DEV), torch.zeros((N,), device=tk.DEV)
     dyd = d(dy).to(torch.bfloat16) if dy16 else d(dy)
-    if xmode == 'rows':
+    if xmode in ('rows', 'rows16'):
         x = tk.rnd((M, K), 22)
-        X = x
-        call = lambda: ops.linear_wgrad(dyd, d(x), dW, db)  # noqa
+        if xmode == 'rows16':
+            x = x.to(torch.bfloat16)
+        X = x.float()
+        xd = d(x)
+        call = lambda: ops.linear_wgrad(dyd, xd, dW, db)  # noqa
     elif xmode == 'ln':
         x = 0.3 + 1.5 * tk.rnd((M, K), 22)
         lw, lb = 1 + 0.2 * tk.rnd((K,), 23), 0.1 * tk.rnd((K,), 24)

@@ -143,8 +143,9 @@ def test_detector_head_golden_and_grads(gpu, golden_dir, manifest):
 
 
 def test_head_level_streams_equal_single_stream(gpu, manifest, monkeypatch):
-    """The per-level HIP streams of the head towers (yolo_head._towers_streams) only reorder independent launches: predictions,
-    losses, BatchNorm buffers and every gradient are bit-identical to the grouped single-stream path, repeated to catch a race."""
+    """The per-level HIP streams of the head towers (yolo_head._towers_streams) only reorder independent launches: predictions, losses
+    and BatchNorm buffers are bit-identical to the grouped single-stream path and the gradients agree to the order of their fp32
+    atomics; repeated to catch a race."""
     from leod_amd.models.detection.yolox.models import yolo_head as yh
 
     def rnd(shape, seed):
@@ -172,7 +173,10 @@ def test_head_level_streams_equal_single_stream(gpu, manifest, monkeypatch):
         got = run(True)
         assert got.keys() == ref.keys()
         for k in ref:
-            assert torch.equal(got[k], ref[k]), k
+            if k.startswith(('g.', 'gf.')):      # weight gradients accumulate with fp32 atomics (order varies from run to run in either mode)
+                torch.testing.assert_close(got[k], ref[k], rtol=2e-5, atol=1e-6, msg=k)
+            else:
+                assert torch.equal(got[k], ref[k]), k
 
 
 def test_backbone_backward_vs_oracle(gpu, manifest):
