@@ -261,6 +261,8 @@ LEOD_API int leod_stem_conv_fwd(const void* x, int x_is_u8, const float* w, floa
     int rc = LEOD_OK;
     const bool lds = use_gemm_lds(M, cdiv(N, 16 * nt));
     static const int stem_patch = getenv("LEOD_STEM_PATCH") ? atoi(getenv("LEOD_STEM_PATCH")) : 1;
+    if (stem_patch && x_is_u8 && leod_precision() == 1 && stem_fwd_bf16_supported(x, Cin, H, W, N, stride, pad))
+        return stem_fwd_bf16_launch(x, w, y, B, Cin, H, W, Ho, Wo, N, stream);         // k_stem.hip: bf16 patch, weights resident in LDS
     if (stem_patch && x_is_u8 && stride == 4 && pad == 3 && N <= 64 && !(N & 15) && !(W & 3) && Cin * 19 * 72 <= 60000 &&
         ((uintptr_t)x & 3) == 0 && ((long)Cin * H * W) % 4 == 0) {
         // LDS-resident uint8 patch kernel (dedicated to the RVT stem geometry); anything else takes the generic path

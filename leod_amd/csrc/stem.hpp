@@ -5,3 +5,5 @@
 bool stem_wgrad_bf16_supported(const void* x, int Cin, int H, int W, int N, int stride, int pad);
 int stem_wgrad_bf16_launch(const float* dy, const void* x, float* dW, int B, int Cin, int H, int W, int Ho, int Wo, int N,
                            hipStream_t s);
+bool stem_fwd_bf16_supported(const void* x, int Cin, int H, int W, int N, int stride, int pad);
+int stem_fwd_bf16_launch(const void* x, const float* w, float* y, int B, int Cin, int H, int W, int Ho, int Wo, int N, hipStream_t s);

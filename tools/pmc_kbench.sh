@@ -11,7 +11,7 @@ for CTRS in "$@"; do
   i=$((i+1))
   D=$ROOT/gpurun_out/pmc_${OUT}_$i
   rm -rf $D
-  KBENCH_EAGER=1 timeout 900 rocprofv3 --kernel-trace --pmc $CTRS -d $D -o p -- python $ROOT/tools/kbench.py $FILTER > $D.log 2>&1
+  KBENCH_EAGER=1 timeout ${PMC_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc $CTRS -d $D -o p -- python $ROOT/tools/kbench.py $FILTER > $D.log 2>&1
   DB=$(find $D -name "*.db" | head -1)
   python $ROOT/tools/pmc_summary.py $DB >> $ROOT/gpurun_out/pmc_${OUT}.txt
 done
