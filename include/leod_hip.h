@@ -185,10 +185,10 @@ int leod_bn_silu_fwd(const float* z, const double* colstats, int stat_rep, const
                      float* save_rstd, float* run_mean, float* run_var, int M, int N, double count,
                      const double* count_dev, float eps, float momentum, leod_stream_t stream);
 int leod_bn_silu_bwd_reduce(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
-                            const float* b, double* sums, int M, int N, leod_stream_t stream);
+                            const float* b, double* sums, int M, int N, int lddy, leod_stream_t stream);
 int leod_bn_silu_bwd_apply(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
                            const float* b, const double* sums, float* dz, float* dw, float* db, int M, int N, double count,
-                           const double* count_dev, leod_stream_t stream);
+                           const double* count_dev, int lddy, leod_stream_t stream);
 
 /* ---- YOLOX head tail (models/detection/yolox/models/yolo_head.py) --------------------------------- */
 
@@ -247,6 +247,13 @@ int leod_adamw_clip_step(float* p, float* g, float* m, float* v, long n, float l
                          leod_stream_t stream);
 /* dst[0..3] = (a,b,c,d) on the device (launch-time scalars for a replayed hipGraph). */
 int leod_set_scalars4(float* dst, float a, float b, float c, float d, leod_stream_t stream);
+/* Recurrent-state plumbing as one launch per call (host arrays of up to 16 entries; pointers and sizes 16-byte aligned):
+ * leod_rows_masked_zero -- tensors[k][b, :] = 0 where mask[b] (B rows of row_bytes[k] each): RNNStates.reset over the (h, c) of all
+ *   stages, reference modules/utils/detection.py:60-75 (`t[mask] = 0` per tensor);
+ * leod_copy_multi -- dst[k][:] = src[k][:]: the initial (h, c) of a stage into slot 0 of its sequence buffers
+ *   (reference models/layers/rnn.py:53-60 takes them as h_and_c_previous). */
+int leod_rows_masked_zero(void* const* tensors, const long* row_bytes, int n, const unsigned char* mask, int B, leod_stream_t stream);
+int leod_copy_multi(void* const* dst, const void* const* src, const long* nbytes, int n, leod_stream_t stream);
 /* StackedHistogram.construct (data/utils/representations.py:78-123): int64 events -> uint8 [2*bins,H,W]. */
 int leod_voxelize_u8(const long* x, const long* y, const long* pol, const long* t, long n_events, int* counts_ws,
                      unsigned char* out, int bins, int H, int W, int count_cutoff, int fastmode, leod_stream_t stream);

@@ -88,6 +88,64 @@ LEOD_API int leod_set_scalars4(float* dst, float a, float b, float c, float d, h
     return leod_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Recurrent-state plumbing of the time-batched step as ONE launch per call instead of one ATen kernel per tensor:
+//   leod_rows_masked_zero: t_k[b, :] = 0 where mask[b], for up to 16 tensors of B rows each (RNNStates.reset: h and c of the four
+//     stages, reference modules/utils/detection.py:60-75 `t[mask] = 0` per tensor);
+//   leod_copy_multi: dst_k[:] = src_k[:] for up to 16 buffers (the initial (h, c) of a stage into slot 0 of its sequence buffers).
+// Sizes are in 16-byte units; every pointer 16-byte aligned.
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+struct MultiBuf { void* dst[16]; const void* src[16]; long n16[16]; };
+
+__global__ __launch_bounds__(256) void rows_masked_zero_kernel(MultiBuf mb, const unsigned char* __restrict__ mask, int B) {
+    const int k = blockIdx.y;
+    const long row16 = mb.n16[k];                              // 16-byte units per batch row
+    u4v* p = reinterpret_cast<u4v*>(mb.dst[k]);
+    const u4v z = {0u, 0u, 0u, 0u};
+    for (int b = 0; b < B; ++b) {
+        if (!mask[b]) continue;                                // block-uniform
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < row16; e += (long)gridDim.x * 256) p[b * row16 + e] = z;
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_multi_kernel(MultiBuf mb) {
+    const int k = blockIdx.y;
+    const long n = mb.n16[k];
+    u4v* d = reinterpret_cast<u4v*>(mb.dst[k]);
+    const u4v* s = reinterpret_cast<const u4v*>(mb.src[k]);
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) d[e] = s[e];
+}
+
+LEOD_API int leod_rows_masked_zero(void* const* tensors, const long* row_bytes, int n, const unsigned char* mask, int B, hipStream_t stream) {
+    if (!tensors || !row_bytes || !mask || n < 0 || n > 16 || B < 0) return LEOD_ERR_ARG;
+    if (n == 0 || B == 0) return LEOD_OK;
+    MultiBuf mb{};
+    long mx = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!tensors[k] || (row_bytes[k] & 15) || ((uintptr_t)tensors[k] & 15)) return LEOD_ERR_ARG;
+        mb.dst[k] = tensors[k]; mb.n16[k] = row_bytes[k] / 16;
+        mx = mb.n16[k] > mx ? mb.n16[k] : mx;
+    }
+    const int gx = (int)((mx + 1023) / 1024 < 1 ? 1 : ((mx + 1023) / 1024 > 64 ? 64 : (mx + 1023) / 1024));
+    hipLaunchKernelGGL(rows_masked_zero_kernel, dim3(gx, n), dim3(256), 0, stream, mb, mask, B);
+    return leod_launch_status();
+}
+
+LEOD_API int leod_copy_multi(void* const* dst, const void* const* src, const long* nbytes, int n, hipStream_t stream) {
+    if (!dst || !src || !nbytes || n < 0 || n > 16) return LEOD_ERR_ARG;
+    if (n == 0) return LEOD_OK;
+    MultiBuf mb{};
+    long mx = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!dst[k] || !src[k] || (nbytes[k] & 15) || ((uintptr_t)dst[k] & 15) || ((uintptr_t)src[k] & 15)) return LEOD_ERR_ARG;
+        mb.dst[k] = dst[k]; mb.src[k] = src[k]; mb.n16[k] = nbytes[k] / 16;
+        mx = mb.n16[k] > mx ? mb.n16[k] : mx;
+    }
+    const int gx = (int)((mx + 1023) / 1024 < 1 ? 1 : ((mx + 1023) / 1024 > 256 ? 256 : (mx + 1023) / 1024));
+    hipLaunchKernelGGL(copy_multi_kernel, dim3(gx, n), dim3(256), 0, stream, mb);
+    return leod_launch_status();
+}
+
 LEOD_API const char* leod_version() { return "leod_hip 0.2 (gfx950)"; }
 
 // precision mode of the contractions (see common.hpp): process-wide, set once before the first step

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ w, const float* __restrict__ b,
-                                                                 double* __restrict__ sums, long M, int N) {
+                                                                 double* __restrict__ sums, long M, int N, long lddy) {
     // thread t owns 4 consecutive channels c = 4*(t % (N/4)) and strides over rows; partial sums are combined in
     // LDS so that each workgroup issues ONE double atomic per (channel, statistic)
     extern __shared__ float sred[];                 // [2*N]
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const float* __
         for (long row = (long)blockIdx.x * rstep + rlane; row < M; row += (long)gridDim.x * rstep) {
             const f4 xh = (ld4(z + row * N + c) - mu) * rs;
             const f4 u = xh * ww + bb;
-            f4 du = ld4(dy + row * N + c);
+            f4 du = ld4(dy + row * lddy + c);
 #pragma unroll
             for (int k = 0; k < 4; ++k) du[k] *= silu_grad(u[k]);
             s0 += du; s1 += du * xh;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const float* __r
                                                                 const float* __restrict__ w, const float* __restrict__ b,
                                                                 const double* __restrict__ sums, float* __restrict__ dz,
                                                                 float* __restrict__ dw, float* __restrict__ db, long M, int N,
-                                                                double count, const double* __restrict__ count_dev) {
+                                                                double count, const double* __restrict__ count_dev, long lddy) {
     if (count_dev) count = count * count_dev[0];     // SyncBatchNorm: rows per image (host) x images over all ranks (device)
     const long n4 = M * N / 4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const float* __r
         const f4 mu = ld4(mean + c), rs = ld4(rstd + c), ww = ld4(w + c), bb = ld4(b + c);
         const f4 xh = (ld4(z + e) - mu) * rs;
         const f4 u = xh * ww + bb;
-        f4 du = ld4(dy + e), r;
+        f4 du = ld4(lddy == N ? dy + e : dy + (e / N) * lddy + c), r;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             du[k] *= silu_grad(u[k]);
@@ -408,24 +408,25 @@ LEOD_API int leod_bn_silu_fwd(const float* z, const double* colstats, int stat_r
 }
 
 LEOD_API int leod_bn_silu_bwd_reduce(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
-                                     const float* b, double* sums, int M, int N, hipStream_t stream) {
-    if (!dy || !z || !mean || !rstd || !w || !b || !sums || (N & 3) || N / 4 > 256) return LEOD_ERR_ARG;
+                                     const float* b, double* sums, int M, int N, int lddy, hipStream_t stream) {
+    if (!dy || !z || !mean || !rstd || !w || !b || !sums || (N & 3) || N / 4 > 256 || (lddy && (lddy < N || (lddy & 3)))) return LEOD_ERR_ARG;
     if (M <= 0) return LEOD_OK;
     const int rstep = 256 / (N / 4);
     // every workgroup ends with 2 N double atomics on the same few cache lines (1024 workgroups x 192 atomics: 31 us for the
     // 40960 x 96 level-0 maps, 16 us with 256 workgroups): >= 16 rows per thread, <= 256 workgroups (tools/kbench_bn.py)
     static const int cap = getenv("LEOD_BN_BWD_BLOCKS") ? atoi(getenv("LEOD_BN_BWD_BLOCKS")) : 256;
     const int grid = (int)min((long)cap, max((long)1, ((long)M + rstep * 16 - 1) / (rstep * 16)));
-    hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3(grid), dim3(256), 2 * N * sizeof(float), stream, dy, z, mean, rstd, w, b, sums, (long)M, N);
+    hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3(grid), dim3(256), 2 * N * sizeof(float), stream, dy, z, mean, rstd, w, b, sums, (long)M, N,
+                       (long)(lddy ? lddy : N));
     return leod_launch_status();
 }
 
 LEOD_API int leod_bn_silu_bwd_apply(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
                                     const float* b, const double* sums, float* dz, float* dw, float* db, int M, int N,
-                                    double count, const double* count_dev, hipStream_t stream) {
-    if (!dy || !z || !mean || !rstd || !w || !b || !sums || !dz || (N & 3)) return LEOD_ERR_ARG;
+                                    double count, const double* count_dev, int lddy, hipStream_t stream) {
+    if (!dy || !z || !mean || !rstd || !w || !b || !sums || !dz || (N & 3) || (lddy && (lddy < N || (lddy & 3)))) return LEOD_ERR_ARG;
     if (M <= 0) return LEOD_OK;
     hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(flat_grid((long)M * N / 4)), dim3(256), 0, stream, dy, z, mean, rstd,
-                       w, b, sums, dz, dw, db, (long)M, N, count, count_dev);
+                       w, b, sums, dz, dw, db, (long)M, N, count, count_dev, (long)(lddy ? lddy : N));
     return leod_launch_status();
 }

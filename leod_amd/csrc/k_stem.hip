@@ -160,7 +160,7 @@ int launch(const float* dy, const uint8_t* x, float* dW, int B, int Cin, int H, 
     const int ntiles = B * tiles_x * tiles_y;
     const size_t patch = (((size_t)Cin * PR * RS + 7) & ~(size_t)7) * 2;
     const size_t lds = patch + (size_t)4 * NT * BST * 2;
-    static const int workers = getenv("LEOD_STEM_WORKERS") ? atoi(getenv("LEOD_STEM_WORKERS")) : 256;
+    static const int workers = getenv("LEOD_STEM_WGRAD_WORKERS") ? atoi(getenv("LEOD_STEM_WGRAD_WORKERS")) : 256;
     const int gx = ntiles < workers ? ntiles : workers;
     static bool attr = false;
     if (!attr) {

@@ -207,6 +207,12 @@ def _cont(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if t is None else (t if t.is_contiguous() else t.contiguous())
 
 
+def _rows(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """A gradient for the BatchNorm backward kernels: as it is when its rows are evenly spaced (contiguous, or the channel slice that
+    ``torch.cat``'s backward hands to each branch of a CSP / PAFPN concat -- read in place with its row stride), else a contiguous copy."""
+    return None if t is None else (t if ops.row_stride(t, t.shape[-1]) else t.contiguous())
+
+
 # ---------------------------------------------------------------------------------------------------
 class ConvLNFn(Function):
     """ConvDownsampling_Cf2Cl (maxvit.py:143-182): conv(no bias) -> NHWC -> LayerNorm.
@@ -335,6 +341,16 @@ class ConvLSTMFn(Function):
 
 
 # ---------------------------------------------------------------------------------------------------
+def _lstm_wx(w, W2, C):
+    """The x half W[:, :C] of a ConvLSTM 1x1 weight [4C, 2C] as a contiguous matrix, cached in ``ops.PackCache`` until the weights
+    change (the x projection of the forward pass and the dx GEMM of the backward pass each made their own copy per step)."""
+    buf, valid = ops.PackCache.get(w, ('lstm_wx', C), 4 * C * C)
+    wx = buf[:4 * C * C].view(4 * C, C)
+    if not valid:
+        wx.copy_(W2[:, :C])
+    return wx
+
+
 class ConvLSTMSeqFn(Function):
     """DWSConvLSTM2d (models/layers/rnn.py:37-70) unrolled over a whole sequence: x_seq [T,B,H,W,C] (channels-last rows),
     initial state (h0, c0) or None.  Only this recurrence is sequential in an RVT stage -- everything in front of it
@@ -355,6 +371,9 @@ class ConvLSTMSeqFn(Function):
         if h0 is None:
             hbuf[0].zero_()
             cbuf[0].zero_()
+        elif h0.dtype is hbuf.dtype and c0.dtype is cbuf.dtype and h0.is_contiguous() and c0.is_contiguous() and \
+                h0.shape == hbuf[0].shape and c0.shape == cbuf[0].shape and ops.multi_ok([hbuf[0], cbuf[0], h0, c0]):
+            ops.copy_multi([hbuf[0], cbuf[0]], [h0, c0])        # one launch for the pair
         else:
             hbuf[0].copy_(h0)
             cbuf[0].copy_(c0)
@@ -369,7 +388,7 @@ class ConvLSTMSeqFn(Function):
             # mode 3 (stage 4): the waves stream their weight fragments from a packed bf16 copy (shared with the backward pass)
             xin = x_seq
             if mode >= 2:
-                xin, _, _ = ops.ln_linear_fwd(x_seq.view(T * M, C), None, None, W2[:, :C].contiguous(), b)
+                xin, _, _ = ops.ln_linear_fwd(x_seq.view(T * M, C), None, None, _lstm_wx(w, W2, C), b)
             if mode == 3:
                 wpack = ops.convlstm_seq_pack(W2, C)
             ops.convlstm_seq_fwd(xin, mode >= 2, hbuf, cbuf, W2, b, gates, zero_state=h0 is None, wpack=wpack)
@@ -404,7 +423,7 @@ class ConvLSTMSeqFn(Function):
         assert seq_ok or not g16, 'fp16 gates are only written when the backward sequence kernel exists'
         if seq_ok:
             # backward through time in one launch; dx of all timesteps is ONE GEMM dgates W_x over T*M rows
-            dx_seq = ops.linear_dgrad(dgates.view(T * M, 4 * C), W2[:, :C].contiguous()).view(x_seq.shape)
+            dx_seq = ops.linear_dgrad(dgates.view(T * M, 4 * C), _lstm_wx(w, W2, C)).view(x_seq.shape)
             dh_next, dc_next = dh0, dc0
         else:
             dx_seq = torch.empty_like(x_seq)
@@ -441,7 +460,7 @@ class BaseConvFn(Function):
     @staticmethod
     def backward(ctx, dy):
         x, z, mean, rstd, conv_w, bn_w, bn_b = ctx.saved_tensors
-        dx = _conv_bn_bwd([(ctx.mod, x, z, mean, rstd, conv_w, bn_w, bn_b, ctx.stride, ctx.count, ctx.count_dev, _cont(dy),
+        dx = _conv_bn_bwd([(ctx.mod, x, z, mean, rstd, conv_w, bn_w, bn_b, ctx.stride, ctx.count, ctx.count_dev, _rows(dy),
                             ctx.needs_input_grad[1])])[0]
         return None, dx, None, None, None, None, None
 
@@ -537,7 +556,7 @@ class BaseConvGroupFn(Function):
         for i in range(n):
             x, z, mean, rstd, conv_w, bn_w, bn_b = sv[7 * i:7 * i + 7]
             members.append((mods[i], x, z, mean, rstd, conv_w, bn_w, bn_b, mods[i].stride, ctx.meta[i][0], ctx.meta[i][1],
-                            _cont(dys[i]), ctx.needs_input_grad[1 + i]))
+                            _rows(dys[i]), ctx.needs_input_grad[1 + i]))
         dxs = _conv_bn_bwd(members)
         return (None,) + tuple(dxs) + (None,) * (3 * n)
 

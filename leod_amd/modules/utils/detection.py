@@ -104,6 +104,17 @@ class RNNStates:
                 assert len(indices_or_bool_tensor) > 0
                 t[indices_or_bool_tensor] = 0
             return t
+        if th.is_tensor(indices_or_bool_tensor) and indices_or_bool_tensor.dtype == th.bool:
+            # device states: the masked reset of ALL tensors (h and c of every stage) is one kernel launch
+            ts = []
+            _map_tensors(inp, lambda t: ts.append(t) or t)
+            if ts and all(t.is_cuda and not t.requires_grad for t in ts):
+                from leod_amd import ops
+                mask = indices_or_bool_tensor.to(ts[0].device, non_blocking=True).contiguous()
+                if ops.multi_ok(ts) and all(t.shape[0] == mask.numel() for t in ts):
+                    assert mask.numel() > 0
+                    ops.rows_masked_zero(ts, mask)
+                    return inp
         return _map_tensors(inp, zero)
 
     def save_states_and_detach(self, worker_id: int, states) -> None:

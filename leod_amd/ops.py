@@ -85,6 +85,14 @@ def _ck(t: Optional[torch.Tensor], dtype=F32, name='tensor'):
         raise LeodHipError(f'{name}: expected a contiguous tensor, got strides {t.stride()}')
 
 
+def _ck_dtype_dev(t: torch.Tensor, dtype=F32, name='tensor'):
+    """``_ck`` without the contiguity requirement (for operands a kernel reads with an explicit row stride)."""
+    if not t.is_cuda:
+        raise LeodHipError(f'{name}: the LEOD HIP path needs device tensors (got {t.device}); there is no CPU fallback')
+    if t.dtype != dtype:
+        raise LeodHipError(f'{name}: expected {dtype}, got {t.dtype}')
+
+
 def _empty(shape, like: torch.Tensor, dtype=F32):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
@@ -643,12 +651,32 @@ class StatArena:
         return torch.zeros(shape, dtype=dtype, device=device)
 
 
+def row_stride(t: torch.Tensor, N: int) -> int:
+    """Row stride (elements) of ``t`` seen as [rows, N] when its rows are evenly spaced -- a contiguous tensor (N) or the channel slice
+    ``wide[..., c0:c0 + N]`` of a contiguous wider map, which is what ``torch.cat``'s backward hands out; 0: anything else."""
+    if t.is_contiguous():
+        return N
+    if t.dim() < 2 or t.shape[-1] != N or t.stride(-1) != 1:
+        return 0
+    ld = t.stride(-2)
+    exp = ld
+    for d in range(t.dim() - 2, -1, -1):
+        if t.shape[d] != 1 and t.stride(d) != exp:
+            return 0
+        exp *= t.shape[d]
+    return ld if (ld >= N and ld % 4 == 0 and t.storage_offset() % 4 == 0) else 0
+
+
 def bn_silu_bwd_reduce(dy, z, mean, rstd, w, b, out=None):
-    _ck(dy, name='dy')
+    """dy: contiguous, or a channel slice of a wider contiguous map (see ``row_stride``) -- read in place with its row stride."""
     N = z.shape[-1]
     M = z.numel() // N
+    ld = row_stride(dy, N)
+    if not ld:
+        raise LeodHipError('bn_silu_bwd_reduce: dy must be contiguous or a channel slice of a contiguous map')
+    _ck_dtype_dev(dy, F32, 'dy')
     sums = StatArena.zeros((2, N), z.device) if out is None else out
-    check(_l().leod_bn_silu_bwd_reduce(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(sums), M, N, _stream()),
+    check(_l().leod_bn_silu_bwd_reduce(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(sums), M, N, ld, _stream()),
           'bn_silu_bwd_reduce')
     return sums
 
@@ -656,9 +684,13 @@ def bn_silu_bwd_reduce(dy, z, mean, rstd, w, b, out=None):
 def bn_silu_bwd_apply(dy, z, mean, rstd, w, b, sums, dw, db, count, count_dev=None):
     N = z.shape[-1]
     M = z.numel() // N
+    ld = row_stride(dy, N)
+    if not ld:
+        raise LeodHipError('bn_silu_bwd_apply: dy must be contiguous or a channel slice of a contiguous map')
+    _ck_dtype_dev(dy, F32, 'dy')
     dz = _empty(z.shape, z)
     check(_l().leod_bn_silu_bwd_apply(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(sums), _p(dz), _p(dw), _p(db),
-                                       M, N, float(count), _p(count_dev), _stream()), 'bn_silu_bwd_apply')
+                                       M, N, float(count), _p(count_dev), ld, _stream()), 'bn_silu_bwd_apply')
     return dz
 
 
@@ -779,6 +811,45 @@ def adamw_clip_step(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, weight_d
         _ck(t, name='adamw buffer')
     check(_l().leod_adamw_clip_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
                                      int(step), float(clip_value), float(grad_scale), _p(hp_dev), _stream()), 'adamw_clip_step')
+
+
+def _ptr_array(ts):
+    import ctypes
+    return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def _long_array(v):
+    import ctypes
+    return (ctypes.c_long * len(v))(*[int(x) for x in v])
+
+
+def multi_ok(ts) -> bool:
+    """Operands the multi-buffer plumbing kernels take: dense device tensors, 16-byte aligned, a multiple of 16 bytes per row."""
+    def dense(t):      # rows (dim 0) back to back, each row dense: plain contiguous, or NCHW-shaped views of NHWC memory
+        return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+    return 0 < len(ts) <= 16 and all(t.is_cuda and dense(t) and t.data_ptr() % 16 == 0 and t.numel() > 0 and
+                                     (t[0].numel() * t.element_size()) % 16 == 0 for t in ts)
+
+
+def rows_masked_zero(tensors, mask):
+    """t[b] = 0 where mask[b], for every t in ``tensors`` ([B, ...] each), in one launch (RNNStates.reset)."""
+    if mask.dtype is not torch.bool or not mask.is_cuda or not mask.is_contiguous() or not multi_ok(tensors):
+        raise LeodHipError('rows_masked_zero: contiguous device tensors with 16-byte rows and a bool device mask')
+    B = mask.numel()
+    if any(t.shape[0] != B for t in tensors):
+        raise LeodHipError('rows_masked_zero: every tensor needs one row per mask entry')
+    check(_l().leod_rows_masked_zero(_ptr_array(tensors), _long_array([t[0].numel() * t.element_size() for t in tensors]), len(tensors),
+                                      _p(mask), B, _stream()), 'rows_masked_zero')
+
+
+def copy_multi(dsts, srcs):
+    """dst_k[:] = src_k[:] for all k in one launch (same dtype and element count per pair)."""
+    if len(dsts) != len(srcs) or not multi_ok(dsts) or not multi_ok(srcs) or \
+            any(d.dtype is not s_.dtype or d.shape != s_.shape or d.stride() != s_.stride() or (d.numel() * d.element_size()) % 16
+                for d, s_ in zip(dsts, srcs)):
+        raise LeodHipError('copy_multi: pairs of dense, 16-byte aligned device tensors of equal dtype, shape and strides')
+    check(_l().leod_copy_multi(_ptr_array(dsts), _ptr_array(srcs), _long_array([d.numel() * d.element_size() for d in dsts]), len(dsts),
+                                _stream()), 'copy_multi')
 
 
 def set_scalars4(dst, a, b, c, d):

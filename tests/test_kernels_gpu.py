@@ -373,6 +373,43 @@ def test_conv_bn_eval_and_train(ops, stat_rep):
     close(dbb, bb.grad, rtol=2e-4, atol=5e-5)
     dx = ops.conv_nhwc_dgrad(dz, w.detach().to(DEV), xn.shape)
     close(dx, x.grad.permute(0, 2, 3, 1), rtol=2e-4, atol=2e-5)
+    # dy as the channel slice torch.cat's backward hands to one branch of a concat: read in place with its row stride, same bits
+    wide = torch.randn((B, H, W, N + 96), device=DEV)
+    wide[..., 32:32 + N] = dyn
+    dys = wide[..., 32:32 + N]
+    assert not dys.is_contiguous() and ops.row_stride(dys, N) == N + 96 and ops.row_stride(dys.permute(0, 2, 1, 3), N) == 0
+    sums2 = ops.bn_silu_bwd_reduce(dys, zz, mean, rstd, bw.detach().to(DEV), bb.detach().to(DEV))
+    dz2 = ops.bn_silu_bwd_apply(dys, zz, mean, rstd, bw.detach().to(DEV), bb.detach().to(DEV), sums2, torch.zeros(N, device=DEV),
+                                torch.zeros(N, device=DEV), M)
+    close(sums2, sums, rtol=1e-6, atol=1e-7)
+    close(dz2, dz, rtol=1e-6, atol=1e-7)
+
+
+def test_state_plumbing_multi_buffer_kernels(ops):
+    """rows_masked_zero == `t[mask] = 0` per tensor (reference modules/utils/detection.py:60-75), copy_multi == copy_ per pair --
+    over contiguous and NCHW-shaped-over-NHWC tensors of different row sizes, bit-exact."""
+    B = 8
+    g = torch.Generator().manual_seed(3)
+    ts = [torch.randn((B, 64, 80, 48), generator=g), torch.randn((B, 8, 10, 384), generator=g).permute(0, 3, 1, 2),
+          torch.randn((B, 20), generator=g), torch.randn((B, 16, 20, 192), generator=g)]
+    mask = torch.tensor([1, 0, 0, 1, 0, 1, 1, 0], dtype=torch.bool)
+    ref = [t.clone() for t in ts]
+    for r in ref:
+        r[mask] = 0
+    dev = [t.to(DEV) for t in ts]
+    assert not dev[1].is_contiguous() and ops.multi_ok(dev)
+    ops.rows_masked_zero(dev, mask.to(DEV))
+    for d, r in zip(dev, ref):
+        assert torch.equal(d.cpu(), r)
+    none = torch.zeros(B, dtype=torch.bool, device=DEV)
+    before = [d.clone() for d in dev]
+    ops.rows_masked_zero(dev, none)
+    assert all(torch.equal(a, b) for a, b in zip(dev, before))
+    dst = [torch.zeros_like(d) for d in dev]
+    ops.copy_multi(dst, dev)
+    assert all(torch.equal(a, b) for a, b in zip(dst, dev))
+    with pytest.raises(Exception):
+        ops.copy_multi([torch.zeros((B, 3), device=DEV)], [torch.zeros((B, 3), device=DEV)])     # 12-byte rows: refused, not mis-copied
 
 
 # ---------------------------------------------------------------------------------------------------
