@@ -16,6 +16,8 @@ for MODE in two single; do
   SUF=""; [ $MODE = single ] && SUF="_single_stream"
   python tools/rocprof_summary.py $D $OUT/${TAG}_bench_bf16${SUF}_steps5_kernel_stats.csv > /dev/null 2>&1
   [ $MODE = two ] && python tools/stream_gaps.py $D > $OUT/${TAG}_main_stream_gaps_under_rocprof.txt 2>&1
+  [ $MODE = two ] && python tools/stream_tail.py $D > $OUT/${TAG}_stream_tail_under_rocprof.txt 2>&1
+  python tools/last_step_kernels.py $D $OUT/${TAG}_last_step${SUF}_kernels.csv > /dev/null 2>&1
   rm -rf $D
 done
 # PMC: attention (bf16 tiles) and the Linear GEMM family
