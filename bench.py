@@ -140,6 +140,7 @@ def main():
     ap.add_argument('--no-second-dtype', action='store_true', help='skip the secondary line measured in the other precision (N=1 only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--dump-calls', default='', help='file for the per-launch table (C entry point, shape arguments, us) of the probe steps')
     args = ap.parse_args()
 
     from leod_amd.parallel import init_distributed
@@ -248,6 +249,10 @@ def main():
                 roofline_gemm = probe.finish(PEAK_HBM_GBS, peak_t, target='linear_gemm')
                 # every C entry point bracketed with events during the same two single-stream steps: the line audits itself
                 family_ms = probe.family_ms(2)
+                if args.dump_calls:                           # every C launch of the two probe steps, in order (tools / profiles)
+                    with open(args.dump_calls, 'w') as f:
+                        for n, ints, us in probe.call_table():
+                            f.write(f'{us:9.1f}  {n:<34s} {ints}\n')
             # HBM bytes per launch of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
             # separate rocprofv3 --pmc runs; bench.py itself cannot sample hardware counters)
             tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')

@@ -185,9 +185,9 @@ int leod_bn_silu_fwd(const float* z, const double* colstats, int stat_rep, const
                      float* save_rstd, float* run_mean, float* run_var, int M, int N, double count,
                      const double* count_dev, float eps, float momentum, leod_stream_t stream);
 int leod_bn_silu_bwd_reduce(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
-                            const float* b, double* sums, int M, int N, int lddy, leod_stream_t stream);
+                            const float* b, double* sums, int rep, int M, int N, int lddy, leod_stream_t stream);
 int leod_bn_silu_bwd_apply(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
-                           const float* b, const double* sums, float* dz, float* dw, float* db, int M, int N, double count,
+                           const float* b, const double* sums, int rep, float* dz, float* dw, float* db, int M, int N, double count,
                            const double* count_dev, int lddy, leod_stream_t stream);
 
 /* ---- YOLOX head tail (models/detection/yolox/models/yolo_head.py) --------------------------------- */

@@ -280,11 +280,15 @@ __global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const float* __restric
     }
 }
 
+// RPT rows per thread, all 2 * RPT 16-byte loads of a thread issued before the first use (the row loop of the previous version paid one
+// memory round trip per 4 rows: 13.7 us for a 2560-row map); the workgroup's sums go to replica blockIdx.x % rep of the
+// (sum du, sum du*xhat) block, so that the double atomics on one address are gridDim.x / rep deep (bn_silu_bwd_apply folds the replicas).
+template <int RPT>
 __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ w, const float* __restrict__ b,
-                                                                 double* __restrict__ sums, long M, int N, long lddy) {
-    // thread t owns 4 consecutive channels c = 4*(t % (N/4)) and strides over rows; partial sums are combined in
+                                                                 double* __restrict__ sums, int rep, long M, int N, long lddy) {
+    // thread t owns 4 consecutive channels c = 4*(t % (N/4)) and rows r0 + rstep * e; partial sums are combined in
     // LDS so that each workgroup issues ONE double atomic per (channel, statistic)
     extern __shared__ float sred[];                 // [2*N]
     for (int c = threadIdx.x; c < 2 * N; c += blockDim.x) sred[c] = 0.f;
@@ -294,31 +298,51 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const float* __
     const int rlane = threadIdx.x / ncg, rstep = blockDim.x / ncg;
     if (rlane < rstep) {
         const int c = 4 * cg;
+        const long r0 = (long)blockIdx.x * rstep * RPT + rlane;
+        f4 zv[RPT], dv[RPT];
+#pragma unroll
+        for (int e = 0; e < RPT; ++e) {
+            const long row = min(r0 + (long)e * rstep, M - 1);
+            zv[e] = ld4(z + row * N + c);
+            dv[e] = ld4(dy + row * lddy + c);
+        }
         const f4 mu = ld4(mean + c), rs = ld4(rstd + c), ww = ld4(w + c), bb = ld4(b + c);
         f4 s0 = zero4(), s1 = zero4();
-#pragma unroll 4
-        for (long row = (long)blockIdx.x * rstep + rlane; row < M; row += (long)gridDim.x * rstep) {
-            const f4 xh = (ld4(z + row * N + c) - mu) * rs;
-            const f4 u = xh * ww + bb;
-            f4 du = ld4(dy + row * lddy + c);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) du[k] *= silu_grad(u[k]);
+        for (int e = 0; e < RPT; ++e) {
+            const f4 xh = (zv[e] - mu) * rs;
+            const f4 u = xh * ww + bb;
+            f4 du = dv[e];
+            const bool ok = r0 + (long)e * rstep < M;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) du[k] = ok ? du[k] * silu_grad(u[k]) : 0.f;
             s0 += du; s1 += du * xh;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) { atomicAdd(&sred[c + k], s0[k]); atomicAdd(&sred[N + c + k], s1[k]); }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * N; c += blockDim.x) atomicAdd(sums + c, (double)sred[c]);
+    double* dst = sums + (size_t)(blockIdx.x % rep) * 2 * N;
+    for (int c = threadIdx.x; c < 2 * N; c += blockDim.x) atomicAdd(dst + c, (double)sred[c]);
 }
 
 __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 const float* __restrict__ w, const float* __restrict__ b,
-                                                                const double* __restrict__ sums, float* __restrict__ dz,
+                                                                const double* __restrict__ sums, int rep, float* __restrict__ dz,
                                                                 float* __restrict__ dw, float* __restrict__ db, long M, int N,
                                                                 double count, const double* __restrict__ count_dev, long lddy) {
+    // every workgroup folds the `rep` replicas once and keeps per channel (sum du / count, sum du*xhat / count, w * rstd) in LDS:
+    // the double-precision divides run once per channel and workgroup instead of twice per element
+    extern __shared__ float sst[];                   // [3][N]
     if (count_dev) count = count * count_dev[0];     // SyncBatchNorm: rows per image (host) x images over all ranks (device)
+    for (int c = threadIdx.x; c < N; c += blockDim.x) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int r = 0; r < rep; ++r) { s0 += sums[(size_t)r * 2 * N + c]; s1 += sums[(size_t)r * 2 * N + N + c]; }
+        sst[c] = (float)(s0 / count); sst[N + c] = (float)(s1 / count); sst[2 * N + c] = w[c] * rstd[c];
+        if (blockIdx.x == 0 && dw) { dw[c] += (float)s1; db[c] += (float)s0; }
+    }
+    __syncthreads();
     const long n4 = M * N / 4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
         const long e = idx * 4; const int c = (int)(e % N);
@@ -326,16 +350,15 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const float* __r
         const f4 xh = (ld4(z + e) - mu) * rs;
         const f4 u = xh * ww + bb;
         f4 du = ld4(lddy == N ? dy + e : dy + (e / N) * lddy + c), r;
+        const f4 m0 = *reinterpret_cast<const f4*>(sst + c), m1 = *reinterpret_cast<const f4*>(sst + N + c);
+        const f4 wr = *reinterpret_cast<const f4*>(sst + 2 * N + c);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             du[k] *= silu_grad(u[k]);
-            const float m0 = (float)(sums[c + k] / count), m1 = (float)(sums[N + c + k] / count);
-            r[k] = ww[k] * rs[k] * (du[k] - m0 - xh[k] * m1);
+            r[k] = wr[k] * (du[k] - m0[k] - xh[k] * m1[k]);
         }
         *reinterpret_cast<f4*>(dz + e) = r;
     }
-    if (blockIdx.x == 0 && dw)
-        for (int c = threadIdx.x; c < N; c += blockDim.x) { dw[c] += (float)sums[N + c]; db[c] += (float)sums[c]; }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -408,25 +431,33 @@ LEOD_API int leod_bn_silu_fwd(const float* z, const double* colstats, int stat_r
 }
 
 LEOD_API int leod_bn_silu_bwd_reduce(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
-                                     const float* b, double* sums, int M, int N, int lddy, hipStream_t stream) {
+                                     const float* b, double* sums, int rep, int M, int N, int lddy, hipStream_t stream) {
     if (!dy || !z || !mean || !rstd || !w || !b || !sums || (N & 3) || N / 4 > 256 || (lddy && (lddy < N || (lddy & 3)))) return LEOD_ERR_ARG;
     if (M <= 0) return LEOD_OK;
+    if (rep < 1) rep = 1;
     const int rstep = 256 / (N / 4);
-    // every workgroup ends with 2 N double atomics on the same few cache lines (1024 workgroups x 192 atomics: 31 us for the
-    // 40960 x 96 level-0 maps, 16 us with 256 workgroups): >= 16 rows per thread, <= 256 workgroups (tools/kbench_bn.py)
-    static const int cap = getenv("LEOD_BN_BWD_BLOCKS") ? atoi(getenv("LEOD_BN_BWD_BLOCKS")) : 256;
-    const int grid = (int)min((long)cap, max((long)1, ((long)M + rstep * 16 - 1) / (rstep * 16)));
-    hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3(grid), dim3(256), 2 * N * sizeof(float), stream, dy, z, mean, rstd, w, b, sums, (long)M, N,
-                       (long)(lddy ? lddy : N));
+    // 8 rows per thread (4 when that leaves fewer than 128 workgroups); the same-address double atomics at the end of a workgroup
+    // are spread over `rep` replicas (1024 workgroups x 192 atomics on ONE copy took 31 us for the 40960 x 96 maps, tools/kbench_bn.py)
+    const long lddy_ = (long)(lddy ? lddy : N);
+    const int rpt = ((long)M + rstep * 8 - 1) / (rstep * 8) >= 128 ? 8 : 4;
+    const int grid = (int)(((long)M + rstep * rpt - 1) / (rstep * rpt));
+    if (rpt == 8)
+        hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel<8>, dim3(grid), dim3(256), 2 * N * sizeof(float), stream, dy, z, mean, rstd, w, b, sums, rep,
+                           (long)M, N, lddy_);
+    else
+        hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel<4>, dim3(grid), dim3(256), 2 * N * sizeof(float), stream, dy, z, mean, rstd, w, b, sums, rep,
+                           (long)M, N, lddy_);
     return leod_launch_status();
 }
 
 LEOD_API int leod_bn_silu_bwd_apply(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
-                                    const float* b, const double* sums, float* dz, float* dw, float* db, int M, int N,
+                                    const float* b, const double* sums, int rep, float* dz, float* dw, float* db, int M, int N,
                                     double count, const double* count_dev, int lddy, hipStream_t stream) {
     if (!dy || !z || !mean || !rstd || !w || !b || !sums || !dz || (N & 3) || (lddy && (lddy < N || (lddy & 3)))) return LEOD_ERR_ARG;
     if (M <= 0) return LEOD_OK;
-    hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(flat_grid((long)M * N / 4)), dim3(256), 0, stream, dy, z, mean, rstd,
-                       w, b, sums, dz, dw, db, (long)M, N, count, count_dev, (long)(lddy ? lddy : N));
+    if (rep < 1) rep = 1;
+    const int grid = (int)min((long)1024, max((long)1, ((long)M * N / 4 + 255) / 256));
+    hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid), dim3(256), 3 * N * sizeof(float), stream, dy, z, mean, rstd,
+                       w, b, sums, rep, dz, dw, db, (long)M, N, count, count_dev, (long)(lddy ? lddy : N));
     return leod_launch_status();
 }

@@ -508,15 +508,21 @@ def _conv_bn_bwd(members):
     dxs = {}
     if live:
         dev = live[0][1].device
-        block = ops.StatArena.zeros((sum(2 * m[5].shape[0] for m in live),), dev)
+        # the reductions spread their closing atomics over R copies of a member's sums (R by rows), the apply kernels fold them
+        sync = _sync_bn_on()
+
+        def rows_of(z):       # SyncBatchNorm: the block is all-reduced, so its layout must not depend on this rank's image count
+            return (32 if sync else z.shape[0]) * (z.numel() // (z.shape[0] * z.shape[-1]))
+        reps = [ops.bn_bwd_replicas(rows_of(m[2])) for m in live]
+        block = ops.StatArena.zeros((sum(2 * R * m[5].shape[0] for m, R in zip(live, reps)),), dev)
         off = 0
         slices = []
-        for mod, x, z, mean, rstd, conv_w, bn_w, bn_b, stride, count, count_dev, dy, need_dx in live:
+        for (mod, x, z, mean, rstd, conv_w, bn_w, bn_b, stride, count, count_dev, dy, need_dx), R in zip(live, reps):
             N = conv_w.shape[0]
-            sl = block[off:off + 2 * N].view(2, N)
+            sl = block[off:off + 2 * R * N].view(R, 2, N)
             ops.bn_silu_bwd_reduce(dy, z, mean, rstd, bn_w, bn_b, out=sl)
             slices.append(sl)
-            off += 2 * N
+            off += 2 * R * N
         _allreduce_stats(block)
         for (mod, x, z, mean, rstd, conv_w, bn_w, bn_b, stride, count, count_dev, dy, need_dx), sl in zip(live, slices):
             dz = ops.bn_silu_bwd_apply(dy, z, mean, rstd, bn_w, bn_b, sl, grad_buf(mod.bn.weight), grad_buf(mod.bn.bias), count,

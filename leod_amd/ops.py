@@ -667,16 +667,28 @@ def row_stride(t: torch.Tensor, N: int) -> int:
     return ld if (ld >= N and ld % 4 == 0 and t.storage_offset() % 4 == 0) else 0
 
 
+def bn_bwd_replicas(rows: int) -> int:
+    """Copies of the (sum du, sum du*xhat) block the workgroups of bn_silu_bwd_reduce spread their closing atomics over: one per
+    2560 rows, a power of two in [1, 16]; bn_silu_bwd_apply folds them in every workgroup."""
+    r = 1
+    while r < 16 and r * 2560 < rows:
+        r *= 2
+    return r
+
+
 def bn_silu_bwd_reduce(dy, z, mean, rstd, w, b, out=None):
-    """dy: contiguous, or a channel slice of a wider contiguous map (see ``row_stride``) -- read in place with its row stride."""
+    """out: zero-filled float64 [2,N] or [R,2,N] (R replicas, see ``bn_bwd_replicas``).
+    dy: contiguous, or a channel slice of a wider contiguous map (see ``row_stride``) -- read in place with its row stride."""
     N = z.shape[-1]
     M = z.numel() // N
     ld = row_stride(dy, N)
     if not ld:
         raise LeodHipError('bn_silu_bwd_reduce: dy must be contiguous or a channel slice of a contiguous map')
     _ck_dtype_dev(dy, F32, 'dy')
-    sums = StatArena.zeros((2, N), z.device) if out is None else out
-    check(_l().leod_bn_silu_bwd_reduce(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(sums), M, N, ld, _stream()),
+    sums = StatArena.zeros((bn_bwd_replicas(M), 2, N), z.device) if out is None else out
+    _ck(sums, torch.float64, 'sums')
+    rep = sums.shape[0] if sums.dim() == 3 else 1
+    check(_l().leod_bn_silu_bwd_reduce(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(sums), rep, M, N, ld, _stream()),
           'bn_silu_bwd_reduce')
     return sums
 
@@ -689,7 +701,8 @@ def bn_silu_bwd_apply(dy, z, mean, rstd, w, b, sums, dw, db, count, count_dev=No
         raise LeodHipError('bn_silu_bwd_apply: dy must be contiguous or a channel slice of a contiguous map')
     _ck_dtype_dev(dy, F32, 'dy')
     dz = _empty(z.shape, z)
-    check(_l().leod_bn_silu_bwd_apply(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(sums), _p(dz), _p(dw), _p(db),
+    rep = sums.shape[0] if sums.dim() == 3 else 1
+    check(_l().leod_bn_silu_bwd_apply(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(sums), rep, _p(dz), _p(dw), _p(db),
                                        M, N, float(count), _p(count_dev), ld, _stream()), 'bn_silu_bwd_apply')
     return dz
 
@@ -893,6 +906,7 @@ class KernelProbe:
         self.bytes = {t: 0.0 for t in self.targets}
         self.flops = {t: 0.0 for t in self.targets}
         self.fam_events = {}
+        self.calls = []                    # (C entry point, small integer arguments, start event, end event) in launch order
         self.by_rows = {}
         self.real_lib = _l()
         if families:
@@ -919,6 +933,10 @@ class KernelProbe:
         """{C entry point: ms per step}, largest first, from the per-call event brackets (single-stream probe steps)."""
         tot = {k: sum(a.elapsed_time(b) for a, b in v) / max(steps, 1) for k, v in self.fam_events.items()}
         return {k: round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:top]}
+
+    def call_table(self):
+        """[(C entry point, small integer arguments (shapes / flags), us)] of every bracketed launch, in launch order."""
+        return [(n, ints, round(1e3 * a.elapsed_time(b), 1)) for n, ints, a, b in self.calls]
 
     def finish(self, peak_gbs, peak_tflops=157.3, target=None):
         """Roofline object of one probed family.  The bound is chosen by the family's arithmetic intensity
@@ -980,6 +998,7 @@ class _ProbedLib:
                     rc = _real(*a)
                     e1.record()
                     probe.fam_events.setdefault(_name, []).append((e0, e1))
+                    probe.calls.append((_name, [x for x in a if isinstance(x, int) and not isinstance(x, bool) and 0 < x < (1 << 24)], e0, e1))
                     return rc
             self._cache[name] = fn
         return fn

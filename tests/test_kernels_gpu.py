@@ -385,6 +385,29 @@ def test_conv_bn_eval_and_train(ops, stat_rep):
     close(dz2, dz, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize('M,N,rep', [(5000, 96, 1), (5000, 96, 4), (40960, 48, 16), (2563, 384, 2), (77, 192, 1), (10240, 192, 4)])
+def test_bn_silu_bwd_replicas(ops, M, N, rep):
+    """BatchNorm + SiLU backward (network_blocks.py:47-51) on rows: the reduce kernel's 4 / 8-row threads with a ragged tail, its
+    closing atomics spread over `rep` copies of the sums, the apply kernel folding them -- against torch autograd in fp64."""
+    z = rnd((M, N), 11).double().requires_grad_(True)
+    bw, bb = (1 + 0.2 * rnd((N,), 12)).double().requires_grad_(True), (0.1 * rnd((N,), 13)).double().requires_grad_(True)
+    dy = rnd((M, N), 14).double()
+    mean, var = z.mean(0), z.var(0, unbiased=False)
+    F.silu((z - mean) / torch.sqrt(var + 1e-5) * bw + bb).backward(dy)
+    zd, dyd = z.detach().float().to(DEV), dy.float().to(DEV)
+    meand, rstdd = mean.detach().float().to(DEV), (1.0 / torch.sqrt(var.detach() + 1e-5)).float().to(DEV)
+    bwd, bbd = bw.detach().float().to(DEV), bb.detach().float().to(DEV)
+    sums = torch.zeros((rep, 2, N) if rep > 1 else (2, N), dtype=torch.float64, device=DEV)
+    ops.bn_silu_bwd_reduce(dyd, zd, meand, rstdd, bwd, bbd, out=sums)
+    if rep > 1:
+        assert int((sums.abs().sum((1, 2)) > 0).sum()) == rep          # every copy took some workgroups' atomics
+    dbw, dbb = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
+    dz = ops.bn_silu_bwd_apply(dyd, zd, meand, rstdd, bwd, bbd, sums, dbw, dbb, M)
+    close(dbw, bw.grad.float(), rtol=2e-4, atol=2e-4 * float(bw.grad.abs().max()))
+    close(dbb, bb.grad.float(), rtol=2e-4, atol=2e-4 * float(bb.grad.abs().max()))
+    close(dz, z.grad.float(), rtol=2e-4, atol=2e-5)
+
+
 def test_state_plumbing_multi_buffer_kernels(ops):
     """rows_masked_zero == `t[mask] = 0` per tensor (reference modules/utils/detection.py:60-75), copy_multi == copy_ per pair --
     over contiguous and NCHW-shaped-over-NHWC tensors of different row sizes, bit-exact."""

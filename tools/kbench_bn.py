@@ -15,7 +15,7 @@ for name, M, N in [('s8 96', 32 * 32 * 40, 96), ('s8 48', 32 * 32 * 40, 48), ('s
                    ('s32 192', 32 * 8 * 10, 192), ('s32 384', 32 * 8 * 10, 384)]:
     z, dy = torch.randn(M, N, device=DEV), torch.randn(M, N, device=DEV)
     mean, rstd, w, b = torch.zeros(N, device=DEV), torch.ones(N, device=DEV), torch.ones(N, device=DEV), torch.zeros(N, device=DEV)
-    sums = torch.zeros(2, N, dtype=torch.float64, device=DEV)
+    sums = torch.zeros(ops.bn_bwd_replicas(M), 2, N, dtype=torch.float64, device=DEV)
     dw, db = torch.zeros(N, device=DEV), torch.zeros(N, device=DEV)
     tr = timeit(lambda: ops.bn_silu_bwd_reduce(dy, z, mean, rstd, w, b, out=sums))
     ta = timeit(lambda: ops.bn_silu_bwd_apply(dy, z, mean, rstd, w, b, sums, dw, db, float(M)))
