@@ -428,6 +428,7 @@ struct BLPackT2 {                 // parity-class dgrad on PACKED weights wd[c][
 // Epilogues.  acc[t][r] = Out[row0 + 4*(lane>>4) + r][col(nblk,t,lane&15)]
 // =================================================================================================
 enum { ACT_NONE = 0, ACT_GELU_DUAL = 1, ACT_AFFINE_SILU = 2, ACT_MUL_GELU_GRAD = 3 };
+struct RowPre { f4 v[4]; };        // prefetched global operand of a row epilogue: one 16-byte piece per row group of the lane
 
 struct EpStore {
     float* out; long ld;            // primary output
@@ -506,6 +507,7 @@ struct EpStore {
     // q, q+4, q+8, q+12 -> every global access is a 16-byte access and a wave instruction covers whole row segments
     // (NT*64 contiguous bytes per row) instead of 64-byte column slivers of 4-byte stores.
     static constexpr bool kRowEpilogue = true;
+    static constexpr bool kPrefetchRows = false;
     template <int NT, class BL>
     __device__ __forceinline__ void run_rows(const float* so, int ldo, const BL& bl, int row0, int nblk, int lane, int M) const {
         const int c4 = lane & 15, q = lane >> 4;
@@ -597,8 +599,27 @@ struct EpLsRes {                    // t = acc + bias; tout = t; out = res + gam
         }
     }
     static constexpr bool kRowEpilogue = true;
+    // the residual rows of a 16-row fragment, loaded for all four row groups of the lane at once and -- by the callers -- one fragment
+    // ahead of their use (read inside the row loop every row group paid its own memory round trip)
+    static constexpr bool kPrefetchRows = true;
+    template <int NT, class BL>
+    __device__ __forceinline__ RowPre prefetch_rows(const BL& bl, int row0, int nblk, int lane, int M) const {
+        RowPre r;
+        const int c4 = lane & 15, q = lane >> 4;
+        const int n = bl.col(nblk, 0, 0) + 4 * c4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = row0 + q + 4 * p;
+            r.v[p] = (c4 < NT * 4 && n < N && row < M) ? ld4(res + (long)row * ld + n) : zero4();
+        }
+        return r;
+    }
     template <int NT, class BL>
     __device__ __forceinline__ void run_rows(const float* so, int ldo, const BL& bl, int row0, int nblk, int lane, int M) const {
+        run_rows<NT, BL>(so, ldo, bl, row0, nblk, lane, M, prefetch_rows<NT, BL>(bl, row0, nblk, lane, M));
+    }
+    template <int NT, class BL>
+    __device__ __forceinline__ void run_rows(const float* so, int ldo, const BL& bl, int row0, int nblk, int lane, int M, const RowPre& pre) const {
         const int c4 = lane & 15, q = lane >> 4;
         const int n = bl.col(nblk, 0, 0) + 4 * c4;
         if (c4 >= NT * 4 || n >= N) return;
@@ -611,7 +632,7 @@ struct EpLsRes {                    // t = acc + bias; tout = t; out = res + gam
             const long o = (long)row * ld + n;
             const f4 tv = *reinterpret_cast<const f4*>(so + lr * ldo + 4 * c4) + bv;
             if (tout) *reinterpret_cast<f4*>(tout + o) = tv;
-            *reinterpret_cast<f4*>(out + o) = ld4(res + o) + g * tv;
+            *reinterpret_cast<f4*>(out + o) = pre.v[p] + g * tv;
         }
     }
 };
@@ -963,16 +984,24 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
     }
     if constexpr (EP::kRowEpilogue) {
         float* so = smem + wave * 16 * LDO;                   // wave-private 16 x BN tile
+        // the epilogue's own global operand (gelu' pre-activations / residual rows) travels one fragment ahead of its use
+        RowPre pre;
+        if constexpr (EP::kPrefetchRows) pre = ep.template prefetch_rows<NT, BL>(bl, brow0 + 16 * (RW * wave), nblk, lane, M);
 #pragma unroll
         for (int w = 0; w < RW; ++w) {
             const int row0 = brow0 + 16 * (RW * wave + w);
+            const RowPre cur = pre;
+            if constexpr (EP::kPrefetchRows) { if (w + 1 < RW) pre = ep.template prefetch_rows<NT, BL>(bl, row0 + 16, nblk, lane, M); }
             __syncthreads();                                  // operand buffers (w = 0) / previous tile (w > 0) are done with
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) so[(4 * q + r) * LDO + 16 * t + i] = acc[w][t][r];
             __syncthreads();
-            if (row0 < M) ep.template run_rows<NT, BL>(so, LDO, bl, row0, nblk, lane, M);
+            if (row0 < M) {
+                if constexpr (EP::kPrefetchRows) ep.template run_rows<NT, BL>(so, LDO, bl, row0, nblk, lane, M, cur);
+                else ep.template run_rows<NT, BL>(so, LDO, bl, row0, nblk, lane, M);
+            }
         }
     } else {
 #pragma unroll

@@ -424,7 +424,9 @@ LEOD_API int leod_bn_silu_fwd(const float* z, const double* colstats, int stat_r
                               double count, const double* count_dev, float eps, float momentum, hipStream_t stream) {
     if (!z || !colstats || !w || !b || !y || !save_mean || !save_rstd || (N & 3)) return LEOD_ERR_ARG;
     if (M <= 0) return LEOD_OK;
-    hipLaunchKernelGGL(bn_silu_fwd_kernel, dim3(flat_grid((long)M * N / 4)), dim3(256), 2 * N * sizeof(float), stream, z, colstats,
+    // every workgroup folds the stat_rep copies of (sum, sumsq): <= 1024 workgroups with a grid-stride row loop (4096 workgroups re-read
+    // up to 49 KB of replicas each)
+    hipLaunchKernelGGL(bn_silu_fwd_kernel, dim3(min(flat_grid((long)M * N / 4), 1024)), dim3(256), 2 * N * sizeof(float), stream, z, colstats,
                        stat_rep > 1 ? stat_rep : 1, w, b, y,
                        save_mean, save_rstd, run_mean, run_var, (long)M, N, count, count_dev, eps, momentum);
     return leod_launch_status();
