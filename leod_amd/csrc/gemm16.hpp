@@ -508,11 +508,66 @@ struct EpStore {
     // (NT*64 contiguous bytes per row) instead of 64-byte column slivers of 4-byte stores.
     static constexpr bool kRowEpilogue = true;
     static constexpr bool kPrefetchRows = false;
+    // Branch-free body for a fragment that lies inside the matrix, in the configurations of the Linear layers (OUTF: 0 fp32 / 1 fp16 /
+    // 2 bf16 store; GG: times gelu'(fp16 pre-activation); ADD: plus a second gradient source).  The generic body below has a
+    // data-dependent branch per row group (`row < M`) and wave-uniform ones per option: at every join hipcc's waitcnt insertion falls
+    // back to `s_waitcnt vmcnt(0)`, so each of the four row groups waited for the write acknowledgements of the previous one's stores
+    // (and for every load in flight) -- 16 exposed memory round trips per 64-row tile of a one-workgroup-per-CU kernel.
+    template <int OUTF, bool GG, bool ADD>
+    __device__ __forceinline__ void run_rows_fast(const float* so, int ldo, int row0, int n, int c4, int q) const {
+        const f4 bv = bias ? ld4(bias + n) : zero4();
+        f4 ux[4];
+        if constexpr (GG) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const f2_ h = *reinterpret_cast<const f2_*>(reinterpret_cast<const unsigned short*>(aux) + (long)(row0 + q + 4 * p) * ldaux + n);
+                ux[p].x = h.x; ux[p].y = h.y;
+            }
+        }
+        if constexpr (ADD) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) ux[p] = ld4(addsrc + (long)(row0 + q + 4 * p) * ld + n);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int lr = q + 4 * p;
+            const long row = row0 + lr;
+            f4 v = *reinterpret_cast<const f4*>(so + lr * ldo + 4 * c4) + bv;
+            if constexpr (GG) {
+                const f4 u = unpack_h16(__builtin_bit_cast(s4, f2_{ux[p].x, ux[p].y}));
+                v.x *= gelu_erf_grad(u.x); v.y *= gelu_erf_grad(u.y); v.z *= gelu_erf_grad(u.z); v.w *= gelu_erf_grad(u.w);
+            }
+            if constexpr (ADD) v += ux[p];
+            if constexpr (OUTF != 0) {
+                unsigned short* pp = reinterpret_cast<unsigned short*>(out) + row * ld + n;
+                *reinterpret_cast<s4*>(pp) = OUTF == 1 ? pack_h16(v) : pack_bf16(v);
+            } else {
+                *reinterpret_cast<f4*>(out + row * ld + n) = v;
+            }
+        }
+    }
     template <int NT, class BL>
     __device__ __forceinline__ void run_rows(const float* so, int ldo, const BL& bl, int row0, int nblk, int lane, int M) const {
         const int c4 = lane & 15, q = lane >> 4;
         const int n = bl.col(nblk, 0, 0) + 4 * c4;
         const bool nok = c4 < NT * 4 && n < N;
+        {
+            const bool gg = act == ACT_MUL_GELU_GRAD;
+            // 0 generic; 1 fp32; 2 fp32 + addsrc; 3 fp16; 4 bf16; 5 gelu' x -> bf16      (all wave-uniform)
+            const int fast = (row0 + 16 > M || colstats || colsum || nsplit != 0 || accumulate || rm_Q > 0 || !(act == ACT_NONE || (gg && aux_fmt == 1))) ? 0
+                             : gg ? ((out_fmt == 2 && !addsrc) ? 5 : 0)
+                             : out_fmt == 0 ? (addsrc ? 2 : 1) : (addsrc ? 0 : out_fmt == 1 ? 3 : 4);
+            if (fast) {
+                if (nok) {
+                    if (fast == 1) run_rows_fast<0, false, false>(so, ldo, row0, n, c4, q);
+                    else if (fast == 2) run_rows_fast<0, false, true>(so, ldo, row0, n, c4, q);
+                    else if (fast == 3) run_rows_fast<1, false, false>(so, ldo, row0, n, c4, q);
+                    else if (fast == 4) run_rows_fast<2, false, false>(so, ldo, row0, n, c4, q);
+                    else run_rows_fast<2, true, false>(so, ldo, row0, n, c4, q);
+                }
+                return;
+            }
+        }
         f4 bv = zero4(), sc = {1.f, 1.f, 1.f, 1.f}, sh = zero4();
         if (nok) {
             if (bias) bv = ld4(bias + n);
@@ -607,6 +662,13 @@ struct EpLsRes {                    // t = acc + bias; tout = t; out = res + gam
         RowPre r;
         const int c4 = lane & 15, q = lane >> 4;
         const int n = bl.col(nblk, 0, 0) + 4 * c4;
+        if (row0 + 16 <= M) {                                   // whole fragment inside (wave-uniform): four loads, no per-row branch
+            if (c4 < NT * 4 && n < N) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) r.v[p] = ld4(res + (long)(row0 + q + 4 * p) * ld + n);
+            }
+            return r;
+        }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int row = row0 + q + 4 * p;
@@ -625,6 +687,15 @@ struct EpLsRes {                    // t = acc + bias; tout = t; out = res + gam
         if (c4 >= NT * 4 || n >= N) return;
         const f4 bv = bias ? ld4(bias + n) : zero4();
         const f4 g = gamma ? ld4(gamma + n) : f4{1.f, 1.f, 1.f, 1.f};
+        if (row0 + 16 <= M && !tout) {                          // branch-free body (see EpStore::run_rows_fast)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int lr = q + 4 * p;
+                const f4 tv = *reinterpret_cast<const f4*>(so + lr * ldo + 4 * c4) + bv;
+                *reinterpret_cast<f4*>(out + (long)(row0 + lr) * ld + n) = pre.v[p] + g * tv;
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int lr = q + 4 * p, row = row0 + lr;
