@@ -513,9 +513,10 @@ struct EpStore {
     // data-dependent branch per row group (`row < M`) and wave-uniform ones per option: at every join hipcc's waitcnt insertion falls
     // back to `s_waitcnt vmcnt(0)`, so each of the four row groups waited for the write acknowledgements of the previous one's stores
     // (and for every load in flight) -- 16 exposed memory round trips per 64-row tile of a one-workgroup-per-CU kernel.
-    template <int OUTF, bool GG, bool ADD>
+    template <int OUTF, bool GG, bool ADD, bool STATS = false>
     __device__ __forceinline__ void run_rows_fast(const float* so, int ldo, int row0, int n, int c4, int q) const {
         const f4 bv = bias ? ld4(bias + n) : zero4();
+        f4 s1 = zero4(), s2 = zero4();
         f4 ux[4];
         if constexpr (GG) {
 #pragma unroll
@@ -544,6 +545,24 @@ struct EpStore {
             } else {
                 *reinterpret_cast<f4*>(out + row * ld + n) = v;
             }
+            if constexpr (STATS) { s1 += v; s2 += v * v; }
+        }
+        if constexpr (STATS) stats_tail(s1, s2, row0, n, q, true);
+    }
+    // column sums of the stored values of one fragment (BatchNorm statistics / bias gradient): 4 row groups folded by DPP, one atomic
+    // per column from the q = 0 lanes.  Every lane of the wave must call (nok: this lane owns valid columns).
+    __device__ __forceinline__ void stats_tail(const f4& s1, const f4& s2, int row0, int n, int q, bool nok) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = quad16_sum(s1[j]);
+            const float b = colstats ? quad16_sum(s2[j]) : 0.f;
+            if (q == 0 && nok) {
+                if (colstats) {
+                    double* cs = colstats + (stat_rep > 1 ? (size_t)((row0 >> 4) & (stat_rep - 1)) * 2 * N : 0);
+                    atomicAdd(cs + n + j, (double)a); atomicAdd(cs + N + n + j, (double)b);
+                }
+                if (colsum) atomicAdd(colsum + n + j, a);
+            }
         }
     }
     template <int NT, class BL>
@@ -554,9 +573,25 @@ struct EpStore {
         {
             const bool gg = act == ACT_MUL_GELU_GRAD;
             // 0 generic; 1 fp32; 2 fp32 + addsrc; 3 fp16; 4 bf16; 5 gelu' x -> bf16      (all wave-uniform)
-            const int fast = (row0 + 16 > M || colstats || colsum || nsplit != 0 || accumulate || rm_Q > 0 || !(act == ACT_NONE || (gg && aux_fmt == 1))) ? 0
+            const bool st = colstats || colsum;
+            const int fast = (row0 + 16 > M || nsplit != 0 || accumulate || rm_Q > 0 || !(act == ACT_NONE || (gg && aux_fmt == 1))) ? 0
+                             : st ? ((!gg && out_fmt == 0 && !addsrc) ? 6 : 0)
                              : gg ? ((out_fmt == 2 && !addsrc) ? 5 : 0)
                              : out_fmt == 0 ? (addsrc ? 2 : 1) : (addsrc ? 0 : out_fmt == 1 ? 3 : 4);
+            if (fast == 6) {                                   // conv 1x1 + BatchNorm statistics: the DPP sums need every lane
+                if (nok) run_rows_fast<0, false, false, false>(so, ldo, row0, n, c4, q);
+                f4 s1 = zero4(), s2 = zero4();
+                if (nok) {
+                    const f4 bv = bias ? ld4(bias + n) : zero4();
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const f4 v = *reinterpret_cast<const f4*>(so + (q + 4 * p) * ldo + 4 * c4) + bv;
+                        s1 += v; s2 += v * v;
+                    }
+                }
+                stats_tail(s1, s2, row0, n, q, nok);
+                return;
+            }
             if (fast) {
                 if (nok) {
                     if (fast == 1) run_rows_fast<0, false, false>(so, ldo, row0, n, c4, q);
@@ -615,20 +650,7 @@ struct EpStore {
             }
             s1 += v; s2 += v * v;
         }
-        if (colstats || colsum) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float a = quad16_sum(s1[j]);
-                const float b = colstats ? quad16_sum(s2[j]) : 0.f;
-                if (q == 0 && nok) {
-                    if (colstats) {
-                        double* cs = colstats + (stat_rep > 1 ? (size_t)((row0 >> 4) & (stat_rep - 1)) * 2 * N : 0);
-                        atomicAdd(cs + n + j, (double)a); atomicAdd(cs + N + n + j, (double)b);
-                    }
-                    if (colsum) atomicAdd(colsum + n + j, a);
-                }
-            }
-        }
+        if (colstats || colsum) stats_tail(s1, s2, row0, n, q, nok);
     }
 };
 
