@@ -428,7 +428,19 @@ struct BLPackT2 {                 // parity-class dgrad on PACKED weights wd[c][
 // Epilogues.  acc[t][r] = Out[row0 + 4*(lane>>4) + r][col(nblk,t,lane&15)]
 // =================================================================================================
 enum { ACT_NONE = 0, ACT_GELU_DUAL = 1, ACT_AFFINE_SILU = 2, ACT_MUL_GELU_GRAD = 3 };
-struct RowPre { f4 v[4]; };        // prefetched global operand of a row epilogue: one 16-byte piece per row group of the lane
+struct RowPre { f4 v[4]; };
+// f(std::integral_constant<int, mode>) for a run-time mode in [0, NM]
+template <int NM, class F>
+__device__ __forceinline__ void dispatch_fast_mode(int mode, F&& f) {
+    if (mode == 0) f(std::integral_constant<int, 0>{});
+    else if (NM >= 1 && mode == 1) f(std::integral_constant<int, (NM >= 1 ? 1 : 0)>{});
+    else if (NM >= 2 && mode == 2) f(std::integral_constant<int, (NM >= 2 ? 2 : 0)>{});
+    else if (NM >= 3 && mode == 3) f(std::integral_constant<int, (NM >= 3 ? 3 : 0)>{});
+    else if (NM >= 4 && mode == 4) f(std::integral_constant<int, (NM >= 4 ? 4 : 0)>{});
+    else if (NM >= 5 && mode == 5) f(std::integral_constant<int, (NM >= 5 ? 5 : 0)>{});
+    else if (NM >= 6 && mode == 6) f(std::integral_constant<int, (NM >= 6 ? 6 : 0)>{});
+    else f(std::integral_constant<int, 0>{});
+}        // prefetched global operand of a row epilogue: one 16-byte piece per row group of the lane
 
 struct EpStore {
     float* out; long ld;            // primary output
@@ -565,44 +577,51 @@ struct EpStore {
             }
         }
     }
+    // Configuration of a launch as one of the branch-free bodies (wave-uniform; the kernels pick the body ONCE per tile, outside their
+    // fragment loop: a choice inside run_rows joins the generic body after every fragment, and at that join the waitcnt pass drains
+    // again).  0 generic; 1 fp32; 2 fp32 + addsrc; 3 fp16; 4 bf16; 5 gelu' x -> bf16; 6 fp32 + column statistics
+    static constexpr int kFastModes = 6;
+    __device__ __forceinline__ int fast_mode() const {
+        const bool gg = act == ACT_MUL_GELU_GRAD, st = colstats || colsum;
+        return (nsplit != 0 || accumulate || rm_Q > 0 || !(act == ACT_NONE || (gg && aux_fmt == 1))) ? 0
+               : st ? ((!gg && out_fmt == 0 && !addsrc) ? 6 : 0)
+               : gg ? ((out_fmt == 2 && !addsrc) ? 5 : 0)
+               : out_fmt == 0 ? (addsrc ? 2 : 1) : (addsrc ? 0 : out_fmt == 1 ? 3 : 4);
+    }
+    template <int MODE, int NT, class BL>
+    __device__ __forceinline__ RowPre prefetch_full(const BL&, int, int, int) const { return RowPre{}; }
+    // fragment rows row0 .. row0 + 15 all inside the matrix
+    template <int MODE, int NT, class BL>
+    __device__ __forceinline__ void run_rows_full(const float* so, int ldo, const BL& bl, int row0, int nblk, int lane, const RowPre&) const {
+        const int c4 = lane & 15, q = lane >> 4;
+        const int n = bl.col(nblk, 0, 0) + 4 * c4;
+        const bool nok = c4 < NT * 4 && n < N;
+        if constexpr (MODE == 6) {                             // the DPP sums need every lane
+            f4 s1 = zero4(), s2 = zero4();
+            if (nok) {
+                const f4 bv = bias ? ld4(bias + n) : zero4();
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int lr = q + 4 * p;
+                    const f4 v = *reinterpret_cast<const f4*>(so + lr * ldo + 4 * c4) + bv;
+                    *reinterpret_cast<f4*>(out + (long)(row0 + lr) * ld + n) = v;
+                    s1 += v; s2 += v * v;
+                }
+            }
+            stats_tail(s1, s2, row0, n, q, nok);
+        } else if (nok) {
+            if constexpr (MODE == 1) run_rows_fast<0, false, false>(so, ldo, row0, n, c4, q);
+            else if constexpr (MODE == 2) run_rows_fast<0, false, true>(so, ldo, row0, n, c4, q);
+            else if constexpr (MODE == 3) run_rows_fast<1, false, false>(so, ldo, row0, n, c4, q);
+            else if constexpr (MODE == 4) run_rows_fast<2, false, false>(so, ldo, row0, n, c4, q);
+            else run_rows_fast<2, true, false>(so, ldo, row0, n, c4, q);
+        }
+    }
     template <int NT, class BL>
     __device__ __forceinline__ void run_rows(const float* so, int ldo, const BL& bl, int row0, int nblk, int lane, int M) const {
         const int c4 = lane & 15, q = lane >> 4;
         const int n = bl.col(nblk, 0, 0) + 4 * c4;
         const bool nok = c4 < NT * 4 && n < N;
-        {
-            const bool gg = act == ACT_MUL_GELU_GRAD;
-            // 0 generic; 1 fp32; 2 fp32 + addsrc; 3 fp16; 4 bf16; 5 gelu' x -> bf16      (all wave-uniform)
-            const bool st = colstats || colsum;
-            const int fast = (row0 + 16 > M || nsplit != 0 || accumulate || rm_Q > 0 || !(act == ACT_NONE || (gg && aux_fmt == 1))) ? 0
-                             : st ? ((!gg && out_fmt == 0 && !addsrc) ? 6 : 0)
-                             : gg ? ((out_fmt == 2 && !addsrc) ? 5 : 0)
-                             : out_fmt == 0 ? (addsrc ? 2 : 1) : (addsrc ? 0 : out_fmt == 1 ? 3 : 4);
-            if (fast == 6) {                                   // conv 1x1 + BatchNorm statistics: the DPP sums need every lane
-                if (nok) run_rows_fast<0, false, false, false>(so, ldo, row0, n, c4, q);
-                f4 s1 = zero4(), s2 = zero4();
-                if (nok) {
-                    const f4 bv = bias ? ld4(bias + n) : zero4();
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        const f4 v = *reinterpret_cast<const f4*>(so + (q + 4 * p) * ldo + 4 * c4) + bv;
-                        s1 += v; s2 += v * v;
-                    }
-                }
-                stats_tail(s1, s2, row0, n, q, nok);
-                return;
-            }
-            if (fast) {
-                if (nok) {
-                    if (fast == 1) run_rows_fast<0, false, false>(so, ldo, row0, n, c4, q);
-                    else if (fast == 2) run_rows_fast<0, false, true>(so, ldo, row0, n, c4, q);
-                    else if (fast == 3) run_rows_fast<1, false, false>(so, ldo, row0, n, c4, q);
-                    else if (fast == 4) run_rows_fast<2, false, false>(so, ldo, row0, n, c4, q);
-                    else run_rows_fast<2, true, false>(so, ldo, row0, n, c4, q);
-                }
-                return;
-            }
-        }
         f4 bv = zero4(), sc = {1.f, 1.f, 1.f, 1.f}, sh = zero4();
         if (nok) {
             if (bias) bv = ld4(bias + n);
@@ -679,18 +698,39 @@ struct EpLsRes {                    // t = acc + bias; tout = t; out = res + gam
     // the residual rows of a 16-row fragment, loaded for all four row groups of the lane at once and -- by the callers -- one fragment
     // ahead of their use (read inside the row loop every row group paid its own memory round trip)
     static constexpr bool kPrefetchRows = true;
+    // branch-free bodies for fragments inside the matrix, chosen once per tile by the kernels (see EpStore::fast_mode): 1 = no `tout`
+    static constexpr int kFastModes = 1;
+    __device__ __forceinline__ int fast_mode() const { return tout ? 0 : 1; }
+    template <int MODE, int NT, class BL>
+    __device__ __forceinline__ RowPre prefetch_full(const BL& bl, int row0, int nblk, int lane) const {
+        RowPre r;
+        const int c4 = lane & 15, q = lane >> 4;
+        const int n = bl.col(nblk, 0, 0) + 4 * c4;
+        if (c4 < NT * 4 && n < N) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) r.v[p] = ld4(res + (long)(row0 + q + 4 * p) * ld + n);
+        }
+        return r;
+    }
+    template <int MODE, int NT, class BL>
+    __device__ __forceinline__ void run_rows_full(const float* so, int ldo, const BL& bl, int row0, int nblk, int lane, const RowPre& pre) const {
+        const int c4 = lane & 15, q = lane >> 4;
+        const int n = bl.col(nblk, 0, 0) + 4 * c4;
+        if (c4 >= NT * 4 || n >= N) return;
+        const f4 bv = bias ? ld4(bias + n) : zero4();
+        const f4 g = gamma ? ld4(gamma + n) : f4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int lr = q + 4 * p;
+            const f4 tv = *reinterpret_cast<const f4*>(so + lr * ldo + 4 * c4) + bv;
+            *reinterpret_cast<f4*>(out + (long)(row0 + lr) * ld + n) = pre.v[p] + g * tv;
+        }
+    }
     template <int NT, class BL>
     __device__ __forceinline__ RowPre prefetch_rows(const BL& bl, int row0, int nblk, int lane, int M) const {
         RowPre r;
         const int c4 = lane & 15, q = lane >> 4;
         const int n = bl.col(nblk, 0, 0) + 4 * c4;
-        if (row0 + 16 <= M) {                                   // whole fragment inside (wave-uniform): four loads, no per-row branch
-            if (c4 < NT * 4 && n < N) {
-#pragma unroll
-                for (int p = 0; p < 4; ++p) r.v[p] = ld4(res + (long)(row0 + q + 4 * p) * ld + n);
-            }
-            return r;
-        }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int row = row0 + q + 4 * p;
@@ -709,15 +749,6 @@ struct EpLsRes {                    // t = acc + bias; tout = t; out = res + gam
         if (c4 >= NT * 4 || n >= N) return;
         const f4 bv = bias ? ld4(bias + n) : zero4();
         const f4 g = gamma ? ld4(gamma + n) : f4{1.f, 1.f, 1.f, 1.f};
-        if (row0 + 16 <= M && !tout) {                          // branch-free body (see EpStore::run_rows_fast)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int lr = q + 4 * p;
-                const f4 tv = *reinterpret_cast<const f4*>(so + lr * ldo + 4 * c4) + bv;
-                *reinterpret_cast<f4*>(out + (long)(row0 + lr) * ld + n) = pre.v[p] + g * tv;
-            }
-            return;
-        }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int lr = q + 4 * p, row = row0 + lr;
@@ -1077,25 +1108,34 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
     }
     if constexpr (EP::kRowEpilogue) {
         float* so = smem + wave * 16 * LDO;                   // wave-private 16 x BN tile
-        // the epilogue's own global operand (gelu' pre-activations / residual rows) travels one fragment ahead of its use
-        RowPre pre;
-        if constexpr (EP::kPrefetchRows) pre = ep.template prefetch_rows<NT, BL>(bl, brow0 + 16 * (RW * wave), nblk, lane, M);
+        // one body per tile: mode 0 = the generic row epilogue (edge tiles, rare options), modes >= 1 = the epilogue's branch-free
+        // bodies (EP::fast_mode()), picked OUTSIDE the fragment loop so that no fragment ends at a join with the generic code
+        auto ep_tile = [&](auto modec) {
+            constexpr int MODE = decltype(modec)::value;
+            RowPre pre;
+            if constexpr (MODE > 0) pre = ep.template prefetch_full<MODE, NT, BL>(bl, brow0 + 16 * (RW * wave), nblk, lane);
+            else if constexpr (EP::kPrefetchRows) pre = ep.template prefetch_rows<NT, BL>(bl, brow0 + 16 * (RW * wave), nblk, lane, M);
 #pragma unroll
-        for (int w = 0; w < RW; ++w) {
-            const int row0 = brow0 + 16 * (RW * wave + w);
-            const RowPre cur = pre;
-            if constexpr (EP::kPrefetchRows) { if (w + 1 < RW) pre = ep.template prefetch_rows<NT, BL>(bl, row0 + 16, nblk, lane, M); }
-            __syncthreads();                                  // operand buffers (w = 0) / previous tile (w > 0) are done with
+            for (int w = 0; w < RW; ++w) {
+                const int row0 = brow0 + 16 * (RW * wave + w);
+                const RowPre cur = pre;
+                if constexpr (MODE > 0) { if (w + 1 < RW) pre = ep.template prefetch_full<MODE, NT, BL>(bl, row0 + 16, nblk, lane); }
+                else if constexpr (EP::kPrefetchRows) { if (w + 1 < RW) pre = ep.template prefetch_rows<NT, BL>(bl, row0 + 16, nblk, lane, M); }
+                __syncthreads();                              // operand buffers (w = 0) / previous tile (w > 0) are done with
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) so[(4 * q + r) * LDO + 16 * t + i] = acc[w][t][r];
-            __syncthreads();
-            if (row0 < M) {
-                if constexpr (EP::kPrefetchRows) ep.template run_rows<NT, BL>(so, LDO, bl, row0, nblk, lane, M, cur);
-                else ep.template run_rows<NT, BL>(so, LDO, bl, row0, nblk, lane, M);
+                    for (int r = 0; r < 4; ++r) so[(4 * q + r) * LDO + 16 * t + i] = acc[w][t][r];
+                __syncthreads();
+                if constexpr (MODE > 0) ep.template run_rows_full<MODE, NT, BL>(so, LDO, bl, row0, nblk, lane, cur);
+                else if (row0 < M) {
+                    if constexpr (EP::kPrefetchRows) ep.template run_rows<NT, BL>(so, LDO, bl, row0, nblk, lane, M, cur);
+                    else ep.template run_rows<NT, BL>(so, LDO, bl, row0, nblk, lane, M);
+                }
             }
-        }
+        };
+        const int fm = brow0 + BM <= M ? ep.fast_mode() : 0;  // workgroup-uniform
+        dispatch_fast_mode<EP::kFastModes>(fm, ep_tile);
     } else {
 #pragma unroll
         for (int w = 0; w < RW; ++w) {

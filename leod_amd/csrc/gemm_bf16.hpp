@@ -159,30 +159,40 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_bf16_kernel(AL al, BL bl, EP
         if (last) {
             const int rbk = tile_c / nblocks_n;
             const int brow_c = rbk * BM, nblk_c = tile_c - rbk * nblocks_n;
-            // the epilogue's own global operand (gelu' pre-activations, residual rows, second gradient source) one fragment ahead
-            RowPre pre;
-            if constexpr (EP::kPrefetchRows) pre = ep.template prefetch_rows<NTW, BL>(blw, brow_c + 64 * wm, nblk_c * 4 + wn, lane, M);
+            // one body per tile (see gemm_lds_kernel): mode 0 = generic row epilogue, modes >= 1 = the epilogue's branch-free bodies
+            auto ep_tile = [&](auto modec) {
+                constexpr int MODE = decltype(modec)::value;
+                RowPre pre;
+                if constexpr (MODE > 0) pre = ep.template prefetch_full<MODE, NTW, BL>(blw, brow_c + 64 * wm, nblk_c * 4 + wn, lane);
+                else if constexpr (EP::kPrefetchRows) pre = ep.template prefetch_rows<NTW, BL>(blw, brow_c + 64 * wm, nblk_c * 4 + wn, lane, M);
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const int row0 = brow_c + 64 * wm + 16 * w;
-                const RowPre cur = pre;
-                if constexpr (EP::kPrefetchRows) { if (w < 3) pre = ep.template prefetch_rows<NTW, BL>(blw, row0 + 16, nblk_c * 4 + wn, lane, M); }
-                // LDS operations of one wave execute in order: only the COMPILER has to keep write -> read -> write order
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
+                for (int w = 0; w < 4; ++w) {
+                    const int row0 = brow_c + 64 * wm + 16 * w;
+                    const RowPre cur = pre;
+                    if constexpr (MODE > 0) { if (w < 3) pre = ep.template prefetch_full<MODE, NTW, BL>(blw, row0 + 16, nblk_c * 4 + wn, lane); }
+                    else if constexpr (EP::kPrefetchRows) { if (w < 3) pre = ep.template prefetch_rows<NTW, BL>(blw, row0 + 16, nblk_c * 4 + wn, lane, M); }
+                    // LDS operations of one wave execute in order: only the COMPILER has to keep write -> read -> write order
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int t = 0; t < NTW; ++t)
+                    for (int t = 0; t < NTW; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) so[(4 * q + r) * LDO + 16 * t + i] = acc[w][t][r];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                if (row0 < M && !(dbg & 1)) {
-                    if constexpr (EP::kPrefetchRows) ep.template run_rows<NTW, BL>(so, LDO, blw, row0, nblk_c * 4 + wn, lane, M, cur);
-                    else ep.template run_rows<NTW, BL>(so, LDO, blw, row0, nblk_c * 4 + wn, lane, M);
+                        for (int r = 0; r < 4; ++r) so[(4 * q + r) * LDO + 16 * t + i] = acc[w][t][r];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    if (!(dbg & 1)) {
+                        if constexpr (MODE > 0) ep.template run_rows_full<MODE, NTW, BL>(so, LDO, blw, row0, nblk_c * 4 + wn, lane, cur);
+                        else if (row0 < M) {
+                            if constexpr (EP::kPrefetchRows) ep.template run_rows<NTW, BL>(so, LDO, blw, row0, nblk_c * 4 + wn, lane, M, cur);
+                            else ep.template run_rows<NTW, BL>(so, LDO, blw, row0, nblk_c * 4 + wn, lane, M);
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t) acc[w][t] = zero4();
                 }
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[w][t] = zero4();
-            }
+            };
+            const int fm = brow_c + BM <= M ? ep.fast_mode() : 0;          // workgroup-uniform
+            dispatch_fast_mode<EP::kFastModes>(fm, ep_tile);
             ch_c = 0;
             ++tile_c;
         }
