@@ -21,22 +21,28 @@
 //     of gemm16.hpp, EpStore / EpLsRes::run_rows, through wave-private 16 x 64 tiles) overlaps the loads of the next tile.
 #pragma once
 
-template <int NTW, class AL, class BL, class EP>
-__global__ __launch_bounds__(512, 2) void gemm_wide_bf16_kernel(AL al, BL bl, EP ep, int M, int K, int nblocks_n, int dbg) {
-    constexpr int KCH = 64, K4 = KCH / 4, BM = 128, BN = 64 * NTW, LD = KCH + 16;
+// WN = 4, KCH = 64: the 8-wave workgroup described above (one per CU).  WN = 2, KCH = 32 (NTW = 3 only): a 4-wave workgroup with the same
+// 128 x 192 tile -- waves 2 x 2, each 64 rows x 96 columns = 4 x 6 accumulator tiles, epilogue in two 48-column halves -- on 76 KB of LDS,
+// so two workgroups can share a CU (kept as a template option; see launch_gemm_wide for what it measured).
+template <int NTW, class AL, class BL, class EP, int WN = 4, int KCH = 64>
+__global__ __launch_bounds__(128 * WN, 2) void gemm_wide_bf16_kernel(AL al, BL bl, EP ep, int M, int K, int nblocks_n, int dbg) {
+    constexpr int K4 = KCH / 4, BM = 128, BN = 64 * NTW, LD = KCH + 16;
+    constexpr int NTHR = 128 * WN, NWAVE = 2 * WN, RS = NTHR / K4;   // threads, waves, rows per staging pass
+    constexpr int TW = 4 * NTW / WN, NH = TW / NTW;                  // accumulator column tiles per wave; epilogue halves of NTW tiles
+    static_assert(BM % RS == 0 && TW * WN == 4 * NTW && NH * NTW == TW, "wave grid");
     constexpr int NTB = BN / 16;                     // 16-column blocks of the B tile
     constexpr int BST = 16 * 16 + 16;                // bf16 elements per [16 k][16 n] block of transposed weights (+ 32 bytes)
-    constexpr int RA = BM * K4 / 512;                // = 4 staging slots per thread (rows r0 + 32 p)
-    constexpr int RB = BL::kTrans ? KCH * (BN / 4) / 512 : BN * K4 / 512;
+    constexpr int RA = BM / RS;                      // = 4 staging slots per thread (rows r0 + RS p)
+    constexpr int RB = BL::kTrans ? KCH * (BN / 4) / NTHR : BN * K4 / NTHR;
     constexpr int ASZ = BM * LD;                     // bf16 elements
     constexpr int BSZ = BL::kTrans ? (KCH / 16) * NTB * BST : BN * LD;
     constexpr int LDO = 64;
     static_assert(std::is_same<BL, BLRows>::value || std::is_same<BL, BLTrans>::value, "weights as W[n][k] or W[k][n]");
     __shared__ __attribute__((aligned(16))) unsigned short sOp[2][ASZ + BSZ];       // double-buffered operand tiles
-    __shared__ __attribute__((aligned(16))) float sOut[8][16 * LDO];                // wave-private transposition tiles of the epilogue
+    __shared__ __attribute__((aligned(16))) float sOut[NWAVE][16 * LDO];                // wave-private transposition tiles of the epilogue
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
     // ---- persistent workgroup: a contiguous range of (row block, n-block) tiles, n-blocks of a row block consecutive (the A rows
     // are re-read from this CU's L1 / this XCD's L2) ----------------------------------------------------------------------------------
     const int nch = (K + KCH - 1) / KCH;
@@ -44,7 +50,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_bf16_kernel(AL al, BL bl, EP
     const int tile_begin = (int)(ntiles * blockIdx.x / gridDim.x), tile_end = (int)(ntiles * (blockIdx.x + 1) / gridDim.x);
     if (tile_begin >= tile_end) return;
     // ---- staging slots: thread = (row r0 = tid / 16, k offset ak = 4 * (tid % 16)); slot p adds 32 rows -------------------------------
-    const int ak = (tid & 15) * 4, r0 = tid >> 4;
+    const int ak = (tid % K4) * 4, r0 = tid / K4;
     // A tile position of k offset ak inside its 32-k group: natural for row-major weights, (k = 4g + j -> 8 (g % 4) + 4 (g / 4) + j)
     // for transposed weights (the order the two transpose reads of a B fragment deliver)
     const int g8 = (ak >> 2) & 7;
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_bf16_kernel(AL al, BL bl, EP
     int bn[RB], bk[RB], b_off[RB];
 #pragma unroll
     for (int p = 0; p < RB; ++p) {
-        const int e = tid + 512 * p;
+        const int e = tid + NTHR * p;
         if constexpr (!BL::kTrans) { bn[p] = e / K4; bk[p] = (e - bn[p] * K4) * 4; b_off[p] = bn[p] * LD + bk[p]; }
         else {
             const int kl = e / (BN / 4), n4 = (e - kl * (BN / 4)) * 4;
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_bf16_kernel(AL al, BL bl, EP
         const int rbk = tile_f / nblocks_n;
         brow_f = rbk * BM; ncol_f = (tile_f - rbk * nblocks_n) * BN;
 #pragma unroll
-        for (int p = 0; p < RA; ++p) ast[p] = al.init(brow_f + r0 + 32 * p, M, 0, false);
+        for (int p = 0; p < RA; ++p) ast[p] = al.init(brow_f + r0 + RS * p, M, 0, false);
     };
     f4 ra[RA], rb[RB];
     typename a_two_phase<AL>::Raw raw_a[RA];
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_bf16_kernel(AL al, BL bl, EP
 #pragma unroll
         for (int p = 0; p < RA; ++p) {
             const f4 v = al.fin_k(ast[p], raw_a[p], raw_a[0]);
-            *reinterpret_cast<s4*>(sA + a_off + 32 * p * LD) = pack_bf16((ast[p].ok && kok) ? v : zero4());
+            *reinterpret_cast<s4*>(sA + a_off + RS * p * LD) = pack_bf16((ast[p].ok && kok) ? v : zero4());
         }
 #pragma unroll
         for (int p = 0; p < RB; ++p) {
@@ -110,11 +116,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_bf16_kernel(AL al, BL bl, EP
         }
         return true;
     };
-    f4 acc[4][NTW];
+    f4 acc[4][TW];
 #pragma unroll
     for (int w = 0; w < 4; ++w)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[w][t] = zero4();
+        for (int t = 0; t < TW; ++t) acc[w][t] = zero4();
     set_fetch_tile();
     fetch();
     stash(0);
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_bf16_kernel(AL al, BL bl, EP
     if (pending) fetch();
     __syncthreads();
     const int pa_off = (64 * wm + i) * LD + 8 * q;
-    const int pb_off = ASZ + (BL::kTrans ? (NTW * wn) * BST + (4 * q + (i >> 2)) * 16 + 4 * (i & 3) : (16 * NTW * wn + i) * LD + 8 * q);
+    const int pb_off = ASZ + (BL::kTrans ? (TW * wn) * BST + (4 * q + (i >> 2)) * 16 + 4 * (i & 3) : (16 * TW * wn + i) * LD + 8 * q);
     typedef __attribute__((address_space(3))) s4 lds_s4;
     float* so = sOut[wave];
     BL blw = bl;
@@ -135,11 +141,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_bf16_kernel(AL al, BL bl, EP
 #pragma unroll
         for (int c = 0; c < KCH / 32; ++c) {
             if (dbg & 2) break;
-            s8v av[4], bv[NTW];
+            s8v av[4], bv[TW];
 #pragma unroll
             for (int w = 0; w < 4; ++w) av[w] = *reinterpret_cast<const s8v*>(pa + 16 * w * LD + 32 * c);
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) {
+            for (int t = 0; t < TW; ++t) {
                 if constexpr (BL::kTrans) {
                     const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(pb + ((2 * c) * NTB + t) * BST));
                     const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(pb + ((2 * c + 1) * NTB + t) * BST));
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_bf16_kernel(AL al, BL bl, EP
                 }
             }
 #pragma unroll
-            for (int t = 0; t < NTW; ++t)
+            for (int t = 0; t < TW; ++t)
 #pragma unroll
                 for (int w = 0; w < 4; ++w) acc[w][t] = mfma32_bf16(av[w], bv[t], acc[w][t]);
         }
@@ -162,33 +168,47 @@ __global__ __launch_bounds__(512, 2) void gemm_wide_bf16_kernel(AL al, BL bl, EP
             // one body per tile (see gemm_lds_kernel): mode 0 = generic row epilogue, modes >= 1 = the epilogue's branch-free bodies
             auto ep_tile = [&](auto modec) {
                 constexpr int MODE = decltype(modec)::value;
+                // fragments f = (w, h): 16 rows x (16 NTW) columns; virtual n-block (of 16 NTW columns) = 4 nblk + NH wn + h
+                const int vb0 = nblk_c * 4 + NH * wn;
                 RowPre pre;
-                if constexpr (MODE > 0) pre = ep.template prefetch_full<MODE, NTW, BL>(blw, brow_c + 64 * wm, nblk_c * 4 + wn, lane);
-                else if constexpr (EP::kPrefetchRows) pre = ep.template prefetch_rows<NTW, BL>(blw, brow_c + 64 * wm, nblk_c * 4 + wn, lane, M);
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
+                if constexpr (MODE > 0) pre = ep.template prefetch_full<MODE, NTW, BL>(blw, brow_c + 64 * wm, vb0, lane);
+                else if constexpr (EP::kPrefetchRows) pre = ep.template prefetch_rows<NTW, BL>(blw, brow_c + 64 * wm, vb0, lane, M);
+                // (one call per fragment with a compile-time index: the eight copies of the generic body exceed the unroller's size limit,
+                // and a loop that stays rolled indexes acc dynamically -> the accumulators would live in scratch memory)
+                auto frag = [&](auto fc) {
+                    constexpr int f = decltype(fc)::value;
+                    constexpr int w = f / NH, h = f % NH;
                     const int row0 = brow_c + 64 * wm + 16 * w;
                     const RowPre cur = pre;
-                    if constexpr (MODE > 0) { if (w < 3) pre = ep.template prefetch_full<MODE, NTW, BL>(blw, row0 + 16, nblk_c * 4 + wn, lane); }
-                    else if constexpr (EP::kPrefetchRows) { if (w < 3) pre = ep.template prefetch_rows<NTW, BL>(blw, row0 + 16, nblk_c * 4 + wn, lane, M); }
+                    if (f + 1 < 4 * NH) {
+                        const int rown = brow_c + 64 * wm + 16 * ((f + 1) / NH), vbn = vb0 + (f + 1) % NH;
+                        if constexpr (MODE > 0) pre = ep.template prefetch_full<MODE, NTW, BL>(blw, rown, vbn, lane);
+                        else if constexpr (EP::kPrefetchRows) pre = ep.template prefetch_rows<NTW, BL>(blw, rown, vbn, lane, M);
+                    }
                     // LDS operations of one wave execute in order: only the COMPILER has to keep write -> read -> write order
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int t = 0; t < NTW; ++t)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) so[(4 * q + r) * LDO + 16 * t + i] = acc[w][t][r];
+                        for (int r = 0; r < 4; ++r) so[(4 * q + r) * LDO + 16 * t + i] = acc[w][h * NTW + t][r];
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_wave_barrier();
                     if (!(dbg & 1)) {
-                        if constexpr (MODE > 0) ep.template run_rows_full<MODE, NTW, BL>(so, LDO, blw, row0, nblk_c * 4 + wn, lane, cur);
+                        if constexpr (MODE > 0) ep.template run_rows_full<MODE, NTW, BL>(so, LDO, blw, row0, vb0 + h, lane, cur);
                         else if (row0 < M) {
-                            if constexpr (EP::kPrefetchRows) ep.template run_rows<NTW, BL>(so, LDO, blw, row0, nblk_c * 4 + wn, lane, M, cur);
-                            else ep.template run_rows<NTW, BL>(so, LDO, blw, row0, nblk_c * 4 + wn, lane, M);
+                            if constexpr (EP::kPrefetchRows) ep.template run_rows<NTW, BL>(so, LDO, blw, row0, vb0 + h, lane, M, cur);
+                            else ep.template run_rows<NTW, BL>(so, LDO, blw, row0, vb0 + h, lane, M);
                         }
                     }
 #pragma unroll
-                    for (int t = 0; t < NTW; ++t) acc[w][t] = zero4();
+                    for (int t = 0; t < NTW; ++t) acc[w][h * NTW + t] = zero4();
+                };
+                frag(std::integral_constant<int, 0>{}); frag(std::integral_constant<int, 1>{});
+                frag(std::integral_constant<int, 2>{}); frag(std::integral_constant<int, 3>{});
+                if constexpr (NH == 2) {
+                    frag(std::integral_constant<int, 4>{}); frag(std::integral_constant<int, 5>{});
+                    frag(std::integral_constant<int, 6>{}); frag(std::integral_constant<int, 7>{});
                 }
             };
             const int fm = brow_c + BM <= M ? ep.fast_mode() : 0;          // workgroup-uniform
@@ -223,6 +243,9 @@ static inline int launch_gemm_wide(const AL& al, const BL& bl, const EP& ep, int
     const int nbn = cdiv(N, 64 * NTW);
     const long ntiles = (long)cdiv(M, 128) * nbn;
     static const int dbg = getenv("LEOD_WIDE_DBG") ? atoi(getenv("LEOD_WIDE_DBG")) : 0;
+    // (The WN = 2 / KCH = 32 variant -- two 4-wave workgroups per CU -- is not instantiated: tools/kbench_gemm.py, stages 3-4, measured it
+    // equal on the 53 k-row launches and 1.2-1.5x slower on the 13 k-row ones, whose 105-210 tiles then run on four waves per CU each:
+    // 40 -> 57 us dgrad of fc1, 59 -> 75 us fc2; LN -> fc1 -> GELU alone gained, 66 -> 60 us.  The step did not move.)
     // one persistent 8-wave workgroup per CU (132-152 KB of LDS each)
     hipLaunchKernelGGL((gemm_wide_bf16_kernel<NTW, AL, BL, EP>), dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(512), 0, s, al, bl, ep, M, K, nbn, dbg);
     return leod_launch_status();
