@@ -753,33 +753,44 @@ __device__ __forceinline__ s4 a16_tfrag(const unsigned* base, int row0, int sd, 
 // row (SDW / 4 > UNITS) and the 8 slack dwords behind the last row are ZEROED: the fragments of the last part of a row read 8 elements
 // past it, and although those values only ever meet a zeroed operand or feed discarded output columns, 0 * NaN is NaN.
 template <int NTHR, int TOK, int UNITS, int SDW, bool SRC16>
-__device__ __forceinline__ void a16_stage(unsigned* dst, const void* src, const long* srow, long ld, long col0, int tid) {
-    constexpr int UR = SDW / 4;                                // units per staged row, padding included
-    constexpr int NL = (TOK * UR + NTHR - 1) / NTHR;
+struct A16Raw {                                                 // the global loads of one staged operand, still in registers
+    static constexpr int UR = SDW / 4;                          // units per staged row, padding included
+    static constexpr int NL = (TOK * UR + NTHR - 1) / NTHR;
     u4v_ raw16[SRC16 ? NL : 1]; f4 raw32[SRC16 ? 1 : 2 * NL];
-    unsigned ok = 0;
+    unsigned ok;
+    __device__ __forceinline__ void load(const void* src, const long* srow, long ld, long col0, int tid) {
+        ok = 0;
 #pragma unroll
-    for (int j = 0; j < NL; ++j) {
-        const int e = tid + j * NTHR, tok = min(e / UR, TOK - 1), f = e - (e / UR) * UR;
-        const long row = srow[tok];
-        ok |= (unsigned)(e < TOK * UR && f < UNITS && row >= 0) << j;
-        const long off = max(row, 0L) * ld + col0 + 8 * min(f, UNITS - 1);
-        if constexpr (SRC16) raw16[j] = *reinterpret_cast<const u4v_*>(reinterpret_cast<const unsigned short*>(src) + off);
-        else { raw32[2 * j] = ld4(reinterpret_cast<const float*>(src) + off); raw32[2 * j + 1] = ld4(reinterpret_cast<const float*>(src) + off + 4); }
-    }
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-        const int e = tid + j * NTHR, tok = e / UR, f = e - tok * UR;
-        u4v_ v;
-        if constexpr (SRC16) v = raw16[j];
-        else {
-            const s4 lo = pack_bf16(raw32[2 * j]), hi = pack_bf16(raw32[2 * j + 1]);
-            const u2_ a = __builtin_bit_cast(u2_, lo), b = __builtin_bit_cast(u2_, hi);
-            v = u4v_{a.x, a.y, b.x, b.y};
+        for (int j = 0; j < NL; ++j) {
+            const int e = tid + j * NTHR, tok = min(e / UR, TOK - 1), f = e - (e / UR) * UR;
+            const long row = srow[tok];
+            ok |= (unsigned)(e < TOK * UR && f < UNITS && row >= 0) << j;
+            const long off = max(row, 0L) * ld + col0 + 8 * min(f, UNITS - 1);
+            if constexpr (SRC16) raw16[j] = *reinterpret_cast<const u4v_*>(reinterpret_cast<const unsigned short*>(src) + off);
+            else { raw32[2 * j] = ld4(reinterpret_cast<const float*>(src) + off); raw32[2 * j + 1] = ld4(reinterpret_cast<const float*>(src) + off + 4); }
         }
-        if (e < TOK * UR) *reinterpret_cast<u4v_*>(dst + tok * SDW + 4 * f) = (ok >> j) & 1u ? v : u4v_{0u, 0u, 0u, 0u};
     }
-    if (tid < 8) dst[TOK * SDW + tid] = 0u;
+    __device__ __forceinline__ void store(unsigned* dst, int tid) const {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int e = tid + j * NTHR, tok = e / UR, f = e - tok * UR;
+            u4v_ v;
+            if constexpr (SRC16) v = raw16[j];
+            else {
+                const s4 lo = pack_bf16(raw32[2 * j]), hi = pack_bf16(raw32[2 * j + 1]);
+                const u2_ a = __builtin_bit_cast(u2_, lo), b = __builtin_bit_cast(u2_, hi);
+                v = u4v_{a.x, a.y, b.x, b.y};
+            }
+            if (e < TOK * UR) *reinterpret_cast<u4v_*>(dst + tok * SDW + 4 * f) = (ok >> j) & 1u ? v : u4v_{0u, 0u, 0u, 0u};
+        }
+        if (tid < 8) dst[TOK * SDW + tid] = 0u;
+    }
+};
+template <int NTHR, int TOK, int UNITS, int SDW, bool SRC16>
+__device__ __forceinline__ void a16_stage(unsigned* dst, const void* src, const long* srow, long ld, long col0, int tid) {
+    A16Raw<NTHR, TOK, UNITS, SDW, SRC16> r;
+    r.load(src, srow, ld, col0, tid);
+    r.store(dst, tid);
 }
 
 template <int PT, int D, int HG>
@@ -888,9 +899,18 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds16_kernel(const void
             okl |= (unsigned)(e < HG * TOK && row >= 0) << j;
             stagel[j] = lse[max(row, 0L) * g.heads + h0 + hh];
         }
-        a16_stage<NTHR, TOK, F8, SD, true>(sq, qkv, srow, ld, (long)h0 * 3 * d, tid);
-        if (g.fmt & 8) a16_stage<NTHR, TOK, A16L<D, HG>::RWD / 8, SDD, true>(sdo, dout, srow, (long)g.C, (long)h0 * d, tid);
-        else a16_stage<NTHR, TOK, A16L<D, HG>::RWD / 8, SDD, false>(sdo, dout, srow, (long)g.C, (long)h0 * d, tid);
+        // every global load of the workgroup's operands before the first LDS store (qkv staged, THEN dO loaded cost a second round trip)
+        A16Raw<NTHR, TOK, F8, SD, true> rq;
+        rq.load(qkv, srow, ld, (long)h0 * 3 * d, tid);
+        if (g.fmt & 8) {
+            A16Raw<NTHR, TOK, A16L<D, HG>::RWD / 8, SDD, true> rd;
+            rd.load(dout, srow, (long)g.C, (long)h0 * d, tid);
+            rq.store(sq, tid); rd.store(sdo, tid);
+        } else {
+            A16Raw<NTHR, TOK, A16L<D, HG>::RWD / 8, SDD, false> rd;
+            rd.load(dout, srow, (long)g.C, (long)h0 * d, tid);
+            rq.store(sq, tid); rd.store(sdo, tid);
+        }
 #pragma unroll
         for (int j = 0; j < NLl; ++j) {
             const int e = tid + j * NTHR;
