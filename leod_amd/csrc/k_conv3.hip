@@ -175,35 +175,50 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
 #pragma unroll
     for (int n = 0; n < NTO; ++n) { cs[n] = 0.f; cq[n] = 0.f; }
     float* yb = y + ((long)(b * Ho + y0) * Wo) * Cout + co0;
+    // the whole fragment loop once per value of `accumulate`: with the read-modify-write arm inside the row loop every row group ended at
+    // a join with a pending load, where hipcc drains vmcnt -- i.e. each 16-byte store waited for the previous one's acknowledgement
+    auto rows_out = [&](auto accc) {
+        constexpr bool ACC = decltype(accc)::value;
+        constexpr int NK = (16 * NTO * 4 + 63) / 64;
 #pragma unroll
-    for (int t = 0; t < TW; ++t) {
-        if (!tok[t]) continue;                                             // wave-uniform
-        const int tile = wave + 4 * t;
+        for (int t = 0; t < TW; ++t) {
+            if (!tok[t]) continue;                                             // wave-uniform
+            const int tile = wave + 4 * t;
 #pragma unroll
-        for (int n = 0; n < NTO; ++n)
+            for (int n = 0; n < NTO; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = acc[t][n][r];
-                so[(4 * q + r) * LDO + 16 * n + i] = v;
-                if (tile * 16 + 4 * q + r < P) { cs[n] += v; cq[n] += v * v; }
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[t][n][r];
+                    so[(4 * q + r) * LDO + 16 * n + i] = v;
+                    if (tile * 16 + 4 * q + r < P) { cs[n] += v; cq[n] += v * v; }
+                }
+            f4 old[ACC ? NK : 1];
+            if constexpr (ACC) {                                               // all read-modify-write loads of the fragment first
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int idx = min(k * 64 + lane, 16 * NTO * 4 - 1);
+                    const int row = idx / (NTO * 4), c4 = (idx - row * (NTO * 4)) * 4;
+                    old[k] = ld4(yb + (long)min(tile * 16 + row, P - 1) * Cout + c4);
+                }
             }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int k = 0; k < (16 * NTO * 4 + 63) / 64; ++k) {
-            const int idx = k * 64 + lane;
-            const int row = idx / (NTO * 4), c4 = (idx - row * (NTO * 4)) * 4;
-            const int p = tile * 16 + row;
-            if (idx < 16 * NTO * 4 && p < P) {
-                f4 v = *reinterpret_cast<const f4*>(so + row * LDO + c4);
-                float* dst = yb + (long)p * Cout + c4;
-                if (accumulate) v += ld4(dst);
-                *reinterpret_cast<f4*>(dst) = v;
+            for (int k = 0; k < NK; ++k) {
+                const int idx = k * 64 + lane;
+                const int row = idx / (NTO * 4), c4 = (idx - row * (NTO * 4)) * 4;
+                const int p = tile * 16 + row;
+                if (idx < 16 * NTO * 4 && p < P) {
+                    f4 v = *reinterpret_cast<const f4*>(so + row * LDO + c4);
+                    if constexpr (ACC) v += old[k];
+                    *reinterpret_cast<f4*>(yb + (long)p * Cout + c4) = v;
+                }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-    }
+    };
+    if (accumulate) rows_out(std::true_type{}); else rows_out(std::false_type{});
     if (colstats) {
         double* cst = colstats + (stat_rep > 1 ? (size_t)((blockIdx.x * 4 + wave) & (stat_rep - 1)) * 2 * Cout : 0);
 #pragma unroll
@@ -339,35 +354,48 @@ __global__ __launch_bounds__(256) void conv3s2_dgrad_kernel(const float* __restr
     float* so = reinterpret_cast<float*>(smem_raw) + wave * 16 * LDO;
     const int H = 2 * Ho, W = 2 * Wo;
     float* xb = dx + (long)b * H * W * Cin + c0;
+    auto rows_out = [&](auto accc) {                                          // see conv3s1_kernel: no read-modify-write arm inside the row loop
+        constexpr bool ACC = decltype(accc)::value;
+        constexpr int NK = (16 * NTO * 4 + 63) / 64;
 #pragma unroll
-    for (int t = 0; t < TW; ++t) {
-        if (!tok[t]) continue;                                             // wave-uniform
-        const int tile = wave + 4 * t;
+        for (int t = 0; t < TW; ++t) {
+            if (!tok[t]) continue;                                             // wave-uniform
+            const int tile = wave + 4 * t;
 #pragma unroll
-        for (int cl = 0; cl < 4; ++cl) {
+            for (int cl = 0; cl < 4; ++cl) {
 #pragma unroll
-            for (int n = 0; n < NTO; ++n)
+                for (int n = 0; n < NTO; ++n)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) so[(4 * q + r) * LDO + 16 * n + i] = acc[cl][t][n][r];
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    for (int r = 0; r < 4; ++r) so[(4 * q + r) * LDO + 16 * n + i] = acc[cl][t][n][r];
+                long doff[NK];
+                f4 old[ACC ? NK : 1];
 #pragma unroll
-            for (int k = 0; k < (16 * NTO * 4 + 63) / 64; ++k) {
-                const int idx = k * 64 + lane;
-                const int row = idx / (NTO * 4), c4 = (idx - row * (NTO * 4)) * 4;
-                const int p = tile * 16 + row;
-                if (idx < 16 * NTO * 4 && p < P) {
+                for (int k = 0; k < NK; ++k) {
+                    const int idx = min(k * 64 + lane, 16 * NTO * 4 - 1);
+                    const int row = idx / (NTO * 4), c4 = (idx - row * (NTO * 4)) * 4;
+                    const int p = min(tile * 16 + row, P - 1);
                     const int py = p / Wo, px = p - py * Wo;
-                    f4 v = *reinterpret_cast<const f4*>(so + row * LDO + c4);
-                    float* dst = xb + ((long)(2 * (a0 + py) + (cl >> 1)) * W + 2 * px + (cl & 1)) * Cin + c4;
-                    if (accumulate) v += ld4(dst);
-                    *reinterpret_cast<f4*>(dst) = v;
+                    doff[k] = ((long)(2 * (a0 + py) + (cl >> 1)) * W + 2 * px + (cl & 1)) * Cin + c4;
+                    if constexpr (ACC) old[k] = ld4(xb + doff[k]);
                 }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int idx = k * 64 + lane;
+                    const int row = idx / (NTO * 4), c4 = (idx - row * (NTO * 4)) * 4;
+                    if (idx < 16 * NTO * 4 && tile * 16 + row < P) {
+                        f4 v = *reinterpret_cast<const f4*>(so + row * LDO + c4);
+                        if constexpr (ACC) v += old[k];
+                        *reinterpret_cast<f4*>(xb + doff[k]) = v;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
         }
-    }
+    };
+    if (accumulate) rows_out(std::true_type{}); else rows_out(std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
