@@ -566,6 +566,10 @@ LEOD_API int leod_convlstm_seq_mode(int C) {
     const bool bf = leod_precision() == 1;
     static const int stream_on = getenv("LEOD_LSTM_STREAM") ? atoi(getenv("LEOD_LSTM_STREAM")) : 1;
     if (bf && stream_on && (C == 256 || C == 384)) return 3;               // hoisted x projection + weights streamed from a packed bf16 copy
+    // C = 192: the register-resident kernels spill (96 weight registers of the 168 a wave gets at 12 waves per workgroup: 79 / 83 spilled
+    // VGPRs, tools/kernel_regs.py) -- streamed fragments (295 KB per timestep and workgroup from L2) are the faster of the two
+    static const int stream192 = getenv("LEOD_LSTM_STREAM192") ? atoi(getenv("LEOD_LSTM_STREAM192")) : 1;
+    if (bf && stream_on && stream192 && C == 192) return 3;
     if (C != 32 && C != 48 && C != 64 && C != 96 && C != 128 && C != 192) return 0;
     if (fwd_bregs(2 * C, bf) <= 96) return 1;                               // beyond ~100 resident registers the kernels spill
     if (fwd_bregs(C, bf) <= (C >= 192 ? 96 : 128)) return 2;
@@ -613,6 +617,8 @@ LEOD_API int leod_convlstm_seq_fwd(const float* xin, int x_is_projection, float*
         const dim3 g3(cdiv(M, 16));
         if (C == 384 && gates16) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<384, true>), g3, dim3(768), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
         else if (C == 384) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<384>), g3, dim3(768), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
+        else if (C == 192 && gates16) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<192, true>), g3, dim3(384), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
+        else if (C == 192) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<192>), g3, dim3(384), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
         else if (gates16) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<256, true>), g3, dim3(512), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
         else hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<256>), g3, dim3(512), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
         return leod_launch_status();
@@ -644,6 +650,8 @@ LEOD_API int leod_convlstm_seq_bwd(const float* dh_seq, const float* dc_last, co
         const dim3 g3(cdiv(M, 16));
         if (C == 384 && gates16) hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<384, true>), g3, dim3(768), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
         else if (C == 384) hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<384>), g3, dim3(768), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
+        else if (C == 192 && gates16) hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<192, true>), g3, dim3(384), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
+        else if (C == 192) hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<192>), g3, dim3(384), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
         else if (gates16) hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<256, true>), g3, dim3(512), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
         else hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<256>), g3, dim3(512), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
         return leod_launch_status();
