@@ -66,38 +66,53 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     f4 aw[CJ], ab[CJ];
 #pragma unroll
     for (int j = 0; j < CJ; ++j) { aw[j] = zero4(); ab[j] = zero4(); }
+    // every global load of an iteration (x, dn, the residual gradient, the row statistics) is issued before the first use, on clamped
+    // coordinates: the loop used to fetch x, then dn, then dres behind one another -- three dependent round trips per 4 rows of a wave
+    f4 wv[CJ]; bool cok[CJ]; int cc[CJ];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) {
+        const int c = 4 * i + 64 * j;
+        cok[j] = c < C; cc[j] = cok[j] ? c : 0;
+        wv[j] = cok[j] ? ld4(w + c) : zero4();
+    }
     for (long base = ((long)blockIdx.x * 4 + wave) * 4; base < M; base += (long)gridDim.x * 16) {
         const long row = base + rg;
         const bool rok = row < M;
-        f4 xv[CJ], gv[CJ];
+        const long rc = rok ? row : (long)M - 1;
+        f4 xv[CJ], gv[CJ], dv[CJ], rv[CJ];
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            xv[j] = ld4(x + rc * C + cc[j]);
+            dv[j] = ld4(dn + rc * C + cc[j]);
+        }
+        if (dres) {
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) rv[j] = ld4(dres + rc * C + cc[j]);
+        }
+        float mean = 0.f, rstd = 0.f;
+        if (stats) { mean = stats[2 * rc]; rstd = stats[2 * rc + 1]; }
         float sum = 0.f;
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
-            const int c = 4 * i + 64 * j;
-            xv[j] = (rok && c < C) ? ld4(x + row * C + c) : zero4();
+            if (!(rok && cok[j])) { xv[j] = zero4(); dv[j] = zero4(); }
             sum += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
         }
-        float mean, rstd;
-        if (stats) { mean = rok ? stats[2 * row] : 0.f; rstd = rok ? stats[2 * row + 1] : 0.f; }
-        else {
+        if (!stats) {
             mean = row16_sum(sum) / (float)C;
             float var = 0.f;
 #pragma unroll
-            for (int j = 0; j < CJ; ++j) {
-                const int c = 4 * i + 64 * j;
-                if (c < C) { const f4 d = xv[j] - mean; var += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
-            }
+            for (int j = 0; j < CJ; ++j)
+                if (cok[j]) { const f4 d = xv[j] - mean; var += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w); }
             rstd = rsqrtf(row16_sum(var) / (float)C + eps);
         }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
-            const int c = 4 * i + 64 * j;
-            if (rok && c < C) {
-                const f4 d = ld4(dn + row * C + c);
+            if (rok && cok[j]) {
+                const f4 d = dv[j];
                 const f4 xh = (xv[j] - mean) * rstd;
                 xv[j] = xh;
-                gv[j] = d * ld4(w + c);
+                gv[j] = d * wv[j];
                 aw[j] += d * xh; ab[j] += d;
                 s1 += (gv[j].x + gv[j].y) + (gv[j].z + gv[j].w);
                 const f4 gx = gv[j] * xh;
@@ -109,11 +124,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         if (!rok) continue;
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
-            const int c = 4 * i + 64 * j;
-            if (c < C) {
+            if (cok[j]) {
                 f4 r = (gv[j] - s1 - xv[j] * s2) * rstd;
-                if (dres) r += ld4(dres + row * C + c);
-                *reinterpret_cast<f4*>(dx + row * C + c) = r;
+                if (dres) r += rv[j];
+                *reinterpret_cast<f4*>(dx + row * C + cc[j]) = r;
             }
         }
     }
