@@ -121,15 +121,21 @@ __global__ __launch_bounds__(256) void head_pred_bwd_w_kernel(const float* __res
             f[u] = feat[pc * Hd + kk];
             dp[u] = d_raw + ((long)b * A + a0 + p) * nch + ch0;
         }
+        // all U x CH gradient values first (clamped channel: always inside the row), then the arithmetic: loaded inside the channel
+        // loop behind `ok[u] ? .. : 0`, every one of the 64 loads of an iteration was waited for on its own
+        float dv[U][CH];
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int c = 0; c < CH; ++c)
-                if (c < nme) {
-                    const float d = ok[u] ? dp[u][c] * gsc : 0.f;
-                    acc[c] = fmaf(d, f[u], acc[c]);
-                    bacc[c] += d;
-                }
+            for (int c = 0; c < CH; ++c) dv[u][c] = dp[u][min(c, nme - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const float d = (ok[u] && c < nme) ? dv[u][c] * gsc : 0.f;
+                acc[c] = fmaf(d, f[u], acc[c]);
+                bacc[c] += d;
+            }
     }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
