@@ -304,9 +304,9 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const float* __
                                                                  double* __restrict__ sums, int rep, long M, int N, long lddy) {
     // thread t owns 4 consecutive channels c = 4*(t % (N/4)) and rows r0 + rstep * e; partial sums are combined in
     // LDS so that each workgroup issues ONE double atomic per (channel, statistic)
-    extern __shared__ float sred[];                 // [2*N]
-    for (int c = threadIdx.x; c < 2 * N; c += blockDim.x) sred[c] = 0.f;
-    __syncthreads();
+    // (fixed-order fold of the row lanes' partials in double: LDS float atomics made the sums -- and with them every gradient behind
+    // this BatchNorm -- vary in their last bits from run to run)
+    extern __shared__ float sred[];                 // [rstep][2*N]
     const int ncg = N / 4;
     const int cg = threadIdx.x % ncg;
     const int rlane = threadIdx.x / ncg, rstep = blockDim.x / ncg;
@@ -332,12 +332,17 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const float* __
             for (int k = 0; k < 4; ++k) du[k] = ok ? du[k] * silu_grad(u[k]) : 0.f;
             s0 += du; s1 += du * xh;
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { atomicAdd(&sred[c + k], s0[k]); atomicAdd(&sred[N + c + k], s1[k]); }
+        float* mine = sred + (size_t)rlane * 2 * N;
+        *reinterpret_cast<f4*>(mine + c) = s0;
+        *reinterpret_cast<f4*>(mine + N + c) = s1;
     }
     __syncthreads();
     double* dst = sums + (size_t)(blockIdx.x % rep) * 2 * N;
-    for (int c = threadIdx.x; c < 2 * N; c += blockDim.x) atomicAdd(dst + c, (double)sred[c]);
+    for (int c = threadIdx.x; c < 2 * N; c += blockDim.x) {
+        double a = 0.0;
+        for (int r = 0; r < rstep; ++r) a += (double)sred[(size_t)r * 2 * N + c];
+        atomicAdd(dst + c, a);
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z,
@@ -458,10 +463,10 @@ LEOD_API int leod_bn_silu_bwd_reduce(const float* dy, const float* z, const floa
     const int rpt = ((long)M + rstep * 8 - 1) / (rstep * 8) >= 128 ? 8 : 4;
     const int grid = (int)(((long)M + rstep * rpt - 1) / (rstep * rpt));
     if (rpt == 8)
-        hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel<8>, dim3(grid), dim3(256), 2 * N * sizeof(float), stream, dy, z, mean, rstd, w, b, sums, rep,
+        hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel<8>, dim3(grid), dim3(256), (size_t)rstep * 2 * N * sizeof(float), stream, dy, z, mean, rstd, w, b, sums, rep,
                            (long)M, N, lddy_);
     else
-        hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel<4>, dim3(grid), dim3(256), 2 * N * sizeof(float), stream, dy, z, mean, rstd, w, b, sums, rep,
+        hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel<4>, dim3(grid), dim3(256), (size_t)rstep * 2 * N * sizeof(float), stream, dy, z, mean, rstd, w, b, sums, rep,
                            (long)M, N, lddy_);
     return leod_launch_status();
 }

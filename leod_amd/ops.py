@@ -522,17 +522,27 @@ class PackCache:
     as long as the weights they were made from are unchanged: the 20 3x3 convs of PAFPN + head each re-packed their weights on every
     forward AND dgrad call (40 pack launches per training step) although weights change once per optimiser step.
 
-    An entry is valid for (weight storage, direction, geometry) while the parameter's torch version counter, the library's precision
-    mode and ``epoch`` are unchanged.  ``epoch`` is advanced by whatever rewrites parameters behind torch's back -- the fused AdamW
+    An entry is valid for (weight tensor object, direction, geometry) while the tensor's address, its torch version counter, the
+    library's precision mode and ``epoch`` are unchanged.  ``epoch`` is advanced by whatever rewrites parameters behind torch's back -- the fused AdamW
     kernel (``FlatParams.adamw_step``) -- and must be advanced (``PackCache.invalidate()``) by any other code that edits parameter
     memory through another alias (e.g. in-place ops on ``FlatParams.data``; ``FlatParams`` wraps that in ``FlatParams.touch()``)."""
     epoch = 0
     entries = {}
+    next_token = 1
 
     @classmethod
     def get(cls, w, key, nfloats):
-        k = (w.data_ptr(),) + key
-        ver = (w._version, cls.epoch, w.numel(), get_precision())
+        # Identity of the WEIGHT TENSOR OBJECT, not of its address: a token stored on the tensor the first time it is seen.  Keyed by
+        # data_ptr alone, the parameter of a NEW module that the allocator placed at the address of a dead module's parameter (same
+        # geometry, same version counter, no optimiser step in between -- two evaluation models in one process) hit the dead
+        # module's pack: stale weights in that conv (seen as a 25 % flake of the TTA test inside the full suite).
+        tok = getattr(w, '_leod_pack_token', None)
+        if tok is None:
+            tok = cls.next_token
+            cls.next_token += 1
+            w._leod_pack_token = tok
+        k = (tok,) + key
+        ver = (w.data_ptr(), w._version, cls.epoch, w.numel(), get_precision())
         e = cls.entries.get(k)
         if e is not None and e[1] == ver and e[0].numel() >= nfloats:
             return e[0], 1

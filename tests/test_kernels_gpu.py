@@ -408,6 +408,25 @@ def test_bn_silu_bwd_replicas(ops, M, N, rep):
     close(dz, z.grad.float(), rtol=2e-4, atol=2e-5)
 
 
+def test_conv_pack_cache_is_keyed_by_tensor_not_address(ops):
+    """The packed-weight cache of the 3x3 convs must not serve the pack of a DEAD weight tensor to a new tensor that the allocator
+    placed at the same address (same geometry, same version counter): two evaluation models in one process."""
+    B, H, W, Cin, N = 2, 8, 10, 32, 48
+    xn = rnd((B, H, W, Cin), 1).to(DEV)
+    ptrs = set()
+    for seed in (2, 3, 4):
+        w = rnd((N, Cin, 3, 3), seed, 0.1).to(DEV)                # freed at the end of the iteration: the next one reuses the block
+        ptrs.add(w.data_ptr())
+        y = ops.conv_nhwc_fwd(xn, w, None)
+        ref = F.conv2d(xn.permute(0, 3, 1, 2).cpu(), w.cpu(), None, padding=1).permute(0, 2, 3, 1)
+        close(y, ref, rtol=2e-4, atol=2e-5)
+        dx = ops.conv_nhwc_dgrad(y, w, xn.shape)
+        refdx = F.conv_transpose2d(y.permute(0, 3, 1, 2).cpu(), w.cpu(), None, padding=1).permute(0, 2, 3, 1)
+        close(dx, refdx, rtol=2e-4, atol=2e-4)
+        del w, y, dx
+    assert len(ptrs) < 3, 'the allocator did not reuse the weight block: the scenario was not exercised'
+
+
 def test_state_plumbing_multi_buffer_kernels(ops):
     """rows_masked_zero == `t[mask] = 0` per tensor (reference modules/utils/detection.py:60-75), copy_multi == copy_ per pair --
     over contiguous and NCHW-shaped-over-NHWC tensors of different row sizes, bit-exact."""
