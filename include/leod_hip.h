@@ -180,7 +180,9 @@ int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, float* dbia
 
 /* BatchNorm2d (batch statistics) + SiLU on rows and its autograd (network_blocks.py:47-51).  `count` = rows that
  * entered colstats/sums.  SyncBatchNorm: with count_dev (device scalar) the row count is count * count_dev[0] -- pass count =
- * rows per image and count_dev = images over all ranks (one all-reduced scalar per step), colstats/sums all-reduced. */
+ * rows per image and count_dev = images over all ranks (one all-reduced scalar per step), colstats/sums all-reduced.
+ * sums of the backward pair: zero-filled double [rep][2][N]; the reduce kernel's workgroups spread their closing atomics over the rep
+ * copies (rep >= 1, chosen by the caller from the row count), the apply kernel folds them. */
 int leod_bn_silu_fwd(const float* z, const double* colstats, int stat_rep, const float* w, const float* b, float* y, float* save_mean,
                      float* save_rstd, float* run_mean, float* run_var, int M, int N, double count,
                      const double* count_dev, float eps, float momentum, leod_stream_t stream);

@@ -251,8 +251,8 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __rest
 // BatchNorm2d (training statistics) + SiLU, channels-last rows  (network_blocks.py:29-51)
 //   fwd : colstats[2][N] (double sum, sumsq from the conv epilogue) -> mean / biased var ;
 //         y = silu((z-mean)*rstd*w + b) ; block 0 stores save_mean/save_rstd and updates the running buffers
-//   bwd1: sums[0][n] = sum du, sums[1][n] = sum du*xhat   with du = dy * silu'(u)
-//   bwd2: dz = w*rstd*(du - sums0/M - xhat*sums1/M) ; block 0: dw += sums1, db += sums0
+//   bwd1: sums[r][0][n] += sum du, sums[r][1][n] += sum du*xhat   with du = dy * silu'(u); workgroup b adds into copy r = b mod rep
+//   bwd2: dz = w*rstd*(du - sums0/M - xhat*sums1/M) with sums = the fold of the rep copies ; block 0: dw += sums1, db += sums0
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const float* __restrict__ z, const double* __restrict__ colstats, int rep,
                                                           const float* __restrict__ w, const float* __restrict__ b,
