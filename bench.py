@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')    # kernel-argument blocks in device memory (see leod_amd/__init__.py); before HIP initialises
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
