@@ -276,6 +276,22 @@ int leod_linear_dgrad_lnbwd(const float* dy, const float* W, const float* x, con
                             const float* dres, float* dx, float* dgamma, float* dbeta, int M, int N, int K, int dy_bf16,
                             leod_stream_t stream);
 
+/* ---- launch plans (no counterpart in the reference: its answer to launch overhead is torch.compile(mode='reduce-overhead') = CUDA
+ * graphs, config/model/maxvit_yolox/default.yaml:8-11, modules/detection.py:43-44) -----------------------------------------------
+ * A plan replays a stream-captured hipGraph as plain stream launches from one C loop: hip_graph (hipGraph_t of a finished capture:
+ * kernel / memset / 1-D memcpy nodes) is sorted topologically, its chains become lanes (lane 0 = the stream given to
+ * leod_plan_launch, lanes 1 .. max_lanes-1 = streams owned by the plan), edges between lanes become event record / wait pairs.
+ * ~3 us of host time per kernel, parallel branches stay parallel (hipGraphLaunch on ROCm 7.2: 8 us per node single-stream, and as
+ * slow as eager Python launches once the graph forks).  The graph must outlive the plan (kernel argument blocks are borrowed).
+ * leod_plan_create returns a handle > 0 or a negative error (-3: a node type a plan cannot replay; leod_plan_last_error() names it).
+ * leod_plan_info: info[8] = kernels, memsets, memcpys, empty nodes, lanes, events, cross-lane waits, ops. */
+long leod_plan_create(void* hip_graph, int max_lanes);
+int leod_plan_launch(long plan, leod_stream_t stream);
+int leod_plan_info(long plan, int* info);
+int leod_plan_destroy(long plan);
+int leod_plan_dump(long plan, const char* path); /* debug listing: lane, kernel, events per op in launch order */
+const char* leod_plan_last_error(void);
+
 /* ---- host-side C++ of the path (no GPU involved) ------------------------------------------------------------------
  * Tracking post-filter of the pseudo-label loop: linear-velocity tracklets, confidence-ordered greedy IoU association,
  * short-tracklet removal and in-painting of missed detections.  Replaces modules/tracking/linear.py:10-292,

@@ -42,6 +42,8 @@ class TrainEngine:
         # fill the device while the sequential parts of the backward pass (BPTT of the ConvLSTMs: 2 small launches per
         # timestep) run on the launch stream.  45.4 -> 43.6 ms per step; not used inside hipGraph capture.
         self.wgrad_side = os.environ.get('LEOD_WGRAD_STREAM', '1') == '1'
+        # experiment switch: keep the weight-gradient fork / join inside a captured graph (parallel branches of the hipGraph)
+        self.graph_side = os.environ.get('LEOD_GRAPH_SIDE', '0') == '1'
 
     def current_lr(self):
         h = self.hp
@@ -85,7 +87,7 @@ class TrainEngine:
             self.dp.begin_step()                         # per-stage gradient buckets are exchanged under the backward pass
         ops.StatArena.begin_step(ev_seq.device)          # one memset for all BatchNorm statistic accumulators of the step
         _, losses, new_states = self.forward_loss(ev_seq, labels, label_tb, is_first, states)
-        WgradSide.active = self.wgrad_side and not self._capturing and not torch.cuda.is_current_stream_capturing()
+        WgradSide.active = self.wgrad_side and (self.graph_side or (not self._capturing and not torch.cuda.is_current_stream_capturing()))
         try:
             losses['loss'].backward()
         finally:
@@ -109,7 +111,7 @@ class TrainEngine:
         return losses
 
     # ---- hipGraph replay ---------------------------------------------------------------------------------
-    def capture(self, ev_seq, labels, label_tb, is_first):
+    def capture(self, ev_seq, labels, label_tb, is_first, plan: bool = False, max_lanes: int = 8):
         """Capture the WHOLE training step (zero-grad, 21 timesteps, head/loss, backward, all-reduce, AdamW, state
         hand-over) into one hipGraph.  Shapes are static (reference asserts constant B and HxW, detection.py:176-199);
         per-step scalars (lr, bias corrections) live in device memory.  ~4400 kernel launches per step then cost one
@@ -139,10 +141,17 @@ class TrainEngine:
             self._graph_body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self._graph = torch.cuda.CUDAGraph()
+        # plan=True: the capture is replayed by a launch plan (ops.LaunchPlan: plain stream launches from one C loop, parallel branches
+        # on the plan's side streams) instead of hipGraphLaunch -- the fork / join of the weight-gradient side stream and of the head's
+        # level streams is then worth capturing
+        self._graph = torch.cuda.CUDAGraph(keep_graph=True) if plan else torch.cuda.CUDAGraph()
+        side_in_graph, self.graph_side = self.graph_side, self.graph_side or plan
+        ops.PackCache.invalidate()                                      # the capture must contain the weight packs of a step
         with torch.cuda.graph(self._graph):
             self._g_losses = self._graph_body()
+        self.graph_side = side_in_graph
         self._capturing = False
+        self._plan = ops.LaunchPlan(self._graph, max_lanes) if plan else None
         # undo the side effects of the warm-up + capture passes (capture itself does not execute)
         self.flat.data.copy_(saved[0]); self.flat.exp_avg.copy_(saved[1]); self.flat.exp_avg_sq.copy_(saved[2])
         self.flat.touch()
@@ -156,9 +165,15 @@ class TrainEngine:
     def _graph_body(self):
         losses, new_states = self._step_body(self._g_ev, self._g_labels, self._g_label_tb, self._g_first, self._g_states,
                                              hp_dev=self._g_hp)
-        for (gh, gc), (h, c) in zip(self._g_states, new_states):        # hand the states over to the next replay
-            gh.copy_(h)
-            gc.copy_(c)
+        # hand the states over to the next replay: one copy kernel (a tensor.copy_ would be captured as a 1-D memcpy node, which a launch
+        # plan cannot read back from the graph)
+        dst = [t for pair in self._g_states for t in pair]
+        src = [t for pair in new_states for t in pair]
+        if ops.multi_ok(dst) and ops.multi_ok(src) and all(d.stride() == s_.stride() for d, s_ in zip(dst, src)):
+            ops.copy_multi(dst, src)
+        else:
+            for d, s_ in zip(dst, src):
+                d.copy_(s_)
         return torch.stack([losses[k] for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')])
 
     def step_graph(self, ev_seq=None, labels=None, is_first=None):
@@ -170,7 +185,10 @@ class TrainEngine:
         if is_first is not None:
             self._g_first.copy_(is_first, non_blocking=True)
         ops.set_scalars4(self._g_hp, *self.flat.step_scalars(self.current_lr(), 1.0 / self.dp.world_size))
-        self._graph.replay()
+        if getattr(self, '_plan', None) is not None:
+            self._plan.launch()
+        else:
+            self._graph.replay()
         ops.PackCache.invalidate()                          # the replayed AdamW kernel rewrote the parameters
         self.global_step += 1
         self.states = self._g_states

@@ -637,3 +637,17 @@ class HeadTailFn(Function):
                                          ctx.offs[k], gscale=gscale)
             grads += [dcf, drf]
         return (None, None) + tuple(grads) + (None,) * len(params)
+
+
+class PickLossFn(Function):
+    """losses[0] as its own autograd node.  Plain indexing would put a SelectBackward node in front of ``HeadTailFn``: a zero fill of a
+    [6] tensor plus a 4-byte device-to-device memcpy per backward pass -- and a memcpy NODE in a captured step, which a launch plan
+    (``ops.LaunchPlan``) cannot read back from the graph.  The seed is handed on as a stride-0 view: ``HeadTailFn.backward`` reads element 0."""
+
+    @staticmethod
+    def forward(ctx, losses):
+        return losses[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.reshape(1).expand(6)

@@ -20,6 +20,9 @@ LOSS_KEYS = ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')
 
 _LEVEL_STREAMS = __import__('os').environ.get('LEOD_HEAD_STREAMS', '1') == '1'   # pyramid levels of the head on their own HIP streams
 
+_GRAPH_LEVEL_STREAMS = __import__('os').environ.get('LEOD_GRAPH_HEAD_STREAMS', '0') == '1'   # experiment: level streams inside a captured graph
+
+
 class YOLOXHead(nn.Module):
     def __init__(self, num_classes=80, strides=(8, 16, 32), in_channels=(256, 512, 1024), act="silu", depthwise=False,
                  compile_cfg: Optional[Dict] = None, obj_focal_loss=False, bbox_loss_weighting='', ignore_bg_k=-1,
@@ -108,7 +111,7 @@ class YOLOXHead(nn.Module):
 
     def _towers(self, xin):
         if (_LEVEL_STREAMS and xin[0].is_cuda and len(xin) > 1 and not Fn._sync_bn_on()
-                and not torch.cuda.is_current_stream_capturing()):
+                and (_GRAPH_LEVEL_STREAMS or not torch.cuda.is_current_stream_capturing())):
             return self._towers_streams(list(xin))
         # the three levels are independent: layers of equal depth form one group (one SyncBatchNorm exchange per group)
         n = len(xin)
@@ -139,7 +142,9 @@ class YOLOXHead(nn.Module):
             assert labels is not None
             labels = labels.to(dtype=torch.float32).contiguous()
             losses, out = Fn.HeadTailFn.apply(self, labels, *feats, *params)
-            return out, {k: losses[i] for i, k in enumerate(LOSS_KEYS)}
+            d = {k: losses[i] for i, k in enumerate(LOSS_KEYS)}
+            d['loss'] = Fn.PickLossFn.apply(losses)           # the one differentiable entry, without a SelectBackward node
+            return out, d
         B = feats[0].shape[0]
         A = sum(h * w for h, w in self.hw)
         out = torch.empty((B, A, 5 + self.num_classes), dtype=torch.float32, device=feats[0].device)

@@ -892,6 +892,44 @@ def voxelize_u8(x, y, pol, t, bins, height, width, count_cutoff=None, fastmode=T
     return out
 
 
+
+# ---------------------------------------------------------------------------------------------------
+# launch plans: a captured hipGraph replayed as plain stream launches (csrc/k_plan.hip)
+# ---------------------------------------------------------------------------------------------------
+class LaunchPlan:
+    """``LaunchPlan(torch.cuda.CUDAGraph(keep_graph=True) after capture)``: ``launch()`` enqueues every kernel / memset / copy of
+    the captured work on torch's current stream (lane 0) and on the plan's own side streams (parallel branches of the capture), in one
+    C loop.  The CUDAGraph object (it owns the hipGraph whose argument blocks the plan borrows, and the memory pool) is kept alive here."""
+
+    def __init__(self, graph: 'torch.cuda.CUDAGraph', max_lanes: int = 8):
+        self.graph = graph
+        raw = graph.raw_cuda_graph()
+        h = int(_l().leod_plan_create(ctypes.c_void_p(int(raw)), int(max_lanes)))
+        if h <= 0:
+            raise LeodHipError(f'leod_plan_create: {_l().leod_plan_last_error().decode()} (rc {h})')
+        self.handle = h
+        info = (ctypes.c_int * 8)()
+        check(_l().leod_plan_info(h, info), 'plan_info')
+        self.info = dict(zip(('kernels', 'memsets', 'memcpys', 'empty', 'lanes', 'events', 'waits', 'ops'), list(info)))
+
+    def launch(self):
+        check(_l().leod_plan_launch(self.handle, _stream()), 'plan_launch')
+
+    def dump(self, path: str):
+        check(_l().leod_plan_dump(self.handle, path.encode()), 'plan_dump')
+
+    def close(self):
+        if getattr(self, 'handle', 0):
+            _l().leod_plan_destroy(self.handle)
+            self.handle = 0
+        self.graph = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                     # interpreter shutdown
+            pass
+
 # ---------------------------------------------------------------------------------------------------
 # live kernel timing for bench.py's roofline object
 # ---------------------------------------------------------------------------------------------------

@@ -761,37 +761,46 @@ class _CudaLikeFp32Ops(torch.overrides.TorchFunctionMode):
 
 def _ref_train_step(det, ev_padded, labels, hw, T, B, mode):
     """One forward + backward of the reference detector driven like Module.training_step (as g12), in ``mode``:
-    'fp32' | 'ac' (torch.autocast('cpu', bfloat16) as it is) | 'acf' (the same with CUDA autocast's fp32-op placement).
+    'fp32' | 'ac' (torch.autocast('cpu', bfloat16) as it is) | 'acf' (the same with CUDA autocast's fp32-op placement) |
+    'h16' / 'h16f' (the same two placements under torch.autocast('cpu', float16) -- the dtype the reference trains with,
+    Lightning precision=16, train.py:236-243 -- with the loss scaled as GradScaler does: start at 2**16, halve until every
+    gradient is finite, un-scale afterwards).
     -> dict(losses[6], grads {name: tensor}, feats of the last timestep {stage: tensor}, final LSTM (h, c) per stage)"""
     import contextlib
     det.train()
-    for p_ in det.parameters():
-        p_.grad = None
-    ctx = contextlib.ExitStack()
-    if mode in ('ac', 'acf'):
-        ctx.enter_context(torch.autocast('cpu', dtype=torch.bfloat16))
-    if mode == 'acf':
-        ctx.enter_context(_CudaLikeFp32Ops())
-    with ctx:
-        rnn = RNNStates()
-        rnn.reset(worker_id=0, indices_or_bool_tensor=torch.ones(B, dtype=torch.bool))
-        prev = rnn.get_states(worker_id=0)
-        sel = BackboneFeatureSelector()
-        obj_labels = []
-        feats = None
-        for t in range(T):
-            feats, prev = det.forward_backbone(x=ev_padded[t], previous_states=prev)
-            idx = [b for b in range(B) if labels[t][b] is not None]
-            if idx:
-                sel.add_backbone_features(backbone_features=feats, selected_indices=idx)
-                obj_labels.extend(ObjectLabels(labels[t][b], hw) for b in idx)
-        targets = ObjectLabels.get_labels_as_batched_tensor(obj_label_list=obj_labels, format_='yolox')
-        preds, losses = det.forward_detect(backbone_features=sel.get_batched_backbone_features(), targets=targets)
-        losses['loss'].float().backward()
+    half = mode in ('h16', 'h16f')
+    scale = 65536.0 if half else 1.0
+    while True:
+        for p_ in det.parameters():
+            p_.grad = None
+        ctx = contextlib.ExitStack()
+        if mode in ('ac', 'acf', 'h16', 'h16f'):
+            ctx.enter_context(torch.autocast('cpu', dtype=torch.float16 if half else torch.bfloat16))
+        if mode in ('acf', 'h16f'):
+            ctx.enter_context(_CudaLikeFp32Ops())
+        with ctx:
+            rnn = RNNStates()
+            rnn.reset(worker_id=0, indices_or_bool_tensor=torch.ones(B, dtype=torch.bool))
+            prev = rnn.get_states(worker_id=0)
+            sel = BackboneFeatureSelector()
+            obj_labels = []
+            feats = None
+            for t in range(T):
+                feats, prev = det.forward_backbone(x=ev_padded[t], previous_states=prev)
+                idx = [b for b in range(B) if labels[t][b] is not None]
+                if idx:
+                    sel.add_backbone_features(backbone_features=feats, selected_indices=idx)
+                    obj_labels.extend(ObjectLabels(labels[t][b], hw) for b in idx)
+            targets = ObjectLabels.get_labels_as_batched_tensor(obj_label_list=obj_labels, format_='yolox')
+            preds, losses = det.forward_detect(backbone_features=sel.get_batched_backbone_features(), targets=targets)
+            (losses['loss'].float() * scale).backward()
+        if not half or all(bool(torch.isfinite(p_.grad).all()) for p_ in det.parameters() if p_.grad is not None) or scale <= 1.0:
+            break
+        scale /= 2.0                                   # GradScaler: skip the step, back off, try again
     return dict(losses=np.array([float(losses[k]) for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')], dtype=np.float64),
-                grads={n: p_.grad.detach().float().clone() for n, p_ in det.named_parameters() if p_.grad is not None},
+                grads={n: (p_.grad.detach().float() / scale).clone() for n, p_ in det.named_parameters() if p_.grad is not None},
                 feats={k: v.detach().float().clone() for k, v in feats.items()},
-                states=[(h.detach().float().clone(), c.detach().float().clone()) for h, c in prev])
+                states=[(h.detach().float().clone(), c.detach().float().clone()) for h, c in prev], loss_scale=scale)
 
 
 def _rel(a, b):
@@ -810,6 +819,7 @@ def _class_record(out, tag, ref, run):
     """Deviation of one 16-bit run of the reference from its fp32 run: what the HIP bf16 mode is allowed to differ by."""
     names = sorted(ref['grads'])
     out[f'{tag}_losses'] = run['losses']
+    out[f'{tag}_loss_scale'] = np.float64(run.get('loss_scale', 1.0))
     out[f'{tag}_grad_rel'] = np.array([_rel(run['grads'][n], ref['grads'][n]) for n in names], dtype=np.float64)
     out[f'{tag}_grad_cos'] = np.array([_cos(run['grads'][n], ref['grads'][n]) for n in names], dtype=np.float64)
     flat = lambda g: torch.cat([g[n].flatten() for n in names])
@@ -825,11 +835,13 @@ def _class_record(out, tag, ref, run):
 
 
 def g18_autocast(full_size=True):
-    """The reference's own 16-bit class: the reference run in fp32 and under torch.autocast (bf16 on CPU -- the
-    only 16-bit autocast this container has; the reference trains with fp16 autocast on CUDA, train.py:236-243), once as CPU
-    autocast places ops ('ac') and once with CUDA autocast's fp32-op list emulated ('acf').  Stored: the fp32 run's losses /
+    """The reference's own 16-bit classes: the reference run in fp32 and under torch.autocast on the CPU,
+    in bfloat16 ('ac' / 'acf') and in float16 with GradScaler-style loss scaling ('h16' / 'h16f': the dtype the reference itself
+    trains with on CUDA, Lightning precision=16, train.py:236-243), each once as CPU autocast places ops ('ac', 'h16') and once
+    with CUDA autocast's fp32-op list emulated ('acf', 'h16f').  Stored: the fp32 run's losses /
     gradient norms (so that the tests can pin their own fp32 side to it) and, per tensor, how far each 16-bit run is from fp32.
-    The -m gpu tests bound the HIP bf16 mode's deviation from fp32 by 1.5 x these.
+    The -m gpu tests bound the HIP bf16 mode's deviation from fp32 by 1.5 x the bf16 class and print / record it as a multiple
+    of the fp16 class.
       micro_*   micro detector, T=5 B=2 (the g12 set-up, step 0)
       tiny_*    RVT-tiny at 256x320, T=2 B=1 forward features (the g04 set-up)
       small_*   RVT-small Gen1 240x304 T=21 bs=8, the benchmark workload (bench.make_batch seed 7): scalars only"""
@@ -842,13 +854,13 @@ def g18_autocast(full_size=True):
     ev = InputPadderFromShape(desired_hw=(64, 96)).pad_tensor_ev_repr(synth_events(T, B, 20, 60, 90, seed=20, as_uint8=False))
     lab_list = micro_labels(T * B, seed=30)
     labels = [[lab_list[t * B + b] if (t in (2, 4) or (t == 1 and b == 0)) else None for b in range(B)] for t in range(T)]
-    runs = {m: _ref_train_step(det, ev, labels, (60, 90), T, B, m) for m in ('fp32', 'ac', 'acf')}
+    runs = {m: _ref_train_step(det, ev, labels, (60, 90), T, B, m) for m in ('fp32', 'ac', 'acf', 'h16', 'h16f')}
     names = sorted(runs['fp32']['grads'])
     out['micro_grad_keys'] = np.array(names)
     out['micro_fp32_losses'] = runs['fp32']['losses']
     out['micro_fp32_grad_norms'] = np.array([float(runs['fp32']['grads'][n].double().norm()) for n in names], dtype=np.float64)
     out['micro_fp32_feat_norms'] = np.array([float(runs['fp32']['feats'][k].double().norm()) for k in sorted(runs['fp32']['feats'])])
-    for m in ('ac', 'acf'):
+    for m in ('ac', 'acf', 'h16', 'h16f'):
         _class_record(out, f'micro_{m}', runs['fp32'], runs[m])
     # ---- RVT-tiny forward at the real geometry ----------------------------------------------------------------------------
     det = YoloXDetector(make_cfg(32, 32, 0.33, (256, 320), (8, 10)))
@@ -857,17 +869,17 @@ def g18_autocast(full_size=True):
     ev = InputPadderFromShape(desired_hw=(256, 320)).pad_tensor_ev_repr(synth_events(2, 1, 20, 240, 304, seed=5, as_uint8=False))
     import contextlib
     fe = {}
-    for m in ('fp32', 'ac', 'acf'):
+    for m in ('fp32', 'ac', 'acf', 'h16', 'h16f'):
         with contextlib.ExitStack() as ctx, torch.no_grad():
             if m != 'fp32':
-                ctx.enter_context(torch.autocast('cpu', dtype=torch.bfloat16))
-            if m == 'acf':
+                ctx.enter_context(torch.autocast('cpu', dtype=torch.float16 if m.startswith('h16') else torch.bfloat16))
+            if m in ('acf', 'h16f'):
                 ctx.enter_context(_CudaLikeFp32Ops())
             f_, st = det.forward_backbone(ev[0], None)
             f_, st = det.forward_backbone(ev[1], st)
             fe[m] = {k: v.float() for k, v in f_.items()}
     out['tiny_fp32_feat_norms'] = np.array([float(fe['fp32'][k].double().norm()) for k in sorted(fe['fp32'])])
-    for m in ('ac', 'acf'):
+    for m in ('ac', 'acf', 'h16', 'h16f'):
         out[f'tiny_{m}_feat_rel'] = np.array([_rel(fe[m][k], fe['fp32'][k]) for k in sorted(fe['fp32'])], dtype=np.float64)
         out[f'tiny_{m}_feat_maxrel'] = np.array([float((fe[m][k] - fe['fp32'][k]).abs().max() / fe['fp32'][k].abs().max())
                                                  for k in sorted(fe['fp32'])], dtype=np.float64)
@@ -891,7 +903,7 @@ def g18_autocast(full_size=True):
         det.load_state_dict(synth_state_dict(man, 0), strict=True)
         x = InputPadderFromShape(desired_hw=(256, 320)).pad_tensor_ev_repr(evu.to(torch.float32))
         runs = {}
-        for m in ('fp32', 'ac', 'acf'):
+        for m in ('fp32', 'ac', 'acf', 'h16', 'h16f'):
             t0 = time.time()
             runs[m] = _ref_train_step(det, x, labels, hw, T, B, m)
             print(f'small {m}: {time.time() - t0:.1f} s, losses {runs[m]["losses"]}')
@@ -899,7 +911,7 @@ def g18_autocast(full_size=True):
         out['small_grad_keys'] = np.array(names)
         out['small_fp32_losses'] = runs['fp32']['losses']
         out['small_fp32_grad_norms'] = np.array([float(runs['fp32']['grads'][n].double().norm()) for n in names], dtype=np.float64)
-        for m in ('ac', 'acf'):
+        for m in ('ac', 'acf', 'h16', 'h16f'):
             _class_record(out, f'small_{m}', runs['fp32'], runs[m])
     save('g18_autocast.npz', **out)
     for k in sorted(out):
