@@ -141,6 +141,7 @@ def main():
     ap.add_argument('--no-second-dtype', action='store_true', help='skip the secondary line measured in the other precision (N=1 only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-plan', action='store_true', help='eager Python launches for every step (LEOD_PLAN=0): no launch plans')
     ap.add_argument('--dump-calls', default='', help='file for the per-launch table (C entry point, shape arguments, us) of the probe steps')
     args = ap.parse_args()
 
@@ -220,6 +221,8 @@ def main():
             step_no[0] += 1
             return out
 
+        if args.no_plan:
+            module.plan_mode = False
         for s in range(args.warmup):
             run(first_mask(s))
         masks = [first_mask(1 + args.warmup + s) for s in range(args.steps)]
@@ -233,23 +236,43 @@ def main():
         if dist.is_initialized():
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dt = float(t_max)
+        # host side of one step: enqueue time of single steps launched into an IDLE device (inside the timed loop the host runs ahead of
+        # the GPU and its launch calls block on the full hardware queue, so the loop's own host time says nothing)
+        host_ms = []
+        for s in range(5):
+            m = first_mask(2 + s)
+            b = loader_batch(m)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            fit_step(module, opt, sched, b, step_no[0])
+            host_ms.append(1e3 * (time.perf_counter() - t1))
+            step_no[0] += 1
+        torch.cuda.synchronize()
+        host_ms = sorted(host_ms)[len(host_ms) // 2]
+        plans = [e for e in module._plans.entries.values() if not isinstance(e, str)]
+        plan_info = None
+        if plans and module.plan_mode:
+            e = plans[-1]
+            plan_info = {'forward': e.fwd.info, 'backward': e.bwd.info, 'captures': module._plans.captures, 'replays': module._plans.replays}
         # roofline of the dominant kernel: two extra steps with HIP events around each of its launches
-        roofline = roofline_gemm = family_ms = None
+        roofline = roofline_gemm = family_ms = probe = family_all = None
         if not args.no_roofline:
             # EVERY rank runs the two probe steps (a step contains collectives: a rank-0-only step would dead-lock N > 1);
             # only rank 0 brackets the kernel with events and reports
             probe = ops.KernelProbe() if rank == 0 else None
             # isolated launches: no co-running kernels inside the event bracket (wgrad on the launch stream)
             side, module.wgrad_side = module.wgrad_side, False
+            planned, module.plan_mode = module.plan_mode, False           # eager launches: every C entry point is bracketed
             for s in range(2):
                 run(first_mask(1))
-            module.wgrad_side = side
+            module.wgrad_side, module.plan_mode = side, planned
             if probe is not None:
                 peak_t = PEAK_BF16_MFMA_TFLOPS if dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS
                 roofline = probe.finish(PEAK_HBM_GBS, peak_t, target='linear_wgrad')
                 roofline_gemm = probe.finish(PEAK_HBM_GBS, peak_t, target='linear_gemm')
                 # every C entry point bracketed with events during the same two single-stream steps: the line audits itself
                 family_ms = probe.family_ms(2)
+                family_all = probe.family_ms(2, top=1000)
                 if args.dump_calls:                           # every C launch of the two probe steps, in order (tools / profiles)
                     with open(args.dump_calls, 'w') as f:
                         for n, ints, us in probe.call_table():
@@ -264,9 +287,11 @@ def main():
         barrier()
         loss_val = float(out['loss'].detach())
 
-        launch = (f'eager, schedule={"batched" if module.time_batched else "timestep"}, wgrad side stream {"on" if module.wgrad_side else "off"}, '
+        how = ('launch plans (step captured once, replayed as plain stream launches from C: modules/step_plan.py)' if plan_info else 'eager')
+        launch = (f'{how}, schedule={"batched" if module.time_batched else "timestep"}, wgrad side stream {"on" if module.wgrad_side else "off"}, '
                   f'precision mode {ops.get_precision()}')
-        return dict(dt=dt, loss=loss_val, roofline=roofline, roofline_gemm=roofline_gemm, family_ms=family_ms, launch=launch)
+        return dict(dt=dt, loss=loss_val, roofline=roofline, roofline_gemm=roofline_gemm, family_ms=family_ms, launch=launch, family_ms_all=family_all,
+                    host_ms=host_ms, plan_info=plan_info, calls=(len(probe.calls) // 2 if probe is not None and hasattr(probe, 'calls') else None))
 
     main_run = measure(args.dtype, args.steps, args.warmup, not args.no_roofline)
     dt, loss_val, roofline, launch = main_run['dt'], main_run['loss'], main_run['roofline'], main_run['launch']
@@ -303,7 +328,15 @@ def main():
                        if headline else None,
                        'algorithmic_MB_per_event_frame': round(ALGO_MB_PER_FRAME[args.dtype], 2) if headline else None,
                        # GPU time per C entry point (= kernel family) and step, HIP events around every launch of two single-stream steps
-                       'family_ms_per_step': main_run['family_ms']},
+                       'family_ms_per_step': main_run['family_ms'],
+                       # host side: wall time of the Python call chain of ONE step launched into an idle device (median of 5), the kernels
+                       # of the step's launch plans (+ ~12 eager launches: zero-grad, copy-ins, optimiser) or, eager, the C calls of a step
+                       'host_enqueue_ms_per_step': round(main_run['host_ms'], 3),
+                       'kernel_ms_per_step': round(sum((main_run['family_ms_all'] or {}).values()), 3) if main_run.get('family_ms_all') else None,
+                       'launches_per_step': (main_run['plan_info']['forward']['kernels'] + main_run['plan_info']['backward']['kernels'] + 12)
+                       if main_run['plan_info'] else None,
+                       'c_calls_per_eager_step': main_run['calls'],
+                       'launch_plans': main_run['plan_info']},
             'roofline': roofline,
             'roofline_linear_gemm': main_run['roofline_gemm'],
         }

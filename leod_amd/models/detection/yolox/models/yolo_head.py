@@ -58,6 +58,7 @@ class YOLOXHead(nn.Module):
         self.ignore_bbox_thresh = ignore_bbox_thresh
         self.ignore_label = ignore_label
         self.last_assignment = None
+        self.last_losses6 = None
         self.hw = None
         self.initialize_biases(prior_prob=0.01)
 
@@ -142,6 +143,7 @@ class YOLOXHead(nn.Module):
             assert labels is not None
             labels = labels.to(dtype=torch.float32).contiguous()
             losses, out = Fn.HeadTailFn.apply(self, labels, *feats, *params)
+            self.last_losses6 = losses.detach()              # the six scalars as one tensor (launch plans read them back from here)
             d = {k: losses[i] for i, k in enumerate(LOSS_KEYS)}
             d['loss'] = Fn.PickLossFn.apply(losses)           # the one differentiable entry, without a SelectBackward node
             return out, d

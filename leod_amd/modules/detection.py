@@ -64,6 +64,12 @@ class Module(_Base):
         self.time_batched = os.environ.get('LEOD_SCHEDULE', 'batched') == 'batched'
         self.wgrad_side = os.environ.get('LEOD_WGRAD_STREAM', '1') == '1'
         self._row_idx_cache: Dict[Any, th.Tensor] = {}
+        # launch plans (modules/step_plan.py): a training-step geometry seen twice is captured once and replayed from C afterwards --
+        # this build's counterpart of the reference's ``backbone.compile`` switch (torch.compile(mode='reduce-overhead') = CUDA graphs,
+        # modules/detection.py:43-44).  LEOD_PLAN=0 keeps every step eager.
+        from .step_plan import TrainStepPlans
+        self.plan_mode = os.environ.get('LEOD_PLAN', '1') == '1'
+        self._plans = TrainStepPlans()
         self._pin_ring: List[Any] = []
         self._pin_next = 0
 
@@ -228,6 +234,10 @@ class Module(_Base):
         ign = dict(ignore=self.mdl_config.get('ignore_image', False),
                    ignore_label=self.mdl_config.head.get('ignore_label', 1024))
         device = data[DataType.EV_REPR][0].device
+        if self.plan_mode and self.time_batched and device.type == 'cuda' and th.is_grad_enabled() and self._plans.allowed():
+            planned = self._training_step_planned(data, worker_id, ign, log)
+            if planned is not None:
+                return planned
         ops.StatArena.begin_step(device)             # one memset for every BatchNorm statistic accumulator of the step
         feats, obj_labels, _, B = self._run_sequence(Mode.TRAIN, data, worker_id, ign)
         assert len(obj_labels) > 0
@@ -240,6 +250,59 @@ class Module(_Base):
         WgradSide.active = self.wgrad_side and torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()
         output = {'loss': losses['loss'],
                   'log_dict': {f'{mode_2_string[Mode.TRAIN]}/{k}': v for k, v in losses.items()}}
+        if hasattr(self, 'log_dict') and log and _Base is not th.nn.Module:  # pragma: no cover
+            self.log_dict(output['log_dict'], on_step=True, on_epoch=True, batch_size=B, sync_dist=False, rank_zero_only=True)
+        return output
+
+    def _training_step_planned(self, data, worker_id: int, ign, log: bool):
+        """The same step through a launch plan (modules/step_plan.py), or None when this batch has to run eagerly: the first
+        occurrence of its geometry, host-resident frames, no labelled frame, or a geometry whose capture failed."""
+        from .step_plan import PlanLossFn, StepPlan, LOSS_KEYS
+        ev_seq = data[DataType.EV_REPR]
+        labels_seq = data[DataType.OBJLABELS_SEQ]
+        is_first = data[DataType.IS_FIRST_SAMPLE]
+        L, B = len(ev_seq), len(labels_seq[0])
+        obj_labels, where = [], []
+        for tidx in range(L):
+            cur, idx = labels_seq[tidx].get_valid_labels_and_batch_indices(**ign)
+            obj_labels.extend(cur)
+            where.extend((tidx, b) for b in idx)
+        if not where:
+            return None
+        ev = self._stack_frames(ev_seq)
+        labels_yolox = ObjectLabels.get_labels_as_batched_tensor(obj_label_list=obj_labels, format_='yolox').to(th.float32)
+        key, nmax_pad = self._plans.key_of(ev, len(where), labels_yolox.shape[1])
+        hit = self._plans.lookup(key)
+        if hit is None:
+            return None
+        mode = Mode.TRAIN
+        hw = tuple(ev.shape[-2:])
+        if self.mode_2_batch_size[mode] is None or self.mode_2_hw[mode] is None:
+            return None                                  # the eager step records them (reference asserts, detection.py:176-179,196-199)
+        assert self.mode_2_batch_size[mode] == B and self.mode_2_hw[mode] == hw
+        rnn = self.mode_2_rnn_states[mode]
+        if hit == 'capture':
+            like = rnn.get_states(worker_id) or next(iter(rnn.states.values()), None)
+            if like is None:
+                return None
+            hit = self._plans.build(key, self, ev, len(where), nmax_pad, like, self.wgrad_side)
+            if hit is None:
+                return None
+        entry: StepPlan = hit
+        self.started_training = True
+        rows = self._row_index(tuple(t * B + b for t, b in where), ev.device)
+        entry.load_states(rnn, worker_id)
+        entry.stage_inputs(ev, labels_yolox, rows, is_first)
+        entry.run_forward()
+        rnn.save_states_and_detach(worker_id=worker_id, states=entry.states)
+        self._plans.replays += 1
+        if self._plans.anchor is None or self._plans.anchor.device != ev.device:
+            self._plans.anchor = th.zeros(1, device=ev.device, requires_grad=True)
+        out6 = entry.losses6.clone()                     # the static loss buffer is overwritten by the next replay
+        loss = PlanLossFn.apply(entry, self._plans.anchor, out6[0])
+        losses = {k: out6[i] for i, k in enumerate(LOSS_KEYS)}
+        losses['loss'] = loss
+        output = {'loss': loss, 'log_dict': {f'{mode_2_string[Mode.TRAIN]}/{k}': v for k, v in losses.items()}}
         if hasattr(self, 'log_dict') and log and _Base is not th.nn.Module:  # pragma: no cover
             self.log_dict(output['log_dict'], on_step=True, on_epoch=True, batch_size=B, sync_dist=False, rank_zero_only=True)
         return output

@@ -1,0 +1,241 @@
+"""Launch plans for ``Module.training_step``: the host's answer to launch overhead on the product path.
+
+The reference's answer is ``torch.compile(mode='reduce-overhead')`` = CUDA graphs on the backbone (config/model/maxvit_yolox/
+default.yaml:8-11, modules/detection.py:43-44; static shapes asserted at :176-179,196-199).  Here the unit is the whole training step
+of one static shape: the SECOND time ``training_step`` sees a batch geometry (event tensor shape, number of labelled frames, padded
+label count) its forward pass -- LSTM-row reset, stage-major backbone over the L frames, PAFPN + head + SimOTA + losses -- and its
+backward pass are stream-captured ONCE (two captures sharing a private memory pool; nothing executes during capture), turned into
+two ``ops.LaunchPlan`` objects (csrc/k_plan.hip: the captured kernels replayed as plain stream launches from one C loop, ~3 us each, the
+weight-gradient fork / join on the plan's own side stream), and from then on a step of that geometry is
+
+    copy-in of (frames, labels, row indices, is_first)  ->  forward plan  ->  [loss.backward()]  backward plan  ->  optimiser
+
+with ~10 Python-level launches instead of ~600.  The first occurrence of a geometry runs eagerly (it is the warm-up a capture needs
+and a real training step), any geometry that is never repeated stays eager, and so does everything a capture cannot hold: more
+than one rank with SyncBatchNorm (collectives between the kernels), or a graph node the plan cannot replay (reported once).
+
+Measured (RVT-S Gen1 bs 8 L 21, bf16 mode, profiles/r04_*): hipGraphLaunch of the same captures costs 8 us of host time per node and
+loses the side stream; the plans make the step independent of the host (16.5 ms on a host where the eager step is 17.7 ms).
+"""
+import os
+import warnings
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+import torch as th
+from torch.autograd import Function
+
+from leod_amd import functions as Fn
+from leod_amd import ops
+from leod_amd._lib import LeodHipError
+
+LOSS_KEYS = ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')
+NMAX_PAD = 8          # label rows are padded to a multiple of this (all-zero rows are "no box" to SimOTA / the loss, yolo_head.py:437-441)
+
+
+def _flat(states) -> List[th.Tensor]:
+    return [t for pair in states for t in pair]
+
+
+class PlanLossFn(Function):
+    """The loss of a replayed step as an autograd leaf-to-loss edge: ``forward`` has already happened (the forward plan), ``backward``
+    hands the seed gradient to the captured backward pass and launches the backward plan.  Parameter gradients land in the flat
+    gradient buffer as in the eager step (the captured weight-gradient kernels accumulate into the same addresses)."""
+
+    @staticmethod
+    def forward(ctx, entry, anchor, loss):
+        ctx.entry = entry
+        return loss.view_as(loss)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.entry.run_backward(g)
+        return None, None, None
+
+
+class StepPlan:
+    """One captured step geometry: static inputs / states / outputs, the two launch plans and the bookkeeping a replay owes the module."""
+
+    def __init__(self, key, module, ev: th.Tensor, n_frames: int, nmax: int, states_like):
+        dev = ev.device
+        self.key = key
+        self.ev = th.empty_like(ev)
+        self.labels = th.zeros((n_frames, nmax, 7), dtype=th.float32, device=dev)
+        self.rows = th.zeros((n_frames,), dtype=th.long, device=dev)
+        self.is_first = th.ones((ev.shape[1],), dtype=th.bool, device=dev)
+        self.seed = th.ones((), dtype=th.float32, device=dev)
+        self.states = [(th.zeros_like(h), th.zeros_like(c)) for h, c in states_like]      # strides preserved (NCHW views of NHWC rows)
+        self.arena = th.zeros(ops.StatArena.SIZE, dtype=th.uint8, device=dev)             # private scratch arena of this plan
+        self.arena_high = 0
+        self.bn_incs: List[Tuple[Any, int]] = []
+        self.losses6: Optional[th.Tensor] = None
+        self.fwd: Optional[ops.LaunchPlan] = None
+        self.bwd: Optional[ops.LaunchPlan] = None
+        self.owner = None                      # worker id whose LSTM state currently lives in ``self.states``
+        self.pin: Optional[th.Tensor] = None
+        self.pin_event = None
+        self.uses = 0
+
+    # ---- capture ------------------------------------------------------------------------------------------------------------
+    def capture(self, module, wgrad_side: bool, max_lanes: int):
+        mdl = module.mdl
+        in_features = tuple(mdl.fpn.in_features)
+        mods = [m for m in mdl.modules() if hasattr(m, 'bn_calls_pending')]
+        pending0 = [m.bn_calls_pending for m in mods]
+        saved_arena = ops.StatArena.swap(self.arena)
+        from leod_amd.parallel import GradBuckets
+        saved_buckets, GradBuckets.current = GradBuckets.current, None
+        saved_side = Fn.WgradSide.active
+        ops.PackCache.invalidate()                         # the capture must contain the weight packs of a step
+        g_f = th.cuda.CUDAGraph(keep_graph=True)
+        g_b = th.cuda.CUDAGraph(keep_graph=True)
+        try:
+            with th.enable_grad():
+                with th.cuda.graph(g_f):
+                    ops.StatArena.begin_step(self.ev.device)
+                    ops.rows_masked_zero(_flat(self.states), self.is_first)                       # RNNStates.reset (detection.py:95-157)
+                    _, new_states, feats = mdl.backbone.forward_sequence(self.ev, self.states, select_rows=self.rows, select_stages=in_features)
+                    _, losses = mdl.forward_detect(backbone_features=feats, targets=self.labels)
+                    self.losses6 = mdl.yolox_head.last_losses6
+                    ops.copy_multi(_flat(self.states), [t.detach() for t in _flat(new_states)])      # state hand-over to the next step
+                with th.cuda.graph(g_b, pool=g_f.pool()):
+                    Fn.WgradSide.active = wgrad_side
+                    try:
+                        losses['loss'].backward(gradient=self.seed)
+                    finally:
+                        Fn.WgradSide.active = False
+                        Fn.WgradSide.join()
+            self.arena_high = ops.StatArena.high
+            self.fwd = ops.LaunchPlan(g_f, max_lanes)
+            self.bwd = ops.LaunchPlan(g_b, max_lanes)
+        finally:
+            ops.StatArena.swap(*saved_arena)
+            GradBuckets.current = saved_buckets
+            Fn.WgradSide.active = saved_side
+            ops.PackCache.invalidate()                     # nothing was executed: the pack buffers do not hold what the cache believes
+            self.bn_incs = [(m, m.bn_calls_pending - p0) for m, p0 in zip(mods, pending0) if m.bn_calls_pending != p0]
+            for m, p0 in zip(mods, pending0):
+                m.bn_calls_pending = p0
+        return self
+
+    # ---- replay -------------------------------------------------------------------------------------------------------------
+    def stage_inputs(self, ev: th.Tensor, labels_host_or_dev: th.Tensor, rows: th.Tensor, is_first: th.Tensor):
+        if ev.data_ptr() != self.ev.data_ptr():
+            self.ev.copy_(ev, non_blocking=True)
+        n, nmax = labels_host_or_dev.shape[0], labels_host_or_dev.shape[1]
+        if labels_host_or_dev.is_cuda:
+            if nmax != self.labels.shape[1]:
+                self.labels.zero_()
+            self.labels[:, :nmax].copy_(labels_host_or_dev)
+        else:
+            # host labels: padded on the host, ONE asynchronous copy from a pinned staging buffer (reused once its copy has completed)
+            if self.pin is None:
+                self.pin = th.zeros(self.labels.shape, dtype=th.float32).pin_memory()
+            elif self.pin_event is not None:
+                self.pin_event.synchronize()
+            if nmax != self.labels.shape[1]:
+                self.pin.zero_()
+            self.pin[:, :nmax].copy_(labels_host_or_dev)
+            self.labels.copy_(self.pin, non_blocking=True)
+            self.pin_event = th.cuda.Event()
+            self.pin_event.record()
+        self.rows.copy_(rows, non_blocking=True)
+        self.is_first.copy_(is_first, non_blocking=True)
+
+    def load_states(self, rnn, worker_id):
+        """The LSTM state of ``worker_id`` into the static state buffers (RNNStates semantics: one state set per loader worker)."""
+        if self.owner is not None and self.owner != worker_id:
+            held = rnn.get_states(self.owner)
+            if held is not None and _flat(held)[0].data_ptr() == _flat(self.states)[0].data_ptr():
+                spill = [(th.empty_like(h), th.empty_like(c)) for h, c in self.states]      # the previous owner keeps its state
+                ops.copy_multi(_flat(spill), _flat(self.states))
+                rnn.save_states_and_detach(self.owner, spill)
+        saved = rnn.get_states(worker_id)
+        if saved is None:
+            for t in _flat(self.states):
+                t.zero_()
+        elif _flat(saved)[0].data_ptr() != _flat(self.states)[0].data_ptr():
+            src, dst = _flat(saved), _flat(self.states)
+            if ops.multi_ok(src) and ops.multi_ok(dst) and all(a.stride() == b.stride() and a.dtype is b.dtype for a, b in zip(src, dst)):
+                ops.copy_multi(dst, src)
+            else:
+                for a, b in zip(dst, src):
+                    a.copy_(b)
+        self.owner = worker_id
+
+    def run_forward(self):
+        if self.arena_high:
+            self.arena[:self.arena_high].zero_()           # BatchNorm statistic accumulators / LayerScale scratch of the captured step
+        self.fwd.launch()
+        for m, inc in self.bn_incs:
+            m.bn_calls_pending += inc
+        self.uses += 1
+
+    def run_backward(self, g: th.Tensor):
+        self.seed.copy_(g.reshape(()), non_blocking=True)
+        self.bwd.launch()
+        ops.PackCache.invalidate()                         # the replayed step re-packed conv weights behind the cache's back
+
+    def close(self):
+        for p in (self.fwd, self.bwd):
+            if p is not None:
+                p.close()
+        self.fwd = self.bwd = None
+
+
+class TrainStepPlans:
+    """Per-module cache {geometry key: StepPlan | 'seen' | 'eager'} with a small LRU bound (each plan owns the activation pool of its
+    step: ~13 GB for RVT-S bs 8 L 21 of the 288 GB)."""
+
+    def __init__(self, max_plans: Optional[int] = None, max_lanes: Optional[int] = None):
+        self.entries: Dict[Any, Any] = {}
+        self.max_plans = int(os.environ.get('LEOD_PLAN_MAX', '4')) if max_plans is None else max_plans
+        self.max_lanes = int(os.environ.get('LEOD_PLAN_LANES', '2')) if max_lanes is None else max_lanes
+        self.anchor = None
+        self.captures = 0
+        self.replays = 0
+
+    @staticmethod
+    def allowed() -> bool:
+        """No plan while the step contains collectives between kernels (SyncBatchNorm over > 1 rank) or a step is being captured."""
+        return not Fn._sync_bn_on() and not th.cuda.is_current_stream_capturing()
+
+    def key_of(self, ev: th.Tensor, n_frames: int, nmax: int):
+        nmax_pad = max(NMAX_PAD, -(-nmax // NMAX_PAD) * NMAX_PAD)
+        return (tuple(ev.shape), ev.dtype, str(ev.device), n_frames, nmax_pad, ops.get_precision()), nmax_pad
+
+    def lookup(self, key):
+        """-> StepPlan to replay | 'capture' (second occurrence) | None (run eagerly)."""
+        e = self.entries.get(key)
+        if isinstance(e, StepPlan):
+            self.entries[key] = self.entries.pop(key)       # most recently used last
+            return e
+        if e is None:
+            self.entries[key] = 'seen'
+            return None
+        if e == 'seen':
+            return 'capture'
+        return None                                           # 'eager': a capture of this geometry failed before
+
+    def build(self, key, module, ev, n_frames, nmax_pad, states_like, wgrad_side) -> Optional[StepPlan]:
+        plans = [k for k, v in self.entries.items() if isinstance(v, StepPlan)]
+        while len(plans) >= self.max_plans:
+            old = plans.pop(0)
+            self.entries.pop(old).close()
+        entry = StepPlan(key, module, ev, n_frames, nmax_pad, states_like)
+        try:
+            entry.capture(module, wgrad_side, self.max_lanes)
+        except (LeodHipError, RuntimeError) as e:
+            warnings.warn(f'leod_amd: the training step of geometry {key} could not be turned into a launch plan ({e}); it stays eager')
+            entry.close()
+            self.entries[key] = 'eager'
+            return None
+        self.entries[key] = entry
+        self.captures += 1
+        return entry
+
+    def clear(self):
+        for v in self.entries.values():
+            if isinstance(v, StepPlan):
+                v.close()
+        self.entries.clear()

@@ -647,6 +647,14 @@ class StatArena:
         cls.active = False
 
     @classmethod
+    def swap(cls, buf, off=0, high=0, active=False):
+        """Install another arena buffer (a captured step keeps a private one: its replays write at the offsets handed out during capture,
+        behind the back of this class's high-water bookkeeping); returns the state to hand back to ``swap`` afterwards."""
+        old = (cls.buf, cls.off, cls.high, cls.active)
+        cls.buf, cls.off, cls.high, cls.active = buf, off, high, active
+        return old
+
+    @classmethod
     def zeros(cls, shape, device, dtype=torch.float64):
         n = 1
         for d in shape:

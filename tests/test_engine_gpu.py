@@ -87,7 +87,7 @@ def test_graph_replay_equals_eager(gpu, manifest):
     T, B = 4, 2
     label_tb = [[], [0], [], [0, 1]]
     res = {}
-    for mode in ('eager', 'graph'):
+    for mode in ('eager', 'graph', 'plan'):
         det, _ = micro_detector(manifest, 9)
         eng = TrainEngine(det, lr=2e-4, total_steps=1000)
         out = []
@@ -98,15 +98,17 @@ def test_graph_replay_equals_eager(gpu, manifest):
             labels[:, :ll.shape[1]] = ll
             labels = labels.to(DEV)
             is_first = torch.tensor([step == 0, True], device=DEV)
-            if mode == 'graph':
-                if step == 0:
-                    eng.capture(ev, labels, label_tb, is_first)
+            if mode in ('graph', 'plan'):
+                if step == 0:                                 # 'plan': the same capture replayed by a launch plan (csrc/k_plan.hip), side stream included
+                    eng.capture(ev, labels, label_tb, is_first, plan=(mode == 'plan'))
                 losses = eng.step_graph(ev, labels, is_first)
             else:
                 losses = eng.step(ev, labels, label_tb, is_first)
             out.append([float(losses[k]) for k in KEYS])
         res[mode] = (np.array(out), eng.flat.data.clone().cpu(), [c.clone().cpu() for _, c in eng.states])
     np.testing.assert_allclose(res['graph'][0], res['eager'][0], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(res['plan'][0], res['eager'][0], rtol=1e-4, atol=1e-5)
+    assert float(np.abs(res['plan'][1].numpy() - res['eager'][1].numpy()).max()) < 3.5e-4
     # parameters: Adam turns noise-level gradients (fp32 atomics accumulate in a different order on every run) into
     # +-lr steps, so a handful of elements may differ by up to 2*sum(lr) = 3.4e-4; everything else must agree tightly
     pg, pe = res['graph'][1].numpy(), res['eager'][1].numpy()

@@ -355,6 +355,53 @@ def test_module_two_training_steps_match_reference_golden(gpu, golden_dir, manif
     assert opt.flat.step_count == 2 and float(opt.flat.exp_avg.abs().sum()) > 0
 
 
+def test_module_plan_replay_equals_eager(gpu, manifest):
+    """Launch plans through the product path (modules/step_plan.py): six optimisation steps of one geometry driven by ``fit_step`` --
+    eager (``plan_mode = False``) vs plan mode (step 0 eager, step 1 captured and replayed, steps 2-5 replayed) on identical batches,
+    with a partial LSTM reset every step, two loader workers taking turns (their states must not alias) and a label count that changes
+    inside the padded width.  Losses per step, parameters, optimiser moments and carried states must agree as tightly as two eager
+    runs do (fp32 atomics reorder noise-level gradients)."""
+    from leod_amd.modules.utils.detection import Mode, WORKER_ID_KEY
+    from leod_amd.optim import fit_step
+    L, B = 4, 2
+    keys6 = ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')
+    res = {}
+    for plan in (False, True):
+        mod, _, cfg = micro_module(manifest, 9, 'fit')
+        cfg.training.lr_scheduler.total_steps = 1000
+        mod.train()
+        mod.plan_mode = plan
+        oc = mod.configure_optimizers()
+        opt, sched = oc['optimizer'], oc['lr_scheduler']['scheduler']
+        out_l = []
+        for step in range(6):
+            ev = synth_events(L, B, 20, HW[0], HW[1], seed=90 + step, as_uint8=True)
+            flat = micro_labels(3, 95 + step, [1e6, 2e6, 2e6])
+            if step % 2:
+                flat[1] = flat[1][:1]                     # fewer boxes on one frame: same padded label width
+            labels_tb = [[None, None], [flat[0], None], [None, None], [flat[1], flat[2]]]
+            is_first = torch.tensor([step < 2, step % 3 == 0])
+            batch = loader_batch(ev, labels_tb, is_first)
+            batch[WORKER_ID_KEY] = step % 2               # two streaming workers, each with its own LSTM state
+            out = fit_step(mod, opt, sched, batch, step)
+            out_l.append([float(out['log_dict'][f'train/{k}'].detach()) for k in keys6])
+        st = mod.mode_2_rnn_states[Mode.TRAIN]
+        res[plan] = (np.array(out_l), opt.flat.data.detach().cpu().numpy().copy(), opt.flat.exp_avg.detach().cpu().numpy().copy(),
+                     [[c.detach().cpu().numpy().copy() for _, c in st.get_states(w)] for w in (0, 1)])
+        if plan:
+            assert mod._plans.captures == 1 and mod._plans.replays == 5, (mod._plans.captures, mod._plans.replays, mod._plans.entries)
+            info = [e for e in mod._plans.entries.values() if not isinstance(e, str)][0]
+            assert info.fwd.info['kernels'] > 50 and info.bwd.info['kernels'] > 50 and info.fwd.info['memcpys'] == 0
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=2e-4, atol=1e-5)
+    pg, pe = res[True][1], res[False][1]
+    diff = np.abs(pg - pe)
+    assert diff.max() < 2.5e-3                            # <= 2 * sum(lr) over six steps (lr <= 2e-4) for a sign flip of a noise-level gradient
+    assert (diff > 2e-6 + 1e-4 * np.abs(pe)).mean() < 5e-3
+    for w in (0, 1):
+        for a, b in zip(res[True][3][w], res[False][3][w]):
+            np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4)
+
+
 def _module_world2_worker(rank, port, manifest, q):
     import os
     import torch.distributed as dist
