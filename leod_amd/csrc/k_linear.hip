@@ -637,11 +637,26 @@ LEOD_API int leod_set_workspace(void* ws, long bytes, hipStream_t stream) {
     return LEOD_OK;
 }
 
+// Profiling aid (LEOD_FAMILY_MARKERS=1, used by the PMC passes of tools/pmc_bench_traffic.sh only): one-thread marker kernels in front of
+// and behind every launch of the roofline family, so that tools/roofline_traffic.py sums the HBM counters of exactly the dispatches the
+// event probe of bench.py brackets (the kernel names alone do not separate the Linear weight gradients from the 1x1-conv ones).
+__global__ void leod_family_marker_kernel(int begin) { (void)begin; }
+struct FamilyMarker {
+    hipStream_t s; bool on;
+    explicit FamilyMarker(hipStream_t st) : s(st) {
+        static const bool env = getenv("LEOD_FAMILY_MARKERS") && atoi(getenv("LEOD_FAMILY_MARKERS"));
+        on = env;
+        if (on) hipLaunchKernelGGL(leod_family_marker_kernel, dim3(1), dim3(1), 0, s, 1);
+    }
+    ~FamilyMarker() { if (on) hipLaunchKernelGGL(leod_family_marker_kernel, dim3(1), dim3(1), 0, s, 0); }
+};
+
 // dW[N,K] += dy[M,N]^T @ X[M,K] ; dbias[N] += colsum(dy)  with X = x, LN(x) (stats + ln_w/ln_b) or [x | x2]
 LEOD_API int leod_linear_wgrad(const float* dy, long lddy, const float* x, long ldx, const float* stats,
                                const float* ln_w, const float* ln_b, const float* x2, long ldx2, int K1,
                                float* dW, float* dbias, int M, int N, int K, int dy_bf16, hipStream_t stream) {
     if (!dy || !x || !dW) return LEOD_ERR_ARG;
+    FamilyMarker fm(stream);
     XRows xl{x, ldx, stats, ln_w, ln_b, x2, ldx2, K1};
     const int df = (dy_bf16 & 1) ? 1 : 0;
     if (dy_bf16 & 2) {                              // bit 1: x holds bf16 rows -- the wide kernel only
@@ -847,6 +862,7 @@ LEOD_API int leod_linear_dgrad_gelu16(const float* dy, const float* kscale, cons
 LEOD_API int leod_linear_wgrad_gelu16(const float* dy, long lddy, const void* u16, float* dW, float* dbias, int M, int N, int K,
                                       hipStream_t stream) {
     if (!dy || !u16 || !dW) return LEOD_ERR_ARG;
+    FamilyMarker fm(stream);
     XRows xl{reinterpret_cast<const float*>(u16), (long)K, nullptr, nullptr, nullptr, nullptr, 0, 0, 1};
     if (use_wgrad_wide(xl, lddy, M, N, K, 0)) return launch_wgrad_wide(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, 0);
     if (use_wgradw(M)) return launch_wgradw(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);

@@ -128,7 +128,7 @@ class RandomLoader(_PrefetchLoader):
     """Shuffled (or class-weighted) batches of independent samples; ``drop_last`` as in the reference's training loader."""
 
     def __init__(self, dataset: CustomConcatDataset, batch_size: int, sampler=None, pin_memory: bool = True, prefetch: int = 3,
-                 io_threads: int = 8, num_workers: int = 1, rank: int = 0, world_size: int = 1, seed: int = 0):
+                 io_threads: int = 8, num_workers: int = 1, rank: int = 0, world_size: int = 1, seed: int = 0, epoch: int = 0):
         super().__init__(prefetch)
         self.dataset, self.batch_size, self.sampler = dataset, batch_size, sampler
         seq = dataset.datasets[0].sequence
@@ -136,7 +136,9 @@ class RandomLoader(_PrefetchLoader):
         self.num_workers = max(1, num_workers)
         # N > 1 ranks: ONE order per epoch shared by all ranks (generator seeded seed + epoch, the same on every rank), rank r
         # takes order[r::world] -- what DistributedSampler / DistributedSamplerWrapper do for the reference under Lightning DDP
-        self.rank, self.world_size, self.seed, self.epoch = rank, max(1, world_size), seed, 0
+        # ``epoch``: where the shuffle sequence starts -- a loader that is re-created every epoch (a forked ProcessLoader worker, or a
+        # trainer that calls train_dataloader() per epoch) is handed the count kept by its creator, a persistent one counts itself
+        self.rank, self.world_size, self.seed, self.epoch = rank, max(1, world_size), seed, int(epoch)
 
     def _per_rank(self) -> int:
         return -(-len(self.dataset) // self.world_size)
@@ -240,6 +242,7 @@ class DataModule:
         self.rank, self.world_size = dist_rank_world(rank, world_size)
         self._seed_shared: Optional[int] = None
         self._rank_seeded = False
+        self._train_loaders_made = 0           # in-process train loaders created so far (their shuffle epoch, see RandomLoader)
         self.sampling_mode_2_dataset: Dict[Any, Any] = {}
         self.sampling_mode_2_train_workers: Dict[Any, int] = {}
         self.sampling_mode_2_train_batch_size: Dict[Any, int] = {}
@@ -291,7 +294,7 @@ class DataModule:
         else:
             raise NotImplementedError(stage)
 
-    def _in_process(self, build, batch_size: int):
+    def _in_process(self, build, batch_size: int, takes_epoch: bool = False):
         """``build(**loader_kw)`` as it is, or behind a ``ProcessLoader`` (the worker's loaders then keep one batch of
         look-ahead of their own: the ring is the prefetch queue)."""
         if not self.worker_process:
@@ -301,7 +304,8 @@ class DataModule:
         hw = self.get_dataloading_hw()
         L = self.dataset_config.sequence_length
         slot = L * batch_size * 20 * hw[0] * hw[1]
-        return ProcessLoader(lambda: build(**kw), slot_bytes=slot, n_slots=self.ring_slots, device=self.device, rank=self.rank)
+        fn = (lambda epoch=0: build(epoch=epoch, **kw)) if takes_epoch else (lambda: build(**kw))
+        return ProcessLoader(fn, slot_bytes=slot, n_slots=self.ring_slots, device=self.device, rank=self.rank)
 
     def train_dataloader(self):
         B = max(self.sampling_mode_2_train_batch_size.values())
@@ -310,11 +314,22 @@ class DataModule:
                 self._seed_shared = shared_seed(self.world_size)
             if not self.worker_process and not self._rank_seeded:
                 from leod_amd.modules.data.process_loader import draw_base_seed, seed_worker
-                seed_worker(draw_base_seed(), self.rank)
+                # NOTE: this reseeds the PROCESS-GLOBAL torch / numpy / random generators of the training process (once): the in-process
+                # loaders draw shuffles and augmentations from them and the ranks must not draw the same.  A seed_everything() done
+                # before is superseded from here on -- said out loud, not silently; worker_process=True keeps the
+                # training process's generators untouched.
+                import warnings
+                base = draw_base_seed()
+                warnings.warn(f'leod_amd DataModule: reseeding the global RNGs of rank {self.rank} with {base} + rank for the in-process '
+                              'training loaders (use worker_process=True to leave the training process\'s generators alone)')
+                seed_worker(base, self.rank)
                 self._rank_seeded = True
-        return self._in_process(self._train_loaders, B)
+        if self.worker_process:
+            return self._in_process(self._train_loaders, B, takes_epoch=True)        # the ProcessLoader counts its epochs and hands them to the worker
+        epoch, self._train_loaders_made = self._train_loaders_made, self._train_loaders_made + 1
+        return self._train_loaders(epoch=epoch, **self.loader_kw)
 
-    def _train_loaders(self, **loader_kw):
+    def _train_loaders(self, epoch: int = 0, **loader_kw):
         loaders = {}
         for mode, dataset in self.sampling_mode_2_dataset.items():
             workers, bs = self.sampling_mode_2_train_workers[mode], self.sampling_mode_2_train_batch_size[mode]
@@ -323,7 +338,7 @@ class DataModule:
             else:
                 sampler = get_weighted_random_sampler(dataset) if self.dataset_config.train.random.weighted_sampling else None
                 loaders[mode] = RandomLoader(dataset, batch_size=bs, sampler=sampler, num_workers=workers, rank=self.rank,
-                                             world_size=self.world_size, seed=self._seed_shared or 0, **loader_kw)
+                                             world_size=self.world_size, seed=self._seed_shared or 0, epoch=epoch, **loader_kw)
         return next(iter(loaders.values())) if len(loaders) == 1 else MixedLoader(loaders)
 
     def _eval_loader(self, dataset):

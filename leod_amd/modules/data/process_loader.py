@@ -162,7 +162,18 @@ def seed_worker(base_seed: int, rank: int = 0) -> int:
     return seed
 
 
-def _worker(loader_fn: Callable[[], Iterable], ring: _Ring, results, free_slots, base_seed: int = 0, rank: int = 0):
+def _call_loader_fn(loader_fn, epoch: int):
+    """``loader_fn(epoch=e)`` when it takes the epoch (the worker is a fresh fork every epoch, so the loaders it builds cannot count
+    epochs themselves: without the parent's counter a RandomLoader would shuffle with seed + 0 every epoch), else ``loader_fn()``."""
+    import inspect
+    try:
+        takes = 'epoch' in inspect.signature(loader_fn).parameters
+    except (TypeError, ValueError):
+        takes = False
+    return loader_fn(epoch=epoch) if takes else loader_fn()
+
+
+def _worker(loader_fn: Callable[[], Iterable], ring: _Ring, results, free_slots, base_seed: int = 0, rank: int = 0, epoch: int = 0):
     try:
         torch.set_num_threads(1)                                  # a forked child must not enter the parent's OpenMP pool
         # a forked child inherits the parent's RNG state unchanged: without a fresh seed every epoch replays the same shuffles and
@@ -178,7 +189,7 @@ def _worker(loader_fn: Callable[[], Iterable], ring: _Ring, results, free_slots,
             return ring.view(slot, shape)
 
         BatchAssembler.buffer_source = staticmethod(acquire)
-        for batch in loader_fn():
+        for batch in _call_loader_fn(loader_fn, epoch):
             results.put((_BATCH, _Packer(ring).payload(batch)))
         results.put((_END, None))
     except BaseException:                                         # surface loader errors in the consumer
@@ -202,6 +213,7 @@ class ProcessLoader:
         self.ring: Optional[_Ring] = None
         self.registered = False
         self.copy_stream = None
+        self.epoch = 0                                            # iterations started so far: handed to loader_fn(epoch=...) in the worker
 
     # -- shared ring, pinned once per loader -------------------------------------------------------------------------------------------
     def _ensure_ring(self):
@@ -231,7 +243,8 @@ class ProcessLoader:
         # one draw from the parent's generator per epoch (as torch's DataLoader does): it advances the parent state, so consecutive
         # epochs get different worker seeds, and a seeded parent gives a reproducible sequence of epochs
         base_seed = draw_base_seed()
-        proc = ctx.Process(target=_worker, args=(self.loader_fn, self.ring, results, free_slots, base_seed, self.rank), daemon=True,
+        epoch, self.epoch = self.epoch, self.epoch + 1
+        proc = ctx.Process(target=_worker, args=(self.loader_fn, self.ring, results, free_slots, base_seed, self.rank, epoch), daemon=True,
                            name='leod-loader-proc')
         proc.start()
         pending: 'collections.deque' = collections.deque()       # (event | None, slots) waiting to go back to the worker

@@ -10,7 +10,9 @@
   buffer is laid out in that module order, so each of the five buckets is ONE contiguous slice: it is all-reduced on a
   communication stream the moment its boundary node fires in the backward pass (``functions.BucketBoundaryFn``), under
   the rest of the backward pass; the optimiser waits for the five handles.  ``LEOD_DP_BUCKETS=0`` falls back to one
-  flat all-reduce after the backward pass; ``LEOD_DP_WIRE=bf16`` sends bf16 (half the bytes; fp32 sum on arrival).
+  flat all-reduce after the backward pass (needed for gradient accumulation: the buckets assume ONE backward pass per optimiser
+  step); ``LEOD_DP_WIRE=bf16`` all-reduces a bf16 copy of each bucket -- half the bytes, but the cross-rank sum itself is then carried
+  out and rounded in bf16 at every ring step (log2(world) bits of the gradient sum are lost; off by default).
 * SyncBatchNorm statistics go through ``functions.set_sync_batchnorm`` (reference: train.py:247).
 * Pseudo-labelling shards whole recordings over ranks with no collective on the data path
   (``shard_sequences``; reference: data/utils/stream_sharded_datapipe.py:40-57,88-105).
@@ -102,6 +104,7 @@ class DataParallel:
     def broadcast_parameters(self, src=0):
         if self.world_size > 1 or self.force:
             dist.broadcast(self.flat.data, src=src, group=self.group)
+            self.flat.touch()                                  # parameter memory was rewritten behind the parameters' backs: drop packed copies
 
     def make_buckets(self, module: torch.nn.Module) -> Optional['GradBuckets']:
         """Per-stage buckets for ``module`` (None: one rank, or LEOD_DP_BUCKETS=0 -> flat all-reduce after the backward pass)."""
@@ -161,8 +164,14 @@ class GradBuckets:
         self.works, self.done, self.order = [], set(), []
         GradBuckets.current = self
 
-    def ready(self, k: int):
-        """Bucket k is final on the launch stream and on the weight-gradient side stream(s): all-reduce it on the comm stream."""
+    def ready(self, k: int, closing: bool = False):
+        """Bucket k is final on the launch stream and on the weight-gradient side stream(s): all-reduce it on the comm stream.
+        One backward pass per optimiser step: a boundary that fires a second time (gradient accumulation, two losses) would add local
+        gradients to a slice that is already summed over ranks or still in flight -- refused loudly (use LEOD_DP_BUCKETS=0 there)."""
+        if k in self.done and not closing and self.ranges[k] is not None:
+            GradBuckets.current = None
+            raise RuntimeError('GradBuckets: a second backward pass reached the boundary of gradient bucket %d before the optimiser step; '
+                               'gradient accumulation needs the flat exchange (LEOD_DP_BUCKETS=0)' % k)
         if k in self.done or self.ranges[k] is None:
             self.done.add(k)
             return
@@ -186,20 +195,22 @@ class GradBuckets:
 
     def finish(self):
         """Release what no boundary released (stage 1), then make the launch stream wait for every exchange."""
-        for k in reversed(range(len(self.ranges))):
-            self.ready(k)
-        for work, wire, g in self.works:
-            if self.comm is not None:
-                with torch.cuda.stream(self.comm):
+        try:
+            for k in reversed(range(len(self.ranges))):
+                self.ready(k, closing=True)
+            for work, wire, g in self.works:
+                if self.comm is not None:
+                    with torch.cuda.stream(self.comm):
+                        work.wait()
+                        if wire is not None:
+                            g.copy_(wire)
+                else:
                     work.wait()
-                    if wire is not None:
-                        g.copy_(wire)
-            else:
-                work.wait()
-        if self.comm is not None:
-            torch.cuda.current_stream().wait_stream(self.comm)
-        self.works = []
-        GradBuckets.current = None
+            if self.comm is not None:
+                torch.cuda.current_stream().wait_stream(self.comm)
+        finally:
+            self.works = []
+            GradBuckets.current = None                          # never left set behind a step that raised
 
 
 def init_distributed(backend: Optional[str] = None):

@@ -358,3 +358,33 @@ def test_bound_host_threads_respects_quota_and_env(monkeypatch):
         assert host.bound_host_threads() == 2                                     # idempotent without force
     finally:
         torch.set_num_threads(before)
+
+
+def test_grad_buckets_refuse_a_second_backward(monkeypatch):
+    """the bucketed exchange assumes one backward pass per optimiser step; a boundary that fires again (gradient accumulation)
+    must raise instead of adding local gradients into an already-reduced slice, and ``GradBuckets.current`` must not stay set."""
+    import torch.distributed as dist
+    from leod_amd import parallel as P
+
+    class Work:
+        def wait(self):
+            return True
+    monkeypatch.setattr(dist, 'all_reduce', lambda t, group=None, async_op=False: Work())
+    net = torch.nn.Module()
+    net.backbone = torch.nn.Module()
+    net.backbone.stages = torch.nn.ModuleList([torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)])
+    net.head = torch.nn.Linear(4, 2)
+    flat = P.FlatParams(net)
+
+    class DP:
+        group = None
+    b = P.GradBuckets(flat, net, DP())
+    b.begin_step()
+    b.ready(1)
+    with pytest.raises(RuntimeError, match='second backward'):
+        b.ready(1)
+    assert P.GradBuckets.current is None
+    b.begin_step()
+    b.ready(0)
+    b.finish()                                            # closes the remaining buckets without complaint
+    assert P.GradBuckets.current is None and b.works == []

@@ -540,3 +540,37 @@ def test_random_loader_is_deterministic_with_a_thread_pool_and_frame_stores_are_
         assert 1 <= len(misc.FRAME_STORES) <= 2
     finally:
         misc.FRAME_STORES = old
+
+
+def test_random_loader_epoch_survives_recreation():
+    """under N > 1 ranks the shuffle of epoch e is seeded seed + e, but a loader that is re-created every epoch (the
+    forked worker of ProcessLoader builds its loaders anew per epoch; a trainer may call train_dataloader() per epoch) started at
+    epoch 0 each time -- every epoch replayed one permutation.  The creator now hands the epoch in."""
+    import inspect
+    from leod_amd.modules.data import genx as G
+    from leod_amd.modules.data import process_loader as PL
+
+    class DS:                                            # the two attributes RandomLoader.__init__ / _order touch
+        class _S:
+            class sequence:
+                seq_len, frame_shape = 2, (20, 4, 4)
+        datasets = [_S]
+        def __len__(self):
+            return 64
+
+    def order(epoch, recreate):
+        ld = G.RandomLoader(DS(), batch_size=4, rank=1, world_size=2, seed=5, epoch=epoch if recreate else 0, pin_memory=False)
+        if not recreate:
+            for _ in range(epoch):
+                ld._order()
+        return ld._order()
+    e0, e1, e2 = order(0, True), order(1, True), order(2, True)
+    assert e0 != e1 != e2 and e0 != e2                   # a re-created loader no longer replays epoch 0
+    assert e1 == order(1, False) and e2 == order(2, False)      # and matches what a persistent loader does in that epoch
+    # the plumbing: ProcessLoader counts its iterations and its worker passes the count to loader_fn(epoch=...)
+    seen = []
+    assert PL._call_loader_fn(lambda epoch=0: seen.append(epoch) or [], 3) == [] and seen == [3]
+    assert PL._call_loader_fn(lambda: ['x'], 7) == ['x']
+    assert 'epoch' in inspect.signature(G.DataModule._train_loaders).parameters
+    src = inspect.getsource(PL.ProcessLoader.__iter__)
+    assert 'self.epoch + 1' in src and 'epoch)' in src

@@ -1,48 +1,59 @@
 #!/usr/bin/env python
-"""HBM traffic of the roofline kernel from two rocprofv3 --pmc passes over bench.py (FETCH_SIZE and WRITE_SIZE are
-collected in separate runs, MI355X_MICROARCH.md).  Corrections applied as that guide prescribes for gfx950:
-counters are in KiB; FETCH_SIZE of wide coalesced reads reports half the bytes -> x2.
-usage: roofline_traffic.py <fetch.db|dir> <write.db|dir> <kernel-regex> <out.json> <out.csv> [launch-regex]
-The bytes of every dispatch matching kernel-regex are summed; they are divided by the dispatches matching launch-regex (default: the
-same) -- a weight-gradient "launch" of precision mode bf16 is wgrad_wide_bf16_kernel plus its wgrad_wide_reduce_kernel."""
-import csv, glob, json, os, re, sqlite3, sys
+"""HBM traffic of the roofline kernel FAMILY from two rocprofv3 --pmc passes over bench.py (FETCH_SIZE and WRITE_SIZE are collected in
+separate runs, MI355X_MICROARCH.md).  Corrections applied as that guide prescribes for gfx950: counters are in KiB; FETCH_SIZE of wide
+coalesced reads reports half the bytes -> x2.
+
+The family is delimited by marker dispatches (LEOD_FAMILY_MARKERS=1: the library launches ``leod_family_marker_kernel`` in front of and
+behind every ``leod_linear_wgrad`` / ``leod_linear_wgrad_gelu16`` call; single-stream eager run, so dispatch order = program order): the
+bytes of every dispatch between a begin and an end marker are summed and divided by the number of marker pairs -- the same launches the
+HIP-event probe of bench.py brackets (36 per training step), whatever kernels they resolve to (round 3 divided the bytes of the name
+pattern wgrad_wide|wgradw by 102 launches of which 30 were 1x1-conv weight gradients: 208 MB reported, 284 MB true).
+usage: roofline_traffic.py <fetch.db|dir> <write.db|dir> <out.json> <out.csv>"""
+import collections, csv, glob, json, os, re, sqlite3, sys
+
+MARK = 'leod_family_marker_kernel'
 
 
-def load(src, counter, sub):
+def load(src, counter):
+    """-> (bytes-per-kernel-name dict of lists, number of marker pairs) for the dispatches inside marker pairs"""
     if os.path.isdir(src):
         src = sorted(glob.glob(os.path.join(src, '**', '*.db'), recursive=True))[0]
     con = sqlite3.connect(src)
-    rows = {}
-    for name, disp, val in con.execute('select kernel_name, dispatch_id, sum(value) from counters_collection '
-                                       'where counter_name = ? group by kernel_name, dispatch_id', (counter,)):
-        name = re.sub(r'\(.*$', '', name).replace('void ', '')
-        if re.search(sub, name):
-            rows.setdefault(name, []).append(val)
-    return rows
+    rows = list(con.execute('select dispatch_id, kernel_name, sum(value) from counters_collection where counter_name = ? '
+                            'group by dispatch_id, kernel_name order by dispatch_id', (counter,)))
+    inside, pairs = False, 0
+    per = collections.defaultdict(list)
+    for _, name, val in rows:
+        short = re.sub(r'\(.*$', '', name).replace('void ', '')
+        if MARK in short:
+            if inside:
+                pairs += 1
+            inside = not inside
+            continue
+        if inside:
+            per[short].append(val)
+    return per, pairs
 
 
-def main(fdb, wdb, sub, out_json, out_csv, launch_sub=None):
-    f, w = load(fdb, 'FETCH_SIZE', sub), load(wdb, 'WRITE_SIZE', sub)
-    launch_sub = launch_sub or sub
-    tot_f = tot_w = n_f = n_w = 0
+def main(fdb, wdb, out_json, out_csv):
+    f, nf = load(fdb, 'FETCH_SIZE')
+    w, nw = load(wdb, 'WRITE_SIZE')
+    tot_f = sum(sum(v) for v in f.values())
+    tot_w = sum(sum(v) for v in w.values())
     with open(out_csv, 'w', newline='') as fh:
         wr = csv.writer(fh)
-        wr.writerow(['# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) over bench.py; KiB as reported'])
-        wr.writerow(['kernel', 'dispatches', 'FETCH_SIZE_KiB_sum', 'WRITE_SIZE_KiB_sum', 'read_bytes_per_launch(x2 corrected)', 'write_bytes_per_launch'])
+        wr.writerow(['# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate runs) over bench.py; KiB as reported; dispatches inside '
+                     f'family markers only: {nf} / {nw} leod_linear_wgrad* calls'])
+        wr.writerow(['kernel', 'dispatches', 'FETCH_SIZE_KiB_sum', 'WRITE_SIZE_KiB_sum'])
         for name in sorted(set(f) | set(w)):
-            fv, wv = f.get(name, []), w.get(name, [])
-            tot_f += sum(fv); tot_w += sum(wv)
-            if re.search(launch_sub, name):
-                n_f += len(fv); n_w += len(wv)
-            wr.writerow([name, len(fv), f'{sum(fv):.1f}', f'{sum(wv):.1f}',
-                         f'{2 * 1024 * sum(fv) / max(len(fv), 1):.0f}', f'{1024 * sum(wv) / max(len(wv), 1):.0f}'])
-    rd = 2 * 1024 * tot_f / max(n_f, 1)
-    wt = 1024 * tot_w / max(n_w, 1)
-    json.dump({'kernel': sub, 'launches_sampled': [n_f, n_w], 'hbm_bytes_per_launch': round(rd + wt),
-               'read_bytes_per_launch': round(rd), 'write_bytes_per_launch': round(wt), 'source': os.path.relpath(out_csv)},
-              open(out_json, 'w'), indent=1)
+            wr.writerow([name, len(f.get(name, [])), f'{sum(f.get(name, [])):.1f}', f'{sum(w.get(name, [])):.1f}'])
+    rd = 2 * 1024 * tot_f / max(nf, 1)
+    wt = 1024 * tot_w / max(nw, 1)
+    json.dump({'kernel': 'every dispatch inside leod_linear_wgrad / leod_linear_wgrad_gelu16 (family markers)', 'launches_sampled': [nf, nw],
+               'hbm_bytes_per_launch': round(rd + wt), 'read_bytes_per_launch': round(rd), 'write_bytes_per_launch': round(wt),
+               'source': os.path.relpath(out_csv)}, open(out_json, 'w'), indent=1)
     print(open(out_json).read())
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:7])
+    main(*sys.argv[1:5])
