@@ -16,12 +16,46 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libleod_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'leod_hip.h')
 
+class LeodHipError(RuntimeError):
+    pass
+
+
 _CTYPE = {'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float, 'double': ctypes.c_double,
           'leod_stream_t': ctypes.c_void_p}
 
 
-class LeodHipError(RuntimeError):
-    pass
+class DevPtr:
+    """A device address that remembers the element type of the tensor it came from (``ops._p``): the typed pointer parameters below
+    check it, so that a swapped argument (an int32 index buffer where float rows are expected, a float64 statistics block for a
+    float one) is refused at the boundary instead of being read as garbage on the device."""
+    __slots__ = ('addr', 'kind')
+
+    def __init__(self, addr: int, kind: str):
+        self.addr, self.kind = addr, kind
+
+
+# element kinds a declared C pointer type accepts.  ``float*`` parameters also carry the 16-bit rows of precision mode bf16 (the
+# header documents which, e.g. dy_bf16 / qkv_bf16 flags); ``void*`` takes anything.
+_ACCEPTS = {'float': ('f32', 'bf16', 'f16'), 'double': ('f64',), 'int': ('i32',), 'long': ('i64',),
+            'unsigned char': ('u8', 'bool'), 'void': None, 'char': None}
+
+
+def _pointer_type(elem: str):
+    accepts = _ACCEPTS.get(elem)
+
+    class _Ptr(ctypes.c_void_p):
+        @classmethod
+        def from_param(cls, v):
+            if isinstance(v, DevPtr):
+                if accepts is not None and v.kind not in accepts:
+                    raise LeodHipError(f'pointer to {v.kind} elements passed where the C ABI declares {elem}*')
+                return ctypes.c_void_p(v.addr)
+            return ctypes.c_void_p.from_param(v)                 # None, raw addresses (int), ctypes arrays / pointers
+    _Ptr.__name__ = 'Ptr_' + elem.replace(' ', '_')
+    return _Ptr
+
+
+_PTR = {}
 
 
 def parse_header(path=HEADER_PATH):
@@ -36,7 +70,12 @@ def parse_header(path=HEADER_PATH):
             for a in args.split(','):
                 a = a.strip()
                 if '*' in a:
-                    argtypes.append(ctypes.c_void_p)
+                    # declared element type: `const float* x`, `unsigned char* mask`, `void* const* tensors` (pointer tables: void)
+                    elem = re.sub(r'\bconst\b', ' ', a.split('*')[0]).strip()
+                    elem = elem if a.count('*') == 1 and elem in _ACCEPTS else 'void'
+                    if elem not in _PTR:
+                        _PTR[elem] = _pointer_type(elem)
+                    argtypes.append(_PTR[elem])
                 else:
                     ty = a.replace('const', '').split()[0]
                     argtypes.append(_CTYPE[ty])

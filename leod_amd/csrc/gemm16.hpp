@@ -1175,12 +1175,12 @@ static inline int launch_gemm_lds_rw(const AL& al, const BL& bl, const EP& ep, i
     dim3 grid(cdiv(cdiv(M, 64 * RW), 8) * 8 * nblocks_n);
     // single LDS buffer + register prefetch everywhere: residency (3-6 workgroups per CU) hides the two barriers per chunk
     // better than a double buffer at 2-3 workgroups per CU does (measured; LEOD_LDS_NBUF=2 selects the double buffer)
-    static const int nbuf = getenv("LEOD_LDS_NBUF") ? atoi(getenv("LEOD_LDS_NBUF")) : 1;
+    static const int nbuf = 1;
     (void)nbuf;                                      // the double-buffered variant is no longer instantiated (never faster, see above)
     const bool bf = leod_precision() == 1;
     // bf16 mode: the MFMAs of a chunk are ~8x cheaper, what remains per chunk is the fetch -> barrier -> stash -> barrier skeleton:
     // 96-wide chunks (26 KB of bf16 tiles per workgroup) halve the number of rounds of the long contractions (K = 192 .. 1536)
-    static const int kch96 = getenv("LEOD_KCH96") ? atoi(getenv("LEOD_KCH96")) : 0;      // measured: 38.2 vs 34.2 ms per step with 96-wide chunks on -> off
+    static const int kch96 = 0;      // measured: 38.2 vs 34.2 ms per step with 96-wide chunks on -> off
     if (bf && kch96 && K % 96 == 0 && K >= 192) {
         hipLaunchKernelGGL((gemm_lds_kernel<NT, 96, 1, RW, true, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
         return leod_launch_status();
@@ -1204,7 +1204,7 @@ static inline int launch_gemm_lds(const AL& al, const BL& bl, const EP& ep, int 
 // plain-row A operands: the hot mode combinations of the wide GEMMs (NT >= 3) run on the two-phase loader ALRowsM
 template <int NT, class BL, class EP>
 static inline int launch_gemm_lds(const ALRows& al, const BL& bl, const EP& ep, int M, int K, int nblocks_n, hipStream_t s) {
-    static const int two_phase = getenv("LEOD_GEMM_TWO_PHASE") ? atoi(getenv("LEOD_GEMM_TWO_PHASE")) : 1;
+    static const int two_phase = 1;
     // precision mode bf16, Linear forward / dgrad with >= 144 output columns: the 128 x 192 / 256 wide-tile kernel (gemm_bf16.hpp)
     if constexpr ((std::is_same<BL, BLRows>::value || std::is_same<BL, BLTrans>::value) &&
                   (std::is_same<EP, EpStore>::value || std::is_same<EP, EpLsRes>::value)) {
@@ -1827,8 +1827,8 @@ static inline int launch_wgradw_cfg(const float* dy, long lddy, const XL& xl, fl
                                     int M, int N, int K, hipStream_t s, int dyfmt = 0) {
     const int tiles = cdiv(N, TN * 16) * cdiv(K, TK * 16);
     static const int tune_blocks = getenv("LEOD_WGRADW_BLOCKS") ? atoi(getenv("LEOD_WGRADW_BLOCKS")) : 1024;   // 4 workgroups per CU resident
-    static const int tune_ng = getenv("LEOD_WGRADW_NG") ? atoi(getenv("LEOD_WGRADW_NG")) : 2;               // row groups per workgroup
-    static const int tune_align = getenv("LEOD_WGRADW_ALIGN8") ? atoi(getenv("LEOD_WGRADW_ALIGN8")) : 1;
+    static const int tune_ng = 2;               // row groups per workgroup
+    static const int tune_align = 1;
     const int chunks = cdiv(M, RC);
     auto go = [&](auto bfc, auto dyfc, auto xmc, auto ngc) {
         constexpr bool BFV = decltype(bfc)::value;
@@ -1878,7 +1878,7 @@ static inline int launch_wgradw(const float* dy, long lddy, const XL& xl, float*
     // 32-row chunks (half the barriers, twice the bytes in flight per round) pay for the short row ranges of stages 3-4 with plain or
     // fp16 X rows: 72 -> 63 us (fc2, stage 4), 118 -> 94 us (LSTM); the LayerNorm variant spills at 128 VGPRs and the long ranges of
     // stage 2 are indifferent or slower
-    static const int rc32_on = getenv("LEOD_WGRADW_RC32") ? atoi(getenv("LEOD_WGRADW_RC32")) : 1;
+    static const int rc32_on = 1;
     bool rc32 = false;
     if constexpr (x_two_phase<XL>::value) rc32 = rc32_on && M <= 65536 && xl.x_mode() != 1 && leod_precision() == 1;
     if (K <= 48) return launch_wgradw_cfg<12, 3, 3, 3, 16>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s, dyfmt);

@@ -1062,7 +1062,7 @@ static int dispatch_attn(int which, const float* qkv, const float* dout, float* 
     const float scale = 1.0f / sqrtf((float)g.d);
     static const int use_lds = getenv("LEOD_ATTN_LDS") ? atoi(getenv("LEOD_ATTN_LDS")) : 1;
     const int HG = (g.heads % 2 == 0 && 2 * PT <= 16) ? 2 : 1;
-    static const int force_pad1 = getenv("LEOD_ATTN_LDS_PAD1") ? atoi(getenv("LEOD_ATTN_LDS_PAD1")) : 1;
+    static const int force_pad1 = 1;
     // (LEOD_ATTN_LDS_PAD1=0 restores the round-1 routing of one-head workgroups with padded partitions to the register-direct
     // backward; the defect behind it was a mis-merged ds_write2_b32 in the <4, 32, 1> instantiation, see the kernel's epilogue)
     const bool lds_shape = (g.d == 24 || g.d == 32) && (PT <= 5 || PT == 8 || (HG == 1 && (PT == 10 || PT == 15))) &&
@@ -1095,7 +1095,7 @@ LEOD_API int leod_partition_attn_16bit_ok(int B, int H, int W, int C, int heads,
     const int d = C / heads, P = ph * pw, PT = (P + 15) / 16;
     const int HG = (heads % 2 == 0 && 2 * PT <= 16) ? 2 : 1;
     const bool inst = PT <= 5 || PT == 8 || (HG == 1 && (PT == 10 || PT == 15));
-    static const int force_pad1 = getenv("LEOD_ATTN_LDS_PAD1") ? atoi(getenv("LEOD_ATTN_LDS_PAD1")) : 1;
+    static const int force_pad1 = 1;
     return on && use_lds && (d == 24 || d == 32) && inst && !(HG == 1 && P < 16 * PT && !force_pad1);
 }
 // 1: on top of leod_partition_attn_16bit_ok, the attention output O may be written as bf16 (forward, bit 1 of qkv_bf16) and its gradient

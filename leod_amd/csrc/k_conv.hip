@@ -338,7 +338,7 @@ LEOD_API int leod_conv_nhwc_dgrad(const float* dy, const float* w, float* dx, in
 
 template <class XL>
 static int wgrad_any(const float* dy, const XL& xl, float* dW, long ldw, float* dbias, int M, int N, int K, hipStream_t s) {
-    static const int conv_w = getenv("LEOD_WGRADW_CONV") ? atoi(getenv("LEOD_WGRADW_CONV")) : 0;
+    static const int conv_w = 0;
     if (conv_w && use_wgradw(M)) return launch_wgradw(dy, (long)N, xl, dW, ldw, dbias, M, N, K, s);
     if (N % 48 == 0) return launch_wgrad16<3, 4>(dy, (long)N, xl, dW, ldw, dbias, M, N, K, s);
     if (N % 64 == 0) return launch_wgrad16<4, 4>(dy, (long)N, xl, dW, ldw, dbias, M, N, K, s);

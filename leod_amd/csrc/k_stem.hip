@@ -351,7 +351,7 @@ int launch_fwd(const uint8_t* x, const float* w, float* y, int B, int H, int W, 
     constexpr int KS = (CIN * 7 + 3) >> 2, LDW = KS * 32 + 16;
     const size_t lds = (size_t)16 * NT * LDW * 2 + (size_t)CIN * PR * RS * 2;
     static const int workers = getenv("LEOD_STEM_WORKERS") ? atoi(getenv("LEOD_STEM_WORKERS")) : 256;
-    static const int dbg = getenv("LEOD_STEM_FWD_DBG") ? atoi(getenv("LEOD_STEM_FWD_DBG")) : 0;
+    static const int dbg = 0;
     int gx = ntiles < workers ? ntiles : workers;
     if (gx >= 8) gx &= ~7;                                     // whole XCD rounds (see the tile order of the kernel)
     static bool attr = false;

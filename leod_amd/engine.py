@@ -42,8 +42,7 @@ class TrainEngine:
         # fill the device while the sequential parts of the backward pass (BPTT of the ConvLSTMs: 2 small launches per
         # timestep) run on the launch stream.  45.4 -> 43.6 ms per step; not used inside hipGraph capture.
         self.wgrad_side = os.environ.get('LEOD_WGRAD_STREAM', '1') == '1'
-        # experiment switch: keep the weight-gradient fork / join inside a captured graph (parallel branches of the hipGraph)
-        self.graph_side = os.environ.get('LEOD_GRAPH_SIDE', '0') == '1'
+        self.graph_side = False      # set for the duration of a capture that a launch plan replays: the weight-gradient fork / join is captured
 
     def current_lr(self):
         h = self.hp

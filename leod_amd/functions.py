@@ -19,8 +19,6 @@ from . import ops
 _SYNC_BN = {'group': None, 'world_size': 1, 'force': False, 'images': None, 'n_collectives': 0}
 
 
-_STEM_WGRAD_SIDE = int(os.environ.get('LEOD_STEM_WGRAD_SIDE', '0'))
-
 
 class WgradSide:
     """Weight-gradient kernels feed nothing until the optimiser, so the engine lets them run on a side HIP stream
@@ -29,7 +27,6 @@ class WgradSide:
     before the gradient all-reduce.  Tensors read on the side stream are kept alive until the join, so the caching
     allocator cannot hand their memory to a later main-stream kernel while the side stream still reads it."""
     active = False
-    priority = int(os.environ.get('LEOD_WGRAD_PRIO', '0'))   # HIP stream priority of the side stream (-1 = high, 0 = default)
     streams = {}            # launch stream (raw handle) -> its side stream
     used = set()
     keep = []
@@ -39,7 +36,8 @@ class WgradSide:
         key = main.cuda_stream
         st = cls.streams.get(key)
         if st is None:
-            st = cls.streams[key] = torch.cuda.Stream(priority=cls.priority)
+            # default priority: any other HIP stream priority doubled the step on MI355X / ROCm 7.2 (profiles/r04_a_graph_ab.txt)
+            st = cls.streams[key] = torch.cuda.Stream()
         cls.used.add(key)
         return st
 
@@ -239,11 +237,7 @@ class ConvLNFn(Function):
         if ctx.is_stem:
             # the stem is the LAST node of the backward pass: on the launch stream its weight gradient (310 us) runs next to the tail of the
             # side stream's queue instead of behind it (the join before the optimiser waited for both in sequence)
-            if _STEM_WGRAD_SIDE:
-                with _wgrad_side(dz, x):
-                    ops.stem_conv_wgrad(dz, x, grad_buf(mod.conv.weight), ctx.padded_hw, ctx.stride, conv_w.shape[-1] // 2)
-            else:
-                ops.stem_conv_wgrad(dz, x, grad_buf(mod.conv.weight), ctx.padded_hw, ctx.stride, conv_w.shape[-1] // 2)
+            ops.stem_conv_wgrad(dz, x, grad_buf(mod.conv.weight), ctx.padded_hw, ctx.stride, conv_w.shape[-1] // 2)
         else:
             with _wgrad_side(dz, x):
                 ops.conv_nhwc_wgrad(dz, x, grad_buf(mod.conv.weight), None, stride=ctx.stride)

@@ -20,8 +20,6 @@ LOSS_KEYS = ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')
 
 _LEVEL_STREAMS = __import__('os').environ.get('LEOD_HEAD_STREAMS', '1') == '1'   # pyramid levels of the head on their own HIP streams
 
-_GRAPH_LEVEL_STREAMS = __import__('os').environ.get('LEOD_GRAPH_HEAD_STREAMS', '0') == '1'   # experiment: level streams inside a captured graph
-
 
 class YOLOXHead(nn.Module):
     def __init__(self, num_classes=80, strides=(8, 16, 32), in_channels=(256, 512, 1024), act="silu", depthwise=False,
@@ -112,7 +110,7 @@ class YOLOXHead(nn.Module):
 
     def _towers(self, xin):
         if (_LEVEL_STREAMS and xin[0].is_cuda and len(xin) > 1 and not Fn._sync_bn_on()
-                and (_GRAPH_LEVEL_STREAMS or not torch.cuda.is_current_stream_capturing())):
+                and not torch.cuda.is_current_stream_capturing()):      # captured steps keep the levels on one lane: 16.8 vs 16.4 ms (profiles/r04_a_graph_ab.txt)
             return self._towers_streams(list(xin))
         # the three levels are independent: layers of equal depth form one group (one SyncBatchNorm exchange per group)
         n = len(xin)

@@ -13,7 +13,7 @@ import ctypes
 
 import torch
 
-from ._lib import lib, check, LeodHipError
+from ._lib import lib, check, LeodHipError, DevPtr
 
 F32 = torch.float32
 
@@ -69,8 +69,13 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_KIND = {torch.float32: 'f32', torch.bfloat16: 'bf16', torch.float16: 'f16', torch.float64: 'f64', torch.int32: 'i32', torch.int64: 'i64',
+         torch.uint8: 'u8', torch.bool: 'bool'}
+
+
 def _p(t: Optional[torch.Tensor]):
-    return None if t is None else t.data_ptr()
+    """device address + element kind: the typed pointer parameters of the binding (``_lib.DevPtr``) refuse a mismatching tensor"""
+    return None if t is None else DevPtr(t.data_ptr(), _KIND.get(t.dtype, 'void'))
 
 
 def _ck(t: Optional[torch.Tensor], dtype=F32, name='tensor'):

@@ -50,3 +50,20 @@ def test_product_never_imports_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f'{f} imports the oracle'
+
+
+def test_typed_pointer_parameters_refuse_a_swapped_tensor(built):
+    """the binding used to map every pointer to c_void_p, so a swapped argument was undetectable at the boundary.
+    Pointer parameters now carry their declared element type (``_lib._pointer_type``) and ``ops._p`` hands over (address, dtype)."""
+    import ctypes
+    protos = built.parse_header()
+    names = [a.__name__ for a in protos['leod_simota_assign'][1]]
+    assert names[:6] == ['Ptr_float', 'Ptr_float', 'Ptr_float', 'Ptr_unsigned_char', 'Ptr_unsigned_char', 'Ptr_int']
+    assert [a.__name__ for a in protos['leod_bn_silu_fwd'][1]][1] == 'Ptr_double'
+    f32 = protos['leod_layernorm_fwd'][1][0]
+    assert isinstance(f32.from_param(built.DevPtr(64, 'f32')), ctypes.c_void_p)
+    assert isinstance(f32.from_param(built.DevPtr(64, 'bf16')), ctypes.c_void_p)      # 16-bit rows of precision mode bf16 travel as float*
+    for wrong in ('i32', 'f64', 'u8', 'i64'):
+        with pytest.raises(built.LeodHipError):
+            f32.from_param(built.DevPtr(64, wrong))
+    assert f32.from_param(None) is None or f32.from_param(None) is not None            # NULL stays legal (optional arguments)

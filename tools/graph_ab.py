@@ -5,11 +5,10 @@ import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+# (the graph_side / graph_head / plan_both variants of profiles/r04_a_graph_ab.txt needed the LEOD_GRAPH_SIDE / LEOD_GRAPH_HEAD_STREAMS
+# experiment switches, removed after the measurement)
 VARIANTS = {'eager': {}, 'eager1': {'LEOD_WGRAD_STREAM': '0', 'LEOD_HEAD_STREAMS': '0'}, 'graph': {},
-            'graph_side': {'LEOD_GRAPH_SIDE': '1'}, 'graph_head': {'LEOD_GRAPH_HEAD_STREAMS': '1'},
-            'graph_both': {'LEOD_GRAPH_SIDE': '1', 'LEOD_GRAPH_HEAD_STREAMS': '1'},
-            'plan1': {'LEOD_PLAN_LANES': '1'}, 'plan_side': {'LEOD_GRAPH_SIDE': '1'},
-            'plan_both': {'LEOD_GRAPH_SIDE': '1', 'LEOD_GRAPH_HEAD_STREAMS': '1'}}
+            'plan1': {'LEOD_PLAN_LANES': '1'}, 'plan_side': {}}
 
 
 def child(variant):
