@@ -124,6 +124,133 @@ def cpu_baseline_bounded(timeout_s=300):
                 sample=f'CPU leg did not finish within {timeout_s} s on this host')
 
 
+def pseudo_cpu_baseline(L=21, B=2, timed=2):
+    """The oracle's pseudo-label inference (backbone over L, head, NMS; hflip copy included) on a bounded sample: B source streams."""
+    from oracle import train_step as ot
+    from oracle.synth import synth_state_dict
+    import json as _json
+    threads = usable_cores()
+    torch.set_num_threads(threads)
+    man = _json.load(open(os.path.join(ROOT, 'tests', 'golden', 'g11_manifest.json')))['small_gen1']
+    sd = synth_state_dict(man, 0)
+    for k in sd:
+        if ('obj_preds' in k or 'cls_preds' in k) and k.endswith('bias'):
+            sd[k] = sd[k] + 4.0
+    ev, _, _, _ = make_batch(L, B, (240, 304), 2, 7, 'cpu', ())
+    cfg = ot.model_cfg(48, 24, 0.33, (8, 10))
+    best = float('inf')
+    with torch.no_grad():
+        for i in range(1 + timed):
+            t0 = time.time()
+            ot.infer_sequence(sd, cfg, ev, None, conf_thre=0.01, hflip=True)
+            if i:
+                best = min(best, time.time() - t0)
+    return dict(value=round(L * B / best, 3), unit='source event-frames/s', cores=threads, kind='port',
+                sample=f'oracle pseudo-label inference (hflip TTA, NMS) RVT-S Gen1 L={L}, {B} source streams: 1 warm-up + {timed} timed passes of '
+                       f'{L * B} source frames, best {best:.2f} s')
+
+
+def pseudo_main(args):
+    """BASELINE.json configs[4], single-GPU leg: the pseudo-label inference loop through the product class -- ``PseudoLabeler.predict_step``
+    (modules/pseudo_labeler.py:622-770) on loader-shaped streaming batches of B source recordings x L frames with horizontal-flip TTA
+    (2B frame streams through the backbone), head on every frame, batched NMS, pred2label and the per-recording bookkeeping.  Weights
+    are random-init plus the +4.0 objectness / class bias bump of SURVEY 8d so that NMS sees O(100) candidates per frame."""
+    from leod_amd.parallel import init_distributed
+    rank, local, world = init_distributed()
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    import torch.distributed as dist
+    from leod_amd.config import full_config, dynamically_modify_train_config
+    from leod_amd.data.genx_utils.labels import SparselyBatchedObjectLabels
+    from leod_amd.data.utils.types import DataType
+    from leod_amd.modules.pseudo_labeler import PseudoLabeler
+    from leod_amd.modules.utils.detection import DATA_KEY, WORKER_ID_KEY
+    from leod_amd import ops
+    L, B = args.seq_len, args.batch
+    over = dict(dataset=dict(sequence_length=L), tta=dict(enable=True, hflip=True, tflip=False))
+    cfg = dynamically_modify_train_config(full_config('gen1', args.size, model='pseudo_labeler', overrides=over))
+    cfg.training.precision = 16 if args.dtype == 'bf16' else 32
+    cfg.model.postprocess.confidence_threshold = 0.01
+    torch.manual_seed(0)
+    mod = PseudoLabeler(cfg).to(dev).eval()
+    mod.setup('predict')
+    with torch.no_grad():
+        for k in range(3):
+            mod.mdl.yolox_head.obj_preds[k].bias += 4.0
+            mod.mdl.yolox_head.cls_preds[k].bias += 4.0
+    hw = (240, 304)
+    ev, _, _, _ = make_batch(L, B, hw, 2, rank, dev, ())
+    none_seq = lambda: [SparselyBatchedObjectLabels([None] * B) for _ in range(L)]   # noqa: E731
+    step_no = [0]
+
+    def batch():
+        s = step_no[0]
+        step_no[0] += 1
+        first = torch.full((B,), s == 0)
+        return {WORKER_ID_KEY: 0, DATA_KEY: {
+            DataType.EV_REPR: [ev[t] for t in range(L)], DataType.OBJLABELS_SEQ: none_seq(), DataType.SKIPPED_OBJLABELS_SEQ: none_seq(),
+            DataType.IS_FIRST_SAMPLE: first.to(dev), DataType.IS_LAST_SAMPLE: torch.zeros(B, dtype=torch.bool),
+            DataType.IS_REVERSED: torch.zeros(B, dtype=torch.bool), DataType.EV_IDX: [torch.full((B,), L * s + t, dtype=torch.long) for t in range(L)],
+            DataType.IS_PADDED_MASK: [torch.zeros(B, dtype=torch.bool) for _ in range(L)], DataType.PATH: [f'train/rec{rank}_{b}' for b in range(B)]}}
+
+    def barrier():
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        mod.predict_step(batch(), 0)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mod.predict_step(batch(), 0)
+    barrier()
+    dt = time.perf_counter() - t0
+    t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist.is_initialized():
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    dt = float(t_max)
+    n_lab = sum(len(l) for e in mod.ev_path_2_ev_data.values() for l in e.frame_idx_2_labels.values() if l is not None)
+    roofline = family_ms = None
+    if not args.no_roofline and rank == 0:
+        probe = ops.KernelProbe()
+        for _ in range(2):
+            mod.predict_step(batch(), 0)
+        roofline = probe.finish(PEAK_HBM_GBS, PEAK_BF16_MFMA_TFLOPS if args.dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS, target='linear_gemm')
+        family_ms = probe.family_ms(2)
+    if rank == 0:
+        fps = world * B * L * args.steps / dt
+        # SURVEY 8d: inference-forward bytes per PROCESSED frame (backbone 15.22 MB + PAFPN / head forward 9.67 MB at 16-bit activations;
+        # twice that in fp32 mode); a source frame is processed twice (hflip copy)
+        mb_frame = (15.22 + 9.67) * (1 if args.dtype == 'bf16' else 2)
+        out = {'metric': 'source event-frames/sec (pseudo-label inference: RVT-S backbone + head + batched NMS + pred2label, hflip TTA), whole job',
+               'value': round(fps, 2), 'unit': 'source event-frames/s (whole job)', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': args.dtype, 'data': 'synthetic',
+               'config': {'workload': f'LEOD pseudo-label pass (BASELINE configs[4], one shard): RVT-{args.size} gen1 {hw[0]}x{hw[1]} L={L}, {B} source streams '
+                                      f'/GPU + hflip TTA = {2 * B} frame streams, conf 0.01 / NMS 0.45, random-init weights + 4.0 obj / cls bias bump',
+                          'driver': 'PseudoLabeler.predict_step (leod_amd/modules/pseudo_labeler.py), eager launches',
+                          'processed_frames_per_s': round(2 * fps, 2), 'pseudo_labels_stored': n_lab,
+                          'algorithmic_MB_per_processed_frame': mb_frame,
+                          'whole_pass_hbm_frac_of_peak': round(mb_frame * 1e6 * 2 * fps / world / (PEAK_HBM_GBS * 1e9), 5),
+                          'family_ms_per_step': family_ms},
+               'roofline': roofline}
+        if not args.no_cpu_baseline and world == 1:
+            import subprocess
+            code = ('import json, sys; sys.path.insert(0, %r); import bench; print("CPUBASE " + json.dumps(bench.pseudo_cpu_baseline()))' % ROOT)
+            try:
+                so = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300,
+                                    env=dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')).stdout
+                out['cpu_baseline'] = next(json.loads(l[8:]) for l in so.splitlines() if l.startswith('CPUBASE '))
+            except Exception as e:                           # noqa: BLE001
+                out['cpu_baseline'] = dict(value=None, unit='source event-frames/s', cores=usable_cores(), kind='port', sample=f'CPU leg failed: {e}')
+        print(json.dumps(out), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -143,7 +270,13 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-plan', action='store_true', help='eager Python launches for every step (LEOD_PLAN=0): no launch plans')
     ap.add_argument('--dump-calls', default='', help='file for the per-launch table (C entry point, shape arguments, us) of the probe steps')
+    ap.add_argument('--pseudo', action='store_true', help='the pseudo-label inference pass of BASELINE configs[4] (single-GPU leg) instead of '
+                    'the training step: PseudoLabeler.predict_step, --batch source streams + hflip TTA, --seq-len frames per chunk')
     args = ap.parse_args()
+    if args.pseudo:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs an MI355X (no CPU fallback for the HIP path)')
+        return pseudo_main(args)
 
     from leod_amd.parallel import init_distributed
     rank, local, world = init_distributed()
