@@ -55,7 +55,7 @@ def make_batch(T, B, hw, num_classes, seed, device, label_ts):
                 labs.append(np.stack([c, x + w / 2, y + h / 2, w, h, np.ones(n), np.ones(n)], 1).astype(np.float32))
         else:
             label_tb.append([])
-    nmax = max(len(l) for l in labs)
+    nmax = max([len(l) for l in labs] or [1])
     tg = np.zeros((len(labs), nmax, 7), np.float32)
     for i, l in enumerate(labs):
         tg[i, :len(l)] = l
@@ -386,7 +386,7 @@ def main():
         plan_info = None
         if plans and module.plan_mode:
             e = plans[-1]
-            plan_info = {'forward': e.fwd.info, 'backward': e.bwd.info, 'captures': module._plans.captures, 'replays': module._plans.replays}
+            plan_info = {'forward': e.fwd.info(), 'backward': e.bwd.info(), 'captures': module._plans.captures, 'replays': module._plans.replays}
         # roofline of the dominant kernel: two extra steps with HIP events around each of its launches
         roofline = roofline_gemm = family_ms = probe = family_all = None
         if not args.no_roofline:

@@ -87,8 +87,12 @@ class BucketBoundaryFn(Function):
     @staticmethod
     def backward(ctx, *gs):
         from .parallel import GradBuckets
-        if GradBuckets.current is not None:
-            GradBuckets.current.ready(ctx.k)
+        b = GradBuckets.current
+        if b is not None:
+            from .modules.step_plan import PlanRecorder
+            k = ctx.k
+            if not PlanRecorder.split(lambda: GradBuckets.current is not None and GradBuckets.current.ready(k)):
+                b.ready(k)
         return (None,) + tuple(gs)
 
 
@@ -150,8 +154,15 @@ def _sync_bn_on() -> bool:
 def _allreduce_stats(t: torch.Tensor):
     if _sync_bn_on():
         import torch.distributed as dist
-        dist.all_reduce(t, group=_SYNC_BN['group'])
-        _SYNC_BN['n_collectives'] += 1
+        group = _SYNC_BN['group']
+
+        def exchange():
+            dist.all_reduce(t, group=group)
+            _SYNC_BN['n_collectives'] += 1
+        # a step that is being recorded into launch plans takes the exchange as a host callback between two plan segments
+        from .modules.step_plan import PlanRecorder
+        if not PlanRecorder.split(exchange):
+            exchange()
 
 
 def sync_bn_begin(n_images: int, device) -> None:

@@ -37,6 +37,70 @@ def _flat(states) -> List[th.Tensor]:
     return [t for pair in states for t in pair]
 
 
+class PlanRecorder:
+    """Stream capture of a step in SEGMENTS.  Whatever cannot live inside a capture -- a collective between two kernels (the SyncBatchNorm
+    statistic exchanges, the release of a gradient bucket to the communication stream) -- calls ``PlanRecorder.split(callback)``: the
+    capture in progress is closed and becomes one launch plan, the callback is remembered, a new capture begins in the same memory
+    pool.  A replay is  plan 0 -> callback 0 -> plan 1 -> callback 1 ... : the callbacks run eagerly on tensors of the pool (static
+    addresses), exactly where the eager step would have issued them.  Captures use the relaxed error mode: the backward pass runs on
+    autograd's device thread, which therefore ends / begins captures that the calling thread started."""
+    current: Optional['PlanRecorder'] = None
+
+    def __init__(self, max_lanes: int, pool=None):
+        self.max_lanes, self.pool = max_lanes, pool
+        self.segments: List[Tuple[Optional[ops.LaunchPlan], Any]] = []
+        self.graph = None
+
+    def begin(self):
+        self.graph = th.cuda.CUDAGraph(keep_graph=True)
+        if self.pool is None:
+            self.pool = th.cuda.graph_pool_handle()          # one private pool for every segment of the step (forward and backward)
+        self.graph.capture_begin(pool=self.pool, capture_error_mode='relaxed')
+
+    def end(self, callback=None):
+        Fn.WgradSide.join()                                  # every forked stream back on the capturing stream before the capture ends
+        self.graph.capture_end()
+        try:
+            plan = ops.LaunchPlan(self.graph, self.max_lanes)
+        except LeodHipError as e:
+            if 'empty graph' not in str(e):
+                raise
+            plan = None                                      # two callbacks back to back: nothing was launched in between
+        self.segments.append((plan, callback))
+        self.graph = None
+
+    @classmethod
+    def split(cls, callback) -> bool:
+        """Called where the step needs the host: True = a recording is in progress and took the callback (do NOT run it now)."""
+        rec = cls.current
+        if rec is None or rec.graph is None:
+            return False
+        rec.end(callback)
+        rec.begin()
+        return True
+
+    def replay(self):
+        for plan, callback in self.segments:
+            if plan is not None:
+                plan.launch()
+            if callback is not None:
+                callback()
+
+    def info(self):
+        k = sum(p.info['kernels'] for p, _ in self.segments if p is not None)
+        return {'kernels': k, 'memsets': sum(p.info['memsets'] for p, _ in self.segments if p is not None),
+                'memcpys': sum(p.info['memcpys'] for p, _ in self.segments if p is not None),
+                'lanes': max([p.info['lanes'] for p, _ in self.segments if p is not None] or [0]),
+                'waits': sum(p.info['waits'] for p, _ in self.segments if p is not None),
+                'segments': len(self.segments), 'callbacks': sum(1 for _, c in self.segments if c is not None)}
+
+    def close(self):
+        for p, _ in self.segments:
+            if p is not None:
+                p.close()
+        self.segments = []
+
+
 class PlanLossFn(Function):
     """The loss of a replayed step as an autograd leaf-to-loss edge: ``forward`` has already happened (the forward plan), ``backward``
     hands the seed gradient to the captured backward pass and launches the backward plan.  Parameter gradients land in the flat
@@ -69,8 +133,8 @@ class StepPlan:
         self.arena_high = 0
         self.bn_incs: List[Tuple[Any, int]] = []
         self.losses6: Optional[th.Tensor] = None
-        self.fwd: Optional[ops.LaunchPlan] = None
-        self.bwd: Optional[ops.LaunchPlan] = None
+        self.fwd: Optional['PlanRecorder'] = None
+        self.bwd: Optional['PlanRecorder'] = None
         self.owner = None                      # worker id whose LSTM state currently lives in ``self.states``
         self.pin: Optional[th.Tensor] = None
         self.pin_event = None
@@ -84,31 +148,52 @@ class StepPlan:
         pending0 = [m.bn_calls_pending for m in mods]
         saved_arena = ops.StatArena.swap(self.arena)
         from leod_amd.parallel import GradBuckets
-        saved_buckets, GradBuckets.current = GradBuckets.current, None
+        saved_buckets = GradBuckets.current
         saved_side = Fn.WgradSide.active
         ops.PackCache.invalidate()                         # the capture must contain the weight packs of a step
-        g_f = th.cuda.CUDAGraph(keep_graph=True)
-        g_b = th.cuda.CUDAGraph(keep_graph=True)
+        capture_stream = th.cuda.Stream(device=self.ev.device)
+        capture_stream.wait_stream(th.cuda.current_stream())
+        th.cuda.synchronize()
+        fwd = PlanRecorder(max_lanes)
+        bwd = None
         try:
-            with th.enable_grad():
-                with th.cuda.graph(g_f):
-                    ops.StatArena.begin_step(self.ev.device)
-                    ops.rows_masked_zero(_flat(self.states), self.is_first)                       # RNNStates.reset (detection.py:95-157)
-                    _, new_states, feats = mdl.backbone.forward_sequence(self.ev, self.states, select_rows=self.rows, select_stages=in_features)
-                    _, losses = mdl.forward_detect(backbone_features=feats, targets=self.labels)
-                    self.losses6 = mdl.yolox_head.last_losses6
-                    ops.copy_multi(_flat(self.states), [t.detach() for t in _flat(new_states)])      # state hand-over to the next step
-                with th.cuda.graph(g_b, pool=g_f.pool()):
-                    Fn.WgradSide.active = wgrad_side
-                    try:
-                        losses['loss'].backward(gradient=self.seed)
-                    finally:
-                        Fn.WgradSide.active = False
-                        Fn.WgradSide.join()
+            with th.enable_grad(), th.cuda.stream(capture_stream):
+                PlanRecorder.current = fwd
+                GradBuckets.current = saved_buckets           # boundary nodes reach the buckets through PlanRecorder.split
+                fwd.begin()
+                ops.StatArena.begin_step(self.ev.device)
+                ops.rows_masked_zero(_flat(self.states), self.is_first)                       # RNNStates.reset (detection.py:95-157)
+                _, new_states, feats = mdl.backbone.forward_sequence(self.ev, self.states, select_rows=self.rows, select_stages=in_features)
+                _, losses = mdl.forward_detect(backbone_features=feats, targets=self.labels)
+                self.losses6 = mdl.yolox_head.last_losses6
+                ops.copy_multi(_flat(self.states), [t.detach() for t in _flat(new_states)])      # state hand-over to the next step
+                fwd.end()
+                bwd = PlanRecorder(max_lanes, pool=fwd.pool)
+                PlanRecorder.current = bwd
+                bwd.begin()
+                Fn.WgradSide.active = wgrad_side
+                try:
+                    losses['loss'].backward(gradient=self.seed)
+                finally:
+                    Fn.WgradSide.active = False
+                bwd.end()
             self.arena_high = ops.StatArena.high
-            self.fwd = ops.LaunchPlan(g_f, max_lanes)
-            self.bwd = ops.LaunchPlan(g_b, max_lanes)
+            self.fwd, self.bwd = fwd, bwd
+        except BaseException:
+            with th.cuda.stream(capture_stream):              # leave no stream in capture mode behind (a capturing graph aborts in its destructor)
+                for rec in (fwd, bwd):
+                    if rec is not None and rec.graph is not None:
+                        try:
+                            Fn.WgradSide.join()
+                            rec.graph.capture_end()
+                        except Exception:                     # noqa: BLE001
+                            pass
+                    if rec is not None:
+                        rec.close()
+            raise
         finally:
+            PlanRecorder.current = None
+            th.cuda.current_stream().wait_stream(capture_stream)
             ops.StatArena.swap(*saved_arena)
             GradBuckets.current = saved_buckets
             Fn.WgradSide.active = saved_side
@@ -166,14 +251,14 @@ class StepPlan:
     def run_forward(self):
         if self.arena_high:
             self.arena[:self.arena_high].zero_()           # BatchNorm statistic accumulators / LayerScale scratch of the captured step
-        self.fwd.launch()
+        self.fwd.replay()
         for m, inc in self.bn_incs:
             m.bn_calls_pending += inc
         self.uses += 1
 
     def run_backward(self, g: th.Tensor):
         self.seed.copy_(g.reshape(()), non_blocking=True)
-        self.bwd.launch()
+        self.bwd.replay()
         ops.PackCache.invalidate()                         # the replayed step re-packed conv weights behind the cache's back
 
     def close(self):
@@ -197,8 +282,11 @@ class TrainStepPlans:
 
     @staticmethod
     def allowed() -> bool:
-        """No plan while the step contains collectives between kernels (SyncBatchNorm over > 1 rank) or a step is being captured."""
-        return not Fn._sync_bn_on() and not th.cuda.is_current_stream_capturing()
+        """Not while a step is being captured.  (Collectives between kernels -- SyncBatchNorm, gradient buckets -- split the capture into
+        segments, see ``PlanRecorder``; LEOD_PLAN_DIST=0 keeps steps with collectives eager.)"""
+        if th.cuda.is_current_stream_capturing():
+            return False
+        return not Fn._sync_bn_on() or os.environ.get('LEOD_PLAN_DIST', '1') == '1'
 
     def key_of(self, ev: th.Tensor, n_frames: int, nmax: int):
         nmax_pad = max(NMAX_PAD, -(-nmax // NMAX_PAD) * NMAX_PAD)
@@ -226,6 +314,9 @@ class TrainStepPlans:
         try:
             entry.capture(module, wgrad_side, self.max_lanes)
         except (LeodHipError, RuntimeError) as e:
+            if os.environ.get('LEOD_PLAN_DEBUG'):
+                import traceback
+                traceback.print_exc()
             warnings.warn(f'leod_amd: the training step of geometry {key} could not be turned into a launch plan ({e}); it stays eager')
             entry.close()
             self.entries[key] = 'eager'
