@@ -83,6 +83,21 @@ int leod_linear_dgrad_gelu16(const float* dy, const float* kscale, const float* 
 int leod_linear_wgrad_gelu16(const float* dy, long lddy, const void* u16, float* dW, float* dbias, int M, int N, int K,
                              leod_stream_t stream);
 
+/* The whole MLP of a MaxViT block in one row-streaming launch (maxvit.py:110-118, 268-269), precision mode bf16, K = 48 / H = 192 (stage 1
+ * of RVT-S / -T), M >= 16384:  z[M,K] = y + g2 * (gelu(LN(y) W1^T + b1) W2^T + b2) with the hidden in registers (csrc/k_mlp.hip).
+ * u16 [M,H] fp16 + stats [M,2] (both or neither): what the backward pass reads back (training).  -3: not covered -- the caller runs
+ * leod_ln_linear_gelu16_fwd + leod_linear_lsres_gelu16_fwd. */
+int leod_mlp_fwd_fused(const float* y, const float* ln_w, const float* ln_b, float eps, const float* W1, const float* b1, const float* W2,
+                       const float* b2, const float* g2, float* out, void* u16, float* stats, int M, int H, int K, leod_stream_t stream);
+
+/* Backward of that MLP along the activation path, one launch: u is recomputed from y, du = ((dz g2) W2) gelu'(u) is written as bf16 rows
+ * (du16 [M,H], optional: the fc1 weight gradient reads it), dy = dz + LayerNorm-backward(du W1), dgamma / dbeta [K] += (norm2).
+ * stats [M,2] = the (mean, rstd) of the forward pass.  Replaces leod_linear_dgrad_gelu16 + leod_linear_dgrad_lnbwd where it applies
+ * (same coverage as leod_mlp_fwd_fused; -3 otherwise). */
+int leod_mlp_bwd_dgrad_fused(const float* dz, const float* y, const float* stats, const float* ln_w, const float* ln_b, const float* W1,
+                             const float* b1, const float* W2, const float* g2, float* dy, void* du16, float* dgamma, float* dbeta, int M,
+                             int H, int K, leod_stream_t stream);
+
 /* Fused ConvLSTM cell, DWSConvLSTM2d.forward with dws_conv=False (models/layers/rnn.py:37-70):
  * gates = [x|h_prev] W[4C,2C]^T + b, (f,i,o)=sigmoid, g=tanh, c=f*c_prev+i*g, h=o*tanh(c).
  * h_prev/c_prev NULL = zero state; gates_out (optional) [M,4,C] post-activation gates. */

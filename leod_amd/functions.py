@@ -274,9 +274,16 @@ class AttnBlockFn(Function):
         o, lse = ops.partition_attn_fwd(qkv, heads, part, window, want_lse=need, out_bf16=o16)
         # the pre-LayerScale outputs are NOT stored: dgamma is recovered from the un-scaled weight gradient in backward
         y, _ = ops.linear_lsres_fwd(o, proj_w, proj_b, g1, x, want_t=False)
-        # precision mode bf16, stages 1-2: u comes back as ONE fp16 tensor (h is None) and fc2 applies GELU while loading it
-        u, h, st2 = ops.ln_linear_fwd(y, n2w, n2b, fc1_w, fc1_b, want_act=True, want_stats=True)
-        z, _ = ops.linear_lsres_fwd(h if h is not None else u, fc2_w, fc2_b, g2, y, want_t=False)
+        # precision mode bf16, stage 1: the whole MLP in one launch, the hidden in registers (csrc/k_mlp.hip); with a backward pass to
+        # come it also leaves the fp16 pre-activation and the LayerNorm statistics behind
+        fused = ops.mlp_fwd_fused(y, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, g2, want_saved=need)
+        if fused is not None:
+            z, u, st2 = fused
+            h = None
+        else:
+            # precision mode bf16, stages 1-2: u comes back as ONE fp16 tensor (h is None) and fc2 applies GELU while loading it
+            u, h, st2 = ops.ln_linear_fwd(y, n2w, n2b, fc1_w, fc1_b, want_act=True, want_stats=True)
+            z, _ = ops.linear_lsres_fwd(h if h is not None else u, fc2_w, fc2_b, g2, y, want_t=False)
         if need:
             ctx.mod = mod
             ctx.u16 = h is None
@@ -292,8 +299,14 @@ class AttnBlockFn(Function):
         heads, part, window = sa.num_heads, mod.partition_size, mod.partition_window
         dz = _cont(dz)
         # ---- dgrad chain (critical path); LayerScale is folded into the dgrad loader (dz * gamma) -------------------------
-        du = ops.linear_dgrad(dz, fc2_w, kscale=g2, aux_u=u)
-        dy = ops.linear_dgrad_ln_bwd(du, fc1_w, y, st2, n2w, dz, grad_buf(mod.norm2.weight), grad_buf(mod.norm2.bias))
+        fused = None
+        if ctx.u16:                                           # stage 1, precision mode bf16: the MLP's dgrad chain in one launch (csrc/k_mlp.hip)
+            fused = ops.mlp_bwd_dgrad_fused(dz, y, st2, n2w, n2b, fc1_w, fc1_b, fc2_w, g2, grad_buf(mod.norm2.weight), grad_buf(mod.norm2.bias))
+        if fused is not None:
+            dy, du = fused
+        else:
+            du = ops.linear_dgrad(dz, fc2_w, kscale=g2, aux_u=u)
+            dy = ops.linear_dgrad_ln_bwd(du, fc1_w, y, st2, n2w, dz, grad_buf(mod.norm2.weight), grad_buf(mod.norm2.bias))
         do = ops.linear_dgrad(dy, proj_w, kscale=g1, out_bf16=o.dtype is torch.bfloat16)
         dqkv = ops.partition_attn_bwd(qkv, do, lse, heads, part, window)
         # ---- weight gradients: off the critical path (side stream when the engine enables it) ------

@@ -197,6 +197,52 @@ def _linear_lsres_fwd(a, W, bias, gamma, res, want_t, K, N, M):
     return out, tout
 
 
+def mlp_fwd_fused(y, ln_w, ln_b, W1, b1, W2, b2, gamma, want_saved=False, eps=1e-5):
+    """z = y + gamma * (gelu(LN(y) W1^T + b1) W2^T + b2) in ONE launch (csrc/k_mlp.hip) -> (z, u16 | None, stats | None), or None where
+    the fused kernel does not cover the shape / precision mode (the caller then runs ln_linear_fwd + linear_lsres_fwd)."""
+    for t, n in ((y, 'y'), (ln_w, 'ln_w'), (ln_b, 'ln_b'), (W1, 'W1'), (b1, 'b1'), (W2, 'W2'), (b2, 'b2'), (gamma, 'gamma')):
+        _ck(t, name=n)
+    K = y.shape[-1]
+    H = W1.shape[0]
+    M = y.numel() // K
+    out = _empty(y.shape, y)
+    u16 = torch.empty(y.shape[:-1] + (H,), dtype=torch.float16, device=y.device) if want_saved else None
+    stats = _empty((M, 2), y) if want_saved else None
+    ev = _probe('linear_gemm', 8.0 * M * K + 4.0 * 2 * H * K + (2.0 * M * H if want_saved else 0.0), 4.0 * M * H * K)
+    rc = _l().leod_mlp_fwd_fused(_p(y), _p(ln_w), _p(ln_b), eps, _p(W1), _p(b1), _p(W2), _p(b2), _p(gamma), _p(out), _p(u16), _p(stats),
+                                 M, H, K, _stream())
+    if ev is not None:
+        ev.record()
+    if rc == -3:
+        return None
+    check(rc, 'mlp_fwd_fused')
+    return out, u16, stats
+
+
+def mlp_bwd_dgrad_fused(dz, y, stats, ln_w, ln_b, W1, b1, W2, gamma, dgamma, dbeta, want_du=True):
+    """The activation-path backward of the fused MLP in ONE launch (csrc/k_mlp.hip) -> (dy, du bf16 | None), or None where it does not
+    apply (the caller then runs linear_dgrad(aux_u=) + linear_dgrad_ln_bwd).  dgamma / dbeta accumulate norm2's gradients."""
+    for t, n in ((dz, 'dz'), (y, 'y'), (stats, 'stats'), (ln_w, 'ln_w'), (ln_b, 'ln_b'), (W1, 'W1'), (b1, 'b1'), (W2, 'W2'),
+                 (gamma, 'gamma'), (dgamma, 'dgamma'), (dbeta, 'dbeta')):
+        _ck(t, name=n)
+    K = y.shape[-1]
+    H = W1.shape[0]
+    M = y.numel() // K
+    if not BF16_GRADS:
+        return None
+    dy = _empty(y.shape, y)
+    du = torch.empty(y.shape[:-1] + (H,), dtype=torch.bfloat16, device=y.device) if want_du else None
+    ev = _probe('linear_gemm', 12.0 * M * K + 4.0 * 2 * H * K + (2.0 * M * H if want_du else 0.0), 8.0 * M * H * K)
+    rc = _l().leod_mlp_bwd_dgrad_fused(_p(dz), _p(y), _p(stats), _p(ln_w), _p(ln_b), _p(W1), _p(b1), _p(W2), _p(gamma), _p(dy), _p(du),
+                                       _p(dgamma), _p(dbeta), M, H, K, _stream())
+    if ev is not None:
+        ev.record()
+    if rc == -3:
+        return None
+    check(rc, 'mlp_bwd_dgrad_fused')
+    return dy, du
+
+
 def partition_attn_fwd(qkv, heads, part, window, want_lse=False, out_bf16=False):
     """qkv [B,H,W,3C] -> out [B,H,W,C] (+ lse [B,H,W,heads]); out_bf16 (attn_block_o16_ok): out as bf16 rows."""
     q16 = qkv.dtype is torch.bfloat16

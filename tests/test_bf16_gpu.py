@@ -453,3 +453,75 @@ def test_linear_dgrad_ln_bwd_from_bf16_rows(bf16_ops, M, N, K, with_res):
     tk.close(dx, x.grad + (dres if with_res else 0), what='dx')
     tk.close(dw, lw.grad, what='d ln weight')
     tk.close(db, lb.grad, what='d ln bias')
+
+
+@pytest.mark.parametrize('M,saved', [(16384, True), (20007, True), (70001, False), (16391, False)])
+def test_mlp_fwd_fused_bf16(bf16_ops, M, saved):
+    """The whole stage-1 MLP in one launch (csrc/k_mlp.hip: fc1 evaluated transposed so that its accumulators are fc2's A operands, the
+    hidden never leaves the registers): z = y + g * (gelu(LN(y) W1^T + b1) W2^T + b2) against the fp32 CPU arithmetic (maxvit.py:110-118,
+    268-269), full and ragged row counts; with ``want_saved`` the fp16 pre-activation and the LayerNorm statistics the backward pass reads
+    must be the ones the unfused producer writes."""
+    import torch.nn.functional as F
+    ops = bf16_ops
+    C = 48
+    y = tk.rnd((M, C), 21)
+    lw, lb = 1 + 0.2 * tk.rnd((C,), 22), 0.1 * tk.rnd((C,), 23)
+    W1, b1 = tk.rnd((4 * C, C), 24, 0.2), tk.rnd((4 * C,), 25, 0.2)
+    W2, b2, g = tk.rnd((C, 4 * C), 26, 0.1), tk.rnd((C,), 27, 0.1), 0.5 + 0.1 * tk.rnd((C,), 28)
+    u = F.linear(F.layer_norm(y, (C,), lw, lb, 1e-5), W1, b1)
+    z = y + g * F.linear(F.gelu(u), W2, b2)
+    d = lambda t: t.detach().to(tk.DEV)  # noqa
+    out = ops.mlp_fwd_fused(d(y), d(lw), d(lb), d(W1), d(b1), d(W2), d(b2), d(g), want_saved=saved)
+    assert out is not None, 'K = 48 / H = 192 / M >= 16384 in precision mode bf16 is what the fused kernel covers'
+    zz, u16, st = out
+    tk.close(zz, z, what='fused MLP output')
+    if saved:
+        assert u16.dtype is torch.float16 and tuple(u16.shape) == (M, 4 * C) and tuple(st.shape) == (M, 2)
+        tk.close(u16.float(), u, what='fp16 pre-activation of the fused MLP')
+        u_ref, _, st_ref = ops.ln_linear_fwd(d(y), d(lw), d(lb), d(W1), d(b1), want_act=True, want_stats=True)
+        assert float((u16.float() - u_ref.float()).abs().max()) <= 2e-2 * float(u_ref.float().abs().max())
+        torch.testing.assert_close(st, st_ref, rtol=1e-5, atol=1e-6)
+    else:
+        assert u16 is None and st is None
+    # shapes outside the fused kernel's coverage are refused (the caller falls back to the two-launch path)
+    assert ops.mlp_fwd_fused(d(y)[:1000].contiguous(), d(lw), d(lb), d(W1), d(b1), d(W2), d(b2), d(g)) is None
+
+
+@pytest.mark.parametrize('M', [16384, 20007, 70001])
+def test_mlp_bwd_dgrad_fused_bf16(bf16_ops, M):
+    """The activation-path backward of the stage-1 MLP in one launch (csrc/k_mlp.hip): u recomputed from y, du = ((dz g) W2) gelu'(u) as
+    bf16 rows, dy = dz + LayerNorm-backward(du W1), norm2's weight / bias gradients -- against fp32 autograd of the same block
+    (maxvit.py:110-118, 268-269) and against the two-launch path it replaces."""
+    import torch.nn.functional as F
+    ops = bf16_ops
+    C = 48
+    y = tk.rnd((M, C), 31)
+    lw, lb = 1 + 0.2 * tk.rnd((C,), 32), 0.1 * tk.rnd((C,), 33)
+    W1, b1 = tk.rnd((4 * C, C), 34, 0.2), tk.rnd((4 * C,), 35, 0.2)
+    W2, b2, g = tk.rnd((C, 4 * C), 36, 0.1), tk.rnd((C,), 37, 0.1), 0.5 + 0.1 * tk.rnd((C,), 38)
+    dz = tk.rnd((M, C), 39)
+    yr = y.clone().requires_grad_(True)
+    lwr, lbr = lw.clone().requires_grad_(True), lb.clone().requires_grad_(True)
+    u = F.linear(F.layer_norm(yr, (C,), lwr, lbr, 1e-5), W1, b1)
+    u.retain_grad()
+    z = yr + g * F.linear(F.gelu(u), W2, b2)
+    z.backward(dz)
+    d = lambda t: t.detach().to(tk.DEV)  # noqa
+    fwd = ops.mlp_fwd_fused(d(y), d(lw), d(lb), d(W1), d(b1), d(W2), d(b2), d(g), want_saved=True)
+    assert fwd is not None
+    _, u16, st = fwd
+    dlw, dlb = torch.zeros((C,), device=tk.DEV), torch.zeros((C,), device=tk.DEV)
+    out = ops.mlp_bwd_dgrad_fused(d(dz), d(y), st, d(lw), d(lb), d(W1), d(b1), d(W2), d(g), dlw, dlb)
+    assert out is not None
+    dy, du = out
+    assert du.dtype is torch.bfloat16 and tuple(du.shape) == (M, 4 * C)
+    tk.close(du.float(), u.grad, what='gradient of the hidden pre-activation (bf16 rows)')
+    tk.close(dy, yr.grad, what='dy = dz + LayerNorm backward')
+    tk.close(dlw, lwr.grad, what='LayerNorm weight gradient')
+    tk.close(dlb, lbr.grad, what='LayerNorm bias gradient')
+    # and the two launches it replaces (same operands, same roundings up to the fp16 storage of u)
+    du2 = ops.linear_dgrad(d(dz), d(W2), kscale=d(g), aux_u=u16)
+    dlw2, dlb2 = torch.zeros((C,), device=tk.DEV), torch.zeros((C,), device=tk.DEV)
+    dy2 = ops.linear_dgrad_ln_bwd(du2, d(W1), d(y), st, d(lw), d(dz), dlw2, dlb2)
+    assert float((dy - dy2).abs().max()) <= 2e-2 * float(dy2.abs().max())
+    assert float((dlw - dlw2).abs().max()) <= 2e-2 * float(dlw2.abs().max())
