@@ -413,7 +413,7 @@ def main():
             # HBM bytes per launch of the same kernel from the PMC passes kept under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
             # separate rocprofv3 --pmc runs; bench.py itself cannot sample hardware counters)
             tpath = os.path.join(ROOT, 'profiles', 'roofline_traffic.json')
-            if rank == 0 and roofline is not None and os.path.exists(tpath):
+            if rank == 0 and roofline is not None and headline and os.path.exists(tpath):      # measured on the headline workload only
                 tj = json.load(open(tpath)).get(dtype, {})
                 roofline['traffic'] = tj.get('hbm_bytes_per_launch')
                 roofline['traffic_source'] = tj.get('source')

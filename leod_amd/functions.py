@@ -27,6 +27,7 @@ class WgradSide:
     before the gradient all-reduce.  Tensors read on the side stream are kept alive until the join, so the caching
     allocator cannot hand their memory to a later main-stream kernel while the side stream still reads it."""
     active = False
+    hold_main = False       # set around sections that are recorded in many short plan segments (see _conv_bn_bwd): no fork there
     streams = {}            # launch stream (raw handle) -> its side stream
     used = set()
     keep = []
@@ -59,7 +60,7 @@ class _wgrad_side:
         self.ctx = None
 
     def __enter__(self):
-        if not WgradSide.active:
+        if not WgradSide.active or WgradSide.hold_main:
             return
         main = torch.cuda.current_stream()
         side = WgradSide.side_of(main)
@@ -542,12 +543,19 @@ def _conv_bn_bwd(members):
             slices.append(sl)
             off += 2 * R * N
         _allreduce_stats(block)
+        # SyncBatchNorm while the step is being recorded into launch plans: every exchange closes a plan segment, and a segment can only
+        # end with the side stream joined -- the small weight gradients of the neck / head then stay on the launch stream instead of
+        # forking and joining once per layer (17.97 -> see profiles/r04_*_rccl_force_collectives.txt)
+        from .modules.step_plan import PlanRecorder
+        hold = sync and PlanRecorder.current is not None
+        prev_hold, WgradSide.hold_main = WgradSide.hold_main, hold or WgradSide.hold_main
         for (mod, x, z, mean, rstd, conv_w, bn_w, bn_b, stride, count, count_dev, dy, need_dx), sl in zip(live, slices):
             dz = ops.bn_silu_bwd_apply(dy, z, mean, rstd, bn_w, bn_b, sl, grad_buf(mod.bn.weight), grad_buf(mod.bn.bias), count,
                                        count_dev=count_dev)
             with _wgrad_side(dz, x):
                 ops.conv_nhwc_wgrad(dz, x, grad_buf(mod.conv.weight), None, stride=stride)
             dxs[id(mod)] = ops.conv_nhwc_dgrad(dz, conv_w, x.shape, stride=stride) if need_dx else None
+        WgradSide.hold_main = prev_hold
     return [dxs.get(id(m[0])) for m in members]
 
 
