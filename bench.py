@@ -198,12 +198,15 @@ def pseudo_main(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    mod.pipelined = True                       # as leod_amd.predict.run_pseudo_labeling drives it: host half of chunk i - 1 under chunk i
     for _ in range(args.warmup):
         mod.predict_step(batch(), 0)
+    mod.flush_predictions()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         mod.predict_step(batch(), 0)
+    mod.flush_predictions()
     barrier()
     dt = time.perf_counter() - t0
     t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -216,6 +219,7 @@ def pseudo_main(args):
         probe = ops.KernelProbe()
         for _ in range(2):
             mod.predict_step(batch(), 0)
+        mod.flush_predictions()
         roofline = probe.finish(PEAK_HBM_GBS, PEAK_BF16_MFMA_TFLOPS if args.dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS, target='linear_gemm')
         family_ms = probe.family_ms(2)
     if rank == 0:
@@ -229,7 +233,7 @@ def pseudo_main(args):
                'dtype': args.dtype, 'data': 'synthetic',
                'config': {'workload': f'LEOD pseudo-label pass (BASELINE configs[4], one shard): RVT-{args.size} gen1 {hw[0]}x{hw[1]} L={L}, {B} source streams '
                                       f'/GPU + hflip TTA = {2 * B} frame streams, conf 0.01 / NMS 0.45, random-init weights + 4.0 obj / cls bias bump',
-                          'driver': 'PseudoLabeler.predict_step (leod_amd/modules/pseudo_labeler.py), eager launches',
+                          'driver': 'PseudoLabeler.predict_step, pipelined as leod_amd.predict.run_pseudo_labeling drives it (host bookkeeping of chunk i - 1 under the device work of chunk i), eager launches',
                           'processed_frames_per_s': round(2 * fps, 2), 'pseudo_labels_stored': n_lab,
                           'algorithmic_MB_per_processed_frame': mb_frame,
                           'whole_pass_hbm_frac_of_peak': round(mb_frame * 1e6 * 2 * fps / world / (PEAK_HBM_GBS * 1e9), 5),

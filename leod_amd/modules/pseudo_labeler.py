@@ -18,10 +18,11 @@ import torch as th
 from leod_amd.data.genx_utils.labels import ObjectLabels, SparselyBatchedObjectLabels, BBOX_DTYPE  # noqa: F401
 from leod_amd.data.utils import misc
 from leod_amd.data.utils.types import DataType
-from leod_amd.models.detection.yolox.utils.boxes import postprocess
+from leod_amd import ops
+from leod_amd.models.detection.yolox.utils.boxes import postprocess, postprocess_padded  # noqa: F401
 from .detection import Module
 from .utils.detection import BackboneFeatureSelector, SeqLens, Mode, DATA_KEY
-from .utils.ssod import pred2label, filter_pred_boxes
+from .utils.ssod import pred2label, pred2label_padded, filter_pred_boxes  # noqa: F401
 from .utils.tta import tta_postprocess as _tta_rows
 from .tracking import track as _native_track
 
@@ -227,6 +228,10 @@ class PseudoLabeler(Module):
         self.use_gt = self.full_config.get('use_gt', True)
         self.tta_cfg = self.full_config.tta
         self.filter_bbox_fn = lambda b: filter_pred_boxes(b, dataset_name=self.dst_name, downsampled_by_2=self.ds_by2)
+        self.pipelined = False                 # host half of chunk i - 1 under the device half of chunk i (see predict_step)
+        self._pending = None
+        self._host_slots: List[Any] = []
+        self._host_next = 0
 
     def get_data_from_batch(self, batch: Any):
         """hflip TTA: the flipped copy is concatenated on the batch dim (B -> 2B) and labels are flipped; padding is
@@ -287,6 +292,7 @@ class PseudoLabeler(Module):
         ev_seq = data[DataType.EV_REPR]
         obj_labels, skipped = data[DataType.OBJLABELS_SEQ], data[DataType.SKIPPED_OBJLABELS_SEQ]
         is_first = data[DataType.IS_FIRST_SAMPLE]
+        first_host = is_first.cpu().numpy().tolist()          # before anything of this chunk is enqueued: the copy waits for nothing new
         L, B = len(obj_labels), len(obj_labels[0])
         assert L > 0 and B > 0
         if self.mode_2_batch_size[mode] is None:
@@ -330,47 +336,77 @@ class PseudoLabeler(Module):
             feats = selector.get_batched_backbone_features()
         rnn.save_states_and_detach(worker_id=worker_id, states=prev)
         self.mode_2_seq_lens.update_lens(worker_id=worker_id, lens=torch.ones(B).long() * L)
-        pse_labels: List[ObjectLabels] = []
+        lab = lcnt = ready = None
         if feats is not None:
             preds, _ = self.mdl.forward_detect(backbone_features=feats)
-            dets = postprocess(prediction=preds, num_classes=self.num_classes,
-                               conf_thre=self.mdl_config.postprocess.confidence_threshold,
-                               nms_thre=self.mdl_config.postprocess.nms_threshold,
-                               pad=th.zeros((0, 7), device=preds.device))
-            pse_labels = pred2label(dets, obj_thresh=self.mdl_config.pseudo_label.obj_thresh,
-                                    cls_thresh=self.mdl_config.pseudo_label.cls_thresh, filter_bbox_fn=self.filter_bbox_fn,
-                                    hw=tuple(self.dst_config.ev_repr_hw), dataset_name=self.dst_name,
-                                    downsampled_by_2=self.ds_by2)
-        all_labels = [[None] * L for _ in range(B)]
-        skipped_gt_pse_labels: List[ObjectLabels] = []
-        gi = pi = 0
-        for t in range(L):
-            for b in range(B):
-                if skipped_gt_mask[t, b]:
-                    assert pse_mask[t, b], 'should predict on skipped GT frames'
-                    skipped_gt_pse_labels.append(pse_labels[pi])
-                if pse_mask[t, b]:
-                    all_labels[b][t] = pse_labels[pi]
-                    pi += 1
-                elif gt_mask[t, b]:
-                    all_labels[b][t] = gt_labels[gi]
-                    gi += 1
-        assert pi == int(pse_mask.sum()) and gi == int(gt_mask.sum()) and len(skipped_gt_pse_labels) == len(skipped_gt_labels)
-        if skipped_gt_labels and mode in self.mode_2_psee_evaluator:
-            # quality of the pseudo labels on frames whose GT was withheld (reference :753-763): detection KPIs at the end of the
-            # run (``run_psee_evaluator``; gathered over ranks by ``leod_amd.predict.run_pseudo_labeling``)
-            from leod_amd.utils.evaluation.prophesee.io.box_loading import to_prophesee
-            labels_proph, preds_proph = to_prophesee(skipped_gt_labels, skipped_gt_pse_labels)
-            self.mode_2_psee_evaluator[mode].add_labels(labels_proph)
-            self.mode_2_psee_evaluator[mode].add_predictions(preds_proph)
-        ev_idx = th.stack(data[DataType.EV_IDX]).transpose(1, 0).cpu().numpy().tolist()
-        padding = th.stack(data[DataType.IS_PADDED_MASK]).transpose(1, 0).cpu().numpy().tolist()
-        return (all_labels, data[DataType.PATH], ev_idx, is_first.cpu().numpy().tolist(),
-                data[DataType.IS_LAST_SAMPLE].cpu().numpy().tolist(), padding, data['is_hflip'],
-                data[DataType.IS_REVERSED].cpu().numpy().tolist())
+            # postprocess + pred2label (reference :724-741) in their padded, sync-free forms: NMS and the pseudo-label filters of all
+            # L * B frames are two launches -- the list forms cost one slice-copy launch per frame (672 per chunk of 32 streams x 21
+            # frames) on top of their own synchronisation
+            det, cnt = postprocess_padded(preds, self.num_classes, self.mdl_config.postprocess.confidence_threshold,
+                                          self.mdl_config.postprocess.nms_threshold)
+            lab, lcnt = pred2label_padded(det, cnt, self.mdl_config.pseudo_label.obj_thresh, self.mdl_config.pseudo_label.cls_thresh,
+                                          self.dst_name, self.ds_by2)
+            # The label rows and their counts go to the HOST in one asynchronous copy each, enqueued HERE -- behind this chunk's kernels
+            # and in front of whatever the caller enqueues next: everything that follows is per-frame bookkeeping (un-flip, merge of
+            # the TTA views, GT checks, scaling -- EventSeqData.update), which as device ops was ~1000 tiny launches and
+            # synchronisations per chunk (22 of 57 ms).  The final TTA merge moves its padded batch to the device again (utils/tta.py).
+            slot = self._host_slots[self._host_next] if self._host_slots else None
+            if slot is None or slot[0].shape != lab.shape:
+                self._host_slots = [(th.empty(lab.shape, dtype=lab.dtype).pin_memory(), th.empty(lcnt.shape, dtype=lcnt.dtype).pin_memory())
+                                    for _ in range(2)]
+                self._host_next = 0
+                slot = self._host_slots[0]
+            self._host_next = (self._host_next + 1) % 2
+            slot[0].copy_(lab, non_blocking=True)
+            slot[1].copy_(lcnt, non_blocking=True)
+            ready = th.cuda.Event()
+            ready.record()
+            lab, lcnt = slot
 
-    def predict_step(self, batch: Any, batch_idx: int = 0) -> None:
-        out = self._predict_step_impl(batch=batch, mode=Mode.TEST)
+        def finish():
+            """The host half of the step: waits for THIS chunk's copies only (a pipelined caller has the next chunk enqueued already)."""
+            pse_labels: List[ObjectLabels] = []
+            if lab is not None:
+                ready.synchronize()
+                counts = lcnt.tolist()
+                if counts and min(counts) < 0:
+                    raise ops.LeodHipError('pred2label: an image overflowed the LDS candidate arrays and no workspace was given')
+                hw_lab = tuple(self.dst_config.ev_repr_hw)
+                rows = lab[:, :max(1, max(counts))].clone()        # the pinned slot is reused two chunks later
+                pse_labels = [ObjectLabels(rows[i, :n], hw_lab) for i, n in enumerate(counts)]
+            all_labels = [[None] * L for _ in range(B)]
+            skipped_gt_pse_labels: List[ObjectLabels] = []
+            gi = pi = 0
+            for t in range(L):
+                for b in range(B):
+                    if skipped_gt_mask[t, b]:
+                        assert pse_mask[t, b], 'should predict on skipped GT frames'
+                        skipped_gt_pse_labels.append(pse_labels[pi])
+                    if pse_mask[t, b]:
+                        all_labels[b][t] = pse_labels[pi]
+                        pi += 1
+                    elif gt_mask[t, b]:
+                        all_labels[b][t] = gt_labels[gi]
+                        gi += 1
+            assert pi == int(pse_mask.sum()) and gi == int(gt_mask.sum()) and len(skipped_gt_pse_labels) == len(skipped_gt_labels)
+            if skipped_gt_labels and mode in self.mode_2_psee_evaluator:
+                # quality of the pseudo labels on frames whose GT was withheld (reference :753-763): detection KPIs at the end of the
+                # run (``run_psee_evaluator``; gathered over ranks by ``leod_amd.predict.run_pseudo_labeling``)
+                from leod_amd.utils.evaluation.prophesee.io.box_loading import to_prophesee
+                labels_proph, preds_proph = to_prophesee(skipped_gt_labels, skipped_gt_pse_labels)
+                self.mode_2_psee_evaluator[mode].add_labels(labels_proph)
+                self.mode_2_psee_evaluator[mode].add_predictions(preds_proph)
+            return (all_labels, data[DataType.PATH], ev_idx_l, first_l, last_l, padding_l, data['is_hflip'], reversed_l)
+
+        # small host-side lists of the chunk, read now (host tensors from the loader; device ones cost their copy here, not later)
+        ev_idx_l = th.stack(data[DataType.EV_IDX]).transpose(1, 0).cpu().numpy().tolist()
+        padding_l = th.stack(data[DataType.IS_PADDED_MASK]).transpose(1, 0).cpu().numpy().tolist()
+        first_l = first_host
+        last_l = data[DataType.IS_LAST_SAMPLE].cpu().numpy().tolist()
+        reversed_l = data[DataType.IS_REVERSED].cpu().numpy().tolist()
+        return finish
+
+    def _consume(self, out) -> None:
         for labels, path, ev_idx, is_first, is_last, padded, hflip, tflip in zip(*out):
             if not path:                                      # padding slot of the streaming loader
                 assert not is_first and not is_last and all(padded) and all(i == -1 for i in ev_idx), 'invalid empty data'
@@ -384,3 +420,21 @@ class PseudoLabeler(Module):
             self.ev_path_2_ev_data[path].update(labels=labels, ev_idx=ev_idx, is_last_sample=is_last,
                                                 is_padded_mask=padded, is_hflip=bool(hflip), is_tflip=bool(tflip),
                                                 tflip_offset=self.dst_config.data_augmentation.tflip_offset)
+
+    def flush_predictions(self) -> None:
+        """Pipelined mode: finish the chunk whose host half is still outstanding (call after the last ``predict_step``)."""
+        pend, self._pending = self._pending, None
+        if pend is not None:
+            self._consume(pend())
+
+    def predict_step(self, batch: Any, batch_idx: int = 0) -> None:
+        """One chunk (reference :622-796).  ``self.pipelined`` (set by ``leod_amd.predict.run_pseudo_labeling``): the device work of chunk
+        i is enqueued, THEN the host bookkeeping of chunk i - 1 runs under it; ``flush_predictions()`` finishes the last chunk.  Default:
+        both halves here, the results are in ``ev_path_2_ev_data`` when the call returns."""
+        finish = self._predict_step_impl(batch=batch, mode=Mode.TEST)
+        if not self.pipelined:
+            self._consume(finish())
+            return
+        pend, self._pending = self._pending, finish
+        if pend is not None:
+            self._consume(pend())

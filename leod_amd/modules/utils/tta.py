@@ -22,12 +22,18 @@ def tta_postprocess(preds: List[th.Tensor], conf_thre: float = 0.7, nms_thre: fl
         return out
     nmax = max(preds[i].shape[0] for i in live)
     dev = preds[live[0]].device
-    rows = th.zeros((len(live), nmax, 7), dtype=th.float32, device=dev)
+    on_host = dev.type == 'cpu'            # host-resident label rows (the pseudo-label loop keeps them there): assemble on the host,
+    rows = th.zeros((len(live), nmax, 7), dtype=th.float32, device=dev)       # one copy to the device, one copy of the result back
     rows[:, :, 4] = -1.0
     for j, i in enumerate(live):
         rows[j, :preds[i].shape[0]] = preds[i]
+    if on_host:
+        rows = rows.to(th.device('cuda', th.cuda.current_device()))
     det, cnt = tta_postprocess_padded(rows, conf_thre, nms_thre, class_agnostic)
-    for j, (i, n) in enumerate(zip(live, ops.host_counts(cnt, 'tta_postprocess'))):
+    counts = ops.host_counts(cnt, 'tta_postprocess')
+    if on_host:
+        det = det[:, :max(1, max(counts))].cpu()
+    for j, (i, n) in enumerate(zip(live, counts)):
         if n > 0:
             out[i] = det[j, :n]
     return out

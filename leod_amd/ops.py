@@ -870,12 +870,26 @@ def host_counts(cnt, what='postprocess_nms'):
     return counts
 
 
+_THRESHOLDS = {}
+
+
+def _threshold_tensor(thr, device):
+    """Per-class thresholds as a device tensor, uploaded once per distinct value (a fresh pageable upload per call made every
+    pseudo-label chunk wait for the device at this point)."""
+    key = ((float(thr),) if isinstance(thr, (float, int)) else tuple(float(t) for t in thr), str(device))
+    t = _THRESHOLDS.get(key)
+    if t is None:
+        if len(_THRESHOLDS) > 64:
+            _THRESHOLDS.clear()
+        t = _THRESHOLDS[key] = torch.tensor(key[0], dtype=F32, device=device)
+    return t
+
+
 def pseudo_filter(det, cnt, obj_thr, cls_thr, filter_boxes, frame_hw):
     _ck(det, name='det')
     _ck(cnt, torch.int32, 'cnt')
     B, max_det, _ = det.shape
-    ot = torch.as_tensor([obj_thr] if isinstance(obj_thr, float) else list(obj_thr), dtype=F32, device=det.device)
-    ct = torch.as_tensor([cls_thr] if isinstance(cls_thr, float) else list(cls_thr), dtype=F32, device=det.device)
+    ot, ct = _threshold_tensor(obj_thr, det.device), _threshold_tensor(cls_thr, det.device)
     if ot.numel() != ct.numel():
         raise LeodHipError('obj_thresh and cls_thresh must both be floats or per-class lists of equal length')
     lab = torch.empty((B, max_det, 8), dtype=F32, device=det.device)

@@ -39,9 +39,15 @@ def run_pseudo_labeling(config, module, data_module, device: Optional[torch.devi
         batches = DevicePrefetcher(loader, module, device)
     else:
         batches = (module.transfer_batch_to_device(b, device, 0) for b in loader)
+    pipelined = hasattr(module, 'flush_predictions') and torch.device(device).type == 'cuda'
+    if pipelined:
+        module.pipelined = True                # host bookkeeping of chunk i - 1 under the device work of chunk i
     with torch.no_grad():
         for i, batch in enumerate(batches):
             module.predict_step(batch, i)
+        if pipelined:
+            module.flush_predictions()
+            module.pipelined = False
     saved = []
     if save and module.save_dir:
         if rank == 0:

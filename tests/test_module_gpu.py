@@ -125,7 +125,8 @@ def test_validation_steps_and_evaluator_vs_oracle(gpu, manifest):
     assert not mod.mode_2_psee_evaluator[Mode.VAL].has_data()
 
 
-def test_pseudo_labeler_predict_step_vs_oracle(gpu, manifest):
+@pytest.mark.parametrize('pipelined', [False, True])
+def test_pseudo_labeler_predict_step_vs_oracle(gpu, manifest, pipelined):
     """PseudoLabeler.predict_step over two streaming batches with horizontal-flip TTA and one GT frame: what lands in
     EventSeqData after aggregation (un-flipped, TTA-merged labels per frame; GT stored once, GT frames not predicted) vs the oracle's inference + pred2label + tta_postprocess (pseudo_labeler.py:107-177,458-495,622-770)."""
     from leod_amd.config import full_config, dynamically_modify_train_config
@@ -147,6 +148,7 @@ def test_pseudo_labeler_predict_step_vs_oracle(gpu, manifest):
     mod.mdl.load_state_dict(sd)
     mod.to(DEV).eval()
     mod.setup('predict')
+    mod.pipelined = pipelined          # True: the host half of a chunk runs under the device half of the next one (as run_pseudo_labeling drives it)
     L, B, W = 4, 2, HW[1]
     gt = micro_labels(1, 77, [1234567.0])[0]
     states, want = None, {0: {}, 1: {}}
@@ -185,6 +187,9 @@ def test_pseudo_labeler_predict_step_vs_oracle(gpu, manifest):
                 merged = op.tta_postprocess([xyxy], 0.01, 0.45)[0]
                 if merged is not None:
                     want[b][frame] = ('pse', merged)
+    if pipelined:
+        assert not mod.ev_path_2_ev_data['rec/seqA'].eoe, 'the last chunk is still pending'
+        mod.flush_predictions()
     assert set(mod.ev_path_2_ev_data) == {'rec/seqA', 'rec/seqB'}
     total = 0
     for b, path in enumerate(['rec/seqA', 'rec/seqB']):
