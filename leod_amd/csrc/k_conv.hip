@@ -64,10 +64,12 @@ LEOD_API int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bia
     const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
     const int M = B * Ho * Wo, K = ks * ks * Cin;
     // PAFPN / head 3x3 convs in precision mode bf16: direct convolution from an LDS-resident input halo (k_conv3.hip)
-    if (ks == 3 && stride == 1 && pad == 1 && !bias && !bn_w && wpack && conv3s1_supported(H, W, Cin, N))
-        return conv3s1_launch(x, w, y, colstats, stat_rep, 0, B, H, W, Cin, N, 0, wpack, stream, 1, wpack_valid);
-    if (ks == 3 && stride == 2 && pad == 1 && !bias && !bn_w && wpack && conv3s2_fwd_supported(B, H, W, Cin, N))
-        return conv3s1_launch(x, w, y, colstats, stat_rep, 0, B, H, W, Cin, N, 0, wpack, stream, 2, wpack_valid);
+    // (eval mode, bn_w != NULL: the folded BatchNorm + SiLU run in the direct kernel's row epilogue -- the pseudo-label pass spent a third
+    // of its device time in the implicit-GEMM form of these convs)
+    if (ks == 3 && stride == 1 && pad == 1 && !bias && !(bn_w && colstats) && wpack && conv3s1_supported(H, W, Cin, N))
+        return conv3s1_launch(x, w, y, colstats, stat_rep, 0, B, H, W, Cin, N, 0, wpack, stream, 1, wpack_valid, bn_w, bn_b, bn_rm, bn_rv, bn_eps);
+    if (ks == 3 && stride == 2 && pad == 1 && !bias && !(bn_w && colstats) && wpack && conv3s2_fwd_supported(B, H, W, Cin, N))
+        return conv3s1_launch(x, w, y, colstats, stat_rep, 0, B, H, W, Cin, N, 0, wpack, stream, 2, wpack_valid, bn_w, bn_b, bn_rm, bn_rv, bn_eps);
     EpStore ep = conv_epilogue(y, N, bias, colstats, stat_rep, bn_w, bn_b, bn_rm, bn_rv, bn_eps);
     const int nt = pick_nt(N);
     int rc = LEOD_OK;

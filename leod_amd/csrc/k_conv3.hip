@@ -39,10 +39,13 @@ __global__ __launch_bounds__(256) void conv3_pack_kernel(const float* __restrict
 // S = 2 (forward only): the stride-2 convs of the backbone / PAFPN -- output pixel (oy, ox) reads halo pixel (2 oy + ky, 2 ox + kx);
 // H, W are the INPUT size, the pixel-row stride of the halo keeps the 16 lanes of a fragment read in different banks at DOUBLE the
 // pixel distance (dword stride of 2 pixels == 8 (mod 16) for the 16-byte reads, 4 * odd for the 8-byte reads)
+// eval-mode BaseConv: y = silu((conv - running_mean) * w / sqrt(running_var + eps) + b) applied to the finished rows (w == NULL: plain conv)
+struct BnEval { const float* w; const float* b; const float* rm; const float* rv; float eps; };
+
 template <int KC, int NTO, int TW, int S = 1>
 __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wp, float* __restrict__ y,
                                                        double* __restrict__ colstats, int stat_rep, int accumulate,
-                                                       int B, int H, int W, int Cout, int RH) {
+                                                       int B, int H, int W, int Cout, int RH, BnEval bne) {
     constexpr bool K32 = KC % 2 == 0;
     // operand rows (halo pixels, weight rows): bf16 rows whose dword stride is 4 * odd for the 8-byte fragment reads of the 16-k MFMA
     // and == 8 (mod 16) for the 16-byte reads of the 32-k MFMA (conflict-free ds_read_b64 / ds_read_b128, MI355X_MICROARCH.md LDS)
@@ -177,9 +180,21 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
     float* yb = y + ((long)(b * Ho + y0) * Wo) * Cout + co0;
     // the whole fragment loop once per value of `accumulate`: with the read-modify-write arm inside the row loop every row group ended at
     // a join with a pending load, where hipcc drains vmcnt -- i.e. each 16-byte store waited for the previous one's acknowledgement
-    auto rows_out = [&](auto accc) {
+    auto rows_out = [&](auto accc, auto bnc) {
         constexpr bool ACC = decltype(accc)::value;
+        constexpr bool BNE = decltype(bnc)::value;
         constexpr int NK = (16 * NTO * 4 + 63) / 64;
+        f4 bsc[BNE ? NK : 1], bsh[BNE ? NK : 1];               // folded scale / shift of this lane's column slots (one per store slot k)
+        if constexpr (BNE) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int idx = min(k * 64 + lane, 16 * NTO * 4 - 1);
+                const int c4 = (idx % (NTO * 4)) * 4 + co0;
+                const f4 w4 = ld4(bne.w + c4), b4 = ld4(bne.b + c4), m4 = ld4(bne.rm + c4), v4 = ld4(bne.rv + c4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bsc[k][j] = w4[j] * rsqrtf(v4[j] + bne.eps); bsh[k][j] = b4[j] - m4[j] * bsc[k][j]; }
+            }
+        }
 #pragma unroll
         for (int t = 0; t < TW; ++t) {
             if (!tok[t]) continue;                                             // wave-uniform
@@ -211,6 +226,10 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
                 if (idx < 16 * NTO * 4 && p < P) {
                     f4 v = *reinterpret_cast<const f4*>(so + row * LDO + c4);
                     if constexpr (ACC) v += old[k];
+                    if constexpr (BNE) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = siluf_(fmaf(v[j], bsc[k][j], bsh[k][j]));
+                    }
                     *reinterpret_cast<f4*>(yb + (long)p * Cout + c4) = v;
                 }
             }
@@ -218,7 +237,9 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
             __builtin_amdgcn_wave_barrier();
         }
     };
-    if (accumulate) rows_out(std::true_type{}); else rows_out(std::false_type{});
+    if (bne.w) rows_out(std::false_type{}, std::true_type{});
+    else if (accumulate) rows_out(std::true_type{}, std::false_type{});
+    else rows_out(std::false_type{}, std::false_type{});
     if (colstats) {
         double* cst = colstats + (stat_rep > 1 ? (size_t)((blockIdx.x * 4 + wave) & (stat_rep - 1)) * 2 * Cout : 0);
 #pragma unroll
@@ -701,7 +722,10 @@ size_t conv3s1_pack_bytes(int Cin, int Cout) { return (size_t)9 * Cin * Cout * s
 // x [B,H,W,Cin] -> y [B,H,W,Cout].  transposed = 0: y = conv3x3(x, w[Cout][Cin][3][3]); 1: the dgrad of a conv whose weight is
 // w[Cin][Cout][3][3] (x = dy).  wpack: scratch of conv3s1_pack_bytes.
 int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, int stat_rep, int accumulate, int B, int H, int W,
-                   int Cin, int Cout, int transposed, void* wpack, hipStream_t stream, int stride, int packed) {
+                   int Cin, int Cout, int transposed, void* wpack, hipStream_t stream, int stride, int packed,
+                   const float* bn_w, const float* bn_b, const float* bn_rm, const float* bn_rv, float bn_eps) {
+    const BnEval bne{bn_w, bn_b, bn_rm, bn_rv, bn_eps};
+    if (bn_w && (accumulate || colstats || !bn_b || !bn_rm || !bn_rv)) return LEOD_ERR_ARG;
     bf16_t* wp = reinterpret_cast<bf16_t*>(wpack);
     const long total = (long)9 * Cin * Cout;
     // the packed layout is [tap][out rows][k]; for the dgrad the stored weight is [N = Cin of this call][C = Cout of this call]
@@ -723,7 +747,7 @@ int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, i
             hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3s1_kernel<KCV, NTOV, TWV, SV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_set = true;                                                                                                         \
         }                                                                                                                            \
-        hipLaunchKernelGGL((conv3s1_kernel<KCV, NTOV, TWV, SV>), grid, dim3(256), smem, stream, x, wp, y, colstats, stat_rep, accumulate, B, H, W, Cout, RH); \
+        hipLaunchKernelGGL((conv3s1_kernel<KCV, NTOV, TWV, SV>), grid, dim3(256), smem, stream, x, wp, y, colstats, stat_rep, accumulate, B, H, W, Cout, RH, bne); \
         return leod_launch_status();                                                                                                 \
     }
     C3_CASE(3, 3, 1) C3_CASE(3, 6, 1) C3_CASE(6, 3, 1) C3_CASE(6, 6, 1) C3_CASE(12, 3, 1) C3_CASE(12, 6, 1)
