@@ -52,7 +52,7 @@ __device__ __forceinline__ constexpr int wgw_slot_off(int e) {
 // dynamic LDS of a workgroup: the double-buffered staging, or the accumulator exchange of waves that split the row steps (MS of them)
 template <int TN, int TK, int RC, int MS = 1>
 constexpr int wgw_lds_bytes() {
-    return 2 * ((RC / 16) * (TN + TK) * 272) * 2 > (MS - 1) * 12 * 1024 ? 2 * ((RC / 16) * (TN + TK) * 272) * 2 : (MS - 1) * 12 * 1024;
+    return 2 * ((RC / 16) * (TN + TK) * 272) * 2 > (MS - 1) * 12 * 1024 ? 2 * ((RC / 16) * (TN + TK) * 272) * 2 : (MS - 1) * 12 * 1024;   // (MS > 1 only with 3 x 3 tiles per wave)
 }
 
 // TN x TK: 16 x 16 tiles of the workgroup's dW tile; NWN x NWK: wave grid over it (each wave 3 x 3 tiles; waves left over split the
@@ -62,7 +62,13 @@ __global__ __launch_bounds__(256, OCC) void wgrad_wide_bf16_kernel(const void* _
                                                                     float* dbias, f4* __restrict__ part, int M, int N, int K, int dbg) {
     constexpr int WA = TN / NWN, WB = TK / NWK, MS = 4 / (NWN * NWK), KS = RC / 32;
     constexpr bool K16 = KS % MS != 0;              // the waves split 16-row steps instead (16-k MFMA): the 48 x 48 tile
-    static_assert(WA == 3 && WB == 3 && NWN * NWK * MS == 4 && (RC / 16) % MS == 0, "4 waves of 3 x 3 tiles");
+    // a wave holds WA x WB tiles: 3 x 3, or (stages 2-4) 6 x 3 / 3 x 6 -- 192 x 96 / 96 x 192 outputs per workgroup, so that the fp32 operand
+    // is fetched by half as many workgroups.  Measured (tools/wgrad_big_ab.sh): -2 % on the 54 k / 13 k-row launches, 0.1-0.2 ms per step;
+    // those launches are bound by the latency of ONE chunk of loads in flight per workgroup (~3 us per 32-row chunk at 2-3 workgroups per CU:
+    // cutting their L2 traffic by a third changed little, and a second chunk in flight spilled at this register budget: 79 -> 103-134 us).
+    constexpr int NSL = WA * WB + WA;                   // 64-lane f4 slots of a wave's partial: its tiles, then its column-sum tiles
+    static_assert((WA == 3 || WA == 6) && (WB == 3 || WB == 6) && WA * WB <= 18 && NWN * NWK * MS == 4 && (RC / 16) % MS == 0 &&
+                  (MS == 1 || (WA == 3 && WB == 3)), "4 waves of 3 x 3, 6 x 3 or 3 x 6 tiles");
     constexpr int BST = 16 * 16 + 16;
     constexpr int DCW = DYF ? 8 : 4, XCW = XM >= 2 ? 8 : 4;                 // columns per 16-byte load
     constexpr int DSPR = 16 * TN / DCW, XSPR = 16 * TK / XCW;
@@ -286,8 +292,8 @@ __global__ __launch_bounds__(256, OCC) void wgrad_wide_bf16_kernel(const void* _
 #pragma unroll
             for (int a = 0; a < WA; ++a) {
 #pragma unroll
-                for (int b = 0; b < WB; ++b) sred[((ws - 1) * 12 + a * WB + b) * 64 + lane] = acc[a][b];
-                sred[((ws - 1) * 12 + 9 + a) * 64 + lane] = bacc[a];
+                for (int b = 0; b < WB; ++b) sred[((ws - 1) * NSL + a * WB + b) * 64 + lane] = acc[a][b];
+                sred[((ws - 1) * NSL + WA * WB + a) * 64 + lane] = bacc[a];
             }
         }
         __syncthreads();
@@ -297,8 +303,8 @@ __global__ __launch_bounds__(256, OCC) void wgrad_wide_bf16_kernel(const void* _
 #pragma unroll
             for (int a = 0; a < WA; ++a) {
 #pragma unroll
-                for (int b = 0; b < WB; ++b) acc[a][b] += sred[(o * 12 + a * WB + b) * 64 + lane];
-                bacc[a] += sred[(o * 12 + 9 + a) * 64 + lane];
+                for (int b = 0; b < WB; ++b) acc[a][b] += sred[(o * NSL + a * WB + b) * 64 + lane];
+                bacc[a] += sred[(o * NSL + WA * WB + a) * 64 + lane];
             }
     }
     if (dbg & 1) return;
@@ -322,12 +328,12 @@ __global__ __launch_bounds__(256, OCC) void wgrad_wide_bf16_kernel(const void* _
         // from here: 1024 workgroups x 9216 elements on the SAME addresses took 130 us of a 200 us launch, see the header of the reduce.)
         constexpr int NW = NWN * NWK;
         const long tile = (long)blockIdx.y * gridDim.z + blockIdx.z, ntiles = (long)gridDim.y * gridDim.z;
-        f4* dst = part + (((long)blockIdx.x * ntiles + tile) * NW + (wk * NWN + wn)) * (12 * 64) + lane;
+        f4* dst = part + (((long)blockIdx.x * ntiles + tile) * NW + (wk * NWN + wn)) * (NSL * 64) + lane;
 #pragma unroll
         for (int a = 0; a < WA; ++a) {
 #pragma unroll
             for (int b = 0; b < WB; ++b) dst[(a * WB + b) * 64] = acc[a][b];
-            if (bias_out && a % NWK == wk) dst[(9 + a) * 64] = bacc[a];
+            if (bias_out && a % NWK == wk) dst[(WA * WB + a) * 64] = bacc[a];
         }
         return;
     }
@@ -361,13 +367,13 @@ __global__ __launch_bounds__(256, OCC) void wgrad_wide_bf16_kernel(const void* _
 template <int TN, int TK, int NWN, int NWK>
 __global__ __launch_bounds__(256) void wgrad_wide_reduce_kernel(const f4* __restrict__ part, int gx, int ny, int nz, int per, float* dW, long ldw,
                                                                 float* dbias, int N, int K) {
-    constexpr int NW = NWN * NWK, WA = TN / NWN, WB = TK / NWK;
-    const long O = (long)ny * nz * NW * 12 * 64;
+    constexpr int NW = NWN * NWK, WA = TN / NWN, WB = TK / NWK, NT9 = WA * WB, NSL = NT9 + WA;
+    const long O = (long)ny * nz * NW * NSL * 64;
     const long o = (long)blockIdx.x * 256 + threadIdx.x;
     if (o >= O) return;
-    const int lane = (int)(o & 63), t = (int)((o >> 6) % 12), w = (int)((o / (64 * 12)) % NW), tile = (int)(o / (64 * 12 * NW));
+    const int lane = (int)(o & 63), t = (int)((o >> 6) % NSL), w = (int)((o / (64 * NSL)) % NW), tile = (int)(o / (64 * NSL * NW));
     const int ty = tile / nz, tz = tile - ty * nz, wn = w % NWN, wk = w / NWN, i = lane & 15, q = lane >> 4;
-    if (t >= 9 && !(dbias != nullptr && tz == 0 && (t - 9) % NWK == wk && i == 0)) return;
+    if (t >= NT9 && !(dbias != nullptr && tz == 0 && (t - NT9) % NWK == wk && i == 0)) return;
     const int g0 = blockIdx.y * per, g1 = min(gx, g0 + per);
     f4 s0 = zero4(), s1 = zero4(), s2 = zero4(), s3 = zero4();
     const f4* p = part + (long)g0 * O + o;
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_reduce_kernel(const f4* __rest
     for (; g < g1; ++g, p += O) s0 += p[0];
     const f4 v = (s0 + s1) + (s2 + s3);
     const bool single = gridDim.y == 1;
-    if (t < 9) {
+    if (t < NT9) {
         const int a = t / WB, b = t - a * WB;
         const int k = tz * TK * 16 + 16 * (wk * WB + b) + i;
 #pragma unroll
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_reduce_kernel(const f4* __rest
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int n = ty * TN * 16 + 16 * (wn * WA + (t - 9)) + 4 * q + r;
+            const int n = ty * TN * 16 + 16 * (wn * WA + (t - NT9)) + 4 * q + r;
             if (n < N) { if (single) dbias[n] += v[r]; else atomicAdd(dbias + n, v[r]); }
         }
     }
@@ -439,8 +445,8 @@ static inline int launch_wgrad_wide_cfg(const void* dy, long lddy, const XRows& 
     static bool attr_set = false;                             // dynamic LDS opt-in, once per instantiation
     if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
     static const int use_part = getenv("LEOD_WGRAD_WIDE_PART") ? atoi(getenv("LEOD_WGRAD_WIDE_PART")) : 1;
-    constexpr int NW = NWN * NWK;
-    const long O = (long)tiles * NW * 12 * 64;                // f4 per partial
+    constexpr int NW = NWN * NWK, NSL = (TN / NWN) * (TK / NWK) + TN / NWN;
+    const long O = (long)tiles * NW * NSL * 64;               // f4 per partial
     f4* part = (use_part && gx > 1) ? wgrad_wide_scratch(s, (size_t)gx * O * sizeof(f4)) : nullptr;
     hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, dy, lddy, xl, dW, ldw, dbias, part, M, N, K, dbg);
     if (part != nullptr && !(dbg & 1)) {
@@ -466,6 +472,11 @@ static inline int wgrad_wide_combo(const XRows& xl, int N, int K, int dyfmt) {
     if (N <= 48 && K <= 48) return c == 0 ? 1 : c == 3 ? 8 : 0;
     if (K <= 48) return c == 5 ? 2 : 0;
     if (N <= 48) return c == 2 ? 3 : 0;
+    // 192-wide tiles along the 16-bit operand's side: 192 x 96 outputs for bf16 dY with fp32 X (qkv, fc1, ConvLSTM), 96 x 192 for fp32 dY
+    // with 16-bit X (fc2 on the fp16 hidden, proj on bf16 O)
+    static const int big = getenv("LEOD_WGRAD_WIDE_BIG") ? atoi(getenv("LEOD_WGRAD_WIDE_BIG")) : 1;
+    if (big && N % 192 == 0 && K >= 96 && (c == 5 || c == 4)) return c == 5 ? 10 : 11;
+    if (big && K % 192 == 0 && N >= 96 && (c == 2 || c == 3)) return c == 2 ? 12 : 13;
     return c == 0 ? 4 : c == 5 ? 5 : c == 2 ? 6 : c == 4 ? 7 : c == 3 ? 9 : 0;
 }
 static inline bool use_wgrad_wide(const XRows& xl, long lddy, int M, int N, int K, int dyfmt) {
@@ -491,6 +502,10 @@ static inline int launch_wgrad_wide(const void* dy, long lddy, const XRows& xl, 
         case 7: LEOD_WGW(6, 6, 2, 2, 32, 1, 0, 3);
         case 8: LEOD_WGW(3, 3, 1, 1, 64, 0, 3, 2);
         case 9: LEOD_WGW(6, 6, 2, 2, 32, 0, 3, 3);
+        case 10: LEOD_WGW(12, 6, 2, 2, 32, 1, 1, 2);
+        case 11: LEOD_WGW(12, 6, 2, 2, 32, 1, 0, 2);
+        case 12: LEOD_WGW(6, 12, 2, 2, 64, 0, 2, 2);
+        case 13: LEOD_WGW(6, 12, 2, 2, 32, 0, 3, 2);
     }
 #undef LEOD_WGW
     return LEOD_ERR_UNSUPPORTED;

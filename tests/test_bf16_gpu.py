@@ -284,6 +284,9 @@ def test_mlp_hidden_stored_once_as_fp16(bf16_ops, M, C):
     (20011, 384, 192, True, 'concat'), (8705, 768, 384, True, 'concat'),      # ConvLSTM 1x1 on [x | h] with bf16 gate gradients
     (20011, 384, 192, False, 'concat'),
     (40009, 48, 48, False, 'rows16'), (20011, 96, 96, False, 'rows16'), (9001, 192, 192, False, 'rows16'),    # proj from the bf16 attention output
+    # 192 x 96 / 96 x 192 workgroup tiles (round 4: six tiles per wave along the 16-bit operand), stage-4 and ragged shapes
+    (13440, 1536, 384, True, 'ln'), (8705, 1152, 384, True, 'ln'), (8707, 384, 96, True, 'ln'), (13440, 384, 1536, False, 'gelu16'),
+    (8705, 1536, 768, True, 'concat'), (8201, 384, 384, False, 'rows16'),
 ])
 def test_wgrad_wide_bf16(bf16_ops, M, N, K, dy16, xmode):
     import torch.nn.functional as F
