@@ -262,6 +262,17 @@ int leod_pseudo_filter(const float* det, const int* det_cnt, float* lab, int* la
 int leod_adamw_clip_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                          float weight_decay, int step, float clip_value, float grad_scale, const float* hp_dev,
                          leod_stream_t stream);
+/* bf16 shadow of a flat fp32 parameter buffer (the reference keeps ONE copy of the weights and lets autocast convert them per op,
+ * train.py:236-243 precision=16; here the Linear kernels of precision mode bf16 read a 16-bit copy made once per optimiser step).
+ * leod_set_weight_shadow registers shadow16 (n bf16 values, caller-owned) for the n floats at base (shadow16 == NULL withdraws it);
+ * leod_weight_shadow_refresh rounds the registered buffers whose shadow is stale (force != 0: all of them, flags untouched -- for a
+ * launch that is being recorded into a step plan / hipGraph) and returns the number of launches; leod_adamw_clip_step on a registered
+ * buffer and leod_weight_shadow_invalidate mark shadows stale (stale shadows are never read); leod_weight_shadow_pin(1) makes the
+ * launchers read the shadows regardless of the flags while a step is being recorded behind a forced refresh. */
+int leod_set_weight_shadow(const float* base, long n, void* shadow16);
+int leod_weight_shadow_refresh(int force, leod_stream_t stream);
+int leod_weight_shadow_invalidate(void);
+int leod_weight_shadow_pin(int on);
 /* dst[0..3] = (a,b,c,d) on the device (launch-time scalars for a replayed hipGraph). */
 int leod_set_scalars4(float* dst, float a, float b, float c, float d, leod_stream_t stream);
 /* Recurrent-state plumbing as one launch per call (host arrays of up to 16 entries; pointers and sizes 16-byte aligned):

@@ -155,4 +155,8 @@ template <bool BF> __device__ __forceinline__ f4 mfma_frag(const Frag16<BF>& a, 
 // Precision mode of the library (host side): 0 = fp32 end to end (bit-tight against the fp32 oracle), 1 = bf16 MFMA operands
 // with fp32 accumulation / statistics / state.  Set through leod_set_precision; read by the launchers.
 int leod_precision();
+// bf16 shadow of a registered fp32 weight buffer (k_misc.hip: leod_set_weight_shadow / leod_weight_shadow_refresh): the bf16 copy of
+// the weight at `w` if `w` lies in a registered buffer whose shadow is fresh, else nullptr.  The GEMM weight loaders of precision mode
+// bf16 read it instead of converting fp32 weights on every tile load (same rounding: pack_bf16) -- half the L2 -> CU bytes.
+const unsigned short* leod_shadow_of(const float* w);
 #define LEOD_BY_PREC(CALL_BF, CALL_F32) (leod_precision() == 1 ? (CALL_BF) : (CALL_F32))

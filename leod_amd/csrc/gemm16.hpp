@@ -294,11 +294,18 @@ struct BLRows {
     __device__ __forceinline__ f4 load_n4(int, int, int, int) const { return zero4(); }                 // W[n][k], row stride ld (torch Linear / 1x1 conv weight)
     template <int KCH> __device__ __forceinline__ f4 load2(int nblk, int t, int i, int k0, int bk, int Kt, int a = 0) const { return load(nblk, t, i, k0 + bk, Kt, a); }
     const float* w; long ld; int N; int NT;
+    const unsigned short* w16 = nullptr;          // bf16 shadow of w (leod_shadow_of), same indexing; precision mode bf16 only
     __device__ __forceinline__ int col(int nblk, int t, int i) const { return (nblk * NT + t) * 16 + i; }
     __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt, int = 0) const {
         const int n = col(nblk, t, i);
         if (n >= N || k >= Kt) return zero4();
         return ld4(w + (long)n * ld + k);
+    }
+    // four bf16 W[n][k..k+3] of the shadow (0 outside the matrix)
+    __device__ __forceinline__ u2_ load16(int nblk, int t, int i, int k, int Kt) const {
+        const int n = col(nblk, t, i);
+        if (n >= N || k >= Kt) return u2_{0u, 0u};
+        return *reinterpret_cast<const u2_*>(w16 + (long)n * ld + k);
     }
 };
 struct BLGates {
@@ -316,6 +323,12 @@ struct BLTrans {
     static constexpr bool kTrans = true;          // memory is contiguous along n (W[k][n]): stage with float4 along n                // B(n,k) = W[k][n]  (dgrad of a Linear: W is [Kred][N])
     template <int KCH> __device__ __forceinline__ f4 load2(int nblk, int t, int i, int k0, int bk, int Kt, int a = 0) const { return load(nblk, t, i, k0 + bk, Kt, a); }
     const float* w; long ld; int N; int NT;
+    const unsigned short* w16 = nullptr;          // bf16 shadow of w (leod_shadow_of), same indexing; precision mode bf16 only
+    __device__ __forceinline__ u2_ load_n4_16(int nblk, int nl, int k, int Kt) const {
+        const int n = nblk * NT * 16 + nl;
+        if (n >= N || k >= Kt) return u2_{0u, 0u};
+        return *reinterpret_cast<const u2_*>(w16 + (long)k * ld + n);
+    }
     __device__ __forceinline__ int col(int nblk, int t, int i) const { return (nblk * NT + t) * 16 + i; }
     __device__ __forceinline__ f4 load(int nblk, int t, int i, int k, int Kt, int = 0) const {
         const int n = col(nblk, t, i);
@@ -330,6 +343,23 @@ struct BLTrans {
         return ld4(w + (long)k * ld + n);
     }
 };
+// weight loaders that stage their tiles from the bf16 shadow (w16 != nullptr, set by the launchers): separate TYPES, so that the kernels
+// carry no run-time branch around their loads (a uniform branch inside the fetch block made the compiler wait for all loads at the join,
+// i.e. before the MFMAs the loads are supposed to fly under: 16.15 -> 16.8 ms per step)
+struct BLRows16 : BLRows {};
+struct BLTrans16 : BLTrans {};
+template <class BL> struct bl_is16 { static constexpr bool value = false; };
+template <> struct bl_is16<BLRows16> { static constexpr bool value = true; };
+template <> struct bl_is16<BLTrans16> { static constexpr bool value = true; };
+template <class BL> struct bl_shadow_type { typedef void type; };
+template <> struct bl_shadow_type<BLRows> { typedef BLRows16 type; };
+template <> struct bl_shadow_type<BLTrans> { typedef BLTrans16 type; };
+// (the four bf16 travel in the first two dwords of the f4 staging register; whole-vector bit casts -- per-element casts inside a braced
+// initialiser were folded by the compiler into ONE dword load duplicated into both halves)
+typedef unsigned u4s_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 shadow_bits(u2_ h) { const u4s_ u = {h.x, h.y, 0u, 0u}; return __builtin_bit_cast(f4, u); }
+__device__ __forceinline__ s4 shadow_s4(f4 v) { const u4s_ u = __builtin_bit_cast(u4s_, v); const u2_ r = {u.x, u.y}; return __builtin_bit_cast(s4, r); }
+
 struct BLConvW {
     static constexpr bool kTrans = false;
     __device__ __forceinline__ f4 load_n4(int, int, int, int) const { return zero4(); }                // conv weight [N][Cin][ks][ks] read as B(n, k' = tap*Cin + c)
@@ -1006,7 +1036,10 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
         for (int p = 0; p < RB; ++p) {
             rb[p] = zero4();
             if (bok[p]) {
-                if (!BL::kTrans) rb[p] = bl.template load2<KCH>(nblk, bn[p] >> 4, bn[p] & 15, k0, bk[p], K, aux);
+                if constexpr (BF && bl_is16<BL>::value) {   // four bf16 of the shadow, carried in rb[p].xy
+                    if constexpr (!BL::kTrans) rb[p] = shadow_bits(bl.load16(nblk, bn[p] >> 4, bn[p] & 15, k0 + bk[p], K));
+                    else rb[p] = shadow_bits(bl.load_n4_16(nblk, bn[p], k0 + bk[p], K));
+                } else if (!BL::kTrans) rb[p] = bl.template load2<KCH>(nblk, bn[p] >> 4, bn[p] & 15, k0, bk[p], K, aux);
                 else rb[p] = bl.load_n4(nblk, bn[p], k0 + bk[p], K);
             }
         }
@@ -1027,7 +1060,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
 #pragma unroll
             for (int p = 0; p < RA; ++p) if (aok[p]) *reinterpret_cast<s4*>(a16 + al_off[p]) = pack_bf16(ra[p]);
 #pragma unroll
-            for (int p = 0; p < RB; ++p) if (bok[p]) *reinterpret_cast<s4*>(b16 + bl_off[p]) = pack_bf16(rb[p]);
+            for (int p = 0; p < RB; ++p) if (bok[p]) *reinterpret_cast<s4*>(b16 + bl_off[p]) = bl_is16<BL>::value ? shadow_s4(rb[p]) : pack_bf16(rb[p]);
         } else {
 #pragma unroll
             for (int p = 0; p < RA; ++p) if (aok[p]) *reinterpret_cast<f4*>(&sA[buf][al_off[p]]) = ra[p];
@@ -1170,8 +1203,30 @@ static inline int launch_row_stats(const float* x, long ld, float* stats, int M,
     return leod_launch_status();
 }
 
+// host side: the loader type that reads the bf16 shadow, if the weights lie in a registered buffer with a fresh shadow (precision mode bf16;
+// only in translation units that ask for the extra instantiations: LEOD_SHADOW_KERNELS, the Linear layers of k_linear.hip)
+template <class BL> static inline const unsigned short* bl_shadow_ptr(const BL& bl) {
+#ifdef LEOD_SHADOW_KERNELS
+    if constexpr (!std::is_void<typename bl_shadow_type<BL>::type>::value) {
+        if (leod_precision() == 1 && !(bl.ld & 3)) return leod_shadow_of(bl.w);
+    }
+#endif
+    return nullptr;
+}
+template <class BL> static inline typename bl_shadow_type<BL>::type bl_as16(const BL& bl, const unsigned short* sh) {
+    typename bl_shadow_type<BL>::type b;
+    static_cast<BL&>(b) = bl;
+    b.w16 = sh;
+    return b;
+}
+
 template <int NT, int RW, class AL, class BL, class EP>
 static inline int launch_gemm_lds_rw(const AL& al, const BL& bl, const EP& ep, int M, int K, int nblocks_n, hipStream_t s) {
+#ifdef LEOD_SHADOW_KERNELS
+    if constexpr (!std::is_void<typename bl_shadow_type<BL>::type>::value) {
+        if (const unsigned short* sh = bl_shadow_ptr(bl)) return launch_gemm_lds_rw<NT, RW>(al, bl_as16(bl, sh), ep, M, K, nblocks_n, s);
+    }
+#endif
     dim3 grid(cdiv(cdiv(M, 64 * RW), 8) * 8 * nblocks_n);
     // single LDS buffer + register prefetch everywhere: residency (3-6 workgroups per CU) hides the two barriers per chunk
     // better than a double buffer at 2-3 workgroups per CU does (measured; LEOD_LDS_NBUF=2 selects the double buffer)

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_wide_bf16_kernel(AL al, BL b
     constexpr int ASZ = BM * LD;                     // bf16 elements
     constexpr int BSZ = BL::kTrans ? (KCH / 16) * NTB * BST : BN * LD;
     constexpr int LDO = 64;
-    static_assert(std::is_same<BL, BLRows>::value || std::is_same<BL, BLTrans>::value, "weights as W[n][k] or W[k][n]");
+    static_assert(std::is_base_of<BLRows, BL>::value || std::is_base_of<BLTrans, BL>::value, "weights as W[n][k] or W[k][n]");
     __shared__ __attribute__((aligned(16))) unsigned short sOp[2][ASZ + BSZ];       // double-buffered operand tiles
     __shared__ __attribute__((aligned(16))) float sOut[NWAVE][16 * LDO];                // wave-private transposition tiles of the epilogue
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -88,8 +88,10 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_wide_bf16_kernel(AL al, BL b
         al.raw_k(ka, raw_a[0]);                                // LayerNorm weight / bias, per-k scale: once per chunk and thread
 #pragma unroll
         for (int p = 0; p < RB; ++p) {
-            if constexpr (!BL::kTrans) rb[p] = ld4(bl.w + (long)min(ncol_f + bn[p], bl.N - 1) * bl.ld + min(k0 + bk[p], K - 4));
-            else rb[p] = ld4(bl.w + (long)min(k0 + bk[p], K - 1) * bl.ld + min(ncol_f + bn[p], bl.N - 4));
+            const long off = !BL::kTrans ? (long)min(ncol_f + bn[p], bl.N - 1) * bl.ld + min(k0 + bk[p], K - 4)
+                                         : (long)min(k0 + bk[p], K - 1) * bl.ld + min(ncol_f + bn[p], bl.N - 4);
+            if constexpr (bl_is16<BL>::value) rb[p] = shadow_bits(*reinterpret_cast<const u2_*>(bl.w16 + off));    // bf16 shadow: 8-byte loads, no conversion
+            else rb[p] = ld4(bl.w + off);
         }
     };
     auto stash = [&](int buf) {                                // raw registers -> operand values -> bf16 tiles of buffer `buf`
@@ -105,7 +107,8 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_wide_bf16_kernel(AL al, BL b
 #pragma unroll
         for (int p = 0; p < RB; ++p) {
             const bool ok = (ncol_f + bn[p] < bl.N) && (k0 + bk[p] < K);
-            *reinterpret_cast<s4*>(sB + b_off[p]) = pack_bf16(ok ? rb[p] : zero4());
+            if constexpr (bl_is16<BL>::value) *reinterpret_cast<s4*>(sB + b_off[p]) = ok ? shadow_s4(rb[p]) : s4{0, 0, 0, 0};
+            else *reinterpret_cast<s4*>(sB + b_off[p]) = pack_bf16(ok ? rb[p] : zero4());
         }
     };
     auto advance_fetch = [&]() -> bool {                       // next chunk of this workgroup's range; false: none left
@@ -240,6 +243,11 @@ static inline int gemm_wide_ntw(int M, int N, int K) {
 
 template <int NTW, class AL, class BL, class EP>
 static inline int launch_gemm_wide(const AL& al, const BL& bl, const EP& ep, int M, int K, int N, hipStream_t s) {
+#ifdef LEOD_SHADOW_KERNELS
+    if constexpr (!std::is_void<typename bl_shadow_type<BL>::type>::value) {
+        if (const unsigned short* sh = bl_shadow_ptr(bl)) return launch_gemm_wide<NTW>(al, bl_as16(bl, sh), ep, M, K, N, s);
+    }
+#endif
     const int nbn = cdiv(N, 64 * NTW);
     const long ntiles = (long)cdiv(M, 128) * nbn;
     static const int dbg = getenv("LEOD_WIDE_DBG") ? atoi(getenv("LEOD_WIDE_DBG")) : 0;

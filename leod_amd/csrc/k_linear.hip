@@ -3,6 +3,7 @@
 // ("rows" = tokens of an NHWC map).  C-ABI declared in include/leod_hip.h.
 #include <type_traits>
 
+#define LEOD_SHADOW_KERNELS 1        // bf16-shadow weight loaders for the Linear layers (gemm16.hpp: BLRows16 / BLTrans16)
 #include "gemm16.hpp"
 #include "wgrad_bf16.hpp"
 

@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void adamw_clip_kernel(float* __restrict__ p, 
     }
 }
 
+static void shadow_mark_stale(const float* p, long n);
 LEOD_API int leod_adamw_clip_step(float* p, float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                                   float eps, float weight_decay, int step, float clip_value, float grad_scale,
                                   const float* hp_dev, hipStream_t stream) {
@@ -34,7 +35,80 @@ LEOD_API int leod_adamw_clip_step(float* p, float* g, float* m, float* v, long n
     const int grid = (int)min((long)2048, (n + 255) / 256);
     hipLaunchKernelGGL(adamw_clip_kernel, dim3(grid), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
                        bc1, sqrtf(bc2), clip_value, grad_scale, hp_dev);
+    shadow_mark_stale(p, n);                          // bf16 shadows of these parameters (below) are out of date
     return leod_launch_status();
+}
+
+// ---- bf16 shadow of the flat parameter buffer ------------------------------------------------------------------------------------
+// In precision mode bf16 every GEMM rounds its fp32 weight tile to bf16 while staging it; the stage 2-4 Linear launches are bound by
+// the L2 -> CU traffic of exactly those tiles (5 040 workgroups x 98 KB of fp32 weights for one stage-4 dgrad).  A caller that owns a
+// flat parameter buffer registers a bf16 buffer of the same length; leod_weight_shadow_refresh() rounds the parameters into it (the
+// same pack_bf16 as the loaders: results are bit-identical) and marks it fresh; leod_adamw_clip_step() on a registered buffer and
+// leod_weight_shadow_invalidate() mark it stale, and stale shadows are not used (the loaders read the fp32 weights as before).
+// Recording a step for replay (stream capture): the caller records a forced refresh as the first launch of the step and pins the
+// shadows (leod_weight_shadow_pin) while it records, so that the recorded GEMMs read them; a replayed step then always starts from
+// fresh shadows, whatever happened to the parameters in between.
+#include <mutex>
+#include <vector>
+namespace {
+struct ShadowEntry { const float* base; long n; unsigned short* sh; bool fresh; };
+std::mutex g_shadow_mu;
+std::vector<ShadowEntry> g_shadows;
+bool g_shadow_pinned = false;
+}
+const unsigned short* leod_shadow_of(const float* w) {
+    if (!w) return nullptr;
+    std::lock_guard<std::mutex> lock(g_shadow_mu);
+    for (const ShadowEntry& e : g_shadows)
+        if ((e.fresh || g_shadow_pinned) && w >= e.base && w < e.base + e.n) return e.sh + (w - e.base);
+    return nullptr;
+}
+__global__ __launch_bounds__(256) void weight_shadow_kernel(const float* __restrict__ p, unsigned short* __restrict__ sh, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+        *reinterpret_cast<s4*>(sh + 4 * i) = pack_bf16(ld4(p + 4 * i));
+}
+// shadow16 == NULL (or n <= 0) withdraws the registration of `base`.  n % 4 == 0, base 16-byte and shadow16 8-byte aligned.
+LEOD_API int leod_set_weight_shadow(const float* base, long n, void* shadow16) {
+    if (!base) return LEOD_ERR_ARG;
+    std::lock_guard<std::mutex> lock(g_shadow_mu);
+    for (size_t k = 0; k < g_shadows.size(); ++k)
+        if (g_shadows[k].base == base) { g_shadows.erase(g_shadows.begin() + k); break; }
+    if (!shadow16 || n <= 0) return LEOD_OK;
+    if ((n & 3) || (reinterpret_cast<uintptr_t>(base) & 15) || (reinterpret_cast<uintptr_t>(shadow16) & 7)) return LEOD_ERR_ARG;
+    g_shadows.push_back(ShadowEntry{base, n, reinterpret_cast<unsigned short*>(shadow16), false});
+    return LEOD_OK;
+}
+LEOD_API int leod_weight_shadow_invalidate() {
+    std::lock_guard<std::mutex> lock(g_shadow_mu);
+    for (ShadowEntry& e : g_shadows) e.fresh = false;
+    return LEOD_OK;
+}
+LEOD_API int leod_weight_shadow_pin(int on) {
+    std::lock_guard<std::mutex> lock(g_shadow_mu);
+    g_shadow_pinned = on != 0;
+    return LEOD_OK;
+}
+// Rounds every registered buffer whose shadow is stale; force != 0: every buffer, and the freshness flags are left alone (for
+// launches that are being RECORDED, not executed).  Returns the number of launches (>= 0) or an error code.
+LEOD_API int leod_weight_shadow_refresh(int force, hipStream_t stream) {
+    static const int on = getenv("LEOD_WEIGHT_SHADOW") ? atoi(getenv("LEOD_WEIGHT_SHADOW")) : 1;
+    if (!on || leod_precision() != 1) return 0;
+    std::lock_guard<std::mutex> lock(g_shadow_mu);
+    int launches = 0;
+    for (ShadowEntry& e : g_shadows) {
+        if (e.fresh && !force) continue;
+        const long n4 = e.n / 4;
+        hipLaunchKernelGGL(weight_shadow_kernel, dim3((unsigned)min((long)2048, (n4 + 255) / 256)), dim3(256), 0, stream, e.base, e.sh, n4);
+        if (leod_launch_status() != LEOD_OK) return LEOD_ERR_LAUNCH;
+        if (!force) e.fresh = true;
+        ++launches;
+    }
+    return launches;
+}
+static void shadow_mark_stale(const float* p, long n) {
+    std::lock_guard<std::mutex> lock(g_shadow_mu);
+    for (ShadowEntry& e : g_shadows)
+        if (p < e.base + e.n && e.base < p + n) e.fresh = false;
 }
 
 // ---- stacked histogram ---------------------------------------------------------------------------

@@ -54,7 +54,11 @@ std::string g_err;
 
 int new_event(Plan& p) {
     hipEvent_t e;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
+    // the events only order lanes of ONE device against each other (hipStreamWaitEvent; the host never inspects them), so the system-scope
+    // fence of a default event is left out: 15.84 -> 15.70 ms per step (profiles/r04_a_graph_ab.txt).  LEOD_PLAN_EVENT_FLAGS=0 restores it.
+    static const unsigned extra = getenv("LEOD_PLAN_EVENT_FLAGS") ? (unsigned)strtoul(getenv("LEOD_PLAN_EVENT_FLAGS"), nullptr, 0)
+                                                                  : (unsigned)hipEventDisableSystemFence;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming | extra) != hipSuccess) return -1;
     p.events.push_back(e);
     return (int)p.events.size() - 1;
 }

@@ -438,7 +438,12 @@ static inline int launch_wgrad_wide_cfg(const void* dy, long lddy, const XRows& 
     const int tiles = cdiv(N, TN * 16) * cdiv(K, TK * 16), chunks = cdiv(M, RC);
     // all workgroups resident (OCC per CU); >= 2 chunks each; a multiple of 8 per output tile keeps the workgroups that stream the same
     // rows for different tiles on one XCD (see launch_wgradw_cfg)
-    int gx = max(1, min(chunks / 2, tune_wgs / tiles));
+    // launches of <= 60 k rows (stages 3-4) run beside the main lane's kernels and are latency-bound: 384 workgroups instead of OCC * 256
+    // leave wave slots to the other lane and halve the partial tiles (15.84 -> 15.76-15.79 ms per step, profiles/r04_a_graph_ab.txt)
+    static const int tune_small = getenv("LEOD_WGRAD_WIDE_WGS_SMALL") ? atoi(getenv("LEOD_WGRAD_WIDE_WGS_SMALL")) : 384;
+    static const int small_rows = getenv("LEOD_WGRAD_WIDE_SMALL_ROWS") ? atoi(getenv("LEOD_WGRAD_WIDE_SMALL_ROWS")) : 60000;
+    const int wgs = (tune_small > 0 && M <= small_rows) ? tune_small : tune_wgs;
+    int gx = max(1, min(chunks / 2, wgs / tiles));
     if (gx >= 16) gx &= ~7;
     dim3 grid(gx, cdiv(N, TN * 16), cdiv(K, TK * 16));
     auto kern = wgrad_wide_bf16_kernel<TN, TK, NWN, NWK, RC, DYF, XM, OCC>;

@@ -81,6 +81,7 @@ class TrainEngine:
         return self._idx_cache[key]
 
     def _step_body(self, ev_seq, labels, label_tb, is_first, states, hp_dev=None, lr=None, scale=1.0):
+        self.flat.ensure_shadow(force=torch.cuda.is_current_stream_capturing())   # bf16 copy of the weights for the Linear kernels
         self.flat.zero_grad()
         if not self._capturing and not torch.cuda.is_current_stream_capturing():
             self.dp.begin_step()                         # per-stage gradient buckets are exchanged under the backward pass
@@ -146,8 +147,12 @@ class TrainEngine:
         self._graph = torch.cuda.CUDAGraph(keep_graph=True) if plan else torch.cuda.CUDAGraph()
         side_in_graph, self.graph_side = self.graph_side, self.graph_side or plan
         ops.PackCache.invalidate()                                      # the capture must contain the weight packs of a step
-        with torch.cuda.graph(self._graph):
-            self._g_losses = self._graph_body()
+        ops.weight_shadow_pin(True)                                     # the recorded GEMMs read the shadow the recorded refresh writes
+        try:
+            with torch.cuda.graph(self._graph):
+                self._g_losses = self._graph_body()
+        finally:
+            ops.weight_shadow_pin(False)
         self.graph_side = side_in_graph
         self._capturing = False
         self._plan = ops.LaunchPlan(self._graph, max_lanes) if plan else None

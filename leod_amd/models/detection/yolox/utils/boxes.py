@@ -25,13 +25,17 @@ def postprocess_padded(prediction: torch.Tensor, num_classes: int, conf_thre=0.7
     return ops.postprocess_nms(prediction, num_classes, conf_thre, nms_thre, class_agnostic, max_det, GPU_VANILLA_LIMIT)
 
 
-def postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45, class_agnostic=False, pad=None) -> List:
+def postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45, class_agnostic=False, pad=None,
+                host: bool = False) -> List:
     """prediction [B,N,5+nc] (cx,cy,w,h,obj,cls..) -> list of [n_i,7] (x1,y1,x2,y2,obj,cls_conf,cls_id) in
-    score-descending order, ``pad`` where nothing survives."""
+    score-descending order, ``pad`` where nothing survives.  ``host=True`` hands the rows over as CPU tensors copied
+    in ONE transfer (for callers that convert every frame to numpy records, e.g. the validation step)."""
     if len(prediction) == 0:
         return []
     det, cnt = postprocess_padded(prediction, num_classes, conf_thre, nms_thre, class_agnostic)
     counts = ops.host_counts(cnt)              # the only host sync of the call (the API returns ragged lists)
+    if host:
+        det = det[:, :max(max(counts), 1)].cpu()
     return [det[i, :n] if n > 0 else pad for i, n in enumerate(counts)]
 
 

@@ -70,6 +70,7 @@ class Module(_Base):
         from .step_plan import TrainStepPlans
         self.plan_mode = os.environ.get('LEOD_PLAN', '1') == '1'
         self._plans = TrainStepPlans()
+        self._flat = None                                # FlatParams of configure_optimizers (owner of the bf16 weight shadow)
         self._pin_ring: List[Any] = []
         self._pin_next = 0
 
@@ -155,6 +156,8 @@ class Module(_Base):
         range(L)`` loop of detection.py:188-226).  Default schedule: stage-major and time-batched
         (``RNNDetector.forward_sequence``: every per-frame layer sees L*B frames per launch, only the ConvLSTM walks over
         t) -- same values as the per-timestep loop, which stays available (``self.time_batched = False``)."""
+        if self._flat is not None:
+            self._flat.ensure_shadow()                   # bf16 copy of the flat parameters for the Linear kernels (stale after every optimiser step)
         ev_seq = data[DataType.EV_REPR]
         labels_seq = data[DataType.OBJLABELS_SEQ]
         is_first = data[DataType.IS_FIRST_SAMPLE]
@@ -322,7 +325,7 @@ class Module(_Base):
         predictions, _ = self.mdl.forward_detect(backbone_features=feats)
         pred_processed = postprocess(prediction=predictions, num_classes=self.num_classes,
                                      conf_thre=self.mdl_config.postprocess.confidence_threshold,
-                                     nms_thre=self.mdl_config.postprocess.nms_threshold)
+                                     nms_thre=self.mdl_config.postprocess.nms_threshold, host=True)
         # Prophesee records [t, x, y, w, h, class_id, class_confidence], (x, y) = top-left corner (reference :384-399)
         labels_proph, preds_proph = to_prophesee(obj_labels, pred_processed)
         if self.started_training and mode in self.mode_2_psee_evaluator:
@@ -389,6 +392,7 @@ class Module(_Base):
         tc = self.full_config.training
         opt = FlatAdamW(self.mdl, lr=tc.learning_rate, weight_decay=tc.weight_decay,
                         clip_value=tc.get('gradient_clip_val', None))
+        self._flat = opt.flat
         sp = tc.lr_scheduler
         if not sp.use:
             return opt

@@ -151,6 +151,9 @@ class StepPlan:
         saved_buckets = GradBuckets.current
         saved_side = Fn.WgradSide.active
         ops.PackCache.invalidate()                         # the capture must contain the weight packs of a step
+        flat = getattr(module, '_flat', None)              # FlatParams of configure_optimizers: the recorded step starts by refreshing
+        if flat is not None:                               # its bf16 weight shadow, and the recorded GEMMs read it
+            ops.weight_shadow_pin(True)
         capture_stream = th.cuda.Stream(device=self.ev.device)
         capture_stream.wait_stream(th.cuda.current_stream())
         th.cuda.synchronize()
@@ -161,6 +164,8 @@ class StepPlan:
                 PlanRecorder.current = fwd
                 GradBuckets.current = saved_buckets           # boundary nodes reach the buckets through PlanRecorder.split
                 fwd.begin()
+                if flat is not None:
+                    flat.ensure_shadow(force=True)
                 ops.StatArena.begin_step(self.ev.device)
                 ops.rows_masked_zero(_flat(self.states), self.is_first)                       # RNNStates.reset (detection.py:95-157)
                 _, new_states, feats = mdl.backbone.forward_sequence(self.ev, self.states, select_rows=self.rows, select_stages=in_features)
@@ -192,6 +197,8 @@ class StepPlan:
                         rec.close()
             raise
         finally:
+            if flat is not None:
+                ops.weight_shadow_pin(False)
             PlanRecorder.current = None
             th.cuda.current_stream().wait_stream(capture_stream)
             ops.StatArena.swap(*saved_arena)

@@ -909,6 +909,42 @@ def adamw_clip_step(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, weight_d
                                      int(step), float(clip_value), float(grad_scale), _p(hp_dev), _stream()), 'adamw_clip_step')
 
 
+def set_weight_shadow(base: torch.Tensor, shadow: Optional[torch.Tensor]) -> None:
+    """Register ``shadow`` (bf16, same length) as the 16-bit copy of the flat fp32 parameter buffer ``base`` (None: withdraw it)."""
+    _ck(base, name='weight buffer')
+    if shadow is not None and (shadow.dtype != torch.bfloat16 or shadow.numel() != base.numel() or shadow.device != base.device):
+        raise ValueError('weight shadow: bf16 tensor of the length and device of the parameter buffer')
+    check(_l().leod_set_weight_shadow(_p(base), base.numel(), _p(shadow)), 'set_weight_shadow')
+
+
+def unset_weight_shadow_ptr(base_ptr: int) -> None:
+    """Withdraw the registration of the buffer that lived at ``base_ptr`` (finaliser of its owner; the tensor may be gone)."""
+    try:
+        _l().leod_set_weight_shadow(DevPtr(base_ptr, 'f32'), 0, None)
+    except Exception:                                      # noqa: BLE001 -- interpreter shutdown
+        pass
+
+
+def weight_shadow_refresh(force: bool = False) -> int:
+    """Round the registered parameter buffers whose shadow is stale into their shadows (``force``: all of them, freshness untouched --
+    for launches that are being recorded, see ``weight_shadow_pin``).  Returns the number of launches."""
+    if not torch.cuda.is_available():
+        return 0
+    rc = _l().leod_weight_shadow_refresh(1 if force else 0, _stream())
+    if rc < 0:
+        check(rc, 'weight_shadow_refresh')
+    return rc
+
+
+def weight_shadow_invalidate() -> None:
+    check(_l().leod_weight_shadow_invalidate(), 'weight_shadow_invalidate')
+
+
+def weight_shadow_pin(on: bool) -> None:
+    """While a step is being recorded behind a forced refresh, the GEMM launchers read the shadows whatever their freshness flags say."""
+    check(_l().leod_weight_shadow_pin(1 if on else 0), 'weight_shadow_pin')
+
+
 def _ptr_array(ts):
     import ctypes
     return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])

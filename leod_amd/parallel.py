@@ -49,6 +49,15 @@ class FlatParams:
             p.grad = self.grad[o:o + k].view(p.shape)
         self.offsets = offs
         self.step_count = 0
+        # bf16 shadow of the parameters for the Linear kernels of precision mode bf16 (csrc/k_misc.hip): registered with the library for
+        # as long as this object lives; made fresh by ``ensure_shadow`` at the start of a step, stale by the AdamW kernel / ``touch``
+        self.shadow = None
+        self._param_versions = None
+        if dev.type == 'cuda' and os.environ.get('LEOD_WEIGHT_SHADOW', '1') != '0':
+            import weakref
+            self.shadow = torch.empty(n, dtype=torch.bfloat16, device=dev)
+            ops.set_weight_shadow(self.data, self.shadow)
+            weakref.finalize(self, ops.unset_weight_shadow_ptr, self.data.data_ptr())
 
     def zero_grad(self):
         self.grad.zero_()
@@ -61,11 +70,28 @@ class FlatParams:
         ops.adamw_clip_step(self.data, self.grad, self.exp_avg, self.exp_avg_sq, lr, max(self.step_count, 1), betas=betas,
                             eps=eps, weight_decay=weight_decay, clip_value=clip_value, grad_scale=grad_scale, hp_dev=hp_dev)
         ops.PackCache.invalidate()                     # the kernel rewrote every parameter: packed weight copies are stale
+        # (the library marked the bf16 shadow stale itself: leod_adamw_clip_step knows the buffer it rewrote)
 
     def touch(self):
         """Call after editing ``self.data`` (or any parameter through another alias than the parameter itself) outside the optimiser:
-        cached derived copies of the weights (``ops.PackCache``) are dropped."""
+        cached derived copies of the weights (``ops.PackCache``, the bf16 shadow) are dropped."""
         ops.PackCache.invalidate()
+        if self.shadow is not None:
+            ops.weight_shadow_invalidate()
+
+    def ensure_shadow(self, force: bool = False) -> None:
+        """Start of a step: the bf16 shadow is rounded from the parameters if it is stale -- after an optimiser step or ``touch()``, or when
+        torch's version counters say a parameter was edited in place since the last look (``load_state_dict``, ``p.copy_``).  ``force``:
+        always (a step that is being recorded starts with the refresh, so a replay never depends on these flags)."""
+        if self.shadow is None:
+            return
+        ver = self.data._version
+        for p in self.params:
+            ver += p._version
+        if ver != self._param_versions:
+            self._param_versions = ver
+            ops.weight_shadow_invalidate()
+        ops.weight_shadow_refresh(force)
 
     def step_scalars(self, lr, grad_scale=1.0, betas=(0.9, 0.999)):
         """Advance the step counter and return [lr, 1-b1^t, sqrt(1-b2^t), grad_scale] for the graph-replayed optimiser."""

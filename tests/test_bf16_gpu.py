@@ -528,3 +528,60 @@ def test_mlp_bwd_dgrad_fused_bf16(bf16_ops, M):
     dy2 = ops.linear_dgrad_ln_bwd(du2, d(W1), d(y), st, d(lw), d(dz), dlw2, dlb2)
     assert float((dy - dy2).abs().max()) <= 2e-2 * float(dy2.abs().max())
     assert float((dlw - dlw2).abs().max()) <= 2e-2 * float(dlw2.abs().max())
+
+
+@pytest.mark.parametrize('M,C', [(13440, 384), (53760, 192), (20011, 96), (5003, 384), (9001, 256)])
+def test_weight_shadow_is_bit_identical(bf16_ops, M, C):
+    """bf16 shadow of a registered flat weight buffer (csrc/k_misc.hip, ops.set_weight_shadow): the Linear forward / dgrad kernels of
+    stages 2-4 stage their weight tiles from it instead of rounding fp32 weights on every tile load.  Same rounding -> the results must
+    be bit-identical with and without the shadow, for every loader (row-major forward weights, transposed dgrad weights, both GEMM
+    kernels), on ragged row counts; a stale shadow (after ``weight_shadow_invalidate`` or an AdamW launch on the buffer) is not read."""
+    ops = bf16_ops
+    n1, n2 = 4 * C * C, C * 4 * C
+    flat = torch.zeros(n1 + n2 + 3 * C * C + C * C, device=tk.DEV)
+    shadow = torch.empty(flat.numel(), dtype=torch.bfloat16, device=tk.DEV)
+    W1 = flat[:n1].view(4 * C, C)
+    W2 = flat[n1:n1 + n2].view(C, 4 * C)
+    Wq = flat[n1 + n2:n1 + n2 + 3 * C * C].view(3 * C, C)
+    Wp = flat[n1 + n2 + 3 * C * C:].view(C, C)
+    for k, w in enumerate((W1, W2, Wq, Wp)):
+        w.copy_(tk.rnd(tuple(w.shape), 20 + k, 0.2))
+    x, res = tk.rnd((M, C), 1).to(tk.DEV), tk.rnd((M, C), 2).to(tk.DEV)
+    lw, lb = (1 + 0.2 * tk.rnd((C,), 3)).to(tk.DEV), (0.1 * tk.rnd((C,), 4)).to(tk.DEV)
+    b1, b2, g = tk.rnd((4 * C,), 6, 0.2).to(tk.DEV), tk.rnd((C,), 8, 0.1).to(tk.DEV), (0.5 + 0.1 * tk.rnd((C,), 9)).to(tk.DEV)
+    bq = tk.rnd((3 * C,), 12, 0.1).to(tk.DEV)
+    dz, dq = tk.rnd((M, C), 10).to(tk.DEV), tk.rnd((M, 3 * C), 11).to(tk.DEV)
+
+    def chain():
+        u16, _, st = ops.ln_linear_fwd(x, lw, lb, W1, b1, want_act=True, want_stats=True)          # LN -> fc1 (row-major weights)
+        z, _ = ops.linear_lsres_fwd(u16, W2, b2, g, res, want_t=False)                             # fc2 + LayerScale + residual
+        q, _, _ = ops.ln_linear_fwd(x, lw, lb, Wq, bq)                                             # LN -> qkv
+        p, _ = ops.linear_lsres_fwd(x, Wp, b2, g, res, want_t=False)                               # proj + LayerScale + residual
+        du = ops.linear_dgrad(dz, W2, kscale=g, aux_u=u16)                                          # dgrad of fc2 through GELU (transposed weights)
+        dn = ops.linear_dgrad(du, W1)                                                               # dgrad of fc1
+        dx = ops.linear_dgrad(dq, Wq)                                                               # dgrad of qkv
+        do = ops.linear_dgrad(dz, Wp, kscale=g)                                                     # dgrad of proj
+        return [t.clone() for t in (u16, z, q, p, du, dn, dx, do)]
+
+    ref = chain()                                          # no shadow registered: fp32 weight tiles rounded by the loaders
+    ops.set_weight_shadow(flat, shadow)
+    try:
+        shadow.fill_(float('nan'))
+        stale = chain()                                    # registered but never refreshed: must not be read
+        for a, b in zip(ref, stale):
+            assert torch.equal(a, b)
+        assert ops.weight_shadow_refresh() == 1 and ops.weight_shadow_refresh() == 0
+        assert torch.equal(shadow.float(), flat.to(torch.bfloat16).float())
+        fresh = chain()
+        for k, (a, b) in enumerate(zip(ref, fresh)):
+            assert torch.equal(a, b), f'output {k} differs with the bf16 weight shadow'
+        # an optimiser launch on the buffer makes the shadow stale: poison it, the kernels must be back on the fp32 weights
+        gbuf, m, v = torch.zeros_like(flat), torch.zeros_like(flat), torch.zeros_like(flat)
+        ops.adamw_clip_step(flat, gbuf, m, v, 0.0, 1)
+        shadow.fill_(float('nan'))
+        after = chain()
+        for a, b in zip(ref, after):
+            assert torch.equal(a, b)
+        assert ops.weight_shadow_refresh() == 1
+    finally:
+        ops.set_weight_shadow(flat, None)
