@@ -388,3 +388,24 @@ def test_grad_buckets_refuse_a_second_backward(monkeypatch):
     b.ready(0)
     b.finish()                                            # closes the remaining buckets without complaint
     assert P.GradBuckets.current is None and b.works == []
+
+
+def test_loss_modules_forward_match_oracle():
+    """IOUloss / FocalLoss used on their own (the training path evaluates them inside leod_yolox_loss): oracle/head.py restatements of
+    the reference's losses.py:18-43, 69-85."""
+    import torch
+    from leod_amd.models.detection.yolox.models.losses import IOUloss, FocalLoss
+    from oracle import head as oh
+    g = torch.Generator().manual_seed(5)
+    pred = torch.rand(64, 4, generator=g) * torch.tensor([100., 80., 40., 30.]) + 1
+    tgt = pred + torch.randn(64, 4, generator=g) * 5
+    tgt[:, 2:] = tgt[:, 2:].abs() + 1
+    tgt[:8, :2] += 500                                      # disjoint boxes: iou = 0, loss = 1
+    want = oh.iou_loss_fn(pred, tgt)
+    assert torch.allclose(IOUloss(reduction='none')(pred, tgt), want, atol=1e-6)
+    assert torch.allclose(IOUloss(reduction='mean')(pred, tgt), want.mean(), atol=1e-6)
+    assert torch.all(IOUloss()(pred, tgt)[:8] == 1)
+    x, t = torch.randn(32, 3, generator=g) * 3, (torch.rand(32, 3, generator=g) > 0.7).float()
+    want = oh.sigmoid_focal_loss(x, t, alpha=0.25, gamma=2.0)
+    assert torch.allclose(FocalLoss(0.25, 2.0)(x, t), want, atol=1e-6)
+    assert torch.allclose(FocalLoss(0.25, 2.0, reduction='sum')(x, t), want.sum(), atol=1e-4)
