@@ -189,7 +189,7 @@ def pseudo_main(args):
         first = torch.full((B,), s == 0)
         return {WORKER_ID_KEY: 0, DATA_KEY: {
             DataType.EV_REPR: [ev[t] for t in range(L)], DataType.OBJLABELS_SEQ: none_seq(), DataType.SKIPPED_OBJLABELS_SEQ: none_seq(),
-            DataType.IS_FIRST_SAMPLE: first.to(dev), DataType.IS_LAST_SAMPLE: torch.zeros(B, dtype=torch.bool),
+            DataType.IS_FIRST_SAMPLE: first, DataType.IS_LAST_SAMPLE: torch.zeros(B, dtype=torch.bool),
             DataType.IS_REVERSED: torch.zeros(B, dtype=torch.bool), DataType.EV_IDX: [torch.full((B,), L * s + t, dtype=torch.long) for t in range(L)],
             DataType.IS_PADDED_MASK: [torch.zeros(B, dtype=torch.bool) for _ in range(L)], DataType.PATH: [f'train/rec{rank}_{b}' for b in range(B)]}}
 
@@ -222,6 +222,10 @@ def pseudo_main(args):
         mod.flush_predictions()
         roofline = probe.finish(PEAK_HBM_GBS, PEAK_BF16_MFMA_TFLOPS if args.dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS, target='linear_gemm')
         family_ms = probe.family_ms(2)
+        if args.dump_calls:                               # every C launch of the two probe chunks, in order
+            with open(args.dump_calls, 'w') as f:
+                for n, ints, us in probe.call_table():
+                    f.write(f'{us:9.1f}  {n:<34s} {ints}\n')
     if rank == 0:
         fps = world * B * L * args.steps / dt
         # inference-forward bytes per PROCESSED frame (backbone 15.22 MB + PAFPN / head forward 9.67 MB at 16-bit activations;

@@ -413,11 +413,21 @@ class Module(_Base):
         optimizer = getattr(optimizer, 'optimizer', optimizer)          # LightningOptimizer wrapper
         optimizer.clip_value = float(gradient_clip_val)
 
+    # The inference drivers (PseudoLabeler, TTAModule) read the small per-chunk tensors of a batch (first / last / reversed flags, frame
+    # indices, padding masks) on the HOST: on the device every such read is a blocking copy behind the chunk's kernels, i.e. the host
+    # cannot run a chunk ahead of the GPU.  They set this, and the batch keeps those tensors where the loader made them; the one the
+    # device needs as well (the state-reset mask) is uploaded through pinned memory by the step.
+    control_tensors_on_host = False
+
     def transfer_batch_to_device(self, batch: Any, device, dataloader_idx: int = 0) -> Any:
         """Tensors go to the device asynchronously; box labels stay on the host (their per-frame bookkeeping is host work,
         the padded target tensor is uploaded once per step in ``training_step``)."""
+        host_ctl = self.control_tensors_on_host
+
         def move(o, key=None):
             if th.is_tensor(o):
+                if host_ctl and o.device.type == 'cpu' and o.numel() <= 4096:
+                    return o                             # flags / indices / masks of the chunk: read by the host bookkeeping (see the class attribute)
                 return o.to(device, non_blocking=True)
             if isinstance(o, (ObjectLabels, SparselyBatchedObjectLabels)) or o is None or isinstance(o, (str, int, float, bool)):
                 return o

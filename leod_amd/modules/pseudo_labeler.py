@@ -213,6 +213,8 @@ class EventSeqData:
 
 
 class PseudoLabeler(Module):
+    control_tensors_on_host = True          # flags / indices / masks of a chunk stay host tensors (Module.transfer_batch_to_device)
+
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.mode_2_seq_lens = SeqLens()
@@ -292,7 +294,15 @@ class PseudoLabeler(Module):
         ev_seq = data[DataType.EV_REPR]
         obj_labels, skipped = data[DataType.OBJLABELS_SEQ], data[DataType.SKIPPED_OBJLABELS_SEQ]
         is_first = data[DataType.IS_FIRST_SAMPLE]
-        first_host = is_first.cpu().numpy().tolist()          # before anything of this chunk is enqueued: the copy waits for nothing new
+        if is_first.device.type == 'cpu':                     # the loader's tensor (``control_tensors_on_host``): no device round trip at all
+            first_host = is_first.numpy().tolist()
+            dev0 = ev_seq[0].device
+            is_first_dev = is_first.pin_memory().to(dev0, non_blocking=True) if dev0.type == 'cuda' else is_first
+        else:
+            # a device tensor: this copy is enqueued behind whatever the caller has in flight -- in pipelined mode the PREVIOUS chunk's
+            # kernels, which the host then waits for (28.0 instead of 25.x ms per chunk in bench.py --pseudo)
+            first_host = is_first.cpu().numpy().tolist()
+            is_first_dev = is_first
         L, B = len(obj_labels), len(obj_labels[0])
         assert L > 0 and B > 0
         if self.mode_2_batch_size[mode] is None:
@@ -305,9 +315,9 @@ class PseudoLabeler(Module):
         else:
             assert self.mode_2_hw[mode] == hw
         rnn = self.mode_2_rnn_states[mode]
-        rnn.reset(worker_id=worker_id, indices_or_bool_tensor=is_first)
+        rnn.reset(worker_id=worker_id, indices_or_bool_tensor=is_first_dev)
         prev = rnn.get_states(worker_id=worker_id)
-        self.mode_2_seq_lens.reset(worker_id=worker_id, indices_or_bool_tensor=is_first)
+        self.mode_2_seq_lens.reset(worker_id=worker_id, indices_or_bool_tensor=th.tensor(first_host, dtype=th.bool))     # host lengths, host mask
         pse_mask, gt_mask, skipped_gt_mask = self._get_pred_mask(worker_id, data)
         skipped_gt_labels: List[ObjectLabels] = [skipped[t][b] for t in range(L) for b in range(B) if skipped_gt_mask[t, b]]
         gt_labels: List[ObjectLabels] = []
@@ -323,7 +333,9 @@ class PseudoLabeler(Module):
             # per-timestep loop of pseudo_labeler.py:687-722, see RNNDetector.forward_sequence)
             ev = self._stack_frames(ev_seq)
             feats_all, prev = self.mdl.backbone.forward_sequence(ev, prev)
-            if rows:
+            if len(rows) == L * B:                            # every frame is predicted on (no GT frames in the chunk): the maps as they are
+                feats = {k: feats_all[k] for k in in_features}
+            elif rows:
                 ridx = self._row_index(rows, ev.device)
                 feats = {k: feats_all[k].permute(0, 2, 3, 1).index_select(0, ridx).permute(0, 3, 1, 2) for k in in_features}
         else:

@@ -130,6 +130,8 @@ class TTAModule(Module):
     views the loader delivers (time-reversed copies) or that are made here (horizontal flip, concatenated on the batch
     dimension), ``on_test_epoch_end`` merges them and runs the Prophesee evaluator."""
 
+    control_tensors_on_host = True          # flags / indices / masks of a chunk stay host tensors (Module.transfer_batch_to_device)
+
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.ev_path_2_ev_pred: Dict[str, EventSeqResult] = {}

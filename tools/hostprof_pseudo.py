@@ -16,7 +16,7 @@ cfg = dynamically_modify_train_config(full_config('gen1', 'small', model='pseudo
 cfg.training.precision = 16
 cfg.model.postprocess.confidence_threshold = 0.01
 torch.manual_seed(0)
-mod = PseudoLabeler(cfg).to(dev).eval(); mod.setup('predict')
+mod = PseudoLabeler(cfg).to(dev).eval(); mod.setup('predict'); mod.pipelined = True
 with torch.no_grad():
     for k in range(3):
         mod.mdl.yolox_head.obj_preds[k].bias += 4.0; mod.mdl.yolox_head.cls_preds[k].bias += 4.0
@@ -26,7 +26,7 @@ step = [0]
 def batch():
     s = step[0]; step[0] += 1
     return {WORKER_ID_KEY: 0, DATA_KEY: {DataType.EV_REPR: [ev[t] for t in range(L)], DataType.OBJLABELS_SEQ: none_seq(), DataType.SKIPPED_OBJLABELS_SEQ: none_seq(),
-            DataType.IS_FIRST_SAMPLE: torch.full((B,), s == 0).to(dev), DataType.IS_LAST_SAMPLE: torch.zeros(B, dtype=torch.bool), DataType.IS_REVERSED: torch.zeros(B, dtype=torch.bool),
+            DataType.IS_FIRST_SAMPLE: torch.full((B,), s == 0), DataType.IS_LAST_SAMPLE: torch.zeros(B, dtype=torch.bool), DataType.IS_REVERSED: torch.zeros(B, dtype=torch.bool),
             DataType.EV_IDX: [torch.full((B,), L * s + t, dtype=torch.long) for t in range(L)], DataType.IS_PADDED_MASK: [torch.zeros(B, dtype=torch.bool) for _ in range(L)],
             DataType.PATH: [f'train/rec_{b}' for b in range(B)]}}
 for _ in range(3):
@@ -39,4 +39,5 @@ for _ in range(3):
 torch.cuda.synchronize()
 print('ms per step', 1e3 * (time.perf_counter() - t0) / 3)
 pr.disable()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(40)
+pstats.Stats(pr).sort_stats('cumulative').print_stats(45)
+pstats.Stats(pr).sort_stats('tottime').print_stats(25)
