@@ -113,7 +113,8 @@ int leod_convlstm_gates_bwd(const float* dh, const float* dh2, const float* dc_n
  * resident in registers.  leod_convlstm_seq_mode(C): 1 = xin is x_seq [T,M,C] (fused [x|h] contraction), 2 / 3 = xin is the
  * time-batched projection gx [T,M,4C] = x W_x^T + b computed by the caller, 0 = not available for this C / precision mode
  * (callers then loop leod_convlstm_fwd).  hbuf, cbuf [T+1,M,C]: slot 0 = incoming state (zero_state: taken as zeros, not read),
- * slots 1..T are written; gates_out [T,M,4,C] optional. */
+ * slots 1..T are written; gates_out [T,M,4,C] optional -- without it (inference: no backward pass will read the history) only slot T of cbuf
+ * is written. */
 int leod_convlstm_seq_mode(int C);
 /* mode 3 (C = 256 / 384 in precision mode bf16: the weight slice of a wave does not fit its registers): like mode 2, and the waves
  * stream their MFMA B fragments from a fragment-ordered bf16 copy of W_h -- leod_convlstm_seq_pack writes it (once per step, shared by
@@ -282,6 +283,12 @@ int leod_set_scalars4(float* dst, float a, float b, float c, float d, leod_strea
  *   (reference models/layers/rnn.py:53-60 takes them as h_and_c_previous). */
 int leod_rows_masked_zero(void* const* tensors, const long* row_bytes, int n, const unsigned char* mask, int B, leod_stream_t stream);
 int leod_copy_multi(void* const* dst, const void* const* src, const long* nbytes, int n, leod_stream_t stream);
+/* Channel concatenation of two NHWC maps, the first optionally upsampled x2 (nearest) on the way: out [B,H,W,Ca+Cb] from a [B,H>>up,W>>up,Ca]
+ * and b [B,H,W,Cb] -- torch.cat([upsample(a), b], 1) of the PAFPN top-down path (models/detection/yolox_extension/models/yolo_pafpn.py:113-123)
+ * and the cat of CSPLayer (models/detection/yolox/models/network_blocks.py:160-166) as one launch; _bwd: da (summed over the 2 x 2 copies when
+ * up = 1) and db from dout.  fp32, Ca % 4 == Cb % 4 == 0, up in {0, 1}. */
+int leod_cat2_up_fwd(const float* a, const float* b, float* out, int B, int H, int W, int Ca, int Cb, int up, leod_stream_t stream);
+int leod_cat2_up_bwd(const float* dout, float* da, float* db, int B, int H, int W, int Ca, int Cb, int up, leod_stream_t stream);
 /* StackedHistogram.construct (data/utils/representations.py:78-123): int64 events -> uint8 [2*bins,H,W]. */
 int leod_voxelize_u8(const long* x, const long* y, const long* pol, const long* t, long n_events, int* counts_ws,
                      unsigned char* out, int bins, int H, int W, int count_cutoff, int fastmode, leod_stream_t stream);

@@ -736,6 +736,8 @@ int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, i
     const int RH = conv3_rows_per_block(H, W, Cin, nto, stride);
     if (RH <= 0) return LEOD_ERR_UNSUPPORTED;
     const int Ho = H / stride, Wo = W / stride;
+    // (Two workgroups per CU for the large launches of the inference passes -- fewer output rows per workgroup, <= 80 KB of LDS each --
+    // measured equal: 26.55 vs 26.56 ms per pseudo-label chunk, profiles/r04_a_graph_ab.txt; one workgroup per CU and the smaller halo overlap stay.)
     const dim3 grid(B * cdiv(Ho, RH), Cout / (16 * nto));
     const size_t smem = conv3_smem(RH, W, Cin, nto, stride);
     const int tw = cdiv(cdiv(min(RH, Ho) * Wo, 16), 4) <= 2 ? 2 : 3;          // row tiles per wave

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(C * 4) void lstm_seq_fwd_kernel(const float* __rest
             sA[buf ^ 1][(4 * q + r) * LD + HOFF + ch] = a_elem<BF>(hn);
             if (rok[r]) {
                 hp[oc[r]] = hn;
-                cp[oc[r]] = cn;
+                if (gates_out || t + 1 == T) cp[oc[r]] = cn;       // the c history is read by the backward pass only (which needs the gates too)
                 if (!G16 && gp) {
                     float* gr = gp + (4 * oc[r] - 3 * ch);
                     gr[0] = f; gr[C] = ig; gr[2 * C] = o; gr[3 * C] = g;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(C * 2) void lstm_seq_fwd_stream_kernel(const float*
                 sA[buf ^ 1][(4 * q + r) * LD + ch] = to_bf16(hn);
                 if (rok[r]) {
                     hp[ocg[r]] = hn;
-                    cp[ocg[r]] = cn;
+                    if (go || t + 1 == T) cp[ocg[r]] = cn;           // the c history is read by the backward pass only (which needs the gates too)
                     if (!G16 && go) {
                         float* gr = go + (4u * ocg[r] - 3u * ch);
                         gr[0] = f; gr[C] = ig; gr[2 * C] = o; gr[3 * C] = g;

@@ -220,6 +220,66 @@ LEOD_API int leod_copy_multi(void* const* dst, const void* const* src, const lon
     return leod_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Channel concatenation of two NHWC maps with an optional nearest x2 upsampling of the first (PAFPN top-down path:
+// torch.cat([upsample(a), b], 1), yolo_pafpn.py:113-123 of the reference; CSPLayer: cat(x_1, x_2), network_blocks.py:160-166):
+//   forward : out[b, y, x, :Ca] = a[b, y >> up, x >> up, :], out[b, y, x, Ca:] = bsrc[b, y, x, :]
+//   backward: da[b, y', x', :] = sum over the 2^up x 2^up pixels it was copied to of dout[..., :Ca];  db = dout[..., Ca:]
+// instead of expand + reshape-copy + cat (forward) and two slice copies + a reduction (backward).  4-byte elements, Ca % 4 == Cb % 4 == 0.
+__global__ __launch_bounds__(256) void cat2_up_fwd_kernel(const float* __restrict__ a, const float* __restrict__ bsrc, float* __restrict__ out,
+                                                          long npix, int H, int W, int Ca, int Cb, int up) {
+    const int C4 = (Ca + Cb) / 4, A4 = Ca / 4;
+    const long total = npix * C4;
+    const int Ha = H >> up, Wa = W >> up;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long pix = e / C4; const int c4 = (int)(e - pix * C4);
+        f4 v;
+        if (c4 < A4) {
+            long src = pix;
+            if (up) { const int x = (int)(pix % W); const long r = pix / W; const int y = (int)(r % H); const long b = r / H;
+                      src = (b * Ha + (y >> 1)) * Wa + (x >> 1); }
+            v = ld4(a + src * Ca + 4 * c4);
+        } else v = ld4(bsrc + pix * Cb + 4 * (c4 - A4));
+        *reinterpret_cast<f4*>(out + pix * (Ca + Cb) + 4 * c4) = v;
+    }
+}
+__global__ __launch_bounds__(256) void cat2_up_bwd_kernel(const float* __restrict__ dout, float* __restrict__ da, float* __restrict__ db,
+                                                          long npix, int H, int W, int Ca, int Cb, int up) {
+    // one thread per float4 of da and of db: (pixels of a) * Ca / 4 + npix * Cb / 4 work items
+    const int A4 = Ca / 4, B4 = Cb / 4, C = Ca + Cb;
+    const int Ha = H >> up, Wa = W >> up;
+    const long na = (up ? npix / 4 : npix) * A4, total = na + npix * B4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        if (e < na) {
+            const long pa = e / A4; const int c4 = (int)(e - pa * A4);
+            f4 v;
+            if (up) {
+                const int x = (int)(pa % Wa); const long r = pa / Wa; const int y = (int)(r % Ha); const long b = r / Ha;
+                const float* p = dout + ((b * H + 2 * y) * W + 2 * x) * C + 4 * c4;
+                v = (ld4(p) + ld4(p + C)) + (ld4(p + (long)W * C) + ld4(p + (long)W * C + C));
+            } else v = ld4(dout + pa * C + 4 * c4);
+            *reinterpret_cast<f4*>(da + pa * Ca + 4 * c4) = v;
+        } else {
+            const long f = e - na; const long pix = f / B4; const int c4 = (int)(f - pix * B4);
+            *reinterpret_cast<f4*>(db + pix * Cb + 4 * c4) = ld4(dout + pix * C + Ca + 4 * c4);
+        }
+    }
+}
+LEOD_API int leod_cat2_up_fwd(const float* a, const float* b, float* out, int B, int H, int W, int Ca, int Cb, int up, hipStream_t stream) {
+    if (!a || !b || !out || B <= 0 || H <= 0 || W <= 0 || Ca <= 0 || Cb <= 0 || (Ca & 3) || (Cb & 3) || up < 0 || up > 1 ||
+        (up && ((H | W) & 1))) return LEOD_ERR_ARG;
+    const long npix = (long)B * H * W, total = npix * ((Ca + Cb) / 4);
+    hipLaunchKernelGGL(cat2_up_fwd_kernel, dim3((unsigned)min((long)4096, (total + 255) / 256)), dim3(256), 0, stream, a, b, out, npix, H, W, Ca, Cb, up);
+    return leod_launch_status();
+}
+LEOD_API int leod_cat2_up_bwd(const float* dout, float* da, float* db, int B, int H, int W, int Ca, int Cb, int up, hipStream_t stream) {
+    if (!dout || !da || !db || B <= 0 || H <= 0 || W <= 0 || Ca <= 0 || Cb <= 0 || (Ca & 3) || (Cb & 3) || up < 0 || up > 1 ||
+        (up && ((H | W) & 1))) return LEOD_ERR_ARG;
+    const long npix = (long)B * H * W, total = (up ? npix / 4 : npix) * (Ca / 4) + npix * (Cb / 4);
+    hipLaunchKernelGGL(cat2_up_bwd_kernel, dim3((unsigned)min((long)4096, (total + 255) / 256)), dim3(256), 0, stream, dout, da, db, npix, H, W, Ca, Cb, up);
+    return leod_launch_status();
+}
+
 LEOD_API const char* leod_version() { return "leod_hip 0.2 (gfx950)"; }
 
 // precision mode of the contractions (see common.hpp): process-wide, set once before the first step

@@ -665,6 +665,35 @@ class HeadTailFn(Function):
         return (None, None) + tuple(grads) + (None,) * len(params)
 
 
+class Cat2Fn(Function):
+    """cat([upsample2(a) if up else a, b], channel axis) on NHWC maps as ONE launch each way (``ops.cat2_up_fwd`` / ``_bwd``): the PAFPN
+    top-down joins (yolo_pafpn.py:113-123) and the CSPLayer join (network_blocks.py:160-166) were expand + copy + cat forward and two slice
+    copies + a reduction backward."""
+
+    @staticmethod
+    def forward(ctx, a, b, up):
+        ctx.ca, ctx.up = a.shape[-1], bool(up)
+        return ops.cat2_up_fwd(a.contiguous(), b.contiguous(), ctx.up)
+
+    @staticmethod
+    def backward(ctx, dout):
+        da, db = ops.cat2_up_bwd(dout.contiguous(), ctx.ca, ctx.up)
+        return da, db, None
+
+
+def cat2_nhwc(a: torch.Tensor, b: torch.Tensor, up: bool = False) -> torch.Tensor:
+    """Channel concat of two NHWC maps, ``a`` nearest-upsampled x2 first if ``up``.  HIP fp32 maps with channel counts % 4 == 0 take the
+    fused kernel; anything else the torch ops it replaces."""
+    ok = (a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 4 and b.dim() == 4 and
+          a.shape[-1] % 4 == 0 and b.shape[-1] % 4 == 0 and (not up or (b.shape[1] % 2 == 0 and b.shape[2] % 2 == 0)))
+    if ok:
+        return Cat2Fn.apply(a, b, up)
+    if up:
+        B, H, W, C = a.shape
+        a = a[:, :, None, :, None, :].expand(B, H, 2, W, 2, C).reshape(B, 2 * H, 2 * W, C)
+    return torch.cat((a, b), dim=-1)
+
+
 class PickLossFn(Function):
     """losses[0] as its own autograd node.  Plain indexing would put a SelectBackward node in front of ``HeadTailFn``: a zero fill of a
     [6] tensor plus a 4-byte device-to-device memcpy per backward pass -- and a memcpy NODE in a captured step, which a launch plan

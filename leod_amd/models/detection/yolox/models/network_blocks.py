@@ -64,7 +64,7 @@ class CSPLayer(nn.Module):
         x1, x2 = Fn.base_conv_group([self.conv1, self.conv2], [x, x])     # same input, independent: one statistics exchange
         for b in self.m:
             x1 = b.forward_nhwc(x1)
-        return self.conv3.forward_nhwc(torch.cat((x1, x2), dim=-1))
+        return self.conv3.forward_nhwc(Fn.cat2_nhwc(x1, x2))
 
     def forward(self, x):
         return Fn.as_nchw(self.forward_nhwc(Fn.to_nhwc(x)))

@@ -38,12 +38,12 @@ class YOLOPAFPN(nn.Module):
 
     def forward_nhwc(self, x2, x1, x0):
         fpn_out0 = self.lateral_conv0.forward_nhwc(x0)
-        f_out0 = self.C3_p4.forward_nhwc(th.cat([upsample2_nhwc(fpn_out0), x1], -1))
+        f_out0 = self.C3_p4.forward_nhwc(Fn.cat2_nhwc(fpn_out0, x1, up=True))        # cat([upsample(fpn_out0), x1]) in one launch
         fpn_out1 = self.reduce_conv1.forward_nhwc(f_out0)
-        pan_out2 = self.C3_p3.forward_nhwc(th.cat([upsample2_nhwc(fpn_out1), x2], -1))
-        p_out1 = th.cat([self.bu_conv2.forward_nhwc(pan_out2), fpn_out1], -1)
+        pan_out2 = self.C3_p3.forward_nhwc(Fn.cat2_nhwc(fpn_out1, x2, up=True))
+        p_out1 = Fn.cat2_nhwc(self.bu_conv2.forward_nhwc(pan_out2), fpn_out1)
         pan_out1 = self.C3_n3.forward_nhwc(p_out1)
-        p_out0 = th.cat([self.bu_conv1.forward_nhwc(pan_out1), fpn_out0], -1)
+        p_out0 = Fn.cat2_nhwc(self.bu_conv1.forward_nhwc(pan_out1), fpn_out0)
         pan_out0 = self.C3_n4.forward_nhwc(p_out0)
         return pan_out2, pan_out1, pan_out0
 

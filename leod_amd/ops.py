@@ -909,6 +909,30 @@ def adamw_clip_step(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, weight_d
                                      int(step), float(clip_value), float(grad_scale), _p(hp_dev), _stream()), 'adamw_clip_step')
 
 
+def cat2_up_fwd(a: torch.Tensor, b: torch.Tensor, up: bool = False) -> torch.Tensor:
+    """out [B,H,W,Ca+Cb] = cat(a (nearest x2 upsampled if ``up``), b) on the channel axis of NHWC maps, one launch."""
+    _ck(a, name='a')
+    _ck(b, name='b')
+    B, H, W, Cb = b.shape
+    Ca = a.shape[-1]
+    if tuple(a.shape[:3]) != ((B, H // 2, W // 2) if up else (B, H, W)):
+        raise ValueError(f'cat2_up: a {tuple(a.shape)} does not match b {tuple(b.shape)} (up={up})')
+    out = _empty((B, H, W, Ca + Cb), b)
+    check(_l().leod_cat2_up_fwd(_p(a), _p(b), _p(out), B, H, W, Ca, Cb, 1 if up else 0, _stream()), 'cat2_up_fwd')
+    return out
+
+
+def cat2_up_bwd(dout: torch.Tensor, Ca: int, up: bool = False):
+    """-> (da [B,H>>up,W>>up,Ca], db [B,H,W,C-Ca]) of ``cat2_up_fwd``."""
+    _ck(dout, name='dout')
+    B, H, W, C = dout.shape
+    Cb = C - Ca
+    da = _empty((B, H // 2, W // 2, Ca) if up else (B, H, W, Ca), dout)
+    db = _empty((B, H, W, Cb), dout)
+    check(_l().leod_cat2_up_bwd(_p(dout), _p(da), _p(db), B, H, W, Ca, Cb, 1 if up else 0, _stream()), 'cat2_up_bwd')
+    return da, db
+
+
 def set_weight_shadow(base: torch.Tensor, shadow: Optional[torch.Tensor]) -> None:
     """Register ``shadow`` (bf16, same length) as the 16-bit copy of the flat fp32 parameter buffer ``base`` (None: withdraw it)."""
     _ck(base, name='weight buffer')

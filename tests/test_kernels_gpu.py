@@ -842,3 +842,24 @@ def test_linear_dgrad_ln_bwd(ops, M, N, K, with_res):
     close(dx, x.grad + (dres if with_res else 0), rtol=1e-4, atol=1e-5, what='dx')
     close(dw, lw.grad, rtol=3e-4, atol=1e-4, what='d ln weight')
     close(db, lb.grad, rtol=3e-4, atol=1e-4, what='d ln bias')
+
+
+@pytest.mark.parametrize('B,H,W,Ca,Cb,up', [(2, 16, 20, 192, 192, True), (3, 32, 40, 96, 96, True), (2, 8, 10, 48, 96, False), (1, 6, 8, 4, 12, True),
+                                            (5, 16, 20, 96, 192, False)])
+def test_cat2_up_matches_torch(ops, B, H, W, Ca, Cb, up):
+    """Channel concat of two NHWC maps with the first upsampled x2 (nearest) on the way -- the PAFPN top-down joins and the CSPLayer join
+    (reference yolo_pafpn.py:113-123, network_blocks.py:160-166) -- forward and backward against the torch ops it replaces (exact: copies
+    and 4-term sums)."""
+    from leod_amd import functions as Fn
+    a = rnd((B, H // 2, W // 2, Ca) if up else (B, H, W, Ca), 1).to(DEV).requires_grad_(True)
+    b = rnd((B, H, W, Cb), 2).to(DEV).requires_grad_(True)
+    out = Fn.cat2_nhwc(a, b, up=up)
+    a2, b2 = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    au = a2[:, :, None, :, None, :].expand(B, H // 2, 2, W // 2, 2, Ca).reshape(B, H, W, Ca) if up else a2
+    want = torch.cat([au, b2], -1)
+    assert torch.equal(out, want)
+    g = rnd(tuple(out.shape), 3).to(DEV)
+    out.backward(g)
+    want.backward(g)
+    assert torch.equal(b.grad, b2.grad)
+    assert torch.allclose(a.grad, a2.grad, rtol=0, atol=1e-6)
