@@ -378,9 +378,13 @@ __global__ __launch_bounds__(256) void wgrad_wide_reduce_kernel(const f4* __rest
     f4 s0 = zero4(), s1 = zero4(), s2 = zero4(), s3 = zero4();
     const f4* p = part + (long)g0 * O + o;
     int g = g0;
+    f4 s4 = zero4(), s5 = zero4(), s6 = zero4(), s7 = zero4();
+    for (; g + 8 <= g1; g += 8, p += 8 * O) {          // eight independent 16-byte loads in flight per thread
+        s0 += p[0]; s1 += p[O]; s2 += p[2 * O]; s3 += p[3 * O]; s4 += p[4 * O]; s5 += p[5 * O]; s6 += p[6 * O]; s7 += p[7 * O];
+    }
     for (; g + 4 <= g1; g += 4, p += 4 * O) { s0 += p[0]; s1 += p[O]; s2 += p[2 * O]; s3 += p[3 * O]; }
     for (; g < g1; ++g, p += O) s0 += p[0];
-    const f4 v = (s0 + s1) + (s2 + s3);
+    const f4 v = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
     const bool single = gridDim.y == 1;
     if (t < NT9) {
         const int a = t / WB, b = t - a * WB;
@@ -457,7 +461,10 @@ static inline int launch_wgrad_wide_cfg(const void* dy, long lddy, const XRows& 
     if (part != nullptr && !(dbg & 1)) {
         // ~2048 waves of reduce threads: groups of `per` partials
         const int ob = (int)cdiv(O, 256);
-        int groups = max(1, min(gx, 512 / ob));
+        // (every group ends with one atomic per element: 42 groups on the 192 x 48 tile of stage 1 = 387 k atomics on 9 216 addresses took
+        // 290 us of the tail of the weight-gradient lane; capped, each thread sums more partials instead)
+        static const int gcap = getenv("LEOD_WGW_REDUCE_GROUPS") ? atoi(getenv("LEOD_WGW_REDUCE_GROUPS")) : 512;
+        int groups = max(1, min(min(gx, 512 / ob), gcap));
         const int per = cdiv(gx, groups);
         groups = cdiv(gx, per);
         hipLaunchKernelGGL((wgrad_wide_reduce_kernel<TN, TK, NWN, NWK>), dim3(ob, groups), dim3(256), 0, s, part, gx, (int)grid.y, (int)grid.z, per,
