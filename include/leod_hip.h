@@ -317,6 +317,8 @@ int leod_linear_dgrad_lnbwd(const float* dy, const float* W, const float* x, con
  * ~3 us of host time per kernel, parallel branches stay parallel (hipGraphLaunch on ROCm 7.2: 8 us per node single-stream, and as
  * slow as eager Python launches once the graph forks).  The graph must outlive the plan (kernel argument blocks are borrowed).
  * leod_plan_create returns a handle > 0 or a negative error (-3: a node type a plan cannot replay; leod_plan_last_error() names it).
+ * The library's own weight-pack kernels (conv3_pack_kernel, lstm_pack_kernel: they read parameters only) are taken out of the chain the capture
+ * put them in and run on lane 1 from the start of the plan (LEOD_PLAN_HOIST=0: left where they were captured).
  * leod_plan_info: info[8] = kernels, memsets, memcpys, empty nodes, lanes, events, cross-lane waits, ops. */
 long leod_plan_create(void* hip_graph, int max_lanes);
 int leod_plan_launch(long plan, leod_stream_t stream);

@@ -14,6 +14,7 @@
 #include "common.hpp"
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <mutex>
 #include <queue>
 #include <string>
@@ -44,7 +45,7 @@ struct Plan {
     std::vector<int> lane_first_wait;        // per lane > 0: 1 when the lane has ops (it then waits for the start event)
     int start_event = -1;                    // recorded on the caller's stream before anything else
     std::vector<int> tail_event;             // per lane > 0: event recorded after its last op (-1: lane unused)
-    int n_kernel = 0, n_memset = 0, n_memcpy = 0, n_nop = 0, n_waits = 0;
+    int n_kernel = 0, n_memset = 0, n_memcpy = 0, n_nop = 0, n_waits = 0, n_hoisted = 0;
 };
 
 std::mutex g_mu;
@@ -150,15 +151,54 @@ LEOD_API long leod_plan_create(void* hip_graph, int max_lanes) {
             return LEOD_ERR_UNSUPPORTED;
         }
     }
+    // ---- weight packs leave the critical chain -----------------------------------------------------------------------------------------
+    // conv3_pack_kernel / lstm_pack_kernel read parameters only (constant while a step runs) and write a buffer nobody else writes; the capture
+    // ordered each behind the kernel that happened to precede it on the stream (41 of them in a training step, ~5 us + a launch gap each, in the
+    // middle of the neck / head chains).  Their incoming edges are dropped (predecessors are linked to their successors instead), they are chained
+    // among themselves and put on lane 1 at the START of the plan, and every consumer waits for the LAST of them -- one wait on the critical lane.
+    std::vector<char> hoisted(n, 0);
+    static const int hoist_on = getenv("LEOD_PLAN_HOIST") ? atoi(getenv("LEOD_PLAN_HOIST")) : 1;
+    if (hoist_on && max_lanes >= 2) {
+        std::vector<int> hs;
+        for (size_t i = 0; i < n; ++i) {
+            if (ops[i].type != OP_KERNEL) continue;
+            const char* nm = hipKernelNameRefByPtr(ops[i].kp.func, nullptr);
+            if (nm && (strstr(nm, "conv3_pack_kernel") || strstr(nm, "lstm_pack_kernel"))) hs.push_back((int)i);
+        }
+        auto erase = [](std::vector<int>& v, int x) { v.erase(std::remove(v.begin(), v.end(), x), v.end()); };
+        auto add_edge = [&](int a, int b) {
+            if (a == b || std::find(succ[a].begin(), succ[a].end(), b) != succ[a].end()) return;
+            succ[a].push_back(b); pred[b].push_back(a);
+        };
+        if (hs.size() >= 2) {
+            for (int v : hs) hoisted[v] = 1;
+            for (int v : hs) {
+                const std::vector<int> ps = pred[v], ss = succ[v];
+                for (int q : ps) { erase(succ[q], v); for (int s2 : ss) add_edge(q, s2); }
+                pred[v].clear();
+            }
+            const int last = hs.back();
+            for (int v : hs) {
+                if (v == last) continue;
+                const std::vector<int> ss = succ[v];
+                for (int s2 : ss) { erase(succ[v], s2); erase(pred[s2], v); if (!hoisted[s2]) add_edge(last, s2); }
+            }
+            for (size_t k = 0; k + 1 < hs.size(); ++k) add_edge(hs[k], hs[k + 1]);
+            p->n_hoisted = (int)hs.size();
+        }
+    }
     // topological order, capture order (node index) first among the ready nodes
     std::vector<int> indeg(n), order;
     order.reserve(n);
-    std::priority_queue<int, std::vector<int>, std::greater<int>> ready;
-    for (size_t i = 0; i < n; ++i) { indeg[i] = (int)pred[i].size(); if (!indeg[i]) ready.push((int)i); }
+    // (hoisted weight packs come first: keys below every node index)
+    std::priority_queue<long, std::vector<long>, std::greater<long>> ready;
+    auto key = [&](int v) { return hoisted[v] ? (long)v - (long)n : (long)v; };
+    for (size_t i = 0; i < n; ++i) { indeg[i] = (int)pred[i].size(); if (!indeg[i]) ready.push(key((int)i)); }
     while (!ready.empty()) {
-        int v = ready.top(); ready.pop();
+        const long kv = ready.top(); ready.pop();
+        const int v = (int)(kv < 0 ? kv + (long)n : kv);
         order.push_back(v);
-        for (int s : succ[v]) if (--indeg[s] == 0) ready.push(s);
+        for (int s : succ[v]) if (--indeg[s] == 0) ready.push(key(s));
     }
     if (order.size() != n) { g_err = "graph has a cycle"; delete p; return LEOD_ERR_ARG; }
     // height = kernels on the longest path from the node to a sink; the successor with the greatest height inherits a node's lane
@@ -178,18 +218,19 @@ LEOD_API long leod_plan_create(void* hip_graph, int max_lanes) {
     std::vector<int> lane_tail;              // last node placed on each lane
     std::vector<double> lane_load;
     int root = order[0];
-    for (int v : order) if (pred[v].empty() && height[v] > height[root]) root = v;
+    for (int v : order) if (hoisted[root] || (pred[v].empty() && !hoisted[v] && height[v] > height[root])) root = v;
     for (int v : order) {
         int l = -1;
         if (max_lanes == 1) l = 0;
+        else if (hoisted[v]) l = 1;
         else if (v == root) l = 0;
         else {
             double best = -1.0;
-            for (int q : pred[v]) if (heir[q] == v && lane_tail[lane[q]] == q && height[q] > best) { best = height[q]; l = lane[q]; }
+            for (int q : pred[v]) if (!hoisted[q] && heir[q] == v && lane_tail[lane[q]] == q && height[q] > best) { best = height[q]; l = lane[q]; }
             // not the heir of any predecessor, but one of them is still the tail of its lane (its heir went on with another lane):
             // go on there rather than open a lane
             if (l < 0)
-                for (int q : pred[v]) if (lane_tail[lane[q]] == q && height[q] > best) { best = height[q]; l = lane[q]; }
+                for (int q : pred[v]) if (!hoisted[q] && lane_tail[lane[q]] == q && height[q] > best) { best = height[q]; l = lane[q]; }
         }
         if (l < 0) {
             // a branch starts here: a lane of its own while there are lanes left (lane 0 is kept for the root's chain), else the

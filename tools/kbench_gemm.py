@@ -58,6 +58,17 @@ def main():
             ('lstm_xproj', lambda: ops.ln_linear_fwd(x, None, None, Wl[:, :C].contiguous(), b1), 4 * M * 5 * C, 2 * M * C * 4 * C),
             ('lstm_dx', lambda: ops.linear_dgrad(dy4, Wl[:, :C].contiguous()), 4 * M * 5 * C, 2 * M * C * 4 * C),
         ]
+        # the same plain contractions through torch.mm (hipBLASLt / rocBLAS, bf16 operands, fp32 accumulation): what a library GEMM does here
+        W1b, Wqb, W2b, Wpb = W1.to(torch.bfloat16), Wqkv.to(torch.bfloat16), W2.to(torch.bfloat16), Wp.to(torch.bfloat16)
+        xb, dyCb = x.to(torch.bfloat16), dyC.to(torch.bfloat16)
+        cases += [
+            ('mm dgrad_fc1', lambda: torch.mm(dy4b, W1b), 4 * M * 3 * C, 2 * M * C * 4 * C),
+            ('mm dgrad_qkv', lambda: torch.mm(dy3b, Wqb), 4 * M * 2.5 * C, 2 * M * C * 3 * C),
+            ('mm dgrad_fc2', lambda: torch.mm(dyCb, W2b), 4 * M * 3 * C, 2 * M * C * 4 * C),
+            ('mm fwd_fc1', lambda: torch.mm(xb, W1b.t()), 4 * M * 3 * C, 2 * M * C * 4 * C),
+            ('mm fwd_qkv', lambda: torch.mm(xb, Wqb.t()), 4 * M * 2.5 * C, 2 * M * C * 3 * C),
+            ('mm fwd_proj', lambda: torch.mm(xb, Wpb.t()), 4 * M * 1 * C, 2 * M * C * C),
+        ]
         flt = os.environ.get('KBENCH_FILTER', '')
         for name, fn, nbytes, flops in cases:
             if flt and not any(f in name for f in flt.split(',')):
