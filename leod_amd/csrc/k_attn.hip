@@ -1061,7 +1061,11 @@ static int dispatch_attn(int which, const float* qkv, const float* dout, float* 
     const int P = g.ph * g.pw, PT = (P + 15) / 16, DCH = (g.d + 15) / 16;
     const float scale = 1.0f / sqrtf((float)g.d);
     static const int use_lds = getenv("LEOD_ATTN_LDS") ? atoi(getenv("LEOD_ATTN_LDS")) : 1;
-    const int HG = (g.heads % 2 == 0 && 2 * PT <= 16) ? 2 : 1;
+    // One head per workgroup (5 waves for an 80-token partition) instead of two (10 waves, the CU's wave limit at three workgroups): six
+    // workgroups per CU overlap their load / MFMA / store phases better -- backward 984 -> 889 us per step over the four stages, forward of
+    // stage 1 126 -> 116 us, the rest equal (tools/kbench.py attn, profiles/r04_z_attn_hg_kbench.txt).  LEOD_ATTN_HG1: bit 0 forward, bit 1 backward.
+    static const int hg1 = getenv("LEOD_ATTN_HG1") ? atoi(getenv("LEOD_ATTN_HG1")) : 3;
+    const int HG = (g.heads % 2 == 0 && 2 * PT <= 16 && !((hg1 & 1) && which == 0) && !((hg1 & 2) && which != 0)) ? 2 : 1;
     static const int force_pad1 = 1;
     // (LEOD_ATTN_LDS_PAD1=0 restores the round-1 routing of one-head workgroups with padded partitions to the register-direct
     // backward; the defect behind it was a mis-merged ds_write2_b32 in the <4, 32, 1> instantiation, see the kernel's epilogue)
