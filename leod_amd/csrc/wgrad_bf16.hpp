@@ -461,10 +461,9 @@ static inline int launch_wgrad_wide_cfg(const void* dy, long lddy, const XRows& 
     if (part != nullptr && !(dbg & 1)) {
         // ~2048 waves of reduce threads: groups of `per` partials
         const int ob = (int)cdiv(O, 256);
-        // (every group ends with one atomic per element: 42 groups on the 192 x 48 tile of stage 1 = 387 k atomics on 9 216 addresses took
-        // 290 us of the tail of the weight-gradient lane; capped, each thread sums more partials instead)
-        static const int gcap = getenv("LEOD_WGW_REDUCE_GROUPS") ? atoi(getenv("LEOD_WGW_REDUCE_GROUPS")) : 512;
-        int groups = max(1, min(min(gx, 512 / ob), gcap));
+        // (capping the groups -- fewer atomics per element, more partials per thread -- did not shorten this kernel: its 100-300 us at the tail of
+        // the weight-gradient lane are contention with the other lane's kernels, 17 us when it runs alone; profiles/r04_a_graph_ab.txt)
+        int groups = max(1, min(gx, 512 / ob));
         const int per = cdiv(gx, groups);
         groups = cdiv(gx, per);
         hipLaunchKernelGGL((wgrad_wide_reduce_kernel<TN, TK, NWN, NWK>), dim3(ob, groups), dim3(256), 0, s, part, gx, (int)grid.y, (int)grid.z, per,
