@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..')
 from leod_amd import ops  # noqa: E402
 
 DEV = 'cuda'
+KEEP = []
 TB = int(os.environ.get('KBENCH_T', '21'))
 STAGES = {1: (40960 * TB, 48), 2: (10240 * TB, 96), 3: (2560 * TB, 192), 4: (640 * TB, 384)}
 
@@ -37,8 +38,16 @@ def main():
     for si in stages:
         M, C = STAGES[si]
         x, lw, lb, g = r(M, C), r(C), r(C), r(C)
-        Wqkv, bqkv, Wp, bp = r(3 * C, C) * .1, r(3 * C), r(C, C) * .1, r(C)
-        W1, b1, W2, b2 = r(4 * C, C) * .1, r(4 * C), r(C, 4 * C) * .1, r(C)
+        # the weights live in one flat buffer, as the parameters of a model do (parallel.FlatParams); KBENCH_SHADOW=1 registers its bf16 shadow
+        flat = torch.randn(12 * C * C, device=DEV) * .1
+        Wqkv, Wp = flat[:3 * C * C].view(3 * C, C), flat[3 * C * C:4 * C * C].view(C, C)
+        W1, W2 = flat[4 * C * C:8 * C * C].view(4 * C, C), flat[8 * C * C:12 * C * C].view(C, 4 * C)
+        bqkv, bp, b1, b2 = r(3 * C), r(C), r(4 * C), r(C)
+        if os.environ.get('KBENCH_SHADOW') == '1':
+            shadow = torch.empty(flat.numel(), dtype=torch.bfloat16, device=DEV)
+            ops.set_weight_shadow(flat, shadow)
+            ops.weight_shadow_refresh()
+            KEEP.append((flat, shadow))
         u, dyC, dy3, dy4 = r(M, 4 * C), r(M, C), r(M, 3 * C), r(M, 4 * C)
         u16, dy4b, dy3b = u.to(torch.float16), dy4.to(torch.bfloat16), dy3.to(torch.bfloat16)
         Wl = r(4 * C, 2 * C) * .1
