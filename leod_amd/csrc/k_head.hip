@@ -27,6 +27,64 @@ __device__ __forceinline__ void anchor_geom(const Levels& L, int a, float& gx, f
 //   raw = (reg(4), obj(1), cls(nc)) ; xy = (raw_xy + grid)*stride ; wh = exp(raw_wh)*stride
 //   out_train: decoded boxes + logits ; out_infer: decoded boxes + sigmoid probabilities
 // ---------------------------------------------------------------------------------------------------
+// Feature rows staged through LDS (Hd <= 128): a workgroup takes 64 positions, copies their reg / cls rows with coalesced 16-byte loads
+// (row stride Hd + 4 floats: the rows a wave reads next fall on different banks) and then computes its 64 x (5 + nc) outputs, one per thread and
+// round, from LDS.  The per-(position, channel) kernel below reads the rows straight from global memory: neighbouring lanes are 384 bytes apart
+// and every row is fetched by 5 + 2 lanes -- 424 us for the 860 k positions of level 0 in the pseudo-label pass (1.5 TB/s); a per-position variant
+// without LDS was slower still (689 us: profiles/r04_a_graph_ab.txt).  Same fmaf chain per output (k ascending): the values are unchanged.
+template <int HDMAX>
+__global__ __launch_bounds__(256) void head_pred_fwd_lds_kernel(const float* __restrict__ cls_feat, const float* __restrict__ reg_feat,
+                                                                const float* __restrict__ cls_w, const float* __restrict__ cls_b,
+                                                                const float* __restrict__ reg_w, const float* __restrict__ reg_b,
+                                                                const float* __restrict__ obj_w, const float* __restrict__ obj_b,
+                                                                float* __restrict__ out_train, float* __restrict__ out_infer,
+                                                                int B, int hw, int wl, int Hd, int nc, int stride, int a0, int A) {
+    constexpr int TP = 64, LDR = HDMAX + 4, MAXCH = 5 + 16;
+    __shared__ __attribute__((aligned(16))) float sR[TP * LDR];
+    __shared__ __attribute__((aligned(16))) float sC[TP * LDR];
+    __shared__ __attribute__((aligned(16))) float sW[MAXCH * HDMAX];     // the 5 + nc weight rows (a global load per k step was a latency chain)
+    __shared__ float sBias[MAXCH];
+    const int nch = 5 + nc, tid = threadIdx.x;
+    const long total = (long)B * hw;
+    const int k4n = Hd / 4;
+    for (int e = tid; e < nch * k4n; e += 256) {
+        const int ch = e / k4n, k4 = e - ch * k4n;
+        const float* w = ch < 4 ? reg_w + (long)ch * Hd : ch == 4 ? obj_w : cls_w + (long)(ch - 5) * Hd;
+        *reinterpret_cast<f4*>(&sW[ch * HDMAX + 4 * k4]) = ld4(w + 4 * k4);
+    }
+    if (tid < nch) sBias[tid] = tid < 4 ? reg_b[tid] : tid == 4 ? obj_b[0] : cls_b[tid - 5];
+    for (long p0 = (long)blockIdx.x * TP; p0 < total; p0 += (long)gridDim.x * TP) {
+        const int np = (int)min((long)TP, total - p0);
+        __syncthreads();                                  // the previous tile's readers are done
+        for (int e = tid; e < np * k4n; e += 256) {
+            const int r = e / k4n, k4 = e - r * k4n;
+            *reinterpret_cast<f4*>(&sR[r * LDR + 4 * k4]) = ld4(reg_feat + (p0 + r) * Hd + 4 * k4);
+            *reinterpret_cast<f4*>(&sC[r * LDR + 4 * k4]) = ld4(cls_feat + (p0 + r) * Hd + 4 * k4);
+        }
+        __syncthreads();
+        for (int o = tid; o < np * nch; o += 256) {
+            const int r = o / nch, ch = o - r * nch;
+            const long pos = p0 + r;
+            const int p = (int)(pos % hw), b = (int)(pos / hw);
+            const float* f = (ch < 5 ? sR : sC) + r * LDR;
+            const float* w = sW + ch * HDMAX;
+            float acc = 0.f;
+#pragma unroll 4
+            for (int k = 0; k < Hd; k += 4) {
+                const f4 a = *reinterpret_cast<const f4*>(f + k), ww = *reinterpret_cast<const f4*>(w + k);
+                acc = fmaf(a.x, ww.x, acc); acc = fmaf(a.y, ww.y, acc); acc = fmaf(a.z, ww.z, acc); acc = fmaf(a.w, ww.w, acc);
+            }
+            acc += sBias[ch];
+            float vt = acc, vi = acc;
+            if (ch < 2) { const int gy = p / wl, gx = p - gy * wl; vt = vi = (acc + (float)(ch == 0 ? gx : gy)) * (float)stride; }
+            else if (ch < 4) { vt = vi = expf(acc) * (float)stride; }
+            else { vi = sigmoidf_(acc); }
+            const long oo = ((long)b * A + a0 + p) * nch + ch;
+            if (out_train) out_train[oo] = vt;
+            if (out_infer) out_infer[oo] = vi;
+        }
+    }
+}
 __global__ __launch_bounds__(256) void head_pred_fwd_kernel(const float* __restrict__ cls_feat, const float* __restrict__ reg_feat,
                                                             const float* __restrict__ cls_w, const float* __restrict__ cls_b,
                                                             const float* __restrict__ reg_w, const float* __restrict__ reg_b,
@@ -736,6 +794,15 @@ LEOD_API int leod_head_pred_fwd(const float* cls_feat, const float* reg_feat, co
     if (!cls_feat || !reg_feat || (Hd & 3) || (!out_train && !out_infer)) return LEOD_ERR_ARG;
     const long total = (long)B * h * w * (5 + nc);
     if (total == 0) return LEOD_OK;
+    static const int lds_on = getenv("LEOD_HEAD_PRED_LDS") ? atoi(getenv("LEOD_HEAD_PRED_LDS")) : 1;
+    if (lds_on && Hd <= 128 && nc <= 16 && (long)B * h * w >= 4096) {
+        const int grid = (int)min((long)2048, ((long)B * h * w + 63) / 64);
+        if (Hd <= 96) hipLaunchKernelGGL(head_pred_fwd_lds_kernel<96>, dim3(grid), dim3(256), 0, stream, cls_feat, reg_feat, cls_w, cls_b,
+                                         reg_w, reg_b, obj_w, obj_b, out_train, out_infer, B, h * w, w, Hd, nc, stride, a0, A);
+        else hipLaunchKernelGGL(head_pred_fwd_lds_kernel<128>, dim3(grid), dim3(256), 0, stream, cls_feat, reg_feat, cls_w, cls_b,
+                                reg_w, reg_b, obj_w, obj_b, out_train, out_infer, B, h * w, w, Hd, nc, stride, a0, A);
+        return leod_launch_status();
+    }
     hipLaunchKernelGGL(head_pred_fwd_kernel, dim3(flat_grid(total)), dim3(256), 0, stream, cls_feat, reg_feat, cls_w, cls_b,
                        reg_w, reg_b, obj_w, obj_b, out_train, out_infer, B, h * w, w, Hd, nc, stride, a0, A);
     return leod_launch_status();
