@@ -289,6 +289,10 @@ int leod_copy_multi(void* const* dst, const void* const* src, const long* nbytes
  * up = 1) and db from dout.  fp32, Ca % 4 == Cb % 4 == 0, up in {0, 1}. */
 int leod_cat2_up_fwd(const float* a, const float* b, float* out, int B, int H, int W, int Ca, int Cb, int up, leod_stream_t stream);
 int leod_cat2_up_bwd(const float* dout, float* da, float* db, int B, int H, int W, int Ca, int Cb, int up, leod_stream_t stream);
+/* dst[idx[j], :] += src[j, :] for j < nsel, rows of row_floats floats (% 4 == 0), idx unique and in [0, nrows_dst): the gradient of the labelled
+ * frames added into the gradient of a stage's output map (the `selected_indices` gather of BackboneFeatureSelector, modules/utils/detection.py:120-157,
+ * differentiated).  No atomics: the indices of one call must be distinct. */
+int leod_rows_index_add(float* dst, const float* src, const long* idx, int nsel, long row_floats, int nrows_dst, leod_stream_t stream);
 /* StackedHistogram.construct (data/utils/representations.py:78-123): int64 events -> uint8 [2*bins,H,W]. */
 int leod_voxelize_u8(const long* x, const long* y, const long* pol, const long* t, long n_events, int* counts_ws,
                      unsigned char* out, int bins, int H, int W, int count_cutoff, int fastmode, leod_stream_t stream);

@@ -280,6 +280,27 @@ LEOD_API int leod_cat2_up_bwd(const float* dout, float* da, float* db, int B, in
     return leod_launch_status();
 }
 
+// dst[idx[j], :] += src[j, :] for rows of n4 float4 (UNIQUE indices: no atomics) -- the labelled frames' gradient added into the gradient of a
+// stage's output map (functions.ForkSelectFn; torch's index_add_ took 20 us per stage for this)
+__global__ __launch_bounds__(256) void rows_index_add_kernel(float* __restrict__ dst, const float* __restrict__ src, const long* __restrict__ idx,
+                                                             long n4, int nrows_dst) {
+    const long j = blockIdx.y;
+    const long r = idx[j];
+    if (r < 0 || r >= nrows_dst) return;
+    f4* d = reinterpret_cast<f4*>(dst) + r * n4;
+    const f4* sp = reinterpret_cast<const f4*>(src) + j * n4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) d[e] = d[e] + sp[e];
+}
+LEOD_API int leod_rows_index_add(float* dst, const float* src, const long* idx, int nsel, long row_floats, int nrows_dst, hipStream_t stream) {
+    if (!dst || !src || !idx || nsel < 0 || row_floats <= 0 || (row_floats & 3) || nrows_dst <= 0 ||
+        ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15)) return LEOD_ERR_ARG;
+    if (nsel == 0) return LEOD_OK;
+    const long n4 = row_floats / 4;
+    const int gx = (int)min((long)64, (n4 + 255) / 256);
+    hipLaunchKernelGGL(rows_index_add_kernel, dim3(gx, nsel), dim3(256), 0, stream, dst, src, idx, n4, nrows_dst);
+    return leod_launch_status();
+}
+
 LEOD_API const char* leod_version() { return "leod_hip 0.2 (gfx950)"; }
 
 // precision mode of the contractions (see common.hpp): process-wide, set once before the first step

@@ -131,7 +131,11 @@ class ForkSelectFn(Function):
         else:
             dx = _cont(g_pass)
         if g_sel is not None:
-            dx.index_add_(0, idx, _cont(g_sel))
+            gs = _cont(g_sel)
+            if dx.is_cuda and dx.dtype is torch.float32 and gs.dtype is torch.float32 and idx.dtype is torch.int64 and dx[0].numel() % 4 == 0:
+                ops.rows_index_add(dx, gs, idx)               # the frame indices of a step are distinct (t * B + b)
+            else:
+                dx.index_add_(0, idx, gs)
         return dx, None
 
 

@@ -909,6 +909,17 @@ def adamw_clip_step(p, g, m, v, lr, step, betas=(0.9, 0.999), eps=1e-8, weight_d
                                      int(step), float(clip_value), float(grad_scale), _p(hp_dev), _stream()), 'adamw_clip_step')
 
 
+def rows_index_add(dst: torch.Tensor, src: torch.Tensor, idx: torch.Tensor) -> None:
+    """dst[idx[j]] += src[j] on dim 0 (fp32, contiguous, UNIQUE int64 indices on the device): one launch, no atomics."""
+    _ck(dst, name='dst')
+    _ck(src, name='src')
+    _ck(idx, torch.int64, 'idx')
+    if dst.shape[1:] != src.shape[1:] or src.shape[0] != idx.numel():
+        raise ValueError('rows_index_add: src rows must match idx and the row shape of dst')
+    row = dst[0].numel()
+    check(_l().leod_rows_index_add(_p(dst), _p(src), _p(idx), int(idx.numel()), row, int(dst.shape[0]), _stream()), 'rows_index_add')
+
+
 def cat2_up_fwd(a: torch.Tensor, b: torch.Tensor, up: bool = False) -> torch.Tensor:
     """out [B,H,W,Ca+Cb] = cat(a (nearest x2 upsampled if ``up``), b) on the channel axis of NHWC maps, one launch."""
     _ck(a, name='a')

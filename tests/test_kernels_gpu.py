@@ -863,3 +863,16 @@ def test_cat2_up_matches_torch(ops, B, H, W, Ca, Cb, up):
     want.backward(g)
     assert torch.equal(b.grad, b2.grad)
     assert torch.allclose(a.grad, a2.grad, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize('N,row,nsel', [(168, (16, 20, 192), 32), (40, (8, 10, 384), 7), (21, (32, 40, 96), 21), (5, (3, 4), 1)])
+def test_rows_index_add_matches_torch(ops, N, row, nsel):
+    """dst[idx[j]] += src[j] with unique indices (the labelled frames' gradient added into a stage output's gradient, functions.ForkSelectFn --
+    the gather of BackboneFeatureSelector, reference modules/utils/detection.py:120-157, differentiated) against torch.index_add_ (exact)."""
+    g = torch.Generator().manual_seed(3)
+    dst = rnd((N,) + row, 1).to(DEV)
+    src = rnd((nsel,) + row, 2).to(DEV)
+    idx = torch.randperm(N, generator=g)[:nsel].sort().values.to(DEV)
+    want = dst.clone().index_add_(0, idx, src)
+    ops.rows_index_add(dst, src, idx)
+    assert torch.equal(dst, want)
