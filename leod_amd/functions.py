@@ -553,12 +553,23 @@ def _conv_bn_bwd(members):
         from .modules.step_plan import PlanRecorder
         hold = sync and PlanRecorder.current is not None
         prev_hold, WgradSide.hold_main = WgradSide.hold_main, hold or WgradSide.hold_main
+        shared_dx = {}
         for (mod, x, z, mean, rstd, conv_w, bn_w, bn_b, stride, count, count_dev, dy, need_dx), sl in zip(live, slices):
             dz = ops.bn_silu_bwd_apply(dy, z, mean, rstd, bn_w, bn_b, sl, grad_buf(mod.bn.weight), grad_buf(mod.bn.bias), count,
                                        count_dev=count_dev)
             with _wgrad_side(dz, x):
                 ops.conv_nhwc_wgrad(dz, x, grad_buf(mod.conv.weight), None, stride=stride)
-            dxs[id(mod)] = ops.conv_nhwc_dgrad(dz, conv_w, x.shape, stride=stride) if need_dx else None
+            if not need_dx:
+                dxs[id(mod)] = None
+                continue
+            # members that read the SAME input (conv1 / conv2 of a CSP layer, the first cls / reg tower convs of a head level) add their input
+            # gradients in the dgrad epilogue of the later member instead of as two autograd edges summed by an extra add kernel
+            key = (x.data_ptr(), tuple(x.shape), stride)
+            if key in shared_dx:
+                ops.conv_nhwc_dgrad(dz, conv_w, x.shape, stride=stride, out=shared_dx[key], accumulate=True)
+                dxs[id(mod)] = None
+            else:
+                dxs[id(mod)] = shared_dx[key] = ops.conv_nhwc_dgrad(dz, conv_w, x.shape, stride=stride)
         WgradSide.hold_main = prev_hold
     return [dxs.get(id(m[0])) for m in members]
 
@@ -600,7 +611,9 @@ class BaseConvGroupFn(Function):
 def base_conv_group(mods, xs):
     """[BaseConv], [NHWC maps] -> [outputs]; grouped into one node (one statistics exchange) in SyncBatchNorm training, plain
     per-layer calls otherwise."""
-    if len(mods) > 1 and mods[0].training and _sync_bn_on():
+    # members reading the same map: their input gradients are summed inside the node (LEOD_GROUP_SHARED=0: separate nodes, autograd adds)
+    shared = len({id(x) for x in xs}) < len(xs) and os.environ.get('LEOD_GROUP_SHARED', '1') != '0' 
+    if len(mods) > 1 and mods[0].training and (_sync_bn_on() or (shared and torch.is_grad_enabled() and xs[0].is_cuda)):
         params = []
         for m in mods:
             params += [m.conv.weight, m.bn.weight, m.bn.bias]
