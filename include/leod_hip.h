@@ -23,10 +23,16 @@ typedef void* leod_stream_t; /* hipStream_t */
 
 const char* leod_version(void);
 
-/* Precision of the contractions (process-wide; set before the first step).  0: fp32 end to end -- v_mfma_f32_16x16x4_f32, bitwise an
- * fp32 fmaf chain, the mode the parity tests pin against the fp32 oracle.  1: the reference's mixed precision (Lightning precision=16,
- * train.py:236-243): GEMM / conv / attention operands rounded to bf16 for v_mfma_f32_16x16x16_bf16, fp32 accumulation; LayerNorm /
- * BatchNorm statistics, softmax, the residual stream, LSTM state, SimOTA cost, losses and the optimiser stay fp32. */
+/* Precision of the contractions (process-wide; set before the first step).
+ * 0: fp32 end to end -- v_mfma_f32_16x16x4_f32, bitwise an fp32 fmaf chain, the mode the parity tests pin against the fp32 oracle.
+ * 2 ("16f"): the reference's mixed precision (Lightning precision=16 = fp16 autocast + GradScaler, train.py:236-243): the FORWARD
+ *    contractions (GEMM, conv, attention, ConvLSTM, stem) take fp16 operands for v_mfma_f32_16x16x16_f16 / 16x16x32_f16 with fp32
+ *    accumulation, and the 16-bit tensors the forward pass stores (qkv, attention output, MLP hidden, LSTM gates) are fp16; the GRADIENT
+ *    contractions take bf16 operands (fp32's exponent range: no loss scaler) and gradient rows (dqkv, du, dO, gate gradients) are bf16.
+ * 1 ("bf16", Lightning bf16-mixed): bf16 operands and bf16 rows in both directions.
+ * In both 16-bit modes LayerNorm / BatchNorm statistics, softmax, the residual stream, LSTM state, SimOTA cost, losses and the optimiser
+ * stay fp32.  Wherever a comment below says "precision mode bf16" it means "modes 1 and 2"; the parameters called *_bf16 that describe
+ * FORWARD-stored activation rows (qkv, the attention output) carry fp16 rows in mode 2. */
 int leod_set_precision(int mode);
 int leod_get_precision(void);
 
@@ -271,6 +277,10 @@ int leod_adamw_clip_step(float* p, float* g, float* m, float* v, long n, float l
  * buffer and leod_weight_shadow_invalidate mark shadows stale (stale shadows are never read); leod_weight_shadow_pin(1) makes the
  * launchers read the shadows regardless of the flags while a step is being recorded behind a forced refresh. */
 int leod_set_weight_shadow(const float* base, long n, void* shadow16);
+/* fp16 copy (n values, caller-owned, 8-byte aligned; NULL withdraws it) of a buffer registered above: leod_weight_shadow_refresh writes it
+ * next to the bf16 copy in precision mode 2 ("16f"), whose forward GEMMs read it (the gradient GEMMs keep reading the bf16 copy).
+ * LEOD_ERR_ARG if base is not registered. */
+int leod_set_weight_shadow_f16(const float* base, void* shadow_f16);
 int leod_weight_shadow_refresh(int force, leod_stream_t stream);
 int leod_weight_shadow_invalidate(void);
 int leod_weight_shadow_pin(int on);

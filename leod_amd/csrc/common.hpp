@@ -138,13 +138,45 @@ __device__ __forceinline__ f4 mfma32_bf16(s8v a, s8v b, f4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
 }
 
-// Operand fragment of one 16-k chunk in either precision: BF = false keeps the f4 (four exact fp32 MFMAs consume it),
-// BF = true packs it to 4 bf16 once (one bf16 MFMA consumes it).
-template <bool BF> struct Frag16;
-template <> struct Frag16<false> { f4 v; __device__ __forceinline__ void set(f4 x) { v = x; } };
-template <> struct Frag16<true> { s4 v; __device__ __forceinline__ void set(f4 x) { v = pack_bf16(x); } };
-template <bool BF> __device__ __forceinline__ f4 mfma_frag(const Frag16<BF>& a, const Frag16<BF>& b, f4 c) {
-    if constexpr (BF) return mfma16_bf16(a.v, b.v, c);
+// ---- fp16 MFMA operands (precision mode "16f": the reference's own autocast dtype, train.py:236-243 precision=16 -> torch.float16) ----
+// Same operand layouts and issue rates as the bf16 forms above; 11 significand bits instead of 8.  Forward contractions of mode 16f use
+// these (activations and weights of the path are bounded: LayerNorm / BatchNorm+SiLU outputs, |h| < 1, uint8 counts, softmax weights);
+// gradient contractions keep bf16 operands (the range of fp32 without a loss scaler).
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f4 mfma16_f16(s4 a, s4 b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4v, a), __builtin_bit_cast(h4v, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f4 mfma32_f16(s8v a, s8v b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), __builtin_bit_cast(h8v, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ s4 pack_h16_raw(f4 v) {          // no clamp: operands known to be far inside the fp16 range (weights, LayerNorm rows, P)
+    const f2_ lo = {v.x, v.y}, hi = {v.z, v.w};
+    const u2_ r = {__builtin_bit_cast(unsigned, __builtin_convertvector(lo, h2_)),
+                   __builtin_bit_cast(unsigned, __builtin_convertvector(hi, h2_))};
+    return __builtin_bit_cast(s4, r);
+}
+__device__ __forceinline__ s4 pack_h16_sat(f4 v) {          // one v_med3_f32 per element: an outlier saturates instead of becoming inf
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], -65504.f, 65504.f);
+    return pack_h16_raw(v);
+}
+// Operand format OF of a 16-bit contraction: 1 = bf16, 2 = fp16 (0 = fp32 kernels never call these).  Kernels carry it as an int
+// template parameter (`BF` in the older skeletons: 0 / 1 / 2, every `if constexpr (BF)` reads "16-bit operands").
+template <int OF> __device__ __forceinline__ s4 pack16(f4 v) { if constexpr (OF == 2) return pack_h16_sat(v); else return pack_bf16(v); }
+template <int OF> __device__ __forceinline__ s4 pack16_raw(f4 v) { if constexpr (OF == 2) return pack_h16_raw(v); else return pack_bf16(v); }
+template <int OF> __device__ __forceinline__ f4 unpack16(s4 v) { if constexpr (OF == 2) return unpack_h16(v); else return unpack_bf16(v); }
+template <int OF> __device__ __forceinline__ f4 mfma16_16(s4 a, s4 b, f4 c) { if constexpr (OF == 2) return mfma16_f16(a, b, c); else return mfma16_bf16(a, b, c); }
+template <int OF> __device__ __forceinline__ f4 mfma32_16(s8v a, s8v b, f4 c) { if constexpr (OF == 2) return mfma32_f16(a, b, c); else return mfma32_bf16(a, b, c); }
+// fp16 -> bf16 re-rounding of four stored values (backward kernels of mode 16f that contract forward-stored fp16 rows with bf16 gradients)
+__device__ __forceinline__ s4 h16_to_bf16(s4 v) { return pack_bf16(unpack_h16(v)); }
+
+// Operand fragment of one 16-k chunk: OF = 0 keeps the f4 (four exact fp32 MFMAs consume it), OF = 1 / 2 packs it to 4 bf16 / fp16 once
+// (one 16-bit MFMA consumes it).
+template <int OF> struct Frag16 { s4 v; __device__ __forceinline__ void set(f4 x) { v = pack16<OF>(x); } };
+template <> struct Frag16<0> { f4 v; __device__ __forceinline__ void set(f4 x) { v = x; } };
+template <int OF> __device__ __forceinline__ f4 mfma_frag(const Frag16<OF>& a, const Frag16<OF>& b, f4 c) {
+    if constexpr (OF != 0) return mfma16_16<OF>(a.v, b.v, c);
     else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) c = mfma16(a.v[j], b.v[j], c);
@@ -152,11 +184,43 @@ template <bool BF> __device__ __forceinline__ f4 mfma_frag(const Frag16<BF>& a, 
     }
 }
 
-// Precision mode of the library (host side): 0 = fp32 end to end (bit-tight against the fp32 oracle), 1 = bf16 MFMA operands
-// with fp32 accumulation / statistics / state.  Set through leod_set_precision; read by the launchers.
+// Precision mode of the library (host side), set through leod_set_precision:
+//   0 = fp32 end to end (bit-tight against the fp32 oracle);
+//   1 = "bf16": bf16 MFMA operands everywhere, fp32 accumulation / statistics / state;
+//   2 = "16f": as 1, but the FORWARD contractions take fp16 operands (the reference's autocast dtype) and the 16-bit activations the
+//       forward pass leaves in HBM (qkv, attention output, MLP hidden, conv packs, weight shadow) are fp16; gradients stay bf16.
+// leod_precision() is 1 in both 16-bit modes (tensor layouts, kernel families); leod_opfmt() is the operand format (0 / 1 / 2) of the
+// contraction being launched: 2 only inside a LeodFwdScope of mode 2.  Forward entry points of the C ABI open such a scope.
 int leod_precision();
-// bf16 shadow of a registered fp32 weight buffer (k_misc.hip: leod_set_weight_shadow / leod_weight_shadow_refresh): the bf16 copy of
-// the weight at `w` if `w` lies in a registered buffer whose shadow is fresh, else nullptr.  The GEMM weight loaders of precision mode
-// bf16 read it instead of converting fp32 weights on every tile load (same rounding: pack_bf16) -- half the L2 -> CU bytes.
-const unsigned short* leod_shadow_of(const float* w);
+int leod_precision_mode();
+int leod_opfmt();
+struct LeodFwdScope { LeodFwdScope(); ~LeodFwdScope(); LeodFwdScope(const LeodFwdScope&) = delete; };
+// 16-bit shadow of a registered fp32 weight buffer (k_misc.hip: leod_set_weight_shadow / leod_weight_shadow_refresh): the copy of the
+// weight at `w` in operand format `of` (1 bf16 / 2 fp16) if `w` lies in a registered buffer whose shadow is fresh, else nullptr.  The GEMM
+// weight loaders of the 16-bit modes read it instead of converting fp32 weights on every tile load (same rounding) -- half the L2 -> CU bytes.
+const unsigned short* leod_shadow_of(const float* w, int of = 1);
 #define LEOD_BY_PREC(CALL_BF, CALL_F32) (leod_precision() == 1 ? (CALL_BF) : (CALL_F32))
+// run CALL with `constexpr int OF` = the operand format of the launch (leod_opfmt())
+#define LEOD_BY_OPFMT(...)                                                   \
+    switch (leod_opfmt()) {                                                  \
+        case 2: { constexpr int OF = 2; __VA_ARGS__; } break;                \
+        case 1: { constexpr int OF = 1; __VA_ARGS__; } break;                \
+        default: { constexpr int OF = 0; __VA_ARGS__; } break;               \
+    }
+// the same where operand format 2 is only instantiated when FWD (a compile-time bool: the loader types of forward contractions)
+#define LEOD_BY_OPFMT_IF(FWD, ...)                                           \
+    switch (leod_opfmt()) {                                                  \
+        case 2: if constexpr (FWD) { constexpr int OF = 2; __VA_ARGS__; break; }   \
+        case 1: { constexpr int OF = 1; __VA_ARGS__; } break;                \
+        default: { constexpr int OF = 0; __VA_ARGS__; } break;               \
+    }
+#define LEOD_BY_OPFMT16_IF(FWD, ...)                                         \
+    switch (leod_opfmt()) {                                                  \
+        case 2: if constexpr (FWD) { constexpr int OF = 2; __VA_ARGS__; break; }   \
+        default: { constexpr int OF = 1; __VA_ARGS__; } break;               \
+    }
+#define LEOD_BY_OPFMT16(...)                                                 \
+    switch (leod_opfmt()) {                                                  \
+        case 2: { constexpr int OF = 2; __VA_ARGS__; } break;                \
+        default: { constexpr int OF = 1; __VA_ARGS__; } break;               \
+    }

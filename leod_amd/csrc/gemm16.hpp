@@ -37,7 +37,7 @@ struct ALRows {                 // plain rows, optional LayerNorm prologue, opti
     float* stats_out;                                   // optional [M,2] (mean, rstd) written by n-block 0
     int K;                                              // row length used for the LN statistics
     const float* stats_in;                              // optional precomputed [M,2] (mean, rstd): skips the statistics passes
-    int fmt;                                            // 0: x is fp32; 1: x is an fp16 PRE-activation, A = gelu(x) (the MLP hidden of stages 1-2 is stored
+    int fmt;                                            // 2: bf16 rows; 3: fp16 rows (plain); 0: x is fp32; 1: x is an fp16 PRE-activation, A = gelu(x) (the MLP hidden of stages 1-2 is stored
                                                         // once, as fp16, in precision mode bf16: maxvit.py:110-118 under the reference's autocast)
     struct St { const float* p; float mean, rstd; bool ok; };
     __device__ __forceinline__ int klen(const St&, int K) const { return K; }
@@ -75,6 +75,10 @@ struct ALRows {                 // plain rows, optional LayerNorm prologue, opti
         if (fmt == 2) {                                  // bf16 gradient rows (precision mode bf16: du / dqkv are stored as the bf16 the MFMAs consume)
             f4 v = unpack_bf16(*reinterpret_cast<const s4*>(reinterpret_cast<const unsigned short*>(s.p) + k));
             if (kscale) v = v * ld4(kscale + k);
+            return s.ok ? v : zero4();
+        }
+        if (fmt == 3) {                                  // fp16 activation rows (precision mode 16f: the attention output)
+            f4 v = unpack_h16(*reinterpret_cast<const s4*>(reinterpret_cast<const unsigned short*>(s.p) + k));
             return s.ok ? v : zero4();
         }
         f4 v = ld4(s.p + k);
@@ -119,6 +123,7 @@ struct ALRowsM : ALRows {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
         } else if constexpr (FMT == 2) v = unpack_bf16(__builtin_bit_cast(s4, r.h));
+        else if constexpr (FMT == 3) v = unpack_h16(__builtin_bit_cast(s4, r.h));
         else v = r.v;
         if constexpr (LN) v = (v - st.mean) * st.rstd * rk.g + rk.b;
         if constexpr (KS) v = v * rk.s;
@@ -131,6 +136,7 @@ struct ALRowsM : ALRows {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
         } else if constexpr (FMT == 2) v = unpack_bf16(__builtin_bit_cast(s4, r.h));
+        else if constexpr (FMT == 3) v = unpack_h16(__builtin_bit_cast(s4, r.h));
         else v = r.v;
         if constexpr (LN) v = (v - st.mean) * st.rstd * r.g + r.b;
         if constexpr (KS) v = v * r.s;
@@ -351,6 +357,12 @@ struct BLTrans16 : BLTrans {};
 template <class BL> struct bl_is16 { static constexpr bool value = false; };
 template <> struct bl_is16<BLRows16> { static constexpr bool value = true; };
 template <> struct bl_is16<BLTrans16> { static constexpr bool value = true; };
+// weight loaders of FORWARD contractions (W[n][k] as stored): the only ones instantiated with fp16 operands (precision mode 16f)
+template <class BL> struct bl_fwd { static constexpr bool value = !BL::kTrans; };
+struct BLConvWT; struct BLConvWT2; struct BLPackT2;
+template <> struct bl_fwd<BLConvWT> { static constexpr bool value = false; };
+template <> struct bl_fwd<BLConvWT2> { static constexpr bool value = false; };
+template <> struct bl_fwd<BLPackT2> { static constexpr bool value = false; };
 template <class BL> struct bl_shadow_type { typedef void type; };
 template <> struct bl_shadow_type<BLRows> { typedef BLRows16 type; };
 template <> struct bl_shadow_type<BLTrans> { typedef BLTrans16 type; };
@@ -829,7 +841,7 @@ struct EpLstm {                     // NT must be 4: tiles = (f, i, o, g) of cha
 //            and 4x shorter dependent MFMA chains, no atomics.
 // Operand loads run two chunks ahead of the MFMAs (register ring of depth 2).
 // =================================================================================================
-template <int NT, int KS, bool BF, class AL, class BL, class EP>
+template <int NT, int KS, int BF, class AL, class BL, class EP>
 __global__ __launch_bounds__(256) void gemm16_kernel(AL al, BL bl, EP ep, int M, int K) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -870,9 +882,9 @@ __global__ __launch_bounds__(256) void gemm16_kernel(AL al, BL bl, EP ep, int M,
                 for (int t = 0; t < NT; ++t) b0[t] = bl.load(nblk, t, i, kn * 16 + 4 * q, K, aux);
             }
             if constexpr (BF) {
-                Frag16<true> fa; fa.set(ta);
+                Frag16<BF> fa; fa.set(ta);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) { Frag16<true> fb; fb.set(tb[t]); acc[t] = mfma_frag<true>(fa, fb, acc[t]); }
+                for (int t = 0; t < NT; ++t) { Frag16<BF> fb; fb.set(tb[t]); acc[t] = mfma_frag<BF>(fa, fb, acc[t]); }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -891,9 +903,9 @@ __global__ __launch_bounds__(256) void gemm16_kernel(AL al, BL bl, EP ep, int M,
                 for (int t = 0; t < NT; ++t) b1[t] = bl.load(nblk, t, i, kn * 16 + 4 * q, K, aux);
             }
             if constexpr (BF) {
-                Frag16<true> fa; fa.set(ta);
+                Frag16<BF> fa; fa.set(ta);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) { Frag16<true> fb; fb.set(tb[t]); acc[t] = mfma_frag<true>(fa, fb, acc[t]); }
+                for (int t = 0; t < NT; ++t) { Frag16<BF> fb; fb.set(tb[t]); acc[t] = mfma_frag<BF>(fa, fb, acc[t]); }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -928,15 +940,12 @@ static inline int launch_gemm16(const AL& al, const BL& bl, const EP& ep, int M,
     if (M <= 0) return LEOD_OK;
     // fewer than ~2 workgroups per CU and a long K loop: split K across the 4 waves of each workgroup
     const bool ksplit = (long)cdiv(M, 64) * nblocks_n < 512 && K >= 128;
-    const bool bf = leod_precision() == 1;
     if (ksplit) {
         dim3 grid(cdiv(M, 16), nblocks_n);
-        if (bf) hipLaunchKernelGGL((gemm16_kernel<NT, 4, true, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
-        else hipLaunchKernelGGL((gemm16_kernel<NT, 4, false, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+        LEOD_BY_OPFMT_IF(bl_fwd<BL>::value, hipLaunchKernelGGL((gemm16_kernel<NT, 4, OF, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K));
     } else {
         dim3 grid(cdiv(M, 64), nblocks_n);
-        if (bf) hipLaunchKernelGGL((gemm16_kernel<NT, 1, true, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
-        else hipLaunchKernelGGL((gemm16_kernel<NT, 1, false, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K);
+        LEOD_BY_OPFMT_IF(bl_fwd<BL>::value, hipLaunchKernelGGL((gemm16_kernel<NT, 1, OF, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K));
     }
     return leod_launch_status();
 }
@@ -958,7 +967,7 @@ static inline int launch_gemm16(const AL& al, const BL& bl, const EP& ep, int M,
 // distinct bank pairs.  Transposed weights (dgrad: W[k][n], n contiguous) are stored as [16 k][16 n] blocks in their natural
 // orientation (8-byte stores of 4 n; block stride 512 + 32 bytes keeps the 16-lane store groups conflict-free) and read back with
 // ds_read_b64_tr_b16, whose 16-lane groups return the [4 k][16 n] block column-wise: lane (i, q) gets W[4q..4q+3][n = i].
-template <int NT, int KCH, int NBUF, int RW, bool BF, class AL, class BL, class EP>
+template <int NT, int KCH, int NBUF, int RW, int BF, class AL, class BL, class EP>
 __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_lds_kernel(AL al, BL bl, EP ep, int M, int K, int nblocks_n) {
     constexpr int BM = 64 * RW;
     // ds_read_b128 is serviced in 4 groups of 16 lanes, {0-3,12-15,20-27}, ...: rows {0-3,12-15} at k-offset 4q and rows
@@ -1058,9 +1067,9 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
             unsigned short* __restrict__ a16 = reinterpret_cast<unsigned short*>(sA[buf]);
             unsigned short* __restrict__ b16 = reinterpret_cast<unsigned short*>(sB[buf]);
 #pragma unroll
-            for (int p = 0; p < RA; ++p) if (aok[p]) *reinterpret_cast<s4*>(a16 + al_off[p]) = pack_bf16(ra[p]);
+            for (int p = 0; p < RA; ++p) if (aok[p]) *reinterpret_cast<s4*>(a16 + al_off[p]) = pack16<BF>(ra[p]);
 #pragma unroll
-            for (int p = 0; p < RB; ++p) if (bok[p]) *reinterpret_cast<s4*>(b16 + bl_off[p]) = bl_is16<BL>::value ? shadow_s4(rb[p]) : pack_bf16(rb[p]);
+            for (int p = 0; p < RB; ++p) if (bok[p]) *reinterpret_cast<s4*>(b16 + bl_off[p]) = bl_is16<BL>::value ? shadow_s4(rb[p]) : pack16_raw<BF>(rb[p]);
         } else {
 #pragma unroll
             for (int p = 0; p < RA; ++p) if (aok[p]) *reinterpret_cast<f4*>(&sA[buf][al_off[p]]) = ra[p];
@@ -1102,7 +1111,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? (RW == 1 ? 4 : 3) : 2) void gemm_l
                     if constexpr (BL::kTrans) bv = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(pb + (c * NT + t) * BST));
                     else bv = *reinterpret_cast<const s4*>(pb + 16 * t * LD + 16 * c);
 #pragma unroll
-                    for (int w = 0; w < RW; ++w) acc[w][t] = mfma16_bf16(av[w], bv, acc[w][t]);
+                    for (int w = 0; w < RW; ++w) acc[w][t] = mfma16_16<BF>(av[w], bv, acc[w][t]);
                 }
             }
         } else {
@@ -1208,7 +1217,7 @@ static inline int launch_row_stats(const float* x, long ld, float* stats, int M,
 template <class BL> static inline const unsigned short* bl_shadow_ptr(const BL& bl) {
 #ifdef LEOD_SHADOW_KERNELS
     if constexpr (!std::is_void<typename bl_shadow_type<BL>::type>::value) {
-        if (leod_precision() == 1 && !(bl.ld & 3)) return leod_shadow_of(bl.w);
+        if (leod_precision() == 1 && !(bl.ld & 3)) return leod_shadow_of(bl.w, leod_opfmt());
     }
 #endif
     return nullptr;
@@ -1232,20 +1241,11 @@ static inline int launch_gemm_lds_rw(const AL& al, const BL& bl, const EP& ep, i
     // better than a double buffer at 2-3 workgroups per CU does (measured; LEOD_LDS_NBUF=2 selects the double buffer)
     static const int nbuf = 1;
     (void)nbuf;                                      // the double-buffered variant is no longer instantiated (never faster, see above)
-    const bool bf = leod_precision() == 1;
-    // bf16 mode: the MFMAs of a chunk are ~8x cheaper, what remains per chunk is the fetch -> barrier -> stash -> barrier skeleton:
-    // 96-wide chunks (26 KB of bf16 tiles per workgroup) halve the number of rounds of the long contractions (K = 192 .. 1536)
-    static const int kch96 = 0;      // measured: 38.2 vs 34.2 ms per step with 96-wide chunks on -> off
-    if (bf && kch96 && K % 96 == 0 && K >= 192) {
-        hipLaunchKernelGGL((gemm_lds_kernel<NT, 96, 1, RW, true, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
-        return leod_launch_status();
-    }
+    // (96-wide chunks in the 16-bit modes, measured: 38.2 vs 34.2 ms per step on -> off; not instantiated)
     if (K % 48 == 0) {
-        if (bf) hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 1, RW, true, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
-        else hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 1, RW, false, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
+        LEOD_BY_OPFMT_IF(bl_fwd<BL>::value, hipLaunchKernelGGL((gemm_lds_kernel<NT, 48, 1, RW, OF, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n));
     } else {
-        if (bf) hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 1, RW, true, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
-        else hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 1, RW, false, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n);
+        LEOD_BY_OPFMT_IF(bl_fwd<BL>::value, hipLaunchKernelGGL((gemm_lds_kernel<NT, 64, 1, RW, OF, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, K, nblocks_n));
     }
     return leod_launch_status();
 }
@@ -1279,6 +1279,7 @@ static inline int launch_gemm_lds(const ALRows& al, const BL& bl, const EP& ep, 
             } else if constexpr (rows && !store) {          // proj / fc2 + LayerScale + residual (fc2: gelu of the fp16 pre-activation)
                 if (al.fmt == 0 && !ln && !ks) LEOD_WIDE(0, false, false)
                 if (al.fmt == 1 && !ln && !ks) LEOD_WIDE(1, false, false)
+                if (al.fmt == 3 && !ln && !ks) LEOD_WIDE(3, false, false)
             } else if constexpr (!rows && store) {          // dgrads: fp32 / bf16 gradient rows, optional LayerScale factor
                 if (al.fmt == 0 && !ln && !ks) LEOD_WIDE(0, false, false)
                 if (al.fmt == 0 && !ln && ks) LEOD_WIDE(0, false, true)
@@ -1297,6 +1298,7 @@ static inline int launch_gemm_lds(const ALRows& al, const BL& bl, const EP& ep, 
             if (al.fmt == 2 && !ln && !ks) LEOD_ALM(2, false, false)
             if (al.fmt == 2 && !ln && ks) LEOD_ALM(2, false, true)
             if (al.fmt == 1 && !ln && !ks) LEOD_ALM(1, false, false)
+            if (al.fmt == 3 && !ln && !ks) LEOD_ALM(3, false, false)
 #undef LEOD_ALM
         }
     }
@@ -1313,7 +1315,7 @@ static inline bool use_gemm_lds(int M, int nblocks_n) { return (long)cdiv(M, 64)
 struct XRows {                      // X(m,k) = x[m][k], optional LayerNorm with saved (mean, rstd)
     const float* x; long ld; const float* stats; const float* ln_w; const float* ln_b;
     const float* x2; long ld2; int K1;          // optional concat source for k >= K1
-    int fmt;                                    // 1: x is an fp16 pre-activation, X = gelu(x) (see ALRows::fmt); 2: x holds bf16 rows
+    int fmt;                                    // 1: x is an fp16 pre-activation, X = gelu(x) (see ALRows::fmt); 2: x holds bf16 rows; 3: fp16 rows
     __device__ __forceinline__ float get(int m, int k) const {
         if (fmt == 1) return gelu_erf(unpack_h16_1(reinterpret_cast<const unsigned short*>(x)[(long)m * ld + k]));
         if (x2 && k >= K1) return x2[(long)m * ld2 + (k - K1)];
@@ -1355,7 +1357,7 @@ struct XRows {                      // X(m,k) = x[m][k], optional LayerNorm with
         if constexpr (XM == 1) { const f4 n = (v - st.x) * st.y * g + b; return (x2 && k >= K1) ? v : n; }
         return v;
     }
-    int x_mode() const { return fmt == 2 ? 3 : fmt == 1 ? 2 : (stats ? 1 : 0); }    // 3: bf16 rows (wgrad_wide_bf16_kernel only)
+    int x_mode() const { return fmt == 3 ? 4 : fmt == 2 ? 3 : fmt == 1 ? 2 : (stats ? 1 : 0); }    // 3 / 4: bf16 / fp16 rows (wgrad_wide_bf16_kernel only)
     __device__ __forceinline__ long waddr(int n, int k, long ldw) const { return (long)n * ldw + k; }
 };
 // loaders with the raw4 / fin4 pair (see XRows) are staged in two phases by wgradw_kernel

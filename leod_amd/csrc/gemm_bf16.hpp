@@ -24,7 +24,8 @@
 // WN = 4, KCH = 64: the 8-wave workgroup described above (one per CU).  WN = 2, KCH = 32 (NTW = 3 only): a 4-wave workgroup with the same
 // 128 x 192 tile -- waves 2 x 2, each 64 rows x 96 columns = 4 x 6 accumulator tiles, epilogue in two 48-column halves -- on 76 KB of LDS,
 // so two workgroups can share a CU (kept as a template option; see launch_gemm_wide for what it measured).
-template <int NTW, class AL, class BL, class EP, int WN = 4, int KCH = 64>
+// OF: operand format, 1 = bf16, 2 = fp16 (forward launches of precision mode 16f)
+template <int NTW, class AL, class BL, class EP, int OF = 1, int WN = 4, int KCH = 64>
 __global__ __launch_bounds__(128 * WN, 2) void gemm_wide_bf16_kernel(AL al, BL bl, EP ep, int M, int K, int nblocks_n, int dbg) {
     constexpr int K4 = KCH / 4, BM = 128, BN = 64 * NTW, LD = KCH + 16;
     constexpr int NTHR = 128 * WN, NWAVE = 2 * WN, RS = NTHR / K4;   // threads, waves, rows per staging pass
@@ -102,13 +103,13 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_wide_bf16_kernel(AL al, BL b
 #pragma unroll
         for (int p = 0; p < RA; ++p) {
             const f4 v = al.fin_k(ast[p], raw_a[p], raw_a[0]);
-            *reinterpret_cast<s4*>(sA + a_off + RS * p * LD) = pack_bf16((ast[p].ok && kok) ? v : zero4());
+            *reinterpret_cast<s4*>(sA + a_off + RS * p * LD) = pack16<OF>((ast[p].ok && kok) ? v : zero4());
         }
 #pragma unroll
         for (int p = 0; p < RB; ++p) {
             const bool ok = (ncol_f + bn[p] < bl.N) && (k0 + bk[p] < K);
             if constexpr (bl_is16<BL>::value) *reinterpret_cast<s4*>(sB + b_off[p]) = ok ? shadow_s4(rb[p]) : s4{0, 0, 0, 0};
-            else *reinterpret_cast<s4*>(sB + b_off[p]) = pack_bf16(ok ? rb[p] : zero4());
+            else *reinterpret_cast<s4*>(sB + b_off[p]) = pack16_raw<OF>(ok ? rb[p] : zero4());
         }
     };
     auto advance_fetch = [&]() -> bool {                       // next chunk of this workgroup's range; false: none left
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_wide_bf16_kernel(AL al, BL b
 #pragma unroll
             for (int t = 0; t < TW; ++t)
 #pragma unroll
-                for (int w = 0; w < 4; ++w) acc[w][t] = mfma32_bf16(av[w], bv[t], acc[w][t]);
+                for (int w = 0; w < 4; ++w) acc[w][t] = mfma32_16<OF>(av[w], bv[t], acc[w][t]);
         }
         // ---- last chunk of a tile: epilogue, one 16 x (16 NTW) accumulator fragment at a time through the wave-private tile; the
         // loads of the next tile's first chunk are already in flight ---------------------------------------------------------------
@@ -255,6 +256,6 @@ static inline int launch_gemm_wide(const AL& al, const BL& bl, const EP& ep, int
     // equal on the 53 k-row launches and 1.2-1.5x slower on the 13 k-row ones, whose 105-210 tiles then run on four waves per CU each:
     // 40 -> 57 us dgrad of fc1, 59 -> 75 us fc2; LN -> fc1 -> GELU alone gained, 66 -> 60 us.  The step did not move.)
     // one persistent 8-wave workgroup per CU (132-152 KB of LDS each)
-    hipLaunchKernelGGL((gemm_wide_bf16_kernel<NTW, AL, BL, EP>), dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(512), 0, s, al, bl, ep, M, K, nbn, dbg);
+    LEOD_BY_OPFMT16_IF(bl_fwd<BL>::value, hipLaunchKernelGGL((gemm_wide_bf16_kernel<NTW, AL, BL, EP, OF>), dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(512), 0, s, al, bl, ep, M, K, nbn, dbg));
     return leod_launch_status();
 }

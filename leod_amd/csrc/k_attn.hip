@@ -359,12 +359,12 @@ __device__ __forceinline__ KFrag<D> kfrag_load(const float* row, int rg) {
 // BF (precision mode bf16): operands rounded to bf16 in registers, one v_mfma_f32_16x16x16_bf16 per 16-wide chunk and one for the
 // 8-wide tail (both operands carry their two tail values in slots 0, 1 and zeros in 2, 3: a contraction only needs the two
 // operands to agree on which slot holds which k).
-template <int D, bool BF = false>
+template <int D, int BF = 0>
 __device__ __forceinline__ f4 kfrag_mfma(const KFrag<D>& a, const KFrag<D>& b, f4 acc) {
-    if constexpr (BF) {
+    if constexpr (BF != 0) {
 #pragma unroll
-        for (int c = 0; c < KFrag<D>::NC; ++c) acc = mfma16_bf16(pack_bf16(a.c[c]), pack_bf16(b.c[c]), acc);
-        if (KFrag<D>::TAIL) acc = mfma16_bf16(pack_bf16(f4{a.t0, a.t1, 0.f, 0.f}), pack_bf16(f4{b.t0, b.t1, 0.f, 0.f}), acc);
+        for (int c = 0; c < KFrag<D>::NC; ++c) acc = mfma16_16<BF>(pack16<BF>(a.c[c]), pack16<BF>(b.c[c]), acc);
+        if (KFrag<D>::TAIL) acc = mfma16_16<BF>(pack16<BF>(f4{a.t0, a.t1, 0.f, 0.f}), pack16<BF>(f4{b.t0, b.t1, 0.f, 0.f}), acc);
         return acc;
     } else {
 #pragma unroll
@@ -376,7 +376,7 @@ __device__ __forceinline__ f4 kfrag_mfma(const KFrag<D>& a, const KFrag<D>& b, f
     }
 }
 
-template <int PT, int D, int HG, bool BF = false>
+template <int PT, int D, int HG, int BF = 0>
 __global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                       float* __restrict__ lse, AttnGeom g, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -459,13 +459,13 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds_kernel(const float*
         // ONE bf16 MFMA per (key tile, column tile) instead of four fp32 ones
 #pragma unroll
         for (int mt = 0; mt < PT; ++mt) {
-            const s4 pa = pack_bf16(s[mt] * inv);
+            const s4 pa = pack16_raw<BF>(s[mt] * inv);
             const float* vrow = hb + (16 * mt + 4 * rg) * S + 2 * d;
 #pragma unroll
             for (int ct = 0; ct < DCH; ++ct) {
                 const bool ok = 16 * ct + i < d;
                 const f4 vv = ok ? f4{vrow[16 * ct + i], vrow[S + 16 * ct + i], vrow[2 * S + 16 * ct + i], vrow[3 * S + 16 * ct + i]} : zero4();
-                o[ct] = mfma16_bf16(pa, pack_bf16(vv), o[ct]);
+                o[ct] = mfma16_16<BF>(pa, pack16<BF>(vv), o[ct]);
             }
         }
     } else {
@@ -752,7 +752,9 @@ __device__ __forceinline__ s4 a16_tfrag(const unsigned* base, int row0, int sd, 
 // stage rows of 8-element units: src rows are bf16 (SRC16) or fp32; all global loads first, then the LDS stores.  The padding units of a
 // row (SDW / 4 > UNITS) and the 8 slack dwords behind the last row are ZEROED: the fragments of the last part of a row read 8 elements
 // past it, and although those values only ever meet a zeroed operand or feed discarded output columns, 0 * NaN is NaN.
-template <int NTHR, int TOK, int UNITS, int SDW, bool SRC16>
+// CVT (SRC16 only): the source rows are fp16 (forward-stored tensors of precision mode 16f) and are re-rounded to the bf16 the gradient
+// MFMAs take while they are stored to LDS
+template <int NTHR, int TOK, int UNITS, int SDW, bool SRC16, bool CVT = false>
 struct A16Raw {                                                 // the global loads of one staged operand, still in registers
     static constexpr int UR = SDW / 4;                          // units per staged row, padding included
     static constexpr int NL = (TOK * UR + NTHR - 1) / NTHR;
@@ -775,7 +777,11 @@ struct A16Raw {                                                 // the global lo
         for (int j = 0; j < NL; ++j) {
             const int e = tid + j * NTHR, tok = e / UR, f = e - tok * UR;
             u4v_ v;
-            if constexpr (SRC16) v = raw16[j];
+            if constexpr (SRC16 && CVT) {
+                const u2_ lo = __builtin_bit_cast(u2_, h16_to_bf16(__builtin_bit_cast(s4, u2_{raw16[j].x, raw16[j].y})));
+                const u2_ hi = __builtin_bit_cast(u2_, h16_to_bf16(__builtin_bit_cast(s4, u2_{raw16[j].z, raw16[j].w})));
+                v = u4v_{lo.x, lo.y, hi.x, hi.y};
+            } else if constexpr (SRC16) v = raw16[j];
             else {
                 const s4 lo = pack_bf16(raw32[2 * j]), hi = pack_bf16(raw32[2 * j + 1]);
                 const u2_ a = __builtin_bit_cast(u2_, lo), b = __builtin_bit_cast(u2_, hi);
@@ -793,7 +799,8 @@ __device__ __forceinline__ void a16_stage(unsigned* dst, const void* src, const 
     r.store(dst, tid);
 }
 
-template <int PT, int D, int HG>
+// OF: 1 = bf16 rows and operands, 2 = fp16 rows and operands (precision mode 16f: q, k, v, P and the stored O in the reference's autocast dtype)
+template <int PT, int D, int HG, int OF = 1>
 __global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds16_kernel(const void* __restrict__ qkv, float* __restrict__ out,
                                                                         float* __restrict__ lse, AttnGeom g, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned smem16[];
@@ -817,7 +824,7 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds16_kernel(const void
     const s8v qf = a16_mask<D>(a16_frag(sq, 16 * qt + i, SD, hq, rg), rg);
     f4 s[PT];
 #pragma unroll
-    for (int mt = 0; mt < PT; ++mt) s[mt] = mfma32_bf16(a16_frag(sq, 16 * mt + i, SD, hk, rg), qf, zero4());
+    for (int mt = 0; mt < PT; ++mt) s[mt] = mfma32_16<OF>(a16_frag(sq, 16 * mt + i, SD, hk, rg), qf, zero4());
     float mx = -INFINITY;
 #pragma unroll
     for (int mt = 0; mt < PT; ++mt)
@@ -846,9 +853,9 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds16_kernel(const void
     for (int ct = 0; ct < DCH; ++ct) o[ct] = zero4();
 #pragma unroll
     for (int mt = 0; mt < PT; ++mt) {
-        const s4 pa = pack_bf16(s[mt] * inv);
+        const s4 pa = pack16_raw<OF>(s[mt] * inv);
 #pragma unroll
-        for (int ct = 0; ct < DCH; ++ct) o[ct] = mfma16_bf16(pa, a16_tfrag(sq, 16 * mt, SD, hv + 8 * ct, i, rg), o[ct]);
+        for (int ct = 0; ct < DCH; ++ct) o[ct] = mfma16_16<OF>(pa, a16_tfrag(sq, 16 * mt, SD, hv + 8 * ct, i, rg), o[ct]);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -864,12 +871,13 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_fwd_lds16_kernel(const void
         const long row = srow[16 * qt + tok];
         if (row < 0) continue;
         const f4 v = *reinterpret_cast<const f4*>(sout + tok * SO + 4 * c4);
-        if (g.fmt & 4) *reinterpret_cast<s4*>(reinterpret_cast<unsigned short*>(out) + row * g.C + (h0 + hl) * d + 4 * c4) = pack_bf16(v);
+        if (g.fmt & 4) *reinterpret_cast<s4*>(reinterpret_cast<unsigned short*>(out) + row * g.C + (h0 + hl) * d + 4 * c4) = pack16<OF>(v);
         else *reinterpret_cast<f4*>(out + row * g.C + (h0 + hl) * d + 4 * c4) = v;
     }
 }
 
-template <int PT, int D, int HG>
+// QH: the qkv rows are fp16 (precision mode 16f) -- re-rounded to bf16 while staged; every contraction of the backward pass takes bf16 operands
+template <int PT, int D, int HG, bool QH = false>
 __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds16_kernel(const void* __restrict__ qkv, const float* __restrict__ dout,
                                                                         const float* __restrict__ lse, void* __restrict__ dqkv,
                                                                         AttnGeom g, float scale) {
@@ -900,7 +908,7 @@ __global__ __launch_bounds__(64 * PT * HG) void attn_bwd_lds16_kernel(const void
             stagel[j] = lse[max(row, 0L) * g.heads + h0 + hh];
         }
         // every global load of the workgroup's operands before the first LDS store (qkv staged, THEN dO loaded cost a second round trip)
-        A16Raw<NTHR, TOK, F8, SD, true> rq;
+        A16Raw<NTHR, TOK, F8, SD, true, QH> rq;
         rq.load(qkv, srow, ld, (long)h0 * 3 * d, tid);
         if (g.fmt & 8) {
             A16Raw<NTHR, TOK, A16L<D, HG>::RWD / 8, SDD, true> rd;
@@ -1017,22 +1025,23 @@ static int run_attn_lds(int which, const float* qkv, const float* dout, float* o
     if (nblk == 0) return LEOD_OK;
     const int TOK = 16 * PT, S = HG * 3 * D + 4, Sd = HG * D + 4;
     // precision mode bf16 with bf16 qkv rows (and bf16 dqkv): the bf16-tile kernels
-    static const int t16 = getenv("LEOD_ATTN_TILE16") ? atoi(getenv("LEOD_ATTN_TILE16")) : 1;
-    if (t16 && leod_precision() == 1 && which == 0 && (g.fmt & 1)) {
+    const bool h16 = leod_precision_mode() == 2;               // 16-bit qkv / O rows are fp16
+    if (leod_precision() == 1 && which == 0 && (g.fmt & 1)) {
         const size_t lds = ((size_t)TOK * A16L<D, HG>::SD + 8) * 4 + (size_t)PT * HG * 16 * (D + 4) * 4;
-        hipLaunchKernelGGL((attn_fwd_lds16_kernel<PT, D, HG>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, out, lse, g, scale);
+        if (h16) hipLaunchKernelGGL((attn_fwd_lds16_kernel<PT, D, HG, 2>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, out, lse, g, scale);
+        else hipLaunchKernelGGL((attn_fwd_lds16_kernel<PT, D, HG, 1>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, out, lse, g, scale);
         return leod_launch_status();
     }
-    if (t16 && leod_precision() == 1 && which == 1 && (g.fmt & 3) == 3) {
+    if (leod_precision() == 1 && which == 1 && (g.fmt & 3) == 3) {
         const size_t lds = ((size_t)TOK * (A16L<D, HG>::SD + A16L<D, HG>::SDD) + 16) * 4;
-        hipLaunchKernelGGL((attn_bwd_lds16_kernel<PT, D, HG>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, dout, lse, dqkv, g, scale);
+        if (h16) hipLaunchKernelGGL((attn_bwd_lds16_kernel<PT, D, HG, true>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, dout, lse, dqkv, g, scale);
+        else hipLaunchKernelGGL((attn_bwd_lds16_kernel<PT, D, HG, false>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, dout, lse, dqkv, g, scale);
         return leod_launch_status();
     }
-    if (g.fmt & 12) return LEOD_ERR_UNSUPPORTED;               // bf16 O / dO rows: the bf16-tile kernels only
+    if ((g.fmt & 12) || (g.fmt && h16)) return LEOD_ERR_UNSUPPORTED;   // 16-bit O / dO rows, fp16 rows: the 16-bit-tile kernels only
     if (which == 0) {
         const size_t lds = (size_t)TOK * S * sizeof(float);
-        if (leod_precision() == 1) hipLaunchKernelGGL((attn_fwd_lds_kernel<PT, D, HG, true>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, out, lse, g, scale);
-        else hipLaunchKernelGGL((attn_fwd_lds_kernel<PT, D, HG>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, out, lse, g, scale);
+        LEOD_BY_OPFMT(hipLaunchKernelGGL((attn_fwd_lds_kernel<PT, D, HG, OF>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, out, lse, g, scale));
     } else {
         const size_t lds = (size_t)TOK * (S + Sd) * sizeof(float);
         if (leod_precision() == 1) hipLaunchKernelGGL((attn_bwd_lds_kernel<PT, D, HG, true>), dim3(nblk), dim3(64 * PT * HG), lds, s, qkv, dout, lse, dqkv, g, scale);
@@ -1105,13 +1114,13 @@ LEOD_API int leod_partition_attn_16bit_ok(int B, int H, int W, int C, int heads,
 // 1: on top of leod_partition_attn_16bit_ok, the attention output O may be written as bf16 (forward, bit 1 of qkv_bf16) and its gradient
 // dO read as bf16 (backward, bit 1 of qkv_bf16): the bf16-tile kernels stage both as the bf16 MFMA operands they are anyway
 LEOD_API int leod_partition_attn_o16_ok(int B, int H, int W, int C, int heads, int ph, int pw) {
-    static const int t16 = getenv("LEOD_ATTN_TILE16") ? atoi(getenv("LEOD_ATTN_TILE16")) : 1;
     static const int on = getenv("LEOD_O16") ? atoi(getenv("LEOD_O16")) : 1;
-    return on && t16 && leod_partition_attn_16bit_ok(B, H, W, C, heads, ph, pw);
+    return on && leod_partition_attn_16bit_ok(B, H, W, C, heads, ph, pw);
 }
 
 LEOD_API int leod_partition_attn_fwd(const float* qkv, float* out, float* lse, int B, int H, int W, int C, int heads,
                                      int ph, int pw, int window, int qkv_bf16, hipStream_t stream) {
+    LeodFwdScope fwd_scope;
     if (!qkv || !out || heads <= 0) return LEOD_ERR_ARG;
     AttnGeom g{B, H, W, C, heads, C / heads, ph, pw, window, ((qkv_bf16 & 1) ? 1 : 0) | ((qkv_bf16 & 2) ? 4 : 0)};
     return dispatch_attn(0, qkv, nullptr, out, lse, nullptr, nullptr, g, stream);

@@ -60,6 +60,7 @@ LEOD_API int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bia
                                 const float* bn_w, const float* bn_b, const float* bn_rm, const float* bn_rv, float bn_eps,
                                 int B, int H, int W, int Cin, int N, int ks, int stride, int pad, float* wpack, int wpack_valid,
                                 hipStream_t stream) {
+    LeodFwdScope fwd_scope;                                   // forward contraction: fp16 operands in precision mode 16f
     if (!x || !w || !y || (Cin & 3) || (stat_rep > 1 && (stat_rep & (stat_rep - 1)))) return LEOD_ERR_ARG;
     const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
     const int M = B * Ho * Wo, K = ks * ks * Cin;
@@ -104,7 +105,7 @@ LEOD_API int leod_conv_nhwc_fwd(const float* x, const float* w, const float* bia
 // assembled from LDS bytes through a per-workgroup k -> byte-offset table.  Weights stream through LDS in 64-wide K chunks
 // exactly as in gemm_lds_kernel; outputs leave through the row-layout float4 epilogue.
 // =====================================================================================================================
-template <int NT, bool BF = false>
+template <int NT, int BF = 0>
 __global__ __launch_bounds__(256, 3) void stem_u8_fwd_kernel(const uint8_t* __restrict__ x, const float* __restrict__ w,
                                                              float* __restrict__ y, int Cin, int H, int W, int Ho, int Wo,
                                                              int N, int tiles_x, int tiles_y) {
@@ -194,10 +195,10 @@ __global__ __launch_bounds__(256, 3) void stem_u8_fwd_kernel(const uint8_t* __re
                 av.x = (float)pix[o.x]; av.y = (float)pix[o.y]; av.z = (float)pix[o.z]; av.w = (float)pix[o.w];
             }
             if constexpr (BF) {                               // uint8 counts are exact in bf16; the weights are rounded
-                const s4 pa = pack_bf16(av);
+                const s4 pa = pack16_raw<BF>(av);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    acc[t] = mfma16_bf16(pa, pack_bf16(*reinterpret_cast<const f4*>(pb + 16 * t * LD + 16 * c)), acc[t]);
+                    acc[t] = mfma16_16<BF>(pa, pack16_raw<BF>(*reinterpret_cast<const f4*>(pb + 16 * t * LD + 16 * c)), acc[t]);
             } else {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -241,12 +242,8 @@ static int launch_stem_u8(const uint8_t* x, const float* w, float* y, int B, int
     const size_t patch = ((size_t)Cin * 19 * 72 + 4 + 15) & ~(size_t)15;
     size_t lds = patch + (((size_t)KP * 4 + 15) & ~(size_t)15) + (size_t)NT * 16 * 72 * 4;
     lds = lds < 4 * 16 * 64 * 4 ? 4 * 16 * 64 * 4 : lds;                 // the epilogue tile aliases the front of the buffer
-    if (leod_precision() == 1)
-        hipLaunchKernelGGL((stem_u8_fwd_kernel<NT, true>), dim3(B * tiles_x * tiles_y), dim3(256), lds, s, x, w, y, Cin, H, W, Ho, Wo, N,
-                           tiles_x, tiles_y);
-    else
-        hipLaunchKernelGGL((stem_u8_fwd_kernel<NT>), dim3(B * tiles_x * tiles_y), dim3(256), lds, s, x, w, y, Cin, H, W, Ho, Wo, N,
-                           tiles_x, tiles_y);
+    LEOD_BY_OPFMT(hipLaunchKernelGGL((stem_u8_fwd_kernel<NT, OF>), dim3(B * tiles_x * tiles_y), dim3(256), lds, s, x, w, y, Cin, H, W, Ho, Wo, N,
+                                     tiles_x, tiles_y));
     return leod_launch_status();
 }
 
@@ -254,6 +251,7 @@ static int launch_stem_u8(const uint8_t* x, const float* w, float* y, int B, int
 // (Ho = (Hp + 2*pad - ks)/stride + 1).  x_is_u8: raw uint8 stacked-histogram voxels.
 LEOD_API int leod_stem_conv_fwd(const void* x, int x_is_u8, const float* w, float* y, int B, int Cin, int H, int W,
                                 int Hp, int Wp, int N, int ks, int stride, int pad, hipStream_t stream) {
+    LeodFwdScope fwd_scope;                                   // forward contraction: fp16 operands in precision mode 16f
     if (!x || !w || !y || ((Cin * ks * ks) & 3)) return LEOD_ERR_ARG;
     if (ks != 7) return LEOD_ERR_UNSUPPORTED;       // stem loaders hard-code the 7x7 tap decode
     const int Ho = (Hp + 2 * pad - ks) / stride + 1, Wo = (Wp + 2 * pad - ks) / stride + 1;

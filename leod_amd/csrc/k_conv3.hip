@@ -22,13 +22,14 @@ typedef unsigned short bf16_t;
 // w [N][Cin][3][3] fp32 -> bf16, K-contiguous per tap.
 //   mode 0 (forward): wp[tap][n][c]                      B rows = output channels, k = input channel
 //   mode 1 (dgrad)  : wp[8 - tap][c][n]                  B rows = input channels (the dgrad's outputs), k = output channel
-__global__ __launch_bounds__(256) void conv3_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int N, int Cin, int mode) {
+// h16: the packed copy holds fp16 (forward packs of precision mode 16f)
+__global__ __launch_bounds__(256) void conv3_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int N, int Cin, int mode, int h16) {
     const long total = (long)N * Cin * 9;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int tap = (int)(e % 9); const long r = e / 9; const int c = (int)(r % Cin), n = (int)(r / Cin);
         const long o = mode == 0 ? ((long)tap * N + n) * Cin + c : ((long)(8 - tap) * Cin + c) * N + n;
         const f2_ p = {w[e], 0.f};
-        out[o] = (bf16_t)(__builtin_bit_cast(unsigned, __builtin_convertvector(p, bf2_)) & 0xffffu);
+        out[o] = h16 ? __builtin_bit_cast(bf16_t, (_Float16)w[e]) : (bf16_t)(__builtin_bit_cast(unsigned, __builtin_convertvector(p, bf2_)) & 0xffffu);
     }
 }
 
@@ -42,7 +43,8 @@ __global__ __launch_bounds__(256) void conv3_pack_kernel(const float* __restrict
 // eval-mode BaseConv: y = silu((conv - running_mean) * w / sqrt(running_var + eps) + b) applied to the finished rows (w == NULL: plain conv)
 struct BnEval { const float* w; const float* b; const float* rm; const float* rv; float eps; };
 
-template <int KC, int NTO, int TW, int S = 1>
+// OF: operand format, 1 = bf16 (also the dgrad form of every mode), 2 = fp16 (forward of precision mode 16f; wp packed as fp16)
+template <int KC, int NTO, int TW, int S = 1, int OF = 1>
 __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wp, float* __restrict__ y,
                                                        double* __restrict__ colstats, int stat_rep, int accumulate,
                                                        int B, int H, int W, int Cout, int RH, BnEval bne) {
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
         }
 #pragma unroll
         for (int j = 0; j < HB; ++j)
-            if (ho[j] >= 0) *reinterpret_cast<s4*>(halo + ho[j]) = pack_bf16(hv[j]);
+            if (ho[j] >= 0) *reinterpret_cast<s4*>(halo + ho[j]) = pack16<OF>(hv[j]);
     }
     stash_b(0, rb[0]);
     fetch_b(3, rb[0]);
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
                 for (int n = 0; n < NTO; ++n) {
                     const s8v bv = *reinterpret_cast<const s8v*>(pb + 16 * n * LDB + 32 * kc);
 #pragma unroll
-                    for (int t = 0; t < TW; ++t) acc[t][n] = mfma32_bf16(a[t], bv, acc[t][n]);   // absent tiles compute on pixel 0 (discarded)
+                    for (int t = 0; t < TW; ++t) acc[t][n] = mfma32_16<OF>(a[t], bv, acc[t][n]);   // absent tiles compute on pixel 0 (discarded)
                 }
             }
         } else {
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
                 for (int n = 0; n < NTO; ++n) {
                     const s4 bv = *reinterpret_cast<const s4*>(pb + 16 * n * LDB + 16 * kc);
 #pragma unroll
-                    for (int t = 0; t < TW; ++t) acc[t][n] = mfma16_bf16(a[t], bv, acc[t][n]);
+                    for (int t = 0; t < TW; ++t) acc[t][n] = mfma16_16<OF>(a[t], bv, acc[t][n]);
                 }
             }
         }
@@ -728,10 +730,11 @@ int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, i
     if (bn_w && (accumulate || colstats || !bn_b || !bn_rm || !bn_rv)) return LEOD_ERR_ARG;
     bf16_t* wp = reinterpret_cast<bf16_t*>(wpack);
     const long total = (long)9 * Cin * Cout;
+    const int of = (!transposed && leod_opfmt() == 2) ? 2 : 1;      // forward launches of precision mode 16f: fp16 halo and fp16 packed weights
     // the packed layout is [tap][out rows][k]; for the dgrad the stored weight is [N = Cin of this call][C = Cout of this call]
     if (!packed)
         hipLaunchKernelGGL(conv3_pack_kernel, dim3((int)min((long)1024, (total + 255) / 256)), dim3(256), 0, stream, w, wp,
-                           transposed ? Cin : Cout, transposed ? Cout : Cin, transposed ? 1 : 0);
+                           transposed ? Cin : Cout, transposed ? Cout : Cin, transposed ? 1 : 0, of == 2 ? 1 : 0);
     const int nto = Cout == 48 ? 3 : 6;
     const int RH = conv3_rows_per_block(H, W, Cin, nto, stride);
     if (RH <= 0) return LEOD_ERR_UNSUPPORTED;
@@ -741,15 +744,15 @@ int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, i
     const dim3 grid(B * cdiv(Ho, RH), Cout / (16 * nto));
     const size_t smem = conv3_smem(RH, W, Cin, nto, stride);
     const int tw = cdiv(cdiv(min(RH, Ho) * Wo, 16), 4) <= 2 ? 2 : 3;          // row tiles per wave
-#define C3_CASE(KCV, NTOV, SV) C3_CASE2(KCV, NTOV, 2, SV) C3_CASE2(KCV, NTOV, 3, SV)
-#define C3_CASE2(KCV, NTOV, TWV, SV)                                                                                                 \
-    if (Cin == 16 * KCV && nto == NTOV && tw == TWV && stride == SV) {                                                                \
+#define C3_CASE(KCV, NTOV, SV) C3_CASE2(KCV, NTOV, 2, SV, 1) C3_CASE2(KCV, NTOV, 3, SV, 1) C3_CASE2(KCV, NTOV, 2, SV, 2) C3_CASE2(KCV, NTOV, 3, SV, 2)
+#define C3_CASE2(KCV, NTOV, TWV, SV, OFV)                                                                                            \
+    if (Cin == 16 * KCV && nto == NTOV && tw == TWV && stride == SV && of == OFV) {                                                   \
         static bool attr_set = false;                                                                                                \
         if (!attr_set) {                                                                                                             \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3s1_kernel<KCV, NTOV, TWV, SV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3s1_kernel<KCV, NTOV, TWV, SV, OFV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_set = true;                                                                                                         \
         }                                                                                                                            \
-        hipLaunchKernelGGL((conv3s1_kernel<KCV, NTOV, TWV, SV>), grid, dim3(256), smem, stream, x, wp, y, colstats, stat_rep, accumulate, B, H, W, Cout, RH, bne); \
+        hipLaunchKernelGGL((conv3s1_kernel<KCV, NTOV, TWV, SV, OFV>), grid, dim3(256), smem, stream, x, wp, y, colstats, stat_rep, accumulate, B, H, W, Cout, RH, bne); \
         return leod_launch_status();                                                                                                 \
     }
     C3_CASE(3, 3, 1) C3_CASE(3, 6, 1) C3_CASE(6, 3, 1) C3_CASE(6, 6, 1) C3_CASE(12, 3, 1) C3_CASE(12, 6, 1)
@@ -896,7 +899,7 @@ bool conv3s2_dgrad_supported(int H, int W, int Cin, int N) {
 int conv3s2_dgrad_launch(const float* dy, const float* w, float* dx, int accumulate, int B, int H, int W, int Cin, int N, void* wpack, hipStream_t stream, int packed) {
     bf16_t* wp = reinterpret_cast<bf16_t*>(wpack);
     const long total = (long)9 * Cin * N;
-    if (!packed) hipLaunchKernelGGL(conv3_pack_kernel, dim3((int)min((long)1024, (total + 255) / 256)), dim3(256), 0, stream, w, wp, N, Cin, 1);
+    if (!packed) hipLaunchKernelGGL(conv3_pack_kernel, dim3((int)min((long)1024, (total + 255) / 256)), dim3(256), 0, stream, w, wp, N, Cin, 1, 0);
     const int Ho = H / 2, Wo = W / 2;
     const int RH = conv3s2_dgrad_rows(Ho, Wo, N);
     if (RH <= 0) return LEOD_ERR_UNSUPPORTED;

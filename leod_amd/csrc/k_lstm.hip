@@ -61,19 +61,23 @@ __device__ __forceinline__ void dgates16_copy(unsigned short* __restrict__ dg16,
     }
 }
 
-template <bool BF> struct AElem;
-template <> struct AElem<true> { typedef unsigned short T; };
-template <> struct AElem<false> { typedef float T; };
+// BF (int): operand format 0 = fp32, 1 = bf16, 2 = fp16 (forward kernels of precision mode 16f)
+template <int BF> struct AElem { typedef unsigned short T; };
+template <> struct AElem<0> { typedef float T; };
 __device__ __forceinline__ unsigned short to_bf16(float v) {
     const f2_ p = {v, 0.f};
     return (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(p, bf2_)) & 0xffffu);
 }
-template <bool BF> __device__ __forceinline__ typename AElem<BF>::T a_elem(float v) {
-    if constexpr (BF) return to_bf16(v); else return v;
+__device__ __forceinline__ unsigned short to_h16(float v) {   // |h| < 1 and LayerNorm-ed / bounded x: no saturation needed
+    return __builtin_bit_cast(unsigned short, (_Float16)v);
+}
+template <int OF> __device__ __forceinline__ unsigned short to_op16(float v) { if constexpr (OF == 2) return to_h16(v); else return to_bf16(v); }
+template <int BF> __device__ __forceinline__ typename AElem<BF>::T a_elem(float v) {
+    if constexpr (BF == 2) return to_h16(v); else if constexpr (BF == 1) return to_bf16(v); else return v;
 }
 
 // One timestep's MFMAs of a wave: acc[g] += A[16 x 16*KC] . B_g   (A fragments from the LDS tile, B fragments in registers)
-template <int KC, int NG, bool BF, class BT>
+template <int KC, int NG, int BF, class BT>
 __device__ __forceinline__ void tile_mfma(f4 (&acc)[NG], const typename AElem<BF>::T* __restrict__ arow, const BT (&b)[NG][KC]) {
 #pragma unroll
     for (int kc = 0; kc < KC; ++kc) {
@@ -82,7 +86,7 @@ __device__ __forceinline__ void tile_mfma(f4 (&acc)[NG], const typename AElem<BF
         if constexpr (BF) {
             const s4 a = *reinterpret_cast<const s4*>(arow + 16 * kc);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = mfma16_bf16(a, b[g][kc], acc[g]);
+            for (int g = 0; g < NG; ++g) acc[g] = mfma16_16<BF>(a, b[g][kc], acc[g]);
         } else {
             const f4 a = *reinterpret_cast<const f4*>(arow + 16 * kc);
 #pragma unroll
@@ -99,7 +103,7 @@ __device__ __forceinline__ void tile_mfma(f4 (&acc)[NG], const typename AElem<BF
 //   hbuf, cbuf [T+1][M][C]: slot 0 = incoming state (zero_state != 0: treated as zeros and not read), slots 1..T written
 //   W [4C][2C] (gate-major rows f, i, o, g; columns [x | h]), bias [4C]; gates_out [T][M][4][C] post-activation or NULL
 // ---------------------------------------------------------------------------------------------------------------------
-template <int C, bool FX, bool BF, bool G16 = false>
+template <int C, bool FX, int BF, bool G16 = false>
 __global__ __launch_bounds__(C * 4) void lstm_seq_fwd_kernel(const float* __restrict__ xin, float* __restrict__ hbuf, float* __restrict__ cbuf,
                                                               const float* __restrict__ W, const float* __restrict__ bias,
                                                               float* __restrict__ gates_out, int M, int T, int zero_state) {
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(C * 4) void lstm_seq_fwd_kernel(const float* __rest
     constexpr int HOFF = FX ? C : 0;                 // column of h inside the A tile
     constexpr bool PF = C < 192;                     // prefetch the next timestep's projection (register room permitting)
     typedef typename AElem<BF>::T AT;
-    typedef typename std::conditional<BF, s4, f4>::type BT;
+    typedef typename std::conditional<BF != 0, s4, f4>::type BT;
     __shared__ __attribute__((aligned(16))) AT sA[2][16 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(C * 4) void lstm_seq_fwd_kernel(const float* __rest
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             const f4 w = ld4(wr + 16 * kc);
-            if constexpr (BF) bw[g][kc] = pack_bf16(w); else bw[g][kc] = w;
+            if constexpr (BF != 0) bw[g][kc] = pack16_raw<BF>(w); else bw[g][kc] = w;
         }
     }
     float bg[4];
@@ -195,9 +199,9 @@ __global__ __launch_bounds__(C * 4) void lstm_seq_fwd_kernel(const float* __rest
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float f = sigmoidf_(acc[0][r] + bg[0]), ig = sigmoidf_(acc[1][r] + bg[1]), o = sigmoidf_(acc[2][r] + bg[2]);
-            const float g = tanh_<BF>(acc[3][r] + bg[3]);
+            const float g = tanh_<(BF != 0)>(acc[3][r] + bg[3]);
             const float cn = f * cst[r] + ig * g;
-            const float hn = o * tanh_<BF>(cn);
+            const float hn = o * tanh_<(BF != 0)>(cn);
             cst[r] = cn;
             gv[0][r] = f; gv[1][r] = ig; gv[2][r] = o; gv[3][r] = g;
             sA[buf ^ 1][(4 * q + r) * LD + HOFF + ch] = a_elem<BF>(hn);
@@ -329,7 +333,8 @@ __global__ __launch_bounds__(C * 4) void lstm_seq_bwd_kernel(const float* __rest
 // issues at the same cost per instruction, i.e. half the rate, and needed twice the load instructions):
 // wpf[((w*2 + grp)*KC + kc)*4 + g][lane] = bf16 W[g*C + 32w + 16grp + i][C + 32kc + 8q .. +7]          (forward, KC = C/32)
 // wpb[(w*2 + grp)*4KC + kc][lane]        = bf16 (W[32kc + 8q + j][C + 32w + 16grp + i]), j = 0..7        (backward)
-__global__ __launch_bounds__(256) void lstm_pack_kernel(const float* __restrict__ W, s8v* __restrict__ wpf, s8v* __restrict__ wpb, int C) {
+// fwd_h16: the forward copy holds fp16 fragments (precision mode 16f); the backward copy is always bf16
+__global__ __launch_bounds__(256) void lstm_pack_kernel(const float* __restrict__ W, s8v* __restrict__ wpf, s8v* __restrict__ wpb, int C, int fwd_h16) {
     const int KC = C / 32, NWV = C / 32;
     const int nf = NWV * 2 * KC * 4 * 64, nb = NWV * 2 * 4 * KC * 64;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < nf + nb; e += gridDim.x * 256) {
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(256) void lstm_pack_kernel(const float* __restrict_
             const int lane = e & 63, g = (e >> 6) & 3, r = e >> 8, kc = r % KC, wg = r / KC;      // wg = w*2 + grp
             const int i = lane & 15, q = lane >> 4;
             const float* wr = W + (long)(g * C + 16 * wg + i) * (2 * C) + C + 32 * kc + 8 * q;
-            const s4 lo = pack_bf16(ld4(wr)), hi = pack_bf16(ld4(wr + 4));
+            const s4 lo = fwd_h16 ? pack_h16_raw(ld4(wr)) : pack_bf16(ld4(wr)), hi = fwd_h16 ? pack_h16_raw(ld4(wr + 4)) : pack_bf16(ld4(wr + 4));
             wpf[e] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         } else {
             const int o = e - nf, lane = o & 63, r = o >> 6, kc = r % (4 * KC), wg = r / (4 * KC);
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(256) void lstm_pack_kernel(const float* __restrict_
     }
 }
 
-template <int C, bool G16 = false>
+template <int C, bool G16 = false, int OF = 1>
 __global__ __launch_bounds__(C * 2) void lstm_seq_fwd_stream_kernel(const float* __restrict__ gxin, float* __restrict__ hbuf, float* __restrict__ cbuf,
                                                                      const s8v* __restrict__ wpf, float* __restrict__ gates_out, int M, int T,
                                                                      int zero_state) {
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(C * 2) void lstm_seq_fwd_stream_kernel(const float*
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             cst[grp][r] = zero_state ? 0.f : cbuf[oc[grp][r]];
-            sA[0][(4 * q + r) * LD + 32 * wave + 16 * grp + i] = to_bf16(zero_state ? 0.f : hbuf[oc[grp][r]]);
+            sA[0][(4 * q + r) * LD + 32 * wave + 16 * grp + i] = to_op16<OF>(zero_state ? 0.f : hbuf[oc[grp][r]]);
         }
     __syncthreads();
     // wave-uniform base (scalar registers) + lane: the 192 fragment loads of a timestep address as SGPR base + lane offset + immediate;
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(C * 2) void lstm_seq_fwd_stream_kernel(const float*
                 for (int k = 0; k < NB; ++k) {
                     const s8v a = *reinterpret_cast<const s8v*>(arow + 32 * (bt * NB + k));
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[g] = mfma32_bf16(a, bb[bt & 1][k][g], acc[g]);
+                    for (int g = 0; g < 4; ++g) acc[g] = mfma32_16<OF>(a, bb[bt & 1][k][g], acc[g]);
                 }
             }
             float gv[4][4];
@@ -433,7 +438,7 @@ __global__ __launch_bounds__(C * 2) void lstm_seq_fwd_stream_kernel(const float*
                 const float hn = o * tanh_<true>(cn);
                 cst[grp][r] = cn;
                 gv[0][r] = f; gv[1][r] = ig; gv[2][r] = o; gv[3][r] = g;
-                sA[buf ^ 1][(4 * q + r) * LD + ch] = to_bf16(hn);
+                sA[buf ^ 1][(4 * q + r) * LD + ch] = to_op16<OF>(hn);
                 if (rok[r]) {
                     hp[ocg[r]] = hn;
                     if (go || t + 1 == T) cp[ocg[r]] = cn;           // the c history is read by the backward pass only (which needs the gates too)
@@ -578,9 +583,9 @@ LEOD_API int leod_convlstm_seq_mode(int C) {
 
 #define LSTM_FWD_CASE(CV, FXV)                                                                                                  \
     if (C == CV && fx == FXV) {                                                                                                 \
-        if (bf && gates16) hipLaunchKernelGGL((lstm_seq_fwd_kernel<CV, FXV, true, true>), grid, dim3(CV * 4), 0, stream, xin, hbuf, cbuf, W, bias, gates_out, M, T, zero_state); \
-        else if (bf) hipLaunchKernelGGL((lstm_seq_fwd_kernel<CV, FXV, true>), grid, dim3(CV * 4), 0, stream, xin, hbuf, cbuf, W, bias, gates_out, M, T, zero_state); \
-        else hipLaunchKernelGGL((lstm_seq_fwd_kernel<CV, FXV, false>), grid, dim3(CV * 4), 0, stream, xin, hbuf, cbuf, W, bias, gates_out, M, T, zero_state);  \
+        if (bf && gates16) { LEOD_BY_OPFMT16(hipLaunchKernelGGL((lstm_seq_fwd_kernel<CV, FXV, OF, true>), grid, dim3(CV * 4), 0, stream, xin, hbuf, cbuf, W, bias, gates_out, M, T, zero_state)); } \
+        else if (bf) { LEOD_BY_OPFMT16(hipLaunchKernelGGL((lstm_seq_fwd_kernel<CV, FXV, OF>), grid, dim3(CV * 4), 0, stream, xin, hbuf, cbuf, W, bias, gates_out, M, T, zero_state)); } \
+        else hipLaunchKernelGGL((lstm_seq_fwd_kernel<CV, FXV, 0>), grid, dim3(CV * 4), 0, stream, xin, hbuf, cbuf, W, bias, gates_out, M, T, zero_state);  \
         return leod_launch_status();                                                                                            \
     }
 
@@ -601,12 +606,14 @@ LEOD_API long leod_convlstm_seq_pack_bytes(int C) { return leod_convlstm_seq_mod
 LEOD_API int leod_convlstm_seq_pack(const float* W, void* wpack, int C, hipStream_t stream) {
     if (!W || !wpack || leod_convlstm_seq_mode(C) != 3) return LEOD_ERR_ARG;
     s8v* wpf = reinterpret_cast<s8v*>(wpack);                    // C * C / 2 sixteen-byte fragments each for the forward and the backward copy
-    hipLaunchKernelGGL(lstm_pack_kernel, dim3(cdiv((long)C * C, 256)), dim3(256), 0, stream, W, wpf, wpf + (long)C * C / 2, C);
+    hipLaunchKernelGGL(lstm_pack_kernel, dim3(cdiv((long)C * C, 256)), dim3(256), 0, stream, W, wpf, wpf + (long)C * C / 2, C,
+                       leod_precision_mode() == 2 ? 1 : 0);
     return leod_launch_status();
 }
 
 LEOD_API int leod_convlstm_seq_fwd(const float* xin, int x_is_projection, float* hbuf, float* cbuf, const float* W, const float* bias,
                                    float* gates_out, const void* wpack, int M, int C, int T, int zero_state, int gates16, hipStream_t stream) {
+    LeodFwdScope fwd_scope;
     if (gates16 && !leod_convlstm_seq_gates16_ok(C)) return LEOD_ERR_ARG;
     if (!xin || !hbuf || !cbuf || !W || !bias || M <= 0 || T <= 0 || (long)M * 4 * C >= (1L << 31)) return LEOD_ERR_ARG;
     const int mode = leod_convlstm_seq_mode(C);
@@ -615,12 +622,14 @@ LEOD_API int leod_convlstm_seq_fwd(const float* xin, int x_is_projection, float*
         if (!wpack) return LEOD_ERR_ARG;
         const s8v* wpf = reinterpret_cast<const s8v*>(wpack);
         const dim3 g3(cdiv(M, 16));
-        if (C == 384 && gates16) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<384, true>), g3, dim3(768), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
-        else if (C == 384) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<384>), g3, dim3(768), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
-        else if (C == 192 && gates16) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<192, true>), g3, dim3(384), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
-        else if (C == 192) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<192>), g3, dim3(384), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
-        else if (gates16) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<256, true>), g3, dim3(512), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
-        else hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<256>), g3, dim3(512), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
+        LEOD_BY_OPFMT16({
+            if (C == 384 && gates16) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<384, true, OF>), g3, dim3(768), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
+            else if (C == 384) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<384, false, OF>), g3, dim3(768), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
+            else if (C == 192 && gates16) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<192, true, OF>), g3, dim3(384), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
+            else if (C == 192) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<192, false, OF>), g3, dim3(384), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
+            else if (gates16) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<256, true, OF>), g3, dim3(512), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
+            else hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<256, false, OF>), g3, dim3(512), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
+        });
         return leod_launch_status();
     }
     const bool bf = leod_precision() == 1, fx = mode == 1;

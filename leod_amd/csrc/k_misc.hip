@@ -51,21 +51,29 @@ LEOD_API int leod_adamw_clip_step(float* p, float* g, float* m, float* v, long n
 #include <mutex>
 #include <vector>
 namespace {
-struct ShadowEntry { const float* base; long n; unsigned short* sh; bool fresh; };
+struct ShadowEntry { const float* base; long n; unsigned short* sh; bool fresh; unsigned short* shf; };   // shf: fp16 copy (mode 16f) | NULL
 std::mutex g_shadow_mu;
 std::vector<ShadowEntry> g_shadows;
 bool g_shadow_pinned = false;
 }
-const unsigned short* leod_shadow_of(const float* w) {
+const unsigned short* leod_shadow_of(const float* w, int of) {
     if (!w) return nullptr;
     std::lock_guard<std::mutex> lock(g_shadow_mu);
     for (const ShadowEntry& e : g_shadows)
-        if ((e.fresh || g_shadow_pinned) && w >= e.base && w < e.base + e.n) return e.sh + (w - e.base);
+        if ((e.fresh || g_shadow_pinned) && w >= e.base && w < e.base + e.n) {
+            if (of == 2) return e.shf ? e.shf + (w - e.base) : nullptr;
+            return e.sh + (w - e.base);
+        }
     return nullptr;
 }
-__global__ __launch_bounds__(256) void weight_shadow_kernel(const float* __restrict__ p, unsigned short* __restrict__ sh, long n4) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
-        *reinterpret_cast<s4*>(sh + 4 * i) = pack_bf16(ld4(p + 4 * i));
+// one pass over the parameters writes the bf16 copy and (mode 16f: shf != NULL) the fp16 copy the forward GEMMs read
+__global__ __launch_bounds__(256) void weight_shadow_kernel(const float* __restrict__ p, unsigned short* __restrict__ sh,
+                                                            unsigned short* __restrict__ shf, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f4 v = ld4(p + 4 * i);
+        *reinterpret_cast<s4*>(sh + 4 * i) = pack_bf16(v);
+        if (shf) *reinterpret_cast<s4*>(shf + 4 * i) = pack_h16_sat(v);
+    }
 }
 // shadow16 == NULL (or n <= 0) withdraws the registration of `base`.  n % 4 == 0, base 16-byte and shadow16 8-byte aligned.
 LEOD_API int leod_set_weight_shadow(const float* base, long n, void* shadow16) {
@@ -75,8 +83,17 @@ LEOD_API int leod_set_weight_shadow(const float* base, long n, void* shadow16) {
         if (g_shadows[k].base == base) { g_shadows.erase(g_shadows.begin() + k); break; }
     if (!shadow16 || n <= 0) return LEOD_OK;
     if ((n & 3) || (reinterpret_cast<uintptr_t>(base) & 15) || (reinterpret_cast<uintptr_t>(shadow16) & 7)) return LEOD_ERR_ARG;
-    g_shadows.push_back(ShadowEntry{base, n, reinterpret_cast<unsigned short*>(shadow16), false});
+    g_shadows.push_back(ShadowEntry{base, n, reinterpret_cast<unsigned short*>(shadow16), false, nullptr});
     return LEOD_OK;
+}
+// fp16 copy (n values, caller-owned, 8-byte aligned) of a buffer registered above: written by the refresh in precision mode 16f and read
+// by the forward GEMMs of that mode; NULL withdraws it.  LEOD_ERR_ARG if `base` is not registered.
+LEOD_API int leod_set_weight_shadow_f16(const float* base, void* shadow_f16) {
+    if (!base || (reinterpret_cast<uintptr_t>(shadow_f16) & 7)) return LEOD_ERR_ARG;
+    std::lock_guard<std::mutex> lock(g_shadow_mu);
+    for (ShadowEntry& e : g_shadows)
+        if (e.base == base) { e.shf = reinterpret_cast<unsigned short*>(shadow_f16); e.fresh = false; return LEOD_OK; }
+    return LEOD_ERR_ARG;
 }
 LEOD_API int leod_weight_shadow_invalidate() {
     std::lock_guard<std::mutex> lock(g_shadow_mu);
@@ -98,7 +115,8 @@ LEOD_API int leod_weight_shadow_refresh(int force, hipStream_t stream) {
     for (ShadowEntry& e : g_shadows) {
         if (e.fresh && !force) continue;
         const long n4 = e.n / 4;
-        hipLaunchKernelGGL(weight_shadow_kernel, dim3((unsigned)min((long)2048, (n4 + 255) / 256)), dim3(256), 0, stream, e.base, e.sh, n4);
+        hipLaunchKernelGGL(weight_shadow_kernel, dim3((unsigned)min((long)2048, (n4 + 255) / 256)), dim3(256), 0, stream, e.base, e.sh,
+                           leod_precision_mode() == 2 ? e.shf : nullptr, n4);
         if (leod_launch_status() != LEOD_OK) return LEOD_ERR_LAUNCH;
         if (!force) e.fresh = true;
         ++launches;
@@ -305,9 +323,15 @@ LEOD_API const char* leod_version() { return "leod_hip 0.2 (gfx950)"; }
 
 // precision mode of the contractions (see common.hpp): process-wide, set once before the first step
 static int g_precision = 0;
-int leod_precision() { return g_precision; }
+static thread_local int t_fwd_depth = 0;
+int leod_precision() { return g_precision ? 1 : 0; }
+int leod_precision_mode() { return g_precision; }
+int leod_opfmt() { return g_precision == 2 ? (t_fwd_depth > 0 ? 2 : 1) : g_precision; }
+LeodFwdScope::LeodFwdScope() { ++t_fwd_depth; }
+LeodFwdScope::~LeodFwdScope() { --t_fwd_depth; }
 LEOD_API int leod_set_precision(int mode) {
-    if (mode != 0 && mode != 1) return LEOD_ERR_ARG;
+    if (mode != 0 && mode != 1 && mode != 2) return LEOD_ERR_ARG;
+    if (mode != g_precision) leod_weight_shadow_invalidate();      // the set of copies a refresh writes depends on the mode
     g_precision = mode;
     return LEOD_OK;
 }

@@ -56,7 +56,8 @@ __device__ __forceinline__ f4 gelu_grad4(f4 u) {              // Phi(u) + u * ph
 __host__ __device__ constexpr int mlp_unit_of_row(int R) { return 32 * (R >> 5) + 8 * ((R & 15) >> 2) + 4 * ((R >> 4) & 1) + (R & 3); }
 
 // KC: input / output width K = 16 KC; NHT: hidden width H = 16 NHT (even); SU: also store u16 = fp16(u) [M][H] and stats [M][2]
-template <int KC, int NHT, bool SU>
+// OF: operand format of the three contractions, 1 = bf16, 2 = fp16 (precision mode 16f)
+template <int KC, int NHT, bool SU, int OF = 1>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_fused_kernel(const float* __restrict__ y, const float* __restrict__ ln_w,
                                                                const float* __restrict__ ln_b, float eps, const float* __restrict__ W1,
                                                                const float* __restrict__ b1, const float* __restrict__ W2,
@@ -73,11 +74,11 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_fused_kernel(const float* __re
     const int i = lane & 15, q = lane >> 4;
     for (int e = tid; e < H * (K / 4); e += 256) {
         const int R = e / (K / 4), k4 = (e - R * (K / 4)) * 4;
-        *reinterpret_cast<s4*>(&sW1[R * LD1 + k4]) = pack_bf16(ld4(W1 + (long)mlp_unit_of_row(R) * K + k4));
+        *reinterpret_cast<s4*>(&sW1[R * LD1 + k4]) = pack16_raw<OF>(ld4(W1 + (long)mlp_unit_of_row(R) * K + k4));
     }
     for (int e = tid; e < K * (H / 4); e += 256) {
         const int n = e / (H / 4), j4 = (e - n * (H / 4)) * 4;
-        *reinterpret_cast<s4*>(&sW2[n * LD2 + j4]) = pack_bf16(ld4(W2 + (long)n * H + j4));
+        *reinterpret_cast<s4*>(&sW2[n * LD2 + j4]) = pack16_raw<OF>(ld4(W2 + (long)n * H + j4));
     }
     for (int e = tid; e < H; e += 256) sB1[e] = b1 ? b1[mlp_unit_of_row(e)] : 0.f;
     f4 lw[KC], lb[KC];
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_fused_kernel(const float* __re
         }
         s4 nb[KC];
 #pragma unroll
-        for (int c = 0; c < KC; ++c) nb[c] = pack_bf16((f.a[c] - mean) * rstd * lw[c] + lb[c]);
+        for (int c = 0; c < KC; ++c) nb[c] = pack16<OF>((f.a[c] - mean) * rstd * lw[c] + lb[c]);
         // fc1 transposed, GELU, fc2: hidden tiles two at a time
         f4 acc[KC];
 #pragma unroll
@@ -148,16 +149,16 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_fused_kernel(const float* __re
                 f4 u = *reinterpret_cast<const f4*>(&sB1[16 * (t + h) + 4 * q]);
 #pragma unroll
                 for (int c = 0; c < KC; ++c)
-                    u = mfma16_bf16(*reinterpret_cast<const s4*>(&sW1[(16 * (t + h) + i) * LD1 + 16 * c + 4 * q]), nb[c], u);
+                    u = mfma16_16<OF>(*reinterpret_cast<const s4*>(&sW1[(16 * (t + h) + i) * LD1 + 16 * c + 4 * q]), nb[c], u);
                 if (SU) hu[h] = pack_h16(u);
-                ha[h] = pack_bf16(gelu4(u));
+                ha[h] = pack16<OF>(gelu4(u));
             }
             // the lane's 8 values of this pair = hidden units 16t + 8q .. + 7 of row i
             if (SU && row_ok) *reinterpret_cast<s8v*>(urow + 16 * t) = __builtin_shufflevector(hu[0], hu[1], 0, 1, 2, 3, 4, 5, 6, 7);
             const s8v a8 = __builtin_shufflevector(ha[0], ha[1], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
             for (int c = 0; c < KC; ++c)
-                acc[c] = mfma32_bf16(a8, *reinterpret_cast<const s8v*>(&sW2[(16 * c + i) * LD2 + 16 * t + 8 * q]), acc[c]);
+                acc[c] = mfma32_16<OF>(a8, *reinterpret_cast<const s8v*>(&sW2[(16 * c + i) * LD2 + 16 * t + 8 * q]), acc[c]);
         }
         // acc[c][r] = t[row 4q + r][col 16c + i] -> rows through the wave-private tile (LDS operations of one wave execute in order: only
         // the compiler must keep write -> read -> write order, no fence that would drain the prefetched fragments)
@@ -206,10 +207,13 @@ LEOD_API int leod_mlp_fwd_fused(const float* y, const float* ln_w, const float* 
     static const int on = getenv("LEOD_MLP_FUSED") ? atoi(getenv("LEOD_MLP_FUSED")) : 1;
     if (!on || leod_precision() != 1 || K != 48 || H != 192 || M < 16384) return LEOD_ERR_UNSUPPORTED;
     const int grid = min(cdiv(cdiv(M, 16), 4), 256 * 2);       // two resident workgroups per CU (1 / 4 per CU measured slower: 222 / 184 vs 181 us)
-    if (u16) hipLaunchKernelGGL((mlp_fwd_fused_kernel<3, 12, true>), dim3(grid), dim3(256), 0, stream, y, ln_w, ln_b, eps, W1, b1, W2, b2, g2, out,
-                                reinterpret_cast<unsigned short*>(u16), stats, M);
-    else hipLaunchKernelGGL((mlp_fwd_fused_kernel<3, 12, false>), dim3(grid), dim3(256), 0, stream, y, ln_w, ln_b, eps, W1, b1, W2, b2, g2, out,
-                            nullptr, nullptr, M);
+    LeodFwdScope fwd_scope;
+    LEOD_BY_OPFMT16({
+        if (u16) hipLaunchKernelGGL((mlp_fwd_fused_kernel<3, 12, true, OF>), dim3(grid), dim3(256), 0, stream, y, ln_w, ln_b, eps, W1, b1, W2, b2, g2, out,
+                                    reinterpret_cast<unsigned short*>(u16), stats, M);
+        else hipLaunchKernelGGL((mlp_fwd_fused_kernel<3, 12, false, OF>), dim3(grid), dim3(256), 0, stream, y, ln_w, ln_b, eps, W1, b1, W2, b2, g2, out,
+                                nullptr, nullptr, M);
+    });
     return leod_launch_status();
 }
 

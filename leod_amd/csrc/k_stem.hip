@@ -185,7 +185,8 @@ int launch(const float* dy, const uint8_t* x, float* dW, int B, int Cin, int H, 
 //   * PD tiles of raw uint8 patch dwords are in flight in registers (13 dwords per thread and tile): one workgroup per CU cannot hide
 //     an HBM round trip behind ~1 us of MFMAs with a single tile in flight.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT, int CIN, int PD>
+// OF: operand format, 1 = bf16, 2 = fp16 (precision mode 16f; the uint8 counts are exact in both, the weights round to 11 bits)
+template <int NT, int CIN, int PD, int OF = 1>
 __global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(const uint8_t* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
                                                                int B, int H, int W, int Ho, int Wo, int N, int tiles_x, int tiles_y, int dbg) {
     constexpr int NT0 = (NT + 1) / 2;                          // n-tiles of channel group 0
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(const uint8_t* __
                     v = code == 0u ? v : (code == 1u ? v << 24 : (code == 2u ? v >> 8 : 0u));
                 }
                 const f4 f = {(float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24)};
-                *reinterpret_cast<s4*>(patch + 4 * e) = pack_bf16(f);
+                *reinterpret_cast<s4*>(patch + 4 * e) = pack16_raw<OF>(f);
             }
         }
     };
@@ -274,8 +275,8 @@ __global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(const uint8_t* __
             lo = f4{wp[0], wp[1], wp[2], wp[3]};
             hi = f4{wp[4], wp[5], wp[6], 0.f};
         }
-        *reinterpret_cast<s4*>(sw + n * LDW + 8 * row) = pack_bf16(lo);
-        *reinterpret_cast<s4*>(sw + n * LDW + 8 * row + 4) = pack_bf16(hi);
+        *reinterpret_cast<s4*>(sw + n * LDW + 8 * row) = pack16_raw<OF>(lo);
+        *reinterpret_cast<s4*>(sw + n * LDW + 8 * row + 4) = pack16_raw<OF>(hi);
     }
     if (tile < umax) stash(0);
     fetch(0, tile + PD * slots);
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(const uint8_t* __
                     const u4s_ bq = {b0.x, b0.y, b1.x, b1.y};
                     const s8v bv = __builtin_bit_cast(s8v, bq);
 #pragma unroll
-                    for (int t = 0; t < NT0; ++t) acc[t] = mfma32_bf16(*reinterpret_cast<const s8v*>(pa0 + 16 * t * LDW + 32 * s2), bv, acc[t]);
+                    for (int t = 0; t < NT0; ++t) acc[t] = mfma32_16<OF>(*reinterpret_cast<const s8v*>(pa0 + 16 * t * LDW + 32 * s2), bv, acc[t]);
                     if (s2 % 6 == 5) __builtin_amdgcn_sched_barrier(0);       // bound how far the scheduler hoists fragment reads (registers)
                 }
             } else {
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(const uint8_t* __
                     const u4s_ bq = {b0.x, b0.y, b1.x, b1.y};
                     const s8v bv = __builtin_bit_cast(s8v, bq);
 #pragma unroll
-                    for (int t = 0; t < NT - NT0; ++t) acc[t] = mfma32_bf16(*reinterpret_cast<const s8v*>(pa0 + 16 * t * LDW + 32 * s2), bv, acc[t]);
+                    for (int t = 0; t < NT - NT0; ++t) acc[t] = mfma32_16<OF>(*reinterpret_cast<const s8v*>(pa0 + 16 * t * LDW + 32 * s2), bv, acc[t]);
                     if (s2 % 6 == 5) __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -354,12 +355,14 @@ int launch_fwd(const uint8_t* x, const float* w, float* y, int B, int H, int W, 
     static const int dbg = 0;
     int gx = ntiles < workers ? ntiles : workers;
     if (gx >= 8) gx &= ~7;                                     // whole XCD rounds (see the tile order of the kernel)
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_bf16_kernel<NT, CIN, PD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
-    hipLaunchKernelGGL((stem_fwd_bf16_kernel<NT, CIN, PD>), dim3(gx), dim3(512), lds, s, x, w, y, B, H, W, Ho, Wo, N, tiles_x, tiles_y, dbg);
+    LEOD_BY_OPFMT16({
+        static bool attr = false;
+        if (!attr) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_bf16_kernel<NT, CIN, PD, OF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
+        }
+        hipLaunchKernelGGL((stem_fwd_bf16_kernel<NT, CIN, PD, OF>), dim3(gx), dim3(512), lds, s, x, w, y, B, H, W, Ho, Wo, N, tiles_x, tiles_y, dbg);
+    });
     return leod_launch_status();
 }
 

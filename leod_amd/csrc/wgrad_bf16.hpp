@@ -56,7 +56,7 @@ constexpr int wgw_lds_bytes() {
 }
 
 // TN x TK: 16 x 16 tiles of the workgroup's dW tile; NWN x NWK: wave grid over it (each wave 3 x 3 tiles; waves left over split the
-// 32-row steps of a chunk); RC rows per chunk; DYF: dY fp32 (0) / bf16 (1); XM: see XRows (0 rows, 1 LayerNorm, 2 gelu(fp16), 3 bf16 rows)
+// 32-row steps of a chunk); RC rows per chunk; DYF: dY fp32 (0) / bf16 (1); XM: see XRows (0 rows, 1 LayerNorm, 2 gelu(fp16), 3 bf16 rows, 4 fp16 rows)
 template <int TN, int TK, int NWN, int NWK, int RC, int DYF, int XM, int OCC>
 __global__ __launch_bounds__(256, OCC) void wgrad_wide_bf16_kernel(const void* __restrict__ dyv, long lddy, XRows xl, float* dW, long ldw,
                                                                     float* dbias, f4* __restrict__ part, int M, int N, int K, int dbg) {
@@ -190,6 +190,13 @@ __global__ __launch_bounds__(256, OCC) void wgrad_wide_bf16_kernel(const void* _
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = ok ? v[j] : 0u;
                     *reinterpret_cast<u4_*>(d + wgw_slot_off<XRG, TK, BST>(e)) = v;
+                } else if constexpr (XM == 4) {                     // fp16 rows (precision mode 16f: the attention output): re-rounded to bf16
+                    auto cv = [&](unsigned w) -> unsigned {          // two fp16 values -> two bf16 values
+                        const h2_ h = __builtin_bit_cast(h2_, w);
+                        return ok ? pack_bf16x2(f2_{(float)h.x, (float)h.y}) : 0u;
+                    };
+                    const u4_ o = {cv(rx[e].x), cv(rx[e].y), cv(rx[e].z), cv(rx[e].w)};
+                    *reinterpret_cast<u4_*>(d + wgw_slot_off<XRG, TK, BST>(e)) = o;
                 } else {
                     f4 v = __builtin_bit_cast(f4, rx[e]);
                     if constexpr (XM == 1) v = (v - rst[e].x) * rst[e].y;
@@ -479,7 +486,16 @@ static inline int launch_wgrad_wide_cfg(const void* dy, long lddy, const XRows& 
 //   96 x 96   stages 2-4 and the ConvLSTM 1x1: the four pairs above and bf16 dY with fp32 [x | h] rows
 // chunk rows: ~18-25 KB of loads per chunk (fp32 rows carry twice the bytes of 16-bit rows, and twice the staging registers)
 static inline int wgrad_wide_combo(const XRows& xl, int N, int K, int dyfmt) {
-    const int xm = xl.x_mode(), c = (dyfmt ? 1 : 0) * 4 + xm;        // 0: f32/rows 1: f32/LN 2: f32/gelu16 3: f32/bf16 rows 4: bf16/rows 5: bf16/LN
+    const int xm = xl.x_mode();
+    if (xm == 4) {                                                   // fp32 dY, fp16 rows (mode 16f): the tilings of the bf16-row cases
+        if (dyfmt) return 0;
+        if (N <= 48 && K <= 48) return 14;
+        if (K <= 48 || N <= 48) return 0;
+        static const int big4 = getenv("LEOD_WGRAD_WIDE_BIG") ? atoi(getenv("LEOD_WGRAD_WIDE_BIG")) : 1;
+        return (big4 && K % 192 == 0 && N >= 96) ? 16 : 15;
+    }
+    const int c = (dyfmt ? 1 : 0) * 4 + xm;        // 0: f32/rows 1: f32/LN 2: f32/gelu16 3: f32/bf16 rows 4: bf16/rows 5: bf16/LN
+    if (c > 5) return 0;
     if (N <= 48 && K <= 48) return c == 0 ? 1 : c == 3 ? 8 : 0;
     if (K <= 48) return c == 5 ? 2 : 0;
     if (N <= 48) return c == 2 ? 3 : 0;
@@ -517,6 +533,9 @@ static inline int launch_wgrad_wide(const void* dy, long lddy, const XRows& xl, 
         case 11: LEOD_WGW(12, 6, 2, 2, 32, 1, 0, 2);
         case 12: LEOD_WGW(6, 12, 2, 2, 64, 0, 2, 2);
         case 13: LEOD_WGW(6, 12, 2, 2, 32, 0, 3, 2);
+        case 14: LEOD_WGW(3, 3, 1, 1, 64, 0, 4, 2);
+        case 15: LEOD_WGW(6, 6, 2, 2, 32, 0, 4, 3);
+        case 16: LEOD_WGW(6, 12, 2, 2, 32, 0, 4, 2);
     }
 #undef LEOD_WGW
     return LEOD_ERR_UNSUPPORTED;

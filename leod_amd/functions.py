@@ -278,7 +278,7 @@ class AttnBlockFn(Function):
         o16 = q16 and ops.attn_block_o16_ok(x.shape[0], x.shape[1], x.shape[2], x.shape[3], heads, part)
         o, lse = ops.partition_attn_fwd(qkv, heads, part, window, want_lse=need, out_bf16=o16)
         # the pre-LayerScale outputs are NOT stored: dgamma is recovered from the un-scaled weight gradient in backward
-        y, _ = ops.linear_lsres_fwd(o, proj_w, proj_b, g1, x, want_t=False)
+        y, _ = ops.linear_lsres_fwd(o, proj_w, proj_b, g1, x, want_t=False, a_gelu=False)
         # precision mode bf16, stage 1: the whole MLP in one launch, the hidden in registers (csrc/k_mlp.hip); with a backward pass to
         # come it also leaves the fp16 pre-activation and the LayerNorm statistics behind
         fused = ops.mlp_fwd_fused(y, n2w, n2b, fc1_w, fc1_b, fc2_w, fc2_b, g2, want_saved=need)
@@ -288,7 +288,7 @@ class AttnBlockFn(Function):
         else:
             # precision mode bf16, stages 1-2: u comes back as ONE fp16 tensor (h is None) and fc2 applies GELU while loading it
             u, h, st2 = ops.ln_linear_fwd(y, n2w, n2b, fc1_w, fc1_b, want_act=True, want_stats=True)
-            z, _ = ops.linear_lsres_fwd(h if h is not None else u, fc2_w, fc2_b, g2, y, want_t=False)
+            z, _ = ops.linear_lsres_fwd(h if h is not None else u, fc2_w, fc2_b, g2, y, want_t=False, a_gelu=h is None)
         if need:
             ctx.mod = mod
             ctx.u16 = h is None
@@ -312,15 +312,15 @@ class AttnBlockFn(Function):
         else:
             du = ops.linear_dgrad(dz, fc2_w, kscale=g2, aux_u=u)
             dy = ops.linear_dgrad_ln_bwd(du, fc1_w, y, st2, n2w, dz, grad_buf(mod.norm2.weight), grad_buf(mod.norm2.bias))
-        do = ops.linear_dgrad(dy, proj_w, kscale=g1, out_bf16=o.dtype is torch.bfloat16)
+        do = ops.linear_dgrad(dy, proj_w, kscale=g1, out_bf16=o.dtype is not torch.float32)
         dqkv = ops.partition_attn_bwd(qkv, do, lse, heads, part, window)
         # ---- weight gradients: off the critical path (side stream when the engine enables it) ------
         with _wgrad_side(dz, h, du, y, st2, dy, o, dqkv, x, st1):
             ops.layerscale_linear_wgrad(dz, h, fc2_w, fc2_b, g2, grad_buf(mlp.net[2].weight), grad_buf(mlp.net[2].bias),
-                                        grad_buf(mod.ls2.gamma))
+                                        grad_buf(mod.ls2.gamma), h_gelu=ctx.u16)
             ops.linear_wgrad(du, y, grad_buf(mlp.net[0][0].weight), grad_buf(mlp.net[0][0].bias), stats=st2, ln_w=n2w, ln_b=n2b)
             ops.layerscale_linear_wgrad(dy, o, proj_w, proj_b, g1, grad_buf(sa.proj.weight), grad_buf(sa.proj.bias),
-                                        grad_buf(mod.ls1.gamma))
+                                        grad_buf(mod.ls1.gamma), h_gelu=False)
             if n1w is not None:
                 ops.linear_wgrad(dqkv, x, grad_buf(sa.qkv.weight), grad_buf(sa.qkv.bias), stats=st1, ln_w=n1w, ln_b=n1b)
             else:

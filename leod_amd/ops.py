@@ -35,31 +35,53 @@ except AttributeError:                                        # pragma: no cover
     _raw_stream = None
 
 
-PRECISIONS = {'f32': 0, 'fp32': 0, 'float32': 0, 32: 0, 'bf16': 1, 'bfloat16': 1, 16: 1, '16': 1, '32': 0}
+PRECISIONS = {'f32': 0, 'fp32': 0, 'float32': 0, 32: 0, '32': 0, '32-true': 0,
+              'bf16': 1, 'bfloat16': 1, 'bf16-mixed': 1,
+              '16f': 2, 'f16': 2, 'fp16': 2, 'float16': 2, 16: 2, '16': 2, '16-mixed': 2}
+PRECISION_NAMES = {0: 'f32', 1: 'bf16', 2: '16f'}
 
 
 def set_precision(mode) -> int:
-    """'f32' (default): fp32 end to end, bit-tight against the fp32 oracle.  'bf16' (the reference's ``precision=16`` placement,
-    train.py:236-243): contraction operands rounded to bf16 for the bf16 MFMA, fp32 accumulation; statistics, softmax, residual
-    stream, LSTM state, SimOTA cost, losses and optimiser in fp32.  Process-wide; returns the previous mode (0 / 1)."""
+    """'f32' (default): fp32 end to end, bit-tight against the fp32 oracle.
+    '16f' (the reference's ``precision=16`` = fp16 autocast, train.py:236-243): the FORWARD contractions take fp16 operands (fp16 MFMA, fp32
+    accumulation) and the 16-bit activations the forward pass leaves in HBM (qkv, attention output, MLP hidden) are fp16; the gradient
+    contractions take bf16 operands (fp32's exponent range, so no loss scaler); statistics, softmax, residual stream, LSTM state,
+    SimOTA cost, losses and optimiser in fp32.
+    'bf16' (Lightning's ``bf16-mixed``): bf16 operands in both directions.
+    Process-wide; returns the previous mode (0 / 1 / 2)."""
     prev = int(_l().leod_get_precision())
     check(_l().leod_set_precision(PRECISIONS[mode] if not isinstance(mode, bool) and mode in PRECISIONS else int(mode)), 'set_precision')
     return prev
 
 
 def precision_from_config(training_cfg=None) -> str:
-    """The mode a run asks for: ``LEOD_PRECISION`` (f32 | bf16) if set, else the reference's ``training.precision`` key
-    (config/general.yaml: 16 -> the mixed-precision mode, here bf16; 32 -> fp32)."""
+    """The mode a run asks for: ``LEOD_PRECISION`` (f32 | bf16 | 16f) if set, else the reference's ``training.precision`` key
+    (config/general.yaml: 16 -> fp16 mixed precision = mode 16f; 'bf16' / 'bf16-mixed' -> bf16; 32 -> fp32)."""
     import os
     env = os.environ.get('LEOD_PRECISION')
     if env:
-        return 'bf16' if PRECISIONS[env] == 1 else 'f32'
+        return PRECISION_NAMES[PRECISIONS[env]]
     prec = None if training_cfg is None else training_cfg.get('precision', 32)
-    return 'bf16' if str(prec).lower() in ('16', 'bf16', '16-mixed', 'bf16-mixed') else 'f32'
+    return PRECISION_NAMES[PRECISIONS.get(str(prec).lower(), 0)]
 
 
 def get_precision() -> str:
-    return 'bf16' if int(_l().leod_get_precision()) == 1 else 'f32'
+    return PRECISION_NAMES[int(_l().leod_get_precision())]
+
+
+def is_16bit() -> bool:
+    """One of the two mixed-precision modes ('bf16', '16f'): the 16-bit tensor layouts and kernel families are in use."""
+    return int(_l().leod_get_precision()) != 0
+
+
+def act16_dtype():
+    """torch dtype of the 16-bit activation rows the forward pass stores (qkv, attention output): fp16 in mode 16f, else bf16.  Gradient
+    rows (dqkv, du, dO, LSTM gate gradients) are bf16 in both modes; the MLP hidden pre-activation and the LSTM gates fp16 in both."""
+    return torch.float16 if int(_l().leod_get_precision()) == 2 else torch.bfloat16
+
+
+def _is16(t) -> bool:
+    return t.dtype is torch.bfloat16 or t.dtype is torch.float16
 
 
 def _stream():
@@ -130,14 +152,14 @@ def _ln_linear_fwd(x, ln_w, ln_b, W, bias, want_act, want_stats, eps, out_bf16, 
             _PROBE.flops['linear_gemm'] += 2.0 * M * N * K
     if out_bf16 and not want_act:
         # the qkv rows in precision mode bf16 (consumed only by bf16 MFMAs): stored as bf16 where the kernels allow (rc -3: they do not)
-        o16 = torch.empty(x.shape[:-1] + (N,), dtype=torch.bfloat16, device=x.device)
+        o16 = torch.empty(x.shape[:-1] + (N,), dtype=act16_dtype(), device=x.device)
         stats = _empty((M, 2), x) if ln_w is not None else None
         rc = _l().leod_ln_linear_bf16_fwd(_p(x), _p(ln_w), _p(ln_b), eps, _p(W), _p(bias), _p(o16), _p(stats), M, N, K, _stream())
         if rc != -3:
             check(rc, 'ln_linear_bf16_fwd')
             tally(2.0)
             return o16, None, stats
-    if want_act and want_stats and ln_w is not None and get_precision() == 'bf16':
+    if want_act and want_stats and ln_w is not None and is_16bit():
         # precision mode bf16: the hidden pre-activation is stored once, as fp16 (the reference's autocast dtype); consumers apply GELU on load
         u16 = torch.empty(x.shape[:-1] + (N,), dtype=torch.float16, device=x.device)
         stats = _empty((M, 2), x)
@@ -156,8 +178,11 @@ def _ln_linear_fwd(x, ln_w, ln_b, W, bias, want_act, want_stats, eps, out_bf16, 
     return out, act, stats
 
 
-def linear_lsres_fwd(a, W, bias, gamma, res, want_t=True):
-    """out = res + gamma * (a W^T + b); also returns t = a W^T + b when want_t."""
+def linear_lsres_fwd(a, W, bias, gamma, res, want_t=True, a_gelu=None):
+    """out = res + gamma * (a W^T + b); also returns t = a W^T + b when want_t.
+    a_gelu: ``a`` is the fp16 PRE-activation of the MLP hidden (the kernel applies GELU on load).  None: decided by the dtype as before
+    mode 16f existed -- torch.float16 means pre-activation; callers that hand over plain fp16 rows (the attention output of mode 16f)
+    say a_gelu=False."""
     for t, n in ((W, 'W'), (bias, 'bias'), (gamma, 'gamma'), (res, 'res')):
         _ck(t, name=n)
     K = a.shape[-1]
@@ -166,14 +191,14 @@ def linear_lsres_fwd(a, W, bias, gamma, res, want_t=True):
     # algorithmic bytes: a once (stored width), W, residual in, output out
     ev = _probe('linear_gemm', a.element_size() * M * K + 4.0 * N * K + (12.0 if want_t else 8.0) * M * N, 2.0 * M * N * K)
     try:
-        return _linear_lsres_fwd(a, W, bias, gamma, res, want_t, K, N, M)
+        return _linear_lsres_fwd(a, W, bias, gamma, res, want_t, K, N, M, a_gelu)
     finally:
         if ev is not None:
             ev.record()
 
 
-def _linear_lsres_fwd(a, W, bias, gamma, res, want_t, K, N, M):
-    if a.dtype is torch.float16:                             # a = fp16 pre-activation: out = res + gamma * (gelu(a) W^T + b)
+def _linear_lsres_fwd(a, W, bias, gamma, res, want_t, K, N, M, a_gelu=None):
+    if a.dtype is torch.float16 and a_gelu is not False:     # a = fp16 pre-activation: out = res + gamma * (gelu(a) W^T + b)
         _ck(a, torch.float16, 'a')
         if want_t:
             raise LeodHipError('linear_lsres_fwd: the fp16 pre-activation path does not return t')
@@ -181,10 +206,10 @@ def _linear_lsres_fwd(a, W, bias, gamma, res, want_t, K, N, M):
         check(_l().leod_linear_lsres_gelu16_fwd(_p(a), _p(W), _p(bias), _p(gamma), _p(res), _p(out), M, N, K, _stream()),
               'linear_lsres_gelu16_fwd')
         return out, None
-    if a.dtype is torch.bfloat16:                            # a = bf16 rows (the attention output of precision mode bf16)
-        _ck(a, torch.bfloat16, 'a')
+    if _is16(a):                                             # a = 16-bit rows (the attention output: bf16, or fp16 in mode 16f)
+        _ck(a, act16_dtype(), 'a')
         if want_t:
-            raise LeodHipError('linear_lsres_fwd: the bf16-row path does not return t')
+            raise LeodHipError('linear_lsres_fwd: the 16-bit-row path does not return t')
         out = _empty(res.shape, res)
         check(_l().leod_linear_lsres_bf16_fwd(_p(a), _p(W), _p(bias), _p(gamma), _p(res), _p(out), M, N, K, _stream()),
               'linear_lsres_bf16_fwd')
@@ -245,11 +270,11 @@ def mlp_bwd_dgrad_fused(dz, y, stats, ln_w, ln_b, W1, b1, W2, gamma, dgamma, dbe
 
 def partition_attn_fwd(qkv, heads, part, window, want_lse=False, out_bf16=False):
     """qkv [B,H,W,3C] -> out [B,H,W,C] (+ lse [B,H,W,heads]); out_bf16 (attn_block_o16_ok): out as bf16 rows."""
-    q16 = qkv.dtype is torch.bfloat16
-    _ck(qkv, torch.bfloat16 if q16 else F32, 'qkv')
+    q16 = _is16(qkv)
+    _ck(qkv, act16_dtype() if q16 else F32, 'qkv')
     B, H, W, C3 = qkv.shape
     C = C3 // 3
-    out = torch.empty((B, H, W, C), dtype=torch.bfloat16 if out_bf16 else F32, device=qkv.device)
+    out = torch.empty((B, H, W, C), dtype=act16_dtype() if out_bf16 else F32, device=qkv.device)
     lse = torch.empty((B, H, W, heads), dtype=F32, device=qkv.device) if want_lse else None
     check(_l().leod_partition_attn_fwd(_p(qkv), _p(out), _p(lse), B, H, W, C, heads, part[0], part[1],
                                         1 if window else 0, (1 if q16 else 0) | (2 if out_bf16 else 0), _stream()), 'partition_attn_fwd')
@@ -267,14 +292,14 @@ def partition_attn_16bit_ok(B, H, W, C, heads, part) -> bool:
 
 
 def partition_attn_bwd(qkv, dout, lse, heads, part, window):
-    q16 = qkv.dtype is torch.bfloat16
-    _ck(qkv, torch.bfloat16 if q16 else F32, 'qkv')
+    q16 = _is16(qkv)
+    _ck(qkv, act16_dtype() if q16 else F32, 'qkv')
     do16 = dout.dtype is torch.bfloat16                       # bf16 dO rows (attn_block_o16_ok)
     _ck(dout, torch.bfloat16 if do16 else F32, 'dout')
     _ck(lse, name='lse')
     B, H, W, C3 = qkv.shape
     C = C3 // 3
-    dqkv = torch.empty(qkv.shape, dtype=qkv.dtype, device=qkv.device)     # bf16 qkv <=> bf16 dqkv (partition_attn_16bit_ok)
+    dqkv = torch.empty(qkv.shape, dtype=torch.bfloat16 if q16 else F32, device=qkv.device)     # 16-bit qkv <=> bf16 dqkv (partition_attn_16bit_ok)
     dsum = torch.empty(lse.shape, dtype=F32, device=qkv.device)
     check(_l().leod_partition_attn_bwd(_p(qkv), _p(dout), _p(lse), _p(dsum), _p(dqkv), B, H, W, C, heads, part[0],
                                         part[1], 1 if window else 0, (1 if q16 else 0) | (2 if do16 else 0), 1 if q16 else 0, _stream()), 'partition_attn_bwd')
@@ -429,8 +454,8 @@ def _wgrad_workspace(device):
         _WORKSPACES[s] = ws
 
 
-def linear_wgrad(dy, x, dW, dbias=None, stats=None, ln_w=None, ln_b=None, x2=None):
-    """dW += dy^T X ; dbias += colsum(dy).  X = x | LN(x) | [x|x2]."""
+def linear_wgrad(dy, x, dW, dbias=None, stats=None, ln_w=None, ln_b=None, x2=None, x_gelu=None):
+    """dW += dy^T X ; dbias += colsum(dy).  X = x | LN(x) | [x|x2] | gelu(x) (x the fp16 pre-activation; x_gelu as in linear_lsres_fwd)."""
     dy16 = dy.dtype is torch.bfloat16
     _ck(dy, torch.bfloat16 if dy16 else F32, 'dy')
     for t, n in ((dW, 'dW'), (dbias, 'dbias'), (stats, 'stats'), (ln_w, 'ln_w'), (ln_b, 'ln_b'), (x2, 'x2')):
@@ -439,9 +464,9 @@ def linear_wgrad(dy, x, dW, dbias=None, stats=None, ln_w=None, ln_b=None, x2=Non
     K = dW.numel() // N
     M = dy.numel() // N
     K1 = x.shape[-1]
-    if M >= 8192 and _stream() not in _WORKSPACES and get_precision() == 'bf16':
+    if M >= 8192 and _stream() not in _WORKSPACES and is_16bit():
         _wgrad_workspace(dW.device)
-    if x.dtype is torch.float16:                             # X = gelu(x): x is the fp16 pre-activation of the MLP hidden
+    if x.dtype is torch.float16 and x_gelu is not False:     # X = gelu(x): x is the fp16 pre-activation of the MLP hidden
         _ck(x, torch.float16, 'x')
         if stats is not None or x2 is not None or dy16:
             raise LeodHipError('linear_wgrad: LayerNorm / concat / bf16-dy options do not combine with an fp16 pre-activation')
@@ -450,13 +475,14 @@ def linear_wgrad(dy, x, dW, dbias=None, stats=None, ln_w=None, ln_b=None, x2=Non
         if ev is not None:
             ev.record()
         return
-    x16 = x.dtype is torch.bfloat16                           # bf16 rows (the attention output of precision mode bf16)
-    _ck(x, torch.bfloat16 if x16 else F32, 'x')
+    x16 = _is16(x)                                            # 16-bit rows (the attention output: bf16, or fp16 in mode 16f)
+    xh = x.dtype is torch.float16
+    _ck(x, x.dtype if x16 else F32, 'x')
     # algorithmic work of one launch: reads dy, X once, read-modify-writes dW once; 2*M*N*K flops
     ev = _probe('linear_wgrad', (2.0 if dy16 else 4.0) * M * N + (2.0 if x16 else 4.0) * M * K + 4.0 * N * K, 2.0 * M * N * K, rows=M)
     check(_l().leod_linear_wgrad(_p(dy), N, _p(x), K1, _p(stats), _p(ln_w), _p(ln_b), _p(x2),
                                   (x2.shape[-1] if x2 is not None else 0), K1, _p(dW), _p(dbias), M, N, K,
-                                  (1 if dy16 else 0) | (2 if x16 else 0), _stream()), 'linear_wgrad')
+                                  (1 if dy16 else 0) | (4 if xh else (2 if x16 else 0)), _stream()), 'linear_wgrad')
     if ev is not None:
         ev.record()
 
@@ -511,14 +537,14 @@ def layerscale_bwd(dz, t, gamma, dgamma):
     return dt
 
 
-def layerscale_linear_wgrad(dz, h, W, b, gamma, dW, db, dgamma):
+def layerscale_linear_wgrad(dz, h, W, b, gamma, dW, db, dgamma, h_gelu=None):
     """Weight, bias and LayerScale gradients of z = res + gamma * (h W^T + b) from dz alone: the un-scaled G = dz^T h goes
     into a scratch buffer (one wgrad launch), ``leod_layerscale_finalize`` turns it into dW, db and dgamma -- the stored
     pre-scale tensor of the forward pass and the scaled copy of dz are not needed."""
     N, K = W.shape
     scratch = StatArena.zeros((N * K + N,), dz.device, torch.float32)         # one memset per step instead of 16 fill kernels
     G, s = scratch[:N * K].view(N, K), scratch[N * K:]
-    linear_wgrad(dz, h, G, s)
+    linear_wgrad(dz, h, G, s, x_gelu=h_gelu)
     check(_l().leod_layerscale_finalize(_p(W), _p(b), _p(gamma), _p(G), _p(s), _p(dW), _p(db), _p(dgamma), N, K, _stream()),
           'layerscale_finalize')
 
@@ -950,6 +976,14 @@ def set_weight_shadow(base: torch.Tensor, shadow: Optional[torch.Tensor]) -> Non
     if shadow is not None and (shadow.dtype != torch.bfloat16 or shadow.numel() != base.numel() or shadow.device != base.device):
         raise ValueError('weight shadow: bf16 tensor of the length and device of the parameter buffer')
     check(_l().leod_set_weight_shadow(_p(base), base.numel(), _p(shadow)), 'set_weight_shadow')
+
+
+def set_weight_shadow_f16(base: torch.Tensor, shadow_f16: Optional[torch.Tensor]) -> None:
+    """Attach ``shadow_f16`` (fp16, same length) to the registration of ``base``: the copy the forward GEMMs of precision mode 16f read."""
+    _ck(base, name='weight buffer')
+    if shadow_f16 is not None and (shadow_f16.dtype != torch.float16 or shadow_f16.numel() != base.numel() or shadow_f16.device != base.device):
+        raise ValueError('weight shadow: fp16 tensor of the length and device of the parameter buffer')
+    check(_l().leod_set_weight_shadow_f16(_p(base), _p(shadow_f16)), 'set_weight_shadow_f16')
 
 
 def unset_weight_shadow_ptr(base_ptr: int) -> None:

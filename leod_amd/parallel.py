@@ -56,7 +56,9 @@ class FlatParams:
         if dev.type == 'cuda' and os.environ.get('LEOD_WEIGHT_SHADOW', '1') != '0':
             import weakref
             self.shadow = torch.empty(n, dtype=torch.bfloat16, device=dev)
+            self.shadow_f16 = torch.empty(n, dtype=torch.float16, device=dev)     # written / read in precision mode 16f only (forward GEMMs)
             ops.set_weight_shadow(self.data, self.shadow)
+            ops.set_weight_shadow_f16(self.data, self.shadow_f16)
             weakref.finalize(self, ops.unset_weight_shadow_ptr, self.data.data_ptr())
 
     def zero_grad(self):

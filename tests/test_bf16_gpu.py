@@ -1,6 +1,8 @@
-"""Precision mode 'bf16' (ops.set_precision; the reference's Lightning precision=16 placement, train.py:236-243): the contraction
-tests of tests/test_kernels_gpu.py run again with bf16 MFMA operands against the SAME fp32 CPU references, at the tolerance stated
-there (worst element 3e-2 of the tensor's magnitude, rms error 4x tighter).  ``pytest -m gpu``."""
+"""The 16-bit precision modes (ops.set_precision; the reference's Lightning precision=16 placement, train.py:236-243): the contraction
+tests of tests/test_kernels_gpu.py run again with 16-bit MFMA operands against the SAME fp32 CPU references, at the tolerance stated
+there (worst element 3e-2 of the tensor's magnitude, rms error 4x tighter).  Every case runs in BOTH modes: 'bf16' (bf16 operands in both
+directions) and '16f' (fp16 operands and fp16 activation rows in the forward pass -- the reference's autocast dtype -- bf16 gradients).
+``pytest -m gpu``."""
 import pytest
 import torch
 
@@ -9,12 +11,18 @@ pytestmark = pytest.mark.gpu
 import test_kernels_gpu as tk  # noqa: E402
 
 
-@pytest.fixture()
-def bf16_ops():
+def A16():
+    """dtype of the forward-stored 16-bit activation rows (qkv, attention output) in the mode under test"""
+    from leod_amd import ops
+    return ops.act16_dtype()
+
+
+@pytest.fixture(params=['bf16', '16f'])
+def bf16_ops(request):
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     from leod_amd import ops
-    prev = ops.set_precision('bf16')
+    prev = ops.set_precision(request.param)
     tk.MODE['bf16'] = True
     try:
         yield ops
@@ -24,9 +32,24 @@ def bf16_ops():
 
 
 def test_precision_switch(bf16_ops):
-    assert bf16_ops.get_precision() == 'bf16'
-    assert bf16_ops.set_precision('f32') == 1 and bf16_ops.get_precision() == 'f32'
-    bf16_ops.set_precision('bf16')
+    mode = bf16_ops.get_precision()
+    assert mode in ('bf16', '16f') and bf16_ops.is_16bit()
+    assert bf16_ops.set_precision('f32') == bf16_ops.PRECISIONS[mode] and bf16_ops.get_precision() == 'f32' and not bf16_ops.is_16bit()
+    bf16_ops.set_precision(mode)
+    assert bf16_ops.act16_dtype() is (torch.float16 if mode == '16f' else torch.bfloat16)
+    # the reference's training.precision key (config/general.yaml): 16 = fp16 autocast -> mode 16f (LEOD_PRECISION, set by conftest, overrides it)
+    import os
+    env = os.environ.pop('LEOD_PRECISION', None)
+    try:
+        _precision_keys(bf16_ops)
+    finally:
+        if env is not None:
+            os.environ['LEOD_PRECISION'] = env
+
+
+def _precision_keys(bf16_ops):
+    assert bf16_ops.precision_from_config({'precision': 16}) == '16f' and bf16_ops.precision_from_config({'precision': 'bf16'}) == 'bf16'
+    assert bf16_ops.precision_from_config({'precision': 32}) == 'f32' and bf16_ops.precision_from_config(None) == 'f32'
 
 
 @pytest.mark.parametrize('M,N,K,ln,act', [(200, 144, 48, True, False), (64, 1152, 384, True, False), (77, 64, 16, True, True),
@@ -151,7 +174,7 @@ def test_partition_attn_bf16_tensors(bf16_ops, B, H, W, C, heads, part, window):
     MFMAs, so the results are those of the fp32-tensor path on the same (rounded) values -- checked against the fp32 CPU attention."""
     ops = bf16_ops
     assert ops.partition_attn_16bit_ok(B, H, W, C, heads, part)
-    qkv16 = tk.rnd((B, H, W, 3 * C), 7).to(torch.bfloat16)
+    qkv16 = tk.rnd((B, H, W, 3 * C), 7).to(A16())
     qkv = qkv16.float().requires_grad_(True)
     ref = tk._attn_ref(qkv, heads, part, window)
     dout = tk.rnd(ref.shape, 8)
@@ -164,8 +187,8 @@ def test_partition_attn_bf16_tensors(bf16_ops, B, H, W, C, heads, part, window):
     tk.close(dq.float(), qkv.grad, what='bf16 dqkv')
     # the attention output written as bf16 rows / its gradient read as bf16 rows (bit 1 of qkv_bf16): the same values, rounded once
     o16, lse2 = ops.partition_attn_fwd(q, heads, part, window, want_lse=True, out_bf16=True)
-    assert o16.dtype is torch.bfloat16 and torch.equal(lse2, lse)
-    assert torch.equal(o16, out.to(torch.bfloat16)), 'bf16 O = the fp32 O of the same kernel, rounded to nearest even'
+    assert o16.dtype is A16() and torch.equal(lse2, lse)
+    assert torch.equal(o16, out.to(A16())), '16-bit O = the fp32 O of the same kernel, rounded to nearest even'
     do16 = dout.to(torch.bfloat16)
     qkv2 = qkv16.float().requires_grad_(True)
     tk._attn_ref(qkv2, heads, part, window).backward(do16.float())
@@ -182,17 +205,17 @@ def test_attention_block_keeps_o_and_do_as_bf16(bf16_ops, B, H, W, C, heads):
     ops = bf16_ops
     assert ops.attn_block_o16_ok(B, H, W, C, heads, (8, 10))
     M = B * H * W
-    o16 = tk.rnd((M, C), 1).to(torch.bfloat16)
+    o16 = tk.rnd((M, C), 1).to(A16())
     res, dy = tk.rnd((M, C), 2), tk.rnd((M, C), 3)
     Wp, bp, g = tk.rnd((C, C), 4, 0.2), tk.rnd((C,), 5, 0.2), 0.5 + 0.1 * tk.rnd((C,), 6)
     d = lambda t: t.detach().to(tk.DEV)  # noqa
-    y, _ = ops.linear_lsres_fwd(d(o16), d(Wp), d(bp), d(g), d(res), want_t=False)
+    y, _ = ops.linear_lsres_fwd(d(o16), d(Wp), d(bp), d(g), d(res), want_t=False, a_gelu=False)
     tk.close(y, res + g * F.linear(o16.float(), Wp, bp), what='proj + LayerScale + residual from bf16 O')
     do = ops.linear_dgrad(d(dy), d(Wp), kscale=d(g), out_bf16=True)
     assert do.dtype is torch.bfloat16
     tk.close(do.float(), (dy * g) @ Wp, what='bf16 dO')
     dW, db = torch.zeros((C, C), device=tk.DEV), torch.zeros((C,), device=tk.DEV)
-    ops.linear_wgrad(d(dy), d(o16), dW, db)
+    ops.linear_wgrad(d(dy), d(o16), dW, db, x_gelu=False)
     tk.close(dW, (dy.double().t() @ o16.double()).float(), what='proj weight gradient from bf16 O')
     tk.close(db, dy.double().sum(0).float(), what='proj bias gradient')
 
@@ -207,7 +230,7 @@ def test_ln_qkv_bf16_rows(bf16_ops, M, N, K):
     ref = F.linear(F.layer_norm(x, (K,), lw, lb, 1e-5), W, b)
     d = lambda t: t.to(tk.DEV)  # noqa
     o16, _, st = ops.ln_linear_fwd(d(x), d(lw), d(lb), d(W), d(b), want_stats=True, out_bf16=True)
-    assert o16.dtype is torch.bfloat16 and st is not None
+    assert o16.dtype is A16() and st is not None
     tk.close(o16.float(), ref, what='bf16 qkv rows')
     mean = x.mean(1)
     tk.close(st[:, 0], mean, rtol=1e-4, atol=1e-5, what='LayerNorm mean')
@@ -220,7 +243,7 @@ def test_qkv_bf16_rows_without_layernorm(bf16_ops):
     for M, N, K in ((9001, 576, 192), (20011, 288, 96), (40009, 144, 48)):
         x, W, b = tk.rnd((M, K), 1), tk.rnd((N, K), 4, 0.2), tk.rnd((N,), 5, 0.2)
         o16, _, st = ops.ln_linear_fwd(x.to(tk.DEV), None, None, W.to(tk.DEV), b.to(tk.DEV), out_bf16=True)
-        assert o16.dtype is torch.bfloat16 and st is None
+        assert o16.dtype is A16() and st is None
         tk.close(o16.float(), F.linear(x, W, b), what=f'bf16 qkv rows without LayerNorm {M}x{N}x{K}')
 
 
@@ -300,10 +323,10 @@ def test_wgrad_wide_bf16(bf16_ops, M, N, K, dy16, xmode):
     if xmode in ('rows', 'rows16'):
         x = tk.rnd((M, K), 22)
         if xmode == 'rows16':
-            x = x.to(torch.bfloat16)
+            x = x.to(A16())
         X = x.float()
         xd = d(x)
-        call = lambda: ops.linear_wgrad(dyd, xd, dW, db)  # noqa
+        call = lambda: ops.linear_wgrad(dyd, xd, dW, db, x_gelu=False)  # noqa
     elif xmode == 'ln':
         x = 0.3 + 1.5 * tk.rnd((M, K), 22)
         lw, lb = 1 + 0.2 * tk.rnd((K,), 23), 0.1 * tk.rnd((K,), 24)
@@ -540,6 +563,7 @@ def test_weight_shadow_is_bit_identical(bf16_ops, M, C):
     n1, n2 = 4 * C * C, C * 4 * C
     flat = torch.zeros(n1 + n2 + 3 * C * C + C * C, device=tk.DEV)
     shadow = torch.empty(flat.numel(), dtype=torch.bfloat16, device=tk.DEV)
+    shadow_f16 = torch.empty(flat.numel(), dtype=torch.float16, device=tk.DEV)     # mode 16f: the forward GEMMs read an fp16 copy
     W1 = flat[:n1].view(4 * C, C)
     W2 = flat[n1:n1 + n2].view(C, 4 * C)
     Wq = flat[n1 + n2:n1 + n2 + 3 * C * C].view(3 * C, C)
@@ -565,13 +589,17 @@ def test_weight_shadow_is_bit_identical(bf16_ops, M, C):
 
     ref = chain()                                          # no shadow registered: fp32 weight tiles rounded by the loaders
     ops.set_weight_shadow(flat, shadow)
+    ops.set_weight_shadow_f16(flat, shadow_f16)
     try:
         shadow.fill_(float('nan'))
+        shadow_f16.fill_(float('nan'))
         stale = chain()                                    # registered but never refreshed: must not be read
         for a, b in zip(ref, stale):
             assert torch.equal(a, b)
         assert ops.weight_shadow_refresh() == 1 and ops.weight_shadow_refresh() == 0
         assert torch.equal(shadow.float(), flat.to(torch.bfloat16).float())
+        if ops.get_precision() == '16f':
+            assert torch.equal(shadow_f16.float(), flat.to(torch.float16).float())
         fresh = chain()
         for k, (a, b) in enumerate(zip(ref, fresh)):
             assert torch.equal(a, b), f'output {k} differs with the bf16 weight shadow'
@@ -579,6 +607,7 @@ def test_weight_shadow_is_bit_identical(bf16_ops, M, C):
         gbuf, m, v = torch.zeros_like(flat), torch.zeros_like(flat), torch.zeros_like(flat)
         ops.adamw_clip_step(flat, gbuf, m, v, 0.0, 1)
         shadow.fill_(float('nan'))
+        shadow_f16.fill_(float('nan'))
         after = chain()
         for a, b in zip(ref, after):
             assert torch.equal(a, b)
