@@ -30,6 +30,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3    # dense fp32 MFMA peak: 256 FLOP/clk/CU x 256 CU
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF figure includes 2:1 sparsity)
 # SURVEY 8d / DESIGN.md: algorithmic HBM traffic of one RVT-S training event-frame: 16-bit activations (68.61 MB backbone + 32/168 of the
 # 29.01 MB of PAFPN + head per labelled frame) + 395/168 MB of optimiser traffic = 76.5 MB; with fp32 activations twice the activation part
+CFG_PRECISION = {'16f': 16, 'bf16': 'bf16', 'f32': 32}      # training.precision per bench mode (16 = the reference's fp16 autocast -> mode 16f)
+DTYPE_NAME = {'16f': 'fp16', 'bf16': 'bf16', 'f32': 'f32'}   # the JSON line's dtype: the operand type of the forward contractions
 ALGO_MB_PER_FRAME = {'bf16': 68.61 + 32.0 / 168.0 * 29.01 + 395.0 / 168.0,
                      'f32': 2 * (68.61 + 32.0 / 168.0 * 29.01) + 395.0 / 168.0}
 
@@ -169,7 +171,7 @@ def pseudo_main(args):
     L, B = args.seq_len, args.batch
     over = dict(dataset=dict(sequence_length=L), tta=dict(enable=True, hflip=True, tflip=False))
     cfg = dynamically_modify_train_config(full_config('gen1', args.size, model='pseudo_labeler', overrides=over))
-    cfg.training.precision = 16 if args.dtype == 'bf16' else 32
+    cfg.training.precision = CFG_PRECISION[args.dtype]
     cfg.model.postprocess.confidence_threshold = 0.01
     torch.manual_seed(0)
     mod = PseudoLabeler(cfg).to(dev).eval()
@@ -220,7 +222,7 @@ def pseudo_main(args):
         for _ in range(2):
             mod.predict_step(batch(), 0)
         mod.flush_predictions()
-        roofline = probe.finish(PEAK_HBM_GBS, PEAK_BF16_MFMA_TFLOPS if args.dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS, target='linear_gemm')
+        roofline = probe.finish(PEAK_HBM_GBS, PEAK_BF16_MFMA_TFLOPS if args.dtype != 'f32' else PEAK_F32_MFMA_TFLOPS, target='linear_gemm')
         family_ms = probe.family_ms(2)
         if args.dump_calls:                               # every C launch of the two probe chunks, in order
             with open(args.dump_calls, 'w') as f:
@@ -230,11 +232,11 @@ def pseudo_main(args):
         fps = world * B * L * args.steps / dt
         # inference-forward bytes per PROCESSED frame (backbone 15.22 MB + PAFPN / head forward 9.67 MB at 16-bit activations;
         # twice that in fp32 mode); a source frame is processed twice (hflip copy)
-        mb_frame = (15.22 + 9.67) * (1 if args.dtype == 'bf16' else 2)
+        mb_frame = (15.22 + 9.67) * (1 if args.dtype != 'f32' else 2)
         out = {'metric': 'source event-frames/sec (pseudo-label inference: RVT-S backbone + head + batched NMS + pred2label, hflip TTA), whole job',
                'value': round(fps, 2), 'unit': 'source event-frames/s (whole job)', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': args.dtype, 'data': 'synthetic',
+               'dtype': DTYPE_NAME[args.dtype], 'precision_mode': args.dtype, 'data': 'synthetic',
                'config': {'workload': f'LEOD pseudo-label pass (BASELINE configs[4], one shard): RVT-{args.size} gen1 {hw[0]}x{hw[1]} L={L}, {B} source streams '
                                       f'/GPU + hflip TTA = {2 * B} frame streams, conf 0.01 / NMS 0.45, random-init weights + 4.0 obj / cls bias bump',
                           'driver': 'PseudoLabeler.predict_step, pipelined as leod_amd.predict.run_pseudo_labeling drives it (host bookkeeping of chunk i - 1 under the device work of chunk i), eager launches',
@@ -270,9 +272,10 @@ def main():
     ap.add_argument('--dataset', choices=('gen1', 'gen4'), default='gen1', help='gen4: 3 classes, 360x640 frames (downsampled by 2)')
     ap.add_argument('--full-res', action='store_true', help='gen4 at 720x1280 -> 768x1280, 240-token partitions '
                     '(BASELINE configs[3]: --dataset gen4 --full-res --size base --seq-len 11 --batch 2)')
-    ap.add_argument('--dtype', choices=('bf16', 'f32'), default='bf16',
-                    help='precision mode of the contractions (leod_set_precision): bf16 = the reference\'s precision=16 placement (bf16 MFMA '
-                         'operands, fp32 accumulation / statistics / state / optimiser), f32 = fp32 end to end (the bit-tight parity mode)')
+    ap.add_argument('--dtype', choices=('16f', 'bf16', 'f32'), default='16f',
+                    help='precision mode of the contractions (leod_set_precision): 16f = the reference\'s precision=16 (fp16 MFMA operands and fp16 '
+                         'activation rows in the forward pass, bf16 operands for the gradients, fp32 accumulation / statistics / state / optimiser), '
+                         'bf16 = bf16 operands in both directions, f32 = fp32 end to end (the bit-tight parity mode)')
     ap.add_argument('--no-second-dtype', action='store_true', help='skip the secondary line measured in the other precision (N=1 only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -316,7 +319,7 @@ def main():
         # The product path, through the reference's own surface (train.py:131-133,228-250): fetch_model_module(config) ->
         # Module.setup('fit') -> configure_optimizers() -> per batch what Lightning's automatic optimisation does
         # (optimizer.step(closure: zero_grad, training_step, backward), scheduler.step()).
-        cfg.training.precision = 16 if dtype == 'bf16' else 32
+        cfg.training.precision = CFG_PRECISION[dtype]
         os.environ.pop('LEOD_PRECISION', None)                # the config decides (Module.setup -> leod_set_precision)
         torch.manual_seed(0)                                  # identical random-init weights on every rank
         module = fetch_model_module(cfg).to(dev)
@@ -408,7 +411,7 @@ def main():
                 run(first_mask(1))
             module.wgrad_side, module.plan_mode = side, planned
             if probe is not None:
-                peak_t = PEAK_BF16_MFMA_TFLOPS if dtype == 'bf16' else PEAK_F32_MFMA_TFLOPS
+                peak_t = PEAK_BF16_MFMA_TFLOPS if dtype != 'f32' else PEAK_F32_MFMA_TFLOPS      # fp16 and bf16 MFMA share one dense peak
                 roofline = probe.finish(PEAK_HBM_GBS, peak_t, target='linear_wgrad')
                 roofline_gemm = probe.finish(PEAK_HBM_GBS, peak_t, target='linear_gemm')
                 # every C entry point bracketed with events during the same two single-stream steps: the line audits itself
@@ -439,7 +442,7 @@ def main():
     other = None
     if world == 1 and headline and not args.no_second_dtype:
         torch.cuda.empty_cache()
-        od = 'f32' if args.dtype == 'bf16' else 'bf16'
+        od = 'f32' if args.dtype != 'f32' else '16f'
         r2 = measure(od, args.steps, args.warmup, not args.no_roofline)
         other = {'dtype': od, 'value': round(B * T * args.steps / r2['dt'], 2), 'unit': 'event-frames/s (whole job)',
                  'ms_per_step': round(1000 * r2['dt'] / args.steps, 3), 'final_loss': round(r2['loss'], 4), 'roofline': r2['roofline'],
@@ -452,22 +455,25 @@ def main():
             'metric': 'event-frames/sec/GPU (RVT-S train, Gen1 T=21) at 1/2/4/8 GPUs; mAP@0.5 parity',
             'value': round(fps, 2), 'unit': 'event-frames/s (whole job)', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1000 * dt / args.steps, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE_NAME[args.dtype], 'precision_mode': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'RVT-{args.size} {args.dataset} {hw[0]}x{hw[1]} (pad {in_hw[0]}x{in_hw[1]}) T={T} bs={B}/GPU fully-supervised train step, '
                                    f'{len(label_ts)} labelled frames/sequence, random-init weights',
                        'global_batch': world * B, 'seq_len': T, 'parallelism': f'dp{world}',
                        'driver': 'fetch_model_module(cfg) -> Module.training_step + FlatAdamW.step + OneCycleLR.step (leod_amd.optim.fit_step)',
                        'launch': launch,
-                       'precision': ('bf16 MFMA operands (GEMM / conv / stem), fp32 accumulation, fp32 LayerNorm / BatchNorm statistics, softmax, '
-                                     'residual stream, LSTM state, SimOTA cost, losses, master weights and AdamW (the placement of the reference\'s '
-                                     'precision=16 run, train.py:236-243)') if args.dtype == 'bf16' else 'fp32 end to end',
+                       'precision': {'16f': 'mode 16f: fp16 MFMA operands and fp16 activation rows in the forward contractions (GEMM / conv / attention / ConvLSTM / '
+                                            'stem: the reference\'s fp16 autocast, train.py:236-243), bf16 MFMA operands for the gradient contractions (no loss '
+                                            'scaler), fp32 accumulation, fp32 LayerNorm / BatchNorm statistics, softmax, residual stream, LSTM state, SimOTA cost, '
+                                            'losses, master weights and AdamW',
+                                     'bf16': 'mode bf16: bf16 MFMA operands in both directions, fp32 accumulation / statistics / state / optimiser',
+                                     'f32': 'fp32 end to end'}[args.dtype],
                        'collective_backend': dist.get_backend() if dist.is_initialized() else None,
                        'collective_world_size': dist.get_world_size() if dist.is_initialized() else 1,
                        'per_gpu_event_frames_per_s': round(fps / world, 2), 'final_loss': round(loss_val, 4),
                        # algorithmic bytes of the MEASURED precision mode: 76.5 MB per event-frame with 16-bit activations
-                       'whole_step_hbm_frac_of_peak': round(ALGO_MB_PER_FRAME[args.dtype] * 1e6 * fps / world / (PEAK_HBM_GBS * 1e9), 5)
+                       'whole_step_hbm_frac_of_peak': round(ALGO_MB_PER_FRAME['f32' if args.dtype == 'f32' else 'bf16'] * 1e6 * fps / world / (PEAK_HBM_GBS * 1e9), 5)
                        if headline else None,
-                       'algorithmic_MB_per_event_frame': round(ALGO_MB_PER_FRAME[args.dtype], 2) if headline else None,
+                       'algorithmic_MB_per_event_frame': round(ALGO_MB_PER_FRAME['f32' if args.dtype == 'f32' else 'bf16'], 2) if headline else None,
                        # GPU time per C entry point (= kernel family) and step, HIP events around every launch of two single-stream steps
                        'family_ms_per_step': main_run['family_ms'],
                        # host side: wall time of the Python call chain of ONE step launched into an idle device (median of 5), the kernels

@@ -88,12 +88,18 @@ def cls16(g, prefix, key):
 
 # HIP-bf16 deviation as a multiple of the reference's fp16 class: measured ceilings (round 4, see the printed values) with ~30 % head room.
 # bf16 keeps 8 significand bits against fp16's 11: a factor of 8 per rounding is the number format itself.
-FP16_CLASS_MULT = {'feat': 10.5, 'state_c': 10.5, 'one_minus_cos': 5.0}      # measured: 5.4-8.0, 5.6-7.9, 3.7-3.8
+# Mode '16f' (round 5: fp16 operands and fp16 activation rows in the forward pass, the reference's own autocast dtype; bf16 gradients): the
+# forward quantities must sit AT the fp16 class (<= 2 x), the gradient direction within 2 x of it.
+FP16_CLASS_MULT = {'bf16': {'feat': 10.5, 'state_c': 10.5, 'one_minus_cos': 5.0},      # measured: 5.4-8.0, 5.6-7.9, 3.7-3.8
+                   '16f': {'feat': 1.5, 'state_c': 1.5, 'one_minus_cos': 1.5}}      # measured (r05_a_16f_class_first_run.log): 0.7-0.9, 0.7-0.9, 0.04-0.7
+MODES16 = ['bf16', '16f']
 MEASURED = {}
 
 
-def _check_against_class(tag, g, prefix, names, grads16, grads32, losses16, losses32, h16, h32, c16, c32, frac_ok=0.97):
+def _check_against_class(tag, g, prefix, names, grads16, grads32, losses16, losses32, h16, h32, c16, c32, frac_ok=0.97, mode='bf16'):
     """Shared assertions of the micro and the full-size step; everything measured is printed (run with -s to see it)."""
+    MULT = FP16_CLASS_MULT[mode]
+    tag = f'{tag}/{mode}'
     # ---- losses: each component within SLACK x the reference's own 16-bit deviation (never tighter than 1e-2 of the total)
     ref32 = np.asarray(g[f'{prefix}_fp32_losses'])
     band = SLACK * np.maximum(np.abs(np.asarray(g[f'{prefix}_ac_losses']) - ref32), np.abs(np.asarray(g[f'{prefix}_acf_losses']) - ref32))
@@ -123,7 +129,7 @@ def _check_against_class(tag, g, prefix, names, grads16, grads32, losses16, loss
     print(f'[{tag}] ... as multiples of the reference fp16-autocast class: stage features x{np.round(mh, 1)} (class {np.round(h16, 5)}), '
           f'cell states x{np.round(mc, 1)} (class {np.round(c16cls, 5)})')
     MEASURED[tag] = {'feat_x_fp16': mh.tolist(), 'state_c_x_fp16': mc.tolist()}
-    assert np.all(mh <= FP16_CLASS_MULT['feat']) and np.all(mc <= FP16_CLASS_MULT['state_c']), (mh, mc)
+    assert np.all(mh <= MULT['feat']) and np.all(mc <= MULT['state_c']), (mh, mc)
     # ---- gradients: global direction, then per tensor
     flat16 = np.concatenate([grads16[n].ravel() for n in names])
     flat32 = np.concatenate([grads32[n].ravel() for n in names])
@@ -137,7 +143,7 @@ def _check_against_class(tag, g, prefix, names, grads16, grads32, losses16, loss
     print(f'[{tag}] ... reference fp16 autocast vs fp32: cosine h16 {float(g[f"{prefix}_h16_grad_cos_global"]):.4f}, h16f '
           f'{float(g[f"{prefix}_h16f_grad_cos_global"]):.4f}; (1 - cos) of HIP bf16 = x{m_cos:.1f} the fp16 class')
     MEASURED[tag]['one_minus_cos_x_fp16'] = m_cos
-    assert m_cos <= FP16_CLASS_MULT['one_minus_cos'], m_cos
+    assert m_cos <= MULT['one_minus_cos'], m_cos
     assert 1.0 - c_hip <= SLACK * (1.0 - c_cls), f'gradient cosine {c_hip:.4f}: outside {SLACK} x the reference class ({c_cls:.4f})'
     assert r_hip <= SLACK * r_cls + nfg_shift
     dev = np.array([rel(grads16[n], grads32[n]) for n in names])
@@ -167,25 +173,28 @@ def _micro_run(manifest, mode):
                 [c.detach().cpu().numpy() for _, c in eng.states])
 
 
-def test_micro_step_bf16_within_reference_autocast_class(gpu, manifest, g18):
+@pytest.mark.parametrize('mode16', MODES16)
+def test_micro_step_bf16_within_reference_autocast_class(gpu, manifest, g18, mode16):
     """The g12 micro training step (T=5, B=2): fp32 mode == the reference's recorded fp32 run; bf16 mode within SLACK x the
     deviation of the reference's own autocast runs from it, per loss component, stage feature, LSTM state and parameter gradient."""
     l32, g32, h32, c32 = _micro_run(manifest, 'f32')
     names = [str(k) for k in g18['micro_grad_keys']]
     np.testing.assert_allclose(l32, g18['micro_fp32_losses'], rtol=1e-4, err_msg='fp32 mode vs the reference fp32 run')
     np.testing.assert_allclose([np.linalg.norm(g32[n].astype(np.float64)) for n in names], g18['micro_fp32_grad_norms'], rtol=3e-3, atol=1e-6)
-    l16, g16, h16, c16 = _micro_run(manifest, 'bf16')
-    _check_against_class('micro', g18, 'micro', names, g16, g32, l16, l32, h16, h32, c16, c32, frac_ok=0.9)
+    l16, g16, h16, c16 = _micro_run(manifest, mode16)
+    _check_against_class('micro', g18, 'micro', names, g16, g32, l16, l32, h16, h32, c16, c32, frac_ok=0.9, mode=mode16)
 
 
-def test_tiny256_forward_bf16_within_reference_autocast_class(gpu, manifest, g18):
+@pytest.mark.parametrize('mode16', MODES16)
+def test_tiny256_forward_bf16_within_reference_autocast_class(gpu, manifest, g18, mode16):
     """RVT-tiny at the real Gen1 geometry, two timesteps (the g04 set-up): stage features of the bf16 mode against the fp32 mode,
     bounded by the reference's autocast-vs-fp32 deviation of the same features and by 2e-2."""
     ev = synth_events(2, 1, 20, 240, 304, seed=5, as_uint8=True).to(DEV)
     out = {}
-    for mode in ('f32', 'bf16'):
+    for mode in ('f32', mode16):
         with precision(mode), torch.no_grad():
             det, _, _ = tm.build(manifest, 'tiny_gen1', 6, 'tiny')
+            mode = 'bf16' if mode == mode16 else mode            # the 16-bit run is stored under 'bf16' whichever mode it is
             feats, states = det.forward_backbone(ev[0], None)
             feats, states = det.forward_backbone(ev[1], states)
             out[mode] = {k: v.float().cpu().numpy() for k, v in feats.items()}
@@ -196,8 +205,8 @@ def test_tiny256_forward_bf16_within_reference_autocast_class(gpu, manifest, g18
     print('tiny256 feature rel dev', dev, 'class', cls(g18, 'tiny', 'feat_rel'), 'max-rel', mx, 'class', cls(g18, 'tiny', 'feat_maxrel'))
     m16 = dev / cls16(g18, 'tiny', 'feat_rel')
     print('tiny256 ... as multiples of the reference fp16-autocast class', np.round(m16, 1), '(class', cls16(g18, 'tiny', 'feat_rel'), ')')
-    MEASURED['tiny256'] = {'feat_x_fp16': m16.tolist()}
-    assert np.all(m16 <= FP16_CLASS_MULT['feat']), m16
+    MEASURED[f'tiny256/{mode16}'] = {'feat_x_fp16': m16.tolist()}
+    assert np.all(m16 <= FP16_CLASS_MULT[mode16]['feat']), m16
     assert np.all(dev <= np.minimum(SLACK * cls(g18, 'tiny', 'feat_rel'), 2e-2))
     assert np.all(mx <= SLACK * cls(g18, 'tiny', 'feat_maxrel'))
 
@@ -234,7 +243,8 @@ def _small_run(manifest, mode, ev, rows, label_tb):
     return res
 
 
-def test_full_size_step_bf16_within_reference_autocast_class(gpu, manifest, g18):
+@pytest.mark.parametrize('mode16', MODES16)
+def test_full_size_step_bf16_within_reference_autocast_class(gpu, manifest, g18, mode16):
     """BASELINE configs[1] (RVT-S Gen1 240x304 T=21 bs=8, bench.py's batch, synthetic weights) through Module.training_step +
     FlatAdamW.  fp32 mode == the REFERENCE's recorded fp32 run of this very workload (six losses 2e-5, 259 gradient norms 3e-3); the
     bf16 mode -- the mode bench.py's headline number is measured in -- within SLACK x the reference's own autocast deviation.
@@ -246,8 +256,8 @@ def test_full_size_step_bf16_within_reference_autocast_class(gpu, manifest, g18)
     np.testing.assert_allclose(l32[:5], g18['small_fp32_losses'][:5], rtol=2e-5, atol=1e-6, err_msg='fp32 mode vs the reference fp32 run')
     assert l32[5] == pytest.approx(float(g18['small_fp32_losses'][5]), rel=1e-6)
     np.testing.assert_allclose([np.linalg.norm(g32[n].astype(np.float64)) for n in names], g18['small_fp32_grad_norms'], rtol=3e-3, atol=1e-7)
-    l16, g16, h16, c16 = _small_run(manifest, 'bf16', ev, rows, label_tb)
-    _check_against_class('small', g18, 'small', names, g16, g32, l16, l32, h16, h32, c16, c32, frac_ok=0.97)
+    l16, g16, h16, c16 = _small_run(manifest, mode16, ev, rows, label_tb)
+    _check_against_class('small', g18, 'small', names, g16, g32, l16, l32, h16, h32, c16, c32, frac_ok=0.97, mode=mode16)
 
 
 def _device_batch(T, B, seed, label_ts=(4, 9, 14, 19)):
@@ -272,7 +282,8 @@ def _device_batch(T, B, seed, label_ts=(4, 9, 14, 19)):
     return ev, lab, label_tb
 
 
-def test_loss_trajectory_30_steps_bf16_vs_f32(gpu):
+@pytest.mark.parametrize('mode16', MODES16)
+def test_loss_trajectory_30_steps_bf16_vs_f32(gpu, mode16):
     """30 optimiser steps at the benchmark size from the same random initialisation on identical batches (10 distinct batches, three
     passes) at the START of the reference's 400 k-step OneCycle schedule (the warm-up from max_lr / 20 = 1e-5; ``training.max_steps`` below
     does not reach the scheduler -- the 200-step test that follows runs a whole scaled schedule), carried LSTM state on the stream half: the two
@@ -289,7 +300,7 @@ def test_loss_trajectory_30_steps_bf16_vs_f32(gpu):
         m[:B // 2] = torch.rand(B // 2, generator=g) < 0.05
         firsts.append(m)
     traj = {}
-    for mode in ('f32', 'bf16'):
+    for mode in ('f32', mode16):
         cfg = dynamically_modify_train_config(full_config('gen1', 'small'))
         cfg.training.max_steps = 60
         torch.manual_seed(0)
@@ -306,7 +317,7 @@ def test_loss_trajectory_30_steps_bf16_vs_f32(gpu):
                 ev, lab, label_tb = batches[s % len(batches)]
                 res = fit_step(mod, opt, lrs, te._loader_batch(ev, lab, label_tb, firsts[s].to(DEV)), s)
                 out.append([float(res['log_dict'][f'train/{k}'].detach()) for k in KEYS])
-            traj[mode] = np.array(out)
+            traj['f32' if mode == 'f32' else 'bf16'] = np.array(out)
         del mod, opt, lrs, oc
         torch.cuda.empty_cache()
     a, b = traj['f32'][:, 0], traj['bf16'][:, 0]
@@ -333,7 +344,8 @@ def test_loss_trajectory_30_steps_bf16_vs_f32(gpu):
         assert abs(x - y) <= 5e-2 * abs(x) + 1e-3, (KEYS[i], x, y)
 
 
-def test_loss_trajectory_200_steps_onecycle_bf16_vs_f32(gpu):
+@pytest.mark.parametrize('mode16', MODES16)
+def test_loss_trajectory_200_steps_onecycle_bf16_vs_f32(gpu, mode16):
     """a WHOLE OneCycle schedule, scaled to 200 optimiser steps (20 warm-up steps from max_lr / 20 to the 2e-4 peak, 180
     steps of linear decay -- the reference's shape, modules/detection.py:498-511, with pct_start 0.1 instead of 0.005 so that the warm-up is
     more than one step), at the benchmark size on identical batches (16 distinct batches cycled, carried LSTM state on the stream half):
@@ -354,7 +366,7 @@ def test_loss_trajectory_200_steps_onecycle_bf16_vs_f32(gpu):
     # weights are perturbed ONCE by relative Gaussian noise of 2^-9 (one bf16 rounding): how far a perturbation of that size is amplified
     # by 200 steps of training from random init
     for tag in ('f32', 'f32_again', 'f32_perturbed', 'bf16'):
-        mode = 'bf16' if tag == 'bf16' else 'f32'
+        mode = mode16 if tag == 'bf16' else 'f32'
         cfg = dynamically_modify_train_config(full_config('gen1', 'small'))
         cfg.training.max_steps = steps
         cfg.training.lr_scheduler.total_steps = steps
@@ -395,7 +407,7 @@ def test_loss_trajectory_200_steps_onecycle_bf16_vs_f32(gpu):
     print('loss f32 again        :', np.round(a2[::20], 3))
     print('loss bf16 (every 20th):', np.round(b[::20], 3))
     print(f'fp32 run-to-run smoothed relative difference: max {noise.max():.4f}, mean {noise.mean():.4f}')
-    print(f'smoothed relative difference: max {rel_d.max():.4f}, mean {rel_d.mean():.4f}; first / last 20-step means f32 {a[:20].mean():.3f} / '
+    print(f'[{mode16}] smoothed relative difference: max {rel_d.max():.4f}, mean {rel_d.mean():.4f}; first / last 20-step means f32 {a[:20].mean():.3f} / '
           f'{a[-20:].mean():.3f}, bf16 {b[:20].mean():.3f} / {b[-20:].mean():.3f}')
     MEASURED['trajectory200'] = {'max_smoothed_rel_diff': float(rel_d.max()), 'final_f32': float(a[-20:].mean()), 'final_bf16': float(b[-20:].mean())}
     assert not np.array_equal(a, b)
@@ -408,22 +420,28 @@ def test_loss_trajectory_200_steps_onecycle_bf16_vs_f32(gpu):
     # (the bounds are those of a chaotic system observed over ~35 runs -- worst seen: 0.058 before step 100, 0.30 overall, finals 6.69 vs 9.53 --
     # with head room: this test documents the difference and catches a mode that stops learning or runs away, it cannot pin a trajectory.
     # What the difference is and is not: profiles/r04_z_trajectory_ablation.txt)
+    # Mode 16f (round 5): the forward pass computes in the reference's own fp16 class and the effect is gone -- measured max smoothed
+    # difference 0.012 over the whole schedule with finals 9.19 (fp32) / 9.16 (16f), INSIDE fp32's own run-to-run spread of the same run
+    # (0.051; perturbed control 0.061).  Its bounds are those of two fp32 runs (worst fp32-vs-fp32 seen over ~35 runs: 0.058 early, finals
+    # 8.87-9.53) with head room, not the 0.45 the bf16 mode needs.
     early = slice(0, 90)
-    assert rel_d[early].max() <= 0.10, rel_d[early].max()
-    assert rel_d.max() <= 0.45, rel_d.max()
-    assert abs(a[-20:].mean() - b[-20:].mean()) <= 0.45 * a[-20:].mean()
+    lim_early, lim_all = (0.10, 0.45) if mode16 == 'bf16' else (0.08, 0.15)
+    assert rel_d[early].max() <= lim_early, rel_d[early].max()
+    assert rel_d.max() <= lim_all, rel_d.max()
+    assert abs(a[-20:].mean() - b[-20:].mean()) <= lim_all * a[-20:].mean()
     MEASURED['trajectory200'].update(fp32_run_to_run=float(noise.max()), fp32_perturbed=float(pert.max()), early_max=float(rel_d[early].max()))
     print('MEASURED', MEASURED['trajectory200'])
 
 
+@pytest.mark.parametrize('mode16', MODES16)
 @pytest.mark.parametrize('size,full_res,T', [('base', False, 2), ('base', True, 2), ('small', True, 1), ('tiny', False, 2)])
-def test_gen4_geometries_fwd_bwd_bf16(gpu, g18, size, full_res, T):
+def test_gen4_geometries_fwd_bwd_bf16(gpu, g18, size, full_res, T, mode16):
     """The geometries of BASELINE configs[3] in the bf16 mode (tests/test_model_gpu.py::test_gen4_geometries_fwd_bwd runs them in
     fp32 mode): RVT-B / RVT-S / RVT-T on Gen4 frames at 384x640 (60-token partitions) and 768x1280 (240-token partitions), carried
     LSTM state, against the fp32 ORACLE: stage features and states 2e-2 (L2) / the reference class's worst-element deviation,
     the smooth test loss 1e-2, every backbone gradient tensor within 4 % (L2) with cosine > 0.999 -- there is no SimOTA in this
     loss, so gradient noise is the kernels' rounding only."""
-    with precision('bf16'):
+    with precision(mode16):
         det, sd, cfg = tm._build_gen4(size, full_res, 21)
         in_hw = tuple(cfg.model.backbone.in_res_hw)
         part = tuple(cfg.model.backbone.stage.attention.partition_size)
@@ -475,7 +493,8 @@ def test_gen4_geometries_fwd_bwd_bf16(gpu, g18, size, full_res, T):
         assert r <= 0.04 and c >= 0.999, (k, r, c)
 
 
-def test_pseudo_label_inference_bf16_vs_oracle(gpu, manifest):
+@pytest.mark.parametrize('mode16', MODES16)
+def test_pseudo_label_inference_bf16_vs_oracle(gpu, manifest, mode16):
     """The pseudo-label pass (tests/test_engine_gpu.py::test_pseudo_label_inference_vs_oracle) in the bf16 mode, the mode
     tools/bench_pseudo.py quotes its rate in: hflip-TTA inference + postprocess / NMS + pred2label against the fp32 oracle.  Scores
     near a threshold may cross it under 16-bit rounding: per frame the keep count may drift by max(2, 10 %); every HIP box must have
@@ -483,7 +502,7 @@ def test_pseudo_label_inference_bf16_vs_oracle(gpu, manifest):
     drift allowance."""
     from leod_amd.engine import PseudoLabelEngine
     ev = synth_events(4, 2, 20, 60, 90, seed=3, as_uint8=True)
-    with precision('bf16'):
+    with precision(mode16):
         det, sd = te.micro_detector(manifest, 5)
         pl = PseudoLabelEngine(det, 2, conf_thre=0.01, obj_thresh=[0.1, 0.05], cls_thresh=[0.1, 0.05], hflip=True, max_det=126)
         lab, lcnt, dets, cnt = pl.step(ev.to(DEV))
