@@ -280,6 +280,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-plan', action='store_true', help='eager Python launches for every step (LEOD_PLAN=0): no launch plans')
+    ap.add_argument('--vary-labels', default='', metavar='LO:HI', help='draw the labelled frames of every step at random: B\' ~ U{LO..HI} distinct '
+                    '(t, b) positions per step (the reference\'s loaders deliver a data-dependent number of labelled frames per step, '
+                    'modules/detection.py:209-224); default: the fixed frames t in {4, 9, 14, 19} of every sequence (B\' = 32).  NOT the BASELINE '
+                    'headline workload: reported with config.vary_labels set and the plan cache\'s hit rate')
     ap.add_argument('--dump-calls', default='', help='file for the per-launch table (C entry point, shape arguments, us) of the probe steps')
     ap.add_argument('--pseudo', action='store_true', help='the pseudo-label inference pass of BASELINE configs[4] (single-GPU leg) instead of '
                     'the training step: PseudoLabeler.predict_step, --batch source streams + hflip TTA, --seq-len frames per chunk')
@@ -339,15 +343,27 @@ def main():
                 m[:B // 2] = torch.rand(B // 2, generator=g) < 0.05
             return m.to(dev)
 
+        vary = tuple(int(v) for v in args.vary_labels.split(':')) if args.vary_labels else None
+        vrng = np.random.RandomState(4242 + rank)
+        if vary:                                              # a pool of label sets to draw from: one per possible labelled frame of a step
+            prng = np.random.RandomState(2000 + rank)
+            while len(lab8) < vary[1]:
+                lab8.append(lab8[prng.randint(0, len(lab8))].copy())
+
         def loader_batch(mask):
             """The dictionary the reference's loaders emit (modules/data/genx.py:120-144): a list of L frame tensors [B,20,H,W]
             (uint8, device-resident: consecutive views of one buffer), L SparselyBatchedObjectLabels built from host arrays on
             every step, the is_first_sample flags, the worker id that keys the LSTM state."""
+            tb = label_tb
+            if vary:                                          # this step's labelled frames: B' ~ U{lo..hi} distinct (t, b) positions
+                n = int(vrng.randint(vary[0], vary[1] + 1))
+                pos = sorted(vrng.choice(T * B, size=n, replace=False).tolist())
+                tb = [[p % B for p in pos if p // B == t] for t in range(T)]
             it = iter(lab8)
             seq = []
             for t in range(T):
                 row = [None] * B
-                for b in label_tb[t]:
+                for b in tb[t]:
                     row[b] = ObjectLabels(torch.from_numpy(next(it).copy()), hw)
                 seq.append(SparselyBatchedObjectLabels(row))
             return {WORKER_ID_KEY: 0, DATA_KEY: {DataType.EV_REPR: [ev[t] for t in range(T)], DataType.OBJLABELS_SEQ: seq,
@@ -370,12 +386,14 @@ def main():
         for s in range(args.warmup):
             run(first_mask(s))
         masks = [first_mask(1 + args.warmup + s) for s in range(args.steps)]
+        pl0 = (module._plans.steps, module._plans.replays, module._plans.eager_steps, module._plans.captures, module._plans.head_captures)
         barrier()
         t0 = time.perf_counter()
         for s in range(args.steps):
             out = run(masks[s])
         barrier()
         dt = time.perf_counter() - t0
+        pl_t = (module._plans.steps, module._plans.replays, module._plans.eager_steps, module._plans.captures, module._plans.head_captures)
         t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
         if dist.is_initialized():
             dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
@@ -393,11 +411,13 @@ def main():
             step_no[0] += 1
         torch.cuda.synchronize()
         host_ms = sorted(host_ms)[len(host_ms) // 2]
-        plans = [e for e in module._plans.entries.values() if not isinstance(e, str)]
-        plan_info = None
-        if plans and module.plan_mode:
-            e = plans[-1]
-            plan_info = {'forward': e.fwd.info(), 'backward': e.bwd.info(), 'captures': module._plans.captures, 'replays': module._plans.replays}
+        plan_info = module._plans.info() if module.plan_mode else None
+        if plan_info is not None:
+            # the plan cache over the TIMED steps alone (warm-up and the probe steps excluded)
+            pl = module._plans
+            plan_info['timed_region'] = {'planned_steps': pl_t[0] - pl0[0], 'replays': pl_t[1] - pl0[1], 'eager_steps': pl_t[2] - pl0[2],
+                                         'backbone_captures': pl_t[3] - pl0[3], 'head_captures': pl_t[4] - pl0[4],
+                                         'plan_hit_rate': round((pl_t[1] - pl0[1]) / max(args.steps, 1), 4)}
         # roofline of the dominant kernel: two extra steps with HIP events around each of its launches
         roofline = roofline_gemm = family_ms = probe = family_all = None
         if not args.no_roofline:
@@ -456,9 +476,10 @@ def main():
             'value': round(fps, 2), 'unit': 'event-frames/s (whole job)', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1000 * dt / args.steps, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE_NAME[args.dtype], 'precision_mode': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'RVT-{args.size} {args.dataset} {hw[0]}x{hw[1]} (pad {in_hw[0]}x{in_hw[1]}) T={T} bs={B}/GPU fully-supervised train step, '
-                                   f'{len(label_ts)} labelled frames/sequence, random-init weights',
+            'config': {'workload': f'RVT-{args.size} {args.dataset} {hw[0]}x{hw[1]} (pad {in_hw[0]}x{in_hw[1]}) T={T} bs={B}/GPU fully-supervised train step, ' +
+                                   (f'{len(label_ts)} labelled frames/sequence' if not args.vary_labels else f'labelled frames drawn per step, B\' ~ U{{{args.vary_labels}}}') + ', random-init weights',
                        'global_batch': world * B, 'seq_len': T, 'parallelism': f'dp{world}',
+                       'vary_labels': args.vary_labels or None,
                        'driver': 'fetch_model_module(cfg) -> Module.training_step + FlatAdamW.step + OneCycleLR.step (leod_amd.optim.fit_step)',
                        'launch': launch,
                        'precision': {'16f': 'mode 16f: fp16 MFMA operands and fp16 activation rows in the forward contractions (GEMM / conv / attention / ConvLSTM / '

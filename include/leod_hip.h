@@ -335,6 +335,11 @@ int leod_linear_dgrad_lnbwd(const float* dy, const float* W, const float* x, con
  * put them in and run on lane 1 from the start of the plan (LEOD_PLAN_HOIST=0: left where they were captured).
  * leod_plan_info: info[8] = kernels, memsets, memcpys, empty nodes, lanes, events, cross-lane waits, ops. */
 long leod_plan_create(void* hip_graph, int max_lanes);
+/* Address ranges (start address as a long, length in bytes; n of them, copied) of PERSISTENT weight-pack buffers.  leod_plan_create moves a
+ * weight-pack kernel (conv3_pack_kernel / lstm_pack_kernel) to the start of the plan -- dropping the stream-order edges of its capture --
+ * only when the buffer it writes lies inside one of these ranges: a pack into a temporary of the captured step keeps its captured order
+ * (that temporary may share its address with another temporary of the same capture). */
+int leod_plan_set_hoist_ranges(const long* starts, const long* bytes, int n);
 int leod_plan_launch(long plan, leod_stream_t stream);
 int leod_plan_info(long plan, int* info);
 int leod_plan_destroy(long plan);

@@ -75,6 +75,26 @@ void free_plan(Plan* p) {
 
 LEOD_API const char* leod_plan_last_error() { return g_err.c_str(); }
 
+// persistent weight-pack buffers (see the header): a pack kernel's destination is its SECOND argument (conv3_pack_kernel(w, out, ..),
+// lstm_pack_kernel(W, wpf, wpb, ..): one buffer, wpf first)
+namespace {
+std::vector<std::pair<uintptr_t, uintptr_t>> g_hoist_ranges;
+bool pack_dest_persistent(const hipKernelNodeParams& kp) {
+    if (!kp.kernelParams || !kp.kernelParams[1]) return false;
+    const uintptr_t dst = reinterpret_cast<uintptr_t>(*reinterpret_cast<void* const*>(kp.kernelParams[1]));
+    for (const auto& r : g_hoist_ranges)
+        if (dst >= r.first && dst < r.first + r.second) return true;
+    return false;
+}
+}  // namespace
+LEOD_API int leod_plan_set_hoist_ranges(const long* starts, const long* bytes, int n) {
+    if (n < 0 || (n > 0 && (!starts || !bytes))) return LEOD_ERR_ARG;
+    g_hoist_ranges.clear();
+    for (int k = 0; k < n; ++k)
+        if (bytes[k] > 0) g_hoist_ranges.emplace_back((uintptr_t)starts[k], (uintptr_t)bytes[k]);
+    return LEOD_OK;
+}
+
 // hip_graph: hipGraph_t of a finished stream capture.  max_lanes: streams the plan may use (1 = everything on the caller's
 // stream in a topological order).  Returns a handle > 0, or LEOD_ERR_ARG / LEOD_ERR_UNSUPPORTED (leod_plan_last_error() says why).
 LEOD_API long leod_plan_create(void* hip_graph, int max_lanes) {
@@ -163,7 +183,7 @@ LEOD_API long leod_plan_create(void* hip_graph, int max_lanes) {
         for (size_t i = 0; i < n; ++i) {
             if (ops[i].type != OP_KERNEL) continue;
             const char* nm = hipKernelNameRefByPtr(ops[i].kp.func, nullptr);
-            if (nm && (strstr(nm, "conv3_pack_kernel") || strstr(nm, "lstm_pack_kernel"))) hs.push_back((int)i);
+            if (nm && (strstr(nm, "conv3_pack_kernel") || strstr(nm, "lstm_pack_kernel")) && pack_dest_persistent(ops[i].kp)) hs.push_back((int)i);
         }
         auto erase = [](std::vector<int>& v, int x) { v.erase(std::remove(v.begin(), v.end(), x), v.end()); };
         auto add_edge = [&](int a, int b) {

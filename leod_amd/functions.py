@@ -139,6 +139,28 @@ class ForkSelectFn(Function):
         return dx, None
 
 
+class ForkInjectFn(Function):
+    """ForkSelectFn for a step whose backbone and head are recorded as SEPARATE launch plans (modules/step_plan.py): the forward pass only
+    exposes the stage output (``holder.x_out[stage]``, which the head plan gathers the labelled frames from) and hands out a token tensor;
+    the backward pass -- started from the tokens -- adds the gradient of the gathered rows, which the head plan left in the static buffer
+    ``holder.gsel[stage]``, into the gradient arriving from the next stage through the static row-index buffer ``holder.rows`` (frame
+    indices, -1 beyond the step's labelled-frame count: skipped by the kernel).  Nothing here depends on how many frames are labelled."""
+
+    @staticmethod
+    def forward(ctx, x, holder, stage):
+        ctx.set_materialize_grads(False)
+        ctx.holder, ctx.stage, ctx.shape = holder, stage, tuple(x.shape)
+        holder.x_out[stage] = x.detach()
+        return x.view_as(x), x.new_empty(1)
+
+    @staticmethod
+    def backward(ctx, g_pass, g_tok):
+        h = ctx.holder
+        dx = torch.zeros(ctx.shape, dtype=torch.float32, device=h.rows.device) if g_pass is None else _cont(g_pass)
+        ops.rows_index_add(dx, h.gsel[ctx.stage], h.rows)
+        return dx, None, None
+
+
 def fork_select(x_nchw: torch.Tensor, idx: torch.Tensor):
     """x [N,C,H,W] (channels-last memory) -> (x for the next consumer, x[idx]), both logical NCHW views of NHWC memory."""
     xp, xs = ForkSelectFn.apply(to_nhwc(x_nchw), idx)

@@ -65,6 +65,13 @@ class RNNDetectorStage(nn.Module):
         return self.lstm.forward_sequence(nhwC_2_nChw(x), T, h_and_c_previous)
 
 
+def _ensure_shadows():
+    """16-bit weight shadows of flat parameter buffers (leod_amd.parallel.FlatParams) follow in-place edits of the weights on EVERY forward
+    entry point, not only on the ones that go through Module._run_sequence"""
+    from leod_amd.parallel import FlatParams
+    FlatParams.ensure_all_shadows()
+
+
 class RNNDetector(BaseDetector):
     def __init__(self, mdl_config):
         super().__init__()
@@ -108,6 +115,7 @@ class RNNDetector(BaseDetector):
         if prev_states is None:
             prev_states = [None] * self.num_stages
         assert len(prev_states) == self.num_stages
+        _ensure_shadows()
         padded_hw = self.in_res_hw if (self.in_res_hw is not None and tuple(x.shape[-2:]) != self.in_res_hw) else None
         states, output = [], {}
         for i, stage in enumerate(self.stages):
@@ -116,7 +124,7 @@ class RNNDetector(BaseDetector):
             output[i + 1] = x
         return output, states
 
-    def forward_sequence(self, x_seq: th.Tensor, prev_states=None, select_rows: Optional[th.Tensor] = None, select_stages=()):
+    def forward_sequence(self, x_seq: th.Tensor, prev_states=None, select_rows: Optional[th.Tensor] = None, select_stages=(), inject=None):
         """x_seq [T,B,C,H,W]: stage-major, time-batched evaluation of a whole sequence (see
         ``RNNDetectorStage.forward_sequence``).  Returns {stage: features of all timesteps [T*B,C,h,w]} and the final
         states -- the per-timestep loop of modules/detection.py:188-226 with the loops interchanged.
@@ -124,6 +132,7 @@ class RNNDetector(BaseDetector):
         those frames} (what ``BackboneFeatureSelector`` gathers, modules/utils/detection.py:27-58), selected inside the stage loop so
         that the two consumers of a stage output share one autograd node (``functions.ForkSelectFn``)."""
         T, B = x_seq.shape[:2]
+        _ensure_shadows()
         if prev_states is None:
             prev_states = [None] * self.num_stages
         padded_hw = self.in_res_hw if (self.in_res_hw is not None and tuple(x_seq.shape[-2:]) != self.in_res_hw) else None
@@ -137,7 +146,11 @@ class RNNDetector(BaseDetector):
                 x = bucket_boundary(i, x)
             x, state = stage.forward_sequence(x, T, prev_states[i], padded_hw if i == 0 else None)
             states.append(state)
-            if select_rows is not None and (i + 1) in select_stages:
+            if inject is not None and (i + 1) in select_stages:
+                # a step recorded as separate backbone / head launch plans (modules/step_plan.py): the stage output is exposed to the head plan
+                # and the labelled frames' gradient comes back through static buffers of ``inject``
+                x = inject.fork(i + 1, x)
+            elif select_rows is not None and (i + 1) in select_stages:
                 x, selected[i + 1] = fork_select(x, select_rows)
             output[i + 1] = x
         return (output, states) if select_rows is None else (output, states, selected)

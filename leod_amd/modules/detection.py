@@ -260,7 +260,7 @@ class Module(_Base):
     def _training_step_planned(self, data, worker_id: int, ign, log: bool):
         """The same step through a launch plan (modules/step_plan.py), or None when this batch has to run eagerly: the first
         occurrence of its geometry, host-resident frames, no labelled frame, or a geometry whose capture failed."""
-        from .step_plan import PlanLossFn, StepPlan, LOSS_KEYS
+        from .step_plan import PlanLossFn, BackbonePlan, LOSS_KEYS
         ev_seq = data[DataType.EV_REPR]
         labels_seq = data[DataType.OBJLABELS_SEQ]
         is_first = data[DataType.IS_FIRST_SAMPLE]
@@ -274,9 +274,11 @@ class Module(_Base):
             return None
         ev = self._stack_frames(ev_seq)
         labels_yolox = ObjectLabels.get_labels_as_batched_tensor(obj_label_list=obj_labels, format_='yolox').to(th.float32)
-        key, nmax_pad = self._plans.key_of(ev, len(where), labels_yolox.shape[1])
-        hit = self._plans.lookup(key)
+        plans = self._plans
+        key = plans.key_of(ev)
+        hit = plans.lookup(key)
         if hit is None:
+            plans.eager_steps += 1
             return None
         mode = Mode.TRAIN
         hw = tuple(ev.shape[-2:])
@@ -284,25 +286,42 @@ class Module(_Base):
             return None                                  # the eager step records them (reference asserts, detection.py:176-179,196-199)
         assert self.mode_2_batch_size[mode] == B and self.mode_2_hw[mode] == hw
         rnn = self.mode_2_rnn_states[mode]
+        fresh = False                                    # a plan of this step was captured in this very call
         if hit == 'capture':
             like = rnn.get_states(worker_id) or next(iter(rnn.states.values()), None)
             if like is None:
                 return None
-            hit = self._plans.build(key, self, ev, len(where), nmax_pad, like, self.wgrad_side)
+            hit = plans.build(key, self, ev, like, self.wgrad_side)
             if hit is None:
+                plans.eager_steps += 1
                 return None
-        entry: StepPlan = hit
+            fresh = True
+        bb: BackbonePlan = hit
+        # the data-dependent part: PAFPN + head for THIS labelled-frame count (captured the first time the count is seen; nothing has been
+        # executed yet, so a failed capture simply leaves the step to the eager path)
+        hkey, nmax_pad = plans.head_key_of(len(where), labels_yolox.shape[1])
+        hd = bb.head(hkey)
+        if hd is None:
+            hd = plans.build_head(bb, hkey, self, len(where), nmax_pad, self.wgrad_side)
+            fresh = True
+        if hd is None or hd == 'eager':
+            plans.eager_steps += 1
+            return None
         self.started_training = True
-        rows = self._row_index(tuple(t * B + b for t, b in where), ev.device)
-        entry.load_states(rnn, worker_id)
-        entry.stage_inputs(ev, labels_yolox, rows, is_first)
-        entry.run_forward()
-        rnn.save_states_and_detach(worker_id=worker_id, states=entry.states)
-        self._plans.replays += 1
-        if self._plans.anchor is None or self._plans.anchor.device != ev.device:
-            self._plans.anchor = th.zeros(1, device=ev.device, requires_grad=True)
+        rows_host = tuple(t * B + b for t, b in where)
+        bb.load_states(rnn, worker_id)
+        bb.stage_inputs(ev, rows_host, self._row_index(rows_host + (-1,) * (bb.n_max - len(rows_host)), ev.device), is_first)
+        hd.stage_labels(labels_yolox)
+        bb.run_forward()
+        hd.run_forward()
+        rnn.save_states_and_detach(worker_id=worker_id, states=bb.states)
+        plans.steps += 1
+        plans.replays += 0 if fresh else 1
+        if plans.anchor is None or plans.anchor.device != ev.device:
+            plans.anchor = th.zeros(1, device=ev.device, requires_grad=True)
+        entry = hd
         out6 = entry.losses6.clone()                     # the static loss buffer is overwritten by the next replay
-        loss = PlanLossFn.apply(entry, self._plans.anchor, out6[0])
+        loss = PlanLossFn.apply(bb, hd, plans.anchor, out6[0])
         losses = {k: out6[i] for i, k in enumerate(LOSS_KEYS)}
         losses['loss'] = loss
         output = {'loss': loss, 'log_dict': {f'{mode_2_string[Mode.TRAIN]}/{k}': v for k, v in losses.items()}}

@@ -102,76 +102,76 @@ class PlanRecorder:
 
 
 class PlanLossFn(Function):
-    """The loss of a replayed step as an autograd leaf-to-loss edge: ``forward`` has already happened (the forward plan), ``backward``
-    hands the seed gradient to the captured backward pass and launches the backward plan.  Parameter gradients land in the flat
-    gradient buffer as in the eager step (the captured weight-gradient kernels accumulate into the same addresses)."""
+    """The loss of a replayed step as an autograd leaf-to-loss edge: ``forward`` has already happened (the forward plans), ``backward``
+    hands the seed gradient to the captured backward passes and launches them.  Parameter gradients land in the flat gradient buffer as
+    in the eager step (the captured weight-gradient kernels accumulate into the same addresses).  The plans hold ONE step's activations:
+    a second forward of the same geometry before this backward (two losses summed, ``retain_graph`` replays) would differentiate the first
+    loss with the second step's activations -- refused loudly."""
 
     @staticmethod
-    def forward(ctx, entry, anchor, loss):
-        ctx.entry = entry
+    def forward(ctx, bb, hd, anchor, loss):
+        ctx.bb, ctx.hd, ctx.gen = bb, hd, bb.uses
         return loss.view_as(loss)
 
     @staticmethod
     def backward(ctx, g):
-        ctx.entry.run_backward(g)
-        return None, None, None
+        bb, hd = ctx.bb, ctx.hd
+        if bb.uses != ctx.gen or bb.consumed == ctx.gen or hd.fwd is None or bb.fwd is None:
+            raise RuntimeError('leod_amd launch plans: backward() of a planned training step whose activations are gone (another '
+                               'training_step of the same geometry ran before this backward, backward ran twice, or the plan was evicted); '
+                               'run such steps with Module.plan_mode = False')
+        bb.consumed = ctx.gen
+        hd.run_backward(g)
+        bb.run_backward()
+        return None, None, None, None
 
 
-class StepPlan:
-    """One captured step geometry: static inputs / states / outputs, the two launch plans and the bookkeeping a replay owes the module."""
+class HeadPlan:
+    """PAFPN + head + SimOTA + losses and their backward for ONE labelled-frame count B' (and padded label width): the data-dependent part
+    of the step (modules/detection.py:209-224 -- the reference gathers the labelled frames' features per step; its static-shape unit is
+    the backbone, config/model/maxvit_yolox/default.yaml:8-11).  Reads the backbone plan's static stage outputs through the static row-index
+    buffer, writes the gradient of the gathered rows into the backbone plan's static gradient slots.  Cheap to hold (one small private
+    pool shared by all head plans of a backbone plan; they never run concurrently and keep nothing across steps)."""
 
-    def __init__(self, key, module, ev: th.Tensor, n_frames: int, nmax: int, states_like):
-        dev = ev.device
-        self.key = key
-        self.ev = th.empty_like(ev)
+    def __init__(self, bb: 'BackbonePlan', n_frames: int, nmax: int):
+        dev = bb.ev.device
+        self.bb, self.n_frames = bb, n_frames
         self.labels = th.zeros((n_frames, nmax, 7), dtype=th.float32, device=dev)
-        self.rows = th.zeros((n_frames,), dtype=th.long, device=dev)
-        self.is_first = th.ones((ev.shape[1],), dtype=th.bool, device=dev)
         self.seed = th.ones((), dtype=th.float32, device=dev)
-        self.states = [(th.zeros_like(h), th.zeros_like(c)) for h, c in states_like]      # strides preserved (NCHW views of NHWC rows)
-        self.arena = th.zeros(ops.StatArena.SIZE, dtype=th.uint8, device=dev)             # private scratch arena of this plan
         self.arena_high = 0
         self.bn_incs: List[Tuple[Any, int]] = []
         self.losses6: Optional[th.Tensor] = None
         self.fwd: Optional['PlanRecorder'] = None
         self.bwd: Optional['PlanRecorder'] = None
-        self.owner = None                      # worker id whose LSTM state currently lives in ``self.states``
         self.pin: Optional[th.Tensor] = None
         self.pin_event = None
-        self.uses = 0
 
-    # ---- capture ------------------------------------------------------------------------------------------------------------
     def capture(self, module, wgrad_side: bool, max_lanes: int):
-        mdl = module.mdl
+        bb, mdl = self.bb, module.mdl
         in_features = tuple(mdl.fpn.in_features)
         mods = [m for m in mdl.modules() if hasattr(m, 'bn_calls_pending')]
         pending0 = [m.bn_calls_pending for m in mods]
-        saved_arena = ops.StatArena.swap(self.arena)
+        saved_arena = ops.StatArena.swap(bb.head_arena)
         from leod_amd.parallel import GradBuckets
         saved_buckets = GradBuckets.current
         saved_side = Fn.WgradSide.active
-        ops.PackCache.invalidate()                         # the capture must contain the weight packs of a step
-        flat = getattr(module, '_flat', None)              # FlatParams of configure_optimizers: the recorded step starts by refreshing
-        if flat is not None:                               # its bf16 weight shadow, and the recorded GEMMs read it
-            ops.weight_shadow_pin(True)
-        capture_stream = th.cuda.Stream(device=self.ev.device)
+        ops.PackCache.invalidate()                         # the capture must contain the weight packs of the head
+        capture_stream = th.cuda.Stream(device=bb.ev.device)
         capture_stream.wait_stream(th.cuda.current_stream())
         th.cuda.synchronize()
-        fwd = PlanRecorder(max_lanes)
+        fwd = PlanRecorder(max_lanes, pool=bb.head_pool)
         bwd = None
         try:
             with th.enable_grad(), th.cuda.stream(capture_stream):
                 PlanRecorder.current = fwd
-                GradBuckets.current = saved_buckets           # boundary nodes reach the buckets through PlanRecorder.split
+                GradBuckets.current = saved_buckets
                 fwd.begin()
-                if flat is not None:
-                    flat.ensure_shadow(force=True)
-                ops.StatArena.begin_step(self.ev.device)
-                ops.rows_masked_zero(_flat(self.states), self.is_first)                       # RNNStates.reset (detection.py:95-157)
-                _, new_states, feats = mdl.backbone.forward_sequence(self.ev, self.states, select_rows=self.rows, select_stages=in_features)
-                _, losses = mdl.forward_detect(backbone_features=feats, targets=self.labels)
+                bb.head_pool = fwd.pool
+                ops.StatArena.begin_step(bb.ev.device)
+                rows = bb.rows[:self.n_frames]
+                sel = {k: bb.x_out[k].index_select(0, rows).requires_grad_() for k in in_features}
+                _, losses = mdl.forward_detect(backbone_features={k: Fn.as_nchw(v) for k, v in sel.items()}, targets=self.labels)
                 self.losses6 = mdl.yolox_head.last_losses6
-                ops.copy_multi(_flat(self.states), [t.detach() for t in _flat(new_states)])      # state hand-over to the next step
                 fwd.end()
                 bwd = PlanRecorder(max_lanes, pool=fwd.pool)
                 PlanRecorder.current = bwd
@@ -181,24 +181,16 @@ class StepPlan:
                     losses['loss'].backward(gradient=self.seed)
                 finally:
                     Fn.WgradSide.active = False
+                # the gradient of the gathered rows -> the backbone plan's static slots (first B' frames; its backward adds them into the stage
+                # outputs' gradients through the static row-index buffer)
+                ops.copy_multi([bb.gsel[k][:self.n_frames] for k in in_features], [sel[k].grad for k in in_features])
                 bwd.end()
             self.arena_high = ops.StatArena.high
             self.fwd, self.bwd = fwd, bwd
         except BaseException:
-            with th.cuda.stream(capture_stream):              # leave no stream in capture mode behind (a capturing graph aborts in its destructor)
-                for rec in (fwd, bwd):
-                    if rec is not None and rec.graph is not None:
-                        try:
-                            Fn.WgradSide.join()
-                            rec.graph.capture_end()
-                        except Exception:                     # noqa: BLE001
-                            pass
-                    if rec is not None:
-                        rec.close()
+            _abort_captures(capture_stream, fwd, bwd)
             raise
         finally:
-            if flat is not None:
-                ops.weight_shadow_pin(False)
             PlanRecorder.current = None
             th.cuda.current_stream().wait_stream(capture_stream)
             ops.StatArena.swap(*saved_arena)
@@ -210,10 +202,7 @@ class StepPlan:
                 m.bn_calls_pending = p0
         return self
 
-    # ---- replay -------------------------------------------------------------------------------------------------------------
-    def stage_inputs(self, ev: th.Tensor, labels_host_or_dev: th.Tensor, rows: th.Tensor, is_first: th.Tensor):
-        if ev.data_ptr() != self.ev.data_ptr():
-            self.ev.copy_(ev, non_blocking=True)
+    def stage_labels(self, labels_host_or_dev: th.Tensor):
         n, nmax = labels_host_or_dev.shape[0], labels_host_or_dev.shape[1]
         if labels_host_or_dev.is_cuda:
             if nmax != self.labels.shape[1]:
@@ -231,7 +220,142 @@ class StepPlan:
             self.labels.copy_(self.pin, non_blocking=True)
             self.pin_event = th.cuda.Event()
             self.pin_event.record()
-        self.rows.copy_(rows, non_blocking=True)
+
+    def run_forward(self):
+        if self.arena_high:
+            self.bb.head_arena[:self.arena_high].zero_()   # BatchNorm statistic accumulators of the captured head pass
+        self.fwd.replay()
+        for m, inc in self.bn_incs:
+            m.bn_calls_pending += inc
+
+    def run_backward(self, g: th.Tensor):
+        self.seed.copy_(g.reshape(()), non_blocking=True)
+        self.bwd.replay()
+
+    def close(self):
+        for p in (self.fwd, self.bwd):
+            if p is not None:
+                p.close()
+        self.fwd = self.bwd = None
+
+
+def _abort_captures(capture_stream, *recs):
+    with th.cuda.stream(capture_stream):                  # leave no stream in capture mode behind (a capturing graph aborts in its destructor)
+        for rec in recs:
+            if rec is not None and rec.graph is not None:
+                try:
+                    Fn.WgradSide.join()
+                    rec.graph.capture_end()
+                except Exception:                             # noqa: BLE001
+                    pass
+            if rec is not None:
+                rec.close()
+
+
+class BackbonePlan:
+    """The static-shape unit of the step, keyed by the event tensor's shape alone (the reference's unit too: ``torch.compile`` of the
+    backbone, shapes asserted at modules/detection.py:176-179,196-199): LSTM-row reset + stage-major backbone over the L frames, and its
+    backward pass.  The data-dependent part -- which frames carry labels, how many -- enters through two static buffers: ``rows`` (frame
+    indices t * B + b of the labelled frames, padded with -1 to T * B entries) read by the head plans' gathers and by this plan's backward
+    (``ops.rows_index_add`` skips negative indices), and ``gsel`` (the gradient of the gathered rows per PAFPN input stage, written by the
+    head plan's backward).  One captured backbone serves every step of its geometry, whatever B' is."""
+
+    def __init__(self, key, module, ev: th.Tensor, states_like):
+        dev = ev.device
+        self.key = key
+        self.ev = th.empty_like(ev)
+        self.n_max = int(ev.shape[0] * ev.shape[1])
+        self.rows = th.full((self.n_max,), -1, dtype=th.long, device=dev)
+        self.is_first = th.ones((ev.shape[1],), dtype=th.bool, device=dev)
+        self.states = [(th.zeros_like(h), th.zeros_like(c)) for h, c in states_like]      # strides preserved (NCHW views of NHWC rows)
+        self.arena = th.zeros(ops.StatArena.SIZE, dtype=th.uint8, device=dev)             # private scratch arena of this plan
+        self.head_arena = th.zeros(ops.StatArena.SIZE, dtype=th.uint8, device=dev)        # ... and of its head plans (one runs at a time)
+        self.head_pool = None
+        self.arena_high = 0
+        self.x_out: Dict[int, th.Tensor] = {}              # stage -> its output rows [T*B, H, W, C] inside this plan's pool (static)
+        self.gsel: Dict[int, th.Tensor] = {}               # stage -> gradient of the gathered rows (first B' frames live)
+        self.tokens: List[th.Tensor] = []
+        self.fwd: Optional['PlanRecorder'] = None
+        self.bwd: Optional['PlanRecorder'] = None
+        self.heads: Dict[Any, HeadPlan] = {}
+        self.max_heads = int(os.environ.get('LEOD_PLAN_MAX_HEADS', '64'))
+        self.owner = None                      # worker id whose LSTM state currently lives in ``self.states``
+        self.uses = 0
+        self.consumed = -1
+        self.rows_host: Optional[tuple] = None
+
+    # called from RNNDetector.forward_sequence at every PAFPN input stage while the plan is being recorded
+    def fork(self, stage: int, x_nchw: th.Tensor) -> th.Tensor:
+        xp, tok = Fn.ForkInjectFn.apply(Fn.to_nhwc(x_nchw), self, stage)
+        self.tokens.append(tok)
+        return Fn.as_nchw(xp)
+
+    def capture(self, module, wgrad_side: bool, max_lanes: int):
+        mdl = module.mdl
+        in_features = tuple(mdl.fpn.in_features)
+        saved_arena = ops.StatArena.swap(self.arena)
+        from leod_amd.parallel import GradBuckets
+        saved_buckets = GradBuckets.current
+        saved_side = Fn.WgradSide.active
+        ops.PackCache.invalidate()                         # the capture must contain the weight packs of a step
+        flat = getattr(module, '_flat', None)              # FlatParams of configure_optimizers: the recorded step starts by refreshing
+        if flat is not None:                               # its 16-bit weight shadows, and the recorded GEMMs read them
+            ops.weight_shadow_pin(True)
+        capture_stream = th.cuda.Stream(device=self.ev.device)
+        capture_stream.wait_stream(th.cuda.current_stream())
+        th.cuda.synchronize()
+        fwd = PlanRecorder(max_lanes)
+        bwd = None
+        try:
+            with th.enable_grad(), th.cuda.stream(capture_stream):
+                PlanRecorder.current = fwd
+                GradBuckets.current = saved_buckets           # boundary nodes reach the buckets through PlanRecorder.split
+                fwd.begin()
+                if flat is not None:
+                    flat.ensure_shadow(force=True)
+                ops.StatArena.begin_step(self.ev.device)
+                ops.rows_masked_zero(_flat(self.states), self.is_first)                       # RNNStates.reset (detection.py:95-157)
+                self.tokens = []
+                _, new_states = mdl.backbone.forward_sequence(self.ev, self.states, select_stages=in_features, inject=self)
+                ops.copy_multi(_flat(self.states), [t.detach() for t in _flat(new_states)])      # state hand-over to the next step
+                fwd.end()
+                if set(self.x_out) != set(in_features):
+                    raise LeodHipError('backbone plan: the stage outputs the PAFPN reads were not exposed by forward_sequence')
+                for k in in_features:                          # static gradient slots (no capture is in progress here: ordinary memory)
+                    self.gsel[k] = th.zeros(self.x_out[k].shape, dtype=th.float32, device=self.ev.device)
+                bwd = PlanRecorder(max_lanes, pool=fwd.pool)
+                PlanRecorder.current = bwd
+                bwd.begin()
+                Fn.WgradSide.active = wgrad_side
+                try:
+                    th.autograd.backward(self.tokens, [th.ones_like(t) for t in self.tokens])
+                finally:
+                    Fn.WgradSide.active = False
+                bwd.end()
+            self.tokens = []
+            self.arena_high = ops.StatArena.high
+            self.fwd, self.bwd = fwd, bwd
+        except BaseException:
+            _abort_captures(capture_stream, fwd, bwd)
+            raise
+        finally:
+            if flat is not None:
+                ops.weight_shadow_pin(False)
+            PlanRecorder.current = None
+            th.cuda.current_stream().wait_stream(capture_stream)
+            ops.StatArena.swap(*saved_arena)
+            GradBuckets.current = saved_buckets
+            Fn.WgradSide.active = saved_side
+            ops.PackCache.invalidate()                     # nothing was executed: the pack buffers do not hold what the cache believes
+        return self
+
+    # ---- replay -------------------------------------------------------------------------------------------------------------
+    def stage_inputs(self, ev: th.Tensor, rows_host: tuple, rows_dev_padded: th.Tensor, is_first: th.Tensor):
+        if ev.data_ptr() != self.ev.data_ptr():
+            self.ev.copy_(ev, non_blocking=True)
+        if rows_host != self.rows_host:                    # the labelled frames moved: one small copy (frame indices, -1 beyond B')
+            self.rows.copy_(rows_dev_padded, non_blocking=True)
+            self.rows_host = rows_host
         self.is_first.copy_(is_first, non_blocking=True)
 
     def load_states(self, rnn, worker_id):
@@ -257,18 +381,33 @@ class StepPlan:
 
     def run_forward(self):
         if self.arena_high:
-            self.arena[:self.arena_high].zero_()           # BatchNorm statistic accumulators / LayerScale scratch of the captured step
+            self.arena[:self.arena_high].zero_()           # LayerScale scratch of the captured backward pass
         self.fwd.replay()
-        for m, inc in self.bn_incs:
-            m.bn_calls_pending += inc
         self.uses += 1
 
-    def run_backward(self, g: th.Tensor):
-        self.seed.copy_(g.reshape(()), non_blocking=True)
+    def run_backward(self):
         self.bwd.replay()
-        ops.PackCache.invalidate()                         # the replayed step re-packed conv weights behind the cache's back
+        ops.PackCache.invalidate()                         # the replayed step re-packed conv / LSTM weights behind the cache's back
+
+    def head(self, key):
+        """-> HeadPlan | 'eager' (its capture failed before) | None"""
+        h = self.heads.get(key)
+        if h is not None:
+            self.heads[key] = self.heads.pop(key)          # most recently used last
+        return h
+
+    def add_head(self, key, h):
+        while len(self.heads) >= self.max_heads:
+            old = self.heads.pop(next(iter(self.heads)))
+            if isinstance(old, HeadPlan):
+                old.close()
+        self.heads[key] = h
 
     def close(self):
+        for h in self.heads.values():
+            if isinstance(h, HeadPlan):
+                h.close()
+        self.heads.clear()
         for p in (self.fwd, self.bwd):
             if p is not None:
                 p.close()
@@ -276,8 +415,12 @@ class StepPlan:
 
 
 class TrainStepPlans:
-    """Per-module cache {geometry key: StepPlan | 'seen' | 'eager'} with a small LRU bound (each plan owns the activation pool of its
-    step: ~13 GB for RVT-S bs 8 L 21 of the 288 GB)."""
+    """Per-module cache of launch plans.  {event-tensor geometry: BackbonePlan | 'seen' | 'eager'} with a small LRU bound (each backbone
+    plan owns the activation pool of its step: ~13 GB for RVT-S bs 8 L 21 of the 288 GB); every backbone plan holds its head plans
+    {(B', padded label width): HeadPlan} (up to LEOD_PLAN_MAX_HEADS = 64, small).  A backbone geometry is captured the second time it is
+    seen (the first, eager, step is the warm-up a capture needs); a head geometry is captured the first time it is seen under a captured
+    backbone -- the labelled-frame count is data dependent and every new count would otherwise cost an eager step.  Counters:
+    ``steps`` planned-path steps, ``replays`` of them executed entirely from plans captured EARLIER, ``captures`` / ``head_captures``."""
 
     def __init__(self, max_plans: Optional[int] = None, max_lanes: Optional[int] = None):
         self.entries: Dict[Any, Any] = {}
@@ -285,7 +428,10 @@ class TrainStepPlans:
         self.max_lanes = int(os.environ.get('LEOD_PLAN_LANES', '2')) if max_lanes is None else max_lanes
         self.anchor = None
         self.captures = 0
+        self.head_captures = 0
         self.replays = 0
+        self.steps = 0
+        self.eager_steps = 0
 
     @staticmethod
     def allowed() -> bool:
@@ -295,36 +441,50 @@ class TrainStepPlans:
             return False
         return not Fn._sync_bn_on() or os.environ.get('LEOD_PLAN_DIST', '1') == '1'
 
-    def key_of(self, ev: th.Tensor, n_frames: int, nmax: int):
+    @staticmethod
+    def key_of(ev: th.Tensor):
+        return (tuple(ev.shape), ev.dtype, str(ev.device), ops.get_precision())
+
+    @staticmethod
+    def head_key_of(n_frames: int, nmax: int):
         nmax_pad = max(NMAX_PAD, -(-nmax // NMAX_PAD) * NMAX_PAD)
-        return (tuple(ev.shape), ev.dtype, str(ev.device), n_frames, nmax_pad, ops.get_precision()), nmax_pad
+        return (n_frames, nmax_pad), nmax_pad
+
+    def hit_rate(self) -> float:
+        """fraction of the training steps so far that ran entirely from previously captured plans"""
+        n = self.steps + self.eager_steps
+        return self.replays / n if n else 0.0
 
     def lookup(self, key):
-        """-> StepPlan to replay | 'capture' (second occurrence) | None (run eagerly)."""
+        """-> BackbonePlan to replay | 'capture' (second occurrence) | None (run eagerly)."""
         e = self.entries.get(key)
-        if isinstance(e, StepPlan):
+        if isinstance(e, BackbonePlan):
             self.entries[key] = self.entries.pop(key)       # most recently used last
             return e
         if e is None:
+            if len(self.entries) > 64:                      # geometries seen once and never again do not accumulate
+                for k in [k for k, v in self.entries.items() if not isinstance(v, BackbonePlan)]:
+                    del self.entries[k]
             self.entries[key] = 'seen'
             return None
         if e == 'seen':
             return 'capture'
         return None                                           # 'eager': a capture of this geometry failed before
 
-    def build(self, key, module, ev, n_frames, nmax_pad, states_like, wgrad_side) -> Optional[StepPlan]:
-        plans = [k for k, v in self.entries.items() if isinstance(v, StepPlan)]
+    def build(self, key, module, ev, states_like, wgrad_side) -> Optional[BackbonePlan]:
+        plans = [k for k, v in self.entries.items() if isinstance(v, BackbonePlan)]
         while len(plans) >= self.max_plans:
             old = plans.pop(0)
             self.entries.pop(old).close()
-        entry = StepPlan(key, module, ev, n_frames, nmax_pad, states_like)
+            self.entries[old] = 'eager'                     # an evicted geometry is not captured again (no capture / evict thrash)
+        entry = BackbonePlan(key, module, ev, states_like)
         try:
             entry.capture(module, wgrad_side, self.max_lanes)
         except (LeodHipError, RuntimeError) as e:
             if os.environ.get('LEOD_PLAN_DEBUG'):
                 import traceback
                 traceback.print_exc()
-            warnings.warn(f'leod_amd: the training step of geometry {key} could not be turned into a launch plan ({e}); it stays eager')
+            warnings.warn(f'leod_amd: the backbone of geometry {key} could not be turned into a launch plan ({e}); its steps stay eager')
             entry.close()
             self.entries[key] = 'eager'
             return None
@@ -332,8 +492,43 @@ class TrainStepPlans:
         self.captures += 1
         return entry
 
+    def build_head(self, bb: BackbonePlan, hkey, module, n_frames, nmax_pad, wgrad_side) -> Optional[HeadPlan]:
+        h = HeadPlan(bb, n_frames, nmax_pad)
+        try:
+            h.capture(module, wgrad_side, self.max_lanes)
+        except (LeodHipError, RuntimeError) as e:
+            if os.environ.get('LEOD_PLAN_DEBUG'):
+                import traceback
+                traceback.print_exc()
+            warnings.warn(f'leod_amd: the head pass for {n_frames} labelled frames could not be turned into a launch plan ({e}); such steps stay eager')
+            h.close()
+            bb.add_head(hkey, 'eager')
+            return None
+        bb.add_head(hkey, h)
+        self.head_captures += 1
+        return h
+
+    def info(self) -> Optional[Dict[str, Any]]:
+        """What the most recently used (backbone, head) plan pair launches per step, and the cache's counters."""
+        bbs = [v for v in self.entries.values() if isinstance(v, BackbonePlan)]
+        if not bbs:
+            return None
+        bb = bbs[-1]
+        hds = [h for h in bb.heads.values() if isinstance(h, HeadPlan)]
+        if not hds:
+            return None
+        hd = hds[-1]
+
+        def both(a, b):
+            return {k: (max(a[k], b[k]) if k == 'lanes' else a[k] + b[k]) for k in a}
+        return {'forward': both(bb.fwd.info(), hd.fwd.info()), 'backward': both(hd.bwd.info(), bb.bwd.info()),
+                'backbone_forward_kernels': bb.fwd.info()['kernels'], 'head_forward_kernels': hd.fwd.info()['kernels'],
+                'head_backward_kernels': hd.bwd.info()['kernels'], 'backbone_backward_kernels': bb.bwd.info()['kernels'],
+                'captures': self.captures, 'head_captures': self.head_captures, 'head_plans': len(hds), 'planned_steps': self.steps,
+                'replays': self.replays, 'eager_steps': self.eager_steps, 'plan_hit_rate': round(self.hit_rate(), 4)}
+
     def clear(self):
         for v in self.entries.values():
-            if isinstance(v, StepPlan):
+            if isinstance(v, BackbonePlan):
                 v.close()
         self.entries.clear()

@@ -345,8 +345,12 @@ def convlstm_seq_pack(W, C: int):
     if n == 0:
         return None
     _ck(W, name='W')
-    wp = torch.empty(n, dtype=torch.uint8, device=W.device)
-    check(_l().leod_convlstm_seq_pack(_p(W), _p(wp), int(C), _stream()), 'convlstm_seq_pack')
+    # a persistent buffer of the pack cache (never a temporary of the calling step: the launch plans run weight packs ahead of the captured
+    # order, which is only sound for buffers no other kernel of the step ever writes), re-packed once per optimiser step
+    buf, valid = PackCache.get(W, ('lstm', int(C)), (n + 3) // 4)
+    wp = buf.view(torch.uint8)[:n]
+    if not valid:
+        check(_l().leod_convlstm_seq_pack(_p(W), _p(wp), int(C), _stream()), 'convlstm_seq_pack')
     return wp
 
 
@@ -623,11 +627,35 @@ class PackCache:
         e = cls.entries.get(k)
         if e is not None and e[1] == ver and e[0].numel() >= nfloats:
             return e[0], 1
-        buf = e[0] if (e is not None and e[0].numel() >= nfloats and e[0].device == w.device) else torch.empty(nfloats, dtype=F32, device=w.device)
+        buf = e[0] if (e is not None and e[0].numel() >= nfloats and e[0].device == w.device) else cls._alloc(nfloats, w.device)
         if len(cls.entries) > 4096:
             cls.entries.clear()
         cls.entries[k] = (buf, ver)
         return buf, 0
+
+    _aux = {}
+
+    @classmethod
+    def _alloc(cls, nfloats, device):
+        """A pack buffer lives as long as the cache and must never come out of a stream capture's private pool: a buffer from that pool may
+        alias a temporary of the captured step, and the launch plans hoist weight packs out of their captured order (csrc/k_plan.hip).
+        While the current stream is capturing, the allocation is made on a non-capturing stream (torch's allocator then serves it from the
+        ordinary pool; the capture runs in relaxed mode)."""
+        if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            st = cls._aux.get(device)
+            if st is None:
+                st = cls._aux[device] = torch.cuda.Stream(device=device)
+            with torch.cuda.stream(st):
+                return torch.empty(nfloats, dtype=F32, device=device)
+        return torch.empty(nfloats, dtype=F32, device=device)
+
+    @classmethod
+    def ranges(cls):
+        """[(address, bytes)] of every live pack buffer (what a launch plan may hoist a weight pack into)"""
+        seen = {}
+        for buf, _ in cls.entries.values():
+            seen[buf.data_ptr()] = buf.numel() * 4
+        return sorted(seen.items())
 
     @classmethod
     def invalidate(cls):
@@ -1082,6 +1110,9 @@ class LaunchPlan:
     def __init__(self, graph: 'torch.cuda.CUDAGraph', max_lanes: int = 8):
         self.graph = graph
         raw = graph.raw_cuda_graph()
+        # weight-pack kernels may leave their captured position only when they write a persistent pack buffer (PackCache)
+        rg = PackCache.ranges()
+        check(_l().leod_plan_set_hoist_ranges(_long_array([a for a, _ in rg]), _long_array([b for _, b in rg]), len(rg)), 'plan_set_hoist_ranges')
         h = int(_l().leod_plan_create(ctypes.c_void_p(int(raw)), int(max_lanes)))
         if h <= 0:
             raise LeodHipError(f'leod_plan_create: {_l().leod_plan_last_error().decode()} (rc {h})')

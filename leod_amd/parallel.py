@@ -30,6 +30,9 @@ ALIGN = 4   # floats (16 bytes): weight rows are read with 16-byte loads
 
 
 class FlatParams:
+    import weakref as _weakref
+    live = _weakref.WeakSet()          # instances with a registered weight shadow (see ``ensure_all_shadows``)
+
     def __init__(self, module: torch.nn.Module):
         self.params = [p for p in module.parameters() if p.requires_grad]
         dev = self.params[0].device
@@ -59,10 +62,23 @@ class FlatParams:
             self.shadow_f16 = torch.empty(n, dtype=torch.float16, device=dev)     # written / read in precision mode 16f only (forward GEMMs)
             ops.set_weight_shadow(self.data, self.shadow)
             ops.set_weight_shadow_f16(self.data, self.shadow_f16)
+            FlatParams.live.add(self)
             weakref.finalize(self, ops.unset_weight_shadow_ptr, self.data.data_ptr())
 
     def zero_grad(self):
         self.grad.zero_()
+
+    @classmethod
+    def ensure_all_shadows(cls) -> None:
+        """Every forward entry point of a model whose parameters may live in a flat buffer calls this (``RNNDetector.forward`` /
+        ``forward_sequence``): a shadow marked fresh must not outlive an in-place edit of the weights made outside the optimiser
+        (``load_state_dict``, ``p.copy_``, EMA) on a path that does not go through ``Module._run_sequence`` -- ``PseudoLabeler`` drives the
+        backbone itself, and so does any direct ``mdl(...)`` call.  Not while a step is being recorded (the recording starts with a forced
+        refresh and pins the shadows)."""
+        if not cls.live or torch.cuda.is_current_stream_capturing():
+            return
+        for fp in list(cls.live):
+            fp.ensure_shadow()
 
     def adamw_step(self, lr, weight_decay=0.0, clip_value=1.0, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8, hp_dev=None):
         """value-clip + AdamW (reference: train.py:236-237 gradient_clip_val=1.0 by value; detection.py:485-488).
