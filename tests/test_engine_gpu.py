@@ -408,7 +408,6 @@ def test_full_size_three_steps_through_plans_vs_oracle(gpu, manifest):
     # every step (<= 2 lr apart per step); the typical tensor agrees to 1e-6
     assert worst[0][0] < 1.2e-4, worst[:4]
     assert np.median([w[0] for w in worst]) < 2e-5, worst
-        assert (np.abs(a - b) > 2e-6 + 1e-4 * np.abs(b)).mean() < 2e-2, k
     states = mod.mode_2_rnn_states[Mode.TRAIN].get_states(0)
     for (h, c), (rh, rc) in zip(states, otr.states):
         np.testing.assert_allclose(c.cpu().numpy(), rc.numpy(), rtol=5e-4, atol=5e-5)
