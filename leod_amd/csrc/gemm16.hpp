@@ -1238,7 +1238,7 @@ static inline int launch_gemm_lds_rw(const AL& al, const BL& bl, const EP& ep, i
 #endif
     dim3 grid(cdiv(cdiv(M, 64 * RW), 8) * 8 * nblocks_n);
     // single LDS buffer + register prefetch everywhere: residency (3-6 workgroups per CU) hides the two barriers per chunk
-    // better than a double buffer at 2-3 workgroups per CU does (measured; LEOD_LDS_NBUF=2 selects the double buffer)
+    // better than a double buffer at 2-3 workgroups per CU does (measured)
     static const int nbuf = 1;
     (void)nbuf;                                      // the double-buffered variant is no longer instantiated (never faster, see above)
     // (96-wide chunks in the 16-bit modes, measured: 38.2 vs 34.2 ms per step on -> off; not instantiated)
@@ -1553,8 +1553,8 @@ static inline int launch_wgrad16(const float* dy, long lddy, const XL& xl, float
     const int tiles = cdiv(N, TN * 16) * cdiv(K, TK * 16);
     // ~768 workgroups in total, at least 4 staged chunks (128 rows) each: every workgroup ends with one fp32 atomic
     // per dW element, so a few fat workgroups beat many thin ones
-    static const int tune_blocks = getenv("LEOD_WGRAD_BLOCKS") ? atoi(getenv("LEOD_WGRAD_BLOCKS")) : 768;   // tuning knob
-    static const int tune_minrows = getenv("LEOD_WGRAD_MINROWS") ? atoi(getenv("LEOD_WGRAD_MINROWS")) : 128;
+    static const int tune_blocks = 768;   // tuning knob
+    static const int tune_minrows = 128;
     int rpb = cdiv(M, max(1, tune_blocks / tiles));
     rpb = max(tune_minrows, ((rpb + 31) / 32) * 32);
     dim3 grid(cdiv(M, rpb), cdiv(N, TN * 16), cdiv(K, TK * 16));
@@ -1883,7 +1883,7 @@ template <int TN, int TK, int WA, int WB, int RC, class XL>
 static inline int launch_wgradw_cfg(const float* dy, long lddy, const XL& xl, float* dW, long ldw, float* dbias,
                                     int M, int N, int K, hipStream_t s, int dyfmt = 0) {
     const int tiles = cdiv(N, TN * 16) * cdiv(K, TK * 16);
-    static const int tune_blocks = getenv("LEOD_WGRADW_BLOCKS") ? atoi(getenv("LEOD_WGRADW_BLOCKS")) : 1024;   // 4 workgroups per CU resident
+    static const int tune_blocks = 1024;   // 4 workgroups per CU resident
     static const int tune_ng = 2;               // row groups per workgroup
     static const int tune_align = 1;
     const int chunks = cdiv(M, RC);
@@ -1945,6 +1945,6 @@ static inline int launch_wgradw(const float* dy, long lddy, const XL& xl, float*
 }
 // large row counts only: small problems keep the round-robin kernel (more workgroups per output tile)
 static inline bool use_wgradw(int M) {
-    static const int mode = getenv("LEOD_WGRADW") ? atoi(getenv("LEOD_WGRADW")) : 1;
+    static const int mode = 1;
     return mode != 0 && M >= 8192;
 }

@@ -1072,11 +1072,11 @@ static int dispatch_attn(int which, const float* qkv, const float* dout, float* 
     static const int use_lds = getenv("LEOD_ATTN_LDS") ? atoi(getenv("LEOD_ATTN_LDS")) : 1;
     // One head per workgroup (5 waves for an 80-token partition) instead of two (10 waves, the CU's wave limit at three workgroups): six
     // workgroups per CU overlap their load / MFMA / store phases better -- backward 984 -> 889 us per step over the four stages, forward of
-    // stage 1 126 -> 116 us, the rest equal (tools/kbench.py attn, profiles/r04_z_attn_hg_kbench.txt).  LEOD_ATTN_HG1: bit 0 forward, bit 1 backward.
-    static const int hg1 = getenv("LEOD_ATTN_HG1") ? atoi(getenv("LEOD_ATTN_HG1")) : 3;
+    // stage 1 126 -> 116 us, the rest equal (tools/kbench.py attn, profiles/r04_z_attn_hg_kbench.txt).  (hg1: bit 0 forward, bit 1 backward.)
+    static const int hg1 = 3;
     const int HG = (g.heads % 2 == 0 && 2 * PT <= 16 && !((hg1 & 1) && which == 0) && !((hg1 & 2) && which != 0)) ? 2 : 1;
     static const int force_pad1 = 1;
-    // (LEOD_ATTN_LDS_PAD1=0 restores the round-1 routing of one-head workgroups with padded partitions to the register-direct
+    // (round 1 routed one-head workgroups with padded partitions to the register-direct
     // backward; the defect behind it was a mis-merged ds_write2_b32 in the <4, 32, 1> instantiation, see the kernel's epilogue)
     const bool lds_shape = (g.d == 24 || g.d == 32) && (PT <= 5 || PT == 8 || (HG == 1 && (PT == 10 || PT == 15))) &&
                            !(HG == 1 && P < 16 * PT && which != 0 && !force_pad1);
@@ -1104,7 +1104,7 @@ static int dispatch_attn(int which, const float* qkv, const float* dout, float* 
 LEOD_API int leod_partition_attn_16bit_ok(int B, int H, int W, int C, int heads, int ph, int pw) {
     if (leod_precision() != 1 || heads <= 0 || C % heads || H % ph || W % pw) return 0;
     static const int use_lds = getenv("LEOD_ATTN_LDS") ? atoi(getenv("LEOD_ATTN_LDS")) : 1;
-    static const int on = getenv("LEOD_QKV16") ? atoi(getenv("LEOD_QKV16")) : 1;
+    static const int on = 1;
     const int d = C / heads, P = ph * pw, PT = (P + 15) / 16;
     const int HG = (heads % 2 == 0 && 2 * PT <= 16) ? 2 : 1;
     const bool inst = PT <= 5 || PT == 8 || (HG == 1 && (PT == 10 || PT == 15));
@@ -1114,7 +1114,7 @@ LEOD_API int leod_partition_attn_16bit_ok(int B, int H, int W, int C, int heads,
 // 1: on top of leod_partition_attn_16bit_ok, the attention output O may be written as bf16 (forward, bit 1 of qkv_bf16) and its gradient
 // dO read as bf16 (backward, bit 1 of qkv_bf16): the bf16-tile kernels stage both as the bf16 MFMA operands they are anyway
 LEOD_API int leod_partition_attn_o16_ok(int B, int H, int W, int C, int heads, int ph, int pw) {
-    static const int on = getenv("LEOD_O16") ? atoi(getenv("LEOD_O16")) : 1;
+    static const int on = 1;
     return on && leod_partition_attn_16bit_ok(B, H, W, C, heads, ph, pw);
 }
 

@@ -260,7 +260,7 @@ LEOD_API int leod_stem_conv_fwd(const void* x, int x_is_u8, const float* w, floa
     const int nt = pick_nt(N);
     int rc = LEOD_OK;
     const bool lds = use_gemm_lds(M, cdiv(N, 16 * nt));
-    static const int stem_patch = getenv("LEOD_STEM_PATCH") ? atoi(getenv("LEOD_STEM_PATCH")) : 1;
+    static const int stem_patch = 1;
     if (stem_patch && x_is_u8 && leod_precision() == 1 && stem_fwd_bf16_supported(x, Cin, H, W, N, stride, pad))
         return stem_fwd_bf16_launch(x, w, y, B, Cin, H, W, Ho, Wo, N, stream);         // k_stem.hip: bf16 patch, weights resident in LDS
     if (stem_patch && x_is_u8 && stride == 4 && pad == 3 && N <= 64 && !(N & 15) && !(W & 3) && Cin * 19 * 72 <= 60000 &&
@@ -363,7 +363,7 @@ LEOD_API int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, fl
         XRows xl{x, (long)Cin, nullptr, nullptr, nullptr, nullptr, 0, 0};
         // 1 x 1 convs are Linear layers over the pixel rows: the wave-tiled weight gradient of the Linear layers for the large maps in
         // bf16 mode (22 -> 15, 28 -> 23, 18 -> 12 us on the PAFPN shapes; fp32 mode: 24 -> 28, 22 -> 26 us, not used)
-        static const int w11 = getenv("LEOD_WGRADW_CONV1X1") ? atoi(getenv("LEOD_WGRADW_CONV1X1")) : 1;
+        static const int w11 = 1;
         if (w11 && leod_precision() == 1 && use_wgradw(M)) return launch_wgradw(dy, (long)N, xl, dw, (long)Cin, dbias, M, N, K, stream);
         return wgrad_any(dy, xl, dw, (long)Cin, dbias, M, N, K, stream);
     }
@@ -526,7 +526,7 @@ LEOD_API int leod_stem_conv_wgrad(const float* dy, const void* x, int x_is_u8, f
     if (ks != 7) return LEOD_ERR_UNSUPPORTED;
     const int Ho = (Hp + 2 * pad - ks) / stride + 1, Wo = (Wp + 2 * pad - ks) / stride + 1;
     const int M = B * Ho * Wo, K = Cin * ks * ks;
-    static const int stem_patch = getenv("LEOD_STEM_PATCH") ? atoi(getenv("LEOD_STEM_PATCH")) : 1;
+    static const int stem_patch = 1;
     if (stem_patch && x_is_u8 && leod_precision() == 1 && stem_wgrad_bf16_supported(x, Cin, H, W, N, stride, pad))
         return stem_wgrad_bf16_launch(dy, x, dw, B, Cin, H, W, Ho, Wo, N, stream);     // k_stem.hip
     if (stem_patch && x_is_u8 && stride == 4 && pad == 3 && N <= 64 && !(N & 15) && !(W & 3) && Cin * 19 * 18 <= 27 * 256 &&

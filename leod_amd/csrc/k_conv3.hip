@@ -703,7 +703,7 @@ static inline int conv3_rows_per_block(int H, int W, int Cin, int nto, int S = 1
 // forward of the stride-2 convs on the same kernel (S = 2)
 bool conv3s2_fwd_supported(int B, int H, int W, int Cin, int Cout) {
     static const int on = getenv("LEOD_CONV3_DIRECT") ? atoi(getenv("LEOD_CONV3_DIRECT")) : 1;
-    static const int on2 = getenv("LEOD_CONV3_FWD2") ? atoi(getenv("LEOD_CONV3_FWD2")) : 1;
+    static const int on2 = 1;
     if (!on || !on2 || leod_precision() != 1) return false;
     if ((H & 1) || (W & 1) || W / 2 > 160 || W / 2 < 4) return false;
     // (192 input channels: the weight tile takes half the LDS, 4 output rows per workgroup -- stage 4 of RVT-S, 13440 output pixels,
@@ -766,7 +766,7 @@ int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, i
 // slices of 96
 bool conv3_wgrad_supported(int H, int W, int Cin, int Cout, int stride) {
     static const int on = getenv("LEOD_CONV3_DIRECT") ? atoi(getenv("LEOD_CONV3_DIRECT")) : 1;
-    static const int on2 = getenv("LEOD_CONV3_WGRAD_WIDE") ? atoi(getenv("LEOD_CONV3_WGRAD_WIDE")) : 1;      // everything but the 96 -> 96 / stride 1 case
+    static const int on2 = 1;      // everything but the 96 -> 96 / stride 1 case
     if (!on || leod_precision() != 1) return false;
     if (stride != 1 && stride != 2) return false;
     if (stride == 2 && ((H & 1) || (W & 1))) return false;
@@ -780,7 +780,7 @@ bool conv3_wgrad_supported(int H, int W, int Cin, int Cout, int stride) {
 // the 8-wave / nine-tap kernel takes everything but the smallest problems (a few regions: the three kernel-row workgroups of
 // conv3_wgrad_kernel fill more CUs; 96 -> 96 on the 8 x 10 level: 17 vs 21 us)
 static inline bool conv3_wgrad_nine(int nregions, int nslices) {
-    static const int on = getenv("LEOD_CONV3_WGRAD9") ? atoi(getenv("LEOD_CONV3_WGRAD9")) : 1;
+    static const int on = 1;
     return on && nregions * nslices > 32;
 }
 struct Conv3WgradPlan { int RH, workers, wvs, nslices, ci; bool nine; size_t smem; };
@@ -791,7 +791,7 @@ static inline Conv3WgradPlan conv3_wgrad_plan(int B, int H, int W, int Cin, int 
     pl.wvs = pl.ci == 48 ? 2 : 1;
     pl.nslices = (Cout / 96) * (Cin / pl.ci);
     const int LDX = pl.ci + (S == 1 ? 16 : 8), LDY = 96 + 16;
-    static const int ldskb = getenv("LEOD_CONV3_WGRAD_LDSKB") ? atoi(getenv("LEOD_CONV3_WGRAD_LDSKB")) : 160;
+    static const int ldskb = 160;
     int RH = max(1, min(Ho, 160 / Wo));
     while (RH > 0) {
         const size_t halo = (((size_t)(S * (RH - 1) + 3) * (W + 2) * LDX + 7) & ~(size_t)7) * 2;
@@ -808,8 +808,8 @@ static inline Conv3WgradPlan conv3_wgrad_plan(int B, int H, int W, int Cin, int 
     // region workers per (kernel row, slice): each walks over nregions / workers regions.  96 -> 96 / stride 1 (level-0 head conv)
     // measured: 64 -> 42 us, 85 -> 47, 128 -> 51; the sliced / strided shapes fill the chip once (3 * slices * workers ~ 256) with a
     // multiple of 8 workers, so that the three kernel rows of a region (dispatch slots workers apart) share an XCD's L2
-    static const int cap = getenv("LEOD_CONV3_WORKERS") ? atoi(getenv("LEOD_CONV3_WORKERS")) : 64;
-    static const int fill = getenv("LEOD_CONV3_FILL") ? atoi(getenv("LEOD_CONV3_FILL")) : 256;
+    static const int cap = 64;
+    static const int fill = 256;
     int workers = cap;
     if (!(S == 1 && Cin == 96 && Cout == 96)) {
         workers = max(1, fill / (3 * pl.nslices));
@@ -820,7 +820,7 @@ static inline Conv3WgradPlan conv3_wgrad_plan(int B, int H, int W, int Cin, int 
         // 9-tap workgroups, one per CU (LDS): slices * workers of them, and each writes a whole 9 x 96 x CI slice of partial sums that
         // the reduce kernel reads back -- 256 workgroups when each gets >= 2 regions (the backbone convs on 168 frames: stage 2
         // 174 -> 103 us, stage 3 141 -> 69, stage 4 169 -> 74), 128 for the PAFPN / head convs on the 32 labelled frames (38 vs 43 us)
-        static const int fill9 = getenv("LEOD_CONV3_FILL9") ? atoi(getenv("LEOD_CONV3_FILL9")) : 0;
+        static const int fill9 = 0;
         const int target = fill9 ? fill9 : (nregions * pl.nslices >= 512 ? 256 : 128);
         workers = max(1, target / pl.nslices);
     }
@@ -889,7 +889,7 @@ static inline int conv3s2_dgrad_rows(int Ho, int Wo, int N) {
 // x [B,H,W,Cin] <- dy [B,H/2,W/2,N]
 bool conv3s2_dgrad_supported(int H, int W, int Cin, int N) {
     static const int on = getenv("LEOD_CONV3_DIRECT") ? atoi(getenv("LEOD_CONV3_DIRECT")) : 1;
-    static const int on2 = getenv("LEOD_CONV3_DGRAD2") ? atoi(getenv("LEOD_CONV3_DGRAD2")) : 1;
+    static const int on2 = 1;
     if (!on || !on2 || leod_precision() != 1) return false;
     if ((H & 1) || (W & 1) || W / 2 > 160 || W / 2 < 4) return false;
     if (Cin % 48 != 0 || (N != 96 && N != 192 && N != 384)) return false;

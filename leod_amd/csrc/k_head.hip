@@ -794,7 +794,7 @@ LEOD_API int leod_head_pred_fwd(const float* cls_feat, const float* reg_feat, co
     if (!cls_feat || !reg_feat || (Hd & 3) || (!out_train && !out_infer)) return LEOD_ERR_ARG;
     const long total = (long)B * h * w * (5 + nc);
     if (total == 0) return LEOD_OK;
-    static const int lds_on = getenv("LEOD_HEAD_PRED_LDS") ? atoi(getenv("LEOD_HEAD_PRED_LDS")) : 1;
+    static const int lds_on = 1;
     if (lds_on && Hd <= 128 && nc <= 16 && (long)B * h * w >= 4096) {
         const int grid = (int)min((long)2048, ((long)B * h * w + 63) / 64);
         if (Hd <= 96) hipLaunchKernelGGL(head_pred_fwd_lds_kernel<96>, dim3(grid), dim3(256), 0, stream, cls_feat, reg_feat, cls_w, cls_b,

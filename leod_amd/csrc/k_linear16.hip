@@ -16,9 +16,9 @@ LEOD_API int leod_ln_linear_gelu16_fwd(const float* x, const float* ln_w, const 
                                        void* u16, float* stats_out, int M, int N, int K, hipStream_t stream) {
     LeodFwdScope fwd_scope;                                   // forward contraction: fp16 operands in precision mode 16f
     if (!x || !W || !u16 || !ln_w || !stats_out) return LEOD_ERR_ARG;
-    static const int on = getenv("LEOD_U16") ? atoi(getenv("LEOD_U16")) : 1;
+    static const int on = 1;
     const int slab = rowstream_slab(M, N, K);
-    static const int gen16 = getenv("LEOD_GENERIC16") ? atoi(getenv("LEOD_GENERIC16")) : 1;
+    static const int gen16 = 1;
     if (!on || leod_precision() != 1) return LEOD_ERR_UNSUPPORTED;
     if (!slab) return gen16 ? ln_linear_16_generic(x, ln_w, ln_b, eps, W, bias, u16, stats_out, M, N, K, 1, stream) : LEOD_ERR_UNSUPPORTED;
     const int slabs = N / (16 * slab);
@@ -57,7 +57,7 @@ LEOD_API int leod_ln_linear_bf16_fwd(const float* x, const float* ln_w, const fl
     LeodFwdScope fwd_scope;                                   // forward contraction: fp16 operands in precision mode 16f
     if (!x || !W || !out16 || (ln_w && !stats_out)) return LEOD_ERR_ARG;
     const int slab = ln_w ? rowstream_slab(M, N, K) : 0;
-    static const int gen16 = getenv("LEOD_GENERIC16") ? atoi(getenv("LEOD_GENERIC16")) : 1;
+    static const int gen16 = 1;
     if (leod_precision() != 1) return LEOD_ERR_UNSUPPORTED;
     // the stored rows are the attention kernels' MFMA operands: bf16, or fp16 in precision mode 16f
     if (!slab) return gen16 ? ln_linear_16_generic(x, ln_w, ln_b, eps, W, bias, out16, stats_out, M, N, K, leod_opfmt() == 2 ? 1 : 2, stream) : LEOD_ERR_UNSUPPORTED;

@@ -81,7 +81,7 @@ LEOD_API int leod_linear_dgrad_gelu16(const float* dy, const float* kscale, cons
     const int slab = rowstream_slab(M, K, N);
     if (!slab) {
         // generic shapes (stages 3-4): LDS-staged / wide-tile dgrad, gelu'(fp16 u) and the 16-bit store in the row epilogue
-        static const int gen16 = getenv("LEOD_GENERIC16") ? atoi(getenv("LEOD_GENERIC16")) : 1;
+        static const int gen16 = 1;
         const int nt = pick_nt(K);
         if (!gen16 || (N & 3) || (K & 3) || !use_gemm_lds(M, cdiv(K, 16 * nt))) return LEOD_ERR_UNSUPPORTED;
         ALRows al{}; al.x = dy; al.ld = N; al.kscale = kscale; al.K = N;

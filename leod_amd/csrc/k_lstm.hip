@@ -569,11 +569,11 @@ static inline int fwd_bregs(int K, bool bf) { return 4 * (K / 16) * (bf ? 2 : 4)
 LEOD_API int leod_convlstm_seq_mode(int C) {
     if (getenv("LEOD_LSTM_SEQ") && atoi(getenv("LEOD_LSTM_SEQ")) == 0) return 0;
     const bool bf = leod_precision() == 1;
-    static const int stream_on = getenv("LEOD_LSTM_STREAM") ? atoi(getenv("LEOD_LSTM_STREAM")) : 1;
+    static const int stream_on = 1;
     if (bf && stream_on && (C == 256 || C == 384)) return 3;               // hoisted x projection + weights streamed from a packed bf16 copy
     // C = 192: the register-resident kernels spill (96 weight registers of the 168 a wave gets at 12 waves per workgroup: 79 / 83 spilled
     // VGPRs, tools/kernel_regs.py) -- streamed fragments (295 KB per timestep and workgroup from L2) are the faster of the two
-    static const int stream192 = getenv("LEOD_LSTM_STREAM192") ? atoi(getenv("LEOD_LSTM_STREAM192")) : 1;
+    static const int stream192 = 1;
     if (bf && stream_on && stream192 && C == 192) return 3;
     if (C != 32 && C != 48 && C != 64 && C != 96 && C != 128 && C != 192) return 0;
     if (fwd_bregs(2 * C, bf) <= 96) return 1;                               // beyond ~100 resident registers the kernels spill
@@ -592,7 +592,7 @@ LEOD_API int leod_convlstm_seq_mode(int C) {
 // 1: the sequence kernels of this channel count keep the gates as fp16 (opaque layout, T x ceil(M / 16) * 16 x 4C halfs) and write the
 // gate gradients as bf16 rows [T][M][4C] when asked to (gates16 of leod_convlstm_seq_fwd / _bwd); 0: fp32 tensors only
 LEOD_API int leod_convlstm_seq_gates16_ok(int C) {
-    static const int on = getenv("LEOD_LSTM_G16") ? atoi(getenv("LEOD_LSTM_G16")) : 1;
+    static const int on = 1;
     if (!on || leod_precision() != 1) return 0;
     const int mode = leod_convlstm_seq_mode(C);
     if (mode == 3) return 1;

@@ -56,9 +56,8 @@ std::string g_err;
 int new_event(Plan& p) {
     hipEvent_t e;
     // the events only order lanes of ONE device against each other (hipStreamWaitEvent; the host never inspects them), so the system-scope
-    // fence of a default event is left out: 15.84 -> 15.70 ms per step (profiles/r04_a_graph_ab.txt).  LEOD_PLAN_EVENT_FLAGS=0 restores it.
-    static const unsigned extra = getenv("LEOD_PLAN_EVENT_FLAGS") ? (unsigned)strtoul(getenv("LEOD_PLAN_EVENT_FLAGS"), nullptr, 0)
-                                                                  : (unsigned)hipEventDisableSystemFence;
+    // fence of a default event is left out: 15.84 -> 15.70 ms per step (profiles/r04_a_graph_ab.txt).
+    static const unsigned extra = (unsigned)hipEventDisableSystemFence;
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming | extra) != hipSuccess) return -1;
     p.events.push_back(e);
     return (int)p.events.size() - 1;
@@ -177,7 +176,7 @@ LEOD_API long leod_plan_create(void* hip_graph, int max_lanes) {
     // middle of the neck / head chains).  Their incoming edges are dropped (predecessors are linked to their successors instead), they are chained
     // among themselves and put on lane 1 at the START of the plan, and every consumer waits for the LAST of them -- one wait on the critical lane.
     std::vector<char> hoisted(n, 0);
-    static const int hoist_on = getenv("LEOD_PLAN_HOIST") ? atoi(getenv("LEOD_PLAN_HOIST")) : 1;
+    static const int hoist_on = 1;
     if (hoist_on && max_lanes >= 2) {
         std::vector<int> hs;
         for (size_t i = 0; i < n; ++i) {

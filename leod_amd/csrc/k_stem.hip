@@ -160,7 +160,7 @@ int launch(const float* dy, const uint8_t* x, float* dW, int B, int Cin, int H, 
     const int ntiles = B * tiles_x * tiles_y;
     const size_t patch = (((size_t)Cin * PR * RS + 7) & ~(size_t)7) * 2;
     const size_t lds = patch + (size_t)4 * NT * BST * 2;
-    static const int workers = getenv("LEOD_STEM_WGRAD_WORKERS") ? atoi(getenv("LEOD_STEM_WGRAD_WORKERS")) : 256;
+    static const int workers = 256;
     const int gx = ntiles < workers ? ntiles : workers;
     static bool attr = false;
     if (!attr) {
@@ -351,7 +351,7 @@ int launch_fwd(const uint8_t* x, const float* w, float* y, int B, int H, int W, 
     const int ntiles = B * tiles_x * tiles_y;
     constexpr int KS = (CIN * 7 + 3) >> 2, LDW = KS * 32 + 16;
     const size_t lds = (size_t)16 * NT * LDW * 2 + (size_t)CIN * PR * RS * 2;
-    static const int workers = getenv("LEOD_STEM_WORKERS") ? atoi(getenv("LEOD_STEM_WORKERS")) : 256;
+    static const int workers = 256;
     static const int dbg = 0;
     int gx = ntiles < workers ? ntiles : workers;
     if (gx >= 8) gx &= ~7;                                     // whole XCD rounds (see the tile order of the kernel)
@@ -369,7 +369,7 @@ int launch_fwd(const uint8_t* x, const float* w, float* y, int B, int H, int W, 
 }  // namespace
 
 bool stem_wgrad_bf16_supported(const void* x, int Cin, int H, int W, int N, int stride, int pad) {
-    static const int on = getenv("LEOD_STEM_BF16") ? atoi(getenv("LEOD_STEM_BF16")) : 1;
+    static const int on = 1;
     return on && stride == 4 && pad == 3 && N >= 16 && N <= 48 && !(N & 15) && !(W & 3) && Cin * PR * RD <= RX * 512 &&
            Cin * 7 <= 2 * 8 * KT && ((uintptr_t)x & 3) == 0 && ((long)Cin * H * W) % 4 == 0;
 }
@@ -387,7 +387,7 @@ int stem_wgrad_bf16_launch(const float* dy, const void* x, float* dW, int B, int
 // forward: the 20 event-representation channels of every RVT configuration; weights of all N channels (16 NT x 35 x 32 + pad bf16) and
 // the patch fill the 160 KB of LDS (N = 64, RVT-B, does not fit: it stays on stem_u8_fwd_kernel)
 bool stem_fwd_bf16_supported(const void* x, int Cin, int H, int W, int N, int stride, int pad) {
-    static const int on = getenv("LEOD_STEM_FWD_BF16") ? atoi(getenv("LEOD_STEM_FWD_BF16")) : 1;
+    static const int on = 1;
     return on && stride == 4 && pad == 3 && Cin == 20 && (N == 32 || N == 48) && !(W & 3) && ((uintptr_t)x & 3) == 0 &&
            ((long)Cin * H * W) % 4 == 0;
 }

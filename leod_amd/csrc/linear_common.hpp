@@ -464,7 +464,7 @@ static inline bool use_rowstream_narrow(int M, int Kc, int Nout) {
 }
 // stage 2 of RVT-S in precision mode bf16: 16-bit A rows (fp16 hidden, bf16 du / dqkv), 288 / 384 -> 96 columns
 static inline bool use_rowstream_narrow96(int M, int Kc, int Nout) {
-    static const int on = getenv("LEOD_ROWSTREAM96") ? atoi(getenv("LEOD_ROWSTREAM96")) : 1;
+    static const int on = 1;
     return on && leod_precision() == 1 && M >= 16384 && Nout == 96 && (Kc == 288 || Kc == 384);
 }
 template <int MODE>

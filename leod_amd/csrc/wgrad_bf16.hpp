@@ -444,15 +444,15 @@ template <int TN, int TK, int NWN, int NWK, int RC, int DYF, int XM, int OCC>
 static inline int launch_wgrad_wide_cfg(const void* dy, long lddy, const XRows& xl, float* dW, long ldw, float* dbias,
                                         int M, int N, int K, hipStream_t s) {
     static const int dbg = getenv("LEOD_WGRAD_WIDE_DBG") ? atoi(getenv("LEOD_WGRAD_WIDE_DBG")) : 0;
-    static const int tune_wgs = getenv("LEOD_WGRAD_WIDE_WGS") ? atoi(getenv("LEOD_WGRAD_WIDE_WGS")) : OCC * 256;
+    static const int tune_wgs = OCC * 256;
     constexpr int LDS = wgw_lds_bytes<TN, TK, RC, 4 / (NWN * NWK)>();
     const int tiles = cdiv(N, TN * 16) * cdiv(K, TK * 16), chunks = cdiv(M, RC);
     // all workgroups resident (OCC per CU); >= 2 chunks each; a multiple of 8 per output tile keeps the workgroups that stream the same
     // rows for different tiles on one XCD (see launch_wgradw_cfg)
     // launches of <= 60 k rows (stages 3-4) run beside the main lane's kernels and are latency-bound: 384 workgroups instead of OCC * 256
     // leave wave slots to the other lane and halve the partial tiles (15.84 -> 15.76-15.79 ms per step, profiles/r04_a_graph_ab.txt)
-    static const int tune_small = getenv("LEOD_WGRAD_WIDE_WGS_SMALL") ? atoi(getenv("LEOD_WGRAD_WIDE_WGS_SMALL")) : 384;
-    static const int small_rows = getenv("LEOD_WGRAD_WIDE_SMALL_ROWS") ? atoi(getenv("LEOD_WGRAD_WIDE_SMALL_ROWS")) : 60000;
+    static const int tune_small = 384;
+    static const int small_rows = 60000;
     const int wgs = (tune_small > 0 && M <= small_rows) ? tune_small : tune_wgs;
     int gx = max(1, min(chunks / 2, wgs / tiles));
     if (gx >= 16) gx &= ~7;
@@ -460,7 +460,7 @@ static inline int launch_wgrad_wide_cfg(const void* dy, long lddy, const XRows& 
     auto kern = wgrad_wide_bf16_kernel<TN, TK, NWN, NWK, RC, DYF, XM, OCC>;
     static bool attr_set = false;                             // dynamic LDS opt-in, once per instantiation
     if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
-    static const int use_part = getenv("LEOD_WGRAD_WIDE_PART") ? atoi(getenv("LEOD_WGRAD_WIDE_PART")) : 1;
+    static const int use_part = 1;
     constexpr int NW = NWN * NWK, NSL = (TN / NWN) * (TK / NWK) + TN / NWN;
     const long O = (long)tiles * NW * NSL * 64;               // f4 per partial
     f4* part = (use_part && gx > 1) ? wgrad_wide_scratch(s, (size_t)gx * O * sizeof(f4)) : nullptr;
@@ -491,7 +491,7 @@ static inline int wgrad_wide_combo(const XRows& xl, int N, int K, int dyfmt) {
         if (dyfmt) return 0;
         if (N <= 48 && K <= 48) return 14;
         if (K <= 48 || N <= 48) return 0;
-        static const int big4 = getenv("LEOD_WGRAD_WIDE_BIG") ? atoi(getenv("LEOD_WGRAD_WIDE_BIG")) : 1;
+        static const int big4 = 1;
         return (big4 && K % 192 == 0 && N >= 96) ? 16 : 15;
     }
     const int c = (dyfmt ? 1 : 0) * 4 + xm;        // 0: f32/rows 1: f32/LN 2: f32/gelu16 3: f32/bf16 rows 4: bf16/rows 5: bf16/LN
@@ -501,7 +501,7 @@ static inline int wgrad_wide_combo(const XRows& xl, int N, int K, int dyfmt) {
     if (N <= 48) return c == 2 ? 3 : 0;
     // 192-wide tiles along the 16-bit operand's side: 192 x 96 outputs for bf16 dY with fp32 X (qkv, fc1, ConvLSTM), 96 x 192 for fp32 dY
     // with 16-bit X (fc2 on the fp16 hidden, proj on bf16 O)
-    static const int big = getenv("LEOD_WGRAD_WIDE_BIG") ? atoi(getenv("LEOD_WGRAD_WIDE_BIG")) : 1;
+    static const int big = 1;
     if (big && N % 192 == 0 && K >= 96 && (c == 5 || c == 4)) return c == 5 ? 10 : 11;
     if (big && K % 192 == 0 && N >= 96 && (c == 2 || c == 3)) return c == 2 ? 12 : 13;
     return c == 0 ? 4 : c == 5 ? 5 : c == 2 ? 6 : c == 4 ? 7 : c == 3 ? 9 : 0;

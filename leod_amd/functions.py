@@ -634,7 +634,7 @@ def base_conv_group(mods, xs):
     """[BaseConv], [NHWC maps] -> [outputs]; grouped into one node (one statistics exchange) in SyncBatchNorm training, plain
     per-layer calls otherwise."""
     # members reading the same map: their input gradients are summed inside the node (LEOD_GROUP_SHARED=0: separate nodes, autograd adds)
-    shared = len({id(x) for x in xs}) < len(xs) and os.environ.get('LEOD_GROUP_SHARED', '1') != '0' 
+    shared = len({id(x) for x in xs}) < len(xs) 
     if len(mods) > 1 and mods[0].training and (_sync_bn_on() or (shared and torch.is_grad_enabled() and xs[0].is_cuda)):
         params = []
         for m in mods:

@@ -585,7 +585,7 @@ def stem_conv_wgrad(dy, x_nchw, dw, padded_hw, stride, pad):
                                      padded_hw[0], padded_hw[1], N, ks, stride, pad, _stream()), 'stem_conv_wgrad')
 
 
-BF16_GRADS = __import__('os').environ.get('LEOD_BF16_GRADS', '1') == '1'   # precision mode bf16: du (and dqkv) stored as bf16
+BF16_GRADS = True          # 16-bit modes: du (and dqkv) stored as bf16
 STAT_REPLICAS = 32          # most copies of the BatchNorm (sum, sumsq) accumulators a conv epilogue spreads its atomics over
 
 
