@@ -8,5 +8,5 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
     line=$(env $envs MASTER_ADDR=127.0.0.1 MASTER_PORT=29544 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-second-dtype --no-roofline $flags 2>/dev/null | grep '^{"metric' | tail -1)
     echo "$name $(echo "$line" | python -c 'import json,sys; d=json.loads(sys.stdin.read()); c=d["config"]; print(d["ms_per_step"], d["value"], c.get("host_enqueue_ms_per_step"), c.get("collective_backend"), (c.get("launch_plans") or {}).get("backward"))' 2>/dev/null || echo FAILED)"
   done; done
-} > gpurun_out/r04_m_rccl_force_collectives.txt 2>&1
-cat gpurun_out/r04_m_rccl_force_collectives.txt
+} > gpurun_out/r05_h_rccl_force_collectives.txt 2>&1
+cat gpurun_out/r05_h_rccl_force_collectives.txt
