@@ -341,6 +341,10 @@ long leod_plan_create(void* hip_graph, int max_lanes);
  * (that temporary may share its address with another temporary of the same capture). */
 int leod_plan_set_hoist_ranges(const long* starts, const long* bytes, int n);
 int leod_plan_launch(long plan, leod_stream_t stream);
+/* leod_plan_launch without its closing join: `stream` does not wait for the plan's side lanes; leod_plan_join(plan, stream) makes it wait
+ * later (before the plan is launched again and before anything reads what the side lanes wrote). */
+int leod_plan_launch_nojoin(long plan, leod_stream_t stream);
+int leod_plan_join(long plan, leod_stream_t stream);
 int leod_plan_info(long plan, int* info);
 int leod_plan_destroy(long plan);
 int leod_plan_dump(long plan, const char* path); /* debug listing: lane, kernel, events per op in launch order */

@@ -306,7 +306,7 @@ LEOD_API long leod_plan_create(void* hip_graph, int max_lanes) {
 }
 
 // Replay on `stream` (lane 0); the other lanes start after everything enqueued on `stream` so far and are joined back into it.
-LEOD_API int leod_plan_launch(long handle, hipStream_t stream) {
+static int plan_launch(long handle, hipStream_t stream, bool join) {
     Plan* p;
     {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -345,8 +345,25 @@ LEOD_API int leod_plan_launch(long handle, hipStream_t stream) {
     }
     for (int k = 1; k < nl; ++k) {
         if (hipEventRecord(p->events[p->tail_event[k]], p->lanes[k]) != hipSuccess) return LEOD_ERR_LAUNCH;
-        if (hipStreamWaitEvent(stream, p->events[p->tail_event[k]], 0) != hipSuccess) return LEOD_ERR_LAUNCH;
+        if (join && hipStreamWaitEvent(stream, p->events[p->tail_event[k]], 0) != hipSuccess) return LEOD_ERR_LAUNCH;
     }
+    return LEOD_OK;
+}
+LEOD_API int leod_plan_launch(long handle, hipStream_t stream) { return plan_launch(handle, stream, true); }
+// The same without the closing join: `stream` does not wait for the plan's side lanes (their work -- weight gradients -- feeds nothing the
+// caller enqueues next).  leod_plan_join(plan, stream) makes `stream` wait for them later; it must be called before the plan is launched
+// again and before anything reads what the side lanes wrote.
+LEOD_API int leod_plan_launch_nojoin(long handle, hipStream_t stream) { return plan_launch(handle, stream, false); }
+LEOD_API int leod_plan_join(long handle, hipStream_t stream) {
+    Plan* p;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_plans.find(handle);
+        if (it == g_plans.end()) return LEOD_ERR_ARG;
+        p = it->second;
+    }
+    for (int k = 1; k < (int)p->lanes.size(); ++k)
+        if (hipStreamWaitEvent(stream, p->events[p->tail_event[k]], 0) != hipSuccess) return LEOD_ERR_LAUNCH;
     return LEOD_OK;
 }
 

@@ -79,12 +79,19 @@ class PlanRecorder:
         rec.begin()
         return True
 
-    def replay(self):
-        for plan, callback in self.segments:
+    def replay(self, join_last: bool = True):
+        """``join_last=False``: the last segment's side lanes are not joined into the current stream (``join()`` does it later)."""
+        last = len(self.segments) - 1
+        for k, (plan, callback) in enumerate(self.segments):
             if plan is not None:
-                plan.launch()
+                plan.launch(join=join_last or k < last or callback is not None)
             if callback is not None:
                 callback()
+
+    def join(self):
+        plan = self.segments[-1][0] if self.segments else None
+        if plan is not None:
+            plan.join()
 
     def info(self):
         k = sum(p.info['kernels'] for p, _ in self.segments if p is not None)
@@ -123,6 +130,7 @@ class PlanLossFn(Function):
         bb.consumed = ctx.gen
         hd.run_backward(g)
         bb.run_backward()
+        hd.bwd.join()
         return None, None, None, None
 
 
@@ -229,8 +237,10 @@ class HeadPlan:
             m.bn_calls_pending += inc
 
     def run_backward(self, g: th.Tensor):
+        # the head's weight gradients (side lane) feed nothing the backbone's backward pass reads: the current stream goes on without waiting
+        # for them, PlanLossFn joins them after the backbone plan has been launched
         self.seed.copy_(g.reshape(()), non_blocking=True)
-        self.bwd.replay()
+        self.bwd.replay(join_last=False)
 
     def close(self):
         for p in (self.fwd, self.bwd):

@@ -1121,8 +1121,16 @@ class LaunchPlan:
         check(_l().leod_plan_info(h, info), 'plan_info')
         self.info = dict(zip(('kernels', 'memsets', 'memcpys', 'empty', 'lanes', 'events', 'waits', 'ops'), list(info)))
 
-    def launch(self):
-        check(_l().leod_plan_launch(self.handle, _stream()), 'plan_launch')
+    def launch(self, join: bool = True):
+        """``join=False``: the current stream does not wait for the plan's side lanes (call ``join()`` before the next launch of this plan
+        and before anything reads what they wrote)."""
+        if join:
+            check(_l().leod_plan_launch(self.handle, _stream()), 'plan_launch')
+        else:
+            check(_l().leod_plan_launch_nojoin(self.handle, _stream()), 'plan_launch_nojoin')
+
+    def join(self):
+        check(_l().leod_plan_join(self.handle, _stream()), 'plan_join')
 
     def dump(self, path: str):
         check(_l().leod_plan_dump(self.handle, path.encode()), 'plan_dump')
