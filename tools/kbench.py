@@ -56,7 +56,7 @@ def main():
         Wqkv, bqkv, Wp, bp, g = r(3 * C, C) * .1, r(3 * C), r(C, C) * .1, r(C), r(C)
         W1, b1, W2, b2 = r(4 * C, C) * .1, r(4 * C), r(C, 4 * C) * .1, r(C)
         qkv4 = r(B, H, W, 3 * C)
-        qkv16 = qkv4.to(torch.bfloat16)
+        qkv16 = qkv4.to(ops.act16_dtype())
         u, dyC, dy3, dy4 = r(M, 4 * C), r(M, C), r(M, 3 * C), r(M, 4 * C)
         dy3b, dy4b, u16 = dy3.to(torch.bfloat16), dy4.to(torch.bfloat16), u.to(torch.float16)
         _, _, st = ops.ln_linear_fwd(x, lw, lb, Wqkv, bqkv, want_stats=True)
