@@ -27,7 +27,7 @@ def configure(dev_kernarg=None, plan=None, precision=None):
                  it initialises, so this only has an effect BEFORE the first HIP call of the process; afterwards it raises.
                  ``False`` also undoes the default this package's import installed.
     plan         True / False: launch plans for ``Module.training_step`` of modules created from now on (LEOD_PLAN).
-    precision    'f32' | 'bf16': ``ops.set_precision`` (overrides nothing that a later ``Module.setup`` derives from its config).
+    precision    'f32' | 'bf16' | '16f': ``ops.set_precision`` (overrides nothing that a later ``Module.setup`` derives from its config).
     Returns the settings in force."""
     global _DEV_KERNARG_SET_HERE
     if dev_kernarg is not None:
