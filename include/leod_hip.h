@@ -284,6 +284,8 @@ int leod_set_weight_shadow_f16(const float* base, void* shadow_f16);
 int leod_weight_shadow_refresh(int force, leod_stream_t stream);
 int leod_weight_shadow_invalidate(void);
 int leod_weight_shadow_pin(int on);
+/* out[i] = (i == idx) ? *g : 0 for i < n <= 64 (device scalar g): the gradient of one entry of the six-entry loss vector as a zero-padded vector. */
+int leod_onehot_scale(const float* g, float* out, int n, int idx, leod_stream_t stream);
 /* dst[0..3] = (a,b,c,d) on the device (launch-time scalars for a replayed hipGraph). */
 int leod_set_scalars4(float* dst, float a, float b, float c, float d, leod_stream_t stream);
 /* Recurrent-state plumbing as one launch per call (host arrays of up to 16 entries; pointers and sizes 16-byte aligned):

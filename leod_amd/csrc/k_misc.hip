@@ -319,6 +319,18 @@ LEOD_API int leod_rows_index_add(float* dst, const float* src, const long* idx, 
     return leod_launch_status();
 }
 
+// out[i] = (i == idx) ? *g : 0 for i < n: the seed gradient of ONE entry of a small loss vector as a real zero-padded vector (one launch;
+// no memset / memcpy nodes in a captured step)
+__global__ void onehot_scale_kernel(const float* __restrict__ g, float* __restrict__ out, int n, int idx) {
+    const int i = threadIdx.x;
+    if (i < n) out[i] = i == idx ? g[0] : 0.f;
+}
+LEOD_API int leod_onehot_scale(const float* g, float* out, int n, int idx, hipStream_t stream) {
+    if (!g || !out || n <= 0 || n > 64 || idx < 0 || idx >= n) return LEOD_ERR_ARG;
+    hipLaunchKernelGGL(onehot_scale_kernel, dim3(1), dim3(64), 0, stream, g, out, n, idx);
+    return leod_launch_status();
+}
+
 LEOD_API const char* leod_version() { return "leod_hip 0.2 (gfx950)"; }
 
 // precision mode of the contractions (see common.hpp): process-wide, set once before the first step

@@ -736,12 +736,18 @@ def cat2_nhwc(a: torch.Tensor, b: torch.Tensor, up: bool = False) -> torch.Tenso
 class PickLossFn(Function):
     """losses[0] as its own autograd node.  Plain indexing would put a SelectBackward node in front of ``HeadTailFn``: a zero fill of a
     [6] tensor plus a 4-byte device-to-device memcpy per backward pass -- and a memcpy NODE in a captured step, which a launch plan
-    (``ops.LaunchPlan``) cannot read back from the graph.  The seed is handed on as a stride-0 view: ``HeadTailFn.backward`` reads element 0."""
+    (``ops.LaunchPlan``) cannot read back from the graph.  The backward hands on a real zero-padded vector [g, 0, 0, 0, 0, 0] written by
+    one small launch (``leod_onehot_scale``), so a node placed between this one and ``HeadTailFn`` sees the true gradient."""
 
     @staticmethod
     def forward(ctx, losses):
+        ctx.n = losses.numel()
         return losses[0]
 
     @staticmethod
     def backward(ctx, g):
-        return g.reshape(1).expand(6)
+        if g.is_cuda and g.dtype is torch.float32:
+            return ops.onehot_scale(g.contiguous(), ctx.n, 0)
+        out = g.new_zeros(ctx.n)
+        out[0] = g
+        return out

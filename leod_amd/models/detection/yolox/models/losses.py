@@ -18,18 +18,20 @@ def _reduce(loss: torch.Tensor, reduction: str) -> torch.Tensor:
 
 
 class IOUloss(nn.Module):
-    """1 - IoU^2 of boxes given as (cx, cy, w, h) rows (:18-43, ``loss_type='iou'``)."""
+    """IoU losses of boxes given as (cx, cy, w, h) rows (:11-66): ``'iou'`` = 1 - IoU^2, ``'giou'`` = 1 - GIoU; optional per-box weights."""
 
     def __init__(self, reduction="none", loss_type="iou"):
         super().__init__()
-        if loss_type != 'iou':
-            raise NotImplementedError('only the plain IoU loss (1 - iou^2) is used by the reference configs')
+        if loss_type not in ('iou', 'giou'):
+            raise NotImplementedError(f'IOUloss: loss_type {loss_type!r}')
         self.reduction = reduction
         self.loss_type = loss_type
 
-    def forward(self, pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    def forward(self, pred: torch.Tensor, target: torch.Tensor, weights=None):
         if pred.shape[0] != target.shape[0]:
             raise ValueError('IOUloss: one target box per predicted box')
+        if pred.shape[0] == 0:
+            return 0.                                           # the reference's convention for an empty match set (:21-22)
         pred, target = pred.reshape(-1, 4), target.reshape(-1, 4)
         half_p, half_t = pred[:, 2:] * 0.5, target[:, 2:] * 0.5
         lo = torch.maximum(pred[:, :2] - half_p, target[:, :2] - half_t)
@@ -37,7 +39,19 @@ class IOUloss(nn.Module):
         overlap = ((hi - lo).prod(dim=1)) * (lo < hi).all(dim=1).to(pred.dtype)
         union = pred[:, 2:].prod(dim=1) + target[:, 2:].prod(dim=1) - overlap
         iou = overlap / (union + 1e-16)
-        return _reduce(1.0 - iou * iou, self.reduction)
+        if self.loss_type == 'iou':
+            loss = 1.0 - iou * iou
+        else:                                                   # enclosing-box penalty (:39-48)
+            c_lo = torch.minimum(pred[:, :2] - half_p, target[:, :2] - half_t)
+            c_hi = torch.maximum(pred[:, :2] + half_p, target[:, :2] + half_t)
+            area_c = (c_hi - c_lo).prod(dim=1)
+            giou = iou - (area_c - union) / area_c.clamp(1e-16)
+            loss = 1.0 - giou.clamp(min=-1.0, max=1.0)
+        if weights is not None and isinstance(weights, torch.Tensor) and bool((weights != 1.).any()):
+            if weights.shape[0] != loss.shape[0]:
+                raise ValueError('IOUloss: one weight per box')
+            loss = loss * weights
+        return _reduce(loss, self.reduction)
 
 
 class FocalLoss(nn.Module):

@@ -1081,6 +1081,14 @@ def copy_multi(dsts, srcs):
                                 _stream()), 'copy_multi')
 
 
+def onehot_scale(g: torch.Tensor, n: int, idx: int) -> torch.Tensor:
+    """[0, .., g, .., 0] (n entries, g a device scalar at position idx) in one launch."""
+    _ck(g.reshape(1), name='g')
+    out = torch.empty((n,), dtype=F32, device=g.device)
+    check(_l().leod_onehot_scale(_p(g), _p(out), int(n), int(idx), _stream()), 'onehot_scale')
+    return out
+
+
 def set_scalars4(dst, a, b, c, d):
     _ck(dst, name='dst')
     check(_l().leod_set_scalars4(_p(dst), float(a), float(b), float(c), float(d), _stream()), 'set_scalars4')

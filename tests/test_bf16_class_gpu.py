@@ -425,9 +425,10 @@ def test_loss_trajectory_200_steps_onecycle_bf16_vs_f32(gpu, mode16):
     # same runs: 0.8-5 %); the last-20-step means then land at 9.16 / 8.76 / 8.38 / 7.60 / ... against fp32's 8.70-9.30 and the perturbed-fp32
     # control's 8.67-8.88: the end of the schedule, where the 16 cycled batches are memorised, is a chaotic observable of THIS test problem
     # (a 2^-9 perturbation of the initial weights moves fp32 itself by up to 6 %), and the 16-bit modes keep landing on the low side of it.
-    # The early bound is the parity statement (tight for 16f); the whole-schedule bound catches a mode that stops learning or runs away.
+    # The early bound is the parity statement (0.10: two fp32 runs have differed by 0.058 there; 16f measured 0.010-0.027 in eight runs); the
+    # whole-schedule bound catches a mode that stops learning or runs away.
     early = slice(0, 90)
-    lim_early, lim_all = (0.10, 0.45) if mode16 == 'bf16' else (0.06, 0.45)
+    lim_early, lim_all = 0.10, 0.45          # both modes: two fp32 runs have differed by up to 0.058 before step 90 (round 4); 16f measured 0.010-0.027 in eight runs
     assert rel_d[early].max() <= lim_early, rel_d[early].max()
     assert rel_d.max() <= lim_all, rel_d.max()
     assert abs(a[-20:].mean() - b[-20:].mean()) <= lim_all * a[-20:].mean()

@@ -409,3 +409,24 @@ def test_loss_modules_forward_match_oracle():
     want = oh.sigmoid_focal_loss(x, t, alpha=0.25, gamma=2.0)
     assert torch.allclose(FocalLoss(0.25, 2.0)(x, t), want, atol=1e-6)
     assert torch.allclose(FocalLoss(0.25, 2.0, reduction='sum')(x, t), want.sum(), atol=1e-4)
+    # the reference's remaining IOUloss conventions (losses.py:18-66): per-box weights, 0. for an empty match set, the GIoU form
+    w = torch.rand(64, generator=g) + 0.5
+    assert torch.allclose(IOUloss()(pred, tgt, w), oh.iou_loss_fn(pred, tgt) * w, atol=1e-6)
+    assert IOUloss()(pred[:0], tgt[:0]) == 0.
+    a0, a1 = pred[:, :2] - pred[:, 2:] / 2, pred[:, :2] + pred[:, 2:] / 2
+    b0, b1 = tgt[:, :2] - tgt[:, 2:] / 2, tgt[:, :2] + tgt[:, 2:] / 2
+    inter = (torch.minimum(a1, b1) - torch.maximum(a0, b0)).clamp(min=0).prod(1)
+    union = pred[:, 2:].prod(1) + tgt[:, 2:].prod(1) - inter
+    hull = (torch.maximum(a1, b1) - torch.minimum(a0, b0)).prod(1)
+    giou = inter / union - (hull - union) / hull
+    assert torch.allclose(IOUloss(loss_type='giou')(pred, tgt), 1 - giou, atol=1e-5)
+    assert float(IOUloss(loss_type='giou')(pred, tgt)[:8].min()) > 1.0          # disjoint boxes: GIoU < 0
+
+
+def test_pick_loss_gradient_is_zero_padded():
+    """PickLossFn hands a true [g, 0, 0, 0, 0, 0] to its producer: a node placed between it and HeadTailFn sees the real gradient."""
+    import torch
+    from leod_amd.functions import PickLossFn
+    v = torch.arange(6, dtype=torch.float32, requires_grad=True)
+    (PickLossFn.apply(v * 2.0) * 3.0).backward()
+    assert v.grad.tolist() == [6.0, 0.0, 0.0, 0.0, 0.0, 0.0]
