@@ -244,6 +244,22 @@ int leod_yolox_loss(const float* outputs, const float* labels, const unsigned ch
                     double* sums, float* losses, float* d_raw, int B, int Nmax, int nc, int nlv, const int* hs,
                     const int* ws, const int* strides, int focal, float reg_weight, float obj_weight, float cls_weight,
                     float grad_scale, leod_stream_t stream);
+/* leod_yolox_loss under ``bbox_loss_weighting`` (_get_bbox_loss_weight, yolo_head.py:358-381; normalisation :550-553 / :928-931):
+ * label_w [B,Nmax] = the configured expression of each label row's obj / cls / obj*cls confidence; the IoU and class terms of a
+ * foreground anchor and their gradients are scaled by label_w[its box] / (mean of that over the batch's foreground anchors).
+ * wsum[1] double caller-zeroed (the sum behind the mean). */
+int leod_yolox_loss_weighted(const float* outputs, const float* labels, const unsigned char* fg_mask,
+                             const unsigned char* ignore_mask, const int* matched_row, const float* pred_iou, const int* totals,
+                             const float* label_w, double* wsum, double* sums, float* losses, float* d_raw, int B, int Nmax, int nc,
+                             int nlv, const int* hs, const int* ws, const int* strides, int focal, float reg_weight,
+                             float obj_weight, float cls_weight, float grad_scale, leod_stream_t stream);
+/* ``ignore_bg_k`` (_get_highest_score_mask, yolo_head.py:335-356, applied at :541-542): marks in ignore_mask [B,A] the
+ * int(#background anchors * k) highest objectness logits (outputs[...,4]) among each image's background anchors (fg_mask == 0), so
+ * that leod_yolox_loss leaves them out of the objectness term.  Does nothing when any label row carries ignore_label: such a
+ * batch takes the reference's get_losses_w_ignore, which has no such step.  0 < k <= 1; ties at the threshold go to the lowest
+ * anchor indices (torch.topk leaves that order unspecified). */
+int leod_bg_topk_ignore(const float* outputs, const float* labels, const unsigned char* fg_mask, unsigned char* ignore_mask,
+                        int B, int Nmax, int A, int nc, double k, float ignore_label, leod_stream_t stream);
 
 /* ---- post-processing (models/detection/yolox/utils/boxes.py:32-86; modules/utils/ssod.py:40-188) -- */
 

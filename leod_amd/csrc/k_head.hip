@@ -443,12 +443,15 @@ __global__ __launch_bounds__(256) void yolox_loss_kernel(const float* __restrict
                                                          const int* __restrict__ matched_row, const float* __restrict__ pred_iou,
                                                          const int* __restrict__ totals, double* __restrict__ sums,
                                                          float* __restrict__ d_raw, Levels L, int B, int Nmax, int nc,
-                                                         int focal, float reg_w, float obj_w, float cls_w, float gscale) {
+                                                         int focal, float reg_w, float obj_w, float cls_w, float gscale,
+                                                         const float* __restrict__ label_w, const double* __restrict__ wsum) {
     __shared__ double red[3][4];
     const int nch = 5 + nc, A = L.A;
     const int nfg_raw = totals[0];
     const float num_fg = (float)max(nfg_raw, 1);
     const float inv_fg_mean = nfg_raw > 0 ? 1.f / (float)nfg_raw : 0.f;      // IOUloss reduction='mean'
+    // bbox_loss_weighting (:550-553): per-box weights divided by their mean over the batch's foreground anchors
+    const float wnorm = label_w ? (float)nfg_raw / (float)wsum[0] : 1.f;
     double s_iou = 0.0, s_obj = 0.0, s_cls = 0.0;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long)B * A; idx += (long)gridDim.x * blockDim.x) {
         const int b = (int)(idx / A), a = (int)(idx - (long)b * A);
@@ -468,7 +471,8 @@ __global__ __launch_bounds__(256) void yolox_loss_kernel(const float* __restrict
             const float area_i = iw * ih * en;
             const float u = area_p + area_g - area_i + 1e-16f;
             const float iou = area_i / u;
-            s_iou += (double)(1.f - iou * iou);
+            const float bw = label_w ? label_w[(long)b * Nmax + matched_row[idx]] * wnorm : 1.f;
+            s_iou += (double)((1.f - iou * iou) * bw);
             // d(1 - iou^2)
             const float dl_diou = -2.f * iou;
             const float diou_dI = (u + area_i) / (u * u), diou_dP = -area_i / (u * u);
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(256) void yolox_loss_kernel(const float* __restrict
             const float al = p_l > t_l ? 1.f : 0.f, ar = p_r < t_r ? 1.f : 0.f, at = p_t > t_t ? 1.f : 0.f, ab = p_b < t_b ? 1.f : 0.f;
             const float dI_dpx = dI_dtlx * al + dI_dbrx * ar, dI_dpy = dI_dtly * at + dI_dbry * ab;
             const float dI_dpw = -0.5f * dI_dtlx * al + 0.5f * dI_dbrx * ar, dI_dph = -0.5f * dI_dtly * at + 0.5f * dI_dbry * ab;
-            const float k = reg_w * inv_fg_mean * dl_diou * gscale;
+            const float k = reg_w * inv_fg_mean * dl_diou * gscale * bw;
             g0 = k * diou_dI * dI_dpx; g1 = k * diou_dI * dI_dpy;
             g2 = k * (diou_dI * dI_dpw + diou_dP * ph); g3 = k * (diou_dI * dI_dph + diou_dP * pw);
             // class BCE-with-logits against onehot * matched IoU (:507-509)
@@ -484,8 +488,8 @@ __global__ __launch_bounds__(256) void yolox_loss_kernel(const float* __restrict
             const float piou = pred_iou[idx];
             for (int c = 0; c < nc; ++c) {
                 const float x = pr[5 + c], t = c == gcls ? piou : 0.f;
-                s_cls += (double)(fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x))));
-                if (dr) dr[5 + c] = (sigmoidf_(x) - t) * cls_w / num_fg * gscale;
+                s_cls += (double)((fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)))) * bw);
+                if (dr) dr[5 + c] = (sigmoidf_(x) - t) * cls_w / num_fg * gscale * bw;
             }
         } else if (dr) {
             for (int c = 0; c < nc; ++c) dr[5 + c] = 0.f;
@@ -525,6 +529,85 @@ __global__ __launch_bounds__(256) void yolox_loss_kernel(const float* __restrict
     }
     __syncthreads();
     if (threadIdx.x < 3) atomicAdd(sums + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+// sum of the per-box weights over the foreground anchors (the mean that normalises them, :552)
+__global__ __launch_bounds__(256) void bbox_wsum_kernel(const unsigned char* __restrict__ fg_mask, const int* __restrict__ matched_row,
+                                                        const float* __restrict__ label_w, double* __restrict__ wsum, long BA, int A, int Nmax) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < BA; idx += (long)gridDim.x * blockDim.x)
+        if (fg_mask[idx]) s += (double)label_w[(idx / A) * Nmax + matched_row[idx]];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { const double t = red[0] + red[1] + red[2] + red[3]; if (t != 0.0) atomicAdd(wsum, t); }
+}
+
+// ignore_bg_k (_get_highest_score_mask, :335-356): the n = int(#background anchors * k) highest objectness LOGITS among the anchors
+// SimOTA left in the background are dropped from the objectness loss (marked in ignore_mask).  One workgroup per image: radix select
+// of the n-th largest key (4 x 8 bits), then one marking pass; ties at the threshold go to the lowest anchor indices (torch.topk leaves
+// the order among equal scores unspecified).  The step belongs to get_losses only (:541-542): a batch with any ignore box goes
+// through get_losses_w_ignore, which has no such step -- every workgroup scans the labels and leaves if it finds one.
+__device__ __forceinline__ unsigned f32_order_key(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__global__ __launch_bounds__(1024) void bg_topk_ignore_kernel(const float* __restrict__ outputs, const float* __restrict__ labels,
+                                                              const unsigned char* __restrict__ fg_mask, unsigned char* __restrict__ ignore_mask,
+                                                              int BN, int A, int nch, double kfrac, float ignore_label) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_cnt, s_prefix, s_remain, s_flag;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    if (tid == 0) { s_cnt = 0; s_flag = 0; }
+    __syncthreads();
+    for (int j = tid; j < BN; j += blockDim.x)
+        if (labels[(long)j * 7] == ignore_label) s_flag = 1;
+    const unsigned char* fg = fg_mask + (long)b * A;
+    const float* sc = outputs + (long)b * A * nch + 4;
+    unsigned local = 0;
+    for (int a = tid; a < A; a += blockDim.x) local += fg[a] ? 0u : 1u;
+    if (local) atomicAdd(&s_cnt, local);
+    __syncthreads();
+    if (s_flag) return;
+    const int n = (int)((double)(float)s_cnt * kfrac);
+    if (n <= 0) return;
+    if (tid == 0) { s_prefix = 0; s_remain = (unsigned)n; }
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned prefix = s_prefix, himask = pass ? 0xFFFFFFFFu << (shift + 8) : 0u;
+        for (int a = tid; a < A; a += blockDim.x) {
+            if (fg[a]) continue;
+            const unsigned key = f32_order_key(sc[(long)a * nch]);
+            if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned remain = s_remain;
+            int d = 255;
+            for (; d > 0; --d) { if (hist[d] >= remain) break; remain -= hist[d]; }
+            s_prefix = prefix | ((unsigned)d << shift);
+            s_remain = remain;                                  // elements still to take among those sharing the new prefix
+        }
+        __syncthreads();
+    }
+    const unsigned thr = s_prefix, take_eq = s_remain;
+    // hist[thr & 255] of the last pass = number of background anchors whose key equals the threshold
+    const bool all_eq = hist[thr & 255u] == take_eq;
+    unsigned char* ig = ignore_mask + (long)b * A;
+    for (int a = tid; a < A; a += blockDim.x) {
+        if (fg[a]) continue;
+        const unsigned key = f32_order_key(sc[(long)a * nch]);
+        if (key > thr || (all_eq && key == thr)) ig[a] = 1;
+    }
+    if (!all_eq && tid == 0) {
+        unsigned left = take_eq;
+        for (int a = 0; a < A && left; ++a)
+            if (!fg[a] && f32_order_key(sc[(long)a * nch]) == thr) { ig[a] = 1; --left; }
+    }
 }
 
 __global__ void yolox_loss_finalize_kernel(const double* __restrict__ sums, const int* __restrict__ totals, float* __restrict__ losses,
@@ -863,8 +946,43 @@ LEOD_API int leod_yolox_loss(const float* outputs, const float* labels, const un
     if (B > 0)
         hipLaunchKernelGGL(yolox_loss_kernel, dim3(flat_grid((long)B * L.A)), dim3(256), 0, stream, outputs, labels, fg_mask,
                            ignore_mask, matched_row, pred_iou, totals, sums, d_raw, L, B, Nmax, nc, focal, reg_weight,
-                           obj_weight, cls_weight, grad_scale);
+                           obj_weight, cls_weight, grad_scale, (const float*)nullptr, (const double*)nullptr);
     hipLaunchKernelGGL(yolox_loss_finalize_kernel, dim3(1), dim3(1), 0, stream, sums, totals, losses, reg_weight, obj_weight, cls_weight);
+    return leod_launch_status();
+}
+
+// leod_yolox_loss with bbox_loss_weighting (yolo_head.py:358-381, :550-553): label_w [B, Nmax] = the configured expression of every
+// label row's confidence (the host evaluates it on the label tensor: it is elementwise, so gathering after it equals the reference's
+// order); the IoU and class terms (and their gradients) of a foreground anchor are scaled by label_w[its box] / mean over all
+// foreground anchors of the batch.  wsum[1] double, caller-zeroed.
+LEOD_API int leod_yolox_loss_weighted(const float* outputs, const float* labels, const unsigned char* fg_mask,
+                                      const unsigned char* ignore_mask, const int* matched_row, const float* pred_iou,
+                                      const int* totals, const float* label_w, double* wsum, double* sums, float* losses, float* d_raw,
+                                      int B, int Nmax, int nc, int nlv, const int* hs, const int* wsz, const int* strides, int focal,
+                                      float reg_weight, float obj_weight, float cls_weight, float grad_scale, hipStream_t stream) {
+    if (!outputs || !labels || !fg_mask || !ignore_mask || !matched_row || !pred_iou || !totals || !sums || !losses || !label_w || !wsum)
+        return LEOD_ERR_ARG;
+    const Levels L = make_levels(nlv, hs, wsz, strides);
+    if (B > 0) {
+        hipLaunchKernelGGL(bbox_wsum_kernel, dim3(flat_grid((long)B * L.A)), dim3(256), 0, stream, fg_mask, matched_row, label_w, wsum,
+                           (long)B * L.A, L.A, Nmax);
+        hipLaunchKernelGGL(yolox_loss_kernel, dim3(flat_grid((long)B * L.A)), dim3(256), 0, stream, outputs, labels, fg_mask,
+                           ignore_mask, matched_row, pred_iou, totals, sums, d_raw, L, B, Nmax, nc, focal, reg_weight,
+                           obj_weight, cls_weight, grad_scale, label_w, (const double*)wsum);
+    }
+    hipLaunchKernelGGL(yolox_loss_finalize_kernel, dim3(1), dim3(1), 0, stream, sums, totals, losses, reg_weight, obj_weight, cls_weight);
+    return leod_launch_status();
+}
+
+// ignore_bg_k (yolo_head.py:335-356, :541-542): outputs [B, A, 5 + nc] (objectness LOGIT in column 4), labels [B, Nmax, 7] after
+// _ignore_bbox, fg_mask / ignore_mask [B, A] of leod_simota_assign; marks the top int(#background * k) background logits of every
+// image in ignore_mask -- unless any label row carries ignore_label (then the reference's other loss routine runs, without this step).
+LEOD_API int leod_bg_topk_ignore(const float* outputs, const float* labels, const unsigned char* fg_mask, unsigned char* ignore_mask,
+                                 int B, int Nmax, int A, int nc, double k, float ignore_label, hipStream_t stream) {
+    if (!outputs || !labels || !fg_mask || !ignore_mask || A <= 0 || !(k <= 1.0)) return LEOD_ERR_ARG;
+    if (B == 0 || !(k > 0.0)) return LEOD_OK;
+    hipLaunchKernelGGL(bg_topk_ignore_kernel, dim3(B), dim3(1024), 0, stream, outputs, labels, fg_mask, ignore_mask, B * Nmax, A, 5 + nc,
+                       k, ignore_label);
     return leod_launch_status();
 }
 

@@ -673,10 +673,12 @@ class HeadTailFn(Function):
             a0 += hws[k][0] * hws[k][1]
         labels = mod._ignore_bbox(labels)
         asg = ops.simota_assign(out_train, labels, hws, mod.strides, ignore_label=float(mod.ignore_label))
+        if mod.ignore_bg_k > 0:                                  # top fraction of the background objectness logits leaves the loss (:541-542)
+            ops.bg_topk_ignore(out_train, labels, asg, mod.ignore_bg_k, ignore_label=float(mod.ignore_label))
         need = any(ctx.needs_input_grad)
         losses, d_raw = ops.yolox_loss(out_train, labels, asg, hws, mod.strides, want_grad=need,
                                        focal=mod.obj_focal_loss, reg_weight=mod.reg_weight, obj_weight=mod.obj_weight,
-                                       cls_weight=mod.cls_weight)
+                                       cls_weight=mod.cls_weight, label_w=mod._bbox_label_weights(labels))
         mod.last_assignment = asg
         if need:
             ctx.mod, ctx.offs = mod, offs

@@ -26,8 +26,12 @@ class YOLOXHead(nn.Module):
                  compile_cfg: Optional[Dict] = None, obj_focal_loss=False, bbox_loss_weighting='', ignore_bg_k=-1,
                  reg_weight=5.0, obj_weight=1.0, cls_weight=1.0, ignore_bbox_thresh=None, ignore_label=1024):
         super().__init__()
-        if depthwise or bbox_loss_weighting or (ignore_bg_k is not None and ignore_bg_k > 0):
-            raise NotImplementedError('HIP head: depthwise / bbox_loss_weighting / ignore_bg_k are off in every shipped config')
+        if depthwise:
+            raise NotImplementedError('HIP head: depthwise convolutions are off in every shipped config')
+        if ignore_bg_k is not None and ignore_bg_k > 1:
+            raise ValueError('ignore_bg_k is a fraction of the background anchors')
+        if bbox_loss_weighting and bbox_loss_weighting.split('-', 1)[0] not in ('obj', 'cls', 'objxcls'):
+            raise NotImplementedError(f'Unknow {bbox_loss_weighting=}')
         self.num_classes = num_classes
         self.decode_in_inference = True
         self.cls_convs, self.reg_convs = nn.ModuleList(), nn.ModuleList()
@@ -51,7 +55,7 @@ class YOLOXHead(nn.Module):
         self.iou_loss = IOUloss(reduction="mean")
         self.strides = tuple(int(s) for s in strides)
         self.reg_weight, self.obj_weight, self.cls_weight = reg_weight, obj_weight, cls_weight
-        self.ignore_bg_k = ignore_bg_k
+        self.ignore_bg_k = ignore_bg_k if ignore_bg_k is not None else -1
         self.bbox_loss_weighting = bbox_loss_weighting
         self.ignore_bbox_thresh = ignore_bbox_thresh
         self.ignore_label = ignore_label
@@ -65,6 +69,22 @@ class YOLOXHead(nn.Module):
         for conv in list(self.cls_preds) + list(self.obj_preds):
             with torch.no_grad():
                 conv.bias.fill_(v)
+
+    @torch.no_grad()
+    def _bbox_label_weights(self, labels):
+        """``bbox_loss_weighting`` (reference :358-381): 'obj' | 'cls' | 'objxcls', optionally followed by '-<expression of w>'
+        ('cls-w**2'), evaluated here on every label ROW (labels [B,N,7]) -- the expression is elementwise, so weighting a foreground
+        anchor by the value of its matched row equals the reference's evaluate-after-gather; the kernel does the gather and the
+        division by the batch mean.  None when the option is off."""
+        if not self.bbox_loss_weighting:
+            return None
+        val, expr = self.bbox_loss_weighting.split('-', 1) if '-' in self.bbox_loss_weighting else (self.bbox_loss_weighting, 'w')
+        obj_conf, cls_conf = labels[:, :, 5], labels[:, :, 6]
+        w = obj_conf if val == 'obj' else cls_conf if val == 'cls' else obj_conf * cls_conf
+        w = eval(expr, {'torch': torch, 'math': math}, {'w': w})  # noqa: S307  (the reference evaluates the configured string, :376)
+        if not torch.is_tensor(w) or w.shape != obj_conf.shape:
+            raise ValueError('bbox_loss_weighting: the expression must be elementwise in w')
+        return w.to(torch.float32).contiguous()
 
     @torch.no_grad()
     def _ignore_bbox(self, labels):

@@ -885,13 +885,35 @@ def simota_assign(outputs, labels, hws, strides, ignore_label=1024.0):
     return r
 
 
+def bg_topk_ignore(outputs, labels, assign, k, ignore_label=1024.0):
+    """``ignore_bg_k`` of the YOLOX head (yolo_head.py:335-356): marks the top ``k`` fraction of each image's background objectness logits
+    in ``assign['ignore_mask']`` (in place), unless the batch holds an ignore box."""
+    B, A, nch = outputs.shape
+    check(_l().leod_bg_topk_ignore(_p(outputs), _p(labels), _p(assign['fg_mask']), _p(assign['ignore_mask']), B, labels.shape[1], A,
+                                    nch - 5, float(k), float(ignore_label), _stream()), 'bg_topk_ignore')
+
+
 def yolox_loss(outputs, labels, assign, hws, strides, want_grad=True, focal=False, reg_weight=5.0, obj_weight=1.0,
-               cls_weight=1.0, grad_scale=1.0):
+               cls_weight=1.0, grad_scale=1.0, label_w=None):
+    """label_w [B, Nmax] (``bbox_loss_weighting``): per-label weights of the IoU / class terms, normalised on the device to mean 1 over
+    the batch's foreground anchors."""
     B, A, nch = outputs.shape
     dev = outputs.device
     sums = StatArena.zeros((3,), dev, torch.float64)
     losses = torch.empty((6,), dtype=F32, device=dev)
     d_raw = torch.empty_like(outputs) if want_grad else None
+    if label_w is not None:
+        _ck(label_w, name='label_w')
+        if tuple(label_w.shape) != tuple(labels.shape[:2]):
+            raise ValueError('yolox_loss: one weight per label row')
+        wsum = StatArena.zeros((1,), dev, torch.float64)
+        check(_l().leod_yolox_loss_weighted(_p(outputs), _p(labels), _p(assign['fg_mask']), _p(assign['ignore_mask']),
+                                             _p(assign['matched_row']), _p(assign['pred_iou']), _p(assign['totals']), _p(label_w),
+                                             _p(wsum), _p(sums), _p(losses), _p(d_raw), B, labels.shape[1], nch - 5, len(hws),
+                                             _iarr([h for h, _ in hws]), _iarr([w for _, w in hws]), _iarr(strides),
+                                             1 if focal else 0, reg_weight, obj_weight, cls_weight, grad_scale, _stream()),
+              'yolox_loss_weighted')
+        return losses, d_raw
     check(_l().leod_yolox_loss(_p(outputs), _p(labels), _p(assign['fg_mask']), _p(assign['ignore_mask']),
                                 _p(assign['matched_row']), _p(assign['pred_iou']), _p(assign['totals']), _p(sums), _p(losses),
                                 _p(d_raw), B, labels.shape[1], nch - 5, len(hws), _iarr([h for h, _ in hws]),

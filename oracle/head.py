@@ -246,11 +246,49 @@ def ignore_bbox_(labels, ignore_bbox_thresh, ignore_label=1024):
     return labels
 
 
+def highest_score_mask(scores, k, exclude_mask=None):
+    """_get_highest_score_mask, yolo_head.py:335-356: the top k (fraction) objectness logits of one image,
+    counted and picked among the anchors outside ``exclude_mask`` (the foreground)."""
+    if k <= 0:
+        return None
+    scores = scores.reshape(-1)
+    if exclude_mask is not None and bool(exclude_mask.any()):
+        n = int((~exclude_mask).float().sum().item() * k)
+        ex = exclude_mask.reshape(-1).type_as(scores)
+        scores = scores * (1. - ex) + ex * (-1e6)
+    else:
+        n = int(scores.shape[0] * k)
+    mask = torch.zeros_like(scores).bool()
+    if n == 0:
+        return mask
+    mask[scores.topk(n, dim=0, largest=True, sorted=False)[1]] = True
+    return mask
+
+
+def bbox_loss_weight(spec, matched_gt_inds, obj_conf, cls_conf):
+    """_get_bbox_loss_weight, yolo_head.py:358-381: 'obj' | 'cls' | 'objxcls', optionally '-<expr of w>' ('cls-w**2')."""
+    if not spec:
+        return None
+    val, expr = spec.split('-', 1) if '-' in spec else (spec, 'w')
+    if val == 'obj':
+        w = obj_conf[matched_gt_inds]
+    elif val == 'cls':
+        w = cls_conf[matched_gt_inds]
+    elif val == 'objxcls':
+        w = obj_conf[matched_gt_inds] * cls_conf[matched_gt_inds]
+    else:
+        raise NotImplementedError(spec)
+    return eval(expr)  # noqa: S307  (the reference evaluates the configured expression the same way, :376)
+
+
 def get_losses(gx, gy, gs, labels, outputs, num_classes=None, obj_focal_loss=False,
                reg_weight=5.0, obj_weight=1.0, cls_weight=1.0, ignore_bbox_thresh=None,
-               ignore_label=1024, return_assign=False):
-    """get_losses / get_losses_w_ignore, yolo_head.py:403-597, 776-972 (use_l1 False,
-    bbox_loss_weighting '', ignore_bg_k 0 -- the shipped configs).
+               ignore_label=1024, return_assign=False, bbox_loss_weighting='', ignore_bg_k=0):
+    """get_losses / get_losses_w_ignore, yolo_head.py:403-597, 776-972 (use_l1 False).  ``bbox_loss_weighting``
+    weighs the IoU and class terms of a foreground anchor by its box's confidence, normalised to batch mean 1
+    (:523-524, :550-553, :903-904, :928-931); ``ignore_bg_k`` drops the top fraction of background objectness
+    logits of each image from the objectness loss -- only on batches without ignore boxes (:541-542, :558-570;
+    get_losses_w_ignore has no such step).
 
     labels [B,N,7] = (cls, cx, cy, w, h, obj_conf, cls_conf), zero rows = padding (assumed to be a
     suffix, :466); outputs [B,A,5+nc] = decoded boxes + obj/cls logits."""
@@ -262,8 +300,9 @@ def get_losses(gx, gy, gs, labels, outputs, num_classes=None, obj_focal_loss=Fal
     nlabel = (nonzero & valid).sum(dim=1)
     nlabel_w = nonzero.sum(dim=1)
     A = outputs.shape[1]
-    cls_t, reg_t, obj_t, fg_ms, ign_ms, assigns = [], [], [], [], [], []
+    cls_t, reg_t, obj_t, fg_ms, ign_ms, assigns, bbox_ws = [], [], [], [], [], [], []
     num_fg, num_gts = 0.0, 0.0
+    top_bg = ignore_bg_k > 0 and not bool((labels[:, :, 0] == ignore_label).any())
     for b in range(outputs.shape[0]):
         n = int(nlabel[b])
         num_gts += n
@@ -278,7 +317,7 @@ def get_losses(gx, gy, gs, labels, outputs, num_classes=None, obj_focal_loss=Fal
                 n_ign = int((labels[b, :, 0] == ignore_label).sum())
                 ign = is_in_centers(labels[b, :n_ign, 1:5], gx, gy, gs).sum(0) > 0
             fg_ms.append(fg)
-            ign_ms.append(ign)
+            ign_ms.append(highest_score_mask(obj_preds[b].detach(), ignore_bg_k, fg) if top_bg else ign)
             assigns.append(None)
             continue
         nw = int(nlabel_w[b])
@@ -290,21 +329,28 @@ def get_losses(gx, gy, gs, labels, outputs, num_classes=None, obj_focal_loss=Fal
         obj_t.append(res['fg_mask'].unsqueeze(-1).to(outputs.dtype))
         reg_t.append(labels[b, :nw, 1:5][valid[b, :nw]][res['matched_gt_inds']])
         fg_ms.append(res['fg_mask'])
-        ign_ms.append(res['ignore_mask'])
+        ign_ms.append(highest_score_mask(obj_preds[b].detach(), ignore_bg_k, res['fg_mask']) if top_bg else res['ignore_mask'])
         assigns.append(res)
+        if bbox_loss_weighting:
+            bbox_ws.append(bbox_loss_weight(bbox_loss_weighting, res['matched_gt_inds'], labels[b, :nw, 5][valid[b, :nw]],
+                                            labels[b, :nw, 6][valid[b, :nw]]))
     cls_t, reg_t, obj_t = torch.cat(cls_t, 0), torch.cat(reg_t, 0), torch.cat(obj_t, 0)
     fg_ms, ign_ms = torch.cat(fg_ms, 0), torch.cat(ign_ms, 0)
     num_fg = max(num_fg, 1)
     fg_boxes = bbox_preds.reshape(-1, 4)[fg_ms]
     # IOUloss(reduction='mean'); returns the python float 0. when there is no fg (losses.py:20-21)
-    loss_iou = iou_loss_fn(fg_boxes, reg_t).mean() if fg_boxes.shape[0] > 0 else outputs.new_zeros(())
+    w = 1.
+    if bbox_loss_weighting and bbox_ws:
+        w = torch.cat(bbox_ws, 0)
+        w = w / w.mean()                                            # batch mean 1 (:552)
+    loss_iou = (iou_loss_fn(fg_boxes, reg_t) * w).mean() if fg_boxes.shape[0] > 0 else outputs.new_zeros(())
     keep = ~ign_ms
     ol, ot = obj_preds.reshape(-1, 1)[keep], obj_t[keep]
     obj_l = sigmoid_focal_loss(ol, ot) if obj_focal_loss else \
         F.binary_cross_entropy_with_logits(ol, ot, reduction='none')
     loss_obj = obj_l.sum() / num_fg
-    loss_cls = F.binary_cross_entropy_with_logits(cls_preds.reshape(-1, nc)[fg_ms], cls_t,
-                                                  reduction='none').sum() / num_fg
+    loss_cls = (F.binary_cross_entropy_with_logits(cls_preds.reshape(-1, nc)[fg_ms], cls_t, reduction='none') *
+                (w[:, None] if torch.is_tensor(w) else w)).sum() / num_fg
     loss_iou = reg_weight * loss_iou
     loss_obj = obj_weight * loss_obj
     loss_cls = cls_weight * loss_cls
@@ -322,7 +368,7 @@ def detect_forward(feats, sd, cfg, labels=None, training=False):
     cfg: dict(n_bottleneck, strides, in_stages, + loss kwargs)."""
     fpn = pafpn_forward(feats, sd, cfg['n_bottleneck'], tuple(cfg.get('in_stages', (2, 3, 4))),
                         training=training)
-    kw = {k: cfg[k] for k in ('obj_focal_loss', 'ignore_bbox_thresh', 'ignore_label') if k in cfg}
+    kw = {k: cfg[k] for k in ('obj_focal_loss', 'ignore_bbox_thresh', 'ignore_label', 'bbox_loss_weighting', 'ignore_bg_k') if k in cfg}
     return head_forward(fpn, sd, cfg['strides'], labels=labels, training=training, **kw)
 
 

@@ -919,9 +919,47 @@ def g18_autocast(full_size=True):
             print(k, out[k])
 
 
+def g19_head_options():
+    """The two head-loss options every shipped config leaves off (yolo_head.py:335-381): ``bbox_loss_weighting`` and ``ignore_bg_k``.
+    Losses AND the gradient wrt the decoded predictions of the reference, on the Gen1 anchors; the batch holds an image without labels."""
+    from oracle.head import make_grids
+    gx, gy, gs = make_grids([(32, 40), (16, 20), (8, 10)], (8, 16, 32))
+    A = gx.numel()
+    g = torch.Generator().manual_seed(191)
+    B = 4
+    labs = synth_labels(B, (240, 304), 2, seed=190, max_boxes=6, min_boxes=2)
+    tg = ObjectLabels.get_labels_as_batched_tensor([ObjectLabels(l, (240, 304)) for l in labs])
+    tg[3] = 0
+    nz = (tg.sum(2) > 0).float()
+    tg[:, :, 5] = (0.3 + 0.7 * torch.rand(tg.shape[:2], generator=g)) * nz        # objectness / class confidences of pseudo boxes
+    tg[:, :, 6] = (0.3 + 0.7 * torch.rand(tg.shape[:2], generator=g)) * nz
+    outputs = torch.cat([
+        torch.stack([(gx + 0.5) * gs, (gy + 0.5) * gs, gs * 3, gs * 2.5], 1)[None].repeat(B, 1, 1)
+        + torch.randn(B, A, 4, generator=g), torch.randn(B, A, 3, generator=g)], -1)
+    xs = [gx[None, :1280], gx[None, 1280:1600], gx[None, 1600:]]
+    ys = [gy[None, :1280], gy[None, 1280:1600], gy[None, 1600:]]
+    ss = [gs[None, :1280], gs[None, 1280:1600], gs[None, 1600:]]
+    tg_ign = tg.clone()
+    tg_ign[0, 1, 0] = 1024
+    out = dict(targets=tg, targets_ign=tg_ign, outputs=outputs)
+    cases = dict(w_obj=dict(bbox_loss_weighting='obj'), w_cls=dict(bbox_loss_weighting='cls'), w_objxcls=dict(bbox_loss_weighting='objxcls'),
+                 w_cls_sq=dict(bbox_loss_weighting='cls-w**2'), bg05=dict(ignore_bg_k=0.05), bg30=dict(ignore_bg_k=0.3),
+                 w_obj_bg10=dict(bbox_loss_weighting='obj', ignore_bg_k=0.1), w_obj_focal=dict(bbox_loss_weighting='obj', obj_focal_loss=True))
+    for name, kw in cases.items():
+        head = YoloXDetector(make_cfg(32, 32, 0.33, (256, 320), (8, 10), **kw)).yolox_head
+        for suffix, targets in (('', tg), ('_ign', tg_ign)):              # '_ign': a batch WITH an ignore box (get_losses_w_ignore, no top-k step)
+            o = outputs.clone().requires_grad_(True)
+            res = head.get_losses(xs, ys, ss, targets.clone(), o, [], torch.float32)
+            res[0].backward()
+            out[f'{name}{suffix}_losses'] = np.array([float(r) for r in res], dtype=np.float64)
+            out[f'{name}{suffix}_grad'] = o.grad.clone()
+    save('g19_head_options.npz', **out)
+
+
 ALL = dict(g01=g01_convlstm, g02=g02_partition, g03=g03_attention, g04=g04_backbone, g05=g05_head,
            g06=g06_simota, g07=g07_postprocess, g08=g08_pseudo, g10=g10_voxel, g11=g11_manifest,
-           g12=g12_trainstep, g13=g13_tracker, g14=g14_augment, g15=g15_evaluator, g16=g16_tta_result, g17=g17_loader, g18=g18_autocast)
+           g12=g12_trainstep, g13=g13_tracker, g14=g14_augment, g15=g15_evaluator, g16=g16_tta_result, g17=g17_loader, g18=g18_autocast,
+           g19=g19_head_options)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)

@@ -508,6 +508,97 @@ def test_simota_and_loss(ops, seed, with_ignore, geom):
     close(d_raw, gref, rtol=1e-4, atol=1e-7)
 
 
+HEAD_OPTION_CASES = dict(w_obj=dict(bbox_loss_weighting='obj'), w_cls=dict(bbox_loss_weighting='cls'), w_objxcls=dict(bbox_loss_weighting='objxcls'),
+                         w_cls_sq=dict(bbox_loss_weighting='cls-w**2'), bg05=dict(ignore_bg_k=0.05), bg30=dict(ignore_bg_k=0.3),
+                         w_obj_bg10=dict(bbox_loss_weighting='obj', ignore_bg_k=0.1), w_obj_focal=dict(bbox_loss_weighting='obj', obj_focal_loss=True))
+
+
+def _head_with_options(strides, nc=2, **kw):
+    from leod_amd.models.detection.yolox.models.yolo_head import YOLOXHead
+    return YOLOXHead(num_classes=nc, strides=strides, in_channels=(32, 64, 128), **kw)
+
+
+def _loss_with_options(ops, head, od, td, hws, strides):
+    """The option steps in the order of HeadTailFn.forward: ignore thresholds, SimOTA, top-k background, weighted losses."""
+    td = head._ignore_bbox(td.clone())
+    asg = ops.simota_assign(od, td, hws, strides, ignore_label=float(head.ignore_label))
+    if head.ignore_bg_k > 0:
+        ops.bg_topk_ignore(od, td, asg, head.ignore_bg_k, ignore_label=float(head.ignore_label))
+    losses, d_raw = ops.yolox_loss(od, td, asg, hws, strides, focal=head.obj_focal_loss, label_w=head._bbox_label_weights(td))
+    return losses, d_raw, asg
+
+
+@pytest.mark.parametrize('name', sorted(HEAD_OPTION_CASES))
+def test_head_loss_options_golden(ops, golden_dir, name):
+    """bbox_loss_weighting / ignore_bg_k (yolo_head.py:335-381) against the losses AND gradients the reference produced (g19); '_ign' is the
+    same batch with one ignore box, which takes the reference through get_losses_w_ignore (weights apply, no top-k step)."""
+    g = np.load(os.path.join(golden_dir, 'g19_head_options.npz'))
+    hws, strides = [(32, 40), (16, 20), (8, 10)], (8, 16, 32)
+    gx, gy, gs = oh.make_grids(hws, strides)
+    outp = torch.from_numpy(g['outputs'])
+    head = _head_with_options(strides, **HEAD_OPTION_CASES[name])
+    for suffix, key in (('', 'targets'), ('_ign', 'targets_ign')):
+        losses, d_raw, _ = _loss_with_options(ops, head, outp.to(DEV), torch.from_numpy(g[key]).to(DEV), hws, strides)
+        close(losses, g[f'{name}{suffix}_losses'], rtol=2e-5, atol=1e-6)
+        gref = torch.from_numpy(g[f'{name}{suffix}_grad']).clone()           # reference gradient wrt the decoded boxes -> raw conv outputs
+        gref[..., 0:2] *= gs[None, :, None]
+        gref[..., 2:4] *= outp[..., 2:4]
+        close(d_raw, gref, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize('geom,kfrac,quant', [('gen1', 0.02, 0), ('gen4', 0.25, 0), ('1mpx', 0.1, 0), ('gen1', 0.3, 8), ('1mpx', 0.07, 4)])
+def test_bg_topk_ignore_vs_oracle(ops, geom, kfrac, quant):
+    """The per-image top-k background mask at the three head sizes against the oracle's topk; ``quant`` rounds the objectness logits to a
+    grid so that many anchors tie at the threshold: the mask then has the oracle's COUNT and the same multiset of values (which of the
+    tied anchors are taken is unspecified in torch.topk)."""
+    B = 4
+    hws, strides, (gx, gy, gs), outputs, tg = _gen1_case(B, 11, geom=geom)
+    if quant:
+        outputs[..., 4] = torch.round(outputs[..., 4] * quant) / quant
+    nc = HEAD_GEOMS[geom][2]
+    od, td = outputs.to(DEV), tg.to(DEV)
+    asg = ops.simota_assign(od, td, hws, strides)
+    fg = asg['fg_mask'].cpu().bool()
+    assert not bool(asg['ignore_mask'].any())
+    ops.bg_topk_ignore(od, td, asg, kfrac)
+    got = asg['ignore_mask'].cpu().bool()
+    for b in range(B):
+        want = oh.highest_score_mask(outputs[b, :, 4:5], kfrac, fg[b])
+        assert int(got[b].sum()) == int(want.sum()) > 0
+        assert not bool((got[b] & fg[b]).any())
+        if quant:
+            assert torch.equal(outputs[b, :, 4][got[b]].sort()[0], outputs[b, :, 4][want].sort()[0])
+        else:
+            assert torch.equal(got[b], want)
+    # a batch with an ignore box: the step is skipped altogether
+    tg2 = tg.clone()
+    tg2[0, 0, 0] = 1024
+    asg2 = ops.simota_assign(od, tg2.to(DEV), hws, strides)
+    before = asg2['ignore_mask'].clone()
+    ops.bg_topk_ignore(od, tg2.to(DEV), asg2, kfrac)
+    assert torch.equal(before, asg2['ignore_mask'])
+    # full loss with both options at this size against the oracle
+    head = _head_with_options(strides, nc=nc, bbox_loss_weighting='objxcls-w**0.5', ignore_bg_k=kfrac)
+    g = torch.Generator().manual_seed(5)
+    tg3 = tg.clone()
+    nz = (tg3.sum(2) > 0).float()
+    tg3[:, :, 5] = (0.2 + 0.8 * torch.rand(tg3.shape[:2], generator=g)) * nz
+    tg3[:, :, 6] = (0.2 + 0.8 * torch.rand(tg3.shape[:2], generator=g)) * nz
+    outr = outputs.clone().requires_grad_(True)
+    ref = oh.get_losses(gx, gy, gs, tg3.clone(), outr, num_classes=nc, bbox_loss_weighting='objxcls-w**0.5', ignore_bg_k=kfrac)
+    ref['loss'].backward()
+    losses, d_raw, _ = _loss_with_options(ops, head, od, tg3.to(DEV), hws, strides)
+    want = torch.tensor([float(ref[k]) for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')])
+    if not quant:
+        close(losses, want, rtol=2e-5, atol=1e-6)
+        gref = outr.grad.clone()
+        gref[..., 0:2] *= gs[None, :, None]
+        gref[..., 2:4] *= outputs[..., 2:4]
+        close(d_raw, gref, rtol=1e-4, atol=1e-7)
+    else:                                                   # tied picks may differ, their loss contributions do not
+        close(losses, want, rtol=2e-5, atol=1e-6)
+
+
 def test_simota_golden(ops, golden_dir):
     g = np.load(os.path.join(golden_dir, 'g06_simota.npz'))
     hws, strides = [(32, 40), (16, 20), (8, 10)], (8, 16, 32)

@@ -142,6 +142,47 @@ def test_detector_head_golden_and_grads(gpu, golden_dir, manifest):
     np.testing.assert_allclose(mine, g['grad_norms'], rtol=2e-3, atol=1e-6)
 
 
+def test_detector_head_with_loss_options_vs_oracle(gpu, manifest):
+    """``bbox_loss_weighting`` + ``ignore_bg_k`` (off in the shipped configs, yolo_head.py:335-381) through the whole detection head
+    (FPN -> towers -> HeadTailFn): losses and the gradients of the backbone features / parameters against the oracle's autograd."""
+    det, sd, _ = build(manifest, 'micro', 5, 'small', micro=True)
+
+    def rnd(shape, seed):
+        return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+    feats_cpu = {2: rnd((3, 32, 8, 12), 51), 3: rnd((3, 64, 4, 6), 52), 4: rnd((3, 128, 2, 3), 53)}
+    labs = micro_labels(3, seed=7)
+    targets = op.batched_yolox_labels(labs)
+    g = torch.Generator().manual_seed(9)
+    nz = (targets.sum(2) > 0).float()
+    targets[:, :, 5] = (0.3 + 0.7 * torch.rand(targets.shape[:2], generator=g)) * nz
+    targets[:, :, 6] = (0.3 + 0.7 * torch.rand(targets.shape[:2], generator=g)) * nz
+    det.yolox_head.bbox_loss_weighting, det.yolox_head.ignore_bg_k = 'cls-w**2', 0.2
+    det.train()
+    fg = {k: v.to(DEV).requires_grad_(True) for k, v in feats_cpu.items()}
+    _, losses = det.forward_detect(fg, targets=targets.to(DEV))
+    losses['loss'].backward()
+    assert int(det.yolox_head.last_assignment['ignore_mask'].sum()) > 0
+    osd = {k: v.clone() for k, v in sd.items()}
+    pkeys = [k for k, v in osd.items() if v.is_floating_point() and 'running_' not in k]
+    for k in pkeys:
+        osd[k].requires_grad_(True)
+    fo = {k: v.clone().requires_grad_(True) for k, v in feats_cpu.items()}
+    _, olosses = oh.detect_forward(fo, osd, dict(MICRO, bbox_loss_weighting='cls-w**2', ignore_bg_k=0.2), labels=targets.clone(), training=True)
+    olosses['loss'].backward()
+    _, plain = oh.detect_forward({k: v.clone() for k, v in feats_cpu.items()}, {k: v.detach() for k, v in osd.items()}, MICRO,
+                                 labels=targets.clone(), training=True)
+    assert abs(float(plain['loss']) - float(olosses['loss'])) > 1e-3          # the options do change this batch's loss
+    for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg'):
+        close(losses[k], float(olosses[k]), rtol=5e-5, what=k)
+    params = dict(det.named_parameters())
+    for k in pkeys:
+        if osd[k].grad is not None:
+            close(params[k].grad, osd[k].grad, rtol=2e-3, atol=2e-5, what='grad ' + k)
+    for k in fo:
+        close(fg[k].grad, fo[k].grad, rtol=2e-3, atol=2e-5, what=f'grad feature {k}')
+
+
 def test_head_level_streams_equal_single_stream(gpu, manifest, monkeypatch):
     """The per-level HIP streams of the head towers (yolo_head._towers_streams) only reorder independent launches: predictions, losses
     and BatchNorm buffers are bit-identical to the grouped single-stream path and the gradients agree to the order of their fp32

@@ -409,6 +409,43 @@ def test_module_plan_replay_equals_eager(gpu, manifest):
             np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4)
 
 
+def test_module_head_loss_options_through_plans_equal_eager(gpu, manifest):
+    """``model.head.bbox_loss_weighting`` / ``ignore_bg_k`` (off in the shipped configs) through ``Module.training_step``: the extra launches
+    (per-row weights, the sum behind their mean, the top-k background selection) are part of the captured head pass; four steps of plan
+    mode equal four eager steps, and the options do change the losses."""
+    from leod_amd.optim import fit_step
+    L, B = 4, 2
+    keys6 = ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')
+    res = {}
+    for tag, plan, opts in (('plain', False, False), ('eager', False, True), ('plan', True, True)):
+        mod, _, cfg = micro_module(manifest, 9, 'fit')
+        cfg.training.lr_scheduler.total_steps = 1000
+        if opts:
+            mod.mdl.yolox_head.bbox_loss_weighting, mod.mdl.yolox_head.ignore_bg_k = 'objxcls', 0.15
+        mod.train()
+        mod.plan_mode = plan
+        oc = mod.configure_optimizers()
+        opt, sched = oc['optimizer'], oc['lr_scheduler']['scheduler']
+        out_l = []
+        for step in range(4):
+            ev = synth_events(L, B, 20, HW[0], HW[1], seed=90 + step, as_uint8=True)
+            flat = micro_labels(3, 95 + step, [1e6, 2e6, 2e6])
+            g = torch.Generator().manual_seed(500 + step)
+            for l in flat:                                   # pseudo-label confidences (columns 6, 7 of the loader's label rows)
+                l[:, 6] = 0.3 + 0.7 * torch.rand(l.shape[0], generator=g)
+                l[:, 7] = 0.3 + 0.7 * torch.rand(l.shape[0], generator=g)
+            labels_tb = [[None, None], [flat[0], None], [None, None], [flat[1], flat[2]]]
+            out = fit_step(mod, opt, sched, loader_batch(ev, labels_tb, torch.tensor([step == 0, step % 2 == 0])), step)
+            out_l.append([float(out['log_dict'][f'train/{k}'].detach()) for k in keys6])
+        res[tag] = (np.array(out_l), opt.flat.data.detach().cpu().numpy().copy())
+        if plan:
+            pl = mod._plans
+            assert (pl.captures, pl.head_captures, pl.steps, pl.replays, pl.eager_steps) == (1, 1, 3, 2, 1), pl.info()
+    np.testing.assert_allclose(res['plan'][0], res['eager'][0], rtol=2e-4, atol=1e-5)
+    assert np.abs(res['plan'][1] - res['eager'][1]).max() < 2e-3
+    assert np.abs(res['eager'][0][:, 0] - res['plain'][0][:, 0]).min() > 1e-3      # weighted + top-k-ignored losses differ from the plain ones
+
+
 def test_module_plans_with_varying_label_counts_equal_eager(gpu, manifest):
     """The labelled-frame count B' is data dependent (modules/detection.py:209-224; the reference's static-shape unit is the backbone,
     config/model/maxvit_yolox/default.yaml:8-11).  Twelve optimisation steps whose B' takes SIX distinct values (1 .. 6 of the 8 frames,

@@ -194,6 +194,30 @@ def test_g06_simota(golden_dir):
                                g['thr_losses'], rtol=2e-6)
 
 
+HEAD_OPTION_CASES = dict(w_obj=dict(bbox_loss_weighting='obj'), w_cls=dict(bbox_loss_weighting='cls'), w_objxcls=dict(bbox_loss_weighting='objxcls'),
+                         w_cls_sq=dict(bbox_loss_weighting='cls-w**2'), bg05=dict(ignore_bg_k=0.05), bg30=dict(ignore_bg_k=0.3),
+                         w_obj_bg10=dict(bbox_loss_weighting='obj', ignore_bg_k=0.1), w_obj_focal=dict(bbox_loss_weighting='obj', obj_focal_loss=True))
+
+
+@pytest.mark.parametrize('name', sorted(HEAD_OPTION_CASES))
+def test_g19_head_loss_options(golden_dir, name):
+    """bbox_loss_weighting / ignore_bg_k (yolo_head.py:335-381) against the reference's losses and gradients; the '_ign' batch holds an
+    ignore box, which sends the reference through get_losses_w_ignore (weights apply, the top-k background step does not)."""
+    g = G(golden_dir, 'g19_head_options.npz')
+    gx, gy, gs = oh.make_grids([(32, 40), (16, 20), (8, 10)], (8, 16, 32))
+    outp = torch.from_numpy(g['outputs'])
+    for suffix, key in (('', 'targets'), ('_ign', 'targets_ign')):
+        o = outp.clone().requires_grad_(True)
+        r = oh.get_losses(gx, gy, gs, torch.from_numpy(g[key]).clone(), o, num_classes=2, **HEAD_OPTION_CASES[name])
+        r['loss'].backward()
+        got = np.array([float(r[k]) for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')])
+        np.testing.assert_allclose(got, g[f'{name}{suffix}_losses'], rtol=2e-6)
+        np.testing.assert_allclose(o.grad.numpy(), g[f'{name}{suffix}_grad'], rtol=1e-5, atol=1e-9)
+    if 'bg' in name:                                        # the option does change the objectness term, and only without ignore boxes
+        base = oh.get_losses(gx, gy, gs, torch.from_numpy(g['targets']).clone(), outp.clone(), num_classes=2)
+        assert float(base['conf_loss']) > g[f'{name}_losses'][2] * 1.01
+
+
 @pytest.mark.parametrize('name,nc,conf,agn', [
     ('rand_c0.1', 2, 0.1, False), ('rand_c0.01', 2, 0.01, False), ('rand_c0.001', 2, 0.001, False),
     ('rand_agnostic', 2, 0.1, True), ('adv_c0.1', 3, 0.1, False), ('adv_c0.001', 3, 0.001, False),

@@ -9,7 +9,7 @@ if os.path.isdir(src):
 sub = sys.argv[2] if len(sys.argv) > 2 else 'copyBuffer'
 con = sqlite3.connect(src)
 rows = list(con.execute('select start, end, stream_id, name from kernels order by start'))
-short = lambda n: re.sub(r'\(.*$', '', n).replace('void ', '')[:60]
+short = lambda n: re.sub(r'\(.*$', '', n.replace('(anonymous namespace)::', '')).replace('void ', '')[:60]
 idx = [i for i, r in enumerate(rows) if 'adamw' in r[3]]
 seg = rows[idx[-2] + 1: idx[-1] + 1]
 by_stream = collections.defaultdict(list)

@@ -8,7 +8,7 @@ if os.path.isdir(src):
     src = sorted(glob.glob(os.path.join(src, '**', '*.db'), recursive=True))[0]
 con = sqlite3.connect(src)
 rows = list(con.execute('select start, end, stream_id, name from kernels order by start'))
-short = lambda n: re.sub(r'\(.*$', '', n).replace('void ', '')[:110]
+short = lambda n: re.sub(r'\(.*$', '', n.replace('(anonymous namespace)::', '')).replace('void ', '')[:110]
 idx = [i for i, r in enumerate(rows) if 'adamw' in r[3]]
 a, b = idx[-2], idx[-1]
 seg = rows[a + 1:b + 1]

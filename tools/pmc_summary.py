@@ -14,7 +14,7 @@ if q is None:
     sys.exit()
 acc = {}
 for name, gx, gy, cname, val, n in con.execute(q):
-    name = re.sub(r'\(.*$', '', name).replace('void ', '')
+    name = re.sub(r'\(.*$', '', name.replace('(anonymous namespace)::', '')).replace('void ', '')
     if flt and flt not in name:
         continue
     acc.setdefault((name, gx, gy), {})[cname] = (val, n)

@@ -14,7 +14,7 @@ def load(src):
     acc = {}
     for name, cname, val, n in con.execute('select kernel_name, counter_name, sum(value), count(distinct dispatch_id) '
                                            'from counters_collection group by kernel_name, counter_name'):
-        name = re.sub(r'\(.*$', '', name).replace('void ', '')
+        name = re.sub(r'\(.*$', '', name.replace('(anonymous namespace)::', '')).replace('void ', '')
         acc.setdefault(name, {})[cname] = (val, n)
     return acc
 

@@ -23,7 +23,7 @@ def main(src, dst):
                     f'launches={sum(r[1] for r in rows)}', f'first_to_last_kernel_ms={(t1 - t0) / 1e6:.3f}'])
         w.writerow(['kernel', 'calls', 'total_ms', 'avg_us', 'min_us', 'max_us', 'pct'])
         for name, n, s, a, mn, mx in rows:
-            name = re.sub(r'\(.*$', '', name).replace('void ', '')
+            name = re.sub(r'\(.*$', '', name.replace('(anonymous namespace)::', '')).replace('void ', '')
             w.writerow([name, n, f'{s / 1e6:.3f}', f'{a / 1e3:.2f}', f'{mn / 1e3:.2f}', f'{mx / 1e3:.2f}', f'{100 * s / tot:.2f}'])
     print('wrote', dst)
 

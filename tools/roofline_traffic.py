@@ -24,7 +24,7 @@ def load(src, counter):
     inside, pairs = False, 0
     per = collections.defaultdict(list)
     for _, name, val in rows:
-        short = re.sub(r'\(.*$', '', name).replace('void ', '')
+        short = re.sub(r'\(.*$', '', name.replace('(anonymous namespace)::', '')).replace('void ', '')
         if MARK in short:
             if inside:
                 pairs += 1

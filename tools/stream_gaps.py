@@ -8,7 +8,7 @@ if os.path.isdir(src):
 min_gap = float(sys.argv[2]) if len(sys.argv) > 2 else 15.0
 con = sqlite3.connect(src)
 rows = list(con.execute('select start, end, stream_id, name from kernels order by start'))
-short = lambda n: re.sub(r'\(.*$', '', n).replace('void ', '')[:70]
+short = lambda n: re.sub(r'\(.*$', '', n.replace('(anonymous namespace)::', '')).replace('void ', '')[:70]
 main = collections.Counter(r[2] for r in rows).most_common(1)[0][0]
 mr = [r for r in rows if r[2] == main]
 side = [r for r in rows if r[2] != main]
