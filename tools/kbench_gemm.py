@@ -16,9 +16,31 @@ STAGES = {1: (40960 * TB, 48), 2: (10240 * TB, 96), 3: (2560 * TB, 192), 4: (640
 
 
 def timeit(fn, reps):
+    """KBENCH_GRAPH=1: `reps` calls captured in one hipGraph and replayed (GPU time per call without the host's launch rate: repeated
+    eager launches of a < 25 us kernel measure the ~20 us per call of the Python / ctypes launch path instead)."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    if os.environ.get('KBENCH_GRAPH') == '1':
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fn()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / (3 * reps)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -46,8 +68,10 @@ def main():
         if os.environ.get('KBENCH_SHADOW') == '1':
             shadow = torch.empty(flat.numel(), dtype=torch.bfloat16, device=DEV)
             ops.set_weight_shadow(flat, shadow)
+            shadow16 = torch.empty(flat.numel(), dtype=torch.float16, device=DEV)
+            ops.set_weight_shadow_f16(flat, shadow16)
             ops.weight_shadow_refresh()
-            KEEP.append((flat, shadow))
+            KEEP.append((flat, shadow, shadow16))
         u, dyC, dy3, dy4 = r(M, 4 * C), r(M, C), r(M, 3 * C), r(M, 4 * C)
         u16, dy4b, dy3b = u.to(torch.float16), dy4.to(torch.bfloat16), dy3.to(torch.bfloat16)
         Wl = r(4 * C, 2 * C) * .1
