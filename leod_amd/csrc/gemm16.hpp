@@ -1268,7 +1268,12 @@ static inline int launch_gemm_lds(const ALRows& al, const BL& bl, const EP& ep, 
         // into wide outputs are bound by their epilogue traffic, which the many small workgroups of gemm_lds_kernel overlap better
         // (tools/kbench_gemm.py; LEOD_GEMM_WIDE=2 routes every covered shape here)
         static const int wide_mode = getenv("LEOD_GEMM_WIDE") ? atoi(getenv("LEOD_GEMM_WIDE")) : 1;
-        const int ntw = ((!ln || al.stats_in) && (wide_mode >= 2 || ln || K >= 2 * bl.N)) ? gemm_wide_ntw(M, bl.N, K) : 0;
+        // (round 5, tools/kbench_gemm.py graph-timed, profiles/r05_j_gemm_wide_routing_ab.txt) launches of <= 60 k rows (stages 3-4): also the
+        // square projections (proj + LayerScale, its dgrad: 24 -> 16-22 us) and the plain x projection of the ConvLSTM (85 / 75 -> 70 / 67 us); NOT
+        // the dgrad of fc2 through GELU (short contraction, wide output, heavy epilogue: 134 -> 191 us on the wide tiles)
+        bool small_ok = M <= 60000 && (K >= bl.N || (std::is_same<BL, BLRows>::value && std::is_same<EP, EpStore>::value));
+        if constexpr (std::is_same<EP, EpStore>::value) small_ok = small_ok && ep.act != ACT_MUL_GELU_GRAD;
+        const int ntw = ((!ln || al.stats_in) && (wide_mode >= 2 || ln || K >= 2 * bl.N || small_ok)) ? gemm_wide_ntw(M, bl.N, K) : 0;
         if (ntw) {
 #define LEOD_WIDE(F, L, S) { ALRowsM<F, L, S> am; static_cast<ALRows&>(am) = al;                                                     \
                              return ntw == 3 ? launch_gemm_wide<3>(am, bl, ep, M, K, bl.N, s) : launch_gemm_wide<4>(am, bl, ep, M, K, bl.N, s); }
