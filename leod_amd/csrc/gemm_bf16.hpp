@@ -77,7 +77,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_wide_bf16_kernel(AL al, BL b
         const int rbk = tile_f / nblocks_n;
         brow_f = rbk * BM; ncol_f = (tile_f - rbk * nblocks_n) * BN;
 #pragma unroll
-        for (int p = 0; p < RA; ++p) ast[p] = al.init(brow_f + r0 + RS * p, M, 0, false);
+        for (int p = 0; p < RA; ++p) ast[p] = al.init((dbg & 32) ? r0 + RS * p : brow_f + r0 + RS * p, M, 0, false);
     };
     f4 ra[RA], rb[RB];
     typename a_two_phase<AL>::Raw raw_a[RA];
@@ -96,6 +96,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_wide_bf16_kernel(AL al, BL b
         }
     };
     auto stash = [&](int buf) {                                // raw registers -> operand values -> bf16 tiles of buffer `buf`
+        if (dbg & 8) return;
         const int k0 = ch_f * KCH;
         unsigned short* sA = sOp[buf];
         unsigned short* sB = sA + ASZ;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_wide_bf16_kernel(AL al, BL b
                 }
             };
             const int fm = brow_c + BM <= M ? ep.fast_mode() : 0;          // workgroup-uniform
-            dispatch_fast_mode<EP::kFastModes>(fm, ep_tile);
+            if (!(dbg & 16)) dispatch_fast_mode<EP::kFastModes>(fm, ep_tile);
             ch_c = 0;
             ++tile_c;
         }
