@@ -956,10 +956,92 @@ def g19_head_options():
     save('g19_head_options.npz', **out)
 
 
+def _ref_trajectory(mode, steps, perturb=0.0, seed=0, T=5, B=2, nb=16, hw=(60, 90), pad=(64, 96)):
+    """``steps`` AdamW steps of the micro detector through ONE OneCycle schedule (peak 2e-4, pct_start 0.1, the reference's shape,
+    modules/detection.py:498-511) on ``nb`` cycled batches, driven like Module.training_step (sample 0 streams its LSTM state, sample 1
+    restarts every step), in ``mode``: 'fp32' | 'h16f' (torch.autocast(float16) with CUDA autocast's fp32-op placement and GradScaler-style
+    loss scaling: the class the reference trains in, train.py:236-243) | 'acf' (the same placement in bfloat16).  ``perturb``: relative
+    Gaussian noise applied ONCE to the initial weights (the chaos control).  -> loss per step [steps]"""
+    import contextlib
+    padder = InputPadderFromShape(desired_hw=pad)
+    data = []
+    for i in range(nb):
+        ev = padder.pad_tensor_ev_repr(synth_events(T, B, 20, hw[0], hw[1], seed=700 + i, as_uint8=False))
+        labs = micro_labels(T * B, seed=800 + i)
+        data.append((ev, [[labs[t * B + b] if (t in (2, 4) or (t == 1 and b == 0)) else None for b in range(B)] for t in range(T)]))
+    torch.manual_seed(0)
+    det = YoloXDetector(make_cfg(**MICRO))
+    load_synth(det, 9)
+    if perturb:
+        g = torch.Generator().manual_seed(100 + seed)
+        with torch.no_grad():
+            for p in det.parameters():
+                p.mul_(1.0 + perturb * torch.randn(p.shape, generator=g))
+    det.train()
+    opt = torch.optim.AdamW(det.parameters(), lr=2e-4, weight_decay=0)
+    sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=2e-4, div_factor=20, final_div_factor=500, total_steps=steps, pct_start=0.1,
+                                              cycle_momentum=False, anneal_strategy='linear')
+    half = mode == 'h16f'
+    scale, good = 65536.0, 0
+    rnn = RNNStates()
+    seen = []
+    for step in range(steps):
+        ev, labels = data[step % nb]
+        while True:
+            opt.zero_grad(set_to_none=True)
+            ctx = contextlib.ExitStack()
+            if mode in ('h16f', 'acf'):
+                ctx.enter_context(torch.autocast('cpu', dtype=torch.float16 if half else torch.bfloat16))
+                ctx.enter_context(_CudaLikeFp32Ops())
+            with ctx:
+                rnn.reset(worker_id=0, indices_or_bool_tensor=torch.tensor([step == 0, True]))
+                prev = rnn.get_states(worker_id=0)
+                sel = BackboneFeatureSelector()
+                obj_labels = []
+                for t in range(T):
+                    feats, prev = det.forward_backbone(x=ev[t], previous_states=prev)
+                    idx = [b for b in range(B) if labels[t][b] is not None]
+                    if idx:
+                        sel.add_backbone_features(backbone_features=feats, selected_indices=idx)
+                        obj_labels.extend(ObjectLabels(labels[t][b], hw) for b in idx)
+                targets = ObjectLabels.get_labels_as_batched_tensor(obj_label_list=obj_labels, format_='yolox')
+                _, losses = det.forward_detect(backbone_features=sel.get_batched_backbone_features(), targets=targets)
+                (losses['loss'].float() * (scale if half else 1.0)).backward()
+            if not half:
+                break
+            if all(bool(torch.isfinite(p.grad).all()) for p in det.parameters() if p.grad is not None):
+                with torch.no_grad():
+                    for p in det.parameters():
+                        if p.grad is not None:
+                            p.grad.div_(scale)
+                good += 1
+                if good % 2000 == 0:
+                    scale *= 2.0
+                break
+            scale, good = scale / 2.0, 0                       # GradScaler: skip the step, back off, try again
+        rnn.save_states_and_detach(worker_id=0, states=[(h.float(), c.float()) for h, c in prev])
+        torch.nn.utils.clip_grad_value_(det.parameters(), 1.0)
+        opt.step()
+        sch.step()
+        seen.append(float(losses['loss']))
+    return np.array(seen, dtype=np.float64)
+
+
+def g20_trajectory(steps=200):
+    """Whole training trajectories of the reference (micro geometry, ~5 min of CPU): its fp32 run, two fp32 runs from initial weights perturbed
+    by 2^-12 / 2^-9 (how chaotic the observable is in the reference itself) and its fp16-autocast run -- what a 200-step run of the HIP
+    precision modes is compared with (tests/test_module_gpu.py::test_module_200_step_trajectory_vs_reference)."""
+    out = {}
+    for name, mode, eps, seed in (('fp32', 'fp32', 0.0, 0), ('fp32_p12', 'fp32', 2.0 ** -12, 1), ('fp32_p9', 'fp32', 2.0 ** -9, 3), ('h16f', 'h16f', 0.0, 0)):
+        out[name] = _ref_trajectory(mode, steps, eps, seed)
+        print(name, np.round(out[name][::20], 3), 'last-20 mean', round(float(out[name][-20:].mean()), 3))
+    save('g20_trajectory_micro.npz', **out)
+
+
 ALL = dict(g01=g01_convlstm, g02=g02_partition, g03=g03_attention, g04=g04_backbone, g05=g05_head,
            g06=g06_simota, g07=g07_postprocess, g08=g08_pseudo, g10=g10_voxel, g11=g11_manifest,
            g12=g12_trainstep, g13=g13_tracker, g14=g14_augment, g15=g15_evaluator, g16=g16_tta_result, g17=g17_loader, g18=g18_autocast,
-           g19=g19_head_options)
+           g19=g19_head_options, g20=g20_trajectory)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)

@@ -360,6 +360,71 @@ def test_module_two_training_steps_match_reference_golden(gpu, golden_dir, manif
     assert opt.flat.step_count == 2 and float(opt.flat.exp_avg.abs().sum()) > 0
 
 
+def _traj_batch(i, step, T=5, B=2):
+    """Batch ``i`` of the reference-recorded trajectories (tests/golden/make_golden.py::_ref_trajectory): sample 0 streams, sample 1 restarts."""
+    ev = synth_events(T, B, 20, 60, 90, seed=700 + i, as_uint8=True)
+    lab_list = synth_labels(T * B, HW, 2, seed=800 + i, max_boxes=4)
+    for l in lab_list:
+        l[:, 3] = l[:, 3].clamp(max=30)
+        l[:, 4] = l[:, 4].clamp(max=24)
+        l[:, 1] = torch.minimum(l[:, 1], HW[1] - 1 - l[:, 3])
+        l[:, 2] = torch.minimum(l[:, 2], HW[0] - 1 - l[:, 4])
+    labels_tb = [[lab_list[t * B + b] if (t in (2, 4) or (t == 1 and b == 0)) else None for b in range(B)] for t in range(T)]
+    return loader_batch(ev, labels_tb, torch.tensor([step == 0, True]))
+
+
+def test_module_200_step_trajectory_vs_reference(gpu, golden_dir, manifest):
+    """A WHOLE OneCycle schedule against the reference itself: 200 optimisation steps of the micro detector on 16 cycled batches, recorded by
+    running the reference's own training loop (g20: its fp32 run, two fp32 runs from initial weights perturbed by 2^-12 / 2^-9, its
+    fp16-autocast run) and repeated here through ``Module.training_step`` + ``FlatAdamW`` + OneCycleLR in all three precision modes.
+    The first steps are deterministic and must agree tightly; afterwards training from random init amplifies any rounding difference --
+    the reference's own perturbed runs drift 6-10 % (smoothed) from its unperturbed run and end at 0.93-0.99 of it -- so the HIP runs
+    are held to that class.  Measured over six runs on MI355X (profiles/r05_n_reference_trajectory_cpu.txt): smoothed difference to the
+    reference's fp32 curve 0.06-0.11 (f32), 0.07-0.12 (16f), 0.06-0.10 (bf16); last-20-step mean 0.95-1.08 / 0.90-1.06 / 0.96-1.03 of the
+    reference's -- no mode is offset, and the fp32 mode's own run-to-run spread (the order of its fp32 atomics) is as wide as the 16-bit
+    modes'.  Bounds with head room for a chaotic observable: 0.20 everywhere, 0.16 on the last-20-step mean."""
+    import os
+    from leod_amd import ops
+    from leod_amd.optim import fit_step
+    g = np.load(os.path.join(golden_dir, 'g20_trajectory_micro.npz'))
+    ref = g['fp32']
+    steps, nb = len(ref), 16
+    sm = lambda x: np.convolve(x, np.ones(10) / 10, mode='valid')   # noqa: E731
+    chaos = max(np.abs(sm(g[k]) - sm(ref)).__truediv__(sm(ref)).max() for k in ('fp32_p12', 'fp32_p9', 'h16f'))
+    print(f'reference: perturbed / fp16-autocast runs differ from its fp32 run by up to {chaos:.3f} (smoothed); finals '
+          f'{[round(float(g[k][-20:].mean() / ref[-20:].mean()), 3) for k in ("fp32_p12", "fp32_p9", "h16f")]}')
+    assert 0.04 < chaos < 0.15
+    prev_mode = ops.get_precision()
+    try:
+        for mode in ('f32', '16f', 'bf16'):
+            mod, _, cfg = micro_module(manifest, 9, 'fit')
+            cfg.training.lr_scheduler.total_steps = steps
+            cfg.training.lr_scheduler.pct_start = 0.1
+            mod.train()
+            oc = mod.configure_optimizers()
+            opt, sched = oc['optimizer'], oc['lr_scheduler']['scheduler']
+            ops.set_precision(mode)
+            got = []
+            for step in range(steps):
+                out = fit_step(mod, opt, sched, _traj_batch(step % nb, step), step)
+                got.append(out['log_dict']['train/loss'].detach())
+            got = torch.stack(got).cpu().numpy().astype(np.float64)
+            d = np.abs(sm(got) - sm(ref)) / sm(ref)
+            fin = got[-20:].mean() / ref[-20:].mean()
+            print(f'[{mode}] first steps {np.round(got[:4], 4)} (reference {np.round(ref[:4], 4)}); smoothed relative difference to the reference fp32 run: '
+                  f'max {d.max():.3f}, before step 100 {d[:90].max():.3f}; last-20 mean {got[-20:].mean():.3f} = {fin:.3f} x reference')
+            if mode == 'f32':
+                np.testing.assert_allclose(got[:3], ref[:3], rtol=5e-4)          # the deterministic start of the schedule
+            else:       # 16-bit rounding may flip a SimOTA decision of these 13 boxes (measured at step 0: 13 instead of 12 matched boxes, loss -4.7 %)
+                np.testing.assert_allclose(got[:3], ref[:3], rtol=8e-2)
+            assert got[-20:].mean() < 0.85 * got[:20].mean()                      # it learns (16.5 -> ~12.9)
+            assert d.max() <= 0.20 and abs(fin - 1.0) <= 0.16, (mode, d.max(), fin)
+            del mod, opt, sched, oc
+            torch.cuda.empty_cache()
+    finally:
+        ops.set_precision(prev_mode)
+
+
 def test_module_plan_replay_equals_eager(gpu, manifest):
     """Launch plans through the product path (modules/step_plan.py): six optimisation steps of one geometry driven by ``fit_step`` --
     eager (``plan_mode = False``) vs plan mode (step 0 eager, step 1 captured and replayed, steps 2-5 replayed) on identical batches,

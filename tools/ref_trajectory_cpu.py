@@ -16,7 +16,6 @@ OneCycle schedule of 200 AdamW steps on 16 cycled batches, in
 
 and prints the loss every 20 steps, the last-20-step means and the smoothed relative differences to the fp32 run.
 usage: python tools/ref_trajectory_cpu.py [steps=200] [out.txt]"""
-import contextlib
 import os
 import sys
 import time
@@ -33,79 +32,13 @@ T, B, NB = 5, 2, 16
 HW, PAD = (60, 90), (64, 96)
 
 
-def batches():
-    padder = mg.InputPadderFromShape(desired_hw=PAD)
-    out = []
-    for i in range(NB):
-        ev = padder.pad_tensor_ev_repr(mg.synth_events(T, B, 20, HW[0], HW[1], seed=700 + i, as_uint8=False))
-        labs = mg.micro_labels(T * B, seed=800 + i)
-        labels = [[labs[t * B + b] if (t in (2, 4) or (t == 1 and b == 0)) else None for b in range(B)] for t in range(T)]
-        out.append((ev, labels))
-    return out
-
-
-def run(mode, data, perturb=0.0, seed=0):
-    torch.manual_seed(0)
-    det = mg.YoloXDetector(mg.make_cfg(**mg.MICRO))
-    mg.load_synth(det, 9)
-    if perturb:
-        g = torch.Generator().manual_seed(100 + seed)
-        with torch.no_grad():
-            for p in det.parameters():
-                p.mul_(1.0 + perturb * torch.randn(p.shape, generator=g))
-    det.train()
-    opt = torch.optim.AdamW(det.parameters(), lr=2e-4, weight_decay=0)
-    sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=2e-4, div_factor=20, final_div_factor=500, total_steps=STEPS, pct_start=0.1,
-                                              cycle_momentum=False, anneal_strategy='linear')
-    half = mode == 'h16f'
-    scale, good = 65536.0, 0
-    rnn = mg.RNNStates()
-    losses_seen = []
-    for step in range(STEPS):
-        ev, labels = data[step % NB]
-        while True:
-            opt.zero_grad(set_to_none=True)
-            ctx = contextlib.ExitStack()
-            if mode in ('h16f', 'acf'):
-                ctx.enter_context(torch.autocast('cpu', dtype=torch.float16 if half else torch.bfloat16))
-                ctx.enter_context(mg._CudaLikeFp32Ops())
-            with ctx:
-                rnn.reset(worker_id=0, indices_or_bool_tensor=torch.tensor([step == 0, True]))       # one streaming sample, one random-access sample
-                prev = rnn.get_states(worker_id=0)
-                sel = mg.BackboneFeatureSelector()
-                obj_labels = []
-                for t in range(T):
-                    feats, prev = det.forward_backbone(x=ev[t], previous_states=prev)
-                    idx = [b for b in range(B) if labels[t][b] is not None]
-                    if idx:
-                        sel.add_backbone_features(backbone_features=feats, selected_indices=idx)
-                        obj_labels.extend(mg.ObjectLabels(labels[t][b], HW) for b in idx)
-                targets = mg.ObjectLabels.get_labels_as_batched_tensor(obj_label_list=obj_labels, format_='yolox')
-                _, losses = det.forward_detect(backbone_features=sel.get_batched_backbone_features(), targets=targets)
-                (losses['loss'].float() * (scale if half else 1.0)).backward()
-            if not half:
-                break
-            if all(bool(torch.isfinite(p.grad).all()) for p in det.parameters() if p.grad is not None):
-                with torch.no_grad():
-                    for p in det.parameters():
-                        if p.grad is not None:
-                            p.grad.div_(scale)
-                good += 1
-                if good % 2000 == 0:
-                    scale *= 2.0
-                break
-            scale, good = scale / 2.0, 0                       # GradScaler: skip, back off, try again
-        rnn.save_states_and_detach(worker_id=0, states=[(h.float(), c.float()) for h, c in prev])
-        torch.nn.utils.clip_grad_value_(det.parameters(), 1.0)
-        opt.step()
-        sch.step()
-        losses_seen.append(float(losses['loss']))
-    return np.array(losses_seen)
+def run(mode, _data, perturb=0.0, seed=0):
+    return mg._ref_trajectory(mode, STEPS, perturb, seed, T=T, B=B, nb=NB, hw=HW, pad=PAD)
 
 
 def main():
     torch.set_num_threads(8)
-    data = batches()
+    data = None
     runs = [('fp32', 'fp32', 0.0, 0), ('fp32 + 2^-12 (a)', 'fp32', 2.0 ** -12, 1), ('fp32 + 2^-12 (b)', 'fp32', 2.0 ** -12, 2),
             ('fp32 + 2^-9 (a)', 'fp32', 2.0 ** -9, 3), ('fp32 + 2^-9 (b)', 'fp32', 2.0 ** -9, 4),
             ('h16f', 'h16f', 0.0, 0), ('h16f + 2^-12', 'h16f', 2.0 ** -12, 1), ('acf (bf16)', 'acf', 0.0, 0), ('acf + 2^-12', 'acf', 2.0 ** -12, 1)]
