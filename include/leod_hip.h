@@ -359,6 +359,12 @@ long leod_plan_create(void* hip_graph, int max_lanes);
  * (that temporary may share its address with another temporary of the same capture). */
 int leod_plan_set_hoist_ranges(const long* starts, const long* bytes, int n);
 int leod_plan_launch(long plan, leod_stream_t stream);
+/* The step's input tensor without a copy: every kernel of the plan that reads it (the stem convolution and its weight gradient register
+ * themselves) and was captured with a pointer inside [captured_base, captured_base + bytes) reads new_base + the same offset from the next
+ * launch on.  Returns the number of kernels re-pointed (0: none in this plan -- copy into the captured buffer instead), < 0 on error.  The
+ * new buffer must stay alive and unchanged until the launches reading it have completed (the backward plan's stem weight gradient is the
+ * last reader) -- what the reference's autograd requires of the event tensor too (modules/detection.py:196-207). */
+int leod_plan_rebase_input(long plan, const void* captured_base, long bytes, const void* new_base);
 /* leod_plan_launch without its closing join: `stream` does not wait for the plan's side lanes; leod_plan_join(plan, stream) makes it wait
  * later (before the plan is launched again and before anything reads what the side lanes wrote). */
 int leod_plan_launch_nojoin(long plan, leod_stream_t stream);

@@ -194,6 +194,10 @@ template <int OF> __device__ __forceinline__ f4 mfma_frag(const Frag16<OF>& a, c
 int leod_precision();
 int leod_precision_mode();
 int leod_opfmt();
+// Launch plans (k_plan.hip): kernels that read the step's INPUT tensor register themselves once (host function pointer, index of the input pointer
+// among their arguments, argument count), so that a plan can re-point them at the batch's own buffer instead of copying the batch into a static one.
+void leod_register_input_kernel(const void* func, int arg_index, int nargs);
+
 struct LeodFwdScope { LeodFwdScope(); ~LeodFwdScope(); LeodFwdScope(const LeodFwdScope&) = delete; };
 // 16-bit shadow of a registered fp32 weight buffer (k_misc.hip: leod_set_weight_shadow / leod_weight_shadow_refresh): the copy of the
 // weight at `w` in operand format `of` (1 bf16 / 2 fp16) if `w` lies in a registered buffer whose shadow is fresh, else nullptr.  The GEMM

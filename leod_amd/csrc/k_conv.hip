@@ -242,8 +242,11 @@ static int launch_stem_u8(const uint8_t* x, const float* w, float* y, int B, int
     const size_t patch = ((size_t)Cin * 19 * 72 + 4 + 15) & ~(size_t)15;
     size_t lds = patch + (((size_t)KP * 4 + 15) & ~(size_t)15) + (size_t)NT * 16 * 72 * 4;
     lds = lds < 4 * 16 * 64 * 4 ? 4 * 16 * 64 * 4 : lds;                 // the epilogue tile aliases the front of the buffer
-    LEOD_BY_OPFMT(hipLaunchKernelGGL((stem_u8_fwd_kernel<NT, OF>), dim3(B * tiles_x * tiles_y), dim3(256), lds, s, x, w, y, Cin, H, W, Ho, Wo, N,
-                                     tiles_x, tiles_y));
+    LEOD_BY_OPFMT({
+        static const bool reg = (leod_register_input_kernel(reinterpret_cast<const void*>(&stem_u8_fwd_kernel<NT, OF>), 0, 11), true);
+        (void)reg;
+        hipLaunchKernelGGL((stem_u8_fwd_kernel<NT, OF>), dim3(B * tiles_x * tiles_y), dim3(256), lds, s, x, w, y, Cin, H, W, Ho, Wo, N, tiles_x, tiles_y);
+    });
     return leod_launch_status();
 }
 
@@ -511,6 +514,9 @@ static int launch_stem_u8_wgrad(const float* dy, const uint8_t* x, float* dW, in
     const size_t lds = (((size_t)Cin * 19 * 72 + 15) & ~(size_t)15) + (size_t)64 * (NT * 16 + 4) * 4;
     const int ntiles = B * tiles_x * tiles_y;
     const int gx = ntiles < 192 ? ntiles : 192;
+    static const bool reg = (leod_register_input_kernel(reinterpret_cast<const void*>(&stem_u8_wgrad_kernel<NT, true>), 1, 12),
+                             leod_register_input_kernel(reinterpret_cast<const void*>(&stem_u8_wgrad_kernel<NT>), 1, 12), true);
+    (void)reg;
     if (leod_precision() == 1)
         hipLaunchKernelGGL((stem_u8_wgrad_kernel<NT, true>), dim3(gx, zs), dim3(256), lds, s, dy, x, dW, B, Cin, H, W, Ho, Wo, N, tiles_x,
                            tiles_y);

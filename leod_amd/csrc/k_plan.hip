@@ -36,6 +36,11 @@ struct PlanOp {
     hipMemcpyKind cp_kind = hipMemcpyDeviceToDevice;
     std::vector<int> waits;      // events this op's lane waits for before the op
     int record = -1;             // event recorded on the op's lane after the op
+    // input kernels (leod_register_input_kernel): a plan-owned copy of the argument pointer array whose input slot points at in_value
+    std::vector<void*> own_params;
+    int in_index = -1;
+    void* in_captured = nullptr; // the input pointer the kernel was captured with
+    void* in_value = nullptr;    // the input pointer of the next replay
 };
 
 struct Plan {
@@ -45,10 +50,12 @@ struct Plan {
     std::vector<int> lane_first_wait;        // per lane > 0: 1 when the lane has ops (it then waits for the start event)
     int start_event = -1;                    // recorded on the caller's stream before anything else
     std::vector<int> tail_event;             // per lane > 0: event recorded after its last op (-1: lane unused)
-    int n_kernel = 0, n_memset = 0, n_memcpy = 0, n_nop = 0, n_waits = 0, n_hoisted = 0;
+    int n_kernel = 0, n_memset = 0, n_memcpy = 0, n_nop = 0, n_waits = 0, n_hoisted = 0, n_input = 0;
 };
 
 std::mutex g_mu;
+std::mutex g_in_mu;
+std::unordered_map<const void*, std::pair<int, int>> g_input_kernels;    // host function pointer -> (input argument index, argument count)
 std::unordered_map<long, Plan*> g_plans;
 long g_next = 1;
 std::string g_err;
@@ -73,6 +80,11 @@ void free_plan(Plan* p) {
 }  // namespace
 
 LEOD_API const char* leod_plan_last_error() { return g_err.c_str(); }
+
+void leod_register_input_kernel(const void* func, int arg_index, int nargs) {
+    std::lock_guard<std::mutex> lk(g_in_mu);
+    g_input_kernels[func] = std::make_pair(arg_index, nargs);
+}
 
 // persistent weight-pack buffers (see the header): a pack kernel's destination is its SECOND argument (conv3_pack_kernel(w, out, ..),
 // lstm_pack_kernel(W, wpf, wpb, ..): one buffer, wpf first)
@@ -300,6 +312,22 @@ LEOD_API long leod_plan_create(void* hip_graph, int max_lanes) {
     for (int k = 1; k < nl; ++k) p->tail_event[k] = new_event(*p);
     p->ops.reserve(n);
     for (int v : order) p->ops.push_back(std::move(ops[v]));
+    // kernels that read the step's input: the plan launches them with its own copy of the argument pointers, the input slot pointing at a
+    // value the caller may re-point per replay (leod_plan_rebase_input)
+    {
+        std::lock_guard<std::mutex> lk2(g_in_mu);
+        for (PlanOp& o : p->ops) {
+            if (o.type != OP_KERNEL || !o.kp.kernelParams) continue;
+            auto it = g_input_kernels.find(o.kp.func);
+            if (it == g_input_kernels.end()) continue;
+            const int idx = it->second.first, na = it->second.second;
+            o.own_params.assign(o.kp.kernelParams, o.kp.kernelParams + na);
+            o.in_index = idx;
+            o.in_captured = o.in_value = *reinterpret_cast<void* const*>(o.kp.kernelParams[idx]);
+        }
+        for (PlanOp& o : p->ops)
+            if (o.in_index >= 0) { o.own_params[o.in_index] = &o.in_value; o.kp.kernelParams = o.own_params.data(); ++p->n_input; }
+    }
     long h = g_next++;
     g_plans[h] = p;
     return h;
@@ -354,6 +382,31 @@ LEOD_API int leod_plan_launch(long handle, hipStream_t stream) { return plan_lau
 // caller enqueues next).  leod_plan_join(plan, stream) makes `stream` wait for them later; it must be called before the plan is launched
 // again and before anything reads what the side lanes wrote.
 LEOD_API int leod_plan_launch_nojoin(long handle, hipStream_t stream) { return plan_launch(handle, stream, false); }
+// The step's input without a copy: every kernel of the plan that reads the input tensor (leod_register_input_kernel: the stem convolution and
+// its weight gradient) and was captured with a pointer inside [captured_base, captured_base + bytes) reads new_base + the same offset from
+// the next launch on.  Returns the number of kernels re-pointed (0: the plan holds none -- the caller copies instead).  The caller keeps
+// the new buffer alive and unchanged until the launches that read it have completed (the backward plan reads it last).
+LEOD_API int leod_plan_rebase_input(long handle, const void* captured_base, long bytes, const void* new_base) {
+    Plan* p;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_plans.find(handle);
+        if (it == g_plans.end()) return LEOD_ERR_ARG;
+        p = it->second;
+    }
+    if (!captured_base || !new_base || bytes <= 0) return LEOD_ERR_ARG;
+    int n = 0;
+    const char* lo = static_cast<const char*>(captured_base);
+    for (PlanOp& o : p->ops) {
+        if (o.in_index < 0) continue;
+        const char* c = static_cast<const char*>(o.in_captured);
+        if (c < lo || c >= lo + bytes) continue;
+        o.in_value = const_cast<char*>(static_cast<const char*>(new_base) + (c - lo));
+        ++n;
+    }
+    return n;
+}
+
 LEOD_API int leod_plan_join(long handle, hipStream_t stream) {
     Plan* p;
     {

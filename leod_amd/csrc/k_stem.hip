@@ -167,6 +167,8 @@ int launch(const float* dy, const uint8_t* x, float* dW, int B, int Cin, int H, 
         hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_bf16_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr = true;
     }
+    static const bool reg = (leod_register_input_kernel(reinterpret_cast<const void*>(&stem_wgrad_bf16_kernel<NT>), 1, 12), true);
+    (void)reg;
     hipLaunchKernelGGL((stem_wgrad_bf16_kernel<NT>), dim3(gx), dim3(512), lds, s, dy, x, dW, B, Cin, H, W, Ho, Wo, N, tiles_x, tiles_y);
     return leod_launch_status();
 }
@@ -359,6 +361,7 @@ int launch_fwd(const uint8_t* x, const float* w, float* y, int B, int H, int W, 
         static bool attr = false;
         if (!attr) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_fwd_bf16_kernel<NT, CIN, PD, OF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            leod_register_input_kernel(reinterpret_cast<const void*>(&stem_fwd_bf16_kernel<NT, CIN, PD, OF>), 0, 12);
             attr = true;
         }
         hipLaunchKernelGGL((stem_fwd_bf16_kernel<NT, CIN, PD, OF>), dim3(gx), dim3(512), lds, s, x, w, y, B, H, W, Ho, Wo, N, tiles_x, tiles_y, dbg);

@@ -1162,6 +1162,15 @@ class LaunchPlan:
     def join(self):
         check(_l().leod_plan_join(self.handle, _stream()), 'plan_join')
 
+    def rebase_input(self, captured: torch.Tensor, new: torch.Tensor) -> int:
+        """Re-point the plan's input-reading kernels (the stem convolution and its weight gradient) from the buffer they were captured with
+        to ``new`` (same shape / dtype / layout).  -> number of kernels re-pointed (0: none here)."""
+        n = int(_l().leod_plan_rebase_input(self.handle, ctypes.c_void_p(captured.data_ptr()), captured.numel() * captured.element_size(),
+                                             ctypes.c_void_p(new.data_ptr())))
+        if n < 0:
+            raise LeodHipError(f'leod_plan_rebase_input: rc {n}')
+        return n
+
     def dump(self, path: str):
         check(_l().leod_plan_dump(self.handle, path.encode()), 'plan_dump')
 

@@ -461,6 +461,14 @@ def test_full_size_plans_equal_eager_in_16bit_modes(gpu, mode16):
                     n_keep = sum(len(label_tb[t]) for t in keep)
                     label_tb = [label_tb[t] if t in keep else [] for t in range(21)]
                     rows = rows[:n_keep]
+                if plan and step >= 2:
+                    # replayed steps read the batch's own event tensor in place (leod_plan_rebase_input re-points the stem convolution and its weight
+                    # gradient): the buffer the plans were captured with is poisoned here, so any kernel still reading it would show in the losses
+                    from leod_amd.modules.step_plan import BackbonePlan
+                    bb = [e for e in mod._plans.entries.values() if isinstance(e, BackbonePlan)][0]
+                    assert (bb.rebase_ok and bb.rebase_count == 2) or os.environ.get('LEOD_PLAN_INPUT_COPY') == '1', (bb.rebase_ok, bb.rebase_count)
+                    if bb.rebase_ok:
+                        bb.ev.fill_(255)
                 r = fit_step(mod, opt, lrs, te._loader_batch(ev, rows, label_tb, firsts[step].to(DEV)), step)
                 out.append([float(r['log_dict'][f'train/{k}'].detach()) for k in KEYS])
             states = mod.mode_2_rnn_states[Mode.TRAIN].get_states(0)
@@ -468,11 +476,15 @@ def test_full_size_plans_equal_eager_in_16bit_modes(gpu, mode16):
             if plan:
                 pl = mod._plans
                 assert (pl.captures, pl.head_captures, pl.steps, pl.replays, pl.eager_steps) == (1, 2, 3, 1, 1), pl.info()
+                assert (bb.ev_now is not bb.ev) == bb.rebase_ok
         del mod, opt, lrs
         torch.cuda.empty_cache()
     a, b = res[True][0], res[False][0]
     print(f'[{mode16}] losses through plans', np.round(a[:, 0], 4), 'eager', np.round(b[:, 0], 4))
-    np.testing.assert_allclose(a[:, 0], b[:, 0], rtol=2e-3)                   # total loss (measured: equal to 5 digits on steps 0-2, 6e-4 on step 3)
+    # total loss: steps 0-1 equal to 5 digits; from step 2 on BOTH executors are bimodal from run to run in the bf16 mode (17.269 | 17.346 at step 2, whichever
+    # path: one SimOTA assignment on a knife edge after two noisy updates), so a plan run may meet an eager run of the other branch (0.45 %)
+    np.testing.assert_allclose(a[:2, 0], b[:2, 0], rtol=1e-4)
+    np.testing.assert_allclose(a[2:, 0], b[2:, 0], rtol=1e-2)
     np.testing.assert_allclose(a[:, 1:4], b[:, 1:4], rtol=3e-2, atol=1e-3)     # components: a SimOTA assignment may flip after three noisy updates
     np.testing.assert_allclose(a[:, 5], b[:, 5], rtol=3e-2)
     for x, y in zip(res[True][1], res[False][1]):

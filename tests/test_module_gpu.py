@@ -453,8 +453,17 @@ def test_module_plan_replay_equals_eager(gpu, manifest):
             is_first = torch.tensor([step < 2, step % 3 == 0])
             batch = loader_batch(ev, labels_tb, is_first)
             batch[WORKER_ID_KEY] = step % 2               # two streaming workers, each with its own LSTM state
+            if plan and step >= 2:
+                # the batch's own event tensor is read in place (leod_plan_rebase_input): nothing may read the buffer the plans were captured with
+                from leod_amd.modules.step_plan import BackbonePlan
+                for bb in [e for e in mod._plans.entries.values() if isinstance(e, BackbonePlan)]:
+                    if bb.rebase_ok:                          # (the fp32 stem of this micro geometry may run on unregistered generic kernels: then the batch is copied in)
+                        bb.ev.fill_(255)
             out = fit_step(mod, opt, sched, batch, step)
             out_l.append([float(out['log_dict'][f'train/{k}'].detach()) for k in keys6])
+            if plan and step >= 2:
+                bb = [e for e in mod._plans.entries.values() if isinstance(e, BackbonePlan)][0]
+                assert (bb.ev_now is not bb.ev) == bb.rebase_ok
         st = mod.mode_2_rnn_states[Mode.TRAIN]
         res[plan] = (np.array(out_l), opt.flat.data.detach().cpu().numpy().copy(), opt.flat.exp_avg.detach().cpu().numpy().copy(),
                      [[c.detach().cpu().numpy().copy() for _, c in st.get_states(w)] for w in (0, 1)])
