@@ -297,6 +297,8 @@ class Module(_Base):
                 return None
             fresh = True
         bb: BackbonePlan = hit
+        if self._head_eager():
+            return self._planned_backbone_eager_head(bb, plans, fresh, ev, labels_yolox, where, is_first, worker_id, rnn, B, log)
         # the data-dependent part: PAFPN + head for THIS labelled-frame count (captured the first time the count is seen; nothing has been
         # executed yet, so a failed capture simply leaves the step to the eager path)
         hkey, nmax_pad = plans.head_key_of(len(where), labels_yolox.shape[1])
@@ -325,6 +327,41 @@ class Module(_Base):
         losses = {k: out6[i] for i, k in enumerate(LOSS_KEYS)}
         losses['loss'] = loss
         output = {'loss': loss, 'log_dict': {f'{mode_2_string[Mode.TRAIN]}/{k}': v for k, v in losses.items()}}
+        if hasattr(self, 'log_dict') and log and _Base is not th.nn.Module:  # pragma: no cover
+            self.log_dict(output['log_dict'], on_step=True, on_epoch=True, batch_size=B, sync_dist=False, rank_zero_only=True)
+        return output
+
+    def _head_eager(self) -> bool:
+        """Planned backbone + eager head (LEOD_PLAN_HEAD_EAGER=1): an option for N > 1, where every SyncBatchNorm exchange inside a captured
+        head is a plan segment boundary (the backbone has no BatchNorm: its plans stay whole apart from the gradient buckets).  Measured
+        with every collective issued on a one-rank RCCL communicator (profiles/r05_p_rccl_force_collectives.txt): 16.98 ms per step against
+        17.3-17.4 with the captured head and 16.3-16.5 all-eager (15.4 without collectives) -- but 10.5 instead of 4.1 ms of host time per
+        step, i.e. it depends on the host the way eager launches do; the captured head stays the default."""
+        return os.environ.get('LEOD_PLAN_HEAD_EAGER', '0') == '1'
+
+    def _planned_backbone_eager_head(self, bb, plans, fresh, ev, labels_yolox, where, is_first, worker_id, rnn, B, log):
+        from .step_plan import EagerHeadGate
+        from leod_amd import functions as Fn
+        device = ev.device
+        self.started_training = True
+        rows_host = tuple(t * B + b for t, b in where)
+        bb.load_states(rnn, worker_id)
+        bb.stage_inputs(ev, rows_host, self._row_index(rows_host + (-1,) * (bb.n_max - len(rows_host)), device), is_first)
+        if labels_yolox.device != device:
+            labels_yolox = self._upload_pinned(labels_yolox, device)
+        bb.run_forward()
+        rnn.save_states_and_detach(worker_id=worker_id, states=bb.states)
+        plans.steps += 1
+        plans.replays += 0 if fresh else 1
+        if plans.anchor is None or plans.anchor.device != device:
+            plans.anchor = th.zeros(1, device=device, requires_grad=True)
+        ops.StatArena.begin_step(device)             # the eager head's BatchNorm statistic accumulators (the backbone plan has its own arena)
+        in_features = tuple(self.mdl.fpn.in_features)
+        sel = EagerHeadGate.apply(bb, plans.anchor, self._row_index(rows_host, device), *in_features)
+        _, losses = self.mdl.forward_detect(backbone_features={k: Fn.as_nchw(v) for k, v in zip(in_features, sel)},
+                                            targets=labels_yolox.to(torch.float32))
+        WgradSide.active = self.wgrad_side and torch.is_grad_enabled()
+        output = {'loss': losses['loss'], 'log_dict': {f'{mode_2_string[Mode.TRAIN]}/{k}': v for k, v in losses.items()}}
         if hasattr(self, 'log_dict') and log and _Base is not th.nn.Module:  # pragma: no cover
             self.log_dict(output['log_dict'], on_step=True, on_epoch=True, batch_size=B, sync_dist=False, rank_zero_only=True)
         return output

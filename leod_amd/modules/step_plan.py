@@ -138,6 +138,40 @@ class PlanLossFn(Function):
         return None, None, None, None
 
 
+class EagerHeadGate(Function):
+    """Planned backbone, EAGER head (LEOD_PLAN_HEAD_EAGER=1, an option for N > 1): the outputs are the labelled frames' stage features gathered from the backbone
+    plan's static outputs; everything after them -- PAFPN, head, SimOTA, losses and their backward, with the SyncBatchNorm exchanges and the
+    head's gradient buckets issued between the kernels as in an eager step -- is ordinary autograd.  ``backward`` receives the gradient of the
+    gathered rows, puts it into the backbone plan's static slots and launches the captured backbone backward.  (A captured head pays for every
+    collective with a plan segment: a join of the side lanes and a relaunch from the host; the eager head's ~170 launches are enqueued while
+    the GPU is still running the backbone's forward plan.)"""
+
+    @staticmethod
+    def forward(ctx, bb, anchor, rows, *stages):
+        ctx.bb, ctx.gen, ctx.n, ctx.stages = bb, bb.uses, int(rows.shape[0]), stages
+        return tuple(bb.x_out[k].index_select(0, rows) for k in stages)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        bb = ctx.bb
+        if bb.uses != ctx.gen or bb.consumed == ctx.gen or bb.fwd is None:
+            raise RuntimeError('leod_amd launch plans: backward() of a planned training step whose activations are gone (another '
+                               'training_step of the same geometry ran before this backward, backward ran twice, or the plan was evicted); '
+                               'run such steps with Module.plan_mode = False')
+        bb.consumed = ctx.gen
+        dst, src = [], []
+        for k, g in zip(ctx.stages, grads):
+            if g is None:
+                bb.gsel[k][:ctx.n].zero_()
+            else:
+                dst.append(bb.gsel[k][:ctx.n])
+                src.append(g.contiguous())
+        if dst:
+            ops.copy_multi(dst, src)
+        bb.run_backward()
+        return (None, None, None) + (None,) * len(ctx.stages)
+
+
 class HeadPlan:
     """PAFPN + head + SimOTA + losses and their backward for ONE labelled-frame count B' (and padded label width): the data-dependent part
     of the step (modules/detection.py:209-224 -- the reference gathers the labelled frames' features per step; its static-shape unit is
@@ -549,7 +583,13 @@ class TrainStepPlans:
         bb = bbs[-1]
         hds = [h for h in bb.heads.values() if isinstance(h, HeadPlan)]
         if not hds:
-            return None
+            if bb.fwd is None or bb.bwd is None:
+                return None
+            # planned backbone, eager head (EagerHeadGate: the N > 1 configuration)
+            return {'forward': bb.fwd.info(), 'backward': bb.bwd.info(), 'backbone_forward_kernels': bb.fwd.info()['kernels'],
+                    'head_forward_kernels': None, 'head_backward_kernels': None, 'backbone_backward_kernels': bb.bwd.info()['kernels'],
+                    'head': 'eager', 'captures': self.captures, 'head_captures': 0, 'head_plans': 0, 'planned_steps': self.steps,
+                    'replays': self.replays, 'eager_steps': self.eager_steps, 'plan_hit_rate': round(self.hit_rate(), 4)}
         hd = hds[-1]
 
         def both(a, b):

@@ -520,6 +520,46 @@ def test_module_head_loss_options_through_plans_equal_eager(gpu, manifest):
     assert np.abs(res['eager'][0][:, 0] - res['plain'][0][:, 0]).min() > 1e-3      # weighted + top-k-ignored losses differ from the plain ones
 
 
+def test_module_planned_backbone_with_eager_head_equals_eager(gpu, manifest, monkeypatch):
+    """The planned-backbone / eager-head option of the launch plans (LEOD_PLAN_HEAD_EAGER=1, meant for N > 1) on one GPU: the
+    backbone is captured and replayed, PAFPN + head + losses run as ordinary autograd between the backbone's forward and backward plans
+    (``EagerHeadGate``).  Five steps with changing label counts, partial LSTM resets and two loader workers equal five eager steps."""
+    from leod_amd.modules.utils.detection import Mode, WORKER_ID_KEY
+    from leod_amd.optim import fit_step
+    monkeypatch.setenv('LEOD_PLAN_HEAD_EAGER', '1')
+    L, B = 4, 2
+    keys6 = ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')
+    res = {}
+    for plan in (False, True):
+        mod, _, cfg = micro_module(manifest, 9, 'fit')
+        cfg.training.lr_scheduler.total_steps = 1000
+        mod.train()
+        mod.plan_mode = plan
+        oc = mod.configure_optimizers()
+        opt, sched = oc['optimizer'], oc['lr_scheduler']['scheduler']
+        out_l = []
+        for step in range(5):
+            ev = synth_events(L, B, 20, HW[0], HW[1], seed=190 + step, as_uint8=True)
+            flat = micro_labels(3, 195 + step, [1e6, 2e6, 2e6])
+            labels_tb = [[None, None], [flat[0], None], [None, None], [flat[1], flat[2]]] if step % 2 == 0 else \
+                [[None, flat[0]], [None, None], [None, None], [flat[1], None]]            # 3 | 2 labelled frames
+            batch = loader_batch(ev, labels_tb, torch.tensor([step < 2, step % 3 == 0]))
+            batch[WORKER_ID_KEY] = step % 2
+            out = fit_step(mod, opt, sched, batch, step)
+            out_l.append([float(out['log_dict'][f'train/{k}'].detach()) for k in keys6])
+        st = mod.mode_2_rnn_states[Mode.TRAIN]
+        res[plan] = (np.array(out_l), opt.flat.data.detach().cpu().numpy().copy(),
+                     [[c.detach().cpu().numpy().copy() for _, c in st.get_states(w)] for w in (0, 1)])
+        if plan:
+            pl = mod._plans
+            assert (pl.captures, pl.head_captures, pl.steps, pl.replays, pl.eager_steps) == (1, 0, 4, 3, 1), pl.info()
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=2e-4, atol=1e-5)
+    assert np.abs(res[True][1] - res[False][1]).max() < 2.5e-3
+    for w in (0, 1):
+        for a, b in zip(res[True][2][w], res[False][2][w]):
+            np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4)
+
+
 def test_module_plans_with_varying_label_counts_equal_eager(gpu, manifest):
     """The labelled-frame count B' is data dependent (modules/detection.py:209-224; the reference's static-shape unit is the backbone,
     config/model/maxvit_yolox/default.yaml:8-11).  Twelve optimisation steps whose B' takes SIX distinct values (1 .. 6 of the 8 frames,
@@ -602,10 +642,12 @@ def _module_world2_worker(rank, port, manifest, q):
     dist.destroy_process_group()
 
 
-def _module_world2_steps_worker(rank, port, manifest, q, plan, steps):
+def _module_world2_steps_worker(rank, port, manifest, q, plan, steps, head_eager=None):
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK='0')
+    if head_eager is not None:
+        os.environ['LEOD_PLAN_HEAD_EAGER'] = head_eager
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=2)
     from leod_amd.optim import fit_step
@@ -637,20 +679,23 @@ def _module_world2_steps_worker(rank, port, manifest, q, plan, steps):
     dist.destroy_process_group()
 
 
-def test_module_world2_plans_with_collectives_equal_eager(gpu, manifest):
+@pytest.mark.parametrize('head', ['captured', 'eager'])
+def test_module_world2_plans_with_collectives_equal_eager(gpu, manifest, head):
     """N > 1 under launch plans: two ranks on one GPU over gloo, SyncBatchNorm + per-stage gradient buckets, a
-    DIFFERENT number of labelled frames per rank, four optimisation steps.  With plans on, step 1 is recorded in segments -- every
-    SyncBatchNorm exchange and every bucket release is a host callback between two plan segments (``PlanRecorder.split``) -- and steps
-    1-3 are replays; the run must match the eager run of the same ranks: replicas identical across ranks, losses and parameters equal
-    to the eager ones up to the atomics' reorder noise."""
+    DIFFERENT number of labelled frames per rank, four optimisation steps, both ways the plans handle the head's collectives.
+    ``captured`` (LEOD_PLAN_HEAD_EAGER=0): step 1 is recorded in segments -- every SyncBatchNorm exchange and every bucket release is a
+    host callback between two plan segments (``PlanRecorder.split``).  ``eager`` (LEOD_PLAN_HEAD_EAGER=1): only the
+    backbone is captured (its backward holds the bucket releases of the backbone's parameters); PAFPN + head run as ordinary autograd
+    between the backbone's plans (``EagerHeadGate``).  Either way steps 2-3 are replays and the run must match the eager run of the same
+    ranks: replicas identical across ranks, losses and parameters equal to the eager ones up to the atomics' reorder noise."""
     import os
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     res = {}
     for plan in (False, True):
         q = ctx.Queue()
-        port = 35000 + (os.getpid() % 2000) + (7 if plan else 0)
-        procs = [ctx.Process(target=_module_world2_steps_worker, args=(r, port, manifest, q, plan, 4)) for r in range(2)]
+        port = 35000 + (os.getpid() % 2000) + (7 if plan else 0) + (20 if head == 'eager' else 0)
+        procs = [ctx.Process(target=_module_world2_steps_worker, args=(r, port, manifest, q, plan, 4, '1' if head == 'eager' else '0')) for r in range(2)]
         for p in procs:
             p.start()
         got = sorted((q.get(timeout=600) for _ in range(2)), key=lambda r: r[0])
@@ -663,7 +708,10 @@ def test_module_world2_plans_with_collectives_equal_eager(gpu, manifest):
     for r in (0, 1):
         captures, replays, fi, bi = res[True][r][4]
         assert captures == 1 and replays == 2, (captures, replays)          # step 0 eager, step 1 captured, steps 2-3 pure replays
-        assert fi['callbacks'] >= 10 and bi['callbacks'] >= 10, (fi, bi)    # SyncBatchNorm exchanges (+ bucket releases in the backward pass)
+        if head == 'captured':
+            assert fi['callbacks'] >= 10 and bi['callbacks'] >= 10, (fi, bi)    # SyncBatchNorm exchanges (+ bucket releases in the backward pass)
+        else:
+            assert fi['callbacks'] == 0 and 1 <= bi['callbacks'] <= 8, (fi, bi)  # no BatchNorm in the backbone; bucket releases of its parameters
         np.testing.assert_allclose(res[True][r][1], res[False][r][1], rtol=3e-4, atol=1e-5)
     d = np.abs(res[True][0][2] - res[False][0][2])
     assert d.max() < 2e-3 and (d > 2e-6 + 1e-4 * np.abs(res[False][0][2])).mean() < 5e-3
