@@ -176,6 +176,37 @@ class ObjectLabels:
         self._set('x', self.object_labels[:, 1] + z_x0)
         self._set('y', self.object_labels[:, 2] + z_y0)
 
+    def reverse_zoom_in_and_rescale_(self, zoom_coordinates_x0y0, zoom_in_factor: float) -> None:
+        """Inverse of ``zoom_in_and_rescale_`` for boxes that survived it (labels.py:410-434): back to the size of the zoom window, then to
+        the window's position in the frame."""
+        if len(self) == 0:
+            return
+        assert len(zoom_coordinates_x0y0) == 2 and zoom_in_factor >= 1
+        if zoom_in_factor == 1:
+            return
+        frame_hw = self.input_size_hw
+        self.scale_(scaling_multiplier=1 / zoom_in_factor)
+        self._set('x', self.object_labels[:, 1] + zoom_coordinates_x0y0[0])
+        self._set('y', self.object_labels[:, 2] + zoom_coordinates_x0y0[1])
+        self.input_size_hw = frame_hw
+
+    def reverse_zoom_out_and_rescale_(self, zoom_coordinates_x0y0, zoom_out_factor: float) -> None:
+        """Inverse of ``zoom_out_and_rescale_`` (labels.py:459-484): off the paste position, then back up by the factor; the boxes must land
+        inside the frame again."""
+        if len(self) == 0:
+            return
+        assert len(zoom_coordinates_x0y0) == 2 and zoom_out_factor >= 1
+        if zoom_out_factor == 1:
+            return
+        self._set('x', self.object_labels[:, 1] - zoom_coordinates_x0y0[0])
+        self._set('y', self.object_labels[:, 2] - zoom_coordinates_x0y0[1])
+        frame_hw = self.input_size_hw
+        self.scale_(scaling_multiplier=zoom_out_factor)
+        self.input_size_hw = frame_hw
+        o, (ht, wd) = self.object_labels, frame_hw
+        assert bool((o[:, 1] >= 0).all()) and bool((o[:, 1] + o[:, 3] <= wd - 1).all())
+        assert bool((o[:, 2] >= 0).all()) and bool((o[:, 2] + o[:, 4] <= ht - 1).all())
+
     def clamp_to_frame_(self):
         ht, wd = self.input_size_hw
         o = self.object_labels
@@ -326,6 +357,39 @@ class SparselyBatchedObjectLabels:
         for l in self.sparse_object_labels_batch:
             if l is not None:
                 l.flip_lr_()
+
+    def reverse_flip_lr_(self):
+        for l in self.sparse_object_labels_batch:
+            if l is not None:
+                l.reverse_flip_lr_()
+
+    def set_empty_labels_to_none_(self):
+        """A transform may have dropped every box of a frame (labels.py:650-654)."""
+        for i, l in enumerate(self.sparse_object_labels_batch):
+            if l is not None and len(l) == 0:
+                self.sparse_object_labels_batch[i] = None
+
+    def zoom_in_and_rescale_(self, *args, **kwargs):
+        for l in self.sparse_object_labels_batch:
+            if l is not None:
+                l.zoom_in_and_rescale_(*args, **kwargs)
+        self.set_empty_labels_to_none_()
+
+    def zoom_out_and_rescale_(self, *args, **kwargs):
+        for l in self.sparse_object_labels_batch:
+            if l is not None:
+                l.zoom_out_and_rescale_(*args, **kwargs)
+
+    def reverse_zoom_in_and_rescale_(self, *args, **kwargs):
+        for l in self.sparse_object_labels_batch:
+            if l is not None:
+                l.reverse_zoom_in_and_rescale_(*args, **kwargs)
+        self.set_empty_labels_to_none_()
+
+    def reverse_zoom_out_and_rescale_(self, *args, **kwargs):
+        for l in self.sparse_object_labels_batch:
+            if l is not None:
+                l.reverse_zoom_out_and_rescale_(*args, **kwargs)
 
     def time_flip_(self):
         self.sparse_object_labels_batch.reverse()

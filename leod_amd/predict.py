@@ -85,3 +85,81 @@ def run_pseudo_labeling(config, module, data_module, device: Optional[torch.devi
         metrics = box[0]
     return {'num_sequences': sum(r['ev_cnt'] for r in everyone), 'num_sequences_rank': [r['ev_cnt'] for r in everyone],
             'metrics': metrics, 'saved': saved}
+
+
+# ---- integrity check of a generated recording (the reference's own end-to-end verifier, predict.py:35-115) ---------------------------
+def read_old_and_new_data(new_dir: str, old_dir: Optional[str] = None):
+    """The frame count / size of the source recording and the (frame index, label) tables of the source and the generated recording
+    (predict.py:35-55; the source defaults to ``datasets/<gen1|gen4>/train/<recording>`` as there)."""
+    import numpy as np
+    from leod_amd.data.utils import misc
+    new_dir = new_dir[:-1] if new_dir[-1] == '/' else new_dir
+    dst_name = 'gen1' if 'gen1' in new_dir else 'gen4'
+    if old_dir is None:
+        old_dir = os.path.join('datasets', dst_name, 'train', os.path.basename(new_dir))
+    old_ev_dir = misc.get_ev_dir(old_dir)
+    raw = misc.resolve_link(misc.get_ev_raw_fn(old_ev_dir, dst_name))
+    frames = misc.RawFrames(raw) if os.path.exists(raw) else misc.H5Frames(misc.resolve_link(misc.get_ev_h5_fn(old_ev_dir, dst_name)))
+    shape = tuple(frames.data.shape)
+    frames.close()
+    new_labels, new_idx = misc.read_npz_labels(new_dir)
+    old_labels, old_idx = misc.read_npz_labels(old_dir)
+    return (shape, np.asarray(misc.read_objframe_idx_2_repr_idx(new_dir)), new_labels, new_idx,
+            np.asarray(misc.read_objframe_idx_2_repr_idx(old_dir)), old_labels, old_idx)
+
+
+def get_label(labels, objframe_idx_2_label_idx, objframe_idx: int, hw, ds_by2: bool):
+    """The boxes of one labelled frame, clamped to the frame, as numpy-backed ``ObjectLabels`` (predict.py:57-64)."""
+    from leod_amd.data.genx_utils.labels import ObjectLabels
+    start = objframe_idx_2_label_idx[objframe_idx]
+    end = objframe_idx_2_label_idx[objframe_idx + 1] if objframe_idx < len(objframe_idx_2_label_idx) - 1 else labels.shape[0]
+    lab = ObjectLabels.from_structured_array(labels[start:end], hw)
+    if ds_by2:
+        lab.scale_(scaling_multiplier=0.5)
+    lab.clamp_to_frame_()
+    lab.numpy_()
+    return lab
+
+
+def verify_data(new_dir: str, ratio: float = -1, ds_by2: bool = False, old_dir: Optional[str] = None, label_list=None) -> int:
+    """Is a generated (pseudo-labelled) recording consistent with its source?  The reference runs this on 10 % of the recordings it writes
+    (predict.py:67-115, called at :246-256): the labelled-frame table is sorted and inside the recording; every frame whose GT the sparse
+    label list (``ssod_<ratio>-off0.pkl``, or ``label_list``) keeps is still there with all eight fields unchanged to 1e-6; every other frame
+    of the source that survived holds pseudo labels only (t == 0); confidences lie in [0, 1].  -> number of retained GT frames checked."""
+    import numpy as np
+    from leod_amd.data.genx_utils.labels import ObjectLabels
+    shape, new_o2r, new_labels, new_o2l, old_o2r, old_labels, old_o2l = read_old_and_new_data(new_dir, old_dir)
+    hw = tuple(shape[-2:])
+    if ds_by2:
+        hw = tuple(s * 2 for s in hw)
+    if label_list is None:
+        if 0. < ratio < 1.:
+            import pickle
+            from leod_amd.data.genx_utils.dataset_streaming import SPLITS_DIR
+            dst_name = 'gen1' if 'gen1' in new_dir else 'gen4'
+            with open(os.path.join(SPLITS_DIR, dst_name, f'ssod_{ratio:.3f}-off0.pkl'), 'rb') as f:
+                label_list = pickle.load(f)[os.path.basename(new_dir.rstrip('/'))]
+        else:
+            label_list = list(range(len(old_o2r)))
+    label_set = set(int(i) for i in label_list)
+    assert new_o2r[-1] <= shape[0], (new_o2r[-1], shape[0])
+    assert (new_o2r >= 0).all()
+    assert all(idx == new_o2r[:i + 1].max() for i, idx in enumerate(new_o2r)), 'labelled frames not sorted'
+    assert all(old_o2r[i] in new_o2r for i in label_set), 'a GT frame of the sparse label list is missing'
+    checked = 0
+    for old_frame_idx, repr_idx in enumerate(old_o2r):
+        hit = np.where(new_o2r == repr_idx)[0]
+        if len(hit) == 0:
+            assert old_frame_idx not in label_set, 'GT not retained'
+            continue
+        new_label = get_label(new_labels, new_o2l, int(hit[0]), hw=hw, ds_by2=ds_by2)
+        assert (new_label.objectness >= 0).all() and (new_label.objectness <= 1).all()
+        assert (new_label.class_confidence >= 0).all() and (new_label.class_confidence <= 1).all()
+        if old_frame_idx not in label_set:
+            assert new_label.is_pseudo_label().all(), 'should not contain GT'
+            continue
+        old_label = get_label(old_labels, old_o2l, old_frame_idx, hw=hw, ds_by2=ds_by2)
+        for k in ObjectLabels.keys():
+            assert np.abs(old_label.get(k) - new_label.get(k)).max() < 1e-6, (k, old_frame_idx)
+        checked += 1
+    return checked

@@ -430,3 +430,33 @@ def test_pick_loss_gradient_is_zero_padded():
     v = torch.arange(6, dtype=torch.float32, requires_grad=True)
     (PickLossFn.apply(v * 2.0) * 3.0).backward()
     assert v.grad.tolist() == [6.0, 0.0, 0.0, 0.0, 0.0, 0.0]
+
+
+def test_label_transforms_and_their_inverses():
+    """The reference's only executable check of its label transforms (data/genx_utils/labels.py:752-775, a ``__main__`` self-test): zoom-out,
+    zoom-in and horizontal flip followed by their ``reverse_*`` operations restore the boxes -- same boxes, same zoom window."""
+    import copy
+    from leod_amd.data.genx_utils.labels import ObjectLabels, SparselyBatchedObjectLabels
+    row = [9.1e6, 195., 140., 52., 38., 0., 1., 1.]
+    labels = ObjectLabels(torch.tensor([row, row]), (240, 304))
+    xy, factor = (42, 52), 1.321398913860321
+    batch = SparselyBatchedObjectLabels([labels, None])
+    b = copy.deepcopy(batch)
+    b.zoom_out_and_rescale_(zoom_coordinates_x0y0=xy, zoom_out_factor=factor)
+    assert not torch.allclose(b[0].object_labels, batch[0].object_labels)
+    b.reverse_zoom_out_and_rescale_(zoom_coordinates_x0y0=xy, zoom_out_factor=factor)
+    assert torch.allclose(b[0].object_labels, batch[0].object_labels)
+    b = copy.deepcopy(batch)
+    b.zoom_in_and_rescale_(zoom_coordinates_x0y0=xy, zoom_in_factor=factor)
+    assert not torch.allclose(b[0].object_labels, batch[0].object_labels)
+    b.reverse_zoom_in_and_rescale_(zoom_coordinates_x0y0=xy, zoom_in_factor=factor)
+    assert torch.allclose(b[0].object_labels, batch[0].object_labels) and b[0].input_size_hw == (240, 304) and b[1] is None
+    b = copy.deepcopy(batch)
+    b.flip_lr_()
+    assert float(b[0].object_labels[0, 1]) == 304 - 1 - 195 - 52
+    b.reverse_flip_lr_()
+    assert torch.equal(b[0].object_labels, batch[0].object_labels)
+    # a zoom window that leaves a box outside drops the frame's labels altogether
+    far = SparselyBatchedObjectLabels([ObjectLabels(torch.tensor([[1., 2., 3., 10., 8., 1., 1., 1.]]), (240, 304))])
+    far.zoom_in_and_rescale_(zoom_coordinates_x0y0=(150, 120), zoom_in_factor=2.0)
+    assert far[0] is None

@@ -848,3 +848,23 @@ def test_pseudo_label_round_one_rank_equals_two_ranks(gpu, manifest, tmp_path):
     assert n_boxes > 20
     for k, v in one['metrics'].items():
         assert res[2][0][1]['metrics'][k] == pytest.approx(v, rel=1e-6, abs=1e-9), k
+    # the reference's own end-to-end verifier (predict.py:67-115) on every recording both runs wrote: the sparse GT frames are retained
+    # unchanged, every other labelled frame holds pseudo labels only, the frame table is sorted and inside the recording
+    from leod_amd.predict import verify_data
+    kept = 0
+    for name, _, _, lab in LOADER_RECORDINGS:
+        for w in (1, 2):
+            kept += verify_data(str(tmp_path / f'gen1_w{w}' / 'train' / name), old_dir=os.path.join(tree, 'train', name),
+                                label_list=list(range(0, len(lab), 2)))
+    assert kept >= 2 * len(LOADER_RECORDINGS)
+    # ... and it does notice a damaged recording: one GT box moved by a pixel
+    bad = str(tmp_path / 'gen1_w1' / 'train' / LOADER_RECORDINGS[0][0])
+    fn = misc.get_labels_npz_fn(bad)
+    with np.load(fn) as z:
+        labels, idx = z['labels'].copy(), z['objframe_idx_2_label_idx'].copy()
+    gt = np.where(labels['t'] != 0)[0]
+    assert len(gt) > 0
+    labels['x'][gt[0]] += 1.0
+    np.savez(fn, labels=labels, objframe_idx_2_label_idx=idx)
+    with pytest.raises(AssertionError):
+        verify_data(bad, old_dir=os.path.join(tree, 'train', LOADER_RECORDINGS[0][0]), label_list=list(range(0, len(LOADER_RECORDINGS[0][3]), 2)))
