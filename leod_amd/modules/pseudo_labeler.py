@@ -220,6 +220,8 @@ class PseudoLabeler(Module):
         self.mode_2_seq_lens = SeqLens()
         self.ev_path_2_ev_data: Dict[str, EventSeqData] = {}
         self.ev_cnt = 0
+        self.metrics: Dict[str, Any] = {}                  # per-class precision / recall of the pseudo labels on withheld GT (reference :449)
+        self.results: Dict[str, List[float]] = {}          # best IoU / confidences of the pseudo boxes (reference :450)
         self.dst_name = self.dst_config.name
         self.ds_by2 = self.dst_config.downsample_by_factor_2
         assert self.dst_name in ('gen1', 'gen4')
@@ -401,6 +403,8 @@ class PseudoLabeler(Module):
                         all_labels[b][t] = gt_labels[gi]
                         gi += 1
             assert pi == int(pse_mask.sum()) and gi == int(gt_mask.sum()) and len(skipped_gt_pse_labels) == len(skipped_gt_labels)
+            if skipped_gt_labels:
+                self._evaluate_pseudo_label(skipped_gt_labels, skipped_gt_pse_labels)
             if skipped_gt_labels and mode in self.mode_2_psee_evaluator:
                 # quality of the pseudo labels on frames whose GT was withheld (reference :753-763): detection KPIs at the end of the
                 # run (``run_psee_evaluator``; gathered over ranks by ``leod_amd.predict.run_pseudo_labeling``)
@@ -432,6 +436,21 @@ class PseudoLabeler(Module):
             self.ev_path_2_ev_data[path].update(labels=labels, ev_idx=ev_idx, is_last_sample=is_last,
                                                 is_padded_mask=padded, is_hflip=bool(hflip), is_tflip=bool(tflip),
                                                 tflip_offset=self.dst_config.data_augmentation.tflip_offset)
+
+    def _evaluate_pseudo_label(self, gt_obj_labels, pse_obj_labels) -> None:
+        """Precision / recall of the pseudo labels against the GT that was withheld, and the (best IoU, confidence) pairs of the pseudo boxes
+        (reference :591-620): running per-class means in ``self.metrics``, raw lists in ``self.results`` (capped at 1e5 boxes)."""
+        from leod_amd.modules.utils.ssod import evaluate_label, get_scores_ious, AverageMeter
+        mask = np.ones(len(gt_obj_labels), dtype=bool)
+        m = evaluate_label(gt_obj_labels, pse_obj_labels, pred_mask=mask, num_cls=self.num_classes, prefix='ssod/')
+        for k, v in m.items():
+            if k.startswith('num_'):
+                continue
+            self.metrics.setdefault(k, AverageMeter()).update(v, n=m[f'num_{k.split("_")[-1]}'])
+        if self.results and len(self.results['ssod/true_ious_all']) > 1e5:
+            return
+        for k, v in get_scores_ious(gt_obj_labels, pse_obj_labels, pred_mask=mask, num_cls=self.num_classes, prefix='ssod/').items():
+            self.results.setdefault(k, []).extend(v)
 
     def flush_predictions(self) -> None:
         """Pipelined mode: finish the chunk whose host half is still outstanding (call after the last ``predict_step``)."""

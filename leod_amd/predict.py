@@ -60,6 +60,8 @@ def run_pseudo_labeling(config, module, data_module, device: Optional[torch.devi
     # ---- end of run: one small gather ----------------------------------------------------------------------------------
     evaluator = module.mode_2_psee_evaluator.get(Mode.TEST)
     mine = dict(ev_cnt=module.ev_cnt, paths=sorted(module.ev_path_2_ev_data),
+                quality={k: (m.sum, m.count) for k, m in getattr(module, 'metrics', {}).items()},
+                results={k: list(v) for k, v in getattr(module, 'results', {}).items()},
                 labels=evaluator._buffer[evaluator.LABELS] if evaluator is not None else [],
                 predictions=evaluator._buffer[evaluator.PREDICTIONS] if evaluator is not None else [],
                 hw=module.mode_2_hw[Mode.TEST], batch_size=module.mode_2_batch_size[Mode.TEST])
@@ -83,8 +85,30 @@ def run_pseudo_labeling(config, module, data_module, device: Optional[torch.devi
         box = [metrics]
         dist.broadcast_object_list(box, src=0, group=process_group)
         metrics = box[0]
+    # precision / recall of the pseudo labels on the frames whose GT was withheld (PseudoLabeler._evaluate_pseudo_label): the ranks' running
+    # means merge by their weights; the raw (best IoU, confidence) lists are written next to the generated dataset as the reference does
+    # (predict.py:226-230: <parent of save_dir>/model_results.pkl)
+    sums: Dict[str, Any] = {}
+    for r in everyone:
+        for k, (sm, n) in r['quality'].items():
+            a = sums.setdefault(k, [0., 0])
+            a[0] += sm
+            a[1] += n
+    label_quality = {k: v[0] / max(v[1], 1) for k, v in sums.items()} or None
+    results_fn = None
+    if save and module.save_dir and rank == 0:
+        merged: Dict[str, list] = {}
+        for r in everyone:
+            for k, v in r['results'].items():
+                merged.setdefault(k, []).extend(v)
+        if merged:
+            import pickle
+            import numpy as np
+            results_fn = os.path.join(os.path.dirname(module.save_dir.rstrip('/')) or '.', 'model_results.pkl')
+            with open(results_fn, 'wb') as f:
+                pickle.dump({k: np.array(v) for k, v in merged.items()}, f)
     return {'num_sequences': sum(r['ev_cnt'] for r in everyone), 'num_sequences_rank': [r['ev_cnt'] for r in everyone],
-            'metrics': metrics, 'saved': saved}
+            'metrics': metrics, 'label_quality': label_quality, 'model_results': results_fn, 'saved': saved}
 
 
 # ---- integrity check of a generated recording (the reference's own end-to-end verifier, predict.py:35-115) ---------------------------

@@ -1038,10 +1038,52 @@ def g20_trajectory(steps=200):
     save('g20_trajectory_micro.npz', **out)
 
 
+def g21_label_quality():
+    """The pseudo-label quality statistics of the reference (modules/utils/ssod.py:209-350: ``evaluate_label``, ``get_scores_ious``) on seeded
+    synthetic GT / pseudo-label lists of a two-class and a three-class head: perturbed copies of the GT boxes (hits at various IoUs), dropped
+    boxes (misses), extra boxes (false positives), an empty pseudo frame, a frame without GT and a frame masked out by ``pred_mask``."""
+    from modules.utils.ssod import evaluate_label, get_scores_ious
+    out = {}
+    for tag, nc, hw in (('gen1', 2, (240, 304)), ('gen4', 3, (360, 640))):
+        g = torch.Generator().manual_seed(211 + nc)
+        gts = synth_labels(8, hw, nc, seed=210 + nc, max_boxes=6, min_boxes=1)
+        gt_l, pse_l, rows = [], [], []
+        for i, lab in enumerate(gts):
+            p = lab.clone()
+            p[:, 1:5] += torch.randn(p[:, 1:5].shape, generator=g) * torch.tensor([4., 4., 6., 6.]) * (i % 3)      # frames 0, 3, 6: exact copies
+            p[:, 3:5].clamp_(min=2.)
+            p[:, 6] = torch.rand(len(p), generator=g)
+            p[:, 7] = torch.rand(len(p), generator=g)
+            if i % 4 == 1:
+                p = p[:-1]                                             # a missed box
+            if i % 4 == 2:
+                extra = p[:1].clone()
+                extra[:, 1:3] = torch.tensor([5., 7.])
+                extra[:, 5] = float((i // 4) % nc)
+                p = torch.cat([p, extra])                              # a false positive
+            if i == 5:
+                p = p[:0]                                              # nothing predicted on this frame
+            p[:, 0] = 0
+            gt_l.append(None if i == 7 else ObjectLabels(lab, hw))
+            pse_l.append(ObjectLabels(p, hw))
+            rows.append((lab, p))
+        mask = np.ones(8, dtype=bool)
+        mask[4] = False
+        ev = evaluate_label(gt_l, pse_l, pred_mask=mask, num_cls=nc, prefix='ssod/')
+        sc = get_scores_ious(gt_l, pse_l, pred_mask=mask, num_cls=nc, prefix='ssod/')
+        for i, (lab, p) in enumerate(rows):
+            out[f'{tag}_gt{i}'], out[f'{tag}_pse{i}'] = lab, p
+        out[f'{tag}_eval_keys'] = np.array(sorted(ev))
+        out[f'{tag}_eval_vals'] = np.array([float(ev[k]) for k in sorted(ev)], dtype=np.float64)
+        for k, v in sc.items():
+            out[f'{tag}_scores_' + k.replace('/', '_')] = np.array(v, dtype=np.float64)
+    save('g21_label_quality.npz', **out)
+
+
 ALL = dict(g01=g01_convlstm, g02=g02_partition, g03=g03_attention, g04=g04_backbone, g05=g05_head,
            g06=g06_simota, g07=g07_postprocess, g08=g08_pseudo, g10=g10_voxel, g11=g11_manifest,
            g12=g12_trainstep, g13=g13_tracker, g14=g14_augment, g15=g15_evaluator, g16=g16_tta_result, g17=g17_loader, g18=g18_autocast,
-           g19=g19_head_options, g20=g20_trajectory)
+           g19=g19_head_options, g20=g20_trajectory, g21=g21_label_quality)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)

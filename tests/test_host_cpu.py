@@ -460,3 +460,47 @@ def test_label_transforms_and_their_inverses():
     far = SparselyBatchedObjectLabels([ObjectLabels(torch.tensor([[1., 2., 3., 10., 8., 1., 1., 1.]]), (240, 304))])
     far.zoom_in_and_rescale_(zoom_coordinates_x0y0=(150, 120), zoom_in_factor=2.0)
     assert far[0] is None
+
+
+@pytest.mark.parametrize('tag,nc,hw', [('gen1', 2, (240, 304)), ('gen4', 3, (360, 640))])
+def test_pseudo_label_quality_statistics_golden(golden_dir, tag, nc, hw):
+    """``evaluate_label`` / ``get_scores_ious`` (the pseudo-label quality statistics of the reference's predict loop, modules/utils/ssod.py:209-350)
+    against what the reference's own functions returned on the same label lists (g21): every key, every number; then through the
+    ``PseudoLabeler._evaluate_pseudo_label`` bookkeeping (running weighted means + capped raw lists, pseudo_labeler.py:591-620)."""
+    import os
+    from leod_amd.data.genx_utils.labels import ObjectLabels
+    from leod_amd.modules.utils.ssod import evaluate_label, get_scores_ious, merge_label, AverageMeter
+    g = np.load(os.path.join(golden_dir, 'g21_label_quality.npz'))
+    gt_l = [None if i == 7 else ObjectLabels(torch.from_numpy(g[f'{tag}_gt{i}']), hw) for i in range(8)]
+    pse_l = [ObjectLabels(torch.from_numpy(g[f'{tag}_pse{i}']), hw) for i in range(8)]
+    mask = np.ones(8, dtype=bool)
+    mask[4] = False
+    ev = evaluate_label(gt_l, pse_l, pred_mask=mask, num_cls=nc, prefix='ssod/')
+    assert sorted(ev) == [str(k) for k in g[f'{tag}_eval_keys']]
+    np.testing.assert_allclose(np.array([float(ev[k]) for k in sorted(ev)]), g[f'{tag}_eval_vals'], rtol=1e-6, atol=1e-7)
+    sc = get_scores_ious(gt_l, pse_l, pred_mask=mask, num_cls=nc, prefix='ssod/')
+    keys = sorted(k for k in g.files if k.startswith(f'{tag}_scores_'))
+    assert sorted(f'{tag}_scores_' + k.replace('/', '_') for k in sc) == keys
+    for k, v in sc.items():
+        np.testing.assert_allclose(np.array(v, dtype=np.float64), g[f'{tag}_scores_' + k.replace('/', '_')], rtol=1e-6, atol=1e-7, err_msg=k)
+    # the [L][B] form the reference's temporal_wrapper accepts gives the same numbers
+    ev2 = evaluate_label([gt_l[:4], gt_l[4:]], [pse_l[:4], pse_l[4:]], pred_mask=mask.reshape(2, 4), num_cls=nc, prefix='ssod/')
+    assert {k: float(v) for k, v in ev2.items()} == {k: float(v) for k, v in ev.items()}
+    # merge_label: GT where present, pseudo label elsewhere
+    merged, had_gt = merge_label(list(gt_l), pse_l)
+    assert had_gt == [True] * 7 + [False] and merged[7] is pse_l[7] and merged[0] is gt_l[0]
+    # the module's bookkeeping: two chunks weigh by the number of frames with GT of the class
+    class _M:
+        pass
+    from leod_amd.modules.pseudo_labeler import PseudoLabeler
+    m = _M()
+    m.metrics, m.results, m.num_classes = {}, {}, nc
+    halves = [([x for x in gt_l[:4]], pse_l[:4]), ([x for x in gt_l[4:7]], pse_l[4:7])]
+    for gl, pl in halves:
+        PseudoLabeler._evaluate_pseudo_label(m, gl, pl)
+    whole = evaluate_label(gt_l[:7], pse_l[:7], pred_mask=np.ones(7, dtype=bool), num_cls=nc, prefix='ssod/')
+    for k, meter in m.metrics.items():
+        if 'teacher_A' in k:                                  # means of per-frame ratios: chunk-weighted mean == mean over all frames
+            assert isinstance(meter, AverageMeter) and abs(meter.avg - float(whole[k])) < 1e-6, k
+    all_sc = get_scores_ious(gt_l[:7], pse_l[:7], pred_mask=np.ones(7, dtype=bool), num_cls=nc, prefix='ssod/')
+    assert m.results['ssod/true_ious_all'] == pytest.approx(all_sc['ssod/true_ious_all'])

@@ -848,6 +848,17 @@ def test_pseudo_label_round_one_rank_equals_two_ranks(gpu, manifest, tmp_path):
     assert n_boxes > 20
     for k, v in one['metrics'].items():
         assert res[2][0][1]['metrics'][k] == pytest.approx(v, rel=1e-6, abs=1e-9), k
+    # precision / recall of the pseudo labels on the withheld GT frames (reference pseudo_labeler.py:591-620): per-class running means merged
+    # over the ranks equal the one-rank run; the raw lists are written next to the dataset (predict.py:226-230)
+    q1, q2 = one['label_quality'], res[2][0][1]['label_quality']
+    assert q1 and sorted(q1) == sorted(q2) and any('teacher_AR@50' in k for k in q1)
+    for k, v in q1.items():
+        assert q2[k] == pytest.approx(v, rel=1e-5, abs=1e-6), k
+        assert 0.0 <= v or 'num' in k
+    import pickle
+    with open(one['model_results'], 'rb') as f:
+        raw = pickle.load(f)
+    assert len(raw['ssod/true_ious_all']) == len(raw['ssod/obj_scores_all']) > 0 and float(raw['ssod/true_ious_all'].max()) <= 1.0
     # the reference's own end-to-end verifier (predict.py:67-115) on every recording both runs wrote: the sparse GT frames are retained
     # unchanged, every other labelled frame holds pseudo labels only, the frame table is sorted and inside the recording
     from leod_amd.predict import verify_data
