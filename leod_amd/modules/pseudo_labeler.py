@@ -291,6 +291,18 @@ class PseudoLabeler(Module):
     # tracking filter), which inference tensors only allow inside Lightning's own inference-mode predict loop
     @torch.no_grad()
     def _predict_step_impl(self, batch: Any, mode: Mode = Mode.TEST):
+        if self.dst_config.get('only_load_labels', False):
+            # tracking-only post-processing of an existing pseudo dataset (reference :625-637, predict.py:137-155): the loader delivers the labels
+            # without event frames, nothing is predicted, EventSeqData applies the tracker filter when the recordings are saved
+            data = batch[DATA_KEY]
+            assert all(lbl.is_empty() for lbl in data[DataType.SKIPPED_OBJLABELS_SEQ])
+            labels_bl = [list(lbl) for lbl in zip(*data[DataType.OBJLABELS_SEQ])]                  # L x B -> B x L
+            B = len(labels_bl)
+            out = (labels_bl, data[DataType.PATH], th.stack(data[DataType.EV_IDX]).transpose(1, 0).cpu().numpy().tolist(),
+                   data[DataType.IS_FIRST_SAMPLE].cpu().numpy().tolist(), data[DataType.IS_LAST_SAMPLE].cpu().numpy().tolist(),
+                   th.stack(data[DataType.IS_PADDED_MASK]).transpose(1, 0).cpu().numpy().tolist(),
+                   data['is_hflip'] if 'is_hflip' in data else [False] * B, data[DataType.IS_REVERSED].cpu().numpy().tolist())
+            return lambda: out
         data = self.get_data_from_batch(batch)
         worker_id = self.get_worker_id_from_batch(batch)
         ev_seq = data[DataType.EV_REPR]

@@ -754,7 +754,7 @@ def test_module_world2_through_reference_surface(gpu, manifest):
 
 
 # ---- the pseudo-label pass over a dataset on disk, one rank vs two ranks ---------------------------------------
-def _pseudo_label_worker(rank, world, port, tree, save_dir, manifest, q):
+def _pseudo_label_worker(rank, world, port, tree, save_dir, manifest, q, min_track_len=2, track_only=False):
     import os
     import torch.distributed as dist
     if world > 1:
@@ -774,7 +774,11 @@ def _pseudo_label_worker(rank, world, port, tree, save_dir, manifest, q):
     cfg.model.backbone.stage.attention.partition_size = (2, 3)
     cfg.model.postprocess.confidence_threshold = 0.01
     cfg.model.pseudo_label.obj_thresh, cfg.model.pseudo_label.cls_thresh = [0.1, 0.05], [0.1, 0.05]
-    cfg.model.pseudo_label.min_track_len = 2
+    cfg.model.pseudo_label.min_track_len = min_track_len
+    if track_only:                                     # predict.py:137-155: a second pass over a pseudo dataset that only runs the tracker filter
+        cfg.tta.enable = False
+        cfg.dataset.ratio = cfg.dataset.train_ratio = -1
+        cfg.dataset.only_load_labels = True
     mod = fetch_model_module(cfg)
     mod.mdl.load_state_dict(synth_state_dict(manifest['micro'], 8))
     mod.to(DEV)
@@ -784,6 +788,75 @@ def _pseudo_label_worker(rank, world, port, tree, save_dir, manifest, q):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def test_tracking_only_pass_over_a_pseudo_dataset(gpu, manifest, tmp_path):
+    """The two-step variant of the pseudo-label round (predict.py:137-155, pseudo_labeler.py:625-637): pass 1 writes pseudo labels without
+    the tracker filter (min_track_len 1); pass 2 reads that dataset with ``dataset.only_load_labels`` -- no event frames, no model forward --
+    and applies the tracker filter when it saves: every box of the first pass is still there, boxes on short tracklets have become ignore
+    boxes, missed detections of surviving tracklets are in-painted as ignore boxes; the retained GT survives (the reference's verifier)."""
+    import os
+    import pickle
+    import torch.multiprocessing as mp
+    from oracle.synth import LOADER_RECORDINGS, synth_dataset_tree
+    from leod_amd.data.genx_utils import dataset_streaming
+    from leod_amd.data.utils import misc
+    from leod_amd.predict import verify_data
+    tree = synth_dataset_tree(str(tmp_path / 'src'), 'gen1', False, frame_hw=HW)
+    fn = os.path.join(dataset_streaming.SPLITS_DIR, 'gen1', 'ssod_0.500-off0.pkl')
+    had = os.path.exists(fn)
+    os.makedirs(os.path.dirname(fn), exist_ok=True)
+    if not had:
+        with open(fn, 'wb') as f:
+            pickle.dump({name: list(range(0, len(lab), 2)) for name, _, _, lab in LOADER_RECORDINGS}, f)
+    ctx = mp.get_context('spawn')
+
+    def run(src, dst, **kw):
+        q = ctx.Queue()
+        p = ctx.Process(target=_pseudo_label_worker, args=(0, 1, 0, src, dst, manifest, q), kwargs=kw)
+        p.start()
+        out = q.get(timeout=300)
+        p.join(120)
+        assert p.exitcode == 0
+        return out[1]
+    try:
+        one_pass = run(tree, str(tmp_path / 'gen1_onepass' / 'train'), min_track_len=2)
+        first = run(tree, str(tmp_path / 'gen1_notrack' / 'train'), min_track_len=1)
+        second = run(str(tmp_path / 'gen1_notrack'), str(tmp_path / 'gen1_notrack_trk' / 'train'), min_track_len=2, track_only=True)
+    finally:
+        if not had:
+            os.remove(fn)
+    assert second['num_sequences'] == first['num_sequences'] == len(LOADER_RECORDINGS) and second['metrics'] is None
+    n_marked = n_added = n_onepass_ign = 0
+    for name, _, _, lab in LOADER_RECORDINGS:
+        a, b, c = (str(tmp_path / d / 'train' / name) for d in ('gen1_onepass', 'gen1_notrack_trk', 'gen1_notrack'))
+        assert misc.read_objframe_idx_2_repr_idx(a).tolist() == misc.read_objframe_idx_2_repr_idx(b).tolist()
+        (la, _), (lb, sb), (lc, sc) = misc.read_npz_labels(a), misc.read_npz_labels(b), misc.read_npz_labels(c)
+        fb, fc = misc.read_objframe_idx_2_repr_idx(b).tolist(), misc.read_objframe_idx_2_repr_idx(c).tolist()
+        assert set(fc) <= set(fb)                                   # in-painting may add labelled frames, never drops one
+        eb, ec = np.append(sb, len(lb)), np.append(sc, len(lc))
+        for k, f in enumerate(fc):
+            rows_c = lc[ec[k]:ec[k + 1]]
+            kb = fb.index(f)
+            rows_b = lb[eb[kb]:eb[kb + 1]]
+            # every box of the first pass is still there (same geometry); the tracker filter only re-labels boxes on short tracklets as
+            # ignore boxes (class id 1024, pseudo_labeler.py:296-309) and in-paints missed detections of surviving tracklets as ignore boxes
+            # (geometry as the loader of the second pass sees it: clamped to the frame, labels.py clamp_to_frame_)
+            def box(x):
+                x0, y0 = np.clip(x['x'], 0, HW[1] - 1), np.clip(x['y'], 0, HW[0] - 1)
+                x1, y1 = np.clip(x['x'] + x['w'], 0, HW[1] - 1), np.clip(x['y'] + x['h'], 0, HW[0] - 1)
+                return tuple(np.round([x0, y0, x1, y1], 2))
+            import collections
+            gc_, gb_ = collections.Counter(box(x) for x in rows_c), collections.Counter(box(x) for x in rows_b)
+            assert all(gb_[g] >= n for g, n in gc_.items()), (name, f)
+            live_c, live_b = int((rows_c['class_id'] != 1024).sum()), int((rows_b['class_id'] != 1024).sum())
+            assert live_b <= live_c and set(rows_b['class_id'].tolist()) <= set(rows_c['class_id'].tolist()) | {1024}
+            n_marked += live_c - live_b
+            n_added += len(rows_b) - len(rows_c)
+            assert (rows_b['t'][rows_b['class_id'] == 1024] == 0).all()          # ignore boxes are pseudo labels, never GT
+        n_onepass_ign += int((la['class_id'] == 1024).sum())
+        assert verify_data(b, old_dir=os.path.join(tree, 'train', name), label_list=list(range(0, len(lab), 2))) >= 1
+    assert n_marked + n_added > 0 and n_onepass_ign > 0           # the filter acted in both variants
 
 
 def test_pseudo_label_round_one_rank_equals_two_ranks(gpu, manifest, tmp_path):
