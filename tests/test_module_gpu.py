@@ -790,6 +790,65 @@ def _pseudo_label_worker(rank, world, port, tree, save_dir, manifest, q, min_tra
         dist.destroy_process_group()
 
 
+def test_fit_and_evaluation_drivers(gpu, manifest, tmp_path):
+    """``leod_amd.train.fit`` / ``run_evaluation`` (the Lightning-free restatement of train.py:221-250 / val.py:83-96) on a synthetic dataset
+    tree through the product surface: DataModule('fit') (mixed sampling: random-access + streaming loaders), ``Module.training_step`` under
+    launch plans, FlatAdamW + OneCycle, a validation pass every 6 steps (on the TEST split, as the reference's fit stage does), a
+    Lightning-shaped checkpoint; then evaluation of the checkpoint in a fresh module and a resumed run that continues the schedule."""
+    import os
+    from oracle.synth import synth_dataset_tree
+    from leod_amd.config import full_config, dynamically_modify_train_config
+    from leod_amd.modules.data.genx import DataModule
+    from leod_amd.modules.utils.fetch import fetch_model_module
+    from leod_amd.train import fit, run_evaluation
+    tree = synth_dataset_tree(str(tmp_path / 'src'), 'gen1', False, frame_hw=HW)
+
+    def build():
+        over = dict(model=dict(backbone=dict(embed_dim=16, stage=dict(attention=dict(dim_head=8)))),
+                    # (no spatial augmentation: the synthetic 60 x 90 recordings carry Gen1's 240 x 304 as their label frame size, which is what the
+                    # label transforms and the zoom-in window work in; the augmentation path has its own tests against the reference, g14)
+                    dataset=dict(path=tree, sequence_length=4, data_augmentation=dict(
+                        random=dict(prob_hflip=0, zoom=dict(prob=0)), stream=dict(start_from_zero=True, prob_hflip=0, zoom=dict(prob=0)))))
+        cfg = dynamically_modify_train_config(full_config('gen1', 'small', overrides=over))
+        cfg.dataset.ev_repr_hw = HW
+        cfg.model.backbone.in_res_hw = (64, 96)
+        cfg.model.backbone.stage.attention.partition_size = (2, 3)
+        cfg.model.postprocess.confidence_threshold = 0.001
+        cfg.training.max_steps = 15
+        cfg.training.lr_scheduler.total_steps = 15
+        cfg.validation.val_check_interval = 6
+        mod = fetch_model_module(cfg)
+        mod.mdl.load_state_dict(synth_state_dict(manifest['micro'], 8))
+        mod.to(DEV)
+        return cfg, mod, DataModule(cfg.dataset, 2, 1, 2, 2, prefetch=2)
+
+    cfg, mod, dm = build()
+    ck = str(tmp_path / 'ck' / 'last.ckpt')
+    seen = []
+    hist = fit(cfg, mod, dm, max_steps=12, log_every_n_steps=3, ckpt_path=ck, on_step=lambda s, out: seen.append(s))
+    assert hist['global_step'] == 12 and seen == list(range(1, 13))
+    assert [s for s, _ in hist['loss']] == [3, 6, 9, 12] and all(np.isfinite(v) for _, v in hist['loss'])
+    assert [s for s, _ in hist['val']] == [6, 12] and all(kp is not None and 'val/AP' in kp for _, kp in hist['val'])
+    assert mod._plans.replays >= 6, mod._plans.info()              # the training steps did go through the launch plans
+    assert os.path.exists(ck)
+    saved = torch.load(ck, map_location='cpu', weights_only=False)
+    assert saved['global_step'] == 12 and any(k.startswith('mdl.') for k in saved['state_dict'])
+    # evaluation of the checkpoint in a fresh module (val.py): same KPIs as the last validation of the fit (same split, same weights)
+    cfg2, mod2, dm2 = build()
+    mod2.load_weight(ck)
+    kp = run_evaluation(cfg2, mod2, dm2, 'test')
+    last = hist['val'][-1][1]
+    assert set(k.split('/')[1] for k in kp) == set(k.split('/')[1] for k in last)
+    for k, v in last.items():
+        assert kp['test/' + k.split('/')[1]] == pytest.approx(v, rel=1e-4, abs=1e-6), k
+    # a resumed run continues at step 12 with the optimiser state and the schedule of the checkpoint
+    cfg3, mod3, dm3 = build()
+    lr_seen = []
+    h3 = fit(cfg3, mod3, dm3, log_every_n_steps=1, resume_from=ck, val_check_interval=0, limit_val_batches=1,
+             on_step=lambda s, out: lr_seen.append(mod3.optimizers_lr() if hasattr(mod3, 'optimizers_lr') else None))
+    assert h3['global_step'] == 15 and [s for s, _ in h3['loss']] == [13, 14, 15]
+
+
 def test_tracking_only_pass_over_a_pseudo_dataset(gpu, manifest, tmp_path):
     """The two-step variant of the pseudo-label round (predict.py:137-155, pseudo_labeler.py:625-637): pass 1 writes pseudo labels without
     the tracker filter (min_track_len 1); pass 2 reads that dataset with ``dataset.only_load_labels`` -- no event frames, no model forward --
