@@ -1,0 +1,78 @@
+"""Box-format helpers with the interface of the reference's utils/bbox.py:11-92 (numpy arrays or torch tensors; coordinates either in the
+last axis, ``last4=True``, or as the four leading rows, ``last4=False``; ``format_`` 'center' = (cx, cy, w, h), 'corner' = (x0, y0, w, h)).
+The hot path does these conversions inside its kernels (pseudo_filter_kernel, postprocess_nms_kernel); the module exists for callers of
+the reference's helpers (analysis scripts, the tracker's host code)."""
+from typing import List, Tuple, Union
+
+import numpy as np
+import torch as th
+
+Boxes = Union[np.ndarray, th.Tensor]
+
+
+def _lib(values):
+    first = values[0]
+    if isinstance(first, np.ndarray):
+        return 'np'
+    if isinstance(first, th.Tensor):
+        return 'th'
+    raise ValueError(f'Unknown type {type(first)}')
+
+
+def np_th_stack(values: List[Boxes], axis: int = 0):
+    return np.stack(values, axis=axis) if _lib(values) == 'np' else th.stack(values, dim=axis)
+
+
+def np_th_concat(values: List[Boxes], axis: int = 0):
+    return np.concatenate(values, axis=axis) if _lib(values) == 'np' else th.cat(values, dim=axis)
+
+
+def get_bbox_coords(bbox: Boxes, last4: bool = None) -> Tuple[Tuple[Boxes, Boxes, Boxes, Boxes], bool]:
+    """The four coordinate arrays of ``bbox`` and where they were found.  ``last4=None`` guesses from the shape -- four leading rows win, as in
+    the reference (a [4, 4] array is therefore read row-wise)."""
+    if isinstance(bbox, list):
+        bbox = np_th_stack(bbox, axis=0)
+    if last4 is None:
+        if bbox.shape[0] == 4:
+            last4 = False
+        elif bbox.shape[-1] == 4:
+            last4 = True
+        else:
+            raise ValueError(f'Unknown shape {bbox.shape}')
+    if last4:
+        return (bbox[..., 0], bbox[..., 1], bbox[..., 2], bbox[..., 3]), True
+    a, b, c, d = bbox
+    return (a, b, c, d), False
+
+
+def construct_bbox(abcd: Tuple[Boxes, Boxes, Boxes, Boxes], last4: bool):
+    return np_th_stack(list(abcd), axis=-1 if last4 else 0)
+
+
+def xywh2xyxy(xywh, format_: str = 'center', last4: bool = None):
+    from leod_amd.data.genx_utils.labels import ObjectLabels
+    if isinstance(xywh, ObjectLabels):
+        return xywh.get_xyxy()
+    (x, y, w, h), last4 = get_bbox_coords(xywh, last4=last4)
+    if format_ == 'center':
+        x1, x2, y1, y2 = x - w / 2., x + w / 2., y - h / 2., y + h / 2.
+    elif format_ == 'corner':
+        x1, x2, y1, y2 = x, x + w, y, y + h
+    else:
+        raise NotImplementedError(f'Unknown format {format_}')
+    return construct_bbox((x1, y1, x2, y2), last4=last4)
+
+
+def xyxy2xywh(xyxy, format_: str = 'center', last4: bool = None):
+    from leod_amd.data.genx_utils.labels import ObjectLabels
+    if isinstance(xyxy, ObjectLabels):
+        return xyxy.get_xywh(format_=format_)
+    (x1, y1, x2, y2), last4 = get_bbox_coords(xyxy, last4=last4)
+    w, h = x2 - x1, y2 - y1
+    if format_ == 'center':
+        x, y = (x1 + x2) / 2., (y1 + y2) / 2.
+    elif format_ == 'corner':
+        x, y = x1, y1
+    else:
+        raise NotImplementedError(f'Unknown format {format_}')
+    return construct_bbox((x, y, w, h), last4=last4)

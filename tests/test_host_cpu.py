@@ -504,3 +504,37 @@ def test_pseudo_label_quality_statistics_golden(golden_dir, tag, nc, hw):
             assert isinstance(meter, AverageMeter) and abs(meter.avg - float(whole[k])) < 1e-6, k
     all_sc = get_scores_ious(gt_l[:7], pse_l[:7], pred_mask=np.ones(7, dtype=bool), num_cls=nc, prefix='ssod/')
     assert m.results['ssod/true_ious_all'] == pytest.approx(all_sc['ssod/true_ious_all'])
+
+
+def test_bbox_format_helpers():
+    """``leod_amd.utils.bbox`` (the reference's utils/bbox.py:11-92): numpy and torch, coordinates in the last axis or as four leading rows,
+    centre and corner formats, round trips, the ObjectLabels shortcut, the shape guess of ``last4=None``."""
+    from leod_amd.data.genx_utils.labels import ObjectLabels
+    from leod_amd.utils import bbox as B
+    g = torch.Generator().manual_seed(3)
+    xyxy = torch.rand(7, 4, generator=g) * 50
+    xyxy[:, 2:] += xyxy[:, :2] + 1
+    for to in (lambda t: t, lambda t: t.numpy()):
+        a = to(xyxy)
+        for fmt in ('center', 'corner'):
+            w = B.xyxy2xywh(a, format_=fmt)
+            assert type(w) is type(a) and tuple(w.shape) == (7, 4)
+            ref = torch.stack([(xyxy[:, 0] + xyxy[:, 2]) / 2 if fmt == 'center' else xyxy[:, 0],
+                               (xyxy[:, 1] + xyxy[:, 3]) / 2 if fmt == 'center' else xyxy[:, 1], xyxy[:, 2] - xyxy[:, 0], xyxy[:, 3] - xyxy[:, 1]], -1)
+            np.testing.assert_allclose(np.asarray(w), ref.numpy(), rtol=1e-6)
+            np.testing.assert_allclose(np.asarray(B.xywh2xyxy(w, format_=fmt)), xyxy.numpy(), rtol=1e-5, atol=1e-5)
+            # four leading rows ([4, N]); a [4, 4] array is read row-wise when last4 is not given (the reference's documented quirk)
+            rows = a.T if isinstance(a, np.ndarray) else a.t()
+            wr = B.xyxy2xywh(rows, format_=fmt)
+            assert tuple(wr.shape) == (4, 7)
+            np.testing.assert_allclose(np.asarray(wr).T, np.asarray(w), rtol=1e-6)
+        (c0, c1, c2, c3), last4 = B.get_bbox_coords(a[:4])
+        assert last4 is False and np.allclose(np.asarray(c0), np.asarray(a[0]))
+        assert B.get_bbox_coords(a[:4], last4=True)[1] is True
+    assert torch.equal(B.np_th_concat([xyxy[:2], xyxy[2:]]), xyxy) and np.array_equal(B.np_th_stack([xyxy[0].numpy(), xyxy[1].numpy()]), xyxy[:2].numpy())
+    with pytest.raises(ValueError):
+        B.get_bbox_coords(torch.zeros(3, 5))
+    with pytest.raises(NotImplementedError):
+        B.xyxy2xywh(xyxy, format_='polar')
+    lab = ObjectLabels(torch.tensor([[1., 10., 20., 6., 4., 0., 1., 1.]]), (240, 304))
+    assert B.xywh2xyxy(lab).tolist() == [[10., 20., 16., 24.]] and B.xyxy2xywh(lab, format_='center').tolist() == [[13., 22., 6., 4.]]
