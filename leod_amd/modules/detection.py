@@ -502,11 +502,21 @@ class Module(_Base):
     def predict_one_seq(self, batch: Any, head_every: int = 128):
         """B=1 full sequence (reference :520-581): the backbone over chunks of ``head_every`` timesteps (time-batched, LSTM
         state carried from chunk to chunk), the head + postprocess once per chunk."""
+        mode = Mode.TEST
         data = self.get_data_from_batch(batch)
+        worker_id = self.get_worker_id_from_batch(batch)
         ev_seq = data[DataType.EV_REPR]
         labels_seq = data[DataType.OBJLABELS_SEQ]
-        prev, preds = None, []
+        is_first = data[DataType.IS_FIRST_SAMPLE]
         L = len(ev_seq)
+        assert L > 0 and ev_seq[0].shape[0] == len(labels_seq[0]) == is_first.shape[0] == 1, 'one recording at a time'
+        self.mode_2_rnn_states[mode].reset(worker_id=worker_id, indices_or_bool_tensor=is_first)
+        hw = tuple(ev_seq[0].shape[-2:])
+        if self.mode_2_hw[mode] is None:
+            self.mode_2_hw[mode] = hw
+        else:
+            assert self.mode_2_hw[mode] == hw
+        prev, preds = None, []                           # (the reference starts the recording from a zero state, :544)
         in_features = self.mdl.fpn.in_features
         for lo in range(0, L, head_every):
             chunk = ev_seq[lo:lo + head_every]

@@ -790,6 +790,34 @@ def _pseudo_label_worker(rank, world, port, tree, save_dir, manifest, q, min_tra
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('time_batched', [True, False])
+def test_predict_one_seq_vs_oracle(gpu, manifest, time_batched):
+    """``Module.predict_one_seq`` (reference modules/detection.py:520-581, the entry of vis_pred.py): one recording of 9 frames, the backbone in
+    chunks of 4 timesteps with the LSTM state carried from chunk to chunk, head + NMS per chunk -- detections of every frame against the
+    oracle's frame-by-frame inference, in both schedules."""
+    mod, sd, cfg = micro_module(manifest, 6, 'test')
+    mod.eval()
+    mod.time_batched = time_batched
+    cfg.model.postprocess.confidence_threshold = 0.001
+    L = 9
+    ev = synth_events(L, 1, 20, HW[0], HW[1], seed=77, as_uint8=True)
+    flat = micro_labels(2, 78, [1e6, 2e6])
+    labels_tb = [[flat[0]] if t == 3 else [flat[1]] if t == 8 else [None] for t in range(L)]
+    with torch.no_grad():
+        preds, ev_out, lbls = mod.predict_one_seq(loader_batch(ev, labels_tb, torch.ones(1, dtype=torch.bool)), head_every=4)
+        dets, _, _ = ot.infer_sequence({k: v.clone() for k, v in sd.items()}, MICRO, ev, conf_thre=0.001, nms_thre=0.45)
+    assert len(preds) == len(dets) == L and tuple(ev_out.shape) == (L, 20, HW[0], HW[1])
+    assert [l is not None for l in lbls] == [t in (3, 8) for t in range(L)]
+    n = 0
+    for p, d in zip(preds, dets):
+        assert len(p) == len(d)
+        if len(d):
+            np.testing.assert_allclose(p.cpu().numpy()[:, :6], d.numpy()[:, :6], rtol=2e-4, atol=2e-4)
+            assert np.array_equal(p.cpu().numpy()[:, 6], d.numpy()[:, 6])
+        n += len(d)
+    assert n > 20
+
+
 def test_fit_and_evaluation_drivers(gpu, manifest, tmp_path):
     """``leod_amd.train.fit`` / ``run_evaluation`` (the Lightning-free restatement of train.py:221-250 / val.py:83-96) on a synthetic dataset
     tree through the product surface: DataModule('fit') (mixed sampling: random-access + streaming loaders), ``Module.training_step`` under
