@@ -89,6 +89,19 @@ class ObjectLabels:
     def new_zeros(self) -> 'ObjectLabels':
         return ObjectLabels(self.object_labels.new_zeros((0, len(FIELDS))), self.input_size_hw)
 
+    def __eq__(self, other) -> bool:
+        """Same frame size and the same boxes in any order, to 1e-3 per field (labels.py:271-286)."""
+        if not isinstance(other, ObjectLabels) or self.input_size_hw != other.input_size_hw or \
+                tuple(self.object_labels.shape) != tuple(other.object_labels.shape):
+            return False
+        if len(self) == 0:
+            return True
+        a, b = th.as_tensor(self.object_labels).float(), th.as_tensor(other.object_labels).float()
+        near = (a[None, :, :] - b[:, None, :]).abs().amax(dim=2) < 1e-3        # [other row, own row]
+        return bool(near.any(dim=1).all())
+
+    __hash__ = None
+
     def get_reverse(self) -> 'ObjectLabels':
         """Rows in reverse order (labels.py:515-519): the time-reversed view used by backward tracking."""
         return ObjectLabels(self.object_labels.flip(0), self.input_size_hw)
@@ -362,6 +375,19 @@ class SparselyBatchedObjectLabels:
         for l in self.sparse_object_labels_batch:
             if l is not None:
                 l.reverse_flip_lr_()
+
+    def __eq__(self, other) -> bool:
+        if not isinstance(other, SparselyBatchedObjectLabels) or len(self) != len(other):
+            return False
+        return all((a is None and b is None) or (a is not None and b is not None and a == b)
+                   for a, b in zip(self.sparse_object_labels_batch, other.sparse_object_labels_batch))
+
+    __hash__ = None
+
+    def get_labels_padded(self, pad=None):
+        """The labels with ``pad`` where a sample has none, and the indices of the samples that have labels (labels.py:731-734)."""
+        return ([l if l is not None else pad for l in self.sparse_object_labels_batch],
+                [i for i, l in enumerate(self.sparse_object_labels_batch) if l is not None])
 
     def set_empty_labels_to_none_(self):
         """A transform may have dropped every box of a frame (labels.py:650-654)."""

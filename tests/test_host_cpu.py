@@ -538,3 +538,20 @@ def test_bbox_format_helpers():
         B.xyxy2xywh(xyxy, format_='polar')
     lab = ObjectLabels(torch.tensor([[1., 10., 20., 6., 4., 0., 1., 1.]]), (240, 304))
     assert B.xywh2xyxy(lab).tolist() == [[10., 20., 16., 24.]] and B.xyxy2xywh(lab, format_='center').tolist() == [[13., 22., 6., 4.]]
+
+
+def test_label_equality_and_padding_helpers():
+    """``ObjectLabels.__eq__`` (order-invariant, 1e-3 per field, labels.py:271-286), ``SparselyBatchedObjectLabels.__eq__`` / ``get_labels_padded``
+    (:632-638, :731-734)."""
+    from leod_amd.data.genx_utils.labels import ObjectLabels, SparselyBatchedObjectLabels
+    rows = torch.tensor([[1., 10., 20., 6., 4., 0., 1., 1.], [1., 50., 30., 8., 8., 1., .5, .7]])
+    a, b = ObjectLabels(rows.clone(), (240, 304)), ObjectLabels(rows.flip(0).clone(), (240, 304))
+    assert a == b and b == a and not (a != b)
+    c = ObjectLabels(rows.clone(), (240, 304))
+    c.object_labels[0, 1] += 0.01
+    assert a != c and a != ObjectLabels(rows[:1].clone(), (240, 304)) and a != ObjectLabels(rows.clone(), (120, 152)) and a != 3
+    assert a.new_zeros() == b.new_zeros()
+    s1, s2 = SparselyBatchedObjectLabels([a, None, c]), SparselyBatchedObjectLabels([b, None, c])
+    assert s1 == s2 and s1 != SparselyBatchedObjectLabels([a, c, None]) and s1 != SparselyBatchedObjectLabels([a, None])
+    padded, idx = s1.get_labels_padded(pad='PAD')
+    assert padded[0] is a and padded[1] == 'PAD' and padded[2] is c and idx == [0, 2]
