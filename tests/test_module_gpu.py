@@ -827,7 +827,7 @@ def test_fit_and_evaluation_drivers(gpu, manifest, tmp_path):
     from oracle.synth import synth_dataset_tree
     from leod_amd.config import full_config, dynamically_modify_train_config
     from leod_amd.modules.data.genx import DataModule
-    from leod_amd.modules.utils.fetch import fetch_model_module
+    from leod_amd.modules.utils.fetch import fetch_model_module, fetch_data_module
     from leod_amd.train import fit, run_evaluation
     tree = synth_dataset_tree(str(tmp_path / 'src'), 'gen1', False, frame_hw=HW)
 
@@ -848,7 +848,11 @@ def test_fit_and_evaluation_drivers(gpu, manifest, tmp_path):
         mod = fetch_model_module(cfg)
         mod.mdl.load_state_dict(synth_state_dict(manifest['micro'], 8))
         mod.to(DEV)
-        return cfg, mod, DataModule(cfg.dataset, 2, 1, 2, 2, prefetch=2)
+        cfg.batch_size.train = cfg.batch_size.eval = 2
+        cfg.hardware.num_workers.train, cfg.hardware.num_workers.eval = 2, 1
+        dm = fetch_data_module(cfg, prefetch=2)                    # the reference's own constructor path (modules/utils/fetch.py:22-38)
+        assert isinstance(dm, DataModule) and dm.overall_batch_size_train == 2 and dm.overall_num_workers_eval == 1
+        return cfg, mod, dm
 
     cfg, mod, dm = build()
     ck = str(tmp_path / 'ck' / 'last.ckpt')
