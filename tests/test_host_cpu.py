@@ -555,3 +555,22 @@ def test_label_equality_and_padding_helpers():
     assert s1 == s2 and s1 != SparselyBatchedObjectLabels([a, c, None]) and s1 != SparselyBatchedObjectLabels([a, None])
     padded, idx = s1.get_labels_padded(pad='PAD')
     assert padded[0] is a and padded[1] == 'PAD' and padded[2] is c and idx == [0, 2]
+
+
+def test_list_helpers_and_temporal_wrapper():
+    """utils/helpers.py:7-104 of the reference: flatten / unflatten of [L][B] lists and the wrapper built on them."""
+    from leod_amd.utils import helpers as H
+    assert H.th_cat([]).numel() == 0 and H.th_cat([torch.ones(2), torch.zeros(1)]).tolist() == [1., 1., 0.]
+    assert H.clamp(5, 0, 3) == 3 and H.clamp(-1, 0, 3) == 0 and H.clamp(2, 0, 3) == 2
+    assert H.subsample_list(list(range(10)), 3) == [0, 3, 6] and H.subsample_list(list(range(10)), 3, offset=1) == [1, 4, 7]
+    flat, lens = H.list2d_to_list1d([[1, 2], [3], [4, 5, 6]])
+    assert flat == [1, 2, 3, 4, 5, 6] and lens == [2, 1, 3] and H.list1d_to_list2d(flat, lens) == [[1, 2], [3], [4, 5, 6]]
+    assert H.list2d_to_list1d([1, 2]) == ([1, 2], None) and H.list1d_to_list2d([1, 2]) == [1, 2]
+
+    @H.temporal_wrapper
+    def double_and_count(xs, ys, k=2):
+        return [x * k for x in xs], [y + 1 for y in ys], len(xs)
+    a, b, n = double_and_count([[1, 2], [3]], [[10, 20], [30]])
+    assert a == [[2, 4], [6]] and b == [[11, 21], [31]] and n == 3
+    a, b, n = double_and_count([1, 2, 3], [4, 5, 6], k=3)
+    assert a == [3, 6, 9] and b == [5, 6, 7] and n == 3
