@@ -49,30 +49,33 @@ def construct_bbox(abcd: Tuple[Boxes, Boxes, Boxes, Boxes], last4: bool):
     return np_th_stack(list(abcd), axis=-1 if last4 else 0)
 
 
+# (origin of the box in x / y as a multiple of its width / height: centre boxes start half a size before their anchor point)
+_ORIGIN = {'center': 0.5, 'corner': 0.0}
+
+
+def _anchor_shift(format_: str) -> float:
+    if format_ not in _ORIGIN:
+        raise NotImplementedError(f'Unknown format {format_}')
+    return _ORIGIN[format_]
+
+
 def xywh2xyxy(xywh, format_: str = 'center', last4: bool = None):
+    """(x, y, w, h) -> (x1, y1, x2, y2); ``ObjectLabels`` answer with their own corner boxes."""
     from leod_amd.data.genx_utils.labels import ObjectLabels
     if isinstance(xywh, ObjectLabels):
         return xywh.get_xyxy()
-    (x, y, w, h), last4 = get_bbox_coords(xywh, last4=last4)
-    if format_ == 'center':
-        x1, x2, y1, y2 = x - w / 2., x + w / 2., y - h / 2., y + h / 2.
-    elif format_ == 'corner':
-        x1, x2, y1, y2 = x, x + w, y, y + h
-    else:
-        raise NotImplementedError(f'Unknown format {format_}')
-    return construct_bbox((x1, y1, x2, y2), last4=last4)
+    k = _anchor_shift(format_)
+    (ax, ay, bw, bh), last4 = get_bbox_coords(xywh, last4=last4)
+    left, top = ax - k * bw, ay - k * bh
+    return construct_bbox((left, top, left + bw, top + bh), last4=last4)
 
 
 def xyxy2xywh(xyxy, format_: str = 'center', last4: bool = None):
+    """(x1, y1, x2, y2) -> (x, y, w, h) with the anchor point at the centre or at the top-left corner."""
     from leod_amd.data.genx_utils.labels import ObjectLabels
     if isinstance(xyxy, ObjectLabels):
         return xyxy.get_xywh(format_=format_)
-    (x1, y1, x2, y2), last4 = get_bbox_coords(xyxy, last4=last4)
-    w, h = x2 - x1, y2 - y1
-    if format_ == 'center':
-        x, y = (x1 + x2) / 2., (y1 + y2) / 2.
-    elif format_ == 'corner':
-        x, y = x1, y1
-    else:
-        raise NotImplementedError(f'Unknown format {format_}')
-    return construct_bbox((x, y, w, h), last4=last4)
+    k = _anchor_shift(format_)
+    (left, top, right, bottom), last4 = get_bbox_coords(xyxy, last4=last4)
+    bw, bh = right - left, bottom - top
+    return construct_bbox((left + k * bw, top + k * bh, bw, bh), last4=last4)
