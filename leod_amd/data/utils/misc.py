@@ -228,3 +228,34 @@ def ev_repr_files(seq_or_ev_dir: str, dst_name: Optional[str] = None) -> List[st
         if os.path.lexists(fn):
             out.append(fn)
     return out
+
+
+def read_ev_repr(fn: str) -> np.ndarray:
+    """All frames of a recording as one array [N, 20, H, W] (misc.py:83-88 of the reference reads the HDF5 file; here the raw twin is preferred)."""
+    if 'event_representations_v2' not in fn:
+        fn = get_ev_h5_fn(fn)
+    raw = resolve_link(os.path.splitext(fn)[0] + '.npy')
+    if os.path.exists(raw):
+        return np.load(raw)
+    store = H5Frames(resolve_link(fn))
+    try:
+        return store.data[:]
+    finally:
+        store.close()
+
+
+def read_labels_as_list(seq_dir: str, dst_cfg, L: int, start_idx: int = 0) -> List[Any]:
+    """The full-frequency labels of frames start_idx .. start_idx + L - 1 of a recording: ``ObjectLabels`` where a frame is labelled, None
+    elsewhere (misc.py:28-46; what vis_pred.py pairs predictions with)."""
+    from leod_amd.data.genx_utils.labels import ObjectLabelFactory
+    labels, objframe_idx_2_label_idx = read_npz_labels(seq_dir)
+    hw = tuple(dst_cfg.ev_repr_hw)
+    ds2 = bool(dst_cfg.downsample_by_factor_2)
+    if ds2:
+        hw = tuple(s * 2 for s in hw)
+    factory = ObjectLabelFactory.from_structured_array(labels, objframe_idx_2_label_idx, hw, 2 if ds2 else None)
+    out: List[Any] = [None] * L
+    for objframe_idx, repr_idx in enumerate(read_objframe_idx_2_repr_idx(seq_dir)):
+        if start_idx <= repr_idx < start_idx + L:
+            out[int(repr_idx) - start_idx] = factory[objframe_idx]
+    return out

@@ -574,3 +574,26 @@ def test_random_loader_epoch_survives_recreation():
     assert 'epoch' in inspect.signature(G.DataModule._train_loaders).parameters
     src = inspect.getsource(PL.ProcessLoader.__iter__)
     assert 'self.epoch + 1' in src and 'epoch)' in src
+
+
+def test_read_helpers_of_a_recording(tmp_path):
+    """``misc.read_ev_repr`` / ``read_labels_as_list`` (data/utils/misc.py:28-46,83-88 of the reference) on a synthetic recording: all frames as one
+    array; labels placed at their frame positions inside a window, None elsewhere."""
+    from types import SimpleNamespace
+    from oracle.synth import LOADER_RECORDINGS, synth_dataset_tree
+    from leod_amd.data.utils import misc
+    tree = synth_dataset_tree(str(tmp_path / 'src'), 'gen1', False, frame_hw=(6, 8))
+    name, _, n_frames, lab = LOADER_RECORDINGS[0]
+    seq = os.path.join(tree, 'train', name)
+    ev = misc.read_ev_repr(seq)
+    assert ev.dtype == np.uint8 and ev.shape == (n_frames, 20, 6, 8)
+    o2r = misc.read_objframe_idx_2_repr_idx(seq).tolist()
+    cfg = SimpleNamespace(ev_repr_hw=(240, 304), downsample_by_factor_2=False)
+    full = misc.read_labels_as_list(seq, cfg, L=n_frames)
+    assert len(full) == n_frames and [i for i, l in enumerate(full) if l is not None] == o2r
+    labels, starts = misc.read_npz_labels(seq)
+    assert sum(len(l) for l in full if l is not None) == len(labels)
+    lo = o2r[1]
+    window = misc.read_labels_as_list(seq, cfg, L=3, start_idx=lo)
+    assert window[0] is not None and len(window) == 3 and [i for i, l in enumerate(window) if l is not None] == [r - lo for r in o2r if lo <= r < lo + 3]
+    np.testing.assert_allclose(window[0].x.numpy() if hasattr(window[0].x, 'numpy') else window[0].x, full[lo].x)
