@@ -176,6 +176,16 @@ def get_scores_ious(gt_label, pseudo_label, pred_mask, num_cls: int, prefix: str
     return log
 
 
+def filter_w_thresh(scores: th.Tensor, class_ids: th.Tensor, thresh) -> th.Tensor:
+    """scores above one threshold, or above the threshold of their class (:136-145)."""
+    if isinstance(thresh, float):
+        return scores > thresh
+    mask = th.zeros_like(scores, dtype=th.bool)
+    for i, t in enumerate(thresh):
+        mask |= (class_ids == i) & (scores > t)
+    return mask
+
+
 class AverageMeter:
     """Running weighted mean (the reference keeps its label-quality metrics in nerv.utils.AverageMeter, pseudo_labeler.py:604-607)."""
 

@@ -992,9 +992,21 @@ def test_pseudo_label_round_one_rank_equals_two_ranks(gpu, manifest, tmp_path):
             for p in procs:
                 p.join(120)
                 assert p.exitcode == 0
+        # val_dst.py as a function: the generated dataset against the original one under the same sparse-label regime -- per-frame checks (kept
+        # GT identical, everything else pseudo) and precision / recall of the thresholded pseudo labels on the withheld GT frames
+        from leod_amd.config import full_config, dynamically_modify_train_config
+        from leod_amd.predict import evaluate_pseudo_dataset
+        over = dict(model=dict(backbone=dict(embed_dim=16, stage=dict(attention=dict(dim_head=8)))),
+                    dataset=dict(path=tree, sequence_length=4, ratio=0.5))
+        vcfg = dynamically_modify_train_config(full_config('gen1', 'small', model='pseudo_labeler', is_train=False, overrides=over))
+        vcfg.dataset.ev_repr_hw = HW
+        vcfg.hardware.num_workers.eval = 1
+        vcfg.model.pseudo_label.obj_thresh, vcfg.model.pseudo_label.cls_thresh = [0.1, 0.05], [0.1, 0.05]
+        quality = evaluate_pseudo_dataset(vcfg, pseudo_path=str(tmp_path / 'gen1_w1'), original_path=tree)
     finally:
         if not had:
             os.remove(fn)
+    assert quality and all(0.0 <= v for v in quality.values()) and any(k.startswith('ssod/teacher_AR@50_') for k in quality)
     one = res[1][0][1]
     assert one['num_sequences'] == len(LOADER_RECORDINGS) and len(one['saved']) == len(LOADER_RECORDINGS)
     assert one['metrics'] is not None
