@@ -881,6 +881,99 @@ def test_fit_and_evaluation_drivers(gpu, manifest, tmp_path):
     assert h3['global_step'] == 15 and [s for s, _ in h3['loss']] == [13, 14, 15]
 
 
+def test_self_training_round_end_to_end(gpu, manifest, tmp_path):
+    """LEOD's loop on a synthetic dataset tree, every stage through this package's drivers: (0) train on sparse labels (every second labelled
+    frame, ``dataset.ratio`` 0.5), (1) pseudo-label the training split with that checkpoint (hflip + time-flip TTA, tracker filter), (2) check
+    and score the generated dataset the way predict.py / val_dst.py do, (3) train the soft-anchor model (``model=rnndet-soft``: low-confidence
+    pseudo boxes become ignore boxes) on the generated dataset, (4) evaluate it.  What is asserted is that every hand-over works: checkpoint
+    -> PseudoLabeler, generated tree -> training loaders (pseudo labels do arrive in the training batches), plans on the training steps."""
+    import os
+    import pickle
+    from oracle.synth import LOADER_RECORDINGS, synth_dataset_tree
+    from leod_amd.config import full_config, dynamically_modify_train_config
+    from leod_amd.data.genx_utils import dataset_streaming
+    from leod_amd.data.utils.types import DataType
+    from leod_amd.modules.utils.detection import DATA_KEY
+    from leod_amd.modules.utils.fetch import fetch_model_module, fetch_data_module
+    from leod_amd.predict import run_pseudo_labeling, verify_data, evaluate_pseudo_dataset
+    from leod_amd.train import fit, run_evaluation
+    tree = synth_dataset_tree(str(tmp_path / 'src'), 'gen1', False, frame_hw=HW)
+    fn = os.path.join(dataset_streaming.SPLITS_DIR, 'gen1', 'ssod_0.500-off0.pkl')
+    had = os.path.exists(fn)
+    os.makedirs(os.path.dirname(fn), exist_ok=True)
+    if not had:
+        with open(fn, 'wb') as f:
+            pickle.dump({name: list(range(0, len(lab), 2)) for name, _, _, lab in LOADER_RECORDINGS}, f)
+
+    def config(model, path, ratio, **kw):
+        over = dict(model=dict(backbone=dict(embed_dim=16, stage=dict(attention=dict(dim_head=8)))),
+                    dataset=dict(path=path, sequence_length=4, ratio=ratio, data_augmentation=dict(
+                        random=dict(prob_hflip=0, zoom=dict(prob=0)), stream=dict(start_from_zero=True, prob_hflip=0, zoom=dict(prob=0)))), **kw)
+        cfg = dynamically_modify_train_config(full_config('gen1', 'small', model=model, is_train=(model != 'pseudo_labeler'), overrides=over))
+        cfg.dataset.ev_repr_hw = HW
+        cfg.model.backbone.in_res_hw = (64, 96)
+        cfg.model.backbone.stage.attention.partition_size = (2, 3)
+        cfg.model.postprocess.confidence_threshold = 0.01
+        cfg.batch_size.train = cfg.batch_size.eval = 2
+        cfg.hardware.num_workers.train, cfg.hardware.num_workers.eval = 2, 1
+        if model != 'pseudo_labeler':
+            cfg.training.max_steps = cfg.training.lr_scheduler.total_steps = 8
+            cfg.validation.val_check_interval = 8
+        return cfg
+    try:
+        # (0) supervised round on the sparse labels
+        cfg0 = config('rnndet', tree, 0.5)
+        mod0 = fetch_model_module(cfg0)
+        mod0.mdl.load_state_dict(synth_state_dict(manifest['micro'], 8))
+        mod0.to(DEV)
+        ck0 = str(tmp_path / 'round0.ckpt')
+        h0 = fit(cfg0, mod0, fetch_data_module(cfg0, prefetch=2), ckpt_path=ck0, log_every_n_steps=4)
+        assert h0['global_step'] == 8 and all(np.isfinite(v) for _, v in h0['loss'])
+        # (1) pseudo labels for the training split from that checkpoint
+        new_root = str(tmp_path / 'gen1_x0.5_ss')
+        cfgp = config('pseudo_labeler', tree, 0.5, save_dir=os.path.join(new_root, 'train'), tta=dict(enable=True, hflip=True, tflip=True))
+        cfgp.model.pseudo_label.obj_thresh, cfgp.model.pseudo_label.cls_thresh = [0.1, 0.05], [0.1, 0.05]
+        cfgp.model.pseudo_label.min_track_len = 2
+        labeler = fetch_model_module(cfgp)
+        labeler.load_weight(ck0)
+        labeler.to(DEV)
+        out = run_pseudo_labeling(cfgp, labeler, fetch_data_module(cfgp, prefetch=2))
+        assert out['num_sequences'] == len(LOADER_RECORDINGS) and out['label_quality']
+        # (2) the reference's checks of what was written
+        for name, _, _, lab in LOADER_RECORDINGS:
+            assert verify_data(os.path.join(new_root, 'train', name), old_dir=os.path.join(tree, 'train', name), label_list=list(range(0, len(lab), 2))) >= 1
+        quality = evaluate_pseudo_dataset(cfgp, pseudo_path=new_root, original_path=tree)
+        assert quality
+        assert os.path.islink(os.path.join(new_root, 'val')) and os.path.islink(os.path.join(new_root, 'test'))
+    finally:
+        if not had:
+            os.remove(fn)
+    # (3) self-training round on the generated dataset with the soft-anchor head (every label of the new dataset is used: ratio -1)
+    cfg1 = config('rnndet-soft', new_root, -1)
+    assert cfg1.model.head.ignore_bbox_thresh is not None
+    dm1 = fetch_data_module(cfg1, prefetch=2)
+    dm1.setup('fit')
+    n_pseudo = n_gt = 0
+    for i, batch in enumerate(dm1.train_dataloader()):
+        from leod_amd.modules.utils.detection import merge_mixed_batches
+        for lbls in merge_mixed_batches(batch)[DATA_KEY][DataType.OBJLABELS_SEQ]:      # (mixed sampling: one batch per loader, merged as training_step does)
+            for l in lbls:
+                if l is not None:
+                    n_pseudo += int(l.is_pseudo_label().sum())
+                    n_gt += int(l.is_gt_label().sum())
+        if i >= 3:
+            break
+    assert n_pseudo > 0 and n_gt > 0, (n_pseudo, n_gt)            # the training batches carry the kept GT AND the generated labels
+    mod1 = fetch_model_module(cfg1)
+    mod1.load_weight(ck0)
+    mod1.to(DEV)
+    h1 = fit(cfg1, mod1, fetch_data_module(cfg1, prefetch=2), log_every_n_steps=4)
+    assert h1['global_step'] == 8 and all(np.isfinite(v) for _, v in h1['loss']) and mod1._plans.replays >= 3
+    # (4) the usual evaluation of the round-1 model on the original test split (linked into the generated tree)
+    kp = run_evaluation(cfg1, mod1, fetch_data_module(cfg1, prefetch=2), 'test')
+    assert kp is None or 'test/AP' in kp
+
+
 def test_tracking_only_pass_over_a_pseudo_dataset(gpu, manifest, tmp_path):
     """The two-step variant of the pseudo-label round (predict.py:137-155, pseudo_labeler.py:625-637): pass 1 writes pseudo labels without
     the tracker filter (min_track_len 1); pass 2 reads that dataset with ``dataset.only_load_labels`` -- no event frames, no model forward --
