@@ -50,6 +50,10 @@ class Bottleneck(nn.Module):
         y = self.conv2.forward_nhwc(self.conv1.forward_nhwc(x))
         return y + x if self.use_add else y
 
+    def forward(self, x):
+        """NCHW-logical in/out (reference signature, network_blocks.py:111-115)."""
+        return Fn.as_nchw(self.forward_nhwc(Fn.to_nhwc(x)))
+
 
 class CSPLayer(nn.Module):
     def __init__(self, in_channels, out_channels, n=1, shortcut=True, expansion=0.5, depthwise=False, act="silu"):

@@ -380,3 +380,37 @@ def test_1mpx_training_step_and_nms_vs_oracle(gpu):
         assert d[np.arange(len(b)), j].max() < 2e-3 and len(set(j.tolist())) == len(b)
         sc_a, sc_b = a[:, 4] * a[:, 5], b[:, 4] * b[:, 5]
         assert np.all(np.diff(sc_a) <= 1e-6) and np.abs(sc_a - sc_b).max() < 1e-5
+
+
+def test_yolox_blocks_reference_signatures(gpu):
+    """``BaseConv`` / ``Bottleneck`` / ``CSPLayer`` called the reference's way (NCHW tensor in, NCHW tensor out, network_blocks.py:55-166) equal a
+    plain torch restatement built from their own parameters (eval mode: folded BatchNorm + SiLU)."""
+    import torch.nn.functional as F
+    from leod_amd.models.detection.yolox.models.network_blocks import BaseConv, Bottleneck, CSPLayer
+    torch.manual_seed(3)
+
+    def ref_conv(m, x):
+        y = F.conv2d(x, m.conv.weight, None, m.stride, (m.conv.kernel_size[0] - 1) // 2)
+        y = F.batch_norm(y, m.bn.running_mean, m.bn.running_var, m.bn.weight, m.bn.bias, False, 0., m.bn.eps)
+        return F.silu(y)
+
+    def randomize(mod):
+        for m in mod.modules():
+            if isinstance(m, BaseConv):
+                m.bn.running_mean.normal_(0, 0.2)
+                m.bn.running_var.uniform_(0.5, 1.5)
+                m.bn.weight.data.uniform_(0.5, 1.5)
+                m.bn.bias.data.normal_(0, 0.2)
+    x = torch.randn(2, 32, 8, 12, device=DEV)
+    conv = BaseConv(32, 64, 3, 1).to(DEV).eval()
+    bott = Bottleneck(32, 32, shortcut=True, expansion=1.0).to(DEV).eval()
+    csp = CSPLayer(32, 64, n=1, shortcut=False).to(DEV).eval()
+    for m in (conv, bott, csp):
+        randomize(m)
+    with torch.no_grad():
+        close(conv(x), ref_conv(conv, x), rtol=2e-4, atol=2e-5)
+        close(bott(x), x + ref_conv(bott.conv2, ref_conv(bott.conv1, x)), rtol=2e-4, atol=2e-5)
+        b = csp.m[0]
+        x1 = ref_conv(b.conv2, ref_conv(b.conv1, ref_conv(csp.conv1, x)))
+        close(csp(x), ref_conv(csp.conv3, torch.cat([x1, ref_conv(csp.conv2, x)], 1)), rtol=2e-4, atol=2e-5)
+    assert tuple(bott(x).shape) == (2, 32, 8, 12) and tuple(csp(x).shape) == (2, 64, 8, 12)
