@@ -178,6 +178,22 @@ def _sync_bn_on() -> bool:
     return _SYNC_BN['world_size'] > 1 or _SYNC_BN['force']
 
 
+def _capture_collectives(group) -> bool:
+    """LEOD_PLAN_CAPTURE_COLLECTIVES=1 (option, RCCL only): SyncBatchNorm exchanges issued while a step is being recorded are left to
+    ProcessGroupNCCL's own stream capture and become nodes of the launch plan, instead of closing a plan segment each (a host callback,
+    the side lane joined, the neck / head weight gradients held on the launch lane).  One rank, every collective issued
+    (profiles/r05_q_captured_collectives.txt): 16.14 ms per step against 17.41 with callbacks and 15.42 without collectives.  NOT the default:
+    a one-rank all-reduce puts no kernel into the graph, so the replay of real RCCL kernel nodes by the plan executor has never run."""
+    import os
+    if os.environ.get('LEOD_PLAN_CAPTURE_COLLECTIVES') != '1':
+        return False
+    import torch.distributed as dist
+    try:
+        return dist.get_backend(group) == 'nccl'
+    except Exception:                                      # noqa: BLE001
+        return False
+
+
 def _allreduce_stats(t: torch.Tensor):
     if _sync_bn_on():
         import torch.distributed as dist
@@ -186,8 +202,12 @@ def _allreduce_stats(t: torch.Tensor):
         def exchange():
             dist.all_reduce(t, group=group)
             _SYNC_BN['n_collectives'] += 1
-        # a step that is being recorded into launch plans takes the exchange as a host callback between two plan segments
+        # a step that is being recorded into launch plans takes the exchange as a host callback between two plan segments -- or, as an
+        # option, leaves it to ProcessGroupNCCL's own stream capture (_capture_collectives)
         from .modules.step_plan import PlanRecorder
+        if _capture_collectives(group) and torch.cuda.is_current_stream_capturing():
+            exchange()
+            return
         if not PlanRecorder.split(exchange):
             exchange()
 
@@ -573,7 +593,7 @@ def _conv_bn_bwd(members):
         # end with the side stream joined -- the small weight gradients of the neck / head then stay on the launch stream instead of
         # forking and joining once per layer (17.97 -> see profiles/r04_*_rccl_force_collectives.txt)
         from .modules.step_plan import PlanRecorder
-        hold = sync and PlanRecorder.current is not None
+        hold = sync and PlanRecorder.current is not None and not _capture_collectives(_SYNC_BN['group'])
         prev_hold, WgradSide.hold_main = WgradSide.hold_main, hold or WgradSide.hold_main
         shared_dx = {}
         for (mod, x, z, mean, rstd, conv_w, bn_w, bn_b, stride, count, count_dev, dy, need_dx), sl in zip(live, slices):

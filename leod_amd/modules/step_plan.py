@@ -388,7 +388,7 @@ class BackbonePlan:
             # how many kernels of the two plans read the event tensor through a re-pointable argument: the stem convolution in the forward plan and
             # its weight gradient in the backward plan, or none (float events take the generic convolution: the batch is then copied in)
             nf, nb = fwd.rebase_input(self.ev, self.ev), bwd.rebase_input(self.ev, self.ev)
-            self.rebase_ok, self.rebase_count = (nf >= 1 and nb >= 1 and os.environ.get('LEOD_PLAN_INPUT_COPY', '0') != '1'), nf + nb
+            self.rebase_ok, self.rebase_count = (nf >= 1 and nb >= 1), nf + nb
         except BaseException:
             _abort_captures(capture_stream, fwd, bwd)
             raise

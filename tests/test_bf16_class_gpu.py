@@ -466,7 +466,7 @@ def test_full_size_plans_equal_eager_in_16bit_modes(gpu, mode16):
                     # gradient): the buffer the plans were captured with is poisoned here, so any kernel still reading it would show in the losses
                     from leod_amd.modules.step_plan import BackbonePlan
                     bb = [e for e in mod._plans.entries.values() if isinstance(e, BackbonePlan)][0]
-                    assert (bb.rebase_ok and bb.rebase_count == 2) or os.environ.get('LEOD_PLAN_INPUT_COPY') == '1', (bb.rebase_ok, bb.rebase_count)
+                    assert bb.rebase_ok and bb.rebase_count == 2, (bb.rebase_ok, bb.rebase_count)
                     if bb.rebase_ok:
                         bb.ev.fill_(255)
                 r = fit_step(mod, opt, lrs, te._loader_batch(ev, rows, label_tb, firsts[step].to(DEV)), step)
