@@ -25,6 +25,7 @@ os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')    # kernel-argument blocks 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+PROBE_STEPS = 3                 # bracketed single-stream eager steps behind roofline / family_ms_per_step (median step), after one warm step
 PEAK_HBM_GBS = 8000.0           # MI355X HBM3E peak (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFLOPS = 157.3    # dense fp32 MFMA peak: 256 FLOP/clk/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF figure includes 2:1 sparsity)
@@ -219,11 +220,12 @@ def pseudo_main(args):
     roofline = family_ms = None
     if not args.no_roofline and rank == 0:
         probe = ops.KernelProbe()
-        for _ in range(2):
+        for _ in range(PROBE_STEPS):
             mod.predict_step(batch(), 0)
+            probe.mark_step()
         mod.flush_predictions()
         roofline = probe.finish(PEAK_HBM_GBS, PEAK_BF16_MFMA_TFLOPS if args.dtype != 'f32' else PEAK_F32_MFMA_TFLOPS, target='linear_gemm')
-        family_ms = probe.family_ms(2)
+        family_ms = probe.family_ms()
         if args.dump_calls:                               # every C launch of the two probe chunks, in order
             with open(args.dump_calls, 'w') as f:
                 for n, ints, us in probe.call_table():
@@ -280,6 +282,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-plan', action='store_true', help='eager Python launches for every step (LEOD_PLAN=0): no launch plans')
+    ap.add_argument('--single-stream', action='store_true', help='profiling aid: every kernel on the launch stream (no weight-gradient side stream, '
+                    'no per-level head streams); use with --no-plan')
     ap.add_argument('--vary-labels', default='', metavar='LO:HI', help='draw the labelled frames of every step at random: B\' ~ U{LO..HI} distinct '
                     '(t, b) positions per step (the reference\'s loaders deliver a data-dependent number of labelled frames per step, '
                     'modules/detection.py:209-224); default: the fixed frames t in {4, 9, 14, 19} of every sequence (B\' = 32).  NOT the BASELINE '
@@ -383,6 +387,9 @@ def main():
 
         if args.no_plan:
             module.plan_mode = False
+        if args.single_stream:
+            from leod_amd.models.detection.yolox.models import yolo_head as _yh
+            module.wgrad_side, _yh._LEVEL_STREAMS = False, False
         for s in range(args.warmup):
             run(first_mask(s))
         masks = [first_mask(1 + args.warmup + s) for s in range(args.steps)]
@@ -417,27 +424,39 @@ def main():
             pl = module._plans
             plan_info['timed_region'] = {'planned_steps': pl_t[0] - pl0[0], 'replays': pl_t[1] - pl0[1], 'eager_steps': pl_t[2] - pl0[2],
                                          'backbone_captures': pl_t[3] - pl0[3], 'head_captures': pl_t[4] - pl0[4],
-                                         'plan_hit_rate': round((pl_t[1] - pl0[1]) / max(args.steps, 1), 4)}
+                                         'plan_hit_rate': round((pl_t[1] - pl0[1]) / max((pl_t[0] - pl0[0]) + (pl_t[2] - pl0[2]), 1), 4)}
         # roofline of the dominant kernel: two extra steps with HIP events around each of its launches
-        roofline = roofline_gemm = family_ms = probe = family_all = None
+        roofline = roofline_gemm = family_ms = probe = family_all = probe_note = None
         if not args.no_roofline:
-            # EVERY rank runs the two probe steps (a step contains collectives: a rank-0-only step would dead-lock N > 1);
-            # only rank 0 brackets the kernel with events and reports
-            probe = ops.KernelProbe() if rank == 0 else None
-            # isolated launches: no co-running kernels inside the event bracket (wgrad on the launch stream)
+            # EVERY rank runs the probe steps (a step contains collectives: a rank-0-only step would dead-lock N > 1);
+            # only rank 0 brackets the kernels with events and reports
+            # isolated launches: no co-running kernels inside the event bracket (wgrad on the launch stream), eager launches so that
+            # every C entry point is bracketed
             side, module.wgrad_side = module.wgrad_side, False
-            planned, module.plan_mode = module.plan_mode, False           # eager launches: every C entry point is bracketed
-            for s in range(2):
+            planned, module.plan_mode = module.plan_mode, False
+            run(first_mask(1))                            # the eager single-stream path once UN-bracketed (allocator pools, code objects
+            torch.cuda.synchronize()                      # and autograd buffers of this path warm), then PROBE_STEPS bracketed steps
+            probe = ops.KernelProbe() if rank == 0 else None
+            for s in range(PROBE_STEPS):
                 run(first_mask(1))
+                if probe is not None:
+                    probe.mark_step()
             module.wgrad_side, module.plan_mode = side, planned
             if probe is not None:
                 peak_t = PEAK_BF16_MFMA_TFLOPS if dtype != 'f32' else PEAK_F32_MFMA_TFLOPS      # fp16 and bf16 MFMA share one dense peak
                 roofline = probe.finish(PEAK_HBM_GBS, peak_t, target='linear_wgrad')
                 roofline_gemm = probe.finish(PEAK_HBM_GBS, peak_t, target='linear_gemm')
-                # every C entry point bracketed with events during the same two single-stream steps: the line audits itself
-                family_ms = probe.family_ms(2)
-                family_all = probe.family_ms(2, top=1000)
-                if args.dump_calls:                           # every C launch of the two probe steps, in order (tools / profiles)
+                # every C entry point bracketed with events during the same single-stream steps (median step per family): the line audits itself
+                family_ms = probe.family_ms(top=8)
+                family_all = probe.family_ms(top=1000)
+                # self-check: the bracketed single-stream kernel time of a step must be of the order of the measured step (two lanes overlap,
+                # brackets add gaps: 0.5x .. 2x); otherwise a bracket caught a host stall and the table is not evidence
+                kms = sum(family_all.values())
+                step_ms = 1e3 * dt / args.steps
+                if not (0.5 * step_ms <= kms <= 2.0 * step_ms):
+                    probe_note = f'bracketed kernel time {kms:.2f} ms per step is outside 0.5x..2x of ms_per_step {step_ms:.2f}: family table and secondary roofline withheld'
+                    family_ms = family_all = roofline_gemm = None
+                if args.dump_calls:                           # every C launch of the first probe step, in order (tools / profiles)
                     with open(args.dump_calls, 'w') as f:
                         for n, ints, us in probe.call_table():
                             f.write(f'{us:9.1f}  {n:<34s} {ints}\n')
@@ -455,7 +474,8 @@ def main():
         launch = (f'{how}, schedule={"batched" if module.time_batched else "timestep"}, wgrad side stream {"on" if module.wgrad_side else "off"}, '
                   f'precision mode {ops.get_precision()}')
         return dict(dt=dt, loss=loss_val, roofline=roofline, roofline_gemm=roofline_gemm, family_ms=family_ms, launch=launch, family_ms_all=family_all,
-                    host_ms=host_ms, plan_info=plan_info, calls=(len(probe.calls) // 2 if probe is not None and hasattr(probe, 'calls') else None))
+                    host_ms=host_ms, plan_info=plan_info, probe_note=probe_note,
+                    calls=(len(probe.calls) // probe.steps if probe is not None else None))
 
     main_run = measure(args.dtype, args.steps, args.warmup, not args.no_roofline)
     dt, loss_val, roofline, launch = main_run['dt'], main_run['loss'], main_run['roofline'], main_run['launch']
@@ -503,7 +523,7 @@ def main():
                        'kernel_ms_per_step': round(sum((main_run['family_ms_all'] or {}).values()), 3) if main_run.get('family_ms_all') else None,
                        'launches_per_step': (main_run['plan_info']['forward']['kernels'] + main_run['plan_info']['backward']['kernels'] + 12)
                        if main_run['plan_info'] else None,
-                       'c_calls_per_eager_step': main_run['calls'],
+                       'c_calls_per_eager_step': main_run['calls'], 'probe_steps': PROBE_STEPS, 'probe_note': main_run['probe_note'],
                        'launch_plans': main_run['plan_info']},
             'roofline': roofline,
             'roofline_linear_gemm': main_run['roofline_gemm'],

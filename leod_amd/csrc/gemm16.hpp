@@ -1266,8 +1266,8 @@ static inline int launch_gemm_lds(const ALRows& al, const BL& bl, const EP& ep, 
         const bool ln = al.ln_w != nullptr, ks = al.kscale != nullptr;
         // the persistent wide tiles win where the main loop dominates (LayerNorm on load, contractions of >= 2 N); short contractions
         // into wide outputs are bound by their epilogue traffic, which the many small workgroups of gemm_lds_kernel overlap better
-        // (tools/kbench_gemm.py; LEOD_GEMM_WIDE=2 routes every covered shape here)
-        static const int wide_mode = getenv("LEOD_GEMM_WIDE") ? atoi(getenv("LEOD_GEMM_WIDE")) : 1;
+        // (tools/kbench_gemm.py; wide_mode = 2 would route every covered shape here)
+        constexpr int wide_mode = 1;
         // (round 5, tools/kbench_gemm.py graph-timed, profiles/r05_j_gemm_wide_routing_ab.txt) launches of <= 60 k rows (stages 3-4): also the
         // square projections (proj + LayerScale, its dgrad: 24 -> 16-22 us) and the plain x projection of the ConvLSTM (85 / 75 -> 70 / 67 us); NOT
         // the dgrad of fc2 through GELU (short contraction, wide output, heavy epilogue: 134 -> 191 us on the wide tiles)

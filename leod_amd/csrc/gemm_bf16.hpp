@@ -234,8 +234,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_wide_bf16_kernel(AL al, BL b
 
 // Column tiles per wave for N output columns: 3 (192-column workgroups) or 4 (256); 0 = the shape stays on gemm_lds_kernel
 static inline int gemm_wide_ntw(int M, int N, int K) {
-    static const int on = getenv("LEOD_GEMM_WIDE") ? atoi(getenv("LEOD_GEMM_WIDE")) : 1;
-    if (!on || leod_precision() != 1 || M < 4096 || N < 144 || K < 32 || (K & 3) || (N & 3)) return 0;
+    if (leod_precision() != 1 || M < 4096 || N < 144 || K < 32 || (K & 3) || (N & 3)) return 0;
     const long p3 = (long)cdiv(N, 192) * 192, p4 = (long)cdiv(N, 256) * 256;
     const int ntw = p3 <= p4 ? 3 : 4;
     const long pad = ntw == 3 ? p3 : p4;
@@ -252,7 +251,7 @@ static inline int launch_gemm_wide(const AL& al, const BL& bl, const EP& ep, int
 #endif
     const int nbn = cdiv(N, 64 * NTW);
     const long ntiles = (long)cdiv(M, 128) * nbn;
-    static const int dbg = getenv("LEOD_WIDE_DBG") ? atoi(getenv("LEOD_WIDE_DBG")) : 0;
+    constexpr int dbg = 0;          // ablation bits (skip stores / MFMAs / loads): compile-time, for experiments
     // (The WN = 2 / KCH = 32 variant -- two 4-wave workgroups per CU -- is not instantiated: tools/kbench_gemm.py, stages 3-4, measured it
     // equal on the 53 k-row launches and 1.2-1.5x slower on the 13 k-row ones, whose 105-210 tiles then run on four waves per CU each:
     // 40 -> 57 us dgrad of fc1, 59 -> 75 us fc2; LN -> fc1 -> GELU alone gained, 66 -> 60 us.  The step did not move.)

@@ -1069,7 +1069,7 @@ static int dispatch_attn(int which, const float* qkv, const float* dout, float* 
     if (g.C != g.heads * g.d || (g.d & 3) || g.d > 32 || g.H % g.ph || g.W % g.pw) return LEOD_ERR_ARG;
     const int P = g.ph * g.pw, PT = (P + 15) / 16, DCH = (g.d + 15) / 16;
     const float scale = 1.0f / sqrtf((float)g.d);
-    static const int use_lds = getenv("LEOD_ATTN_LDS") ? atoi(getenv("LEOD_ATTN_LDS")) : 1;
+    constexpr int use_lds = 1;
     // One head per workgroup (5 waves for an 80-token partition) instead of two (10 waves, the CU's wave limit at three workgroups): six
     // workgroups per CU overlap their load / MFMA / store phases better -- backward 984 -> 889 us per step over the four stages, forward of
     // stage 1 126 -> 116 us, the rest equal (tools/kbench.py attn, profiles/r04_z_attn_hg_kbench.txt).  (hg1: bit 0 forward, bit 1 backward.)
@@ -1103,7 +1103,7 @@ static int dispatch_attn(int which, const float* qkv, const float* dout, float* 
 // over as bf16 (qkv_bf16) and dqkv produced as bf16 (dqkv_bf16); 0: fp32 tensors only
 LEOD_API int leod_partition_attn_16bit_ok(int B, int H, int W, int C, int heads, int ph, int pw) {
     if (leod_precision() != 1 || heads <= 0 || C % heads || H % ph || W % pw) return 0;
-    static const int use_lds = getenv("LEOD_ATTN_LDS") ? atoi(getenv("LEOD_ATTN_LDS")) : 1;
+    constexpr int use_lds = 1;
     static const int on = 1;
     const int d = C / heads, P = ph * pw, PT = (P + 15) / 16;
     const int HG = (heads % 2 == 0 && 2 * PT <= 16) ? 2 : 1;

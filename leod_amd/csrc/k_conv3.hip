@@ -702,7 +702,7 @@ static inline int conv3_rows_per_block(int H, int W, int Cin, int nto, int S = 1
 
 // forward of the stride-2 convs on the same kernel (S = 2)
 bool conv3s2_fwd_supported(int B, int H, int W, int Cin, int Cout) {
-    static const int on = getenv("LEOD_CONV3_DIRECT") ? atoi(getenv("LEOD_CONV3_DIRECT")) : 1;
+    constexpr int on = 1;
     static const int on2 = 1;
     if (!on || !on2 || leod_precision() != 1) return false;
     if ((H & 1) || (W & 1) || W / 2 > 160 || W / 2 < 4) return false;
@@ -713,7 +713,7 @@ bool conv3s2_fwd_supported(int B, int H, int W, int Cin, int Cout) {
 }
 
 bool conv3s1_supported(int H, int W, int Cin, int Cout) {
-    static const int on = getenv("LEOD_CONV3_DIRECT") ? atoi(getenv("LEOD_CONV3_DIRECT")) : 1;
+    constexpr int on = 1;
     if (!on || leod_precision() != 1) return false;
     if (W > 160 || W < 4 || (Cin != 48 && Cin != 96 && Cin != 192) || (Cout != 48 && Cout != 96 && Cout != 192)) return false;
     return conv3_rows_per_block(H, W, Cin, Cout == 48 ? 3 : 6) > 0;
@@ -765,7 +765,7 @@ int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, i
 // shapes of the direct weight-gradient kernel: stride 1 or 2 (even H, W), output channels in slices of 96, input channels 48 or in
 // slices of 96
 bool conv3_wgrad_supported(int H, int W, int Cin, int Cout, int stride) {
-    static const int on = getenv("LEOD_CONV3_DIRECT") ? atoi(getenv("LEOD_CONV3_DIRECT")) : 1;
+    constexpr int on = 1;
     static const int on2 = 1;      // everything but the 96 -> 96 / stride 1 case
     if (!on || leod_precision() != 1) return false;
     if (stride != 1 && stride != 2) return false;
@@ -888,7 +888,7 @@ static inline int conv3s2_dgrad_rows(int Ho, int Wo, int N) {
 }
 // x [B,H,W,Cin] <- dy [B,H/2,W/2,N]
 bool conv3s2_dgrad_supported(int H, int W, int Cin, int N) {
-    static const int on = getenv("LEOD_CONV3_DIRECT") ? atoi(getenv("LEOD_CONV3_DIRECT")) : 1;
+    constexpr int on = 1;
     static const int on2 = 1;
     if (!on || !on2 || leod_precision() != 1) return false;
     if ((H & 1) || (W & 1) || W / 2 > 160 || W / 2 < 4) return false;

@@ -567,7 +567,6 @@ static inline int fwd_bregs(int K, bool bf) { return 4 * (K / 16) * (bf ? 2 : 4)
 /* 1 = fused [x | h] contraction, 2 = hoisted x projection (xin = gx), 3 = hoisted + streamed weights (wpack from leod_convlstm_seq_pack),
  * 0 = sequence kernel not available for this C / precision */
 LEOD_API int leod_convlstm_seq_mode(int C) {
-    if (getenv("LEOD_LSTM_SEQ") && atoi(getenv("LEOD_LSTM_SEQ")) == 0) return 0;
     const bool bf = leod_precision() == 1;
     static const int stream_on = 1;
     if (bf && stream_on && (C == 256 || C == 384)) return 3;               // hoisted x projection + weights streamed from a packed bf16 copy

@@ -108,8 +108,7 @@ LEOD_API int leod_weight_shadow_pin(int on) {
 // Rounds every registered buffer whose shadow is stale; force != 0: every buffer, and the freshness flags are left alone (for
 // launches that are being RECORDED, not executed).  Returns the number of launches (>= 0) or an error code.
 LEOD_API int leod_weight_shadow_refresh(int force, hipStream_t stream) {
-    static const int on = getenv("LEOD_WEIGHT_SHADOW") ? atoi(getenv("LEOD_WEIGHT_SHADOW")) : 1;
-    if (!on || leod_precision() != 1) return 0;
+    if (leod_precision() != 1) return 0;
     std::lock_guard<std::mutex> lock(g_shadow_mu);
     int launches = 0;
     for (ShadowEntry& e : g_shadows) {

@@ -204,8 +204,7 @@ LEOD_API int leod_mlp_fwd_fused(const float* y, const float* ln_w, const float* 
                                 const float* W2, const float* b2, const float* g2, float* out, void* u16, float* stats, int M, int H,
                                 int K, hipStream_t stream) {
     if (!y || !ln_w || !ln_b || !W1 || !W2 || !out || ((u16 == nullptr) != (stats == nullptr))) return LEOD_ERR_ARG;
-    static const int on = getenv("LEOD_MLP_FUSED") ? atoi(getenv("LEOD_MLP_FUSED")) : 1;
-    if (!on || leod_precision() != 1 || K != 48 || H != 192 || M < 16384) return LEOD_ERR_UNSUPPORTED;
+    if (leod_precision() != 1 || K != 48 || H != 192 || M < 16384) return LEOD_ERR_UNSUPPORTED;
     const int grid = min(cdiv(cdiv(M, 16), 4), 256 * 2);       // two resident workgroups per CU (1 / 4 per CU measured slower: 222 / 184 vs 181 us)
     LeodFwdScope fwd_scope;
     LEOD_BY_OPFMT16({
@@ -401,8 +400,7 @@ LEOD_API int leod_mlp_bwd_dgrad_fused(const float* dz, const float* y, const flo
                                       const float* W1, const float* b1, const float* W2, const float* g2, float* dy, void* du16,
                                       float* dgamma, float* dbeta, int M, int H, int K, hipStream_t stream) {
     if (!dz || !y || !stats || !ln_w || !ln_b || !W1 || !W2 || !dy || !dgamma || !dbeta) return LEOD_ERR_ARG;
-    static const int on = getenv("LEOD_MLP_FUSED") ? atoi(getenv("LEOD_MLP_FUSED")) : 1;
-    if (!on || leod_precision() != 1 || K != 48 || H != 192 || M < 16384) return LEOD_ERR_UNSUPPORTED;
+    if (leod_precision() != 1 || K != 48 || H != 192 || M < 16384) return LEOD_ERR_UNSUPPORTED;
     constexpr int KC = 3, NHT = 12, Kc = 48, Hc = 192;
     constexpr int LDS = (2 * Hc * (Kc + 8) + Kc * (Hc + 16)) * 2 + Hc * 4 + 4 * 16 * (Kc + 4) * 4;
     const int grid = min(cdiv(cdiv(M, 16), 4), 256 * 2);

@@ -459,7 +459,7 @@ __global__ __launch_bounds__(NTN == 3 ? 256 : 512, NTN == 3 ? 2 : 1) void rowstr
     }
 }
 static inline bool use_rowstream_narrow(int M, int Kc, int Nout) {
-    static const int on = getenv("LEOD_ROWSTREAM") ? atoi(getenv("LEOD_ROWSTREAM")) : 2;
+    constexpr int on = 2;
     return on >= 2 && M >= 16384 && Nout == 48 && (Kc == 144 || Kc == 192);
 }
 // stage 2 of RVT-S in precision mode bf16: 16-bit A rows (fp16 hidden, bf16 du / dqkv), 288 / 384 -> 96 columns
@@ -481,7 +481,7 @@ static int launch_rowstream_narrow(const float* x, const float* W, const float* 
 // (K, N) -> column tiles per slab; 0 = shape not covered.  K = 48: the whole N (9 / 12 tiles); K = 96: slabs of 9 (N = 288) or
 // 8 (N = 384) tiles, so that weights + wave tiles of two workgroups fit the 160 KB of a CU
 static inline int rowstream_slab(int M, int N, int K) {
-    static const int on = getenv("LEOD_ROWSTREAM") ? atoi(getenv("LEOD_ROWSTREAM")) : 2;     // 0 off, 1 stage 1 only, 2 stages 1 + 2
+    constexpr int on = 2;     // 0 off, 1 stage 1 only, 2 stages 1 + 2
     if (!on || M < 16384) return 0;
     if (K == 48 && (N == 144 || N == 192)) return N / 16;                    // RVT-S stage 1
     if (K == 96 && on >= 2) return N == 288 ? 9 : (N == 384 ? 8 : 0);       // RVT-S stage 2

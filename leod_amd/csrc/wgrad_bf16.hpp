@@ -443,7 +443,7 @@ static inline f4* wgrad_wide_scratch(hipStream_t s, size_t bytes) {
 template <int TN, int TK, int NWN, int NWK, int RC, int DYF, int XM, int OCC>
 static inline int launch_wgrad_wide_cfg(const void* dy, long lddy, const XRows& xl, float* dW, long ldw, float* dbias,
                                         int M, int N, int K, hipStream_t s) {
-    static const int dbg = getenv("LEOD_WGRAD_WIDE_DBG") ? atoi(getenv("LEOD_WGRAD_WIDE_DBG")) : 0;
+    constexpr int dbg = 0;          // ablation bits of the kernel (skip epilogue / MFMAs / loads): compile-time, for experiments
     static const int tune_wgs = OCC * 256;
     constexpr int LDS = wgw_lds_bytes<TN, TK, RC, 4 / (NWN * NWK)>();
     const int tiles = cdiv(N, TN * 16) * cdiv(K, TK * 16), chunks = cdiv(M, RC);
@@ -507,8 +507,7 @@ static inline int wgrad_wide_combo(const XRows& xl, int N, int K, int dyfmt) {
     return c == 0 ? 4 : c == 5 ? 5 : c == 2 ? 6 : c == 4 ? 7 : c == 3 ? 9 : 0;
 }
 static inline bool use_wgrad_wide(const XRows& xl, long lddy, int M, int N, int K, int dyfmt) {
-    static const int mode = getenv("LEOD_WGRAD_WIDE") ? atoi(getenv("LEOD_WGRAD_WIDE")) : 1;
-    if (!mode || leod_precision() != 1 || M < 8192) return false;
+    if (leod_precision() != 1 || M < 8192) return false;
     const int xm = xl.x_mode();
     const int dcw = dyfmt ? 8 : 4, xcw = xm >= 2 ? 8 : 4;
     if ((N % dcw) || (lddy % dcw) || (K % xcw) || (xl.ld % xcw)) return false;

@@ -22,14 +22,14 @@ from .utils.host import bound_host_threads
 
 class TrainEngine:
     def __init__(self, detector: torch.nn.Module, lr=2e-4, weight_decay=0.0, total_steps=400000, pct_start=0.005,
-                 div_factor=20, final_div_factor=10000, clip_value=1.0, process_group=None, sync_bn=True):
+                 div_factor=20, final_div_factor=10000, clip_value=1.0, process_group=None, sync_bn=True, grad_buckets=True):
         bound_host_threads()
         self.det = detector
         self.det.train()
         self.flat = FlatParams(detector)
         self.dp = DataParallel(self.flat, process_group, sync_bn=sync_bn)
         self.dp.broadcast_parameters()
-        self.dp.make_buckets(detector)
+        self.dp.make_buckets(detector, bucketed=grad_buckets)
         self.hp = dict(lr=lr, weight_decay=weight_decay, total_steps=total_steps, pct_start=pct_start,
                        div_factor=div_factor, final_div_factor=final_div_factor, clip_value=clip_value)
         self.global_step = 0
@@ -41,7 +41,7 @@ class TrainEngine:
         # weight-gradient kernels on a side HIP stream (eager launches): they feed nothing until the optimiser, so they
         # fill the device while the sequential parts of the backward pass (BPTT of the ConvLSTMs: 2 small launches per
         # timestep) run on the launch stream.  45.4 -> 43.6 ms per step; not used inside hipGraph capture.
-        self.wgrad_side = os.environ.get('LEOD_WGRAD_STREAM', '1') == '1'
+        self.wgrad_side = True
         self.graph_side = False      # set for the duration of a capture that a launch plan replays: the weight-gradient fork / join is captured
 
     def current_lr(self):

@@ -178,14 +178,16 @@ def _sync_bn_on() -> bool:
     return _SYNC_BN['world_size'] > 1 or _SYNC_BN['force']
 
 
+CAPTURE_COLLECTIVES = False     # see _capture_collectives
+
+
 def _capture_collectives(group) -> bool:
-    """LEOD_PLAN_CAPTURE_COLLECTIVES=1 (option, RCCL only): SyncBatchNorm exchanges issued while a step is being recorded are left to
+    """``functions.CAPTURE_COLLECTIVES = True`` (option, RCCL only): SyncBatchNorm exchanges issued while a step is being recorded are left to
     ProcessGroupNCCL's own stream capture and become nodes of the launch plan, instead of closing a plan segment each (a host callback,
     the side lane joined, the neck / head weight gradients held on the launch lane).  One rank, every collective issued
     (profiles/r05_q_captured_collectives.txt): 16.14 ms per step against 17.41 with callbacks and 15.42 without collectives.  NOT the default:
     a one-rank all-reduce puts no kernel into the graph, so the replay of real RCCL kernel nodes by the plan executor has never run."""
-    import os
-    if os.environ.get('LEOD_PLAN_CAPTURE_COLLECTIVES') != '1':
+    if not CAPTURE_COLLECTIVES:
         return False
     import torch.distributed as dist
     try:

@@ -18,7 +18,7 @@ from .network_blocks import BaseConv
 LOSS_KEYS = ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')
 
 
-_LEVEL_STREAMS = __import__('os').environ.get('LEOD_HEAD_STREAMS', '1') == '1'   # pyramid levels of the head on their own HIP streams
+_LEVEL_STREAMS = True   # pyramid levels of the head on their own HIP streams in eager steps (module attribute; off under SyncBatchNorm and capture)
 
 
 class YOLOXHead(nn.Module):
@@ -57,6 +57,20 @@ class YOLOXHead(nn.Module):
         self.reg_weight, self.obj_weight, self.cls_weight = reg_weight, obj_weight, cls_weight
         self.ignore_bg_k = ignore_bg_k if ignore_bg_k is not None else -1
         self.bbox_loss_weighting = bbox_loss_weighting
+        self._blw = None                 # (which confidence, compiled expression of w): parsed and validated ONCE, here
+        if bbox_loss_weighting:
+            val, expr = bbox_loss_weighting.split('-', 1) if '-' in bbox_loss_weighting else (bbox_loss_weighting, 'w')
+            try:
+                code = compile(expr, '<model.head.bbox_loss_weighting>', 'eval')
+            except SyntaxError as e:
+                raise ValueError(f'model.head.bbox_loss_weighting: {expr!r} is not an expression ({e})') from e
+            bad = set(code.co_names) - {'w', 'torch', 'math'} - set(dir(torch)) - set(dir(math)) - set(dir(torch.Tensor))
+            if bad:
+                raise ValueError(f'model.head.bbox_loss_weighting: {expr!r} may only use w, torch and math (found {sorted(bad)})')
+            probe = eval(code, {'__builtins__': {}, 'torch': torch, 'math': math}, {'w': torch.full((2, 3), 0.5)})  # noqa: S307
+            if not torch.is_tensor(probe) or probe.shape != (2, 3):
+                raise ValueError(f'model.head.bbox_loss_weighting: {expr!r} must be elementwise in w (a tensor of w\'s shape)')
+            self._blw = (val, code)
         self.ignore_bbox_thresh = ignore_bbox_thresh
         self.ignore_label = ignore_label
         self.last_assignment = None
@@ -76,14 +90,13 @@ class YOLOXHead(nn.Module):
         ('cls-w**2'), evaluated here on every label ROW (labels [B,N,7]) -- the expression is elementwise, so weighting a foreground
         anchor by the value of its matched row equals the reference's evaluate-after-gather; the kernel does the gather and the
         division by the batch mean.  None when the option is off."""
-        if not self.bbox_loss_weighting:
+        if self._blw is None:
             return None
-        val, expr = self.bbox_loss_weighting.split('-', 1) if '-' in self.bbox_loss_weighting else (self.bbox_loss_weighting, 'w')
+        val, code = self._blw
         obj_conf, cls_conf = labels[:, :, 5], labels[:, :, 6]
         w = obj_conf if val == 'obj' else cls_conf if val == 'cls' else obj_conf * cls_conf
-        w = eval(expr, {'torch': torch, 'math': math}, {'w': w})  # noqa: S307  (the reference evaluates the configured string, :376)
-        if not torch.is_tensor(w) or w.shape != obj_conf.shape:
-            raise ValueError('bbox_loss_weighting: the expression must be elementwise in w')
+        # the reference evaluates the configured string per step (:376); here the compiled, validated expression without builtins
+        w = eval(code, {'__builtins__': {}, 'torch': torch, 'math': math}, {'w': w})  # noqa: S307
         return w.to(torch.float32).contiguous()
 
     @torch.no_grad()

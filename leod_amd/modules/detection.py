@@ -61,8 +61,9 @@ class Module(_Base):
         self.train_eval_every = None
         # 'batched' (default): stage-major, all L timesteps of a stage per launch; anything else: the reference's
         # timestep-major loop over ``forward_backbone`` (same values, ~5x more and smaller launches)
-        self.time_batched = os.environ.get('LEOD_SCHEDULE', 'batched') == 'batched'
-        self.wgrad_side = os.environ.get('LEOD_WGRAD_STREAM', '1') == '1'
+        self.time_batched = True          # stage-major time-batched schedule (False: the reference's timestep-major loop, for state inspection)
+        self.wgrad_side = True            # weight-gradient kernels on a side HIP stream (False: on the launch stream)
+        self.plan_head_eager = False      # option for N > 1: planned backbone, eager PAFPN + head (see _head_eager)
         self._row_idx_cache: Dict[Any, th.Tensor] = {}
         # launch plans (modules/step_plan.py): a training-step geometry seen twice is captured once and replayed from C afterwards --
         # this build's counterpart of the reference's ``backbone.compile`` switch (torch.compile(mode='reduce-overhead') = CUDA graphs,
@@ -241,6 +242,7 @@ class Module(_Base):
             planned = self._training_step_planned(data, worker_id, ign, log)
             if planned is not None:
                 return planned
+            self._plans.eager_steps += 1               # EVERY eager fallback of a plan-mode step is counted here, whatever its reason
         ops.StatArena.begin_step(device)             # one memset for every BatchNorm statistic accumulator of the step
         feats, obj_labels, _, B = self._run_sequence(Mode.TRAIN, data, worker_id, ign)
         assert len(obj_labels) > 0
@@ -278,7 +280,6 @@ class Module(_Base):
         key = plans.key_of(ev)
         hit = plans.lookup(key)
         if hit is None:
-            plans.eager_steps += 1
             return None
         mode = Mode.TRAIN
         hw = tuple(ev.shape[-2:])
@@ -293,7 +294,6 @@ class Module(_Base):
                 return None
             hit = plans.build(key, self, ev, like, self.wgrad_side)
             if hit is None:
-                plans.eager_steps += 1
                 return None
             fresh = True
         bb: BackbonePlan = hit
@@ -307,7 +307,6 @@ class Module(_Base):
             hd = plans.build_head(bb, hkey, self, len(where), nmax_pad, self.wgrad_side)
             fresh = True
         if hd is None or hd == 'eager':
-            plans.eager_steps += 1
             return None
         self.started_training = True
         rows_host = tuple(t * B + b for t, b in where)
@@ -332,12 +331,12 @@ class Module(_Base):
         return output
 
     def _head_eager(self) -> bool:
-        """Planned backbone + eager head (LEOD_PLAN_HEAD_EAGER=1): an option for N > 1, where every SyncBatchNorm exchange inside a captured
+        """Planned backbone + eager head (``module.plan_head_eager = True``): an option for N > 1, where every SyncBatchNorm exchange inside a captured
         head is a plan segment boundary (the backbone has no BatchNorm: its plans stay whole apart from the gradient buckets).  Measured
         with every collective issued on a one-rank RCCL communicator (profiles/r05_p_rccl_force_collectives.txt): 16.98 ms per step against
         17.3-17.4 with the captured head and 16.3-16.5 all-eager (15.4 without collectives) -- but 10.5 instead of 4.1 ms of host time per
         step, i.e. it depends on the host the way eager launches do; the captured head stays the default."""
-        return os.environ.get('LEOD_PLAN_HEAD_EAGER', '0') == '1'
+        return bool(self.plan_head_eager)
 
     def _planned_backbone_eager_head(self, bb, plans, fresh, ev, labels_yolox, where, is_first, worker_id, rnn, B, log):
         from .step_plan import EagerHeadGate

@@ -139,7 +139,7 @@ class PlanLossFn(Function):
 
 
 class EagerHeadGate(Function):
-    """Planned backbone, EAGER head (LEOD_PLAN_HEAD_EAGER=1, an option for N > 1): the outputs are the labelled frames' stage features gathered from the backbone
+    """Planned backbone, EAGER head (``module.plan_head_eager``, an option for N > 1): the outputs are the labelled frames' stage features gathered from the backbone
     plan's static outputs; everything after them -- PAFPN, head, SimOTA, losses and their backward, with the SyncBatchNorm exchanges and the
     head's gradient buckets issued between the kernels as in an eager step -- is ordinary autograd.  ``backward`` receives the gradient of the
     gathered rows, puts it into the backbone plan's static slots and launches the captured backbone backward.  (A captured head pays for every
@@ -328,7 +328,7 @@ class BackbonePlan:
         self.fwd: Optional['PlanRecorder'] = None
         self.bwd: Optional['PlanRecorder'] = None
         self.heads: Dict[Any, HeadPlan] = {}
-        self.max_heads = int(os.environ.get('LEOD_PLAN_MAX_HEADS', '64'))
+        self.max_heads = 64
         self.owner = None                      # worker id whose LSTM state currently lives in ``self.states``
         self.uses = 0
         self.consumed = -1
@@ -491,8 +491,8 @@ class TrainStepPlans:
 
     def __init__(self, max_plans: Optional[int] = None, max_lanes: Optional[int] = None):
         self.entries: Dict[Any, Any] = {}
-        self.max_plans = int(os.environ.get('LEOD_PLAN_MAX', '4')) if max_plans is None else max_plans
-        self.max_lanes = int(os.environ.get('LEOD_PLAN_LANES', '2')) if max_lanes is None else max_lanes
+        self.max_plans = 4 if max_plans is None else max_plans
+        self.max_lanes = 2 if max_lanes is None else max_lanes
         self.anchor = None
         self.captures = 0
         self.head_captures = 0
@@ -500,13 +500,15 @@ class TrainStepPlans:
         self.steps = 0
         self.eager_steps = 0
 
+    plan_dist = True        # N > 1: steps with collectives are recorded in segments (False: such steps stay eager)
+
     @staticmethod
     def allowed() -> bool:
         """Not while a step is being captured.  (Collectives between kernels -- SyncBatchNorm, gradient buckets -- split the capture into
-        segments, see ``PlanRecorder``; LEOD_PLAN_DIST=0 keeps steps with collectives eager.)"""
+        segments, see ``PlanRecorder``; ``TrainStepPlans.plan_dist = False`` keeps steps with collectives eager.)"""
         if th.cuda.is_current_stream_capturing():
             return False
-        return not Fn._sync_bn_on() or os.environ.get('LEOD_PLAN_DIST', '1') == '1'
+        return not Fn._sync_bn_on() or TrainStepPlans.plan_dist
 
     @staticmethod
     def key_of(ev: th.Tensor):
@@ -529,8 +531,11 @@ class TrainStepPlans:
             self.entries[key] = self.entries.pop(key)       # most recently used last
             return e
         if e is None:
-            if len(self.entries) > 64:                      # geometries seen once and never again do not accumulate
-                for k in [k for k, v in self.entries.items() if not isinstance(v, BackbonePlan)]:
+            if len(self.entries) > 64:                      # geometries seen once and never again do not accumulate; 'eager' markers
+                for k in [k for k, v in self.entries.items() if v == 'seen']:      # (failed / evicted captures) stay, bounded below
+                    del self.entries[k]
+                eager = [k for k, v in self.entries.items() if v == 'eager']
+                for k in eager[:max(0, len(eager) - 256)]:
                     del self.entries[k]
             self.entries[key] = 'seen'
             return None

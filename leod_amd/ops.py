@@ -474,7 +474,7 @@ def linear_wgrad(dy, x, dW, dbias=None, stats=None, ln_w=None, ln_b=None, x2=Non
         _ck(x, torch.float16, 'x')
         if stats is not None or x2 is not None or dy16:
             raise LeodHipError('linear_wgrad: LayerNorm / concat / bf16-dy options do not combine with an fp16 pre-activation')
-        ev = _probe('linear_wgrad', 4.0 * (M * N + N * K) + 2.0 * M * K, 2.0 * M * N * K, rows=M)
+        ev = _probe('linear_wgrad', 4.0 * (M * N + N * K) + 2.0 * M * K, 2.0 * M * N * K, rows=M, nbytes16=2.0 * M * (N + K) + 4.0 * N * K)
         check(_l().leod_linear_wgrad_gelu16(_p(dy), N, _p(x), _p(dW), _p(dbias), M, N, K, _stream()), 'linear_wgrad_gelu16')
         if ev is not None:
             ev.record()
@@ -483,7 +483,8 @@ def linear_wgrad(dy, x, dW, dbias=None, stats=None, ln_w=None, ln_b=None, x2=Non
     xh = x.dtype is torch.float16
     _ck(x, x.dtype if x16 else F32, 'x')
     # algorithmic work of one launch: reads dy, X once, read-modify-writes dW once; 2*M*N*K flops
-    ev = _probe('linear_wgrad', (2.0 if dy16 else 4.0) * M * N + (2.0 if x16 else 4.0) * M * K + 4.0 * N * K, 2.0 * M * N * K, rows=M)
+    ev = _probe('linear_wgrad', (2.0 if dy16 else 4.0) * M * N + (2.0 if x16 else 4.0) * M * K + 4.0 * N * K, 2.0 * M * N * K, rows=M,
+                nbytes16=2.0 * M * (N + K) + 4.0 * N * K)
     check(_l().leod_linear_wgrad(_p(dy), N, _p(x), K1, _p(stats), _p(ln_w), _p(ln_b), _p(x2),
                                   (x2.shape[-1] if x2 is not None else 0), K1, _p(dW), _p(dbias), M, N, K,
                                   (1 if dy16 else 0) | (4 if xh else (2 if x16 else 0)), _stream()), 'linear_wgrad')
@@ -1206,25 +1207,28 @@ class KernelProbe:
         self.targets = tuple(targets)
         self.kernel_names = kernel_names or {'linear_wgrad': 'wgrad_wide_bf16_kernel + wgrad_wide_reduce_kernel (bf16 mode) / wgradw_kernel<.., XRows> (f32 mode)',
                                              'linear_gemm': 'rowstream* / gemm_lds_kernel / gemm_wide_bf16_kernel (Linear forward + dgrad)'}
-        self.events = {t: [] for t in self.targets}
-        self.bytes = {t: 0.0 for t in self.targets}
-        self.flops = {t: 0.0 for t in self.targets}
-        self.fam_events = {}
-        self.calls = []                    # (C entry point, small integer arguments, start event, end event) in launch order
-        self.by_rows = {}
+        self.step = 0                      # index of the probe step being recorded (mark_step() closes one)
+        self.events = {t: [] for t in self.targets}     # target -> [(step, e0, e1, bytes, flops, bytes16, rows)]
+        self.fam_events = {}               # C entry point -> [(step, e0, e1)]
+        self.calls = []                    # (C entry point, small integer arguments, start event, end event, step) in launch order
         self.real_lib = _l()
         if families:
             _LIB = _ProbedLib(self.real_lib, self)
         _PROBE = self
 
-    def begin(self, target, nbytes, flops=0.0, rows=None):
+    def mark_step(self):
+        """Closes one probe step: figures are medians over the steps recorded (a host stall inside one bracket -- first use of a code
+        object, a page fault of the launch thread -- lands in one step's sum and the median drops it)."""
+        self.step += 1
+
+    @property
+    def steps(self):
+        return max(self.step, 1)
+
+    def begin(self, target, nbytes, flops=0.0, rows=None, nbytes16=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        self.events[target].append((e0, e1))
-        if rows is not None:
-            self.by_rows.setdefault(target, {}).setdefault(int(rows), []).append((e0, e1, nbytes, flops))
-        self.bytes[target] += nbytes
-        self.flops[target] += flops
+        self.events[target].append((self.step, e0, e1, nbytes, flops, nbytes if nbytes16 is None else nbytes16, rows))
         return e1
 
     def close(self):
@@ -1233,45 +1237,69 @@ class KernelProbe:
         _LIB = self.real_lib
         torch.cuda.synchronize()
 
-    def family_ms(self, steps, top=8):
-        """{C entry point: ms per step}, largest first, from the per-call event brackets (single-stream probe steps)."""
-        tot = {k: sum(a.elapsed_time(b) for a, b in v) / max(steps, 1) for k, v in self.fam_events.items()}
+    @staticmethod
+    def _median(v):
+        v = sorted(v)
+        n = len(v)
+        return 0.0 if not n else (v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2]))
+
+    def family_ms(self, steps=None, top=8):
+        """{C entry point: ms per step}, largest first: per probe step the sum of the entry point's event brackets, then the MEDIAN over
+        the recorded steps (single-stream probe steps)."""
+        tot = {}
+        for k, v in self.fam_events.items():
+            per = [0.0] * self.steps
+            for st, a, b in v:
+                per[min(st, self.steps - 1)] += a.elapsed_time(b)
+            tot[k] = self._median(per)
         return {k: round(v, 3) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])[:top]}
 
-    def call_table(self):
-        """[(C entry point, small integer arguments (shapes / flags), us)] of every bracketed launch, in launch order."""
-        return [(n, ints, round(1e3 * a.elapsed_time(b), 1)) for n, ints, a, b in self.calls]
+    def call_table(self, step=0):
+        """[(C entry point, small integer arguments (shapes / flags), us)] of every bracketed launch of one probe step, in launch order."""
+        return [(n, ints, round(1e3 * a.elapsed_time(b), 1)) for n, ints, a, b, st in self.calls if st == step]
 
     def finish(self, peak_gbs, peak_tflops=157.3, target=None):
         """Roofline object of one probed family.  The bound is chosen by the family's arithmetic intensity
         (sum flops / sum algorithmic bytes) against the ridge peak_tflops / peak_gbs; ``achieved`` is in the unit of that
-        bound, the other roof is reported alongside."""
+        bound, the other roof is reported alongside.  Times: the family's summed event brackets of the MEDIAN probe step.
+        ``achieved`` / ``frac`` are denominated in SURVEY 8(d)'s bytes (activation and gradient operands once at 2 bytes, parameter
+        gradients at 4: ``algorithmic_bytes_16bit_per_launch``); the figure with every operand at its stored width is kept beside it."""
         if _PROBE is self:
             self.close()
         target = target or self.targets[0]
         ev = self.events[target]
         if not ev:
             return None
-        ms = sum(a.elapsed_time(b) for a, b in ev)
-        n = len(ev)
-        nbytes, flops = self.bytes[target], self.flops[target]
+        per = [0.0] * self.steps
+        for e in ev:
+            per[min(e[0], self.steps - 1)] += e[1].elapsed_time(e[2])
+        ms = self._median(per)                                   # one step's worth of launches
+        pick = min(range(self.steps), key=lambda i: (abs(per[i] - ms), i))
+        one = [e for e in ev if min(e[0], self.steps - 1) == pick]
+        n = len(one)
+        stored, flops, nbytes = sum(e[3] for e in one), sum(e[4] for e in one), sum(e[5] for e in one)
         gbs = nbytes / (ms * 1e-3) / 1e9
         tfl = flops / (ms * 1e-3) / 1e12
         ridge = peak_tflops * 1e12 / (peak_gbs * 1e9)
         intensity = flops / max(nbytes, 1.0)
-        out = {'kernel': self.kernel_names.get(target, target), 'launches': n, 'avg_us': round(1e3 * ms / n, 3),
-               'algorithmic_bytes_per_launch': round(nbytes / n, 1), 'algorithmic_flops_per_launch': round(flops / n, 1),
+        out = {'kernel': self.kernel_names.get(target, target), 'launches': n, 'probe_steps': self.steps,
+               'family_ms_per_probe_step': [round(v, 3) for v in per], 'avg_us': round(1e3 * ms / n, 3),
+               'algorithmic_bytes_16bit_per_launch': round(nbytes / n, 1), 'algorithmic_bytes_stored_width_per_launch': round(stored / n, 1),
+               'algorithmic_flops_per_launch': round(flops / n, 1),
                'flop_per_byte': round(intensity, 2), 'ridge_flop_per_byte': round(ridge, 2),
                'hbm_achieved_GBs': round(gbs, 2), 'hbm_frac': round(gbs / peak_gbs, 5),
+               'hbm_frac_stored_width': round(stored / (ms * 1e-3) / 1e9 / peak_gbs, 5),
                'mfma_achieved_TFLOPs': round(tfl, 2), 'mfma_frac': round(tfl / peak_tflops, 5), 'traffic': None}
         # the same family split by the row count of the launch (= the stage of the backbone): the long row ranges of stages 1-2 are
         # the HBM-bound launches, the short ones of stages 3-4 carry the same flops on 1/4 - 1/16 of the bytes
-        if target in self.by_rows:
+        rows = sorted({e[6] for e in one if e[6] is not None}, reverse=True)
+        if rows:
             split = []
-            for rows, evs in sorted(self.by_rows[target].items(), reverse=True):
-                t = sum(a.elapsed_time(b) for a, b, _, _ in evs) * 1e-3
-                by, fl = sum(e[2] for e in evs), sum(e[3] for e in evs)
-                split.append({'rows': rows, 'launches': len(evs), 'avg_us': round(1e6 * t / len(evs), 1), 'hbm_GBs': round(by / t / 1e9, 1),
+            for r in rows:
+                evs = [e for e in one if e[6] == r]
+                t = sum(e[1].elapsed_time(e[2]) for e in evs) * 1e-3
+                by, fl = sum(e[5] for e in evs), sum(e[4] for e in evs)
+                split.append({'rows': int(r), 'launches': len(evs), 'avg_us': round(1e6 * t / len(evs), 1), 'hbm_GBs': round(by / t / 1e9, 1),
                               'hbm_frac': round(by / t / 1e9 / peak_gbs, 4), 'mfma_TFLOPs': round(fl / t / 1e12, 1)})
             out['by_rows'] = split
         if intensity >= ridge:
@@ -1301,14 +1329,16 @@ class _ProbedLib:
                     e0.record()
                     rc = _real(*a)
                     e1.record()
-                    probe.fam_events.setdefault(_name, []).append((e0, e1))
-                    probe.calls.append((_name, [x for x in a if isinstance(x, int) and not isinstance(x, bool) and 0 < x < (1 << 24)], e0, e1))
+                    probe.fam_events.setdefault(_name, []).append((probe.step, e0, e1))
+                    probe.calls.append((_name, [x for x in a if isinstance(x, int) and not isinstance(x, bool) and 0 < x < (1 << 24)], e0, e1, probe.step))
                     return rc
             self._cache[name] = fn
         return fn
 
 
-def _probe(name, nbytes, flops=0.0, rows=None):
+def _probe(name, nbytes, flops=0.0, rows=None, nbytes16=None):
+    """``nbytes``: algorithmic bytes of the launch with every operand at its STORED width; ``nbytes16``: the SURVEY 8(d) figure -- every
+    activation / gradient operand once at 2 bytes (the reference's autocast class), parameters and their gradients at 4."""
     if _PROBE is not None and name in _PROBE.targets:
-        return _PROBE.begin(name, nbytes, flops, rows)
+        return _PROBE.begin(name, nbytes, flops, rows, nbytes16)
     return None

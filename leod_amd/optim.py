@@ -27,12 +27,12 @@ from .parallel import DataParallel, FlatParams
 class FlatAdamW(torch.optim.Optimizer):
     def __init__(self, module: torch.nn.Module, lr=2e-4, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8,
                  clip_value: Optional[float] = None, process_group=None, sync_bn: bool = True,
-                 flat: Optional[FlatParams] = None):
+                 flat: Optional[FlatParams] = None, grad_buckets: bool = True):
         self.module = module
         self.flat = flat if flat is not None else FlatParams(module)
         self.dp = DataParallel(self.flat, process_group, sync_bn=sync_bn)
         self.dp.broadcast_parameters()
-        self.dp.make_buckets(module)                             # per-stage gradient buckets when the job has more than one rank
+        self.dp.make_buckets(module, bucketed=grad_buckets)      # per-stage gradient buckets when the job has more than one rank
         self.clip_value = clip_value
         super().__init__(self.flat.params, dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps))
 

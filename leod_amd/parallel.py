@@ -9,7 +9,7 @@
   so ~98 % of the 39.5 MB (RVT-S) are final before the backward pass of stage 1, the longest, even starts.  The flat
   buffer is laid out in that module order, so each of the five buckets is ONE contiguous slice: it is all-reduced on a
   communication stream the moment its boundary node fires in the backward pass (``functions.BucketBoundaryFn``), under
-  the rest of the backward pass; the optimiser waits for the five handles.  ``LEOD_DP_BUCKETS=0`` falls back to one
+  the rest of the backward pass; the optimiser waits for the five handles.  ``make_buckets(bucketed=False)`` (``FlatAdamW(..., grad_buckets=False)``) falls back to one
   flat all-reduce after the backward pass (needed for gradient accumulation: the buckets assume ONE backward pass per optimiser
   step); ``LEOD_DP_WIRE=bf16`` all-reduces a bf16 copy of each bucket -- half the bytes, but the cross-rank sum itself is then carried
   out and rounded in bf16 at every ring step (log2(world) bits of the gradient sum are lost; off by default).
@@ -56,7 +56,7 @@ class FlatParams:
         # as long as this object lives; made fresh by ``ensure_shadow`` at the start of a step, stale by the AdamW kernel / ``touch``
         self.shadow = None
         self._param_versions = None
-        if dev.type == 'cuda' and os.environ.get('LEOD_WEIGHT_SHADOW', '1') != '0':
+        if dev.type == 'cuda':
             import weakref
             self.shadow = torch.empty(n, dtype=torch.bfloat16, device=dev)
             self.shadow_f16 = torch.empty(n, dtype=torch.float16, device=dev)     # written / read in precision mode 16f only (forward GEMMs)
@@ -150,10 +150,10 @@ class DataParallel:
             dist.broadcast(self.flat.data, src=src, group=self.group)
             self.flat.touch()                                  # parameter memory was rewritten behind the parameters' backs: drop packed copies
 
-    def make_buckets(self, module: torch.nn.Module) -> Optional['GradBuckets']:
-        """Per-stage buckets for ``module`` (None: one rank, or LEOD_DP_BUCKETS=0 -> flat all-reduce after the backward pass)."""
+    def make_buckets(self, module: torch.nn.Module, bucketed: bool = True) -> Optional['GradBuckets']:
+        """Per-stage buckets for ``module`` (None: one rank, or ``bucketed=False`` -> one flat all-reduce after the backward pass)."""
         self.buckets = None
-        if (self.world_size > 1 or self.force) and os.environ.get('LEOD_DP_BUCKETS', '1') != '0':
+        if (self.world_size > 1 or self.force) and bucketed:
             self.buckets = GradBuckets(self.flat, module, self)
         return self.buckets
 
@@ -211,11 +211,11 @@ class GradBuckets:
     def ready(self, k: int, closing: bool = False):
         """Bucket k is final on the launch stream and on the weight-gradient side stream(s): all-reduce it on the comm stream.
         One backward pass per optimiser step: a boundary that fires a second time (gradient accumulation, two losses) would add local
-        gradients to a slice that is already summed over ranks or still in flight -- refused loudly (use LEOD_DP_BUCKETS=0 there)."""
+        gradients to a slice that is already summed over ranks or still in flight -- refused loudly (use the flat exchange there: ``grad_buckets=False``)."""
         if k in self.done and not closing and self.ranges[k] is not None:
             GradBuckets.current = None
             raise RuntimeError('GradBuckets: a second backward pass reached the boundary of gradient bucket %d before the optimiser step; '
-                               'gradient accumulation needs the flat exchange (LEOD_DP_BUCKETS=0)' % k)
+                               'gradient accumulation needs the flat exchange (FlatAdamW(grad_buckets=False))' % k)
         if k in self.done or self.ranges[k] is None:
             self.done.add(k)
             return
@@ -257,14 +257,14 @@ class GradBuckets:
             GradBuckets.current = None                          # never left set behind a step that raised
 
 
-def init_distributed(backend: Optional[str] = None):
-    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torchrun contract)."""
+def init_distributed(backend: Optional[str] = None, local_device: Optional[int] = None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torchrun contract).  ``local_device`` overrides LOCAL_RANK
+    (functional tests of the N > 1 path on one GPU: every rank on device 0 over gloo)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    # functional testing of the N > 1 path on a single GPU: LEOD_DIST_BACKEND=gloo LEOD_FORCE_LOCAL_DEVICE=0
-    if 'LEOD_FORCE_LOCAL_DEVICE' in os.environ:
-        local = int(os.environ['LEOD_FORCE_LOCAL_DEVICE'])
+    if local_device is not None:
+        local = int(local_device)
     if (world > 1 or os.environ.get('LEOD_FORCE_COLLECTIVES') == '1') and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get('LEOD_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')

@@ -1,5 +1,5 @@
 """Training and evaluation drivers without Lightning, for 1..N ranks (what train.py:131-133,221-250 / val.py:83-96 of the reference do with
-``pl.Trainer.fit`` / ``pl.Trainer.test``; pytorch_lightning is not part of the MI355X image -- ``leod_amd.strategy`` binds to it where it exists).
+``pl.Trainer.fit`` / ``pl.Trainer.test``; pytorch_lightning is not part of the MI355X image; INTEGRATION.md section 4 shows the three lines a Lightning user changes).
 
     module = fetch_model_module(config); data_module = fetch_data_module(config)
     history = fit(config, module, data_module)                    # trains for training.max_steps, validates every validation.val_check_interval
@@ -123,7 +123,8 @@ def fit(config, module, data_module, max_steps: Optional[int] = None, val_check_
     opt, sched = (oc['optimizer'], oc['lr_scheduler']['scheduler']) if isinstance(oc, dict) else (oc, None)
     step, epoch = 0, 0
     if resume_from:
-        ck = torch.load(resume_from, map_location='cpu', weights_only=False)
+        # tensors, numbers, strings and containers only (what save_checkpoint writes): no unpickling of arbitrary objects from a path
+        ck = torch.load(resume_from, map_location='cpu', weights_only=True)
         module.load_state_dict(ck['state_dict'])
         opt.load_state_dict(ck['optimizer_states'][0])
         if sched is not None and ck.get('lr_schedulers'):
@@ -147,7 +148,33 @@ def fit(config, module, data_module, max_steps: Optional[int] = None, val_check_
         if hasattr(loader, 'set_epoch'):
             loader.set_epoch(epoch)
         n_in_epoch = 0
-        for batch in _device_batches(loader, module, device):
+        # N > 1: every step issues collectives in lock-step (gradient exchange, SyncBatchNorm, validation), so the ranks must take the SAME
+        # number of steps per epoch although their shards may hold different batch counts: a sized loader is cut to the smallest length of
+        # any rank (one all-reduce per epoch); an unsized (streaming) one agrees per step on "every rank still has a batch"
+        cap, per_step_flag = None, False
+        if world > 1:
+            try:
+                n_mine = len(loader)
+            except TypeError:
+                n_mine = -1
+            agree = torch.tensor([n_mine, -n_mine], dtype=torch.int64, device=device if dist.get_backend(process_group) == 'nccl' else 'cpu')
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN, group=process_group)     # (min length, -max length)
+            if int(agree[0]) >= 0:
+                cap = int(agree[0])
+            else:
+                per_step_flag = True
+        batches = iter(_device_batches(loader, module, device))
+        while True:
+            if cap is not None and n_in_epoch >= cap:
+                break
+            batch = next(batches, None)
+            if per_step_flag:
+                flag = torch.tensor([0 if batch is None else 1], dtype=torch.int32, device=device if dist.get_backend(process_group) == 'nccl' else 'cpu')
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+                if int(flag) == 0:
+                    break
+            elif batch is None:
+                break
             out = fit_step(module, opt, sched, batch, step)
             step += 1
             n_in_epoch += 1

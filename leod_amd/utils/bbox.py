@@ -50,13 +50,18 @@ def construct_bbox(abcd: Tuple[Boxes, Boxes, Boxes, Boxes], last4: bool):
 
 
 # (origin of the box in x / y as a multiple of its width / height: centre boxes start half a size before their anchor point)
-_ORIGIN = {'center': 0.5, 'corner': 0.0}
 
 
-def _anchor_shift(format_: str) -> float:
-    if format_ not in _ORIGIN:
+# per anchor convention: (x, w) -> (x1, x2) and (x1, x2, w) -> x, written with the reference's own arithmetic (utils/bbox.py:63-68,83-86) so that
+# rounding and integer dtypes come out the same: centre boxes halve the extent, corner boxes never leave the input dtype
+_TO_CORNERS = {'center': lambda a, e: (a - e / 2., a + e / 2.), 'corner': lambda a, e: (a, a + e)}
+_TO_ANCHOR = {'center': lambda lo, hi: (lo + hi) / 2., 'corner': lambda lo, hi: lo}
+
+
+def _convention(table, format_: str):
+    if format_ not in table:
         raise NotImplementedError(f'Unknown format {format_}')
-    return _ORIGIN[format_]
+    return table[format_]
 
 
 def xywh2xyxy(xywh, format_: str = 'center', last4: bool = None):
@@ -64,10 +69,10 @@ def xywh2xyxy(xywh, format_: str = 'center', last4: bool = None):
     from leod_amd.data.genx_utils.labels import ObjectLabels
     if isinstance(xywh, ObjectLabels):
         return xywh.get_xyxy()
-    k = _anchor_shift(format_)
+    span = _convention(_TO_CORNERS, format_)
     (ax, ay, bw, bh), last4 = get_bbox_coords(xywh, last4=last4)
-    left, top = ax - k * bw, ay - k * bh
-    return construct_bbox((left, top, left + bw, top + bh), last4=last4)
+    (left, right), (top, bottom) = span(ax, bw), span(ay, bh)
+    return construct_bbox((left, top, right, bottom), last4=last4)
 
 
 def xyxy2xywh(xyxy, format_: str = 'center', last4: bool = None):
@@ -75,7 +80,6 @@ def xyxy2xywh(xyxy, format_: str = 'center', last4: bool = None):
     from leod_amd.data.genx_utils.labels import ObjectLabels
     if isinstance(xyxy, ObjectLabels):
         return xyxy.get_xywh(format_=format_)
-    k = _anchor_shift(format_)
+    anchor = _convention(_TO_ANCHOR, format_)
     (left, top, right, bottom), last4 = get_bbox_coords(xyxy, last4=last4)
-    bw, bh = right - left, bottom - top
-    return construct_bbox((left + k * bw, top + k * bh, bw, bh), last4=last4)
+    return construct_bbox((anchor(left, right), anchor(top, bottom), right - left, bottom - top), last4=last4)

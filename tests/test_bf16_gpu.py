@@ -24,10 +24,11 @@ def bf16_ops(request):
     from leod_amd import ops
     prev = ops.set_precision(request.param)
     tk.MODE['bf16'] = True
+    tk.MODE['fwd16f'] = request.param == '16f'        # forward tensors: the fp16-sized bound of test_kernels_gpu.F16_FWD_RTOL
     try:
         yield ops
     finally:
-        tk.MODE['bf16'] = False
+        tk.MODE['bf16'] = tk.MODE['fwd16f'] = False
         ops.set_precision(prev)
 
 
@@ -101,7 +102,7 @@ def test_conv3x3_direct_bf16(bf16_ops, B, H, W, Cin, N):
     R = 8
     cs = torch.zeros((R, 2, N), dtype=torch.float64, device=tk.DEV)
     y = ops.conv_nhwc_fwd(xn, w.detach().to(tk.DEV), None, colstats=cs)
-    tk.close(y, ref.detach().permute(0, 2, 3, 1), what='conv3x3 fwd')
+    tk.close(y, ref.detach().permute(0, 2, 3, 1), what='conv3x3 fwd', fwd=True)
     # the statistics are sums of the kernel's own outputs
     yd = y.double().reshape(-1, N)
     # (fp32 partial sums of <= 12 rows per lane, double beyond)
@@ -147,7 +148,7 @@ def test_conv3x3_strided_sliced_direct_bf16(bf16_ops, B, H, W, Cin, N, stride):
     R = 8
     cs = torch.zeros((R, 2, N), dtype=torch.float64, device=tk.DEV)
     y = ops.conv_nhwc_fwd(xn, w.detach().to(tk.DEV), None, stride=stride, colstats=cs)
-    tk.close(y, ref.detach().permute(0, 2, 3, 1), what='conv3x3 fwd (strided)')
+    tk.close(y, ref.detach().permute(0, 2, 3, 1), what='conv3x3 fwd (strided)', fwd=True)
     yd = y.double().reshape(-1, N)
     assert torch.allclose(cs.sum(0)[0], yd.sum(0), rtol=1e-4, atol=1e-4 * yd.abs().sum(0).max().item())
     assert torch.allclose(cs.sum(0)[1], (yd * yd).sum(0), rtol=1e-4)
@@ -181,7 +182,7 @@ def test_partition_attn_bf16_tensors(bf16_ops, B, H, W, C, heads, part, window):
     ref.backward(dout)
     q = qkv16.to(tk.DEV)
     out, lse = ops.partition_attn_fwd(q, heads, part, window, want_lse=True)
-    tk.close(out, ref, what='attn fwd from bf16 qkv')
+    tk.close(out, ref, what='attn fwd from bf16 qkv', fwd=True)
     dq = ops.partition_attn_bwd(q, dout.to(tk.DEV), lse, heads, part, window)
     assert dq.dtype is torch.bfloat16
     tk.close(dq.float(), qkv.grad, what='bf16 dqkv')
@@ -210,7 +211,7 @@ def test_attention_block_keeps_o_and_do_as_bf16(bf16_ops, B, H, W, C, heads):
     Wp, bp, g = tk.rnd((C, C), 4, 0.2), tk.rnd((C,), 5, 0.2), 0.5 + 0.1 * tk.rnd((C,), 6)
     d = lambda t: t.detach().to(tk.DEV)  # noqa
     y, _ = ops.linear_lsres_fwd(d(o16), d(Wp), d(bp), d(g), d(res), want_t=False, a_gelu=False)
-    tk.close(y, res + g * F.linear(o16.float(), Wp, bp), what='proj + LayerScale + residual from bf16 O')
+    tk.close(y, res + g * F.linear(o16.float(), Wp, bp), what='proj + LayerScale + residual from bf16 O', fwd=True)
     do = ops.linear_dgrad(d(dy), d(Wp), kscale=d(g), out_bf16=True)
     assert do.dtype is torch.bfloat16
     tk.close(do.float(), (dy * g) @ Wp, what='bf16 dO')
@@ -231,7 +232,7 @@ def test_ln_qkv_bf16_rows(bf16_ops, M, N, K):
     d = lambda t: t.to(tk.DEV)  # noqa
     o16, _, st = ops.ln_linear_fwd(d(x), d(lw), d(lb), d(W), d(b), want_stats=True, out_bf16=True)
     assert o16.dtype is A16() and st is not None
-    tk.close(o16.float(), ref, what='bf16 qkv rows')
+    tk.close(o16.float(), ref, what='bf16 qkv rows', fwd=True)
     mean = x.mean(1)
     tk.close(st[:, 0], mean, rtol=1e-4, atol=1e-5, what='LayerNorm mean')
 
@@ -244,7 +245,7 @@ def test_qkv_bf16_rows_without_layernorm(bf16_ops):
         x, W, b = tk.rnd((M, K), 1), tk.rnd((N, K), 4, 0.2), tk.rnd((N,), 5, 0.2)
         o16, _, st = ops.ln_linear_fwd(x.to(tk.DEV), None, None, W.to(tk.DEV), b.to(tk.DEV), out_bf16=True)
         assert o16.dtype is A16() and st is None
-        tk.close(o16.float(), F.linear(x, W, b), what=f'bf16 qkv rows without LayerNorm {M}x{N}x{K}')
+        tk.close(o16.float(), F.linear(x, W, b), what=f'bf16 qkv rows without LayerNorm {M}x{N}x{K}', fwd=True)
 
 
 @pytest.mark.parametrize('M,C', [(40009, 48), (20011, 96), (16384, 64), (9001, 192), (5003, 384), (4100, 128)])
@@ -268,9 +269,9 @@ def test_mlp_hidden_stored_once_as_fp16(bf16_ops, M, C):
     d = lambda t: t.detach().to(tk.DEV)  # noqa
     u16, hh, st = ops.ln_linear_fwd(d(x), d(lw), d(lb), d(W1), d(b1), want_act=True, want_stats=True)
     assert u16.dtype is torch.float16 and hh is None, 'the row-streaming shapes keep one fp16 tensor'
-    tk.close(u16.float(), u, what='u (fp16)')
+    tk.close(u16.float(), u, what='u (fp16)', fwd=True)
     zz, _ = ops.linear_lsres_fwd(u16, d(W2), d(b2), d(g), d(res), want_t=False)
-    tk.close(zz, z, what='fc2 + LayerScale + residual from the fp16 pre-activation')
+    tk.close(zz, z, what='fc2 + LayerScale + residual from the fp16 pre-activation', fwd=True)
     du = ops.linear_dgrad(d(dz), d(W2), kscale=d(g), aux_u=u16)
     assert du.dtype is (torch.bfloat16 if ops.BF16_GRADS else torch.float32)
     tk.close(du.float(), u.grad, what='dgrad through GELU')
@@ -500,10 +501,10 @@ def test_mlp_fwd_fused_bf16(bf16_ops, M, saved):
     out = ops.mlp_fwd_fused(d(y), d(lw), d(lb), d(W1), d(b1), d(W2), d(b2), d(g), want_saved=saved)
     assert out is not None, 'K = 48 / H = 192 / M >= 16384 in precision mode bf16 is what the fused kernel covers'
     zz, u16, st = out
-    tk.close(zz, z, what='fused MLP output')
+    tk.close(zz, z, what='fused MLP output', fwd=True)
     if saved:
         assert u16.dtype is torch.float16 and tuple(u16.shape) == (M, 4 * C) and tuple(st.shape) == (M, 2)
-        tk.close(u16.float(), u, what='fp16 pre-activation of the fused MLP')
+        tk.close(u16.float(), u, what='fp16 pre-activation of the fused MLP', fwd=True)
         u_ref, _, st_ref = ops.ln_linear_fwd(d(y), d(lw), d(lb), d(W1), d(b1), want_act=True, want_stats=True)
         assert float((u16.float() - u_ref.float()).abs().max()) <= 2e-2 * float(u_ref.float().abs().max())
         torch.testing.assert_close(st, st_ref, rtol=1e-5, atol=1e-6)

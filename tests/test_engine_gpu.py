@@ -138,13 +138,12 @@ def test_pseudo_label_inference_vs_oracle(gpu, manifest):
 # ---- world-size 2 on ONE GPU (gloo carries the device tensors): SyncBatchNorm + gradient all-reduce end to end -------------
 def _world2_worker(rank, port, manifest, q, buckets='1'):
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK='0',
-                      LEOD_DP_BUCKETS=buckets)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK='0')
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=2)
     from leod_amd.engine import TrainEngine
     det, _ = micro_detector(manifest, 9)
-    eng = TrainEngine(det, lr=2e-4, total_steps=1000)
+    eng = TrainEngine(det, lr=2e-4, total_steps=1000, grad_buckets=buckets == '1')
     T, B = 4, 4
     ev = synth_events(T, B, 20, 60, 90, seed=70, as_uint8=True)
     labs_all = micro_labels(T * B, seed=71)
@@ -192,7 +191,7 @@ def test_world2_syncbn_and_replica_consistency(gpu, manifest):
     np.testing.assert_array_equal(res[0][4], res[1][4])
     # single process, full batch: BatchNorm statistics of the forward pass are the global ones
     det, _ = micro_detector(manifest, 9)
-    eng = TrainEngine(det, lr=2e-4, total_steps=1000)
+    eng = TrainEngine(det, lr=2e-4, total_steps=1000, grad_buckets=buckets == '1')
     T, B = 4, 4
     ev = synth_events(T, B, 20, 60, 90, seed=70, as_uint8=True)
     labs_all = micro_labels(T * B, seed=71)

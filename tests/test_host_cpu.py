@@ -192,7 +192,7 @@ class _ToyDetector(torch.nn.Module):
 
 def _bucket_worker(rank, world, port, q, bucketed, wire):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                      LEOD_DP_BUCKETS='1' if bucketed else '0', LEOD_DP_WIRE=wire)
+                      LEOD_DP_WIRE=wire)
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from leod_amd.parallel import init_distributed, FlatParams, DataParallel, GradBuckets
@@ -201,7 +201,7 @@ def _bucket_worker(rank, world, port, q, bucketed, wire):
     m = _ToyDetector()
     flat = FlatParams(m)
     dp = DataParallel(flat, sync_bn=False)
-    buckets = dp.make_buckets(m)
+    buckets = dp.make_buckets(m, bucketed=bucketed)
     assert (buckets is not None) == bucketed
     flat.zero_grad()
     dp.begin_step()

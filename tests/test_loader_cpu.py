@@ -597,3 +597,83 @@ def test_read_helpers_of_a_recording(tmp_path):
     window = misc.read_labels_as_list(seq, cfg, L=3, start_idx=lo)
     assert window[0] is not None and len(window) == 3 and [i for i, l in enumerate(window) if l is not None] == [r - lo for r in o2r if lo <= r < lo + 3]
     np.testing.assert_allclose(window[0].x.numpy() if hasattr(window[0].x, 'numpy') else window[0].x, full[lo].x)
+
+
+class _FakeH5Dataset:
+    """The slice of h5py.Dataset that H5Frames uses (shape, __getitem__, read_direct) over an in-memory array."""
+
+    def __init__(self, arr):
+        self._a = arr
+        self.shape, self.dtype = arr.shape, arr.dtype
+        self.reads = 0
+
+    def __getitem__(self, s):
+        self.reads += 1
+        return self._a[s].copy()
+
+    def read_direct(self, dest, source_sel=None):
+        self.reads += 1
+        np.copyto(dest, self._a[source_sel])
+
+
+def test_h5_frames_agree_with_raw_frames_through_a_stand_in_h5py(tmp_path, monkeypatch):
+    """``misc.H5Frames`` (the reader of the reference's container, sequence_base.py:184-193: ``h5py.File(fn, 'r')['data'][a:b]``) executed through
+    a stand-in ``h5py`` module (h5py is not in this image): every read path of H5Frames and RawFrames returns the same bytes, the frame-store
+    cache and ``open_ev_repr`` / ``read_frame_header`` / ``read_ev_repr`` pick the HDF5 file when no raw twin exists, and a streaming sequence
+    built over the HDF5 file yields the samples of the one built over the twin."""
+    import sys
+    import types
+    from leod_amd.data.utils import misc
+    tree = synth_dataset_tree(str(tmp_path / 'src'), 'gen1', False, frame_hw=(6, 8))
+    name, _, n_frames, _ = LOADER_RECORDINGS[0]
+    seq = os.path.join(tree, 'train', name)
+    raw_fn = misc.get_ev_raw_fn(seq)
+    h5_fn = misc.get_ev_h5_fn(seq)
+    frames = np.load(raw_fn)
+    opened = []
+
+    class File:
+        def __init__(self, fn, mode='r'):
+            assert mode == 'r' and str(fn).endswith('.h5') and os.path.exists(fn)
+            self.ds = _FakeH5Dataset(frames)
+            opened.append(self)
+            self.closed = False
+
+        def __getitem__(self, key):
+            assert key == 'data'
+            return self.ds
+
+        def close(self):
+            self.closed = True
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            self.close()
+
+    fake = types.ModuleType('h5py')
+    fake.File = File
+    monkeypatch.setitem(sys.modules, 'h5py', fake)
+    raw, h5 = misc.RawFrames(raw_fn), misc.H5Frames(h5_fn)
+    assert h5.shape == raw.shape == frames.shape and len(h5) == len(raw) == n_frames
+    for a, b in ((0, 1), (2, 7), (0, n_frames), (n_frames - 1, n_frames)):
+        assert np.array_equal(h5.read(a, b), raw.read(a, b))
+        out_h, out_r = np.empty((b - a,) + frames.shape[1:], np.uint8), np.empty((b - a,) + frames.shape[1:], np.uint8)
+        assert h5.read(a, b, out_h) is out_h and np.array_equal(out_h, raw.read(a, b, out_r))
+    h5.close()
+    assert opened[0].closed
+    # dispatch: with the twin present the raw file wins; without it the HDF5 file is opened
+    assert isinstance(misc.open_ev_repr(seq), misc.RawFrames)
+    os.rename(raw_fn, raw_fn + '.away')
+    try:
+        st = misc.open_ev_repr(seq)
+        assert isinstance(st, misc.H5Frames) and np.array_equal(st.read(1, 4), frames[1:4])
+        st.close()
+        assert misc.read_frame_header(h5_fn) == (n_frames, frames.shape[1:])
+        assert np.array_equal(misc.read_ev_repr(seq), frames)
+        misc.FRAME_STORES.clear()
+        assert isinstance(misc.FRAME_STORES.get(h5_fn), misc.H5Frames)
+        misc.FRAME_STORES.clear()
+    finally:
+        os.rename(raw_fn + '.away', raw_fn)

@@ -210,6 +210,119 @@ def test_pseudo_labeler_predict_step_vs_oracle(gpu, manifest, pipelined):
     assert total > 10
 
 
+@pytest.mark.parametrize('mode', ['f32', '16f'])
+def test_pseudo_labeler_predict_step_full_size_vs_oracle(gpu, manifest, mode):
+    """BASELINE configs[4] at its real geometry: ``PseudoLabeler.predict_step`` on RVT-S, Gen1 240x304, L = 21, B = 2 source streams + hflip
+    TTA, two streaming chunks (LSTM state carried, one GT frame) -- what lands in EventSeqData against the oracle's ``infer_sequence`` +
+    ``pred2label`` + ``tta_postprocess`` (pseudo_labeler.py:622-770).  fp32 mode: label counts exact on every frame, boxes / scores to 3e-4.
+    Mode 16f (the benchmarked one): scores near a threshold may cross it under 16-bit rounding, so per frame the count may drift by
+    max(1, 10 %) and every label needs a partner of the same class within 3e-2 of the frame size / 3e-2 in the scores, <= 3 % unmatched overall."""
+    from leod_amd import ops
+    from leod_amd.config import full_config, dynamically_modify_train_config
+    from leod_amd.data.genx_utils.labels import ObjectLabels, SparselyBatchedObjectLabels
+    from leod_amd.data.utils.types import DataType
+    from leod_amd.modules.pseudo_labeler import PseudoLabeler
+    from leod_amd.modules.utils.detection import WORKER_ID_KEY, DATA_KEY
+    hw, L, B = (240, 304), 21, 2
+    W = hw[1]
+    over = dict(dataset=dict(sequence_length=L), tta=dict(enable=True, hflip=True, tflip=False))
+    cfg = dynamically_modify_train_config(full_config('gen1', 'small', model='pseudo_labeler', overrides=over))
+    cfg.model.postprocess.confidence_threshold = 0.01
+    obj_thr, cls_thr = [0.1, 0.05], [0.1, 0.05]
+    cfg.model.pseudo_label.obj_thresh, cfg.model.pseudo_label.cls_thresh = obj_thr, cls_thr
+    sd = synth_state_dict(manifest['small_gen1'], 3)
+    for k in sd:                                  # SURVEY 8d's bias bump, sized for the synthetic weights: every anchor is an NMS candidate, boxes of
+        if ('obj_preds' in k or 'cls_preds' in k) and k.endswith('bias'):       # ~4.5 strides overlap (NMS keeps ~300 of 1680 per frame), scores
+            sd[k] = sd[k] + 2.0                                                  # straddle the per-class obj / cls thresholds of pred2label
+        if 'reg_preds' in k and k.endswith('bias'):
+            sd[k] = sd[k].clone()
+            sd[k][2:4] += 1.5
+    full = ot.model_cfg(48, 24, 0.33, (8, 10))
+    prev = ops.get_precision()
+    import os
+    env = os.environ.pop('LEOD_PRECISION', None)  # the module's config decides (Module.setup -> leod_set_precision)
+    try:
+        cfg.training.precision = {'f32': 32, '16f': 16}[mode]
+        mod = PseudoLabeler(cfg)
+        mod.mdl.load_state_dict(sd)
+        mod.to(DEV).eval()
+        mod.setup('predict')
+        assert ops.get_precision() == mode
+        mod.pipelined = True
+        gt = torch.tensor([[1234567.0, 40.0, 50.0, 60.0, 45.0, 1.0, 1.0, 1.0], [1234567.0, 150.0, 100.0, 30.0, 38.0, 0.0, 1.0, 1.0]])
+        states, want = None, {0: {}, 1: {}}
+        osd = {k: v.clone() for k, v in sd.items()}
+        for step in range(2):
+            ev = synth_events(L, B, 20, hw[0], hw[1], seed=90 + step, as_uint8=True)
+            labels_tb = [[None, None] for _ in range(L)]
+            if step == 0:
+                labels_tb[9][1] = gt
+            seq = [SparselyBatchedObjectLabels([None if l is None else ObjectLabels(l.clone(), hw) for l in labels_tb[t]]) for t in range(L)]
+            none_seq = [SparselyBatchedObjectLabels([None] * B) for _ in range(L)]
+            data = {DataType.EV_REPR: [ev[t].to(DEV) for t in range(L)], DataType.OBJLABELS_SEQ: seq,
+                    DataType.SKIPPED_OBJLABELS_SEQ: none_seq, DataType.IS_FIRST_SAMPLE: torch.full((B,), step == 0).to(DEV),
+                    DataType.IS_LAST_SAMPLE: torch.full((B,), step == 1), DataType.IS_REVERSED: torch.zeros(B, dtype=torch.bool),
+                    DataType.EV_IDX: [torch.full((B,), L * step + t, dtype=torch.long) for t in range(L)],
+                    DataType.IS_PADDED_MASK: [torch.zeros(B, dtype=torch.bool) for _ in range(L)], DataType.PATH: ['rec/fullA', 'rec/fullB']}
+            mod.predict_step({DATA_KEY: data, WORKER_ID_KEY: 0}, step)
+            with torch.no_grad():
+                dets, states, _ = ot.infer_sequence(osd, full, ev, states, conf_thre=0.01, hflip=True)
+            for t in range(L):
+                for b in range(B):
+                    frame = L * step + t
+                    if labels_tb[t][b] is not None:
+                        want[b][frame] = ('gt', labels_tb[t][b])
+                        continue
+                    views = op.pred2label([dets[t * 2 * B + b].clone(), dets[t * 2 * B + B + b].clone()], obj_thr, cls_thr, 'gen1', False)
+                    flipped = views[1].clone()
+                    flipped[:, 1] = W - 1 - flipped[:, 1] - flipped[:, 3]
+                    rows = torch.cat([views[0], flipped], 0)
+                    if len(rows) == 0:
+                        continue
+                    xyxy = torch.cat([rows[:, 1:3], rows[:, 1:3] + rows[:, 3:5], rows[:, 7:8], rows[:, 6:7], rows[:, 5:6]], 1)
+                    merged = op.tta_postprocess([xyxy], 0.01, 0.45)[0]
+                    if merged is not None:
+                        want[b][frame] = ('pse', merged)
+        mod.flush_predictions()
+    finally:
+        if env is not None:
+            os.environ['LEOD_PRECISION'] = env
+        ops.set_precision(prev)
+    tot = dict(ref=0, got=0, unmatched=0, frames=0)
+    for b, path in enumerate(['rec/fullA', 'rec/fullB']):
+        esd = mod.ev_path_2_ev_data[path]
+        assert esd.eoe and esd.aug
+        esd._aggregate_results(num_frames=2 * L)
+        got = {f: l for f, l in zip(esd.frame_idx, esd.labels) if len(l)}
+        if mode == 'f32':
+            assert set(got) == set(want[b]), (sorted(got), sorted(want[b]))
+        for f, (kind, ref) in want[b].items():
+            if kind == 'gt':
+                assert torch.equal(got[f].object_labels.cpu(), ref)
+                continue
+            o = got[f].object_labels.cpu() if f in got else torch.zeros((0, 8))
+            rb = torch.cat([ref[:, 0:2], ref[:, 2:4] - ref[:, 0:2]], 1).numpy()         # x, y, w, h
+            rs, rc = ref[:, [6, 5, 4]].numpy(), ref[:, 6].numpy()                        # (class id, class confidence, objectness)
+            tot['ref'] += len(ref); tot['got'] += len(o); tot['frames'] += 1
+            if mode == 'f32':
+                assert len(o) == len(ref) and bool((o[:, 0] == 0).all()), (b, f, len(o), len(ref))
+                np.testing.assert_allclose(o[:, 1:5].numpy(), rb, rtol=3e-4, atol=3e-4)
+                np.testing.assert_allclose(o[:, 5:8].numpy(), rs, rtol=3e-4, atol=1e-6)
+                continue
+            assert abs(len(o) - len(ref)) <= max(1, int(0.1 * len(ref))), f'stream {b} frame {f}: {len(o)} labels, oracle {len(ref)}'
+            ob_, os_ = o[:, 1:5].numpy(), o[:, 5:8].numpy()
+            used = set()
+            for i in range(len(ref)):
+                d = np.abs(ob_ - rb[i]).max(1) / W if len(o) else np.zeros(0)
+                ok = [j for j in np.argsort(d) if j not in used and d[j] <= 3e-2 and os_[j, 0] == rc[i] and np.abs(os_[j, 1:] - rs[i, 1:]).max() <= 3e-2]
+                if ok:
+                    used.add(ok[0])
+            tot['unmatched'] += (len(ref) - len(used)) + (len(o) - len(used))
+    print(f'full-size pseudo-label pass ({mode}) vs oracle:', tot)
+    assert tot['ref'] > 200, tot
+    assert tot['unmatched'] <= 0.03 * (tot['ref'] + tot['got']), tot
+
+
 def test_event_seq_result_golden(gpu, golden_dir):
     """EventSeqResult on device tensors (TTA merge = one batched HIP NMS launch) vs the records the reference produced."""
     import os
@@ -521,12 +634,11 @@ def test_module_head_loss_options_through_plans_equal_eager(gpu, manifest):
 
 
 def test_module_planned_backbone_with_eager_head_equals_eager(gpu, manifest, monkeypatch):
-    """The planned-backbone / eager-head option of the launch plans (LEOD_PLAN_HEAD_EAGER=1, meant for N > 1) on one GPU: the
+    """The planned-backbone / eager-head option of the launch plans (``module.plan_head_eager = True``, meant for N > 1) on one GPU: the
     backbone is captured and replayed, PAFPN + head + losses run as ordinary autograd between the backbone's forward and backward plans
     (``EagerHeadGate``).  Five steps with changing label counts, partial LSTM resets and two loader workers equal five eager steps."""
     from leod_amd.modules.utils.detection import Mode, WORKER_ID_KEY
     from leod_amd.optim import fit_step
-    monkeypatch.setenv('LEOD_PLAN_HEAD_EAGER', '1')
     L, B = 4, 2
     keys6 = ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')
     res = {}
@@ -535,6 +647,7 @@ def test_module_planned_backbone_with_eager_head_equals_eager(gpu, manifest, mon
         cfg.training.lr_scheduler.total_steps = 1000
         mod.train()
         mod.plan_mode = plan
+        mod.plan_head_eager = True
         oc = mod.configure_optimizers()
         opt, sched = oc['optimizer'], oc['lr_scheduler']['scheduler']
         out_l = []
@@ -646,8 +759,6 @@ def _module_world2_steps_worker(rank, port, manifest, q, plan, steps, head_eager
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK='0')
-    if head_eager is not None:
-        os.environ['LEOD_PLAN_HEAD_EAGER'] = head_eager
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=2)
     from leod_amd.optim import fit_step
@@ -655,6 +766,7 @@ def _module_world2_steps_worker(rank, port, manifest, q, plan, steps, head_eager
     cfg.training.lr_scheduler.total_steps = 1000
     mod.train()
     mod.plan_mode = plan
+    mod.plan_head_eager = head_eager == '1'
     oc = mod.configure_optimizers()
     opt, sched = oc['optimizer'], oc['lr_scheduler']['scheduler']
     assert opt.world_size == 2 and opt.dp.buckets is not None
@@ -683,8 +795,8 @@ def _module_world2_steps_worker(rank, port, manifest, q, plan, steps, head_eager
 def test_module_world2_plans_with_collectives_equal_eager(gpu, manifest, head):
     """N > 1 under launch plans: two ranks on one GPU over gloo, SyncBatchNorm + per-stage gradient buckets, a
     DIFFERENT number of labelled frames per rank, four optimisation steps, both ways the plans handle the head's collectives.
-    ``captured`` (LEOD_PLAN_HEAD_EAGER=0): step 1 is recorded in segments -- every SyncBatchNorm exchange and every bucket release is a
-    host callback between two plan segments (``PlanRecorder.split``).  ``eager`` (LEOD_PLAN_HEAD_EAGER=1): only the
+    ``captured`` (``plan_head_eager = False``): step 1 is recorded in segments -- every SyncBatchNorm exchange and every bucket release is a
+    host callback between two plan segments (``PlanRecorder.split``).  ``eager`` (``plan_head_eager = True``): only the
     backbone is captured (its backward holds the bucket releases of the backbone's parameters); PAFPN + head run as ordinary autograd
     between the backbone's plans (``EagerHeadGate``).  Either way steps 2-3 are replays and the run must match the eager run of the same
     ranks: replicas identical across ranks, losses and parameters equal to the eager ones up to the atomics' reorder noise."""
