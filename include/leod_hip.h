@@ -200,6 +200,18 @@ long leod_conv_nhwc_wgrad_workspace_floats(int B, int H, int W, int Cin, int N, 
 int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, float* dbias, float* ws, int B, int H, int W, int Cin, int N,
                          int ks, int stride, int pad, leod_stream_t stream);
 
+/* Depthwise convolution (groups == channels) on NHWC maps, w[C,1,ks,ks]: the depthwise half of DWConv (network_blocks.py:57-76, selected
+ * by `depthwise` at yolo_pafpn.py:37 / yolo_head.py:52) and conv3x3_dws of the ConvLSTM (models/layers/rnn.py:20-30,50-55).  Same epilogue
+ * options as leod_conv_nhwc_fwd: +bias, colstats [stat_rep,2,C] double += (sum, sumsq), or eval BatchNorm folded + SiLU.  C % 4 == 0.
+ * dgrad: dx[B,H,W,C] (+= when accumulate) from dy[B,Ho,Wo,C]; wgrad: dw[C,1,ks,ks] += , dbias[C] += (optional).  fp32 in every mode. */
+int leod_dwconv_nhwc_fwd(const float* x, const float* w, const float* bias, float* y, double* colstats, int stat_rep, const float* bn_w,
+                         const float* bn_b, const float* bn_rm, const float* bn_rv, float bn_eps, int B, int H, int W, int C,
+                         int ks, int stride, int pad, leod_stream_t stream);
+int leod_dwconv_nhwc_dgrad(const float* dy, const float* w, float* dx, int accumulate, int B, int H, int W, int C, int ks,
+                           int stride, int pad, leod_stream_t stream);
+int leod_dwconv_nhwc_wgrad(const float* dy, const float* x, float* dw, float* dbias, int B, int H, int W, int C, int ks,
+                           int stride, int pad, leod_stream_t stream);
+
 /* BatchNorm2d (batch statistics) + SiLU on rows and its autograd (network_blocks.py:47-51).  `count` = rows that
  * entered colstats/sums.  SyncBatchNorm: with count_dev (device scalar) the row count is count * count_dev[0] -- pass count =
  * rows per image and count_dev = images over all ranks (one all-reduced scalar per step), colstats/sums all-reduced.

@@ -407,6 +407,32 @@ class ConvLSTMFn(Function):
         return None, dx, dh_prev, dc_prev, None, None
 
 
+class DepthwiseConvFn(Function):
+    """k x k depthwise convolution with bias on an NHWC map, channels [lo, hi) of the layer's filters: ``conv3x3_dws`` of the ConvLSTM
+    (models/layers/rnn.py:26-30,50-55) -- on h alone, or on x and h with the two halves of a [2C,1,k,k] filter bank (a depthwise conv of
+    cat(x, h) is the two depthwise convs side by side).  apply(conv module, x, weight, bias, lo, hi) -> y"""
+
+    @staticmethod
+    def forward(ctx, conv, x, w, b, lo: int, hi: int):
+        wv, bv = w[lo:hi], (b[lo:hi] if b is not None else None)
+        y = ops.conv_nhwc_fwd(x, wv, bv, stride=1)
+        if any(ctx.needs_input_grad):
+            ctx.conv, ctx.lohi = conv, (lo, hi)
+            ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        lo, hi = ctx.lohi
+        dy = _cont(dy)
+        db = grad_buf(ctx.conv.bias)[lo:hi] if ctx.conv.bias is not None else None
+        with _wgrad_side(dy, x):
+            ops.conv_nhwc_wgrad(dy, x, grad_buf(ctx.conv.weight)[lo:hi], db, stride=1)
+        dx = ops.conv_nhwc_dgrad(dy, w[lo:hi], x.shape, stride=1) if ctx.needs_input_grad[1] else None
+        return None, dx, None, None, None, None
+
+
 # ---------------------------------------------------------------------------------------------------
 def _lstm_wx(w, W2, C):
     """The x half W[:, :C] of a ConvLSTM 1x1 weight [4C, 2C] as a contiguous matrix, cached in ``ops.PackCache`` until the weights

@@ -18,10 +18,13 @@ def get_activation(name="silu", inplace=True):
 class BaseConv(nn.Module):
     def __init__(self, in_channels, out_channels, ksize, stride, groups=1, bias=False, act="silu"):
         super().__init__()
-        if groups != 1 or bias or act != 'silu' or ksize not in (1, 3):
-            raise NotImplementedError('HIP BaseConv: dense 1x1/3x3 conv, no bias, SiLU (shipped configs)')
+        depthwise = groups > 1 and groups == in_channels == out_channels         # DWConv.dconv: one k x k filter per channel (k_dwconv.hip)
+        if (groups != 1 and not depthwise) or bias or act != 'silu' or (ksize not in (1, 3) and not depthwise) or ksize % 2 == 0:
+            raise NotImplementedError('HIP BaseConv: dense 1x1 / 3x3 or depthwise k x k conv, no bias, SiLU')
+        if depthwise and in_channels % 4:
+            raise NotImplementedError('HIP depthwise conv: channels must be a multiple of 4')
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=ksize, stride=stride, padding=(ksize - 1) // 2,
-                              groups=1, bias=False)
+                              groups=groups, bias=False)
         self.bn = nn.BatchNorm2d(out_channels)
         self.act = get_activation(act, inplace=True)
         self.stride = stride
@@ -36,14 +39,28 @@ class BaseConv(nn.Module):
         return Fn.as_nchw(self.forward_nhwc(Fn.to_nhwc(x)))
 
 
+class DWConv(nn.Module):
+    """Depthwise k x k BaseConv followed by a pointwise 1 x 1 BaseConv (network_blocks.py:57-76; keys ``dconv.*`` / ``pconv.*``)."""
+
+    def __init__(self, in_channels, out_channels, ksize, stride=1, act="silu"):
+        super().__init__()
+        self.dconv = BaseConv(in_channels, in_channels, ksize=ksize, stride=stride, groups=in_channels, act=act)
+        self.pconv = BaseConv(in_channels, out_channels, ksize=1, stride=1, groups=1, act=act)
+
+    def forward_nhwc(self, x):
+        return self.pconv.forward_nhwc(self.dconv.forward_nhwc(x))
+
+    def forward(self, x):
+        return Fn.as_nchw(self.forward_nhwc(Fn.to_nhwc(x)))
+
+
 class Bottleneck(nn.Module):
     def __init__(self, in_channels, out_channels, shortcut=True, expansion=0.5, depthwise=False, act="silu"):
         super().__init__()
-        if depthwise:
-            raise NotImplementedError('depthwise convs are disabled in every shipped config')
         hidden = int(out_channels * expansion)
+        Conv = DWConv if depthwise else BaseConv
         self.conv1 = BaseConv(in_channels, hidden, 1, stride=1, act=act)
-        self.conv2 = BaseConv(hidden, out_channels, 3, stride=1, act=act)
+        self.conv2 = Conv(hidden, out_channels, 3, stride=1, act=act)
         self.use_add = shortcut and in_channels == out_channels
 
     def forward_nhwc(self, x):

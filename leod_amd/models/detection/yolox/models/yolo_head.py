@@ -13,7 +13,7 @@ import torch.nn as nn
 from leod_amd import functions as Fn
 from leod_amd import ops
 from .losses import IOUloss, FocalLoss
-from .network_blocks import BaseConv
+from .network_blocks import BaseConv, DWConv
 
 LOSS_KEYS = ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')
 
@@ -26,8 +26,6 @@ class YOLOXHead(nn.Module):
                  compile_cfg: Optional[Dict] = None, obj_focal_loss=False, bbox_loss_weighting='', ignore_bg_k=-1,
                  reg_weight=5.0, obj_weight=1.0, cls_weight=1.0, ignore_bbox_thresh=None, ignore_label=1024):
         super().__init__()
-        if depthwise:
-            raise NotImplementedError('HIP head: depthwise convolutions are off in every shipped config')
         if ignore_bg_k is not None and ignore_bg_k > 1:
             raise ValueError('ignore_bg_k is a fraction of the background anchors')
         if bbox_loss_weighting and bbox_loss_weighting.split('-', 1)[0] not in ('obj', 'cls', 'objxcls'):
@@ -39,12 +37,14 @@ class YOLOXHead(nn.Module):
         self.stems = nn.ModuleList()
         hidden_dim = int(256 * (in_channels[-1] / 1024))
         self.hidden_dim = hidden_dim
+        self.depthwise = bool(depthwise)
+        Conv = DWConv if depthwise else BaseConv          # the tower convs (yolo_head.py:52)
         for c in in_channels:
             self.stems.append(BaseConv(c, hidden_dim, ksize=1, stride=1, act=act))
-            self.cls_convs.append(nn.Sequential(BaseConv(hidden_dim, hidden_dim, 3, 1, act=act),
-                                                BaseConv(hidden_dim, hidden_dim, 3, 1, act=act)))
-            self.reg_convs.append(nn.Sequential(BaseConv(hidden_dim, hidden_dim, 3, 1, act=act),
-                                                BaseConv(hidden_dim, hidden_dim, 3, 1, act=act)))
+            self.cls_convs.append(nn.Sequential(Conv(hidden_dim, hidden_dim, 3, 1, act=act),
+                                                Conv(hidden_dim, hidden_dim, 3, 1, act=act)))
+            self.reg_convs.append(nn.Sequential(Conv(hidden_dim, hidden_dim, 3, 1, act=act),
+                                                Conv(hidden_dim, hidden_dim, 3, 1, act=act)))
             self.cls_preds.append(nn.Conv2d(hidden_dim, num_classes, 1, 1, 0))
             self.reg_preds.append(nn.Conv2d(hidden_dim, 4, 1, 1, 0))
             self.obj_preds.append(nn.Conv2d(hidden_dim, 1, 1, 1, 0))
@@ -56,8 +56,25 @@ class YOLOXHead(nn.Module):
         self.strides = tuple(int(s) for s in strides)
         self.reg_weight, self.obj_weight, self.cls_weight = reg_weight, obj_weight, cls_weight
         self.ignore_bg_k = ignore_bg_k if ignore_bg_k is not None else -1
-        self.bbox_loss_weighting = bbox_loss_weighting
-        self._blw = None                 # (which confidence, compiled expression of w): parsed and validated ONCE, here
+        self.bbox_loss_weighting = bbox_loss_weighting      # property: parsed and validated once per assignment (below)
+        self.ignore_bbox_thresh = ignore_bbox_thresh
+        self.ignore_label = ignore_label
+        self.last_assignment = None
+        self.last_losses6 = None
+        self.hw = None
+        self.initialize_biases(prior_prob=0.01)
+
+    @property
+    def bbox_loss_weighting(self) -> str:
+        return self._bbox_loss_weighting
+
+    @bbox_loss_weighting.setter
+    def bbox_loss_weighting(self, bbox_loss_weighting) -> None:
+        bbox_loss_weighting = bbox_loss_weighting or ''
+        if bbox_loss_weighting and bbox_loss_weighting.split('-', 1)[0] not in ('obj', 'cls', 'objxcls'):
+            raise NotImplementedError(f'Unknow {bbox_loss_weighting=}')
+        self._bbox_loss_weighting = bbox_loss_weighting
+        self._blw = None                 # (which confidence, compiled expression of w)
         if bbox_loss_weighting:
             val, expr = bbox_loss_weighting.split('-', 1) if '-' in bbox_loss_weighting else (bbox_loss_weighting, 'w')
             try:
@@ -71,12 +88,6 @@ class YOLOXHead(nn.Module):
             if not torch.is_tensor(probe) or probe.shape != (2, 3):
                 raise ValueError(f'model.head.bbox_loss_weighting: {expr!r} must be elementwise in w (a tensor of w\'s shape)')
             self._blw = (val, code)
-        self.ignore_bbox_thresh = ignore_bbox_thresh
-        self.ignore_label = ignore_label
-        self.last_assignment = None
-        self.last_losses6 = None
-        self.hw = None
-        self.initialize_biases(prior_prob=0.01)
 
     def initialize_biases(self, prior_prob):
         v = -math.log((1 - prior_prob) / prior_prob)
@@ -142,6 +153,16 @@ class YOLOXHead(nn.Module):
         return feats
 
     def _towers(self, xin):
+        if self.depthwise:                                # DWConv towers: two BaseConvs per layer, evaluated layer by layer
+            feats = []
+            for k in range(len(xin)):
+                x = self.stems[k].forward_nhwc(xin[k])
+                c = r = x
+                for d in (0, 1):
+                    c = self.cls_convs[k][d].forward_nhwc(c)
+                    r = self.reg_convs[k][d].forward_nhwc(r)
+                feats += [c, r]
+            return feats
         if (_LEVEL_STREAMS and xin[0].is_cuda and len(xin) > 1 and not Fn._sync_bn_on()
                 and not torch.cuda.is_current_stream_capturing()):      # captured steps keep the levels on one lane: 16.8 vs 16.4 ms (profiles/r04_a_graph_ab.txt)
             return self._towers_streams(list(xin))

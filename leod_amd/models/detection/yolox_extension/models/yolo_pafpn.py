@@ -6,7 +6,7 @@ import torch as th
 import torch.nn as nn
 
 from leod_amd import functions as Fn
-from ...yolox.models.network_blocks import BaseConv, CSPLayer
+from ...yolox.models.network_blocks import BaseConv, CSPLayer, DWConv
 
 
 def upsample2_nhwc(x: th.Tensor) -> th.Tensor:
@@ -21,20 +21,19 @@ class YOLOPAFPN(nn.Module):
                  compile_cfg: Optional[Dict] = None):
         super().__init__()
         assert len(in_stages) == len(in_channels) == 3
-        if depthwise:
-            raise NotImplementedError('depthwise convs are disabled in every shipped config')
+        Conv = DWConv if depthwise else BaseConv          # bottom-up convs and the Bottleneck 3x3s (yolo_pafpn.py:37)
         self.in_features = tuple(in_stages)
         self.in_channels = tuple(in_channels)
         n = round(3 * depth)
         c0, c1, c2 = in_channels
         self.lateral_conv0 = BaseConv(c2, c1, 1, 1, act=act)
-        self.C3_p4 = CSPLayer(2 * c1, c1, n, False, act=act)
+        self.C3_p4 = CSPLayer(2 * c1, c1, n, False, depthwise=depthwise, act=act)
         self.reduce_conv1 = BaseConv(c1, c0, 1, 1, act=act)
-        self.C3_p3 = CSPLayer(2 * c0, c0, n, False, act=act)
-        self.bu_conv2 = BaseConv(c0, c0, 3, 2, act=act)
-        self.C3_n3 = CSPLayer(2 * c0, c1, n, False, act=act)
-        self.bu_conv1 = BaseConv(c1, c1, 3, 2, act=act)
-        self.C3_n4 = CSPLayer(2 * c1, c2, n, False, act=act)
+        self.C3_p3 = CSPLayer(2 * c0, c0, n, False, depthwise=depthwise, act=act)
+        self.bu_conv2 = Conv(c0, c0, 3, 2, act=act)
+        self.C3_n3 = CSPLayer(2 * c0, c1, n, False, depthwise=depthwise, act=act)
+        self.bu_conv1 = Conv(c1, c1, 3, 2, act=act)
+        self.C3_n4 = CSPLayer(2 * c1, c2, n, False, depthwise=depthwise, act=act)
 
     def forward_nhwc(self, x2, x1, x0):
         fpn_out0 = self.lateral_conv0.forward_nhwc(x0)

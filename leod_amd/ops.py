@@ -148,8 +148,8 @@ def _ln_linear_fwd(x, ln_w, ln_b, W, bias, want_act, want_stats, eps, out_bf16, 
     def tally(out_bytes_per_el, n_out=1):
         # algorithmic bytes: x once, W once, the output(s) at their stored width; 2 M N K flops
         if ev is not None:
-            _PROBE.bytes['linear_gemm'] += 4.0 * M * K + 4.0 * N * K + out_bytes_per_el * n_out * M * N
-            _PROBE.flops['linear_gemm'] += 2.0 * M * N * K
+            _PROBE.amend('linear_gemm', 4.0 * M * K + 4.0 * N * K + out_bytes_per_el * n_out * M * N, 2.0 * M * N * K,
+                         2.0 * M * K + 4.0 * N * K + 2.0 * n_out * M * N)
     if out_bf16 and not want_act:
         # the qkv rows in precision mode bf16 (consumed only by bf16 MFMAs): stored as bf16 where the kernels allow (rc -3: they do not)
         o16 = torch.empty(x.shape[:-1] + (N,), dtype=act16_dtype(), device=x.device)
@@ -663,6 +663,11 @@ class PackCache:
         cls.epoch += 1
 
 
+def _is_depthwise(w, cin: int) -> bool:
+    """a conv weight [C,1,ks,ks] over a C-channel map (C > 1) is a depthwise convolution (nn.Conv2d(C, C, ks, groups=C))"""
+    return w.dim() == 4 and w.shape[1] == 1 and cin > 1 and w.shape[0] == cin
+
+
 def conv_nhwc_fwd(x, w, bias=None, stride=1, colstats=None, bn=None, bn_eps=1e-5):
     """x [B,H,W,Cin] -> y [B,Ho,Wo,N]; pad = (ks-1)//2.  bn = (weight, bias, running_mean, running_var) -> eval BN+SiLU fused.
     colstats: zero-filled float64 [2,N] or [R,2,N] (R a power of two: the epilogue's atomics are spread over the R copies)."""
@@ -680,6 +685,11 @@ def conv_nhwc_fwd(x, w, bias=None, stride=1, colstats=None, bn=None, bn_eps=1e-5
         bw, bb, brm, brv = bn
         for t in bn:
             _ck(t, name='bn')
+    if _is_depthwise(w, Cin):                    # groups == channels: w [C,1,ks,ks] (DWConv.dconv, conv3x3_dws of the ConvLSTM)
+        rep = colstats.shape[0] if colstats is not None and colstats.dim() == 3 else 1
+        check(_l().leod_dwconv_nhwc_fwd(_p(x), _p(w), _p(bias), _p(y), _p(colstats), rep, _p(bw), _p(bb), _p(brm), _p(brv), bn_eps,
+                                         B, H, W, Cin, ks, stride, pad, _stream()), 'dwconv_nhwc_fwd')
+        return y
     wpack, valid = PackCache.get(w, ('fwd', B, H, W, stride, bn is not None, bias is not None), N * Cin * ks * ks) if ks > 1 else (None, 0)
     rep = colstats.shape[0] if colstats is not None and colstats.dim() == 3 else 1
     check(_l().leod_conv_nhwc_fwd(_p(x), _p(w), _p(bias), _p(y), _p(colstats), rep, _p(bw), _p(bb), _p(brm), _p(brv), bn_eps,
@@ -697,6 +707,10 @@ def conv_nhwc_dgrad(dy, w, x_shape, stride=1, out=None, accumulate=False):
         out = _empty(tuple(x_shape), dy)
         accumulate = False
     _ck(out, name='dx')
+    if _is_depthwise(w, Cin):
+        check(_l().leod_dwconv_nhwc_dgrad(_p(dy), _p(w), _p(out), 1 if accumulate else 0, B, H, W, Cin, ks, stride, pad, _stream()),
+              'dwconv_nhwc_dgrad')
+        return out
     wpack, valid = PackCache.get(w, ('dgrad', B, H, W, stride), N * Cin * ks * ks) if ks > 1 else (None, 0)
     check(_l().leod_conv_nhwc_dgrad(_p(dy), _p(w), _p(out), 1 if accumulate else 0, B, H, W, Cin, N, ks, stride, pad,
                                      _p(wpack), valid, _stream()), 'conv_nhwc_dgrad')
@@ -709,6 +723,9 @@ def conv_nhwc_wgrad(dy, x, dw, dbias=None, stride=1):
     B, H, W, Cin = x.shape
     N, ks = dw.shape[0], dw.shape[-1]
     pad = (ks - 1) // 2
+    if _is_depthwise(dw, Cin):
+        check(_l().leod_dwconv_nhwc_wgrad(_p(dy), _p(x), _p(dw), _p(dbias), B, H, W, Cin, ks, stride, pad, _stream()), 'dwconv_nhwc_wgrad')
+        return
     nws = int(_l().leod_conv_nhwc_wgrad_workspace_floats(B, H, W, Cin, N, ks, stride, pad, 0 if dbias is None else 1))
     ws = _empty((nws,), dy) if nws else None
     check(_l().leod_conv_nhwc_wgrad(_p(dy), _p(x), _p(dw), _p(dbias), _p(ws), B, H, W, Cin, N, ks, stride, pad, _stream()),
@@ -1230,6 +1247,11 @@ class KernelProbe:
         e0.record()
         self.events[target].append((self.step, e0, e1, nbytes, flops, nbytes if nbytes16 is None else nbytes16, rows))
         return e1
+
+    def amend(self, target, nbytes, flops, nbytes16=None):
+        """Sets the work of the bracket ``begin`` opened last for ``target`` (the byte count was not known when it was opened)."""
+        st, e0, e1, _, _, _, rows = self.events[target][-1]
+        self.events[target][-1] = (st, e0, e1, nbytes, flops, nbytes if nbytes16 is None else nbytes16, rows)
 
     def close(self):
         global _PROBE, _LIB

@@ -97,12 +97,19 @@ def conv_downsample(x, sd, prefix, stride):
 
 
 def conv_lstm(x, hc, sd, prefix):
-    """DWSConvLSTM2d.forward with dws_conv=False, models/layers/rnn.py:37-70.  NCHW."""
+    """DWSConvLSTM2d.forward, models/layers/rnn.py:37-70.  NCHW.  ``dws_conv`` (rnn.py:20-30,50-55) is read off the state dict: a
+    ``conv3x3_dws.weight`` of C filters is the depthwise conv on h alone (``dws_conv_only_hidden``), of 2C filters the one on cat(x, h)."""
     if hc is None:
         hc = (torch.zeros_like(x), torch.zeros_like(x))
     h0, c0 = hc
     C = x.shape[1]
-    mix = F.conv2d(torch.cat((x, h0), dim=1), sd[prefix + '.conv1x1.weight'], sd[prefix + '.conv1x1.bias'])
+    wd = sd.get(prefix + '.conv3x3_dws.weight')
+    if wd is not None and wd.shape[0] == C:
+        h0 = F.conv2d(h0, wd, sd[prefix + '.conv3x3_dws.bias'], padding=wd.shape[-1] // 2, groups=C)
+    xh = torch.cat((x, h0), dim=1)
+    if wd is not None and wd.shape[0] == 2 * C:
+        xh = F.conv2d(xh, wd, sd[prefix + '.conv3x3_dws.bias'], padding=wd.shape[-1] // 2, groups=2 * C)
+    mix = F.conv2d(xh, sd[prefix + '.conv1x1.weight'], sd[prefix + '.conv1x1.bias'])
     gates, cell_in = torch.tensor_split(mix, [3 * C], dim=1)
     f, i, o = torch.tensor_split(torch.sigmoid(gates), 3, dim=1)
     g = torch.tanh(cell_in)

@@ -16,9 +16,12 @@ def base_conv(x, sd, prefix, stride=1, training=False):
     """BaseConv.forward, network_blocks.py:29-51: conv(no bias, pad (k-1)//2) -> BatchNorm2d -> SiLU.
     In training mode batch statistics are used and the running buffers in ``sd`` are updated in
     place (momentum 0.1, unbiased variance), like nn.BatchNorm2d."""
+    if (prefix + '.dconv.conv.weight') in sd:       # DWConv, network_blocks.py:57-76: depthwise k x k BaseConv -> pointwise 1 x 1 BaseConv
+        return base_conv(base_conv(x, sd, prefix + '.dconv', stride=stride, training=training), sd, prefix + '.pconv', training=training)
     w = sd[prefix + '.conv.weight']
     k = w.shape[-1]
-    y = F.conv2d(x, w, None, stride=stride, padding=(k - 1) // 2)
+    groups = x.shape[1] if (w.shape[1] == 1 and x.shape[1] > 1 and w.shape[0] == x.shape[1]) else 1    # groups=in_channels (:63)
+    y = F.conv2d(x, w, None, stride=stride, padding=(k - 1) // 2, groups=groups)
     rm, rv = sd[prefix + '.bn.running_mean'], sd[prefix + '.bn.running_var']
     if training and (prefix + '.bn.num_batches_tracked') in sd:
         sd[prefix + '.bn.num_batches_tracked'] += 1

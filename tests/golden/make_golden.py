@@ -1085,6 +1085,72 @@ ALL = dict(g01=g01_convlstm, g02=g02_partition, g03=g03_attention, g04=g04_backb
            g12=g12_trainstep, g13=g13_tracker, g14=g14_augment, g15=g15_evaluator, g16=g16_tta_result, g17=g17_loader, g18=g18_autocast,
            g19=g19_head_options, g20=g20_trajectory, g21=g21_label_quality)
 
+def g22_depthwise():
+    """The depthwise options the shipped configs leave off: ``DWSConvLSTM2d(dws_conv=True)`` in both placements
+    (rnn.py:20-30,50-55) over three chained timesteps with gradients, and PAFPN + head built with ``depthwise=True``
+    (network_blocks.py:57-76, yolo_pafpn.py:37, yolo_head.py:52): eval predictions, training losses, every parameter gradient."""
+    out = {}
+    for tag, only_hidden, ks in (('h', True, 3), ('xh', False, 3), ('h5', True, 5)):
+        m = DWSConvLSTM2d(dim=16, dws_conv=True, dws_conv_only_hidden=only_hidden, dws_conv_kernel_size=ks)
+        load_synth(m, 21)
+        out[f'lstm_{tag}_manifest'] = json.dumps(manifest_of(m))
+        xs = [rnd((2, 16, 8, 10), 220 + t).requires_grad_(True) for t in range(3)]
+        h0, c0 = rnd((2, 16, 8, 10), 230, 0.5).requires_grad_(True), rnd((2, 16, 8, 10), 231, 0.5).requires_grad_(True)
+        for start in ('none', 'state'):
+            for p in m.parameters():
+                p.grad = None
+            for t in xs + [h0, c0]:
+                t.grad = None
+            hc, hs = (None if start == 'none' else (h0, c0)), []
+            for x in xs:
+                hc = m(x, hc)
+                hs.append(hc[0])
+            loss = sum((h * rnd(h.shape, 240 + i)).sum() for i, h in enumerate(hs)) + (hc[1] * rnd(hc[1].shape, 250)).sum()
+            loss.backward()
+            pre = f'lstm_{tag}_{start}_'
+            out[pre + 'h'] = torch.stack(hs)
+            out[pre + 'c'] = hc[1]
+            out[pre + 'dx'] = torch.stack([x.grad for x in xs])
+            if start == 'state':
+                out[pre + 'dh0'], out[pre + 'dc0'] = h0.grad, c0.grad
+            for n, p in m.named_parameters():
+                out[pre + 'grad_' + n.replace('.', '_')] = p.grad
+    cfg = make_cfg(**MICRO, depthwise=True)
+    cfg.fpn.depthwise = True
+    det = YoloXDetector(cfg)
+    load_synth(det, 22)
+    out['det_manifest'] = json.dumps(manifest_of(det))
+    feats = {2: rnd((3, 32, 8, 12), 51), 3: rnd((3, 64, 4, 6), 52), 4: rnd((3, 128, 2, 3), 53)}
+    det.eval()
+    with torch.no_grad():
+        out['pred_eval'], _ = det.forward_detect(feats)
+    labs = micro_labels(3, seed=7)
+    targets = ObjectLabels.get_labels_as_batched_tensor([ObjectLabels(l, (60, 90)) for l in labs])
+    det.train()
+    for p in det.parameters():
+        p.grad = None
+    fin = {k: v.clone().requires_grad_(True) for k, v in feats.items()}
+    pred_tr, losses = det.forward_detect(fin, targets=targets.clone())
+    losses['loss'].backward()
+    out.update(pred_train=pred_tr, targets=targets, **{f'loss_{k}': (v.detach() if torch.is_tensor(v) else v) for k, v in losses.items()})
+    for k, v in fin.items():
+        out[f'dfeat{k}'] = v.grad
+    sd = det.state_dict()
+    for k in ['fpn.bu_conv2.dconv.bn.running_mean', 'fpn.bu_conv2.pconv.bn.running_var', 'yolox_head.cls_convs.2.1.dconv.bn.running_var']:
+        out['bn_' + k.replace('.', '_')] = sd[k]
+    gk = sorted(n for n, p in det.named_parameters() if p.grad is not None)
+    out['grad_keys'] = np.array(gk)
+    params = dict(det.named_parameters())
+    for n in gk:
+        if '.dconv.' in n:                        # the depthwise filters and their BatchNorm: full gradients
+            out['grad_' + n.replace('.', '_')] = params[n].grad
+    out['grad_norms'] = np.array([float(params[k].grad.norm()) for k in gk], dtype=np.float64)
+    save('g22_depthwise.npz', **out)
+
+
+ALL['g22'] = g22_depthwise
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)
     for w in which:

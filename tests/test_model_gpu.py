@@ -414,3 +414,144 @@ def test_yolox_blocks_reference_signatures(gpu):
         x1 = ref_conv(b.conv2, ref_conv(b.conv1, ref_conv(csp.conv1, x)))
         close(csp(x), ref_conv(csp.conv3, torch.cat([x1, ref_conv(csp.conv2, x)], 1)), rtol=2e-4, atol=2e-5)
     assert tuple(bott(x).shape) == (2, 32, 8, 12) and tuple(csp(x).shape) == (2, 64, 8, 12)
+
+
+# ---- the depthwise variants (off in every shipped config; north_star names the depthwise stems) --------------------------------
+@pytest.mark.parametrize('B,H,W,C,ks,stride', [(2, 8, 12, 32, 3, 1), (3, 16, 20, 96, 3, 2), (2, 8, 10, 16, 5, 1), (1, 9, 7, 48, 7, 2),
+                                               (32, 32, 40, 96, 3, 1)])
+def test_depthwise_conv_kernels_vs_torch(gpu, B, H, W, C, ks, stride):
+    """leod_dwconv_nhwc_{fwd,dgrad,wgrad} (nn.Conv2d(C, C, ks, stride, groups=C): DWConv.dconv network_blocks.py:61-68, conv3x3_dws
+    rnn.py:26-30) against torch's fp32 grouped convolution: plain + bias, training-BatchNorm statistics, eval BatchNorm + SiLU, input
+    gradient (also accumulating), weight and bias gradient."""
+    import torch.nn.functional as F
+    from leod_amd import ops
+
+    def rnd(shape, seed, s=1.0):
+        return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * s
+
+    pad = (ks - 1) // 2
+    x = rnd((B, C, H, W), 1).requires_grad_(True)
+    w = rnd((C, 1, ks, ks), 2, 0.3).requires_grad_(True)
+    b = rnd((C,), 3, 0.2).requires_grad_(True)
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad, groups=C)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd, bd = w.detach().to(DEV), b.detach().to(DEV)
+    y = ops.conv_nhwc_fwd(xd, wd, bd, stride=stride)
+    close(y, ref.permute(0, 2, 3, 1), rtol=2e-5, atol=2e-6, what='depthwise forward')
+    # training BatchNorm statistics out of the same launch (4 replicas of the accumulators)
+    cs = torch.zeros((4, 2, C), dtype=torch.float64, device=DEV)
+    y2 = ops.conv_nhwc_fwd(xd, wd, None, stride=stride, colstats=cs)
+    r0 = F.conv2d(x, w, None, stride=stride, padding=pad, groups=C).detach().permute(0, 2, 3, 1).reshape(-1, C).double()
+    close(y2.reshape(-1, C), r0.float(), rtol=2e-5, atol=2e-6)
+    close(cs.sum(0)[0], r0.sum(0), rtol=1e-5, atol=1e-4)
+    close(cs.sum(0)[1], (r0 * r0).sum(0), rtol=1e-5, atol=1e-4)
+    # eval BatchNorm folded + SiLU
+    bw, bb, rm, rv = 0.5 + rnd((C,), 4).abs(), rnd((C,), 5, 0.3), rnd((C,), 6, 0.2), 0.5 + rnd((C,), 7).abs()
+    y3 = ops.conv_nhwc_fwd(xd, wd, None, stride=stride, bn=tuple(t.to(DEV) for t in (bw, bb, rm, rv)))
+    r3 = F.silu(F.batch_norm(F.conv2d(x, w, None, stride=stride, padding=pad, groups=C), rm, rv, bw, bb, training=False, eps=1e-5))
+    close(y3, r3.detach().permute(0, 2, 3, 1), rtol=5e-5, atol=5e-6, what='depthwise + eval BatchNorm + SiLU')
+    # gradients
+    dy = rnd(tuple(ref.shape), 8)
+    ref.backward(dy)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dx = ops.conv_nhwc_dgrad(dyd, wd, xd.shape, stride=stride)
+    close(dx, x.grad.permute(0, 2, 3, 1), rtol=5e-5, atol=5e-6, what='depthwise dgrad')
+    dx2 = ops.conv_nhwc_dgrad(dyd, wd, xd.shape, stride=stride, out=dx.clone(), accumulate=True)
+    close(dx2, 2 * x.grad.permute(0, 2, 3, 1), rtol=5e-5, atol=1e-5, what='depthwise dgrad accumulates')
+    dw, db = torch.zeros_like(wd), torch.zeros_like(bd)
+    ops.conv_nhwc_wgrad(dyd, xd, dw, db, stride=stride)
+    close(dw, w.grad, rtol=2e-4, atol=2e-4 * float(w.grad.abs().max()), what='depthwise wgrad')
+    close(db, b.grad, rtol=2e-4, atol=2e-4 * float(b.grad.abs().max()), what='depthwise bias gradient')
+
+
+@pytest.mark.parametrize('tag,only_hidden,ks', [('h', True, 3), ('xh', False, 3), ('h5', True, 5)])
+@pytest.mark.parametrize('seq', [False, True])
+def test_depthwise_convlstm_golden(gpu, golden_dir, tag, only_hidden, ks, seq):
+    """``DWSConvLSTM2d(dws_conv=True)`` on the HIP path against the REFERENCE's own three chained timesteps (g22): outputs and every
+    gradient, through ``forward`` per timestep and through the time-batched ``forward_sequence``."""
+    import json
+    from leod_amd.models.layers.rnn import DWSConvLSTM2d
+    g = np.load(os.path.join(golden_dir, 'g22_depthwise.npz'))
+
+    def rnd(shape, seed, s=1.0):
+        return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * s
+
+    man = json.loads(str(g[f'lstm_{tag}_manifest']))
+    for start in ('none', 'state'):
+        m = DWSConvLSTM2d(dim=16, dws_conv=True, dws_conv_only_hidden=only_hidden, dws_conv_kernel_size=ks)
+        assert {k: list(v.shape) for k, v in m.state_dict().items()} == man
+        m.load_state_dict(synth_state_dict(man, 21))
+        m.to(DEV)
+        xs = [rnd((2, 16, 8, 10), 220 + t).to(DEV).requires_grad_(True) for t in range(3)]
+        h0, c0 = rnd((2, 16, 8, 10), 230, 0.5).to(DEV).requires_grad_(True), rnd((2, 16, 8, 10), 231, 0.5).to(DEV).requires_grad_(True)
+        hc = None if start == 'none' else (h0, c0)
+        if seq:
+            xcat = torch.cat(xs, 0)                       # [T*B, C, H, W]
+            hall, hc = m.forward_sequence(xcat, 3, hc)
+            hs = list(hall.reshape(3, 2, 16, 8, 10))
+        else:
+            hs = []
+            for x in xs:
+                hc = m(x, hc)
+                hs.append(hc[0])
+        loss = sum((h * rnd(tuple(h.shape), 240 + i).to(DEV)).sum() for i, h in enumerate(hs)) + (hc[1] * rnd(tuple(hc[1].shape), 250).to(DEV)).sum()
+        loss.backward()
+        pre = f'lstm_{tag}_{start}_'
+        close(torch.stack(hs), g[pre + 'h'], rtol=2e-5, what='h')
+        close(hc[1], g[pre + 'c'], rtol=2e-5, what='c')
+        close(torch.stack([x.grad for x in xs]), g[pre + 'dx'], rtol=2e-4, atol=2e-6, what='dx')
+        if start == 'state':
+            close(h0.grad, g[pre + 'dh0'], rtol=2e-4, atol=2e-6, what='dh0')
+            close(c0.grad, g[pre + 'dc0'], rtol=2e-4, atol=2e-6, what='dc0')
+        for n, p in m.named_parameters():
+            ref = g[pre + 'grad_' + n.replace('.', '_')]
+            close(p.grad, ref, rtol=5e-4, atol=5e-4 * float(np.abs(ref).max()), what='grad ' + n)
+
+
+def test_depthwise_head_golden(gpu, golden_dir, manifest):
+    """PAFPN + head built with ``depthwise=True`` (DWConv in the Bottlenecks, the bottom-up convs and the head towers: yolo_pafpn.py:37,
+    yolo_head.py:52, network_blocks.py:57-76) against the REFERENCE (g22): state-dict manifest, eval predictions, training losses, BatchNorm
+    buffers, the gradients of the input features, of every depthwise filter / BatchNorm and the norm of every parameter gradient."""
+    import json
+    from leod_amd.config import full_config, dynamically_modify_train_config
+    from leod_amd.models.detection.yolox_extension.models.detector import YoloXDetector
+    g = np.load(os.path.join(golden_dir, 'g22_depthwise.npz'))
+    over = dict(model=dict(backbone=dict(embed_dim=16, stage=dict(attention=dict(dim_head=8))), fpn=dict(depth=0.33, depthwise=True),
+                           head=dict(depthwise=True)))
+    cfg = dynamically_modify_train_config(full_config('gen1', 'small', overrides=over))
+    cfg.model.backbone.in_res_hw = (64, 96)
+    cfg.model.backbone.stage.attention.partition_size = (2, 3)
+    det = YoloXDetector(cfg.model)
+    man = json.loads(str(g['det_manifest']))
+    assert {k: list(v.shape) for k, v in det.state_dict().items()} == man
+    det.load_state_dict(synth_state_dict(man, 22), strict=True)
+    det.to(DEV).eval()
+
+    def rnd(shape, seed):
+        return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+    feats_cpu = {2: rnd((3, 32, 8, 12), 51), 3: rnd((3, 64, 4, 6), 52), 4: rnd((3, 128, 2, 3), 53)}
+    with torch.no_grad():
+        pred, losses = det.forward_detect({k: v.to(DEV) for k, v in feats_cpu.items()})
+    assert losses is None
+    close(pred, g['pred_eval'], what='eval predictions')
+    targets = op.batched_yolox_labels(micro_labels(3, seed=7))
+    det.train()
+    fg = {k: v.to(DEV).requires_grad_(True) for k, v in feats_cpu.items()}
+    pred, losses = det.forward_detect(fg, targets=targets.to(DEV))
+    close(pred, g['pred_train'], what='train predictions')
+    for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg'):
+        close(losses[k], g['loss_' + k], rtol=5e-5, what=k)
+    dsd = det.state_dict()
+    for k in ['fpn.bu_conv2.dconv.bn.running_mean', 'fpn.bu_conv2.pconv.bn.running_var', 'yolox_head.cls_convs.2.1.dconv.bn.running_var']:
+        close(dsd[k], g['bn_' + k.replace('.', '_')], rtol=5e-5, atol=1e-6)
+    losses['loss'].backward()
+    for k in fg:
+        close(fg[k].grad, g[f'dfeat{k}'], rtol=2e-3, atol=2e-5, what=f'grad feature {k}')
+    params = dict(det.named_parameters())
+    gk = [str(k) for k in g['grad_keys']]
+    for k in gk:
+        if '.dconv.' in k:
+            close(params[k].grad, g['grad_' + k.replace('.', '_')], rtol=2e-3, atol=2e-5, what='grad ' + k)
+    mine = np.array([float(params[k].grad.norm()) for k in gk])
+    np.testing.assert_allclose(mine, g['grad_norms'], rtol=2e-3, atol=1e-6)

@@ -423,3 +423,69 @@ def test_tta_result_oracle_matches_reference(golden_dir):
             for name in lab.dtype.names:
                 assert np.array_equal(lab[name], g[f'c{case}_lab{k}_{name}']), (case, k, name)
                 assert np.array_equal(prd[name], g[f'c{case}_pred{k}_{name}']), (case, k, name)
+
+
+def _g22_lstm_inputs():
+    xs = [rnd((2, 16, 8, 10), 220 + t) for t in range(3)]
+    return xs, rnd((2, 16, 8, 10), 230, 0.5), rnd((2, 16, 8, 10), 231, 0.5)
+
+
+@pytest.mark.parametrize('tag', ['h', 'xh', 'h5'])
+def test_g22_depthwise_convlstm(golden_dir, tag):
+    """``DWSConvLSTM2d(dws_conv=True)`` (rnn.py:20-30,50-55; off in the shipped configs): the oracle's depthwise placement against three
+    chained timesteps of the reference, outputs and every gradient."""
+    g = G(golden_dir, 'g22_depthwise.npz')
+    man = json.loads(str(g[f'lstm_{tag}_manifest']))
+    for start in ('none', 'state'):
+        sd = {'lstm.' + k: v.clone().requires_grad_(True) for k, v in synth_state_dict(man, 21).items()}
+        xs, h0, c0 = _g22_lstm_inputs()
+        for t in xs + [h0, c0]:
+            t.requires_grad_(True)
+        hc, hs = (None if start == 'none' else (h0, c0)), []
+        for x in xs:
+            hc = ob.conv_lstm(x, hc, sd, 'lstm')
+            hs.append(hc[0])
+        loss = sum((h * rnd(h.shape, 240 + i)).sum() for i, h in enumerate(hs)) + (hc[1] * rnd(hc[1].shape, 250)).sum()
+        loss.backward()
+        pre = f'lstm_{tag}_{start}_'
+        close(torch.stack(hs), g[pre + 'h'])
+        close(hc[1], g[pre + 'c'])
+        close(torch.stack([x.grad for x in xs]), g[pre + 'dx'], rtol=5e-5, atol=1e-6)
+        if start == 'state':
+            close(h0.grad, g[pre + 'dh0'], rtol=5e-5, atol=1e-6)
+            close(c0.grad, g[pre + 'dc0'], rtol=5e-5, atol=1e-6)
+        for k in man:
+            close(sd['lstm.' + k].grad, g[pre + 'grad_' + k.replace('.', '_')], rtol=1e-4, atol=2e-5)
+
+
+def test_g22_depthwise_head(golden_dir):
+    """PAFPN + head with ``depthwise=True`` (DWConv, network_blocks.py:57-76; yolo_pafpn.py:37, yolo_head.py:52): the oracle reads the
+    variant off the state-dict keys (``*.dconv.* / *.pconv.*``)."""
+    g = G(golden_dir, 'g22_depthwise.npz')
+    man = json.loads(str(g['det_manifest']))
+    sd = synth_state_dict(man, 22)
+    feats = {2: rnd((3, 32, 8, 12), 51), 3: rnd((3, 64, 4, 6), 52), 4: rnd((3, 128, 2, 3), 53)}
+    pred, losses = oh.detect_forward(feats, sd, MICRO, training=False)
+    assert losses is None
+    close(pred, g['pred_eval'], rtol=5e-5, atol=5e-6)
+    targets = op.batched_yolox_labels(micro_labels(3, seed=7))
+    close(targets, g['targets'])
+    sd = {k: v.clone() for k, v in sd.items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and 'running_' not in k:
+            v.requires_grad_(True)
+    fin = {k: v.clone().requires_grad_(True) for k, v in feats.items()}
+    pred, losses = oh.detect_forward(fin, sd, MICRO, labels=targets.clone(), training=True)
+    close(pred, g['pred_train'], rtol=5e-5, atol=5e-6)
+    for k in ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg'):
+        close(torch.as_tensor(losses[k]).float(), g['loss_' + k], rtol=2e-5)
+    for k in ['fpn.bu_conv2.dconv.bn.running_mean', 'fpn.bu_conv2.pconv.bn.running_var', 'yolox_head.cls_convs.2.1.dconv.bn.running_var']:
+        close(sd[k], g['bn_' + k.replace('.', '_')], rtol=2e-5, atol=1e-6)
+    losses['loss'].backward()
+    for k in fin:
+        close(fin[k].grad, g[f'dfeat{k}'], rtol=2e-4, atol=1e-6)
+    gk = [str(k) for k in g['grad_keys']]
+    np.testing.assert_allclose(np.array([float(sd[k].grad.norm()) for k in gk]), g['grad_norms'], rtol=2e-4, atol=1e-7)
+    for k in gk:
+        if '.dconv.' in k:
+            close(sd[k].grad, g['grad_' + k.replace('.', '_')], rtol=2e-4, atol=2e-6)
