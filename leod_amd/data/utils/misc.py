@@ -124,20 +124,24 @@ class RawFrames:
 
 
 class H5Frames:
-    """Same interface over the reference's HDF5 files (dataset 'data'); needs h5py (+ hdf5plugin for blosc chunks)."""
+    """Same interface over the reference's HDF5 files (dataset 'data', sequence_base.py:184-193): through h5py (+ hdf5plugin for the blosc
+    chunks) where it is installed, else through the package's own reader of that container (``h5lite``: classic HDF5 layout, blosc-zstd)."""
 
     def __init__(self, fn: str):
+        self.fn = fn
         try:
             import h5py
-        except ImportError as e:                                  # pragma: no cover
-            raise ImportError(f'{fn}: reading HDF5 event representations needs h5py; convert the recording once with '
-                              'tools/h5_to_npy.py and the raw twin is used instead') from e
-        try:                                                      # pragma: no cover
-            import hdf5plugin  # noqa: F401
         except ImportError:
-            pass
-        self.fn = fn
-        self.h5f = h5py.File(fn, 'r')
+            h5py = None
+        if h5py is not None:
+            try:                                                  # pragma: no cover
+                import hdf5plugin  # noqa: F401
+            except ImportError:
+                pass
+            self.h5f = h5py.File(fn, 'r')
+        else:
+            from . import h5lite
+            self.h5f = h5lite.H5File(fn)
         self.data = self.h5f['data']
 
     @property

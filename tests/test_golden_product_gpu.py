@@ -17,6 +17,8 @@ test_f1_worker_dealing_matches_reference_golden = _tl.test_worker_dealing_matche
 test_f1_pseudo_label_dataset_round_trip = _tl.test_pseudo_label_dataset_round_trip
 test_f1_read_helpers_of_a_recording = _tl.test_read_helpers_of_a_recording
 test_f1_h5_frames_agree_with_raw_frames = _tl.test_h5_frames_agree_with_raw_frames_through_a_stand_in_h5py
+test_f1_h5lite_reads_the_reference_container = _tl.test_h5lite_reads_the_reference_container
+test_f1_h5lite_other_dtypes_missing_chunks_and_refusals = _tl.test_h5lite_other_dtypes_missing_chunks_and_refusals
 # f2: tracker post-filter in C++ against the reference-recorded tracks (g13)
 test_f2_native_tracker_matches_oracle = _th.test_native_tracker_matches_oracle
 test_f2_event_seq_data_track_filter_matches_reference = _th.test_event_seq_data_track_filter_matches_reference

@@ -677,3 +677,69 @@ def test_h5_frames_agree_with_raw_frames_through_a_stand_in_h5py(tmp_path, monke
         misc.FRAME_STORES.clear()
     finally:
         os.rename(raw_fn + '.away', raw_fn)
+
+
+@pytest.mark.parametrize('compression', ['blosc', 'blosc-zlib', 'gzip', 'shuffle-gzip', None, 'contiguous'])
+def test_h5lite_reads_the_reference_container(tmp_path, compression):
+    """``leod_amd.data.utils.h5lite`` -- the package's own reader of the reference's container (classic HDF5 layout, dataset ``data``
+    [N,20,H,W] uint8 chunked frame by frame, blosc-zstd filter 32001: sequence_base.py:184-193, utils/preprocessing.py:4-15) -- on files built
+    by ``tests/h5_writer.py`` from the HDF5 / c-blosc specifications (no libhdf5 here): every read path, a multi-level chunk B-tree, missing
+    chunks, other dtypes and filters; then ``misc.H5Frames`` / ``open_ev_repr`` / a streaming sequence over such a file without a raw twin."""
+    from h5_writer import write_h5, blosc_frame
+    from leod_amd.data.utils import h5lite, misc
+    rng = np.random.RandomState(3)
+    frames = ((rng.rand(150, 20, 6, 8) < 0.08) * rng.randint(1, 10, (150, 20, 6, 8))).astype(np.uint8)
+    fn = str(tmp_path / 'event_representations.h5')
+    if compression == 'contiguous':
+        write_h5(fn, frames, chunks=None)
+    else:
+        write_h5(fn, frames, chunks=(1, 20, 6, 8), compression=compression, istore_k=4)      # 150 chunks, 8 per node: a three-level index
+    with h5lite.H5File(fn) as f:
+        assert f.keys() == ['data'] and 'data' in f
+        d = f['data']
+        assert d.shape == frames.shape and d.dtype == np.uint8 and len(d) == 150
+        assert (d.chunks == (1, 20, 6, 8)) == (compression != 'contiguous')
+        assert np.array_equal(d[:], frames) and np.array_equal(d[17:43], frames[17:43]) and np.array_equal(d[149], frames[149])
+        assert d[5:5].shape == (0, 20, 6, 8)
+        out = np.empty((9, 20, 6, 8), np.uint8)
+        d.read_direct(out, np.s_[100:109])
+        assert np.array_equal(out, frames[100:109])
+    # the frame-store interface of the loaders on top of it (h5py is absent: H5Frames takes h5lite)
+    st = misc.H5Frames(fn)
+    assert st.shape == frames.shape and np.array_equal(st.read(3, 11), frames[3:11])
+    buf = np.empty((4, 20, 6, 8), np.uint8)
+    assert st.read(60, 64, buf) is buf and np.array_equal(buf, frames[60:64])
+    st.close()
+    assert misc.read_frame_header(fn) == (150, (20, 6, 8))
+
+
+def test_h5lite_other_dtypes_missing_chunks_and_refusals(tmp_path):
+    from h5_writer import write_h5, blosc_frame
+    from leod_amd.data.utils import h5lite
+    rng = np.random.RandomState(4)
+    b = rng.randn(33, 4, 5).astype(np.float32)
+    fn = write_h5(str(tmp_path / 'f.h5'), b, chunks=(4, 4, 5), compression='blosc', missing=(2,))
+    with h5lite.H5File(fn) as f:
+        want = b.copy()
+        want[8:12] = 0                                             # an unallocated chunk reads as the fill value
+        assert f['data'].dtype == np.float32 and np.array_equal(f['data'][:], want) and np.array_equal(f['data'][7:13], want[7:13])
+    i16 = rng.randint(-3000, 3000, (10, 7)).astype(np.int16)
+    with h5lite.H5File(write_h5(str(tmp_path / 'i.h5'), i16, chunks=(3, 7), compression='shuffle-gzip')) as f:
+        assert f['data'].dtype == np.int16 and np.array_equal(f['data'][:], i16)
+    # blosc frames: split streams with byte shuffle (typesize 4), stored blocks, several blocks
+    raw = b.tobytes() * 20
+    for kw in (dict(split=True, blocksize=4096), dict(split=False, blocksize=1000), dict(codec='zlib')):
+        assert h5lite.blosc_decompress(blosc_frame(raw, 4, kw.pop('codec', 'zstd'), True, **kw)) == raw
+    noise = rng.bytes(5000)
+    assert h5lite.blosc_decompress(blosc_frame(noise, 1)) == noise                 # incompressible: stored streams
+    with pytest.raises(KeyError):
+        h5lite.H5File(fn)['nope']
+    bad = tmp_path / 'bad.h5'
+    bad.write_bytes(b'not an hdf5 file' * 64)
+    with pytest.raises(IOError):
+        h5lite.H5File(str(bad))
+    v2 = bytearray(open(fn, 'rb').read())
+    v2[8] = 2                                                      # superblock version 2 (libver='latest'): refused by name
+    (tmp_path / 'v2.h5').write_bytes(bytes(v2))
+    with pytest.raises(NotImplementedError, match='superblock version 2'):
+        h5lite.H5File(str(tmp_path / 'v2.h5'))

@@ -306,8 +306,15 @@ def test_pseudo_labeler_predict_step_full_size_vs_oracle(gpu, manifest, mode):
             tot['ref'] += len(ref); tot['got'] += len(o); tot['frames'] += 1
             if mode == 'f32':
                 assert len(o) == len(ref) and bool((o[:, 0] == 0).all()), (b, f, len(o), len(ref))
-                np.testing.assert_allclose(o[:, 1:5].numpy(), rb, rtol=3e-4, atol=3e-4)
-                np.testing.assert_allclose(o[:, 5:8].numpy(), rs, rtol=3e-4, atol=1e-6)
+                # rows come in score order and synthetic weights tie scores to ~1e-7: pair every oracle row with its nearest unused row
+                ob_, os_ = o[:, 1:5].numpy(), o[:, 5:8].numpy()
+                free = np.ones(len(o), bool)
+                for i in range(len(ref)):
+                    d = np.abs(ob_ - rb[i]).max(1) + 1e3 * (os_[:, 0] != rc[i]) + 1e6 * ~free
+                    j = int(np.argmin(d))
+                    free[j] = False
+                    np.testing.assert_allclose(ob_[j], rb[i], rtol=3e-4, atol=3e-4, err_msg=f'stream {b} frame {f} box {i}')
+                    np.testing.assert_allclose(os_[j], rs[i], rtol=3e-4, atol=1e-6, err_msg=f'stream {b} frame {f} scores {i}')
                 continue
             assert abs(len(o) - len(ref)) <= max(1, int(0.1 * len(ref))), f'stream {b} frame {f}: {len(o)} labels, oracle {len(ref)}'
             ob_, os_ = o[:, 1:5].numpy(), o[:, 5:8].numpy()
