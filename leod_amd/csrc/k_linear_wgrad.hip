@@ -2,6 +2,7 @@
 // C-ABI declared in include/leod_hip.h.
 #include "linear_common.hpp"
 #include "wgrad_bf16.hpp"
+#include "wgrad_dma.hpp"
 
 // Workspace of the weight-gradient kernels for launches on `stream` (wgrad_bf16.hpp: partial tiles, leod_workspace_bytes() bytes, 16-byte
 // aligned, caller-owned and alive until replaced; ws == NULL withdraws it).
@@ -37,7 +38,11 @@ LEOD_API int leod_linear_wgrad(const float* dy, long lddy, const float* x, long 
     if (dy_bf16 & 6) {                              // bit 1: x holds bf16 rows, bit 2: fp16 rows (precision mode 16f) -- the wide kernel only
         if (stats || x2) return LEOD_ERR_ARG;
         xl.fmt = (dy_bf16 & 4) ? 3 : 2;
-        if (!use_wgrad_wide(xl, lddy, M, N, K, df)) return LEOD_ERR_UNSUPPORTED;
+        if (!use_wgrad_wide(xl, lddy, M, N, K, df) && !(wgrad_dma_ok(xl, lddy, M, N, K, df))) return LEOD_ERR_UNSUPPORTED;
+    }
+    if (wgrad_dma_ok(xl, lddy, M, N, K, df)) {
+        const int rc = launch_wgrad_dma(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, df);
+        if (rc != LEOD_ERR_UNSUPPORTED) return rc;
     }
     if (use_wgrad_wide(xl, lddy, M, N, K, df)) return launch_wgrad_wide(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, df);
     if (use_wgradw(M)) return launch_wgradw(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, df);
@@ -66,6 +71,10 @@ LEOD_API int leod_linear_wgrad_gelu16(const float* dy, long lddy, const void* u1
     if (!dy || !u16 || !dW) return LEOD_ERR_ARG;
     FamilyMarker fm(stream);
     XRows xl{reinterpret_cast<const float*>(u16), (long)K, nullptr, nullptr, nullptr, nullptr, 0, 0, 1};
+    if (wgrad_dma_ok(xl, lddy, M, N, K, 0)) {
+        const int rc = launch_wgrad_dma(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, 0);
+        if (rc != LEOD_ERR_UNSUPPORTED) return rc;
+    }
     if (use_wgrad_wide(xl, lddy, M, N, K, 0)) return launch_wgrad_wide(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, 0);
     if (use_wgradw(M)) return launch_wgradw(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);
     if (N % 48 == 0 && K % 48 == 0) return launch_wgrad16<3, 3>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream);

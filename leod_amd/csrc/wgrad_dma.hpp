@@ -1,0 +1,268 @@
+// Weight-gradient GEMM for the SHORT row ranges (stages 3-4 of the backbone and their ConvLSTMs: 13 k - 54 k rows, N and K multiples of
+// 96 in 192 .. 1536):  dW[n][k] += sum_m dY(m,n) * X(m,k), dbias[n] += sum_m dY(m,n)   (round 6).
+//
+// What bound wgrad_wide_bf16_kernel there (profiles/r06_a_bench_line_default.json, roofline.by_rows: 87-90 us per launch at 13 k AND at 54 k
+// rows = 160 TFLOP/s, 0.5-1.0 TB/s): a workgroup has ONE 32-row chunk of loads in flight (register staging: a second register set spills),
+// so a launch is `chunks per workgroup` dependent memory round trips of ~2 us with 18 MFMAs each in between; and the ablation of
+// profiles/r06_c_ablation_headroom.txt shows that these launches are NOT hidden on the side lane (removing them takes 0.8 ms off the step).
+// Here the operands are plain bf16 rows -- the 16-bit gradient rows as they are, anything else (fp32 gradient rows, LayerNorm inputs,
+// fp16 pre-activations through GELU, fp16 attention outputs, [x | h] of the ConvLSTM) rounded ONCE by wgrad_prep16_kernel, which at
+// these sizes costs 3-35 us -- and stream HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no conversion VALU,
+// no ds_write pass) into a ring of NS slots of RC rows: NS - 1 chunks of loads in flight per workgroup, counted vmcnt waits, ONE raw
+// s_barrier per chunk.  The LDS image of a slot is the [16 row][16 column] block layout of wgrad_bf16.hpp without padding: a DMA
+// instruction (64 lanes x 16 bytes) fills two consecutive blocks, the MFMA operand fragments are the same pairs of ds_read_b64_tr_b16.
+// Accumulators, LayerNorm scale / shift on the finished tile, per-workgroup partial tiles and wgrad_wide_reduce_kernel<6, 6, 2, 2> are
+// those of the 96 x 96 configuration of wgrad_bf16.hpp (same lane -> element map), so the results are bit-identical to it up to the
+// summation order over row chunks.
+#pragma once
+
+struct Prep16 {                 // one operand of wgrad_prep16_kernel
+    const void* src; long ld;   // source rows
+    const float* src2; long ld2; int C1;       // mode 4: columns >= C1 come from src2 (fp32)
+    const float* stats;         // mode 1: (mean, rstd) per row
+    unsigned short* dst;        // bf16 [M][C]
+    int C, mode;                // mode 0 fp32, 1 LayerNorm xhat of fp32 rows, 2 gelu(fp16), 3 fp16, 4 fp32 [x | x2], -1: nothing to do
+};
+
+// 8 columns per thread (one 16-byte store); grid (ceil(M * maxC8 / 256), 2): y picks the operand
+__global__ __launch_bounds__(256) void wgrad_prep16_kernel(Prep16 pa, Prep16 pb, int M) {
+    const Prep16& p = blockIdx.y ? pb : pa;
+    if (p.mode < 0) return;
+    const int C8 = p.C >> 3;
+    const long it = (long)blockIdx.x * 256 + threadIdx.x;
+    if (it >= (long)M * C8) return;
+    const long m = it / C8;
+    const int c = (int)(it - m * C8) << 3;
+    f4 lo, hi;
+    if (p.mode == 2 || p.mode == 3) {
+        const u4_ raw = *reinterpret_cast<const u4_*>(reinterpret_cast<const unsigned short*>(p.src) + m * p.ld + c);
+        auto up = [](unsigned w) -> f2_ { const h2_ h = __builtin_bit_cast(h2_, w); return f2_{(float)h.x, (float)h.y}; };
+        f2_ v0 = up(raw.x), v1 = up(raw.y), v2 = up(raw.z), v3 = up(raw.w);
+        if (p.mode == 2) { v0 = gelu_erf2(v0); v1 = gelu_erf2(v1); v2 = gelu_erf2(v2); v3 = gelu_erf2(v3); }
+        lo = f4{v0.x, v0.y, v1.x, v1.y}; hi = f4{v2.x, v2.y, v3.x, v3.y};
+    } else {
+        const float* s = (p.mode == 4 && c >= p.C1) ? p.src2 + m * p.ld2 + (c - p.C1) : reinterpret_cast<const float*>(p.src) + m * p.ld + c;
+        lo = ld4(s); hi = ld4(s + 4);
+        if (p.mode == 1) {
+            const f2_ st = *reinterpret_cast<const f2_*>(p.stats + 2 * m);
+            lo = (lo - st.x) * st.y; hi = (hi - st.x) * st.y;
+        }
+    }
+    const u4_ o = {pack_bf16x2(f2_{lo.x, lo.y}), pack_bf16x2(f2_{lo.z, lo.w}), pack_bf16x2(f2_{hi.x, hi.y}), pack_bf16x2(f2_{hi.z, hi.w})};
+    *reinterpret_cast<u4_*>(p.dst + m * p.C + c) = o;
+}
+
+// one LDS-DMA instruction: 64 lanes x 16 bytes from per-lane global addresses to LDS bytes [dst, dst + 1024) in lane order.  M0 (the
+// destination base) is written in the same statement that reads it (cdna_hip_programming.md 5.7); hipcc does not count this load: the
+// loop below waits with its own vmcnt.
+__device__ __forceinline__ void wgd_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wgd_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// 96 x 96 outputs per workgroup: 4 waves as 2 x 2, 3 x 3 MFMA tiles (16x16x32 bf16) each.  RC rows per chunk, NS ring slots.
+// LN: X holds xhat; the tile is scaled / shifted by ln_w / ln_b in the epilogue (needs the column sums of dY in every wave).
+template <int T, int RC, int NS, bool LN>
+__global__ __launch_bounds__(256, T == 6 ? 2 : 1) void wgrad_dma_kernel(const unsigned short* __restrict__ A, long lda, const unsigned short* __restrict__ B, long ldb,
+                                                           const float* __restrict__ ln_w, const float* __restrict__ ln_b, float* dbias_flag,
+                                                           f4* __restrict__ part, int chunks, int cpw, int gx, int ny, int nz, int N, int K, int dbg) {
+    constexpr int WA = T / 2, WB = T / 2, NWN = 2, NWK = 2, RB = RC / 16, KS = RC / 32;
+    constexpr int BLK = 256;                                   // bf16 elements of a [16][16] block (512 bytes, no padding)
+    constexpr int SA = RB * T * BLK, SLOT = 2 * SA;            // elements: dY part, then X part
+    constexpr int NI = SLOT * 2 / 1024, IPW = NI / 4;          // DMA instructions per chunk / per wave
+    static_assert(NI % 4 == 0 && RC % 32 == 0, "whole instructions per wave");
+    constexpr int NSL = WA * WB + WA;
+    extern __shared__ __attribute__((aligned(1024))) unsigned short wd_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    const int wn = wave % NWN, wk = wave / NWN;
+    // 1-D grid, XCD-aware (workgroup id -> XCD id % 8 in dispatch order): the ny * nz tiles that stream the SAME row range sit on one XCD
+    // next to each other in time, so that one of them misses in that XCD's L2 and the others hit
+    const int ntl = ny * nz;
+    int tl, bx;
+    if ((gx & 7) == 0) { const int xcd = blockIdx.x & 7, sj = blockIdx.x >> 3; tl = sj % ntl; bx = (sj / ntl) * 8 + xcd; }
+    else { bx = blockIdx.x % gx; tl = blockIdx.x / gx; }
+    const int by = tl / nz, bz = tl - by * nz;
+    const int n0 = by * T * 16, k0 = bz * T * 16;
+    const int c0 = bx * cpw, c1 = min(chunks, c0 + cpw);
+    const int nch = c1 - c0;
+    // ---- DMA sources: instruction t = wave + 4 j fills blocks 2t, 2t + 1 of a slot; lane -> (block, row, half) ---------------------------
+    static_assert(IPW % 2 == 0, "the first half of a wave's instructions fills the dY part, the second half the X part");
+    const char* src[IPW];
+    const long stepA = (long)RC * lda * 2, stepB = (long)RC * ldb * 2;
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) {
+        const int t = wave + 4 * j;
+        const int blk = 2 * t + (lane >> 5), r = (lane & 31) >> 1, half = lane & 1;
+        const bool isb = j >= IPW / 2;                         // (blk >= RB * T for every wave: RB * T / 2 instructions per part, 4 waves)
+        const int b = isb ? blk - RB * T : blk;
+        const int rb = b / T, cb = b - rb * T;
+        const long ld = isb ? ldb : lda;
+        const int col = (isb ? k0 : n0) + cb * 16 + half * 8;
+        src[j] = reinterpret_cast<const char*>(isb ? B : A) + (((long)c0 * RC + rb * 16 + r) * ld + col) * 2;
+    }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)wd_smem);
+    auto issue = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) {
+            wgd_dma16(src[j], __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(slot * SLOT * 2 + (wave + 4 * j) * 1024)));
+            src[j] += j >= IPW / 2 ? stepB : stepA;
+        }
+    };
+    // ---- accumulators -----------------------------------------------------------------------------------------------------------
+    const bool bias_out = dbias_flag != nullptr && bz == 0;
+    const bool bias_any = LN || bias_out;
+    f4 acc[WA][WB], bacc[WA];
+#pragma unroll
+    for (int a = 0; a < WA; ++a) {
+        bacc[a] = zero4();
+#pragma unroll
+        for (int b = 0; b < WB; ++b) acc[a][b] = zero4();
+    }
+    const s8v ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    typedef __attribute__((address_space(3))) s4 lds_s4;
+    const int loff = (4 * q + (i >> 2)) * 16 + 4 * (i & 3);
+    auto mfma_chunk = [&](int slot) {
+        const unsigned short* pdy = wd_smem + slot * SLOT + (wn * WA) * BLK + loff;
+        const unsigned short* px = wd_smem + slot * SLOT + SA + (wk * WB) * BLK + loff;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int st = 2 * ks;
+            s8v pa[WA], pb[WB];
+#pragma unroll
+            for (int a = 0; a < WA; ++a) {
+                const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(pdy + (st * T + a) * BLK));
+                const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(pdy + ((st + 1) * T + a) * BLK));
+                pa[a] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int b = 0; b < WB; ++b) {
+                const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(px + (st * T + b) * BLK));
+                const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(px + ((st + 1) * T + b) * BLK));
+                pb[b] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int a = 0; a < WA; ++a)
+#pragma unroll
+                for (int b = 0; b < WB; ++b) acc[a][b] = mfma32_bf16(pa[a], pb[b], acc[a][b]);
+            if (bias_any) {
+#pragma unroll
+                for (int a = 0; a < WA; ++a)
+                    if (LN || a % NWK == wk) bacc[a] = mfma32_bf16(pa[a], ones, bacc[a]);
+            }
+        }
+    };
+    // ---- chunk stream: NS - 1 chunks in flight; iteration c: own DMA of chunk c landed (counted vmcnt) -> barrier (everyone's landed, and
+    // everyone has finished reading slot (c - 1) % NS) -> refill that slot with chunk c + NS - 1 -> MFMAs on slot c % NS -----------------
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < nch) issue(p);
+    for (int c = 0; c < nch; ++c) {
+        const int ahead = min(nch - 1 - c, NS - 2);            // chunks issued after chunk c that may stay in flight
+        if (ahead >= 2) wgd_wait_vm<2 * IPW>(); else if (ahead == 1) wgd_wait_vm<IPW>(); else wgd_wait_vm<0>();
+        if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
+        if (c + NS - 1 < nch && !(dbg & 2)) issue((c + NS - 1) % NS);
+        if (!(dbg & 1)) mfma_chunk(c % NS);
+    }
+    // ---- epilogue: as wgrad_wide_bf16_kernel (acc[a][b][r] = element (n = 4q + r, k = i) of tile (a, b)) ---------------------------------
+    if constexpr (LN) {
+#pragma unroll
+        for (int b = 0; b < WB; ++b) {
+            const int k = k0 + 16 * (wk * WB + b) + i;
+            const float g = k < K ? ln_w[k] : 0.f, sh = k < K ? ln_b[k] : 0.f;
+#pragma unroll
+            for (int a = 0; a < WA; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[a][b][r] = fmaf(g, acc[a][b][r], sh * bacc[a][r]);
+        }
+    }
+    constexpr int NW = NWN * NWK;
+    const long tile = (long)by * nz + bz, ntiles = ntl;
+    f4* dst = part + (((long)bx * ntiles + tile) * NW + (wk * NWN + wn)) * (NSL * 64) + lane;
+#pragma unroll
+    for (int a = 0; a < WA; ++a) {
+#pragma unroll
+        for (int b = 0; b < WB; ++b) dst[(a * WB + b) * 64] = acc[a][b];
+        if (bias_out && a % NWK == wk) dst[(WA * WB + a) * 64] = bacc[a];
+    }
+}
+
+constexpr int kWgdRC = 64, kWgdNS = 3;
+
+constexpr size_t kWgdOperandBytes = (size_t)176 << 20;       // bf16 copies of both operands of the largest covered launch (54 k x (768 + 192))
+static inline bool wgrad_dma_ok(const XRows& xl, long lddy, int M, int N, int K, int dyfmt) {
+    if (leod_precision() != 1 || M < 8192 || M > 60000 || (M % kWgdRC) || (N % 96) || (K % 96) || N < 96 || K < 96) return false;
+    const int xm = xl.x_mode();
+    if ((lddy & 7) || (xl.ld & 7)) return false;
+    if (xl.x2 && (xm != 0 || (xl.K1 & 7) || (xl.ld2 & 7))) return false;
+    const size_t need = (size_t)M * ((dyfmt ? 0 : N) + (xm == 3 ? 0 : K)) * 2;
+    if (need > kWgdOperandBytes) return false;
+    // the square projections (fp32 dY AND 16-bit attention rows to convert, 4-16 output tiles) stay on the register-staged kernel: the
+    // preparation pass is as long as the contraction there (30 vs 36 us at 53 760 x 192 x 192, 27 vs 28 us at 13 440 x 384 x 384)
+    if (!dyfmt && xm != 3 && (long)N * K < 200000) return false;
+    return true;
+}
+
+template <int T>
+static inline int launch_wgrad_dma_t(const void* dy, long lddy, const XRows& xl, float* dW, long ldw, float* dbias,
+                                     int M, int N, int K, hipStream_t s, int dyfmt) {
+    constexpr int RC = kWgdRC, NS = kWgdNS, TW = T * 16;
+    constexpr int LDS = NS * 2 * (RC / 16) * T * 256 * 2;
+    const int xm = xl.x_mode();
+    const int tiles = (N / TW) * (K / TW), chunks = M / RC;
+    constexpr int dbg = 0;          // ablation bits (1: no MFMAs, 2: no refills, 4: no barrier), compile-time, for experiments
+    constexpr int gx8 = 1;          // row ranges a multiple of 8: the tiles of one row range share an XCD (53 760 x 576 x 192: 62 -> 44 us)
+    const int target = T == 6 ? 512 : 256;                     // resident workgroups
+    int gx = max(1, min(chunks / NS, target / tiles));
+    if (gx8 && gx >= 8) gx &= ~7;
+    const int cpw = cdiv(chunks, gx);
+    if (!(gx8 && gx >= 8)) gx = cdiv(chunks, cpw);
+    constexpr int NW = 4, NSL = (T / 2) * (T / 2) + T / 2;
+    const long O = (long)tiles * NW * NSL * 64;                // f4 per partial
+    const size_t part_bytes = (size_t)gx * O * sizeof(f4);
+    const size_t a_bytes = dyfmt ? 0 : (size_t)M * N * 2, b_bytes = xm == 3 ? 0 : (size_t)M * K * 2;
+    char* ws = reinterpret_cast<char*>(wgrad_wide_scratch(s, part_bytes + a_bytes + b_bytes + 4096));
+    if (!ws) return LEOD_ERR_UNSUPPORTED;
+    f4* part = reinterpret_cast<f4*>(ws);
+    unsigned short* a16 = reinterpret_cast<unsigned short*>(ws + ((part_bytes + 1023) & ~(size_t)1023));
+    unsigned short* b16 = a16 + a_bytes / 2;
+    Prep16 pa{}, pb{};
+    pa.mode = pb.mode = -1;
+    if (!dyfmt) { pa = Prep16{dy, lddy, nullptr, 0, 0, nullptr, a16, N, 0}; }
+    if (xm != 3) pb = Prep16{xl.x, xl.ld, xl.x2, xl.ld2, xl.x2 ? xl.K1 : K, xl.stats, b16, K, xm == 1 ? 1 : xm == 2 ? 2 : xm == 4 ? 3 : (xl.x2 ? 4 : 0)};
+    if (pa.mode >= 0 || pb.mode >= 0) {
+        const int c8 = max(pa.mode >= 0 ? N : 0, pb.mode >= 0 ? K : 0) / 8;
+        hipLaunchKernelGGL(wgrad_prep16_kernel, dim3(cdiv((long)M * c8, 256), 2), dim3(256), 0, s, pa, pb, M);
+    }
+    const unsigned short* A = dyfmt ? reinterpret_cast<const unsigned short*>(dy) : a16;
+    const long lda = dyfmt ? lddy : N;
+    const unsigned short* B = xm == 3 ? reinterpret_cast<const unsigned short*>(xl.x) : b16;
+    const long ldb = xm == 3 ? xl.ld : K;
+    dim3 grid(gx * tiles);
+    const int ny = N / TW, nz = K / TW;
+    if (xm == 1) {
+        auto kern = wgrad_dma_kernel<T, RC, NS, true>;
+        static bool attr_set = false;
+        if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, A, lda, B, ldb, xl.ln_w, xl.ln_b, dbias, part, chunks, cpw, gx, ny, nz, N, K, dbg);
+    } else {
+        auto kern = wgrad_dma_kernel<T, RC, NS, false>;
+        static bool attr_set = false;
+        if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
+        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, A, lda, B, ldb, nullptr, nullptr, dbias, part, chunks, cpw, gx, ny, nz, N, K, dbg);
+    }
+    const int ob = (int)cdiv(O, 256);
+    int groups = max(1, min(gx, 512 / ob));
+    const int per = cdiv(gx, groups);
+    groups = cdiv(gx, per);
+    hipLaunchKernelGGL((wgrad_wide_reduce_kernel<T, T, 2, 2>), dim3(ob, groups), dim3(256), 0, s, part, gx, N / TW, K / TW, per, dW, ldw, dbias, N, K);
+    return leod_launch_status();
+}
+static inline int launch_wgrad_dma(const void* dy, long lddy, const XRows& xl, float* dW, long ldw, float* dbias,
+                                   int M, int N, int K, hipStream_t s, int dyfmt) {
+    // (192 x 192 tiles -- T = 12, one workgroup per CU, half the LDS-DMA bytes per output -- measured slower on 9 of the 10 shapes of
+    // tools/kbench_wgrad_small.py: 593 vs 549 us summed; the chunk stream is not bound by DMA bytes, profiles/r06_d_wgrad_dma_kbench.txt)
+    return launch_wgrad_dma_t<6>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s, dyfmt);
+}

@@ -311,6 +311,11 @@ def test_mlp_hidden_stored_once_as_fp16(bf16_ops, M, C):
     # 192 x 96 / 96 x 192 workgroup tiles (round 4: six tiles per wave along the 16-bit operand), stage-4 and ragged shapes
     (13440, 1536, 384, True, 'ln'), (8705, 1152, 384, True, 'ln'), (8707, 384, 96, True, 'ln'), (13440, 384, 1536, False, 'gelu16'),
     (8705, 1536, 768, True, 'concat'), (8201, 384, 384, False, 'rows16'),
+    # the LDS-DMA kernel of the short row ranges (wgrad_dma.hpp, round 6: rows % 64 == 0, <= 60 k, N and K multiples of 96): every operand
+    # preparation mode, bf16 operands used in place, one chunk per workgroup up to long chunk streams
+    (13440, 384, 384, False, 'rows16'), (13440, 1536, 768, True, 'concat'), (53760, 576, 192, True, 'ln'), (53760, 192, 192, False, 'rows'),
+    (8256, 288, 96, True, 'ln'), (53760, 192, 768, False, 'gelu16'), (13440, 768, 384, False, 'concat'), (8192, 96, 96, True, 'rows'),
+    (13440, 1152, 384, True, 'rows16'),
 ])
 def test_wgrad_wide_bf16(bf16_ops, M, N, K, dy16, xmode):
     import torch.nn.functional as F
