@@ -10,8 +10,8 @@ cd /tmp && export TMPDIR=/tmp
 for DT in 16f bf16 f32; do
   for C in FETCH_SIZE WRITE_SIZE; do
     D=$OUT/${DT}_$C; rm -rf $D
-    LEOD_FAMILY_MARKERS=1 LEOD_WGRAD_STREAM=0 LEOD_HEAD_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --pmc $C -d $D -o p -- python $ROOT/bench.py --steps 1 --warmup 1 --dtype $DT \
-        --no-cpu-baseline --no-second-dtype --no-roofline --no-plan > $D.log 2>&1
+    LEOD_FAMILY_MARKERS=1 timeout 600 rocprofv3 --kernel-trace --pmc $C -d $D -o p -- python $ROOT/bench.py --steps 1 --warmup 1 --dtype $DT \
+        --no-cpu-baseline --no-second-dtype --no-roofline --no-plan --single-stream > $D.log 2>&1
   done
   python $ROOT/tools/roofline_traffic.py $OUT/${DT}_FETCH_SIZE $OUT/${DT}_WRITE_SIZE $OUT/$DT.json $OUT/$DT.csv
   rm -rf $OUT/${DT}_FETCH_SIZE $OUT/${DT}_WRITE_SIZE
