@@ -207,8 +207,11 @@ struct ALStemNCHW {             // stem conv over the raw NCHW event tensor (uin
         s.p = x + (long)b * Cin * H * W; s.iy0 = oy * stride - pad; s.ix0 = ox * stride - pad; return s;
     }
     __device__ __forceinline__ float one(const St& s, int k) const {
-        // the RVT stem is always 7x7 (patch 4 -> kernel 2*4-1): constant divisors compile to multiply-shift
-        const int c = k / 49; const int r = k - c * 49; const int kh = r / 7, kw = r - kh * 7;
+        // the shipped RVT stem is 7x7 (patch 4 -> kernel 2*4-1): constant divisors compile to multiply-shift; non-overlapping patches
+        // (downsample.overlap = False: ks = stride) take the run-time decode
+        int c, kh, kw;
+        if (ks == 7) { c = k / 49; const int r = k - c * 49; kh = r / 7; kw = r - kh * 7; }
+        else { const int kk = ks * ks; c = k / kk; const int r = k - c * kk; kh = r / ks; kw = r - kh * ks; }
         const int iy = s.iy0 + kh, ix = s.ix0 + kw;
         if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) return 0.f;
         return (float)s.p[((long)c * H + iy) * W + ix];
@@ -1394,7 +1397,9 @@ struct XStemNCHW {
     const T* x; int Cin, H, W, Ho, Wo, ks, stride, pad;
     __device__ __forceinline__ float get(int m, int k) const {
         const int ox = m % Wo, t = m / Wo; const int oy = t % Ho, b = t / Ho;
-        const int c = k / 49; const int r = k - c * 49; const int kh = r / 7, kw = r - kh * 7;     // 7x7 stem only
+        int c, kh, kw;                                                                              // 7x7: constant divisors (see ALStemNCHW)
+        if (ks == 7) { c = k / 49; const int r = k - c * 49; kh = r / 7; kw = r - kh * 7; }
+        else { const int kk = ks * ks; c = k / kk; const int r = k - c * kk; kh = r / ks; kw = r - kh * ks; }
         const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
         if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) return 0.f;
         return (float)x[(((long)b * Cin + c) * H + iy) * W + ix];

@@ -256,7 +256,7 @@ LEOD_API int leod_stem_conv_fwd(const void* x, int x_is_u8, const float* w, floa
                                 int Hp, int Wp, int N, int ks, int stride, int pad, hipStream_t stream) {
     LeodFwdScope fwd_scope;                                   // forward contraction: fp16 operands in precision mode 16f
     if (!x || !w || !y || ((Cin * ks * ks) & 3)) return LEOD_ERR_ARG;
-    if (ks != 7) return LEOD_ERR_UNSUPPORTED;       // stem loaders hard-code the 7x7 tap decode
+    if (ks < 1 || ks > 15) return LEOD_ERR_UNSUPPORTED;
     const int Ho = (Hp + 2 * pad - ks) / stride + 1, Wo = (Wp + 2 * pad - ks) / stride + 1;
     const int M = B * Ho * Wo, K = Cin * ks * ks;
     EpStore ep = conv_epilogue(y, N, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0.f);
@@ -264,9 +264,9 @@ LEOD_API int leod_stem_conv_fwd(const void* x, int x_is_u8, const float* w, floa
     int rc = LEOD_OK;
     const bool lds = use_gemm_lds(M, cdiv(N, 16 * nt));
     static const int stem_patch = 1;
-    if (stem_patch && x_is_u8 && leod_precision() == 1 && stem_fwd_bf16_supported(x, Cin, H, W, N, stride, pad))
+    if (stem_patch && ks == 7 && x_is_u8 && leod_precision() == 1 && stem_fwd_bf16_supported(x, Cin, H, W, N, stride, pad))
         return stem_fwd_bf16_launch(x, w, y, B, Cin, H, W, Ho, Wo, N, stream);         // k_stem.hip: bf16 patch, weights resident in LDS
-    if (stem_patch && x_is_u8 && stride == 4 && pad == 3 && N <= 64 && !(N & 15) && !(W & 3) && Cin * 19 * 72 <= 60000 &&
+    if (stem_patch && ks == 7 && x_is_u8 && stride == 4 && pad == 3 && N <= 64 && !(N & 15) && !(W & 3) && Cin * 19 * 72 <= 60000 &&
         ((uintptr_t)x & 3) == 0 && ((long)Cin * H * W) % 4 == 0) {
         // LDS-resident uint8 patch kernel (dedicated to the RVT stem geometry); anything else takes the generic path
         switch (N / 16) {
@@ -529,13 +529,13 @@ static int launch_stem_u8_wgrad(const float* dy, const uint8_t* x, float* dW, in
 LEOD_API int leod_stem_conv_wgrad(const float* dy, const void* x, int x_is_u8, float* dw, int B, int Cin, int H, int W,
                                   int Hp, int Wp, int N, int ks, int stride, int pad, hipStream_t stream) {
     if (!dy || !x || !dw) return LEOD_ERR_ARG;
-    if (ks != 7) return LEOD_ERR_UNSUPPORTED;
+    if (ks < 1 || ks > 15) return LEOD_ERR_UNSUPPORTED;
     const int Ho = (Hp + 2 * pad - ks) / stride + 1, Wo = (Wp + 2 * pad - ks) / stride + 1;
     const int M = B * Ho * Wo, K = Cin * ks * ks;
     static const int stem_patch = 1;
-    if (stem_patch && x_is_u8 && leod_precision() == 1 && stem_wgrad_bf16_supported(x, Cin, H, W, N, stride, pad))
+    if (stem_patch && ks == 7 && x_is_u8 && leod_precision() == 1 && stem_wgrad_bf16_supported(x, Cin, H, W, N, stride, pad))
         return stem_wgrad_bf16_launch(dy, x, dw, B, Cin, H, W, Ho, Wo, N, stream);     // k_stem.hip
-    if (stem_patch && x_is_u8 && stride == 4 && pad == 3 && N <= 64 && !(N & 15) && !(W & 3) && Cin * 19 * 18 <= 27 * 256 &&
+    if (stem_patch && ks == 7 && x_is_u8 && stride == 4 && pad == 3 && N <= 64 && !(N & 15) && !(W & 3) && Cin * 19 * 18 <= 27 * 256 &&
         ((uintptr_t)x & 3) == 0 && ((long)Cin * H * W) % 4 == 0) {
         switch (N / 16) {
             case 1: return launch_stem_u8_wgrad<1>(dy, (const uint8_t*)x, dw, B, Cin, H, W, Ho, Wo, N, stream);

@@ -201,7 +201,7 @@ static inline bool wgrad_dma_ok(const XRows& xl, long lddy, int M, int N, int K,
     if (need > kWgdOperandBytes) return false;
     // the square projections (fp32 dY AND 16-bit attention rows to convert, 4-16 output tiles) stay on the register-staged kernel: the
     // preparation pass is as long as the contraction there (30 vs 36 us at 53 760 x 192 x 192, 27 vs 28 us at 13 440 x 384 x 384)
-    if (!dyfmt && xm != 3 && (long)N * K < 200000) return false;
+    if (!dyfmt && xm != 3 && xm != 2 && (long)N * K < 200000) return false;
     return true;
 }
 

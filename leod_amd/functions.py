@@ -280,7 +280,7 @@ class ConvLNFn(Function):
     def forward(ctx, mod, x, conv_w, ln_w, ln_b, is_stem: bool, stride: int, padded_hw):
         need = any(ctx.needs_input_grad)
         if is_stem:
-            z = ops.stem_conv_fwd(x, conv_w, padded_hw, stride, conv_w.shape[-1] // 2)
+            z = ops.stem_conv_fwd(x, conv_w, padded_hw, stride, mod.conv.padding[0])
         else:
             z = ops.conv_nhwc_fwd(x, conv_w, None, stride=stride)
         y, stats = ops.layernorm_fwd(z, ln_w, ln_b, want_stats=need)
@@ -292,12 +292,16 @@ class ConvLNFn(Function):
     def backward(ctx, dy):
         x, z, stats, conv_w, ln_w = ctx.saved_tensors
         mod = ctx.mod
-        dz = ops.layernorm_bwd(_cont(dy), z, stats, ln_w, None, grad_buf(mod.norm.weight), grad_buf(mod.norm.bias))
+        if mod.norm.weight is not None:
+            dlw, dlb = grad_buf(mod.norm.weight), grad_buf(mod.norm.bias)
+        else:                                                 # norm_affine=False: the kernel's scale / shift gradients go nowhere
+            dlw, dlb = torch.zeros_like(ln_w), torch.zeros_like(ln_w)
+        dz = ops.layernorm_bwd(_cont(dy), z, stats, ln_w, None, dlw, dlb)
         dx = None
         if ctx.is_stem:
             # the stem is the LAST node of the backward pass: on the launch stream its weight gradient (310 us) runs next to the tail of the
             # side stream's queue instead of behind it (the join before the optimiser waited for both in sequence)
-            ops.stem_conv_wgrad(dz, x, grad_buf(mod.conv.weight), ctx.padded_hw, ctx.stride, conv_w.shape[-1] // 2)
+            ops.stem_conv_wgrad(dz, x, grad_buf(mod.conv.weight), ctx.padded_hw, ctx.stride, mod.conv.padding[0])
         else:
             with _wgrad_side(dz, x):
                 ops.conv_nhwc_wgrad(dz, x, grad_buf(mod.conv.weight), None, stride=ctx.stride)

@@ -6,8 +6,9 @@ Differences in *how* things run, not in what they compute:
     kernel (leod_partition_attn_*), so ``window_partition`` & co. below are plain view helpers kept for
     API compatibility and tests;
   * ``PartitionAttentionCl.forward`` is one autograd node (functions.AttnBlockFn) = 5 forward kernels;
-  * only the configuration the reference ships is implemented (SelfAttentionCl, non-gated GELU MLP,
-    LayerScale > 0, drop_path = drop_mlp = 0); anything else raises NotImplementedError loudly.
+  * the attention block implements the configuration the reference ships (SelfAttentionCl, non-gated GELU MLP,
+    LayerScale > 0, drop_path = drop_mlp = 0) and raises NotImplementedError loudly for anything else; the downsample layer
+    takes both of its options (overlap, norm_affine).
 """
 from enum import Enum, auto
 from typing import Tuple
@@ -126,16 +127,19 @@ class DownsampleBase(nn.Module):
 
 
 class ConvDownsampling_Cf2Cl(DownsampleBase):
-    """Overlapping conv (k = 2s-1, pad k//2, no bias) + LayerNorm; NCHW (or raw event tensor) in, NHWC out."""
+    """Conv (no bias) + LayerNorm; NCHW (or raw event tensor) in, NHWC out (maxvit.py:143-182).  ``overlap`` (shipped): k = 2s - 1, pad k // 2;
+    otherwise non-overlapping patches k = s, pad 0.  ``norm_affine=False``: LayerNorm without weight / bias (no such state-dict keys)."""
 
     def __init__(self, dim_in: int, dim_out: int, downsample_factor: int, downsample_cfg):
         super().__init__()
         assert downsample_factor in (2, 4, 8)
-        if not downsample_cfg.get('overlap', True) or not downsample_cfg.get('norm_affine', True):
-            raise NotImplementedError('HIP downsample implements overlap=True, norm_affine=True (shipped config)')
-        k = (downsample_factor - 1) * 2 + 1
-        self.conv = nn.Conv2d(dim_in, dim_out, kernel_size=k, padding=k // 2, stride=downsample_factor, bias=False)
-        self.norm = LayerNorm(num_channels=dim_out, eps=1e-5, affine=True)
+        overlap, affine = downsample_cfg.get('overlap', True), downsample_cfg.get('norm_affine', True)
+        k = (downsample_factor - 1) * 2 + 1 if overlap else downsample_factor
+        self.conv = nn.Conv2d(dim_in, dim_out, kernel_size=k, padding=k // 2 if overlap else 0, stride=downsample_factor, bias=False)
+        self.norm = LayerNorm(num_channels=dim_out, eps=1e-5, affine=affine)
+        if not affine:                       # the kernels take a scale / shift: constants, and their (discarded) gradients, outside the state dict
+            self.register_buffer('_ln_one', torch.ones(dim_out), persistent=False)
+            self.register_buffer('_ln_zero', torch.zeros(dim_out), persistent=False)
         self.stride = downsample_factor
         self.is_stem = downsample_factor == 4
 
@@ -149,8 +153,8 @@ class ConvDownsampling_Cf2Cl(DownsampleBase):
             padded_hw = tuple(padded_hw) if padded_hw is not None else tuple(x.shape[-2:])
         else:
             x = Fn.to_nhwc(x)
-        return Fn.ConvLNFn.apply(self, x, self.conv.weight, self.norm.weight, self.norm.bias, self.is_stem, self.stride,
-                                 padded_hw)
+        ln_w, ln_b = (self.norm.weight, self.norm.bias) if self.norm.weight is not None else (self._ln_one, self._ln_zero)
+        return Fn.ConvLNFn.apply(self, x, self.conv.weight, ln_w, ln_b, self.is_stem, self.stride, padded_hw)
 
     @staticmethod
     def output_is_normed():

@@ -88,12 +88,14 @@ def partition_attention(x, sd, prefix, partition_size, window: bool, dim_head: i
 
 
 def conv_downsample(x, sd, prefix, stride):
-    """ConvDownsampling_Cf2Cl.forward, maxvit.py:160-178: overlapping conv (k=2s-1, pad k//2,
-    no bias) on NCHW -> NHWC -> LayerNorm(eps 1e-5)."""
+    """ConvDownsampling_Cf2Cl.forward, maxvit.py:160-178: conv (no bias; overlapping k=2s-1, pad k//2, or -- ``overlap=False`` -- k=s, pad 0:
+    read off the kernel's parity) on NCHW -> NHWC -> LayerNorm(eps 1e-5; without weight / bias when ``norm_affine=False``)."""
     w = sd[prefix + '.conv.weight']
     k = w.shape[-1]
-    y = F.conv2d(x, w, None, stride=stride, padding=k // 2)
-    return layer_norm(y.permute(0, 2, 3, 1), sd, prefix + '.norm')
+    y = F.conv2d(x, w, None, stride=stride, padding=k // 2 if k % 2 else 0).permute(0, 2, 3, 1)
+    if (prefix + '.norm.weight') not in sd:
+        return F.layer_norm(y, (y.shape[-1],), None, None, 1e-5)
+    return layer_norm(y, sd, prefix + '.norm')
 
 
 def conv_lstm(x, hc, sd, prefix):

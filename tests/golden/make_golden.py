@@ -1151,6 +1151,30 @@ def g22_depthwise():
 ALL['g22'] = g22_depthwise
 
 
+DOWNSAMPLE_CASES = [('f4_patch', 4, 20, 16, False, True), ('f4_noaffine', 4, 20, 16, True, False), ('f2_patch_noaffine', 2, 16, 32, False, False),
+                    ('f2_patch', 2, 16, 32, False, True), ('f4_patch_noaffine', 4, 20, 16, False, False)]
+
+
+def g23_downsample_options():
+    """``ConvDownsampling_Cf2Cl`` with the options the shipped configs leave at their defaults (maxvit.py:160-172): non-overlapping patches
+    (``overlap=False``: kernel = stride, no padding) and a LayerNorm without affine parameters (``norm_affine=False``) -- output and gradients."""
+    out = {}
+    for tag, factor, cin, cout, overlap, affine in DOWNSAMPLE_CASES:
+        m = ref_maxvit.ConvDownsampling_Cf2Cl(cin, cout, factor, DictConfig(dict(type='patch', overlap=overlap, norm_affine=affine)))
+        load_synth(m, 23)
+        out[tag + '_manifest'] = json.dumps(manifest_of(m))
+        x = rnd((2, cin, 16, 24), 230 + factor).requires_grad_(True)
+        y = m(x)
+        (y * rnd(tuple(y.shape), 239)).sum().backward()
+        out[tag + '_y'], out[tag + '_dx'] = y, x.grad
+        for n, p in m.named_parameters():
+            out[tag + '_grad_' + n.replace('.', '_')] = p.grad
+    save('g23_downsample_options.npz', **out)
+
+
+ALL['g23'] = g23_downsample_options
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)
     for w in which:

@@ -555,3 +555,39 @@ def test_depthwise_head_golden(gpu, golden_dir, manifest):
             close(params[k].grad, g['grad_' + k.replace('.', '_')], rtol=2e-3, atol=2e-5, what='grad ' + k)
     mine = np.array([float(params[k].grad.norm()) for k in gk])
     np.testing.assert_allclose(mine, g['grad_norms'], rtol=2e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize('tag,factor,cin,cout,overlap,affine', [('f4_patch', 4, 20, 16, False, True), ('f4_noaffine', 4, 20, 16, True, False),
+                                                                ('f2_patch_noaffine', 2, 16, 32, False, False), ('f2_patch', 2, 16, 32, False, True),
+                                                                ('f4_patch_noaffine', 4, 20, 16, False, False)])
+@pytest.mark.parametrize('mode', ['f32', '16f'])
+def test_downsample_options_golden(gpu, golden_dir, tag, factor, cin, cout, overlap, affine, mode):
+    """``ConvDownsampling_Cf2Cl`` with non-overlapping patches (``overlap=False``) and / or a LayerNorm without affine parameters
+    (``norm_affine=False``; maxvit.py:160-172, defaults in every shipped config) against the REFERENCE (g23): state-dict keys, output, input
+    gradient (stride-2 layers; the stem has no differentiable input) and parameter gradients.  Mode 16f at the 16-bit operand tolerance."""
+    import json
+    from leod_amd import ops
+    from leod_amd.config import create
+    from leod_amd.models.layers.maxvit.maxvit import ConvDownsampling_Cf2Cl
+    g = np.load(os.path.join(golden_dir, 'g23_downsample_options.npz'))
+    man = json.loads(str(g[tag + '_manifest']))
+    prev = ops.set_precision(mode)
+    try:
+        m = ConvDownsampling_Cf2Cl(cin, cout, factor, create(dict(type='patch', overlap=overlap, norm_affine=affine)))
+        assert {k: list(v.shape) for k, v in m.state_dict().items()} == man
+        m.load_state_dict(synth_state_dict(man, 23))
+        m.to(DEV)
+        x = torch.randn((2, cin, 16, 24), generator=torch.Generator().manual_seed(230 + factor)).to(DEV).requires_grad_(factor != 4)
+        y = m(x)
+        r = torch.randn(tuple(y.shape), generator=torch.Generator().manual_seed(239)).to(DEV)
+        (y * r).sum().backward()
+        tol = dict(rtol=2e-5, atol=2e-6) if mode == 'f32' else dict(rtol=3e-2, atol=3e-2)
+        gt = dict(rtol=2e-4, atol=2e-5) if mode == 'f32' else dict(rtol=5e-2, atol=5e-2 * float(np.abs(g[tag + '_dx']).max()))
+        close(y, g[tag + '_y'], what='y', **tol)
+        if factor != 4:
+            close(x.grad, g[tag + '_dx'], what='dx', **gt)
+        for n, p in m.named_parameters():
+            ref = g[tag + '_grad_' + n.replace('.', '_')]
+            close(p.grad, ref, rtol=gt['rtol'], atol=(2e-4 if mode == 'f32' else 5e-2) * float(np.abs(ref).max()), what='grad ' + n)
+    finally:
+        ops.set_precision(prev)

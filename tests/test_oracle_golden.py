@@ -489,3 +489,22 @@ def test_g22_depthwise_head(golden_dir):
     for k in gk:
         if '.dconv.' in k:
             close(sd[k].grad, g['grad_' + k.replace('.', '_')], rtol=2e-4, atol=2e-6)
+
+
+DOWNSAMPLE_CASES = [('f4_patch', 4, 20, 16), ('f4_noaffine', 4, 20, 16), ('f2_patch_noaffine', 2, 16, 32), ('f2_patch', 2, 16, 32),
+                    ('f4_patch_noaffine', 4, 20, 16)]
+
+
+@pytest.mark.parametrize('tag,factor,cin,cout', DOWNSAMPLE_CASES)
+def test_g23_downsample_options(golden_dir, tag, factor, cin, cout):
+    """``ConvDownsampling_Cf2Cl`` with ``overlap=False`` / ``norm_affine=False`` (maxvit.py:160-172): the oracle reads both off the state dict."""
+    g = G(golden_dir, 'g23_downsample_options.npz')
+    man = json.loads(str(g[tag + '_manifest']))
+    sd = {'d.' + k: v.clone().requires_grad_(True) for k, v in synth_state_dict(man, 23).items()}
+    x = rnd((2, cin, 16, 24), 230 + factor).requires_grad_(True)
+    y = ob.conv_downsample(x, sd, 'd', factor)
+    (y * rnd(tuple(y.shape), 239)).sum().backward()
+    close(y, g[tag + '_y'], rtol=2e-5, atol=2e-6)
+    close(x.grad, g[tag + '_dx'], rtol=1e-4, atol=1e-5)
+    for k in man:
+        close(sd['d.' + k].grad, g[tag + '_grad_' + k.replace('.', '_')], rtol=1e-4, atol=2e-5)
