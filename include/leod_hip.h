@@ -312,6 +312,16 @@ int leod_set_weight_shadow_f16(const float* base, void* shadow_f16);
 int leod_weight_shadow_refresh(int force, leod_stream_t stream);
 int leod_weight_shadow_invalidate(void);
 int leod_weight_shadow_pin(int on);
+/* Options of the attention block that no shipped config enables (the shipped block is fused into the GEMM kernels and never comes here).
+ * act: 0 gelu 1 silu / swish 2 relu 3 sigmoid 4 tanh 5 relu6 6 leaky_relu 7 elu 8 hard_sigmoid 9 hard_swish 10 mish 11 selu 12 celu 13 hard_mish
+ * (`mlp_activation`, models/layers/maxvit/maxvit.py:357-365).  gated != 0 (GLU.forward, maxvit.py:80-82): p [M, 2 * inner] = (a | g),
+ * h [M, inner] = a * act(g); gated == 0: p [M, inner], h = act(p).  The backward writes dp (same shape as p) from dh.  inner % 4 == 0. */
+int leod_act_glu_fwd(const float* p, float* h, long M, int inner, int act, int gated, leod_stream_t stream);
+int leod_act_glu_bwd(const float* p, const float* dh, float* dp, long M, int inner, int act, int gated, leod_stream_t stream);
+/* Token masking of the first stage (recurrent_backbone/maxvit_rnn.py:190-192): x[m][:] = token where mask[m] (in place; x [M, C], mask
+ * [M] bytes, token [C]); backward: dtoken[c] += sum of the masked rows of dx, which are then zeroed (in place). */
+int leod_token_mask_fwd(float* x, const unsigned char* mask, const float* token, long M, int C, leod_stream_t stream);
+int leod_token_mask_bwd(float* dx, const unsigned char* mask, float* dtoken, long M, int C, leod_stream_t stream);
 /* out[i] = (i == idx) ? *g : 0 for i < n <= 64 (device scalar g): the gradient of one entry of the six-entry loss vector as a zero-padded vector. */
 int leod_onehot_scale(const float* g, float* out, int n, int idx, leod_stream_t stream);
 /* dst[0..3] = (a,b,c,d) on the device (launch-time scalars for a replayed hipGraph). */

@@ -805,3 +805,102 @@ class PickLossFn(Function):
         out = g.new_zeros(ctx.n)
         out[0] = g
         return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# Composed attention block for the OPTIONS no shipped config enables (gated MLP, other activations, torch-MHA parameter layout, no
+# LayerScale, no biases: models/layers/maxvit/maxvit.py:56-118,185-270,307-325).  The shipped block is ONE autograd node over fused kernels
+# (AttnBlockFn); these variants chain the same C entry points as separate nodes on fp32 rows -- correct in every precision mode, not tuned.
+# Parameter gradients are RETURNED to autograd (the torch-MHA layout routes them through an index_select of the in-projection rows).
+class LNLinearFn(Function):
+    """y = LN(x) W^T + b  (``ln_w`` None: plain rows) on [M, K] fp32 rows."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, W, b):
+        y, _, st = ops.ln_linear_fwd(x, ln_w, ln_b, W, b, want_stats=ln_w is not None)
+        ctx.save_for_backward(x, st, ln_w, ln_b, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, st, ln_w, ln_b, W = ctx.saved_tensors
+        dy = _cont(dy)
+        dW, db = torch.zeros_like(W), torch.zeros(W.shape[0], dtype=W.dtype, device=W.device)
+        if ln_w is not None:
+            ops.linear_wgrad(dy, x, dW, db, stats=st, ln_w=ln_w, ln_b=ln_b)
+            dlw, dlb = torch.zeros_like(ln_w), torch.zeros_like(ln_w)
+            dx = ops.layernorm_bwd(ops.linear_dgrad(dy, W), x, st, ln_w, None, dlw, dlb)
+            return dx, dlw, dlb, dW, db
+        ops.linear_wgrad(dy, x, dW, db)
+        return ops.linear_dgrad(dy, W), None, None, dW, db
+
+
+class AttnCoreFn(Function):
+    """Partition attention core on fp32 qkv rows [B, H, W, 3C] (head h owns columns [3dh, 3d(h+1)) = q | k | v)."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads: int, part, window: bool):
+        o, lse = ops.partition_attn_fwd(qkv, heads, part, window, want_lse=True)
+        ctx.save_for_backward(qkv, lse)
+        ctx.geom = (heads, part, window)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, lse = ctx.saved_tensors
+        heads, part, window = ctx.geom
+        return ops.partition_attn_bwd(qkv, _cont(do), lse, heads, part, window), None, None, None
+
+
+class LinearScaleResFn(Function):
+    """z = res + gamma * (h W^T + b) on fp32 rows (proj / fc2 + LayerScale + residual; gamma = ones: no LayerScale)."""
+
+    @staticmethod
+    def forward(ctx, h, W, b, gamma, res):
+        z, _ = ops.linear_lsres_fwd(h, W, b, gamma, res, want_t=False, a_gelu=False)
+        ctx.save_for_backward(h, W, b, gamma)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        h, W, b, gamma = ctx.saved_tensors
+        dz = _cont(dz)
+        dh = ops.linear_dgrad(dz, W, kscale=gamma)
+        dW, db, dg = torch.zeros_like(W), torch.zeros_like(b), torch.zeros_like(gamma)
+        ops.layerscale_linear_wgrad(dz, h, W, b, gamma, dW, db, dg, h_gelu=False)
+        return dh, dW, db, dg, dz
+
+
+class ActGluFn(Function):
+    """h = a * act(g) with (a | g) = halves of p (GLU.forward, maxvit.py:80-82), or h = act(p)."""
+
+    @staticmethod
+    def forward(ctx, p, act: str, gated: bool):
+        ctx.save_for_backward(p)
+        ctx.opt = (act, gated)
+        return ops.act_glu_fwd(p, act, gated)
+
+    @staticmethod
+    def backward(ctx, dh):
+        (p,) = ctx.saved_tensors
+        return ops.act_glu_bwd(p, _cont(dh), *ctx.opt), None, None
+
+
+class TokenMaskFn(Function):
+    """x[token_mask] = mask_token (maxvit_rnn.py:190-192) on a channels-last map; the masked rows' gradient goes to the token."""
+
+    @staticmethod
+    def forward(ctx, x, mask, token):
+        y = x.clone()
+        ops.token_mask_fwd_(y, mask, token.reshape(-1))
+        ctx.save_for_backward(mask)
+        ctx.tshape = token.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dx = dy.contiguous().clone()
+        dt = torch.zeros(dx.shape[-1], dtype=dx.dtype, device=dx.device)
+        ops.token_mask_bwd_(dx, mask, dt)
+        return dx, None, dt.view(ctx.tshape)

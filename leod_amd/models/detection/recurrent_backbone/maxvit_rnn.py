@@ -32,8 +32,6 @@ class RNNDetectorStage(nn.Module):
                  enable_token_masking: bool, T_max_chrono_init: Optional[int], stage_cfg):
         super().__init__()
         assert isinstance(num_blocks, int) and num_blocks > 0
-        if enable_token_masking:
-            raise NotImplementedError('token masking (enable_masking) is off in every shipped config')
         lstm_cfg = stage_cfg.lstm
         self.downsample_cf2cl = get_downsample_layer_Cf2Cl(dim_in=dim_in, dim_out=stage_dim,
                                                            downsample_factor=spatial_downsample_factor,
@@ -45,21 +43,33 @@ class RNNDetectorStage(nn.Module):
                                   dws_conv_only_hidden=lstm_cfg.dws_conv_only_hidden,
                                   dws_conv_kernel_size=lstm_cfg.dws_conv_kernel_size,
                                   cell_update_dropout=lstm_cfg.get('drop_cell_update', 0))
-        self.mask_token = None
+        # learnable [MASK] token put to masked pixels of the stage's input map (maxvit_rnn.py:174-180; off in every shipped config)
+        self.mask_token = nn.Parameter(th.zeros(1, 1, 1, stage_dim), requires_grad=True) if enable_token_masking else None
+        if self.mask_token is not None:
+            th.nn.init.normal_(self.mask_token, std=.02)
+
+    def _mask_tokens(self, x: th.Tensor, token_mask: Optional[th.Tensor]) -> th.Tensor:
+        """x[token_mask] = mask_token (maxvit_rnn.py:190-192); x [N,H,W,C], token_mask [N,H,W] bool"""
+        if token_mask is None:
+            return x
+        assert self.mask_token is not None, 'No mask token present in this stage'
+        from leod_amd import functions as Fn
+        return Fn.TokenMaskFn.apply(x.contiguous(), token_mask.to(th.bool).contiguous(), self.mask_token)
 
     def forward(self, x: th.Tensor, h_and_c_previous=None, token_mask: Optional[th.Tensor] = None, padded_hw=None):
-        assert token_mask is None, 'token masking is not part of the shipped configs'
         x = self.downsample_cf2cl(x, padded_hw=padded_hw)          # -> N H W C
+        x = self._mask_tokens(x, token_mask)
         for blk in self.att_blocks:
             x = blk(x)
         h_c = self.lstm(nhwC_2_nChw(x), h_and_c_previous)          # zero-copy view, no .contiguous()
         return h_c[0], h_c
 
-    def forward_sequence(self, x: th.Tensor, T: int, h_and_c_previous=None, padded_hw=None):
+    def forward_sequence(self, x: th.Tensor, T: int, h_and_c_previous=None, padded_hw=None, token_mask: Optional[th.Tensor] = None):
         """All T timesteps of a sequence batch at once: x [T*B,...].  Downsampling and the attention blocks are per-frame
         maps, so they run ONCE on the T*B batch (21x larger launches instead of 21x more of them); only the ConvLSTM
         recurrence walks over t (``DWSConvLSTM2d.forward_sequence``).  Same values as T chained ``forward`` calls."""
         x = self.downsample_cf2cl(x, padded_hw=padded_hw)
+        x = self._mask_tokens(x, token_mask)
         for blk in self.att_blocks:
             x = blk(x)
         return self.lstm.forward_sequence(nhwC_2_nChw(x), T, h_and_c_previous)
@@ -124,7 +134,8 @@ class RNNDetector(BaseDetector):
             output[i + 1] = x
         return output, states
 
-    def forward_sequence(self, x_seq: th.Tensor, prev_states=None, select_rows: Optional[th.Tensor] = None, select_stages=(), inject=None):
+    def forward_sequence(self, x_seq: th.Tensor, prev_states=None, select_rows: Optional[th.Tensor] = None, select_stages=(), inject=None,
+                         token_mask: Optional[th.Tensor] = None):
         """x_seq [T,B,C,H,W]: stage-major, time-batched evaluation of a whole sequence (see
         ``RNNDetectorStage.forward_sequence``).  Returns {stage: features of all timesteps [T*B,C,h,w]} and the final
         states -- the per-timestep loop of modules/detection.py:188-226 with the loops interchanged.
@@ -144,7 +155,8 @@ class RNNDetector(BaseDetector):
             if i > 0:
                 # data-parallel training: when the backward pass arrives here, stage i is done -> its gradient bucket is exchanged
                 x = bucket_boundary(i, x)
-            x, state = stage.forward_sequence(x, T, prev_states[i], padded_hw if i == 0 else None)
+            x, state = stage.forward_sequence(x, T, prev_states[i], padded_hw if i == 0 else None,
+                                              token_mask.reshape((T * B,) + tuple(token_mask.shape[2:])) if (token_mask is not None and i == 0) else None)
             states.append(state)
             if inject is not None and (i + 1) in select_stages:
                 # a step recorded as separate backbone / head launch plans (modules/step_plan.py): the stage output is exposed to the head plan

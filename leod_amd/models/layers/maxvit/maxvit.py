@@ -82,17 +82,41 @@ class LayerScale(nn.Module):
         self.gamma = nn.Parameter(init_values * torch.ones(dim))
 
 
+class GLU(nn.Module):
+    """Gated linear unit parameters (maxvit.py:56-82): ``proj`` maps dim_in -> 2 * dim_out, forward = first half * act(second half)."""
+
+    def __init__(self, dim_in: int, dim_out: int, channel_last: bool, act_layer, bias: bool = True):
+        super().__init__()
+        assert channel_last
+        self.proj = nn.Linear(dim_in, dim_out * 2, bias=bias)
+        self.act_layer = act_layer if isinstance(act_layer, nn.Module) else nn.Identity()
+
+
 class MLP(nn.Module):
-    """Linear -> GELU(erf) -> Linear (reference MLP with gated=False, maxvit.py:85-118)."""
+    """Parameters of the block's MLP (maxvit.py:85-118): Linear -> act -> Linear, or GLU -> Linear when ``gated`` (inner width
+    floor(dim * ratio * 2 / 3 / 32) * 32 then).  ``act_layer``: an activation NAME of ``ops.ACTIVATIONS`` (or nn.GELU).  The shipped
+    combination (non-gated, GELU, bias) runs inside the fused block kernels; anything else through ``functions``' composed nodes."""
 
     def __init__(self, dim: int, channel_last: bool, expansion_ratio: int, act_layer=nn.GELU, gated: bool = False,
                  bias: bool = True, drop_prob: float = 0.):
         super().__init__()
-        if gated or not channel_last or not bias or drop_prob > 0 or act_layer is not nn.GELU:
-            raise NotImplementedError('HIP MLP implements the shipped config: channels-last, non-gated, GELU, bias, no dropout')
+        act = 'gelu' if act_layer is nn.GELU else act_layer
+        if not channel_last or drop_prob > 0 or not isinstance(act, str) or act not in ops.ACTIVATIONS:
+            raise NotImplementedError(f'HIP MLP: channels-last, no dropout, activation one of {sorted(ops.ACTIVATIONS)} (got {act_layer!r})')
+        self.act_name, self.gated, self.has_bias = act, bool(gated), bool(bias)
         inner = int(dim * expansion_ratio)
-        self.net = nn.Sequential(nn.Sequential(nn.Linear(dim, inner, bias=True), nn.GELU()), nn.Dropout(p=0.),
-                                 nn.Linear(inner, dim, bias=True))
+        if gated:
+            import math
+            inner = math.floor(inner * 2 / 3 / 32) * 32
+            proj_in = GLU(dim_in=dim, dim_out=inner, channel_last=True, act_layer=None, bias=bias)
+        else:
+            proj_in = nn.Sequential(nn.Linear(dim, inner, bias=bias), nn.GELU() if act == 'gelu' else nn.Identity())
+        self.inner = inner
+        self.net = nn.Sequential(proj_in, nn.Dropout(p=0.), nn.Linear(inner, dim, bias=bias))
+
+    @property
+    def fc1(self) -> nn.Linear:
+        return self.net[0].proj if self.gated else self.net[0][0]
 
 
 class SelfAttentionCl(nn.Module):
@@ -101,8 +125,6 @@ class SelfAttentionCl(nn.Module):
 
     def __init__(self, dim: int, dim_head: int = 32, bias: bool = True):
         super().__init__()
-        if not bias:
-            raise NotImplementedError('attention_bias=False is not implemented')
         self.num_heads = dim // dim_head
         self.dim_head = dim_head
         self.scale = dim_head ** -0.5
@@ -118,6 +140,22 @@ class SelfAttentionCl(nn.Module):
         o, _ = ops.partition_attn_fwd(qkv, self.num_heads, (ph, pw), True)
         out, _, _ = ops.ln_linear_fwd(o, None, None, self.proj.weight, self.proj.bias)
         return out
+
+
+class TorchMHSAWrapperCl(nn.Module):
+    """Parameters in ``nn.MultiheadAttention``'s layout (maxvit.py:307-325: keys ``mha.in_proj_weight`` [3C, C] = (q | k | v) rows,
+    ``mha.out_proj``).  The same attention: the block re-orders the in-projection rows per head into the kernels' (q_h | k_h | v_h)
+    interleaving (``interleave``), gradients flow back through that gather."""
+
+    def __init__(self, dim: int, dim_head: int = 32, bias: bool = True):
+        super().__init__()
+        assert dim % dim_head == 0
+        self.num_heads = dim // dim_head
+        self.dim_head = dim_head
+        self.mha = nn.MultiheadAttention(embed_dim=dim, num_heads=self.num_heads, bias=bias, batch_first=True)
+        d, C = dim_head, dim
+        idx = [part * C + h * d + j for h in range(self.num_heads) for part in range(3) for j in range(d)]
+        self.register_buffer('interleave', torch.tensor(idx, dtype=torch.long), persistent=False)
 
 
 class DownsampleBase(nn.Module):
@@ -177,27 +215,66 @@ class PartitionAttentionCl(nn.Module):
         partition_size = attention_cfg.partition_size
         dim_head = attention_cfg.get('dim_head', 32)
         ls_init_value = attention_cfg.get('ls_init_value', 1e-5)
-        if attention_cfg.use_torch_mha or attention_cfg.mlp_gated or attention_cfg.mlp_activation != 'gelu' \
-                or attention_cfg.get('drop_path', 0.0) > 0 or attention_cfg.get('drop_mlp', 0.0) > 0 \
-                or not ls_init_value > 0 or norm_eps != 1e-5:
-            raise NotImplementedError('HIP PartitionAttentionCl implements the shipped config (SelfAttentionCl, '
-                                      'GELU non-gated MLP, LayerScale>0, no drop path/mlp, eps 1e-5)')
+        if attention_cfg.get('drop_path', 0.0) > 0 or attention_cfg.get('drop_mlp', 0.0) > 0 or norm_eps != 1e-5:
+            raise NotImplementedError('HIP PartitionAttentionCl: no drop path / MLP dropout (0 in every config), LayerNorm eps 1e-5')
+        use_mha, gated, act = bool(attention_cfg.use_torch_mha), bool(attention_cfg.mlp_gated), attention_cfg.mlp_activation
+        attn_bias, mlp_bias = attention_cfg.get('attention_bias', True), attention_cfg.get('mlp_bias', True)
+        # the shipped combination runs as ONE fused autograd node (functions.AttnBlockFn); every other one through the composed nodes
+        self.generic = use_mha or gated or act != 'gelu' or not ls_init_value > 0 or not attn_bias or not mlp_bias
         self.partition_size = (partition_size, partition_size) if isinstance(partition_size, int) else tuple(partition_size)
         assert len(self.partition_size) == 2
         assert isinstance(partition_type, PartitionType)
         self.partition_window = partition_type == PartitionType.WINDOW
         self.norm1 = nn.Identity() if skip_first_norm else LayerNorm(dim, eps=norm_eps)
-        self.self_attn = SelfAttentionCl(dim, dim_head=dim_head, bias=attention_cfg.get('attention_bias', True))
-        self.ls1 = LayerScale(dim=dim, init_values=ls_init_value)
+        self.self_attn = (TorchMHSAWrapperCl if use_mha else SelfAttentionCl)(dim, dim_head=dim_head, bias=attn_bias)
+        self.ls1 = LayerScale(dim=dim, init_values=ls_init_value) if ls_init_value > 0 else nn.Identity()
         self.drop_path1 = nn.Identity()
         self.norm2 = LayerNorm(dim, eps=norm_eps)
-        self.mlp = MLP(dim=dim, channel_last=True, expansion_ratio=attention_cfg.get('mlp_ratio', 4), act_layer=nn.GELU,
-                       gated=False, bias=attention_cfg.get('mlp_bias', True), drop_prob=0.)
-        self.ls2 = LayerScale(dim=dim, init_values=ls_init_value)
+        self.mlp = MLP(dim=dim, channel_last=True, expansion_ratio=attention_cfg.get('mlp_ratio', 4), act_layer=act,
+                       gated=gated, bias=mlp_bias, drop_prob=0.)
+        self.ls2 = LayerScale(dim=dim, init_values=ls_init_value) if ls_init_value > 0 else nn.Identity()
         self.drop_path2 = nn.Identity()
+        self.dim = dim
+
+    def _const(self, name: str, n: int, value: float, like: torch.Tensor) -> torch.Tensor:
+        """constant vectors standing in for parameters an option removes (bias=False, no LayerScale): kept per module and device"""
+        t = self.__dict__.get('_c_' + name)
+        if t is None or t.device != like.device or t.numel() != n:
+            t = torch.full((n,), value, dtype=torch.float32, device=like.device)
+            self.__dict__['_c_' + name] = t
+        return t
+
+    def _forward_generic(self, x):
+        """The block out of composed autograd nodes (functions.LNLinearFn / AttnCoreFn / LinearScaleResFn / ActGluFn) on fp32 rows."""
+        B, H, W, C = x.shape
+        x2 = x.contiguous().view(-1, C)
+        n1 = self.norm1 if isinstance(self.norm1, nn.LayerNorm) else None
+        sa, mlp = self.self_attn, self.mlp
+        if isinstance(sa, TorchMHSAWrapperCl):
+            wq = sa.mha.in_proj_weight.index_select(0, sa.interleave)
+            bq = sa.mha.in_proj_bias.index_select(0, sa.interleave) if sa.mha.in_proj_bias is not None else self._const('b3', 3 * C, 0., x)
+            wp, bp = sa.mha.out_proj.weight, sa.mha.out_proj.bias
+        else:
+            wq, bq, wp, bp = sa.qkv.weight, sa.qkv.bias, sa.proj.weight, sa.proj.bias
+        bq = bq if bq is not None else self._const('b3', 3 * C, 0., x)
+        bp = bp if bp is not None else self._const('b1', C, 0., x)
+        g1 = self.ls1.gamma if isinstance(self.ls1, LayerScale) else self._const('one', C, 1., x)
+        g2 = self.ls2.gamma if isinstance(self.ls2, LayerScale) else self._const('one', C, 1., x)
+        qkv = Fn.LNLinearFn.apply(x2, n1.weight if n1 is not None else None, n1.bias if n1 is not None else None, wq, bq)
+        o = Fn.AttnCoreFn.apply(qkv.view(B, H, W, 3 * C), sa.num_heads, self.partition_size, self.partition_window)
+        y = Fn.LinearScaleResFn.apply(o.reshape(-1, C), wp, bp, g1, x2)
+        fc1, fc2 = mlp.fc1, mlp.net[2]
+        b1 = fc1.bias if fc1.bias is not None else self._const('bh', fc1.weight.shape[0], 0., x)
+        b2 = fc2.bias if fc2.bias is not None else self._const('b1', C, 0., x)
+        p = Fn.LNLinearFn.apply(y, self.norm2.weight, self.norm2.bias, fc1.weight, b1)
+        h = Fn.ActGluFn.apply(p, mlp.act_name, mlp.gated)
+        z = Fn.LinearScaleResFn.apply(h, fc2.weight, b2, g2, y)
+        return z.view(B, H, W, C)
 
     def forward(self, x):
         """x: [B,H,W,C] channels-last."""
+        if self.generic:
+            return self._forward_generic(x)
         n1 = self.norm1 if isinstance(self.norm1, nn.LayerNorm) else None
         sa, mlp = self.self_attn, self.mlp
         return Fn.AttnBlockFn.apply(

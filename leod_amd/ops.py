@@ -1100,6 +1100,49 @@ def multi_ok(ts) -> bool:
                                      (t[0].numel() * t.element_size()) % 16 == 0 for t in ts)
 
 
+ACTIVATIONS = {'gelu': 0, 'silu': 1, 'swish': 1, 'relu': 2, 'sigmoid': 3, 'tanh': 4, 'relu6': 5, 'leaky_relu': 6, 'elu': 7, 'hard_sigmoid': 8,
+               'hardsigmoid': 8, 'hard_swish': 9, 'hardswish': 9, 'mish': 10, 'selu': 11, 'celu': 12, 'hard_mish': 13}
+
+
+def act_glu_fwd(p, act: str, gated: bool):
+    """h = a * act(g) with (a | g) the two halves of p's last dim (gated), or h = act(p): the MLP activation options of the attention block."""
+    _ck(p, name='p')
+    I = p.shape[-1] // 2 if gated else p.shape[-1]
+    M = p.numel() // p.shape[-1]
+    h = _empty(p.shape[:-1] + (I,), p)
+    check(_l().leod_act_glu_fwd(_p(p), _p(h), M, I, ACTIVATIONS[act], 1 if gated else 0, _stream()), 'act_glu_fwd')
+    return h
+
+
+def act_glu_bwd(p, dh, act: str, gated: bool):
+    _ck(p, name='p')
+    _ck(dh, name='dh')
+    I = dh.shape[-1]
+    M = dh.numel() // I
+    dp = _empty(p.shape, p)
+    check(_l().leod_act_glu_bwd(_p(p), _p(dh), _p(dp), M, I, ACTIVATIONS[act], 1 if gated else 0, _stream()), 'act_glu_bwd')
+    return dp
+
+
+def token_mask_fwd_(x, mask, token):
+    """x[mask] = token in place: x [.., C] contiguous rows, mask bool with one entry per row, token [C] (maxvit_rnn.py:190-192)."""
+    _ck(x, name='x')
+    _ck(token, name='token')
+    C = x.shape[-1]
+    if mask.dtype is not torch.bool or not mask.is_contiguous() or mask.device != x.device or mask.numel() * C != x.numel():
+        raise LeodHipError('token_mask: one contiguous bool per row on the device of x')
+    check(_l().leod_token_mask_fwd(_p(x), _p(mask), _p(token), mask.numel(), C, _stream()), 'token_mask_fwd')
+    return x
+
+
+def token_mask_bwd_(dx, mask, dtoken):
+    """dtoken += sum of the masked rows of dx; those rows of dx are zeroed (in place)."""
+    _ck(dx, name='dx')
+    _ck(dtoken, name='dtoken')
+    check(_l().leod_token_mask_bwd(_p(dx), _p(mask), _p(dtoken), mask.numel(), dx.shape[-1], _stream()), 'token_mask_bwd')
+    return dx
+
+
 def rows_masked_zero(tensors, mask):
     """t[b] = 0 where mask[b], for every t in ``tensors`` ([B, ...] each), in one launch (RNNStates.reset)."""
     if mask.dtype is not torch.bool or not mask.is_cuda or not mask.is_contiguous() or not multi_ok(tensors):

@@ -60,30 +60,50 @@ def self_attention(x, sd, prefix, dim_head):
     restore = x.shape[:-1]
     C = x.shape[-1]
     heads = C // dim_head
-    qkv = F.linear(x, sd[prefix + '.qkv.weight'], sd[prefix + '.qkv.bias'])
+    if (prefix + '.mha.in_proj_weight') in sd:
+        # TorchMHSAWrapperCl (maxvit.py:307-325): nn.MultiheadAttention(batch_first) = the same attention with the in-projection rows
+        # ordered (all q | all k | all v), head h owning channels [h d, (h + 1) d) of each
+        qkv = F.linear(x.reshape(Bp, -1, C), sd[prefix + '.mha.in_proj_weight'], sd.get(prefix + '.mha.in_proj_bias'))
+        q, k, v = (t.view(Bp, -1, heads, dim_head).transpose(1, 2) for t in qkv.chunk(3, dim=2))
+        attn = ((q * (dim_head ** -0.5)) @ k.transpose(-2, -1)).softmax(dim=-1)
+        o = (attn @ v).transpose(1, 2).reshape(restore + (-1,))
+        return F.linear(o, sd[prefix + '.mha.out_proj.weight'], sd.get(prefix + '.mha.out_proj.bias'))
+    qkv = F.linear(x, sd[prefix + '.qkv.weight'], sd.get(prefix + '.qkv.bias'))
     q, k, v = qkv.view(Bp, -1, heads, dim_head * 3).transpose(1, 2).chunk(3, dim=3)
     attn = (q @ k.transpose(-2, -1)) * (dim_head ** -0.5)
     attn = attn.softmax(dim=-1)
     o = (attn @ v).transpose(1, 2).reshape(restore + (-1,))
-    return F.linear(o, sd[prefix + '.proj.weight'], sd[prefix + '.proj.bias'])
+    return F.linear(o, sd[prefix + '.proj.weight'], sd.get(prefix + '.proj.bias'))
 
 
-def mlp(x, sd, prefix):
-    """MLP.forward non-gated, maxvit.py:105-118: Linear -> GELU(erf) -> Linear."""
-    h = F.gelu(F.linear(x, sd[prefix + '.net.0.0.weight'], sd[prefix + '.net.0.0.bias']))
-    return F.linear(h, sd[prefix + '.net.2.weight'], sd[prefix + '.net.2.bias'])
+ACTIVATIONS = {'gelu': F.gelu, 'silu': F.silu, 'swish': F.silu, 'relu': F.relu, 'sigmoid': torch.sigmoid, 'tanh': torch.tanh, 'relu6': F.relu6,
+               'leaky_relu': F.leaky_relu, 'elu': F.elu, 'hard_sigmoid': F.hardsigmoid, 'hard_swish': F.hardswish, 'mish': F.mish,
+               'selu': F.selu, 'celu': F.celu, 'hard_mish': lambda x: 0.5 * x * (x + 2).clamp(min=0, max=2)}
+
+
+def mlp(x, sd, prefix, act='gelu'):
+    """MLP.forward, maxvit.py:85-118: Linear -> act -> Linear, or -- gated, read off the state dict -- GLU (:56-82: first half of the
+    projection times act(second half)) -> Linear.  ``act``: the `mlp_activation` name (timm create_act.py:62-79)."""
+    fn = ACTIVATIONS[act]
+    if (prefix + '.net.0.proj.weight') in sd:
+        a, g = torch.tensor_split(F.linear(x, sd[prefix + '.net.0.proj.weight'], sd.get(prefix + '.net.0.proj.bias')), 2, dim=-1)
+        h = a * fn(g)
+    else:
+        h = fn(F.linear(x, sd[prefix + '.net.0.0.weight'], sd.get(prefix + '.net.0.0.bias')))
+    return F.linear(h, sd[prefix + '.net.2.weight'], sd.get(prefix + '.net.2.bias'))
 
 
 def partition_attention(x, sd, prefix, partition_size, window: bool, dim_head: int,
-                        skip_first_norm: bool = False):
-    """PartitionAttentionCl.forward, maxvit.py:252-270.  x: [B,H,W,C] channels-last."""
+                        skip_first_norm: bool = False, act: str = 'gelu'):
+    """PartitionAttentionCl.forward, maxvit.py:252-270.  x: [B,H,W,C] channels-last.  Options read off the state dict: no ``ls*.gamma`` =
+    no LayerScale (ls_init_value 0), ``self_attn.mha.*`` = torch MHA layout, missing biases, gated MLP; ``act`` = `mlp_activation`."""
     hw = x.shape[1:3]
     n1 = x if skip_first_norm else layer_norm(x, sd, prefix + '.norm1')
     part = window_partition(n1, partition_size) if window else grid_partition(n1, partition_size)
     part = self_attention(part, sd, prefix + '.self_attn', dim_head)
     a = window_reverse(part, partition_size, hw) if window else grid_reverse(part, partition_size, hw)
-    x = x + a * sd[prefix + '.ls1.gamma']
-    x = x + mlp(layer_norm(x, sd, prefix + '.norm2'), sd, prefix + '.mlp') * sd[prefix + '.ls2.gamma']
+    x = x + a * sd.get(prefix + '.ls1.gamma', 1.0)
+    x = x + mlp(layer_norm(x, sd, prefix + '.norm2'), sd, prefix + '.mlp', act) * sd.get(prefix + '.ls2.gamma', 1.0)
     return x
 
 
@@ -120,13 +140,15 @@ def conv_lstm(x, hc, sd, prefix):
     return h, c
 
 
-def stage_forward(x, hc, sd, prefix, stride, partition_size, dim_head, num_blocks=1):
-    """RNNDetectorStage.forward, models/detection/recurrent_backbone/maxvit_rnn.py:182-201."""
+def stage_forward(x, hc, sd, prefix, stride, partition_size, dim_head, num_blocks=1, token_mask=None, act='gelu'):
+    """RNNDetectorStage.forward, models/detection/recurrent_backbone/maxvit_rnn.py:182-201 (``token_mask`` [B,H,W] bool: :190-192)."""
     x = conv_downsample(x, sd, prefix + '.downsample_cf2cl', stride)
+    if token_mask is not None:
+        x = torch.where(token_mask[..., None], sd[prefix + '.mask_token'].reshape(1, 1, 1, -1).expand_as(x), x)
     for b in range(num_blocks):
         x = partition_attention(x, sd, f'{prefix}.att_blocks.{b}.att_window', partition_size, True, dim_head,
-                                skip_first_norm=(b == 0))
-        x = partition_attention(x, sd, f'{prefix}.att_blocks.{b}.att_grid', partition_size, False, dim_head)
+                                skip_first_norm=(b == 0), act=act)
+        x = partition_attention(x, sd, f'{prefix}.att_blocks.{b}.att_grid', partition_size, False, dim_head, act=act)
     x = x.permute(0, 3, 1, 2).contiguous()
     h, c = conv_lstm(x, hc, sd, prefix + '.lstm')
     return h, (h, c)
@@ -143,7 +165,7 @@ def backbone_forward(x, prev_states, sd, cfg, prefix='backbone'):
     for s in range(4):
         stride = cfg.get('patch_size', 4) if s == 0 else 2
         x, st = stage_forward(x, prev_states[s], sd, f'{prefix}.stages.{s}', stride,
-                              tuple(cfg['partition_size']), cfg['dim_head'], nb[s])
+                              tuple(cfg['partition_size']), cfg['dim_head'], nb[s], act=cfg.get('mlp_activation', 'gelu'))
         states.append(st)
         out[s + 1] = x
     return out, states

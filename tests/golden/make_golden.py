@@ -1175,6 +1175,68 @@ def g23_downsample_options():
 ALL['g23'] = g23_downsample_options
 
 
+# (tag, window, skip_first_norm, attention-config overrides)
+BLOCK_OPTION_CASES = [
+    ('geglu', True, False, dict(mlp_gated=True, mlp_activation='gelu')),
+    ('swiglu_grid', False, False, dict(mlp_gated=True, mlp_activation='swish')),
+    ('reglu_skipnorm', True, True, dict(mlp_gated=True, mlp_activation='relu')),
+    ('glu_sigmoid_mha', True, False, dict(mlp_gated=True, mlp_activation='sigmoid', use_torch_mha=True)),
+    ('mha_grid', False, False, dict(use_torch_mha=True)),
+    ('relu_plain', True, False, dict(mlp_activation='relu')),
+    ('mish_nols_nobias', False, False, dict(mlp_activation='mish', ls_init_value=0.0, attention_bias=False, mlp_bias=False)),
+    ('hswish_tanhglu', True, False, dict(mlp_activation='hard_swish')),
+    ('tanh_glu_nols', True, False, dict(mlp_gated=True, mlp_activation='tanh', ls_init_value=0.0)),
+    ('elu', False, False, dict(mlp_activation='elu')), ('selu', True, False, dict(mlp_activation='selu')),
+    ('hsig_glu', True, False, dict(mlp_gated=True, mlp_activation='hard_sigmoid')), ('relu6', True, False, dict(mlp_activation='relu6')),
+    ('leaky', True, False, dict(mlp_activation='leaky_relu')), ('celu', True, False, dict(mlp_activation='celu')),
+    ('hmish', True, False, dict(mlp_activation='hard_mish')), ('silu', True, False, dict(mlp_activation='silu')),
+    ('mha_nobias', True, False, dict(use_torch_mha=True, attention_bias=False)),
+]
+
+
+def g24_block_options():
+    """``PartitionAttentionCl`` with the options no shipped config enables (maxvit.py:56-118,185-270,307-325): gated MLP, `mlp_activation`
+    names, torch-MHA parameter layout, no LayerScale, no biases -- output, input gradient and every parameter gradient; and a
+    ``RNNDetectorStage`` with token masking (maxvit_rnn.py:174-192)."""
+    out = {}
+    base = dict(make_cfg(32, 16, 0.33, (256, 320), (8, 10)).backbone.stage.attention)
+    x0 = rnd((1, 16, 20, 32), 241)
+    for tag, window, skip, over in BLOCK_OPTION_CASES:
+        cfg = DictConfig({**base, **over})
+        pt = ref_maxvit.PartitionType.WINDOW if window else ref_maxvit.PartitionType.GRID
+        m = ref_maxvit.PartitionAttentionCl(dim=32, partition_type=pt, attention_cfg=cfg, skip_first_norm=skip)
+        load_synth(m, 24)
+        out[tag + '_manifest'] = json.dumps(manifest_of(m))
+        x = x0.clone().requires_grad_(True)
+        y = m(x)
+        (y * rnd(tuple(y.shape), 242)).sum().backward()
+        out[tag + '_y'], out[tag + '_dx'] = y, x.grad
+        for n, p in m.named_parameters():
+            out[tag + '_grad_' + n.replace('.', '_')] = p.grad
+    # token masking: first stage of a backbone with enable_masking, two timesteps with carried state
+    from models.detection.recurrent_backbone.maxvit_rnn import RNNDetectorStage
+    scfg = make_cfg(16, 8, 0.33, (64, 96), (2, 3)).backbone.stage
+    st = RNNDetectorStage(dim_in=20, stage_dim=16, spatial_downsample_factor=4, num_blocks=1, enable_token_masking=True,
+                          T_max_chrono_init=4, stage_cfg=scfg)
+    load_synth(st, 25)
+    out['mask_manifest'] = json.dumps(manifest_of(st))
+    xs = [rnd((2, 20, 64, 96), 251 + t) for t in range(2)]
+    masks = [torch.rand((2, 16, 24), generator=torch.Generator().manual_seed(255 + t)) < 0.3 for t in range(2)]
+    hc, hs = None, []
+    for x, mk in zip(xs, masks):
+        h, hc = st(x, hc, mk)
+        hs.append(h)
+    (sum((h * rnd(tuple(h.shape), 258 + i)).sum() for i, h in enumerate(hs)) + (hc[1] * rnd(tuple(hc[1].shape), 260)).sum()).backward()
+    out['mask_h'], out['mask_c'] = torch.stack(hs), hc[1]
+    out['mask_masks'] = torch.stack(masks)
+    for n, p in st.named_parameters():
+        out['mask_grad_' + n.replace('.', '_')] = p.grad
+    save('g24_block_options.npz', **out)
+
+
+ALL['g24'] = g24_block_options
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)
     for w in which:

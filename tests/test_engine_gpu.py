@@ -483,3 +483,57 @@ def test_host_feeder_double_buffer(gpu):
     torch.cuda.synchronize()
     for i, (s, x) in enumerate(sums):
         assert torch.equal(x.cpu(), batches[i]) and float(s) == float(batches[i].to(torch.float64).sum())
+
+
+@pytest.mark.parametrize('mode', ['f32', '16f'])
+def test_training_step_with_block_and_depthwise_options_vs_oracle(gpu, mode):
+    """A whole training step of a detector built with the options no shipped config enables -- gated swish MLP (SwiGLU), torch-MHA parameter
+    layout, depthwise ConvLSTM conv, non-overlapping patch downsample without LayerNorm affine, depthwise PAFPN / head -- through
+    ``TrainEngine`` (flat parameter buffer: the composed nodes hand their parameter gradients to autograd, which must add them into the
+    flat gradient views) against ``OracleTrainer``: losses and post-step parameters; fp32 mode tight, mode 16f at the 16-bit class."""
+    from leod_amd import ops
+    from leod_amd.config import full_config, dynamically_modify_train_config
+    from leod_amd.engine import TrainEngine
+    from leod_amd.models.detection.yolox_extension.models.detector import YoloXDetector
+    over = dict(model=dict(backbone=dict(embed_dim=16, stage=dict(attention=dict(dim_head=8, mlp_gated=True, mlp_activation='swish', use_torch_mha=True),
+                                                                    lstm=dict(dws_conv=True, dws_conv_only_hidden=True, dws_conv_kernel_size=3),
+                                                                    downsample=dict(type='patch', overlap=False, norm_affine=False))),
+                           fpn=dict(depthwise=True), head=dict(depthwise=True)))
+    cfg = dynamically_modify_train_config(full_config('gen1', 'small', overrides=over))
+    cfg.model.backbone.in_res_hw = (64, 96)
+    cfg.model.backbone.stage.attention.partition_size = (2, 3)
+    prev = ops.set_precision(mode)
+    try:
+        det = YoloXDetector(cfg.model)
+        man = {k: list(v.shape) for k, v in det.state_dict().items()}
+        assert any('mha.in_proj_weight' in k for k in man) and any('net.0.proj.weight' in k for k in man) and any('conv3x3_dws' in k for k in man) \
+            and any('dconv' in k for k in man) and not any('downsample_cf2cl.norm.weight' in k for k in man)
+        sd = synth_state_dict(man, 31)
+        for k in sd:                                  # (oracle.synth knows no `in_proj_*` keys and draws them N(0, 1): scaled like a Linear layer here,
+            if k.endswith('in_proj_weight'):          # or the attention logits are in the hundreds and the random network is chaotic)
+                sd[k] = sd[k] * (1.2 / sd[k].shape[1] ** 0.5)
+            elif k.endswith('in_proj_bias'):
+                sd[k] = sd[k] * 0.1
+        det.load_state_dict(sd)
+        det.to(DEV)
+        T, B = 3, 2
+        ev = synth_events(T, B, 20, 60, 90, seed=11, as_uint8=True)
+        labs = micro_labels(B, seed=12)
+        labels = [[None] * B for _ in range(T - 1)] + [labs]
+        micro = dict(MICRO, mlp_activation='swish')
+        otr = ot.OracleTrainer({k: v.clone() for k, v in sd.items()}, micro, total_steps=1000)
+        ref_losses, _ = otr.step(ev, labels, torch.ones(B, dtype=torch.bool))
+        eng = TrainEngine(det, total_steps=1000)
+        ptrs = [p.grad.data_ptr() for p in eng.flat.params]
+        losses = eng.step(ev.to(DEV), op.batched_yolox_labels(labs).to(DEV), [[]] * (T - 1) + [list(range(B))],
+                          torch.ones(B, dtype=torch.bool, device=DEV))
+        assert [p.grad.data_ptr() for p in eng.flat.params] == ptrs, 'a parameter gradient left the flat buffer'
+        tol = 1e-4 if mode == 'f32' else 3e-2
+        for k in KEYS:
+            assert abs(float(losses[k]) - float(ref_losses[k])) <= tol * abs(float(ref_losses[k])) + 1e-5, (k, float(losses[k]), float(ref_losses[k]))
+        if mode == 'f32':
+            params = dict(det.named_parameters())
+            worst = max((float((params[k].detach().cpu() - otr.sd[k].detach()).abs().max()), k) for k in otr.param_keys)
+            assert worst[0] < 5e-5, worst
+    finally:
+        ops.set_precision(prev)

@@ -591,3 +591,92 @@ def test_downsample_options_golden(gpu, golden_dir, tag, factor, cin, cout, over
             close(p.grad, ref, rtol=gt['rtol'], atol=(2e-4 if mode == 'f32' else 5e-2) * float(np.abs(ref).max()), what='grad ' + n)
     finally:
         ops.set_precision(prev)
+
+
+BLOCK_OPTION_CASES = [
+    ('geglu', True, False, dict(mlp_gated=True, mlp_activation='gelu')),
+    ('swiglu_grid', False, False, dict(mlp_gated=True, mlp_activation='swish')),
+    ('reglu_skipnorm', True, True, dict(mlp_gated=True, mlp_activation='relu')),
+    ('glu_sigmoid_mha', True, False, dict(mlp_gated=True, mlp_activation='sigmoid', use_torch_mha=True)),
+    ('mha_grid', False, False, dict(use_torch_mha=True)),
+    ('relu_plain', True, False, dict(mlp_activation='relu')),
+    ('mish_nols_nobias', False, False, dict(mlp_activation='mish', ls_init_value=0.0, attention_bias=False, mlp_bias=False)),
+    ('hswish_tanhglu', True, False, dict(mlp_activation='hard_swish')),
+    ('tanh_glu_nols', True, False, dict(mlp_gated=True, mlp_activation='tanh', ls_init_value=0.0)),
+    ('elu', False, False, dict(mlp_activation='elu')), ('selu', True, False, dict(mlp_activation='selu')),
+    ('hsig_glu', True, False, dict(mlp_gated=True, mlp_activation='hard_sigmoid')), ('relu6', True, False, dict(mlp_activation='relu6')),
+    ('leaky', True, False, dict(mlp_activation='leaky_relu')), ('celu', True, False, dict(mlp_activation='celu')),
+    ('hmish', True, False, dict(mlp_activation='hard_mish')), ('silu', True, False, dict(mlp_activation='silu')),
+    ('mha_nobias', True, False, dict(use_torch_mha=True, attention_bias=False)),
+]
+
+
+def _block_cfg(**over):
+    from leod_amd.config import create
+    base = dict(use_torch_mha=False, partition_size=(8, 10), dim_head=16, attention_bias=True, mlp_activation='gelu', mlp_gated=False,
+                mlp_bias=True, mlp_ratio=4, drop_mlp=0, drop_path=0, ls_init_value=1e-5)
+    base.update(over)
+    return create(base)
+
+
+@pytest.mark.parametrize('tag,window,skip,over', BLOCK_OPTION_CASES)
+def test_attention_block_options_golden(gpu, golden_dir, tag, window, skip, over):
+    """``PartitionAttentionCl`` with the options no shipped config enables -- gated MLP (GLU), every `mlp_activation` name but prelu,
+    ``use_torch_mha`` (nn.MultiheadAttention's parameter layout), ``ls_init_value = 0``, ``attention_bias`` / ``mlp_bias`` off
+    (maxvit.py:56-118,185-270,307-325) -- against the REFERENCE (g24): state-dict manifest, output, input gradient, every parameter gradient."""
+    import json
+    from leod_amd.models.layers.maxvit.maxvit import PartitionAttentionCl, PartitionType
+    g = np.load(os.path.join(golden_dir, 'g24_block_options.npz'))
+    man = json.loads(str(g[tag + '_manifest']))
+    m = PartitionAttentionCl(32, PartitionType.WINDOW if window else PartitionType.GRID, _block_cfg(**over), skip_first_norm=skip)
+    assert m.generic and {k: list(v.shape) for k, v in m.state_dict().items()} == man
+    m.load_state_dict(synth_state_dict(man, 24))
+    m.to(DEV)
+    x = torch.randn((1, 16, 20, 32), generator=torch.Generator().manual_seed(241)).to(DEV).requires_grad_(True)
+    y = m(x)
+    r = torch.randn(tuple(y.shape), generator=torch.Generator().manual_seed(242)).to(DEV)
+    (y * r).sum().backward()
+    close(y, g[tag + '_y'], rtol=2e-5, atol=2e-6, what='y')
+    close(x.grad, g[tag + '_dx'], rtol=5e-4, atol=5e-5 * float(np.abs(g[tag + '_dx']).max()), what='dx')      # (fp32 summation order: a few 1e-5 of the largest element)
+    for n, p in m.named_parameters():
+        ref = g[tag + '_grad_' + n.replace('.', '_')]
+        close(p.grad, ref, rtol=5e-4, atol=5e-5 * max(1.0, float(np.abs(ref).max())), what='grad ' + n)
+
+
+def test_token_masking_golden(gpu, golden_dir):
+    """``RNNDetectorStage(enable_token_masking=True)`` (maxvit_rnn.py:174-192: ``x[token_mask] = mask_token`` behind the downsample layer)
+    against the REFERENCE (g24): two timesteps with carried state through ``forward`` and through ``forward_sequence``, every gradient."""
+    import json
+    from leod_amd.config import full_config, dynamically_modify_train_config
+    from leod_amd.models.detection.recurrent_backbone.maxvit_rnn import RNNDetectorStage
+    g = np.load(os.path.join(golden_dir, 'g24_block_options.npz'))
+    man = json.loads(str(g['mask_manifest']))
+    over = dict(model=dict(backbone=dict(embed_dim=16, stage=dict(attention=dict(dim_head=8)))))
+    cfg = dynamically_modify_train_config(full_config('gen1', 'small', overrides=over))
+    cfg.model.backbone.stage.attention.partition_size = (2, 3)
+    masks = torch.from_numpy(g['mask_masks']).to(DEV)
+
+    def rnd(shape, seed):
+        return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+    for seq in (False, True):
+        st = RNNDetectorStage(dim_in=20, stage_dim=16, spatial_downsample_factor=4, num_blocks=1, enable_token_masking=True,
+                              T_max_chrono_init=4, stage_cfg=cfg.model.backbone.stage)
+        assert {k: list(v.shape) for k, v in st.state_dict().items()} == man
+        st.load_state_dict(synth_state_dict(man, 25))
+        st.to(DEV)
+        xs = [rnd((2, 20, 64, 96), 251 + t).to(DEV) for t in range(2)]
+        if seq:
+            hall, hc = st.forward_sequence(torch.cat(xs, 0), 2, None, token_mask=masks.reshape(4, 16, 24))
+            hs = list(hall.reshape(2, 2, 16, 16, 24))
+        else:
+            hc, hs = None, []
+            for x, mk in zip(xs, masks):
+                h, hc = st(x, hc, mk)
+                hs.append(h)
+        (sum((h * rnd(tuple(h.shape), 258 + i).to(DEV)).sum() for i, h in enumerate(hs)) + (hc[1] * rnd(tuple(hc[1].shape), 260).to(DEV)).sum()).backward()
+        close(torch.stack(hs), g['mask_h'], rtol=2e-5, atol=2e-6, what='h')
+        close(hc[1], g['mask_c'], rtol=2e-5, atol=2e-6, what='c')
+        for n, p in st.named_parameters():
+            ref = g['mask_grad_' + n.replace('.', '_')]
+            close(p.grad, ref, rtol=1e-3, atol=1e-4 * max(1.0, float(np.abs(ref).max())), what='grad ' + n)

@@ -508,3 +508,46 @@ def test_g23_downsample_options(golden_dir, tag, factor, cin, cout):
     close(x.grad, g[tag + '_dx'], rtol=1e-4, atol=1e-5)
     for k in man:
         close(sd['d.' + k].grad, g[tag + '_grad_' + k.replace('.', '_')], rtol=1e-4, atol=2e-5)
+
+
+BLOCK_OPTION_CASES = [('geglu', True, False, 'gelu'), ('swiglu_grid', False, False, 'swish'), ('reglu_skipnorm', True, True, 'relu'),
+                      ('glu_sigmoid_mha', True, False, 'sigmoid'), ('mha_grid', False, False, 'gelu'), ('relu_plain', True, False, 'relu'),
+                      ('mish_nols_nobias', False, False, 'mish'), ('hswish_tanhglu', True, False, 'hard_swish'), ('tanh_glu_nols', True, False, 'tanh'),
+                      ('elu', False, False, 'elu'), ('selu', True, False, 'selu'), ('hsig_glu', True, False, 'hard_sigmoid'),
+                      ('relu6', True, False, 'relu6'), ('leaky', True, False, 'leaky_relu'), ('celu', True, False, 'celu'),
+                      ('hmish', True, False, 'hard_mish'), ('silu', True, False, 'silu'), ('mha_nobias', True, False, 'gelu')]
+
+
+@pytest.mark.parametrize('tag,window,skip,act', BLOCK_OPTION_CASES)
+def test_g24_block_options(golden_dir, tag, window, skip, act):
+    """``PartitionAttentionCl`` with the options no shipped config enables (gated MLP, `mlp_activation`, torch-MHA layout, no LayerScale,
+    no biases: maxvit.py:56-118,185-270,307-325): the oracle reads the structure off the state dict, the activation by name."""
+    g = G(golden_dir, 'g24_block_options.npz')
+    man = json.loads(str(g[tag + '_manifest']))
+    sd = {'b.' + k: v.clone().requires_grad_(True) for k, v in synth_state_dict(man, 24).items()}
+    x = rnd((1, 16, 20, 32), 241).requires_grad_(True)
+    y = ob.partition_attention(x, sd, 'b', (8, 10), window, 16, skip_first_norm=skip, act=act)
+    (y * rnd(tuple(y.shape), 242)).sum().backward()
+    close(y, g[tag + '_y'], rtol=2e-5, atol=2e-6)
+    close(x.grad, g[tag + '_dx'], rtol=1e-4, atol=1e-5)
+    for k in man:
+        ref = g[tag + '_grad_' + k.replace('.', '_')]
+        close(sd['b.' + k].grad, ref, rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
+
+
+def test_g24_token_masking(golden_dir):
+    """``RNNDetectorStage`` with ``enable_token_masking`` (maxvit_rnn.py:174-192): two timesteps with carried state, every gradient."""
+    g = G(golden_dir, 'g24_block_options.npz')
+    man = json.loads(str(g['mask_manifest']))
+    sd = {'s.' + k: v.clone().requires_grad_(True) for k, v in synth_state_dict(man, 25).items()}
+    masks = torch.from_numpy(g['mask_masks'])
+    hc, hs = None, []
+    for t in range(2):
+        h, hc = ob.stage_forward(rnd((2, 20, 64, 96), 251 + t), hc, sd, 's', 4, (2, 3), 8, token_mask=masks[t])
+        hs.append(h)
+    (sum((h * rnd(tuple(h.shape), 258 + i)).sum() for i, h in enumerate(hs)) + (hc[1] * rnd(tuple(hc[1].shape), 260)).sum()).backward()
+    close(torch.stack(hs), g['mask_h'], rtol=2e-5, atol=2e-6)
+    close(hc[1], g['mask_c'], rtol=2e-5, atol=2e-6)
+    for k in man:
+        ref = g['mask_grad_' + k.replace('.', '_')]
+        close(sd['s.' + k].grad, ref, rtol=3e-4, atol=3e-5 * max(1.0, float(np.abs(ref).max())))
