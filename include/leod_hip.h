@@ -346,6 +346,11 @@ int leod_rows_index_add(float* dst, const float* src, const long* idx, int nsel,
 /* StackedHistogram.construct (data/utils/representations.py:78-123): int64 events -> uint8 [2*bins,H,W]. */
 int leod_voxelize_u8(const long* x, const long* y, const long* pol, const long* t, long n_events, int* counts_ws,
                      unsigned char* out, int bins, int H, int W, int count_cutoff, int fastmode, leod_stream_t stream);
+/* MixedDensityEventStack.construct (data/utils/representations.py:132-221): int64 events (time sorted) -> int8 [bins,H,W]: polarity sums
+ * (2*pol-1) in the logarithmic time bin floor(max(bins - log(t_norm)/log(1/2), 0)), running sum over the bins in int8 arithmetic, clamp to
+ * +-count_cutoff (count_cutoff < 0 = none, <= 127).  counts_ws: bins*H*W int32 of scratch. */
+int leod_mixed_density_i8(const long* x, const long* y, const long* pol, const long* t, long n_events, int* counts_ws,
+                          signed char* out, int bins, int H, int W, int count_cutoff, leod_stream_t stream);
 
 /* On-device spatial augmentation of uint8 event representations src/dst [T,B,C,H,W] (data/utils/augmentor.py:216-331,
  * 390-401): per batch sample b, params[b] = {hflip, mode (0 none, 1 zoom-in, 2 zoom-out), x0, y0, win_h, win_w, tflip}

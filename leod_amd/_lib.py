@@ -37,7 +37,7 @@ class DevPtr:
 # element kinds a declared C pointer type accepts.  ``float*`` parameters also carry the 16-bit rows of precision mode bf16 (the
 # header documents which, e.g. dy_bf16 / qkv_bf16 flags); ``void*`` takes anything.
 _ACCEPTS = {'float': ('f32', 'bf16', 'f16'), 'double': ('f64',), 'int': ('i32',), 'long': ('i64',),
-            'unsigned char': ('u8', 'bool'), 'void': None, 'char': None}
+            'unsigned char': ('u8', 'bool'), 'signed char': ('i8',), 'void': None, 'char': None}
 
 
 def _pointer_type(elem: str):

@@ -171,6 +171,52 @@ LEOD_API int leod_voxelize_u8(const long* x, const long* y, const long* pol, con
     return leod_launch_status();
 }
 
+// ---- mixed-density event stack (data/utils/representations.py:125-221) --------------------------------
+// counts[bins*H*W] (int32, zeroed) += 2*pol-1 at bin floor(max(bins - log(t_norm)/log(1/2), 0)); then per pixel the running sum over the
+// bins, each stage wrapped to int8 (put_(accumulate) and the assignment of the int64 channel sums both happen in int8), clamped to +-cutoff
+__global__ __launch_bounds__(256) void mixed_density_count_kernel(const long* __restrict__ x, const long* __restrict__ y,
+                                                                  const long* __restrict__ pol, const long* __restrict__ t,
+                                                                  int* __restrict__ counts, long n, int bins, int H, int W) {
+    const long t0 = t[0], t1 = t[n - 1];
+    const float denom = (float)max(t1 - t0, 1L);
+    const float ln_half = (float)-0.6931471805599453;            // math.log(1/2) as the fp32 divisor ATen makes of the python scalar
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float tn = (float)(t[i] - t0) / denom;
+        tn = fminf(fmaxf(tn, 1e-6f), 1.f - 1e-6f);
+        float b = (float)bins - __fdiv_rn(logf(tn), ln_half);
+        b = floorf(fmaxf(b, 0.f));
+        const long idx = x[i] + (long)W * y[i] + (long)H * W * (long)b;
+        atomicAdd(counts + idx, pol[i] ? 1 : -1);
+    }
+}
+__global__ __launch_bounds__(256) void mixed_density_finalize_kernel(const int* __restrict__ counts, signed char* __restrict__ out, long hw,
+                                                                     int bins, int cutoff) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (long)gridDim.x * blockDim.x) {
+        int run = 0;
+        for (int b = 0; b < bins; ++b) {
+            run += counts[(long)b * hw + i];
+            int v = (int)(signed char)(run & 255);
+            if (cutoff >= 0) v = max(-cutoff, min(cutoff, v));
+            out[(long)b * hw + i] = (signed char)v;
+        }
+    }
+}
+
+LEOD_API int leod_mixed_density_i8(const long* x, const long* y, const long* pol, const long* t, long n_events, int* counts_ws,
+                                   signed char* out, int bins, int H, int W, int count_cutoff, hipStream_t stream) {
+    if (!counts_ws || !out || bins < 1 || H < 1 || W < 1 || count_cutoff > 127) return LEOD_ERR_ARG;
+    const long hw = (long)H * W;
+    if (hipMemsetAsync(counts_ws, 0, bins * hw * sizeof(int), stream) != hipSuccess) return LEOD_ERR_LAUNCH;
+    if (n_events > 0) {
+        if (!x || !y || !pol || !t) return LEOD_ERR_ARG;
+        hipLaunchKernelGGL(mixed_density_count_kernel, dim3((int)min((long)2048, (n_events + 255) / 256)), dim3(256), 0, stream, x, y,
+                           pol, t, counts_ws, n_events, bins, H, W);
+    }
+    hipLaunchKernelGGL(mixed_density_finalize_kernel, dim3((int)min((long)2048, (hw + 255) / 256)), dim3(256), 0, stream, counts_ws, out, hw,
+                       bins, count_cutoff);
+    return leod_launch_status();
+}
+
 __global__ void set_scalars4_kernel(float* dst, float a, float b, float c, float d) { dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d; }
 // dst[0..3] = (a,b,c,d): per-step scalars handed to a replayed hipGraph without touching host memory
 LEOD_API int leod_set_scalars4(float* dst, float a, float b, float c, float d, hipStream_t stream) {

@@ -92,7 +92,7 @@ def _stream():
 
 
 _KIND = {torch.float32: 'f32', torch.bfloat16: 'bf16', torch.float16: 'f16', torch.float64: 'f64', torch.int32: 'i32', torch.int64: 'i64',
-         torch.uint8: 'u8', torch.bool: 'bool'}
+         torch.uint8: 'u8', torch.bool: 'bool', torch.int8: 'i8'}
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -1186,6 +1186,20 @@ def voxelize_u8(x, y, pol, t, bins, height, width, count_cutoff=None, fastmode=T
     check(_l().leod_voxelize_u8(_p(x), _p(y), _p(pol), _p(t), x.numel(), _p(ws), _p(out), bins, height, width,
                                  0 if count_cutoff is None else int(count_cutoff), 1 if fastmode else 0, _stream()),
           'voxelize_u8')
+    return out
+
+
+def mixed_density_i8(x, y, pol, t, bins, height, width, count_cutoff=None):
+    """MixedDensityEventStack.construct (data/utils/representations.py:132-221): int64 events sorted in time -> int8 [bins, H, W]."""
+    for a in (x, y, pol, t):
+        _ck(a, torch.int64, 'events')
+    if count_cutoff is not None and not 0 <= int(count_cutoff) <= 127:
+        raise ValueError('count_cutoff must lie in [0, 127]')
+    dev = x.device
+    ws = torch.empty((bins * height * width,), dtype=torch.int32, device=dev)
+    out = torch.empty((bins, height, width), dtype=torch.int8, device=dev)
+    check(_l().leod_mixed_density_i8(_p(x), _p(y), _p(pol), _p(t), x.numel(), _p(ws), _p(out), bins, height, width,
+                                     -1 if count_cutoff is None else int(count_cutoff), _stream()), 'mixed_density_i8')
     return out
 
 

@@ -3,6 +3,7 @@ TEST INFRASTRUCTURE (see oracle/__init__.py).  Citations relative to /root/refer
 """
 from typing import List, Optional, Sequence, Tuple, Union
 
+import math
 import numpy as np
 import torch
 
@@ -198,3 +199,26 @@ def stacked_histogram(x, y, pol, time, bins, height, width, count_cutoff=None, f
         rep = ((counts + 32768) % 65536 - 32768).astype(np.int16)   # int16 wrap
     rep = np.clip(rep, 0, cutoff).astype(np.uint8)
     return rep.reshape(2 * bins, height, width)
+
+
+def mixed_density_stack(x, y, pol, time, bins, height, width, count_cutoff=None):
+    """MixedDensityEventStack.construct (data/utils/representations.py:168-221): events sorted in time -> int8 [bins, H, W].
+    Polarity sums (+-1) in the logarithmic time bin  floor(max(bins - log(t_norm)/log(1/2), 0)),  t_norm clamped to [1e-6, 1-1e-6];
+    put_(accumulate) adds in int8 (wraps), cumsum_channel (representations.py:125-128) assigns the int64 prefix sums over the bins back
+    into int8 (wraps again), then the clamp to +-count_cutoff."""
+    if len(x) == 0:
+        return np.zeros((bins, height, width), dtype=np.int8)
+    t0, t1 = int(time[0]), int(time[-1])
+    t_norm = (np.asarray(time, dtype=np.int64) - t0).astype(np.float32) / np.float32(max(t1 - t0, 1))
+    t_norm = np.clip(t_norm, np.float32(1e-6), np.float32(1 - 1e-6))
+    # fp32 log, fp32 division by the python scalar log(1/2), fp32 subtraction from the integer bin count
+    bin_float = np.float32(bins) - np.log(t_norm, dtype=np.float32) / np.float32(math.log(1 / 2))
+    t_idx = np.floor(np.maximum(bin_float, np.float32(0))).astype(np.int64)
+    idx = np.asarray(x, np.int64) + width * np.asarray(y, np.int64) + height * width * t_idx
+    counts = np.zeros(bins * height * width, dtype=np.int64)
+    np.add.at(counts, idx, 2 * np.asarray(pol, np.int64) - 1)
+    run = np.cumsum(counts.reshape(bins, height, width), axis=0)
+    rep = ((run + 128) % 256 - 128).astype(np.int8)              # int8 wrap of every stage = wrap of the exact prefix sum
+    if count_cutoff is not None:
+        rep = np.clip(rep, -count_cutoff, count_cutoff).astype(np.int8)
+    return rep

@@ -42,7 +42,7 @@ from modules.utils import ssod as ref_ssod  # noqa: E402
 from modules.utils.tta import tta_postprocess as ref_tta_postprocess  # noqa: E402
 from modules.utils.detection import RNNStates, BackboneFeatureSelector  # noqa: E402
 from data.genx_utils.labels import ObjectLabels  # noqa: E402
-from data.utils.representations import StackedHistogram  # noqa: E402
+from data.utils.representations import StackedHistogram, MixedDensityEventStack  # noqa: E402
 from utils.padding import InputPadderFromShape  # noqa: E402
 
 
@@ -1235,6 +1235,35 @@ def g24_block_options():
 
 
 ALL['g24'] = g24_block_options
+
+
+def g25_mixed_density():
+    """MixedDensityEventStack.construct: logarithmic time bins, int8 accumulation and channel running sum, +-cutoff"""
+    rng = np.random.RandomState(125)
+    out = {}
+    for name, n, bins, cutoff in [('a', 20000, 10, None), ('b', 50000, 6, 5), ('c', 3000, 12, 0), ('e', 4096, 8, 127)]:
+        H, W = 24, 30
+        x = rng.randint(0, W, n)
+        y = rng.randint(0, H, n)
+        p = rng.randint(0, 2, n)
+        t = np.sort(rng.randint(1000, 51000, n))
+        if name == 'a':   # a hot pixel overflowing int8 in the accumulation and again in the running sum
+            x[-700:], y[-700:], p[-700:] = 3, 4, 1
+            x[-1500:-700], y[-1500:-700], p[-1500:-700] = 5, 6, 0
+        if name == 'e':   # normalised times at and next to the exact bin edges 2^-k
+            t = np.sort(np.concatenate([[0, 1 << 20]] + [[(1 << k) - 1, 1 << k, (1 << k) + 1] for k in range(1, 20)]
+                                       + [rng.randint(0, 1 << 20, n - 2 - 57)]))
+        rep = MixedDensityEventStack(bins=bins, height=H, width=W, count_cutoff=cutoff).construct(
+            torch.from_numpy(x), torch.from_numpy(y), torch.from_numpy(p), torch.from_numpy(t))
+        out.update({f'{name}_x': x, f'{name}_y': y, f'{name}_p': p, f'{name}_t': t, f'{name}_rep': rep.numpy()})
+    # t0 == t1
+    x, y, p, t = np.array([1, 2, 2]), np.array([0, 1, 1]), np.array([0, 1, 1]), np.array([5, 5, 5])
+    rep = MixedDensityEventStack(bins=4, height=3, width=4).construct(*(torch.from_numpy(a) for a in (x, y, p, t)))
+    out.update(d_rep=rep.numpy())
+    save('g25_mixed_density.npz', **out)
+
+
+ALL['g25'] = g25_mixed_density
 
 
 if __name__ == '__main__':

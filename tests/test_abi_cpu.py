@@ -22,7 +22,7 @@ def test_header_prototypes_parse(built):
     assert len(protos) >= 28
     for must in ('leod_ln_linear_fwd', 'leod_partition_attn_fwd', 'leod_partition_attn_bwd', 'leod_convlstm_fwd',
                  'leod_stem_conv_fwd', 'leod_conv_nhwc_fwd', 'leod_simota_assign', 'leod_yolox_loss',
-                 'leod_postprocess_nms', 'leod_pseudo_filter', 'leod_adamw_clip_step', 'leod_voxelize_u8'):
+                 'leod_postprocess_nms', 'leod_pseudo_filter', 'leod_adamw_clip_step', 'leod_voxelize_u8', 'leod_mixed_density_i8'):
         assert must in protos
 
 

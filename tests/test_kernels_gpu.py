@@ -840,6 +840,32 @@ def test_voxelize_golden(ops, golden_dir):
         assert np.array_equal(rep.cpu().numpy(), g[f'{name}_rep'])
 
 
+def test_mixed_density_golden(ops, golden_dir):
+    """MixedDensityEventStack (data/utils/representations.py:132-221) through the package's class: the outputs recorded from the reference
+    (bin edges at exact powers of 1/2, int8 wrap-around, cutoffs 0 / 5 / 127 / none), the oracle on a larger stream, empty input"""
+    from leod_amd.data.utils.representations import MixedDensityEventStack, StackedHistogram
+    from oracle import postproc as op
+    g = np.load(os.path.join(golden_dir, 'g25_mixed_density.npz'))
+    for name, bins, cutoff in [('a', 10, None), ('b', 6, 5), ('c', 12, 0), ('e', 8, 127)]:
+        ev = [torch.from_numpy(g[f'{name}_{k}'].astype(np.int64)).to(DEV) for k in 'xypt']
+        rep = MixedDensityEventStack(bins, 24, 30, count_cutoff=cutoff).construct(*ev)
+        assert rep.dtype is torch.int8 and np.array_equal(rep.cpu().numpy(), g[f'{name}_rep']), name
+    small = [torch.tensor(a, device=DEV) for a in ([1, 2, 2], [0, 1, 1], [0, 1, 1], [5, 5, 5])]
+    assert np.array_equal(MixedDensityEventStack(4, 3, 4).construct(*small).cpu().numpy(), g['d_rep'])
+    none = [torch.zeros(0, dtype=torch.int64, device=DEV)] * 4
+    assert not MixedDensityEventStack(3, 4, 5).construct(*none).any()
+    rng = np.random.RandomState(7)
+    n, H, W = 2_000_000, 360, 640
+    x, y, p = rng.randint(0, W, n), rng.randint(0, H, n), rng.randint(0, 2, n)
+    t = np.sort(rng.randint(0, 50_000, n))
+    ev = [torch.from_numpy(a.astype(np.int64)).to(DEV) for a in (x, y, p, t)]
+    rep = MixedDensityEventStack(10, H, W, count_cutoff=20).construct(*ev)
+    assert np.array_equal(rep.cpu().numpy(), op.mixed_density_stack(x, y, p, t, 10, H, W, count_cutoff=20))
+    # the histogram class over the same stream
+    hist = StackedHistogram(10, H, W, count_cutoff=10).construct(*ev)
+    assert np.array_equal(hist.cpu().numpy(), op.stacked_histogram(x, y, p, t, 10, H, W, count_cutoff=10))
+
+
 def test_adamw_clip(ops):
     n = 10007
     p0, g0 = rnd((n,), 1), rnd((n,), 2, 2.0)

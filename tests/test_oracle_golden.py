@@ -271,6 +271,16 @@ def test_g10_voxel(golden_dir):
     assert np.array_equal(rep, g['d_rep'])
 
 
+def test_g25_mixed_density(golden_dir):
+    g = G(golden_dir, 'g25_mixed_density.npz')
+    for name, bins, cutoff in [('a', 10, None), ('b', 6, 5), ('c', 12, 0), ('e', 8, 127)]:
+        rep = op.mixed_density_stack(g[f'{name}_x'], g[f'{name}_y'], g[f'{name}_p'], g[f'{name}_t'], bins, 24, 30, count_cutoff=cutoff)
+        assert rep.dtype == np.int8 and np.array_equal(rep, g[f'{name}_rep']), name
+    rep = op.mixed_density_stack(np.array([1, 2, 2]), np.array([0, 1, 1]), np.array([0, 1, 1]), np.array([5, 5, 5]), 4, 3, 4)
+    assert np.array_equal(rep, g['d_rep'])
+    assert not op.mixed_density_stack(np.zeros(0, int), np.zeros(0, int), np.zeros(0, int), np.zeros(0, int), 3, 4, 5).any()
+
+
 def test_g11_onecycle(golden_dir):
     want = json.load(open(os.path.join(golden_dir, 'g11_onecycle.json')))
     from oracle.schedule import one_cycle_lr
