@@ -32,7 +32,11 @@ typedef unsigned u4s_ __attribute__((ext_vector_type(4)));
 template <int NT>
 __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ x,
                                                                  float* __restrict__ dW, int B, int Cin, int H, int W, int Ho,
-                                                                 int Wo, int N, int tiles_x, int tiles_y) {
+                                                                 int Wo, int N, int tiles_x, int tiles_y, int ldn) {
+    // blockIdx.y: slice of N output channels out of the ldn of a dY row (64 channels of RVT-B = two slices of 32: four channel tiles of
+    // accumulators per wave spill, 41 VGPRs at 2 waves per SIMD)
+    dy += blockIdx.y * N;
+    dW += (long)blockIdx.y * N * (Cin * 49);
     constexpr int RY = (64 * NT * 4 + 511) / 512;             // dY float4s per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned short* patch = reinterpret_cast<unsigned short*>(smem_raw);
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(const float* __
             const int e = min(tid + 512 * p, 64 * N4 - 1), px = e / N4, c4 = e - px * N4;   // pixel 0..63 = 16 * row + col
             const int oy = 4 * ty + (px >> 4), ox = 16 * tx + (px & 15);
             ymask |= (uint32_t)(oy < Ho && ox < Wo) << p;
-            ry[p] = ld4(dy + (((long)bb * Ho + min(oy, Ho - 1)) * Wo + min(ox, Wo - 1)) * N + 4 * c4);
+            ry[p] = ld4(dy + (((long)bb * Ho + min(oy, Ho - 1)) * Wo + min(ox, Wo - 1)) * ldn + 4 * c4);
         }
     };
     auto stash = [&]() {
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(const float* __
 }
 
 template <int NT>
-int launch(const float* dy, const uint8_t* x, float* dW, int B, int Cin, int H, int W, int Ho, int Wo, int N, hipStream_t s) {
+int launch(const float* dy, const uint8_t* x, float* dW, int B, int Cin, int H, int W, int Ho, int Wo, int N, hipStream_t s, int slices = 1) {
     const int tiles_x = cdiv(Wo, 16), tiles_y = cdiv(Ho, 4);
     const int ntiles = B * tiles_x * tiles_y;
     const size_t patch = (((size_t)Cin * PR * RS + 7) & ~(size_t)7) * 2;
@@ -167,9 +171,9 @@ int launch(const float* dy, const uint8_t* x, float* dW, int B, int Cin, int H, 
         hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_bf16_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr = true;
     }
-    static const bool reg = (leod_register_input_kernel(reinterpret_cast<const void*>(&stem_wgrad_bf16_kernel<NT>), 1, 12), true);
+    static const bool reg = (leod_register_input_kernel(reinterpret_cast<const void*>(&stem_wgrad_bf16_kernel<NT>), 1, 13), true);
     (void)reg;
-    hipLaunchKernelGGL((stem_wgrad_bf16_kernel<NT>), dim3(gx), dim3(512), lds, s, dy, x, dW, B, Cin, H, W, Ho, Wo, N, tiles_x, tiles_y);
+    hipLaunchKernelGGL((stem_wgrad_bf16_kernel<NT>), dim3(gx, slices), dim3(512), lds, s, dy, x, dW, B, Cin, H, W, Ho, Wo, N, tiles_x, tiles_y, N * slices);
     return leod_launch_status();
 }
 
@@ -373,7 +377,7 @@ int launch_fwd(const uint8_t* x, const float* w, float* y, int B, int H, int W, 
 
 bool stem_wgrad_bf16_supported(const void* x, int Cin, int H, int W, int N, int stride, int pad) {
     static const int on = 1;
-    return on && stride == 4 && pad == 3 && N >= 16 && N <= 48 && !(N & 15) && !(W & 3) && Cin * PR * RD <= RX * 512 &&
+    return on && stride == 4 && pad == 3 && N >= 16 && N <= 64 && !(N & 15) && !(W & 3) && Cin * PR * RD <= RX * 512 &&
            Cin * 7 <= 2 * 8 * KT && ((uintptr_t)x & 3) == 0 && ((long)Cin * H * W) % 4 == 0;
 }
 
@@ -383,7 +387,7 @@ int stem_wgrad_bf16_launch(const float* dy, const void* x, float* dW, int B, int
         case 1: return launch<1>(dy, (const uint8_t*)x, dW, B, Cin, H, W, Ho, Wo, N, s);
         case 2: return launch<2>(dy, (const uint8_t*)x, dW, B, Cin, H, W, Ho, Wo, N, s);
         case 3: return launch<3>(dy, (const uint8_t*)x, dW, B, Cin, H, W, Ho, Wo, N, s);
-        default: return launch<4>(dy, (const uint8_t*)x, dW, B, Cin, H, W, Ho, Wo, N, s);
+        default: return launch<2>(dy, (const uint8_t*)x, dW, B, Cin, H, W, Ho, Wo, 32, s, 2);     // 64 channels: two slices of 32
     }
 }
 

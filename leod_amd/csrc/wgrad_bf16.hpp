@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_reduce_kernel(const f4* __rest
 struct WgwScratch { void* p = nullptr; size_t bytes = 0; };
 static inline std::unordered_map<hipStream_t, WgwScratch>& wgw_scratch_map() { static std::unordered_map<hipStream_t, WgwScratch> m; return m; }
 static inline std::mutex& wgw_scratch_mutex() { static std::mutex m; return m; }
-constexpr size_t kWgwScratchBytes = (size_t)256 << 20;      // partial tiles (1024 workgroups x 4 waves x 12 KB) + the bf16 operand copies of wgrad_dma.hpp
+constexpr size_t kWgwScratchBytes = (size_t)768 << 20;      // partial tiles (1024 workgroups x 4 waves x 12 KB) + the bf16 operand copies of wgrad_dma.hpp
 static inline void wgrad_wide_register_scratch(hipStream_t s, void* p, size_t bytes) {
     std::lock_guard<std::mutex> lock(wgw_scratch_mutex());
     WgwScratch& e = wgw_scratch_map()[s];

@@ -1,5 +1,5 @@
 // Weight-gradient GEMM for the SHORT row ranges (stages 3-4 of the backbone and their ConvLSTMs: 13 k - 54 k rows, N and K multiples of
-// 96 in 192 .. 1536):  dW[n][k] += sum_m dY(m,n) * X(m,k), dbias[n] += sum_m dY(m,n)   (round 6).
+// 96 in 192 .. 1536; for the power-of-two widths of RVT-B, 128 x 128 or 64 x 64 tiles and up to 400 k rows):  dW[n][k] += sum_m dY(m,n) * X(m,k), dbias[n] += sum_m dY(m,n)   (round 6).
 //
 // What bound wgrad_wide_bf16_kernel there (profiles/r06_a_bench_line_default.json, roofline.by_rows: 87-90 us per launch at 13 k AND at 54 k
 // rows = 160 TFLOP/s, 0.5-1.0 TB/s): a workgroup has ONE 32-row chunk of loads in flight (register staging: a second register set spills),
@@ -64,8 +64,11 @@ template <int N> __device__ __forceinline__ void wgd_wait_vm() { asm volatile("s
 
 // 96 x 96 outputs per workgroup: 4 waves as 2 x 2, 3 x 3 MFMA tiles (16x16x32 bf16) each.  RC rows per chunk, NS ring slots.
 // LN: X holds xhat; the tile is scaled / shifted by ln_w / ln_b in the epilogue (needs the column sums of dY in every wave).
+template <int T, int RC, int NS> constexpr int wgd_lds_bytes() { return NS * 2 * (RC / 16) * T * 256 * 2; }
+template <int T, int RC, int NS> constexpr int wgd_occupancy() { return wgd_lds_bytes<T, RC, NS>() <= 52 * 1024 ? 3 : wgd_lds_bytes<T, RC, NS>() <= 80 * 1024 ? 2 : 1; }
+
 template <int T, int RC, int NS, bool LN>
-__global__ __launch_bounds__(256, T == 6 ? 2 : 1) void wgrad_dma_kernel(const unsigned short* __restrict__ A, long lda, const unsigned short* __restrict__ B, long ldb,
+__global__ __launch_bounds__(256, ((wgd_occupancy<T, RC, NS>()) >= 2 ? 2 : 1)) void wgrad_dma_kernel(const unsigned short* __restrict__ A, long lda, const unsigned short* __restrict__ B, long ldb,
                                                            const float* __restrict__ ln_w, const float* __restrict__ ln_b, float* dbias_flag,
                                                            f4* __restrict__ part, int chunks, int cpw, int gx, int ny, int nz, int N, int K, int dbg) {
     constexpr int WA = T / 2, WB = T / 2, NWN = 2, NWK = 2, RB = RC / 16, KS = RC / 32;
@@ -189,32 +192,46 @@ __global__ __launch_bounds__(256, T == 6 ? 2 : 1) void wgrad_dma_kernel(const un
     }
 }
 
-constexpr int kWgdRC = 64, kWgdNS = 3;
+constexpr int kWgdRC = 64;
+constexpr size_t kWgdOperandBytes = (size_t)600 << 20;       // bf16 copies of both operands of the largest covered launch (338 k x (512 + 128))
 
-constexpr size_t kWgdOperandBytes = (size_t)176 << 20;       // bf16 copies of both operands of the largest covered launch (54 k x (768 + 192))
+// tile edge (in 16-column blocks) for an N x K weight: 96 x 96 where the dimensions are multiples of 96 (RVT-T / -S: 32 / 48 channels x 2^s),
+// else 128 x 128 (RVT-B: 64 x 2^s), else 64 x 64; 0: not covered
+static inline int wgd_tile(int N, int K) {
+    if (N % 96 == 0 && K % 96 == 0) return 6;
+    if (N % 128 == 0 && K % 128 == 0) return 8;
+    if (N % 64 == 0 && K % 64 == 0) return 4;
+    return 0;
+}
 static inline bool wgrad_dma_ok(const XRows& xl, long lddy, int M, int N, int K, int dyfmt) {
-    if (leod_precision() != 1 || M < 8192 || M > 60000 || (M % kWgdRC) || (N % 96) || (K % 96) || N < 96 || K < 96) return false;
+    if (leod_precision() != 1 || M < 8192 || (M % kWgdRC) || N < 64 || K < 64) return false;
+    const int T = wgd_tile(N, K);
+    if (!T) return false;
     const int xm = xl.x_mode();
     if ((lddy & 7) || (xl.ld & 7)) return false;
     if (xl.x2 && (xm != 0 || (xl.K1 & 7) || (xl.ld2 & 7))) return false;
     const size_t need = (size_t)M * ((dyfmt ? 0 : N) + (xm == 3 ? 0 : K)) * 2;
     if (need > kWgdOperandBytes) return false;
+    // row ranges above these stay on the register-staged wide kernel, which streams at 2-2.9 TB/s there and needs no preparation pass
+    // (profiles/r06_f_wgrad_dma_1mpx_kbench.txt: RVT-B 1 Mpx stages 2-4, 338 k / 84 k / 21 k rows, 1262 / 1161 / 1719 us -> 948 / 607 / 419;
+    // RVT-S Gen1 stage 2, 215 k rows x 96-multiples: 375 us wide vs 462 us here)
+    if (M > (T == 6 ? 60000 : 400000)) return false;
     // the square projections (fp32 dY AND 16-bit attention rows to convert, 4-16 output tiles) stay on the register-staged kernel: the
     // preparation pass is as long as the contraction there (30 vs 36 us at 53 760 x 192 x 192, 27 vs 28 us at 13 440 x 384 x 384)
     if (!dyfmt && xm != 3 && xm != 2 && (long)N * K < 200000) return false;
     return true;
 }
 
-template <int T>
+template <int T, int RC, int NS>
 static inline int launch_wgrad_dma_t(const void* dy, long lddy, const XRows& xl, float* dW, long ldw, float* dbias,
                                      int M, int N, int K, hipStream_t s, int dyfmt) {
-    constexpr int RC = kWgdRC, NS = kWgdNS, TW = T * 16;
-    constexpr int LDS = NS * 2 * (RC / 16) * T * 256 * 2;
+    constexpr int TW = T * 16;
+    constexpr int LDS = wgd_lds_bytes<T, RC, NS>();
     const int xm = xl.x_mode();
     const int tiles = (N / TW) * (K / TW), chunks = M / RC;
     constexpr int dbg = 0;          // ablation bits (1: no MFMAs, 2: no refills, 4: no barrier), compile-time, for experiments
     constexpr int gx8 = 1;          // row ranges a multiple of 8: the tiles of one row range share an XCD (53 760 x 576 x 192: 62 -> 44 us)
-    const int target = T == 6 ? 512 : 256;                     // resident workgroups
+    const int target = 256 * wgd_occupancy<T, RC, NS>();       // resident workgroups
     int gx = max(1, min(chunks / NS, target / tiles));
     if (gx8 && gx >= 8) gx &= ~7;
     const int cpw = cdiv(chunks, gx);
@@ -264,5 +281,11 @@ static inline int launch_wgrad_dma(const void* dy, long lddy, const XRows& xl, f
                                    int M, int N, int K, hipStream_t s, int dyfmt) {
     // (192 x 192 tiles -- T = 12, one workgroup per CU, half the LDS-DMA bytes per output -- measured slower on 9 of the 10 shapes of
     // tools/kbench_wgrad_small.py: 593 vs 549 us summed; the chunk stream is not bound by DMA bytes, profiles/r06_d_wgrad_dma_kbench.txt)
-    return launch_wgrad_dma_t<6>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s, dyfmt);
+    // 128 x 128 tiles: two ring slots of 64 rows (2 workgroups per CU) beat three slots of 32 or 64 rows and 64 x 64 tiles on every shape of
+    // RVT-B (3597 vs 3703 / 4054 / 4392 us over the twenty launches of profiles/r06_f_wgrad_dma_1mpx_kbench.txt)
+    switch (wgd_tile(N, K)) {
+        case 6: return launch_wgrad_dma_t<6, 64, 3>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s, dyfmt);
+        case 8: return launch_wgrad_dma_t<8, 64, 2>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s, dyfmt);
+        default: return launch_wgrad_dma_t<4, 64, 3>(dy, lddy, xl, dW, ldw, dbias, M, N, K, s, dyfmt);
+    }
 }

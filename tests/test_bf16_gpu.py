@@ -316,6 +316,10 @@ def test_mlp_hidden_stored_once_as_fp16(bf16_ops, M, C):
     (13440, 384, 384, False, 'rows16'), (13440, 1536, 768, True, 'concat'), (53760, 576, 192, True, 'ln'), (53760, 192, 192, False, 'rows'),
     (8256, 288, 96, True, 'ln'), (53760, 192, 768, False, 'gelu16'), (13440, 768, 384, False, 'concat'), (8192, 96, 96, True, 'rows'),
     (13440, 1152, 384, True, 'rows16'),
+    # the same kernel on 128 x 128 tiles (two ring slots) and 64 x 64 tiles: the power-of-two widths of RVT-B, up to 400 k rows
+    (21120, 2048, 512, True, 'ln'), (21120, 512, 2048, False, 'gelu16'), (21120, 2048, 1024, True, 'concat'), (21120, 512, 512, False, 'rows16'),
+    (84480, 768, 256, True, 'ln'), (84480, 256, 1024, False, 'gelu16'), (337920, 512, 128, True, 'ln'), (8192, 128, 128, True, 'rows'),
+    (8256, 192, 64, True, 'ln'), (21120, 64, 320, False, 'gelu16'), (16384, 320, 128, True, 'concat'),
 ])
 def test_wgrad_wide_bf16(bf16_ops, M, N, K, dy16, xmode):
     import torch.nn.functional as F
@@ -450,7 +454,8 @@ def test_partition_attn_bf16(bf16_ops, B, H, W, C, heads, part, window):
 
 
 @pytest.mark.parametrize('u8,B,H,W,Hp,Wp,N', [(True, 2, 60, 90, 64, 96, 48), (True, 2, 60, 88, 64, 96, 48), (True, 1, 240, 304, 256, 320, 48),
-                                              (True, 7, 240, 304, 256, 320, 48), (True, 2, 36, 52, 40, 64, 32)])   # 560 tiles: the persistent loop of k_stem.hip
+                                              (True, 7, 240, 304, 256, 320, 48), (True, 2, 36, 52, 40, 64, 32),   # 560 tiles: the persistent loop of k_stem.hip
+                                              (True, 2, 60, 88, 64, 96, 64), (True, 3, 180, 320, 192, 320, 64)])  # RVT-B: 64 channels = two slices of 32 in the weight gradient
 def test_stem_conv_bf16(bf16_ops, u8, B, H, W, Hp, Wp, N):
     tk.test_stem_conv(bf16_ops, u8, B, H, W, Hp, Wp, N)
 

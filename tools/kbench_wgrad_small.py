@@ -17,7 +17,8 @@ def main():
     ops.set_precision(os.environ.get('LEOD_PRECISION', '16f'))
     r = lambda *s: torch.randn(*s, device=DEV)  # noqa
     tot = 0.0
-    for M, C in ((53760, 192), (13440, 384)):
+    shapes = {'gen1': ((53760, 192), (13440, 384)), 'gen1s2': ((215040, 96),), '1mpx': ((1351680, 64), (337920, 128), (84480, 256), (21120, 512))}[sys.argv[1] if len(sys.argv) > 1 else 'gen1']
+    for M, C in shapes:
         x, lw, lb = r(M, C), r(C), r(C)
         _, st = ops.layernorm_fwd(x, lw, lb, want_stats=True)
         dq, du = r(M, 3 * C).to(torch.bfloat16), r(M, 4 * C).to(torch.bfloat16)
@@ -34,7 +35,7 @@ def main():
         for name, fn, N, K in cases:
             us = timeit(fn)
             tot += us
-            print(f'{M:6d} {name:<30s} {N:5d} x {K:5d}  {us:7.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s  {2.0 * M * (N + K) / us / 1e3:7.0f} GB/s (16-bit operands)')
+            print(f'{M:7d} {name:<30s} {N:5d} x {K:5d}  {us:7.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s  {2.0 * M * (N + K) / us / 1e3:7.0f} GB/s (16-bit operands)')
     print('sum us', round(tot, 1))
 
 
