@@ -359,7 +359,7 @@ template <int C, bool G16 = false, int OF = 1>
 __global__ __launch_bounds__(C * 2) void lstm_seq_fwd_stream_kernel(const float* __restrict__ gxin, float* __restrict__ hbuf, float* __restrict__ cbuf,
                                                                      const s8v* __restrict__ wpf, float* __restrict__ gates_out, int M, int T,
                                                                      int zero_state) {
-    constexpr int KC = C / 32, LD = C + 16, NB = 2, NBT = KC / NB;          // 32-k chunks, NB per register batch; LD / 2 == 8 (mod 16) dwords: conflict-free 16-byte A reads
+    constexpr int KC = C / 32, LD = C + 16, NB = C >= 512 ? 1 : 2, NBT = KC / NB;   // (16 waves: 128 registers per lane, one chunk per batch)          // 32-k chunks, NB per register batch; LD / 2 == 8 (mod 16) dwords: conflict-free 16-byte A reads
     static_assert(KC % NB == 0, "chunk batches");
     __shared__ __attribute__((aligned(16))) unsigned short sA[2][16 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(C * 2) void lstm_seq_bwd_stream_kernel(const float*
                                                                      const float* __restrict__ gates, const float* __restrict__ cbuf,
                                                                      const s8v* __restrict__ wpb, float* __restrict__ dgates_out,
                                                                      float* __restrict__ dh0, float* __restrict__ dc0, int M, int T) {
-    constexpr int KA = 4 * C, KC = KA / 32, LD = KA + 16, NB = 4, NBT = KC / NB;
+    constexpr int KA = 4 * C, KC = KA / 32, LD = KA + 16, NB = C >= 512 ? 2 : 4, NBT = KC / NB;
     static_assert(KC % NB == 0, "chunk batches");
     __shared__ __attribute__((aligned(16))) unsigned short sA[2][16 * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -569,7 +569,7 @@ static inline int fwd_bregs(int K, bool bf) { return 4 * (K / 16) * (bf ? 2 : 4)
 LEOD_API int leod_convlstm_seq_mode(int C) {
     const bool bf = leod_precision() == 1;
     static const int stream_on = 1;
-    if (bf && stream_on && (C == 256 || C == 384)) return 3;               // hoisted x projection + weights streamed from a packed bf16 copy
+    if (bf && stream_on && (C == 256 || C == 384 || C == 512)) return 3;               // hoisted x projection + weights streamed from a packed bf16 copy
     // C = 192: the register-resident kernels spill (96 weight registers of the 168 a wave gets at 12 waves per workgroup: 79 / 83 spilled
     // VGPRs, tools/kernel_regs.py) -- streamed fragments (295 KB per timestep and workgroup from L2) are the faster of the two
     static const int stream192 = 1;
@@ -622,7 +622,9 @@ LEOD_API int leod_convlstm_seq_fwd(const float* xin, int x_is_projection, float*
         const s8v* wpf = reinterpret_cast<const s8v*>(wpack);
         const dim3 g3(cdiv(M, 16));
         LEOD_BY_OPFMT16({
-            if (C == 384 && gates16) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<384, true, OF>), g3, dim3(768), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
+            if (C == 512 && gates16) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<512, true, OF>), g3, dim3(1024), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
+            else if (C == 512) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<512, false, OF>), g3, dim3(1024), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
+            else if (C == 384 && gates16) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<384, true, OF>), g3, dim3(768), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
             else if (C == 384) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<384, false, OF>), g3, dim3(768), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
             else if (C == 192 && gates16) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<192, true, OF>), g3, dim3(384), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
             else if (C == 192) hipLaunchKernelGGL((lstm_seq_fwd_stream_kernel<192, false, OF>), g3, dim3(384), 0, stream, xin, hbuf, cbuf, wpf, gates_out, M, T, zero_state);
@@ -656,7 +658,9 @@ LEOD_API int leod_convlstm_seq_bwd(const float* dh_seq, const float* dc_last, co
         if (!wpack) return LEOD_ERR_ARG;
         const s8v* wpb = reinterpret_cast<const s8v*>(wpack) + (long)C * C / 2;
         const dim3 g3(cdiv(M, 16));
-        if (C == 384 && gates16) hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<384, true>), g3, dim3(768), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
+        if (C == 512 && gates16) hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<512, true>), g3, dim3(1024), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
+        else if (C == 512) hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<512>), g3, dim3(1024), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
+        else if (C == 384 && gates16) hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<384, true>), g3, dim3(768), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
         else if (C == 384) hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<384>), g3, dim3(768), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
         else if (C == 192 && gates16) hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<192, true>), g3, dim3(384), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);
         else if (C == 192) hipLaunchKernelGGL((lstm_seq_bwd_stream_kernel<192>), g3, dim3(384), 0, stream, dh_seq, dc_last, gates, cbuf, wpb, dgates_out, dh0, dc0, M, T);

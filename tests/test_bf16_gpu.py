@@ -365,7 +365,8 @@ def test_wgrad_wide_bf16(bf16_ops, M, N, K, dy16, xmode):
 # (C = 384 runs the per-timestep kernels in either mode: covered by test_convlstm_bf16 above)
 @pytest.mark.parametrize('T,B,H,W,C,state', [(4, 1, 7, 10, 48, True), (3, 2, 8, 10, 32, False), (5, 4, 16, 40, 96, True), (3, 2, 16, 20, 192, True),
                                              (21, 2, 16, 20, 48, True), (21, 1, 8, 10, 192, True),
-                                             (5, 2, 8, 10, 384, True), (3, 1, 5, 7, 256, False)])   # weights streamed from the packed copy
+                                             (5, 2, 8, 10, 384, True), (3, 1, 5, 7, 256, False),    # weights streamed from the packed copy
+                                             (4, 2, 6, 10, 512, True), (11, 1, 5, 7, 512, False)])  # RVT-B stage 4: 16 waves per workgroup
 def test_convlstm_sequence_bf16(bf16_ops, T, B, H, W, C, state):
     tk.test_convlstm_sequence(bf16_ops, T, B, H, W, C, state)
 
