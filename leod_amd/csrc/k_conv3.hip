@@ -47,7 +47,10 @@ struct BnEval { const float* w; const float* b; const float* rm; const float* rv
 template <int KC, int NTO, int TW, int S = 1, int OF = 1>
 __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wp, float* __restrict__ y,
                                                        double* __restrict__ colstats, int stat_rep, int accumulate,
-                                                       int B, int H, int W, int Cout, int RH, BnEval bne) {
+                                                       int B, int H, int W, int Cout, int RH, int WSo, BnEval bne) {
+    // WSo: output columns per workgroup (Wo % WSo == 0).  Maps too wide for a (RH + 2)-row halo of full rows in LDS (160 columns x 128
+    // channels) are cut into column segments; a segment is a map of its own width for the halo and the pixel -> lane mapping, only the
+    // global addresses know the full row.
     constexpr bool K32 = KC % 2 == 0;
     // operand rows (halo pixels, weight rows): bf16 rows whose dword stride is 4 * odd for the 8-byte fragment reads of the 16-k MFMA
     // and == 8 (mod 16) for the 16-byte reads of the 32-k MFMA (conflict-free ds_read_b64 / ds_read_b128, MI355X_MICROARCH.md LDS)
@@ -57,12 +60,14 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int Ho = H / S, Wo = W / S;
-    const int rblocks = (Ho + RH - 1) / RH;
-    const int b = blockIdx.x / rblocks, y0 = (blockIdx.x - b * rblocks) * RH;
+    const int rblocks = (Ho + RH - 1) / RH, csegs = Wo / WSo;
+    const int seg = blockIdx.x % csegs, rb_ = blockIdx.x / csegs;
+    const int b = rb_ / rblocks, y0 = (rb_ - b * rblocks) * RH;
+    const int x0o = seg * WSo, x0 = S * x0o;
     const int rows = min(RH, Ho - y0);
-    const int P = rows * Wo, ntiles = (P + 15) >> 4;
+    const int P = rows * WSo, ntiles = (P + 15) >> 4;
     const int co0 = blockIdx.y * BN;
-    const int WH = W + 2;
+    const int WH = S * WSo + 2;
     const int halo_elems = (S * (RH - 1) + 3) * WH * LDP;
     bf16_t* halo = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* sB = halo + ((halo_elems + 7) & ~7);                 // [2][BN * LDB]
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
             const int e = e0 + 256 * j;
             const int hp = e / (CI / 4), c4 = (e - hp * (CI / 4)) * 4;
             const int hy = hp / WH, hx = hp - hy * WH;
-            const int iy = S * y0 - 1 + hy, ix = hx - 1;
+            const int iy = S * y0 - 1 + hy, ix = x0 + hx - 1;
             ho[j] = e < hslots ? hp * LDP + c4 : -1;
             hv[j] = zero4();
             if (e < hslots && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) hv[j] = ld4(xb + ((long)iy * W + ix) * CI + c4);
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
         tok[t] = tile < ntiles;
         int p = tile * 16 + i;
         if (p >= P) p = 0;
-        const int py = p / Wo, px = p - py * Wo;
+        const int py = p / WSo, px = p - py * WSo;
         hbase[t] = ((S * py + 1) * WH + S * px + 1) * LDP + QK * q;
     }
     f4 acc[TW][NTO];
@@ -179,7 +184,8 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
     float cs[NTO], cq[NTO];
 #pragma unroll
     for (int n = 0; n < NTO; ++n) { cs[n] = 0.f; cq[n] = 0.f; }
-    float* yb = y + ((long)(b * Ho + y0) * Wo) * Cout + co0;
+    float* yb = y + ((long)(b * Ho + y0) * Wo + x0o) * Cout + co0;
+    auto poff = [&](int p) -> long { if (csegs == 1) return p; const int py = p / WSo; return (long)py * Wo + (p - py * WSo); };   // pixel of the region -> pixel of the map
     // the whole fragment loop once per value of `accumulate`: with the read-modify-write arm inside the row loop every row group ended at
     // a join with a pending load, where hipcc drains vmcnt -- i.e. each 16-byte store waited for the previous one's acknowledgement
     auto rows_out = [&](auto accc, auto bnc) {
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
                 for (int k = 0; k < NK; ++k) {
                     const int idx = min(k * 64 + lane, 16 * NTO * 4 - 1);
                     const int row = idx / (NTO * 4), c4 = (idx - row * (NTO * 4)) * 4;
-                    old[k] = ld4(yb + (long)min(tile * 16 + row, P - 1) * Cout + c4);
+                    old[k] = ld4(yb + poff(min(tile * 16 + row, P - 1)) * Cout + c4);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = siluf_(fmaf(v[j], bsc[k][j], bsh[k][j]));
                     }
-                    *reinterpret_cast<f4*>(yb + (long)p * Cout + c4) = v;
+                    *reinterpret_cast<f4*>(yb + poff(p) * Cout + c4) = v;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(256) void conv3s2_dgrad_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NA, int NB, int S, int HB = 12>                      // HB: 16-byte staging loads in flight per thread
 __global__ __launch_bounds__(256) void conv3_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
-                                                           int B, int H, int W, int Ho, int Wo, int Ntot, int Ctot, int RH, int nregions) {
+                                                           int B, int H, int W, int Ho, int Wo, int Ntot, int Ctot, int RH, int nregions, int WSo) {
     static_assert(NA % 2 == 0, "two wave rows over the output channels");
     constexpr int WVB = NB % 2 == 0 ? 2 : 1, WVS = 2 / WVB;               // waves: 2 (n) x WVB (c) x WVS (pixel steps)
     constexpr int N = 16 * NA, CI = 16 * NB, LDX = CI + (S == 1 ? 16 : 8), LDY = N + 16, TA = NA / 2, TB = NB / WVB;
@@ -451,7 +457,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(const float* __restric
     const int g = blockIdx.y;                                     // kernel row: taps 3g .. 3g + 2
     const int nsl = Ntot / N;
     const int n0 = ((int)blockIdx.z % nsl) * N, c0 = ((int)blockIdx.z / nsl) * CI;
-    const int WH = W + 2;
+    const int WH = S * WSo + 2, csegs = Wo / WSo;              // WSo: output columns of a region (column segments of wide maps, as conv3s1_kernel)
     bf16_t* halo = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* sdy = halo + (((S * (RH - 1) + 3) * WH * LDX + 7) & ~7);
     f4 acc[3][TA][TB];
@@ -463,9 +469,11 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(const float* __restric
             for (int b = 0; b < TB; ++b) acc[j][a][b] = zero4();
     const int rblocks = (Ho + RH - 1) / RH;
     for (int reg = blockIdx.x; reg < nregions; reg += gridDim.x) {
-        const int b = reg / rblocks, y0 = (reg - b * rblocks) * RH;
+        const int seg = reg % csegs, rg = reg / csegs;
+        const int b = rg / rblocks, y0 = (rg - b * rblocks) * RH;
+        const int x0o = seg * WSo, x0 = S * x0o;
         const int rows = min(RH, Ho - y0);
-        const int P = rows * Wo, P32 = (P + 31) & ~31, steps = P32 >> 5;
+        const int P = rows * WSo, P32 = (P + 31) & ~31, steps = P32 >> 5;
         // ---- stage the input halo and the dy rows (bf16); all loads of a batch before the first LDS store -----------------------
         // (issuing a region's loads before the previous region's MFMAs -- 28 + 12 staging registers per lane carried across the
         // contraction -- was slower on every shape: 175 -> 189 us stage 2, 169 -> 265 us stage 4)
@@ -478,7 +486,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(const float* __restric
                 const int e = e0 + 256 * j;
                 const int hp = e / (CI / 4), c4 = (e - hp * (CI / 4)) * 4;
                 const int hy = hp / WH, hx = hp - hy * WH;
-                const int iy = S * y0 - 1 + hy, ix = hx - 1;
+                const int iy = S * y0 - 1 + hy, ix = x0 + hx - 1;
                 ho[j] = e < hslots ? hp * LDX + c4 : -1;
                 hv[j] = zero4();
                 if (e < hslots && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) hv[j] = ld4(xb + ((long)iy * W + ix) * Ctot + c4);
@@ -488,14 +496,14 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(const float* __restric
                 if (ho[j] >= 0) *reinterpret_cast<s4*>(halo + ho[j]) = pack_bf16(hv[j]);
         }
         const int dslots = P32 * (N / 4);
-        const float* dyb = dy + ((long)(b * Ho + y0) * Wo) * Ntot + n0;
+        const float* dyb = dy + ((long)(b * Ho + y0) * Wo + x0o) * Ntot + n0;
         for (int e0 = tid; e0 < dslots; e0 += 256 * HB) {
             f4 hv[HB];
 #pragma unroll
             for (int j = 0; j < HB; ++j) {
                 const int e = e0 + 256 * j;
                 const int p = e / (N / 4), c4 = (e - p * (N / 4)) * 4;
-                hv[j] = (e < dslots && p < P) ? ld4(dyb + (long)p * Ntot + c4) : zero4();     // rows P .. P32 - 1: zeros (contribute nothing)
+                hv[j] = (e < dslots && p < P) ? ld4(dyb + (csegs == 1 ? (long)p : (long)(p / WSo) * Wo + p % WSo) * Ntot + c4) : zero4();     // rows P .. P32 - 1: zeros (contribute nothing)
             }
 #pragma unroll
             for (int j = 0; j < HB; ++j) {
@@ -512,7 +520,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(const float* __restric
             for (int h = 0; h < 2; ++h) {
                 int p = 32 * s + 8 * q + 4 * h + (i >> 2);
                 if (p >= P) p = P - 1;                                               // dy is zero there: any valid pixel will do
-                const int py = p / Wo, px = p - py * Wo;
+                const int py = p / WSo, px = p - py * WSo;
                 hx0[h] = ((S * py + g) * WH + S * px) * LDX + 4 * (i & 3);           // tap (g, 0); taps (g, 1), (g, 2): + LDX, + 2 LDX
             }
             const bf16_t* pdy = sdy + (32 * s + 8 * q + (i >> 2)) * LDY + 4 * (i & 3);
@@ -558,7 +566,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(const float* __restric
 // 3 x 3 tile block as above per tap (45 / 36 accumulator tiles); a region's halo and dy rows are fetched and converted ONCE.
 template <int NA, int NB, int S, int HB = 8>
 __global__ __launch_bounds__(512) void conv3_wgrad9_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
-                                                            int B, int H, int W, int Ho, int Wo, int Ntot, int Ctot, int RH, int nregions) {
+                                                            int B, int H, int W, int Ho, int Wo, int Ntot, int Ctot, int RH, int nregions, int WSo) {
     static_assert(NA % 2 == 0, "two wave rows over the output channels");
     constexpr int WVB = NB % 2 == 0 ? 2 : 1, WVS = 2 / WVB;               // waves of a tap group: 2 (n) x WVB (c) x WVS (pixel steps)
     constexpr int N = 16 * NA, CI = 16 * NB, LDX = CI + (S == 1 ? 16 : 8), LDY = N + 16, TA = NA / 2, TB = NB / WVB, NTH = 512, NJ = 5;
@@ -570,7 +578,7 @@ __global__ __launch_bounds__(512) void conv3_wgrad9_kernel(const float* __restri
     const int wa = w4 & 1, wb = WVB == 2 ? w4 >> 1 : 0, ws = WVB == 2 ? 0 : w4 >> 1;
     const int nsl = Ntot / N;
     const int n0 = ((int)blockIdx.y % nsl) * N, c0 = ((int)blockIdx.y / nsl) * CI;
-    const int WH = W + 2;
+    const int WH = S * WSo + 2, csegs = Wo / WSo;              // WSo: output columns of a region (column segments of wide maps, as conv3s1_kernel)
     bf16_t* halo = reinterpret_cast<bf16_t*>(smem_raw);
     bf16_t* sdy = halo + (((S * (RH - 1) + 3) * WH * LDX + 7) & ~7);
     int toff[NJ];                                                 // halo offset of this wave's taps (the group of taps 5-8 repeats tap 8: not stored)
@@ -585,9 +593,11 @@ __global__ __launch_bounds__(512) void conv3_wgrad9_kernel(const float* __restri
             for (int b = 0; b < TB; ++b) acc[j][a][b] = zero4();
     const int rblocks = (Ho + RH - 1) / RH;
     for (int reg = blockIdx.x; reg < nregions; reg += gridDim.x) {
-        const int b = reg / rblocks, y0 = (reg - b * rblocks) * RH;
+        const int seg = reg % csegs, rg = reg / csegs;
+        const int b = rg / rblocks, y0 = (rg - b * rblocks) * RH;
+        const int x0o = seg * WSo, x0 = S * x0o;
         const int rows = min(RH, Ho - y0);
-        const int P = rows * Wo, P32 = (P + 31) & ~31, steps = P32 >> 5;
+        const int P = rows * WSo, P32 = (P + 31) & ~31, steps = P32 >> 5;
         const int hslots = (S * (rows - 1) + 3) * WH * (CI / 4);
         const float* xb = x + (long)b * H * W * Ctot + c0;
         for (int e0 = tid; e0 < hslots; e0 += NTH * HB) {
@@ -597,7 +607,7 @@ __global__ __launch_bounds__(512) void conv3_wgrad9_kernel(const float* __restri
                 const int e = e0 + NTH * j;
                 const int hp = e / (CI / 4), c4 = (e - hp * (CI / 4)) * 4;
                 const int hy = hp / WH, hx = hp - hy * WH;
-                const int iy = S * y0 - 1 + hy, ix = hx - 1;
+                const int iy = S * y0 - 1 + hy, ix = x0 + hx - 1;
                 ho[j] = e < hslots ? hp * LDX + c4 : -1;
                 hv[j] = zero4();
                 if (e < hslots && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) hv[j] = ld4(xb + ((long)iy * W + ix) * Ctot + c4);
@@ -607,14 +617,14 @@ __global__ __launch_bounds__(512) void conv3_wgrad9_kernel(const float* __restri
                 if (ho[j] >= 0) *reinterpret_cast<s4*>(halo + ho[j]) = pack_bf16(hv[j]);
         }
         const int dslots = P32 * (N / 4);
-        const float* dyb = dy + ((long)(b * Ho + y0) * Wo) * Ntot + n0;
+        const float* dyb = dy + ((long)(b * Ho + y0) * Wo + x0o) * Ntot + n0;
         for (int e0 = tid; e0 < dslots; e0 += NTH * HB) {
             f4 hv[HB];
 #pragma unroll
             for (int j = 0; j < HB; ++j) {
                 const int e = e0 + NTH * j;
                 const int p = e / (N / 4), c4 = (e - p * (N / 4)) * 4;
-                hv[j] = (e < dslots && p < P) ? ld4(dyb + (long)p * Ntot + c4) : zero4();     // rows P .. P32 - 1: zeros (contribute nothing)
+                hv[j] = (e < dslots && p < P) ? ld4(dyb + (csegs == 1 ? (long)p : (long)(p / WSo) * Wo + p % WSo) * Ntot + c4) : zero4();     // rows P .. P32 - 1: zeros (contribute nothing)
             }
 #pragma unroll
             for (int j = 0; j < HB; ++j) {
@@ -629,7 +639,7 @@ __global__ __launch_bounds__(512) void conv3_wgrad9_kernel(const float* __restri
             for (int h = 0; h < 2; ++h) {
                 int p = 32 * s + 8 * q + 4 * h + (i >> 2);
                 if (p >= P) p = P - 1;                                               // dy is zero there: any valid pixel will do
-                const int py = p / Wo, px = p - py * Wo;
+                const int py = p / WSo, px = p - py * WSo;
                 hx0[h] = (S * py * WH + S * px) * LDX + 4 * (i & 3);                 // tap (0, 0); the others: + toff
             }
             const bf16_t* pdy = sdy + (32 * s + 8 * q + (i >> 2)) * LDY + 4 * (i & 3);
@@ -700,23 +710,45 @@ static inline int conv3_rows_per_block(int H, int W, int Cin, int nto, int S = 1
     return rh;
 }
 
+// (Cin / 16, column tiles per workgroup, stride) combinations conv3s1_kernel is instantiated for: the 48 / 96 / 192 widths of RVT-T / -S and
+// the 64 / 128 / 256 widths of RVT-B
+static inline int conv3_nto(int Cin, int Cout, int S) {
+    const bool rvt_s = Cin == 48 || Cin == 96 || Cin == 192;
+    if (rvt_s) return S == 1 ? (Cout == 48 ? 3 : (Cout == 96 || Cout == 192) ? 6 : 0) : (Cout % 96 == 0 ? 6 : 0);
+    if (Cin == 64) return S == 1 ? (Cout == 64 ? 4 : 0) : (Cout % 128 == 0 ? 8 : 0);
+    if (Cin == 128) return Cout % 128 == 0 && (S == 2 || Cout == 128) ? 8 : 0;
+    if (Cin == 256) return Cout % 64 == 0 && (S == 2 || Cout == 256) ? 4 : 0;
+    return 0;
+}
+// column segments (1, 2 or 4) and output rows per workgroup; false: the halo of even a quarter row does not fit
+static inline bool conv3_geometry(int H, int W, int Cin, int nto, int S, int& csegs, int& rh) {
+    const int Wo = W / S;
+    for (csegs = 1; csegs <= 4; csegs *= 2) {
+        if (Wo % csegs || Wo / csegs < 4) return false;
+        if (Wo / csegs > 160) continue;
+        rh = conv3_rows_per_block(H, W / csegs, Cin, nto, S);
+        if (rh > 0) return true;
+    }
+    return false;
+}
+
 // forward of the stride-2 convs on the same kernel (S = 2)
 bool conv3s2_fwd_supported(int B, int H, int W, int Cin, int Cout) {
-    constexpr int on = 1;
-    static const int on2 = 1;
-    if (!on || !on2 || leod_precision() != 1) return false;
-    if ((H & 1) || (W & 1) || W / 2 > 160 || W / 2 < 4) return false;
+    if (leod_precision() != 1) return false;
+    if ((H & 1) || (W & 1)) return false;
     // (192 input channels: the weight tile takes half the LDS, 4 output rows per workgroup -- stage 4 of RVT-S, 13440 output pixels,
     // 141 us vs 125 on the LDS GEMM; but the PAFPN bottom-up conv on 32 frames (2560 pixels) would fall to the register-direct GEMM: 114 us)
-    if ((Cin != 48 && Cin != 96 && !(Cin == 192 && (long)B * (H / 2) * (W / 2) < 8192)) || Cout % 96 != 0) return false;
-    return conv3_rows_per_block(H, W, Cin, 6, 2) > 0;
+    if (Cin == 192 && (long)B * (H / 2) * (W / 2) >= 8192) return false;
+    const int nto = conv3_nto(Cin, Cout, 2);
+    int csegs, rh;
+    return nto && conv3_geometry(H, W, Cin, nto, 2, csegs, rh);
 }
 
 bool conv3s1_supported(int H, int W, int Cin, int Cout) {
-    constexpr int on = 1;
-    if (!on || leod_precision() != 1) return false;
-    if (W > 160 || W < 4 || (Cin != 48 && Cin != 96 && Cin != 192) || (Cout != 48 && Cout != 96 && Cout != 192)) return false;
-    return conv3_rows_per_block(H, W, Cin, Cout == 48 ? 3 : 6) > 0;
+    if (leod_precision() != 1) return false;
+    const int nto = conv3_nto(Cin, Cout, 1);
+    int csegs, rh;
+    return nto && conv3_geometry(H, W, Cin, nto, 1, csegs, rh);
 }
 
 size_t conv3s1_pack_bytes(int Cin, int Cout) { return (size_t)9 * Cin * Cout * sizeof(bf16_t); }
@@ -735,15 +767,15 @@ int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, i
     if (!packed)
         hipLaunchKernelGGL(conv3_pack_kernel, dim3((int)min((long)1024, (total + 255) / 256)), dim3(256), 0, stream, w, wp,
                            transposed ? Cin : Cout, transposed ? Cout : Cin, transposed ? 1 : 0, of == 2 ? 1 : 0);
-    const int nto = Cout == 48 ? 3 : 6;
-    const int RH = conv3_rows_per_block(H, W, Cin, nto, stride);
-    if (RH <= 0) return LEOD_ERR_UNSUPPORTED;
-    const int Ho = H / stride, Wo = W / stride;
+    const int nto = conv3_nto(Cin, Cout, stride);
+    int csegs = 1, RH = 0;
+    if (!nto || !conv3_geometry(H, W, Cin, nto, stride, csegs, RH)) return LEOD_ERR_UNSUPPORTED;
+    const int Ho = H / stride, Wo = W / stride, WSo = Wo / csegs;
     // (Two workgroups per CU for the large launches of the inference passes -- fewer output rows per workgroup, <= 80 KB of LDS each --
     // measured equal: 26.55 vs 26.56 ms per pseudo-label chunk, profiles/r04_a_graph_ab.txt; one workgroup per CU and the smaller halo overlap stay.)
-    const dim3 grid(B * cdiv(Ho, RH), Cout / (16 * nto));
-    const size_t smem = conv3_smem(RH, W, Cin, nto, stride);
-    const int tw = cdiv(cdiv(min(RH, Ho) * Wo, 16), 4) <= 2 ? 2 : 3;          // row tiles per wave
+    const dim3 grid(B * cdiv(Ho, RH) * csegs, Cout / (16 * nto));
+    const size_t smem = conv3_smem(RH, W / csegs, Cin, nto, stride);
+    const int tw = cdiv(cdiv(min(RH, Ho) * WSo, 16), 4) <= 2 ? 2 : 3;          // row tiles per wave
 #define C3_CASE(KCV, NTOV, SV) C3_CASE2(KCV, NTOV, 2, SV, 1) C3_CASE2(KCV, NTOV, 3, SV, 1) C3_CASE2(KCV, NTOV, 2, SV, 2) C3_CASE2(KCV, NTOV, 3, SV, 2)
 #define C3_CASE2(KCV, NTOV, TWV, SV, OFV)                                                                                            \
     if (Cin == 16 * KCV && nto == NTOV && tw == TWV && stride == SV && of == OFV) {                                                   \
@@ -752,11 +784,12 @@ int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, i
             hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3s1_kernel<KCV, NTOV, TWV, SV, OFV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_set = true;                                                                                                         \
         }                                                                                                                            \
-        hipLaunchKernelGGL((conv3s1_kernel<KCV, NTOV, TWV, SV, OFV>), grid, dim3(256), smem, stream, x, wp, y, colstats, stat_rep, accumulate, B, H, W, Cout, RH, bne); \
+        hipLaunchKernelGGL((conv3s1_kernel<KCV, NTOV, TWV, SV, OFV>), grid, dim3(256), smem, stream, x, wp, y, colstats, stat_rep, accumulate, B, H, W, Cout, RH, WSo, bne); \
         return leod_launch_status();                                                                                                 \
     }
     C3_CASE(3, 3, 1) C3_CASE(3, 6, 1) C3_CASE(6, 3, 1) C3_CASE(6, 6, 1) C3_CASE(12, 3, 1) C3_CASE(12, 6, 1)
     C3_CASE(3, 6, 2) C3_CASE(6, 6, 2) C3_CASE(12, 6, 2)
+    C3_CASE(4, 4, 1) C3_CASE(8, 8, 1) C3_CASE(16, 4, 1) C3_CASE(4, 8, 2) C3_CASE(8, 8, 2) C3_CASE(16, 4, 2)       // RVT-B
 #undef C3_CASE
 #undef C3_CASE2
     return LEOD_ERR_UNSUPPORTED;
@@ -764,17 +797,22 @@ int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, i
 
 // shapes of the direct weight-gradient kernel: stride 1 or 2 (even H, W), output channels in slices of 96, input channels 48 or in
 // slices of 96
+// (output channels, input channels) per slice, in units of 16: 96 x 96 / 96 x 48 for the widths of RVT-T / -S, 128 x 64 / 64 x 64 for RVT-B
+static inline bool conv3_wgrad_slice(int Cin, int Cout, int stride, int& na, int& nb) {
+    if (Cout % 96 == 0 && (Cin % 96 == 0 || (Cin == 48 && stride == 2))) { na = 6; nb = Cin == 48 ? 3 : 6; return true; }
+    if (Cout % 128 == 0 && Cin % 64 == 0) { na = 8; nb = 4; return true; }
+    if (Cout == 64 && Cin == 64 && stride == 1) { na = 4; nb = 4; return true; }
+    return false;
+}
+struct Conv3WgradPlan { int RH, workers, wvs, nslices, ci, na, csegs; bool nine; size_t smem; };
+static inline Conv3WgradPlan conv3_wgrad_plan(int B, int H, int W, int Cin, int Cout, int S);
 bool conv3_wgrad_supported(int H, int W, int Cin, int Cout, int stride) {
-    constexpr int on = 1;
-    static const int on2 = 1;      // everything but the 96 -> 96 / stride 1 case
-    if (!on || leod_precision() != 1) return false;
+    if (leod_precision() != 1) return false;
     if (stride != 1 && stride != 2) return false;
     if (stride == 2 && ((H & 1) || (W & 1))) return false;
-    const int Wo = W / stride;
-    if (Wo > 160 || Wo < 4 || Cout % 96 != 0) return false;
-    if (stride == 1 && Cin == 96 && Cout == 96) return true;
-    if (!on2) return false;
-    return Cin % 96 == 0 || (Cin == 48 && stride == 2);
+    int na, nb;
+    if (W / stride < 4 || !conv3_wgrad_slice(Cin, Cout, stride, na, nb)) return false;
+    return conv3_wgrad_plan(1, H, W, Cin, Cout, stride).RH > 0;
 }
 
 // the 8-wave / nine-tap kernel takes everything but the smallest problems (a few regions: the three kernel-row workgroups of
@@ -783,28 +821,37 @@ static inline bool conv3_wgrad_nine(int nregions, int nslices) {
     static const int on = 1;
     return on && nregions * nslices > 32;
 }
-struct Conv3WgradPlan { int RH, workers, wvs, nslices, ci; bool nine; size_t smem; };
 static inline Conv3WgradPlan conv3_wgrad_plan(int B, int H, int W, int Cin, int Cout, int S) {
     Conv3WgradPlan pl{};
     const int Ho = H / S, Wo = W / S;
-    pl.ci = Cin == 48 ? 48 : 96;
-    pl.wvs = pl.ci == 48 ? 2 : 1;
-    pl.nslices = (Cout / 96) * (Cin / pl.ci);
-    const int LDX = pl.ci + (S == 1 ? 16 : 8), LDY = 96 + 16;
+    int na = 6, nb = 6;
+    if (!conv3_wgrad_slice(Cin, Cout, S, na, nb)) return pl;
+    pl.na = na; pl.ci = 16 * nb;
+    pl.wvs = nb % 2 ? 2 : 1;
+    pl.nslices = (Cout / (16 * na)) * (Cin / pl.ci);
+    const int LDX = pl.ci + (S == 1 ? 16 : 8), LDY = 16 * na + 16;
     static const int ldskb = 160;
-    int RH = max(1, min(Ho, 160 / Wo));
-    while (RH > 0) {
-        const size_t halo = (((size_t)(S * (RH - 1) + 3) * (W + 2) * LDX + 7) & ~(size_t)7) * 2;
-        const size_t sdy = (size_t)((RH * Wo + 31) & ~31) * LDY * 2;
-        pl.smem = halo + sdy;
-        if (pl.smem <= (size_t)ldskb * 1024) break;
-        --RH;
+    // column segments: 1 unless the halo of a single output row of full width does not fit (320 input columns, stage 2 of RVT-B at 1 Mpx)
+    int RH = 0, WSo = Wo;
+    for (pl.csegs = 1; pl.csegs <= 4; pl.csegs *= 2) {
+        if (Wo % pl.csegs || Wo / pl.csegs < 4) { pl.csegs = 0; break; }
+        WSo = Wo / pl.csegs;
+        if (WSo > 160) continue;
+        RH = max(1, min(Ho, 160 / WSo));
+        while (RH > 0) {
+            const size_t halo = (((size_t)(S * (RH - 1) + 3) * (S * WSo + 2) * LDX + 7) & ~(size_t)7) * 2;
+            const size_t sdy = (size_t)((RH * WSo + 31) & ~31) * LDY * 2;
+            pl.smem = halo + sdy;
+            if (pl.smem <= (size_t)ldskb * 1024) break;
+            --RH;
+        }
+        if (RH > 0) break;
     }
-    if (RH <= 0) { pl.RH = 0; pl.workers = 0; return pl; }
+    if (RH <= 0 || pl.csegs == 0 || pl.csegs > 4) { pl.RH = 0; pl.workers = 0; return pl; }
     RH = cdiv(Ho, cdiv(Ho, RH));                                  // equal row blocks
-    pl.smem = (((size_t)(S * (RH - 1) + 3) * (W + 2) * LDX + 7) & ~(size_t)7) * 2 + (size_t)((RH * Wo + 31) & ~31) * LDY * 2;
+    pl.smem = (((size_t)(S * (RH - 1) + 3) * (S * WSo + 2) * LDX + 7) & ~(size_t)7) * 2 + (size_t)((RH * WSo + 31) & ~31) * LDY * 2;
     pl.RH = RH;
-    const int nregions = B * cdiv(Ho, RH);
+    const int nregions = B * cdiv(Ho, RH) * pl.csegs;
     // region workers per (kernel row, slice): each walks over nregions / workers regions.  96 -> 96 / stride 1 (level-0 head conv)
     // measured: 64 -> 42 us, 85 -> 47, 128 -> 51; the sliced / strided shapes fill the chip once (3 * slices * workers ~ 256) with a
     // multiple of 8 workers, so that the three kernel rows of a region (dispatch slots workers apart) share an XCD's L2
@@ -815,7 +862,7 @@ static inline Conv3WgradPlan conv3_wgrad_plan(int B, int H, int W, int Cin, int 
         workers = max(1, fill / (3 * pl.nslices));
         if (workers >= 8) workers &= ~7;
     }
-    pl.nine = conv3_wgrad_nine(nregions, pl.nslices);
+    pl.nine = conv3_wgrad_nine(nregions, pl.nslices) || pl.na != 6;      // (the three-workgroup kernel exists for the 96-channel slices only)
     if (pl.nine) {
         // 9-tap workgroups, one per CU (LDS): slices * workers of them, and each writes a whole 9 x 96 x CI slice of partial sums that
         // the reduce kernel reads back -- 256 workgroups when each gets >= 2 regions (the backbone convs on 168 frames: stage 2
@@ -839,19 +886,19 @@ int conv3_wgrad_launch(const float* dy, const float* x, float* dW, float* ws, in
     const Conv3WgradPlan pl = conv3_wgrad_plan(B, H, W, Cin, Cout, stride);
     if (pl.workers <= 0 || !ws) return LEOD_ERR_UNSUPPORTED;
     const int Ho = H / stride, Wo = W / stride;
-    const int nregions = B * cdiv(Ho, pl.RH);
+    const int nregions = B * cdiv(Ho, pl.RH) * pl.csegs, WSo = Wo / pl.csegs;
     if (pl.nine) {
         const dim3 grid9(pl.workers, pl.nslices);
-#define C3W9_CASE(NBV, SV)                                                                                                               \
-        if (pl.ci == 16 * NBV && stride == SV) {                                                                                         \
+#define C3W9_CASE(NAV, NBV, SV)                                                                                                          \
+        if (pl.na == NAV && pl.ci == 16 * NBV && stride == SV) {                                                                                         \
             static bool attr_set = false;                                                                                                \
             if (!attr_set) {                                                                                                             \
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgrad9_kernel<6, NBV, SV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgrad9_kernel<NAV, NBV, SV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
                 attr_set = true;                                                                                                         \
             }                                                                                                                            \
-            hipLaunchKernelGGL((conv3_wgrad9_kernel<6, NBV, SV>), grid9, dim3(512), pl.smem, stream, dy, x, ws, B, H, W, Ho, Wo, Cout, Cin, pl.RH, nregions); \
+            hipLaunchKernelGGL((conv3_wgrad9_kernel<NAV, NBV, SV>), grid9, dim3(512), pl.smem, stream, dy, x, ws, B, H, W, Ho, Wo, Cout, Cin, pl.RH, nregions, WSo); \
         } else
-        C3W9_CASE(6, 1) C3W9_CASE(6, 2) C3W9_CASE(3, 2) return LEOD_ERR_UNSUPPORTED;
+        C3W9_CASE(6, 6, 1) C3W9_CASE(6, 6, 2) C3W9_CASE(6, 3, 2) C3W9_CASE(8, 4, 1) C3W9_CASE(8, 4, 2) C3W9_CASE(4, 4, 1) return LEOD_ERR_UNSUPPORTED;
 #undef C3W9_CASE
         hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(cdiv(9 * Cin * Cout, 256)), dim3(256), 0, stream, ws, dW, pl.workers * pl.wvs, Cout, Cin);
         return leod_launch_status();
@@ -864,7 +911,7 @@ int conv3_wgrad_launch(const float* dy, const float* x, float* dW, float* ws, in
             hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgrad_kernel<6, NBV, SV, HBV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_set = true;                                                                                                             \
         }                                                                                                                                \
-        hipLaunchKernelGGL((conv3_wgrad_kernel<6, NBV, SV, HBV>), grid, dim3(256), pl.smem, stream, dy, x, ws, B, H, W, Ho, Wo, Cout, Cin, pl.RH, nregions); \
+        hipLaunchKernelGGL((conv3_wgrad_kernel<6, NBV, SV, HBV>), grid, dim3(256), pl.smem, stream, dy, x, ws, B, H, W, Ho, Wo, Cout, Cin, pl.RH, nregions, WSo); \
     } else
     C3W_CASE(6, 1, 12) C3W_CASE(6, 2, 12) C3W_CASE(3, 2, 12) return LEOD_ERR_UNSUPPORTED;      // (18 loads in flight: no faster)
 #undef C3W_CASE

@@ -87,7 +87,9 @@ def test_convlstm_bf16(bf16_ops, M, C, state):
                                          (4, 16, 20, 96, 96),      # level 1: 8 rows x 20
                                          (3, 8, 10, 192, 192),     # level 2: one workgroup per image and 96-channel slab
                                          (2, 16, 20, 192, 192),    # LDS-limited row count
-                                         (2, 32, 40, 48, 48), (2, 9, 12, 48, 96), (1, 5, 7, 96, 48), (2, 24, 80, 96, 96), (70, 9, 12, 96, 96), (1, 5, 7, 96, 96)])
+                                         (2, 32, 40, 48, 48), (2, 9, 12, 48, 96), (1, 5, 7, 96, 48), (2, 24, 80, 96, 96), (70, 9, 12, 96, 96), (1, 5, 7, 96, 96),
+                                         # RVT-B widths; 160-pixel rows of 128 channels are cut into two column segments
+                                         (2, 24, 40, 128, 128), (1, 48, 80, 128, 128), (1, 12, 160, 128, 128), (2, 24, 40, 256, 256), (1, 13, 160, 64, 64), (2, 7, 12, 128, 128)])
 def test_conv3x3_direct_bf16(bf16_ops, B, H, W, Cin, N):
     """The direct 3x3 / stride-1 convolution of csrc/k_conv3.hip (forward with BatchNorm statistics, and as dgrad) against
     torch's fp32 conv2d on the CPU; ragged last row block (H = 9, 5), widths that are no multiple of 16."""
@@ -127,7 +129,8 @@ def test_conv3x3_direct_bf16(bf16_ops, B, H, W, Cin, N):
                                                 (4, 32, 40, 96, 96, 2),      # PAFPN bottom-up conv
                                                 (2, 16, 20, 192, 192, 2), (3, 16, 20, 192, 192, 1),       # 192 -> 192, both strides
                                                 (2, 10, 12, 48, 96, 2), (1, 6, 8, 96, 96, 2), (70, 8, 12, 96, 96, 2),   # ragged regions, many regions per worker
-                                                (2, 18, 28, 96, 192, 1)])
+                                                (2, 18, 28, 96, 192, 1),
+                                                (2, 24, 320, 64, 128, 2), (2, 48, 160, 128, 256, 2), (3, 24, 80, 256, 512, 2), (2, 48, 160, 128, 128, 2), (2, 24, 80, 256, 256, 2)])  # RVT-B
 def test_conv3x3_strided_sliced_direct_bf16(bf16_ops, B, H, W, Cin, N, stride):
     """The direct kernels of csrc/k_conv3.hip for stride 2 and sliced channel planes -- forward (conv3s1_kernel<.., S = 2>), input
     gradient (conv3s2_dgrad_kernel: four parity classes), weight gradient (conv3_wgrad9_kernel / conv3_wgrad_kernel) -- against torch's
