@@ -269,11 +269,11 @@ __global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ 
 // parity classes on gemm_lds_kernel reached 80-107 TFLOP/s: its im2col chunks are rebuilt from global memory for every class).
 // KC = N / 16 (contraction: dy channels), 48 input channels (3 column tiles) per workgroup (blockIdx.y), TW anchor row tiles per wave.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int KC, int TW>
+template <int KC, int TW, int NTO = 3>
 __global__ __launch_bounds__(256) void conv3s2_dgrad_kernel(const float* __restrict__ dy, const bf16_t* __restrict__ wp, float* __restrict__ dx,
                                                              int accumulate, int B, int Ho, int Wo, int Cin, int RH) {
     static_assert(KC % 2 == 0, "32-k MFMAs");
-    constexpr int NTO = 3, N = 16 * KC, LDP = N + 16, LDB = LDP, BN = NTO * 16, LDO = BN + 4;
+    constexpr int N = 16 * KC, LDP = N + 16, LDB = LDP, BN = NTO * 16, LDO = BN + 4;        // NTO: 3 (48 input channels per workgroup) or 4 (64: RVT-B)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -738,7 +738,8 @@ bool conv3s2_fwd_supported(int B, int H, int W, int Cin, int Cout) {
     if ((H & 1) || (W & 1)) return false;
     // (192 input channels: the weight tile takes half the LDS, 4 output rows per workgroup -- stage 4 of RVT-S, 13440 output pixels,
     // 141 us vs 125 on the LDS GEMM; but the PAFPN bottom-up conv on 32 frames (2560 pixels) would fall to the register-direct GEMM: 114 us)
-    if (Cin == 192 && (long)B * (H / 2) * (W / 2) >= 8192) return false;
+    // (same for 128 / 256 input channels of RVT-B at 1 Mpx: 22 frames x 48 x 80 outputs 364 vs 292 us, 22 x 24 x 40: 601 vs 303)
+    if ((Cin == 192 || Cin == 128 || Cin == 256) && (long)B * (H / 2) * (W / 2) >= 8192) return false;
     const int nto = conv3_nto(Cin, Cout, 2);
     int csegs, rh;
     return nto && conv3_geometry(H, W, Cin, nto, 2, csegs, rh);
@@ -920,27 +921,27 @@ int conv3_wgrad_launch(const float* dy, const float* x, float* dW, float* ws, in
 }
 
 // ---- stride-2 dgrad ----------------------------------------------------------------------------------------------------------------
-static inline size_t conv3s2_dgrad_smem(int RH, int Wo, int N) {
+static inline size_t conv3s2_dgrad_smem(int RH, int Wo, int N, int bn = 48) {
     const int LDP = N + 16;
     const size_t halo = (((size_t)(RH + 1) * (Wo + 1) * LDP + 7) & ~(size_t)7) * 2;
-    const size_t sb = (size_t)2 * 48 * LDP * 2;
-    const size_t so = (size_t)4 * 16 * (48 + 4) * 4;
+    const size_t sb = (size_t)2 * bn * LDP * 2;
+    const size_t so = (size_t)4 * 16 * (bn + 4) * 4;
     return max(halo + sb, so);
 }
-static inline int conv3s2_dgrad_rows(int Ho, int Wo, int N) {
+static inline int conv3s2_dgrad_rows(int Ho, int Wo, int N, int bn = 48) {
     int rh = max(1, min(Ho, 160 / Wo));
-    while (rh > 0 && conv3s2_dgrad_smem(rh, Wo, N) > 160 * 1024) --rh;
+    while (rh > 0 && conv3s2_dgrad_smem(rh, Wo, N, bn) > 160 * 1024) --rh;
     if (rh > 0) rh = cdiv(Ho, cdiv(Ho, rh));
     return rh;
 }
 // x [B,H,W,Cin] <- dy [B,H/2,W/2,N]
 bool conv3s2_dgrad_supported(int H, int W, int Cin, int N) {
-    constexpr int on = 1;
-    static const int on2 = 1;
-    if (!on || !on2 || leod_precision() != 1) return false;
+    if (leod_precision() != 1) return false;
     if ((H & 1) || (W & 1) || W / 2 > 160 || W / 2 < 4) return false;
-    if (Cin % 48 != 0 || (N != 96 && N != 192 && N != 384)) return false;
-    return conv3s2_dgrad_rows(H / 2, W / 2, N) > 0;
+    const bool rvt_s = Cin % 48 == 0 && (N == 96 || N == 192 || N == 384);
+    const bool rvt_b = Cin % 64 == 0 && (N == 128 || N == 256);      // (512 dy channels: the weight tile of 64 input channels does not fit next to a halo row)
+    if (!rvt_s && !rvt_b) return false;
+    return conv3s2_dgrad_rows(H / 2, W / 2, N, rvt_s ? 48 : 64) > 0;
 }
 // w [N][Cin][3][3]; wpack: conv3s1_pack_bytes(Cin, N) bytes of scratch
 int conv3s2_dgrad_launch(const float* dy, const float* w, float* dx, int accumulate, int B, int H, int W, int Cin, int N, void* wpack, hipStream_t stream, int packed) {
@@ -948,22 +949,26 @@ int conv3s2_dgrad_launch(const float* dy, const float* w, float* dx, int accumul
     const long total = (long)9 * Cin * N;
     if (!packed) hipLaunchKernelGGL(conv3_pack_kernel, dim3((int)min((long)1024, (total + 255) / 256)), dim3(256), 0, stream, w, wp, N, Cin, 1, 0);
     const int Ho = H / 2, Wo = W / 2;
-    const int RH = conv3s2_dgrad_rows(Ho, Wo, N);
+    const int bn = (N == 128 || N == 256) ? 64 : 48;
+    const int RH = conv3s2_dgrad_rows(Ho, Wo, N, bn);
     if (RH <= 0) return LEOD_ERR_UNSUPPORTED;
-    const dim3 grid(B * cdiv(Ho, RH), Cin / 48);
-    const size_t smem = conv3s2_dgrad_smem(RH, Wo, N);
+    const dim3 grid(B * cdiv(Ho, RH), Cin / bn);
+    const size_t smem = conv3s2_dgrad_smem(RH, Wo, N, bn);
     const int tw = cdiv(cdiv(RH * Wo, 16), 4);
-#define C3D_CASE(KCV, TWV)                                                                                                               \
-    if (N == 16 * KCV && tw == TWV) {                                                                                                    \
+#define C3D_CASE(KCV, TWV) C3D_CASE3(KCV, TWV, 3)
+#define C3D_CASE3(KCV, TWV, NTOV)                                                                                                        \
+    if (N == 16 * KCV && tw == TWV && bn == 16 * NTOV) {                                                                                                    \
         static bool attr_set = false;                                                                                                    \
         if (!attr_set) {                                                                                                                 \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3s2_dgrad_kernel<KCV, TWV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3s2_dgrad_kernel<KCV, TWV, NTOV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_set = true;                                                                                                             \
         }                                                                                                                                \
-        hipLaunchKernelGGL((conv3s2_dgrad_kernel<KCV, TWV>), grid, dim3(256), smem, stream, dy, wp, dx, accumulate, B, Ho, Wo, Cin, RH); \
+        hipLaunchKernelGGL((conv3s2_dgrad_kernel<KCV, TWV, NTOV>), grid, dim3(256), smem, stream, dy, wp, dx, accumulate, B, Ho, Wo, Cin, RH); \
         return leod_launch_status();                                                                                                     \
     }
     C3D_CASE(6, 1) C3D_CASE(6, 2) C3D_CASE(6, 3) C3D_CASE(12, 1) C3D_CASE(12, 2) C3D_CASE(12, 3) C3D_CASE(24, 1) C3D_CASE(24, 2) C3D_CASE(24, 3)
+    C3D_CASE3(8, 1, 4) C3D_CASE3(8, 2, 4) C3D_CASE3(8, 3, 4) C3D_CASE3(16, 1, 4) C3D_CASE3(16, 2, 4) C3D_CASE3(16, 3, 4)
+#undef C3D_CASE3
 #undef C3D_CASE
     return LEOD_ERR_UNSUPPORTED;
 }
