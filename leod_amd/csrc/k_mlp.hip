@@ -204,9 +204,18 @@ LEOD_API int leod_mlp_fwd_fused(const float* y, const float* ln_w, const float* 
                                 const float* W2, const float* b2, const float* g2, float* out, void* u16, float* stats, int M, int H,
                                 int K, hipStream_t stream) {
     if (!y || !ln_w || !ln_b || !W1 || !W2 || !out || ((u16 == nullptr) != (stats == nullptr))) return LEOD_ERR_ARG;
-    if (leod_precision() != 1 || K != 48 || H != 192 || M < 16384) return LEOD_ERR_UNSUPPORTED;
+    if (leod_precision() != 1 || !((K == 48 && H == 192) || (K == 64 && H == 256)) || M < 16384) return LEOD_ERR_UNSUPPORTED;
     const int grid = min(cdiv(cdiv(M, 16), 4), 256 * 2);       // two resident workgroups per CU (1 / 4 per CU measured slower: 222 / 184 vs 181 us)
     LeodFwdScope fwd_scope;
+    if (K == 64) {                                             // RVT-B stage 1
+        LEOD_BY_OPFMT16({
+            if (u16) hipLaunchKernelGGL((mlp_fwd_fused_kernel<4, 16, true, OF>), dim3(grid), dim3(256), 0, stream, y, ln_w, ln_b, eps, W1, b1, W2, b2, g2, out,
+                                        reinterpret_cast<unsigned short*>(u16), stats, M);
+            else hipLaunchKernelGGL((mlp_fwd_fused_kernel<4, 16, false, OF>), dim3(grid), dim3(256), 0, stream, y, ln_w, ln_b, eps, W1, b1, W2, b2, g2, out,
+                                    nullptr, nullptr, M);
+        });
+        return leod_launch_status();
+    }
     LEOD_BY_OPFMT16({
         if (u16) hipLaunchKernelGGL((mlp_fwd_fused_kernel<3, 12, true, OF>), dim3(grid), dim3(256), 0, stream, y, ln_w, ln_b, eps, W1, b1, W2, b2, g2, out,
                                     reinterpret_cast<unsigned short*>(u16), stats, M);
@@ -228,7 +237,7 @@ LEOD_API int leod_mlp_fwd_fused(const float* y, const float* ln_w, const float* 
 // (du W1, against W1^T rows in LDS); that product is in C layout, where the LayerNorm backward of rowstream_narrow_kernel<.., MODE 2>
 // applies unchanged (row means by 16-lane reductions, dx through the wave-private transposition tile).
 template <int KC, int NHT, bool SDU>
-__global__ __launch_bounds__(256, 2) void mlp_bwd_dgrad_fused_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+__global__ __launch_bounds__(256, (KC <= 3 ? 2 : 1)) void mlp_bwd_dgrad_fused_kernel(const float* __restrict__ dz, const float* __restrict__ y,
                                                                      const float* __restrict__ stats, const float* __restrict__ ln_w,
                                                                      const float* __restrict__ ln_b, const float* __restrict__ W1,
                                                                      const float* __restrict__ b1, const float* __restrict__ W2,
@@ -393,15 +402,11 @@ __global__ __launch_bounds__(256, 2) void mlp_bwd_dgrad_fused_kernel(const float
     }
 }
 
-// dy[M,K] = dz + LN-backward(((dz * g2) W2 * gelu'(LN(y) W1^T + b1)) W1), du16 (optional) [M,H] bf16 = the gradient of the hidden
-// pre-activation, dgamma / dbeta [K] += the LayerNorm weight / bias gradients.  stats [M,2]: the (mean, rstd) the forward pass saved.
-// Same coverage as leod_mlp_fwd_fused; LEOD_ERR_UNSUPPORTED otherwise (callers run leod_linear_dgrad_gelu16 + leod_linear_dgrad_lnbwd).
-LEOD_API int leod_mlp_bwd_dgrad_fused(const float* dz, const float* y, const float* stats, const float* ln_w, const float* ln_b,
+template <int KC, int NHT>
+static int launch_mlp_bwd_dgrad_fused(const float* dz, const float* y, const float* stats, const float* ln_w, const float* ln_b,
                                       const float* W1, const float* b1, const float* W2, const float* g2, float* dy, void* du16,
-                                      float* dgamma, float* dbeta, int M, int H, int K, hipStream_t stream) {
-    if (!dz || !y || !stats || !ln_w || !ln_b || !W1 || !W2 || !dy || !dgamma || !dbeta) return LEOD_ERR_ARG;
-    if (leod_precision() != 1 || K != 48 || H != 192 || M < 16384) return LEOD_ERR_UNSUPPORTED;
-    constexpr int KC = 3, NHT = 12, Kc = 48, Hc = 192;
+                                      float* dgamma, float* dbeta, int M, hipStream_t stream) {
+    constexpr int Kc = 16 * KC, Hc = 16 * NHT;
     constexpr int LDS = (2 * Hc * (Kc + 8) + Kc * (Hc + 16)) * 2 + Hc * 4 + 4 * 16 * (Kc + 4) * 4;
     const int grid = min(cdiv(cdiv(M, 16), 4), 256 * 2);
     static bool attr[2] = {false, false};
@@ -417,3 +422,16 @@ LEOD_API int leod_mlp_bwd_dgrad_fused(const float* dz, const float* y, const flo
     }
     return leod_launch_status();
 }
+
+// dy[M,K] = dz + LN-backward(((dz * g2) W2 * gelu'(LN(y) W1^T + b1)) W1), du16 (optional) [M,H] bf16 = the gradient of the hidden
+// pre-activation, dgamma / dbeta [K] += the LayerNorm weight / bias gradients.  stats [M,2]: the (mean, rstd) the forward pass saved.
+// Same coverage as leod_mlp_fwd_fused; LEOD_ERR_UNSUPPORTED otherwise (callers run leod_linear_dgrad_gelu16 + leod_linear_dgrad_lnbwd).
+LEOD_API int leod_mlp_bwd_dgrad_fused(const float* dz, const float* y, const float* stats, const float* ln_w, const float* ln_b,
+                                      const float* W1, const float* b1, const float* W2, const float* g2, float* dy, void* du16,
+                                      float* dgamma, float* dbeta, int M, int H, int K, hipStream_t stream) {
+    if (!dz || !y || !stats || !ln_w || !ln_b || !W1 || !W2 || !dy || !dgamma || !dbeta) return LEOD_ERR_ARG;
+    if (leod_precision() != 1 || !((K == 48 && H == 192) || (K == 64 && H == 256)) || M < 16384) return LEOD_ERR_UNSUPPORTED;
+    if (K == 64) return launch_mlp_bwd_dgrad_fused<4, 16>(dz, y, stats, ln_w, ln_b, W1, b1, W2, g2, dy, du16, dgamma, dbeta, M, stream);   // RVT-B stage 1
+    return launch_mlp_bwd_dgrad_fused<3, 12>(dz, y, stats, ln_w, ln_b, W1, b1, W2, g2, dy, du16, dgamma, dbeta, M, stream);
+}
+

@@ -496,15 +496,15 @@ def test_linear_dgrad_ln_bwd_from_bf16_rows(bf16_ops, M, N, K, with_res):
     tk.close(db, lb.grad, what='d ln bias')
 
 
+@pytest.mark.parametrize('C', [48, 64])        # stage 1 of RVT-S / -T and of RVT-B
 @pytest.mark.parametrize('M,saved', [(16384, True), (20007, True), (70001, False), (16391, False)])
-def test_mlp_fwd_fused_bf16(bf16_ops, M, saved):
+def test_mlp_fwd_fused_bf16(bf16_ops, M, saved, C):
     """The whole stage-1 MLP in one launch (csrc/k_mlp.hip: fc1 evaluated transposed so that its accumulators are fc2's A operands, the
     hidden never leaves the registers): z = y + g * (gelu(LN(y) W1^T + b1) W2^T + b2) against the fp32 CPU arithmetic (maxvit.py:110-118,
     268-269), full and ragged row counts; with ``want_saved`` the fp16 pre-activation and the LayerNorm statistics the backward pass reads
     must be the ones the unfused producer writes."""
     import torch.nn.functional as F
     ops = bf16_ops
-    C = 48
     y = tk.rnd((M, C), 21)
     lw, lb = 1 + 0.2 * tk.rnd((C,), 22), 0.1 * tk.rnd((C,), 23)
     W1, b1 = tk.rnd((4 * C, C), 24, 0.2), tk.rnd((4 * C,), 25, 0.2)
@@ -528,14 +528,14 @@ def test_mlp_fwd_fused_bf16(bf16_ops, M, saved):
     assert ops.mlp_fwd_fused(d(y)[:1000].contiguous(), d(lw), d(lb), d(W1), d(b1), d(W2), d(b2), d(g)) is None
 
 
+@pytest.mark.parametrize('C', [48, 64])
 @pytest.mark.parametrize('M', [16384, 20007, 70001])
-def test_mlp_bwd_dgrad_fused_bf16(bf16_ops, M):
+def test_mlp_bwd_dgrad_fused_bf16(bf16_ops, M, C):
     """The activation-path backward of the stage-1 MLP in one launch (csrc/k_mlp.hip): u recomputed from y, du = ((dz g) W2) gelu'(u) as
     bf16 rows, dy = dz + LayerNorm-backward(du W1), norm2's weight / bias gradients -- against fp32 autograd of the same block
     (maxvit.py:110-118, 268-269) and against the two-launch path it replaces."""
     import torch.nn.functional as F
     ops = bf16_ops
-    C = 48
     y = tk.rnd((M, C), 31)
     lw, lb = 1 + 0.2 * tk.rnd((C,), 32), 0.1 * tk.rnd((C,), 33)
     W1, b1 = tk.rnd((4 * C, C), 34, 0.2), tk.rnd((4 * C,), 35, 0.2)
