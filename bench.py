@@ -37,6 +37,11 @@ ALGO_MB_PER_FRAME = {'bf16': 68.61 + 32.0 / 168.0 * 29.01 + 395.0 / 168.0,
                      'f32': 2 * (68.61 + 32.0 / 168.0 * 29.01) + 395.0 / 168.0}
 
 
+def _native_comm_active():
+    from leod_amd.comm import NativeComm
+    return NativeComm.active
+
+
 def make_batch(T, B, hw, num_classes, seed, device, label_ts):
     """Synthetic inputs of SURVEY 8d: sparse small-count uint8 voxels, 1-6 boxes on labelled frames."""
     g = torch.Generator(device='cpu').manual_seed(1000 + seed)
@@ -508,7 +513,7 @@ def main():
                                             'losses, master weights and AdamW',
                                      'bf16': 'mode bf16: bf16 MFMA operands in both directions, fp32 accumulation / statistics / state / optimiser',
                                      'f32': 'fp32 end to end'}[args.dtype],
-                       'collective_backend': dist.get_backend() if dist.is_initialized() else None,
+                       'collective_backend': (('rccl (library communicator, csrc/k_comm.hip)' if _native_comm_active() else dist.get_backend()) if dist.is_initialized() else None),
                        'collective_world_size': dist.get_world_size() if dist.is_initialized() else 1,
                        'per_gpu_event_frames_per_s': round(fps / world, 2), 'final_loss': round(loss_val, 4),
                        # algorithmic bytes of the MEASURED precision mode: 76.5 MB per event-frame with 16-bit activations

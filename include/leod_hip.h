@@ -378,7 +378,8 @@ int leod_linear_dgrad_lnbwd(const float* dy, const float* W, const float* x, con
  * leod_plan_create returns a handle > 0 or a negative error (-3: a node type a plan cannot replay; leod_plan_last_error() names it).
  * The library's own weight-pack kernels (conv3_pack_kernel, lstm_pack_kernel: they read parameters only) are taken out of the chain the capture
  * put them in and run on lane 1 from the start of the plan (LEOD_PLAN_HOIST=0: left where they were captured).
- * leod_plan_info: info[8] = kernels, memsets, memcpys, empty nodes, lanes, events, cross-lane waits, ops. */
+ * leod_plan_info: info[9] = kernels, memsets, memcpys, empty nodes, lanes, events, cross-lane waits, ops, collectives (kernel nodes that are
+ * leod_comm_allreduce calls recorded during the capture: the replay issues the all-reduce on the op's lane). */
 long leod_plan_create(void* hip_graph, int max_lanes);
 /* Address ranges (start address as a long, length in bytes; n of them, copied) of PERSISTENT weight-pack buffers.  leod_plan_create moves a
  * weight-pack kernel (conv3_pack_kernel / lstm_pack_kernel) to the start of the plan -- dropping the stream-order edges of its capture --
@@ -400,6 +401,21 @@ int leod_plan_info(long plan, int* info);
 int leod_plan_destroy(long plan);
 int leod_plan_dump(long plan, const char* path); /* debug listing: lane, kernel, events per op in launch order */
 const char* leod_plan_last_error(void);
+
+/* ---- data-parallel exchange: the library's own RCCL communicator (csrc/k_comm.hip) ---------------------------------
+ * The all-reduces of a data-parallel step -- SyncBatchNorm statistics of the detection head, gradient buckets (reference: Lightning's
+ * DDP strategy with sync_batchnorm, train.py:131-133,247) -- enqueued on the caller's stream like kernels.  RCCL is resolved from the
+ * process at run time (dlopen); without it every call returns -3.  Rank 0 draws an id and hands its 128 bytes to the other ranks (the
+ * host side uses torch.distributed for that); leod_comm_init is collective and binds the CURRENT device.  One communicator per process. */
+int leod_comm_unique_id(char* id128);
+int leod_comm_init(const char* id128, int rank, int world);
+int leod_comm_world(void);                                  /* ranks of the communicator, 0 = none */
+/* buf[count] <- element-wise sum over ranks, in place.  dtype: 0 float, 1 double, 2 bf16.  On a stream that is being captured the call
+ * records a marker kernel instead; a launch plan made of that capture (leod_plan_create) issues the all-reduce at that position of every
+ * replay -- a hipGraph launched as such would NOT. */
+int leod_comm_allreduce(void* buf, long count, int dtype, leod_stream_t stream);
+int leod_comm_destroy(void);
+const char* leod_comm_last_error(void);
 
 /* ---- host-side C++ of the path (no GPU involved) ------------------------------------------------------------------
  * Tracking post-filter of the pseudo-label loop: linear-velocity tracklets, confidence-ordered greedy IoU association,

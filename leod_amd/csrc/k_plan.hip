@@ -23,6 +23,8 @@
 
 namespace {
 
+extern "C" int leod_comm_allreduce(void* buf, long count, int dtype, hipStream_t stream);      // k_comm.hip
+
 enum OpType { OP_KERNEL = 0, OP_MEMSET = 1, OP_MEMCPY = 2, OP_NOP = 3 };
 
 struct PlanOp {
@@ -39,6 +41,8 @@ struct PlanOp {
     // input kernels (leod_register_input_kernel): a plan-owned copy of the argument pointer array whose input slot points at in_value
     std::vector<void*> own_params;
     int in_index = -1;
+    // a collective recorded as leod_comm_marker_kernel (k_comm.hip): the replay issues the all-reduce on the op's lane instead of the marker
+    bool coll = false; void* coll_buf = nullptr; long coll_count = 0; int coll_dtype = 0;
     void* in_captured = nullptr; // the input pointer the kernel was captured with
     void* in_value = nullptr;    // the input pointer of the next replay
 };
@@ -50,7 +54,7 @@ struct Plan {
     std::vector<int> lane_first_wait;        // per lane > 0: 1 when the lane has ops (it then waits for the start event)
     int start_event = -1;                    // recorded on the caller's stream before anything else
     std::vector<int> tail_event;             // per lane > 0: event recorded after its last op (-1: lane unused)
-    int n_kernel = 0, n_memset = 0, n_memcpy = 0, n_nop = 0, n_waits = 0, n_hoisted = 0, n_input = 0;
+    int n_kernel = 0, n_memset = 0, n_memcpy = 0, n_nop = 0, n_waits = 0, n_hoisted = 0, n_input = 0, n_coll = 0;
 };
 
 std::mutex g_mu;
@@ -141,6 +145,17 @@ LEOD_API long leod_plan_create(void* hip_graph, int max_lanes) {
             o.type = OP_KERNEL;
             if (hipGraphKernelNodeGetParams(nodes[i], &o.kp) != hipSuccess) { g_err = "hipGraphKernelNodeGetParams failed"; delete p; return LEOD_ERR_ARG; }
             if (!o.kp.func || (!o.kp.kernelParams && !o.kp.extra)) { g_err = "kernel node without function / arguments"; delete p; return LEOD_ERR_UNSUPPORTED; }
+            {
+                const char* knm = hipKernelNameRefByPtr(o.kp.func, nullptr);
+                if (knm && strstr(knm, "leod_comm_marker_kernel")) {
+                    if (!o.kp.kernelParams) { g_err = "collective marker without an argument array"; delete p; return LEOD_ERR_UNSUPPORTED; }
+                    o.coll = true;
+                    o.coll_buf = *reinterpret_cast<void* const*>(o.kp.kernelParams[0]);
+                    o.coll_count = *reinterpret_cast<const long*>(o.kp.kernelParams[1]);
+                    o.coll_dtype = *reinterpret_cast<const int*>(o.kp.kernelParams[2]);
+                    ++p->n_coll;
+                }
+            }
             ++p->n_kernel;
         } else if (t == hipGraphNodeTypeMemset) {
             o.type = OP_MEMSET;
@@ -355,7 +370,8 @@ static int plan_launch(long handle, hipStream_t stream, bool join) {
         hipError_t rc = hipSuccess;
         switch (o.type) {
             case OP_KERNEL:
-                if (o.kp.kernelParams) rc = hipLaunchKernel(o.kp.func, o.kp.gridDim, o.kp.blockDim, o.kp.kernelParams, o.kp.sharedMemBytes, s);
+                if (o.coll) { if (leod_comm_allreduce(o.coll_buf, o.coll_count, o.coll_dtype, s) != LEOD_OK) return LEOD_ERR_LAUNCH; }
+                else if (o.kp.kernelParams) rc = hipLaunchKernel(o.kp.func, o.kp.gridDim, o.kp.blockDim, o.kp.kernelParams, o.kp.sharedMemBytes, s);
                 else rc = hipModuleLaunchKernel((hipFunction_t)o.kp.func, o.kp.gridDim.x, o.kp.gridDim.y, o.kp.gridDim.z, o.kp.blockDim.x,
                                                 o.kp.blockDim.y, o.kp.blockDim.z, o.kp.sharedMemBytes, s, nullptr, o.kp.extra);
                 break;
@@ -427,7 +443,7 @@ LEOD_API int leod_plan_info(long handle, int* info) {
     if (it == g_plans.end() || !info) return LEOD_ERR_ARG;
     Plan* p = it->second;
     info[0] = p->n_kernel; info[1] = p->n_memset; info[2] = p->n_memcpy; info[3] = p->n_nop;
-    info[4] = (int)p->lanes.size(); info[5] = (int)p->events.size(); info[6] = p->n_waits; info[7] = (int)p->ops.size();
+    info[4] = (int)p->lanes.size(); info[5] = (int)p->events.size(); info[6] = p->n_waits; info[7] = (int)p->ops.size(); info[8] = p->n_coll;
     return LEOD_OK;
 }
 

@@ -15,6 +15,7 @@ import torch
 from torch.autograd import Function
 
 from . import ops
+from .comm import NativeComm
 
 _SYNC_BN = {'group': None, 'world_size': 1, 'force': False, 'images': None, 'n_collectives': 0}
 
@@ -187,6 +188,8 @@ def _capture_collectives(group) -> bool:
     the side lane joined, the neck / head weight gradients held on the launch lane).  One rank, every collective issued
     (profiles/r05_q_captured_collectives.txt): 16.14 ms per step against 17.41 with callbacks and 15.42 without collectives.  NOT the default:
     a one-rank all-reduce puts no kernel into the graph, so the replay of real RCCL kernel nodes by the plan executor has never run."""
+    if NativeComm.active and group is None:
+        return True                                         # the library's communicator: a recorded exchange is an op of the launch plan (k_plan.hip)
     if not CAPTURE_COLLECTIVES:
         return False
     import torch.distributed as dist
@@ -202,7 +205,10 @@ def _allreduce_stats(t: torch.Tensor):
         group = _SYNC_BN['group']
 
         def exchange():
-            dist.all_reduce(t, group=group)
+            if NativeComm.usable(t, group):
+                NativeComm.all_reduce(t)                        # on the launch stream, like a kernel (comm.py)
+            else:
+                dist.all_reduce(t, group=group)
             _SYNC_BN['n_collectives'] += 1
         # a step that is being recorded into launch plans takes the exchange as a host callback between two plan segments -- or, as an
         # option, leaves it to ProcessGroupNCCL's own stream capture (_capture_collectives)

@@ -103,7 +103,8 @@ class PlanRecorder:
                 'memcpys': sum(p.info['memcpys'] for p, _ in self.segments if p is not None),
                 'lanes': max([p.info['lanes'] for p, _ in self.segments if p is not None] or [0]),
                 'waits': sum(p.info['waits'] for p, _ in self.segments if p is not None),
-                'segments': len(self.segments), 'callbacks': sum(1 for _, c in self.segments if c is not None)}
+                'segments': len(self.segments), 'callbacks': sum(1 for _, c in self.segments if c is not None),
+                'collectives': sum(p.info.get('collectives', 0) for p, _ in self.segments if p is not None)}
 
     def close(self):
         for p, _ in self.segments:

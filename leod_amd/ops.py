@@ -1222,9 +1222,9 @@ class LaunchPlan:
         if h <= 0:
             raise LeodHipError(f'leod_plan_create: {_l().leod_plan_last_error().decode()} (rc {h})')
         self.handle = h
-        info = (ctypes.c_int * 8)()
+        info = (ctypes.c_int * 9)()
         check(_l().leod_plan_info(h, info), 'plan_info')
-        self.info = dict(zip(('kernels', 'memsets', 'memcpys', 'empty', 'lanes', 'events', 'waits', 'ops'), list(info)))
+        self.info = dict(zip(('kernels', 'memsets', 'memcpys', 'empty', 'lanes', 'events', 'waits', 'ops', 'collectives'), list(info)))
 
     def launch(self, join: bool = True):
         """``join=False``: the current stream does not wait for the plan's side lanes (call ``join()`` before the next launch of this plan

@@ -25,6 +25,7 @@ import torch.distributed as dist
 
 from . import ops
 from . import functions as Fn
+from .comm import NativeComm
 
 ALIGN = 4   # floats (16 bytes): weight rows are read with 16-byte loads
 
@@ -141,6 +142,8 @@ class DataParallel:
         # LEOD_FORCE_COLLECTIVES=1: issue every collective of the N > 1 path even with one rank (exercises RCCL --
         # communicator, all-reduce of the flat gradient, SyncBN exchanges, stream ordering -- on a single-GPU box)
         self.force = os.environ.get('LEOD_FORCE_COLLECTIVES') == '1' and dist.is_available() and dist.is_initialized()
+        if (self.world_size > 1 or self.force) and flat is not None and flat.data.is_cuda:
+            NativeComm.setup(process_group)                    # collective; every rank ends up on the same path (comm.py)
         if sync_bn and (self.world_size > 1 or self.force):
             Fn.set_sync_batchnorm(process_group, self.world_size)
             Fn._SYNC_BN['force'] = self.force
@@ -169,7 +172,10 @@ class DataParallel:
         if b is not None and GradBuckets.current is b:
             b.finish()
         elif self.world_size > 1 or self.force:
-            dist.all_reduce(self.flat.grad, group=self.group)
+            if NativeComm.usable(self.flat.grad, self.group):
+                NativeComm.all_reduce(self.flat.grad)
+            else:
+                dist.all_reduce(self.flat.grad, group=self.group)
         return 1.0 / self.world_size
 
 
@@ -230,10 +236,16 @@ class GradBuckets:
         self.comm.wait_stream(main)
         for key in Fn.WgradSide.used:                          # this stage's weight gradients were enqueued there
             self.comm.wait_stream(Fn.WgradSide.streams[key])
+        native = NativeComm.usable(g, self.dp.group)          # enqueued on the comm stream itself: nothing to wait for but the stream
         with torch.cuda.stream(self.comm):
             if self.wire_bf16:
                 wire = g.to(torch.bfloat16)
-                self.works.append((dist.all_reduce(wire, group=self.dp.group, async_op=True), wire, g))
+                if native:
+                    NativeComm.all_reduce(wire, self.comm)
+                self.works.append((None if native else dist.all_reduce(wire, group=self.dp.group, async_op=True), wire, g))
+            elif native:
+                NativeComm.all_reduce(g, self.comm)
+                self.works.append((None, None, None))
             else:
                 self.works.append((dist.all_reduce(g, group=self.dp.group, async_op=True), None, None))
 
@@ -245,7 +257,8 @@ class GradBuckets:
             for work, wire, g in self.works:
                 if self.comm is not None:
                     with torch.cuda.stream(self.comm):
-                        work.wait()
+                        if work is not None:
+                            work.wait()
                         if wire is not None:
                             g.copy_(wire)
                 else:

@@ -836,6 +836,73 @@ def test_module_world2_plans_with_collectives_equal_eager(gpu, manifest, head):
     assert d.max() < 2e-3 and (d > 2e-6 + 1e-4 * np.abs(res[False][0][2])).mean() < 5e-3
 
 
+def _module_one_rank_rccl_worker(port, manifest, q, plan, native, steps):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', LEOD_FORCE_COLLECTIVES='1')
+    if not native:
+        os.environ['LEOD_DIST_BACKEND'] = 'nccl'           # an explicit torch backend: every exchange through dist.all_reduce
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    from leod_amd.comm import NativeComm
+    from leod_amd.functions import _SYNC_BN
+    from leod_amd.optim import fit_step
+    mod, _, cfg = micro_module(manifest, 9, 'fit')
+    cfg.training.lr_scheduler.total_steps = 1000
+    mod.train()
+    mod.plan_mode = plan
+    oc = mod.configure_optimizers()
+    opt, sched = oc['optimizer'], oc['lr_scheduler']['scheduler']
+    assert opt.dp.force and opt.dp.buckets is not None and NativeComm.active == native
+    T, B = 4, 2
+    losses = []
+    for step in range(steps):
+        ev = synth_events(T, B, 20, HW[0], HW[1], seed=170 + step, as_uint8=True)
+        labs = micro_labels(T * B, 171 + step, [1e6] * (T * B))
+        labels_tb = [[labs[t * B + b] if t in (1, 3) else None for b in range(B)] for t in range(T)]
+        out = fit_step(mod, opt, sched, loader_batch(ev, labels_tb, torch.tensor([step == 0, step % 2 == 0])), step)
+        losses.append(float(out['loss'].detach()))
+    torch.cuda.synchronize()
+    pi = mod._plans.info() if plan else None
+    q.put((losses, opt.flat.data.detach().cpu().numpy(), NativeComm.n_calls, _SYNC_BN['n_collectives'],
+           (pi['forward'], pi['backward']) if pi else None))
+    dist.barrier()
+    NativeComm.shutdown()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('plan', [False, True])
+def test_module_one_rank_rccl_native_communicator(gpu, manifest, plan):
+    """The exchanges of a data-parallel step on the library's own RCCL communicator (leod_amd/comm.py, csrc/k_comm.hip) -- one rank, every
+    collective of the N > 1 path issued (LEOD_FORCE_COLLECTIVES=1: SyncBatchNorm statistics, gradient buckets) -- against the same steps with
+    every exchange through torch.distributed's RCCL process group: with one rank a sum over ranks is the identity, so the two runs
+    execute the same arithmetic.  ``setup`` has verified the communicator against dist.all_reduce in three dtypes before the first step."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    res = {}
+    for native in (True, False):
+        q = ctx.Queue()
+        port = 37000 + (os.getpid() % 2000) + (3 if native else 0) + (11 if plan else 0)
+        p = ctx.Process(target=_module_one_rank_rccl_worker, args=(port, manifest, q, plan, native, 4))
+        p.start()
+        res[native] = q.get(timeout=600)
+        p.join(120)
+        assert p.exitcode == 0
+    assert res[True][2] >= 10 and res[False][2] == 0                             # Python-side calls of leod_comm_allreduce (eager steps, bucket releases)
+    if plan:
+        # recorded SyncBatchNorm exchanges are ops of the plans (replayed from C), only the bucket releases remain host callbacks;
+        # through torch.distributed every exchange closes a plan segment
+        (fn, bn), (ft, bt) = res[True][4], res[False][4]
+        assert fn['collectives'] >= 10 and bn['collectives'] >= 10 and fn['callbacks'] == 0 and bn['callbacks'] <= 8, (fn, bn)
+        assert ft['collectives'] == 0 and ft['callbacks'] >= 10 and bt['callbacks'] >= 10, (ft, bt)
+    else:
+        assert res[True][3] == res[False][3] > 0                                 # the same SyncBatchNorm exchanges either way
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=3e-4, atol=1e-5)
+    d = np.abs(res[True][1] - res[False][1])
+    assert d.max() < 2e-3 and (d > 2e-6 + 1e-4 * np.abs(res[False][1])).mean() < 5e-3
+
+
 def test_module_world2_through_reference_surface(gpu, manifest):
     """N > 1 through the surface train.py uses (fetch_model_module / configure_optimizers / training_step), two ranks on one GPU
     over gloo: replicas bit-identical after the step (one flat all-reduce inside FlatAdamW.step), BatchNorm running statistics
