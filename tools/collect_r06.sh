@@ -28,6 +28,13 @@ done
 python bench.py --pseudo --batch 16 --seq-len 21 --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_line_pseudo.json
 python bench.py --dataset gen4 --full-res --size base --seq-len 11 --batch 2 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_line_1mpx.json
 python bench.py --dataset gen4 --size base --seq-len 5 --batch 12 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_line_gen4ds2.json
+# 3b. 1 Mpx: kernel stats (single stream) + per-launch table; one rank with every collective of the N > 1 path issued
+D=$OUT/prof_1mpx; rm -rf $D
+rocprofv3 --kernel-trace --stats -d $D -o b -- python bench.py --dataset gen4 --full-res --size base --seq-len 11 --batch 2 --steps 5 --warmup 4 --no-cpu-baseline --no-second-dtype --no-roofline --no-plan --single-stream > $D.log 2>&1
+python tools/rocprof_summary.py $D $OUT/bench_1mpx_single_steps5_kernel_stats.csv > /dev/null 2>&1
+rm -rf $D
+python bench.py --dataset gen4 --full-res --size base --seq-len 11 --batch 2 --steps 20 --warmup 5 --no-cpu-baseline --no-second-dtype --dump-calls $OUT/calls_1mpx_single_stream_step.txt 2>/dev/null | tail -1 > /dev/null
+(export LEOD_FORCE_COLLECTIVES=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533; python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-second-dtype --no-roofline 2>/dev/null | grep '^{' | tail -1 > $OUT/bench_line_forced_collectives.json)
 # 4. HBM traffic of the roofline family (PMC, family markers; separate FETCH_SIZE / WRITE_SIZE passes)
 bash tools/pmc_bench_traffic.sh > /dev/null 2>&1
 for DT in 16f bf16 f32; do cp $ROOT/gpurun_out/traffic/$DT.csv $OUT/hbm_traffic_pmc_$DT.csv; cp $ROOT/gpurun_out/traffic/$DT.json $OUT/traffic_$DT.json; done
