@@ -264,6 +264,8 @@ def pseudo_main(args):
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
+        from leod_amd.comm import NativeComm
+        NativeComm.shutdown()
         dist.destroy_process_group()
 
 
@@ -540,6 +542,8 @@ def main():
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
+        from leod_amd.comm import NativeComm
+        NativeComm.shutdown()
         dist.destroy_process_group()
 
 

@@ -574,3 +574,19 @@ def test_list_helpers_and_temporal_wrapper():
     assert a == [[2, 4], [6]] and b == [[11, 21], [31]] and n == 3
     a, b, n = double_and_count([1, 2, 3], [4, 5, 6], k=3)
     assert a == [3, 6, 9] and b == [5, 6, 7] and n == 3
+
+
+def test_native_comm_stays_off_without_rccl_ranks():
+    """leod_amd/comm.py: no process group, a gloo group or CPU tensors -> the exchanges stay with torch.distributed (NativeComm inactive),
+    and the communicator entry points of the library report 'not initialised' instead of touching RCCL."""
+    import ctypes
+    from leod_amd import _lib
+    from leod_amd.comm import NativeComm
+    assert NativeComm.setup() is False and not NativeComm.active
+    t = torch.zeros(4)
+    assert not NativeComm.usable(t)
+    lib = _lib.lib()
+    assert lib.leod_comm_world() == 0
+    assert lib.leod_comm_allreduce(ctypes.c_void_p(t.data_ptr()), 4, 0, None) == -3
+    assert b'not initialised' in lib.leod_comm_last_error()
+    assert lib.leod_comm_destroy() == 0

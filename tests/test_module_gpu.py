@@ -537,7 +537,9 @@ def test_module_200_step_trajectory_vs_reference(gpu, golden_dir, manifest):
                 np.testing.assert_allclose(got[:3], ref[:3], rtol=5e-4)          # the deterministic start of the schedule
             else:       # 16-bit rounding may flip a SimOTA decision of these 13 boxes (measured at step 0: 13 instead of 12 matched boxes, loss -4.7 %)
                 np.testing.assert_allclose(got[:3], ref[:3], rtol=8e-2)
-            assert got[-20:].mean() < 0.85 * got[:20].mean()                      # it learns (16.5 -> ~12.9)
+            # it learns (16.5 -> ~12.9); the bound leaves the run-to-run spread of the final level (0.90-1.09 x the reference's over the rounds'
+            # runs, 1.16 allowed below) inside: 0.85 failed once in round 6 on a bf16 run that ended at 1.085 x
+            assert got[-20:].mean() < 0.93 * got[:20].mean()
             assert d.max() <= 0.20 and abs(fin - 1.0) <= 0.16, (mode, d.max(), fin)
             del mod, opt, sched, oc
             torch.cuda.empty_cache()
