@@ -343,6 +343,10 @@ int leod_cat2_up_bwd(const float* dout, float* da, float* db, int B, int H, int 
  * frames added into the gradient of a stage's output map (the `selected_indices` gather of BackboneFeatureSelector, modules/utils/detection.py:120-157,
  * differentiated).  No atomics: the indices of one call must be distinct. */
 int leod_rows_index_add(float* dst, const float* src, const long* idx, int nsel, long row_floats, int nrows_dst, leod_stream_t stream);
+/* hflip TTA input of the pseudo-label pass (modules/pseudo_labeler.py:469-470: cat([ev, flip(ev, -1)], batch dim)) in one pass:
+ * frames[t] = [B, rows_per_sample, W] bytes (T device pointers in a HOST array), out = [T, 2B, rows_per_sample, W]:
+ * out[t, b] = frames[t][b], out[t, B + b, r, x] = frames[t][b, r, W - 1 - x]. */
+int leod_stack_hflip_u8(const void* const* frames, int T, void* out, int B, long rows_per_sample, int W, leod_stream_t stream);
 /* StackedHistogram.construct (data/utils/representations.py:78-123): int64 events -> uint8 [2*bins,H,W]. */
 int leod_voxelize_u8(const long* x, const long* y, const long* pol, const long* t, long n_events, int* counts_ws,
                      unsigned char* out, int bins, int H, int W, int count_cutoff, int fastmode, leod_stream_t stream);

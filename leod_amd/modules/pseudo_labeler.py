@@ -243,11 +243,17 @@ class PseudoLabeler(Module):
         (pseudo_labeler.py:469-470,493)."""
         data = batch[DATA_KEY]
         assert DataType.AUGM_STATE not in data
-        ev = th.stack(data[DataType.EV_REPR])
-        B = ev.shape[1]
+        frames = data[DataType.EV_REPR]
+        hflip = self.tta_cfg.enable and self.tta_cfg.hflip
+        B = frames[0].shape[0]
+        if hflip and frames[0].is_cuda and frames[0].element_size() == 1:
+            ev = ops.stack_hflip_u8([f.contiguous() for f in frames])        # raw uint8 voxels: frames + flipped copies in one pass
+        else:
+            ev = th.stack(frames)
+            if hflip:
+                ev = th.cat([ev, th.flip(ev, dims=[-1])], dim=1)
         data['is_hflip'] = np.array([False] * B, dtype=bool)
-        if self.tta_cfg.enable and self.tta_cfg.hflip:
-            ev = th.cat([ev, th.flip(ev, dims=[-1])], dim=1)
+        if hflip:
             new = {}
             for k in (DataType.IS_FIRST_SAMPLE, DataType.IS_LAST_SAMPLE, DataType.IS_REVERSED):
                 new[k] = th.cat([data[k]] * 2, dim=-1)

@@ -1177,6 +1177,19 @@ def set_scalars4(dst, a, b, c, d):
     check(_l().leod_set_scalars4(_p(dst), float(a), float(b), float(c), float(d), _stream()), 'set_scalars4')
 
 
+def stack_hflip_u8(frames) -> torch.Tensor:
+    """T frame tensors [B, ...spatial..., W] (uint8 / bool / int8, same shape, contiguous) -> [T, 2B, ..., W]: the frames and, behind them on
+    the batch axis, their horizontally flipped copies (torch.cat([torch.stack(frames), torch.stack(frames).flip(-1)], 1)) in one pass."""
+    f0 = frames[0]
+    if f0.element_size() != 1 or any(f.shape != f0.shape or f.dtype is not f0.dtype or not f.is_cuda or not f.is_contiguous() for f in frames):
+        raise LeodHipError('stack_hflip_u8: contiguous one-byte device tensors of one shape expected')
+    B, W = f0.shape[0], f0.shape[-1]
+    out = torch.empty((len(frames), 2 * B) + tuple(f0.shape[1:]), dtype=f0.dtype, device=f0.device)
+    check(_l().leod_stack_hflip_u8(_ptr_array(frames), len(frames), ctypes.c_void_p(out.data_ptr()), B, f0.numel() // (B * W), W, _stream()),
+          'stack_hflip_u8')
+    return out
+
+
 def voxelize_u8(x, y, pol, t, bins, height, width, count_cutoff=None, fastmode=True):
     for a in (x, y, pol, t):
         _ck(a, torch.int64, 'events')

@@ -840,6 +840,17 @@ def test_voxelize_golden(ops, golden_dir):
         assert np.array_equal(rep.cpu().numpy(), g[f'{name}_rep'])
 
 
+@pytest.mark.parametrize('T,B,C,H,W', [(21, 4, 20, 24, 304), (3, 2, 5, 7, 20), (2, 3, 4, 5, 7), (40, 1, 2, 3, 16)])
+def test_stack_hflip_u8(ops, T, B, C, H, W):
+    """hflip TTA input of the pseudo-label pass (pseudo_labeler.py:469-470) in one launch: 16-byte, 4-byte and scalar row vectors, more
+    than 32 frames (two launches) -- exactly torch.cat([stack, flip(stack)], batch)."""
+    g = torch.Generator().manual_seed(5)
+    frames = [torch.randint(0, 256, (B, C, H, W), generator=g, dtype=torch.uint8).to(DEV) for _ in range(T)]
+    out = ops.stack_hflip_u8(frames)
+    ev = torch.stack(frames)
+    assert torch.equal(out, torch.cat([ev, torch.flip(ev, dims=[-1])], dim=1))
+
+
 def test_mixed_density_golden(ops, golden_dir):
     """MixedDensityEventStack (data/utils/representations.py:132-221) through the package's class: the outputs recorded from the reference
     (bin edges at exact powers of 1/2, int8 wrap-around, cutoffs 0 / 5 / 127 / none), the oracle on a larger stream, empty input"""
