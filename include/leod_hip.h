@@ -200,6 +200,18 @@ long leod_conv_nhwc_wgrad_workspace_floats(int B, int H, int W, int Cin, int N, 
 int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, float* dbias, float* ws, int B, int H, int W, int Cin, int N,
                          int ks, int stride, int pad, leod_stream_t stream);
 
+/* Grouped 3x3 / stride-1 / pad-1 convolutions: n <= 8 independent problems of ONE (Cin, Cout) geometry in one launch -- the convs of equal
+ * depth in the cls / reg towers of the three head levels (yolo_head.py:61-145,208-222).  All array arguments are HOST arrays of length n
+ * (device pointers / sizes per problem); wpack[k] / wpack_valid[k] as in leod_conv_nhwc_fwd.  forward: y_k = conv(x_k, w_k) with the
+ * BatchNorm (sum, sumsq) of y_k into colstats[k] ([stat_rep[k]][2][Cout] doubles, zeroed; NULL: none).  dgrad: dx_k (+)= the input
+ * gradient from dy_k [B,H,W,N]; problems of one call must write different dx buffers.  -3: not coverable, run the problems singly. */
+int leod_conv3x3_group_fwd(int n, const float* const* x, const float* const* w, float* const* y, double* const* colstats,
+                           const int* stat_rep, void* const* wpack, const int* wpack_valid, const int* B, const int* H, const int* W,
+                           int Cin, int Cout, leod_stream_t stream);
+int leod_conv3x3_group_dgrad(int n, const float* const* dy, const float* const* w, float* const* dx, const int* accumulate,
+                             void* const* wpack, const int* wpack_valid, const int* B, const int* H, const int* W, int Cin, int N,
+                             leod_stream_t stream);
+
 /* Depthwise convolution (groups == channels) on NHWC maps, w[C,1,ks,ks]: the depthwise half of DWConv (network_blocks.py:57-76, selected
  * by `depthwise` at yolo_pafpn.py:37 / yolo_head.py:52) and conv3x3_dws of the ConvLSTM (models/layers/rnn.py:20-30,50-55).  Same epilogue
  * options as leod_conv_nhwc_fwd: +bias, colstats [stat_rep,2,C] double += (sum, sumsq), or eval BatchNorm folded + SiLU.  C % 4 == 0.

@@ -9,6 +9,11 @@ int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, i
                    int Cin, int Cout, int transposed, void* wpack, hipStream_t stream, int stride = 1, int packed = 0,
                    const float* bn_w = nullptr, const float* bn_b = nullptr, const float* bn_rm = nullptr, const float* bn_rv = nullptr,
                    float bn_eps = 1e-5f);      // bn_w != NULL: eval-mode BatchNorm + SiLU applied to the finished rows (forward only)
+// n <= 8 independent stride-1 problems of one (Cin, Cout) geometry in one launch (forward with statistics, or transposed = 1: input gradients)
+bool conv3s1_group_supported(int n, const int* H, const int* W, int Cin, int Cout);
+int conv3s1_group(int n, const float* const* x, const float* const* w, float* const* y, double* const* colstats, const int* stat_rep,
+                  const int* accumulate, const int* B, const int* H, const int* W, int Cin, int Cout, int transposed, void* const* wpack,
+                  const int* packed, hipStream_t stream);
 bool conv3s2_fwd_supported(int B, int H, int W, int Cin, int Cout);      // forward of a stride-2 conv on the same kernel (stride = 2, H, W: input size)
 // weight gradient of a 3x3 / pad-1 conv of stride 1 or 2 (x [B,H,W,Cin], dy [B,H/stride,W/stride,Cout])
 bool conv3_wgrad_supported(int H, int W, int Cin, int Cout, int stride);

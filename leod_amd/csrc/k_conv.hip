@@ -526,6 +526,35 @@ static int launch_stem_u8_wgrad(const float* dy, const uint8_t* x, float* dW, in
     return leod_launch_status();
 }
 
+// ---- grouped 3x3 / stride-1 / pad-1 convolutions: n <= 8 independent problems of ONE channel geometry in one launch (k_conv3.hip, C3Group) ----
+// The convs of equal depth in the cls / reg towers of the three head levels (yolo_head.py:61-145 of the reference builds them as separate
+// modules; yolo_head.py:208-222 runs them level by level).  Arrays are HOST arrays of length n.  -3: not coverable (run the problems singly).
+LEOD_API int leod_conv3x3_group_fwd(int n, const float* const* x, const float* const* w, float* const* y, double* const* colstats,
+                                    const int* stat_rep, void* const* wpack, const int* wpack_valid, const int* B, const int* H, const int* W,
+                                    int Cin, int Cout, hipStream_t stream) {
+    if (n < 1 || n > 8 || !x || !w || !y || !colstats || !stat_rep || !wpack || !wpack_valid || !B || !H || !W) return LEOD_ERR_ARG;
+    for (int k = 0; k < n; ++k) if (!x[k] || !w[k] || !y[k] || !wpack[k]) return LEOD_ERR_ARG;
+    if (!conv3s1_group_supported(n, H, W, Cin, Cout)) return LEOD_ERR_UNSUPPORTED;
+    LeodFwdScope fwd_scope;
+    int zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return conv3s1_group(n, x, w, y, colstats, stat_rep, zeros, B, H, W, Cin, Cout, 0, wpack, wpack_valid, stream);
+}
+// dx_k [B,H,W,Cin] (+)= dgrad of y_k = conv3x3(x_k, w_k[N][Cin][3][3]) from dy_k [B,H,W,N]; accumulate[k] != 0: dx_k += (problems of one
+// launch must write DIFFERENT dx buffers)
+LEOD_API int leod_conv3x3_group_dgrad(int n, const float* const* dy, const float* const* w, float* const* dx, const int* accumulate,
+                                      void* const* wpack, const int* wpack_valid, const int* B, const int* H, const int* W, int Cin, int N,
+                                      hipStream_t stream) {
+    if (n < 1 || n > 8 || !dy || !w || !dx || !accumulate || !wpack || !wpack_valid || !B || !H || !W) return LEOD_ERR_ARG;
+    for (int k = 0; k < n; ++k) {
+        if (!dy[k] || !w[k] || !dx[k] || !wpack[k]) return LEOD_ERR_ARG;
+        for (int j = 0; j < k; ++j) if (dx[j] == dx[k]) return LEOD_ERR_ARG;
+    }
+    if (!conv3s1_group_supported(n, H, W, N, Cin)) return LEOD_ERR_UNSUPPORTED;
+    double* nostats[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return conv3s1_group(n, dy, w, dx, nostats, zeros, accumulate, B, H, W, N, Cin, 1, wpack, wpack_valid, stream);
+}
+
 LEOD_API int leod_stem_conv_wgrad(const float* dy, const void* x, int x_is_u8, float* dw, int B, int Cin, int H, int W,
                                   int Hp, int Wp, int N, int ks, int stride, int pad, hipStream_t stream) {
     if (!dy || !x || !dw) return LEOD_ERR_ARG;

@@ -44,10 +44,19 @@ __global__ __launch_bounds__(256) void conv3_pack_kernel(const float* __restrict
 struct BnEval { const float* w; const float* b; const float* rm; const float* rv; float eps; };
 
 // OF: operand format, 1 = bf16 (also the dgrad form of every mode), 2 = fp16 (forward of precision mode 16f; wp packed as fp16)
+// One problem of a launch.  A launch carries up to 8 independent problems of one channel geometry (blockIdx.z): the convs of equal depth in
+// the cls / reg towers of the three head levels are six launches' worth of work for one launch latency, and the small levels (2560 and 10240
+// pixels) no longer leave most of the chip idle while they run (round 6).  nblocks: workgroups (blockIdx.x) this problem uses.
+struct C3Prob { const float* x; const bf16_t* wp; float* y; double* colstats; int stat_rep, accumulate, B, H, W, RH, WSo, nblocks; };
+struct C3Group { C3Prob p[8]; };
+
 template <int KC, int NTO, int TW, int S = 1, int OF = 1>
-__global__ __launch_bounds__(256) void conv3s1_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wp, float* __restrict__ y,
-                                                       double* __restrict__ colstats, int stat_rep, int accumulate,
-                                                       int B, int H, int W, int Cout, int RH, int WSo, BnEval bne) {
+__global__ __launch_bounds__(256) void conv3s1_kernel(C3Group grp, int Cout, BnEval bne) {
+    const C3Prob& pr = grp.p[blockIdx.z];
+    if ((int)blockIdx.x >= pr.nblocks) return;
+    const float* __restrict__ x = pr.x; const bf16_t* __restrict__ wp = pr.wp; float* __restrict__ y = pr.y; double* __restrict__ colstats = pr.colstats;
+    const int stat_rep = pr.stat_rep, accumulate = pr.accumulate, B = pr.B, H = pr.H, W = pr.W, RH = pr.RH, WSo = pr.WSo;
+    (void)B;
     // WSo: output columns per workgroup (Wo % WSo == 0).  Maps too wide for a (RH + 2)-row halo of full rows in LDS (160 columns x 128
     // channels) are cut into column segments; a segment is a map of its own width for the halo and the pixel -> lane mapping, only the
     // global addresses know the full row.
@@ -755,28 +764,37 @@ bool conv3s1_supported(int H, int W, int Cin, int Cout) {
 size_t conv3s1_pack_bytes(int Cin, int Cout) { return (size_t)9 * Cin * Cout * sizeof(bf16_t); }
 
 // x [B,H,W,Cin] -> y [B,H,W,Cout].  transposed = 0: y = conv3x3(x, w[Cout][Cin][3][3]); 1: the dgrad of a conv whose weight is
-// w[Cin][Cout][3][3] (x = dy).  wpack: scratch of conv3s1_pack_bytes.
-int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, int stat_rep, int accumulate, int B, int H, int W,
-                   int Cin, int Cout, int transposed, void* wpack, hipStream_t stream, int stride, int packed,
-                   const float* bn_w, const float* bn_b, const float* bn_rm, const float* bn_rv, float bn_eps) {
-    const BnEval bne{bn_w, bn_b, bn_rm, bn_rv, bn_eps};
-    if (bn_w && (accumulate || colstats || !bn_b || !bn_rm || !bn_rv)) return LEOD_ERR_ARG;
-    bf16_t* wp = reinterpret_cast<bf16_t*>(wpack);
+// w[Cin][Cout][3][3] (x = dy).  wpack: scratch of conv3s1_pack_bytes.  n problems of one (Cin, Cout, stride) geometry in one launch.
+int conv3s1_group_launch(int n, const float* const* x, const float* const* w, float* const* y, double* const* colstats, const int* stat_rep,
+                         const int* accumulate, const int* B, const int* H, const int* W, int Cin, int Cout, int transposed,
+                         void* const* wpack, const int* packed, hipStream_t stream, int stride, const BnEval& bne) {
+    if (n < 1 || n > 8) return LEOD_ERR_ARG;
     const long total = (long)9 * Cin * Cout;
     const int of = (!transposed && leod_opfmt() == 2) ? 2 : 1;      // forward launches of precision mode 16f: fp16 halo and fp16 packed weights
-    // the packed layout is [tap][out rows][k]; for the dgrad the stored weight is [N = Cin of this call][C = Cout of this call]
-    if (!packed)
-        hipLaunchKernelGGL(conv3_pack_kernel, dim3((int)min((long)1024, (total + 255) / 256)), dim3(256), 0, stream, w, wp,
-                           transposed ? Cin : Cout, transposed ? Cout : Cin, transposed ? 1 : 0, of == 2 ? 1 : 0);
     const int nto = conv3_nto(Cin, Cout, stride);
-    int csegs = 1, RH = 0;
-    if (!nto || !conv3_geometry(H, W, Cin, nto, stride, csegs, RH)) return LEOD_ERR_UNSUPPORTED;
-    const int Ho = H / stride, Wo = W / stride, WSo = Wo / csegs;
-    // (Two workgroups per CU for the large launches of the inference passes -- fewer output rows per workgroup, <= 80 KB of LDS each --
-    // measured equal: 26.55 vs 26.56 ms per pseudo-label chunk, profiles/r04_a_graph_ab.txt; one workgroup per CU and the smaller halo overlap stay.)
-    const dim3 grid(B * cdiv(Ho, RH) * csegs, Cout / (16 * nto));
-    const size_t smem = conv3_smem(RH, W / csegs, Cin, nto, stride);
-    const int tw = cdiv(cdiv(min(RH, Ho) * WSo, 16), 4) <= 2 ? 2 : 3;          // row tiles per wave
+    if (!nto) return LEOD_ERR_UNSUPPORTED;
+    C3Group g{};
+    int tw = 2, maxblocks = 0;
+    size_t smem = 0;
+    for (int k = 0; k < n; ++k) {
+        if (bne.w && (accumulate[k] || colstats[k])) return LEOD_ERR_ARG;
+        int csegs = 1, RH = 0;
+        if (!conv3_geometry(H[k], W[k], Cin, nto, stride, csegs, RH)) return LEOD_ERR_UNSUPPORTED;
+        const int Ho = H[k] / stride, Wo = W[k] / stride, WSo = Wo / csegs;
+        bf16_t* wp = reinterpret_cast<bf16_t*>(wpack[k]);
+        // the packed layout is [tap][out rows][k]; for the dgrad the stored weight is [N = Cin of this call][C = Cout of this call]
+        if (!packed[k])
+            hipLaunchKernelGGL(conv3_pack_kernel, dim3((int)min((long)1024, (total + 255) / 256)), dim3(256), 0, stream, w[k], wp,
+                               transposed ? Cin : Cout, transposed ? Cout : Cin, transposed ? 1 : 0, of == 2 ? 1 : 0);
+        // (Two workgroups per CU for the large launches of the inference passes -- fewer output rows per workgroup, <= 80 KB of LDS each --
+        // measured equal: 26.55 vs 26.56 ms per pseudo-label chunk, profiles/r04_a_graph_ab.txt; one workgroup per CU and the smaller halo overlap stay.)
+        const int nb = B[k] * cdiv(Ho, RH) * csegs;
+        g.p[k] = C3Prob{x[k], wp, y[k], colstats[k], stat_rep[k], accumulate[k], B[k], H[k], W[k], RH, WSo, nb};
+        maxblocks = max(maxblocks, nb);
+        smem = max(smem, conv3_smem(RH, W[k] / csegs, Cin, nto, stride));
+        if (cdiv(cdiv(min(RH, Ho) * WSo, 16), 4) > 2) tw = 3;       // row tiles per wave: the largest any problem needs
+    }
+    const dim3 grid(maxblocks, Cout / (16 * nto), n);
 #define C3_CASE(KCV, NTOV, SV) C3_CASE2(KCV, NTOV, 2, SV, 1) C3_CASE2(KCV, NTOV, 3, SV, 1) C3_CASE2(KCV, NTOV, 2, SV, 2) C3_CASE2(KCV, NTOV, 3, SV, 2)
 #define C3_CASE2(KCV, NTOV, TWV, SV, OFV)                                                                                            \
     if (Cin == 16 * KCV && nto == NTOV && tw == TWV && stride == SV && of == OFV) {                                                   \
@@ -785,7 +803,7 @@ int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, i
             hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3s1_kernel<KCV, NTOV, TWV, SV, OFV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr_set = true;                                                                                                         \
         }                                                                                                                            \
-        hipLaunchKernelGGL((conv3s1_kernel<KCV, NTOV, TWV, SV, OFV>), grid, dim3(256), smem, stream, x, wp, y, colstats, stat_rep, accumulate, B, H, W, Cout, RH, WSo, bne); \
+        hipLaunchKernelGGL((conv3s1_kernel<KCV, NTOV, TWV, SV, OFV>), grid, dim3(256), smem, stream, g, Cout, bne);                   \
         return leod_launch_status();                                                                                                 \
     }
     C3_CASE(3, 3, 1) C3_CASE(3, 6, 1) C3_CASE(6, 3, 1) C3_CASE(6, 6, 1) C3_CASE(12, 3, 1) C3_CASE(12, 6, 1)
@@ -794,6 +812,30 @@ int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, i
 #undef C3_CASE
 #undef C3_CASE2
     return LEOD_ERR_UNSUPPORTED;
+}
+
+int conv3s1_launch(const float* x, const float* w, float* y, double* colstats, int stat_rep, int accumulate, int B, int H, int W,
+                   int Cin, int Cout, int transposed, void* wpack, hipStream_t stream, int stride, int packed,
+                   const float* bn_w, const float* bn_b, const float* bn_rm, const float* bn_rv, float bn_eps) {
+    const BnEval bne{bn_w, bn_b, bn_rm, bn_rv, bn_eps};
+    if (bn_w && (!bn_b || !bn_rm || !bn_rv)) return LEOD_ERR_ARG;
+    return conv3s1_group_launch(1, &x, &w, &y, &colstats, &stat_rep, &accumulate, &B, &H, &W, Cin, Cout, transposed, &wpack, &packed, stream,
+                                stride, bne);
+}
+
+// n independent 3x3 / stride-1 / pad-1 problems of one channel geometry in ONE launch (see C3Group): forward with BatchNorm statistics
+// (transposed = 0) or input gradients (transposed = 1: x = dy, y = dx, Cin = the conv's output channels).  LEOD_ERR_UNSUPPORTED: run them singly.
+int conv3s1_group(int n, const float* const* x, const float* const* w, float* const* y, double* const* colstats, const int* stat_rep,
+                  const int* accumulate, const int* B, const int* H, const int* W, int Cin, int Cout, int transposed, void* const* wpack,
+                  const int* packed, hipStream_t stream) {
+    const BnEval none{nullptr, nullptr, nullptr, nullptr, 0.f};
+    return conv3s1_group_launch(n, x, w, y, colstats, stat_rep, accumulate, B, H, W, Cin, Cout, transposed, wpack, packed, stream, 1, none);
+}
+bool conv3s1_group_supported(int n, const int* H, const int* W, int Cin, int Cout) {
+    if (n < 1 || n > 8) return false;
+    for (int k = 0; k < n; ++k)
+        if (!conv3s1_supported(H[k], W[k], Cin, Cout)) return false;
+    return true;
 }
 
 // shapes of the direct weight-gradient kernel: stride 1 or 2 (even H, W), output channels in slices of 96, input channels 48 or in

@@ -580,11 +580,16 @@ def _conv_bn_fwd(members, need):
         return (32 if sync else x.shape[0]) * ((x.shape[1] - 1) // stride + 1) * ((x.shape[2] - 1) // stride + 1)
     reps = [ops.stat_replicas(rows_of(m[1], m[5])) for m in members]
     block = ops.StatArena.zeros((sum(2 * R * m[2].shape[0] for m, R in zip(members, reps)),), dev)
-    zs, off = [], 0
+    zs, off, stat_slices = None, 0, []
     for (mod, x, conv_w, bn_w, bn_b, stride), R in zip(members, reps):
         N = conv_w.shape[0]
-        zs.append(ops.conv_nhwc_fwd(x, conv_w, None, stride=stride, colstats=block[off:off + 2 * R * N].view(R, 2, N)))
+        stat_slices.append(block[off:off + 2 * R * N].view(R, 2, N))
         off += 2 * R * N
+    # members of one channel geometry (the tower convs of equal depth over the head levels) as ONE launch
+    if all(m[5] == 1 for m in members) and ops.conv3x3_group_ok([m[1] for m in members], [m[2] for m in members]):
+        zs = ops.conv3x3_group_fwd([m[1] for m in members], [m[2] for m in members], stat_slices)
+    if zs is None:
+        zs = [ops.conv_nhwc_fwd(x, conv_w, None, stride=stride, colstats=sl) for (mod, x, conv_w, bn_w, bn_b, stride), sl in zip(members, stat_slices)]
     images = _SYNC_BN['images'] if sync else None
     if sync:
         assert images is not None, 'SyncBatchNorm: functions.sync_bn_begin(n_images) must open the pass (YoloXDetector.forward_detect does)'
@@ -634,6 +639,7 @@ def _conv_bn_bwd(members):
         hold = sync and PlanRecorder.current is not None and not _capture_collectives(_SYNC_BN['group'])
         prev_hold, WgradSide.hold_main = WgradSide.hold_main, hold or WgradSide.hold_main
         shared_dx = {}
+        rounds = ([], [])                                   # dgrad problems: (dz, conv_w, x.shape, stride, out, accumulate) -- first writers, then adders
         for (mod, x, z, mean, rstd, conv_w, bn_w, bn_b, stride, count, count_dev, dy, need_dx), sl in zip(live, slices):
             dz = ops.bn_silu_bwd_apply(dy, z, mean, rstd, bn_w, bn_b, sl, grad_buf(mod.bn.weight), grad_buf(mod.bn.bias), count,
                                        count_dev=count_dev)
@@ -646,10 +652,20 @@ def _conv_bn_bwd(members):
             # gradients in the dgrad epilogue of the later member instead of as two autograd edges summed by an extra add kernel
             key = (x.data_ptr(), tuple(x.shape), stride)
             if key in shared_dx:
-                ops.conv_nhwc_dgrad(dz, conv_w, x.shape, stride=stride, out=shared_dx[key], accumulate=True)
+                rounds[1].append((dz, conv_w, x.shape, stride, shared_dx[key], True))
                 dxs[id(mod)] = None
             else:
-                dxs[id(mod)] = shared_dx[key] = ops.conv_nhwc_dgrad(dz, conv_w, x.shape, stride=stride)
+                dxs[id(mod)] = shared_dx[key] = ops._empty(tuple(x.shape), dz)
+                rounds[0].append((dz, conv_w, x.shape, stride, shared_dx[key], False))
+        for probs in rounds:
+            # the input gradients of one round write different buffers: one launch where the members share a channel geometry (head towers)
+            done = False
+            if len(probs) > 1 and all(p[3] == 1 for p in probs) and ops.conv3x3_group_ok([p[0] for p in probs], [p[1].transpose(0, 1) for p in probs]):
+                done = ops.conv3x3_group_dgrad([p[0] for p in probs], [p[1] for p in probs], [p[2] for p in probs], [p[4] for p in probs],
+                                               [p[5] for p in probs])
+            if not done:
+                for dz, conv_w, xshape, stride, out, acc in probs:
+                    ops.conv_nhwc_dgrad(dz, conv_w, xshape, stride=stride, out=out, accumulate=acc)
         WgradSide.hold_main = prev_hold
     return [dxs.get(id(m[0])) for m in members]
 
@@ -689,11 +705,10 @@ class BaseConvGroupFn(Function):
 
 
 def base_conv_group(mods, xs):
-    """[BaseConv], [NHWC maps] -> [outputs]; grouped into one node (one statistics exchange) in SyncBatchNorm training, plain
-    per-layer calls otherwise."""
-    # members reading the same map: their input gradients are summed inside the node (LEOD_GROUP_SHARED=0: separate nodes, autograd adds)
-    shared = len({id(x) for x in xs}) < len(xs) 
-    if len(mods) > 1 and mods[0].training and (_sync_bn_on() or (shared and torch.is_grad_enabled() and xs[0].is_cuda)):
+    """[BaseConv], [NHWC maps] -> [outputs]: independent layers as ONE autograd node in training -- one statistics exchange per direction under
+    SyncBatchNorm, members of one channel geometry as one launch per kernel kind (``ops.conv3x3_group_*``), input gradients of members
+    that read the same map summed inside the node; plain per-layer calls in evaluation."""
+    if len(mods) > 1 and mods[0].training and (_sync_bn_on() or (torch.is_grad_enabled() and xs[0].is_cuda)):
         params = []
         for m in mods:
             params += [m.conv.weight, m.bn.weight, m.bn.bias]

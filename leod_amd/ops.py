@@ -717,6 +717,54 @@ def conv_nhwc_dgrad(dy, w, x_shape, stride=1, out=None, accumulate=False):
     return out
 
 
+def _int_array(v):
+    return (ctypes.c_int * len(v))(*[int(a) for a in v])
+
+
+def conv3x3_group_ok(xs, ws) -> bool:
+    """n <= 8 dense 3x3 convs of one (Cin, Cout) geometry on fp32 NHWC maps: candidates for ``conv3x3_group_fwd`` / ``_dgrad``"""
+    w0 = ws[0]
+    return (1 < len(xs) <= 8 and all(w.shape == w0.shape and w.dim() == 4 and w.shape[-1] == 3 and w.shape[-2] == 3 for w in ws)
+            and all(x.dim() == 4 and x.shape[-1] == w0.shape[1] and x.dtype is F32 and x.is_cuda for x in xs) and not _is_depthwise(w0, xs[0].shape[-1]))
+
+
+def conv3x3_group_fwd(xs, ws, colstats):
+    """[x_k [B,H,W,Cin]], [w_k [N,Cin,3,3]], [colstats_k: zero-filled float64 [R,2,N]] -> [y_k] in ONE launch (stride 1, pad 1), or None
+    where the direct kernel does not cover the geometry (run them singly)."""
+    n = len(xs)
+    for t in list(xs) + list(ws):
+        _ck(t, name='conv3x3_group')
+    for c in colstats:
+        _ck(c, torch.float64, 'colstats')
+    N, Cin = ws[0].shape[0], ws[0].shape[1]
+    ys = [_empty(tuple(x.shape[:3]) + (N,), x) for x in xs]
+    packs = [PackCache.get(w, ('fwd', x.shape[0], x.shape[1], x.shape[2], 1, False, False), N * Cin * 9) for x, w in zip(xs, ws)]
+    rc = _l().leod_conv3x3_group_fwd(n, _ptr_array(xs), _ptr_array(ws), _ptr_array(ys), _ptr_array(colstats),
+                                     _int_array([c.shape[0] if c.dim() == 3 else 1 for c in colstats]), _ptr_array([p for p, _ in packs]),
+                                     _int_array([v for _, v in packs]), _int_array([x.shape[0] for x in xs]), _int_array([x.shape[1] for x in xs]),
+                                     _int_array([x.shape[2] for x in xs]), Cin, N, _stream())
+    if rc == -3:
+        return None
+    check(rc, 'conv3x3_group_fwd')
+    return ys
+
+
+def conv3x3_group_dgrad(dys, ws, x_shapes, outs, accumulate) -> bool:
+    """outs[k] (+)= input gradient of conv(x_k, w_k) from dys[k] in ONE launch; False where not coverable (nothing was written)."""
+    n = len(dys)
+    for t in list(dys) + list(ws) + list(outs):
+        _ck(t, name='conv3x3_group')
+    N, Cin = ws[0].shape[0], ws[0].shape[1]
+    packs = [PackCache.get(w, ('dgrad', sh[0], sh[1], sh[2], 1), N * Cin * 9) for w, sh in zip(ws, x_shapes)]
+    rc = _l().leod_conv3x3_group_dgrad(n, _ptr_array(dys), _ptr_array(ws), _ptr_array(outs), _int_array([1 if a else 0 for a in accumulate]),
+                                       _ptr_array([p for p, _ in packs]), _int_array([v for _, v in packs]), _int_array([sh[0] for sh in x_shapes]),
+                                       _int_array([sh[1] for sh in x_shapes]), _int_array([sh[2] for sh in x_shapes]), Cin, N, _stream())
+    if rc == -3:
+        return False
+    check(rc, 'conv3x3_group_dgrad')
+    return True
+
+
 def conv_nhwc_wgrad(dy, x, dw, dbias=None, stride=1):
     for t, n in ((dy, 'dy'), (x, 'x'), (dw, 'dw'), (dbias, 'dbias')):
         _ck(t, name=n)
