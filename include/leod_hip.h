@@ -238,6 +238,21 @@ int leod_bn_silu_bwd_apply(const float* dy, const float* z, const float* mean, c
                            const float* b, const double* sums, int rep, float* dz, float* dw, float* db, int M, int N, double count,
                            const double* count_dev, int lddy, leod_stream_t stream);
 
+/* The three BatchNorm + SiLU launches above for n <= 8 layers of ONE channel count at once (the layers of equal depth over the head levels and
+ * branches): every array argument is a HOST array of length n holding what the single call takes for layer k.  run_mean / run_var /
+ * count_dev / lddy / dw / db may be NULL as arrays (none for any layer) or hold NULL / 0 entries. */
+int leod_bn_silu_fwd_group(int n, const float* const* z, const double* const* colstats, const int* stat_rep, const float* const* w,
+                           const float* const* b, float* const* y, float* const* save_mean, float* const* save_rstd, float* const* run_mean,
+                           float* const* run_var, const int* M, int N, const double* count, const double* const* count_dev, float eps,
+                           const float* momentum, leod_stream_t stream);
+int leod_bn_silu_bwd_reduce_group(int n, const float* const* dy, const float* const* z, const float* const* mean, const float* const* rstd,
+                                  const float* const* w, const float* const* b, double* const* sums, const int* rep, const int* M, int N,
+                                  const int* lddy, leod_stream_t stream);
+int leod_bn_silu_bwd_apply_group(int n, const float* const* dy, const float* const* z, const float* const* mean, const float* const* rstd,
+                                 const float* const* w, const float* const* b, double* const* sums, const int* rep, float* const* dz,
+                                 float* const* dw, float* const* db, const int* M, int N, const double* count,
+                                 const double* const* count_dev, const int* lddy, leod_stream_t stream);
+
 /* ---- YOLOX head tail (models/detection/yolox/models/yolo_head.py) --------------------------------- */
 
 /* cls/reg/obj 1x1 prediction convs of one level + grid decode (:216-222,289-332): out_train = decoded boxes + logits,

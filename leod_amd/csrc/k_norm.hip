@@ -254,12 +254,22 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_kernel(const float* __rest
 //   bwd1: sums[r][0][n] += sum du, sums[r][1][n] += sum du*xhat   with du = dy * silu'(u); workgroup b adds into copy r = b mod rep
 //   bwd2: dz = w*rstd*(du - sums0/M - xhat*sums1/M) with sums = the fold of the rep copies ; block 0: dw += sums1, db += sums0
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const float* __restrict__ z, const double* __restrict__ colstats, int rep,
-                                                          const float* __restrict__ w, const float* __restrict__ b,
-                                                          float* __restrict__ y, float* __restrict__ save_mean,
-                                                          float* __restrict__ save_rstd, float* __restrict__ run_mean,
-                                                          float* __restrict__ run_var, long M, int N, double count,
-                                                          const double* __restrict__ count_dev, float eps, float momentum) {
+// One problem of a BatchNorm launch; a launch carries up to 8 (blockIdx.y): the layers of equal depth over the head levels / branches share a
+// launch (round 6).  gx: workgroups (blockIdx.x) of this problem.
+struct BnFwdProb {
+    const float* z; const double* colstats; const float* w; const float* b; float* y; float* save_mean; float* save_rstd; float* run_mean;
+    float* run_var; const double* count_dev; long M; double count; float momentum; int rep, gx;
+};
+struct BnFwdGroup { BnFwdProb p[8]; };
+__global__ __launch_bounds__(256) void bn_silu_fwd_kernel(BnFwdGroup grp, int N, float eps) {
+    const BnFwdProb& pr = grp.p[blockIdx.y];
+    const int bx = blockIdx.x, gx = pr.gx;
+    if (bx >= gx) return;
+    const float* __restrict__ z = pr.z; const double* __restrict__ colstats = pr.colstats; const float* __restrict__ w = pr.w;
+    const float* __restrict__ b = pr.b; float* __restrict__ y = pr.y; float* __restrict__ save_mean = pr.save_mean;
+    float* __restrict__ save_rstd = pr.save_rstd; float* __restrict__ run_mean = pr.run_mean; float* __restrict__ run_var = pr.run_var;
+    const double* __restrict__ count_dev = pr.count_dev;
+    const long M = pr.M; double count = pr.count; const float momentum = pr.momentum; const int rep = pr.rep;
     // every workgroup folds the `rep` replicas of (sum, sumsq) once and keeps (mean, rstd) of all N channels in LDS: the
     // double-precision divide / sqrt runs once per channel and workgroup instead of once per element
     extern __shared__ float sstat[];                 // [2][N]: mean, rstd
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const float* __restric
         const double var = fmax(ss / count - mean * mean, 0.0);
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
         sstat[c] = (float)mean; sstat[N + c] = rstd;
-        if (blockIdx.x == 0) {
+        if (bx == 0) {
             save_mean[c] = (float)mean;
             save_rstd[c] = rstd;
             if (run_mean) {
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const float* __restric
     }
     __syncthreads();
     const long n4 = M * N / 4;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
+    for (long idx = (long)bx * blockDim.x + threadIdx.x; idx < n4; idx += (long)gx * blockDim.x) {
         const long e = idx * 4; const int c = (int)(e % N);
         const f4 v = ld4(z + e), mu = *reinterpret_cast<const f4*>(sstat + c), rs = *reinterpret_cast<const f4*>(sstat + N + c);
         const f4 ww = ld4(w + c), bb = ld4(b + c);
@@ -297,11 +307,19 @@ __global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const float* __restric
 // RPT rows per thread, all 2 * RPT 16-byte loads of a thread issued before the first use (the row loop of the previous version paid one
 // memory round trip per 4 rows: 13.7 us for a 2560-row map); the workgroup's sums go to replica blockIdx.x % rep of the
 // (sum du, sum du*xhat) block, so that the double atomics on one address are gridDim.x / rep deep (bn_silu_bwd_apply folds the replicas).
+struct BnBwdProb {
+    const float* dy; const float* z; const float* mean; const float* rstd; const float* w; const float* b; double* sums; float* dz; float* dw;
+    float* db; const double* count_dev; long M, lddy; double count; int rep, gx;
+};
+struct BnBwdGroup { BnBwdProb p[8]; };
 template <int RPT>
-__global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ z,
-                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                 const float* __restrict__ w, const float* __restrict__ b,
-                                                                 double* __restrict__ sums, int rep, long M, int N, long lddy) {
+__global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(BnBwdGroup grp, int N) {
+    const BnBwdProb& pr = grp.p[blockIdx.y];
+    const int bx = blockIdx.x;
+    if (bx >= pr.gx) return;
+    const float* __restrict__ dy = pr.dy; const float* __restrict__ z = pr.z; const float* __restrict__ mean = pr.mean;
+    const float* __restrict__ rstd = pr.rstd; const float* __restrict__ w = pr.w; const float* __restrict__ b = pr.b;
+    double* __restrict__ sums = pr.sums; const int rep = pr.rep; const long M = pr.M, lddy = pr.lddy;
     // thread t owns 4 consecutive channels c = 4*(t % (N/4)) and rows r0 + rstep * e; partial sums are combined in
     // LDS so that each workgroup issues ONE double atomic per (channel, statistic)
     // (fixed-order fold of the row lanes' partials in double: LDS float atomics made the sums -- and with them every gradient behind
@@ -312,7 +330,7 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const float* __
     const int rlane = threadIdx.x / ncg, rstep = blockDim.x / ncg;
     if (rlane < rstep) {
         const int c = 4 * cg;
-        const long r0 = (long)blockIdx.x * rstep * RPT + rlane;
+        const long r0 = (long)bx * rstep * RPT + rlane;
         f4 zv[RPT], dv[RPT];
 #pragma unroll
         for (int e = 0; e < RPT; ++e) {
@@ -337,7 +355,7 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const float* __
         *reinterpret_cast<f4*>(mine + N + c) = s1;
     }
     __syncthreads();
-    double* dst = sums + (size_t)(blockIdx.x % rep) * 2 * N;
+    double* dst = sums + (size_t)(bx % rep) * 2 * N;
     for (int c = threadIdx.x; c < 2 * N; c += blockDim.x) {
         double a = 0.0;
         for (int r = 0; r < rstep; ++r) a += (double)sred[(size_t)r * 2 * N + c];
@@ -345,12 +363,14 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_reduce_kernel(const float* __
     }
 }
 
-__global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ z,
-                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                const float* __restrict__ w, const float* __restrict__ b,
-                                                                const double* __restrict__ sums, int rep, float* __restrict__ dz,
-                                                                float* __restrict__ dw, float* __restrict__ db, long M, int N,
-                                                                double count, const double* __restrict__ count_dev, long lddy) {
+__global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(BnBwdGroup grp, int N) {
+    const BnBwdProb& pr = grp.p[blockIdx.y];
+    const int bx = blockIdx.x, gx = pr.gx;
+    if (bx >= gx) return;
+    const float* __restrict__ dy = pr.dy; const float* __restrict__ z = pr.z; const float* __restrict__ mean = pr.mean;
+    const float* __restrict__ rstd = pr.rstd; const float* __restrict__ w = pr.w; const float* __restrict__ b = pr.b;
+    const double* __restrict__ sums = pr.sums; float* __restrict__ dz = pr.dz; float* __restrict__ dw = pr.dw; float* __restrict__ db = pr.db;
+    const double* __restrict__ count_dev = pr.count_dev; const int rep = pr.rep; const long M = pr.M, lddy = pr.lddy; double count = pr.count;
     // every workgroup folds the `rep` replicas once and keeps per channel (sum du / count, sum du*xhat / count, w * rstd) in LDS:
     // the double-precision divides run once per channel and workgroup instead of twice per element
     extern __shared__ float sst[];                   // [3][N]
@@ -359,11 +379,11 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const float* __r
         double s0 = 0.0, s1 = 0.0;
         for (int r = 0; r < rep; ++r) { s0 += sums[(size_t)r * 2 * N + c]; s1 += sums[(size_t)r * 2 * N + N + c]; }
         sst[c] = (float)(s0 / count); sst[N + c] = (float)(s1 / count); sst[2 * N + c] = w[c] * rstd[c];
-        if (blockIdx.x == 0 && dw) { dw[c] += (float)s1; db[c] += (float)s0; }
+        if (bx == 0 && dw) { dw[c] += (float)s1; db[c] += (float)s0; }
     }
     __syncthreads();
     const long n4 = M * N / 4;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long)gridDim.x * blockDim.x) {
+    for (long idx = (long)bx * blockDim.x + threadIdx.x; idx < n4; idx += (long)gx * blockDim.x) {
         const long e = idx * 4; const int c = (int)(e % N);
         const f4 mu = ld4(mean + c), rs = ld4(rstd + c), ww = ld4(w + c), bb = ld4(b + c);
         const f4 xh = (ld4(z + e) - mu) * rs;
@@ -438,47 +458,93 @@ LEOD_API int leod_convlstm_gates_bwd(const float* dh, const float* dh2, const fl
     return leod_launch_status();
 }
 
+// ---- BatchNorm + SiLU launches: n <= 8 problems of ONE channel count per launch (arrays are HOST arrays of length n) ---------------------
+LEOD_API int leod_bn_silu_fwd_group(int n, const float* const* z, const double* const* colstats, const int* stat_rep, const float* const* w,
+                                    const float* const* b, float* const* y, float* const* save_mean, float* const* save_rstd,
+                                    float* const* run_mean, float* const* run_var, const int* M, int N, const double* count,
+                                    const double* const* count_dev, float eps, const float* momentum, hipStream_t stream) {
+    if (n < 1 || n > 8 || !z || !colstats || !stat_rep || !w || !b || !y || !save_mean || !save_rstd || !M || !count || !momentum || (N & 3)) return LEOD_ERR_ARG;
+    BnFwdGroup g{};
+    int gmax = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!z[k] || !colstats[k] || !w[k] || !b[k] || !y[k] || !save_mean[k] || !save_rstd[k]) return LEOD_ERR_ARG;
+        // every workgroup folds the stat_rep copies of (sum, sumsq): <= 1024 workgroups with a grid-stride row loop (4096 workgroups re-read
+        // up to 49 KB of replicas each)
+        const int gx = M[k] > 0 ? min(flat_grid((long)M[k] * N / 4), 1024) : 0;
+        g.p[k] = BnFwdProb{z[k], colstats[k], w[k], b[k], y[k], save_mean[k], save_rstd[k], run_mean ? run_mean[k] : nullptr,
+                           run_var ? run_var[k] : nullptr, count_dev ? count_dev[k] : nullptr, (long)M[k], count[k], momentum[k],
+                           stat_rep[k] > 1 ? stat_rep[k] : 1, gx};
+        gmax = max(gmax, gx);
+    }
+    if (gmax == 0) return LEOD_OK;
+    hipLaunchKernelGGL(bn_silu_fwd_kernel, dim3(gmax, n), dim3(256), 2 * N * sizeof(float), stream, g, N, eps);
+    return leod_launch_status();
+}
 LEOD_API int leod_bn_silu_fwd(const float* z, const double* colstats, int stat_rep, const float* w, const float* b, float* y,
                               float* save_mean, float* save_rstd, float* run_mean, float* run_var, int M, int N,
                               double count, const double* count_dev, float eps, float momentum, hipStream_t stream) {
     if (!z || !colstats || !w || !b || !y || !save_mean || !save_rstd || (N & 3)) return LEOD_ERR_ARG;
-    if (M <= 0) return LEOD_OK;
-    // every workgroup folds the stat_rep copies of (sum, sumsq): <= 1024 workgroups with a grid-stride row loop (4096 workgroups re-read
-    // up to 49 KB of replicas each)
-    hipLaunchKernelGGL(bn_silu_fwd_kernel, dim3(min(flat_grid((long)M * N / 4), 1024)), dim3(256), 2 * N * sizeof(float), stream, z, colstats,
-                       stat_rep > 1 ? stat_rep : 1, w, b, y,
-                       save_mean, save_rstd, run_mean, run_var, (long)M, N, count, count_dev, eps, momentum);
-    return leod_launch_status();
+    return leod_bn_silu_fwd_group(1, &z, &colstats, &stat_rep, &w, &b, &y, &save_mean, &save_rstd, &run_mean, &run_var, &M, N, &count, &count_dev,
+                                  eps, &momentum, stream);
 }
 
+static int bn_bwd_fill(BnBwdGroup& g, int n, const float* const* dy, const float* const* z, const float* const* mean, const float* const* rstd,
+                       const float* const* w, const float* const* b, double* const* sums, const int* rep, float* const* dz, float* const* dw,
+                       float* const* db, const int* M, int N, const double* count, const double* const* count_dev, const int* lddy) {
+    if (n < 1 || n > 8 || !dy || !z || !mean || !rstd || !w || !b || !sums || !rep || !M || (N & 3) || N / 4 > 256) return LEOD_ERR_ARG;
+    for (int k = 0; k < n; ++k) {
+        const int ld = lddy ? lddy[k] : 0;
+        if (!dy[k] || !z[k] || !mean[k] || !rstd[k] || !w[k] || !b[k] || !sums[k] || (ld && (ld < N || (ld & 3)))) return LEOD_ERR_ARG;
+        g.p[k] = BnBwdProb{dy[k], z[k], mean[k], rstd[k], w[k], b[k], sums[k], dz ? dz[k] : nullptr, dw ? dw[k] : nullptr, db ? db[k] : nullptr,
+                           count_dev ? count_dev[k] : nullptr, (long)M[k], (long)(ld ? ld : N), count ? count[k] : 1.0, rep[k] < 1 ? 1 : rep[k], 0};
+    }
+    return LEOD_OK;
+}
+LEOD_API int leod_bn_silu_bwd_reduce_group(int n, const float* const* dy, const float* const* z, const float* const* mean,
+                                           const float* const* rstd, const float* const* w, const float* const* b, double* const* sums,
+                                           const int* rep, const int* M, int N, const int* lddy, hipStream_t stream) {
+    BnBwdGroup g{};
+    const int rc = bn_bwd_fill(g, n, dy, z, mean, rstd, w, b, sums, rep, nullptr, nullptr, nullptr, M, N, nullptr, nullptr, lddy);
+    if (rc != LEOD_OK) return rc;
+    const int rstep = 256 / (N / 4);
+    // 8 rows per thread (4 when that leaves every problem fewer than 128 workgroups); the same-address double atomics at the end of a workgroup
+    // are spread over `rep` replicas (1024 workgroups x 192 atomics on ONE copy took 31 us for the 40960 x 96 maps, tools/kbench_bn.py)
+    int rpt = 4;
+    for (int k = 0; k < n; ++k) if (((long)M[k] + rstep * 8 - 1) / (rstep * 8) >= 128) rpt = 8;
+    int gmax = 0;
+    for (int k = 0; k < n; ++k) { g.p[k].gx = M[k] > 0 ? (int)(((long)M[k] + rstep * rpt - 1) / (rstep * rpt)) : 0; gmax = max(gmax, g.p[k].gx); }
+    if (gmax == 0) return LEOD_OK;
+    const size_t lds = (size_t)rstep * 2 * N * sizeof(float);
+    if (rpt == 8) hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel<8>, dim3(gmax, n), dim3(256), lds, stream, g, N);
+    else hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel<4>, dim3(gmax, n), dim3(256), lds, stream, g, N);
+    return leod_launch_status();
+}
 LEOD_API int leod_bn_silu_bwd_reduce(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
                                      const float* b, double* sums, int rep, int M, int N, int lddy, hipStream_t stream) {
-    if (!dy || !z || !mean || !rstd || !w || !b || !sums || (N & 3) || N / 4 > 256 || (lddy && (lddy < N || (lddy & 3)))) return LEOD_ERR_ARG;
-    if (M <= 0) return LEOD_OK;
-    if (rep < 1) rep = 1;
-    const int rstep = 256 / (N / 4);
-    // 8 rows per thread (4 when that leaves fewer than 128 workgroups); the same-address double atomics at the end of a workgroup
-    // are spread over `rep` replicas (1024 workgroups x 192 atomics on ONE copy took 31 us for the 40960 x 96 maps, tools/kbench_bn.py)
-    const long lddy_ = (long)(lddy ? lddy : N);
-    const int rpt = ((long)M + rstep * 8 - 1) / (rstep * 8) >= 128 ? 8 : 4;
-    const int grid = (int)(((long)M + rstep * rpt - 1) / (rstep * rpt));
-    if (rpt == 8)
-        hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel<8>, dim3(grid), dim3(256), (size_t)rstep * 2 * N * sizeof(float), stream, dy, z, mean, rstd, w, b, sums, rep,
-                           (long)M, N, lddy_);
-    else
-        hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel<4>, dim3(grid), dim3(256), (size_t)rstep * 2 * N * sizeof(float), stream, dy, z, mean, rstd, w, b, sums, rep,
-                           (long)M, N, lddy_);
-    return leod_launch_status();
+    return leod_bn_silu_bwd_reduce_group(1, &dy, &z, &mean, &rstd, &w, &b, &sums, &rep, &M, N, &lddy, stream);
 }
 
+LEOD_API int leod_bn_silu_bwd_apply_group(int n, const float* const* dy, const float* const* z, const float* const* mean,
+                                          const float* const* rstd, const float* const* w, const float* const* b, double* const* sums,
+                                          const int* rep, float* const* dz, float* const* dw, float* const* db, const int* M, int N,
+                                          const double* count, const double* const* count_dev, const int* lddy, hipStream_t stream) {
+    if (!dz || !count) return LEOD_ERR_ARG;
+    BnBwdGroup g{};
+    const int rc = bn_bwd_fill(g, n, dy, z, mean, rstd, w, b, sums, rep, dz, dw, db, M, N, count, count_dev, lddy);
+    if (rc != LEOD_OK) return rc;
+    int gmax = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!dz[k]) return LEOD_ERR_ARG;
+        g.p[k].gx = M[k] > 0 ? (int)min((long)1024, max((long)1, ((long)M[k] * N / 4 + 255) / 256)) : 0;
+        gmax = max(gmax, g.p[k].gx);
+    }
+    if (gmax == 0) return LEOD_OK;
+    hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(gmax, n), dim3(256), 3 * N * sizeof(float), stream, g, N);
+    return leod_launch_status();
+}
 LEOD_API int leod_bn_silu_bwd_apply(const float* dy, const float* z, const float* mean, const float* rstd, const float* w,
                                     const float* b, const double* sums, int rep, float* dz, float* dw, float* db, int M, int N,
                                     double count, const double* count_dev, int lddy, hipStream_t stream) {
-    if (!dy || !z || !mean || !rstd || !w || !b || !sums || !dz || (N & 3) || (lddy && (lddy < N || (lddy & 3)))) return LEOD_ERR_ARG;
-    if (M <= 0) return LEOD_OK;
-    if (rep < 1) rep = 1;
-    const int grid = (int)min((long)1024, max((long)1, ((long)M * N / 4 + 255) / 256));
-    hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid), dim3(256), 3 * N * sizeof(float), stream, dy, z, mean, rstd,
-                       w, b, sums, rep, dz, dw, db, (long)M, N, count, count_dev, (long)(lddy ? lddy : N));
-    return leod_launch_status();
+    double* s_ = const_cast<double*>(sums);
+    return leod_bn_silu_bwd_apply_group(1, &dy, &z, &mean, &rstd, &w, &b, &s_, &rep, &dz, &dw, &db, &M, N, &count, &count_dev, &lddy, stream);
 }

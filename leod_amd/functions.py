@@ -594,17 +594,23 @@ def _conv_bn_fwd(members, need):
     if sync:
         assert images is not None, 'SyncBatchNorm: functions.sync_bn_begin(n_images) must open the pass (YoloXDetector.forward_detect does)'
         _allreduce_stats(block)
-    out, off = [], 0
-    for (mod, x, conv_w, bn_w, bn_b, stride), z, R in zip(members, zs, reps):
-        N = conv_w.shape[0]
-        rows = z.numel() // N
-        count = rows // z.shape[0] if sync else rows            # SyncBN: rows per image; the kernels multiply by ``images``
-        mom = mod.bn.momentum if mod.bn.momentum is not None else 0.1
-        y, mean, rstd = ops.bn_silu_fwd(z, block[off:off + 2 * R * N].view(R, 2, N), bn_w, bn_b, mod.bn.running_mean, mod.bn.running_var,
-                                        count, eps=mod.bn.eps, momentum=mom, count_dev=images)
-        off += 2 * R * N
+    out = []
+    counts, moms = [], []
+    for (mod, x, conv_w, bn_w, bn_b, stride), z in zip(members, zs):
+        rows = z.numel() // conv_w.shape[0]
+        counts.append(rows // z.shape[0] if sync else rows)        # SyncBN: rows per image; the kernels multiply by ``images``
+        moms.append(mod.bn.momentum if mod.bn.momentum is not None else 0.1)
         mod.bn_calls_pending = getattr(mod, 'bn_calls_pending', 0) + 1     # flushed into num_batches_tracked lazily (flush_bn_counters)
-        out.append((y, (z, mean, rstd, count, images) if need else None))
+    same = len(members) > 1 and len(members) <= 8 and len({(m[2].shape[0], m[0].bn.eps) for m in members}) == 1
+    if same:                                                        # one launch for the layers of one channel count
+        res = ops.bn_silu_fwd_group(zs, stat_slices, [m[3] for m in members], [m[4] for m in members], [m[0].bn.running_mean for m in members],
+                                    [m[0].bn.running_var for m in members], counts, members[0][0].bn.eps, moms,
+                                    count_devs=[images] * len(members))
+    else:
+        res = [ops.bn_silu_fwd(z, sl, m[3], m[4], m[0].bn.running_mean, m[0].bn.running_var, c, eps=m[0].bn.eps, momentum=mo, count_dev=images)
+               for m, z, sl, c, mo in zip(members, zs, stat_slices, counts, moms)]
+    for (y, mean, rstd), z, c in zip(res, zs, counts):
+        out.append((y, (z, mean, rstd, c, images) if need else None))
     return out
 
 
@@ -627,10 +633,15 @@ def _conv_bn_bwd(members):
         slices = []
         for (mod, x, z, mean, rstd, conv_w, bn_w, bn_b, stride, count, count_dev, dy, need_dx), R in zip(live, reps):
             N = conv_w.shape[0]
-            sl = block[off:off + 2 * R * N].view(R, 2, N)
-            ops.bn_silu_bwd_reduce(dy, z, mean, rstd, bn_w, bn_b, out=sl)
-            slices.append(sl)
+            slices.append(block[off:off + 2 * R * N].view(R, 2, N))
             off += 2 * R * N
+        same = 1 < len(live) <= 8 and len({m[5].shape[0] for m in live}) == 1       # one launch per kernel kind for layers of one channel count
+        if same:
+            ops.bn_silu_bwd_reduce_group([m[11] for m in live], [m[2] for m in live], [m[3] for m in live], [m[4] for m in live],
+                                         [m[6] for m in live], [m[7] for m in live], slices)
+        else:
+            for (mod, x, z, mean, rstd, conv_w, bn_w, bn_b, stride, count, count_dev, dy, need_dx), sl in zip(live, slices):
+                ops.bn_silu_bwd_reduce(dy, z, mean, rstd, bn_w, bn_b, out=sl)
         _allreduce_stats(block)
         # SyncBatchNorm while the step is being recorded into launch plans: every exchange closes a plan segment, and a segment can only
         # end with the side stream joined -- the small weight gradients of the neck / head then stay on the launch stream instead of
@@ -640,9 +651,14 @@ def _conv_bn_bwd(members):
         prev_hold, WgradSide.hold_main = WgradSide.hold_main, hold or WgradSide.hold_main
         shared_dx = {}
         rounds = ([], [])                                   # dgrad problems: (dz, conv_w, x.shape, stride, out, accumulate) -- first writers, then adders
-        for (mod, x, z, mean, rstd, conv_w, bn_w, bn_b, stride, count, count_dev, dy, need_dx), sl in zip(live, slices):
-            dz = ops.bn_silu_bwd_apply(dy, z, mean, rstd, bn_w, bn_b, sl, grad_buf(mod.bn.weight), grad_buf(mod.bn.bias), count,
-                                       count_dev=count_dev)
+        if same:
+            dzs = ops.bn_silu_bwd_apply_group([m[11] for m in live], [m[2] for m in live], [m[3] for m in live], [m[4] for m in live],
+                                              [m[6] for m in live], [m[7] for m in live], slices, [grad_buf(m[0].bn.weight) for m in live],
+                                              [grad_buf(m[0].bn.bias) for m in live], [m[9] for m in live], count_devs=[m[10] for m in live])
+        else:
+            dzs = [ops.bn_silu_bwd_apply(dy, z, mean, rstd, bn_w, bn_b, sl, grad_buf(mod.bn.weight), grad_buf(mod.bn.bias), count, count_dev=count_dev)
+                   for (mod, x, z, mean, rstd, conv_w, bn_w, bn_b, stride, count, count_dev, dy, need_dx), sl in zip(live, slices)]
+        for (mod, x, z, mean, rstd, conv_w, bn_w, bn_b, stride, count, count_dev, dy, need_dx), dz in zip(live, dzs):
             with _wgrad_side(dz, x):
                 ops.conv_nhwc_wgrad(dz, x, grad_buf(mod.conv.weight), None, stride=stride)
             if not need_dx:

@@ -794,6 +794,66 @@ def bn_silu_fwd(z, colstats, w, b, run_mean, run_var, count, eps=1e-5, momentum=
     return y, mean, rstd
 
 
+def _ptr_array_opt(ts):
+    return (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+def _f64_array(v):
+    return (ctypes.c_double * len(v))(*[float(a) for a in v])
+
+
+def _f32_array(v):
+    return (ctypes.c_float * len(v))(*[float(a) for a in v])
+
+
+def bn_silu_fwd_group(zs, colstats, ws, bs, run_means, run_vars, counts, eps, momenta, count_devs=None):
+    """``bn_silu_fwd`` for n <= 8 layers of one channel count in ONE launch -> [(y, mean, rstd)]"""
+    n = len(zs)
+    N = zs[0].shape[-1]
+    for z_, c_ in zip(zs, colstats):
+        _ck(z_, name='z')
+        _ck(c_, torch.float64, 'colstats')
+        if z_.shape[-1] != N:
+            raise LeodHipError('bn_silu_fwd_group: one channel count per launch')
+    ys = [_empty(z_.shape, z_) for z_ in zs]
+    means = [_empty((N,), z_) for z_ in zs]
+    rstds = [_empty((N,), z_) for z_ in zs]
+    cd = None if count_devs is None or all(c is None for c in count_devs) else _ptr_array_opt(count_devs)
+    check(_l().leod_bn_silu_fwd_group(n, _ptr_array(zs), _ptr_array(colstats), _int_array([c.shape[0] if c.dim() == 3 else 1 for c in colstats]),
+                                       _ptr_array(ws), _ptr_array(bs), _ptr_array(ys), _ptr_array(means), _ptr_array(rstds),
+                                       _ptr_array_opt(run_means), _ptr_array_opt(run_vars), _int_array([z_.numel() // N for z_ in zs]), N,
+                                       _f64_array(counts), cd, float(eps), _f32_array(momenta), _stream()), 'bn_silu_fwd_group')
+    return list(zip(ys, means, rstds))
+
+
+def bn_silu_bwd_reduce_group(dys, zs, means, rstds, ws, bs, outs):
+    n, N = len(zs), zs[0].shape[-1]
+    lds = []
+    for dy, z_ in zip(dys, zs):
+        ld = row_stride(dy, N)
+        if not ld or z_.shape[-1] != N:
+            raise LeodHipError('bn_silu_bwd_reduce_group: dy contiguous or a channel slice of a contiguous map; one channel count per launch')
+        _ck_dtype_dev(dy, F32, 'dy')
+        lds.append(ld)
+    check(_l().leod_bn_silu_bwd_reduce_group(n, _ptr_array(dys), _ptr_array(zs), _ptr_array(means), _ptr_array(rstds), _ptr_array(ws), _ptr_array(bs),
+                                              _ptr_array(outs), _int_array([o.shape[0] if o.dim() == 3 else 1 for o in outs]),
+                                              _int_array([z_.numel() // N for z_ in zs]), N, _int_array(lds), _stream()), 'bn_silu_bwd_reduce_group')
+
+
+def bn_silu_bwd_apply_group(dys, zs, means, rstds, ws, bs, sums, dws, dbs, counts, count_devs=None):
+    n, N = len(zs), zs[0].shape[-1]
+    lds = [row_stride(dy, N) for dy in dys]
+    if not all(lds):
+        raise LeodHipError('bn_silu_bwd_apply_group: dy must be contiguous or a channel slice of a contiguous map')
+    dzs = [_empty(z_.shape, z_) for z_ in zs]
+    cd = None if count_devs is None or all(c is None for c in count_devs) else _ptr_array_opt(count_devs)
+    check(_l().leod_bn_silu_bwd_apply_group(n, _ptr_array(dys), _ptr_array(zs), _ptr_array(means), _ptr_array(rstds), _ptr_array(ws), _ptr_array(bs),
+                                             _ptr_array(sums), _int_array([o.shape[0] if o.dim() == 3 else 1 for o in sums]), _ptr_array(dzs),
+                                             _ptr_array(dws), _ptr_array(dbs), _int_array([z_.numel() // N for z_ in zs]), N, _f64_array(counts), cd,
+                                             _int_array(lds), _stream()), 'bn_silu_bwd_apply_group')
+    return dzs
+
+
 class StatArena:
     """Zero-initialised scratch of ONE training step: the BatchNorm statistic accumulators ((sum, sumsq) per conv in the forward pass,
     (sum du, sum du*xhat) in the backward pass: 78 tiny float64 buffers per step) and the fp32 un-scaled weight-gradient scratch of
