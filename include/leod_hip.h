@@ -211,6 +211,11 @@ int leod_conv3x3_group_fwd(int n, const float* const* x, const float* const* w, 
 int leod_conv3x3_group_dgrad(int n, const float* const* dy, const float* const* w, float* const* dx, const int* accumulate,
                              void* const* wpack, const int* wpack_valid, const int* B, const int* H, const int* W, int Cin, int N,
                              leod_stream_t stream);
+/* weight gradients of the same problems: dw_k [N,Cin,3,3] += ... in one launch + one reduce launch; ws[k]: scratch of
+ * leod_conv3x3_group_wgrad_workspace_floats(B[k], H[k], W[k], Cin, N) floats (0: not coverable -> -3 from the call) */
+long leod_conv3x3_group_wgrad_workspace_floats(int B, int H, int W, int Cin, int N);
+int leod_conv3x3_group_wgrad(int n, const float* const* dy, const float* const* x, float* const* dw, float* const* ws, const int* B,
+                             const int* H, const int* W, int Cin, int N, leod_stream_t stream);
 
 /* Depthwise convolution (groups == channels) on NHWC maps, w[C,1,ks,ks]: the depthwise half of DWConv (network_blocks.py:57-76, selected
  * by `depthwise` at yolo_pafpn.py:37 / yolo_head.py:52) and conv3x3_dws of the ConvLSTM (models/layers/rnn.py:20-30,50-55).  Same epilogue

@@ -19,6 +19,11 @@ bool conv3s2_fwd_supported(int B, int H, int W, int Cin, int Cout);      // forw
 bool conv3_wgrad_supported(int H, int W, int Cin, int Cout, int stride);
 size_t conv3_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride);
 int conv3_wgrad_launch(const float* dy, const float* x, float* dW, float* ws, int B, int H, int W, int Cin, int Cout, int stride, hipStream_t stream);
+// n <= 8 weight gradients of one (Cin, Cout, stride) geometry on the nine-tap kernel in one launch (+ one reduce launch); ws[k]:
+// conv3_wgrad_group_workspace_floats(B[k], H[k], W[k], ..) floats
+size_t conv3_wgrad_group_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride);
+int conv3_wgrad_group_launch(int n, const float* const* dy, const float* const* x, float* const* dW, float* const* ws, const int* B, const int* H,
+                             const int* W, int Cin, int Cout, int stride, hipStream_t stream, bool force = true);
 // input gradient of a 3x3 / stride-2 / pad-1 conv: dx [B,H,W,Cin] from dy [B,H/2,W/2,N], w [N][Cin][3][3]; wpack: conv3s1_pack_bytes(Cin, N)
 bool conv3s2_dgrad_supported(int H, int W, int Cin, int N);
 int conv3s2_dgrad_launch(const float* dy, const float* w, float* dx, int accumulate, int B, int H, int W, int Cin, int N, void* wpack, hipStream_t stream, int packed = 0);

@@ -555,6 +555,21 @@ LEOD_API int leod_conv3x3_group_dgrad(int n, const float* const* dy, const float
     return conv3s1_group(n, dy, w, dx, nostats, zeros, accumulate, B, H, W, N, Cin, 1, wpack, wpack_valid, stream);
 }
 
+// dw_k [N,Cin,3,3] += weight gradient of y_k = conv3x3(x_k [B,H,W,Cin], w_k) from dy_k [B,H,W,N] (stride 1), n <= 8 problems of one geometry in
+// one launch + one reduce launch.  ws[k]: leod_conv3x3_group_wgrad_workspace_floats(B[k], H[k], W[k], Cin, N) floats (0: not coverable)
+LEOD_API long leod_conv3x3_group_wgrad_workspace_floats(int B, int H, int W, int Cin, int N) {
+    return conv3_wgrad_supported(H, W, Cin, N, 1) ? (long)conv3_wgrad_group_workspace_floats(B, H, W, Cin, N, 1) : 0;
+}
+LEOD_API int leod_conv3x3_group_wgrad(int n, const float* const* dy, const float* const* x, float* const* dw, float* const* ws, const int* B,
+                                      const int* H, const int* W, int Cin, int N, hipStream_t stream) {
+    if (n < 1 || n > 8 || !dy || !x || !dw || !ws || !B || !H || !W) return LEOD_ERR_ARG;
+    for (int k = 0; k < n; ++k) {
+        if (!dy[k] || !x[k] || !dw[k] || !ws[k]) return LEOD_ERR_ARG;
+        if (!conv3_wgrad_supported(H[k], W[k], Cin, N, 1)) return LEOD_ERR_UNSUPPORTED;
+    }
+    return conv3_wgrad_group_launch(n, dy, x, dw, ws, B, H, W, Cin, N, 1, stream, true);
+}
+
 LEOD_API int leod_stem_conv_wgrad(const float* dy, const void* x, int x_is_u8, float* dw, int B, int Cin, int H, int W,
                                   int Hp, int Wp, int N, int ks, int stride, int pad, hipStream_t stream) {
     if (!dy || !x || !dw) return LEOD_ERR_ARG;

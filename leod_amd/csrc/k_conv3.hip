@@ -573,9 +573,16 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(const float* __restric
 // Same contraction with all NINE taps in one 8-wave workgroup (conv3_wgrad_kernel is bound by its staging loads: the three kernel-row
 // workgroups of a region each fetch the same fp32 halo and dy rows).  Waves 0-3 own taps 0-4, waves 4-7 taps 5-8, each wave the same
 // 3 x 3 tile block as above per tap (45 / 36 accumulator tiles); a region's halo and dy rows are fetched and converted ONCE.
+// One problem of a weight-gradient launch (blockIdx.z picks it: the tower convs of equal depth over the head levels share a launch, round 6).
+struct C3WProb { const float* dy; const float* x; float* part; int B, H, W, Ho, Wo, RH, nregions, WSo, workers; };
+struct C3WGroup { C3WProb p[8]; };
 template <int NA, int NB, int S, int HB = 8>
-__global__ __launch_bounds__(512) void conv3_wgrad9_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
-                                                            int B, int H, int W, int Ho, int Wo, int Ntot, int Ctot, int RH, int nregions, int WSo) {
+__global__ __launch_bounds__(512) void conv3_wgrad9_kernel(C3WGroup probs, int Ntot, int Ctot) {
+    const C3WProb& pr = probs.p[blockIdx.z];
+    if ((int)blockIdx.x >= pr.workers) return;
+    const float* __restrict__ dy = pr.dy; const float* __restrict__ x = pr.x; float* __restrict__ part = pr.part;
+    const int B = pr.B, H = pr.H, W = pr.W, Ho = pr.Ho, Wo = pr.Wo, RH = pr.RH, nregions = pr.nregions, WSo = pr.WSo, nworkers = pr.workers;
+    (void)B;
     static_assert(NA % 2 == 0, "two wave rows over the output channels");
     constexpr int WVB = NB % 2 == 0 ? 2 : 1, WVS = 2 / WVB;               // waves of a tap group: 2 (n) x WVB (c) x WVS (pixel steps)
     constexpr int N = 16 * NA, CI = 16 * NB, LDX = CI + (S == 1 ? 16 : 8), LDY = N + 16, TA = NA / 2, TB = NB / WVB, NTH = 512, NJ = 5;
@@ -601,7 +608,7 @@ __global__ __launch_bounds__(512) void conv3_wgrad9_kernel(const float* __restri
 #pragma unroll
             for (int b = 0; b < TB; ++b) acc[j][a][b] = zero4();
     const int rblocks = (Ho + RH - 1) / RH;
-    for (int reg = blockIdx.x; reg < nregions; reg += gridDim.x) {
+    for (int reg = blockIdx.x; reg < nregions; reg += nworkers) {
         const int seg = reg % csegs, rg = reg / csegs;
         const int b = rg / rblocks, y0 = (rg - b * rblocks) * RH;
         const int x0o = seg * WSo, x0 = S * x0o;
@@ -691,8 +698,12 @@ __global__ __launch_bounds__(512) void conv3_wgrad9_kernel(const float* __restri
     }
 }
 
-// dW[n][c][tap] += sum over workers of part[worker][tap][n][c]
-__global__ __launch_bounds__(256) void conv3_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int workers, int N, int CI) {
+// dW[n][c][tap] += sum over workers of part[worker][tap][n][c]   (blockIdx.y: problem of a grouped launch)
+struct C3RProb { const float* part; float* dW; int workers; };
+struct C3RGroup { C3RProb p[8]; };
+__global__ __launch_bounds__(256) void conv3_wgrad_reduce_kernel(C3RGroup grp, int N, int CI) {
+    const C3RProb& pr = grp.p[blockIdx.y];
+    const float* __restrict__ part = pr.part; float* __restrict__ dW = pr.dW; const int workers = pr.workers;
     const int total = 9 * N * CI;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
@@ -848,7 +859,7 @@ static inline bool conv3_wgrad_slice(int Cin, int Cout, int stride, int& na, int
     return false;
 }
 struct Conv3WgradPlan { int RH, workers, wvs, nslices, ci, na, csegs; bool nine; size_t smem; };
-static inline Conv3WgradPlan conv3_wgrad_plan(int B, int H, int W, int Cin, int Cout, int S);
+static inline Conv3WgradPlan conv3_wgrad_plan(int B, int H, int W, int Cin, int Cout, int S, bool force_nine = false);
 bool conv3_wgrad_supported(int H, int W, int Cin, int Cout, int stride) {
     if (leod_precision() != 1) return false;
     if (stride != 1 && stride != 2) return false;
@@ -864,7 +875,7 @@ static inline bool conv3_wgrad_nine(int nregions, int nslices) {
     static const int on = 1;
     return on && nregions * nslices > 32;
 }
-static inline Conv3WgradPlan conv3_wgrad_plan(int B, int H, int W, int Cin, int Cout, int S) {
+static inline Conv3WgradPlan conv3_wgrad_plan(int B, int H, int W, int Cin, int Cout, int S, bool force_nine) {
     Conv3WgradPlan pl{};
     const int Ho = H / S, Wo = W / S;
     int na = 6, nb = 6;
@@ -905,7 +916,7 @@ static inline Conv3WgradPlan conv3_wgrad_plan(int B, int H, int W, int Cin, int 
         workers = max(1, fill / (3 * pl.nslices));
         if (workers >= 8) workers &= ~7;
     }
-    pl.nine = conv3_wgrad_nine(nregions, pl.nslices) || pl.na != 6;      // (the three-workgroup kernel exists for the 96-channel slices only)
+    pl.nine = force_nine || conv3_wgrad_nine(nregions, pl.nslices) || pl.na != 6;      // (the three-workgroup kernel exists for the 96-channel slices only)
     if (pl.nine) {
         // 9-tap workgroups, one per CU (LDS): slices * workers of them, and each writes a whole 9 x 96 x CI slice of partial sums that
         // the reduce kernel reads back -- 256 workgroups when each gets >= 2 regions (the backbone convs on 168 frames: stage 2
@@ -924,28 +935,52 @@ size_t conv3_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int 
     return (size_t)pl.workers * pl.wvs * 9 * Cin * Cout;
 }
 
+// n problems of one (Cin, Cout, stride) geometry on the nine-tap kernel in ONE launch + one reduce launch.  force: every problem takes the nine-tap
+// plan (a grouped call); otherwise the problems' own plans must all be nine-tap (the single call).
+size_t conv3_wgrad_group_workspace_floats(int B, int H, int W, int Cin, int Cout, int stride) {
+    const Conv3WgradPlan pl = conv3_wgrad_plan(B, H, W, Cin, Cout, stride, true);
+    return (size_t)pl.workers * pl.wvs * 9 * Cin * Cout;
+}
+int conv3_wgrad_group_launch(int n, const float* const* dy, const float* const* x, float* const* dW, float* const* ws, const int* B, const int* H,
+                             const int* W, int Cin, int Cout, int stride, hipStream_t stream, bool force) {
+    if (n < 1 || n > 8) return LEOD_ERR_ARG;
+    C3WGroup g{};
+    C3RGroup rg{};
+    int maxw = 0, na = 0, ci = 0, nslices = 0, wvs = 1;
+    size_t smem = 0;
+    for (int k = 0; k < n; ++k) {
+        const Conv3WgradPlan pl = conv3_wgrad_plan(B[k], H[k], W[k], Cin, Cout, stride, force);
+        if (pl.workers <= 0 || !pl.nine || !ws[k]) return LEOD_ERR_UNSUPPORTED;
+        const int Ho = H[k] / stride, Wo = W[k] / stride;
+        g.p[k] = C3WProb{dy[k], x[k], ws[k], B[k], H[k], W[k], Ho, Wo, pl.RH, B[k] * cdiv(Ho, pl.RH) * pl.csegs, Wo / pl.csegs, pl.workers};
+        rg.p[k] = C3RProb{ws[k], dW[k], pl.workers * pl.wvs};
+        maxw = max(maxw, pl.workers); smem = max(smem, pl.smem);
+        na = pl.na; ci = pl.ci; nslices = pl.nslices; wvs = pl.wvs;
+    }
+    (void)wvs;
+    const dim3 grid9(maxw, nslices, n);
+#define C3W9_CASE(NAV, NBV, SV)                                                                                                          \
+    if (na == NAV && ci == 16 * NBV && stride == SV) {                                                                                   \
+        static bool attr_set = false;                                                                                                    \
+        if (!attr_set) {                                                                                                                 \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgrad9_kernel<NAV, NBV, SV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                                                             \
+        }                                                                                                                                \
+        hipLaunchKernelGGL((conv3_wgrad9_kernel<NAV, NBV, SV>), grid9, dim3(512), smem, stream, g, Cout, Cin);                            \
+    } else
+    C3W9_CASE(6, 6, 1) C3W9_CASE(6, 6, 2) C3W9_CASE(6, 3, 2) C3W9_CASE(8, 4, 1) C3W9_CASE(8, 4, 2) C3W9_CASE(4, 4, 1) return LEOD_ERR_UNSUPPORTED;
+#undef C3W9_CASE
+    hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(cdiv(9 * Cin * Cout, 256), n), dim3(256), 0, stream, rg, Cout, Cin);
+    return leod_launch_status();
+}
+
 // dW[Cout][Cin][3][3] += wgrad of y = conv3x3(x, stride) for dy [B,Ho,Wo,Cout], x [B,H,W,Cin]; ws: conv3_wgrad_workspace_floats floats
 int conv3_wgrad_launch(const float* dy, const float* x, float* dW, float* ws, int B, int H, int W, int Cin, int Cout, int stride, hipStream_t stream) {
     const Conv3WgradPlan pl = conv3_wgrad_plan(B, H, W, Cin, Cout, stride);
     if (pl.workers <= 0 || !ws) return LEOD_ERR_UNSUPPORTED;
     const int Ho = H / stride, Wo = W / stride;
     const int nregions = B * cdiv(Ho, pl.RH) * pl.csegs, WSo = Wo / pl.csegs;
-    if (pl.nine) {
-        const dim3 grid9(pl.workers, pl.nslices);
-#define C3W9_CASE(NAV, NBV, SV)                                                                                                          \
-        if (pl.na == NAV && pl.ci == 16 * NBV && stride == SV) {                                                                                         \
-            static bool attr_set = false;                                                                                                \
-            if (!attr_set) {                                                                                                             \
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_wgrad9_kernel<NAV, NBV, SV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                attr_set = true;                                                                                                         \
-            }                                                                                                                            \
-            hipLaunchKernelGGL((conv3_wgrad9_kernel<NAV, NBV, SV>), grid9, dim3(512), pl.smem, stream, dy, x, ws, B, H, W, Ho, Wo, Cout, Cin, pl.RH, nregions, WSo); \
-        } else
-        C3W9_CASE(6, 6, 1) C3W9_CASE(6, 6, 2) C3W9_CASE(6, 3, 2) C3W9_CASE(8, 4, 1) C3W9_CASE(8, 4, 2) C3W9_CASE(4, 4, 1) return LEOD_ERR_UNSUPPORTED;
-#undef C3W9_CASE
-        hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(cdiv(9 * Cin * Cout, 256)), dim3(256), 0, stream, ws, dW, pl.workers * pl.wvs, Cout, Cin);
-        return leod_launch_status();
-    }
+    if (pl.nine) return conv3_wgrad_group_launch(1, &dy, &x, &dW, &ws, &B, &H, &W, Cin, Cout, stride, stream, false);
     const dim3 grid(pl.workers, 3, pl.nslices);
 #define C3W_CASE(NBV, SV, HBV)                                                                                                           \
     if (pl.ci == 16 * NBV && stride == SV) {                                                                                             \
@@ -958,7 +993,7 @@ int conv3_wgrad_launch(const float* dy, const float* x, float* dW, float* ws, in
     } else
     C3W_CASE(6, 1, 12) C3W_CASE(6, 2, 12) C3W_CASE(3, 2, 12) return LEOD_ERR_UNSUPPORTED;      // (18 loads in flight: no faster)
 #undef C3W_CASE
-    hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(cdiv(9 * Cin * Cout, 256)), dim3(256), 0, stream, ws, dW, pl.workers * pl.wvs, Cout, Cin);
+    { C3RGroup rg{}; rg.p[0] = C3RProb{ws, dW, pl.workers * pl.wvs}; hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3(cdiv(9 * Cin * Cout, 256), 1), dim3(256), 0, stream, rg, Cout, Cin); }
     return leod_launch_status();
 }
 

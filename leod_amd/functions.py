@@ -658,9 +658,14 @@ def _conv_bn_bwd(members):
         else:
             dzs = [ops.bn_silu_bwd_apply(dy, z, mean, rstd, bn_w, bn_b, sl, grad_buf(mod.bn.weight), grad_buf(mod.bn.bias), count, count_dev=count_dev)
                    for (mod, x, z, mean, rstd, conv_w, bn_w, bn_b, stride, count, count_dev, dy, need_dx), sl in zip(live, slices)]
+        wg_done = False
+        if all(m[8] == 1 for m in live) and ops.conv3x3_group_ok([m[1] for m in live], [m[5] for m in live]):
+            with _wgrad_side(*dzs, *[m[1] for m in live]):         # the weight gradients of the group: one launch on the side lane
+                wg_done = ops.conv3x3_group_wgrad(dzs, [m[1] for m in live], [grad_buf(m[0].conv.weight) for m in live])
         for (mod, x, z, mean, rstd, conv_w, bn_w, bn_b, stride, count, count_dev, dy, need_dx), dz in zip(live, dzs):
-            with _wgrad_side(dz, x):
-                ops.conv_nhwc_wgrad(dz, x, grad_buf(mod.conv.weight), None, stride=stride)
+            if not wg_done:
+                with _wgrad_side(dz, x):
+                    ops.conv_nhwc_wgrad(dz, x, grad_buf(mod.conv.weight), None, stride=stride)
             if not need_dx:
                 dxs[id(mod)] = None
                 continue

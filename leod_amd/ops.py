@@ -765,6 +765,28 @@ def conv3x3_group_dgrad(dys, ws, x_shapes, outs, accumulate) -> bool:
     return True
 
 
+def conv3x3_group_wgrad(dys, xs, dws) -> bool:
+    """dws[k] += weight gradient of conv(x_k, w_k) from dys[k] (stride 1) in ONE launch (+ one reduce); False where not coverable."""
+    n = len(dys)
+    for t in list(dys) + list(xs) + list(dws):
+        _ck(t, name='conv3x3_group')
+    N, Cin = dws[0].shape[0], dws[0].shape[1]
+    sizes = [int(_l().leod_conv3x3_group_wgrad_workspace_floats(x.shape[0], x.shape[1], x.shape[2], Cin, N)) for x in xs]
+    if not all(sizes):
+        return False
+    ws = _empty((sum(sizes),), dys[0])
+    parts, off = [], 0
+    for sz in sizes:
+        parts.append(ws[off:off + sz])
+        off += sz
+    rc = _l().leod_conv3x3_group_wgrad(n, _ptr_array(dys), _ptr_array(xs), _ptr_array(dws), _ptr_array(parts), _int_array([x.shape[0] for x in xs]),
+                                       _int_array([x.shape[1] for x in xs]), _int_array([x.shape[2] for x in xs]), Cin, N, _stream())
+    if rc == -3:
+        return False
+    check(rc, 'conv3x3_group_wgrad')
+    return True
+
+
 def conv_nhwc_wgrad(dy, x, dw, dbias=None, stride=1):
     for t, n in ((dy, 'dy'), (x, 'x'), (dw, 'dw'), (dbias, 'dbias')):
         _ck(t, name=n)
