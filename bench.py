@@ -395,8 +395,7 @@ def main():
         if args.no_plan:
             module.plan_mode = False
         if args.single_stream:
-            from leod_amd.models.detection.yolox.models import yolo_head as _yh
-            module.wgrad_side, _yh._LEVEL_STREAMS = False, False
+            module.wgrad_side = False
         for s in range(args.warmup):
             run(first_mask(s))
         masks = [first_mask(1 + args.warmup + s) for s in range(args.steps)]

@@ -205,6 +205,7 @@ int leod_conv_nhwc_wgrad(const float* dy, const float* x, float* dw, float* dbia
  * (device pointers / sizes per problem); wpack[k] / wpack_valid[k] as in leod_conv_nhwc_fwd.  forward: y_k = conv(x_k, w_k) with the
  * BatchNorm (sum, sumsq) of y_k into colstats[k] ([stat_rep[k]][2][Cout] doubles, zeroed; NULL: none).  dgrad: dx_k (+)= the input
  * gradient from dy_k [B,H,W,N]; problems of one call must write different dx buffers.  -3: not coverable, run the problems singly. */
+int leod_conv3x3_group_supported(int n, const int* H, const int* W, int Cin, int Cout);   /* 1: the forward call covers these maps (dgrad: ask with (Cout, Cin)) */
 int leod_conv3x3_group_fwd(int n, const float* const* x, const float* const* w, float* const* y, double* const* colstats,
                            const int* stat_rep, void* const* wpack, const int* wpack_valid, const int* B, const int* H, const int* W,
                            int Cin, int Cout, leod_stream_t stream);

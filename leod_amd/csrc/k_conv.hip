@@ -529,6 +529,11 @@ static int launch_stem_u8_wgrad(const float* dy, const uint8_t* x, float* dW, in
 // ---- grouped 3x3 / stride-1 / pad-1 convolutions: n <= 8 independent problems of ONE channel geometry in one launch (k_conv3.hip, C3Group) ----
 // The convs of equal depth in the cls / reg towers of the three head levels (yolo_head.py:61-145 of the reference builds them as separate
 // modules; yolo_head.py:208-222 runs them level by level).  Arrays are HOST arrays of length n.  -3: not coverable (run the problems singly).
+// 1: leod_conv3x3_group_fwd covers these n maps for Cin -> Cout in the current precision mode (callers ask BEFORE they hand out weight-pack
+// buffers: a refused call must not leave a pack marked valid); the dgrad of the same convs: ask with (Cout, Cin)
+LEOD_API int leod_conv3x3_group_supported(int n, const int* H, const int* W, int Cin, int Cout) {
+    return (H && W && conv3s1_group_supported(n, H, W, Cin, Cout)) ? 1 : 0;
+}
 LEOD_API int leod_conv3x3_group_fwd(int n, const float* const* x, const float* const* w, float* const* y, double* const* colstats,
                                     const int* stat_rep, void* const* wpack, const int* wpack_valid, const int* B, const int* H, const int* W,
                                     int Cin, int Cout, hipStream_t stream) {

@@ -18,9 +18,6 @@ from .network_blocks import BaseConv, DWConv
 LOSS_KEYS = ('loss', 'iou_loss', 'conf_loss', 'cls_loss', 'l1_loss', 'num_fg')
 
 
-_LEVEL_STREAMS = True   # pyramid levels of the head on their own HIP streams in eager steps (module attribute; off under SyncBatchNorm and capture)
-
-
 class YOLOXHead(nn.Module):
     def __init__(self, num_classes=80, strides=(8, 16, 32), in_channels=(256, 512, 1024), act="silu", depthwise=False,
                  compile_cfg: Optional[Dict] = None, obj_focal_loss=False, bbox_loss_weighting='', ignore_bg_k=-1,
@@ -123,35 +120,6 @@ class YOLOXHead(nn.Module):
         labels[:, :, 0] = torch.where(ign, torch.full_like(cls_idx, float(self.ignore_label)), cls_idx)
         return labels
 
-    def _towers_streams(self, xin):
-        """One HIP stream per pyramid level (stem -> two cls convs, two reg convs): the 32x40 level keeps the launch stream, the
-        16x20 and 8x10 levels -- 4x and 16x smaller launches that cannot fill 256 CUs either -- run next to it instead of behind it
-        (15 conv + BatchNorm launch pairs in sequence were ~0.4 ms forward for 7 % of the model's FLOPs).  Autograd replays each
-        node's backward on the stream of its forward, so the backward pass overlaps the same way."""
-        n = len(xin)
-        main = torch.cuda.current_stream()
-        if getattr(self, '_level_streams', None) is None or len(self._level_streams) != n - 1:
-            self._level_streams = [torch.cuda.Stream(device=xin[0].device) for _ in range(n - 1)]
-        feats = [None] * (2 * n)
-        for k in range(n):
-            st = main if k == 0 else self._level_streams[k - 1]
-            if k:
-                st.wait_stream(main)
-                xin[k].record_stream(st)
-            with torch.cuda.stream(st):
-                x = self.stems[k].forward_nhwc(xin[k])
-                c = r = x
-                for d in (0, 1):
-                    c = self.cls_convs[k][d].forward_nhwc(c)
-                    r = self.reg_convs[k][d].forward_nhwc(r)
-                if k:
-                    c.record_stream(main)
-                    r.record_stream(main)
-                feats[2 * k], feats[2 * k + 1] = c, r
-        for st in self._level_streams:
-            main.wait_stream(st)
-        return feats
-
     def _towers(self, xin):
         if self.depthwise:                                # DWConv towers: two BaseConvs per layer, evaluated layer by layer
             feats = []
@@ -163,10 +131,9 @@ class YOLOXHead(nn.Module):
                     r = self.reg_convs[k][d].forward_nhwc(r)
                 feats += [c, r]
             return feats
-        if (_LEVEL_STREAMS and xin[0].is_cuda and len(xin) > 1 and not Fn._sync_bn_on()
-                and not torch.cuda.is_current_stream_capturing()):      # captured steps keep the levels on one lane: 16.8 vs 16.4 ms (profiles/r04_a_graph_ab.txt)
-            return self._towers_streams(list(xin))
-        # the three levels are independent: layers of equal depth form one group (one SyncBatchNorm exchange per group)
+        # the three levels are independent: layers of equal depth form one group -- one launch per kernel kind for the six tower convs of a
+        # depth (functions.base_conv_group -> ops.conv3x3_group_* / bn_silu_*_group), one SyncBatchNorm exchange per group.  (Rounds 3-5 ran
+        # the levels on their own HIP streams in eager steps instead: 15.09 ms against 14.84 for the grouped launches, round 6.)
         n = len(xin)
         xs = Fn.base_conv_group(list(self.stems), list(xin))
         for d in (0, 1):

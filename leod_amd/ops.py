@@ -737,14 +737,14 @@ def conv3x3_group_fwd(xs, ws, colstats):
     for c in colstats:
         _ck(c, torch.float64, 'colstats')
     N, Cin = ws[0].shape[0], ws[0].shape[1]
+    if not _l().leod_conv3x3_group_supported(n, _int_array([x.shape[1] for x in xs]), _int_array([x.shape[2] for x in xs]), Cin, N):
+        return None                                           # asked before any pack buffer is handed out (a refused call must not leave one marked valid)
     ys = [_empty(tuple(x.shape[:3]) + (N,), x) for x in xs]
     packs = [PackCache.get(w, ('fwd', x.shape[0], x.shape[1], x.shape[2], 1, False, False), N * Cin * 9) for x, w in zip(xs, ws)]
     rc = _l().leod_conv3x3_group_fwd(n, _ptr_array(xs), _ptr_array(ws), _ptr_array(ys), _ptr_array(colstats),
                                      _int_array([c.shape[0] if c.dim() == 3 else 1 for c in colstats]), _ptr_array([p for p, _ in packs]),
                                      _int_array([v for _, v in packs]), _int_array([x.shape[0] for x in xs]), _int_array([x.shape[1] for x in xs]),
                                      _int_array([x.shape[2] for x in xs]), Cin, N, _stream())
-    if rc == -3:
-        return None
     check(rc, 'conv3x3_group_fwd')
     return ys
 
@@ -755,12 +755,12 @@ def conv3x3_group_dgrad(dys, ws, x_shapes, outs, accumulate) -> bool:
     for t in list(dys) + list(ws) + list(outs):
         _ck(t, name='conv3x3_group')
     N, Cin = ws[0].shape[0], ws[0].shape[1]
+    if not _l().leod_conv3x3_group_supported(n, _int_array([sh[1] for sh in x_shapes]), _int_array([sh[2] for sh in x_shapes]), N, Cin):
+        return False
     packs = [PackCache.get(w, ('dgrad', sh[0], sh[1], sh[2], 1), N * Cin * 9) for w, sh in zip(ws, x_shapes)]
     rc = _l().leod_conv3x3_group_dgrad(n, _ptr_array(dys), _ptr_array(ws), _ptr_array(outs), _int_array([1 if a else 0 for a in accumulate]),
                                        _ptr_array([p for p, _ in packs]), _int_array([v for _, v in packs]), _int_array([sh[0] for sh in x_shapes]),
                                        _int_array([sh[1] for sh in x_shapes]), _int_array([sh[2] for sh in x_shapes]), Cin, N, _stream())
-    if rc == -3:
-        return False
     check(rc, 'conv3x3_group_dgrad')
     return True
 

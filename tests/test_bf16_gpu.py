@@ -123,6 +123,70 @@ def test_conv3x3_direct_bf16(bf16_ops, B, H, W, Cin, N):
     tk.close(dw, 2 * w.grad, what='conv3x3 wgrad accumulates')
 
 
+@pytest.mark.parametrize('C,sizes', [(96, [(4, 32, 40), (4, 16, 20), (4, 8, 10), (4, 32, 40), (4, 16, 20), (4, 8, 10)]),     # the six tower convs of a depth
+                                     (128, [(2, 12, 160), (2, 24, 40)]), (48, [(3, 9, 12), (1, 5, 7), (2, 32, 40)])])
+def test_conv3x3_group_equals_single_calls(bf16_ops, C, sizes):
+    """n problems of one channel geometry in ONE launch (csrc/k_conv3.hip: problem tables; leod_conv3x3_group_fwd / _dgrad / _wgrad,
+    leod_bn_silu_*_group) against the same problems launched one by one: forward outputs, BatchNorm statistics and input gradients
+    bit-identical (same arithmetic per output), weight gradients to the order of the workers' partial sums; a second round of input
+    gradients accumulates."""
+    ops = bf16_ops
+    n = len(sizes)
+    xs = [tk.rnd((B, H, W, C), 10 + k).to(tk.DEV) for k, (B, H, W) in enumerate(sizes)]
+    ws = [tk.rnd((C, C, 3, 3), 30 + k, 0.05).to(tk.DEV) for k in range(n)]
+    dys = [tk.rnd((B, H, W, C), 50 + k).to(tk.DEV) for k, (B, H, W) in enumerate(sizes)]
+    R = 4
+    cs_g = [torch.zeros((R, 2, C), dtype=torch.float64, device=tk.DEV) for _ in range(n)]
+    cs_s = [torch.zeros((R, 2, C), dtype=torch.float64, device=tk.DEV) for _ in range(n)]
+    assert ops.conv3x3_group_ok(xs, ws)
+    ys = ops.conv3x3_group_fwd(xs, ws, cs_g)
+    assert ys is not None
+    for k in range(n):
+        y1 = ops.conv_nhwc_fwd(xs[k], ws[k], None, colstats=cs_s[k])
+        assert torch.equal(ys[k], y1), f'forward {k}'
+        assert torch.allclose(cs_g[k].sum(0), cs_s[k].sum(0), rtol=1e-12, atol=1e-9), f'statistics {k}'
+    outs = [torch.empty_like(x) for x in xs]
+    assert ops.conv3x3_group_dgrad(dys, ws, [tuple(x.shape) for x in xs], outs, [False] * n)
+    singles = [ops.conv_nhwc_dgrad(dys[k], ws[k], tuple(xs[k].shape)) for k in range(n)]
+    for k in range(n):
+        assert torch.equal(outs[k], singles[k]), f'dgrad {k}'
+    assert ops.conv3x3_group_dgrad(dys, ws, [tuple(x.shape) for x in xs], outs, [True] * n)
+    for k in range(n):
+        tk.close(outs[k], 2 * singles[k], rtol=1e-6, atol=1e-6, what=f'dgrad accumulate {k}')
+    dws_g = [torch.zeros_like(w) for w in ws]
+    dws_s = [torch.zeros_like(w) for w in ws]
+    if ops.conv3x3_group_wgrad(dys, xs, dws_g):
+        for k in range(n):
+            ops.conv_nhwc_wgrad(dys[k], xs[k], dws_s[k], None)
+            tk.close(dws_g[k], dws_s[k], rtol=2e-5, atol=2e-5 * float(dws_s[k].abs().max()), what=f'wgrad {k}')
+    else:       # refused as a whole (the direct weight-gradient kernel has no 48 -> 48 / stride-1 form): nothing was written
+        assert C == 48 and all(not d.any() for d in dws_g)
+    # BatchNorm + SiLU of the same maps, grouped against single launches
+    bw = [1 + 0.2 * tk.rnd((C,), 70 + k).to(tk.DEV) for k in range(n)]
+    bb = [0.1 * tk.rnd((C,), 80 + k).to(tk.DEV) for k in range(n)]
+    counts = [y.numel() // C for y in ys]
+    rm = [torch.zeros(C, device=tk.DEV) for _ in range(2 * n)]
+    rv = [torch.ones(C, device=tk.DEV) for _ in range(2 * n)]
+    res = ops.bn_silu_fwd_group(ys, cs_g, bw, bb, rm[:n], rv[:n], counts, 1e-5, [0.1] * n)
+    for k in range(n):
+        a, mean, rstd = ops.bn_silu_fwd(ys[k], cs_s[k], bw[k], bb[k], rm[n + k], rv[n + k], counts[k], eps=1e-5, momentum=0.1)
+        assert torch.equal(res[k][0], a) and torch.equal(res[k][1], mean) and torch.equal(res[k][2], rstd), f'bn forward {k}'
+        assert torch.equal(rm[k], rm[n + k]) and torch.equal(rv[k], rv[n + k])
+    sums_g = [torch.zeros((R, 2, C), dtype=torch.float64, device=tk.DEV) for _ in range(n)]
+    means, rstds = [r[1] for r in res], [r[2] for r in res]
+    ops.bn_silu_bwd_reduce_group(dys, ys, means, rstds, bw, bb, sums_g)
+    dgw = [torch.zeros(C, device=tk.DEV) for _ in range(2 * n)]
+    dgb = [torch.zeros(C, device=tk.DEV) for _ in range(2 * n)]
+    dzs = ops.bn_silu_bwd_apply_group(dys, ys, means, rstds, bw, bb, sums_g, dgw[:n], dgb[:n], counts)
+    for k in range(n):
+        s1 = torch.zeros((R, 2, C), dtype=torch.float64, device=tk.DEV)
+        ops.bn_silu_bwd_reduce(dys[k], ys[k], means[k], rstds[k], bw[k], bb[k], out=s1)
+        tk.close(sums_g[k].sum(0).float(), s1.sum(0).float(), rtol=1e-5, atol=1e-5 * float(s1.sum(0).abs().max()), what=f'bn backward sums {k}')
+        dz1 = ops.bn_silu_bwd_apply(dys[k], ys[k], means[k], rstds[k], bw[k], bb[k], s1, dgw[n + k], dgb[n + k], counts[k])
+        tk.close(dzs[k], dz1, rtol=1e-5, atol=1e-5, what=f'bn backward dz {k}')
+        tk.close(dgw[k], dgw[n + k], rtol=1e-5, atol=1e-5 * float(dgw[n + k].abs().max()), what=f'bn dgamma {k}')
+
+
 @pytest.mark.parametrize('B,H,W,Cin,N,stride', [(5, 64, 80, 48, 96, 2),      # backbone downsampling, stage 2: 48-channel slice, pixel steps dealt to wave pairs
                                                 (3, 32, 40, 96, 192, 2),     # stage 3: two output-channel slices
                                                 (9, 16, 20, 192, 384, 2),    # stage 4: 4 x 2 slices, one region per image

@@ -183,20 +183,21 @@ def test_detector_head_with_loss_options_vs_oracle(gpu, manifest):
         close(fg[k].grad, fo[k].grad, rtol=2e-3, atol=2e-5, what=f'grad feature {k}')
 
 
-def test_head_level_streams_equal_single_stream(gpu, manifest, monkeypatch):
-    """The per-level HIP streams of the head towers (yolo_head._towers_streams) only reorder independent launches: predictions, losses
-    and BatchNorm buffers are bit-identical to the grouped single-stream path and the gradients agree to the order of their fp32
-    atomics; repeated to catch a race."""
-    from leod_amd.models.detection.yolox.models import yolo_head as yh
+def test_head_grouped_launches_equal_per_layer(gpu, manifest, monkeypatch):
+    """The grouped launches of the head towers (functions.base_conv_group: six convs / BatchNorm layers of equal depth per launch) against the
+    same layers evaluated one by one: predictions, losses and BatchNorm buffers bit-identical, gradients equal to the order of their fp32
+    atomics; repeated to catch a race between the problems of a launch."""
+    from leod_amd import functions as Fn
 
     def rnd(shape, seed):
         return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
 
     feats_cpu = {2: rnd((3, 32, 8, 12), 51), 3: rnd((3, 64, 4, 6), 52), 4: rnd((3, 128, 2, 3), 53)}
     targets = op.batched_yolox_labels(micro_labels(3, seed=7))
+    grouped_fn = Fn.base_conv_group
 
-    def run(streams):
-        monkeypatch.setattr(yh, '_LEVEL_STREAMS', streams)
+    def run(grouped):
+        monkeypatch.setattr(Fn, 'base_conv_group', grouped_fn if grouped else (lambda mods, xs: [m.forward_nhwc(x) for m, x in zip(mods, xs)]))
         det, _, _ = build(manifest, 'micro', 5, 'small', micro=True)
         det.train()
         fg = {k: v.to(DEV).requires_grad_(True) for k, v in feats_cpu.items()}
