@@ -89,6 +89,16 @@ int leod_linear_dgrad_gelu16(const float* dy, const float* kscale, const float* 
 int leod_linear_wgrad_gelu16(const float* dy, long lddy, const void* u16, float* dW, float* dbias, int M, int N, int K,
                              leod_stream_t stream);
 
+/* n <= 4 Linear weight gradients of ONE row count M in one preparation, one contraction and one reduce launch (LDS-DMA kernel with a problem
+ * table): dW_k [N_k, K_k] += dy_k^T X_k, dbias_k += colsum(dy_k).  The four weight gradients of an attention block, which its backward issues
+ * together (maxvit.py:110-118,252-270).  Host arrays of length n.  dy_fmt: 0 fp32 rows, 1 bf16 rows; x_fmt: 0 fp32 rows, 1 fp32 rows through
+ * LayerNorm (stats_k [M,2], ln_w_k, ln_b_k), 2 fp16 pre-activation through GELU, 3 bf16 rows, 4 fp16 rows; dense rows.
+ * -3: not coverable (precision mode f32, M outside 8192 .. 60 000 / 400 000 or not a multiple of 64, widths of different tile classes):
+ * nothing was launched, run the problems singly. */
+int leod_linear_wgrad_group(int n, const void* const* dy, const int* dy_fmt, const void* const* x, const int* x_fmt,
+                            const float* const* stats, const float* const* ln_w, const float* const* ln_b, float* const* dW,
+                            float* const* dbias, int M, const int* N, const int* K, leod_stream_t stream);
+
 /* The whole MLP of a MaxViT block in one row-streaming launch (maxvit.py:110-118, 268-269), precision mode bf16, K = 48 / H = 192 (stage 1
  * of RVT-S / -T), M >= 16384:  z[M,K] = y + g2 * (gelu(LN(y) W1^T + b1) W2^T + b2) with the hidden in registers (csrc/k_mlp.hip).
  * u16 [M,H] fp16 + stats [M,2] (both or neither): what the backward pass reads back (training).  -3: not covered -- the caller runs

@@ -54,6 +54,43 @@ LEOD_API int leod_linear_wgrad(const float* dy, long lddy, const float* x, long 
     return launch_wgrad16<1, 1>(dy, lddy, xl, dW, (long)K, dbias, M, N, K, stream, df);
 }
 
+// n <= 4 Linear weight gradients of ONE row count M in one preparation launch, one contraction launch and one reduce launch (the LDS-DMA
+// kernel of wgrad_dma.hpp with a problem table): the four weight gradients of an attention block -- qkv and fc1 from LayerNorm inputs, proj
+// from the 16-bit attention rows, fc2 through GELU of the fp16 pre-activation (maxvit.py:110-118,252-270) -- which the block's backward
+// issues together.  dy_fmt[k]: 0 fp32 rows, 1 bf16 rows.  x_fmt[k]: 0 fp32 rows, 1 fp32 rows through LayerNorm (stats / ln_w / ln_b of
+// problem k), 2 fp16 pre-activation through GELU, 3 bf16 rows, 4 fp16 rows.  Dense rows (strides N[k] / K[k]).
+// LEOD_ERR_UNSUPPORTED: not coverable (precision mode, row count, widths) -- nothing was launched, run the problems singly.
+LEOD_API int leod_linear_wgrad_group(int n, const void* const* dy, const int* dy_fmt, const void* const* x, const int* x_fmt,
+                                     const float* const* stats, const float* const* ln_w, const float* const* ln_b, float* const* dW,
+                                     float* const* dbias, int M, const int* N, const int* K, hipStream_t stream) {
+    if (n < 1 || n > 4 || !dy || !dy_fmt || !x || !x_fmt || !dW || !N || !K) return LEOD_ERR_ARG;
+    WgdHostProb hp[4];
+    int T = 0;
+    size_t need = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!dy[k] || !x[k] || !dW[k] || x_fmt[k] < 0 || x_fmt[k] > 4) return LEOD_ERR_ARG;
+        XRows xl{reinterpret_cast<const float*>(x[k]), (long)K[k], nullptr, nullptr, nullptr, nullptr, 0, 0};
+        if (x_fmt[k] == 1) {
+            if (!stats || !ln_w || !ln_b || !stats[k] || !ln_w[k] || !ln_b[k]) return LEOD_ERR_ARG;
+            xl.stats = stats[k]; xl.ln_w = ln_w[k]; xl.ln_b = ln_b[k];
+        }
+        xl.fmt = x_fmt[k] == 2 ? 1 : x_fmt[k] == 3 ? 2 : x_fmt[k] == 4 ? 3 : 0;
+        const int t = wgd_tile(N[k], K[k]);
+        if (leod_precision() != 1 || !t || (T && t != T) || M < 8192 || (M % kWgdRC) || M > (t == 6 ? 60000 : 400000) || (N[k] & 7) || (K[k] & 7))
+            return LEOD_ERR_UNSUPPORTED;
+        T = t;
+        need += (size_t)M * ((dy_fmt[k] ? 0 : N[k]) + (xl.x_mode() == 3 ? 0 : K[k])) * 2;
+        hp[k] = WgdHostProb{dy[k], (long)N[k], xl, dW[k], (long)K[k], dbias ? dbias[k] : nullptr, N[k], K[k], dy_fmt[k] ? 1 : 0};
+    }
+    if (need > kWgdOperandBytes) return LEOD_ERR_UNSUPPORTED;
+    FamilyMarker fm(stream);
+    switch (T) {
+        case 6: return launch_wgrad_dma_group_t<6, 64, 3>(n, hp, M, stream);
+        case 8: return launch_wgrad_dma_group_t<8, 64, 2>(n, hp, M, stream);
+        default: return launch_wgrad_dma_group_t<4, 64, 3>(n, hp, M, stream);
+    }
+}
+
 // 1: an attention block of this geometry may keep its attention output O and the gradient dO as bf16 rows in precision mode bf16 --
 // every kernel that touches them has a 16-bit path: the bf16-tile attention kernels, proj forward (LDS-staged GEMM), the dgrad of proj
 // (row epilogue) and the proj weight gradient (wide kernel)

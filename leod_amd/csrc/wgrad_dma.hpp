@@ -24,9 +24,10 @@ struct Prep16 {                 // one operand of wgrad_prep16_kernel
     int C, mode;                // mode 0 fp32, 1 LayerNorm xhat of fp32 rows, 2 gelu(fp16), 3 fp16, 4 fp32 [x | x2], -1: nothing to do
 };
 
-// 8 columns per thread (one 16-byte store); grid (ceil(M * maxC8 / 256), 2): y picks the operand
-__global__ __launch_bounds__(256) void wgrad_prep16_kernel(Prep16 pa, Prep16 pb, int M) {
-    const Prep16& p = blockIdx.y ? pb : pa;
+// 8 columns per thread (one 16-byte store); grid (ceil(M * maxC8 / 256), 2, problems): y picks the operand, z the problem of a grouped launch
+struct Prep16Group { Prep16 a[4]; Prep16 b[4]; };
+__global__ __launch_bounds__(256) void wgrad_prep16_kernel(Prep16Group grp, int M) {
+    const Prep16& p = blockIdx.y ? grp.b[blockIdx.z] : grp.a[blockIdx.z];
     if (p.mode < 0) return;
     const int C8 = p.C >> 3;
     const long it = (long)blockIdx.x * 256 + threadIdx.x;
@@ -67,10 +68,24 @@ template <int N> __device__ __forceinline__ void wgd_wait_vm() { asm volatile("s
 template <int T, int RC, int NS> constexpr int wgd_lds_bytes() { return NS * 2 * (RC / 16) * T * 256 * 2; }
 template <int T, int RC, int NS> constexpr int wgd_occupancy() { return wgd_lds_bytes<T, RC, NS>() <= 52 * 1024 ? 3 : wgd_lds_bytes<T, RC, NS>() <= 80 * 1024 ? 2 : 1; }
 
+// One problem of a launch; a launch carries up to 4 of one row count (the four Linear weight gradients of an attention block: qkv, proj,
+// fc1, fc2 -- issued together at the end of the block's backward) in the 1-D grid, problem k owning workgroups [blk0, blk0 + gx * ny * nz).
+struct WgdProb {
+    const unsigned short* A; long lda; const unsigned short* B; long ldb; const float* ln_w; const float* ln_b; float* dbias_flag; f4* part;
+    int cpw, gx, ny, nz, N, K, blk0;
+};
+struct WgdGroup { WgdProb p[4]; int n; };
+// LN: some problem of the launch has X = xhat (ln_w != NULL for that problem): its tiles are scaled / shifted in the epilogue
 template <int T, int RC, int NS, bool LN>
-__global__ __launch_bounds__(256, ((wgd_occupancy<T, RC, NS>()) >= 2 ? 2 : 1)) void wgrad_dma_kernel(const unsigned short* __restrict__ A, long lda, const unsigned short* __restrict__ B, long ldb,
-                                                           const float* __restrict__ ln_w, const float* __restrict__ ln_b, float* dbias_flag,
-                                                           f4* __restrict__ part, int chunks, int cpw, int gx, int ny, int nz, int N, int K, int dbg) {
+__global__ __launch_bounds__(256, ((wgd_occupancy<T, RC, NS>()) >= 2 ? 2 : 1)) void wgrad_dma_kernel(WgdGroup grp, int chunks, int dbg) {
+    int pk = 0;
+    for (int k = 1; k < grp.n; ++k) if ((int)blockIdx.x >= grp.p[k].blk0) pk = k;
+    const WgdProb& pr = grp.p[pk];
+    const unsigned short* __restrict__ A = pr.A; const unsigned short* __restrict__ B = pr.B; const long lda = pr.lda, ldb = pr.ldb;
+    const float* __restrict__ ln_w = pr.ln_w; const float* __restrict__ ln_b = pr.ln_b; float* dbias_flag = pr.dbias_flag; f4* __restrict__ part = pr.part;
+    const int cpw = pr.cpw, gx = pr.gx, ny = pr.ny, nz = pr.nz, K = pr.K;
+    const int bid = (int)blockIdx.x - pr.blk0;
+    const bool ln = LN && ln_w != nullptr;
     constexpr int WA = T / 2, WB = T / 2, NWN = 2, NWK = 2, RB = RC / 16, KS = RC / 32;
     constexpr int BLK = 256;                                   // bf16 elements of a [16][16] block (512 bytes, no padding)
     constexpr int SA = RB * T * BLK, SLOT = 2 * SA;            // elements: dY part, then X part
@@ -85,8 +100,8 @@ __global__ __launch_bounds__(256, ((wgd_occupancy<T, RC, NS>()) >= 2 ? 2 : 1)) v
     // next to each other in time, so that one of them misses in that XCD's L2 and the others hit
     const int ntl = ny * nz;
     int tl, bx;
-    if ((gx & 7) == 0) { const int xcd = blockIdx.x & 7, sj = blockIdx.x >> 3; tl = sj % ntl; bx = (sj / ntl) * 8 + xcd; }
-    else { bx = blockIdx.x % gx; tl = blockIdx.x / gx; }
+    if ((gx & 7) == 0) { const int xcd = bid & 7, sj = bid >> 3; tl = sj % ntl; bx = (sj / ntl) * 8 + xcd; }
+    else { bx = bid % gx; tl = bid / gx; }
     const int by = tl / nz, bz = tl - by * nz;
     const int n0 = by * T * 16, k0 = bz * T * 16;
     const int c0 = bx * cpw, c1 = min(chunks, c0 + cpw);
@@ -116,7 +131,7 @@ __global__ __launch_bounds__(256, ((wgd_occupancy<T, RC, NS>()) >= 2 ? 2 : 1)) v
     };
     // ---- accumulators -----------------------------------------------------------------------------------------------------------
     const bool bias_out = dbias_flag != nullptr && bz == 0;
-    const bool bias_any = LN || bias_out;
+    const bool bias_any = ln || bias_out;
     f4 acc[WA][WB], bacc[WA];
 #pragma unroll
     for (int a = 0; a < WA; ++a) {
@@ -153,7 +168,7 @@ __global__ __launch_bounds__(256, ((wgd_occupancy<T, RC, NS>()) >= 2 ? 2 : 1)) v
             if (bias_any) {
 #pragma unroll
                 for (int a = 0; a < WA; ++a)
-                    if (LN || a % NWK == wk) bacc[a] = mfma32_bf16(pa[a], ones, bacc[a]);
+                    if (ln || a % NWK == wk) bacc[a] = mfma32_bf16(pa[a], ones, bacc[a]);
             }
         }
     };
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(256, ((wgd_occupancy<T, RC, NS>()) >= 2 ? 2 : 1)) v
         if (!(dbg & 1)) mfma_chunk(c % NS);
     }
     // ---- epilogue: as wgrad_wide_bf16_kernel (acc[a][b][r] = element (n = 4q + r, k = i) of tile (a, b)) ---------------------------------
-    if constexpr (LN) {
+    if (ln) {
 #pragma unroll
         for (int b = 0; b < WB; ++b) {
             const int k = k0 + 16 * (wk * WB + b) + i;
@@ -222,60 +237,142 @@ static inline bool wgrad_dma_ok(const XRows& xl, long lddy, int M, int N, int K,
     return true;
 }
 
+// the partial tiles of up to 4 problems -> dW / dbias (wgrad_wide_reduce_kernel<T, T, 2, 2> with a problem table: blockIdx.z)
+struct WgrProb { const f4* part; float* dW; float* dbias; long ldw; int gx, ny, nz, per, N, K, ob, groups; };
+struct WgrGroup { WgrProb p[4]; };
+template <int T>
+__global__ __launch_bounds__(256) void wgrad_dma_reduce_kernel(WgrGroup grp) {
+    const WgrProb& pr = grp.p[blockIdx.z];
+    if ((int)blockIdx.x >= pr.ob || (int)blockIdx.y >= pr.groups) return;
+    constexpr int NWN = 2, NWK = 2, NW = 4, WA = T / 2, WB = T / 2, NT9 = WA * WB, NSL = NT9 + WA;
+    const int gx = pr.gx, nz = pr.nz, per = pr.per, N = pr.N, K = pr.K;
+    float* dW = pr.dW; float* dbias = pr.dbias; const long ldw = pr.ldw;
+    const long O = (long)pr.ny * nz * NW * NSL * 64;
+    const long o = (long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= O) return;
+    const int lane = (int)(o & 63), t = (int)((o >> 6) % NSL), w = (int)((o / (64 * NSL)) % NW), tile = (int)(o / (64 * NSL * NW));
+    const int ty = tile / nz, tz = tile - ty * nz, wn = w % NWN, wk = w / NWN, i = lane & 15, q = lane >> 4;
+    if (t >= NT9 && !(dbias != nullptr && tz == 0 && (t - NT9) % NWK == wk && i == 0)) return;
+    const int g0 = blockIdx.y * per, g1 = min(gx, g0 + per);
+    f4 s0 = zero4(), s1 = zero4(), s2 = zero4(), s3 = zero4(), s4 = zero4(), s5 = zero4(), s6 = zero4(), s7 = zero4();
+    const f4* p = pr.part + (long)g0 * O + o;
+    int g = g0;
+    for (; g + 8 <= g1; g += 8, p += 8 * O) {          // eight independent 16-byte loads in flight per thread
+        s0 += p[0]; s1 += p[O]; s2 += p[2 * O]; s3 += p[3 * O]; s4 += p[4 * O]; s5 += p[5 * O]; s6 += p[6 * O]; s7 += p[7 * O];
+    }
+    for (; g + 4 <= g1; g += 4, p += 4 * O) { s0 += p[0]; s1 += p[O]; s2 += p[2 * O]; s3 += p[3 * O]; }
+    for (; g < g1; ++g, p += O) s0 += p[0];
+    const f4 v = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+    const bool single = pr.groups == 1;
+    if (t < NT9) {
+        const int a = t / WB, b = t - a * WB;
+        const int k = tz * T * 16 + 16 * (wk * WB + b) + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = ty * T * 16 + 16 * (wn * WA + a) + 4 * q + r;
+            if (n < N && k < K) {
+                float* d = dW + (long)n * ldw + k;
+                if (single) *d += v[r]; else atomicAdd(d, v[r]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = ty * T * 16 + 16 * (wn * WA + (t - NT9)) + 4 * q + r;
+            if (n < N) { if (single) dbias[n] += v[r]; else atomicAdd(dbias + n, v[r]); }
+        }
+    }
+}
+
+struct WgdHostProb { const void* dy; long lddy; XRows xl; float* dW; long ldw; float* dbias; int N, K, dyfmt; };
+
+// n <= 4 problems of ONE row count M and one tile edge T: one preparation launch, one contraction launch, one reduce launch
 template <int T, int RC, int NS>
-static inline int launch_wgrad_dma_t(const void* dy, long lddy, const XRows& xl, float* dW, long ldw, float* dbias,
-                                     int M, int N, int K, hipStream_t s, int dyfmt) {
+static inline int launch_wgrad_dma_group_t(int n, const WgdHostProb* hp, int M, hipStream_t s) {
     constexpr int TW = T * 16;
     constexpr int LDS = wgd_lds_bytes<T, RC, NS>();
-    const int xm = xl.x_mode();
-    const int tiles = (N / TW) * (K / TW), chunks = M / RC;
     constexpr int dbg = 0;          // ablation bits (1: no MFMAs, 2: no refills, 4: no barrier), compile-time, for experiments
-    constexpr int gx8 = 1;          // row ranges a multiple of 8: the tiles of one row range share an XCD (53 760 x 576 x 192: 62 -> 44 us)
-    const int target = 256 * wgd_occupancy<T, RC, NS>();       // resident workgroups
-    int gx = max(1, min(chunks / NS, target / tiles));
-    if (gx8 && gx >= 8) gx &= ~7;
-    const int cpw = cdiv(chunks, gx);
-    if (!(gx8 && gx >= 8)) gx = cdiv(chunks, cpw);
     constexpr int NW = 4, NSL = (T / 2) * (T / 2) + T / 2;
-    const long O = (long)tiles * NW * NSL * 64;                // f4 per partial
-    const size_t part_bytes = (size_t)gx * O * sizeof(f4);
-    const size_t a_bytes = dyfmt ? 0 : (size_t)M * N * 2, b_bytes = xm == 3 ? 0 : (size_t)M * K * 2;
-    char* ws = reinterpret_cast<char*>(wgrad_wide_scratch(s, part_bytes + a_bytes + b_bytes + 4096));
-    if (!ws) return LEOD_ERR_UNSUPPORTED;
-    f4* part = reinterpret_cast<f4*>(ws);
-    unsigned short* a16 = reinterpret_cast<unsigned short*>(ws + ((part_bytes + 1023) & ~(size_t)1023));
-    unsigned short* b16 = a16 + a_bytes / 2;
-    Prep16 pa{}, pb{};
-    pa.mode = pb.mode = -1;
-    if (!dyfmt) { pa = Prep16{dy, lddy, nullptr, 0, 0, nullptr, a16, N, 0}; }
-    if (xm != 3) pb = Prep16{xl.x, xl.ld, xl.x2, xl.ld2, xl.x2 ? xl.K1 : K, xl.stats, b16, K, xm == 1 ? 1 : xm == 2 ? 2 : xm == 4 ? 3 : (xl.x2 ? 4 : 0)};
-    if (pa.mode >= 0 || pb.mode >= 0) {
-        const int c8 = max(pa.mode >= 0 ? N : 0, pb.mode >= 0 ? K : 0) / 8;
-        hipLaunchKernelGGL(wgrad_prep16_kernel, dim3(cdiv((long)M * c8, 256), 2), dim3(256), 0, s, pa, pb, M);
+    const int chunks = M / RC;
+    const int target = 256 * wgd_occupancy<T, RC, NS>();       // resident workgroups
+    int total_tiles = 0;
+    for (int k = 0; k < n; ++k) total_tiles += (hp[k].N / TW) * (hp[k].K / TW);
+    // ---- geometry + scratch layout --------------------------------------------------------------------------------------------------
+    WgdGroup g{};
+    WgrGroup rg{};
+    Prep16Group pg{};
+    size_t off = 0, offs_part[4], offs_a[4], offs_b[4];
+    int blk = 0, obmax = 0, grmax = 0, c8max = 0;
+    bool any_ln = false, any_prep = false;
+    for (int k = 0; k < n; ++k) {
+        const WgdHostProb& h = hp[k];
+        const int xm = h.xl.x_mode();
+        const int tiles = (h.N / TW) * (h.K / TW);
+        // row ranges a multiple of 8: the tiles of one row range share an XCD (53 760 x 576 x 192: 62 -> 44 us)
+        int gx = max(1, min(chunks / NS, target / total_tiles));
+        if (gx >= 8) gx &= ~7;
+        const int cpw = cdiv(chunks, gx);
+        if (gx < 8) gx = cdiv(chunks, cpw);
+        const long O = (long)tiles * NW * NSL * 64;            // f4 per partial
+        offs_part[k] = off; off += ((size_t)gx * O * sizeof(f4) + 1023) & ~(size_t)1023;
+        offs_a[k] = off; off += h.dyfmt ? 0 : (((size_t)M * h.N * 2 + 1023) & ~(size_t)1023);
+        offs_b[k] = off; off += xm == 3 ? 0 : (((size_t)M * h.K * 2 + 1023) & ~(size_t)1023);
+        g.p[k].cpw = cpw; g.p[k].gx = gx; g.p[k].ny = h.N / TW; g.p[k].nz = h.K / TW; g.p[k].N = h.N; g.p[k].K = h.K; g.p[k].blk0 = blk;
+        blk += gx * tiles;
+        const int ob = (int)cdiv(O, 256);
+        int groups = max(1, min(gx, 512 / ob));
+        const int per = cdiv(gx, groups);
+        groups = cdiv(gx, per);
+        rg.p[k] = WgrProb{nullptr, h.dW, h.dbias, h.ldw, gx, h.N / TW, h.K / TW, per, h.N, h.K, ob, groups};
+        obmax = max(obmax, ob); grmax = max(grmax, groups);
+        any_ln = any_ln || xm == 1;
     }
-    const unsigned short* A = dyfmt ? reinterpret_cast<const unsigned short*>(dy) : a16;
-    const long lda = dyfmt ? lddy : N;
-    const unsigned short* B = xm == 3 ? reinterpret_cast<const unsigned short*>(xl.x) : b16;
-    const long ldb = xm == 3 ? xl.ld : K;
-    dim3 grid(gx * tiles);
-    const int ny = N / TW, nz = K / TW;
-    if (xm == 1) {
+    g.n = n;
+    char* ws = reinterpret_cast<char*>(wgrad_wide_scratch(s, off + 4096));
+    if (!ws) return LEOD_ERR_UNSUPPORTED;
+    for (int k = 0; k < n; ++k) {
+        const WgdHostProb& h = hp[k];
+        const int xm = h.xl.x_mode();
+        f4* part = reinterpret_cast<f4*>(ws + offs_part[k]);
+        unsigned short* a16 = reinterpret_cast<unsigned short*>(ws + offs_a[k]);
+        unsigned short* b16 = reinterpret_cast<unsigned short*>(ws + offs_b[k]);
+        Prep16 pa{}, pb{};
+        pa.mode = pb.mode = -1;
+        if (!h.dyfmt) pa = Prep16{h.dy, h.lddy, nullptr, 0, 0, nullptr, a16, h.N, 0};
+        if (xm != 3) pb = Prep16{h.xl.x, h.xl.ld, h.xl.x2, h.xl.ld2, h.xl.x2 ? h.xl.K1 : h.K, h.xl.stats, b16, h.K,
+                                 xm == 1 ? 1 : xm == 2 ? 2 : xm == 4 ? 3 : (h.xl.x2 ? 4 : 0)};
+        pg.a[k] = pa; pg.b[k] = pb;
+        if (pa.mode >= 0) { any_prep = true; c8max = max(c8max, h.N / 8); }
+        if (pb.mode >= 0) { any_prep = true; c8max = max(c8max, h.K / 8); }
+        g.p[k].A = h.dyfmt ? reinterpret_cast<const unsigned short*>(h.dy) : a16;
+        g.p[k].lda = h.dyfmt ? h.lddy : h.N;
+        g.p[k].B = xm == 3 ? reinterpret_cast<const unsigned short*>(h.xl.x) : b16;
+        g.p[k].ldb = xm == 3 ? h.xl.ld : h.K;
+        g.p[k].ln_w = xm == 1 ? h.xl.ln_w : nullptr; g.p[k].ln_b = xm == 1 ? h.xl.ln_b : nullptr;
+        g.p[k].dbias_flag = h.dbias; g.p[k].part = part;
+        rg.p[k].part = part;
+    }
+    for (int k = n; k < 4; ++k) { pg.a[k].mode = pg.b[k].mode = -1; }
+    if (any_prep) hipLaunchKernelGGL(wgrad_prep16_kernel, dim3(cdiv((long)M * c8max, 256), 2, n), dim3(256), 0, s, pg, M);
+    if (any_ln) {
         auto kern = wgrad_dma_kernel<T, RC, NS, true>;
         static bool attr_set = false;
         if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
-        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, A, lda, B, ldb, xl.ln_w, xl.ln_b, dbias, part, chunks, cpw, gx, ny, nz, N, K, dbg);
+        hipLaunchKernelGGL(kern, dim3(blk), dim3(256), LDS, s, g, chunks, dbg);
     } else {
         auto kern = wgrad_dma_kernel<T, RC, NS, false>;
         static bool attr_set = false;
         if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_set = true; }
-        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, A, lda, B, ldb, nullptr, nullptr, dbias, part, chunks, cpw, gx, ny, nz, N, K, dbg);
+        hipLaunchKernelGGL(kern, dim3(blk), dim3(256), LDS, s, g, chunks, dbg);
     }
-    const int ob = (int)cdiv(O, 256);
-    int groups = max(1, min(gx, 512 / ob));
-    const int per = cdiv(gx, groups);
-    groups = cdiv(gx, per);
-    hipLaunchKernelGGL((wgrad_wide_reduce_kernel<T, T, 2, 2>), dim3(ob, groups), dim3(256), 0, s, part, gx, N / TW, K / TW, per, dW, ldw, dbias, N, K);
+    hipLaunchKernelGGL(wgrad_dma_reduce_kernel<T>, dim3(obmax, grmax, n), dim3(256), 0, s, rg);
     return leod_launch_status();
+}
+template <int T, int RC, int NS>
+static inline int launch_wgrad_dma_t(const void* dy, long lddy, const XRows& xl, float* dW, long ldw, float* dbias,
+                                     int M, int N, int K, hipStream_t s, int dyfmt) {
+    const WgdHostProb h{dy, lddy, xl, dW, ldw, dbias, N, K, dyfmt};
+    return launch_wgrad_dma_group_t<T, RC, NS>(1, &h, M, s);
 }
 static inline int launch_wgrad_dma(const void* dy, long lddy, const XRows& xl, float* dW, long ldw, float* dbias,
                                    int M, int N, int K, hipStream_t s, int dyfmt) {

@@ -370,15 +370,22 @@ class AttnBlockFn(Function):
         dqkv = ops.partition_attn_bwd(qkv, do, lse, heads, part, window)
         # ---- weight gradients: off the critical path (side stream when the engine enables it) ------
         with _wgrad_side(dz, h, du, y, st2, dy, o, dqkv, x, st1):
-            ops.layerscale_linear_wgrad(dz, h, fc2_w, fc2_b, g2, grad_buf(mlp.net[2].weight), grad_buf(mlp.net[2].bias),
-                                        grad_buf(mod.ls2.gamma), h_gelu=ctx.u16)
-            ops.linear_wgrad(du, y, grad_buf(mlp.net[0][0].weight), grad_buf(mlp.net[0][0].bias), stats=st2, ln_w=n2w, ln_b=n2b)
-            ops.layerscale_linear_wgrad(dy, o, proj_w, proj_b, g1, grad_buf(sa.proj.weight), grad_buf(sa.proj.bias),
-                                        grad_buf(mod.ls1.gamma), h_gelu=False)
-            if n1w is not None:
-                ops.linear_wgrad(dqkv, x, grad_buf(sa.qkv.weight), grad_buf(sa.qkv.bias), stats=st1, ln_w=n1w, ln_b=n1b)
-            else:
-                ops.linear_wgrad(dqkv, x, grad_buf(sa.qkv.weight), grad_buf(sa.qkv.bias))
+            # stages 3-4 (short row ranges, LDS-DMA kernel): the four weight gradients as ONE preparation / contraction / reduce launch
+            grouped = ops.attn_block_wgrads(dz, h, ctx.u16, du, y, st2, n2w, n2b, dy, o, dqkv, x, st1, n1w, n1b,
+                                            (fc2_w, fc2_b, g2, grad_buf(mlp.net[2].weight), grad_buf(mlp.net[2].bias), grad_buf(mod.ls2.gamma)),
+                                            (grad_buf(mlp.net[0][0].weight), grad_buf(mlp.net[0][0].bias)),
+                                            (proj_w, proj_b, g1, grad_buf(sa.proj.weight), grad_buf(sa.proj.bias), grad_buf(mod.ls1.gamma)),
+                                            (grad_buf(sa.qkv.weight), grad_buf(sa.qkv.bias)))
+            if not grouped:
+                ops.layerscale_linear_wgrad(dz, h, fc2_w, fc2_b, g2, grad_buf(mlp.net[2].weight), grad_buf(mlp.net[2].bias),
+                                            grad_buf(mod.ls2.gamma), h_gelu=ctx.u16)
+                ops.linear_wgrad(du, y, grad_buf(mlp.net[0][0].weight), grad_buf(mlp.net[0][0].bias), stats=st2, ln_w=n2w, ln_b=n2b)
+                ops.layerscale_linear_wgrad(dy, o, proj_w, proj_b, g1, grad_buf(sa.proj.weight), grad_buf(sa.proj.bias),
+                                            grad_buf(mod.ls1.gamma), h_gelu=False)
+                if n1w is not None:
+                    ops.linear_wgrad(dqkv, x, grad_buf(sa.qkv.weight), grad_buf(sa.qkv.bias), stats=st1, ln_w=n1w, ln_b=n1b)
+                else:
+                    ops.linear_wgrad(dqkv, x, grad_buf(sa.qkv.weight), grad_buf(sa.qkv.bias))
         if n1w is not None:
             dx = ops.linear_dgrad_ln_bwd(dqkv, qkv_w, x, st1, n1w, dy, grad_buf(mod.norm1.weight), grad_buf(mod.norm1.bias))
         else:

@@ -492,6 +492,87 @@ def linear_wgrad(dy, x, dW, dbias=None, stats=None, ln_w=None, ln_b=None, x2=Non
         ev.record()
 
 
+def _x_fmt(x, stats, gelu):
+    if gelu:
+        return 2
+    if x.dtype is torch.bfloat16:
+        return 3
+    if x.dtype is torch.float16:
+        return 4
+    return 1 if stats is not None else 0
+
+
+def linear_wgrad_group(problems) -> bool:
+    """n <= 4 Linear weight gradients of one row count in ONE preparation / contraction / reduce launch (``leod_linear_wgrad_group``).
+    problems: dicts with dy, x, dW, dbias and optionally stats + ln_w + ln_b (X = LayerNorm(x)) or gelu=True (x the fp16 pre-activation).
+    False: not coverable -- nothing was launched (the caller runs them singly)."""
+    n = len(problems)
+    if not (1 <= n <= 4) or not is_16bit():
+        return False
+    M = None
+    Ns, Ks, dyf, xf = [], [], [], []
+    nb = fl = nb16 = 0.0
+    for p in problems:
+        dy, x, dW = p['dy'], p['x'], p['dW']
+        N = dW.shape[0]
+        K = dW.numel() // N
+        m = dy.numel() // N
+        if M is None:
+            M = m
+        if m != M or x.numel() != m * K or x.shape[-1] != K or p.get('x2') is not None:
+            return False
+        dy16 = dy.dtype is torch.bfloat16
+        _ck(dy, torch.bfloat16 if dy16 else F32, 'dy')
+        _ck(x, x.dtype, 'x')
+        fmt = _x_fmt(x, p.get('stats'), p.get('gelu'))
+        if fmt == 2 and x.dtype is not torch.float16:
+            return False
+        for t_ in (dW, p.get('dbias'), p.get('stats'), p.get('ln_w'), p.get('ln_b')):
+            _ck(t_, name='linear_wgrad_group')
+        Ns.append(N); Ks.append(K); dyf.append(1 if dy16 else 0); xf.append(fmt)
+        nb += (2.0 if dy16 else 4.0) * M * N + (2.0 if fmt >= 2 else 4.0) * M * K + 4.0 * N * K
+        fl += 2.0 * M * N * K
+        nb16 += 2.0 * M * (N + K) + 4.0 * N * K
+    if M >= 8192 and _stream() not in _WORKSPACES:
+        _wgrad_workspace(problems[0]['dW'].device)
+    ev = _probe('linear_wgrad', nb, fl, rows=M, nbytes16=nb16)
+    rc = _l().leod_linear_wgrad_group(n, _ptr_array([p['dy'] for p in problems]), _int_array(dyf), _ptr_array([p['x'] for p in problems]), _int_array(xf),
+                                      _ptr_array_opt([p.get('stats') for p in problems]), _ptr_array_opt([p.get('ln_w') for p in problems]),
+                                      _ptr_array_opt([p.get('ln_b') for p in problems]), _ptr_array([p['dW'] for p in problems]),
+                                      _ptr_array_opt([p.get('dbias') for p in problems]), M, _int_array(Ns), _int_array(Ks), _stream())
+    if rc == -3:
+        if ev is not None:
+            _PROBE.cancel('linear_wgrad')
+        return False
+    check(rc, 'linear_wgrad_group')
+    if ev is not None:
+        ev.record()
+    return True
+
+
+def attn_block_wgrads(dz, h, h_gelu, du, y, st2, n2w, n2b, dy, o, dqkv, x, st1, n1w, n1b, fc2, fc1, proj, qkv) -> bool:
+    """The four weight gradients of an attention block (fc2 and proj behind LayerScale, fc1 and qkv behind LayerNorm) in one grouped launch.
+    fc2 / proj = (W, b, gamma, dW, db, dgamma); fc1 / qkv = (dW, db).  False: not coverable, nothing was launched."""
+    W2, b2, g2, dW2, db2, dg2 = fc2
+    Wp, bp, g1, dWp, dbp, dg1 = proj
+    (N2, K2), (Np, Kp) = W2.shape, Wp.shape
+    if not is_16bit() or dz.numel() // N2 < 8192:
+        return False
+    scratch = StatArena.zeros((N2 * K2 + N2 + Np * Kp + Np,), dz.device, torch.float32)
+    G2, s2 = scratch[:N2 * K2].view(N2, K2), scratch[N2 * K2:N2 * K2 + N2]
+    off = N2 * K2 + N2
+    Gp, sp = scratch[off:off + Np * Kp].view(Np, Kp), scratch[off + Np * Kp:]
+    probs = [dict(dy=dz, x=h, dW=G2, dbias=s2, gelu=bool(h_gelu)),
+             dict(dy=du, x=y, dW=fc1[0], dbias=fc1[1], stats=st2, ln_w=n2w, ln_b=n2b),
+             dict(dy=dy, x=o, dW=Gp, dbias=sp),
+             dict(dy=dqkv, x=x, dW=qkv[0], dbias=qkv[1], stats=st1 if n1w is not None else None, ln_w=n1w, ln_b=n1b)]
+    if not linear_wgrad_group(probs):
+        return False
+    check(_l().leod_layerscale_finalize(_p(W2), _p(b2), _p(g2), _p(G2), _p(s2), _p(dW2), _p(db2), _p(dg2), N2, K2, _stream()), 'layerscale_finalize')
+    check(_l().leod_layerscale_finalize(_p(Wp), _p(bp), _p(g1), _p(Gp), _p(sp), _p(dWp), _p(dbp), _p(dg1), Np, Kp, _stream()), 'layerscale_finalize')
+    return True
+
+
 def layernorm_fwd(x, w, b, want_stats=False, eps=1e-5):
     for t, n in ((x, 'x'), (w, 'w'), (b, 'b')):
         _ck(t, name=n)
@@ -1447,6 +1528,10 @@ class KernelProbe:
         e0.record()
         self.events[target].append((self.step, e0, e1, nbytes, flops, nbytes if nbytes16 is None else nbytes16, rows))
         return e1
+
+    def cancel(self, target):
+        """Drops the bracket ``begin`` opened last for ``target`` (the call it was opened for launched nothing)."""
+        self.events[target].pop()
 
     def amend(self, target, nbytes, flops, nbytes16=None):
         """Sets the work of the bracket ``begin`` opened last for ``target`` (the byte count was not known when it was opened)."""

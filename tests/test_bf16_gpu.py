@@ -123,6 +123,42 @@ def test_conv3x3_direct_bf16(bf16_ops, B, H, W, Cin, N):
     tk.close(dw, 2 * w.grad, what='conv3x3 wgrad accumulates')
 
 
+@pytest.mark.parametrize('M,C', [(13440, 384), (53760, 192), (21120, 512), (8256, 96)])
+def test_linear_wgrad_group_equals_single_calls(bf16_ops, M, C):
+    """The four weight gradients of an attention block (qkv and fc1 behind LayerNorm with bf16 gradient rows, proj from 16-bit attention rows,
+    fc2 through GELU of the fp16 pre-activation; maxvit.py:110-118,252-270) as ONE grouped launch of the LDS-DMA kernel
+    (leod_linear_wgrad_group) against the four single calls; a second call accumulates."""
+    ops = bf16_ops
+    d = lambda t: t.to(tk.DEV)  # noqa
+    x, y = d(tk.rnd((M, C), 1)), d(tk.rnd((M, C), 2))
+    lw1, lb1, lw2, lb2 = (d(1 + 0.2 * tk.rnd((C,), 3)), d(0.1 * tk.rnd((C,), 4)), d(1 + 0.2 * tk.rnd((C,), 5)), d(0.1 * tk.rnd((C,), 6)))
+    _, st1 = ops.layernorm_fwd(x, lw1, lb1, want_stats=True)
+    _, st2 = ops.layernorm_fwd(y, lw2, lb2, want_stats=True)
+    dqkv, du = d(tk.rnd((M, 3 * C), 7)).to(torch.bfloat16), d(tk.rnd((M, 4 * C), 8)).to(torch.bfloat16)
+    dz, dy = d(tk.rnd((M, C), 9)), d(tk.rnd((M, C), 10))
+    o16, u16 = d(tk.rnd((M, C), 11)).to(A16()), d(tk.rnd((M, 4 * C), 12)).to(torch.float16)
+    shapes = [(C, 4 * C), (4 * C, C), (C, C), (3 * C, C)]
+
+    def bufs():
+        return [torch.zeros(s_, device=tk.DEV) for s_ in shapes], [torch.zeros(s_[0], device=tk.DEV) for s_ in shapes]
+
+    (W2, W1, Wp, Wq), (b2, b1, bp, bq) = bufs()
+    probs = [dict(dy=dz, x=u16, dW=W2, dbias=b2, gelu=True), dict(dy=du, x=y, dW=W1, dbias=b1, stats=st2, ln_w=lw2, ln_b=lb2),
+             dict(dy=dy, x=o16, dW=Wp, dbias=bp), dict(dy=dqkv, x=x, dW=Wq, dbias=bq, stats=st1, ln_w=lw1, ln_b=lb1)]
+    assert ops.linear_wgrad_group(probs)
+    (S2, S1, Sp, Sq), (c2, c1, cp, cq) = bufs()
+    ops.linear_wgrad(dz, u16, S2, c2)
+    ops.linear_wgrad(du, y, S1, c1, stats=st2, ln_w=lw2, ln_b=lb2)
+    ops.linear_wgrad(dy, o16, Sp, cp, x_gelu=False)
+    ops.linear_wgrad(dqkv, x, Sq, cq, stats=st1, ln_w=lw1, ln_b=lb1)
+    for name, g, r in (('fc2', W2, S2), ('fc1', W1, S1), ('proj', Wp, Sp), ('qkv', Wq, Sq), ('b fc2', b2, c2), ('b fc1', b1, c1), ('b proj', bp, cp),
+                       ('b qkv', bq, cq)):
+        tk.close(g, r, what=name + ' grouped vs single')
+    assert ops.linear_wgrad_group(probs)
+    tk.close(W1, 2 * S1, what='fc1 accumulates')
+    tk.close(bq, 2 * cq, what='qkv bias accumulates')
+
+
 @pytest.mark.parametrize('C,sizes', [(96, [(4, 32, 40), (4, 16, 20), (4, 8, 10), (4, 32, 40), (4, 16, 20), (4, 8, 10)]),     # the six tower convs of a depth
                                      (128, [(2, 12, 160), (2, 24, 40)]), (48, [(3, 9, 12), (1, 5, 7), (2, 32, 40)])])
 def test_conv3x3_group_equals_single_calls(bf16_ops, C, sizes):
